@@ -1,0 +1,192 @@
+"""Headline benchmark: FLAME frames/s of one full training step (forward + backward + gradient all-reduce + clip +
+Adam) of final_model.yaml at BASELINE.json's synthetic dims (50-d FLAME + 27-d speech), T = 80, batch 256 per GPU.
+
+  python bench.py --gpus 1 --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line. `value` = frames processed by all ranks / max-over-ranks wall time of the K timed steps
+(inputs resident in HBM before the timed region). `roofline` is for the dominant kernel, the cond_transform GEMM
+(F x Ks*D x E on the f32 MFMA), timed with HIP events on its launch stream inside the timed region. `cpu_baseline`
+(N = 1 only) times the CPU oracle — a plain-PyTorch port of the reference's per-timestep loop — on the host cores on a
+bounded sample of the same workload; it is a reported baseline, not the thing measured above.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+F32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+
+
+def synthetic_batch(B, T, C, S, seed, device):
+    g = torch.Generator().manual_seed(seed)
+    out = {}
+    for name, d in (("p1_face", C), ("p2_face", C), ("p1_speech", S), ("p2_speech", S)):
+        out[name] = torch.randn(B, T, d, generator=g, dtype=torch.float32).to(device).contiguous()
+    return out
+
+
+def cpu_baseline(hp, C, S, T, budget_s):
+    """The oracle (kind "port") on the host cores: forward + backward of the reference's op sequence."""
+    from oracle import seqglow_oracle as oracle
+    from lets_face_it_amd.glow.models import SeqGlow
+    from argparse import Namespace
+    import copy
+    threads = torch.get_num_threads()
+    torch.manual_seed(1234)
+    m = SeqGlow(Namespace(**copy.deepcopy(hp)))
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    for k, v in sd.items():
+        if v.dtype.is_floating_point and not k.endswith((".p", ".sign_s")):
+            v.requires_grad_(True)
+    B = 16
+    batch = oracle.synthetic_batch(B, T, C, S, seed=1234)
+    start = oracle.longest_history(hp["Conditioning"])
+    frames = B * (T - start)
+
+    def step():
+        for v in sd.values():
+            v.grad = None
+        loss = oracle.seqglow_forward(hp, sd, batch)[1]
+        loss.sum().backward()
+
+    t0 = time.time()
+    step()  # warm-up
+    warm = time.time() - t0
+    times = []
+    while len(times) < 2 or (sum(times) + warm < budget_s and len(times) < 5):
+        t0 = time.time()
+        step()
+        times.append(time.time() - t0)
+    times.sort()
+    med = times[len(times) // 2]
+    return {"value": frames / med, "unit": "frames/s", "cores": threads, "kind": "port",
+            "sample": "oracle/seqglow_oracle.py fwd+bwd (torch CPU fp32, per-timestep loop as the reference), "
+                      "final_model C=%d S=%d T=%d at batch %d, median of %d steps after 1 warm-up" % (C, S, T, B, len(times))}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=256, help="per-GPU batch (BASELINE: 256)")
+    ap.add_argument("--seq-len", type=int, default=80)
+    ap.add_argument("--cpu-baseline-seconds", type=float, default=25.0, help="0 disables the CPU baseline leg")
+    ap.add_argument("--hparams", default=os.path.join(ROOT, "lets_face_it_amd", "hparams", "final_model_synthetic.yaml"))
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
+    device = torch.device("cuda", local_rank)
+    torch.cuda.set_device(device)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)
+
+    import random
+    import numpy as np
+    from argparse import Namespace
+    from lets_face_it_amd.glow.lets_face_it_glow import LetsFaceItGlow
+    from lets_face_it_amd.glow.utils import load_hparams_file
+    from lets_face_it_amd.trainer import Trainer
+
+    hp = load_hparams_file(args.hparams)
+    hp["batch_size"] = args.batch
+    hp["Train"]["seq_len"] = args.seq_len
+    random.seed(1234)
+    np.random.seed(1234)
+    torch.manual_seed(1234)
+    ns = Namespace(**hp)
+    model = LetsFaceItGlow(ns)
+    model.to(device)
+    model.train()
+    trainer = Trainer(ns, device=device)
+    model.seq_glow.allreduce_hook = trainer.allreduce_stats
+    model.nll_sync_hook = trainer.sync_scalar
+    trainer.broadcast_parameters(model)
+    allreduce = trainer.allreduce_grads if world > 1 else None
+
+    spec = model.seq_glow.spec
+    C, S, T, B = spec.C, spec.S, args.seq_len, args.batch
+    N = T - spec.start
+    batches = [synthetic_batch(B, T, C, S, 1234 + 1000 * rank + i, device) for i in range(2)]
+    lr = trainer.lr_at(0)
+
+    def step(i):
+        return model.fused_training_step(batches[i & 1], lr, world, allreduce)
+
+    for i in range(args.warmup):  # includes the one-off ActNorm data-dependent init
+        step(i)
+    eng = model.seq_glow.engine
+    eng.enable_timing(True)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    loss = None
+    for i in range(args.steps):
+        loss = step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    timing = eng.timing_summary()
+    eng.enable_timing(False)
+
+    frames = world * B * N * args.steps
+    F = B * N
+    KD = spec.Ks * spec.D
+    flops_fwd = 2.0 * F * KD * spec.E  # algorithmic FLOPs of one cond_transform GEMM launch (2*E*D per step and frame)
+    n_launch, ms = timing.get("gemm_cond_fwd", (0, float("nan")))
+    achieved = flops_fwd / (ms * 1e-3) / 1e12 if n_launch else float("nan")
+    others = {t: {"launches": n, "ms": round(m_, 4)} for t, (n, m_) in timing.items()}
+
+    if rank == 0:
+        out = {
+            "metric": "FLAME frames/s, full training step (fwd+bwd+clip+Adam), final_model.yaml batch 256 per GPU",
+            "value": frames / elapsed, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "final_model.yaml training step, synthetic 50-d FLAME + 27-d speech, T=%d, "
+                                   "batch %d per GPU (BASELINE.json configs[1]%s)" % (T, B, "" if world == 1 else ", data-parallel"),
+                       "K": spec.Ks, "H": spec.H, "cond_dim": spec.D, "feature_dim": spec.E, "frames_per_step_per_gpu": F,
+                       "parallelism": "dp%d" % world, "params": eng.n_params},
+            "final_loss": float(loss),
+            "roofline": {"bound": "mfma", "kernel": "gemm_f32_kernel<128,128> cond_transform forward (F x Ks*D x E)",
+                         "achieved": achieved, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / F32_MFMA_PEAK_TFLOPS, "traffic": None,
+                         "flops_per_launch": flops_fwd, "ms_per_launch": ms, "launches_timed": n_launch},
+            "kernel_timing": others,
+        }
+        if world == 1 and args.cpu_baseline_seconds > 0:
+            out["cpu_baseline"] = cpu_baseline(hp, C, S, T, args.cpu_baseline_seconds)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,199 @@
+/*
+ * lfi.h — C ABI of liblfi_hip.so: the MI355X (gfx950) kernels behind the conditional-Glow hot path of
+ * jonepatr/lets_face_it.
+ *
+ * The reference has no FFI of its own for this path (it is pure PyTorch: SURVEY.md §8b); the Python object
+ * surface it exposes (SeqGlow.forward / inference / invert, LetsFaceItGlow.training_step /
+ * configure_optimizers) is mirrored by lets_face_it_amd/glow/, and THIS header is what that host code binds
+ * with ctypes. Each entry point names the reference code it replaces (paths relative to
+ * /root/reference/code/glow_pytorch/).
+ *
+ * Conventions
+ *  - extern "C", plain pointers and sizes; every pointer is a DEVICE pointer to fp32 unless noted.
+ *  - The caller owns every buffer; the library allocates nothing and keeps no global mutable state.
+ *  - `stream` is a hipStream_t passed as void* (torch's current stream); all work is enqueued on it, no host
+ *    synchronisation, so every call is hipGraph-capturable.
+ *  - Return value: 0 = ok, < 0 = error; the message is in lfi_last_error() (thread-local).
+ *  - Frames are time-major: frame f = n * B + b for timestep n (0 .. N-1) and sample b.
+ */
+#ifndef LFI_H
+#define LFI_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LFI_OK 0
+#define LFI_ERR_ARG (-1)
+#define LFI_ERR_LAUNCH (-2)
+#define LFI_ERR_UNSUPPORTED (-3)
+
+const char* lfi_last_error(void);
+int lfi_version(void);
+
+/* ---------------------------------------------------------------- generic fp32 GEMM on MFMA
+ * C[b] (+)= act( opA(A[b]) * opB(B[b]) + bias[b] ) ,  b = 0 .. batch-1
+ *   a_kcontig = 1: A element (m,k) at A[m*lda + k];  0: at A[k*lda + m]
+ *   b_kcontig = 1: B element (k,n) at B[n*ldb + k];  0: at B[k*ldb + n]
+ * act: 0 none | 1 leaky_relu(slope) | 2 multiply by leaky_relu'(G) (G same shape/ld as C: G > 0 ? 1 : slope)
+ * splitk > 1 needs `work` of lfi_gemm_work_floats() floats; partial sums are reduced deterministically.
+ * Replaces the aten::addmm / aten::mm calls of nn.Linear / nn.GRU input projections and their autograd
+ * (glow/models.py:63,187-190; glow/modules.py:93-95,186).
+ */
+typedef struct {
+  int M, N, K;
+  const float* A; long lda; int a_kcontig;
+  const float* B; long ldb; int b_kcontig;
+  float* C; long ldc;
+  const float* bias;          /* per column n, or NULL */
+  const float* G; long ldg;   /* act == 2 only */
+  int batch; long strideA, strideB, strideC, strideBias, strideG;
+  int accumulate;             /* 1: C = act(..) + C ; 2: C = act(.. + C) (pre-activation add) */
+  int act; float slope;
+  int splitk; float* work;
+} lfi_gemm_desc;
+
+long lfi_gemm_work_floats(const lfi_gemm_desc* d);
+int lfi_gemm_f32(const lfi_gemm_desc* d, void* stream);
+
+/* out[c] (+)= scale * sum_r X[r*ldx + c]  for r < rows, c < cols; batched. Deterministic two-stage reduction.
+ * (bias gradients: autograd of the nn.Linear / GRU biases.) work: lfi_colsum_work_floats floats. */
+long lfi_colsum_work_floats(int rows, int cols, int batch);
+int lfi_colsum_f32(const float* X, long ldx, long strideX, int rows, int cols, int batch,
+                   float* out, long strideOut, float scale, int accumulate, float* work, void* stream);
+
+/* ---------------------------------------------------------------- window encoders (ModalityEncoder, glow/models.py:55-80)
+ * One modality: single-layer GRU from h0 = 0 over a `hist`-frame window ending at frame t (inclusive) for every
+ * (sample, timestep) pair; output cat(seq[:, -1], h_n[0]) written into columns [col, col + 2*hid) of the
+ * feature matrix `cond` (F x ldcond). Window w = n*B + b covers rows b*T + (start + n - hist + 1 + s), s < hist,
+ * of the pre-projected input Xp = X @ W_ih^T (B*T x 3*hid, no bias; made with lfi_gemm_f32).
+ * mask: optional (F x hist) dropout multipliers (glow/models.py:56-58); NULL in eval mode.
+ * gates ([hist][F][4*hid]: r, z, n, W_hn h + b_hn; NULL to skip) and hseq ([hist][F][hid], required: it is the
+ * recurrent state) are step-major stashes for the backward pass. work: lfi_encode_windows_work_floats floats.
+ */
+typedef struct {
+  int B, T, N, start;   /* batch, sequence length, timesteps (T - start), first modelled frame */
+  int hist, hid;        /* window length, hidden size */
+  int ldcond, col;      /* leading dimension of cond and first output column */
+} lfi_enc_desc;
+
+long lfi_encode_windows_work_floats(const lfi_enc_desc* d);
+int lfi_encode_windows_fwd(const lfi_enc_desc* d, const float* Xp, const float* whh /* 3hid x hid */,
+                           const float* b_ih, const float* b_hh, const float* mask,
+                           float* cond, float* gates, float* hseq, float* work, void* stream);
+/* BPTT of the above. dcond (F x lddcond): gradient of the feature matrix; the two output halves are summed.
+ * Writes dgi ([hist][F][3*hid]: grads of the pre-activations on the input side, before the dropout mask) and
+ * dgh ([hist][F][3*hid]: on the hidden side). Weight gradients follow from those with lfi_gemm_f32/lfi_colsum:
+ * dW_hh = dgh[1:]^T hseq[:-1], db_hh = colsum(dgh), db_ih = colsum(dgi), dW_ih = scatter(dgi)^T X. */
+int lfi_encode_windows_bwd(const lfi_enc_desc* d, const float* dcond, int lddcond, const float* whh /* 3hid x hid */,
+                           const float* gates, const float* hseq, float* dgi, float* dgh, float* work, void* stream);
+/* dXp[b*T + p] = sum over the windows (n, s) that read row p of mask * dgi[(n*B+b)*hist + s]   (B*T x 3*hid) */
+int lfi_encode_windows_scatter(const lfi_enc_desc* d, const float* dgi, const float* mask, float* dXp, void* stream);
+/* "enc: none" modality (glow/models.py:76-77) and the flattened p1_face history (glow/models.py:601-603):
+ * cond[f, col + s*dim + c] = X[b, start + n - hist + s + incl, c]   (incl = 0 for prev_p1_face, 1 otherwise) */
+int lfi_gather_windows(const float* X, int B, int T, int dim, int N, int start, int hist, int incl,
+                       float* cond, int ldcond, int col, void* stream);
+
+/* ---------------------------------------------------------------- flow (FlowStep / FlowNet / Glow, glow/models.py:217-521)
+ * Parameters of the Ks = K*L flow steps are struct-of-arrays, step-major: e.g. whh is [Ks][3H][H].
+ */
+typedef struct {
+  int B, N, C, H, D, Ks;     /* batch, timesteps, channels, hidden_channels, cond_dim, flow steps */
+  int affine;                /* 1 affine coupling, 0 additive (glow/models.py:330-341) */
+  int lstm;                  /* 0 GRUCell, 1 LSTMCell coupling net (glow/models.py:176-185) */
+  float scale_eps;           /* Glow.scale_eps */
+} lfi_flow_dims;
+/* derived: Ch = C/2, C2 = C - Ch, Cout = affine ? 2*C2 : C2, G = lstm ? 4H : 3H, I = Ch + D */
+
+typedef struct {
+  const float *an_bias, *an_logs;          /* [Ks][C]   ActNorm2d (glow/modules.py:10-80) */
+  const float *inv_l, *inv_u, *inv_logs;   /* [Ks][C][C], [Ks][C][C], [Ks][C]  InvertibleConv1x1 LU params */
+  const float *inv_p, *inv_sign;           /* [Ks][C][C], [Ks][C]  buffers (glow/modules.py:139-145) */
+  const float *inv_w;                      /* [Ks][C][C] dense weight (LU_decomposed: false), else NULL */
+  const float *w_ih, *w_hh, *b_ih, *b_hh;  /* [Ks][G][I], [Ks][G][H], [Ks][G], [Ks][G]  f.rnn */
+  const float *w_fl, *b_fl, *l_fl;         /* [Ks][Cout][H], [Ks][Cout], [Ks][Cout]  f.final_linear (LinearZeros) */
+} lfi_flow_params;
+
+/* Derived weights, rebuilt once per optimiser step instead of once per (timestep, flow step) as
+ * InvertibleConv1x1.get_weight does (glow/modules.py:147-178). Layout of `prep` (floats), step-major blocks:
+ *   W [Ks][C][C], Wt [Ks][C][C], Winv [Ks][C][C] (reverse weight, fp64 inverse cast to fp32),
+ *   wz_t [Ks][Ch][G], whh_t [Ks][H][G], wfl_t [Ks][H][Cout], logdet_const [1] = C * sum(an_logs + inv_logs) */
+long lfi_flow_prep_floats(const lfi_flow_dims* d);
+int lfi_flow_prep(const lfi_flow_dims* d, const lfi_flow_params* p, float* prep, int with_inverse, void* stream);
+
+/* Teacher-forced pass over all N timesteps and Ks flow steps (SeqGlow.forward's loop, glow/models.py:546-559,
+ * FlowNet.encode :444-451, FlowStep.normal_flow :311-342, f_seq.forward :204-214), walked as anti-diagonals of
+ * the (n, k) grid. x0: p1_face (B x T x C, batch-first), first frame `start`. gic: [Ks][F][G] = hoisted
+ * W_ih[:, Ch:] c + b_ih. stash: lfi_flow_stash_floats floats (activations for the backward pass; also holds z).
+ * nll (F): per-frame NLL in bits (SeqGlow.loss :563-565); z (F x C). */
+long lfi_flow_stash_floats(const lfi_flow_dims* d);
+int lfi_flow_seq_fwd(const lfi_flow_dims* d, const lfi_flow_params* p, const float* prep,
+                     const float* x0, int T, int start, const float* gic,
+                     float* stash, float* z, float* nll, void* stream);
+/* Backward of the above for loss = gscale * sum_f nll[f]. bstash: lfi_flow_bstash_floats floats; afterwards
+ * it holds dlin [Ks][F][Cout], dgi [Ks][F][G], dgh [Ks][F][G], dy [Ks][F][C] and the per-tile partial sums that
+ * lfi_flow_param_grads turns into parameter gradients. dgi doubles as the gradient of gic. */
+long lfi_flow_bstash_floats(const lfi_flow_dims* d);
+int lfi_flow_seq_bwd(const lfi_flow_dims* d, const lfi_flow_params* p, const float* prep,
+                     const float* stash, float gscale, float* bstash, void* stream);
+
+typedef struct {
+  float *an_bias, *an_logs, *inv_l, *inv_u, *inv_logs, *inv_w;
+  float *w_ih, *w_hh, *b_ih, *b_hh, *w_fl, *b_fl, *l_fl;
+} lfi_flow_grads;
+/* Parameter gradients of the flow from the two stashes. c: (F x ldc) LeakyReLU(cond_transform) outputs, step k in
+ * columns [k*D, (k+1)*D). Overwrites (accumulate = 0) or adds to (1) the gradient arrays. work: floats from
+ * lfi_flow_param_grads_work_floats. */
+long lfi_flow_param_grads_work_floats(const lfi_flow_dims* d);
+int lfi_flow_param_grads(const lfi_flow_dims* d, const lfi_flow_params* p, const float* prep,
+                         const float* stash, const float* bstash, const float* c, long ldc, float gscale,
+                         const lfi_flow_grads* g, int accumulate, float* work, void* stream);
+
+/* Pointers into the stashes (host-side address arithmetic only). which: 0 a, 1 y, 2 x_out, 3 h, 4 gates, 5 o, 6 ldc
+ * for the forward stash; 0 dlin, 1 dgi, 2 dgh, 3 dy, 4 dx, 5 dh for the backward stash. */
+float* lfi_flow_stash_ptr(const lfi_flow_dims* d, float* stash, int which);
+float* lfi_flow_bstash_ptr(const lfi_flow_dims* d, float* bstash, int which);
+
+/* ActNorm data-dependent initialisation for flow step k from the first timestep (glow/modules.py:32-43):
+ * stats: accumulates per-channel sum and sum of squares of the step's input over the local batch into
+ * sums[2*C] (fp64 on device, so ranks can all-reduce them); apply: bias = -mean, logs = log(scale/(sqrt(var)+1e-6)). */
+int lfi_actnorm_init_stats(const float* x, int rows, int C, double* sums, void* stream);
+int lfi_actnorm_init_apply(const double* sums, double count, int C, float scale, float* bias, float* logs, void* stream);
+/* One flow step on a (rows x C) batch with explicit state; used by the init walk, by module-level
+ * FlowStep.forward and by the sampler. h_prev/h_out: (rows x H) (NULL h_prev = zeros). reverse = 1 runs
+ * FlowStep.reverse_flow (glow/models.py:345-373). gic_k: (rows x G). ldc_acc (rows): log-det accumulator (+=). */
+int lfi_flow_step(const lfi_flow_dims* d, const lfi_flow_params* p, const float* prep, int k, int rows,
+                  const float* x_in, long ldx, const float* h_prev, const float* gic_k,
+                  float* x_out, long ldxo, float* h_out, float* ldc_acc, int reverse, void* stream);
+
+/* ---------------------------------------------------------------- autoregressive sampling (SeqGlow.inference, glow/models.py:567-596)
+ * Whole sequence in one call. faces (B x seq_len x C, batch-first) holds the `start` seed frames and receives the
+ * generated ones. Per frame t: c = LeakyReLU(pre_static[n] + faces[:, t-hist1:t] Wct[:, :hist1*C]^T) for all Ks steps
+ * (pre_static = everything of cond_transform that does not depend on generated frames, bias included:
+ * (nframes*B) x (Ks*D), frame-major), gic = c W_ih[:, Ch:]^T + b_ih, then the Ks reverse flow steps from the
+ * injected prior noise (nframes x B x C, already scaled by eps_std). h: [Ks][B][H] recurrent state, zero on entry.
+ * Only "enc: none" for p1_face (all shipped hparams). work: lfi_flow_sample_work_floats floats. */
+long lfi_flow_sample_work_floats(const lfi_flow_dims* d);
+int lfi_flow_sample_seq(const lfi_flow_dims* d, const lfi_flow_params* p, const float* prep,
+                        const float* wct /* [Ks*D][E] */, long E, int hist1,
+                        const float* pre_static, const float* noise,
+                        float* faces, int seq_len, int start, int nframes,
+                        float* h, float* work, void* stream);
+
+/* ---------------------------------------------------------------- optimiser (configure_optimizers, glow/lets_face_it_glow.py:61-72)
+ * Flat-buffer Adam with global-norm gradient clipping (Trainer gradient_clip_val, hparams/final_model.yaml:126):
+ * norm: sumsq[0] = sum g^2 (fp64, deterministic). step: coef = min(1, clip/(sqrt(sumsq)+1e-6)) (clip <= 0: 1),
+ * g *= coef * gmul; Adam (no weight decay / amsgrad). step_count is 1-based. */
+int lfi_grad_sumsq(const float* g, long n, double* sumsq, double* work /* 1024 doubles */, void* stream);
+int lfi_adam_clip_step(float* p, const float* g, float* m, float* v, long n, const double* sumsq,
+                       float clip, float gmul, float lr, float beta1, float beta2, float eps, int step_count,
+                       void* stream);
+
+/* ---------------------------------------------------------------- diagnostics */
+/* Checks the MFMA operand/accumulator lane maps the kernels rely on; out[0] = number of mismatches. */
+int lfi_selftest_mfma(int* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LFI_H */

@@ -1,0 +1,133 @@
+"""ctypes binding of liblfi_hip.so (the C ABI declared in include/lfi.h).
+
+There is no CPU or PyTorch fallback: if the shared library is missing the import of
+the compute path fails loudly, and every entry point raises on a non-zero status.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liblfi_hip.so")
+
+c_float_p = C.POINTER(C.c_float)
+c_double_p = C.POINTER(C.c_double)
+
+
+class GemmDesc(C.Structure):
+    _fields_ = [
+        ("M", C.c_int), ("N", C.c_int), ("K", C.c_int),
+        ("A", C.c_void_p), ("lda", C.c_long), ("a_kcontig", C.c_int),
+        ("B", C.c_void_p), ("ldb", C.c_long), ("b_kcontig", C.c_int),
+        ("C", C.c_void_p), ("ldc", C.c_long),
+        ("bias", C.c_void_p),
+        ("G", C.c_void_p), ("ldg", C.c_long),
+        ("batch", C.c_int), ("strideA", C.c_long), ("strideB", C.c_long), ("strideC", C.c_long),
+        ("strideBias", C.c_long), ("strideG", C.c_long),
+        ("accumulate", C.c_int),
+        ("act", C.c_int), ("slope", C.c_float),
+        ("splitk", C.c_int), ("work", C.c_void_p),
+    ]
+
+
+class EncDesc(C.Structure):
+    _fields_ = [("B", C.c_int), ("T", C.c_int), ("N", C.c_int), ("start", C.c_int),
+                ("hist", C.c_int), ("hid", C.c_int), ("ldcond", C.c_int), ("col", C.c_int)]
+
+
+class FlowDims(C.Structure):
+    _fields_ = [("B", C.c_int), ("N", C.c_int), ("C", C.c_int), ("H", C.c_int), ("D", C.c_int), ("Ks", C.c_int),
+                ("affine", C.c_int), ("lstm", C.c_int), ("scale_eps", C.c_float)]
+
+
+_FLOW_PARAM_FIELDS = ["an_bias", "an_logs", "inv_l", "inv_u", "inv_logs", "inv_p", "inv_sign", "inv_w",
+                      "w_ih", "w_hh", "b_ih", "b_hh", "w_fl", "b_fl", "l_fl"]
+_FLOW_GRAD_FIELDS = ["an_bias", "an_logs", "inv_l", "inv_u", "inv_logs", "inv_w",
+                     "w_ih", "w_hh", "b_ih", "b_hh", "w_fl", "b_fl", "l_fl"]
+
+
+class FlowParams(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in _FLOW_PARAM_FIELDS]
+
+
+class FlowGrads(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in _FLOW_GRAD_FIELDS]
+
+
+class LfiError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    """The loaded library; raises if liblfi_hip.so has not been built (python __graft_entry__.py build)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise LfiError(
+            "liblfi_hip.so not found at %s: build it with `make -C lets_face_it_amd/csrc` "
+            "(there is no fallback path)" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, i, l, f, d = C.c_void_p, C.c_int, C.c_long, C.c_float, C.c_double
+    P = C.POINTER
+    sig = {
+        "lfi_last_error": (C.c_char_p, []),
+        "lfi_version": (i, []),
+        "lfi_gemm_work_floats": (l, [P(GemmDesc)]),
+        "lfi_gemm_f32": (i, [P(GemmDesc), vp]),
+        "lfi_colsum_work_floats": (l, [i, i, i]),
+        "lfi_colsum_f32": (i, [vp, l, l, i, i, i, vp, l, f, i, vp, vp]),
+        "lfi_encode_windows_work_floats": (l, [P(EncDesc)]),
+        "lfi_encode_windows_fwd": (i, [P(EncDesc), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+        "lfi_encode_windows_bwd": (i, [P(EncDesc), vp, i, vp, vp, vp, vp, vp, vp, vp]),
+        "lfi_encode_windows_scatter": (i, [P(EncDesc), vp, vp, vp, vp]),
+        "lfi_gather_windows": (i, [vp, i, i, i, i, i, i, i, vp, i, i, vp]),
+        "lfi_flow_prep_floats": (l, [P(FlowDims)]),
+        "lfi_flow_prep": (i, [P(FlowDims), P(FlowParams), vp, i, vp]),
+        "lfi_flow_stash_floats": (l, [P(FlowDims)]),
+        "lfi_flow_bstash_floats": (l, [P(FlowDims)]),
+        "lfi_flow_stash_ptr": (vp, [P(FlowDims), vp, i]),
+        "lfi_flow_bstash_ptr": (vp, [P(FlowDims), vp, i]),
+        "lfi_flow_seq_fwd": (i, [P(FlowDims), P(FlowParams), vp, vp, i, i, vp, vp, vp, vp, vp]),
+        "lfi_flow_seq_bwd": (i, [P(FlowDims), P(FlowParams), vp, vp, f, vp, vp]),
+        "lfi_flow_param_grads_work_floats": (l, [P(FlowDims)]),
+        "lfi_flow_param_grads": (i, [P(FlowDims), P(FlowParams), vp, vp, vp, vp, l, f, P(FlowGrads), i, vp, vp]),
+        "lfi_actnorm_init_stats": (i, [vp, i, i, vp, vp]),
+        "lfi_actnorm_init_apply": (i, [vp, d, i, f, vp, vp, vp]),
+        "lfi_flow_step": (i, [P(FlowDims), P(FlowParams), vp, i, i, vp, l, vp, vp, vp, l, vp, vp, i, vp]),
+        "lfi_flow_sample_work_floats": (l, [P(FlowDims)]),
+        "lfi_flow_sample_seq": (i, [P(FlowDims), P(FlowParams), vp, vp, l, i, vp, vp, vp, i, i, i, vp, vp, vp]),
+        "lfi_grad_sumsq": (i, [vp, l, vp, vp, vp]),
+        "lfi_adam_clip_step": (i, [vp, vp, vp, vp, l, vp, f, f, f, f, f, f, i, vp]),
+        "lfi_selftest_mfma": (i, [vp, vp]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)  # AttributeError here = header and library out of sync
+        fn.restype = res
+        fn.argtypes = args
+    _lib = L
+    return L
+
+
+EXPORTS = [
+    "lfi_last_error", "lfi_version", "lfi_gemm_work_floats", "lfi_gemm_f32", "lfi_colsum_work_floats",
+    "lfi_colsum_f32", "lfi_encode_windows_work_floats", "lfi_encode_windows_fwd", "lfi_encode_windows_bwd",
+    "lfi_encode_windows_scatter", "lfi_gather_windows", "lfi_flow_prep_floats", "lfi_flow_prep",
+    "lfi_flow_stash_floats", "lfi_flow_bstash_floats", "lfi_flow_stash_ptr", "lfi_flow_bstash_ptr",
+    "lfi_flow_seq_fwd", "lfi_flow_seq_bwd", "lfi_flow_param_grads_work_floats", "lfi_flow_param_grads",
+    "lfi_actnorm_init_stats", "lfi_actnorm_init_apply", "lfi_flow_step", "lfi_flow_sample_work_floats",
+    "lfi_flow_sample_seq", "lfi_grad_sumsq", "lfi_adam_clip_step", "lfi_selftest_mfma",
+]
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib().lfi_last_error()
+        raise LfiError("%s failed (%d): %s" % (what or "lfi call", rc, msg.decode() if msg else ""))
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (None -> NULL)."""
+    return None if t is None else t.data_ptr()

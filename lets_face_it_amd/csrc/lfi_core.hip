@@ -1,0 +1,199 @@
+// Error reporting, version, MFMA lane-map self-test, column sums and the flat-buffer optimiser.
+#include <stdarg.h>
+#include <stdio.h>
+
+#include "lfi_common.h"
+
+static thread_local char g_err[512] = "";
+
+void lfi_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+extern "C" const char* lfi_last_error(void) { return g_err; }
+extern "C" int lfi_version(void) { return 100; }
+
+// ------------------------------------------------------------------ MFMA lane-map self-test
+// A(i,k) = 1 + i + 100 k ; B(k,j) = (k == kk) * (1 + 1000 j) summed over k gives D(i,j) = sum_k A(i,k) B(k,j):
+// with small integers every product is exact, and an asymmetric B exposes a transposed accumulator map.
+__global__ void selftest_mfma_kernel(int* out) {
+  const int lane = threadIdx.x;
+  int bad = 0;
+  {  // 16x16x4
+    const int i = lane & 15, k = lane >> 4;
+    const float a = (float)(1 + i + 100 * k);   // A(i, k)
+    const float b = (float)(1 + 7 * k + 31 * i);  // B(k, j = i)
+    f32x4 c = {0.f, 0.f, 0.f, 0.f};
+    c = mfma16(a, b, c);
+    for (int r = 0; r < 4; ++r) {
+      const int row = (lane >> 4) * 4 + r, col = lane & 15;
+      float ref = 0.f;
+      for (int kk = 0; kk < 4; ++kk) ref += (float)(1 + row + 100 * kk) * (float)(1 + 7 * kk + 31 * col);
+      if (c[r] != ref) ++bad;
+    }
+  }
+  {  // 32x32x2
+    const int i = lane & 31, k = lane >> 5;
+    const float a = (float)(1 + i + 100 * k);
+    const float b = (float)(1 + 7 * k + 31 * i);
+    f32x16 c;
+    for (int r = 0; r < 16; ++r) c[r] = 0.f;
+    c = mfma32(a, b, c);
+    for (int r = 0; r < 16; ++r) {
+      const int row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), col = lane & 31;
+      float ref = 0.f;
+      for (int kk = 0; kk < 2; ++kk) ref += (float)(1 + row + 100 * kk) * (float)(1 + 7 * kk + 31 * col);
+      if (c[r] != ref) ++bad;
+    }
+  }
+  atomicAdd(out, bad);
+}
+
+extern "C" int lfi_selftest_mfma(int* out, void* stream) {
+  LFI_REQUIRE(out, "lfi_selftest_mfma: null output");
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(out, 0, sizeof(int), st);
+  if (e != hipSuccess) {
+    lfi_set_error("lfi_selftest_mfma: memset failed: %s", hipGetErrorString(e));
+    return LFI_ERR_LAUNCH;
+  }
+  hipLaunchKernelGGL(selftest_mfma_kernel, dim3(1), dim3(64), 0, st, out);
+  LFI_LAUNCH_CHECK("lfi_selftest_mfma");
+  return LFI_OK;
+}
+
+// ------------------------------------------------------------------ column sums (bias gradients)
+// stage 1: block (cx, ry) sums rows [ry*RB, ry*RB + RB) of 64 columns into part[batch][ry][col]; stage 2 adds the
+// row-blocks in order. Both fixed-order, so results are bitwise reproducible.
+namespace {
+constexpr int CS_ROWS = 256;  // rows per stage-1 block
+
+__global__ __launch_bounds__(256) void colsum_stage1(const float* __restrict__ X, long ldx, long strideX, int rows, int cols,
+                                                     float* __restrict__ part, int nrb) {
+  __shared__ float red[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int rq = threadIdx.x >> 6;
+  const int rb = blockIdx.y, batch = blockIdx.z;
+  const float* x = X + batch * strideX;
+  const int r0 = rb * CS_ROWS, r1 = min(rows, r0 + CS_ROWS);
+  float s = 0.0f;
+  if (c < cols)
+    for (int r = r0 + rq; r < r1; r += 4) s += x[(long)r * ldx + c];
+  red[rq][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (rq == 0 && c < cols) {
+    const int l = threadIdx.x;
+    part[((long)batch * nrb + rb) * cols + c] = (red[0][l] + red[1][l]) + (red[2][l] + red[3][l]);
+  }
+}
+
+__global__ __launch_bounds__(256) void colsum_stage2(const float* __restrict__ part, int nrb, int cols, float* __restrict__ out,
+                                                     long strideOut, float scale, int accumulate) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  const int batch = blockIdx.y;
+  if (c >= cols) return;
+  float s = 0.0f;
+  for (int rb = 0; rb < nrb; ++rb) s += part[((long)batch * nrb + rb) * cols + c];
+  s *= scale;
+  float* o = out + batch * strideOut + c;
+  *o = accumulate ? *o + s : s;
+}
+}  // namespace
+
+extern "C" long lfi_colsum_work_floats(int rows, int cols, int batch) {
+  return (long)batch * lfi_cdiv(rows, CS_ROWS) * cols;
+}
+
+extern "C" int lfi_colsum_f32(const float* X, long ldx, long strideX, int rows, int cols, int batch, float* out,
+                              long strideOut, float scale, int accumulate, float* work, void* stream) {
+  LFI_REQUIRE(X && out && work, "lfi_colsum_f32: null pointer");
+  LFI_REQUIRE(rows >= 1 && cols >= 1 && batch >= 1 && batch <= 65535, "lfi_colsum_f32: bad dims");
+  hipStream_t st = (hipStream_t)stream;
+  const int nrb = lfi_cdiv(rows, CS_ROWS);
+  LFI_REQUIRE(nrb <= 65535, "lfi_colsum_f32: too many rows");
+  hipLaunchKernelGGL(colsum_stage1, dim3(lfi_cdiv(cols, 64), nrb, batch), dim3(256), 0, st, X, ldx, strideX, rows, cols,
+                     work, nrb);
+  LFI_LAUNCH_CHECK("lfi_colsum_f32 stage 1");
+  hipLaunchKernelGGL(colsum_stage2, dim3(lfi_cdiv(cols, 256), batch), dim3(256), 0, st, work, nrb, cols, out, strideOut,
+                     scale, accumulate);
+  LFI_LAUNCH_CHECK("lfi_colsum_f32 stage 2");
+  return LFI_OK;
+}
+
+// ------------------------------------------------------------------ optimiser
+namespace {
+constexpr int SUMSQ_BLOCKS = 1024;
+
+__global__ __launch_bounds__(256) void sumsq_stage1(const float* __restrict__ g, long n, double* __restrict__ part) {
+  __shared__ double red[4];
+  double s = 0.0;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const double v = (double)g[i];
+    s += v * v;
+  }
+  s = wave_sum_d(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) part[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(256) void sumsq_stage2(const double* __restrict__ part, int nparts, double* __restrict__ out) {
+  __shared__ double red[4];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < nparts; i += 256) s += part[i];
+  s = wave_sum_d(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) out[0] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(256) void adam_clip_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                        float* __restrict__ v, long n, const double* __restrict__ sumsq, float clip,
+                                                        float gmul, float step_size, float beta1, float beta2, float eps,
+                                                        float inv_sqrt_bc2) {
+  float coef = gmul;
+  if (clip > 0.0f) {
+    const double total = sqrt(sumsq[0]) * (double)fabsf(gmul);
+    const double c = (double)clip / (total + 1e-6);
+    if (c < 1.0) coef *= (float)c;
+  }
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const float gi = g[i] * coef;
+    const float mi = beta1 * m[i] + (1.0f - beta1) * gi;
+    const float vi = beta2 * v[i] + (1.0f - beta2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    const float denom = sqrtf(vi) * inv_sqrt_bc2 + eps;
+    p[i] -= step_size * (mi / denom);
+  }
+}
+}  // namespace
+
+extern "C" int lfi_grad_sumsq(const float* g, long n, double* sumsq, double* work, void* stream) {
+  LFI_REQUIRE(g && sumsq && work && n >= 0, "lfi_grad_sumsq: bad arguments");
+  hipStream_t st = (hipStream_t)stream;
+  int blocks = (int)min((long)SUMSQ_BLOCKS, (long)lfi_cdiv(n > 0 ? n : 1, 256));
+  hipLaunchKernelGGL(sumsq_stage1, dim3(blocks), dim3(256), 0, st, g, n, work);
+  LFI_LAUNCH_CHECK("lfi_grad_sumsq stage 1");
+  hipLaunchKernelGGL(sumsq_stage2, dim3(1), dim3(256), 0, st, work, blocks, sumsq);
+  LFI_LAUNCH_CHECK("lfi_grad_sumsq stage 2");
+  return LFI_OK;
+}
+
+extern "C" int lfi_adam_clip_step(float* p, const float* g, float* m, float* v, long n, const double* sumsq, float clip,
+                                  float gmul, float lr, float beta1, float beta2, float eps, int step_count, void* stream) {
+  LFI_REQUIRE(p && g && m && v && n >= 0 && step_count >= 1, "lfi_adam_clip_step: bad arguments");
+  LFI_REQUIRE(clip <= 0.0f || sumsq, "lfi_adam_clip_step: clipping needs sumsq");
+  hipStream_t st = (hipStream_t)stream;
+  const double bc1 = 1.0 - pow((double)beta1, step_count), bc2 = 1.0 - pow((double)beta2, step_count);
+  const float step_size = (float)((double)lr / bc1);
+  const float inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+  int blocks = (int)min(2048L, (long)lfi_cdiv(n > 0 ? n : 1, 256));
+  hipLaunchKernelGGL(adam_clip_kernel, dim3(blocks), dim3(256), 0, st, p, g, m, v, n, sumsq, clip, gmul, step_size, beta1,
+                     beta2, eps, inv_sqrt_bc2);
+  LFI_LAUNCH_CHECK("lfi_adam_clip_step");
+  return LFI_OK;
+}

@@ -1,0 +1,1219 @@
+// The conditional-Glow flow itself: FlowStep.normal_flow / reverse_flow (glow/models.py:311-373), f_seq.forward
+// (:204-214), ActNorm2d / InvertibleConv1x1 / LinearZeros (glow/modules.py), SeqGlow.loss (:563-565), and their
+// gradients, as one "cell" kernel per (timestep n, flow step k).
+//
+// Dependency structure. Cell (n, k) needs the flow variable from (n, k-1) and the coupling net's recurrent state from
+// (n-1, k) (the GRUCell hidden state is carried over timesteps, glow/models.py:193-214), so the (n, k) grid is walked
+// in anti-diagonals: all cells with n + k = d are independent and run in ONE launch (up to min(N, Ks) cells x B/16
+// batch tiles of workgroups); N + Ks - 1 launches replace the reference's N * Ks * ~340 ATen calls. Everything that
+// does not depend on the recurrence (cond_transform, the W_ih[:, Ch:] c product) is hoisted into big GEMMs by the
+// caller (gic), and InvertibleConv1x1's W = P L U is built once per optimiser step (lfi_flow_prep) rather than per
+// call (glow/modules.py:163-173).
+//
+// Cell kernel: 16 samples x all channels per workgroup, 4 waves; the four small GEMMs of a cell
+// (a W, [z1|h] [Wz|Whh]^T, h' Wfl^T and their transposes in backward) run on v_mfma_f32_16x16x4_f32 with the A
+// operand staged k-major in LDS and the weights streamed from L2 as coalesced row segments; all elementwise math
+// (actnorm, gates, LinearZeros scaling, affine coupling, log-det) is fused around them in fp32.
+#include <math.h>
+
+#include "lfi_common.h"
+
+namespace {
+
+constexpr int MB = 16;        // samples per workgroup
+constexpr int LT = MB + 1;    // k-major LDS leading dimension
+constexpr float LOG2PI_F = 1.8378770664093453f;
+constexpr float LN2_F = 0.6931471805599453f;
+
+struct FlowK {
+  // dims
+  int B, N, C, H, D, Ks, affine, lstm;
+  float eps;
+  int Ch, C2, Cout, G, I, F, nbt;
+  // params
+  lfi_flow_params p;
+  // prep
+  const float *W, *Wt, *Winv, *wz_t, *whh_t, *wfl_t, *ldconst;
+  // forward stash
+  float *sA, *sY, *sX, *sH, *sG, *sO, *sL;
+  // backward stash
+  float *bDlin, *bDgi, *bDgh, *bDy, *bDx, *bDh, *bPlfl, *bPan;
+  // sequence inputs
+  const float* x0; int T, start;
+  const float* gic;
+  float gscale;
+};
+
+// Everything one forward cell touches, resolved to pointers for its (k, frame block).
+struct CellIO {
+  int k, rows;            // flow step, valid rows in this call (<= B)
+  const float* x_in; long ldx;   // rows x C
+  const float* h_prev;    // rows x H or null (zeros)
+  const float* gic;       // rows x G
+  float *a_out, *y_out, *x_out, *h_out, *g_out, *o_out, *l_out;  // nullable stashes; x_out/h_out required
+  long ldxo;              // leading dimension of x_out
+  int l_accumulate;       // l_out += instead of =
+};
+
+extern __shared__ __attribute__((aligned(16))) float flow_smem[];
+
+__device__ __forceinline__ int rup16(int x) { return (x + 15) & ~15; }
+
+// ---- shared phase: coupling net given z1 (Zt) and h_prev (Ht) in LDS -> new hidden (Hn, LDS) and o (Orm, LDS)
+__device__ __forceinline__ void coupling_net_phase(const FlowK& f, const CellIO& io, int b0, const float* Zt, const float* Ht,
+                                                   float* Hn, float* Orm, int tid) {
+  const int lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, lq = lane >> 4;
+  const int k = io.k, H = f.H, G = f.G, Ch = f.Ch, Cout = f.Cout;
+  const float* wz = f.wz_t + (long)k * Ch * G;
+  const float* wh = f.whh_t + (long)k * H * G;
+  const float* bhh = f.p.b_hh + (long)k * G;
+  const int nht = (H + 15) >> 4;
+  for (int t = wave; t < nht; t += 4) {
+    const int j = t * 16 + l15;
+    const bool jok = j < H;
+    f32x4 ar = {0.f, 0.f, 0.f, 0.f}, au = ar, ain = ar, ahn = ar;
+    // z1 part: three independent accumulator chains interleaved
+    {
+      const int i = l15;
+      int kk0 = 0;
+      for (; kk0 < Ch; kk0 += 4) {
+        const int kk = kk0 + lq;
+        const bool kok = kk < Ch;
+        const float av = kok ? Zt[kk * LT + i] : 0.0f;
+        const float* br = wz + (long)kk * G + j;
+        const bool ok = kok && jok;
+        ar = mfma16(av, ok ? br[0] : 0.0f, ar);
+        au = mfma16(av, ok ? br[H] : 0.0f, au);
+        ain = mfma16(av, ok ? br[2 * H] : 0.0f, ain);
+      }
+      for (kk0 = 0; kk0 < H; kk0 += 4) {
+        const int kk = kk0 + lq;
+        const bool kok = kk < H;
+        const float av = kok ? Ht[kk * LT + i] : 0.0f;
+        const float* br = wh + (long)kk * G + j;
+        const bool ok = kok && jok;
+        ar = mfma16(av, ok ? br[0] : 0.0f, ar);
+        au = mfma16(av, ok ? br[H] : 0.0f, au);
+        ahn = mfma16(av, ok ? br[2 * H] : 0.0f, ahn);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = lq * 4 + r;
+      const int row = b0 + i;
+      float hnew = 0.0f;
+      if (row < io.rows && jok) {
+        const float* gc = io.gic + (long)row * G;
+        const float rr = sigmoidf_(ar[r] + gc[j] + bhh[j]);
+        const float uu = sigmoidf_(au[r] + gc[H + j] + bhh[H + j]);
+        const float ghn = ahn[r] + bhh[2 * H + j];
+        const float nn = tanhf(ain[r] + gc[2 * H + j] + rr * ghn);
+        const float hp = Ht[j * LT + i];
+        hnew = (1.0f - uu) * nn + uu * hp;
+        io.h_out[(long)row * H + j] = hnew;
+        if (io.g_out) {
+          float* gs = io.g_out + (long)row * 4 * H;
+          gs[j] = rr; gs[H + j] = uu; gs[2 * H + j] = nn; gs[3 * H + j] = ghn;
+        }
+      }
+      if (jok) Hn[j * LT + i] = hnew;
+    }
+  }
+  __syncthreads();
+  // o = (h' Wfl^T + b) * exp(3 logs)    (LinearZeros, glow/modules.py:93-95)
+  const float* wf = f.wfl_t + (long)k * H * Cout;
+  const float* bfl = f.p.b_fl + (long)k * Cout;
+  const float* lfl = f.p.l_fl + (long)k * Cout;
+  const int not_ = (Cout + 15) >> 4;
+  const int ldo = Cout + 1;
+  for (int t = wave; t < not_; t += 4) {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    acc = tile16_lds_glb(acc, Hn, LT, wf + t * 16, Cout, H, min(16, Cout - t * 16), lane);
+    const int col = t * 16 + l15;
+    if (col < Cout) {
+      const float bb = bfl[col], sc = expf(3.0f * lfl[col]);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = lq * 4 + r;
+        const int row = b0 + i;
+        const float o = (acc[r] + bb) * sc;
+        Orm[i * ldo + col] = o;
+        if (io.o_out && row < io.rows) io.o_out[(long)row * Cout + col] = o;
+      }
+    }
+  }
+  __syncthreads();
+}
+
+// LDS carve for the cell kernels (floats). Every k-major block is [dim][LT].
+struct Carve {
+  int At, Ht, Zt, Hn, Yrm, Orm, Lg, total;
+};
+__host__ __device__ inline Carve carve_fwd(int C, int H, int Ch, int C2, int Cout) {
+  Carve c;
+  int o = 0;
+  c.At = o; o += C * LT;
+  c.Ht = o; o += H * LT;
+  c.Zt = o; o += (Ch > 0 ? Ch : 1) * LT;
+  c.Hn = o; o += H * LT;
+  c.Yrm = o; o += MB * (C + 1);
+  c.Orm = o; o += MB * (Cout + 1);
+  c.Lg = o; o += MB * (C2 + 1);
+  c.total = o;
+  return c;
+}
+
+// ------------------------------------------------------------------------------------------- forward cell
+__device__ void cell_forward(const FlowK& f, const CellIO& io, int b0) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, lq = lane >> 4;
+  const int C = f.C, H = f.H, Ch = f.Ch, C2 = f.C2, Cout = f.Cout, k = io.k;
+  const Carve cv = carve_fwd(C, H, Ch, C2, Cout);
+  float* At = flow_smem + cv.At;
+  float* Ht = flow_smem + cv.Ht;
+  float* Zt = flow_smem + cv.Zt;
+  float* Hn = flow_smem + cv.Hn;
+  float* Yrm = flow_smem + cv.Yrm;
+  float* Orm = flow_smem + cv.Orm;
+  float* Lg = flow_smem + cv.Lg;
+  const int ldy = C + 1, ldo = Cout + 1, ldl = C2 + 1;
+
+  // P0: actnorm (glow/modules.py:45-52), stage a and h_prev k-major
+  const float* anb = f.p.an_bias + (long)k * C;
+  const float* anl = f.p.an_logs + (long)k * C;
+  for (int idx = tid; idx < MB * C; idx += 256) {
+    const int i = idx / C, c = idx - i * C;
+    const int row = b0 + i;
+    float a = 0.0f;
+    if (row < io.rows) {
+      a = (io.x_in[(long)row * io.ldx + c] + anb[c]) * expf(anl[c]);
+      if (io.a_out) io.a_out[(long)row * C + c] = a;
+    }
+    At[c * LT + i] = a;
+  }
+  for (int idx = tid; idx < MB * H; idx += 256) {
+    const int i = idx / H, j = idx - i * H;
+    const int row = b0 + i;
+    Ht[j * LT + i] = (io.h_prev && row < io.rows) ? io.h_prev[(long)row * H + j] : 0.0f;
+  }
+  __syncthreads();
+
+  // P1: y = a W   (InvertibleConv1x1.forward, glow/modules.py:186; row-vector convention)
+  {
+    const float* W = f.W + (long)k * C * C;
+    const int nt = (C + 15) >> 4;
+    for (int t = wave; t < nt; t += 4) {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      acc = tile16_lds_glb(acc, At, LT, W + t * 16, C, C, min(16, C - t * 16), lane);
+      const int c = t * 16 + l15;
+      if (c < C) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int i = lq * 4 + r;
+          const int row = b0 + i;
+          const float v = acc[r];
+          Yrm[i * ldy + c] = v;
+          if (c < Ch) Zt[c * LT + i] = v;
+          if (io.y_out && row < io.rows) io.y_out[(long)row * C + c] = v;
+        }
+      }
+    }
+  }
+  __syncthreads();
+
+  // P2 + P3: coupling net
+  coupling_net_phase(f, io, b0, Zt, Ht, Hn, Orm, tid);
+
+  // P4: coupling (glow/models.py:330-341) and pass-through half
+  for (int idx = tid; idx < MB * C2; idx += 256) {
+    const int i = idx / C2, jj = idx - i * C2;
+    const int row = b0 + i;
+    const float z2 = Yrm[i * ldy + Ch + jj];
+    float z2n, lg = 0.0f;
+    if (f.affine) {
+      const float shift = Orm[i * ldo + 2 * jj];
+      const float sraw = sigmoidf_(Orm[i * ldo + 2 * jj + 1] + 2.0f);
+      const float sc = fmaxf(sraw, f.eps);
+      z2n = (z2 + shift) * sc;
+      lg = logf(sc);
+    } else {
+      z2n = z2 + Orm[i * ldo + jj];
+    }
+    Lg[i * ldl + jj] = lg;
+    if (row < io.rows) io.x_out[(long)row * io.ldxo + Ch + jj] = z2n;
+  }
+  for (int idx = tid; idx < MB * Ch; idx += 256) {
+    const int i = idx / Ch, c = idx - i * Ch;
+    const int row = b0 + i;
+    if (row < io.rows) io.x_out[(long)row * io.ldxo + c] = Yrm[i * ldy + c];
+  }
+  __syncthreads();
+  if (tid < MB && io.l_out) {
+    const int row = b0 + tid;
+    if (row < io.rows) {
+      float s = 0.0f;
+      for (int jj = 0; jj < C2; ++jj) s += Lg[tid * ldl + jj];
+      if (io.l_accumulate) io.l_out[row] += s; else io.l_out[row] = s;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------- reverse cell
+// FlowStep.reverse_flow (glow/models.py:345-373): coupling^-1 -> invconv^-1 -> actnorm^-1.
+__device__ void cell_reverse(const FlowK& f, const CellIO& io, int b0) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, lq = lane >> 4;
+  const int C = f.C, H = f.H, Ch = f.Ch, C2 = f.C2, Cout = f.Cout, k = io.k;
+  const Carve cv = carve_fwd(C, H, Ch, C2, Cout);
+  float* Yt = flow_smem + cv.At;   // y = [z1 | z2] k-major for the W^-1 product
+  float* Ht = flow_smem + cv.Ht;
+  float* Zt = flow_smem + cv.Zt;
+  float* Hn = flow_smem + cv.Hn;
+  float* Yrm = flow_smem + cv.Yrm;
+  float* Orm = flow_smem + cv.Orm;
+  float* Lg = flow_smem + cv.Lg;
+  const int ldy = C + 1, ldo = Cout + 1, ldl = C2 + 1;
+
+  for (int idx = tid; idx < MB * C; idx += 256) {
+    const int i = idx / C, c = idx - i * C;
+    const int row = b0 + i;
+    const float v = row < io.rows ? io.x_in[(long)row * io.ldx + c] : 0.0f;
+    Yrm[i * ldy + c] = v;
+    if (c < Ch) { Zt[c * LT + i] = v; Yt[c * LT + i] = v; }
+  }
+  for (int idx = tid; idx < MB * H; idx += 256) {
+    const int i = idx / H, j = idx - i * H;
+    const int row = b0 + i;
+    Ht[j * LT + i] = (io.h_prev && row < io.rows) ? io.h_prev[(long)row * H + j] : 0.0f;
+  }
+  __syncthreads();
+  coupling_net_phase(f, io, b0, Zt, Ht, Hn, Orm, tid);
+  for (int idx = tid; idx < MB * C2; idx += 256) {
+    const int i = idx / C2, jj = idx - i * C2;
+    const float z2n = Yrm[i * ldy + Ch + jj];
+    float z2, lg = 0.0f;
+    if (f.affine) {
+      const float shift = Orm[i * ldo + 2 * jj];
+      const float sraw = sigmoidf_(Orm[i * ldo + 2 * jj + 1] + 2.0f);
+      const float sc = fmaxf(sraw, f.eps);
+      z2 = z2n / sc;
+      z2 = z2 - shift;
+      lg = -logf(sc);
+    } else {
+      z2 = z2n - Orm[i * ldo + jj];
+    }
+    Lg[i * ldl + jj] = lg;
+    Yt[(Ch + jj) * LT + i] = z2;
+  }
+  __syncthreads();
+  {
+    const float* Wi = f.Winv + (long)k * C * C;
+    const float* anb = f.p.an_bias + (long)k * C;
+    const float* anl = f.p.an_logs + (long)k * C;
+    const int nt = (C + 15) >> 4;
+    for (int t = wave; t < nt; t += 4) {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      acc = tile16_lds_glb(acc, Yt, LT, Wi + t * 16, C, C, min(16, C - t * 16), lane);
+      const int c = t * 16 + l15;
+      if (c < C) {
+        const float es = expf(-anl[c]), bb = anb[c];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = b0 + lq * 4 + r;
+          if (row < io.rows) io.x_out[(long)row * io.ldxo + c] = acc[r] * es - bb;  // scale then center (modules.py:76-79)
+        }
+      }
+    }
+  }
+  if (tid < MB && io.l_out) {
+    const int row = b0 + tid;
+    if (row < io.rows) {
+      float s = 0.0f;
+      for (int jj = 0; jj < C2; ++jj) s += Lg[tid * ldl + jj];
+      if (io.l_accumulate) io.l_out[row] += s; else io.l_out[row] = s;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void flow_diag_fwd_kernel(FlowK f, int d, int klo) {
+  const int k = klo + blockIdx.y, n = d - k;
+  const long fr = (long)n * f.B;  // first frame of this timestep
+  CellIO io;
+  io.k = k; io.rows = f.B;
+  if (k == 0) { io.x_in = f.x0 + (long)(f.start + n) * f.C; io.ldx = (long)f.T * f.C; }
+  else { io.x_in = f.sX + ((long)(k - 1) * f.F + fr) * f.C; io.ldx = f.C; }
+  io.h_prev = n > 0 ? f.sH + ((long)k * f.F + fr - f.B) * f.H : nullptr;
+  io.gic = f.gic + ((long)k * f.F + fr) * f.G;
+  io.a_out = f.sA + ((long)k * f.F + fr) * f.C;
+  io.y_out = f.sY + ((long)k * f.F + fr) * f.C;
+  io.x_out = f.sX + ((long)k * f.F + fr) * f.C; io.ldxo = f.C;
+  io.h_out = f.sH + ((long)k * f.F + fr) * f.H;
+  io.g_out = f.sG + ((long)k * f.F + fr) * 4 * f.H;
+  io.o_out = f.sO + ((long)k * f.F + fr) * f.Cout;
+  io.l_out = f.sL + (long)k * f.F + fr;
+  io.l_accumulate = 0;
+  cell_forward(f, io, blockIdx.x * MB);
+}
+
+__global__ __launch_bounds__(256) void flow_step_kernel(FlowK f, CellIO io, int reverse) {
+  if (reverse) cell_reverse(f, io, blockIdx.x * MB);
+  else cell_forward(f, io, blockIdx.x * MB);
+}
+
+// nll[f] = -(logdet + sum_c -0.5 (z^2 + log 2pi)) / ln 2   (SeqGlow.loss, glow/models.py:563-565)
+__global__ __launch_bounds__(256) void flow_nll_kernel(FlowK f, float* __restrict__ z, float* __restrict__ nll) {
+  const long fr = (long)blockIdx.x * 256 + threadIdx.x;
+  if (fr >= f.F) return;
+  float ld = f.ldconst[0];
+  for (int k = 0; k < f.Ks; ++k) ld += f.sL[(long)k * f.F + fr];
+  const float* zz = f.sX + ((long)(f.Ks - 1) * f.F + fr) * f.C;
+  float lp = 0.0f;
+  for (int c = 0; c < f.C; ++c) {
+    const float v = zz[c];
+    lp += -0.5f * (v * v + LOG2PI_F);
+    if (z) z[fr * f.C + c] = v;
+  }
+  nll[fr] = -(ld + lp) / LN2_F;
+}
+
+// ------------------------------------------------------------------------------------------- backward cell
+struct CarveB {
+  int Dl, Gi, Gh, Dy, Cy, Pl, total;
+};
+__host__ __device__ inline CarveB carve_bwd(int C, int H, int Cout, int G) {
+  CarveB c;
+  int o = 0;
+  c.Dl = o; o += Cout * LT;
+  c.Gi = o; o += G * LT;
+  c.Gh = o; o += G * LT;
+  c.Dy = o; o += C * LT;
+  c.Cy = o; o += H * LT;
+  c.Pl = o; o += MB * (Cout + 1);
+  c.total = o;
+  return c;
+}
+
+__global__ __launch_bounds__(256) void flow_diag_bwd_kernel(FlowK f, int d, int klo) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, lq = lane >> 4;
+  const int k = klo + blockIdx.y, n = d - k;
+  const int b0 = blockIdx.x * MB;
+  const int B = f.B, C = f.C, H = f.H, Ch = f.Ch, C2 = f.C2, Cout = f.Cout, G = f.G, I = f.I;
+  const long fr = (long)n * B;
+  const long kf = (long)k * f.F + fr;
+  const CarveB cv = carve_bwd(C, H, Cout, G);
+  float* Dl = flow_smem + cv.Dl;
+  float* Gi = flow_smem + cv.Gi;
+  float* Gh = flow_smem + cv.Gh;
+  float* Dy = flow_smem + cv.Dy;
+  float* Cy = flow_smem + cv.Cy;
+  float* Pl = flow_smem + cv.Pl;
+  const int ldp = Cout + 1;
+  const bool last = k == f.Ks - 1;
+  const float gz = f.gscale / LN2_F;   // d loss / d z = z * gz   (prior term)
+  const float dl = -f.gscale / LN2_F;  // d loss / d logdet
+  const float* dxo = last ? f.sX + kf * C : f.bDx + ((long)(k + 1) * f.F + fr) * C;
+  const float dxs = last ? gz : 1.0f;
+
+  // Q0: coupling backward + LinearZeros scale
+  const float* Y = f.sY + kf * C;
+  const float* O = f.sO + kf * Cout;
+  const float* lfl = f.p.l_fl + (long)k * Cout;
+  for (int idx = tid; idx < MB * C2; idx += 256) {
+    const int i = idx / C2, jj = idx - i * C2;
+    const int row = b0 + i;
+    float dz2 = 0.0f, d0 = 0.0f, d1 = 0.0f, p0 = 0.0f, p1 = 0.0f;
+    if (row < B) {
+      const float dz2n = dxo[(long)row * C + Ch + jj] * dxs;
+      if (f.affine) {
+        const float oe = O[(long)row * Cout + 2 * jj], oo = O[(long)row * Cout + 2 * jj + 1];
+        const float sraw = sigmoidf_(oo + 2.0f);
+        const float sc = fmaxf(sraw, f.eps);
+        const float z2 = Y[(long)row * C + Ch + jj];
+        dz2 = dz2n * sc;
+        const float dsc = dz2n * (z2 + oe) + dl / sc;
+        const float dsr = sraw >= f.eps ? dsc : 0.0f;
+        d0 = dz2;                             // d o_even (shift)
+        d1 = dsr * sraw * (1.0f - sraw);      // d o_odd
+        p0 = d0 * oe * 3.0f; p1 = d1 * oo * 3.0f;
+      } else {
+        const float oe = O[(long)row * Cout + jj];
+        dz2 = dz2n; d0 = dz2n; p0 = d0 * oe * 3.0f;
+      }
+    }
+    Dy[(Ch + jj) * LT + i] = dz2;
+    if (row < B) f.bDy[kf * C + (long)row * C + Ch + jj] = dz2;
+    if (f.affine) {
+      const int c0 = 2 * jj, c1 = 2 * jj + 1;
+      const float dl0 = d0 * expf(3.0f * lfl[c0]), dl1 = d1 * expf(3.0f * lfl[c1]);
+      Dl[c0 * LT + i] = dl0; Dl[c1 * LT + i] = dl1;
+      Pl[i * ldp + c0] = p0; Pl[i * ldp + c1] = p1;
+      if (row < B) { f.bDlin[kf * Cout + (long)row * Cout + c0] = dl0; f.bDlin[kf * Cout + (long)row * Cout + c1] = dl1; }
+    } else {
+      const float dl0 = d0 * expf(3.0f * lfl[jj]);
+      Dl[jj * LT + i] = dl0;
+      Pl[i * ldp + jj] = p0;
+      if (row < B) f.bDlin[kf * Cout + (long)row * Cout + jj] = dl0;
+    }
+  }
+  __syncthreads();
+  if (tid < Cout) {
+    float s = 0.0f;
+    for (int i = 0; i < MB; ++i) s += Pl[i * ldp + tid];
+    f.bPlfl[(((long)k * f.N + n) * f.nbt + blockIdx.x) * Cout + tid] = s;
+  }
+
+  // Q1: d h' = dlin Wfl + dh from the next timestep; GRU cell backward
+  const int nht = (H + 15) >> 4;
+  {
+    const float* wfl = f.p.w_fl + (long)k * Cout * H;
+    const float* dhf = (n < f.N - 1) ? f.bDh + ((long)k * f.F + fr + B) * H : nullptr;
+    const float* gs_base = f.sG + kf * 4 * H;
+    const float* hp_base = n > 0 ? f.sH + ((long)k * f.F + fr - B) * H : nullptr;
+    for (int t = wave; t < nht; t += 4) {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      acc = tile16_lds_glb(acc, Dl, LT, wfl + t * 16, H, Cout, min(16, H - t * 16), lane);
+      const int j = t * 16 + l15;
+      if (j < H) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int i = lq * 4 + r;
+          const int row = b0 + i;
+          float dar = 0.f, dau = 0.f, dan = 0.f, danr = 0.f, cy = 0.f;
+          if (row < B) {
+            const float dhn = acc[r] + (dhf ? dhf[(long)row * H + j] : 0.0f);
+            const float* gs = gs_base + (long)row * 4 * H;
+            const float rr = gs[j], uu = gs[H + j], nn = gs[2 * H + j], ghn = gs[3 * H + j];
+            const float hp = hp_base ? hp_base[(long)row * H + j] : 0.0f;
+            const float du = dhn * (hp - nn);
+            const float dn = dhn * (1.0f - uu);
+            cy = dhn * uu;
+            dan = dn * (1.0f - nn * nn);
+            dau = du * uu * (1.0f - uu);
+            dar = dan * ghn * rr * (1.0f - rr);
+            danr = dan * rr;
+            float* gi = f.bDgi + kf * G + (long)row * G;
+            gi[j] = dar; gi[H + j] = dau; gi[2 * H + j] = dan;
+            float* gh = f.bDgh + kf * G + (long)row * G;
+            gh[j] = dar; gh[H + j] = dau; gh[2 * H + j] = danr;
+          }
+          Gi[j * LT + i] = dar; Gi[(H + j) * LT + i] = dau; Gi[(2 * H + j) * LT + i] = dan;
+          Gh[j * LT + i] = dar; Gh[(H + j) * LT + i] = dau; Gh[(2 * H + j) * LT + i] = danr;
+          Cy[j * LT + i] = cy;
+        }
+      }
+    }
+  }
+  __syncthreads();
+
+  // Q2: d h_prev = dgh Whh + carry (to timestep n-1);  d z1 = dgi W_ih[:, :Ch] + pass-through
+  {
+    const float* whh = f.p.w_hh + (long)k * G * H;
+    if (n > 0) {
+      float* dho = f.bDh + kf * H;
+      for (int t = wave; t < nht; t += 4) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        acc = tile16_lds_glb(acc, Gh, LT, whh + t * 16, H, G, min(16, H - t * 16), lane);
+        const int j = t * 16 + l15;
+        if (j < H) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int i = lq * 4 + r;
+            const int row = b0 + i;
+            if (row < B) dho[(long)row * H + j] = acc[r] + Cy[j * LT + i];
+          }
+        }
+      }
+    }
+    const float* wih = f.p.w_ih + (long)k * G * I;
+    const int nzt = (Ch + 15) >> 4;
+    for (int t = 3 - wave; t < nzt; t += 4) {  // start from the other end so these tiles land on the less loaded waves
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      acc = tile16_lds_glb(acc, Gi, LT, wih + t * 16, I, G, min(16, Ch - t * 16), lane);
+      const int c = t * 16 + l15;
+      if (c < Ch) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int i = lq * 4 + r;
+          const int row = b0 + i;
+          float v = 0.0f;
+          if (row < B) {
+            v = acc[r] + dxo[(long)row * C + c] * dxs;
+            f.bDy[kf * C + (long)row * C + c] = v;
+          }
+          Dy[c * LT + i] = v;
+        }
+      }
+    }
+  }
+  __syncthreads();
+
+  // Q3: d a = dy W^T ; actnorm backward ; d x_in to flow step k-1
+  {
+    const float* Wt = f.Wt + (long)k * C * C;
+    const float* anl = f.p.an_logs + (long)k * C;
+    const float* A = f.sA + kf * C;
+    float* dxi = k > 0 ? f.bDx + kf * C : nullptr;
+    float* pan = f.bPan + (((long)k * f.N + n) * f.nbt + blockIdx.x) * 2 * C;
+    const int nt = (C + 15) >> 4;
+    for (int t = wave; t < nt; t += 4) {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      acc = tile16_lds_glb(acc, Dy, LT, Wt + t * 16, C, C, min(16, C - t * 16), lane);
+      const int c = t * 16 + l15;
+      float sl = 0.0f, sb = 0.0f;
+      if (c < C) {
+        const float es = expf(anl[c]);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = b0 + lq * 4 + r;
+          if (row < B) {
+            const float da = acc[r];
+            sl += da * A[(long)row * C + c];
+            sb += da * es;
+            if (dxi) dxi[(long)row * C + c] = da * es;
+          }
+        }
+      }
+      sl += __shfl_xor(sl, 16, 64); sl += __shfl_xor(sl, 32, 64);
+      sb += __shfl_xor(sb, 16, 64); sb += __shfl_xor(sb, 32, 64);
+      if (lq == 0 && c < C) { pan[c] = sl; pan[C + c] = sb; }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------- prep
+// One workgroup per flow step: W = P (L*mask + I)(U*mask^T + diag(sign exp(log_s)))  (glow/modules.py:167-173),
+// its transpose, and (optionally) the reverse weight U^-1 L^-1 P^-1 with fp64 triangular inverses (:175-177).
+__global__ __launch_bounds__(256) void flow_prep_invconv_kernel(FlowK f, float* __restrict__ W, float* __restrict__ Wt,
+                                                                float* __restrict__ Winv, double* __restrict__ dscratch,
+                                                                float* __restrict__ ldpart) {
+  __shared__ int piv;
+  __shared__ double logabs;
+  const int k = blockIdx.x, C = f.C, tid = threadIdx.x;
+  float* Lm = flow_smem;            // C*C
+  float* Um = Lm + C * C;           // C*C
+  float* Tm = Um + C * C;           // C*C
+  const long kc = (long)k * C * C;
+  float* Wk = W + kc;
+  float* Wtk = Wt + kc;
+  if (f.p.inv_w) {
+    for (int idx = tid; idx < C * C; idx += 256) {
+      const int i = idx / C, j = idx - i * C;
+      const float v = f.p.inv_w[kc + idx];
+      Wk[idx] = v;
+      Wtk[(long)j * C + i] = v;
+    }
+    // log|det| and inverse by Gauss-Jordan with partial pivoting in fp64 (torch.slogdet / torch.inverse(double))
+    double* M = dscratch + (long)k * 2 * C * C;  // C x 2C augmented
+    for (int idx = tid; idx < C * C; idx += 256) {
+      const int i = idx / C, j = idx - i * C;
+      M[(long)i * 2 * C + j] = (double)f.p.inv_w[kc + idx];
+      M[(long)i * 2 * C + C + j] = i == j ? 1.0 : 0.0;
+    }
+    if (tid == 0) logabs = 0.0;
+    __syncthreads();
+    for (int col = 0; col < C; ++col) {
+      if (tid == 0) {
+        int best = col;
+        double bv = fabs(M[(long)col * 2 * C + col]);
+        for (int r = col + 1; r < C; ++r) {
+          const double v = fabs(M[(long)r * 2 * C + col]);
+          if (v > bv) { bv = v; best = r; }
+        }
+        piv = best;
+        logabs += log(bv);
+      }
+      __syncthreads();
+      const int pr = piv;
+      if (pr != col)
+        for (int j = tid; j < 2 * C; j += 256) {
+          const double t0 = M[(long)col * 2 * C + j];
+          M[(long)col * 2 * C + j] = M[(long)pr * 2 * C + j];
+          M[(long)pr * 2 * C + j] = t0;
+        }
+      __syncthreads();
+      const double pv = M[(long)col * 2 * C + col];
+      __syncthreads();
+      for (int j = tid; j < 2 * C; j += 256) M[(long)col * 2 * C + j] /= pv;
+      __syncthreads();
+      // two-pass elimination: every row's factor M[r][col] is read before any row is updated
+      double* fac = dscratch + (long)f.Ks * 2 * C * C + (long)k * C;
+      for (int r = tid; r < C; r += 256) fac[r] = (r == col) ? 0.0 : M[(long)r * 2 * C + col];
+      __syncthreads();
+      for (int idx = tid; idx < C * 2 * C; idx += 256) {
+        const int r = idx / (2 * C), j = idx - r * 2 * C;
+        M[(long)r * 2 * C + j] -= fac[r] * M[(long)col * 2 * C + j];
+      }
+      __syncthreads();
+    }
+    if (Winv)
+      for (int idx = tid; idx < C * C; idx += 256) {
+        const int i = idx / C, j = idx - i * C;
+        Winv[kc + idx] = (float)M[(long)i * 2 * C + C + j];
+      }
+    if (tid == 0) {
+      float s = 0.0f;
+      for (int c = 0; c < C; ++c) s += f.p.an_logs[(long)k * C + c];
+      ldpart[k] = (float)C * (s + (float)logabs);
+    }
+    return;
+  }
+  const float* l = f.p.inv_l + kc;
+  const float* u = f.p.inv_u + kc;
+  const float* P = f.p.inv_p + kc;
+  const float* sg = f.p.inv_sign + (long)k * C;
+  const float* ls = f.p.inv_logs + (long)k * C;
+  for (int idx = tid; idx < C * C; idx += 256) {
+    const int i = idx / C, j = idx - i * C;
+    Lm[idx] = i > j ? l[idx] : (i == j ? 1.0f : 0.0f);
+    Um[idx] = i < j ? u[idx] : (i == j ? sg[i] * expf(ls[i]) : 0.0f);
+  }
+  __syncthreads();
+  for (int idx = tid; idx < C * C; idx += 256) {  // T = Lm Um
+    const int i = idx / C, j = idx - i * C;
+    float s = 0.0f;
+    for (int q = 0; q < C; ++q) s += Lm[i * C + q] * Um[q * C + j];
+    Tm[idx] = s;
+  }
+  __syncthreads();
+  for (int idx = tid; idx < C * C; idx += 256) {  // W = P T
+    const int i = idx / C, j = idx - i * C;
+    float s = 0.0f;
+    for (int q = 0; q < C; ++q) s += P[i * C + q] * Tm[q * C + j];
+    Wk[idx] = s;
+    Wtk[(long)j * C + i] = s;
+  }
+  if (tid == 0) {
+    float s = 0.0f;
+    for (int c = 0; c < C; ++c) s += f.p.an_logs[(long)k * C + c] + ls[c];
+    ldpart[k] = (float)C * s;
+  }
+  if (!Winv) return;
+  // fp64 triangular inverses by substitution, one column per thread
+  double* Li = dscratch + (long)k * 2 * C * C;
+  double* Ui = Li + C * C;
+  __syncthreads();
+  for (int j = tid; j < C; j += 256) {
+    // Lm unit lower: solve Lm x = e_j
+    for (int i = 0; i < C; ++i) {
+      double s = (i == j) ? 1.0 : 0.0;
+      for (int q = j; q < i; ++q) s -= (double)Lm[i * C + q] * Li[(long)q * C + j];
+      Li[(long)i * C + j] = i < j ? 0.0 : s;  // diagonal is 1
+    }
+    // Um upper: solve Um x = e_j
+    for (int i = C - 1; i >= 0; --i) {
+      double s = (i == j) ? 1.0 : 0.0;
+      for (int q = i + 1; q <= j; ++q) s -= (double)Um[i * C + q] * Ui[(long)q * C + j];
+      Ui[(long)i * C + j] = i > j ? 0.0 : s / (double)Um[i * C + i];
+    }
+  }
+  __syncthreads();
+  // reference order (fp32): w = u^-1 (l^-1 p^-1), p^-1 = p^T for a permutation
+  for (int idx = tid; idx < C * C; idx += 256) {
+    const int i = idx / C, j = idx - i * C;
+    float s = 0.0f;
+    for (int q = 0; q < C; ++q) s += (float)Li[(long)i * C + q] * P[j * C + q];
+    Tm[idx] = s;
+  }
+  __syncthreads();
+  for (int idx = tid; idx < C * C; idx += 256) {
+    const int i = idx / C, j = idx - i * C;
+    float s = 0.0f;
+    for (int q = 0; q < C; ++q) s += (float)Ui[(long)i * C + q] * Tm[q * C + j];
+    Winv[kc + idx] = s;
+  }
+}
+
+__global__ __launch_bounds__(256) void flow_prep_transpose_kernel(FlowK f, float* __restrict__ wz_t, float* __restrict__ whh_t,
+                                                                  float* __restrict__ wfl_t, const float* __restrict__ ldpart,
+                                                                  float* __restrict__ ldconst) {
+  const int k = blockIdx.y;
+  const int G = f.G, H = f.H, Ch = f.Ch, Cout = f.Cout, I = f.I;
+  const long n1 = (long)Ch * G, n2 = (long)H * G, n3 = (long)H * Cout;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < n1 + n2 + n3; idx += (long)gridDim.x * 256) {
+    if (idx < n1) {
+      const int c = (int)(idx / G), g = (int)(idx - (long)c * G);
+      wz_t[(long)k * n1 + idx] = f.p.w_ih[((long)k * G + g) * I + c];
+    } else if (idx < n1 + n2) {
+      const long q = idx - n1;
+      const int h = (int)(q / G), g = (int)(q - (long)h * G);
+      whh_t[(long)k * n2 + q] = f.p.w_hh[((long)k * G + g) * H + h];
+    } else {
+      const long q = idx - n1 - n2;
+      const int h = (int)(q / Cout), col = (int)(q - (long)h * Cout);
+      wfl_t[(long)k * n3 + q] = f.p.w_fl[((long)k * Cout + col) * H + h];
+    }
+  }
+  if (k == 0 && blockIdx.x == 0 && threadIdx.x == 0) {
+    float s = 0.0f;
+    for (int q = 0; q < f.Ks; ++q) s += ldpart[q];
+    ldconst[0] = s;
+  }
+}
+
+// Gradients of the LU parameters from dW (glow/modules.py:167-173 differentiated), one workgroup per flow step.
+__global__ __launch_bounds__(256) void flow_invconv_bwd_kernel(FlowK f, const float* __restrict__ dW, lfi_flow_grads g,
+                                                               float cconst, int accumulate) {
+  const int k = blockIdx.x, C = f.C, tid = threadIdx.x;
+  const long kc = (long)k * C * C;
+  float* Lm = flow_smem;
+  float* Um = Lm + C * C;
+  float* Q = Um + C * C;  // P^T dW
+  if (f.p.inv_w) {
+    // dense: d weight = dW + cconst * W^-T   (d log|det W| / dW = W^-T)
+    for (int idx = tid; idx < C * C; idx += 256) {
+      const int i = idx / C, j = idx - i * C;
+      const float v = dW[kc + idx] + cconst * f.Winv[kc + (long)j * C + i];
+      g.inv_w[kc + idx] = accumulate ? g.inv_w[kc + idx] + v : v;
+    }
+    return;
+  }
+  const float* l = f.p.inv_l + kc;
+  const float* u = f.p.inv_u + kc;
+  const float* P = f.p.inv_p + kc;
+  const float* sg = f.p.inv_sign + (long)k * C;
+  const float* ls = f.p.inv_logs + (long)k * C;
+  for (int idx = tid; idx < C * C; idx += 256) {
+    const int i = idx / C, j = idx - i * C;
+    Lm[idx] = i > j ? l[idx] : (i == j ? 1.0f : 0.0f);
+    Um[idx] = i < j ? u[idx] : (i == j ? sg[i] * expf(ls[i]) : 0.0f);
+    float s = 0.0f;
+    for (int q = 0; q < C; ++q) s += P[q * C + i] * dW[kc + (long)q * C + j];
+    Q[idx] = s;
+  }
+  __syncthreads();
+  for (int idx = tid; idx < C * C; idx += 256) {
+    const int i = idx / C, j = idx - i * C;
+    if (i > j) {  // dL = Q Um^T, strictly lower
+      float s = 0.0f;
+      for (int q = 0; q < C; ++q) s += Q[i * C + q] * Um[j * C + q];
+      g.inv_l[kc + idx] = accumulate ? g.inv_l[kc + idx] + s : s;
+      if (!accumulate) g.inv_u[kc + idx] = 0.0f;
+    } else {      // dU = Lm^T Q, upper incl. diagonal
+      float s = 0.0f;
+      for (int q = 0; q < C; ++q) s += Lm[q * C + i] * Q[q * C + j];
+      if (i < j) {
+        g.inv_u[kc + idx] = accumulate ? g.inv_u[kc + idx] + s : s;
+        if (!accumulate) g.inv_l[kc + idx] = 0.0f;
+      } else {
+        const float v = s * sg[i] * expf(ls[i]) + cconst;
+        const long o = (long)k * C + i;
+        g.inv_logs[o] = accumulate ? g.inv_logs[o] + v : v;
+        if (!accumulate) { g.inv_l[kc + idx] = 0.0f; g.inv_u[kc + idx] = 0.0f; }
+      }
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void add_const_kernel(float* __restrict__ x, long n, float v) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) x[i] += v;
+}
+
+// ------------------------------------------------------------------------------------------- actnorm init
+__global__ __launch_bounds__(256) void actnorm_stats_kernel(const float* __restrict__ x, int rows, int C, double* __restrict__ sums) {
+  // one block; column c handled by threads c, c+256...; fixed-order fp64 sums
+  for (int c = threadIdx.x; c < C; c += 256) {
+    double s = 0.0, s2 = 0.0;
+    for (int r = 0; r < rows; ++r) {
+      const double v = (double)x[(long)r * C + c];
+      s += v; s2 += v * v;
+    }
+    sums[c] = s; sums[C + c] = s2;
+  }
+}
+__global__ __launch_bounds__(256) void actnorm_apply_kernel(const double* __restrict__ sums, double count, int C, float scale,
+                                                            float* __restrict__ bias, float* __restrict__ logs) {
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const double mean = sums[c] / count;
+    double var = sums[C + c] / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    bias[c] = (float)(-mean);
+    logs[c] = (float)log((double)scale / (sqrt(var) + 1e-6));
+  }
+}
+
+// ------------------------------------------------------------------------------------------- host helpers
+int fill_flow(const lfi_flow_dims* d, const lfi_flow_params* p, const float* prep, FlowK* f, const char* who) {
+  LFI_REQUIRE(d && p, "%s: null dims/params", who);
+  LFI_REQUIRE(d->B > 0 && d->N > 0 && d->C >= 2 && d->H > 0 && d->D > 0 && d->Ks > 0, "%s: bad dims", who);
+  if (d->lstm) {
+    lfi_set_error("%s: LSTM coupling cell not implemented in this build", who);
+    return LFI_ERR_UNSUPPORTED;
+  }
+  f->B = d->B; f->N = d->N; f->C = d->C; f->H = d->H; f->D = d->D; f->Ks = d->Ks;
+  f->affine = d->affine; f->lstm = d->lstm; f->eps = d->scale_eps;
+  f->Ch = d->C / 2; f->C2 = d->C - f->Ch; f->Cout = d->affine ? 2 * f->C2 : f->C2;
+  f->G = 3 * d->H; f->I = f->Ch + d->D; f->F = d->N * d->B; f->nbt = lfi_cdiv(d->B, MB);
+  f->p = *p;
+  if (prep) {
+    const long cc = (long)d->Ks * d->C * d->C;
+    const float* q = prep;
+    f->W = q; q += cc;
+    f->Wt = q; q += cc;
+    f->Winv = q; q += cc;
+    f->wz_t = q; q += (long)d->Ks * f->Ch * f->G;
+    f->whh_t = q; q += (long)d->Ks * d->H * f->G;
+    f->wfl_t = q; q += (long)d->Ks * d->H * f->Cout;
+    f->ldconst = q;
+  }
+  return LFI_OK;
+}
+
+long stash_offsets(const FlowK& f, long* off) {
+  const long KF = (long)f.Ks * f.F;
+  long o = 0;
+  off[0] = o; o += KF * f.C;         // a
+  off[1] = o; o += KF * f.C;         // y
+  off[2] = o; o += KF * f.C;         // x_out
+  off[3] = o; o += KF * f.H;         // h
+  off[4] = o; o += KF * 4 * f.H;     // gates
+  off[5] = o; o += KF * f.Cout;      // o
+  off[6] = o; o += KF;               // coupling log-det
+  return o;
+}
+long bstash_offsets(const FlowK& f, long* off) {
+  const long KF = (long)f.Ks * f.F;
+  long o = 0;
+  off[0] = o; o += KF * f.Cout;      // dlin
+  off[1] = o; o += KF * f.G;         // dgi
+  off[2] = o; o += KF * f.G;         // dgh
+  off[3] = o; o += KF * f.C;         // dy
+  off[4] = o; o += KF * f.C;         // dx
+  off[5] = o; o += KF * f.H;         // dh
+  off[6] = o; o += (long)f.Ks * f.N * f.nbt * f.Cout;   // partial sums for l_fl
+  off[7] = o; o += (long)f.Ks * f.N * f.nbt * 2 * f.C;  // partial sums for actnorm logs | bias
+  return o;
+}
+void bind_stash(FlowK* f, float* stash) {
+  long off[7];
+  stash_offsets(*f, off);
+  f->sA = stash + off[0]; f->sY = stash + off[1]; f->sX = stash + off[2]; f->sH = stash + off[3];
+  f->sG = stash + off[4]; f->sO = stash + off[5]; f->sL = stash + off[6];
+}
+void bind_bstash(FlowK* f, float* b) {
+  long off[8];
+  bstash_offsets(*f, off);
+  f->bDlin = b + off[0]; f->bDgi = b + off[1]; f->bDgh = b + off[2]; f->bDy = b + off[3];
+  f->bDx = b + off[4]; f->bDh = b + off[5]; f->bPlfl = b + off[6]; f->bPan = b + off[7];
+}
+
+template <typename Kf>
+int set_flow_lds(Kf kernel, size_t bytes, const char* who) {
+  if (bytes > 160 * 1024) {
+    lfi_set_error("%s: needs %zu bytes of LDS (C/H too large)", who, bytes);
+    return LFI_ERR_UNSUPPORTED;
+  }
+  if (bytes > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) {
+      lfi_set_error("%s: hipFuncSetAttribute(%zu): %s", who, bytes, hipGetErrorString(e));
+      return LFI_ERR_LAUNCH;
+    }
+  }
+  return LFI_OK;
+}
+
+}  // namespace
+
+// =================================================================================================== C ABI
+extern "C" long lfi_flow_prep_floats(const lfi_flow_dims* d) {
+  if (!d) return 0;
+  const int Ch = d->C / 2, C2 = d->C - Ch, Cout = d->affine ? 2 * C2 : C2, G = (d->lstm ? 4 : 3) * d->H;
+  const long cc = (long)d->Ks * d->C * d->C;
+  long n = 3 * cc + (long)d->Ks * Ch * G + (long)d->Ks * d->H * G + (long)d->Ks * d->H * Cout + 4;
+  // scratch behind the published layout: per-step log-det parts and fp64 workspace for the inverses
+  n += d->Ks + 4;
+  n += 2 * ((long)d->Ks * 2 * d->C * d->C + (long)d->Ks * d->C) + 8;  // doubles, counted as 2 floats each
+  return n;
+}
+
+extern "C" int lfi_flow_prep(const lfi_flow_dims* d, const lfi_flow_params* p, float* prep, int with_inverse, void* stream) {
+  FlowK f = {};
+  int rc = fill_flow(d, p, prep, &f, "lfi_flow_prep");
+  if (rc) return rc;
+  LFI_REQUIRE(prep, "lfi_flow_prep: null prep buffer");
+  LFI_REQUIRE((p->inv_w != nullptr) || (p->inv_l && p->inv_u && p->inv_logs && p->inv_p && p->inv_sign),
+              "lfi_flow_prep: invconv parameters missing");
+  hipStream_t st = (hipStream_t)stream;
+  float* ldconst = (float*)f.ldconst;
+  float* ldpart = ldconst + 4;
+  // 8-byte aligned fp64 scratch after the float part
+  uintptr_t dp = (uintptr_t)(ldpart + d->Ks + 4);
+  dp = (dp + 7) & ~(uintptr_t)7;
+  double* dscratch = (double*)dp;
+  const size_t lds = (size_t)3 * d->C * d->C * sizeof(float);
+  rc = set_flow_lds(flow_prep_invconv_kernel, lds, "lfi_flow_prep");
+  if (rc) return rc;
+  hipLaunchKernelGGL(flow_prep_invconv_kernel, dim3(d->Ks), dim3(256), lds, st, f, (float*)f.W, (float*)f.Wt,
+                     (with_inverse || p->inv_w) ? (float*)f.Winv : nullptr, dscratch, ldpart);
+  LFI_LAUNCH_CHECK("lfi_flow_prep invconv");
+  hipLaunchKernelGGL(flow_prep_transpose_kernel, dim3(64, d->Ks), dim3(256), 0, st, f, (float*)f.wz_t, (float*)f.whh_t,
+                     (float*)f.wfl_t, ldpart, ldconst);
+  LFI_LAUNCH_CHECK("lfi_flow_prep transpose");
+  return LFI_OK;
+}
+
+extern "C" long lfi_flow_stash_floats(const lfi_flow_dims* d) {
+  FlowK f = {};
+  lfi_flow_params p = {};
+  if (fill_flow(d, &p, nullptr, &f, "lfi_flow_stash_floats")) return -1;
+  long off[7];
+  return stash_offsets(f, off);
+}
+extern "C" long lfi_flow_bstash_floats(const lfi_flow_dims* d) {
+  FlowK f = {};
+  lfi_flow_params p = {};
+  if (fill_flow(d, &p, nullptr, &f, "lfi_flow_bstash_floats")) return -1;
+  long off[8];
+  return bstash_offsets(f, off);
+}
+extern "C" float* lfi_flow_stash_ptr(const lfi_flow_dims* d, float* stash, int which) {
+  FlowK f = {};
+  lfi_flow_params p = {};
+  if (which < 0 || which > 6 || fill_flow(d, &p, nullptr, &f, "lfi_flow_stash_ptr")) return nullptr;
+  long off[7];
+  stash_offsets(f, off);
+  return stash + off[which];
+}
+extern "C" float* lfi_flow_bstash_ptr(const lfi_flow_dims* d, float* bstash, int which) {
+  FlowK f = {};
+  lfi_flow_params p = {};
+  if (which < 0 || which > 7 || fill_flow(d, &p, nullptr, &f, "lfi_flow_bstash_ptr")) return nullptr;
+  long off[8];
+  bstash_offsets(f, off);
+  return bstash + off[which];
+}
+
+extern "C" int lfi_flow_seq_fwd(const lfi_flow_dims* d, const lfi_flow_params* p, const float* prep, const float* x0, int T,
+                                int start, const float* gic, float* stash, float* z, float* nll, void* stream) {
+  FlowK f = {};
+  int rc = fill_flow(d, p, prep, &f, "lfi_flow_seq_fwd");
+  if (rc) return rc;
+  LFI_REQUIRE(prep && x0 && gic && stash && nll, "lfi_flow_seq_fwd: null pointer");
+  LFI_REQUIRE(start >= 0 && start + d->N <= T, "lfi_flow_seq_fwd: start %d + N %d > T %d", start, d->N, T);
+  bind_stash(&f, stash);
+  f.x0 = x0; f.T = T; f.start = start; f.gic = gic;
+  hipStream_t st = (hipStream_t)stream;
+  const Carve cv = carve_fwd(f.C, f.H, f.Ch, f.C2, f.Cout);
+  const size_t lds = (size_t)cv.total * sizeof(float);
+  rc = set_flow_lds(flow_diag_fwd_kernel, lds, "lfi_flow_seq_fwd");
+  if (rc) return rc;
+  for (int dg = 0; dg < f.N + f.Ks - 1; ++dg) {
+    const int klo = dg - (f.N - 1) > 0 ? dg - (f.N - 1) : 0;
+    const int khi = dg < f.Ks - 1 ? dg : f.Ks - 1;
+    hipLaunchKernelGGL(flow_diag_fwd_kernel, dim3(f.nbt, khi - klo + 1), dim3(256), lds, st, f, dg, klo);
+  }
+  LFI_LAUNCH_CHECK("lfi_flow_seq_fwd");
+  hipLaunchKernelGGL(flow_nll_kernel, dim3(lfi_cdiv(f.F, 256)), dim3(256), 0, st, f, z, nll);
+  LFI_LAUNCH_CHECK("lfi_flow_seq_fwd nll");
+  return LFI_OK;
+}
+
+extern "C" int lfi_flow_seq_bwd(const lfi_flow_dims* d, const lfi_flow_params* p, const float* prep, const float* stash,
+                                float gscale, float* bstash, void* stream) {
+  FlowK f = {};
+  int rc = fill_flow(d, p, prep, &f, "lfi_flow_seq_bwd");
+  if (rc) return rc;
+  LFI_REQUIRE(prep && stash && bstash, "lfi_flow_seq_bwd: null pointer");
+  bind_stash(&f, (float*)stash);
+  bind_bstash(&f, bstash);
+  f.gscale = gscale;
+  hipStream_t st = (hipStream_t)stream;
+  const CarveB cv = carve_bwd(f.C, f.H, f.Cout, f.G);
+  const size_t lds = (size_t)cv.total * sizeof(float);
+  rc = set_flow_lds(flow_diag_bwd_kernel, lds, "lfi_flow_seq_bwd");
+  if (rc) return rc;
+  for (int dg = f.N + f.Ks - 2; dg >= 0; --dg) {
+    const int klo = dg - (f.N - 1) > 0 ? dg - (f.N - 1) : 0;
+    const int khi = dg < f.Ks - 1 ? dg : f.Ks - 1;
+    hipLaunchKernelGGL(flow_diag_bwd_kernel, dim3(f.nbt, khi - klo + 1), dim3(256), lds, st, f, dg, klo);
+  }
+  LFI_LAUNCH_CHECK("lfi_flow_seq_bwd");
+  return LFI_OK;
+}
+
+extern "C" long lfi_flow_param_grads_work_floats(const lfi_flow_dims* d) {
+  FlowK f = {};
+  lfi_flow_params p = {};
+  if (fill_flow(d, &p, nullptr, &f, "lfi_flow_param_grads_work_floats")) return -1;
+  const int splitk = 16;
+  long gemm_ws = (long)f.Ks * splitk * ((long)f.G * f.I > (long)f.C * f.C ? (long)f.G * f.I : (long)f.C * f.C);
+  long cs = lfi_colsum_work_floats(f.F > f.N * f.nbt ? f.F : f.N * f.nbt, f.G > 2 * f.C ? f.G : 2 * f.C, f.Ks);
+  return (long)f.Ks * f.C * f.C + gemm_ws + cs + 16;
+}
+
+extern "C" int lfi_flow_param_grads(const lfi_flow_dims* d, const lfi_flow_params* p, const float* prep, const float* stash,
+                                    const float* bstash, const float* c, long ldc, float gscale, const lfi_flow_grads* g,
+                                    int accumulate, float* work, void* stream) {
+  FlowK f = {};
+  int rc = fill_flow(d, p, prep, &f, "lfi_flow_param_grads");
+  if (rc) return rc;
+  LFI_REQUIRE(prep && stash && bstash && c && g && work, "lfi_flow_param_grads: null pointer");
+  bind_stash(&f, (float*)stash);
+  bind_bstash(&f, (float*)bstash);
+  hipStream_t st = (hipStream_t)stream;
+  const int Ks = f.Ks, F = f.F, B = f.B, C = f.C, H = f.H, G = f.G, I = f.I, Cout = f.Cout, Ch = f.Ch, D = f.D;
+  float* dW = work;                       // [Ks][C][C]
+  float* gws = dW + (long)Ks * C * C;     // split-k workspace
+  const int splitk = 16;
+  const long gws_floats = (long)Ks * splitk * ((long)G * I > (long)C * C ? (long)G * I : (long)C * C);
+  float* cws = gws + gws_floats;          // colsum workspace
+
+  lfi_gemm_desc q = {};
+  q.batch = Ks; q.accumulate = accumulate; q.splitk = splitk; q.work = gws;
+  q.a_kcontig = 0; q.b_kcontig = 0; q.K = F;
+  // w_fl[k] (Cout x H) = dlin[k]^T h[k]
+  q.M = Cout; q.N = H; q.A = f.bDlin; q.lda = Cout; q.strideA = (long)F * Cout; q.B = f.sH; q.ldb = H; q.strideB = (long)F * H;
+  q.C = g->w_fl; q.ldc = H; q.strideC = (long)Cout * H;
+  if ((rc = lfi_gemm_f32(&q, stream))) return rc;
+  // w_hh[k] (G x H) = dgh[k][n >= 1]^T h[k][n - 1]
+  if (f.N > 1) {
+    q.K = F - B; q.M = G; q.N = H; q.A = f.bDgh + (long)B * G; q.lda = G; q.strideA = (long)F * G; q.B = f.sH; q.ldb = H;
+    q.strideB = (long)F * H; q.C = g->w_hh; q.ldc = H; q.strideC = (long)G * H;
+    if ((rc = lfi_gemm_f32(&q, stream))) return rc;
+  } else if (!accumulate) {
+    (void)hipMemsetAsync(g->w_hh, 0, sizeof(float) * (size_t)Ks * G * H, st);
+  }
+  q.K = F;
+  // w_ih[k][:, :Ch] (G x Ch) = dgi[k]^T z1[k]
+  if (Ch > 0) {
+    q.M = G; q.N = Ch; q.A = f.bDgi; q.lda = G; q.strideA = (long)F * G; q.B = f.sY; q.ldb = C; q.strideB = (long)F * C;
+    q.C = g->w_ih; q.ldc = I; q.strideC = (long)G * I;
+    if ((rc = lfi_gemm_f32(&q, stream))) return rc;
+  }
+  // w_ih[k][:, Ch:] (G x D) = dgi[k]^T c[:, kD:(k+1)D]
+  q.M = G; q.N = D; q.A = f.bDgi; q.lda = G; q.strideA = (long)F * G; q.B = c; q.ldb = ldc; q.strideB = D;
+  q.C = g->w_ih + Ch; q.ldc = I; q.strideC = (long)G * I;
+  if ((rc = lfi_gemm_f32(&q, stream))) return rc;
+  // dW[k] (C x C) = a[k]^T dy[k]  -> LU parameter gradients
+  q.accumulate = 0;
+  q.M = C; q.N = C; q.A = f.sA; q.lda = C; q.strideA = (long)F * C; q.B = f.bDy; q.ldb = C; q.strideB = (long)F * C;
+  q.C = dW; q.ldc = C; q.strideC = (long)C * C;
+  if ((rc = lfi_gemm_f32(&q, stream))) return rc;
+  // constant log-det terms: nll has -(C sum(logs))/ln2 per frame -> d/dlogs = -C/ln2 * gscale * F
+  const float cconst = -(float)((double)gscale * (double)F * (double)C / 0.6931471805599453);
+  {
+    const size_t lds = (size_t)3 * C * C * sizeof(float);
+    rc = set_flow_lds(flow_invconv_bwd_kernel, lds, "lfi_flow_param_grads");
+    if (rc) return rc;
+    hipLaunchKernelGGL(flow_invconv_bwd_kernel, dim3(Ks), dim3(256), lds, st, f, dW, *g, cconst, accumulate);
+    LFI_LAUNCH_CHECK("lfi_flow_param_grads invconv");
+  }
+  // biases and the per-tile partial sums
+  if ((rc = lfi_colsum_f32(f.bDlin, Cout, (long)F * Cout, F, Cout, Ks, g->b_fl, Cout, 1.0f, accumulate, cws, stream))) return rc;
+  if ((rc = lfi_colsum_f32(f.bDgh, G, (long)F * G, F, G, Ks, g->b_hh, G, 1.0f, accumulate, cws, stream))) return rc;
+  if ((rc = lfi_colsum_f32(f.bDgi, G, (long)F * G, F, G, Ks, g->b_ih, G, 1.0f, accumulate, cws, stream))) return rc;
+  const int prow = f.N * f.nbt;
+  if ((rc = lfi_colsum_f32(f.bPlfl, Cout, (long)prow * Cout, prow, Cout, Ks, g->l_fl, Cout, 1.0f, accumulate, cws, stream))) return rc;
+  if ((rc = lfi_colsum_f32(f.bPan, 2 * C, (long)prow * 2 * C, prow, C, Ks, g->an_logs, C, 1.0f, accumulate, cws, stream))) return rc;
+  if ((rc = lfi_colsum_f32(f.bPan + C, 2 * C, (long)prow * 2 * C, prow, C, Ks, g->an_bias, C, 1.0f, accumulate, cws, stream))) return rc;
+  hipLaunchKernelGGL(add_const_kernel, dim3(lfi_cdiv((long)Ks * C, 256)), dim3(256), 0, st, g->an_logs, (long)Ks * C, cconst);
+  LFI_LAUNCH_CHECK("lfi_flow_param_grads const");
+  return LFI_OK;
+}
+
+extern "C" int lfi_actnorm_init_stats(const float* x, int rows, int C, double* sums, void* stream) {
+  LFI_REQUIRE(x && sums && rows > 0 && C > 0, "lfi_actnorm_init_stats: bad arguments");
+  hipLaunchKernelGGL(actnorm_stats_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, x, rows, C, sums);
+  LFI_LAUNCH_CHECK("lfi_actnorm_init_stats");
+  return LFI_OK;
+}
+extern "C" int lfi_actnorm_init_apply(const double* sums, double count, int C, float scale, float* bias, float* logs,
+                                      void* stream) {
+  LFI_REQUIRE(sums && bias && logs && count > 0 && C > 0, "lfi_actnorm_init_apply: bad arguments");
+  hipLaunchKernelGGL(actnorm_apply_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, sums, count, C, scale, bias, logs);
+  LFI_LAUNCH_CHECK("lfi_actnorm_init_apply");
+  return LFI_OK;
+}
+
+extern "C" int lfi_flow_step(const lfi_flow_dims* d, const lfi_flow_params* p, const float* prep, int k, int rows,
+                             const float* x_in, long ldx, const float* h_prev, const float* gic_k, float* x_out, long ldxo,
+                             float* h_out, float* ldc_acc, int reverse, void* stream) {
+  FlowK f = {};
+  int rc = fill_flow(d, p, prep, &f, "lfi_flow_step");
+  if (rc) return rc;
+  LFI_REQUIRE(prep && x_in && gic_k && x_out && h_out, "lfi_flow_step: null pointer");
+  LFI_REQUIRE(k >= 0 && k < d->Ks && rows > 0, "lfi_flow_step: bad k/rows");
+  CellIO io = {};
+  io.k = k; io.rows = rows; io.x_in = x_in; io.ldx = ldx; io.h_prev = h_prev; io.gic = gic_k;
+  io.x_out = x_out; io.ldxo = ldxo; io.h_out = h_out; io.l_out = ldc_acc; io.l_accumulate = 1;
+  const Carve cv = carve_fwd(f.C, f.H, f.Ch, f.C2, f.Cout);
+  const size_t lds = (size_t)cv.total * sizeof(float);
+  rc = set_flow_lds(flow_step_kernel, lds, "lfi_flow_step");
+  if (rc) return rc;
+  hipLaunchKernelGGL(flow_step_kernel, dim3(lfi_cdiv(rows, MB)), dim3(256), lds, (hipStream_t)stream, f, io, reverse);
+  LFI_LAUNCH_CHECK("lfi_flow_step");
+  return LFI_OK;
+}
+
+// SeqGlow.inference (glow/models.py:567-596): everything that does not depend on generated frames was hoisted by the
+// caller into pre_static; per frame two small GEMMs (window part of cond_transform, then W_ih[:, Ch:] c) and Ks
+// reverse cells. The growing torch.cat history of the reference (:591, O(T^2) copies) is a preallocated buffer here.
+extern "C" long lfi_flow_sample_work_floats(const lfi_flow_dims* d) {
+  if (!d) return 0;
+  const int G = (d->lstm ? 4 : 3) * d->H;
+  return (long)d->B * d->Ks * d->D + (long)d->Ks * d->B * G + 2L * d->B * d->C + 16;
+}
+
+extern "C" int lfi_flow_sample_seq(const lfi_flow_dims* d, const lfi_flow_params* p, const float* prep, const float* wct,
+                                   long E, int hist1, const float* pre_static, const float* noise, float* faces, int seq_len,
+                                   int start, int nframes, float* h, float* work, void* stream) {
+  FlowK f = {};
+  int rc = fill_flow(d, p, prep, &f, "lfi_flow_sample_seq");
+  if (rc) return rc;
+  LFI_REQUIRE(prep && wct && pre_static && noise && faces && h && work, "lfi_flow_sample_seq: null pointer");
+  LFI_REQUIRE(hist1 >= 0 && hist1 <= start && start + nframes <= seq_len, "lfi_flow_sample_seq: bad frame range");
+  LFI_REQUIRE((long)hist1 * d->C <= E, "lfi_flow_sample_seq: window wider than the feature vector");
+  const int B = f.B, C = f.C, H = f.H, D = f.D, Ks = f.Ks, G = f.G, I = f.I, Ch = f.Ch;
+  float* cbuf = work;                          // B x Ks*D
+  float* gic = cbuf + (long)B * Ks * D;        // [Ks][B][G]
+  float* xa = gic + (long)Ks * B * G;          // B x C ping
+  float* xb = xa + (long)B * C;                // B x C pong
+  hipStream_t st = (hipStream_t)stream;
+  const Carve cv = carve_fwd(f.C, f.H, f.Ch, f.C2, f.Cout);
+  const size_t lds = (size_t)cv.total * sizeof(float);
+  rc = set_flow_lds(flow_step_kernel, lds, "lfi_flow_sample_seq");
+  if (rc) return rc;
+  for (int n = 0; n < nframes; ++n) {
+    const int t = start + n;
+    // c = LeakyReLU(pre_static[n] + window @ Wct[:, :hist1*C]^T)
+    hipError_t e = hipMemcpyAsync(cbuf, pre_static + (long)n * B * Ks * D, sizeof(float) * (size_t)B * Ks * D,
+                                  hipMemcpyDeviceToDevice, st);
+    if (e != hipSuccess) {
+      lfi_set_error("lfi_flow_sample_seq: memcpy failed: %s", hipGetErrorString(e));
+      return LFI_ERR_LAUNCH;
+    }
+    lfi_gemm_desc q = {};
+    q.batch = 1; q.M = B; q.N = Ks * D; q.K = hist1 * C;
+    q.A = faces + (long)(t - hist1) * C; q.lda = (long)seq_len * C; q.a_kcontig = 1;
+    q.B = wct; q.ldb = E; q.b_kcontig = 1;
+    q.C = cbuf; q.ldc = (long)Ks * D; q.accumulate = 2; q.act = 1; q.slope = 0.01f;
+    if ((rc = lfi_gemm_f32(&q, stream))) return rc;
+    // gic[k] = c[:, kD:(k+1)D] @ W_ih[k][:, Ch:]^T + b_ih[k]
+    lfi_gemm_desc r = {};
+    r.batch = Ks; r.M = B; r.N = G; r.K = D;
+    r.A = cbuf; r.lda = (long)Ks * D; r.a_kcontig = 1; r.strideA = D;
+    r.B = p->w_ih + Ch; r.ldb = I; r.b_kcontig = 1; r.strideB = (long)G * I;
+    r.C = gic; r.ldc = G; r.strideC = (long)B * G;
+    r.bias = p->b_ih; r.strideBias = G;
+    if ((rc = lfi_gemm_f32(&r, stream))) return rc;
+    // reverse flow: z -> x through steps Ks-1 .. 0
+    const float* xin = noise + (long)n * B * C;
+    long ldx = C;
+    for (int k = Ks - 1; k >= 0; --k) {
+      CellIO io = {};
+      io.k = k; io.rows = B; io.x_in = xin; io.ldx = ldx;
+      io.h_prev = n > 0 ? h + (long)k * B * H : nullptr;
+      io.gic = gic + (long)k * B * G;
+      io.h_out = h + (long)k * B * H;
+      if (k == 0) { io.x_out = faces + (long)t * C; io.ldxo = (long)seq_len * C; }
+      else { io.x_out = (k & 1) ? xa : xb; io.ldxo = C; }
+      hipLaunchKernelGGL(flow_step_kernel, dim3(f.nbt), dim3(256), lds, st, f, io, 1);
+      xin = io.x_out; ldx = io.ldxo;
+    }
+  }
+  LFI_LAUNCH_CHECK("lfi_flow_sample_seq");
+  return LFI_OK;
+}

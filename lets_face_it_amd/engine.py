@@ -1,0 +1,533 @@
+"""Host-side orchestration of the HIP kernels for one SeqGlow instance.
+
+PyTorch is plumbing here: device memory (torch.empty), the current HIP stream and
+torch.distributed. All arithmetic of the hot path happens in liblfi_hip.so; this
+module only sequences the C-ABI calls of include/lfi.h:
+
+  forward   encoders (input-projection GEMM + per-step GEMM/gate kernels) -> feature matrix `cond`
+            -> c = LeakyReLU(cond Wct^T + b) for all flow steps in ONE GEMM -> gic = c W_ih[:, Ch:]^T + b_ih
+            (batched GEMM) -> anti-diagonal walk of the (timestep, flow step) grid -> per-frame NLL
+  backward  reverse walk -> deferred weight-gradient GEMMs -> cond_transform / encoder BPTT -> flat gradient buffer
+  step      global-norm clip + Adam on the flat parameter buffer (one kernel each)
+
+What the reference does instead: SeqGlow.forward's Python loop over timesteps and flow steps
+(/root/reference/code/glow_pytorch/glow/models.py:534-561), ~5.4k ATen calls per timestep.
+"""
+import ctypes as C
+import math
+
+import torch
+
+from . import _lib
+from ._lib import EncDesc, FlowDims, FlowGrads, FlowParams, GemmDesc, check, ptr
+
+ENC_ORDER = ("p1_face", "p2_face", "p1_speech", "p2_speech")  # FeatureEncoder concat order (models.py:127-143)
+FLOW_FIELDS = ("an_bias", "an_logs", "inv_l", "inv_u", "inv_logs", "inv_w", "w_ih", "w_hh", "b_ih", "b_hh",
+               "wct", "bct", "w_fl", "b_fl", "l_fl")
+ENC_LEAVES = ("weight_ih", "weight_hh", "bias_ih", "bias_hh")
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+class EncoderSpec:
+    """One modality of the FeatureEncoder (models.py:83-125)."""
+
+    def __init__(self, name, enc, in_dim, hist, hid, dropout):
+        self.name, self.enc, self.in_dim, self.hist, self.hid, self.dropout = name, enc, in_dim, hist, hid, dropout
+        if enc == "rnn":
+            self.dim = 2 * hid
+        elif enc == "none":
+            self.dim = in_dim * hist
+        else:
+            raise NotImplementedError(
+                "encoder type %r for %s: only 'rnn' (GRU) and 'none' have HIP kernels in this build" % (enc, name))
+        self.col = 0
+
+
+class ModelSpec:
+    """Static shape description derived from the hparams namespace."""
+
+    def __init__(self, hparams):
+        cond, glow, data = hparams.Conditioning, hparams.Glow, hparams.Data
+        self.C = int(cond["p1_face"]["dim"])
+        self.S = int(data["speech_dim"])
+        self.D = int(cond["cond_dim"])
+        self.H = int(glow["hidden_channels"])
+        self.Ks = int(glow["K"]) * int(glow["L"])
+        self.affine = 1 if glow["flow_coupling"] == "affine" else 0
+        self.rnn_type = glow.get("rnn_type") or "gru"
+        self.lu = bool(glow["LU_decomposed"])
+        self.scale_eps = float(glow["scale_eps"])
+        self.actnorm_scale = float(glow["actnorm_scale"])
+        if glow["flow_permutation"] != "invconv":
+            raise NotImplementedError("flow_permutation %r: only 'invconv' works in the reference too "
+                                      "(Permute2d is broken, modules.py:98-118)" % glow["flow_permutation"])
+        if cond.get("use_frame_nb"):
+            raise NotImplementedError("use_frame_nb is off in every shipped hparams file; not implemented")
+        self.start = max(cond[m]["history"] for m in ENC_ORDER)
+        self.encoders = []
+        col = 0
+        for m in ENC_ORDER:
+            cfg = cond[m]
+            hist = int(cfg["history"])
+            if m != "p1_face" and not hist:
+                continue
+            in_dim = int(cfg["dim"]) if m.endswith("face") else self.S
+            e = EncoderSpec(m, cfg["enc"], in_dim, hist, int(cfg["hidden_dim"] or 0), float(cfg["dropout"] or 0))
+            e.col = col
+            col += e.dim
+            self.encoders.append(e)
+        self.E = col
+        self.Ch = self.C // 2
+        self.C2 = self.C - self.Ch
+        self.Cout = 2 * self.C2 if self.affine else self.C2
+        self.G = (4 if self.rnn_type == "lstm" else 3) * self.H
+        self.I = self.Ch + self.D
+        p1 = self.encoders[0]
+        self.p1_cols = p1.dim  # width of the autoregressive (prev_p1_face) block, first in the feature vector
+
+    def flow_shapes(self):
+        Ks, C, H, D, E, G, I, Cout = self.Ks, self.C, self.H, self.D, self.E, self.G, self.I, self.Cout
+        shapes = {
+            "an_bias": (Ks, C), "an_logs": (Ks, C),
+            "w_ih": (Ks, G, I), "w_hh": (Ks, G, H), "b_ih": (Ks, G), "b_hh": (Ks, G),
+            "wct": (Ks, D, E), "bct": (Ks, D),
+            "w_fl": (Ks, Cout, H), "b_fl": (Ks, Cout), "l_fl": (Ks, Cout),
+        }
+        if self.lu:
+            shapes.update({"inv_l": (Ks, C, C), "inv_u": (Ks, C, C), "inv_logs": (Ks, C)})
+        else:
+            shapes["inv_w"] = (Ks, C, C)
+        return shapes
+
+
+class _Ctx:
+    pass
+
+
+class GlowEngine:
+    """Owns the flat parameter / gradient / optimiser buffers and the workspaces of one model on one GPU."""
+
+    def __init__(self, spec, device):
+        self.spec = spec
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise _lib.LfiError("GlowEngine needs a GPU device (got %s); there is no CPU path" % device)
+        self.L = _lib.lib()
+        self.layout = {}  # name -> (offset, shape)
+        off = 0
+        for e in spec.encoders:
+            if e.enc == "rnn":
+                for leaf, shape in zip(ENC_LEAVES, ((3 * e.hid, e.in_dim), (3 * e.hid, e.hid), (3 * e.hid,), (3 * e.hid,))):
+                    self.layout["enc.%s.%s" % (e.name, leaf)] = (off, shape)
+                    off += math.prod(shape)
+        shapes = spec.flow_shapes()
+        for name in FLOW_FIELDS:
+            if name in shapes:
+                self.layout["flow." + name] = (off, shapes[name])
+                off += math.prod(shapes[name])
+        self.n_params = off
+        f32 = dict(dtype=torch.float32, device=self.device)
+        self.params = torch.zeros(off, **f32)
+        self.grads = torch.zeros(off, **f32)
+        self.adam_m = None
+        self.adam_v = None
+        self.step_count = 0
+        self.inv_p = torch.zeros(spec.Ks, spec.C, spec.C, **f32)
+        self.inv_sign = torch.zeros(spec.Ks, spec.C, **f32)
+        self.sumsq = torch.zeros(1, dtype=torch.float64, device=self.device)
+        self.sumsq_work = torch.zeros(1024, dtype=torch.float64, device=self.device)
+        self._ws = {}
+        self.prep = None
+        self._last = None
+        self.timers = None  # {tag: [(start_event, end_event), ...]} when kernel timing is switched on (bench.py)
+
+    # ------------------------------------------------------------------ per-kernel timing (HIP events on the launch stream)
+    def enable_timing(self, on=True):
+        self.timers = {} if on else None
+
+    def _tic(self, tag):
+        if self.timers is None or tag is None:
+            return None
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev[0].record()
+        return ev
+
+    def _toc(self, tag, ev):
+        if ev is not None:
+            ev[1].record()
+            self.timers.setdefault(tag, []).append(ev)
+
+    def timing_summary(self):
+        """{tag: (launches, mean milliseconds)}; synchronises."""
+        torch.cuda.synchronize()
+        return {t: (len(evs), sum(a.elapsed_time(b) for a, b in evs) / len(evs)) for t, evs in (self.timers or {}).items()}
+
+    # ------------------------------------------------------------------ views
+    def view(self, name, buf=None):
+        off, shape = self.layout[name]
+        buf = self.params if buf is None else buf
+        return buf[off:off + math.prod(shape)].view(shape)
+
+    def fview(self, name, buf=None):
+        return self.view("flow." + name, buf)
+
+    def _flow_dims(self, B, N):
+        s = self.spec
+        return FlowDims(B, N, s.C, s.H, s.D, s.Ks, s.affine, 1 if s.rnn_type == "lstm" else 0, s.scale_eps)
+
+    def _flow_params(self):
+        s = self.spec
+        p = FlowParams()
+        for name in ("an_bias", "an_logs", "w_ih", "w_hh", "b_ih", "b_hh", "w_fl", "b_fl", "l_fl"):
+            setattr(p, name, self.fview(name).data_ptr())
+        if s.lu:
+            p.inv_l, p.inv_u, p.inv_logs = (self.fview(n).data_ptr() for n in ("inv_l", "inv_u", "inv_logs"))
+            p.inv_p, p.inv_sign = self.inv_p.data_ptr(), self.inv_sign.data_ptr()
+        else:
+            p.inv_w = self.fview("inv_w").data_ptr()
+        return p
+
+    def _flow_grads(self):
+        s = self.spec
+        g = FlowGrads()
+        for name in ("an_bias", "an_logs", "w_ih", "w_hh", "b_ih", "b_hh", "w_fl", "b_fl", "l_fl"):
+            setattr(g, name, self.fview(name, self.grads).data_ptr())
+        if s.lu:
+            g.inv_l, g.inv_u, g.inv_logs = (self.fview(n, self.grads).data_ptr() for n in ("inv_l", "inv_u", "inv_logs"))
+        else:
+            g.inv_w = self.fview("inv_w", self.grads).data_ptr()
+        return g
+
+    # ------------------------------------------------------------------ buffers
+    def _buf(self, name, floats, zero=False):
+        t = self._ws.get(name)
+        if t is None or t.numel() < floats:
+            t = (torch.zeros if zero else torch.empty)(max(int(floats), 1), dtype=torch.float32, device=self.device)
+            self._ws[name] = t
+        elif zero:
+            t.zero_()
+        return t
+
+    # ------------------------------------------------------------------ low-level wrappers
+    def gemm(self, M, N, K, A, lda, akc, Bm, ldb, bkc, Cm, ldc, bias=None, act=0, slope=0.01, G=None, ldg=0,
+             batch=1, sA=0, sB=0, sC=0, sBias=0, sG=0, accumulate=0, splitk=1, a_off=0, b_off=0, c_off=0, bias_off=0,
+             tag=None):
+        """Offsets are in floats relative to the tensors' data pointers."""
+        g = GemmDesc()
+        g.M, g.N, g.K = M, N, K
+        g.A, g.lda, g.a_kcontig = A.data_ptr() + 4 * a_off, lda, akc
+        g.B, g.ldb, g.b_kcontig = Bm.data_ptr() + 4 * b_off, ldb, bkc
+        g.C, g.ldc = Cm.data_ptr() + 4 * c_off, ldc
+        g.bias = None if bias is None else bias.data_ptr() + 4 * bias_off
+        g.G, g.ldg = ptr(G), ldg
+        g.batch, g.strideA, g.strideB, g.strideC, g.strideBias, g.strideG = batch, sA, sB, sC, sBias, sG
+        g.accumulate, g.act, g.slope = accumulate, act, slope
+        g.splitk = splitk
+        if splitk > 1:
+            g.work = self._buf("scratch.gemm_splitk", batch * splitk * M * N).data_ptr()
+        ev = self._tic(tag)
+        check(self.L.lfi_gemm_f32(C.byref(g), _stream()), "lfi_gemm_f32")
+        self._toc(tag, ev)
+
+    def colsum(self, X, ldx, strideX, rows, cols, batch, out, strideOut, scale=1.0, accumulate=0, x_off=0):
+        w = self._buf("scratch.colsum", self.L.lfi_colsum_work_floats(rows, cols, batch))
+        check(self.L.lfi_colsum_f32(X.data_ptr() + 4 * x_off, ldx, strideX, rows, cols, batch, out.data_ptr(), strideOut,
+                                    scale, accumulate, w.data_ptr(), _stream()), "lfi_colsum_f32")
+
+    def run_prep(self, with_inverse=False):
+        """W = P L U (+ transposes, optional fp64 inverse) once per parameter state, not per call (modules.py:147-178)."""
+        d = self._flow_dims(1, 1)
+        need = self.L.lfi_flow_prep_floats(C.byref(d))
+        if self.prep is None or self.prep.numel() < need:
+            self.prep = torch.zeros(need, dtype=torch.float32, device=self.device)
+        p = self._flow_params()
+        check(self.L.lfi_flow_prep(C.byref(d), C.byref(p), self.prep.data_ptr(), 1 if with_inverse else 0, _stream()),
+              "lfi_flow_prep")
+
+    # ------------------------------------------------------------------ conditioning
+    def _check_input(self, x, name, B, Tmin, dim):
+        if not (x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and x.dim() == 3 and x.shape[0] == B
+                and x.shape[1] >= Tmin and x.shape[2] == dim):
+            raise ValueError("%s: expected contiguous float32 GPU tensor (B=%d, T>=%d, %d), got %s %s on %s"
+                             % (name, B, Tmin, dim, tuple(x.shape), x.dtype, x.device))
+
+    def build_features(self, data, faces, B, T, masks, cond, with_stash, skip_p1=False):
+        """FeatureEncoder.forward for every timestep at once (models.py:127-145): fills cond (F x E)."""
+        s = self.spec
+        N = T - s.start
+        F = N * B
+        st = _stream()
+        for e in s.encoders:
+            if e.name == "p1_face":
+                if e.enc != "none":
+                    raise NotImplementedError("p1_face encoder %r: the autoregressive input is only supported as "
+                                              "'none' (all shipped hparams)" % e.enc)
+                if skip_p1:
+                    continue
+                self._check_input(faces, "p1_face", B, T, s.C)
+                check(self.L.lfi_gather_windows(faces.data_ptr(), B, faces.shape[1], s.C, N, s.start, e.hist, 0,
+                                                cond.data_ptr(), s.E, e.col, st), "lfi_gather_windows")
+                continue
+            x = data.get(e.name)
+            if x is None:
+                raise KeyError("batch is missing modality %r" % e.name)
+            self._check_input(x, e.name, B, T, e.in_dim)
+            Tx = x.shape[1]
+            if e.enc == "none":
+                check(self.L.lfi_gather_windows(x.data_ptr(), B, Tx, e.in_dim, N, s.start, e.hist, 1,
+                                                cond.data_ptr(), s.E, e.col, st), "lfi_gather_windows")
+                continue
+            hid = e.hid
+            # input projection hoisted over the B*Tx distinct frames (no bias: it is added after the dropout mask)
+            xp = self._buf("xp." + e.name, B * Tx * 3 * hid)
+            self.gemm(B * Tx, 3 * hid, e.in_dim, x, e.in_dim, 1, self.view("enc.%s.weight_ih" % e.name), e.in_dim, 1,
+                      xp, 3 * hid)
+            gates = self._buf("enc_gates." + e.name, e.hist * F * 4 * hid) if with_stash else None
+            hseq = self._buf("enc_hseq." + e.name, e.hist * F * hid)
+            d = EncDesc(B, Tx, N, s.start, e.hist, hid, s.E, e.col)
+            work = self._buf("scratch.enc", self.L.lfi_encode_windows_work_floats(C.byref(d)))
+            mk = None if masks is None else masks.get(e.name)
+            if mk is not None and not (tuple(mk.shape) == (N, B, e.hist) and mk.is_contiguous()
+                                       and mk.dtype == torch.float32 and mk.is_cuda):
+                raise ValueError("mask for %s must be a contiguous float32 GPU tensor (N, B, hist)" % e.name)
+            check(self.L.lfi_encode_windows_fwd(
+                C.byref(d), xp.data_ptr(), self.view("enc.%s.weight_hh" % e.name).data_ptr(),
+                self.view("enc.%s.bias_ih" % e.name).data_ptr(), self.view("enc.%s.bias_hh" % e.name).data_ptr(),
+                ptr(mk), cond.data_ptr(), ptr(gates), hseq.data_ptr(), work.data_ptr(), st), "lfi_encode_windows_fwd")
+
+    def _project(self, cond, F):
+        """c = LeakyReLU(cond Wct^T + b) for all Ks steps (one GEMM), gic = c W_ih[:, Ch:]^T + b_ih (batched GEMM)."""
+        s = self.spec
+        KD = s.Ks * s.D
+        cbuf = self._buf("c", F * KD)
+        self.gemm(F, KD, s.E, cond, s.E, 1, self.fview("wct"), s.E, 1, cbuf, KD, bias=self.fview("bct"), act=1, slope=0.01,
+                  tag="gemm_cond_fwd")
+        gic = self._buf("gic", s.Ks * F * s.G)
+        self.gemm(F, s.G, s.D, cbuf, KD, 1, self.fview("w_ih"), s.I, 1, gic, s.G, bias=self.fview("b_ih"),
+                  batch=s.Ks, sA=s.D, sB=s.G * s.I, sC=F * s.G, sBias=s.G, b_off=s.Ch)
+        return cbuf, gic
+
+    # ------------------------------------------------------------------ forward / backward
+    def forward(self, batch, masks=None, with_stash=True, init_actnorm=None):
+        """Teacher-forced NLL of a batch dict of (B, T, dim) tensors. Returns z (N, B, C), nll (N, B)."""
+        s = self.spec
+        x = batch["p1_face"]
+        B, T = x.shape[0], x.shape[1]
+        N = T - s.start
+        if N <= 0:
+            raise ValueError("sequence length %d does not exceed the longest history %d" % (T, s.start))
+        F = N * B
+        self.run_prep()
+        cond = self._buf("cond", F * s.E)
+        self.build_features(batch, x, B, T, masks, cond, with_stash)
+        cbuf, gic = self._project(cond, F)
+        dims = self._flow_dims(B, N)
+        if init_actnorm is not None:
+            self._actnorm_init_walk(x, B, T, F, gic, dims, init_actnorm)
+        stash = self._buf("flow_stash", self.L.lfi_flow_stash_floats(C.byref(dims)))
+        z = torch.empty(N, B, s.C, dtype=torch.float32, device=self.device)
+        nll = torch.empty(N, B, dtype=torch.float32, device=self.device)
+        p = self._flow_params()
+        check(self.L.lfi_flow_seq_fwd(C.byref(dims), C.byref(p), self.prep.data_ptr(), x.data_ptr(), T, s.start,
+                                      gic.data_ptr(), stash.data_ptr(), z.data_ptr(), nll.data_ptr(), _stream()),
+              "lfi_flow_seq_fwd")
+        ctx = _Ctx()
+        ctx.batch, ctx.masks, ctx.B, ctx.T, ctx.N, ctx.F = batch, masks, B, T, N, F
+        ctx.cond, ctx.cbuf, ctx.gic, ctx.stash, ctx.dims, ctx.with_stash = cond, cbuf, gic, stash, dims, with_stash
+        self._last = ctx
+        return z, nll
+
+    def _actnorm_init_walk(self, x, B, T, F, gic, dims, allreduce):
+        """Data-dependent ActNorm init from the first timestep, layer by layer (modules.py:32-43,69-70).
+
+        allreduce: callable(sums fp64 tensor) -> number of ranks summed (1 when not distributed)."""
+        s = self.spec
+        st = _stream()
+        xa = self._buf("init_xa", B * s.C)
+        xb = self._buf("init_xb", B * s.C)
+        hd = self._buf("init_h", B * s.H)
+        xa[:B * s.C].view(B, s.C).copy_(x[:, s.start, :])
+        sums = torch.zeros(2 * s.C, dtype=torch.float64, device=self.device)
+        p = self._flow_params()
+        for k in range(s.Ks):
+            check(self.L.lfi_actnorm_init_stats(xa.data_ptr(), B, s.C, sums.data_ptr(), st), "lfi_actnorm_init_stats")
+            world = allreduce(sums)
+            check(self.L.lfi_actnorm_init_apply(sums.data_ptr(), float(B * world), s.C, s.actnorm_scale,
+                                                self.fview("an_bias")[k].data_ptr(), self.fview("an_logs")[k].data_ptr(),
+                                                st), "lfi_actnorm_init_apply")
+            check(self.L.lfi_flow_step(C.byref(dims), C.byref(p), self.prep.data_ptr(), k, B, xa.data_ptr(), s.C, None,
+                                       gic.data_ptr() + 4 * k * F * s.G, xb.data_ptr(), s.C, hd.data_ptr(), None, 0, st),
+                  "lfi_flow_step")
+            xa, xb = xb, xa
+        self.run_prep()  # the constant log-det term depends on the new actnorm logs
+
+    def backward(self, gscale):
+        """Gradients of gscale * sum(nll) w.r.t. every parameter, written into self.grads (overwritten)."""
+        ctx = self._last
+        if ctx is None or not ctx.with_stash:
+            raise _lib.LfiError("backward() needs a preceding forward(with_stash=True)")
+        s = self.spec
+        B, T, N, F = ctx.B, ctx.T, ctx.N, ctx.F
+        KD = s.Ks * s.D
+        st = _stream()
+        dims, p = ctx.dims, self._flow_params()
+        bst = self._buf("flow_bstash", self.L.lfi_flow_bstash_floats(C.byref(dims)))
+        check(self.L.lfi_flow_seq_bwd(C.byref(dims), C.byref(p), self.prep.data_ptr(), ctx.stash.data_ptr(), gscale,
+                                      bst.data_ptr(), st), "lfi_flow_seq_bwd")
+        work = self._buf("scratch.pg", self.L.lfi_flow_param_grads_work_floats(C.byref(dims)))
+        g = self._flow_grads()
+        check(self.L.lfi_flow_param_grads(C.byref(dims), C.byref(p), self.prep.data_ptr(), ctx.stash.data_ptr(),
+                                          bst.data_ptr(), ctx.cbuf.data_ptr(), KD, gscale, C.byref(g), 0, work.data_ptr(),
+                                          st), "lfi_flow_param_grads")
+        # d pre-activation of cond_transform, in place over c: dpre = (dgi[k] W_ih[k][:, Ch:]) * leaky'(c)
+        dgi_off = (self.L.lfi_flow_bstash_ptr(C.byref(dims), bst.data_ptr(), 1) - bst.data_ptr()) // 4
+        self.gemm(F, s.D, s.G, bst, s.G, 1, self.fview("w_ih"), s.I, 0, ctx.cbuf, KD, act=2, slope=0.01, G=ctx.cbuf, ldg=KD,
+                  batch=s.Ks, sA=F * s.G, sB=s.G * s.I, sC=s.D, sG=s.D, a_off=dgi_off, b_off=s.Ch)
+        dpre = ctx.cbuf
+        # cond_transform weight / bias gradients for all steps at once
+        self.gemm(KD, s.E, F, dpre, KD, 0, ctx.cond, s.E, 0, self.fview("wct", self.grads), s.E, tag="gemm_cond_wgrad")
+        self.colsum(dpre, KD, 0, F, KD, 1, self.fview("bct", self.grads), 0)
+        # gradient of the feature matrix, encoder columns only (prev_p1_face is data)
+        rnn = [e for e in s.encoders if e.enc == "rnn"]
+        if rnn:
+            col0 = min(e.col for e in rnn)
+            W = s.E - col0
+            dcond = self._buf("dcond", F * W)
+            self.gemm(F, W, KD, dpre, KD, 1, self.fview("wct"), s.E, 0, dcond, W, b_off=col0, tag="gemm_cond_dgrad")
+            for e in rnn:
+                self._encoder_backward(e, ctx, dcond, W, e.col - col0)
+
+    def _encoder_backward(self, e, ctx, dcond, lddcond, col):
+        s = self.spec
+        B, N, F = ctx.B, ctx.N, ctx.F
+        x = ctx.batch[e.name]
+        Tx, hid, G3 = x.shape[1], e.hid, 3 * e.hid
+        st = _stream()
+        d = EncDesc(B, Tx, N, s.start, e.hist, hid, lddcond, col)
+        gates = self._ws["enc_gates." + e.name]
+        hseq = self._ws["enc_hseq." + e.name]
+        dgi = self._buf("enc_dgi." + e.name, e.hist * F * G3)
+        dgh = self._buf("enc_dgh." + e.name, e.hist * F * G3)
+        work = self._buf("scratch.enc", self.L.lfi_encode_windows_work_floats(C.byref(d)))
+        whh = self.view("enc.%s.weight_hh" % e.name)
+        check(self.L.lfi_encode_windows_bwd(C.byref(d), dcond.data_ptr(), lddcond, whh.data_ptr(), gates.data_ptr(),
+                                            hseq.data_ptr(), dgi.data_ptr(), dgh.data_ptr(), work.data_ptr(), st),
+              "lfi_encode_windows_bwd")
+        mk = None if ctx.masks is None else ctx.masks.get(e.name)
+        dxp = self._buf("dxp." + e.name, B * Tx * G3)
+        check(self.L.lfi_encode_windows_scatter(C.byref(d), dgi.data_ptr(), ptr(mk), dxp.data_ptr(), st),
+              "lfi_encode_windows_scatter")
+        gname = "enc.%s." % e.name
+        rows = B * Tx
+        self.gemm(G3, e.in_dim, rows, dxp, G3, 0, x, e.in_dim, 0, self.view(gname + "weight_ih", self.grads), e.in_dim,
+                  splitk=max(1, min(32, rows // 1024)))
+        self.colsum(dgi, G3, 0, e.hist * F, G3, 1, self.view(gname + "bias_ih", self.grads), 0)
+        if e.hist > 1:
+            kk = (e.hist - 1) * F
+            self.gemm(G3, hid, kk, dgh, G3, 0, hseq, hid, 0, self.view(gname + "weight_hh", self.grads), hid,
+                      splitk=max(1, min(64, kk // 2048)), a_off=F * G3)
+        else:
+            self.view(gname + "weight_hh", self.grads).zero_()
+        self.colsum(dgh, G3, 0, e.hist * F, G3, 1, self.view(gname + "bias_hh", self.grads), 0)
+
+    # ------------------------------------------------------------------ optimiser
+    def optimizer_step(self, lr, beta1, beta2, eps, clip=0.0, gmul=1.0):
+        """clip_grad_norm_(clip) + Adam on the flat buffers (lets_face_it_glow.py:61-72; final_model.yaml:126)."""
+        if self.adam_m is None:
+            self.adam_m = torch.zeros_like(self.params)
+            self.adam_v = torch.zeros_like(self.params)
+        self.step_count += 1
+        st = _stream()
+        if clip and clip > 0:
+            check(self.L.lfi_grad_sumsq(self.grads.data_ptr(), self.n_params, self.sumsq.data_ptr(),
+                                        self.sumsq_work.data_ptr(), st), "lfi_grad_sumsq")
+        check(self.L.lfi_adam_clip_step(self.params.data_ptr(), self.grads.data_ptr(), self.adam_m.data_ptr(),
+                                        self.adam_v.data_ptr(), self.n_params, self.sumsq.data_ptr(),
+                                        float(clip or 0.0), gmul, lr, beta1, beta2, eps, self.step_count, st),
+              "lfi_adam_clip_step")
+
+    def grad_norm(self):
+        check(self.L.lfi_grad_sumsq(self.grads.data_ptr(), self.n_params, self.sumsq.data_ptr(),
+                                    self.sumsq_work.data_ptr(), _stream()), "lfi_grad_sumsq")
+        return float(self.sumsq.sqrt().item())
+
+    # ------------------------------------------------------------------ sampling / inversion
+    def sample(self, seq_len, data, noise, masks=None):
+        """SeqGlow.inference (models.py:567-596) with the prior noise given: (seq_len - start, B, C), already * eps."""
+        s = self.spec
+        seed = data["p1_face"]
+        B = seed.shape[0]
+        nframes = seq_len - s.start
+        if nframes <= 0:
+            raise ValueError("seq_len %d does not exceed the longest history %d" % (seq_len, s.start))
+        self._check_input(seed, "p1_face", B, s.start, s.C)
+        if tuple(noise.shape) != (nframes, B, s.C) or not noise.is_contiguous() or noise.dtype != torch.float32:
+            raise ValueError("noise must be a contiguous float32 (%d, %d, %d) tensor" % (nframes, B, s.C))
+        F = nframes * B
+        KD = s.Ks * s.D
+        faces = torch.zeros(B, seq_len, s.C, dtype=torch.float32, device=self.device)
+        faces[:, :s.start].copy_(seed[:, :s.start])
+        self.run_prep(with_inverse=True)
+        # everything of the features that does not depend on generated frames, through cond_transform (no activation yet)
+        cond = self._buf("cond", F * s.E)
+        self.build_features(data, None, B, seq_len, masks, cond, with_stash=False, skip_p1=True)
+        c1 = s.p1_cols
+        pre = self._buf("pre_static", F * KD)
+        if s.E > c1:
+            self.gemm(F, KD, s.E - c1, cond, s.E, 1, self.fview("wct"), s.E, 1, pre, KD, bias=self.fview("bct"),
+                      a_off=c1, b_off=c1)
+        else:
+            pre[:F * KD].view(F, KD).copy_(self.fview("bct").reshape(1, KD).expand(F, KD))
+        dims = self._flow_dims(B, nframes)
+        h = self._buf("sample_h", s.Ks * B * s.H, zero=True)
+        work = self._buf("scratch.sample", self.L.lfi_flow_sample_work_floats(C.byref(dims)))
+        p = self._flow_params()
+        hist1 = s.encoders[0].hist
+        check(self.L.lfi_flow_sample_seq(C.byref(dims), C.byref(p), self.prep.data_ptr(), self.fview("wct").data_ptr(),
+                                         s.E, hist1, pre.data_ptr(), noise.data_ptr(), faces.data_ptr(), seq_len, s.start,
+                                         nframes, h.data_ptr(), work.data_ptr(), _stream()), "lfi_flow_sample_seq")
+        return faces[:, s.start:]
+
+    def invert(self, z_seq, batch, masks=None):
+        """SeqGlow.invert (models.py:617-645): teacher-forced reverse pass. z_seq (N, B, C) -> x (N, B, C), logdet (N, B)."""
+        s = self.spec
+        x = batch["p1_face"]
+        B, T = x.shape[0], x.shape[1]
+        N = z_seq.shape[0]
+        F = N * B
+        Tn = s.start + N
+        self.run_prep(with_inverse=True)
+        cond = self._buf("cond", F * s.E)
+        self.build_features(batch, x, B, Tn, masks, cond, with_stash=False)
+        _, gic = self._project(cond, F)
+        dims = self._flow_dims(B, N)
+        p = self._flow_params()
+        st = _stream()
+        out = torch.empty(N, B, s.C, dtype=torch.float32, device=self.device)
+        ld = torch.zeros(N, B, dtype=torch.float32, device=self.device)
+        h = self._buf("sample_h", s.Ks * B * s.H, zero=True)
+        xa = self._buf("init_xa", B * s.C)
+        xb = self._buf("init_xb", B * s.C)
+        z_seq = z_seq.contiguous()
+        for n in range(N):
+            src, ldx = z_seq.data_ptr() + 4 * n * B * s.C, s.C
+            for k in range(s.Ks - 1, -1, -1):
+                dst = out.data_ptr() + 4 * n * B * s.C if k == 0 else (xa if (k & 1) else xb).data_ptr()
+                hk = h.data_ptr() + 4 * k * B * s.H
+                check(self.L.lfi_flow_step(C.byref(dims), C.byref(p), self.prep.data_ptr(), k, B, src, ldx,
+                                           hk if n > 0 else None, gic.data_ptr() + 4 * (k * F + n * B) * s.G, dst, s.C, hk,
+                                           ld.data_ptr() + 4 * n * B, 1, st), "lfi_flow_step")
+                src = dst
+        ldconst = self.prep[self._ldconst_offset()]
+        return out, ld - ldconst
+
+    def _ldconst_offset(self):
+        s = self.spec
+        cc = s.Ks * s.C * s.C
+        return 3 * cc + s.Ks * s.Ch * s.G + s.Ks * s.H * s.G + s.Ks * s.H * s.Cout
+
+    def logdet_const(self):
+        return self.prep[self._ldconst_offset()]

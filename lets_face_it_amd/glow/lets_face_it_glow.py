@@ -1,0 +1,129 @@
+"""LetsFaceItGlow: the training wrapper of glow_pytorch/glow/lets_face_it_glow.py without PyTorch-Lightning.
+
+Same constructor, `seq_glow` attribute, `last_missmatched_nll` buffer, training_step / validation_step /
+configure_optimizers semantics (lets_face_it_glow.py:18-72). `training_step` returns a loss whose .backward() runs the
+HIP backward kernels (drop-in for an external optimiser loop); `fused_training_step` is the native path the bundled
+Trainer uses: forward + backward + gradient all-reduce + clip + Adam with no autograd graph and no per-parameter
+kernels.
+"""
+import random
+
+import numpy as np
+import torch
+import torch.nn as nn
+from torch.optim import SGD, Adam, RMSprop
+
+from .models import SeqGlow
+from .utils import derange_batch, get_mismatched_modalities, get_scheduler, test_params
+
+
+class LetsFaceItGlow(nn.Module):
+    def __init__(self, hparams, dataset_root=None, test=None):
+        super().__init__()
+        test_params(hparams)
+        if dataset_root is not None:
+            hparams.dataset_root = dataset_root
+        if test is not None:
+            hparams.Test = test
+        self.hparams = hparams
+        self.register_buffer("last_missmatched_nll", torch.tensor(np.inf))
+        self.seq_glow = SeqGlow(self.hparams)
+        self.missmatched_modalities, self.missmatched_nll_name = None, None
+        if self.hparams.Train["use_negative_nll_loss"]:
+            self.missmatched_modalities, self.missmatched_nll_name = get_mismatched_modalities(self.hparams)
+        self.logged = {}
+        self.global_step = 0
+        self.nll_sync_hook = None  # data-parallel trainer: averages the mismatched NLL over ranks
+
+    # Lightning's self.log, reduced to a dict of the latest values
+    def log(self, name, value, **kwargs):
+        self.logged[name] = value.detach() if torch.is_tensor(value) else value
+
+    def _negative_branch(self):
+        """lets_face_it_glow.py:40-45: only while the last mismatched NLL is > 0, with probability 0.1 (Python RNG)."""
+        return bool(self.hparams.Train["use_negative_nll_loss"] and self.last_missmatched_nll > 0
+                    and random.random() < 0.1 and self.missmatched_modalities)
+
+    def training_step(self, batch, batch_idx):
+        if self._negative_branch():
+            deranged = derange_batch(batch, self.missmatched_modalities)
+            _, loss, _ = self.seq_glow(deranged)
+            self.log("Loss/missmatched_nll", -loss)
+            self._store_mismatched(-loss.detach())
+            loss = loss * -0.1
+        else:
+            _, loss, _ = self.seq_glow(batch)
+        self.log("train_loss", loss)
+        return loss
+
+    def _store_mismatched(self, value):
+        value = value.reshape(()).to(self.last_missmatched_nll.device)
+        if self.nll_sync_hook is not None:
+            value = self.nll_sync_hook(value)
+        self.last_missmatched_nll.copy_(value)
+
+    def fused_training_step(self, batch, lr, world_size=1, allreduce=None):
+        """One optimiser step entirely in the engine. Returns the (detached) loss of this rank.
+
+        allreduce: callable(flat fp32 gradient tensor) summing it over ranks in place (RCCL), or None.
+        """
+        sg = self.seq_glow
+        negative = self._negative_branch()
+        if negative:
+            batch = derange_batch(batch, self.missmatched_modalities)
+        x = batch["p1_face"]
+        eng = sg._ensure_engine(x.device)
+        B, T = x.shape[0], x.shape[1]
+        N = T - sg.spec.start
+        masks = sg._draw_masks(B, N, x.device)
+        init = sg._allreduce() if (sg.training and not sg.glow.actnorm_inited()) else None
+        sg._fwd_counter += 1
+        _, nll = eng.forward(batch, masks, with_stash=True, init_actnorm=init)
+        if init is not None:
+            sg.glow.set_actnorm_init(True)
+        loss = nll.mean().reshape(1)
+        sign = 1.0
+        if negative:
+            self.log("Loss/missmatched_nll", -loss)
+            self._store_mismatched(-loss)
+            sign = -0.1
+            loss = loss * -0.1
+        eng.backward(sign / nll.numel())
+        if allreduce is not None and world_size > 1:
+            allreduce(eng.grads)
+        opt = self.hparams.Optim
+        if opt["name"] != "adam":
+            raise NotImplementedError("fused_training_step implements Adam (final_model.yaml); use training_step with "
+                                      "a torch optimiser for %r" % opt["name"])
+        a = opt["args"]["adam"]
+        eng.optimizer_step(lr, float(a["betas"][0]), float(a["betas"][1]), float(a["eps"]),
+                           clip=float(getattr(self.hparams, "gradient_clip_val", 0) or 0), gmul=1.0 / world_size)
+        self.global_step += 1
+        self.log("train_loss", loss)
+        return loss.detach()
+
+    def validation_step(self, batch, batch_idx):
+        with torch.no_grad():
+            _, loss, _ = self.seq_glow(batch)
+        self.log("val_loss", loss)
+        return loss
+
+    def configure_optimizers(self):
+        name = self.hparams.Optim["name"]
+        optimizer = {"adam": Adam, "sgd": SGD, "rmsprop": RMSprop}[name](
+            self.parameters(), lr=self.hparams.lr, **self.hparams.Optim["args"][name])
+        return [optimizer], get_scheduler(self.hparams.Optim["Schedule"], optimizer)
+
+    @classmethod
+    def load_from_checkpoint(cls, path, dataset_root=None, test=None, map_location="cpu"):
+        """Accepts a Lightning checkpoint of the reference ({'state_dict', 'hyper_parameters' | 'hparams'}) or one
+        written by lets_face_it_amd.trainer.Trainer.save_checkpoint."""
+        from argparse import Namespace
+        ckpt = torch.load(path, map_location=map_location, weights_only=False)
+        hp = ckpt.get("hyper_parameters") or ckpt.get("hparams")
+        if isinstance(hp, dict):
+            hp = Namespace(**hp)
+        model = cls(hp, dataset_root=dataset_root, test=test)
+        model.load_state_dict(ckpt["state_dict"])
+        model.seq_glow.glow.set_actnorm_init(True)  # a trained checkpoint must not re-initialise ActNorm
+        return model

@@ -1,0 +1,120 @@
+"""Minimal training loop standing in for the pytorch_lightning.Trainer the reference drives from train.py:37-38.
+
+One process per GPU; with WORLD_SIZE > 1 the flat gradient buffer is all-reduced with RCCL
+(torch.distributed backend "nccl") — ONE collective of n_params floats per step instead of DDP's per-bucket hooks —
+and ActNorm's data-dependent init statistics and the mismatched-NLL switch are all-reduced so every rank holds
+identical parameters and takes identical branches.
+"""
+import os
+import time
+
+import torch
+import torch.distributed as dist
+
+
+class Trainer:
+    def __init__(self, hparams, device=None, log_every=10):
+        self.hparams = hparams
+        self.world_size = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.device = torch.device(device) if device is not None else torch.device("cuda", self.local_rank)
+        self.log_every = log_every
+        self.max_epochs = int(getattr(hparams, "max_epochs", 1) or 1)
+        self.max_steps = getattr(hparams, "max_steps", None)
+        self.epoch = 0
+
+    # ------------------------------------------------------------------ distributed plumbing
+    def setup_distributed(self):
+        if self.world_size > 1 and not dist.is_initialized():
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            backend = "nccl" if self.device.type == "cuda" else "gloo"
+            if self.device.type == "cuda":
+                torch.cuda.set_device(self.device)
+            dist.init_process_group(backend, rank=self.rank, world_size=self.world_size)
+
+    def allreduce_grads(self, flat):
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+
+    def allreduce_stats(self, sums):
+        if self.world_size > 1:
+            dist.all_reduce(sums, op=dist.ReduceOp.SUM)
+        return self.world_size
+
+    def sync_scalar(self, value):
+        if self.world_size > 1:
+            value = value.clone()
+            dist.all_reduce(value, op=dist.ReduceOp.SUM)
+            value /= self.world_size
+        return value
+
+    def broadcast_parameters(self, model):
+        """Rank 0's initial weights everywhere (DDP's constructor broadcast)."""
+        if self.world_size > 1:
+            eng = model.seq_glow._ensure_engine(self.device)
+            dist.broadcast(eng.params, src=0)
+            dist.broadcast(eng.inv_p, src=0)
+            dist.broadcast(eng.inv_sign, src=0)
+
+    # ------------------------------------------------------------------ schedule (get_scheduler "step", utils.py:72-73)
+    def lr_at(self, epoch):
+        lr = float(self.hparams.lr)
+        sched = self.hparams.Optim["Schedule"]
+        if sched["name"] == "step":
+            a = sched["args"]["step"]
+            lr *= float(a["gamma"]) ** (epoch // int(a["step_size"]))
+        elif sched["name"]:
+            raise NotImplementedError("schedule %r in the fused trainer" % sched["name"])
+        return lr
+
+    # ------------------------------------------------------------------ loop
+    def fit(self, model, datamodule):
+        self.setup_distributed()
+        model.to(self.device)
+        model.train()
+        model.seq_glow.allreduce_hook = self.allreduce_stats
+        model.nll_sync_hook = self.sync_scalar
+        self.broadcast_parameters(model)
+        allreduce = self.allreduce_grads if self.world_size > 1 else None
+        step = 0
+        for epoch in range(self.epoch, self.max_epochs):
+            self.epoch = epoch
+            lr = self.lr_at(epoch)
+            t0, frames = time.time(), 0
+            for batch in datamodule.train_dataloader():
+                batch = {k: v.to(self.device, non_blocking=True).float().contiguous() for k, v in batch.items()}
+                loss = model.fused_training_step(batch, lr, self.world_size, allreduce)
+                x = batch["p1_face"]
+                frames += x.shape[0] * (x.shape[1] - model.seq_glow.spec.start) * self.world_size
+                step += 1
+                if self.rank == 0 and step % self.log_every == 0:
+                    torch.cuda.synchronize()
+                    print("epoch %d step %d lr %.3e loss %.4f  %.0f frames/s" %
+                          (epoch, step, lr, float(loss), frames / (time.time() - t0)), flush=True)
+                if self.max_steps and step >= int(self.max_steps):
+                    return
+            self.validate(model, datamodule)
+
+    def validate(self, model, datamodule):
+        loader = getattr(datamodule, "val_dataloader", None)
+        if loader is None:
+            return None
+        model.eval()
+        total, count = 0.0, 0
+        with torch.no_grad():
+            for i, batch in enumerate(loader()):
+                batch = {k: v.to(self.device).float().contiguous() for k, v in batch.items()}
+                total += float(model.validation_step(batch, i))
+                count += 1
+        model.train()
+        val = total / max(count, 1)
+        if self.rank == 0:
+            print("epoch %d val_loss %.4f" % (self.epoch, val), flush=True)
+        return val
+
+    def save_checkpoint(self, model, path):
+        if self.rank == 0:
+            torch.save({"state_dict": {k: v.detach().cpu() for k, v in model.state_dict().items()},
+                        "hparams": vars(self.hparams), "epoch": self.epoch,
+                        "global_step": model.global_step}, path)

@@ -1,0 +1,85 @@
+"""CPU, world_size 2 over gloo: the data-parallel plumbing of lets_face_it_amd.trainer and the DP arithmetic it
+relies on (mean of per-rank gradients of per-rank mean losses == gradient of the global-batch mean loss; ActNorm
+init statistics summed over ranks == statistics of the concatenated batch)."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, out):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from argparse import Namespace
+    from helpers import Fixture
+    from oracle import seqglow_oracle as oracle
+    from lets_face_it_amd.trainer import Trainer
+    torch.set_num_threads(2)
+    fx = Fixture("tiny")
+    tr = Trainer(Namespace(**fx.hp), device="cpu")
+    tr.setup_distributed()
+    assert dist.get_world_size() == world and tr.rank == rank
+
+    # (1) gradient all-reduce of the flat buffer + 1/world in the optimiser == global-batch gradient
+    sd = {k: v.requires_grad_(v.dtype.is_floating_point and not k.endswith((".p", ".sign_s")))
+          for k, v in fx.state_dict().items()}
+    batch = fx.batch()
+    half = fx.B // world
+    shard = {k: v[rank * half:(rank + 1) * half] for k, v in batch.items()}
+    oracle.seqglow_forward(fx.hp, sd, shard)[1].sum().backward()
+    names = [k for k, v in sd.items() if v.requires_grad]
+    flat = torch.cat([sd[k].grad.reshape(-1) for k in names])
+    tr.allreduce_grads(flat)
+    flat /= world
+    full = {k: v.detach().clone().requires_grad_(v.requires_grad) for k, v in sd.items()}
+    oracle.seqglow_forward(fx.hp, full, batch)[1].sum().backward()
+    ref = torch.cat([full[k].grad.reshape(-1) for k in names])
+    err_grad = float((flat - ref).abs().max() / ref.abs().max())
+
+    # (2) ActNorm init statistics: sum over ranks == concatenated batch
+    x = batch["p1_face"][:, fx.start]
+    xs = x[rank * half:(rank + 1) * half]
+    sums = torch.cat([xs.sum(0), (xs ** 2).sum(0)])
+    n = tr.allreduce_stats(sums)
+    err_stats = float((sums - torch.cat([x.sum(0), (x ** 2).sum(0)])).abs().max())
+
+    # (3) scalar sync used for the mismatched-NLL switch
+    v = tr.sync_scalar(torch.tensor(float(rank + 1)))
+    if rank == 0:
+        out.put((err_grad, err_stats, n, float(v)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_data_parallel():
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    try:
+        err_grad, err_stats, n, v = out.get(timeout=240)
+    finally:
+        for p in procs:
+            p.join(timeout=60)
+            if p.is_alive():
+                p.terminate()
+    assert all(p.exitcode == 0 for p in procs)
+    assert err_grad < 1e-10 and err_stats < 1e-10 and n == 2 and v == 1.5

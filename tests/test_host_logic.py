@@ -1,0 +1,137 @@
+"""CPU: the host-side mirror of the reference surface (no kernels run): construction parity, hparams, helpers."""
+import os
+from argparse import Namespace
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import Fixture, rel_err
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HP = os.path.join(ROOT, "lets_face_it_amd", "hparams")
+
+
+def perturb_like_fixture(model):
+    gen = torch.Generator().manual_seed(4321)
+    with torch.no_grad():
+        for name, p in model.named_parameters():
+            if "final_linear" in name:
+                p.add_(torch.randn(p.shape, generator=gen) * 0.05)
+            elif "actnorm" in name:
+                p.add_(torch.randn(p.shape, generator=gen) * 0.1)
+            elif name.endswith("invconv.log_s"):
+                p.add_(torch.randn(p.shape, generator=gen) * 0.05)
+
+
+@pytest.mark.parametrize("name", ["tiny", "tiny_additive", "odd", "mid"])
+def test_same_seeds_give_the_reference_initialisation(name):
+    """Construction order and RNG use match the reference: seed_everything(1234) -> identical initial weights and keys."""
+    from lets_face_it_amd.glow.models import SeqGlow
+    fx = Fixture(name)
+    torch.manual_seed(1234)
+    np.random.seed(1234)
+    m = SeqGlow(Namespace(**fx.hp))
+    perturb_like_fixture(m)
+    ref = fx.state_dict(torch.float32)
+    sd = m.state_dict()
+    assert sorted(sd) == sorted(ref)
+    for k in ref:
+        assert sd[k].shape == ref[k].shape, k
+        assert torch.equal(sd[k], ref[k]), k
+
+
+def test_model_spec_matches_survey_dims():
+    from lets_face_it_amd.engine import ModelSpec
+    from lets_face_it_amd.glow.utils import load_hparams_file
+    s = ModelSpec(Namespace(**load_hparams_file(os.path.join(HP, "final_model.yaml"))))
+    assert (s.C, s.S, s.D, s.H, s.Ks, s.E, s.start, s.Cout, s.G, s.I) == (56, 30, 512, 128, 16, 1560, 24, 56, 384, 540)
+    s = ModelSpec(Namespace(**load_hparams_file(os.path.join(HP, "final_model_synthetic.yaml"))))
+    assert (s.C, s.S, s.E, s.Ch, s.C2) == (50, 27, 1530, 25, 25)
+    s = ModelSpec(Namespace(**load_hparams_file(os.path.join(HP, "no_speech.yaml"))))
+    assert [e.name for e in s.encoders] == ["p1_face", "p2_face", "p1_speech"] and s.start == 5
+
+
+def test_parameter_count_matches_reference():
+    """17 647 488 parameters for final_model.yaml, 17 342 112 at C=50/S=27."""
+    from lets_face_it_amd.glow.models import SeqGlow
+    from lets_face_it_amd.glow.utils import load_hparams_file
+    for f, n in (("final_model.yaml", 17647488), ("final_model_synthetic.yaml", 17342112)):
+        m = SeqGlow(Namespace(**load_hparams_file(os.path.join(HP, f))))
+        assert sum(p.numel() for p in m.parameters()) == n
+
+
+def test_get_hparams_overrides(tmp_path):
+    from lets_face_it_amd.glow.utils import get_hparams
+    hp, name = get_hparams([os.path.join(HP, "final_model.yaml"), "--max_epochs", "3", "--lr=0.5", "--gpus", "8"])
+    assert name == "final_model.yaml" and hp.max_epochs == 3 and hp.lr == 0.5 and hp.gpus == 8
+    assert hp.Glow["rnn_type"] == "gru" and hp.dataset_root == os.environ.get("LFI_DATA_DIR", "/data")
+    js = tmp_path / "x.json"
+    js.write_text('{"Glow": {"K": 2}, // comment\n "lr": 1e-3 /* c */ }')
+    from lets_face_it_amd.glow.utils import load_hparams_file
+    assert load_hparams_file(str(js))["Glow"] == {"K": 2, "rnn_type": "gru"}
+
+
+def test_helpers_match_reference_semantics():
+    from lets_face_it_amd.glow import utils
+    fx = Fixture("tiny")
+    hp = Namespace(**fx.hp)
+    assert utils.get_longest_history(hp.Conditioning) == fx.start
+    assert utils.get_mismatched_modalities(hp) == (["p2_face", "p2_speech"], "p2")
+    b = fx.batch(torch.float32)
+    torch.manual_seed(0)
+    perm = torch.randperm(fx.B)
+    torch.manual_seed(0)
+    mixed = utils.derange_batch(b, ["p2_face", "p2_speech"])
+    assert torch.equal(mixed["p2_face"], b["p2_face"][perm]) and mixed["p1_face"] is b["p1_face"]
+    x = torch.arange(24.0).reshape(1, 6, 4) ** 3
+    d = x[:, 1:] - x[:, :-1]
+    d = d[:, 1:] - d[:, :-1]
+    assert torch.equal(utils.calc_jerk(x), (d[:, 1:] - d[:, :-1]).abs().mean())
+    with pytest.raises(AssertionError):
+        bad = Namespace(**Fixture("tiny").hp)
+        bad.Train["seq_len"] = 4
+        utils.test_params(bad)
+
+
+def test_trainer_lr_schedule_is_steplr():
+    from lets_face_it_amd.glow.utils import load_hparams_file
+    from lets_face_it_amd.trainer import Trainer
+    hp = Namespace(**load_hparams_file(os.path.join(HP, "final_model.yaml")))
+    t = Trainer(hp, device="cpu")
+    opt = torch.optim.SGD([torch.nn.Parameter(torch.zeros(1))], lr=hp.lr)
+    sched = torch.optim.lr_scheduler.StepLR(opt, **hp.Optim["Schedule"]["args"]["step"])
+    for epoch in range(10):
+        assert abs(t.lr_at(epoch) - opt.param_groups[0]["lr"]) < 1e-12
+        opt.step()
+        sched.step()
+
+
+def test_standalone_modules_roundtrip():
+    """What the reference's test_modules.py prints (forward -> reverse deltas), asserted."""
+    from lets_face_it_amd.glow import modules
+    torch.manual_seed(0)
+    np.random.seed(0)
+    x = torch.rand(6, 54)
+    an = modules.ActNorm2d(54)
+    an.initialize_parameters(x)
+    y, det = an(x, 0.0)
+    x2, det2 = an(y, det, reverse=True)
+    assert (x2 - x).abs().max() < 1e-5 and abs(float(det2)) < 1e-4
+    assert rel_err(y.mean(0), torch.zeros(54)) < 1e-5
+    for lu in (False, True):
+        conv = modules.InvertibleConv1x1(54, LU_decomposed=lu)
+        y, det = conv(x, 0.0)
+        x2, _ = conv(y, None, reverse=True)
+        assert (x2 - x).abs().max() < 1e-4
+        assert abs(float(det)) < 1e-3  # orthogonal init: log|det| = 0
+
+
+def test_oracle_is_not_imported_by_the_product():
+    import re
+    pkg = os.path.join(ROOT, "lets_face_it_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                text = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle", text, re.M), f
