@@ -127,7 +127,10 @@ def test_invert_matches_reference(fx, gpu_device):
     rec, bl = m.invert(z_seq, batch)
     x = batch["p1_face"][:, fx.start:].transpose(0, 1)
     assert rel_err(torch.stack(rec), x) < 1e-4
-    assert rel_err(bl, -loss) < 1e-4  # backward NLL mirrors the forward one (mimicry_logger.py:245-246)
+    # the reverse pass negates the log-det and keeps the prior term: fwd + bwd = -2 mean(log p(z)) / ln 2
+    # (what MimicryLogger.test_invertability divides by the forward loss, mimicry_logger.py:241-251)
+    logp = (-0.5 * (torch.stack(z_seq) ** 2 + oracle.LOG2PI)).sum(-1)
+    assert rel_err(bl + loss, -2.0 * logp.mean().reshape(1) / oracle.LN2) < 1e-4
     if fx.has("invert/x"):
         assert rel_err(torch.stack(rec), fx.get("invert/x")) < 1e-4
         assert rel_err(bl, fx.get("invert/loss")) < 1e-4
@@ -260,7 +263,8 @@ def test_full_size_properties(gpu_device):
         rec, bl = m.invert(z_seq, batch)
         x = batch["p1_face"][:, 24:].transpose(0, 1)
         assert rel_err(torch.stack(rec), x) < 2e-4
-        assert rel_err(bl, -loss) < 1e-4
+        logp = (-0.5 * (torch.stack(z_seq) ** 2 + oracle.LOG2PI)).sum(-1)
+        assert rel_err(bl + loss, -2.0 * logp.mean().reshape(1) / oracle.LN2) < 1e-4
         # (2) samples are independent: a permuted batch gives the permuted result
         perm = torch.randperm(256, generator=torch.Generator().manual_seed(0)).to(gpu_device)
         _, loss_p, losses_p = m({k: v[perm].contiguous() for k, v in batch.items()})
