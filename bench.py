@@ -43,7 +43,10 @@ def cpu_baseline(hp, C, S, T, budget_s):
     from lets_face_it_amd.glow.models import SeqGlow
     from argparse import Namespace
     import copy
-    threads = torch.get_num_threads()
+    # the per-timestep loop is made of small ops: on a many-core host the default (all cores) is far slower than a
+    # modest team, so use at most 16 threads and report that count
+    threads = min(16, os.cpu_count() or 1)
+    torch.set_num_threads(threads)
     torch.manual_seed(1234)
     m = SeqGlow(Namespace(**copy.deepcopy(hp)))
     sd = {k: v.detach().clone() for k, v in m.state_dict().items()}

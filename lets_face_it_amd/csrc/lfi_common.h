@@ -43,29 +43,62 @@ __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
 
-// One 16 x 16 output tile: acc += A(16 x K) * B(K x 16).
-//   A is in LDS, k-major: element (i, k) at a_lds[k * lda + i]           (i = 0..15)
-//   B is in global memory, row-major over k: element (k, j) at b[k * ldb + j], only j < nvalid is read
-// K need not be a multiple of 4 (out-of-range k contributes zero). All 64 lanes must call.
-__device__ __forceinline__ f32x4 tile16_lds_glb(f32x4 acc, const float* a_lds, int lda, const float* __restrict__ b,
-                                                long ldb, int K, int nvalid, int lane) {
+// NACC 16 x 16 output tiles that share the A operand: acc[c] += A(16 x K) * B_c(K x 16), c < NACC.
+//   A is in LDS, k-major: element (i, k) at a_lds[k * lda + i]                       (i = 0..15)
+//   B_c is in global memory, row-major over k: element (k, j) at b[k * ldb + c * cstride + j]; lanes whose column is
+//   outside the matrix pass jok = false and contribute zeros.
+// The cells are latency-bound, not FLOP-bound (4-8 waves per CU, weights streamed from L2): operands are fetched
+// 8 k-steps (32 k) at a time, two chunks in flight (the loads of chunk t+1 are issued before the MFMAs of chunk t),
+// so a chain of K/4 dependent MFMAs pays ~K/32 L2 round trips instead of K/4. A single chain is split in two
+// (even/odd k-steps) because v_mfma_f32_16x16x4_f32 has a 40-cycle dependent latency against a 32-cycle issue.
+// K need not be a multiple of 4. All 64 lanes must call.
+template <int NACC>
+__device__ __forceinline__ void mma16_pf(f32x4 (&acc)[NACC], const float* a_lds, int lda, const float* __restrict__ b,
+                                         int ldb, int cstride, int K, bool jok, int lane) {
+  constexpr int U = NACC == 1 ? 8 : 4;  // k-steps per chunk (two chunks in flight)
   const int i = lane & 15, kq = lane >> 4;
-  const bool jok = i < nvalid;
-  int k = 0;
-  for (; k + 4 <= K; k += 4) {
-    const int kk = k + kq;
-    float av = a_lds[kk * lda + i];
-    float bv = jok ? b[(long)kk * ldb + i] : 0.0f;
-    acc = mfma16(av, bv, acc);
+  float a0[U], a1[U], b0[U][NACC], b1[U][NACC];
+  f32x4 alt = {0.f, 0.f, 0.f, 0.f};
+  auto load = [&](int k0, float (&a)[U], float (&bb)[U][NACC]) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int kk = k0 + 4 * u + kq;
+      const bool ok = kk < K;
+      a[u] = ok ? a_lds[kk * lda + i] : 0.0f;
+#pragma unroll
+      for (int c = 0; c < NACC; ++c) bb[u][c] = (ok && jok) ? b[kk * ldb + c * cstride + i] : 0.0f;  // 32-bit offsets from one base
+    }
+  };
+  auto mma = [&](const float (&a)[U], const float (&bb)[U][NACC]) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (NACC == 1) {
+        if (u & 1) alt = mfma16(a[u], bb[u][0], alt);
+        else acc[0] = mfma16(a[u], bb[u][0], acc[0]);
+      } else {
+#pragma unroll
+        for (int c = 0; c < NACC; ++c) acc[c] = mfma16(a[u], bb[u][c], acc[c]);
+      }
+    }
+  };
+  if (K <= 0) return;
+  load(0, a0, b0);
+  for (int k0 = 0; k0 < K; k0 += 8 * U) {
+    const bool more1 = k0 + 4 * U < K;
+    if (more1) load(k0 + 4 * U, a1, b1);
+    mma(a0, b0);
+    if (k0 + 8 * U < K) load(k0 + 8 * U, a0, b0);
+    if (more1) mma(a1, b1);
   }
-  if (k < K) {
-    const int kk = k + kq;
-    const bool kok = kk < K;
-    float av = kok ? a_lds[kk * lda + i] : 0.0f;
-    float bv = (kok && jok) ? b[(long)kk * ldb + i] : 0.0f;
-    acc = mfma16(av, bv, acc);
-  }
-  return acc;
+  if (NACC == 1) acc[0] += alt;
+}
+
+// One tile: acc += A(16 x K) * B(K x 16) with only columns j < nvalid of B read.
+__device__ __forceinline__ f32x4 tile16_lds_glb(f32x4 acc, const float* a_lds, int lda, const float* __restrict__ b,
+                                                int ldb, int K, int nvalid, int lane) {
+  f32x4 a1[1] = {acc};
+  mma16_pf<1>(a1, a_lds, lda, b, ldb, 0, K, (lane & 15) < nvalid, lane);
+  return a1[0];
 }
 
 // 32 x 32 variant: A(i, k) at a_lds[k * lda + i] (i = 0..31), B(k, j) at b[k * ldb + j], j < nvalid.

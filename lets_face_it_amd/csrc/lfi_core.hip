@@ -69,16 +69,20 @@ extern "C" int lfi_selftest_mfma(int* out, void* stream) {
 // stage 1: block (cx, ry) sums rows [ry*RB, ry*RB + RB) of 64 columns into part[batch][ry][col]; stage 2 adds the
 // row-blocks in order. Both fixed-order, so results are bitwise reproducible.
 namespace {
-constexpr int CS_ROWS = 256;  // rows per stage-1 block
+// rows per stage-1 block: at least 256, and few enough row blocks (<= 64) that stage 2's serial tail stays short
+int cs_rows_per_block(int rows) {
+  const int r = (rows + 63) / 64;
+  return r < 256 ? 256 : r;
+}
 
 __global__ __launch_bounds__(256) void colsum_stage1(const float* __restrict__ X, long ldx, long strideX, int rows, int cols,
-                                                     float* __restrict__ part, int nrb) {
+                                                     float* __restrict__ part, int nrb, int rpb) {
   __shared__ float red[4][64];
   const int c = blockIdx.x * 64 + (threadIdx.x & 63);
   const int rq = threadIdx.x >> 6;
   const int rb = blockIdx.y, batch = blockIdx.z;
   const float* x = X + batch * strideX;
-  const int r0 = rb * CS_ROWS, r1 = min(rows, r0 + CS_ROWS);
+  const int r0 = rb * rpb, r1 = min(rows, r0 + rpb);
   float s = 0.0f;
   if (c < cols)
     for (int r = r0 + rq; r < r1; r += 4) s += x[(long)r * ldx + c];
@@ -104,7 +108,7 @@ __global__ __launch_bounds__(256) void colsum_stage2(const float* __restrict__ p
 }  // namespace
 
 extern "C" long lfi_colsum_work_floats(int rows, int cols, int batch) {
-  return (long)batch * lfi_cdiv(rows, CS_ROWS) * cols;
+  return (long)batch * lfi_cdiv(rows, cs_rows_per_block(rows)) * cols;
 }
 
 extern "C" int lfi_colsum_f32(const float* X, long ldx, long strideX, int rows, int cols, int batch, float* out,
@@ -112,10 +116,10 @@ extern "C" int lfi_colsum_f32(const float* X, long ldx, long strideX, int rows, 
   LFI_REQUIRE(X && out && work, "lfi_colsum_f32: null pointer");
   LFI_REQUIRE(rows >= 1 && cols >= 1 && batch >= 1 && batch <= 65535, "lfi_colsum_f32: bad dims");
   hipStream_t st = (hipStream_t)stream;
-  const int nrb = lfi_cdiv(rows, CS_ROWS);
-  LFI_REQUIRE(nrb <= 65535, "lfi_colsum_f32: too many rows");
+  const int rpb = cs_rows_per_block(rows);
+  const int nrb = lfi_cdiv(rows, rpb);
   hipLaunchKernelGGL(colsum_stage1, dim3(lfi_cdiv(cols, 64), nrb, batch), dim3(256), 0, st, X, ldx, strideX, rows, cols,
-                     work, nrb);
+                     work, nrb, rpb);
   LFI_LAUNCH_CHECK("lfi_colsum_f32 stage 1");
   hipLaunchKernelGGL(colsum_stage2, dim3(lfi_cdiv(cols, 256), batch), dim3(256), 0, st, work, nrb, cols, out, strideOut,
                      scale, accumulate);

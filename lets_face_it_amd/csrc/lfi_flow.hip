@@ -21,6 +21,8 @@
 namespace {
 
 constexpr int MB = 16;        // samples per workgroup
+constexpr int NT = 512;       // threads per workgroup (8 waves: one 16-wide hidden tile each at H = 128)
+constexpr int NW = NT / 64;
 constexpr int LT = MB + 1;    // k-major LDS leading dimension
 constexpr float LOG2PI_F = 1.8378770664093453f;
 constexpr float LN2_F = 0.6931471805599453f;
@@ -62,42 +64,23 @@ __device__ __forceinline__ int rup16(int x) { return (x + 15) & ~15; }
 // ---- shared phase: coupling net given z1 (Zt) and h_prev (Ht) in LDS -> new hidden (Hn, LDS) and o (Orm, LDS)
 __device__ __forceinline__ void coupling_net_phase(const FlowK& f, const CellIO& io, int b0, const float* Zt, const float* Ht,
                                                    float* Hn, float* Orm, int tid) {
-  const int lane = tid & 63, wave = tid >> 6;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l15 = lane & 15, lq = lane >> 4;
   const int k = io.k, H = f.H, G = f.G, Ch = f.Ch, Cout = f.Cout;
   const float* wz = f.wz_t + (long)k * Ch * G;
   const float* wh = f.whh_t + (long)k * H * G;
   const float* bhh = f.p.b_hh + (long)k * G;
   const int nht = (H + 15) >> 4;
-  for (int t = wave; t < nht; t += 4) {
+  for (int t = wave; t < nht; t += NW) {
     const int j = t * 16 + l15;
     const bool jok = j < H;
-    f32x4 ar = {0.f, 0.f, 0.f, 0.f}, au = ar, ain = ar, ahn = ar;
-    // z1 part: three independent accumulator chains interleaved
-    {
-      const int i = l15;
-      int kk0 = 0;
-      for (; kk0 < Ch; kk0 += 4) {
-        const int kk = kk0 + lq;
-        const bool kok = kk < Ch;
-        const float av = kok ? Zt[kk * LT + i] : 0.0f;
-        const float* br = wz + (long)kk * G + j;
-        const bool ok = kok && jok;
-        ar = mfma16(av, ok ? br[0] : 0.0f, ar);
-        au = mfma16(av, ok ? br[H] : 0.0f, au);
-        ain = mfma16(av, ok ? br[2 * H] : 0.0f, ain);
-      }
-      for (kk0 = 0; kk0 < H; kk0 += 4) {
-        const int kk = kk0 + lq;
-        const bool kok = kk < H;
-        const float av = kok ? Ht[kk * LT + i] : 0.0f;
-        const float* br = wh + (long)kk * G + j;
-        const bool ok = kok && jok;
-        ar = mfma16(av, ok ? br[0] : 0.0f, ar);
-        au = mfma16(av, ok ? br[H] : 0.0f, au);
-        ahn = mfma16(av, ok ? br[2 * H] : 0.0f, ahn);
-      }
-    }
+    // input side (z1 part; the conditioning part was hoisted into gic): r, z, n chains share the A operand
+    f32x4 gz[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    mma16_pf<3>(gz, Zt, LT, wz + t * 16, G, H, Ch, jok, lane);
+    // hidden side
+    f32x4 gh[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+    mma16_pf<3>(gh, Ht, LT, wh + t * 16, G, H, H, jok, lane);
+    const f32x4 ar = gz[0] + gh[0], au = gz[1] + gh[1], ain = gz[2], ahn = gh[2];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int i = lq * 4 + r;
@@ -127,7 +110,7 @@ __device__ __forceinline__ void coupling_net_phase(const FlowK& f, const CellIO&
   const float* lfl = f.p.l_fl + (long)k * Cout;
   const int not_ = (Cout + 15) >> 4;
   const int ldo = Cout + 1;
-  for (int t = wave; t < not_; t += 4) {
+  for (int t = wave; t < not_; t += NW) {
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     acc = tile16_lds_glb(acc, Hn, LT, wf + t * 16, Cout, H, min(16, Cout - t * 16), lane);
     const int col = t * 16 + l15;
@@ -166,7 +149,7 @@ __host__ __device__ inline Carve carve_fwd(int C, int H, int Ch, int C2, int Cou
 
 // ------------------------------------------------------------------------------------------- forward cell
 __device__ void cell_forward(const FlowK& f, const CellIO& io, int b0) {
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l15 = lane & 15, lq = lane >> 4;
   const int C = f.C, H = f.H, Ch = f.Ch, C2 = f.C2, Cout = f.Cout, k = io.k;
   const Carve cv = carve_fwd(C, H, Ch, C2, Cout);
@@ -182,7 +165,7 @@ __device__ void cell_forward(const FlowK& f, const CellIO& io, int b0) {
   // P0: actnorm (glow/modules.py:45-52), stage a and h_prev k-major
   const float* anb = f.p.an_bias + (long)k * C;
   const float* anl = f.p.an_logs + (long)k * C;
-  for (int idx = tid; idx < MB * C; idx += 256) {
+  for (int idx = tid; idx < MB * C; idx += NT) {
     const int i = idx / C, c = idx - i * C;
     const int row = b0 + i;
     float a = 0.0f;
@@ -192,7 +175,7 @@ __device__ void cell_forward(const FlowK& f, const CellIO& io, int b0) {
     }
     At[c * LT + i] = a;
   }
-  for (int idx = tid; idx < MB * H; idx += 256) {
+  for (int idx = tid; idx < MB * H; idx += NT) {
     const int i = idx / H, j = idx - i * H;
     const int row = b0 + i;
     Ht[j * LT + i] = (io.h_prev && row < io.rows) ? io.h_prev[(long)row * H + j] : 0.0f;
@@ -203,7 +186,7 @@ __device__ void cell_forward(const FlowK& f, const CellIO& io, int b0) {
   {
     const float* W = f.W + (long)k * C * C;
     const int nt = (C + 15) >> 4;
-    for (int t = wave; t < nt; t += 4) {
+    for (int t = wave; t < nt; t += NW) {
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
       acc = tile16_lds_glb(acc, At, LT, W + t * 16, C, C, min(16, C - t * 16), lane);
       const int c = t * 16 + l15;
@@ -226,7 +209,7 @@ __device__ void cell_forward(const FlowK& f, const CellIO& io, int b0) {
   coupling_net_phase(f, io, b0, Zt, Ht, Hn, Orm, tid);
 
   // P4: coupling (glow/models.py:330-341) and pass-through half
-  for (int idx = tid; idx < MB * C2; idx += 256) {
+  for (int idx = tid; idx < MB * C2; idx += NT) {
     const int i = idx / C2, jj = idx - i * C2;
     const int row = b0 + i;
     const float z2 = Yrm[i * ldy + Ch + jj];
@@ -243,7 +226,7 @@ __device__ void cell_forward(const FlowK& f, const CellIO& io, int b0) {
     Lg[i * ldl + jj] = lg;
     if (row < io.rows) io.x_out[(long)row * io.ldxo + Ch + jj] = z2n;
   }
-  for (int idx = tid; idx < MB * Ch; idx += 256) {
+  for (int idx = tid; idx < MB * Ch; idx += NT) {
     const int i = idx / Ch, c = idx - i * Ch;
     const int row = b0 + i;
     if (row < io.rows) io.x_out[(long)row * io.ldxo + c] = Yrm[i * ldy + c];
@@ -262,7 +245,7 @@ __device__ void cell_forward(const FlowK& f, const CellIO& io, int b0) {
 // ------------------------------------------------------------------------------------------- reverse cell
 // FlowStep.reverse_flow (glow/models.py:345-373): coupling^-1 -> invconv^-1 -> actnorm^-1.
 __device__ void cell_reverse(const FlowK& f, const CellIO& io, int b0) {
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l15 = lane & 15, lq = lane >> 4;
   const int C = f.C, H = f.H, Ch = f.Ch, C2 = f.C2, Cout = f.Cout, k = io.k;
   const Carve cv = carve_fwd(C, H, Ch, C2, Cout);
@@ -275,21 +258,21 @@ __device__ void cell_reverse(const FlowK& f, const CellIO& io, int b0) {
   float* Lg = flow_smem + cv.Lg;
   const int ldy = C + 1, ldo = Cout + 1, ldl = C2 + 1;
 
-  for (int idx = tid; idx < MB * C; idx += 256) {
+  for (int idx = tid; idx < MB * C; idx += NT) {
     const int i = idx / C, c = idx - i * C;
     const int row = b0 + i;
     const float v = row < io.rows ? io.x_in[(long)row * io.ldx + c] : 0.0f;
     Yrm[i * ldy + c] = v;
     if (c < Ch) { Zt[c * LT + i] = v; Yt[c * LT + i] = v; }
   }
-  for (int idx = tid; idx < MB * H; idx += 256) {
+  for (int idx = tid; idx < MB * H; idx += NT) {
     const int i = idx / H, j = idx - i * H;
     const int row = b0 + i;
     Ht[j * LT + i] = (io.h_prev && row < io.rows) ? io.h_prev[(long)row * H + j] : 0.0f;
   }
   __syncthreads();
   coupling_net_phase(f, io, b0, Zt, Ht, Hn, Orm, tid);
-  for (int idx = tid; idx < MB * C2; idx += 256) {
+  for (int idx = tid; idx < MB * C2; idx += NT) {
     const int i = idx / C2, jj = idx - i * C2;
     const float z2n = Yrm[i * ldy + Ch + jj];
     float z2, lg = 0.0f;
@@ -312,7 +295,7 @@ __device__ void cell_reverse(const FlowK& f, const CellIO& io, int b0) {
     const float* anb = f.p.an_bias + (long)k * C;
     const float* anl = f.p.an_logs + (long)k * C;
     const int nt = (C + 15) >> 4;
-    for (int t = wave; t < nt; t += 4) {
+    for (int t = wave; t < nt; t += NW) {
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
       acc = tile16_lds_glb(acc, Yt, LT, Wi + t * 16, C, C, min(16, C - t * 16), lane);
       const int c = t * 16 + l15;
@@ -336,7 +319,7 @@ __device__ void cell_reverse(const FlowK& f, const CellIO& io, int b0) {
   }
 }
 
-__global__ __launch_bounds__(256) void flow_diag_fwd_kernel(FlowK f, int d, int klo) {
+__global__ __launch_bounds__(NT) void flow_diag_fwd_kernel(FlowK f, int d, int klo) {
   const int k = klo + blockIdx.y, n = d - k;
   const long fr = (long)n * f.B;  // first frame of this timestep
   CellIO io;
@@ -356,8 +339,9 @@ __global__ __launch_bounds__(256) void flow_diag_fwd_kernel(FlowK f, int d, int 
   cell_forward(f, io, blockIdx.x * MB);
 }
 
-__global__ __launch_bounds__(256) void flow_step_kernel(FlowK f, CellIO io, int reverse) {
-  if (reverse) cell_reverse(f, io, blockIdx.x * MB);
+template <bool REVERSE>
+__global__ __launch_bounds__(NT) void flow_step_kernel(FlowK f, CellIO io) {
+  if (REVERSE) cell_reverse(f, io, blockIdx.x * MB);
   else cell_forward(f, io, blockIdx.x * MB);
 }
 
@@ -394,8 +378,8 @@ __host__ __device__ inline CarveB carve_bwd(int C, int H, int Cout, int G) {
   return c;
 }
 
-__global__ __launch_bounds__(256) void flow_diag_bwd_kernel(FlowK f, int d, int klo) {
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+__global__ __launch_bounds__(NT) void flow_diag_bwd_kernel(FlowK f, int d, int klo) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l15 = lane & 15, lq = lane >> 4;
   const int k = klo + blockIdx.y, n = d - k;
   const int b0 = blockIdx.x * MB;
@@ -420,7 +404,7 @@ __global__ __launch_bounds__(256) void flow_diag_bwd_kernel(FlowK f, int d, int 
   const float* Y = f.sY + kf * C;
   const float* O = f.sO + kf * Cout;
   const float* lfl = f.p.l_fl + (long)k * Cout;
-  for (int idx = tid; idx < MB * C2; idx += 256) {
+  for (int idx = tid; idx < MB * C2; idx += NT) {
     const int i = idx / C2, jj = idx - i * C2;
     const int row = b0 + i;
     float dz2 = 0.0f, d0 = 0.0f, d1 = 0.0f, p0 = 0.0f, p1 = 0.0f;
@@ -471,7 +455,7 @@ __global__ __launch_bounds__(256) void flow_diag_bwd_kernel(FlowK f, int d, int 
     const float* dhf = (n < f.N - 1) ? f.bDh + ((long)k * f.F + fr + B) * H : nullptr;
     const float* gs_base = f.sG + kf * 4 * H;
     const float* hp_base = n > 0 ? f.sH + ((long)k * f.F + fr - B) * H : nullptr;
-    for (int t = wave; t < nht; t += 4) {
+    for (int t = wave; t < nht; t += NW) {
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
       acc = tile16_lds_glb(acc, Dl, LT, wfl + t * 16, H, Cout, min(16, H - t * 16), lane);
       const int j = t * 16 + l15;
@@ -512,7 +496,7 @@ __global__ __launch_bounds__(256) void flow_diag_bwd_kernel(FlowK f, int d, int 
     const float* whh = f.p.w_hh + (long)k * G * H;
     if (n > 0) {
       float* dho = f.bDh + kf * H;
-      for (int t = wave; t < nht; t += 4) {
+      for (int t = wave; t < nht; t += NW) {
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         acc = tile16_lds_glb(acc, Gh, LT, whh + t * 16, H, G, min(16, H - t * 16), lane);
         const int j = t * 16 + l15;
@@ -528,7 +512,7 @@ __global__ __launch_bounds__(256) void flow_diag_bwd_kernel(FlowK f, int d, int 
     }
     const float* wih = f.p.w_ih + (long)k * G * I;
     const int nzt = (Ch + 15) >> 4;
-    for (int t = 3 - wave; t < nzt; t += 4) {  // start from the other end so these tiles land on the less loaded waves
+    for (int t = NW - 1 - wave; t < nzt; t += NW) {  // start from the other end so these tiles land on the less loaded waves
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
       acc = tile16_lds_glb(acc, Gi, LT, wih + t * 16, I, G, min(16, Ch - t * 16), lane);
       const int c = t * 16 + l15;
@@ -557,7 +541,7 @@ __global__ __launch_bounds__(256) void flow_diag_bwd_kernel(FlowK f, int d, int 
     float* dxi = k > 0 ? f.bDx + kf * C : nullptr;
     float* pan = f.bPan + (((long)k * f.N + n) * f.nbt + blockIdx.x) * 2 * C;
     const int nt = (C + 15) >> 4;
-    for (int t = wave; t < nt; t += 4) {
+    for (int t = wave; t < nt; t += NW) {
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
       acc = tile16_lds_glb(acc, Dy, LT, Wt + t * 16, C, C, min(16, C - t * 16), lane);
       const int c = t * 16 + l15;
@@ -1003,7 +987,7 @@ extern "C" int lfi_flow_seq_fwd(const lfi_flow_dims* d, const lfi_flow_params* p
   for (int dg = 0; dg < f.N + f.Ks - 1; ++dg) {
     const int klo = dg - (f.N - 1) > 0 ? dg - (f.N - 1) : 0;
     const int khi = dg < f.Ks - 1 ? dg : f.Ks - 1;
-    hipLaunchKernelGGL(flow_diag_fwd_kernel, dim3(f.nbt, khi - klo + 1), dim3(256), lds, st, f, dg, klo);
+    hipLaunchKernelGGL(flow_diag_fwd_kernel, dim3(f.nbt, khi - klo + 1), dim3(NT), lds, st, f, dg, klo);
   }
   LFI_LAUNCH_CHECK("lfi_flow_seq_fwd");
   hipLaunchKernelGGL(flow_nll_kernel, dim3(lfi_cdiv(f.F, 256)), dim3(256), 0, st, f, z, nll);
@@ -1028,7 +1012,7 @@ extern "C" int lfi_flow_seq_bwd(const lfi_flow_dims* d, const lfi_flow_params* p
   for (int dg = f.N + f.Ks - 2; dg >= 0; --dg) {
     const int klo = dg - (f.N - 1) > 0 ? dg - (f.N - 1) : 0;
     const int khi = dg < f.Ks - 1 ? dg : f.Ks - 1;
-    hipLaunchKernelGGL(flow_diag_bwd_kernel, dim3(f.nbt, khi - klo + 1), dim3(256), lds, st, f, dg, klo);
+    hipLaunchKernelGGL(flow_diag_bwd_kernel, dim3(f.nbt, khi - klo + 1), dim3(NT), lds, st, f, dg, klo);
   }
   LFI_LAUNCH_CHECK("lfi_flow_seq_bwd");
   return LFI_OK;
@@ -1141,9 +1125,11 @@ extern "C" int lfi_flow_step(const lfi_flow_dims* d, const lfi_flow_params* p, c
   io.x_out = x_out; io.ldxo = ldxo; io.h_out = h_out; io.l_out = ldc_acc; io.l_accumulate = 1;
   const Carve cv = carve_fwd(f.C, f.H, f.Ch, f.C2, f.Cout);
   const size_t lds = (size_t)cv.total * sizeof(float);
-  rc = set_flow_lds(flow_step_kernel, lds, "lfi_flow_step");
+  rc = reverse ? set_flow_lds(flow_step_kernel<true>, lds, "lfi_flow_step")
+               : set_flow_lds(flow_step_kernel<false>, lds, "lfi_flow_step");
   if (rc) return rc;
-  hipLaunchKernelGGL(flow_step_kernel, dim3(lfi_cdiv(rows, MB)), dim3(256), lds, (hipStream_t)stream, f, io, reverse);
+  if (reverse) hipLaunchKernelGGL(flow_step_kernel<true>, dim3(lfi_cdiv(rows, MB)), dim3(NT), lds, (hipStream_t)stream, f, io);
+  else hipLaunchKernelGGL(flow_step_kernel<false>, dim3(lfi_cdiv(rows, MB)), dim3(NT), lds, (hipStream_t)stream, f, io);
   LFI_LAUNCH_CHECK("lfi_flow_step");
   return LFI_OK;
 }
@@ -1174,7 +1160,7 @@ extern "C" int lfi_flow_sample_seq(const lfi_flow_dims* d, const lfi_flow_params
   hipStream_t st = (hipStream_t)stream;
   const Carve cv = carve_fwd(f.C, f.H, f.Ch, f.C2, f.Cout);
   const size_t lds = (size_t)cv.total * sizeof(float);
-  rc = set_flow_lds(flow_step_kernel, lds, "lfi_flow_sample_seq");
+  rc = set_flow_lds(flow_step_kernel<true>, lds, "lfi_flow_sample_seq");
   if (rc) return rc;
   for (int n = 0; n < nframes; ++n) {
     const int t = start + n;
@@ -1210,7 +1196,7 @@ extern "C" int lfi_flow_sample_seq(const lfi_flow_dims* d, const lfi_flow_params
       io.h_out = h + (long)k * B * H;
       if (k == 0) { io.x_out = faces + (long)t * C; io.ldxo = (long)seq_len * C; }
       else { io.x_out = (k & 1) ? xa : xb; io.ldxo = C; }
-      hipLaunchKernelGGL(flow_step_kernel, dim3(f.nbt), dim3(256), lds, st, f, io, 1);
+      hipLaunchKernelGGL(flow_step_kernel<true>, dim3(f.nbt), dim3(NT), lds, st, f, io);
       xin = io.x_out; ldx = io.ldxo;
     }
   }

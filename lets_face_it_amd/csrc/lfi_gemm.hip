@@ -71,28 +71,46 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
   constexpr int EA = BM * BKT / 256, EB = BN * BKT / 256;
   float ra[EA], rb[EB];
 
+  // Per-thread element pattern, fixed for the whole k loop: element i of the staging pass is (mn_i, k_i) of the tile.
+  //   k-contiguous operand: k = tid % 16 (same for every i), mn_i = tid / 16 + 16 i
+  //   mn-contiguous operand: mn = tid % BM (same for every i), k_i = tid / BM + (256 / BM) i
+  // Addresses are a wave-uniform base (advanced once per k-tile) plus a 32-bit per-lane offset computed once, and the
+  // row/column bounds test is hoisted into a bit mask, so the k loop carries no address arithmetic in the VALU.
+  int offA[EA], offB[EB];
+  unsigned okA = 0, okB = 0;
+  int kA[EA], kB[EB];  // k index inside the tile (constant per i)
+#pragma unroll
+  for (int i = 0; i < EA; ++i) {
+    const int idx = tid + 256 * i;
+    int m, k;
+    if (AKC) { k = idx % BKT; m = idx / BKT; } else { m = idx % BM; k = idx / BM; }
+    kA[i] = k;
+    const bool ok = m0 + m < g.M;
+    okA |= (ok ? 1u : 0u) << i;
+    offA[i] = ok ? (AKC ? m * (int)g.lda + k : k * (int)g.lda + m) : 0;
+  }
+#pragma unroll
+  for (int i = 0; i < EB; ++i) {
+    const int idx = tid + 256 * i;
+    int n, k;
+    if (BKC) { k = idx % BKT; n = idx / BKT; } else { n = idx % BN; k = idx / BN; }
+    kB[i] = k;
+    const bool ok = n0 + n < g.N;
+    okB |= (ok ? 1u : 0u) << i;
+    offB[i] = ok ? (BKC ? n * (int)g.ldb + k : k * (int)g.ldb + n) : 0;
+  }
+  const float* __restrict__ tA = AKC ? A + (long)m0 * g.lda + kbeg : A + (long)kbeg * g.lda + m0;  // tile origin, uniform
+  const float* __restrict__ tB = BKC ? B + (long)n0 * g.ldb + kbeg : B + (long)kbeg * g.ldb + n0;
+  const long stepA = AKC ? BKT : (long)BKT * g.lda, stepB = BKC ? BKT : (long)BKT * g.ldb;
+
   auto load_tiles = [&](int kt) {
-    const int k0 = kbeg + kt * BKT;
+    const int krem = kend - (kbeg + kt * BKT);  // valid k in this tile (>= BKT except for the last one)
+    const float* __restrict__ pa = tA + kt * stepA;
+    const float* __restrict__ pb = tB + kt * stepB;
 #pragma unroll
-    for (int i = 0; i < EA; ++i) {
-      const int idx = tid + 256 * i;
-      int m, k;
-      if (AKC) { k = idx % BKT; m = idx / BKT; } else { m = idx % BM; k = idx / BM; }
-      const int gm = m0 + m, gk = k0 + k;
-      float v = 0.0f;
-      if (gm < g.M && gk < kend) v = AKC ? A[(long)gm * g.lda + gk] : A[(long)gk * g.lda + gm];
-      ra[i] = v;
-    }
+    for (int i = 0; i < EA; ++i) ra[i] = (((okA >> i) & 1u) && kA[i] < krem) ? pa[offA[i]] : 0.0f;
 #pragma unroll
-    for (int i = 0; i < EB; ++i) {
-      const int idx = tid + 256 * i;
-      int n, k;
-      if (BKC) { k = idx % BKT; n = idx / BKT; } else { n = idx % BN; k = idx / BN; }
-      const int gn = n0 + n, gk = k0 + k;
-      float v = 0.0f;
-      if (gn < g.N && gk < kend) v = BKC ? B[(long)gn * g.ldb + gk] : B[(long)gk * g.ldb + gn];
-      rb[i] = v;
-    }
+    for (int i = 0; i < EB; ++i) rb[i] = (((okB >> i) & 1u) && kB[i] < krem) ? pb[offB[i]] : 0.0f;
   };
   auto store_tiles = [&](int buf) {
 #pragma unroll
