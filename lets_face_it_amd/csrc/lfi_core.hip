@@ -66,44 +66,42 @@ extern "C" int lfi_selftest_mfma(int* out, void* stream) {
 }
 
 // ------------------------------------------------------------------ column sums (bias gradients)
-// stage 1: block (cx, ry) sums rows [ry*RB, ry*RB + RB) of 64 columns into part[batch][ry][col]; stage 2 adds the
-// row-blocks in order. Both fixed-order, so results are bitwise reproducible.
+// One pass: block (cx, ry) sums rows [ry*rpb, ry*rpb + rpb) of 64 columns, four row lanes per column, into
+// dst[batch][ry][col]. Two passes (rows -> <= 256 row blocks -> 1) with fixed order: bitwise reproducible.
 namespace {
-// rows per stage-1 block: at least 256, and few enough row blocks (<= 64) that stage 2's serial tail stays short
+constexpr int CS_MAX_BLOCKS = 256;
+
 int cs_rows_per_block(int rows) {
-  const int r = (rows + 63) / 64;
-  return r < 256 ? 256 : r;
+  const int r = (rows + CS_MAX_BLOCKS - 1) / CS_MAX_BLOCKS;
+  return r < 64 ? 64 : r;
 }
 
-__global__ __launch_bounds__(256) void colsum_stage1(const float* __restrict__ X, long ldx, long strideX, int rows, int cols,
-                                                     float* __restrict__ part, int nrb, int rpb) {
+__global__ __launch_bounds__(256) void colsum_pass(const float* __restrict__ X, long ldx, long strideX, int rows, int cols,
+                                                   float* __restrict__ dst, long ldd, long strideD, int rpb, float scale,
+                                                   int accumulate) {
   __shared__ float red[4][64];
   const int c = blockIdx.x * 64 + (threadIdx.x & 63);
   const int rq = threadIdx.x >> 6;
   const int rb = blockIdx.y, batch = blockIdx.z;
   const float* x = X + batch * strideX;
   const int r0 = rb * rpb, r1 = min(rows, r0 + rpb);
-  float s = 0.0f;
-  if (c < cols)
-    for (int r = r0 + rq; r < r1; r += 4) s += x[(long)r * ldx + c];
-  red[rq][threadIdx.x & 63] = s;
+  float s0 = 0.0f, s1 = 0.0f;
+  if (c < cols) {
+    int r = r0 + rq;
+    for (; r + 4 < r1; r += 8) {  // two independent chains per thread
+      s0 += x[(long)r * ldx + c];
+      s1 += x[(long)(r + 4) * ldx + c];
+    }
+    if (r < r1) s0 += x[(long)r * ldx + c];
+  }
+  red[rq][threadIdx.x & 63] = s0 + s1;
   __syncthreads();
   if (rq == 0 && c < cols) {
     const int l = threadIdx.x;
-    part[((long)batch * nrb + rb) * cols + c] = (red[0][l] + red[1][l]) + (red[2][l] + red[3][l]);
+    float v = ((red[0][l] + red[1][l]) + (red[2][l] + red[3][l])) * scale;
+    float* o = dst + batch * strideD + (long)rb * ldd + c;
+    *o = accumulate ? *o + v : v;
   }
-}
-
-__global__ __launch_bounds__(256) void colsum_stage2(const float* __restrict__ part, int nrb, int cols, float* __restrict__ out,
-                                                     long strideOut, float scale, int accumulate) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  const int batch = blockIdx.y;
-  if (c >= cols) return;
-  float s = 0.0f;
-  for (int rb = 0; rb < nrb; ++rb) s += part[((long)batch * nrb + rb) * cols + c];
-  s *= scale;
-  float* o = out + batch * strideOut + c;
-  *o = accumulate ? *o + s : s;
 }
 }  // namespace
 
@@ -118,12 +116,18 @@ extern "C" int lfi_colsum_f32(const float* X, long ldx, long strideX, int rows, 
   hipStream_t st = (hipStream_t)stream;
   const int rpb = cs_rows_per_block(rows);
   const int nrb = lfi_cdiv(rows, rpb);
-  hipLaunchKernelGGL(colsum_stage1, dim3(lfi_cdiv(cols, 64), nrb, batch), dim3(256), 0, st, X, ldx, strideX, rows, cols,
-                     work, nrb, rpb);
-  LFI_LAUNCH_CHECK("lfi_colsum_f32 stage 1");
-  hipLaunchKernelGGL(colsum_stage2, dim3(lfi_cdiv(cols, 256), batch), dim3(256), 0, st, work, nrb, cols, out, strideOut,
-                     scale, accumulate);
-  LFI_LAUNCH_CHECK("lfi_colsum_f32 stage 2");
+  if (nrb == 1) {
+    hipLaunchKernelGGL(colsum_pass, dim3(lfi_cdiv(cols, 64), 1, batch), dim3(256), 0, st, X, ldx, strideX, rows, cols, out,
+                       (long)0, strideOut, rows, scale, accumulate);
+    LFI_LAUNCH_CHECK("lfi_colsum_f32");
+    return LFI_OK;
+  }
+  hipLaunchKernelGGL(colsum_pass, dim3(lfi_cdiv(cols, 64), nrb, batch), dim3(256), 0, st, X, ldx, strideX, rows, cols, work,
+                     (long)cols, (long)nrb * cols, rpb, 1.0f, 0);
+  LFI_LAUNCH_CHECK("lfi_colsum_f32 pass 1");
+  hipLaunchKernelGGL(colsum_pass, dim3(lfi_cdiv(cols, 64), 1, batch), dim3(256), 0, st, (const float*)work, (long)cols,
+                     (long)nrb * cols, nrb, cols, out, (long)0, strideOut, nrb, scale, accumulate);
+  LFI_LAUNCH_CHECK("lfi_colsum_f32 pass 2");
   return LFI_OK;
 }
 

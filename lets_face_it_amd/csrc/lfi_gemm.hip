@@ -59,7 +59,14 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
     const int q = ntile >> 3, r = ntile & 7, xcd = bid & 7, idx = bid >> 3;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
-  const int tm = bid / g.tiles_n, tn = bid % g.tiles_n;
+  // ... and walk the tiles in groups of GM tile-rows, column by column inside a group, so the ~100 tiles an XCD has in
+  // flight form a compact GM x 12 patch: every k-slice of an A panel is shared by ~12 tiles and every B slice by GM
+  // (row-major order shared A 64 ways but B only 1.5 ways, and B panels streamed from beyond L2).
+  constexpr int GM = 8;
+  const int per_group = GM * g.tiles_n;
+  const int grp = bid / per_group, in_grp = bid - grp * per_group;
+  const int rows_here = min(GM, g.tiles_m - grp * GM);
+  const int tm = grp * GM + in_grp % rows_here, tn = in_grp / rows_here;
   const int m0 = tm * BM, n0 = tn * BN;
   const int batch = blockIdx.y, split = blockIdx.z;
   const float* __restrict__ A = g.A + batch * g.strideA;
