@@ -62,6 +62,13 @@ long lfi_colsum_work_floats(int rows, int cols, int batch);
 int lfi_colsum_f32(const float* X, long ldx, long strideX, int rows, int cols, int batch,
                    float* out, long strideOut, float scale, int accumulate, float* work, void* stream);
 
+/* Column folding. The reference's GRU encoders emit cat(seq[:, -1], h_n[0]) — the same vector twice (glow/models.py:63-64)
+ * — so cond_transform multiplies two weight column blocks by identical inputs. The engine stores each block once and
+ * folds the weights instead: dst[r][j] = src[r][a[j]] (+ src[r][b[j]] if b[j] >= 0), j < ncols. With b = NULL the same
+ * call is a plain column gather, which is how the folded weight gradient is expanded back (both copies get it). */
+int lfi_cols_fold(const float* src, long lds, long rows, const int* a, const int* b, int ncols, float* dst, long ldd,
+                  void* stream);
+
 /* ---------------------------------------------------------------- window encoders (ModalityEncoder, glow/models.py:55-80)
  * One modality: single-layer GRU from h0 = 0 over a `hist`-frame window ending at frame t (inclusive) for every
  * (sample, timestep) pair; output cat(seq[:, -1], h_n[0]) written into columns [col, col + 2*hid) of the
@@ -75,6 +82,8 @@ typedef struct {
   int B, T, N, start;   /* batch, sequence length, timesteps (T - start), first modelled frame */
   int hist, hid;        /* window length, hidden size */
   int ldcond, col;      /* leading dimension of cond and first output column */
+  int dup;              /* 1: write the state twice, columns [col, col+hid) and [col+hid, col+2*hid) as the reference's
+                           cat(seq[:, -1], h_n[0]) does; 0: once (folded feature layout, see lfi_cols_fold) */
 } lfi_enc_desc;
 
 long lfi_encode_windows_work_floats(const lfi_enc_desc* d);

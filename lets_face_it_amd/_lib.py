@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liblfi_hip.so")
+LIB_PATH = os.environ.get("LFI_LIB_PATH") or os.path.join(_HERE, "liblfi_hip.so")  # override: kernel A/B experiments
 
 c_float_p = C.POINTER(C.c_float)
 c_double_p = C.POINTER(C.c_double)
@@ -31,7 +31,7 @@ class GemmDesc(C.Structure):
 
 class EncDesc(C.Structure):
     _fields_ = [("B", C.c_int), ("T", C.c_int), ("N", C.c_int), ("start", C.c_int),
-                ("hist", C.c_int), ("hid", C.c_int), ("ldcond", C.c_int), ("col", C.c_int)]
+                ("hist", C.c_int), ("hid", C.c_int), ("ldcond", C.c_int), ("col", C.c_int), ("dup", C.c_int)]
 
 
 class FlowDims(C.Structure):
@@ -79,6 +79,7 @@ def lib():
         "lfi_gemm_f32": (i, [P(GemmDesc), vp]),
         "lfi_colsum_work_floats": (l, [i, i, i]),
         "lfi_colsum_f32": (i, [vp, l, l, i, i, i, vp, l, f, i, vp, vp]),
+        "lfi_cols_fold": (i, [vp, l, l, vp, vp, i, vp, l, vp]),
         "lfi_encode_windows_work_floats": (l, [P(EncDesc)]),
         "lfi_encode_windows_fwd": (i, [P(EncDesc), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
         "lfi_encode_windows_bwd": (i, [P(EncDesc), vp, i, vp, vp, vp, vp, vp, vp, vp]),
@@ -113,7 +114,7 @@ def lib():
 
 EXPORTS = [
     "lfi_last_error", "lfi_version", "lfi_gemm_work_floats", "lfi_gemm_f32", "lfi_colsum_work_floats",
-    "lfi_colsum_f32", "lfi_encode_windows_work_floats", "lfi_encode_windows_fwd", "lfi_encode_windows_bwd",
+    "lfi_colsum_f32", "lfi_cols_fold", "lfi_encode_windows_work_floats", "lfi_encode_windows_fwd", "lfi_encode_windows_bwd",
     "lfi_encode_windows_scatter", "lfi_gather_windows", "lfi_flow_prep_floats", "lfi_flow_prep",
     "lfi_flow_stash_floats", "lfi_flow_bstash_floats", "lfi_flow_stash_ptr", "lfi_flow_bstash_ptr",
     "lfi_flow_seq_fwd", "lfi_flow_seq_bwd", "lfi_flow_param_grads_work_floats", "lfi_flow_param_grads",

@@ -131,6 +131,34 @@ extern "C" int lfi_colsum_f32(const float* X, long ldx, long strideX, int rows, 
   return LFI_OK;
 }
 
+// ------------------------------------------------------------------ column fold / gather
+namespace {
+__global__ __launch_bounds__(256) void cols_fold_kernel(const float* __restrict__ src, long lds, long rows, const int* __restrict__ a,
+                                                        const int* __restrict__ b, int ncols, float* __restrict__ dst, long ldd) {
+  const long total = rows * ncols;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const long r = idx / ncols;
+    const int j = (int)(idx - r * ncols);
+    float v = src[r * lds + a[j]];
+    if (b) {
+      const int bj = b[j];
+      if (bj >= 0) v += src[r * lds + bj];
+    }
+    dst[r * ldd + j] = v;
+  }
+}
+}  // namespace
+
+extern "C" int lfi_cols_fold(const float* src, long lds, long rows, const int* a, const int* b, int ncols, float* dst,
+                             long ldd, void* stream) {
+  LFI_REQUIRE(src && a && dst && rows > 0 && ncols > 0, "lfi_cols_fold: bad arguments");
+  const long total = rows * ncols;
+  const int blocks = (int)(lfi_cdiv(total, 256) < 4096 ? lfi_cdiv(total, 256) : 4096);
+  hipLaunchKernelGGL(cols_fold_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, src, lds, rows, a, b, ncols, dst, ldd);
+  LFI_LAUNCH_CHECK("lfi_cols_fold");
+  return LFI_OK;
+}
+
 // ------------------------------------------------------------------ optimiser
 namespace {
 constexpr int SUMSQ_BLOCKS = 1024;

@@ -17,7 +17,7 @@
 namespace {
 
 struct EncArgs {
-  int B, T, N, start, hist, hid, ldcond, col;
+  int B, T, N, start, hist, hid, ldcond, col, dup;
   int F;
   const float* Xp;     // (B*T) x 3hid
   const float* b_ih;
@@ -61,7 +61,7 @@ __global__ __launch_bounds__(256) void enc_gate_fwd_kernel(EncArgs a, int s, con
     if (s == a.hist - 1) {  // cat(seq[:, -1], h_n[0]): the same vector twice (glow/models.py:63-64)
       float* c = a.cond + (long)w * a.ldcond + a.col;
       c[j] = hnew;
-      c[hid + j] = hnew;
+      if (a.dup) c[hid + j] = hnew;
     }
   }
 }
@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256) void enc_gate_bwd_kernel(EncArgs a, int s, con
     if (dh_in) dhn = dh_in[idx];
     else {
       const float* dc = a.dcond + (long)w * a.lddcond + a.col;
-      dhn = dc[j] + dc[hid + j];
+      dhn = a.dup ? dc[j] + dc[hid + j] : dc[j];
     }
     const long sw = (long)s * a.F + w;
     const float* gs = a.gates + sw * 4 * hid;
@@ -134,7 +134,7 @@ int fill_args(const lfi_enc_desc* d, EncArgs* a, const char* who) {
   LFI_REQUIRE(d->start + d->N <= d->T, "%s: start + N > T", who);
   LFI_REQUIRE(d->hist <= d->start + 1, "%s: window longer than start+1", who);
   a->B = d->B; a->T = d->T; a->N = d->N; a->start = d->start; a->hist = d->hist; a->hid = d->hid;
-  a->ldcond = d->ldcond; a->col = d->col;
+  a->ldcond = d->ldcond; a->col = d->col; a->dup = d->dup;
   a->F = d->N * d->B;
   return LFI_OK;
 }

@@ -17,7 +17,13 @@
 
 namespace {
 
-constexpr int BKT = 16;  // k-tile
+#ifndef LFI_GEMM_BKT
+#define LFI_GEMM_BKT 16
+#endif
+#ifndef LFI_GEMM_LDSPIPE
+#define LFI_GEMM_LDSPIPE 1
+#endif
+constexpr int BKT = LFI_GEMM_BKT;  // k-tile
 constexpr int LPAD = 4;
 
 struct GemmArgs {
@@ -153,6 +159,32 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
   for (int kt = 0; kt < nkt; ++kt) {
     const int buf = kt & 1;
     if (kt + 1 < nkt) load_tiles(kt + 1);
+#if LFI_GEMM_LDSPIPE
+    // fragments of k-step s+1 are read from LDS before the MFMAs of k-step s issue: the waves a SIMD holds run in
+    // lock step (same code, launched together), so an LDS round trip that is exposed in one wave is exposed in all
+    float fa[2][2], fb[2][2];
+    fa[0][0] = As[buf][half][wm * 64 + l31];
+    fa[0][1] = As[buf][half][wm * 64 + 32 + l31];
+    fb[0][0] = Bs[buf][half][wn * 64 + l31];
+    fb[0][1] = Bs[buf][half][wn * 64 + 32 + l31];
+#pragma unroll
+    for (int s2 = 0; s2 < BKT / 2; ++s2) {
+      const int c = s2 & 1, n = c ^ 1;
+      if (s2 + 1 < BKT / 2) {
+        const int kk = 2 * (s2 + 1) + half;
+        fa[n][0] = As[buf][kk][wm * 64 + l31];
+        fa[n][1] = As[buf][kk][wm * 64 + 32 + l31];
+        fb[n][0] = Bs[buf][kk][wn * 64 + l31];
+        fb[n][1] = Bs[buf][kk][wn * 64 + 32 + l31];
+      }
+      acc[0][0] = mfma32(fa[c][0], fb[c][0], acc[0][0]);
+      acc[0][1] = mfma32(fa[c][0], fb[c][1], acc[0][1]);
+      acc[1][0] = mfma32(fa[c][1], fb[c][0], acc[1][0]);
+      acc[1][1] = mfma32(fa[c][1], fb[c][1], acc[1][1]);
+      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);  // the next step's two ds_read2 ...
+      __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);  // ... ahead of this step's four MFMAs
+    }
+#else
 #pragma unroll
     for (int kk = 0; kk < BKT; kk += 2) {
       const float a0 = As[buf][kk + half][wm * 64 + l31];
@@ -164,6 +196,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
       acc[1][0] = mfma32(a1, b0, acc[1][0]);
       acc[1][1] = mfma32(a1, b1, acc[1][1]);
     }
+#endif
     if (kt + 1 < nkt) store_tiles(buf ^ 1);
     __syncthreads();
   }

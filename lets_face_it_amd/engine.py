@@ -87,6 +87,19 @@ class ModelSpec:
         self.I = self.Ch + self.D
         p1 = self.encoders[0]
         self.p1_cols = p1.dim  # width of the autoregressive (prev_p1_face) block, first in the feature vector
+        # folded feature layout: a GRU encoder's output appears twice in the reference's vector (cat(seq[:, -1], h_n[0]),
+        # models.py:63-64); the engine stores it once and adds the two weight column blocks instead (lfi_cols_fold)
+        fcol, self.fold_a, self.fold_b, self.unfold = 0, [], [], []
+        for e in self.encoders:
+            e.fcol = fcol
+            e.fdim = e.hid if e.enc == "rnn" else e.dim
+            for j in range(e.fdim):
+                self.fold_a.append(e.col + j)
+                self.fold_b.append(e.col + e.hid + j if e.enc == "rnn" else -1)
+            self.unfold += [fcol + (j % e.fdim) for j in range(e.dim)]
+            fcol += e.fdim
+        self.Ef = fcol
+        self.ldf = (fcol + 15) // 16 * 16  # row stride of the folded feature matrix / weights (16-float aligned)
 
     def flow_shapes(self):
         Ks, C, H, D, E, G, I, Cout = self.Ks, self.C, self.H, self.D, self.E, self.G, self.I, self.Cout
@@ -139,6 +152,11 @@ class GlowEngine:
         self.inv_sign = torch.zeros(spec.Ks, spec.C, **f32)
         self.sumsq = torch.zeros(1, dtype=torch.float64, device=self.device)
         self.sumsq_work = torch.zeros(1024, dtype=torch.float64, device=self.device)
+        i32 = dict(dtype=torch.int32, device=self.device)
+        self.fold_a = torch.tensor(spec.fold_a, **i32)
+        self.fold_b = torch.tensor(spec.fold_b, **i32)
+        self.unfold = torch.tensor(spec.unfold, **i32)
+        self.wct_f = torch.zeros(spec.Ks * spec.D, spec.ldf, **f32)  # folded cond_transform weights, rebuilt by run_prep
         self._ws = {}
         self.prep = None
         self._last = None
@@ -246,6 +264,9 @@ class GlowEngine:
         p = self._flow_params()
         check(self.L.lfi_flow_prep(C.byref(d), C.byref(p), self.prep.data_ptr(), 1 if with_inverse else 0, _stream()),
               "lfi_flow_prep")
+        s = self.spec
+        check(self.L.lfi_cols_fold(self.fview("wct").data_ptr(), s.E, s.Ks * s.D, self.fold_a.data_ptr(),
+                                   self.fold_b.data_ptr(), s.Ef, self.wct_f.data_ptr(), s.ldf, _stream()), "lfi_cols_fold")
 
     # ------------------------------------------------------------------ conditioning
     def _check_input(self, x, name, B, Tmin, dim):
@@ -255,7 +276,7 @@ class GlowEngine:
                              % (name, B, Tmin, dim, tuple(x.shape), x.dtype, x.device))
 
     def build_features(self, data, faces, B, T, masks, cond, with_stash, skip_p1=False):
-        """FeatureEncoder.forward for every timestep at once (models.py:127-145): fills cond (F x E)."""
+        """FeatureEncoder.forward for every timestep at once (models.py:127-145): fills cond (F x ldf, folded layout)."""
         s = self.spec
         N = T - s.start
         F = N * B
@@ -269,7 +290,7 @@ class GlowEngine:
                     continue
                 self._check_input(faces, "p1_face", B, T, s.C)
                 check(self.L.lfi_gather_windows(faces.data_ptr(), B, faces.shape[1], s.C, N, s.start, e.hist, 0,
-                                                cond.data_ptr(), s.E, e.col, st), "lfi_gather_windows")
+                                                cond.data_ptr(), s.ldf, e.fcol, st), "lfi_gather_windows")
                 continue
             x = data.get(e.name)
             if x is None:
@@ -278,7 +299,7 @@ class GlowEngine:
             Tx = x.shape[1]
             if e.enc == "none":
                 check(self.L.lfi_gather_windows(x.data_ptr(), B, Tx, e.in_dim, N, s.start, e.hist, 1,
-                                                cond.data_ptr(), s.E, e.col, st), "lfi_gather_windows")
+                                                cond.data_ptr(), s.ldf, e.fcol, st), "lfi_gather_windows")
                 continue
             hid = e.hid
             # input projection hoisted over the B*Tx distinct frames (no bias: it is added after the dropout mask)
@@ -287,7 +308,7 @@ class GlowEngine:
                       xp, 3 * hid)
             gates = self._buf("enc_gates." + e.name, e.hist * F * 4 * hid) if with_stash else None
             hseq = self._buf("enc_hseq." + e.name, e.hist * F * hid)
-            d = EncDesc(B, Tx, N, s.start, e.hist, hid, s.E, e.col)
+            d = EncDesc(B, Tx, N, s.start, e.hist, hid, s.ldf, e.fcol, 0)
             work = self._buf("scratch.enc", self.L.lfi_encode_windows_work_floats(C.byref(d)))
             mk = None if masks is None else masks.get(e.name)
             if mk is not None and not (tuple(mk.shape) == (N, B, e.hist) and mk.is_contiguous()
@@ -303,7 +324,7 @@ class GlowEngine:
         s = self.spec
         KD = s.Ks * s.D
         cbuf = self._buf("c", F * KD)
-        self.gemm(F, KD, s.E, cond, s.E, 1, self.fview("wct"), s.E, 1, cbuf, KD, bias=self.fview("bct"), act=1, slope=0.01,
+        self.gemm(F, KD, s.Ef, cond, s.ldf, 1, self.wct_f, s.ldf, 1, cbuf, KD, bias=self.fview("bct"), act=1, slope=0.01,
                   tag="gemm_cond_fwd")
         gic = self._buf("gic", s.Ks * F * s.G)
         self.gemm(F, s.G, s.D, cbuf, KD, 1, self.fview("w_ih"), s.I, 1, gic, s.G, bias=self.fview("b_ih"),
@@ -321,7 +342,7 @@ class GlowEngine:
             raise ValueError("sequence length %d does not exceed the longest history %d" % (T, s.start))
         F = N * B
         self.run_prep()
-        cond = self._buf("cond", F * s.E)
+        cond = self._buf("cond", F * s.ldf)
         self.build_features(batch, x, B, T, masks, cond, with_stash)
         cbuf, gic = self._project(cond, F)
         dims = self._flow_dims(B, N)
@@ -388,17 +409,22 @@ class GlowEngine:
                   batch=s.Ks, sA=F * s.G, sB=s.G * s.I, sC=s.D, sG=s.D, a_off=dgi_off, b_off=s.Ch)
         dpre = ctx.cbuf
         # cond_transform weight / bias gradients for all steps at once
-        self.gemm(KD, s.E, F, dpre, KD, 0, ctx.cond, s.E, 0, self.fview("wct", self.grads), s.E, tag="gemm_cond_wgrad")
+        dwf = self._buf("dwct_f", KD * s.ldf)
+        self.gemm(KD, s.Ef, F, dpre, KD, 0, ctx.cond, s.ldf, 0, dwf, s.ldf, tag="gemm_cond_wgrad")
+        # both copies of a duplicated input column receive the folded column's gradient
+        check(self.L.lfi_cols_fold(dwf.data_ptr(), s.ldf, KD, self.unfold.data_ptr(), None, s.E,
+                                   self.fview("wct", self.grads).data_ptr(), s.E, st), "lfi_cols_fold")
         self.colsum(dpre, KD, 0, F, KD, 1, self.fview("bct", self.grads), 0)
         # gradient of the feature matrix, encoder columns only (prev_p1_face is data)
         rnn = [e for e in s.encoders if e.enc == "rnn"]
         if rnn:
-            col0 = min(e.col for e in rnn)
-            W = s.E - col0
-            dcond = self._buf("dcond", F * W)
-            self.gemm(F, W, KD, dpre, KD, 1, self.fview("wct"), s.E, 0, dcond, W, b_off=col0, tag="gemm_cond_dgrad")
+            col0 = min(e.fcol for e in rnn)
+            W = s.Ef - col0
+            ldd = (W + 3) // 4 * 4
+            dcond = self._buf("dcond", F * ldd)
+            self.gemm(F, W, KD, dpre, KD, 1, self.wct_f, s.ldf, 0, dcond, ldd, b_off=col0, tag="gemm_cond_dgrad")
             for e in rnn:
-                self._encoder_backward(e, ctx, dcond, W, e.col - col0)
+                self._encoder_backward(e, ctx, dcond, ldd, e.fcol - col0)
 
     def _encoder_backward(self, e, ctx, dcond, lddcond, col):
         s = self.spec
@@ -406,7 +432,7 @@ class GlowEngine:
         x = ctx.batch[e.name]
         Tx, hid, G3 = x.shape[1], e.hid, 3 * e.hid
         st = _stream()
-        d = EncDesc(B, Tx, N, s.start, e.hist, hid, lddcond, col)
+        d = EncDesc(B, Tx, N, s.start, e.hist, hid, lddcond, col, 0)
         gates = self._ws["enc_gates." + e.name]
         hseq = self._ws["enc_hseq." + e.name]
         dgi = self._buf("enc_dgi." + e.name, e.hist * F * G3)
@@ -472,12 +498,12 @@ class GlowEngine:
         faces[:, :s.start].copy_(seed[:, :s.start])
         self.run_prep(with_inverse=True)
         # everything of the features that does not depend on generated frames, through cond_transform (no activation yet)
-        cond = self._buf("cond", F * s.E)
+        cond = self._buf("cond", F * s.ldf)
         self.build_features(data, None, B, seq_len, masks, cond, with_stash=False, skip_p1=True)
         c1 = s.p1_cols
         pre = self._buf("pre_static", F * KD)
-        if s.E > c1:
-            self.gemm(F, KD, s.E - c1, cond, s.E, 1, self.fview("wct"), s.E, 1, pre, KD, bias=self.fview("bct"),
+        if s.Ef > c1:
+            self.gemm(F, KD, s.Ef - c1, cond, s.ldf, 1, self.wct_f, s.ldf, 1, pre, KD, bias=self.fview("bct"),
                       a_off=c1, b_off=c1)
         else:
             pre[:F * KD].view(F, KD).copy_(self.fview("bct").reshape(1, KD).expand(F, KD))
@@ -486,8 +512,8 @@ class GlowEngine:
         work = self._buf("scratch.sample", self.L.lfi_flow_sample_work_floats(C.byref(dims)))
         p = self._flow_params()
         hist1 = s.encoders[0].hist
-        check(self.L.lfi_flow_sample_seq(C.byref(dims), C.byref(p), self.prep.data_ptr(), self.fview("wct").data_ptr(),
-                                         s.E, hist1, pre.data_ptr(), noise.data_ptr(), faces.data_ptr(), seq_len, s.start,
+        check(self.L.lfi_flow_sample_seq(C.byref(dims), C.byref(p), self.prep.data_ptr(), self.wct_f.data_ptr(),
+                                         s.ldf, hist1, pre.data_ptr(), noise.data_ptr(), faces.data_ptr(), seq_len, s.start,
                                          nframes, h.data_ptr(), work.data_ptr(), _stream()), "lfi_flow_sample_seq")
         return faces[:, s.start:]
 
@@ -500,7 +526,7 @@ class GlowEngine:
         F = N * B
         Tn = s.start + N
         self.run_prep(with_inverse=True)
-        cond = self._buf("cond", F * s.E)
+        cond = self._buf("cond", F * s.ldf)
         self.build_features(batch, x, B, Tn, masks, cond, with_stash=False)
         _, gic = self._project(cond, F)
         dims = self._flow_dims(B, N)
