@@ -24,7 +24,6 @@ namespace {
 #define LFI_GEMM_LDSPIPE 1
 #endif
 constexpr int BKT = LFI_GEMM_BKT;  // k-tile
-constexpr int LPAD = 4;
 
 struct GemmArgs {
   int M, N, K;
@@ -39,6 +38,7 @@ struct GemmArgs {
   int splitk, kchunk;
   float* work;
   int tiles_m, tiles_n;
+  int vecA, vecB;  // operand rows are 16-byte aligned and 4-float granular: 16-byte global loads are legal
 };
 
 __device__ __forceinline__ float apply_act(float v, int act, float slope, const float* G, long gidx) {
@@ -47,18 +47,86 @@ __device__ __forceinline__ float apply_act(float v, int act, float slope, const 
   return v;
 }
 
-template <int BM, int BN, int WM, int WN, bool AKC, bool BKC>
+// LDS images (floats). A k-contiguous operand keeps its rows: [mn][BKT + 4] (80-byte rows: 16-B aligned for
+// ds_write_b128 / ds_read_b128, and 5*row mod 16 distinct over any 16 rows mod 16 -> conflict-free b128 reads). An
+// mn-contiguous operand is stored [k][mn + 4] and read with ds_read_b32. Both are filled with 16-byte loads/stores when
+// the operand is 16-byte aligned (vec flag), with four guarded scalar loads per float4 otherwise.
+// The k index an MFMA slot multiplies is permuted identically for both operands (a sum over k does not care):
+// within a group of 8 k, lane half h at MFMA step t (0..3) takes k = 8q + 4h + t, so a k-contiguous operand's four
+// steps are ONE float4 read.
+constexpr int KROW = BKT + 4;
+
+template <int BMN, bool KC>
+struct Stager {
+  static constexpr int NF4 = BMN * BKT / 4 / 256;  // float4 per thread per k-tile
+  static constexpr int LDS_FLOATS = KC ? BMN * KROW : BKT * (BMN + 4);
+  int off[NF4];        // element offset of the float4 from the tile origin (32-bit)
+  int kk[NF4];         // first k of the float4 inside the tile (KC) / the k row (!KC)
+  int lds[NF4];        // float offset in the LDS image
+  unsigned ok;         // bit i: the float4's mn index is inside the matrix
+  __device__ __forceinline__ void init(int tid, int mn0, int MN, long ld) {
+    ok = 0;
+#pragma unroll
+    for (int i = 0; i < NF4; ++i) {
+      const int f = tid + 256 * i;
+      int mn, k;
+      if (KC) { k = (f % (BKT / 4)) * 4; mn = f / (BKT / 4); } else { mn = (f % (BMN / 4)) * 4; k = f / (BMN / 4); }
+      kk[i] = k;
+      lds[i] = KC ? mn * KROW + k : k * (BMN + 4) + mn;
+      const bool in = mn0 + mn < MN;
+      ok |= (in ? 1u : 0u) << i;
+      off[i] = in ? (KC ? mn * (int)ld + k : k * (int)ld + mn) : 0;
+    }
+  }
+  // p: tile origin for this k-tile; krem: valid k in this tile; mnrem: valid mn from the tile origin.
+  // Loads are predicated, never branched around, and nothing here consumes a loaded value: the loads of tile t+1 stay
+  // in flight under the MFMAs of tile t. The tail masking of a partly valid float4 happens in store().
+  template <bool VEC>
+  __device__ __forceinline__ void load(const float* __restrict__ p, int krem, int mnrem, f32x4 (&r)[NF4]) const {
+#pragma unroll
+    for (int i = 0; i < NF4; ++i) {
+      const bool in = ((ok >> i) & 1u) && kk[i] < krem;
+      if (VEC) {
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        r[i] = in ? *reinterpret_cast<const f32x4*>(p + off[i]) : z;
+      } else if (KC) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) r[i][j] = (in && kk[i] + j < krem) ? p[off[i] + j] : 0.0f;
+      } else {
+        const int mn = lds[i] - kk[i] * (BMN + 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) r[i][j] = (in && mn + j < mnrem) ? p[off[i] + j] : 0.0f;
+      }
+    }
+  }
+  template <bool VEC>
+  __device__ __forceinline__ void store(float* img, int krem, f32x4 (&r)[NF4]) const {
+#pragma unroll
+    for (int i = 0; i < NF4; ++i) {
+      if (VEC && KC) {  // a 16-byte load may have run past K inside the row: zero those lanes
+#pragma unroll
+        for (int j = 1; j < 4; ++j) r[i][j] = (kk[i] + j < krem) ? r[i][j] : 0.0f;
+      }
+      *reinterpret_cast<f32x4*>(img + lds[i]) = r[i];
+    }
+  }
+};
+
+template <int BM, int BN, int WM, int WN, bool AKC, bool BKC, bool VEC>
 __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
   static_assert(WM * WN == 4 && BM == WM * 64 && BN == WN * 64, "wave tile is 64 x 64");
-  __shared__ float As[2][BKT][BM + LPAD];
-  __shared__ float Bs[2][BKT][BN + LPAD];
+  static_assert(BKT == 16, "fragment reads assume two groups of 8 k per tile");
+  using SA = Stager<BM, AKC>;
+  using SB = Stager<BN, BKC>;
+  __shared__ __attribute__((aligned(16))) float As[2][SA::LDS_FLOATS];
+  __shared__ __attribute__((aligned(16))) float Bs[2][SB::LDS_FLOATS];
 
   const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, half = lane >> 5;
 
   // XCD-aware tile order: blocks b, b+8, ... share an XCD (round-robin dispatch); give each XCD a contiguous run of
-  // tiles (bijective also when the tile count is not a multiple of 8).
+  // tiles (bijective also when the tile count is not a multiple of 8) ...
   const int ntile = g.tiles_m * g.tiles_n;
   int bid = blockIdx.x;
   {
@@ -66,8 +134,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
   // ... and walk the tiles in groups of GM tile-rows, column by column inside a group, so the ~100 tiles an XCD has in
-  // flight form a compact GM x 12 patch: every k-slice of an A panel is shared by ~12 tiles and every B slice by GM
-  // (row-major order shared A 64 ways but B only 1.5 ways, and B panels streamed from beyond L2).
+  // flight form a compact GM x 12 patch (every k-slice of an A panel is shared by ~12 tiles, every B slice by GM).
   constexpr int GM = 8;
   const int per_group = GM * g.tiles_n;
   const int grp = bid / per_group, in_grp = bid - grp * per_group;
@@ -81,65 +148,25 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
   const int kend = min(g.K, kbeg + g.kchunk);
   const int nkt = (kend - kbeg + BKT - 1) / BKT;
 
-  constexpr int EA = BM * BKT / 256, EB = BN * BKT / 256;
-  float ra[EA], rb[EB];
-
-  // Per-thread element pattern, fixed for the whole k loop: element i of the staging pass is (mn_i, k_i) of the tile.
-  //   k-contiguous operand: k = tid % 16 (same for every i), mn_i = tid / 16 + 16 i
-  //   mn-contiguous operand: mn = tid % BM (same for every i), k_i = tid / BM + (256 / BM) i
-  // Addresses are a wave-uniform base (advanced once per k-tile) plus a 32-bit per-lane offset computed once, and the
-  // row/column bounds test is hoisted into a bit mask, so the k loop carries no address arithmetic in the VALU.
-  int offA[EA], offB[EB];
-  unsigned okA = 0, okB = 0;
-  int kA[EA], kB[EB];  // k index inside the tile (constant per i)
-#pragma unroll
-  for (int i = 0; i < EA; ++i) {
-    const int idx = tid + 256 * i;
-    int m, k;
-    if (AKC) { k = idx % BKT; m = idx / BKT; } else { m = idx % BM; k = idx / BM; }
-    kA[i] = k;
-    const bool ok = m0 + m < g.M;
-    okA |= (ok ? 1u : 0u) << i;
-    offA[i] = ok ? (AKC ? m * (int)g.lda + k : k * (int)g.lda + m) : 0;
-  }
-#pragma unroll
-  for (int i = 0; i < EB; ++i) {
-    const int idx = tid + 256 * i;
-    int n, k;
-    if (BKC) { k = idx % BKT; n = idx / BKT; } else { n = idx % BN; k = idx / BN; }
-    kB[i] = k;
-    const bool ok = n0 + n < g.N;
-    okB |= (ok ? 1u : 0u) << i;
-    offB[i] = ok ? (BKC ? n * (int)g.ldb + k : k * (int)g.ldb + n) : 0;
-  }
+  SA sa;
+  SB sb;
+  sa.init(tid, m0, g.M, g.lda);
+  sb.init(tid, n0, g.N, g.ldb);
   const float* __restrict__ tA = AKC ? A + (long)m0 * g.lda + kbeg : A + (long)kbeg * g.lda + m0;  // tile origin, uniform
   const float* __restrict__ tB = BKC ? B + (long)n0 * g.ldb + kbeg : B + (long)kbeg * g.ldb + n0;
   const long stepA = AKC ? BKT : (long)BKT * g.lda, stepB = BKC ? BKT : (long)BKT * g.ldb;
+  const int mrem = g.M - m0, nrem = g.N - n0;
 
+  f32x4 ra[SA::NF4], rb[SB::NF4];
   auto load_tiles = [&](int kt) {
-    const int krem = kend - (kbeg + kt * BKT);  // valid k in this tile (>= BKT except for the last one)
-    const float* __restrict__ pa = tA + kt * stepA;
-    const float* __restrict__ pb = tB + kt * stepB;
-#pragma unroll
-    for (int i = 0; i < EA; ++i) ra[i] = (((okA >> i) & 1u) && kA[i] < krem) ? pa[offA[i]] : 0.0f;
-#pragma unroll
-    for (int i = 0; i < EB; ++i) rb[i] = (((okB >> i) & 1u) && kB[i] < krem) ? pb[offB[i]] : 0.0f;
+    const int krem = kend - (kbeg + kt * BKT);
+    sa.template load<VEC>(tA + kt * stepA, krem, mrem, ra);
+    sb.template load<VEC>(tB + kt * stepB, krem, nrem, rb);
   };
-  auto store_tiles = [&](int buf) {
-#pragma unroll
-    for (int i = 0; i < EA; ++i) {
-      const int idx = tid + 256 * i;
-      int m, k;
-      if (AKC) { k = idx % BKT; m = idx / BKT; } else { m = idx % BM; k = idx / BM; }
-      As[buf][k][m] = ra[i];
-    }
-#pragma unroll
-    for (int i = 0; i < EB; ++i) {
-      const int idx = tid + 256 * i;
-      int n, k;
-      if (BKC) { k = idx % BKT; n = idx / BKT; } else { n = idx % BN; k = idx / BN; }
-      Bs[buf][k][n] = rb[i];
-    }
+  auto store_tiles = [&](int kt, int buf) {
+    const int krem = kend - (kbeg + kt * BKT);
+    sa.template store<VEC>(As[buf], krem, ra);
+    sb.template store<VEC>(Bs[buf], krem, rb);
   };
 
   const int wm = wave / WN, wn = wave % WN;
@@ -153,51 +180,42 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
 
   if (nkt > 0) {
     load_tiles(0);
-    store_tiles(0);
+    store_tiles(0, 0);
   }
   __syncthreads();
   for (int kt = 0; kt < nkt; ++kt) {
     const int buf = kt & 1;
     if (kt + 1 < nkt) load_tiles(kt + 1);
-#if LFI_GEMM_LDSPIPE
-    // fragments of k-step s+1 are read from LDS before the MFMAs of k-step s issue: the waves a SIMD holds run in
-    // lock step (same code, launched together), so an LDS round trip that is exposed in one wave is exposed in all
-    float fa[2][2], fb[2][2];
-    fa[0][0] = As[buf][half][wm * 64 + l31];
-    fa[0][1] = As[buf][half][wm * 64 + 32 + l31];
-    fb[0][0] = Bs[buf][half][wn * 64 + l31];
-    fb[0][1] = Bs[buf][half][wn * 64 + 32 + l31];
+    const float* as = As[buf];
+    const float* bs = Bs[buf];
 #pragma unroll
-    for (int s2 = 0; s2 < BKT / 2; ++s2) {
-      const int c = s2 & 1, n = c ^ 1;
-      if (s2 + 1 < BKT / 2) {
-        const int kk = 2 * (s2 + 1) + half;
-        fa[n][0] = As[buf][kk][wm * 64 + l31];
-        fa[n][1] = As[buf][kk][wm * 64 + 32 + l31];
-        fb[n][0] = Bs[buf][kk][wn * 64 + l31];
-        fb[n][1] = Bs[buf][kk][wn * 64 + 32 + l31];
+    for (int q = 0; q < 2; ++q) {
+      f32x4 fa[2], fb[2];
+#pragma unroll
+      for (int t2 = 0; t2 < 2; ++t2) {
+        const int row = wm * 64 + t2 * 32 + l31, col = wn * 64 + t2 * 32 + l31;
+        if (AKC) {
+          fa[t2] = *reinterpret_cast<const f32x4*>(as + row * KROW + 8 * q + 4 * half);
+        } else {
+#pragma unroll
+          for (int t = 0; t < 4; ++t) fa[t2][t] = as[(8 * q + 4 * half + t) * (BM + 4) + row];
+        }
+        if (BKC) {
+          fb[t2] = *reinterpret_cast<const f32x4*>(bs + col * KROW + 8 * q + 4 * half);
+        } else {
+#pragma unroll
+          for (int t = 0; t < 4; ++t) fb[t2][t] = bs[(8 * q + 4 * half + t) * (BN + 4) + col];
+        }
       }
-      acc[0][0] = mfma32(fa[c][0], fb[c][0], acc[0][0]);
-      acc[0][1] = mfma32(fa[c][0], fb[c][1], acc[0][1]);
-      acc[1][0] = mfma32(fa[c][1], fb[c][0], acc[1][0]);
-      acc[1][1] = mfma32(fa[c][1], fb[c][1], acc[1][1]);
-      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);  // the next step's two ds_read2 ...
-      __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);  // ... ahead of this step's four MFMAs
-    }
-#else
 #pragma unroll
-    for (int kk = 0; kk < BKT; kk += 2) {
-      const float a0 = As[buf][kk + half][wm * 64 + l31];
-      const float a1 = As[buf][kk + half][wm * 64 + 32 + l31];
-      const float b0 = Bs[buf][kk + half][wn * 64 + l31];
-      const float b1 = Bs[buf][kk + half][wn * 64 + 32 + l31];
-      acc[0][0] = mfma32(a0, b0, acc[0][0]);
-      acc[0][1] = mfma32(a0, b1, acc[0][1]);
-      acc[1][0] = mfma32(a1, b0, acc[1][0]);
-      acc[1][1] = mfma32(a1, b1, acc[1][1]);
+      for (int t = 0; t < 4; ++t) {
+        acc[0][0] = mfma32(fa[0][t], fb[0][t], acc[0][0]);
+        acc[0][1] = mfma32(fa[0][t], fb[1][t], acc[0][1]);
+        acc[1][0] = mfma32(fa[1][t], fb[0][t], acc[1][0]);
+        acc[1][1] = mfma32(fa[1][t], fb[1][t], acc[1][1]);
+      }
     }
-#endif
-    if (kt + 1 < nkt) store_tiles(buf ^ 1);
+    if (kt + 1 < nkt) store_tiles(kt + 1, buf ^ 1);
     __syncthreads();
   }
 
@@ -249,12 +267,17 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(GemmArgs g) {
   }
 }
 
+template <int BM, int BN, int WM, int WN, bool VEC>
+void launch_gemm_v(const GemmArgs& a, int akc, int bkc, dim3 grid, hipStream_t st) {
+  if (akc && bkc) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, true, true, VEC>), grid, dim3(256), 0, st, a);
+  else if (akc && !bkc) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, true, false, VEC>), grid, dim3(256), 0, st, a);
+  else if (!akc && bkc) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, false, true, VEC>), grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, false, false, VEC>), grid, dim3(256), 0, st, a);
+}
 template <int BM, int BN, int WM, int WN>
 void launch_gemm(const GemmArgs& a, int akc, int bkc, dim3 grid, hipStream_t st) {
-  if (akc && bkc) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, true, true>), grid, dim3(256), 0, st, a);
-  else if (akc && !bkc) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, true, false>), grid, dim3(256), 0, st, a);
-  else if (!akc && bkc) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, false, true>), grid, dim3(256), 0, st, a);
-  else hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, false, false>), grid, dim3(256), 0, st, a);
+  if (a.vecA && a.vecB) launch_gemm_v<BM, BN, WM, WN, true>(a, akc, bkc, grid, st);
+  else launch_gemm_v<BM, BN, WM, WN, false>(a, akc, bkc, grid, st);
 }
 
 int kchunk_for(int K, int splitk) {
@@ -299,6 +322,17 @@ extern "C" int lfi_gemm_f32(const lfi_gemm_desc* d, void* stream) {
   const int bm = shape == 0 ? 128 : (shape == 1 ? 256 : 64), bn = shape == 0 ? 128 : (shape == 1 ? 64 : 256);
   a.tiles_m = lfi_cdiv(d->M, bm);
   a.tiles_n = lfi_cdiv(d->N, bn);
+  // 16-byte loads need: leading dimension and batch stride multiples of 4 floats, base 16-byte aligned (checked per block
+  // on the device too), every k chunk starting on a multiple of 4 (kchunk is a multiple of 16), and for an
+  // mn-contiguous operand a row count that is a multiple of 4 so no float4 straddles the matrix edge. A k-contiguous
+  // operand may read up to 3 floats past K inside its own row: the row stride must cover them.
+  auto vec_ok = [](const float* p, long ld, long stride, int kcontig, int mn, int K) {
+    if ((reinterpret_cast<uintptr_t>(p) & 15) || (ld & 3) || (stride & 3)) return 0;
+    if (kcontig) return ld >= ((long)(K + 3) / 4) * 4 ? 1 : 0;
+    return (mn & 3) == 0 ? 1 : 0;
+  };
+  a.vecA = vec_ok(d->A, d->lda, d->strideA, d->a_kcontig, d->M, d->K);
+  a.vecB = vec_ok(d->B, d->ldb, d->strideB, d->b_kcontig, d->N, d->K);
   dim3 grid(a.tiles_m * a.tiles_n, d->batch, splitk);
   if (shape == 0) launch_gemm<128, 128, 2, 2>(a, d->a_kcontig, d->b_kcontig, grid, st);
   else if (shape == 1) launch_gemm<256, 64, 4, 1>(a, d->a_kcontig, d->b_kcontig, grid, st);

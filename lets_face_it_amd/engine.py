@@ -250,6 +250,12 @@ class GlowEngine:
         check(self.L.lfi_gemm_f32(C.byref(g), _stream()), "lfi_gemm_f32")
         self._toc(tag, ev)
 
+    @staticmethod
+    def _fill_splitk(M, N, K, batch=1):
+        """Split K so that a long-K product with few output tiles still gives every CU ~3 workgroups (256 CUs)."""
+        tiles = ((M + 127) // 128) * ((N + 127) // 128) * batch
+        return max(1, min(16, 768 // max(tiles, 1), K // 1024))
+
     def colsum(self, X, ldx, strideX, rows, cols, batch, out, strideOut, scale=1.0, accumulate=0, x_off=0):
         w = self._buf("scratch.colsum", self.L.lfi_colsum_work_floats(rows, cols, batch))
         check(self.L.lfi_colsum_f32(X.data_ptr() + 4 * x_off, ldx, strideX, rows, cols, batch, out.data_ptr(), strideOut,
@@ -410,7 +416,8 @@ class GlowEngine:
         dpre = ctx.cbuf
         # cond_transform weight / bias gradients for all steps at once
         dwf = self._buf("dwct_f", KD * s.ldf)
-        self.gemm(KD, s.Ef, F, dpre, KD, 0, ctx.cond, s.ldf, 0, dwf, s.ldf, tag="gemm_cond_wgrad")
+        self.gemm(KD, s.Ef, F, dpre, KD, 0, ctx.cond, s.ldf, 0, dwf, s.ldf, tag="gemm_cond_wgrad",
+                  splitk=self._fill_splitk(KD, s.Ef, F))
         # both copies of a duplicated input column receive the folded column's gradient
         check(self.L.lfi_cols_fold(dwf.data_ptr(), s.ldf, KD, self.unfold.data_ptr(), None, s.E,
                                    self.fview("wct", self.grads).data_ptr(), s.E, st), "lfi_cols_fold")

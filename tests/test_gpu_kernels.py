@@ -83,6 +83,33 @@ def test_gemm_strided_views(eng, gpu_device):
     assert rel_err(gic, ref) < 2e-6
 
 
+@pytest.mark.parametrize("akc,bkc", [(1, 1), (1, 0), (0, 1), (0, 0)])
+def test_gemm_padded_rows_take_the_16_byte_path(eng, gpu_device, akc, bkc):
+    """Row strides that are multiples of 4 floats with K / M / N not filling them (folded feature matrix: 890 of 896)."""
+    g = torch.Generator().manual_seed(17 + 2 * akc + bkc)
+    M, N, K = 260, 136, 890
+    lda = 896 if akc else 264
+    ldb = 896 if bkc else 144
+    A = torch.full((M, lda) if akc else (K, lda), float("nan"))
+    Bm = torch.full((N, ldb) if bkc else (K, ldb), float("nan"))
+    if akc:
+        A[:, :K] = torch.randn(M, K, generator=g)
+    else:
+        A[:, :M] = torch.randn(K, M, generator=g)
+    if bkc:
+        Bm[:, :K] = torch.randn(N, K, generator=g)
+    else:
+        Bm[:, :N] = torch.randn(K, N, generator=g)
+    A, Bm = A.to(gpu_device), Bm.to(gpu_device)
+    Cm = torch.zeros(M, N, device=gpu_device)
+    eng.gemm(M, N, K, A, lda, akc, Bm, ldb, bkc, Cm, N)
+    torch.cuda.synchronize()
+    Ad = (A[:, :K] if akc else A[:, :M].t()).double()
+    Bd = (Bm[:, :K].t() if bkc else Bm[:, :N]).double()
+    assert torch.isfinite(Cm).all()
+    assert rel_err(Cm, Ad @ Bd) < 2e-6
+
+
 def test_colsum(eng, gpu_device):
     g = torch.Generator().manual_seed(3)
     X = torch.randn(3, 1000, 90, generator=g).to(gpu_device)

@@ -23,17 +23,20 @@ def main():
     from lets_face_it_amd.engine import GlowEngine, ModelSpec
     dev = torch.device("cuda:0")
     eng = GlowEngine(ModelSpec(Namespace(**Fixture("tiny").hp)), dev)
-    shapes = [("cond_fwd", 14336, 8192, 1530, 1, 1), ("cond_wgrad", 8192, 1530, 14336, 0, 0),
-              ("cond_dgrad", 14336, 1280, 8192, 1, 0), ("enc_step", 14336, 768, 256, 1, 1)]
+    shapes = [("cond_fwd", 14336, 8192, 890, 1, 1), ("cond_wgrad", 8192, 890, 14336, 0, 0),
+              ("cond_dgrad", 14336, 640, 8192, 1, 0), ("enc_step", 14336, 768, 256, 1, 1),
+              ("enc_bwd", 14336, 256, 768, 1, 0), ("enc_wgrad", 768, 256, 329728, 0, 0)]
     for sh in args.shape:
         M, N, K, a, b = [int(v) for v in sh.split(",")]
         shapes.append(("user", M, N, K, a, b))
     g = torch.Generator().manual_seed(0)
+    r16 = lambda v: (v + 15) // 16 * 16  # noqa: E731
     for name, M, N, K, akc, bkc in shapes:
-        A = torch.randn((M, K) if akc else (K, M), generator=g).to(dev)
-        Bm = torch.randn((N, K) if bkc else (K, N), generator=g).to(dev)
+        lda, ldb = (r16(K) if akc else r16(M)), (r16(K) if bkc else r16(N))  # padded rows, as the engine lays them out
+        A = torch.randn((M, lda) if akc else (K, lda), generator=g).to(dev)
+        Bm = torch.randn((N, ldb) if bkc else (K, ldb), generator=g).to(dev)
         Cm = torch.empty(M, N, device=dev)
-        run = lambda: eng.gemm(M, N, K, A, K if akc else M, akc, Bm, K if bkc else N, bkc, Cm, N)  # noqa: E731
+        run = lambda: eng.gemm(M, N, K, A, lda, akc, Bm, ldb, bkc, Cm, N)  # noqa: E731
         for _ in range(3):
             run()
         torch.cuda.synchronize()
