@@ -126,7 +126,8 @@ typedef struct {
 /* Derived weights, rebuilt once per optimiser step instead of once per (timestep, flow step) as
  * InvertibleConv1x1.get_weight does (glow/modules.py:147-178). Layout of `prep` (floats), step-major blocks:
  *   W [Ks][C][C], Wt [Ks][C][C], Winv [Ks][C][C] (reverse weight, fp64 inverse cast to fp32),
- *   wz_t [Ks][Ch][G], whh_t [Ks][H][G], wfl_t [Ks][H][Cout], logdet_const [1] = C * sum(an_logs + inv_logs) */
+ *   wz_t [Ks][Ch][G], whh_t [Ks][H][G], wfl_t [Ks][H][Cout], wc [Ks][G][D] (= W_ih[:, Ch:], 16-byte aligned copy),
+ *   logdet_const [1] = C * sum(an_logs + inv_logs) */
 long lfi_flow_prep_floats(const lfi_flow_dims* d);
 int lfi_flow_prep(const lfi_flow_dims* d, const lfi_flow_params* p, float* prep, int with_inverse, void* stream);
 

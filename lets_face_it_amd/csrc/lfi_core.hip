@@ -139,7 +139,8 @@ __global__ __launch_bounds__(256) void cols_fold_kernel(const float* __restrict_
   for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
     const long r = idx / ncols;
     const int j = (int)(idx - r * ncols);
-    float v = src[r * lds + a[j]];
+    const int aj = a[j];
+    float v = aj >= 0 ? src[r * lds + aj] : 0.0f;  // a[j] < 0: padding column
     if (b) {
       const int bj = b[j];
       if (bj >= 0) v += src[r * lds + bj];

@@ -35,7 +35,7 @@ struct FlowK {
   // params
   lfi_flow_params p;
   // prep
-  const float *W, *Wt, *Winv, *wz_t, *whh_t, *wfl_t, *ldconst;
+  const float *W, *Wt, *Winv, *wz_t, *whh_t, *wfl_t, *wc, *ldconst;
   // forward stash
   float *sA, *sY, *sX, *sH, *sG, *sO, *sL;
   // backward stash
@@ -710,11 +710,16 @@ __global__ __launch_bounds__(256) void flow_prep_invconv_kernel(FlowK f, float* 
 }
 
 __global__ __launch_bounds__(256) void flow_prep_transpose_kernel(FlowK f, float* __restrict__ wz_t, float* __restrict__ whh_t,
-                                                                  float* __restrict__ wfl_t, const float* __restrict__ ldpart,
-                                                                  float* __restrict__ ldconst) {
+                                                                  float* __restrict__ wfl_t, float* __restrict__ wc,
+                                                                  const float* __restrict__ ldpart, float* __restrict__ ldconst) {
   const int k = blockIdx.y;
-  const int G = f.G, H = f.H, Ch = f.Ch, Cout = f.Cout, I = f.I;
-  const long n1 = (long)Ch * G, n2 = (long)H * G, n3 = (long)H * Cout;
+  const int G = f.G, H = f.H, Ch = f.Ch, Cout = f.Cout, I = f.I, D = f.D;
+  const long n1 = (long)Ch * G, n2 = (long)H * G, n3 = (long)H * Cout, n4 = (long)G * D;
+  // wc[k][g][d] = w_ih[k][g][Ch + d]: the conditioning half of W_ih as its own 16-byte aligned matrix
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < n4; idx += (long)gridDim.x * 256) {
+    const int g = (int)(idx / D), dd = (int)(idx - (long)g * D);
+    wc[(long)k * n4 + idx] = f.p.w_ih[((long)k * G + g) * I + Ch + dd];
+  }
   for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < n1 + n2 + n3; idx += (long)gridDim.x * 256) {
     if (idx < n1) {
       const int c = (int)(idx / G), g = (int)(idx - (long)c * G);
@@ -840,6 +845,7 @@ int fill_flow(const lfi_flow_dims* d, const lfi_flow_params* p, const float* pre
     f->wz_t = q; q += (long)d->Ks * f->Ch * f->G;
     f->whh_t = q; q += (long)d->Ks * d->H * f->G;
     f->wfl_t = q; q += (long)d->Ks * d->H * f->Cout;
+    f->wc = q; q += (long)d->Ks * f->G * d->D;
     f->ldconst = q;
   }
   return LFI_OK;
@@ -906,7 +912,7 @@ extern "C" long lfi_flow_prep_floats(const lfi_flow_dims* d) {
   if (!d) return 0;
   const int Ch = d->C / 2, C2 = d->C - Ch, Cout = d->affine ? 2 * C2 : C2, G = (d->lstm ? 4 : 3) * d->H;
   const long cc = (long)d->Ks * d->C * d->C;
-  long n = 3 * cc + (long)d->Ks * Ch * G + (long)d->Ks * d->H * G + (long)d->Ks * d->H * Cout + 4;
+  long n = 3 * cc + (long)d->Ks * Ch * G + (long)d->Ks * d->H * G + (long)d->Ks * d->H * Cout + (long)d->Ks * G * d->D + 4;
   // scratch behind the published layout: per-step log-det parts and fp64 workspace for the inverses
   n += d->Ks + 4;
   n += 2 * ((long)d->Ks * 2 * d->C * d->C + (long)d->Ks * d->C) + 8;  // doubles, counted as 2 floats each
@@ -934,7 +940,7 @@ extern "C" int lfi_flow_prep(const lfi_flow_dims* d, const lfi_flow_params* p, f
                      (with_inverse || p->inv_w) ? (float*)f.Winv : nullptr, dscratch, ldpart);
   LFI_LAUNCH_CHECK("lfi_flow_prep invconv");
   hipLaunchKernelGGL(flow_prep_transpose_kernel, dim3(64, d->Ks), dim3(256), 0, st, f, (float*)f.wz_t, (float*)f.whh_t,
-                     (float*)f.wfl_t, ldpart, ldconst);
+                     (float*)f.wfl_t, (float*)f.wc, ldpart, ldconst);
   LFI_LAUNCH_CHECK("lfi_flow_prep transpose");
   return LFI_OK;
 }
@@ -1152,7 +1158,7 @@ extern "C" int lfi_flow_sample_seq(const lfi_flow_dims* d, const lfi_flow_params
   LFI_REQUIRE(prep && wct && pre_static && noise && faces && h && work, "lfi_flow_sample_seq: null pointer");
   LFI_REQUIRE(hist1 >= 0 && hist1 <= start && start + nframes <= seq_len, "lfi_flow_sample_seq: bad frame range");
   LFI_REQUIRE((long)hist1 * d->C <= E, "lfi_flow_sample_seq: window wider than the feature vector");
-  const int B = f.B, C = f.C, H = f.H, D = f.D, Ks = f.Ks, G = f.G, I = f.I, Ch = f.Ch;
+  const int B = f.B, C = f.C, H = f.H, D = f.D, Ks = f.Ks, G = f.G;
   float* cbuf = work;                          // B x Ks*D
   float* gic = cbuf + (long)B * Ks * D;        // [Ks][B][G]
   float* xa = gic + (long)Ks * B * G;          // B x C ping
@@ -1181,7 +1187,7 @@ extern "C" int lfi_flow_sample_seq(const lfi_flow_dims* d, const lfi_flow_params
     lfi_gemm_desc r = {};
     r.batch = Ks; r.M = B; r.N = G; r.K = D;
     r.A = cbuf; r.lda = (long)Ks * D; r.a_kcontig = 1; r.strideA = D;
-    r.B = p->w_ih + Ch; r.ldb = I; r.b_kcontig = 1; r.strideB = (long)G * I;
+    r.B = f.wc; r.ldb = D; r.b_kcontig = 1; r.strideB = (long)G * D;
     r.C = gic; r.ldc = G; r.strideC = (long)B * G;
     r.bias = p->b_ih; r.strideBias = G;
     if ((rc = lfi_gemm_f32(&r, stream))) return rc;

@@ -322,14 +322,14 @@ extern "C" int lfi_gemm_f32(const lfi_gemm_desc* d, void* stream) {
   const int bm = shape == 0 ? 128 : (shape == 1 ? 256 : 64), bn = shape == 0 ? 128 : (shape == 1 ? 64 : 256);
   a.tiles_m = lfi_cdiv(d->M, bm);
   a.tiles_n = lfi_cdiv(d->N, bn);
-  // 16-byte loads need: leading dimension and batch stride multiples of 4 floats, base 16-byte aligned (checked per block
-  // on the device too), every k chunk starting on a multiple of 4 (kchunk is a multiple of 16), and for an
-  // mn-contiguous operand a row count that is a multiple of 4 so no float4 straddles the matrix edge. A k-contiguous
-  // operand may read up to 3 floats past K inside its own row: the row stride must cover them.
+  // 16-byte loads need: base pointer 16-byte aligned, leading dimension and batch stride multiples of 4 floats, every k
+  // chunk starting on a multiple of 4 (kchunk is a multiple of 16), and a row stride that covers the last float4 of a
+  // row: a load may run up to 3 floats past K (k-contiguous; zeroed before it reaches LDS) or past M/N (mn-contiguous;
+  // those LDS columns only feed output rows/columns that are never stored).
   auto vec_ok = [](const float* p, long ld, long stride, int kcontig, int mn, int K) {
     if ((reinterpret_cast<uintptr_t>(p) & 15) || (ld & 3) || (stride & 3)) return 0;
-    if (kcontig) return ld >= ((long)(K + 3) / 4) * 4 ? 1 : 0;
-    return (mn & 3) == 0 ? 1 : 0;
+    const long need = kcontig ? K : mn;
+    return ld >= (need + 3) / 4 * 4 ? 1 : 0;
   };
   a.vecA = vec_ok(d->A, d->lda, d->strideA, d->a_kcontig, d->M, d->K);
   a.vecB = vec_ok(d->B, d->ldb, d->strideB, d->b_kcontig, d->N, d->K);

@@ -89,8 +89,14 @@ class ModelSpec:
         self.p1_cols = p1.dim  # width of the autoregressive (prev_p1_face) block, first in the feature vector
         # folded feature layout: a GRU encoder's output appears twice in the reference's vector (cat(seq[:, -1], h_n[0]),
         # models.py:63-64); the engine stores it once and adds the two weight column blocks instead (lfi_cols_fold)
+        # every block starts on a 4-float boundary so that column blocks of the folded matrices stay 16-byte aligned;
+        # the padding columns are zero in both the features and the folded weights
         fcol, self.fold_a, self.fold_b, self.unfold = 0, [], [], []
         for e in self.encoders:
+            while fcol % 4:
+                self.fold_a.append(-1)
+                self.fold_b.append(-1)
+                fcol += 1
             e.fcol = fcol
             e.fdim = e.hid if e.enc == "rnn" else e.dim
             for j in range(e.fdim):
@@ -223,7 +229,8 @@ class GlowEngine:
     def _buf(self, name, floats, zero=False):
         t = self._ws.get(name)
         if t is None or t.numel() < floats:
-            t = (torch.zeros if zero else torch.empty)(max(int(floats), 1), dtype=torch.float32, device=self.device)
+            # always born zeroed: padding columns of the folded feature matrix are never written and must stay zero
+            t = torch.zeros(max(int(floats), 1), dtype=torch.float32, device=self.device)
             self._ws[name] = t
         elif zero:
             t.zero_()
@@ -333,8 +340,8 @@ class GlowEngine:
         self.gemm(F, KD, s.Ef, cond, s.ldf, 1, self.wct_f, s.ldf, 1, cbuf, KD, bias=self.fview("bct"), act=1, slope=0.01,
                   tag="gemm_cond_fwd")
         gic = self._buf("gic", s.Ks * F * s.G)
-        self.gemm(F, s.G, s.D, cbuf, KD, 1, self.fview("w_ih"), s.I, 1, gic, s.G, bias=self.fview("b_ih"),
-                  batch=s.Ks, sA=s.D, sB=s.G * s.I, sC=F * s.G, sBias=s.G, b_off=s.Ch)
+        self.gemm(F, s.G, s.D, cbuf, KD, 1, self.prep, s.D, 1, gic, s.G, bias=self.fview("b_ih"),
+                  batch=s.Ks, sA=s.D, sB=s.G * s.D, sC=F * s.G, sBias=s.G, b_off=self._wc_offset())
         return cbuf, gic
 
     # ------------------------------------------------------------------ forward / backward
@@ -411,8 +418,8 @@ class GlowEngine:
                                           st), "lfi_flow_param_grads")
         # d pre-activation of cond_transform, in place over c: dpre = (dgi[k] W_ih[k][:, Ch:]) * leaky'(c)
         dgi_off = (self.L.lfi_flow_bstash_ptr(C.byref(dims), bst.data_ptr(), 1) - bst.data_ptr()) // 4
-        self.gemm(F, s.D, s.G, bst, s.G, 1, self.fview("w_ih"), s.I, 0, ctx.cbuf, KD, act=2, slope=0.01, G=ctx.cbuf, ldg=KD,
-                  batch=s.Ks, sA=F * s.G, sB=s.G * s.I, sC=s.D, sG=s.D, a_off=dgi_off, b_off=s.Ch)
+        self.gemm(F, s.D, s.G, bst, s.G, 1, self.prep, s.D, 0, ctx.cbuf, KD, act=2, slope=0.01, G=ctx.cbuf, ldg=KD,
+                  batch=s.Ks, sA=F * s.G, sB=s.G * s.D, sC=s.D, sG=s.D, a_off=dgi_off, b_off=self._wc_offset())
         dpre = ctx.cbuf
         # cond_transform weight / bias gradients for all steps at once
         dwf = self._buf("dwct_f", KD * s.ldf)
@@ -507,7 +514,7 @@ class GlowEngine:
         # everything of the features that does not depend on generated frames, through cond_transform (no activation yet)
         cond = self._buf("cond", F * s.ldf)
         self.build_features(data, None, B, seq_len, masks, cond, with_stash=False, skip_p1=True)
-        c1 = s.p1_cols
+        c1 = (s.p1_cols + 3) // 4 * 4  # first column after the prev_p1_face block (blocks start on 4-float boundaries)
         pre = self._buf("pre_static", F * KD)
         if s.Ef > c1:
             self.gemm(F, KD, s.Ef - c1, cond, s.ldf, 1, self.wct_f, s.ldf, 1, pre, KD, bias=self.fview("bct"),
@@ -557,10 +564,14 @@ class GlowEngine:
         ldconst = self.prep[self._ldconst_offset()]
         return out, ld - ldconst
 
-    def _ldconst_offset(self):
+    def _wc_offset(self):
         s = self.spec
         cc = s.Ks * s.C * s.C
         return 3 * cc + s.Ks * s.Ch * s.G + s.Ks * s.H * s.G + s.Ks * s.H * s.Cout
+
+    def _ldconst_offset(self):
+        s = self.spec
+        return self._wc_offset() + s.Ks * s.G * s.D
 
     def logdet_const(self):
         return self.prep[self._ldconst_offset()]
