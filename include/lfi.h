@@ -51,6 +51,9 @@ typedef struct {
   int accumulate;             /* 1: C = act(..) + C ; 2: C = act(.. + C) (pre-activation add) */
   int act; float slope;
   int splitk; float* work;
+  int precision;              /* 0: exact fp32 (f32-input MFMA). 1: bf16x3 — operands split into bf16 hi + lo on the fly,
+                                 three bf16 MFMAs per step into fp32 accumulators (~2^-16 relative); needs 16-byte aligned
+                                 operands, otherwise the exact kernel runs */
 } lfi_gemm_desc;
 
 long lfi_gemm_work_floats(const lfi_gemm_desc* d);
@@ -82,6 +85,7 @@ typedef struct {
   int B, T, N, start;   /* batch, sequence length, timesteps (T - start), first modelled frame */
   int hist, hid;        /* window length, hidden size */
   int ldcond, col;      /* leading dimension of cond and first output column */
+  int precision;        /* lfi_gemm_desc.precision of the per-step recurrent GEMMs */
   int dup;              /* 1: write the state twice, columns [col, col+hid) and [col+hid, col+2*hid) as the reference's
                            cat(seq[:, -1], h_n[0]) does; 0: once (folded feature layout, see lfi_cols_fold) */
 } lfi_enc_desc;
@@ -111,6 +115,7 @@ typedef struct {
   int affine;                /* 1 affine coupling, 0 additive (glow/models.py:330-341) */
   int lstm;                  /* 0 GRUCell, 1 LSTMCell coupling net (glow/models.py:176-185) */
   float scale_eps;           /* Glow.scale_eps */
+  int gemm_precision;        /* lfi_gemm_desc.precision of the GEMMs issued by lfi_flow_param_grads / lfi_flow_sample_seq */
 } lfi_flow_dims;
 /* derived: Ch = C/2, C2 = C - Ch, Cout = affine ? 2*C2 : C2, G = lstm ? 4H : 3H, I = Ch + D */
 

@@ -26,17 +26,19 @@ class GemmDesc(C.Structure):
         ("accumulate", C.c_int),
         ("act", C.c_int), ("slope", C.c_float),
         ("splitk", C.c_int), ("work", C.c_void_p),
+        ("precision", C.c_int),
     ]
 
 
 class EncDesc(C.Structure):
     _fields_ = [("B", C.c_int), ("T", C.c_int), ("N", C.c_int), ("start", C.c_int),
-                ("hist", C.c_int), ("hid", C.c_int), ("ldcond", C.c_int), ("col", C.c_int), ("dup", C.c_int)]
+                ("hist", C.c_int), ("hid", C.c_int), ("ldcond", C.c_int), ("col", C.c_int), ("precision", C.c_int),
+                ("dup", C.c_int)]
 
 
 class FlowDims(C.Structure):
     _fields_ = [("B", C.c_int), ("N", C.c_int), ("C", C.c_int), ("H", C.c_int), ("D", C.c_int), ("Ks", C.c_int),
-                ("affine", C.c_int), ("lstm", C.c_int), ("scale_eps", C.c_float)]
+                ("affine", C.c_int), ("lstm", C.c_int), ("scale_eps", C.c_float), ("gemm_precision", C.c_int)]
 
 
 _FLOW_PARAM_FIELDS = ["an_bias", "an_logs", "inv_l", "inv_u", "inv_logs", "inv_p", "inv_sign", "inv_w",

@@ -165,7 +165,7 @@ extern "C" int lfi_encode_windows_fwd(const lfi_enc_desc* d, const float* Xp, co
       g.M = F; g.N = 3 * hid; g.K = hid; g.batch = 1;
       g.A = hseq + (long)(s - 1) * F * hid; g.lda = hid; g.a_kcontig = 1;
       g.B = whh; g.ldb = hid; g.b_kcontig = 1;  // (h W_hh^T)[w][n] = sum_k h[w][k] W_hh[n][k]
-      g.C = work; g.ldc = 3 * hid;
+      g.C = work; g.ldc = 3 * hid; g.precision = d->precision;
       if ((rc = lfi_gemm_f32(&g, stream))) return rc;
     }
     hipLaunchKernelGGL(enc_gate_fwd_kernel, dim3(blocks), dim3(256), 0, st, a, s, s > 0 ? work : nullptr);
@@ -195,7 +195,7 @@ extern "C" int lfi_encode_windows_bwd(const lfi_enc_desc* d, const float* dcond,
       g.M = F; g.N = hid; g.K = 3 * hid; g.batch = 1;
       g.A = dgh + (long)s * F * 3 * hid; g.lda = 3 * hid; g.a_kcontig = 1;
       g.B = whh; g.ldb = hid; g.b_kcontig = 0;  // (dgh W_hh)[w][j] = sum_k dgh[w][k] W_hh[k][j]
-      g.C = dh_out; g.ldc = hid; g.accumulate = 1;
+      g.C = dh_out; g.ldc = hid; g.accumulate = 1; g.precision = d->precision;
       if ((rc = lfi_gemm_f32(&g, stream))) return rc;
     }
     dh_in = dh_out;

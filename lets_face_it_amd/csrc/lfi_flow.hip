@@ -1052,7 +1052,7 @@ extern "C" int lfi_flow_param_grads(const lfi_flow_dims* d, const lfi_flow_param
   float* cws = gws + gws_floats;          // colsum workspace
 
   lfi_gemm_desc q = {};
-  q.batch = Ks; q.accumulate = accumulate; q.splitk = splitk; q.work = gws;
+  q.batch = Ks; q.accumulate = accumulate; q.splitk = splitk; q.work = gws; q.precision = d->gemm_precision;
   q.a_kcontig = 0; q.b_kcontig = 0; q.K = F;
   // w_fl[k] (Cout x H) = dlin[k]^T h[k]
   q.M = Cout; q.N = H; q.A = f.bDlin; q.lda = Cout; q.strideA = (long)F * Cout; q.B = f.sH; q.ldb = H; q.strideB = (long)F * H;
@@ -1181,7 +1181,7 @@ extern "C" int lfi_flow_sample_seq(const lfi_flow_dims* d, const lfi_flow_params
     q.batch = 1; q.M = B; q.N = Ks * D; q.K = hist1 * C;
     q.A = faces + (long)(t - hist1) * C; q.lda = (long)seq_len * C; q.a_kcontig = 1;
     q.B = wct; q.ldb = E; q.b_kcontig = 1;
-    q.C = cbuf; q.ldc = (long)Ks * D; q.accumulate = 2; q.act = 1; q.slope = 0.01f;
+    q.C = cbuf; q.ldc = (long)Ks * D; q.accumulate = 2; q.act = 1; q.slope = 0.01f; q.precision = d->gemm_precision;
     if ((rc = lfi_gemm_f32(&q, stream))) return rc;
     // gic[k] = c[:, kD:(k+1)D] @ W_ih[k][:, Ch:]^T + b_ih[k]
     lfi_gemm_desc r = {};
@@ -1189,7 +1189,7 @@ extern "C" int lfi_flow_sample_seq(const lfi_flow_dims* d, const lfi_flow_params
     r.A = cbuf; r.lda = (long)Ks * D; r.a_kcontig = 1; r.strideA = D;
     r.B = f.wc; r.ldb = D; r.b_kcontig = 1; r.strideB = (long)G * D;
     r.C = gic; r.ldc = G; r.strideC = (long)B * G;
-    r.bias = p->b_ih; r.strideBias = G;
+    r.bias = p->b_ih; r.strideBias = G; r.precision = d->gemm_precision;
     if ((rc = lfi_gemm_f32(&r, stream))) return rc;
     // reverse flow: z -> x through steps Ks-1 .. 0
     const float* xin = noise + (long)n * B * C;

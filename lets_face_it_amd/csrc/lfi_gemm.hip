@@ -47,6 +47,55 @@ __device__ __forceinline__ float apply_act(float v, int act, float slope, const 
   return v;
 }
 
+// Accumulator tile -> C (or the split-K workspace): bias, activation, accumulate. acc[mt][nt] register r holds
+// (row (r&3) + 8*(r>>2) + 4*half, col l31) of the 32 x 32 tile (mt, nt) of this wave's 64 x 64 patch.
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, const f32x16 (&acc)[2][2], int m0, int n0, int wm, int wn,
+                                              int l31, int half, int batch, int split) {
+  const bool partial = g.splitk > 1;
+  float* __restrict__ Cb = partial ? g.work + ((long)batch * g.splitk + split) * (long)g.M * g.N : g.C + batch * g.strideC;
+  const long ldc = partial ? g.N : g.ldc;
+  const float* bias = g.bias ? g.bias + batch * g.strideBias : nullptr;
+  const float* G = g.G ? g.G + batch * g.strideG : nullptr;
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      const int col = n0 + wn * 64 + nt * 32 + l31;
+      if (col >= g.N) continue;
+      const float bv = (!partial && bias) ? bias[col] : 0.0f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (row >= g.M) continue;
+        float v = acc[mt][nt][r];
+        if (!partial) {
+          v += bv;
+          if (g.accumulate == 2) v += Cb[(long)row * ldc + col];
+          v = apply_act(v, g.act, g.slope, G, (long)row * g.ldg + col);
+          if (g.accumulate == 1) v += Cb[(long)row * ldc + col];
+        }
+        Cb[(long)row * ldc + col] = v;
+      }
+    }
+}
+
+// XCD-aware, grouped tile order shared by both GEMM kernels: blocks b, b+8, ... share an XCD (round-robin dispatch);
+// each XCD gets a contiguous run of tiles (bijective also when the tile count is not a multiple of 8), walked in groups
+// of GM tile-rows column by column so the ~100 tiles an XCD has in flight form a compact GM x 12 patch.
+__device__ __forceinline__ void gemm_tile_of_block(const GemmArgs& g, int bid, int* tm, int* tn) {
+  const int ntile = g.tiles_m * g.tiles_n;
+  {
+    const int q = ntile >> 3, r = ntile & 7, xcd = bid & 7, idx = bid >> 3;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  constexpr int GM = 8;
+  const int per_group = GM * g.tiles_n;
+  const int grp = bid / per_group, in_grp = bid - grp * per_group;
+  const int rows_here = min(GM, g.tiles_m - grp * GM);
+  *tm = grp * GM + in_grp % rows_here;
+  *tn = in_grp / rows_here;
+}
+
 // LDS images (floats). A k-contiguous operand keeps its rows: [mn][BKT + 4] (80-byte rows: 16-B aligned for
 // ds_write_b128 / ds_read_b128, and 5*row mod 16 distinct over any 16 rows mod 16 -> conflict-free b128 reads). An
 // mn-contiguous operand is stored [k][mn + 4] and read with ds_read_b32. Both are filled with 16-byte loads/stores when
@@ -125,21 +174,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, half = lane >> 5;
 
-  // XCD-aware tile order: blocks b, b+8, ... share an XCD (round-robin dispatch); give each XCD a contiguous run of
-  // tiles (bijective also when the tile count is not a multiple of 8) ...
-  const int ntile = g.tiles_m * g.tiles_n;
-  int bid = blockIdx.x;
-  {
-    const int q = ntile >> 3, r = ntile & 7, xcd = bid & 7, idx = bid >> 3;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  }
-  // ... and walk the tiles in groups of GM tile-rows, column by column inside a group, so the ~100 tiles an XCD has in
-  // flight form a compact GM x 12 patch (every k-slice of an A panel is shared by ~12 tiles, every B slice by GM).
-  constexpr int GM = 8;
-  const int per_group = GM * g.tiles_n;
-  const int grp = bid / per_group, in_grp = bid - grp * per_group;
-  const int rows_here = min(GM, g.tiles_m - grp * GM);
-  const int tm = grp * GM + in_grp % rows_here, tn = in_grp / rows_here;
+  int tm, tn;
+  gemm_tile_of_block(g, blockIdx.x, &tm, &tn);
   const int m0 = tm * BM, n0 = tn * BN;
   const int batch = blockIdx.y, split = blockIdx.z;
   const float* __restrict__ A = g.A + batch * g.strideA;
@@ -219,33 +255,174 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
     __syncthreads();
   }
 
-  // epilogue
-  const bool partial = g.splitk > 1;
-  float* __restrict__ Cb = partial ? g.work + ((long)batch * g.splitk + split) * (long)g.M * g.N : g.C + batch * g.strideC;
-  const long ldc = partial ? g.N : g.ldc;
-  const float* bias = g.bias ? g.bias + batch * g.strideBias : nullptr;
-  const float* G = g.G ? g.G + batch * g.strideG : nullptr;
+  gemm_epilogue(g, acc, m0, n0, wm, wn, l31, half, batch, split);
+}
+
+// ---------------------------------------------------------------------------------------------- bf16 x 3
+// Same product on the bf16 matrix cores (16x the f32 MFMA rate) without leaving fp32-class accuracy: every fp32 operand
+// is split on the fly into hi = bf16(x) and lo = bf16(x - hi) while it is staged into LDS, and each 32x32x16 step
+// issues three MFMAs into the same fp32 accumulator: hi*hi + hi*lo + lo*hi (the dropped lo*lo term is 2^-16 relative).
+// Block tile 128 x 128, 4 waves x (2 x 2) tiles of 32 x 32, k-tile 32 (two MFMA k-steps), LDS rows of 32 bf16 + 8 pad
+// (80 bytes: 16-byte aligned fragment reads, conflict-free by the same 5*row mod 16 argument as the fp32 kernel),
+// four images per buffer (A hi, A lo, B hi, B lo), two buffers = 80 KB -> two workgroups per CU.
+// Only 16-byte aligned operands take this path (the host falls back to the exact fp32 kernel otherwise).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+constexpr int XBK = 32;
+constexpr int XROW = XBK + 8;                 // bf16 elements per LDS row
+constexpr int XIMG = 128 * XROW;              // bf16 elements per image
+extern __shared__ __attribute__((aligned(16))) __bf16 xsmem[];
+
+__device__ __forceinline__ void split4(const f32x4 v, bf16x4* hi, bf16x4* lo) {
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt)
+  for (int j = 0; j < 4; ++j) {
+    const __bf16 h = (__bf16)v[j];
+    (*hi)[j] = h;
+    (*lo)[j] = (__bf16)(v[j] - (float)h);
+  }
+}
+
+template <bool KC>
+struct XStager {
+  // KC: four float4 along k per thread; !KC: one 4(k) x 4(mn) patch per thread (four float4 along mn)
+  int off[4];
+  int kk[4];      // k of the float4 inside the tile
+  int lds[4];     // KC: bf16 offset of the 4 values in the image; !KC: unused
+  int mn_l, kg4;  // !KC: first mn of the patch, first k
+  bool in[4];
+  __device__ __forceinline__ void init(int tid, int mn0, int MN, long ld) {
+    if (KC) {
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-      const int col = n0 + wn * 64 + nt * 32 + l31;
-      if (col >= g.N) continue;
-      const float bv = (!partial && bias) ? bias[col] : 0.0f;
+      for (int i = 0; i < 4; ++i) {
+        const int f = tid + 256 * i;
+        const int k = (f & 7) * 4, mn = f >> 3;
+        kk[i] = k;
+        in[i] = mn0 + mn < MN;
+        off[i] = in[i] ? mn * (int)ld + k : 0;
+        lds[i] = mn * XROW + k;
+      }
+    } else {
+      kg4 = (tid & 7) * 4;
+      mn_l = (tid >> 3) * 4;
+      const bool ok = mn0 + mn_l < MN;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        if (row >= g.M) continue;
-        float v = acc[mt][nt][r];
-        if (!partial) {
-          v += bv;
-          if (g.accumulate == 2) v += Cb[(long)row * ldc + col];
-          v = apply_act(v, g.act, g.slope, G, (long)row * g.ldg + col);
-          if (g.accumulate == 1) v += Cb[(long)row * ldc + col];
-        }
-        Cb[(long)row * ldc + col] = v;
+      for (int j = 0; j < 4; ++j) {
+        kk[j] = kg4 + j;
+        in[j] = ok;
+        off[j] = ok ? (kg4 + j) * (int)ld + mn_l : 0;
+        lds[j] = 0;
       }
     }
+  }
+  __device__ __forceinline__ void load(const float* __restrict__ p, int krem, f32x4 (&r)[4]) const {
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r[i] = (in[i] && kk[i] < krem) ? *reinterpret_cast<const f32x4*>(p + off[i]) : z;
+  }
+  __device__ __forceinline__ void store(__bf16* hi_img, __bf16* lo_img, int krem, f32x4 (&r)[4]) const {
+    if (KC) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int j = 1; j < 4; ++j) r[i][j] = (kk[i] + j < krem) ? r[i][j] : 0.0f;
+        bf16x4 h, l;
+        split4(r[i], &h, &l);
+        *reinterpret_cast<bf16x4*>(hi_img + lds[i]) = h;
+        *reinterpret_cast<bf16x4*>(lo_img + lds[i]) = l;
+      }
+    } else {
+      // r[j][i] = element (k = kg4 + j, mn = mn_l + i): transpose the 4 x 4 patch so each LDS row gets 4 consecutive k
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const f32x4 col = {r[0][i], r[1][i], r[2][i], r[3][i]};
+        bf16x4 h, l;
+        split4(col, &h, &l);
+        *reinterpret_cast<bf16x4*>(hi_img + (mn_l + i) * XROW + kg4) = h;
+        *reinterpret_cast<bf16x4*>(lo_img + (mn_l + i) * XROW + kg4) = l;
+      }
+    }
+  }
+};
+
+template <bool AKC, bool BKC>
+__global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(GemmArgs g) {
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, half = lane >> 5;
+  int tm, tn;
+  gemm_tile_of_block(g, blockIdx.x, &tm, &tn);
+  const int m0 = tm * 128, n0 = tn * 128;
+  const int batch = blockIdx.y, split = blockIdx.z;
+  const float* __restrict__ A = g.A + batch * g.strideA;
+  const float* __restrict__ B = g.B + batch * g.strideB;
+  const int kbeg = split * g.kchunk;
+  const int kend = min(g.K, kbeg + g.kchunk);
+  const int nkt = (kend - kbeg + XBK - 1) / XBK;
+
+  XStager<AKC> sa;
+  XStager<BKC> sb;
+  sa.init(tid, m0, g.M, g.lda);
+  sb.init(tid, n0, g.N, g.ldb);
+  const float* __restrict__ tA = AKC ? A + (long)m0 * g.lda + kbeg : A + (long)kbeg * g.lda + m0;
+  const float* __restrict__ tB = BKC ? B + (long)n0 * g.ldb + kbeg : B + (long)kbeg * g.ldb + n0;
+  const long stepA = AKC ? XBK : (long)XBK * g.lda, stepB = BKC ? XBK : (long)XBK * g.ldb;
+
+  f32x4 ra[4], rb[4];
+  auto load_tiles = [&](int kt) {
+    const int krem = kend - (kbeg + kt * XBK);
+    sa.load(tA + kt * stepA, krem, ra);
+    sb.load(tB + kt * stepB, krem, rb);
+  };
+  auto store_tiles = [&](int kt, int buf) {
+    const int krem = kend - (kbeg + kt * XBK);
+    __bf16* base = xsmem + buf * 4 * XIMG;
+    sa.store(base, base + XIMG, krem, ra);
+    sb.store(base + 2 * XIMG, base + 3 * XIMG, krem, rb);
+  };
+
+  const int wm = wave >> 1, wn = wave & 1;
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+  if (nkt > 0) {
+    load_tiles(0);
+    store_tiles(0, 0);
+  }
+  __syncthreads();
+  for (int kt = 0; kt < nkt; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nkt) load_tiles(kt + 1);
+    const __bf16* base = xsmem + buf * 4 * XIMG;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+      for (int t2 = 0; t2 < 2; ++t2) {
+        const int ro = (wm * 64 + t2 * 32 + l31) * XROW + ks * 16 + half * 8;
+        const int co = (wn * 64 + t2 * 32 + l31) * XROW + ks * 16 + half * 8;
+        ah[t2] = *reinterpret_cast<const bf16x8*>(base + ro);
+        al[t2] = *reinterpret_cast<const bf16x8*>(base + XIMG + ro);
+        bh[t2] = *reinterpret_cast<const bf16x8*>(base + 2 * XIMG + co);
+        bl[t2] = *reinterpret_cast<const bf16x8*>(base + 3 * XIMG + co);
+      }
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt], bl[nt], acc[mt][nt], 0, 0, 0);
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+        }
+    }
+    if (kt + 1 < nkt) store_tiles(kt + 1, buf ^ 1);
+    __syncthreads();
+  }
+  gemm_epilogue(g, acc, m0, n0, wm, wn, l31, half, batch, split);
 }
 
 __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(GemmArgs g) {
@@ -313,19 +490,9 @@ extern "C" int lfi_gemm_f32(const lfi_gemm_desc* d, void* stream) {
   a.strideBias = d->strideBias; a.strideG = d->strideG;
   a.accumulate = d->accumulate; a.act = d->act; a.slope = d->slope;
   a.splitk = splitk; a.kchunk = splitk > 1 ? kchunk_for(d->K, splitk) : d->K;
+  if (a.kchunk & 31) a.kchunk = (a.kchunk + 31) & ~31;  // also a whole number of bf16x3 k-tiles
   // the chunking may leave trailing splits empty: they still write zeros, which keeps the reduce simple
   a.work = d->work;
-  // tile shape: narrow outputs get the tall tile, short outputs the wide one
-  int shape = 0;  // 128 x 128
-  if (d->N <= 64 && d->M > 128) shape = 1;       // 256 x 64
-  else if (d->M <= 64 && d->N > 128) shape = 2;  // 64 x 256
-  const int bm = shape == 0 ? 128 : (shape == 1 ? 256 : 64), bn = shape == 0 ? 128 : (shape == 1 ? 64 : 256);
-  a.tiles_m = lfi_cdiv(d->M, bm);
-  a.tiles_n = lfi_cdiv(d->N, bn);
-  // 16-byte loads need: base pointer 16-byte aligned, leading dimension and batch stride multiples of 4 floats, every k
-  // chunk starting on a multiple of 4 (kchunk is a multiple of 16), and a row stride that covers the last float4 of a
-  // row: a load may run up to 3 floats past K (k-contiguous; zeroed before it reaches LDS) or past M/N (mn-contiguous;
-  // those LDS columns only feed output rows/columns that are never stored).
   auto vec_ok = [](const float* p, long ld, long stride, int kcontig, int mn, int K) {
     if ((reinterpret_cast<uintptr_t>(p) & 15) || (ld & 3) || (stride & 3)) return 0;
     const long need = kcontig ? K : mn;
@@ -333,8 +500,40 @@ extern "C" int lfi_gemm_f32(const lfi_gemm_desc* d, void* stream) {
   };
   a.vecA = vec_ok(d->A, d->lda, d->strideA, d->a_kcontig, d->M, d->K);
   a.vecB = vec_ok(d->B, d->ldb, d->strideB, d->b_kcontig, d->N, d->K);
+  const bool use_x3 = d->precision == 1 && a.vecA && a.vecB;
+  // tile shape: narrow outputs get the tall tile, short outputs the wide one (the bf16x3 kernel has one shape)
+  int shape = 0;  // 128 x 128
+  if (!use_x3) {
+    if (d->N <= 64 && d->M > 128) shape = 1;       // 256 x 64
+    else if (d->M <= 64 && d->N > 128) shape = 2;  // 64 x 256
+  }
+  const int bm = shape == 0 ? 128 : (shape == 1 ? 256 : 64), bn = shape == 0 ? 128 : (shape == 1 ? 64 : 256);
+  a.tiles_m = lfi_cdiv(d->M, bm);
+  a.tiles_n = lfi_cdiv(d->N, bn);
+  // (16-byte loads need: base pointer 16-byte aligned, leading dimension and batch stride multiples of 4 floats, every k
+  // chunk starting on a multiple of 4, and a row stride that covers the last float4 of a row: a load may run up to 3
+  // floats past K (k-contiguous; zeroed before it reaches LDS) or past M/N (mn-contiguous; those LDS columns only feed
+  // output rows/columns that are never stored) — see vec_ok above.)
   dim3 grid(a.tiles_m * a.tiles_n, d->batch, splitk);
-  if (shape == 0) launch_gemm<128, 128, 2, 2>(a, d->a_kcontig, d->b_kcontig, grid, st);
+  if (use_x3) {
+    const size_t lds = (size_t)2 * 4 * XIMG * sizeof(__bf16);
+    static bool attr_set = false;  // idempotent, per process: raise the dynamic-LDS cap of the four instantiations once
+    if (!attr_set) {
+      hipError_t e1 = hipFuncSetAttribute((const void*)gemm_bf16x3_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipError_t e2 = hipFuncSetAttribute((const void*)gemm_bf16x3_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipError_t e3 = hipFuncSetAttribute((const void*)gemm_bf16x3_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipError_t e4 = hipFuncSetAttribute((const void*)gemm_bf16x3_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess) {
+        lfi_set_error("lfi_gemm_f32: cannot reserve %zu bytes of LDS for the bf16x3 kernel", lds);
+        return LFI_ERR_LAUNCH;
+      }
+      attr_set = true;
+    }
+    if (d->a_kcontig && d->b_kcontig) hipLaunchKernelGGL((gemm_bf16x3_kernel<true, true>), grid, dim3(256), lds, st, a);
+    else if (d->a_kcontig) hipLaunchKernelGGL((gemm_bf16x3_kernel<true, false>), grid, dim3(256), lds, st, a);
+    else if (d->b_kcontig) hipLaunchKernelGGL((gemm_bf16x3_kernel<false, true>), grid, dim3(256), lds, st, a);
+    else hipLaunchKernelGGL((gemm_bf16x3_kernel<false, false>), grid, dim3(256), lds, st, a);
+  } else if (shape == 0) launch_gemm<128, 128, 2, 2>(a, d->a_kcontig, d->b_kcontig, grid, st);
   else if (shape == 1) launch_gemm<256, 64, 4, 1>(a, d->a_kcontig, d->b_kcontig, grid, st);
   else launch_gemm<64, 256, 1, 4>(a, d->a_kcontig, d->b_kcontig, grid, st);
   LFI_LAUNCH_CHECK("lfi_gemm_f32");
