@@ -167,6 +167,9 @@ class GlowEngine:
         self.prep = None
         self._last = None
         self.timers = None  # {tag: [(start_event, end_event), ...]} when kernel timing is switched on (bench.py)
+        # GEMM arithmetic: 0 = exact fp32 on the f32-input MFMA; 1 = bf16x3 (fp32 operands split into bf16 hi + lo on the
+        # fly, three bf16 MFMAs per step, fp32 accumulation: ~2^-16 relative, 16x the MFMA rate)
+        self.precision = 0
 
     # ------------------------------------------------------------------ per-kernel timing (HIP events on the launch stream)
     def enable_timing(self, on=True):
@@ -200,7 +203,7 @@ class GlowEngine:
 
     def _flow_dims(self, B, N):
         s = self.spec
-        return FlowDims(B, N, s.C, s.H, s.D, s.Ks, s.affine, 1 if s.rnn_type == "lstm" else 0, s.scale_eps)
+        return FlowDims(B, N, s.C, s.H, s.D, s.Ks, s.affine, 1 if s.rnn_type == "lstm" else 0, s.scale_eps, self.precision)
 
     def _flow_params(self):
         s = self.spec
@@ -251,6 +254,7 @@ class GlowEngine:
         g.batch, g.strideA, g.strideB, g.strideC, g.strideBias, g.strideG = batch, sA, sB, sC, sBias, sG
         g.accumulate, g.act, g.slope = accumulate, act, slope
         g.splitk = splitk
+        g.precision = self.precision
         if splitk > 1:
             g.work = self._buf("scratch.gemm_splitk", batch * splitk * M * N).data_ptr()
         ev = self._tic(tag)
@@ -321,7 +325,7 @@ class GlowEngine:
                       xp, 3 * hid)
             gates = self._buf("enc_gates." + e.name, e.hist * F * 4 * hid) if with_stash else None
             hseq = self._buf("enc_hseq." + e.name, e.hist * F * hid)
-            d = EncDesc(B, Tx, N, s.start, e.hist, hid, s.ldf, e.fcol, 0)
+            d = EncDesc(B, Tx, N, s.start, e.hist, hid, s.ldf, e.fcol, self.precision, 0)
             work = self._buf("scratch.enc", self.L.lfi_encode_windows_work_floats(C.byref(d)))
             mk = None if masks is None else masks.get(e.name)
             if mk is not None and not (tuple(mk.shape) == (N, B, e.hist) and mk.is_contiguous()
@@ -446,7 +450,7 @@ class GlowEngine:
         x = ctx.batch[e.name]
         Tx, hid, G3 = x.shape[1], e.hid, 3 * e.hid
         st = _stream()
-        d = EncDesc(B, Tx, N, s.start, e.hist, hid, lddcond, col, 0)
+        d = EncDesc(B, Tx, N, s.start, e.hist, hid, lddcond, col, self.precision, 0)
         gates = self._ws["enc_gates." + e.name]
         hseq = self._ws["enc_hseq." + e.name]
         dgi = self._buf("enc_dgi." + e.name, e.hist * F * G3)

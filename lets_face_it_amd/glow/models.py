@@ -204,6 +204,12 @@ class SeqGlow(nn.Module):
         self.spec = _engine.ModelSpec(hparams)
         assert self.spec.E == self.feature_encoder.dim
         self.engine = None
+        # "f32": exact fp32 matrix products; "bf16x3": split-operand bf16 MFMA (see include/lfi.h lfi_gemm_desc.precision).
+        # hparams key `engine_precision` or the LFI_PRECISION environment variable select it; default exact.
+        import os
+        self.precision = str(getattr(hparams, "engine_precision", None) or os.environ.get("LFI_PRECISION") or "f32")
+        if self.precision not in ("f32", "bf16x3"):
+            raise ValueError("engine_precision must be 'f32' or 'bf16x3', got %r" % self.precision)
         self.injected_masks = None  # {modality: (N, B, hist)} overrides the random dropout masks (tests)
         self.allreduce_hook = None  # set by the data-parallel trainer: sums ActNorm init statistics over ranks
         self._param_map = []
@@ -276,6 +282,7 @@ class SeqGlow(nn.Module):
         eng = self.engine
         if eng is None or eng.device != device or not self._still_bound():
             eng = self._bind(device)
+        eng.precision = 1 if self.precision == "bf16x3" else 0
         return eng
 
     def _still_bound(self):

@@ -110,6 +110,42 @@ def test_gemm_padded_rows_take_the_16_byte_path(eng, gpu_device, akc, bkc):
     assert rel_err(Cm, Ad @ Bd) < 2e-6
 
 
+@pytest.mark.parametrize("akc,bkc", [(1, 1), (1, 0), (0, 1), (0, 0)])
+@pytest.mark.parametrize("shape", [(260, 136, 890), (128, 512, 32), (1000, 96, 2500), (64, 64, 100)])
+def test_gemm_bf16x3(eng, gpu_device, akc, bkc, shape):
+    """Split-operand bf16 MFMA path: fp32-class accuracy (bound 3e-5 of the output scale; plain bf16 would be ~3e-3)."""
+    M, N, K = shape
+    g = torch.Generator().manual_seed(M + N + K + 2 * akc + bkc)
+    r4 = lambda v: (v + 3) // 4 * 4  # noqa: E731
+    lda, ldb = (r4(K) + 4 if akc else r4(M) + 4), (r4(K) + 8 if bkc else r4(N))
+    A = torch.full((M, lda) if akc else (K, lda), float("nan"))
+    Bm = torch.full((N, ldb) if bkc else (K, ldb), float("nan"))
+    if akc:
+        A[:, :K] = torch.randn(M, K, generator=g)
+    else:
+        A[:, :M] = torch.randn(K, M, generator=g)
+    if bkc:
+        Bm[:, :K] = torch.randn(N, K, generator=g)
+    else:
+        Bm[:, :N] = torch.randn(K, N, generator=g)
+    A, Bm = A.to(gpu_device), Bm.to(gpu_device)
+    bias = torch.randn(N, generator=g).to(gpu_device)
+    Cm = torch.zeros(M, N, device=gpu_device)
+    eng.precision = 1
+    try:
+        eng.gemm(M, N, K, A, lda, akc, Bm, ldb, bkc, Cm, N, bias=bias, act=1, slope=0.01,
+                 splitk=4 if K >= 2000 else 1)
+    finally:
+        eng.precision = 0
+    torch.cuda.synchronize()
+    Ad = (A[:, :K] if akc else A[:, :M].t()).double()
+    Bd = (Bm[:, :K].t() if bkc else Bm[:, :N]).double()
+    ref = torch.nn.functional.leaky_relu(Ad @ Bd + bias.double(), 0.01)
+    assert torch.isfinite(Cm).all()
+    err = rel_err(Cm, ref)
+    assert err < 3e-5, err
+
+
 def test_colsum(eng, gpu_device):
     g = torch.Generator().manual_seed(3)
     X = torch.randn(3, 1000, 90, generator=g).to(gpu_device)

@@ -18,10 +18,11 @@ pytestmark = pytest.mark.gpu
 GPU_FIXTURES = ("tiny", "tiny_additive", "odd", "mid")  # tiny_lstm: LSTM coupling cell not built (fails loudly, below)
 
 
-def build(fx, device, train=False):
+def build(fx, device, train=False, precision="f32"):
     from lets_face_it_amd.glow.models import SeqGlow
     hp = Namespace(**fx.hp)
     m = SeqGlow(hp)
+    m.precision = precision
     missing = m.load_state_dict(fx.state_dict(torch.float32), strict=True)
     assert not missing.missing_keys and not missing.unexpected_keys
     m.to(device)
@@ -168,6 +169,22 @@ def test_cpu_tensor_is_refused():
         m(fxl.batch(torch.float32))
 
 
+# ------------------------------------------------------------------ bf16x3 mode stays inside the same tolerances
+def test_bf16x3_mode_forward_backward(fx, gpu_device):
+    m = build(fx, gpu_device, train=True, precision="bf16x3")
+    m.injected_masks = fx.masks(torch.float32)
+    z_seq, loss, losses = m(to_dev(fx.batch(), gpu_device))
+    err = max_rel(torch.stack(losses), fx.get("train/nll"), floor=1.0)
+    loss.sum().backward()
+    grads = fx.group("grad/")
+    worst = 0.0
+    for name, p in m.named_parameters():
+        rel = float((p.grad.double().cpu() - grads[name]).norm() / max(float(grads[name].norm()), 1e-12))
+        worst = max(worst, rel)
+    print("%s bf16x3: per-frame NLL max rel err %.3e, worst gradient rel L2 %.3e" % (fx.name, err, worst))
+    assert err < 1e-4 and worst < 2e-3
+
+
 # ------------------------------------------------------------------ full-width model against the oracle
 def final_model_hparams(C=50, S=27, K=16):
     hp = Fixture("mid").hp
@@ -202,11 +219,13 @@ def perturbed_model(hp, device, seed=1234):
     return m, sd
 
 
+@pytest.mark.parametrize("precision", ["f32", "bf16x3"])
 @pytest.mark.parametrize("C,S", [(50, 27), (56, 30)])
-def test_final_model_width_nll_against_oracle(gpu_device, C, S):
+def test_final_model_width_nll_against_oracle(gpu_device, C, S, precision):
     """final_model.yaml widths (K=16, H=128, D=512, GRU 256/128/256), T=80, reduced batch so the CPU oracle takes seconds."""
     hp = final_model_hparams(C, S)
     m, sd = perturbed_model(hp, gpu_device)
+    m.precision = precision
     m.eval()
     batch = oracle.synthetic_batch(12, 80, C, S, seed=1234)
     with torch.no_grad():
@@ -214,7 +233,7 @@ def test_final_model_width_nll_against_oracle(gpu_device, C, S):
     z64, loss64, nll64 = oracle.seqglow_forward(hp, {k: v.double() for k, v in sd.items()},
                                                 {k: v.double() for k, v in batch.items()})
     err = max_rel(torch.stack(losses), nll64, floor=1.0)
-    print("final_model C=%d S=%d: per-frame NLL max rel err vs fp64 oracle %.3e" % (C, S, err))
+    print("final_model C=%d S=%d %s: per-frame NLL max rel err vs fp64 oracle %.3e" % (C, S, precision, err))
     assert err < 1e-4
     assert rel_err(torch.stack(z_seq), z64) < 1e-4
 
