@@ -26,7 +26,8 @@ os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
-F32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+F32_MFMA_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: bf16 MFMA, dense (no 2:1 sparsity)
 
 
 def synthetic_batch(B, T, C, S, seed, device):
@@ -79,6 +80,127 @@ def cpu_baseline(hp, C, S, T, budget_s):
                       "final_model C=%d S=%d T=%d at batch %d, median of %d steps after 1 warm-up" % (C, S, T, B, len(times))}
 
 
+def _timed(fn, steps, world, device):
+    """EXACTLY `steps` calls bracketed by barrier + synchronize on both sides; max over ranks (seconds)."""
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    last = None
+    for i in range(steps):
+        last = fn(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return elapsed, last
+
+
+def _roofline(spec, F, timing, precision):
+    """Dominant kernel = the cond_transform forward GEMM (F x Ks*D x Ef). SURVEY.md par. 8d counts 2*E*D per flow step and
+    frame as written (E = 1530: every GRU output twice); the kernel runs on the folded layout (Ef = 890).
+    `achieved` is the product's FLOPs (2 M N K on the folded K) over the HIP-event launch time. In bf16x3 mode every
+    product costs three bf16 MFMAs, so the MFMA pipe does 3x that work: both fractions are reported."""
+    KD = spec.Ks * spec.D
+    flops_alg = 2.0 * F * KD * spec.E
+    flops = 2.0 * F * KD * spec.Ef
+    n_launch, ms = timing.get("gemm_cond_fwd", (0, float("nan")))
+    ach = flops / (ms * 1e-3) / 1e12 if n_launch else float("nan")
+    if precision == "bf16x3":
+        peak, kern, mult = BF16_MFMA_PEAK_TFLOPS, "gemm_bf16x3_kernel<128,128,k32>", 3.0
+    else:
+        peak, kern, mult = F32_MFMA_PEAK_TFLOPS, "gemm_f32_kernel<128,128,k16>", 1.0
+    return {"bound": "mfma", "kernel": kern + " cond_transform forward (F x Ks*D x Ef)",
+            "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
+            "mfma_flops_multiplier": mult, "frac_of_mfma_issue": mult * ach / peak,
+            "flops_per_launch": flops, "flops_per_launch_algorithmic": flops_alg,
+            "achieved_algorithmic": flops_alg / (ms * 1e-3) / 1e12 if n_launch else None,
+            "ms_per_launch": ms, "launches_timed": n_launch}
+
+
+def bench_train(args, model, trainer, spec, device, world, rank, hp):
+    C, S, T, B = spec.C, spec.S, args.seq_len, args.batch
+    N = T - spec.start
+    batches = [synthetic_batch(B, T, C, S, 1234 + 1000 * rank + i, device) for i in range(2)]
+    lr = trainer.lr_at(0)
+    allreduce = trainer.allreduce_grads if world > 1 else None
+
+    def step(i):
+        return model.fused_training_step(batches[i & 1], lr, world, allreduce)
+
+    for i in range(args.warmup):  # includes the one-off ActNorm data-dependent init
+        step(i)
+    eng = model.seq_glow.engine
+    eng.enable_timing(True)
+    elapsed, loss = _timed(step, args.steps, world, device)
+    timing = eng.timing_summary()
+    eng.enable_timing(False)
+    if rank != 0:
+        return None
+    frames = world * B * N * args.steps
+    F = B * N
+    out = {
+        "metric": "FLAME frames/s, full training step (fwd+bwd+clip+Adam), final_model.yaml batch 256 per GPU",
+        "value": frames / elapsed, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32" if args.precision == "f32" else "f32 (GEMM operands split into bf16 hi+lo, f32 accumulate)",
+        "data": "synthetic",
+        "config": {"workload": "final_model.yaml training step, synthetic 50-d FLAME + 27-d speech, T=%d, "
+                               "batch %d per GPU (BASELINE.json configs[1]%s)" % (T, B, "" if world == 1 else ", data-parallel"),
+                   "K": spec.Ks, "H": spec.H, "cond_dim": spec.D, "feature_dim": spec.E, "frames_per_step_per_gpu": F,
+                   "parallelism": "dp%d" % world, "params": eng.n_params, "gemm_precision": args.precision},
+        "final_loss": float(loss),
+        "roofline": _roofline(spec, F, timing, args.precision),
+        "kernel_timing": {t: {"launches": n, "ms": round(m_, 4)} for t, (n, m_) in timing.items()},
+    }
+    if world == 1 and args.cpu_baseline_seconds > 0:
+        out["cpu_baseline"] = cpu_baseline(hp, C, S, T, args.cpu_baseline_seconds)
+    return out
+
+
+def bench_sample(args, model, spec, device, world, rank):
+    """BASELINE.json configs[3]: SeqGlow.inference, batch 1024, seq_len 300, seed frames zeros, eps 1."""
+    B = args.batch if args.batch != 256 else 1024
+    T = args.seq_len if args.seq_len != 80 else 300
+    C, S = spec.C, spec.S
+    model.eval()
+    model.seq_glow.glow.set_actnorm_init(True)
+    g = torch.Generator().manual_seed(1234 + rank)
+    data = {"p1_face": torch.zeros(B, T, C, device=device)}
+    for name, d in (("p2_face", C), ("p1_speech", S), ("p2_speech", S)):
+        data[name] = torch.randn(B, T, d, generator=g).to(device).contiguous()
+    nframes = T - spec.start
+    noise = torch.randn(nframes, B, C, generator=g).to(device).contiguous()
+
+    def step(i):
+        return model.seq_glow.inference(T, data, noise=noise)
+
+    for i in range(args.warmup):
+        step(i)
+    elapsed, out_faces = _timed(step, args.steps, world, device)
+    if rank != 0:
+        return None
+    frames = world * B * nframes * args.steps
+    return {
+        "metric": "FLAME frames/s, autoregressive sampling (SeqGlow.inference), final_model.yaml",
+        "value": frames / elapsed, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32" if args.precision == "f32" else "f32 (GEMM operands split into bf16 hi+lo, f32 accumulate)",
+        "data": "synthetic",
+        "config": {"workload": "autoregressive sampling, batch %d, seq_len %d (%d generated frames per sequence), "
+                               "BASELINE.json configs[3]" % (B, T, nframes), "K": spec.Ks, "H": spec.H,
+                   "parallelism": "replicas%d" % world, "gemm_precision": args.precision},
+        "ms_per_generated_frame": 1e3 * elapsed / args.steps / nframes,
+        "finite": bool(torch.isfinite(out_faces).all()),
+    }
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -87,6 +209,11 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="per-GPU batch (BASELINE: 256)")
     ap.add_argument("--seq-len", type=int, default=80)
     ap.add_argument("--cpu-baseline-seconds", type=float, default=25.0, help="0 disables the CPU baseline leg")
+    ap.add_argument("--precision", choices=("f32", "bf16x3"), default=os.environ.get("LFI_PRECISION", "f32"),
+                    help="GEMM arithmetic: exact f32 MFMA, or bf16 hi/lo split operands (3 bf16 MFMAs per product)")
+    ap.add_argument("--workload", choices=("train", "sample"), default="train",
+                    help="train: BASELINE.json configs[1] (the headline metric); sample: configs[3], autoregressive "
+                         "inference at --batch 1024 --seq-len 300 unless given")
     ap.add_argument("--hparams", default=os.path.join(ROOT, "lets_face_it_amd", "hparams", "final_model_synthetic.yaml"))
     args = ap.parse_args()
 
@@ -111,6 +238,7 @@ def main():
 
     hp = load_hparams_file(args.hparams)
     hp["batch_size"] = args.batch
+    hp["engine_precision"] = args.precision
     hp["Train"]["seq_len"] = args.seq_len
     random.seed(1234)
     np.random.seed(1234)
@@ -123,74 +251,13 @@ def main():
     model.seq_glow.allreduce_hook = trainer.allreduce_stats
     model.nll_sync_hook = trainer.sync_scalar
     trainer.broadcast_parameters(model)
-    allreduce = trainer.allreduce_grads if world > 1 else None
 
     spec = model.seq_glow.spec
-    C, S, T, B = spec.C, spec.S, args.seq_len, args.batch
-    N = T - spec.start
-    batches = [synthetic_batch(B, T, C, S, 1234 + 1000 * rank + i, device) for i in range(2)]
-    lr = trainer.lr_at(0)
-
-    def step(i):
-        return model.fused_training_step(batches[i & 1], lr, world, allreduce)
-
-    for i in range(args.warmup):  # includes the one-off ActNorm data-dependent init
-        step(i)
-    eng = model.seq_glow.engine
-    eng.enable_timing(True)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    loss = None
-    for i in range(args.steps):
-        loss = step(i)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    timing = eng.timing_summary()
-    eng.enable_timing(False)
-
-    frames = world * B * N * args.steps
-    F = B * N
-    KD = spec.Ks * spec.D
-    # cond_transform GEMM: SURVEY.md §8d counts 2*E*D per flow step and frame as written (E = 1530 with every GRU output
-    # twice); the kernel runs on the folded feature layout (Ef = 890) and the roofline fraction is of the
-    # FLOPs it actually executes
-    flops_alg = 2.0 * F * KD * spec.E
-    flops_fwd = 2.0 * F * KD * spec.Ef
-    n_launch, ms = timing.get("gemm_cond_fwd", (0, float("nan")))
-    achieved = flops_fwd / (ms * 1e-3) / 1e12 if n_launch else float("nan")
-    others = {t: {"launches": n, "ms": round(m_, 4)} for t, (n, m_) in timing.items()}
-
+    if args.workload == "sample":
+        out = bench_sample(args, model, spec, device, world, rank)
+    else:
+        out = bench_train(args, model, trainer, spec, device, world, rank, hp)
     if rank == 0:
-        out = {
-            "metric": "FLAME frames/s, full training step (fwd+bwd+clip+Adam), final_model.yaml batch 256 per GPU",
-            "value": frames / elapsed, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "final_model.yaml training step, synthetic 50-d FLAME + 27-d speech, T=%d, "
-                                   "batch %d per GPU (BASELINE.json configs[1]%s)" % (T, B, "" if world == 1 else ", data-parallel"),
-                       "K": spec.Ks, "H": spec.H, "cond_dim": spec.D, "feature_dim": spec.E, "frames_per_step_per_gpu": F,
-                       "parallelism": "dp%d" % world, "params": eng.n_params},
-            "final_loss": float(loss),
-            "roofline": {"bound": "mfma", "kernel": "gemm_f32_kernel<128,128> cond_transform forward (F x Ks*D x Ef)",
-                         "achieved": achieved, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / F32_MFMA_PEAK_TFLOPS, "traffic": None,
-                         "flops_per_launch": flops_fwd, "flops_per_launch_algorithmic": flops_alg,
-                         "achieved_algorithmic": flops_alg / (ms * 1e-3) / 1e12 if n_launch else None,
-                         "ms_per_launch": ms, "launches_timed": n_launch},
-            "kernel_timing": others,
-        }
-        if world == 1 and args.cpu_baseline_seconds > 0:
-            out["cpu_baseline"] = cpu_baseline(hp, C, S, T, args.cpu_baseline_seconds)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

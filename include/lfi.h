@@ -113,7 +113,8 @@ int lfi_gather_windows(const float* X, int B, int T, int dim, int N, int start, 
 typedef struct {
   int B, N, C, H, D, Ks;     /* batch, timesteps, channels, hidden_channels, cond_dim, flow steps */
   int affine;                /* 1 affine coupling, 0 additive (glow/models.py:330-341) */
-  int lstm;                  /* 0 GRUCell, 1 LSTMCell coupling net (glow/models.py:176-185) */
+  int lstm;                  /* 0 GRUCell, 1 LSTMCell coupling net (glow/models.py:176-185); the LSTM starts from zero
+                                (h, c) at the first modelled frame (the reference's own call, models.py:209-213, crashes) */
   float scale_eps;           /* Glow.scale_eps */
   int gemm_precision;        /* lfi_gemm_desc.precision of the GEMMs issued by lfi_flow_param_grads / lfi_flow_sample_seq */
 } lfi_flow_dims;
@@ -164,8 +165,9 @@ int lfi_flow_param_grads(const lfi_flow_dims* d, const lfi_flow_params* p, const
                          const float* stash, const float* bstash, const float* c, long ldc, float gscale,
                          const lfi_flow_grads* g, int accumulate, float* work, void* stream);
 
-/* Pointers into the stashes (host-side address arithmetic only). which: 0 a, 1 y, 2 x_out, 3 h, 4 gates, 5 o, 6 ldc
- * for the forward stash; 0 dlin, 1 dgi, 2 dgh, 3 dy, 4 dx, 5 dh for the backward stash. */
+/* Pointers into the stashes (host-side address arithmetic only). which: 0 a, 1 y, 2 x_out, 3 h, 4 gates, 5 o, 6 ldc,
+ * 7 LSTM cell state (empty for GRU) for the forward stash; 0 dlin, 1 dgi, 2 dgh, 3 dy, 4 dx, 5 dh, 6/7 per-tile
+ * partial sums, 8 carried d cell state (LSTM) for the backward stash. */
 float* lfi_flow_stash_ptr(const lfi_flow_dims* d, float* stash, int which);
 float* lfi_flow_bstash_ptr(const lfi_flow_dims* d, float* bstash, int which);
 
@@ -175,11 +177,12 @@ float* lfi_flow_bstash_ptr(const lfi_flow_dims* d, float* bstash, int which);
 int lfi_actnorm_init_stats(const float* x, int rows, int C, double* sums, void* stream);
 int lfi_actnorm_init_apply(const double* sums, double count, int C, float scale, float* bias, float* logs, void* stream);
 /* One flow step on a (rows x C) batch with explicit state; used by the init walk, by module-level
- * FlowStep.forward and by the sampler. h_prev/h_out: (rows x H) (NULL h_prev = zeros). reverse = 1 runs
+ * FlowStep.forward and by the sampler. h_prev/h_out: (rows x H) (NULL h_prev = zeros); c_prev/c_out: the LSTM cell
+ * state, same shape (lstm = 1 only; c_out required then, ignored for GRU). reverse = 1 runs
  * FlowStep.reverse_flow (glow/models.py:345-373). gic_k: (rows x G). ldc_acc (rows): log-det accumulator (+=). */
 int lfi_flow_step(const lfi_flow_dims* d, const lfi_flow_params* p, const float* prep, int k, int rows,
-                  const float* x_in, long ldx, const float* h_prev, const float* gic_k,
-                  float* x_out, long ldxo, float* h_out, float* ldc_acc, int reverse, void* stream);
+                  const float* x_in, long ldx, const float* h_prev, const float* c_prev, const float* gic_k,
+                  float* x_out, long ldxo, float* h_out, float* c_out, float* ldc_acc, int reverse, void* stream);
 
 /* ---------------------------------------------------------------- autoregressive sampling (SeqGlow.inference, glow/models.py:567-596)
  * Whole sequence in one call. faces (B x seq_len x C, batch-first) holds the `start` seed frames and receives the
@@ -193,7 +196,8 @@ int lfi_flow_sample_seq(const lfi_flow_dims* d, const lfi_flow_params* p, const 
                         const float* wct /* [Ks*D][E] */, long E, int hist1,
                         const float* pre_static, const float* noise,
                         float* faces, int seq_len, int start, int nframes,
-                        float* h, float* work, void* stream);
+                        float* h, float* cstate /* [Ks][B][H] LSTM cell state, zero on entry; NULL for GRU */,
+                        float* work, void* stream);
 
 /* ---------------------------------------------------------------- optimiser (configure_optimizers, glow/lets_face_it_glow.py:61-72)
  * Flat-buffer Adam with global-norm gradient clipping (Trainer gradient_clip_val, hparams/final_model.yaml:126):

@@ -99,9 +99,9 @@ def lib():
         "lfi_flow_param_grads": (i, [P(FlowDims), P(FlowParams), vp, vp, vp, vp, l, f, P(FlowGrads), i, vp, vp]),
         "lfi_actnorm_init_stats": (i, [vp, i, i, vp, vp]),
         "lfi_actnorm_init_apply": (i, [vp, d, i, f, vp, vp, vp]),
-        "lfi_flow_step": (i, [P(FlowDims), P(FlowParams), vp, i, i, vp, l, vp, vp, vp, l, vp, vp, i, vp]),
+        "lfi_flow_step": (i, [P(FlowDims), P(FlowParams), vp, i, i, vp, l, vp, vp, vp, vp, l, vp, vp, vp, i, vp]),
         "lfi_flow_sample_work_floats": (l, [P(FlowDims)]),
-        "lfi_flow_sample_seq": (i, [P(FlowDims), P(FlowParams), vp, vp, l, i, vp, vp, vp, i, i, i, vp, vp, vp]),
+        "lfi_flow_sample_seq": (i, [P(FlowDims), P(FlowParams), vp, vp, l, i, vp, vp, vp, i, i, i, vp, vp, vp, vp]),
         "lfi_grad_sumsq": (i, [vp, l, vp, vp, vp]),
         "lfi_adam_clip_step": (i, [vp, vp, vp, vp, l, vp, f, f, f, f, f, f, i, vp]),
         "lfi_selftest_mfma": (i, [vp, vp]),

@@ -37,9 +37,9 @@ struct FlowK {
   // prep
   const float *W, *Wt, *Winv, *wz_t, *whh_t, *wfl_t, *wc, *ldconst;
   // forward stash
-  float *sA, *sY, *sX, *sH, *sG, *sO, *sL;
+  float *sA, *sY, *sX, *sH, *sG, *sO, *sL, *sC;   // sC: LSTM cell state (lstm only)
   // backward stash
-  float *bDlin, *bDgi, *bDgh, *bDy, *bDx, *bDh, *bPlfl, *bPan;
+  float *bDlin, *bDgi, *bDgh, *bDy, *bDx, *bDh, *bPlfl, *bPan, *bDc;   // bDc: carried d cell state (lstm only)
   // sequence inputs
   const float* x0; int T, start;
   const float* gic;
@@ -51,6 +51,8 @@ struct CellIO {
   int k, rows;            // flow step, valid rows in this call (<= B)
   const float* x_in; long ldx;   // rows x C
   const float* h_prev;    // rows x H or null (zeros)
+  const float* c_prev;    // LSTM cell state, rows x H or null (zeros); unused for GRU
+  float* c_out;           // LSTM: new cell state (required when lstm)
   const float* gic;       // rows x G
   float *a_out, *y_out, *x_out, *h_out, *g_out, *o_out, *l_out;  // nullable stashes; x_out/h_out required
   long ldxo;              // leading dimension of x_out
@@ -71,6 +73,41 @@ __device__ __forceinline__ void coupling_net_phase(const FlowK& f, const CellIO&
   const float* wh = f.whh_t + (long)k * H * G;
   const float* bhh = f.p.b_hh + (long)k * G;
   const int nht = (H + 15) >> 4;
+  if (f.lstm) {
+    // torch.nn.LSTMCell (gate order i, f, g, o) from zero (h, c) at the first modelled frame (glow/models.py:181-185,
+    // 209-213; the reference's own call crashes there, SURVEY.md finding 2: semantics = zero initial state)
+    for (int t = wave; t < nht; t += NW) {
+      const int j = t * 16 + l15;
+      const bool jok = j < H;
+      f32x4 gz[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+      mma16_pf<4>(gz, Zt, LT, wz + t * 16, G, H, Ch, jok, lane);
+      f32x4 gh[4] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
+      mma16_pf<4>(gh, Ht, LT, wh + t * 16, G, H, H, jok, lane);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = lq * 4 + r;
+        const int row = b0 + i;
+        float hnew = 0.0f;
+        if (row < io.rows && jok) {
+          const float* gc = io.gic + (long)row * G;
+          const float ii = sigmoidf_(gz[0][r] + gh[0][r] + gc[j] + bhh[j]);
+          const float ff = sigmoidf_(gz[1][r] + gh[1][r] + gc[H + j] + bhh[H + j]);
+          const float gg = tanhf(gz[2][r] + gh[2][r] + gc[2 * H + j] + bhh[2 * H + j]);
+          const float oo = sigmoidf_(gz[3][r] + gh[3][r] + gc[3 * H + j] + bhh[3 * H + j]);
+          const float cp = io.c_prev ? io.c_prev[(long)row * H + j] : 0.0f;
+          const float c2 = ff * cp + ii * gg;
+          hnew = oo * tanhf(c2);
+          io.h_out[(long)row * H + j] = hnew;
+          io.c_out[(long)row * H + j] = c2;
+          if (io.g_out) {
+            float* gs = io.g_out + (long)row * 4 * H;
+            gs[j] = ii; gs[H + j] = ff; gs[2 * H + j] = gg; gs[3 * H + j] = oo;
+          }
+        }
+        if (jok) Hn[j * LT + i] = hnew;
+      }
+    }
+  } else
   for (int t = wave; t < nht; t += NW) {
     const int j = t * 16 + l15;
     const bool jok = j < H;
@@ -327,6 +364,8 @@ __global__ __launch_bounds__(NT) void flow_diag_fwd_kernel(FlowK f, int d, int k
   if (k == 0) { io.x_in = f.x0 + (long)(f.start + n) * f.C; io.ldx = (long)f.T * f.C; }
   else { io.x_in = f.sX + ((long)(k - 1) * f.F + fr) * f.C; io.ldx = f.C; }
   io.h_prev = n > 0 ? f.sH + ((long)k * f.F + fr - f.B) * f.H : nullptr;
+  io.c_prev = (f.lstm && n > 0) ? f.sC + ((long)k * f.F + fr - f.B) * f.H : nullptr;
+  io.c_out = f.lstm ? f.sC + ((long)k * f.F + fr) * f.H : nullptr;
   io.gic = f.gic + ((long)k * f.F + fr) * f.G;
   io.a_out = f.sA + ((long)k * f.F + fr) * f.C;
   io.y_out = f.sY + ((long)k * f.F + fr) * f.C;
@@ -455,6 +494,45 @@ __global__ __launch_bounds__(NT) void flow_diag_bwd_kernel(FlowK f, int d, int k
     const float* dhf = (n < f.N - 1) ? f.bDh + ((long)k * f.F + fr + B) * H : nullptr;
     const float* gs_base = f.sG + kf * 4 * H;
     const float* hp_base = n > 0 ? f.sH + ((long)k * f.F + fr - B) * H : nullptr;
+    if (f.lstm) {
+      const float* dcf = (n < f.N - 1) ? f.bDc + ((long)k * f.F + fr + B) * H : nullptr;
+      const float* cp_base = n > 0 ? f.sC + ((long)k * f.F + fr - B) * H : nullptr;
+      const float* c_base = f.sC + kf * H;
+      float* dco = f.bDc + kf * H;
+      for (int t = wave; t < nht; t += NW) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        acc = tile16_lds_glb(acc, Dl, LT, wfl + t * 16, H, Cout, min(16, H - t * 16), lane);
+        const int j = t * 16 + l15;
+        if (j < H) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int i = lq * 4 + r;
+            const int row = b0 + i;
+            float dai = 0.f, daf = 0.f, dag = 0.f, dao = 0.f;
+            if (row < B) {
+              const float dhn = acc[r] + (dhf ? dhf[(long)row * H + j] : 0.0f);
+              const float* gs = gs_base + (long)row * 4 * H;
+              const float ii = gs[j], ff = gs[H + j], gg = gs[2 * H + j], oo = gs[3 * H + j];
+              const float tc = tanhf(c_base[(long)row * H + j]);
+              const float cp = cp_base ? cp_base[(long)row * H + j] : 0.0f;
+              const float dc2 = dhn * oo * (1.0f - tc * tc) + (dcf ? dcf[(long)row * H + j] : 0.0f);
+              dai = dc2 * gg * ii * (1.0f - ii);
+              daf = dc2 * cp * ff * (1.0f - ff);
+              dag = dc2 * ii * (1.0f - gg * gg);
+              dao = dhn * tc * oo * (1.0f - oo);
+              dco[(long)row * H + j] = dc2 * ff;
+              float* gi = f.bDgi + kf * G + (long)row * G;
+              gi[j] = dai; gi[H + j] = daf; gi[2 * H + j] = dag; gi[3 * H + j] = dao;
+              float* gh = f.bDgh + kf * G + (long)row * G;
+              gh[j] = dai; gh[H + j] = daf; gh[2 * H + j] = dag; gh[3 * H + j] = dao;
+            }
+            Gi[j * LT + i] = dai; Gi[(H + j) * LT + i] = daf; Gi[(2 * H + j) * LT + i] = dag; Gi[(3 * H + j) * LT + i] = dao;
+            Gh[j * LT + i] = dai; Gh[(H + j) * LT + i] = daf; Gh[(2 * H + j) * LT + i] = dag; Gh[(3 * H + j) * LT + i] = dao;
+            Cy[j * LT + i] = 0.0f;
+          }
+        }
+      }
+    } else
     for (int t = wave; t < nht; t += NW) {
       f32x4 acc = {0.f, 0.f, 0.f, 0.f};
       acc = tile16_lds_glb(acc, Dl, LT, wfl + t * 16, H, Cout, min(16, H - t * 16), lane);
@@ -827,14 +905,10 @@ __global__ __launch_bounds__(256) void actnorm_apply_kernel(const double* __rest
 int fill_flow(const lfi_flow_dims* d, const lfi_flow_params* p, const float* prep, FlowK* f, const char* who) {
   LFI_REQUIRE(d && p, "%s: null dims/params", who);
   LFI_REQUIRE(d->B > 0 && d->N > 0 && d->C >= 2 && d->H > 0 && d->D > 0 && d->Ks > 0, "%s: bad dims", who);
-  if (d->lstm) {
-    lfi_set_error("%s: LSTM coupling cell not implemented in this build", who);
-    return LFI_ERR_UNSUPPORTED;
-  }
   f->B = d->B; f->N = d->N; f->C = d->C; f->H = d->H; f->D = d->D; f->Ks = d->Ks;
   f->affine = d->affine; f->lstm = d->lstm; f->eps = d->scale_eps;
   f->Ch = d->C / 2; f->C2 = d->C - f->Ch; f->Cout = d->affine ? 2 * f->C2 : f->C2;
-  f->G = 3 * d->H; f->I = f->Ch + d->D; f->F = d->N * d->B; f->nbt = lfi_cdiv(d->B, MB);
+  f->G = (d->lstm ? 4 : 3) * d->H; f->I = f->Ch + d->D; f->F = d->N * d->B; f->nbt = lfi_cdiv(d->B, MB);
   f->p = *p;
   if (prep) {
     const long cc = (long)d->Ks * d->C * d->C;
@@ -861,6 +935,7 @@ long stash_offsets(const FlowK& f, long* off) {
   off[4] = o; o += KF * 4 * f.H;     // gates
   off[5] = o; o += KF * f.Cout;      // o
   off[6] = o; o += KF;               // coupling log-det
+  off[7] = o; o += f.lstm ? KF * f.H : 0;  // LSTM cell state
   return o;
 }
 long bstash_offsets(const FlowK& f, long* off) {
@@ -874,19 +949,20 @@ long bstash_offsets(const FlowK& f, long* off) {
   off[5] = o; o += KF * f.H;         // dh
   off[6] = o; o += (long)f.Ks * f.N * f.nbt * f.Cout;   // partial sums for l_fl
   off[7] = o; o += (long)f.Ks * f.N * f.nbt * 2 * f.C;  // partial sums for actnorm logs | bias
+  off[8] = o; o += f.lstm ? KF * f.H : 0;               // carried d cell state (LSTM)
   return o;
 }
 void bind_stash(FlowK* f, float* stash) {
-  long off[7];
+  long off[8];
   stash_offsets(*f, off);
   f->sA = stash + off[0]; f->sY = stash + off[1]; f->sX = stash + off[2]; f->sH = stash + off[3];
-  f->sG = stash + off[4]; f->sO = stash + off[5]; f->sL = stash + off[6];
+  f->sG = stash + off[4]; f->sO = stash + off[5]; f->sL = stash + off[6]; f->sC = stash + off[7];
 }
 void bind_bstash(FlowK* f, float* b) {
-  long off[8];
+  long off[9];
   bstash_offsets(*f, off);
   f->bDlin = b + off[0]; f->bDgi = b + off[1]; f->bDgh = b + off[2]; f->bDy = b + off[3];
-  f->bDx = b + off[4]; f->bDh = b + off[5]; f->bPlfl = b + off[6]; f->bPan = b + off[7];
+  f->bDx = b + off[4]; f->bDh = b + off[5]; f->bPlfl = b + off[6]; f->bPan = b + off[7]; f->bDc = b + off[8];
 }
 
 template <typename Kf>
@@ -949,29 +1025,29 @@ extern "C" long lfi_flow_stash_floats(const lfi_flow_dims* d) {
   FlowK f = {};
   lfi_flow_params p = {};
   if (fill_flow(d, &p, nullptr, &f, "lfi_flow_stash_floats")) return -1;
-  long off[7];
+  long off[8];
   return stash_offsets(f, off);
 }
 extern "C" long lfi_flow_bstash_floats(const lfi_flow_dims* d) {
   FlowK f = {};
   lfi_flow_params p = {};
   if (fill_flow(d, &p, nullptr, &f, "lfi_flow_bstash_floats")) return -1;
-  long off[8];
+  long off[9];
   return bstash_offsets(f, off);
 }
 extern "C" float* lfi_flow_stash_ptr(const lfi_flow_dims* d, float* stash, int which) {
   FlowK f = {};
   lfi_flow_params p = {};
-  if (which < 0 || which > 6 || fill_flow(d, &p, nullptr, &f, "lfi_flow_stash_ptr")) return nullptr;
-  long off[7];
+  if (which < 0 || which > 7 || fill_flow(d, &p, nullptr, &f, "lfi_flow_stash_ptr")) return nullptr;
+  long off[8];
   stash_offsets(f, off);
   return stash + off[which];
 }
 extern "C" float* lfi_flow_bstash_ptr(const lfi_flow_dims* d, float* bstash, int which) {
   FlowK f = {};
   lfi_flow_params p = {};
-  if (which < 0 || which > 7 || fill_flow(d, &p, nullptr, &f, "lfi_flow_bstash_ptr")) return nullptr;
-  long off[8];
+  if (which < 0 || which > 8 || fill_flow(d, &p, nullptr, &f, "lfi_flow_bstash_ptr")) return nullptr;
+  long off[9];
   bstash_offsets(f, off);
   return bstash + off[which];
 }
@@ -1119,15 +1195,17 @@ extern "C" int lfi_actnorm_init_apply(const double* sums, double count, int C, f
 }
 
 extern "C" int lfi_flow_step(const lfi_flow_dims* d, const lfi_flow_params* p, const float* prep, int k, int rows,
-                             const float* x_in, long ldx, const float* h_prev, const float* gic_k, float* x_out, long ldxo,
-                             float* h_out, float* ldc_acc, int reverse, void* stream) {
+                             const float* x_in, long ldx, const float* h_prev, const float* c_prev, const float* gic_k,
+                             float* x_out, long ldxo, float* h_out, float* c_out, float* ldc_acc, int reverse, void* stream) {
   FlowK f = {};
   int rc = fill_flow(d, p, prep, &f, "lfi_flow_step");
   if (rc) return rc;
   LFI_REQUIRE(prep && x_in && gic_k && x_out && h_out, "lfi_flow_step: null pointer");
   LFI_REQUIRE(k >= 0 && k < d->Ks && rows > 0, "lfi_flow_step: bad k/rows");
+  LFI_REQUIRE(!d->lstm || c_out, "lfi_flow_step: the LSTM cell needs c_out");
   CellIO io = {};
   io.k = k; io.rows = rows; io.x_in = x_in; io.ldx = ldx; io.h_prev = h_prev; io.gic = gic_k;
+  io.c_prev = d->lstm ? c_prev : nullptr; io.c_out = d->lstm ? c_out : nullptr;
   io.x_out = x_out; io.ldxo = ldxo; io.h_out = h_out; io.l_out = ldc_acc; io.l_accumulate = 1;
   const Carve cv = carve_fwd(f.C, f.H, f.Ch, f.C2, f.Cout);
   const size_t lds = (size_t)cv.total * sizeof(float);
@@ -1151,13 +1229,14 @@ extern "C" long lfi_flow_sample_work_floats(const lfi_flow_dims* d) {
 
 extern "C" int lfi_flow_sample_seq(const lfi_flow_dims* d, const lfi_flow_params* p, const float* prep, const float* wct,
                                    long E, int hist1, const float* pre_static, const float* noise, float* faces, int seq_len,
-                                   int start, int nframes, float* h, float* work, void* stream) {
+                                   int start, int nframes, float* h, float* cstate, float* work, void* stream) {
   FlowK f = {};
   int rc = fill_flow(d, p, prep, &f, "lfi_flow_sample_seq");
   if (rc) return rc;
   LFI_REQUIRE(prep && wct && pre_static && noise && faces && h && work, "lfi_flow_sample_seq: null pointer");
   LFI_REQUIRE(hist1 >= 0 && hist1 <= start && start + nframes <= seq_len, "lfi_flow_sample_seq: bad frame range");
   LFI_REQUIRE((long)hist1 * d->C <= E, "lfi_flow_sample_seq: window wider than the feature vector");
+  LFI_REQUIRE(!d->lstm || cstate, "lfi_flow_sample_seq: the LSTM cell needs cstate");
   const int B = f.B, C = f.C, H = f.H, D = f.D, Ks = f.Ks, G = f.G;
   float* cbuf = work;                          // B x Ks*D
   float* gic = cbuf + (long)B * Ks * D;        // [Ks][B][G]
@@ -1200,6 +1279,7 @@ extern "C" int lfi_flow_sample_seq(const lfi_flow_dims* d, const lfi_flow_params
       io.h_prev = n > 0 ? h + (long)k * B * H : nullptr;
       io.gic = gic + (long)k * B * G;
       io.h_out = h + (long)k * B * H;
+      if (f.lstm) { io.c_prev = n > 0 ? cstate + (long)k * B * H : nullptr; io.c_out = cstate + (long)k * B * H; }
       if (k == 0) { io.x_out = faces + (long)t * C; io.ldxo = (long)seq_len * C; }
       else { io.x_out = (k & 1) ? xa : xb; io.ldxo = C; }
       hipLaunchKernelGGL(flow_step_kernel<true>, dim3(f.nbt), dim3(NT), lds, st, f, io);

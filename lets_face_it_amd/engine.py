@@ -387,6 +387,7 @@ class GlowEngine:
         xa = self._buf("init_xa", B * s.C)
         xb = self._buf("init_xb", B * s.C)
         hd = self._buf("init_h", B * s.H)
+        cd = self._buf("init_c", B * s.H)
         xa[:B * s.C].view(B, s.C).copy_(x[:, s.start, :])
         sums = torch.zeros(2 * s.C, dtype=torch.float64, device=self.device)
         p = self._flow_params()
@@ -396,9 +397,9 @@ class GlowEngine:
             check(self.L.lfi_actnorm_init_apply(sums.data_ptr(), float(B * world), s.C, s.actnorm_scale,
                                                 self.fview("an_bias")[k].data_ptr(), self.fview("an_logs")[k].data_ptr(),
                                                 st), "lfi_actnorm_init_apply")
-            check(self.L.lfi_flow_step(C.byref(dims), C.byref(p), self.prep.data_ptr(), k, B, xa.data_ptr(), s.C, None,
-                                       gic.data_ptr() + 4 * k * F * s.G, xb.data_ptr(), s.C, hd.data_ptr(), None, 0, st),
-                  "lfi_flow_step")
+            check(self.L.lfi_flow_step(C.byref(dims), C.byref(p), self.prep.data_ptr(), k, B, xa.data_ptr(), s.C, None, None,
+                                       gic.data_ptr() + 4 * k * F * s.G, xb.data_ptr(), s.C, hd.data_ptr(), cd.data_ptr(),
+                                       None, 0, st), "lfi_flow_step")
             xa, xb = xb, xa
         self.run_prep()  # the constant log-det term depends on the new actnorm logs
 
@@ -527,12 +528,13 @@ class GlowEngine:
             pre[:F * KD].view(F, KD).copy_(self.fview("bct").reshape(1, KD).expand(F, KD))
         dims = self._flow_dims(B, nframes)
         h = self._buf("sample_h", s.Ks * B * s.H, zero=True)
+        cs = self._buf("sample_c", s.Ks * B * s.H, zero=True) if s.rnn_type == "lstm" else None
         work = self._buf("scratch.sample", self.L.lfi_flow_sample_work_floats(C.byref(dims)))
         p = self._flow_params()
         hist1 = s.encoders[0].hist
         check(self.L.lfi_flow_sample_seq(C.byref(dims), C.byref(p), self.prep.data_ptr(), self.wct_f.data_ptr(),
                                          s.ldf, hist1, pre.data_ptr(), noise.data_ptr(), faces.data_ptr(), seq_len, s.start,
-                                         nframes, h.data_ptr(), work.data_ptr(), _stream()), "lfi_flow_sample_seq")
+                                         nframes, h.data_ptr(), ptr(cs), work.data_ptr(), _stream()), "lfi_flow_sample_seq")
         return faces[:, s.start:]
 
     def invert(self, z_seq, batch, masks=None):
@@ -553,6 +555,7 @@ class GlowEngine:
         out = torch.empty(N, B, s.C, dtype=torch.float32, device=self.device)
         ld = torch.zeros(N, B, dtype=torch.float32, device=self.device)
         h = self._buf("sample_h", s.Ks * B * s.H, zero=True)
+        cs = self._buf("sample_c", s.Ks * B * s.H, zero=True)
         xa = self._buf("init_xa", B * s.C)
         xb = self._buf("init_xb", B * s.C)
         z_seq = z_seq.contiguous()
@@ -561,8 +564,10 @@ class GlowEngine:
             for k in range(s.Ks - 1, -1, -1):
                 dst = out.data_ptr() + 4 * n * B * s.C if k == 0 else (xa if (k & 1) else xb).data_ptr()
                 hk = h.data_ptr() + 4 * k * B * s.H
+                ck = cs.data_ptr() + 4 * k * B * s.H
                 check(self.L.lfi_flow_step(C.byref(dims), C.byref(p), self.prep.data_ptr(), k, B, src, ldx,
-                                           hk if n > 0 else None, gic.data_ptr() + 4 * (k * F + n * B) * s.G, dst, s.C, hk,
+                                           hk if n > 0 else None, ck if n > 0 else None,
+                                           gic.data_ptr() + 4 * (k * F + n * B) * s.G, dst, s.C, hk, ck,
                                            ld.data_ptr() + 4 * n * B, 1, st), "lfi_flow_step")
                 src = dst
         ldconst = self.prep[self._ldconst_offset()]

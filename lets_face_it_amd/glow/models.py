@@ -248,9 +248,9 @@ class SeqGlow(nn.Module):
 
     def _bind(self, device):
         """Move every parameter into the engine's flat buffer (values preserved) and alias the module tensors to it."""
-        if self.spec.rnn_type != "gru":
-            raise NotImplementedError("Glow.rnn_type=%r: the HIP coupling cell is GRU in this build (the reference's own "
-                                      "lstm branch crashes on its first timestep, models.py:209-213)" % self.spec.rnn_type)
+        if self.spec.rnn_type not in ("gru", "lstm"):
+            raise NotImplementedError("Glow.rnn_type=%r: the coupling cell is 'gru' or 'lstm' (models.py:176-185)"
+                                      % self.spec.rnn_type)
         eng = _engine.GlowEngine(self.spec, device)
 
         def slot(name, k, buf):

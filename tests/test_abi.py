@@ -34,9 +34,12 @@ def test_argument_errors_are_reported_not_crashes():
     L = _lib.lib()
     assert L.lfi_gemm_f32(None, None) == -1
     assert b"null descriptor" in L.lfi_last_error()
-    d = _lib.FlowDims(4, 2, 16, 32, 32, 2, 1, 1, 1e-4)  # lstm = 1: not built
+    d = _lib.FlowDims(4, 0, 16, 32, 32, 2, 1, 1, 1e-4)  # N = 0
     assert L.lfi_flow_stash_floats(ctypes.byref(d)) == -1
-    assert b"LSTM" in L.lfi_last_error()
+    assert b"bad dims" in L.lfi_last_error()
+    # the LSTM cell stashes its cell state on top of what the GRU cell keeps (host-side arithmetic only)
+    gru, lstm = _lib.FlowDims(4, 2, 16, 32, 32, 2, 1, 0, 1e-4), _lib.FlowDims(4, 2, 16, 32, 32, 2, 1, 1, 1e-4)
+    assert L.lfi_flow_stash_floats(ctypes.byref(lstm)) == L.lfi_flow_stash_floats(ctypes.byref(gru)) + 2 * 8 * 32
 
 
 def _struct_body(text, name):

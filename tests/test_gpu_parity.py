@@ -15,7 +15,7 @@ from oracle import seqglow_oracle as oracle
 
 pytestmark = pytest.mark.gpu
 
-GPU_FIXTURES = ("tiny", "tiny_additive", "odd", "mid")  # tiny_lstm: LSTM coupling cell not built (fails loudly, below)
+GPU_FIXTURES = ("tiny", "tiny_lstm", "tiny_additive", "odd", "mid")
 
 
 def build(fx, device, train=False, precision="f32"):
@@ -151,14 +151,6 @@ def test_actnorm_data_dependent_init(fx, gpu_device):
         assert rel_err(layer.actnorm.bias, fx.get("init/glow.flow.layers.%d.actnorm.bias" % k)) < 1e-4
         assert rel_err(layer.actnorm.logs, fx.get("init/glow.flow.layers.%d.actnorm.logs" % k)) < 1e-4
     assert max_rel(torch.stack(losses), fx.get("init/nll"), floor=1.0) < 2e-4
-
-
-def test_lstm_coupling_fails_loudly(gpu_device):
-    fxl = Fixture("tiny_lstm")
-    from lets_face_it_amd.glow.models import SeqGlow
-    m = SeqGlow(Namespace(**fxl.hp))
-    with pytest.raises(NotImplementedError):
-        m.to(gpu_device)(to_dev(fxl.batch(), gpu_device))
 
 
 def test_cpu_tensor_is_refused():
