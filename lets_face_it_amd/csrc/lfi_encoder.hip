@@ -128,6 +128,321 @@ __global__ __launch_bounds__(256) void gather_windows_kernel(const float* __rest
   for (int i = threadIdx.x; i < tot; i += 256) dst[i] = src[i];
 }
 
+
+// ---------------------------------------------------------------------------------------------- fused persistent path
+// For hid <= 256 the whole window recurrence of a block of windows runs inside ONE workgroup: windows are independent
+// of one another, so a workgroup owns R windows, keeps their state h (R x hid) in LDS across all `hist` steps and
+// per step does   gh = h_{s-1} W_hh^T  on v_mfma_f32_32x32x2_f32 (A = h from LDS k-major, B = W_hh^T streamed from L2
+// straight into the MFMA operand registers, chunk-prefetched) + the gate math on the accumulators. Nothing but the
+// stashes the backward pass needs goes to HBM (the unfused path also wrote and re-read gh, F x 3hid, every step, and
+// paid one GEMM + one gate launch per step). One launch per modality instead of 2 * hist.
+//   workgroup = 4 waves; wave (rg, cg) owns rows [32 rg, 32 rg + 32) x hidden [64 cg, 64 cg + 64) x the 3 gates
+//   (6 accumulator tiles); ncg = column groups = next_pow2(ceil(hid / 64)) <= 4, R = 32 * 4 / ncg rows per workgroup;
+//   LDS = Kp x (R + 1) floats <= 33 KB and <= 256 VGPRs: two workgroups share a CU and one's epilogue (HBM stores)
+//   overlaps the other's MFMAs.
+// The weights are re-laid once per call into a zero-padded image (Kp = hid rounded up to 16 rows of k, Jp = 64 ncg
+// columns) so the k loop carries no bounds checks: every load in it is unconditional.
+constexpr int ENC_NT = 256;
+constexpr int ENC_KC = 4;  // k-pairs per prefetch chunk (two chunks in flight)
+extern __shared__ __attribute__((aligned(16))) float enc_smem[];
+
+struct EncFused {
+  int ncg, R, Kp, Jp;
+  const float* wpad;   // forward: [Kp][3][Jp] = W_hh^T ; backward: [3][Kp][Jp] = W_hh, zero padded
+};
+
+// fwd = 1: dst[(k*3 + g)*Jp + j] = whh[(g*hid + j)*hid + k] ; fwd = 0: dst[(g*Kp + k)*Jp + j] = whh[(g*hid + k)*hid + j]
+__global__ __launch_bounds__(256) void enc_pad_weights_kernel(const float* __restrict__ whh, int hid, int Kp, int Jp, int fwd,
+                                                              float* __restrict__ dst) {
+  const long n = 3L * Kp * Jp;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < n; idx += (long)gridDim.x * 256) {
+    const int j = (int)(idx % Jp);
+    const int q = (int)(idx / Jp);
+    const int g = fwd ? q % 3 : q / Kp, k = fwd ? q / 3 : q % Kp;
+    float v = 0.0f;
+    if (k < hid && j < hid) v = fwd ? whh[((long)g * hid + j) * hid + k] : whh[((long)g * hid + k) * hid + j];
+    dst[idx] = v;
+  }
+}
+
+__device__ __forceinline__ int enc_rowl(int rg, int r, int half) { return rg * 32 + (r & 3) + 8 * (r >> 2) + 4 * half; }
+
+template <bool STASH, bool MASK>
+__global__ __launch_bounds__(ENC_NT, 2) void enc_gru_fwd_fused_kernel(EncArgs a, EncFused q) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, half = lane >> 5;
+  const int cg = wave % q.ncg, rg = wave / q.ncg;
+  const int hid = a.hid, G3 = 3 * hid, ldk = q.R + 1, Jp = q.Jp;
+  const int jb = cg * 64 + l31;               // hidden index of sub-tile 0; sub-tile 1 is jb + 32
+  const int wbase = blockIdx.x * q.R;
+  const int pos0 = a.start - a.hist + 1;
+  float* Als = enc_smem;  // h_{s-1}: element (row, k) at Als[k * ldk + row], rows k >= hid stay zero
+  for (int i = tid; i < q.Kp * ldk; i += ENC_NT) Als[i] = 0.0f;
+
+  float bi[2][3], bh[2][3];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {
+      const int j = jb + 32 * t;
+      const bool ok = j < hid;
+      bi[t][g] = ok ? a.b_ih[g * hid + j] : 0.0f;
+      bh[t][g] = ok ? a.b_hh[g * hid + j] : 0.0f;
+    }
+  const int boff = half * 3 * Jp + jb;         // per-lane offset into the padded weights (k = 2 kp + half)
+  const int aoff = half * ldk + rg * 32 + l31;  // per-lane offset into Als
+  const int nkp = q.Kp >> 1;                    // multiple of 2 * ENC_KC
+  __syncthreads();
+
+  for (int s = 0; s < a.hist; ++s) {
+    f32x16 acc[2][3];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int g = 0; g < 3; ++g)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][g][r] = 0.0f;
+    if (s > 0) {
+      float a0[ENC_KC], a1[ENC_KC], b0[ENC_KC][6], b1[ENC_KC][6];
+      auto load = [&](int kp0, float (&av)[ENC_KC], float (&bv)[ENC_KC][6]) {
+        const float* __restrict__ wk = q.wpad + (long)kp0 * 6 * Jp;  // uniform base, 32-bit per-lane offset: saddr loads
+        const float* ak = Als + kp0 * 2 * ldk;
+#pragma unroll
+        for (int u = 0; u < ENC_KC; ++u) {
+          av[u] = ak[u * 2 * ldk + aoff];
+#pragma unroll
+          for (int g = 0; g < 3; ++g) {
+            const float* __restrict__ wu = wk + (u * 6 + g) * Jp;  // uniform
+            bv[u][g] = wu[(unsigned)boff];
+            bv[u][3 + g] = (wu + 32)[(unsigned)boff];
+          }
+        }
+      };
+      auto mma = [&](const float (&av)[ENC_KC], const float (&bv)[ENC_KC][6]) {
+#pragma unroll
+        for (int u = 0; u < ENC_KC; ++u)
+#pragma unroll
+          for (int g = 0; g < 3; ++g) {
+            acc[0][g] = mfma32(av[u], bv[u][g], acc[0][g]);
+            acc[1][g] = mfma32(av[u], bv[u][3 + g], acc[1][g]);
+          }
+      };
+      load(0, a0, b0);
+      for (int kp = 0; kp < nkp; kp += 2 * ENC_KC) {
+        load(kp + ENC_KC, a1, b1);
+        mma(a0, b0);
+        if (kp + 2 * ENC_KC < nkp) load(kp + 2 * ENC_KC, a0, b0);
+        mma(a1, b1);
+      }
+    }
+    __syncthreads();  // every wave has finished reading h_{s-1}
+    // gate math on the accumulators in four straight-line groups (one hidden sub-tile x 8 registers each: 40 loads in
+    // flight per lane). Rows past F are clamped to the last window (they recompute and re-store its values). The lane
+    // coordinates are laundered through an empty asm so that the per-register address arithmetic stays inside the step
+    // loop instead of being hoisted into ~100 loop-invariant registers (which spilled).
+    int halfv = half, jv = jb;
+    asm volatile("" : "+v"(halfv), "+v"(jv));
+    const float* __restrict__ xs = a.Xp + (long)(pos0 + s) * G3;                 // uniform bases of this step
+    float* __restrict__ hs = STASH ? a.hseq + (long)s * a.F * hid : nullptr;
+    float* __restrict__ gsb = STASH ? a.gates + (long)s * a.F * 4 * hid : nullptr;
+    const float* __restrict__ ms = MASK ? a.mask + s : nullptr;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int j = jv + 32 * t;
+      if (j < hid) {
+#pragma unroll
+        for (int rh = 0; rh < 2; ++rh) {
+          float xr[8], xu[8], xn[8], mk[8], hp[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const int rl = enc_rowl(rg, rh * 8 + e, halfv);
+            const int w = min(wbase + rl, a.F - 1);
+            const int n = w / a.B, b = w - n * a.B;
+            const unsigned xo = (unsigned)(b * a.T + n) * (unsigned)G3 + (unsigned)j;
+            xr[e] = xs[xo]; xu[e] = (xs + hid)[xo]; xn[e] = (xs + 2 * hid)[xo];
+            mk[e] = MASK ? ms[(unsigned)(w * a.hist)] : 1.0f;
+            hp[e] = Als[j * ldk + rl];  // zero at s = 0
+          }
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const int r = rh * 8 + e;
+            const int rl = enc_rowl(rg, r, halfv);
+            const float ghn = acc[t][2][r] + bh[t][2];
+            const float rr = sigmoidf_(mk[e] * xr[e] + bi[t][0] + (acc[t][0][r] + bh[t][0]));
+            const float uu = sigmoidf_(mk[e] * xu[e] + bi[t][1] + (acc[t][1][r] + bh[t][1]));
+            const float nn = tanhf(mk[e] * xn[e] + bi[t][2] + rr * ghn);
+            const float hnew = (1.0f - uu) * nn + uu * hp[e];
+            if (STASH) {
+              const unsigned w = (unsigned)min(wbase + rl, a.F - 1);
+              hs[w * (unsigned)hid + (unsigned)j] = hnew;
+              const unsigned go = w * (unsigned)(4 * hid) + (unsigned)j;
+              gsb[go] = rr; (gsb + hid)[go] = uu; (gsb + 2 * hid)[go] = nn; (gsb + 3 * hid)[go] = ghn;
+            }
+            Als[j * ldk + rl] = hnew;
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    }
+    __syncthreads();
+  }
+  // cat(seq[:, -1], h_n[0]): the final state, once or twice (glow/models.py:63-64), straight from LDS
+  for (int idx = tid; idx < q.R * hid; idx += ENC_NT) {
+    const int rl = idx / hid, j = idx - rl * hid;
+    const int w = wbase + rl;
+    if (w < a.F) {
+      const float v = Als[j * ldk + rl];
+      float* c = a.cond + (long)w * a.ldcond + a.col + j;
+      c[0] = v;
+      if (a.dup) c[hid] = v;
+    }
+  }
+}
+
+// BPTT of the same block of windows in one workgroup: dh lives in the accumulator layout of the wave that owns
+// (rows, hidden) tile (rg, cg); per step the gate derivatives are taken in registers, written to dgi / dgh (the
+// deferred weight-gradient GEMMs read those) and fed gate by gate through LDS as the A operand of
+// dh_{s-1} = dgh_s W_hh + dh_s * u   (K = 3 hid, B = W_hh rows streamed from L2).
+__global__ __launch_bounds__(ENC_NT, 2) void enc_gru_bwd_fused_kernel(EncArgs a, EncFused q) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, half = lane >> 5;
+  const int cg = wave % q.ncg, rg = wave / q.ncg;
+  const int hid = a.hid, G3 = 3 * hid, ldk = q.R + 1, Jp = q.Jp;
+  const int jb = cg * 64 + l31;
+  const bool jok0 = jb < hid, jok1 = jb + 32 < hid;
+  const int wbase = blockIdx.x * q.R;
+  float* Dls = enc_smem;  // one gate's derivatives: element (row, k) at Dls[k * ldk + row], rows k >= hid stay zero
+  for (int i = tid; i < q.Kp * ldk; i += ENC_NT) Dls[i] = 0.0f;
+  const int boff = half * Jp + jb;
+  const int aoff = half * ldk + rg * 32 + l31;
+  const int nkp = q.Kp >> 1;
+
+  f32x16 dh[2];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int w = min(wbase + enc_rowl(rg, r, half), a.F - 1);
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int j = jb + 32 * t;
+      float v = 0.0f;
+      if (j < hid) {
+        const float* dc = a.dcond + (long)w * a.lddcond + a.col;
+        v = a.dup ? dc[j] + dc[hid + j] : dc[j];
+      }
+      dh[t][r] = v;
+    }
+  }
+  __syncthreads();
+  for (int s = a.hist - 1; s >= 0; --s) {
+    float dg[3][2][16];
+    f32x16 acc[2];
+    const float hp_on = s > 0 ? 1.0f : 0.0f;
+    const int sp = s > 0 ? s - 1 : 0;
+    // uniform bases of this step + 32-bit per-lane offsets (saddr addressing); lane coordinates laundered so that the
+    // per-register address arithmetic is not hoisted out of the step loop (see the forward kernel)
+    int halfv = half, jv = jb;
+    asm volatile("" : "+v"(halfv), "+v"(jv));
+    const float* __restrict__ gsb = a.gates + (long)s * a.F * 4 * hid;
+    const float* __restrict__ hpb = a.hseq + (long)sp * a.F * hid;
+    float* __restrict__ gib = a.dgi + (long)s * a.F * G3;
+    float* __restrict__ ghb = a.dgh + (long)s * a.F * G3;
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int j = jv + 32 * t;
+      if (j < hid) {
+#pragma unroll
+        for (int rh = 0; rh < 2; ++rh) {
+          float gr[8], gu[8], gn[8], gg[8], hp[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const unsigned w = (unsigned)min(wbase + enc_rowl(rg, rh * 8 + e, halfv), a.F - 1);
+            const unsigned go = w * (unsigned)(4 * hid) + (unsigned)j;
+            gr[e] = gsb[go]; gu[e] = (gsb + hid)[go]; gn[e] = (gsb + 2 * hid)[go]; gg[e] = (gsb + 3 * hid)[go];
+            hp[e] = hpb[w * (unsigned)hid + (unsigned)j];
+          }
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const int r = rh * 8 + e;
+            const unsigned w = (unsigned)min(wbase + enc_rowl(rg, r, halfv), a.F - 1);
+            const float rr = gr[e], uu = gu[e], nn = gn[e], ghn = gg[e];
+            const float dhn = dh[t][r];
+            const float du = dhn * (hp[e] * hp_on - nn);
+            const float dn = dhn * (1.0f - uu);
+            const float dan = dn * (1.0f - nn * nn);
+            const float dau = du * uu * (1.0f - uu);
+            const float dar = dan * ghn * rr * (1.0f - rr);
+            const float danr = dan * rr;
+            const unsigned o = w * (unsigned)G3 + (unsigned)j;
+            gib[o] = dar; (gib + hid)[o] = dau; (gib + 2 * hid)[o] = dan;
+            ghb[o] = dar; (ghb + hid)[o] = dau; (ghb + 2 * hid)[o] = danr;
+            dg[0][t][r] = dar; dg[1][t][r] = dau; dg[2][t][r] = danr;
+            acc[t][r] = dhn * uu;
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dg[0][t][r] = 0.f; dg[1][t][r] = 0.f; dg[2][t][r] = 0.f; acc[t][r] = 0.f; }
+      }
+    }
+    if (s == 0) break;
+#pragma unroll
+    for (int g = 0; g < 3; ++g) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int rl = enc_rowl(rg, r, halfv);
+        if (jok0) Dls[jv * ldk + rl] = dg[g][0][r];
+        if (jok1) Dls[(jv + 32) * ldk + rl] = dg[g][1][r];
+      }
+      __syncthreads();
+      {
+        float a0[ENC_KC], a1[ENC_KC], b0[ENC_KC][2], b1[ENC_KC][2];
+        const float* __restrict__ wg = q.wpad + (long)g * q.Kp * Jp;
+        auto load = [&](int kp0, float (&av)[ENC_KC], float (&bv)[ENC_KC][2]) {
+          const float* __restrict__ wk = wg + (long)kp0 * 2 * Jp;  // uniform base, 32-bit per-lane offset: saddr loads
+          const float* ak = Dls + kp0 * 2 * ldk;
+#pragma unroll
+          for (int u = 0; u < ENC_KC; ++u) {
+            av[u] = ak[u * 2 * ldk + aoff];
+            const float* __restrict__ wu = wk + u * 2 * Jp;  // uniform
+            bv[u][0] = wu[(unsigned)boff];
+            bv[u][1] = (wu + 32)[(unsigned)boff];
+          }
+        };
+        auto mma = [&](const float (&av)[ENC_KC], const float (&bv)[ENC_KC][2]) {
+#pragma unroll
+          for (int u = 0; u < ENC_KC; ++u) {
+            acc[0] = mfma32(av[u], bv[u][0], acc[0]);
+            acc[1] = mfma32(av[u], bv[u][1], acc[1]);
+          }
+        };
+        load(0, a0, b0);
+        for (int kp = 0; kp < nkp; kp += 2 * ENC_KC) {
+          load(kp + ENC_KC, a1, b1);
+          mma(a0, b0);
+          if (kp + 2 * ENC_KC < nkp) load(kp + 2 * ENC_KC, a0, b0);
+          mma(a1, b1);
+        }
+      }
+      __syncthreads();  // before the next gate overwrites Dls
+    }
+    dh[0] = acc[0];
+    dh[1] = acc[1];
+  }
+}
+
+// shape of the fused path, or 0 when the recurrence is too wide for it
+int enc_fused_shape(int hid, EncFused* q) {
+  if (hid > 256) return 0;
+  int tiles = lfi_cdiv(hid, 64), ncg = 1;
+  while (ncg < tiles) ncg <<= 1;
+  q->ncg = ncg;
+  q->R = 32 * (4 / ncg);
+  q->Kp = (hid + 15) & ~15;
+  q->Jp = 64 * ncg;
+  return 1;
+}
+
 int fill_args(const lfi_enc_desc* d, EncArgs* a, const char* who) {
   LFI_REQUIRE(d, "%s: null descriptor", who);
   LFI_REQUIRE(d->B > 0 && d->T > 0 && d->N > 0 && d->hist > 0 && d->hid > 0, "%s: bad dims", who);
@@ -145,7 +460,9 @@ int ew_blocks(long total) { return (int)(lfi_cdiv(total, 256) < 4096 ? lfi_cdiv(
 
 extern "C" long lfi_encode_windows_work_floats(const lfi_enc_desc* d) {
   if (!d) return 0;
-  return (long)d->N * d->B * 3 * d->hid;  // fwd: gh (F x 3hid); bwd: two F x hid gradient buffers
+  const long unfused = (long)d->N * d->B * 3 * d->hid;  // fwd: gh (F x 3hid); bwd: two F x hid gradient buffers
+  const long fused = 3L * 256 * 256;                    // fused path: zero-padded weight image
+  return unfused > fused ? unfused : fused;
 }
 
 extern "C" int lfi_encode_windows_fwd(const lfi_enc_desc* d, const float* Xp, const float* whh, const float* b_ih,
@@ -154,10 +471,27 @@ extern "C" int lfi_encode_windows_fwd(const lfi_enc_desc* d, const float* Xp, co
   EncArgs a = {};
   int rc = fill_args(d, &a, "lfi_encode_windows_fwd");
   if (rc) return rc;
-  LFI_REQUIRE(Xp && whh && b_ih && b_hh && cond && hseq && work, "lfi_encode_windows_fwd: null pointer");
+  LFI_REQUIRE(Xp && whh && b_ih && b_hh && cond && work, "lfi_encode_windows_fwd: null pointer");
   a.Xp = Xp; a.b_ih = b_ih; a.b_hh = b_hh; a.mask = mask; a.cond = cond; a.gates = gates; a.hseq = hseq;
   hipStream_t st = (hipStream_t)stream;
   const int hid = d->hid, F = a.F;
+  EncFused q = {};
+  if (enc_fused_shape(hid, &q)) {
+    LFI_REQUIRE(!gates || hseq, "lfi_encode_windows_fwd: the gate stash needs the state stash too");
+    // (without a gate stash nothing is kept for a backward pass: hseq is not written either)
+    hipLaunchKernelGGL(enc_pad_weights_kernel, dim3(lfi_cdiv(3L * q.Kp * q.Jp, 256)), dim3(256), 0, st, whh, hid, q.Kp, q.Jp, 1,
+                       work);
+    q.wpad = work;
+    const size_t lds = (size_t)q.Kp * (q.R + 1) * sizeof(float);
+    const dim3 grid(lfi_cdiv(F, q.R));
+    if (gates && mask) hipLaunchKernelGGL((enc_gru_fwd_fused_kernel<true, true>), grid, dim3(ENC_NT), lds, st, a, q);
+    else if (gates) hipLaunchKernelGGL((enc_gru_fwd_fused_kernel<true, false>), grid, dim3(ENC_NT), lds, st, a, q);
+    else if (mask) hipLaunchKernelGGL((enc_gru_fwd_fused_kernel<false, true>), grid, dim3(ENC_NT), lds, st, a, q);
+    else hipLaunchKernelGGL((enc_gru_fwd_fused_kernel<false, false>), grid, dim3(ENC_NT), lds, st, a, q);
+    LFI_LAUNCH_CHECK("lfi_encode_windows_fwd (fused)");
+    return LFI_OK;
+  }
+  LFI_REQUIRE(hseq, "lfi_encode_windows_fwd: hid > 256 needs the state stash hseq");
   const int blocks = ew_blocks((long)F * hid);
   for (int s = 0; s < d->hist; ++s) {
     if (s > 0) {
@@ -184,6 +518,16 @@ extern "C" int lfi_encode_windows_bwd(const lfi_enc_desc* d, const float* dcond,
   a.dcond = dcond; a.lddcond = lddcond; a.gates = (float*)gates; a.hseq = (float*)hseq; a.dgi = dgi; a.dgh = dgh;
   hipStream_t st = (hipStream_t)stream;
   const int hid = d->hid, F = a.F;
+  EncFused q = {};
+  if (enc_fused_shape(hid, &q)) {
+    hipLaunchKernelGGL(enc_pad_weights_kernel, dim3(lfi_cdiv(3L * q.Kp * q.Jp, 256)), dim3(256), 0, st, whh, hid, q.Kp, q.Jp, 0,
+                       work);
+    q.wpad = work;
+    const size_t lds = (size_t)q.Kp * (q.R + 1) * sizeof(float);
+    hipLaunchKernelGGL(enc_gru_bwd_fused_kernel, dim3(lfi_cdiv(F, q.R)), dim3(ENC_NT), lds, st, a, q);
+    LFI_LAUNCH_CHECK("lfi_encode_windows_bwd (fused)");
+    return LFI_OK;
+  }
   const int blocks = ew_blocks((long)F * hid);
   float* buf[2] = {work, work + (long)F * hid};
   const float* dh_in = nullptr;
