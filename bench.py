@@ -209,7 +209,7 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="per-GPU batch (BASELINE: 256)")
     ap.add_argument("--seq-len", type=int, default=80)
     ap.add_argument("--cpu-baseline-seconds", type=float, default=25.0, help="0 disables the CPU baseline leg")
-    ap.add_argument("--precision", choices=("f32", "bf16x3"), default=os.environ.get("LFI_PRECISION", "f32"),
+    ap.add_argument("--precision", choices=("f32", "bf16x3"), default=os.environ.get("LFI_PRECISION", "bf16x3"),
                     help="GEMM arithmetic: exact f32 MFMA, or bf16 hi/lo split operands (3 bf16 MFMAs per product)")
     ap.add_argument("--workload", choices=("train", "sample"), default="train",
                     help="train: BASELINE.json configs[1] (the headline metric); sample: configs[3], autoregressive "

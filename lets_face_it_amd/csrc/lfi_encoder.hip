@@ -149,7 +149,36 @@ extern __shared__ __attribute__((aligned(16))) float enc_smem[];
 struct EncFused {
   int ncg, R, Kp, Jp;
   const float* wpad;   // forward: [Kp][3][Jp] = W_hh^T ; backward: [3][Kp][Jp] = W_hh, zero padded
+  const uint4* wfrag;  // bf16x3 mode: the same matrices split into bf16 hi / lo planes in MFMA B-fragment order
 };
+
+// bf16x3 variant of the fused path (lfi_enc_desc.precision = 1): the state is split into bf16 hi + lo when it is written
+// to LDS (row-major [R][Kp + 8] images, one ds_read_b128 per A fragment) and every 32x32x16 step issues
+// lo*hi + hi*lo + hi*hi into the fp32 accumulators (~2^-16 relative per product, 16x the f32-input MFMA rate). The
+// weights are split ONCE per call into fragment order: the 8 bf16 a lane feeds to v_mfma_f32_32x32x16_bf16 are 16
+// contiguous bytes, a wave's fragment 1 KB: one coalesced global_load_dwordx4 per (k-tile, column tile, plane).
+typedef __bf16 ebf16x8 __attribute__((ext_vector_type(8)));
+union EncFrag { uint4 u; ebf16x8 v; };
+
+// element ((((kt*3 + g)*nct + ct)*2 + plane)*64 + lane)*8 + e  (fwd)  /  ((((g*nkt + kt)*nct + ct)*2 + plane)*64 + lane)*8 + e (bwd)
+// holds k = kt*16 + 8*(lane>>5) + e, column j = ct*32 + (lane&31) of W_hh^T[k][g*hid + j] (fwd) / W_hh[g*hid + k][j] (bwd)
+__global__ __launch_bounds__(256) void enc_frag_weights_kernel(const float* __restrict__ whh, int hid, int Kp, int Jp, int fwd,
+                                                               __bf16* __restrict__ dst) {
+  const int nkt = Kp >> 4, nct = Jp >> 5;
+  const long n = 3L * Kp * Jp * 2;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < n; idx += (long)gridDim.x * 256) {
+    const int e = (int)(idx & 7), l = (int)((idx >> 3) & 63), plane = (int)((idx >> 9) & 1);
+    long q = idx >> 10;
+    const int ct = (int)(q % nct); q /= nct;
+    int g, kt;
+    if (fwd) { g = (int)(q % 3); kt = (int)(q / 3); } else { kt = (int)(q % nkt); g = (int)(q / nkt); }
+    const int k = kt * 16 + 8 * (l >> 5) + e, j = ct * 32 + (l & 31);
+    float v = 0.0f;
+    if (k < hid && j < hid) v = fwd ? whh[((long)g * hid + j) * hid + k] : whh[((long)g * hid + k) * hid + j];
+    const __bf16 hi = (__bf16)v;
+    dst[idx] = plane ? (__bf16)(v - (float)hi) : hi;
+  }
+}
 
 // fwd = 1: dst[(k*3 + g)*Jp + j] = whh[(g*hid + j)*hid + k] ; fwd = 0: dst[(g*Kp + k)*Jp + j] = whh[(g*hid + k)*hid + j]
 __global__ __launch_bounds__(256) void enc_pad_weights_kernel(const float* __restrict__ whh, int hid, int Kp, int Jp, int fwd,
@@ -167,7 +196,7 @@ __global__ __launch_bounds__(256) void enc_pad_weights_kernel(const float* __res
 
 __device__ __forceinline__ int enc_rowl(int rg, int r, int half) { return rg * 32 + (r & 3) + 8 * (r >> 2) + 4 * half; }
 
-template <bool STASH, bool MASK>
+template <bool STASH, bool MASK, bool X3>
 __global__ __launch_bounds__(ENC_NT, 2) void enc_gru_fwd_fused_kernel(EncArgs a, EncFused q) {
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, half = lane >> 5;
@@ -178,6 +207,12 @@ __global__ __launch_bounds__(ENC_NT, 2) void enc_gru_fwd_fused_kernel(EncArgs a,
   const int pos0 = a.start - a.hist + 1;
   float* Als = enc_smem;  // h_{s-1}: element (row, k) at Als[k * ldk + row], rows k >= hid stay zero
   for (int i = tid; i < q.Kp * ldk; i += ENC_NT) Als[i] = 0.0f;
+  // X3: bf16 hi / lo images of the same state, row-major, columns k >= hid stay zero
+  const int ldx = q.Kp + 8;
+  __bf16* Xhi = reinterpret_cast<__bf16*>(enc_smem + q.Kp * ldk);
+  __bf16* Xlo = Xhi + q.R * ldx;
+  if (X3)
+    for (int i = tid; i < q.R * ldx; i += ENC_NT) { Xhi[i] = (__bf16)0.0f; Xlo[i] = (__bf16)0.0f; }
 
   float bi[2][3], bh[2][3];
 #pragma unroll
@@ -202,7 +237,44 @@ __global__ __launch_bounds__(ENC_NT, 2) void enc_gru_fwd_fused_kernel(EncArgs a,
       for (int g = 0; g < 3; ++g)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][g][r] = 0.0f;
-    if (s > 0) {
+    if (X3 && s > 0) {
+      // per 16-deep k-tile: A hi/lo fragments of this wave's 32 rows, B hi/lo fragments of its 2 x 3 column tiles
+      const int nkt = q.Kp >> 4, nct = Jp >> 5;
+      const __bf16* xh = Xhi + (rg * 32 + l31) * ldx + 8 * half;
+      const __bf16* xl = Xlo + (rg * 32 + l31) * ldx + 8 * half;
+      ebf16x8 ah0, al0, ah1, al1;
+      EncFrag f0[2][3][2], f1[2][3][2];  // [t][g][plane]
+      auto load = [&](int kt, ebf16x8& ah, ebf16x8& al, EncFrag (&f)[2][3][2]) {
+        ah = *reinterpret_cast<const ebf16x8*>(xh + kt * 16);
+        al = *reinterpret_cast<const ebf16x8*>(xl + kt * 16);
+#pragma unroll
+        for (int g = 0; g < 3; ++g)
+#pragma unroll
+          for (int t = 0; t < 2; ++t) {
+            const uint4* __restrict__ wf = q.wfrag + ((long)((kt * 3 + g) * nct + cg * 2 + t) * 2) * 64;  // uniform
+            f[t][g][0].u = wf[(unsigned)lane];
+            f[t][g][1].u = (wf + 64)[(unsigned)lane];
+          }
+      };
+      auto mma = [&](const ebf16x8& ah, const ebf16x8& al, const EncFrag (&f)[2][3][2]) {
+#pragma unroll
+        for (int g = 0; g < 3; ++g)
+#pragma unroll
+          for (int t = 0; t < 2; ++t) {
+            acc[t][g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, f[t][g][0].v, acc[t][g], 0, 0, 0);
+            acc[t][g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, f[t][g][1].v, acc[t][g], 0, 0, 0);
+            acc[t][g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, f[t][g][0].v, acc[t][g], 0, 0, 0);
+          }
+      };
+      load(0, ah0, al0, f0);
+      for (int kt = 0; kt < nkt; kt += 2) {
+        if (kt + 1 < nkt) load(kt + 1, ah1, al1, f1);
+        mma(ah0, al0, f0);
+        if (kt + 2 < nkt) load(kt + 2, ah0, al0, f0);
+        if (kt + 1 < nkt) mma(ah1, al1, f1);
+      }
+    }
+    if (!X3 && s > 0) {
       float a0[ENC_KC], a1[ENC_KC], b0[ENC_KC][6], b1[ENC_KC][6];
       auto load = [&](int kp0, float (&av)[ENC_KC], float (&bv)[ENC_KC][6]) {
         const float* __restrict__ wk = q.wpad + (long)kp0 * 6 * Jp;  // uniform base, 32-bit per-lane offset: saddr loads
@@ -279,6 +351,11 @@ __global__ __launch_bounds__(ENC_NT, 2) void enc_gru_fwd_fused_kernel(EncArgs a,
               gsb[go] = rr; (gsb + hid)[go] = uu; (gsb + 2 * hid)[go] = nn; (gsb + 3 * hid)[go] = ghn;
             }
             Als[j * ldk + rl] = hnew;
+            if (X3) {
+              const __bf16 hi = (__bf16)hnew;
+              Xhi[rl * ldx + j] = hi;
+              Xlo[rl * ldx + j] = (__bf16)(hnew - (float)hi);
+            }
           }
           __builtin_amdgcn_sched_barrier(0);
         }
@@ -303,6 +380,7 @@ __global__ __launch_bounds__(ENC_NT, 2) void enc_gru_fwd_fused_kernel(EncArgs a,
 // (rows, hidden) tile (rg, cg); per step the gate derivatives are taken in registers, written to dgi / dgh (the
 // deferred weight-gradient GEMMs read those) and fed gate by gate through LDS as the A operand of
 // dh_{s-1} = dgh_s W_hh + dh_s * u   (K = 3 hid, B = W_hh rows streamed from L2).
+template <bool X3>
 __global__ __launch_bounds__(ENC_NT, 2) void enc_gru_bwd_fused_kernel(EncArgs a, EncFused q) {
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, half = lane >> 5;
@@ -312,7 +390,14 @@ __global__ __launch_bounds__(ENC_NT, 2) void enc_gru_bwd_fused_kernel(EncArgs a,
   const bool jok0 = jb < hid, jok1 = jb + 32 < hid;
   const int wbase = blockIdx.x * q.R;
   float* Dls = enc_smem;  // one gate's derivatives: element (row, k) at Dls[k * ldk + row], rows k >= hid stay zero
-  for (int i = tid; i < q.Kp * ldk; i += ENC_NT) Dls[i] = 0.0f;
+  const int ldx = q.Kp + 8;
+  __bf16* Xhi = reinterpret_cast<__bf16*>(enc_smem);  // X3: bf16 hi / lo images instead, row-major [R][Kp + 8]
+  __bf16* Xlo = Xhi + q.R * ldx;
+  if (X3) {
+    for (int i = tid; i < q.R * ldx; i += ENC_NT) { Xhi[i] = (__bf16)0.0f; Xlo[i] = (__bf16)0.0f; }
+  } else {
+    for (int i = tid; i < q.Kp * ldk; i += ENC_NT) Dls[i] = 0.0f;
+  }
   const int boff = half * Jp + jb;
   const int aoff = half * ldk + rg * 32 + l31;
   const int nkp = q.Kp >> 1;
@@ -391,11 +476,53 @@ __global__ __launch_bounds__(ENC_NT, 2) void enc_gru_bwd_fused_kernel(EncArgs a,
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int rl = enc_rowl(rg, r, halfv);
-        if (jok0) Dls[jv * ldk + rl] = dg[g][0][r];
-        if (jok1) Dls[(jv + 32) * ldk + rl] = dg[g][1][r];
+        if (X3) {
+#pragma unroll
+          for (int t = 0; t < 2; ++t)
+            if (t ? jok1 : jok0) {
+              const float v = dg[g][t][r];
+              const __bf16 hi = (__bf16)v;
+              Xhi[rl * ldx + jv + 32 * t] = hi;
+              Xlo[rl * ldx + jv + 32 * t] = (__bf16)(v - (float)hi);
+            }
+        } else {
+          if (jok0) Dls[jv * ldk + rl] = dg[g][0][r];
+          if (jok1) Dls[(jv + 32) * ldk + rl] = dg[g][1][r];
+        }
       }
       __syncthreads();
-      {
+      if (X3) {
+        const int nkt = q.Kp >> 4, nct = Jp >> 5;
+        const __bf16* xh = Xhi + (rg * 32 + l31) * ldx + 8 * half;
+        const __bf16* xl = Xlo + (rg * 32 + l31) * ldx + 8 * half;
+        ebf16x8 ah0, al0, ah1, al1;
+        EncFrag f0[2][2], f1[2][2];  // [t][plane]
+        auto load = [&](int kt, ebf16x8& ah, ebf16x8& al, EncFrag (&f)[2][2]) {
+          ah = *reinterpret_cast<const ebf16x8*>(xh + kt * 16);
+          al = *reinterpret_cast<const ebf16x8*>(xl + kt * 16);
+#pragma unroll
+          for (int t = 0; t < 2; ++t) {
+            const uint4* __restrict__ wf = q.wfrag + ((long)((g * nkt + kt) * nct + cg * 2 + t) * 2) * 64;  // uniform
+            f[t][0].u = wf[(unsigned)lane];
+            f[t][1].u = (wf + 64)[(unsigned)lane];
+          }
+        };
+        auto mma = [&](const ebf16x8& ah, const ebf16x8& al, const EncFrag (&f)[2][2]) {
+#pragma unroll
+          for (int t = 0; t < 2; ++t) {
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, f[t][0].v, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, f[t][1].v, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, f[t][0].v, acc[t], 0, 0, 0);
+          }
+        };
+        load(0, ah0, al0, f0);
+        for (int kt = 0; kt < nkt; kt += 2) {
+          if (kt + 1 < nkt) load(kt + 1, ah1, al1, f1);
+          mma(ah0, al0, f0);
+          if (kt + 2 < nkt) load(kt + 2, ah0, al0, f0);
+          if (kt + 1 < nkt) mma(ah1, al1, f1);
+        }
+      } else {
         float a0[ENC_KC], a1[ENC_KC], b0[ENC_KC][2], b1[ENC_KC][2];
         const float* __restrict__ wg = q.wpad + (long)g * q.Kp * Jp;
         auto load = [&](int kp0, float (&av)[ENC_KC], float (&bv)[ENC_KC][2]) {
@@ -429,6 +556,17 @@ __global__ __launch_bounds__(ENC_NT, 2) void enc_gru_bwd_fused_kernel(EncArgs a,
     dh[0] = acc[0];
     dh[1] = acc[1];
   }
+}
+
+template <typename Kf>
+int enc_set_lds(Kf kernel, size_t bytes) {
+  if (bytes <= 48 * 1024) return LFI_OK;
+  hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  if (e != hipSuccess) {
+    lfi_set_error("window encoder: cannot reserve %zu bytes of LDS: %s", bytes, hipGetErrorString(e));
+    return LFI_ERR_LAUNCH;
+  }
+  return LFI_OK;
 }
 
 // shape of the fused path, or 0 when the recurrence is too wide for it
@@ -479,15 +617,33 @@ extern "C" int lfi_encode_windows_fwd(const lfi_enc_desc* d, const float* Xp, co
   if (enc_fused_shape(hid, &q)) {
     LFI_REQUIRE(!gates || hseq, "lfi_encode_windows_fwd: the gate stash needs the state stash too");
     // (without a gate stash nothing is kept for a backward pass: hseq is not written either)
-    hipLaunchKernelGGL(enc_pad_weights_kernel, dim3(lfi_cdiv(3L * q.Kp * q.Jp, 256)), dim3(256), 0, st, whh, hid, q.Kp, q.Jp, 1,
-                       work);
+    const bool x3 = d->precision == 1;
+    if (x3) hipLaunchKernelGGL(enc_frag_weights_kernel, dim3(lfi_cdiv(6L * q.Kp * q.Jp, 256)), dim3(256), 0, st, whh, hid, q.Kp,
+                               q.Jp, 1, reinterpret_cast<__bf16*>(work));
+    else hipLaunchKernelGGL(enc_pad_weights_kernel, dim3(lfi_cdiv(3L * q.Kp * q.Jp, 256)), dim3(256), 0, st, whh, hid, q.Kp, q.Jp,
+                            1, work);
     q.wpad = work;
-    const size_t lds = (size_t)q.Kp * (q.R + 1) * sizeof(float);
+    q.wfrag = reinterpret_cast<const uint4*>(work);
+    const size_t lds = (size_t)q.Kp * (q.R + 1) * sizeof(float) + (x3 ? (size_t)2 * q.R * (q.Kp + 8) * sizeof(__bf16) : 0);
     const dim3 grid(lfi_cdiv(F, q.R));
-    if (gates && mask) hipLaunchKernelGGL((enc_gru_fwd_fused_kernel<true, true>), grid, dim3(ENC_NT), lds, st, a, q);
-    else if (gates) hipLaunchKernelGGL((enc_gru_fwd_fused_kernel<true, false>), grid, dim3(ENC_NT), lds, st, a, q);
-    else if (mask) hipLaunchKernelGGL((enc_gru_fwd_fused_kernel<false, true>), grid, dim3(ENC_NT), lds, st, a, q);
-    else hipLaunchKernelGGL((enc_gru_fwd_fused_kernel<false, false>), grid, dim3(ENC_NT), lds, st, a, q);
+    const int variant = (gates ? 4 : 0) | (mask ? 2 : 0) | (x3 ? 1 : 0);
+    rc = LFI_OK;
+    switch (variant) {
+#define LFI_ENC_FWD(ST, MK, X)                                                                                              \
+  rc = enc_set_lds(enc_gru_fwd_fused_kernel<ST, MK, X>, lds);                                                               \
+  if (!rc) hipLaunchKernelGGL((enc_gru_fwd_fused_kernel<ST, MK, X>), grid, dim3(ENC_NT), lds, st, a, q);                    \
+  break
+      case 7: LFI_ENC_FWD(true, true, true);
+      case 6: LFI_ENC_FWD(true, true, false);
+      case 5: LFI_ENC_FWD(true, false, true);
+      case 4: LFI_ENC_FWD(true, false, false);
+      case 3: LFI_ENC_FWD(false, true, true);
+      case 2: LFI_ENC_FWD(false, true, false);
+      case 1: LFI_ENC_FWD(false, false, true);
+      default: LFI_ENC_FWD(false, false, false);
+#undef LFI_ENC_FWD
+    }
+    if (rc) return rc;
     LFI_LAUNCH_CHECK("lfi_encode_windows_fwd (fused)");
     return LFI_OK;
   }
@@ -520,11 +676,20 @@ extern "C" int lfi_encode_windows_bwd(const lfi_enc_desc* d, const float* dcond,
   const int hid = d->hid, F = a.F;
   EncFused q = {};
   if (enc_fused_shape(hid, &q)) {
-    hipLaunchKernelGGL(enc_pad_weights_kernel, dim3(lfi_cdiv(3L * q.Kp * q.Jp, 256)), dim3(256), 0, st, whh, hid, q.Kp, q.Jp, 0,
-                       work);
+    const bool x3 = d->precision == 1;
+    if (x3) hipLaunchKernelGGL(enc_frag_weights_kernel, dim3(lfi_cdiv(6L * q.Kp * q.Jp, 256)), dim3(256), 0, st, whh, hid, q.Kp,
+                               q.Jp, 0, reinterpret_cast<__bf16*>(work));
+    else hipLaunchKernelGGL(enc_pad_weights_kernel, dim3(lfi_cdiv(3L * q.Kp * q.Jp, 256)), dim3(256), 0, st, whh, hid, q.Kp, q.Jp,
+                            0, work);
     q.wpad = work;
-    const size_t lds = (size_t)q.Kp * (q.R + 1) * sizeof(float);
-    hipLaunchKernelGGL(enc_gru_bwd_fused_kernel, dim3(lfi_cdiv(F, q.R)), dim3(ENC_NT), lds, st, a, q);
+    q.wfrag = reinterpret_cast<const uint4*>(work);
+    const size_t ldsf = (size_t)q.Kp * (q.R + 1) * sizeof(float), ldsx = (size_t)2 * q.R * (q.Kp + 8) * sizeof(__bf16);
+    if (x3) {
+      if ((rc = enc_set_lds(enc_gru_bwd_fused_kernel<true>, ldsx))) return rc;
+      hipLaunchKernelGGL(enc_gru_bwd_fused_kernel<true>, dim3(lfi_cdiv(F, q.R)), dim3(ENC_NT), ldsx, st, a, q);
+    } else {
+      hipLaunchKernelGGL(enc_gru_bwd_fused_kernel<false>, dim3(lfi_cdiv(F, q.R)), dim3(ENC_NT), ldsf, st, a, q);
+    }
     LFI_LAUNCH_CHECK("lfi_encode_windows_bwd (fused)");
     return LFI_OK;
   }
