@@ -15,6 +15,7 @@
 // operand staged k-major in LDS and the weights streamed from L2 as coalesced row segments; all elementwise math
 // (actnorm, gates, LinearZeros scaling, affine coupling, log-det) is fused around them in fp32.
 #include <math.h>
+#include <stdlib.h>
 
 #include "lfi_common.h"
 
@@ -36,6 +37,9 @@ struct FlowK {
   lfi_flow_params p;
   // prep
   const float *W, *Wt, *Winv, *wz_t, *whh_t, *wfl_t, *wc, *ldconst;
+  // prep, zero-padded images for the register-resident cell kernels (k rows padded to 4, columns to 16)
+  const float *pW, *pWt, *pwz, *pwh, *pwfl, *bwfl, *bwh, *bwz;
+  int C4, C16, Ch4, Ch16, H4, H16, Co4, Co16, NG;
   // forward stash
   float *sA, *sY, *sX, *sH, *sG, *sO, *sL, *sC;   // sC: LSTM cell state (lstm only)
   // backward stash
@@ -644,6 +648,583 @@ __global__ __launch_bounds__(NT) void flow_diag_bwd_kernel(FlowK f, int d, int k
   }
 }
 
+// ------------------------------------------------------------------------------------------- register-resident cells
+// Same cells for the common sizes (C <= 64, H <= 128): the generic kernels above stream every weight chunk from L2 inside
+// the dependent MFMA chains (4 phases x ~10 chunk round trips per cell: ~54 % of a wave's life is s_waitcnt, rocprof
+// PMC). Weights do not depend on the data, so here each wave issues the loads of ITS slice of a phase's weights one phase
+// ahead, into registers (<= 168 VGPRs), from zero-padded images made by lfi_flow_prep (k rows padded to 4, columns to 16:
+// no bounds checks, no select chains), and the k loops run MFMA-paced from registers + LDS. Elementwise phases use a
+// fixed (row = tid / 32, column = tid % 32 [+ 32]) thread map: no integer divisions, 128-byte row segments.
+constexpr int FC_C4 = 16;   // k-steps (of 4) over C   <= 64
+constexpr int FC_Z4 = 8;    //              over Ch  <= 32
+constexpr int FC_H4 = 32;   //              over H   <= 128
+constexpr int FC_O4 = 16;   //              over Cout <= 64
+
+__host__ __device__ inline bool flow_fast_ok(int C, int H, int Cout) { return C <= 64 && H <= 128 && Cout <= 64; }
+
+struct CarveF {
+  int At, Ht, Zt, Hn, Yrm, Orm, total;
+};
+__host__ __device__ inline CarveF carve_fast_fwd(int C, int C4, int H4, int Ch4, int Cout) {
+  CarveF c;
+  int o = 0;
+  c.At = o; o += C4 * LT;
+  c.Ht = o; o += H4 * LT;
+  c.Zt = o; o += (Ch4 > 0 ? Ch4 : 4) * LT;
+  c.Hn = o; o += H4 * LT;
+  c.Yrm = o; o += MB * (C + 1);
+  c.Orm = o; o += MB * (Cout + 1);
+  c.total = o;
+  return c;
+}
+
+// acc (+)= A(16 x 4 n4) from LDS (k-major, a_lds[kk * LT + i]) times the register-resident B slice w[u] (k = 4u + kq)
+template <int MAXU>
+__device__ __forceinline__ f32x4 mma16_reg(const float* a_lane /* a_lds + kq*LT + l15 */, const float (&w)[MAXU], int n4) {
+  f32x4 e = {0.f, 0.f, 0.f, 0.f}, o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int u = 0; u < MAXU; u += 2) {
+    if (u < n4) e = mfma16(a_lane[u * 4 * LT], w[u], e);
+    if (u + 1 < n4) o = mfma16(a_lane[(u + 1) * 4 * LT], w[u + 1], o);
+  }
+  return e + o;
+}
+
+template <int NG>
+__global__ __launch_bounds__(NT) void flow_diag_fwd_fast_kernel(FlowK f, int d, int klo) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, kq = lane >> 4;
+  const int ri = tid >> 5, cl = tid & 31;  // elementwise thread map
+  const int k = klo + blockIdx.y, n = d - k;
+  const int b0 = blockIdx.x * MB;
+  const int B = f.B, C = f.C, H = f.H, Ch = f.Ch, C2 = f.C2, Cout = f.Cout, G = f.G;
+  const int C4 = f.C4, C16 = f.C16, Ch4 = f.Ch4, H4 = f.H4, H16 = f.H16, Co16 = f.Co16;
+  const long fr = (long)n * B;
+  const long kf = (long)k * f.F + fr;
+  const CarveF cv = carve_fast_fwd(C, C4, H4, Ch4, Cout);
+  float* At = flow_smem + cv.At;
+  float* Ht = flow_smem + cv.Ht;
+  float* Zt = flow_smem + cv.Zt;
+  float* Hn = flow_smem + cv.Hn;
+  float* Yrm = flow_smem + cv.Yrm;
+  float* Orm = flow_smem + cv.Orm;
+  const int ldy = C + 1, ldo = Cout + 1;
+  const int nC4 = C4 >> 2, nZ4 = Ch4 >> 2, nH4 = H4 >> 2;
+
+  // ---- weights of P1 (this wave's 16 output channels of W) and P2 (its 16 hidden units, NG gates), gic/bias of its rows
+  const bool t1 = wave * 16 < C, t2 = wave * 16 < H, t3 = wave * 16 < Cout;
+  float w1[FC_C4], wz[NG][FC_Z4], wh[NG][FC_H4];
+  {
+    const float* Wk = f.pW + (long)k * C4 * C16 + kq * C16 + wave * 16 + l15;
+#pragma unroll
+    for (int u = 0; u < FC_C4; ++u)
+      if (t1 && u < nC4) w1[u] = Wk[u * 4 * C16];
+    const float* zk = f.pwz + (long)k * Ch4 * NG * H16 + kq * NG * H16 + wave * 16 + l15;
+    const float* hk = f.pwh + (long)k * H4 * NG * H16 + kq * NG * H16 + wave * 16 + l15;
+#pragma unroll
+    for (int u = 0; u < FC_Z4; ++u)
+#pragma unroll
+      for (int g = 0; g < NG; ++g)
+        if (t2 && u < nZ4) wz[g][u] = zk[u * 4 * NG * H16 + g * H16];
+#pragma unroll
+    for (int u = 0; u < FC_H4; ++u)
+#pragma unroll
+      for (int g = 0; g < NG; ++g)
+        if (t2 && u < nH4) wh[g][u] = hk[u * 4 * NG * H16 + g * H16];
+  }
+  const int j2 = wave * 16 + l15;         // hidden unit of this lane in P2
+  const bool j2ok = j2 < H;
+  float gc[4][NG], bh[NG], cprev[4];
+  {
+    const float* gicb = f.gic + kf * G;
+    const float* bhh = f.p.b_hh + (long)k * G;
+    const float* cpb = (NG == 4 && n > 0) ? f.sC + (kf - B) * H : nullptr;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) bh[g] = j2ok ? bhh[g * H + j2] : 0.0f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = min(b0 + kq * 4 + r, B - 1);
+#pragma unroll
+      for (int g = 0; g < NG; ++g) gc[r][g] = j2ok ? gicb[(long)row * G + g * H + j2] : 0.0f;
+      cprev[r] = (cpb && j2ok) ? cpb[(long)row * H + j2] : 0.0f;
+    }
+  }
+
+  // ---- P0: actnorm (glow/modules.py:45-52); stage a, h_prev k-major; zero the k padding
+  {
+    const int row = b0 + ri;
+    const bool rok = row < B;
+    const float* xin = (k == 0) ? f.x0 + ((long)row * f.T + f.start + n) * C : f.sX + (kf - f.F + row) * C;
+    const float* anb = f.p.an_bias + (long)k * C;
+    const float* anl = f.p.an_logs + (long)k * C;
+    for (int c = cl; c < C4; c += 32) {
+      float a = 0.0f;
+      if (c < C && rok) {
+        a = (xin[c] + anb[c]) * expf(anl[c]);
+        f.sA[(kf + row) * C + c] = a;
+      }
+      At[c * LT + ri] = a;
+    }
+    const float* hp = n > 0 ? f.sH + (kf - B + row) * H : nullptr;
+    for (int j = cl; j < H4; j += 32) {
+      Ht[j * LT + ri] = (hp && rok && j < H) ? hp[j] : 0.0f;
+      if (j >= H) Hn[j * LT + ri] = 0.0f;
+    }
+    for (int c = Ch + cl; c < Ch4; c += 32) Zt[c * LT + ri] = 0.0f;
+  }
+  __syncthreads();
+
+  // ---- P1: y = a W   (InvertibleConv1x1.forward, glow/modules.py:186)
+  if (t1) {
+    const f32x4 acc = mma16_reg<FC_C4>(At + kq * LT + l15, w1, nC4);
+    const int c = wave * 16 + l15;
+    if (c < C) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = kq * 4 + r;
+        const int row = b0 + i;
+        const float v = acc[r];
+        Yrm[i * ldy + c] = v;
+        if (c < Ch) Zt[c * LT + i] = v;
+        if (row < B) f.sY[(kf + row) * C + c] = v;
+      }
+    }
+  }
+  // weights of P3 (this wave's 16 outputs of LinearZeros): in flight under P2
+  float w3[FC_H4];
+  {
+    const float* fk = f.pwfl + (long)k * H4 * Co16 + kq * Co16 + wave * 16 + l15;
+#pragma unroll
+    for (int u = 0; u < FC_H4; ++u)
+      if (t3 && u < nH4) w3[u] = fk[u * 4 * Co16];
+  }
+  __syncthreads();
+
+  // ---- P2: recurrent cell of the coupling net (f_seq.forward, glow/models.py:204-214)
+  if (t2) {
+    f32x4 az[NG], ah[NG];
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      az[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      ah[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    const float* zl = Zt + kq * LT + l15;
+    const float* hl = Ht + kq * LT + l15;
+#pragma unroll
+    for (int u = 0; u < FC_Z4; ++u)
+      if (u < nZ4) {
+        const float a = zl[u * 4 * LT];
+#pragma unroll
+        for (int g = 0; g < NG; ++g) az[g] = mfma16(a, wz[g][u], az[g]);
+      }
+#pragma unroll
+    for (int u = 0; u < FC_H4; ++u)
+      if (u < nH4) {
+        const float a = hl[u * 4 * LT];
+#pragma unroll
+        for (int g = 0; g < NG; ++g) ah[g] = mfma16(a, wh[g][u], ah[g]);
+      }
+    if (j2ok) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = kq * 4 + r;
+        const int row = b0 + i;
+        float hnew;
+        float gs0, gs1, gs2, gs3;
+        if (NG == 3) {  // torch.nn.GRUCell, gate order r, z, n
+          const float rr = sigmoidf_(az[0][r] + ah[0][r] + gc[r][0] + bh[0]);
+          const float uu = sigmoidf_(az[1][r] + ah[1][r] + gc[r][1] + bh[1]);
+          const float ghn = ah[2][r] + bh[2];
+          const float nn = tanhf(az[2][r] + gc[r][2] + rr * ghn);
+          const float hp = Ht[j2 * LT + i];
+          hnew = (1.0f - uu) * nn + uu * hp;
+          gs0 = rr; gs1 = uu; gs2 = nn; gs3 = ghn;
+        } else {        // torch.nn.LSTMCell, gate order i, f, g, o; zero (h, c) at the first modelled frame
+          const float ii = sigmoidf_(az[0][r] + ah[0][r] + gc[r][0] + bh[0]);
+          const float ff = sigmoidf_(az[1][r] + ah[1][r] + gc[r][1] + bh[1]);
+          const float gg = tanhf(az[2][r] + ah[2][r] + gc[r][2] + bh[2]);
+          const float oo = sigmoidf_(az[NG - 1][r] + ah[NG - 1][r] + gc[r][NG - 1] + bh[NG - 1]);
+          const float c2 = ff * cprev[r] + ii * gg;
+          hnew = oo * tanhf(c2);
+          if (row < B) f.sC[(kf + row) * H + j2] = c2;
+          gs0 = ii; gs1 = ff; gs2 = gg; gs3 = oo;
+        }
+        Hn[j2 * LT + i] = hnew;
+        if (row < B) {
+          f.sH[(kf + row) * H + j2] = hnew;
+          float* gs = f.sG + (kf + row) * 4 * H + j2;
+          gs[0] = gs0; gs[H] = gs1; gs[2 * H] = gs2; gs[3 * H] = gs3;
+        }
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- P3: o = (h' Wfl^T + b) exp(3 logs)   (LinearZeros, glow/modules.py:93-95)
+  if (t3) {
+    const f32x4 acc = mma16_reg<FC_H4>(Hn + kq * LT + l15, w3, nH4);
+    const int col = wave * 16 + l15;
+    if (col < Cout) {
+      const float bb = f.p.b_fl[(long)k * Cout + col], sc = expf(3.0f * f.p.l_fl[(long)k * Cout + col]);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = kq * 4 + r;
+        const int row = b0 + i;
+        const float o = (acc[r] + bb) * sc;
+        Orm[i * ldo + col] = o;
+        if (row < B) f.sO[(kf + row) * Cout + col] = o;
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- P4: coupling (glow/models.py:330-341), pass-through half, log-det of the coupling (wavefront shuffle sum)
+  {
+    const int row = b0 + ri;
+    const bool rok = row < B;
+    float lg = 0.0f;
+    if (cl < C2) {
+      const float z2 = Yrm[ri * ldy + Ch + cl];
+      float z2n;
+      if (f.affine) {
+        const float shift = Orm[ri * ldo + 2 * cl];
+        const float sraw = sigmoidf_(Orm[ri * ldo + 2 * cl + 1] + 2.0f);
+        const float sc = fmaxf(sraw, f.eps);
+        z2n = (z2 + shift) * sc;
+        lg = logf(sc);
+      } else {
+        z2n = z2 + Orm[ri * ldo + cl];
+      }
+      if (rok) f.sX[(kf + row) * C + Ch + cl] = z2n;
+    }
+    if (cl < Ch && rok) f.sX[(kf + row) * C + cl] = Yrm[ri * ldy + cl];
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) lg += __shfl_xor(lg, o, 64);  // the 32 lanes of one row
+    if (cl == 0 && rok) f.sL[kf + row] = lg;
+  }
+}
+
+struct CarveFB {
+  int Dl, Gi, Dy, Cy, Pl, total;
+};
+__host__ __device__ inline CarveFB carve_fast_bwd(int C4, int H4, int Co4, int Cout, int NG) {
+  CarveFB c;
+  int o = 0;
+  c.Dl = o; o += Co4 * LT;
+  c.Gi = o; o += 2 * NG * H4 * LT;   // Gi then Gh, each [NG][H4][LT]
+  c.Dy = o; o += C4 * LT;
+  c.Cy = o; o += H4 * LT;
+  c.Pl = o; o += MB * (Cout + 1);
+  c.total = o;
+  return c;
+}
+
+// acc += A(16 x 4 n4, LDS k-major) * B slice streamed into `w` by the caller; NG blocks of n4 k-steps (a_lane advances by
+// blk floats per block)
+template <int NG, int MAXU>
+__device__ __forceinline__ f32x4 mma16_reg_blocks(f32x4 acc, const float* a_lane, int blk, const float (&w)[NG][MAXU], int n4) {
+  f32x4 o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int g = 0; g < NG; ++g)
+#pragma unroll
+    for (int u = 0; u < MAXU; u += 2) {
+      if (u < n4) acc = mfma16(a_lane[g * blk + u * 4 * LT], w[g][u], acc);
+      if (u + 1 < n4) o = mfma16(a_lane[g * blk + (u + 1) * 4 * LT], w[g][u + 1], o);
+    }
+  return acc + o;
+}
+
+template <int NG>
+__global__ __launch_bounds__(NT) void flow_diag_bwd_fast_kernel(FlowK f, int d, int klo) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, kq = lane >> 4;
+  const int ri = tid >> 5, cl = tid & 31;
+  const int k = klo + blockIdx.y, n = d - k;
+  const int b0 = blockIdx.x * MB;
+  const int B = f.B, C = f.C, H = f.H, Ch = f.Ch, C2 = f.C2, Cout = f.Cout, G = f.G;
+  const int C4 = f.C4, C16 = f.C16, Ch16 = f.Ch16, H4 = f.H4, H16 = f.H16, Co4 = f.Co4;
+  const long fr = (long)n * B;
+  const long kf = (long)k * f.F + fr;
+  const CarveFB cv = carve_fast_bwd(C4, H4, Co4, Cout, NG);
+  float* Dl = flow_smem + cv.Dl;
+  float* Gi = flow_smem + cv.Gi;
+  float* Gh = Gi + NG * H4 * LT;
+  float* Dy = flow_smem + cv.Dy;
+  float* Cy = flow_smem + cv.Cy;
+  float* Pl = flow_smem + cv.Pl;
+  const int ldp = Cout + 1;
+  const int nC4 = C4 >> 2, nH4 = H4 >> 2, nO4 = Co4 >> 2;
+  const bool last = k == f.Ks - 1;
+  const float gz = f.gscale / LN2_F;   // d loss / d z = z * gz   (prior term)
+  const float dl = -f.gscale / LN2_F;  // d loss / d logdet
+  const float* dxo = last ? f.sX + kf * C : f.bDx + (kf + f.F) * C;
+  const float dxs = last ? gz : 1.0f;
+
+  // which tiles this wave owns: hidden tile `wave` (Q1, Q2), z tile `wave` (Q2, waves < Ch16/16), channel tile `wave` (Q3)
+  const bool th = wave * 16 < H, tz = wave * 16 < Ch, tc = wave * 16 < C;
+  // ---- weights of Q1 (dlin Wfl: K = Cout) for this wave's hidden tile
+  float wq1[FC_O4];
+  {
+    const float* wk = f.bwfl + (long)k * Co4 * H16 + kq * H16 + wave * 16 + l15;
+#pragma unroll
+    for (int u = 0; u < FC_O4; ++u)
+      if (th && u < nO4) wq1[u] = wk[u * 4 * H16];
+  }
+  // the z-tile waves stream W_ih[:, :Ch] first (they run dz1 before the barrier), the others W_hh
+  float wq2[NG][FC_H4];
+  {
+    const float* wk = tz ? f.bwz + (long)k * NG * H4 * Ch16 + kq * Ch16 + wave * 16 + l15
+                         : f.bwh + (long)k * NG * H4 * H16 + kq * H16 + wave * 16 + l15;
+    const int ldw = tz ? Ch16 : H16;
+#pragma unroll
+    for (int g = 0; g < NG; ++g)
+#pragma unroll
+      for (int u = 0; u < FC_H4; ++u)
+        if ((tz || th) && u < nH4) wq2[g][u] = wk[(g * H4 + u * 4) * ldw];
+  }
+
+  // ---- Q0: coupling backward + LinearZeros scale; zero the k padding of the LDS operands
+  {
+    const int row = b0 + ri;
+    const bool rok = row < B;
+    const float* lfl = f.p.l_fl + (long)k * Cout;
+    float dz2 = 0.0f, dl0 = 0.0f, dl1 = 0.0f, p0 = 0.0f, p1 = 0.0f;
+    if (cl < C2) {
+      if (rok) {
+        const float dz2n = dxo[(long)row * C + Ch + cl] * dxs;
+        const float* O = f.sO + (kf + row) * Cout;
+        if (f.affine) {
+          const float oe = O[2 * cl], oo = O[2 * cl + 1];
+          const float sraw = sigmoidf_(oo + 2.0f);
+          const float sc = fmaxf(sraw, f.eps);
+          const float z2 = f.sY[(kf + row) * C + Ch + cl];
+          dz2 = dz2n * sc;
+          const float dsc = dz2n * (z2 + oe) + dl / sc;
+          const float dsr = sraw >= f.eps ? dsc : 0.0f;
+          const float d0 = dz2;                             // d o_even (shift)
+          const float d1 = dsr * sraw * (1.0f - sraw);      // d o_odd
+          p0 = d0 * oe * 3.0f; p1 = d1 * oo * 3.0f;
+          dl0 = d0 * expf(3.0f * lfl[2 * cl]); dl1 = d1 * expf(3.0f * lfl[2 * cl + 1]);
+          f.bDlin[(kf + row) * Cout + 2 * cl] = dl0; f.bDlin[(kf + row) * Cout + 2 * cl + 1] = dl1;
+        } else {
+          const float oe = O[cl];
+          dz2 = dz2n; p0 = dz2n * oe * 3.0f;
+          dl0 = dz2n * expf(3.0f * lfl[cl]);
+          f.bDlin[(kf + row) * Cout + cl] = dl0;
+        }
+        f.bDy[(kf + row) * C + Ch + cl] = dz2;
+      }
+      Dy[(Ch + cl) * LT + ri] = dz2;
+      if (f.affine) {
+        Dl[(2 * cl) * LT + ri] = dl0; Dl[(2 * cl + 1) * LT + ri] = dl1;
+        Pl[ri * ldp + 2 * cl] = p0; Pl[ri * ldp + 2 * cl + 1] = p1;
+      } else {
+        Dl[cl * LT + ri] = dl0;
+        Pl[ri * ldp + cl] = p0;
+      }
+    }
+    for (int c = Cout + cl; c < Co4; c += 32) Dl[c * LT + ri] = 0.0f;
+    for (int c = C + cl; c < C4; c += 32) Dy[c * LT + ri] = 0.0f;
+    for (int j = H + cl; j < H4; j += 32) {
+#pragma unroll
+      for (int g = 0; g < NG; ++g) { Gi[(g * H4 + j) * LT + ri] = 0.0f; Gh[(g * H4 + j) * LT + ri] = 0.0f; }
+    }
+  }
+  __syncthreads();
+  if (tid < Cout) {
+    float sum = 0.0f;
+    for (int i = 0; i < MB; ++i) sum += Pl[i * ldp + tid];
+    f.bPlfl[(((long)k * f.N + n) * f.nbt + blockIdx.x) * Cout + tid] = sum;
+  }
+
+  // ---- Q1: d h' = dlin Wfl + dh carried from timestep n + 1; recurrent cell backward
+  if (th) {
+    const f32x4 acc = mma16_reg<FC_O4>(Dl + kq * LT + l15, wq1, nO4);
+    const int j = wave * 16 + l15;
+    if (j < H) {
+      const float* dhf = (n < f.N - 1) ? f.bDh + (kf + B) * H : nullptr;
+      const float* hp_base = n > 0 ? f.sH + (kf - B) * H : nullptr;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = kq * 4 + r;
+        const int row = b0 + i;
+        float gi_[4] = {0.f, 0.f, 0.f, 0.f}, gh_[4] = {0.f, 0.f, 0.f, 0.f}, cy = 0.0f;
+        if (row < B) {
+          const float dhn = acc[r] + (dhf ? dhf[(long)row * H + j] : 0.0f);
+          const float* gs = f.sG + (kf + row) * 4 * H + j;
+          const float g0 = gs[0], g1 = gs[H], g2 = gs[2 * H], g3 = gs[3 * H];
+          if (NG == 3) {
+            const float rr = g0, uu = g1, nn = g2, ghn = g3;
+            const float hp = hp_base ? hp_base[(long)row * H + j] : 0.0f;
+            const float du = dhn * (hp - nn);
+            const float dn = dhn * (1.0f - uu);
+            cy = dhn * uu;
+            const float dan = dn * (1.0f - nn * nn);
+            const float dau = du * uu * (1.0f - uu);
+            const float dar = dan * ghn * rr * (1.0f - rr);
+            gi_[0] = dar; gi_[1] = dau; gi_[2] = dan;
+            gh_[0] = dar; gh_[1] = dau; gh_[2] = dan * rr;
+          } else {
+            const float ii = g0, ff = g1, gg = g2, oo = g3;
+            const float tcv = tanhf(f.sC[(kf + row) * H + j]);
+            const float cp = n > 0 ? f.sC[(kf - B + row) * H + j] : 0.0f;
+            const float dcf = (n < f.N - 1) ? f.bDc[(kf + B + row) * H + j] : 0.0f;
+            const float dc2 = dhn * oo * (1.0f - tcv * tcv) + dcf;
+            gi_[0] = dc2 * gg * ii * (1.0f - ii);
+            gi_[1] = dc2 * cp * ff * (1.0f - ff);
+            gi_[2] = dc2 * ii * (1.0f - gg * gg);
+            gi_[NG - 1] = dhn * tcv * oo * (1.0f - oo);
+#pragma unroll
+            for (int g = 0; g < NG; ++g) gh_[g] = gi_[g];
+            f.bDc[(kf + row) * H + j] = dc2 * ff;
+          }
+          float* go = f.bDgi + (kf + row) * G + j;
+          float* ho = f.bDgh + (kf + row) * G + j;
+#pragma unroll
+          for (int g = 0; g < NG; ++g) { go[g * H] = gi_[g]; ho[g * H] = gh_[g]; }
+        }
+#pragma unroll
+        for (int g = 0; g < NG; ++g) { Gi[(g * H4 + j) * LT + i] = gi_[g]; Gh[(g * H4 + j) * LT + i] = gh_[g]; }
+        Cy[j * LT + i] = cy;
+      }
+    }
+  }
+  // weights of Q3 (dy W^T) for this wave's channel tile: in flight under Q2
+  float wq3[FC_C4];
+  {
+    const float* wk = f.pWt + (long)k * C4 * C16 + kq * C16 + wave * 16 + l15;
+#pragma unroll
+    for (int u = 0; u < FC_C4; ++u)
+      if (tc && u < nC4) wq3[u] = wk[u * 4 * C16];
+  }
+  __syncthreads();
+
+  // ---- Q2: d z1 = dgi W_ih[:, :Ch] + pass-through (z-tile waves, before the barrier: Q3 needs it);
+  //          d h_prev = dgh W_hh + carry (to timestep n - 1; not needed inside this cell)
+  auto dh_prev_tile = [&](const float (&w)[NG][FC_H4]) {
+    if (n > 0 && th) {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      acc = mma16_reg_blocks<NG, FC_H4>(acc, Gh + kq * LT + l15, H4 * LT, w, nH4);
+      const int j = wave * 16 + l15;
+      if (j < H) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int i = kq * 4 + r;
+          const int row = b0 + i;
+          if (row < B) f.bDh[(kf + row) * H + j] = acc[r] + Cy[j * LT + i];
+        }
+      }
+    }
+  };
+  if (tz) {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    acc = mma16_reg_blocks<NG, FC_H4>(acc, Gi + kq * LT + l15, H4 * LT, wq2, nH4);
+    const int c = wave * 16 + l15;
+    if (c < Ch) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = kq * 4 + r;
+        const int row = b0 + i;
+        float v = 0.0f;
+        if (row < B) {
+          v = acc[r] + dxo[(long)row * C + c] * dxs;
+          f.bDy[(kf + row) * C + c] = v;
+        }
+        Dy[c * LT + i] = v;
+      }
+    }
+    // now fetch this wave's W_hh slice for its d h_prev tile (runs after Q3)
+    if (n > 0 && th) {
+      const float* wk = f.bwh + (long)k * NG * H4 * H16 + kq * H16 + wave * 16 + l15;
+#pragma unroll
+      for (int g = 0; g < NG; ++g)
+#pragma unroll
+        for (int u = 0; u < FC_H4; ++u)
+          if (u < nH4) wq2[g][u] = wk[(g * H4 + u * 4) * H16];
+    }
+  } else {
+    dh_prev_tile(wq2);
+  }
+  __syncthreads();
+
+  // ---- Q3: d a = dy W^T ; actnorm backward ; d x_in to flow step k - 1
+  if (tc) {
+    const f32x4 acc = mma16_reg<FC_C4>(Dy + kq * LT + l15, wq3, nC4);
+    const int c = wave * 16 + l15;
+    float sl = 0.0f, sb = 0.0f;
+    if (c < C) {
+      const float es = expf(f.p.an_logs[(long)k * C + c]);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = b0 + kq * 4 + r;
+        if (row < B) {
+          const float da = acc[r];
+          sl += da * f.sA[(kf + row) * C + c];
+          sb += da * es;
+          if (k > 0) f.bDx[(kf + row) * C + c] = da * es;
+        }
+      }
+    }
+    sl += __shfl_xor(sl, 16, 64); sl += __shfl_xor(sl, 32, 64);
+    sb += __shfl_xor(sb, 16, 64); sb += __shfl_xor(sb, 32, 64);
+    if (kq == 0 && c < C) {
+      float* pan = f.bPan + (((long)k * f.N + n) * f.nbt + blockIdx.x) * 2 * C;
+      pan[c] = sl; pan[C + c] = sb;
+    }
+  }
+  if (tz) dh_prev_tile(wq2);
+}
+
+// Zero-padded weight images for the register-resident cells. which: 0 pW, 1 pWt, 2 pwz, 3 pwh, 4 pwfl, 5 bwfl, 6 bwh, 7 bwz
+__global__ __launch_bounds__(256) void flow_prep_pad_kernel(FlowK f, float* pW, float* pWt, float* pwz, float* pwh, float* pwfl,
+                                                            float* bwfl, float* bwh, float* bwz) {
+  const int k = blockIdx.y, which = blockIdx.z;
+  const int C = f.C, H = f.H, Ch = f.Ch, Cout = f.Cout, I = f.I, NG = f.NG;
+  const int C4 = f.C4, C16 = f.C16, Ch4 = f.Ch4, Ch16 = f.Ch16, H4 = f.H4, H16 = f.H16, Co4 = f.Co4, Co16 = f.Co16;
+  const float* W = f.W + (long)k * C * C;
+  const float* wih = f.p.w_ih + (long)k * f.G * I;
+  const float* whh = f.p.w_hh + (long)k * f.G * H;
+  const float* wfl = f.p.w_fl + (long)k * Cout * H;
+  long n;
+  float* dst;
+  switch (which) {
+    case 0: n = (long)C4 * C16; dst = pW + k * n; break;
+    case 1: n = (long)C4 * C16; dst = pWt + k * n; break;
+    case 2: n = (long)Ch4 * NG * H16; dst = pwz + k * n; break;
+    case 3: n = (long)H4 * NG * H16; dst = pwh + k * n; break;
+    case 4: n = (long)H4 * Co16; dst = pwfl + k * n; break;
+    case 5: n = (long)Co4 * H16; dst = bwfl + k * n; break;
+    case 6: n = (long)NG * H4 * H16; dst = bwh + k * n; break;
+    default: n = (long)NG * H4 * Ch16; dst = bwz + k * n; break;
+  }
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < n; idx += (long)gridDim.x * 256) {
+    float v = 0.0f;
+    if (which <= 1) {
+      const int kk = (int)(idx / C16), c = (int)(idx % C16);
+      if (kk < C && c < C) v = which == 0 ? W[kk * C + c] : W[c * C + kk];
+    } else if (which == 2 || which == 3) {
+      const int j = (int)(idx % H16), g = (int)((idx / H16) % NG), kk = (int)(idx / ((long)H16 * NG));
+      if (j < H) {
+        if (which == 2) { if (kk < Ch) v = wih[((long)g * H + j) * I + kk]; }
+        else if (kk < H) v = whh[((long)g * H + j) * H + kk];
+      }
+    } else if (which == 4) {
+      const int kk = (int)(idx / Co16), c = (int)(idx % Co16);
+      if (kk < H && c < Cout) v = wfl[(long)c * H + kk];
+    } else if (which == 5) {
+      const int kk = (int)(idx / H16), j = (int)(idx % H16);
+      if (kk < Cout && j < H) v = wfl[(long)kk * H + j];
+    } else if (which == 6) {
+      const int j = (int)(idx % H16), kk = (int)((idx / H16) % H4), g = (int)(idx / ((long)H16 * H4));
+      if (kk < H && j < H) v = whh[((long)g * H + kk) * H + j];
+    } else {
+      const int c = (int)(idx % Ch16), kk = (int)((idx / Ch16) % H4), g = (int)(idx / ((long)Ch16 * H4));
+      if (kk < H && c < Ch) v = wih[((long)g * H + kk) * I + c];
+    }
+    dst[idx] = v;
+  }
+}
+
 // ------------------------------------------------------------------------------------------- prep
 // One workgroup per flow step: W = P (L*mask + I)(U*mask^T + diag(sign exp(log_s)))  (glow/modules.py:167-173),
 // its transpose, and (optionally) the reverse weight U^-1 L^-1 P^-1 with fp64 triangular inverses (:175-177).
@@ -902,6 +1483,24 @@ __global__ __launch_bounds__(256) void actnorm_apply_kernel(const double* __rest
 }
 
 // ------------------------------------------------------------------------------------------- host helpers
+// floats of the prep buffer up to the end of the scratch area (published layout + log-det parts + fp64 workspace)
+long prep_scratch_end(const lfi_flow_dims* d) {
+  const int Ch = d->C / 2, C2 = d->C - Ch, Cout = d->affine ? 2 * C2 : C2, G = (d->lstm ? 4 : 3) * d->H;
+  const long cc = (long)d->Ks * d->C * d->C;
+  long n = 3 * cc + (long)d->Ks * Ch * G + (long)d->Ks * d->H * G + (long)d->Ks * d->H * Cout + (long)d->Ks * G * d->D + 4;
+  n += d->Ks + 4;
+  n += 2 * ((long)d->Ks * 2 * d->C * d->C + (long)d->Ks * d->C) + 8;  // doubles, counted as 2 floats each
+  return (n + 3) & ~3L;
+}
+long prep_padded_floats(const lfi_flow_dims* d) {
+  const int Ch = d->C / 2, C2 = d->C - Ch, Cout = d->affine ? 2 * C2 : C2, NG = d->lstm ? 4 : 3;
+  auto r4 = [](int x) { return (long)((x + 3) & ~3); };
+  auto r16 = [](int x) { return (long)((x + 15) & ~15); };
+  const long C4 = r4(d->C), C16 = r16(d->C), Ch4 = Ch ? r4(Ch) : 4, Ch16 = Ch ? r16(Ch) : 16, H4 = r4(d->H), H16 = r16(d->H),
+             Co4 = r4(Cout), Co16 = r16(Cout);
+  return d->Ks * (2 * C4 * C16 + Ch4 * NG * H16 + H4 * NG * H16 + H4 * Co16 + Co4 * H16 + NG * H4 * H16 + NG * H4 * Ch16);
+}
+
 int fill_flow(const lfi_flow_dims* d, const lfi_flow_params* p, const float* prep, FlowK* f, const char* who) {
   LFI_REQUIRE(d && p, "%s: null dims/params", who);
   LFI_REQUIRE(d->B > 0 && d->N > 0 && d->C >= 2 && d->H > 0 && d->D > 0 && d->Ks > 0, "%s: bad dims", who);
@@ -910,6 +1509,11 @@ int fill_flow(const lfi_flow_dims* d, const lfi_flow_params* p, const float* pre
   f->Ch = d->C / 2; f->C2 = d->C - f->Ch; f->Cout = d->affine ? 2 * f->C2 : f->C2;
   f->G = (d->lstm ? 4 : 3) * d->H; f->I = f->Ch + d->D; f->F = d->N * d->B; f->nbt = lfi_cdiv(d->B, MB);
   f->p = *p;
+  f->NG = d->lstm ? 4 : 3;
+  f->C4 = (f->C + 3) & ~3; f->C16 = (f->C + 15) & ~15; f->Ch4 = (f->Ch + 3) & ~3; f->Ch16 = (f->Ch + 15) & ~15;
+  f->H4 = (f->H + 3) & ~3; f->H16 = (f->H + 15) & ~15; f->Co4 = (f->Cout + 3) & ~3; f->Co16 = (f->Cout + 15) & ~15;
+  if (f->Ch4 == 0) f->Ch4 = 4;
+  if (f->Ch16 == 0) f->Ch16 = 16;
   if (prep) {
     const long cc = (long)d->Ks * d->C * d->C;
     const float* q = prep;
@@ -921,6 +1525,17 @@ int fill_flow(const lfi_flow_dims* d, const lfi_flow_params* p, const float* pre
     f->wfl_t = q; q += (long)d->Ks * d->H * f->Cout;
     f->wc = q; q += (long)d->Ks * f->G * d->D;
     f->ldconst = q;
+    // scratch (log-det parts, fp64 inverse workspace), then the zero-padded images of the register-resident cells
+    q = prep + prep_scratch_end(d);
+    const long Ks = d->Ks;
+    f->pW = q; q += Ks * f->C4 * f->C16;
+    f->pWt = q; q += Ks * f->C4 * f->C16;
+    f->pwz = q; q += Ks * f->Ch4 * f->NG * f->H16;
+    f->pwh = q; q += Ks * f->H4 * f->NG * f->H16;
+    f->pwfl = q; q += Ks * f->H4 * f->Co16;
+    f->bwfl = q; q += Ks * f->Co4 * f->H16;
+    f->bwh = q; q += Ks * f->NG * f->H4 * f->H16;
+    f->bwz = q; q += Ks * f->NG * f->H4 * f->Ch16;
   }
   return LFI_OK;
 }
@@ -965,6 +1580,12 @@ void bind_bstash(FlowK* f, float* b) {
   f->bDx = b + off[4]; f->bDh = b + off[5]; f->bPlfl = b + off[6]; f->bPan = b + off[7]; f->bDc = b + off[8];
 }
 
+// LFI_FLOW_GENERIC=1 keeps the streaming cell kernels (tests cover both paths at sizes where either applies)
+bool flow_force_generic() {
+  const char* e = getenv("LFI_FLOW_GENERIC");
+  return e && e[0] == '1';
+}
+
 template <typename Kf>
 int set_flow_lds(Kf kernel, size_t bytes, const char* who) {
   if (bytes > 160 * 1024) {
@@ -987,12 +1608,9 @@ int set_flow_lds(Kf kernel, size_t bytes, const char* who) {
 extern "C" long lfi_flow_prep_floats(const lfi_flow_dims* d) {
   if (!d) return 0;
   const int Ch = d->C / 2, C2 = d->C - Ch, Cout = d->affine ? 2 * C2 : C2, G = (d->lstm ? 4 : 3) * d->H;
-  const long cc = (long)d->Ks * d->C * d->C;
-  long n = 3 * cc + (long)d->Ks * Ch * G + (long)d->Ks * d->H * G + (long)d->Ks * d->H * Cout + (long)d->Ks * G * d->D + 4;
-  // scratch behind the published layout: per-step log-det parts and fp64 workspace for the inverses
-  n += d->Ks + 4;
-  n += 2 * ((long)d->Ks * 2 * d->C * d->C + (long)d->Ks * d->C) + 8;  // doubles, counted as 2 floats each
-  return n;
+  (void)Ch; (void)Cout; (void)G;
+  // published layout, scratch (per-step log-det parts, fp64 workspace for the inverses), zero-padded cell images
+  return prep_scratch_end(d) + prep_padded_floats(d) + 16;
 }
 
 extern "C" int lfi_flow_prep(const lfi_flow_dims* d, const lfi_flow_params* p, float* prep, int with_inverse, void* stream) {
@@ -1018,6 +1636,11 @@ extern "C" int lfi_flow_prep(const lfi_flow_dims* d, const lfi_flow_params* p, f
   hipLaunchKernelGGL(flow_prep_transpose_kernel, dim3(64, d->Ks), dim3(256), 0, st, f, (float*)f.wz_t, (float*)f.whh_t,
                      (float*)f.wfl_t, (float*)f.wc, ldpart, ldconst);
   LFI_LAUNCH_CHECK("lfi_flow_prep transpose");
+  if (flow_fast_ok(f.C, f.H, f.Cout)) {
+    hipLaunchKernelGGL(flow_prep_pad_kernel, dim3(8, d->Ks, 8), dim3(256), 0, st, f, (float*)f.pW, (float*)f.pWt, (float*)f.pwz,
+                       (float*)f.pwh, (float*)f.pwfl, (float*)f.bwfl, (float*)f.bwh, (float*)f.bwz);
+    LFI_LAUNCH_CHECK("lfi_flow_prep pad");
+  }
   return LFI_OK;
 }
 
@@ -1062,14 +1685,21 @@ extern "C" int lfi_flow_seq_fwd(const lfi_flow_dims* d, const lfi_flow_params* p
   bind_stash(&f, stash);
   f.x0 = x0; f.T = T; f.start = start; f.gic = gic;
   hipStream_t st = (hipStream_t)stream;
+  const bool fast = flow_fast_ok(f.C, f.H, f.Cout) && !flow_force_generic();
   const Carve cv = carve_fwd(f.C, f.H, f.Ch, f.C2, f.Cout);
-  const size_t lds = (size_t)cv.total * sizeof(float);
-  rc = set_flow_lds(flow_diag_fwd_kernel, lds, "lfi_flow_seq_fwd");
+  const CarveF cf = carve_fast_fwd(f.C, f.C4, f.H4, f.Ch4, f.Cout);
+  const size_t lds = (size_t)(fast ? cf.total : cv.total) * sizeof(float);
+  rc = fast ? (f.lstm ? set_flow_lds(flow_diag_fwd_fast_kernel<4>, lds, "lfi_flow_seq_fwd")
+                      : set_flow_lds(flow_diag_fwd_fast_kernel<3>, lds, "lfi_flow_seq_fwd"))
+            : set_flow_lds(flow_diag_fwd_kernel, lds, "lfi_flow_seq_fwd");
   if (rc) return rc;
   for (int dg = 0; dg < f.N + f.Ks - 1; ++dg) {
     const int klo = dg - (f.N - 1) > 0 ? dg - (f.N - 1) : 0;
     const int khi = dg < f.Ks - 1 ? dg : f.Ks - 1;
-    hipLaunchKernelGGL(flow_diag_fwd_kernel, dim3(f.nbt, khi - klo + 1), dim3(NT), lds, st, f, dg, klo);
+    const dim3 grid(f.nbt, khi - klo + 1);
+    if (!fast) hipLaunchKernelGGL(flow_diag_fwd_kernel, grid, dim3(NT), lds, st, f, dg, klo);
+    else if (f.lstm) hipLaunchKernelGGL(flow_diag_fwd_fast_kernel<4>, grid, dim3(NT), lds, st, f, dg, klo);
+    else hipLaunchKernelGGL(flow_diag_fwd_fast_kernel<3>, grid, dim3(NT), lds, st, f, dg, klo);
   }
   LFI_LAUNCH_CHECK("lfi_flow_seq_fwd");
   hipLaunchKernelGGL(flow_nll_kernel, dim3(lfi_cdiv(f.F, 256)), dim3(256), 0, st, f, z, nll);
@@ -1087,14 +1717,21 @@ extern "C" int lfi_flow_seq_bwd(const lfi_flow_dims* d, const lfi_flow_params* p
   bind_bstash(&f, bstash);
   f.gscale = gscale;
   hipStream_t st = (hipStream_t)stream;
+  const bool fast = flow_fast_ok(f.C, f.H, f.Cout) && !flow_force_generic();
   const CarveB cv = carve_bwd(f.C, f.H, f.Cout, f.G);
-  const size_t lds = (size_t)cv.total * sizeof(float);
-  rc = set_flow_lds(flow_diag_bwd_kernel, lds, "lfi_flow_seq_bwd");
+  const CarveFB cf = carve_fast_bwd(f.C4, f.H4, f.Co4, f.Cout, f.NG);
+  const size_t lds = (size_t)(fast ? cf.total : cv.total) * sizeof(float);
+  rc = fast ? (f.lstm ? set_flow_lds(flow_diag_bwd_fast_kernel<4>, lds, "lfi_flow_seq_bwd")
+                      : set_flow_lds(flow_diag_bwd_fast_kernel<3>, lds, "lfi_flow_seq_bwd"))
+            : set_flow_lds(flow_diag_bwd_kernel, lds, "lfi_flow_seq_bwd");
   if (rc) return rc;
   for (int dg = f.N + f.Ks - 2; dg >= 0; --dg) {
     const int klo = dg - (f.N - 1) > 0 ? dg - (f.N - 1) : 0;
     const int khi = dg < f.Ks - 1 ? dg : f.Ks - 1;
-    hipLaunchKernelGGL(flow_diag_bwd_kernel, dim3(f.nbt, khi - klo + 1), dim3(NT), lds, st, f, dg, klo);
+    const dim3 grid(f.nbt, khi - klo + 1);
+    if (!fast) hipLaunchKernelGGL(flow_diag_bwd_kernel, grid, dim3(NT), lds, st, f, dg, klo);
+    else if (f.lstm) hipLaunchKernelGGL(flow_diag_bwd_fast_kernel<4>, grid, dim3(NT), lds, st, f, dg, klo);
+    else hipLaunchKernelGGL(flow_diag_bwd_fast_kernel<3>, grid, dim3(NT), lds, st, f, dg, klo);
   }
   LFI_LAUNCH_CHECK("lfi_flow_seq_bwd");
   return LFI_OK;
