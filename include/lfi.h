@@ -209,6 +209,9 @@ int lfi_adam_clip_step(float* p, const float* g, float* m, float* v, long n, con
                        void* stream);
 
 /* ---------------------------------------------------------------- diagnostics */
+/* Timing probe of the register-resident forward cells: a device buffer of >= 16 * Ks 64-bit slots stamped with s_memtime
+ * (100 MHz) at the phase boundaries of the cells in workgroup column 0; NULL switches it off. Process-global. */
+int lfi_debug_set_stamps(void* device_buffer);
 /* Checks the MFMA operand/accumulator lane maps the kernels rely on; out[0] = number of mismatches. */
 int lfi_selftest_mfma(int* out, void* stream);
 

@@ -41,7 +41,15 @@ __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
 
-__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+// Gate non-linearities on the hardware transcendental units (v_exp_f32 = 2^x, v_rcp_f32; ~1 ulp each): the libm expf /
+// tanhf calls cost 15-50 VALU instructions apiece and the gate epilogues run hundreds of them per lane. Absolute error
+// ~1e-7 on values in (-1, 1) (tanh near 0 loses relative, not absolute, accuracy), saturating correctly at +-inf.
+__device__ __forceinline__ float sigmoidf_(float x) {
+  return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+}
+__device__ __forceinline__ float tanhf_(float x) {
+  return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.8853900817779268f * x));
+}
 
 // NACC 16 x 16 output tiles that share the A operand: acc[c] += A(16 x K) * B_c(K x 16), c < NACC.
 //   A is in LDS, k-major: element (i, k) at a_lds[k * lda + i]                       (i = 0..15)

@@ -50,7 +50,7 @@ __global__ __launch_bounds__(256) void enc_gate_fwd_kernel(EncArgs a, int s, con
     }
     const float rr = sigmoidf_(mk * xp[j] + a.b_ih[j] + ghr);
     const float uu = sigmoidf_(mk * xp[hid + j] + a.b_ih[hid + j] + ghu);
-    const float nn = tanhf(mk * xp[2 * hid + j] + a.b_ih[2 * hid + j] + rr * ghn);
+    const float nn = tanhf_(mk * xp[2 * hid + j] + a.b_ih[2 * hid + j] + rr * ghn);
     const float hnew = (1.0f - uu) * nn + uu * hp;
     const long sw = (long)s * a.F + w;
     a.hseq[sw * hid + j] = hnew;
@@ -342,7 +342,7 @@ __global__ __launch_bounds__(ENC_NT, 2) void enc_gru_fwd_fused_kernel(EncArgs a,
             const float ghn = acc[t][2][r] + bh[t][2];
             const float rr = sigmoidf_(mk[e] * xr[e] + bi[t][0] + (acc[t][0][r] + bh[t][0]));
             const float uu = sigmoidf_(mk[e] * xu[e] + bi[t][1] + (acc[t][1][r] + bh[t][1]));
-            const float nn = tanhf(mk[e] * xn[e] + bi[t][2] + rr * ghn);
+            const float nn = tanhf_(mk[e] * xn[e] + bi[t][2] + rr * ghn);
             const float hnew = (1.0f - uu) * nn + uu * hp[e];
             if (STASH) {
               const unsigned w = (unsigned)min(wbase + rl, a.F - 1);

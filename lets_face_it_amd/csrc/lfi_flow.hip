@@ -39,7 +39,7 @@ struct FlowK {
   const float *W, *Wt, *Winv, *wz_t, *whh_t, *wfl_t, *wc, *ldconst;
   // prep, zero-padded images for the register-resident cell kernels (k rows padded to 4, columns to 16)
   const float *pW, *pWt, *pwz, *pwh, *pwfl, *bwfl, *bwh, *bwz;
-  int C4, C16, Ch4, Ch16, H4, H16, Co4, Co16, NG;
+  int C16, Ch16, H16, Co16, NG;
   // forward stash
   float *sA, *sY, *sX, *sH, *sG, *sO, *sL, *sC;   // sC: LSTM cell state (lstm only)
   // backward stash
@@ -48,6 +48,7 @@ struct FlowK {
   const float* x0; int T, start;
   const float* gic;
   float gscale;
+  unsigned long long* stamps;  // diagnostics only (lfi_debug_set_stamps): s_memtime at phase boundaries, else null
 };
 
 // Everything one forward cell touches, resolved to pointers for its (k, frame block).
@@ -96,11 +97,11 @@ __device__ __forceinline__ void coupling_net_phase(const FlowK& f, const CellIO&
           const float* gc = io.gic + (long)row * G;
           const float ii = sigmoidf_(gz[0][r] + gh[0][r] + gc[j] + bhh[j]);
           const float ff = sigmoidf_(gz[1][r] + gh[1][r] + gc[H + j] + bhh[H + j]);
-          const float gg = tanhf(gz[2][r] + gh[2][r] + gc[2 * H + j] + bhh[2 * H + j]);
+          const float gg = tanhf_(gz[2][r] + gh[2][r] + gc[2 * H + j] + bhh[2 * H + j]);
           const float oo = sigmoidf_(gz[3][r] + gh[3][r] + gc[3 * H + j] + bhh[3 * H + j]);
           const float cp = io.c_prev ? io.c_prev[(long)row * H + j] : 0.0f;
           const float c2 = ff * cp + ii * gg;
-          hnew = oo * tanhf(c2);
+          hnew = oo * tanhf_(c2);
           io.h_out[(long)row * H + j] = hnew;
           io.c_out[(long)row * H + j] = c2;
           if (io.g_out) {
@@ -132,7 +133,7 @@ __device__ __forceinline__ void coupling_net_phase(const FlowK& f, const CellIO&
         const float rr = sigmoidf_(ar[r] + gc[j] + bhh[j]);
         const float uu = sigmoidf_(au[r] + gc[H + j] + bhh[H + j]);
         const float ghn = ahn[r] + bhh[2 * H + j];
-        const float nn = tanhf(ain[r] + gc[2 * H + j] + rr * ghn);
+        const float nn = tanhf_(ain[r] + gc[2 * H + j] + rr * ghn);
         const float hp = Ht[j * LT + i];
         hnew = (1.0f - uu) * nn + uu * hp;
         io.h_out[(long)row * H + j] = hnew;
@@ -517,7 +518,7 @@ __global__ __launch_bounds__(NT) void flow_diag_bwd_kernel(FlowK f, int d, int k
               const float dhn = acc[r] + (dhf ? dhf[(long)row * H + j] : 0.0f);
               const float* gs = gs_base + (long)row * 4 * H;
               const float ii = gs[j], ff = gs[H + j], gg = gs[2 * H + j], oo = gs[3 * H + j];
-              const float tc = tanhf(c_base[(long)row * H + j]);
+              const float tc = tanhf_(c_base[(long)row * H + j]);
               const float cp = cp_base ? cp_base[(long)row * H + j] : 0.0f;
               const float dc2 = dhn * oo * (1.0f - tc * tc) + (dcf ? dcf[(long)row * H + j] : 0.0f);
               dai = dc2 * gg * ii * (1.0f - ii);
@@ -652,42 +653,83 @@ __global__ __launch_bounds__(NT) void flow_diag_bwd_kernel(FlowK f, int d, int k
 // Same cells for the common sizes (C <= 64, H <= 128): the generic kernels above stream every weight chunk from L2 inside
 // the dependent MFMA chains (4 phases x ~10 chunk round trips per cell: ~54 % of a wave's life is s_waitcnt, rocprof
 // PMC). Weights do not depend on the data, so here each wave issues the loads of ITS slice of a phase's weights one phase
-// ahead, into registers (<= 168 VGPRs), from zero-padded images made by lfi_flow_prep (k rows padded to 4, columns to 16:
-// no bounds checks, no select chains), and the k loops run MFMA-paced from registers + LDS. Elementwise phases use a
-// fixed (row = tid / 32, column = tid % 32 [+ 32]) thread map: no integer divisions, 128-byte row segments.
-constexpr int FC_C4 = 16;   // k-steps (of 4) over C   <= 64
-constexpr int FC_Z4 = 8;    //              over Ch  <= 32
-constexpr int FC_H4 = 32;   //              over H   <= 128
-constexpr int FC_O4 = 16;   //              over Cout <= 64
+// ahead, into registers (<= 136 VGPRs), from zero-padded images made by lfi_flow_prep, and the k loops run MFMA-paced
+// from registers + LDS. Image layout = MFMA B-fragment order in blocks of 16 k: element (k, column) of a K x J operand
+// sits at (((k / 16) * 4 + k % 4) * J16 + column) * 4 + (k / 4) % 4, so the four k-steps of a block are ONE 16-byte load
+// per lane and a wave-load is four 256-byte segments (dword-per-lane loads spent 12k cycles per cell in issue alone,
+// s_memtime stamps). K and J are padded to 16 with zeros: no bounds checks. Elementwise phases use a fixed
+// (row = tid / 32, column = tid % 32 [+ 32]) thread map: no integer divisions, 128-byte row segments.
+#define LFI_STAMP(slot)                                                                                  \
+  do {                                                                                                   \
+    if (f.stamps && tid == 0 && bt == 0) f.stamps[cell * 16 + (slot)] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
+
+constexpr int FB_C = 4;   // blocks of 16 k over C    <= 64
+constexpr int FB_Z = 2;   //                 over Ch   <= 32
+constexpr int FB_H = 8;   //                 over H    <= 128
+constexpr int FB_O = 4;   //                 over Cout <= 64
 
 __host__ __device__ inline bool flow_fast_ok(int C, int H, int Cout) { return C <= 64 && H <= 128 && Cout <= 64; }
+__host__ __device__ inline long flow_img_index(int k, int col, int J) {
+  return ((long)((k >> 4) * 4 + (k & 3)) * J + col) * 4 + ((k >> 2) & 3);
+}
+
+// Workgroup -> (cell, batch tile). Workgroups are dealt round-robin over the 8 XCDs (block b and b + 8 share one), and every
+// cell of a diagonal needs its own 270 KB of weights: give each XCD a contiguous run of (cell, tile) pairs so that a cell's
+// 16 batch tiles (and the same flow step on the next diagonal) hit the same 4 MB L2 instead of all 8 L2s holding all 16
+// steps' weights (4.3 MB: thrashing). Bijective for any grid size; speed only, never correctness.
+__device__ __forceinline__ void flow_cell_of_block(int nbt, int* cell, int* bt) {
+  const int total = gridDim.x * gridDim.y;
+  int bid = blockIdx.x + gridDim.x * blockIdx.y;
+  const int q = total >> 3, r = total & 7, xcd = bid & 7, idx = bid >> 3;
+  bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  *cell = bid / nbt;
+  *bt = bid - *cell * nbt;
+}
 
 struct CarveF {
   int At, Ht, Zt, Hn, Yrm, Orm, total;
 };
-__host__ __device__ inline CarveF carve_fast_fwd(int C, int C4, int H4, int Ch4, int Cout) {
+__host__ __device__ inline CarveF carve_fast_fwd(int C, int C16, int H16, int Ch16, int Cout) {
   CarveF c;
   int o = 0;
-  c.At = o; o += C4 * LT;
-  c.Ht = o; o += H4 * LT;
-  c.Zt = o; o += (Ch4 > 0 ? Ch4 : 4) * LT;
-  c.Hn = o; o += H4 * LT;
+  c.At = o; o += C16 * LT;
+  c.Ht = o; o += H16 * LT;
+  c.Zt = o; o += Ch16 * LT;
+  c.Hn = o; o += H16 * LT;
   c.Yrm = o; o += MB * (C + 1);
   c.Orm = o; o += MB * (Cout + 1);
   c.total = o;
   return c;
 }
 
-// acc (+)= A(16 x 4 n4) from LDS (k-major, a_lds[kk * LT + i]) times the register-resident B slice w[u] (k = 4u + kq)
-template <int MAXU>
-__device__ __forceinline__ f32x4 mma16_reg(const float* a_lane /* a_lds + kq*LT + l15 */, const float (&w)[MAXU], int n4) {
+// sum over nb blocks of 16 k: A(16 x 16 nb) from LDS (k-major: a_lane = a_lds + kq * LT + l15, element k at + k * LT) times
+// the register-resident B slice w[b] (components e: k = 16 b + 4 e + kq). Two interleaved chains (40-cycle dependent latency
+// against a 32-cycle issue).
+template <int MAXB>
+__device__ __forceinline__ f32x4 mma16_reg(const float* a_lane, const f32x4 (&w)[MAXB], int nb) {
   f32x4 e = {0.f, 0.f, 0.f, 0.f}, o = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int u = 0; u < MAXU; u += 2) {
-    if (u < n4) e = mfma16(a_lane[u * 4 * LT], w[u], e);
-    if (u + 1 < n4) o = mfma16(a_lane[(u + 1) * 4 * LT], w[u + 1], o);
-  }
+  for (int b = 0; b < MAXB; ++b)
+    if (b < nb) {
+      const float* ab = a_lane + b * 16 * LT;
+      const float a0 = ab[0], a1 = ab[4 * LT], a2 = ab[8 * LT], a3 = ab[12 * LT];
+      e = mfma16(a0, w[b][0], e);
+      o = mfma16(a1, w[b][1], o);
+      e = mfma16(a2, w[b][2], e);
+      o = mfma16(a3, w[b][3], o);
+    }
   return e + o;
+}
+
+// this lane's slice of one 16-column tile of an image: nb float4 (k blocks), image row pitch J (columns, multiple of 16)
+template <int MAXB>
+__device__ __forceinline__ void load_frag(f32x4 (&w)[MAXB], const float* __restrict__ img, int J, int col, int kq, int nb,
+                                          bool on) {
+  const f32x4* p = reinterpret_cast<const f32x4*>(img) + (long)kq * J + col;
+#pragma unroll
+  for (int b = 0; b < MAXB; ++b)
+    if (on && b < nb) w[b] = p[(long)b * 4 * J];
 }
 
 template <int NG>
@@ -695,13 +737,15 @@ __global__ __launch_bounds__(NT) void flow_diag_fwd_fast_kernel(FlowK f, int d, 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l15 = lane & 15, kq = lane >> 4;
   const int ri = tid >> 5, cl = tid & 31;  // elementwise thread map
-  const int k = klo + blockIdx.y, n = d - k;
-  const int b0 = blockIdx.x * MB;
+  int cell, bt;
+  flow_cell_of_block(f.nbt, &cell, &bt);
+  const int k = klo + cell, n = d - k;
+  const int b0 = bt * MB;
   const int B = f.B, C = f.C, H = f.H, Ch = f.Ch, C2 = f.C2, Cout = f.Cout, G = f.G;
-  const int C4 = f.C4, C16 = f.C16, Ch4 = f.Ch4, H4 = f.H4, H16 = f.H16, Co16 = f.Co16;
+  const int C16 = f.C16, Ch16 = f.Ch16, H16 = f.H16, Co16 = f.Co16;
   const long fr = (long)n * B;
   const long kf = (long)k * f.F + fr;
-  const CarveF cv = carve_fast_fwd(C, C4, H4, Ch4, Cout);
+  const CarveF cv = carve_fast_fwd(C, C16, H16, Ch16, Cout);
   float* At = flow_smem + cv.At;
   float* Ht = flow_smem + cv.Ht;
   float* Zt = flow_smem + cv.Zt;
@@ -709,46 +753,38 @@ __global__ __launch_bounds__(NT) void flow_diag_fwd_fast_kernel(FlowK f, int d, 
   float* Yrm = flow_smem + cv.Yrm;
   float* Orm = flow_smem + cv.Orm;
   const int ldy = C + 1, ldo = Cout + 1;
-  const int nC4 = C4 >> 2, nZ4 = Ch4 >> 2, nH4 = H4 >> 2;
+  const int nbC = C16 >> 4, nbZ = Ch16 >> 4, nbH = H16 >> 4;
+  LFI_STAMP(0);
 
   // ---- weights of P1 (this wave's 16 output channels of W) and P2 (its 16 hidden units, NG gates), gic/bias of its rows
   const bool t1 = wave * 16 < C, t2 = wave * 16 < H, t3 = wave * 16 < Cout;
-  float w1[FC_C4], wz[NG][FC_Z4], wh[NG][FC_H4];
-  {
-    const float* Wk = f.pW + (long)k * C4 * C16 + kq * C16 + wave * 16 + l15;
+  const int tcol = wave * 16 + l15;
+  f32x4 w1[FB_C], wz[NG][FB_Z], wh[NG][FB_H];
+  load_frag<FB_C>(w1, f.pW + (long)k * C16 * C16, C16, tcol, kq, nbC, t1);
 #pragma unroll
-    for (int u = 0; u < FC_C4; ++u)
-      if (t1 && u < nC4) w1[u] = Wk[u * 4 * C16];
-    const float* zk = f.pwz + (long)k * Ch4 * NG * H16 + kq * NG * H16 + wave * 16 + l15;
-    const float* hk = f.pwh + (long)k * H4 * NG * H16 + kq * NG * H16 + wave * 16 + l15;
-#pragma unroll
-    for (int u = 0; u < FC_Z4; ++u)
-#pragma unroll
-      for (int g = 0; g < NG; ++g)
-        if (t2 && u < nZ4) wz[g][u] = zk[u * 4 * NG * H16 + g * H16];
-#pragma unroll
-    for (int u = 0; u < FC_H4; ++u)
-#pragma unroll
-      for (int g = 0; g < NG; ++g)
-        if (t2 && u < nH4) wh[g][u] = hk[u * 4 * NG * H16 + g * H16];
+  for (int g = 0; g < NG; ++g) {
+    load_frag<FB_Z>(wz[g], f.pwz + (long)k * Ch16 * NG * H16, NG * H16, g * H16 + tcol, kq, nbZ, t2);
+    load_frag<FB_H>(wh[g], f.pwh + (long)k * H16 * NG * H16, NG * H16, g * H16 + tcol, kq, nbH, t2);
   }
-  const int j2 = wave * 16 + l15;         // hidden unit of this lane in P2
+  const int j2 = tcol;                    // hidden unit of this lane in P2
   const bool j2ok = j2 < H;
   float gc[4][NG], bh[NG], cprev[4];
   {
     const float* gicb = f.gic + kf * G;
     const float* bhh = f.p.b_hh + (long)k * G;
     const float* cpb = (NG == 4 && n > 0) ? f.sC + (kf - B) * H : nullptr;
+    const int jc = j2ok ? j2 : 0;
 #pragma unroll
-    for (int g = 0; g < NG; ++g) bh[g] = j2ok ? bhh[g * H + j2] : 0.0f;
+    for (int g = 0; g < NG; ++g) bh[g] = bhh[g * H + jc];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int row = min(b0 + kq * 4 + r, B - 1);
 #pragma unroll
-      for (int g = 0; g < NG; ++g) gc[r][g] = j2ok ? gicb[(long)row * G + g * H + j2] : 0.0f;
-      cprev[r] = (cpb && j2ok) ? cpb[(long)row * H + j2] : 0.0f;
+      for (int g = 0; g < NG; ++g) gc[r][g] = gicb[(long)row * G + g * H + jc];
+      cprev[r] = cpb ? cpb[(long)row * H + jc] : 0.0f;
     }
   }
+  LFI_STAMP(1);
 
   // ---- P0: actnorm (glow/modules.py:45-52); stage a, h_prev k-major; zero the k padding
   {
@@ -757,7 +793,7 @@ __global__ __launch_bounds__(NT) void flow_diag_fwd_fast_kernel(FlowK f, int d, 
     const float* xin = (k == 0) ? f.x0 + ((long)row * f.T + f.start + n) * C : f.sX + (kf - f.F + row) * C;
     const float* anb = f.p.an_bias + (long)k * C;
     const float* anl = f.p.an_logs + (long)k * C;
-    for (int c = cl; c < C4; c += 32) {
+    for (int c = cl; c < C16; c += 32) {
       float a = 0.0f;
       if (c < C && rok) {
         a = (xin[c] + anb[c]) * expf(anl[c]);
@@ -766,18 +802,19 @@ __global__ __launch_bounds__(NT) void flow_diag_fwd_fast_kernel(FlowK f, int d, 
       At[c * LT + ri] = a;
     }
     const float* hp = n > 0 ? f.sH + (kf - B + row) * H : nullptr;
-    for (int j = cl; j < H4; j += 32) {
+    for (int j = cl; j < H16; j += 32) {
       Ht[j * LT + ri] = (hp && rok && j < H) ? hp[j] : 0.0f;
       if (j >= H) Hn[j * LT + ri] = 0.0f;
     }
-    for (int c = Ch + cl; c < Ch4; c += 32) Zt[c * LT + ri] = 0.0f;
+    for (int c = Ch + cl; c < Ch16; c += 32) Zt[c * LT + ri] = 0.0f;
   }
   __syncthreads();
+  LFI_STAMP(2);
 
   // ---- P1: y = a W   (InvertibleConv1x1.forward, glow/modules.py:186)
   if (t1) {
-    const f32x4 acc = mma16_reg<FC_C4>(At + kq * LT + l15, w1, nC4);
-    const int c = wave * 16 + l15;
+    const f32x4 acc = mma16_reg<FB_C>(At + kq * LT + l15, w1, nbC);
+    const int c = tcol;
     if (c < C) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -791,14 +828,10 @@ __global__ __launch_bounds__(NT) void flow_diag_fwd_fast_kernel(FlowK f, int d, 
     }
   }
   // weights of P3 (this wave's 16 outputs of LinearZeros): in flight under P2
-  float w3[FC_H4];
-  {
-    const float* fk = f.pwfl + (long)k * H4 * Co16 + kq * Co16 + wave * 16 + l15;
-#pragma unroll
-    for (int u = 0; u < FC_H4; ++u)
-      if (t3 && u < nH4) w3[u] = fk[u * 4 * Co16];
-  }
+  f32x4 w3[FB_H];
+  load_frag<FB_H>(w3, f.pwfl + (long)k * H16 * Co16, Co16, tcol, kq, nbH, t3);
   __syncthreads();
+  LFI_STAMP(3);
 
   // ---- P2: recurrent cell of the coupling net (f_seq.forward, glow/models.py:204-214)
   if (t2) {
@@ -811,18 +844,32 @@ __global__ __launch_bounds__(NT) void flow_diag_fwd_fast_kernel(FlowK f, int d, 
     const float* zl = Zt + kq * LT + l15;
     const float* hl = Ht + kq * LT + l15;
 #pragma unroll
-    for (int u = 0; u < FC_Z4; ++u)
-      if (u < nZ4) {
-        const float a = zl[u * 4 * LT];
+    for (int b = 0; b < FB_Z; ++b)
+      if (b < nbZ) {
+        const float* ab = zl + b * 16 * LT;
+        const float a0 = ab[0], a1 = ab[4 * LT], a2 = ab[8 * LT], a3 = ab[12 * LT];
 #pragma unroll
-        for (int g = 0; g < NG; ++g) az[g] = mfma16(a, wz[g][u], az[g]);
+        for (int g = 0; g < NG; ++g) az[g] = mfma16(a0, wz[g][b][0], az[g]);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) az[g] = mfma16(a1, wz[g][b][1], az[g]);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) az[g] = mfma16(a2, wz[g][b][2], az[g]);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) az[g] = mfma16(a3, wz[g][b][3], az[g]);
       }
 #pragma unroll
-    for (int u = 0; u < FC_H4; ++u)
-      if (u < nH4) {
-        const float a = hl[u * 4 * LT];
+    for (int b = 0; b < FB_H; ++b)
+      if (b < nbH) {
+        const float* ab = hl + b * 16 * LT;
+        const float a0 = ab[0], a1 = ab[4 * LT], a2 = ab[8 * LT], a3 = ab[12 * LT];
 #pragma unroll
-        for (int g = 0; g < NG; ++g) ah[g] = mfma16(a, wh[g][u], ah[g]);
+        for (int g = 0; g < NG; ++g) ah[g] = mfma16(a0, wh[g][b][0], ah[g]);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) ah[g] = mfma16(a1, wh[g][b][1], ah[g]);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) ah[g] = mfma16(a2, wh[g][b][2], ah[g]);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) ah[g] = mfma16(a3, wh[g][b][3], ah[g]);
       }
     if (j2ok) {
 #pragma unroll
@@ -835,17 +882,17 @@ __global__ __launch_bounds__(NT) void flow_diag_fwd_fast_kernel(FlowK f, int d, 
           const float rr = sigmoidf_(az[0][r] + ah[0][r] + gc[r][0] + bh[0]);
           const float uu = sigmoidf_(az[1][r] + ah[1][r] + gc[r][1] + bh[1]);
           const float ghn = ah[2][r] + bh[2];
-          const float nn = tanhf(az[2][r] + gc[r][2] + rr * ghn);
+          const float nn = tanhf_(az[2][r] + gc[r][2] + rr * ghn);
           const float hp = Ht[j2 * LT + i];
           hnew = (1.0f - uu) * nn + uu * hp;
           gs0 = rr; gs1 = uu; gs2 = nn; gs3 = ghn;
         } else {        // torch.nn.LSTMCell, gate order i, f, g, o; zero (h, c) at the first modelled frame
           const float ii = sigmoidf_(az[0][r] + ah[0][r] + gc[r][0] + bh[0]);
           const float ff = sigmoidf_(az[1][r] + ah[1][r] + gc[r][1] + bh[1]);
-          const float gg = tanhf(az[2][r] + ah[2][r] + gc[r][2] + bh[2]);
+          const float gg = tanhf_(az[2][r] + ah[2][r] + gc[r][2] + bh[2]);
           const float oo = sigmoidf_(az[NG - 1][r] + ah[NG - 1][r] + gc[r][NG - 1] + bh[NG - 1]);
           const float c2 = ff * cprev[r] + ii * gg;
-          hnew = oo * tanhf(c2);
+          hnew = oo * tanhf_(c2);
           if (row < B) f.sC[(kf + row) * H + j2] = c2;
           gs0 = ii; gs1 = ff; gs2 = gg; gs3 = oo;
         }
@@ -859,11 +906,12 @@ __global__ __launch_bounds__(NT) void flow_diag_fwd_fast_kernel(FlowK f, int d, 
     }
   }
   __syncthreads();
+  LFI_STAMP(4);
 
   // ---- P3: o = (h' Wfl^T + b) exp(3 logs)   (LinearZeros, glow/modules.py:93-95)
   if (t3) {
-    const f32x4 acc = mma16_reg<FC_H4>(Hn + kq * LT + l15, w3, nH4);
-    const int col = wave * 16 + l15;
+    const f32x4 acc = mma16_reg<FB_H>(Hn + kq * LT + l15, w3, nbH);
+    const int col = tcol;
     if (col < Cout) {
       const float bb = f.p.b_fl[(long)k * Cout + col], sc = expf(3.0f * f.p.l_fl[(long)k * Cout + col]);
 #pragma unroll
@@ -877,6 +925,7 @@ __global__ __launch_bounds__(NT) void flow_diag_fwd_fast_kernel(FlowK f, int d, 
     }
   }
   __syncthreads();
+  LFI_STAMP(5);
 
   // ---- P4: coupling (glow/models.py:330-341), pass-through half, log-det of the coupling (wavefront shuffle sum)
   {
@@ -902,36 +951,41 @@ __global__ __launch_bounds__(NT) void flow_diag_fwd_fast_kernel(FlowK f, int d, 
     for (int o = 16; o > 0; o >>= 1) lg += __shfl_xor(lg, o, 64);  // the 32 lanes of one row
     if (cl == 0 && rok) f.sL[kf + row] = lg;
   }
+  LFI_STAMP(6);
 }
 
 struct CarveFB {
   int Dl, Gi, Dy, Cy, Pl, total;
 };
-__host__ __device__ inline CarveFB carve_fast_bwd(int C4, int H4, int Co4, int Cout, int NG) {
+__host__ __device__ inline CarveFB carve_fast_bwd(int C16, int H16, int Co16, int Cout, int NG) {
   CarveFB c;
   int o = 0;
-  c.Dl = o; o += Co4 * LT;
-  c.Gi = o; o += 2 * NG * H4 * LT;   // Gi then Gh, each [NG][H4][LT]
-  c.Dy = o; o += C4 * LT;
-  c.Cy = o; o += H4 * LT;
+  c.Dl = o; o += Co16 * LT;
+  c.Gi = o; o += 2 * NG * H16 * LT;   // Gi then Gh, each [NG][H16][LT]
+  c.Dy = o; o += C16 * LT;
+  c.Cy = o; o += H16 * LT;
   c.Pl = o; o += MB * (Cout + 1);
   c.total = o;
   return c;
 }
 
-// acc += A(16 x 4 n4, LDS k-major) * B slice streamed into `w` by the caller; NG blocks of n4 k-steps (a_lane advances by
-// blk floats per block)
-template <int NG, int MAXU>
-__device__ __forceinline__ f32x4 mma16_reg_blocks(f32x4 acc, const float* a_lane, int blk, const float (&w)[NG][MAXU], int n4) {
-  f32x4 o = {0.f, 0.f, 0.f, 0.f};
+// acc + sum over NG gate blocks (each nb blocks of 16 k; a_lane advances by blk floats per gate)
+template <int NG, int MAXB>
+__device__ __forceinline__ f32x4 mma16_reg_gates(const float* a_lane, int blk, const f32x4 (&w)[NG][MAXB], int nb) {
+  f32x4 e = {0.f, 0.f, 0.f, 0.f}, o = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int g = 0; g < NG; ++g)
 #pragma unroll
-    for (int u = 0; u < MAXU; u += 2) {
-      if (u < n4) acc = mfma16(a_lane[g * blk + u * 4 * LT], w[g][u], acc);
-      if (u + 1 < n4) o = mfma16(a_lane[g * blk + (u + 1) * 4 * LT], w[g][u + 1], o);
-    }
-  return acc + o;
+    for (int b = 0; b < MAXB; ++b)
+      if (b < nb) {
+        const float* ab = a_lane + g * blk + b * 16 * LT;
+        const float a0 = ab[0], a1 = ab[4 * LT], a2 = ab[8 * LT], a3 = ab[12 * LT];
+        e = mfma16(a0, w[g][b][0], e);
+        o = mfma16(a1, w[g][b][1], o);
+        e = mfma16(a2, w[g][b][2], e);
+        o = mfma16(a3, w[g][b][3], o);
+      }
+  return e + o;
 }
 
 template <int NG>
@@ -939,21 +993,23 @@ __global__ __launch_bounds__(NT) void flow_diag_bwd_fast_kernel(FlowK f, int d, 
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l15 = lane & 15, kq = lane >> 4;
   const int ri = tid >> 5, cl = tid & 31;
-  const int k = klo + blockIdx.y, n = d - k;
-  const int b0 = blockIdx.x * MB;
+  int cell, bt;
+  flow_cell_of_block(f.nbt, &cell, &bt);
+  const int k = klo + cell, n = d - k;
+  const int b0 = bt * MB;
   const int B = f.B, C = f.C, H = f.H, Ch = f.Ch, C2 = f.C2, Cout = f.Cout, G = f.G;
-  const int C4 = f.C4, C16 = f.C16, Ch16 = f.Ch16, H4 = f.H4, H16 = f.H16, Co4 = f.Co4;
+  const int C16 = f.C16, Ch16 = f.Ch16, H16 = f.H16, Co16 = f.Co16;
   const long fr = (long)n * B;
   const long kf = (long)k * f.F + fr;
-  const CarveFB cv = carve_fast_bwd(C4, H4, Co4, Cout, NG);
+  const CarveFB cv = carve_fast_bwd(C16, H16, Co16, Cout, NG);
   float* Dl = flow_smem + cv.Dl;
   float* Gi = flow_smem + cv.Gi;
-  float* Gh = Gi + NG * H4 * LT;
+  float* Gh = Gi + NG * H16 * LT;
   float* Dy = flow_smem + cv.Dy;
   float* Cy = flow_smem + cv.Cy;
   float* Pl = flow_smem + cv.Pl;
   const int ldp = Cout + 1;
-  const int nC4 = C4 >> 2, nH4 = H4 >> 2, nO4 = Co4 >> 2;
+  const int nbC = C16 >> 4, nbH = H16 >> 4, nbO = Co16 >> 4;
   const bool last = k == f.Ks - 1;
   const float gz = f.gscale / LN2_F;   // d loss / d z = z * gz   (prior term)
   const float dl = -f.gscale / LN2_F;  // d loss / d logdet
@@ -962,25 +1018,39 @@ __global__ __launch_bounds__(NT) void flow_diag_bwd_fast_kernel(FlowK f, int d, 
 
   // which tiles this wave owns: hidden tile `wave` (Q1, Q2), z tile `wave` (Q2, waves < Ch16/16), channel tile `wave` (Q3)
   const bool th = wave * 16 < H, tz = wave * 16 < Ch, tc = wave * 16 < C;
+  const int tcol = wave * 16 + l15;
   // ---- weights of Q1 (dlin Wfl: K = Cout) for this wave's hidden tile
-  float wq1[FC_O4];
-  {
-    const float* wk = f.bwfl + (long)k * Co4 * H16 + kq * H16 + wave * 16 + l15;
-#pragma unroll
-    for (int u = 0; u < FC_O4; ++u)
-      if (th && u < nO4) wq1[u] = wk[u * 4 * H16];
-  }
+  f32x4 wq1[FB_O];
+  load_frag<FB_O>(wq1, f.bwfl + (long)k * Co16 * H16, H16, tcol, kq, nbO, th);
   // the z-tile waves stream W_ih[:, :Ch] first (they run dz1 before the barrier), the others W_hh
-  float wq2[NG][FC_H4];
+  f32x4 wq2[NG][FB_H];
+#pragma unroll
+  for (int g = 0; g < NG; ++g) {
+    if (tz) load_frag<FB_H>(wq2[g], f.bwz + ((long)k * NG + g) * H16 * Ch16, Ch16, tcol, kq, nbH, true);
+    else load_frag<FB_H>(wq2[g], f.bwh + ((long)k * NG + g) * H16 * H16, H16, tcol, kq, nbH, th);
+  }
+
+  // ---- every stash operand of Q1 / Q2 / Q3 (none depends on this cell's arithmetic) is requested now: issued inside
+  //      their phases, each of these HBM round trips (~2 us) was exposed behind a barrier
+  float sg[4][4], shp[4], sdhf[4], sc2[4], scp[4], sdcf[4], sdxo[4], sa[4];
   {
-    const float* wk = tz ? f.bwz + (long)k * NG * H4 * Ch16 + kq * Ch16 + wave * 16 + l15
-                         : f.bwh + (long)k * NG * H4 * H16 + kq * H16 + wave * 16 + l15;
-    const int ldw = tz ? Ch16 : H16;
+    const int j = tcol < H ? tcol : 0, cz = tcol < Ch ? tcol : 0, cc = tcol < C ? tcol : 0;
+    const bool hasn = n < f.N - 1, hasp = n > 0;
 #pragma unroll
-    for (int g = 0; g < NG; ++g)
-#pragma unroll
-      for (int u = 0; u < FC_H4; ++u)
-        if ((tz || th) && u < nH4) wq2[g][u] = wk[(g * H4 + u * 4) * ldw];
+    for (int r = 0; r < 4; ++r) {
+      const long row = min(b0 + kq * 4 + r, B - 1);
+      const float* gs = f.sG + (kf + row) * 4 * H + j;
+      sg[r][0] = gs[0]; sg[r][1] = gs[H]; sg[r][2] = gs[2 * H]; sg[r][3] = gs[3 * H];
+      shp[r] = hasp ? f.sH[(kf - B + row) * H + j] : 0.0f;
+      sdhf[r] = hasn ? f.bDh[(kf + B + row) * H + j] : 0.0f;
+      if (NG == 4) {
+        sc2[r] = f.sC[(kf + row) * H + j];
+        scp[r] = hasp ? f.sC[(kf - B + row) * H + j] : 0.0f;
+        sdcf[r] = hasn ? f.bDc[(kf + B + row) * H + j] : 0.0f;
+      }
+      sdxo[r] = dxo[row * C + cz] * dxs;
+      sa[r] = f.sA[(kf + row) * C + cc];
+    }
   }
 
   // ---- Q0: coupling backward + LinearZeros scale; zero the k padding of the LDS operands
@@ -1023,39 +1093,36 @@ __global__ __launch_bounds__(NT) void flow_diag_bwd_fast_kernel(FlowK f, int d, 
         Pl[ri * ldp + cl] = p0;
       }
     }
-    for (int c = Cout + cl; c < Co4; c += 32) Dl[c * LT + ri] = 0.0f;
-    for (int c = C + cl; c < C4; c += 32) Dy[c * LT + ri] = 0.0f;
-    for (int j = H + cl; j < H4; j += 32) {
+    for (int c = Cout + cl; c < Co16; c += 32) Dl[c * LT + ri] = 0.0f;
+    for (int c = C + cl; c < C16; c += 32) Dy[c * LT + ri] = 0.0f;
+    for (int j = H + cl; j < H16; j += 32) {
 #pragma unroll
-      for (int g = 0; g < NG; ++g) { Gi[(g * H4 + j) * LT + ri] = 0.0f; Gh[(g * H4 + j) * LT + ri] = 0.0f; }
+      for (int g = 0; g < NG; ++g) { Gi[(g * H16 + j) * LT + ri] = 0.0f; Gh[(g * H16 + j) * LT + ri] = 0.0f; }
     }
   }
   __syncthreads();
   if (tid < Cout) {
     float sum = 0.0f;
     for (int i = 0; i < MB; ++i) sum += Pl[i * ldp + tid];
-    f.bPlfl[(((long)k * f.N + n) * f.nbt + blockIdx.x) * Cout + tid] = sum;
+    f.bPlfl[(((long)k * f.N + n) * f.nbt + bt) * Cout + tid] = sum;
   }
 
   // ---- Q1: d h' = dlin Wfl + dh carried from timestep n + 1; recurrent cell backward
   if (th) {
-    const f32x4 acc = mma16_reg<FC_O4>(Dl + kq * LT + l15, wq1, nO4);
-    const int j = wave * 16 + l15;
+    const f32x4 acc = mma16_reg<FB_O>(Dl + kq * LT + l15, wq1, nbO);
+    const int j = tcol;
     if (j < H) {
-      const float* dhf = (n < f.N - 1) ? f.bDh + (kf + B) * H : nullptr;
-      const float* hp_base = n > 0 ? f.sH + (kf - B) * H : nullptr;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int i = kq * 4 + r;
         const int row = b0 + i;
         float gi_[4] = {0.f, 0.f, 0.f, 0.f}, gh_[4] = {0.f, 0.f, 0.f, 0.f}, cy = 0.0f;
         if (row < B) {
-          const float dhn = acc[r] + (dhf ? dhf[(long)row * H + j] : 0.0f);
-          const float* gs = f.sG + (kf + row) * 4 * H + j;
-          const float g0 = gs[0], g1 = gs[H], g2 = gs[2 * H], g3 = gs[3 * H];
+          const float dhn = acc[r] + sdhf[r];
+          const float g0 = sg[r][0], g1 = sg[r][1], g2 = sg[r][2], g3 = sg[r][3];
           if (NG == 3) {
             const float rr = g0, uu = g1, nn = g2, ghn = g3;
-            const float hp = hp_base ? hp_base[(long)row * H + j] : 0.0f;
+            const float hp = shp[r];
             const float du = dhn * (hp - nn);
             const float dn = dhn * (1.0f - uu);
             cy = dhn * uu;
@@ -1066,9 +1133,9 @@ __global__ __launch_bounds__(NT) void flow_diag_bwd_fast_kernel(FlowK f, int d, 
             gh_[0] = dar; gh_[1] = dau; gh_[2] = dan * rr;
           } else {
             const float ii = g0, ff = g1, gg = g2, oo = g3;
-            const float tcv = tanhf(f.sC[(kf + row) * H + j]);
-            const float cp = n > 0 ? f.sC[(kf - B + row) * H + j] : 0.0f;
-            const float dcf = (n < f.N - 1) ? f.bDc[(kf + B + row) * H + j] : 0.0f;
+            const float tcv = tanhf_(sc2[r]);
+            const float cp = scp[r];
+            const float dcf = sdcf[r];
             const float dc2 = dhn * oo * (1.0f - tcv * tcv) + dcf;
             gi_[0] = dc2 * gg * ii * (1.0f - ii);
             gi_[1] = dc2 * cp * ff * (1.0f - ff);
@@ -1084,28 +1151,22 @@ __global__ __launch_bounds__(NT) void flow_diag_bwd_fast_kernel(FlowK f, int d, 
           for (int g = 0; g < NG; ++g) { go[g * H] = gi_[g]; ho[g * H] = gh_[g]; }
         }
 #pragma unroll
-        for (int g = 0; g < NG; ++g) { Gi[(g * H4 + j) * LT + i] = gi_[g]; Gh[(g * H4 + j) * LT + i] = gh_[g]; }
+        for (int g = 0; g < NG; ++g) { Gi[(g * H16 + j) * LT + i] = gi_[g]; Gh[(g * H16 + j) * LT + i] = gh_[g]; }
         Cy[j * LT + i] = cy;
       }
     }
   }
   // weights of Q3 (dy W^T) for this wave's channel tile: in flight under Q2
-  float wq3[FC_C4];
-  {
-    const float* wk = f.pWt + (long)k * C4 * C16 + kq * C16 + wave * 16 + l15;
-#pragma unroll
-    for (int u = 0; u < FC_C4; ++u)
-      if (tc && u < nC4) wq3[u] = wk[u * 4 * C16];
-  }
+  f32x4 wq3[FB_C];
+  load_frag<FB_C>(wq3, f.pWt + (long)k * C16 * C16, C16, tcol, kq, nbC, tc);
   __syncthreads();
 
   // ---- Q2: d z1 = dgi W_ih[:, :Ch] + pass-through (z-tile waves, before the barrier: Q3 needs it);
   //          d h_prev = dgh W_hh + carry (to timestep n - 1; not needed inside this cell)
-  auto dh_prev_tile = [&](const float (&w)[NG][FC_H4]) {
+  auto dh_prev_tile = [&](const f32x4 (&w)[NG][FB_H]) {
     if (n > 0 && th) {
-      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-      acc = mma16_reg_blocks<NG, FC_H4>(acc, Gh + kq * LT + l15, H4 * LT, w, nH4);
-      const int j = wave * 16 + l15;
+      const f32x4 acc = mma16_reg_gates<NG, FB_H>(Gh + kq * LT + l15, H16 * LT, w, nbH);
+      const int j = tcol;
       if (j < H) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -1117,9 +1178,8 @@ __global__ __launch_bounds__(NT) void flow_diag_bwd_fast_kernel(FlowK f, int d, 
     }
   };
   if (tz) {
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    acc = mma16_reg_blocks<NG, FC_H4>(acc, Gi + kq * LT + l15, H4 * LT, wq2, nH4);
-    const int c = wave * 16 + l15;
+    const f32x4 acc = mma16_reg_gates<NG, FB_H>(Gi + kq * LT + l15, H16 * LT, wq2, nbH);
+    const int c = tcol;
     if (c < Ch) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
@@ -1127,21 +1187,15 @@ __global__ __launch_bounds__(NT) void flow_diag_bwd_fast_kernel(FlowK f, int d, 
         const int row = b0 + i;
         float v = 0.0f;
         if (row < B) {
-          v = acc[r] + dxo[(long)row * C + c] * dxs;
+          v = acc[r] + sdxo[r];
           f.bDy[(kf + row) * C + c] = v;
         }
         Dy[c * LT + i] = v;
       }
     }
     // now fetch this wave's W_hh slice for its d h_prev tile (runs after Q3)
-    if (n > 0 && th) {
-      const float* wk = f.bwh + (long)k * NG * H4 * H16 + kq * H16 + wave * 16 + l15;
 #pragma unroll
-      for (int g = 0; g < NG; ++g)
-#pragma unroll
-        for (int u = 0; u < FC_H4; ++u)
-          if (u < nH4) wq2[g][u] = wk[(g * H4 + u * 4) * H16];
-    }
+    for (int g = 0; g < NG; ++g) load_frag<FB_H>(wq2[g], f.bwh + ((long)k * NG + g) * H16 * H16, H16, tcol, kq, nbH, n > 0 && th);
   } else {
     dh_prev_tile(wq2);
   }
@@ -1149,8 +1203,8 @@ __global__ __launch_bounds__(NT) void flow_diag_bwd_fast_kernel(FlowK f, int d, 
 
   // ---- Q3: d a = dy W^T ; actnorm backward ; d x_in to flow step k - 1
   if (tc) {
-    const f32x4 acc = mma16_reg<FC_C4>(Dy + kq * LT + l15, wq3, nC4);
-    const int c = wave * 16 + l15;
+    const f32x4 acc = mma16_reg<FB_C>(Dy + kq * LT + l15, wq3, nbC);
+    const int c = tcol;
     float sl = 0.0f, sb = 0.0f;
     if (c < C) {
       const float es = expf(f.p.an_logs[(long)k * C + c]);
@@ -1159,7 +1213,7 @@ __global__ __launch_bounds__(NT) void flow_diag_bwd_fast_kernel(FlowK f, int d, 
         const int row = b0 + kq * 4 + r;
         if (row < B) {
           const float da = acc[r];
-          sl += da * f.sA[(kf + row) * C + c];
+          sl += da * sa[r];
           sb += da * es;
           if (k > 0) f.bDx[(kf + row) * C + c] = da * es;
         }
@@ -1168,60 +1222,56 @@ __global__ __launch_bounds__(NT) void flow_diag_bwd_fast_kernel(FlowK f, int d, 
     sl += __shfl_xor(sl, 16, 64); sl += __shfl_xor(sl, 32, 64);
     sb += __shfl_xor(sb, 16, 64); sb += __shfl_xor(sb, 32, 64);
     if (kq == 0 && c < C) {
-      float* pan = f.bPan + (((long)k * f.N + n) * f.nbt + blockIdx.x) * 2 * C;
+      float* pan = f.bPan + (((long)k * f.N + n) * f.nbt + bt) * 2 * C;
       pan[c] = sl; pan[C + c] = sb;
     }
   }
   if (tz) dh_prev_tile(wq2);
 }
 
-// Zero-padded weight images for the register-resident cells. which: 0 pW, 1 pWt, 2 pwz, 3 pwh, 4 pwfl, 5 bwfl, 6 bwh, 7 bwz
+// Zero-padded fragment-order weight images for the register-resident cells (layout: flow_img_index).
+// which: 0 pW (k = input channel, col = output channel of W), 1 pWt, 2 pwz (k = z channel, col = g*H16 + hidden),
+// 3 pwh (k = hidden in), 4 pwfl (k = hidden, col = output), 5 bwfl (k = output, col = hidden),
+// 6 bwh [g] (k = hidden of gate g, col = hidden), 7 bwz [g] (k = hidden of gate g, col = z channel)
 __global__ __launch_bounds__(256) void flow_prep_pad_kernel(FlowK f, float* pW, float* pWt, float* pwz, float* pwh, float* pwfl,
                                                             float* bwfl, float* bwh, float* bwz) {
   const int k = blockIdx.y, which = blockIdx.z;
   const int C = f.C, H = f.H, Ch = f.Ch, Cout = f.Cout, I = f.I, NG = f.NG;
-  const int C4 = f.C4, C16 = f.C16, Ch4 = f.Ch4, Ch16 = f.Ch16, H4 = f.H4, H16 = f.H16, Co4 = f.Co4, Co16 = f.Co16;
+  const int C16 = f.C16, Ch16 = f.Ch16, H16 = f.H16, Co16 = f.Co16;
   const float* W = f.W + (long)k * C * C;
   const float* wih = f.p.w_ih + (long)k * f.G * I;
   const float* whh = f.p.w_hh + (long)k * f.G * H;
   const float* wfl = f.p.w_fl + (long)k * Cout * H;
-  long n;
+  int K, J, nimg = 1;   // rows (padded), columns (padded), images per flow step
   float* dst;
   switch (which) {
-    case 0: n = (long)C4 * C16; dst = pW + k * n; break;
-    case 1: n = (long)C4 * C16; dst = pWt + k * n; break;
-    case 2: n = (long)Ch4 * NG * H16; dst = pwz + k * n; break;
-    case 3: n = (long)H4 * NG * H16; dst = pwh + k * n; break;
-    case 4: n = (long)H4 * Co16; dst = pwfl + k * n; break;
-    case 5: n = (long)Co4 * H16; dst = bwfl + k * n; break;
-    case 6: n = (long)NG * H4 * H16; dst = bwh + k * n; break;
-    default: n = (long)NG * H4 * Ch16; dst = bwz + k * n; break;
+    case 0: K = C16; J = C16; dst = pW; break;
+    case 1: K = C16; J = C16; dst = pWt; break;
+    case 2: K = Ch16; J = NG * H16; dst = pwz; break;
+    case 3: K = H16; J = NG * H16; dst = pwh; break;
+    case 4: K = H16; J = Co16; dst = pwfl; break;
+    case 5: K = Co16; J = H16; dst = bwfl; break;
+    case 6: K = H16; J = H16; nimg = NG; dst = bwh; break;
+    default: K = H16; J = Ch16; nimg = NG; dst = bwz; break;
   }
-  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < n; idx += (long)gridDim.x * 256) {
+  const long per = (long)K * J;
+  dst += (long)k * nimg * per;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < nimg * per; idx += (long)gridDim.x * 256) {
+    const int g = (int)(idx / per);
+    const long q = idx - g * per;
+    const int kk = (int)(q / J), col = (int)(q - (long)kk * J);
     float v = 0.0f;
-    if (which <= 1) {
-      const int kk = (int)(idx / C16), c = (int)(idx % C16);
-      if (kk < C && c < C) v = which == 0 ? W[kk * C + c] : W[c * C + kk];
-    } else if (which == 2 || which == 3) {
-      const int j = (int)(idx % H16), g = (int)((idx / H16) % NG), kk = (int)(idx / ((long)H16 * NG));
-      if (j < H) {
-        if (which == 2) { if (kk < Ch) v = wih[((long)g * H + j) * I + kk]; }
-        else if (kk < H) v = whh[((long)g * H + j) * H + kk];
-      }
-    } else if (which == 4) {
-      const int kk = (int)(idx / Co16), c = (int)(idx % Co16);
-      if (kk < H && c < Cout) v = wfl[(long)c * H + kk];
-    } else if (which == 5) {
-      const int kk = (int)(idx / H16), j = (int)(idx % H16);
-      if (kk < Cout && j < H) v = wfl[(long)kk * H + j];
-    } else if (which == 6) {
-      const int j = (int)(idx % H16), kk = (int)((idx / H16) % H4), g = (int)(idx / ((long)H16 * H4));
-      if (kk < H && j < H) v = whh[((long)g * H + kk) * H + j];
-    } else {
-      const int c = (int)(idx % Ch16), kk = (int)((idx / Ch16) % H4), g = (int)(idx / ((long)Ch16 * H4));
-      if (kk < H && c < Ch) v = wih[((long)g * H + kk) * I + c];
+    switch (which) {
+      case 0: if (kk < C && col < C) v = W[kk * C + col]; break;
+      case 1: if (kk < C && col < C) v = W[col * C + kk]; break;
+      case 2: { const int gg = col / H16, j = col - gg * H16; if (kk < Ch && j < H) v = wih[((long)gg * H + j) * I + kk]; } break;
+      case 3: { const int gg = col / H16, j = col - gg * H16; if (kk < H && j < H) v = whh[((long)gg * H + j) * H + kk]; } break;
+      case 4: if (kk < H && col < Cout) v = wfl[(long)col * H + kk]; break;
+      case 5: if (kk < Cout && col < H) v = wfl[(long)kk * H + col]; break;
+      case 6: if (kk < H && col < H) v = whh[((long)g * H + kk) * H + col]; break;
+      default: if (kk < H && col < Ch) v = wih[((long)g * H + kk) * I + col]; break;
     }
-    dst[idx] = v;
+    dst[g * per + flow_img_index(kk, col, J)] = v;
   }
 }
 
@@ -1490,16 +1540,16 @@ long prep_scratch_end(const lfi_flow_dims* d) {
   long n = 3 * cc + (long)d->Ks * Ch * G + (long)d->Ks * d->H * G + (long)d->Ks * d->H * Cout + (long)d->Ks * G * d->D + 4;
   n += d->Ks + 4;
   n += 2 * ((long)d->Ks * 2 * d->C * d->C + (long)d->Ks * d->C) + 8;  // doubles, counted as 2 floats each
-  return (n + 3) & ~3L;
+  return (n + 3) & ~3L;  // 16-byte aligned: the images behind it are read with dwordx4 loads
 }
 long prep_padded_floats(const lfi_flow_dims* d) {
   const int Ch = d->C / 2, C2 = d->C - Ch, Cout = d->affine ? 2 * C2 : C2, NG = d->lstm ? 4 : 3;
-  auto r4 = [](int x) { return (long)((x + 3) & ~3); };
   auto r16 = [](int x) { return (long)((x + 15) & ~15); };
-  const long C4 = r4(d->C), C16 = r16(d->C), Ch4 = Ch ? r4(Ch) : 4, Ch16 = Ch ? r16(Ch) : 16, H4 = r4(d->H), H16 = r16(d->H),
-             Co4 = r4(Cout), Co16 = r16(Cout);
-  return d->Ks * (2 * C4 * C16 + Ch4 * NG * H16 + H4 * NG * H16 + H4 * Co16 + Co4 * H16 + NG * H4 * H16 + NG * H4 * Ch16);
+  const long C16 = r16(d->C), Ch16 = Ch ? r16(Ch) : 16, H16 = r16(d->H), Co16 = r16(Cout);
+  return d->Ks * (2 * C16 * C16 + Ch16 * NG * H16 + H16 * NG * H16 + 2 * H16 * Co16 + NG * H16 * H16 + NG * H16 * Ch16);
 }
+
+unsigned long long* g_flow_stamps = nullptr;  // diagnostics only
 
 int fill_flow(const lfi_flow_dims* d, const lfi_flow_params* p, const float* prep, FlowK* f, const char* who) {
   LFI_REQUIRE(d && p, "%s: null dims/params", who);
@@ -1509,10 +1559,9 @@ int fill_flow(const lfi_flow_dims* d, const lfi_flow_params* p, const float* pre
   f->Ch = d->C / 2; f->C2 = d->C - f->Ch; f->Cout = d->affine ? 2 * f->C2 : f->C2;
   f->G = (d->lstm ? 4 : 3) * d->H; f->I = f->Ch + d->D; f->F = d->N * d->B; f->nbt = lfi_cdiv(d->B, MB);
   f->p = *p;
+  f->stamps = g_flow_stamps;
   f->NG = d->lstm ? 4 : 3;
-  f->C4 = (f->C + 3) & ~3; f->C16 = (f->C + 15) & ~15; f->Ch4 = (f->Ch + 3) & ~3; f->Ch16 = (f->Ch + 15) & ~15;
-  f->H4 = (f->H + 3) & ~3; f->H16 = (f->H + 15) & ~15; f->Co4 = (f->Cout + 3) & ~3; f->Co16 = (f->Cout + 15) & ~15;
-  if (f->Ch4 == 0) f->Ch4 = 4;
+  f->C16 = (f->C + 15) & ~15; f->Ch16 = (f->Ch + 15) & ~15; f->H16 = (f->H + 15) & ~15; f->Co16 = (f->Cout + 15) & ~15;
   if (f->Ch16 == 0) f->Ch16 = 16;
   if (prep) {
     const long cc = (long)d->Ks * d->C * d->C;
@@ -1528,14 +1577,14 @@ int fill_flow(const lfi_flow_dims* d, const lfi_flow_params* p, const float* pre
     // scratch (log-det parts, fp64 inverse workspace), then the zero-padded images of the register-resident cells
     q = prep + prep_scratch_end(d);
     const long Ks = d->Ks;
-    f->pW = q; q += Ks * f->C4 * f->C16;
-    f->pWt = q; q += Ks * f->C4 * f->C16;
-    f->pwz = q; q += Ks * f->Ch4 * f->NG * f->H16;
-    f->pwh = q; q += Ks * f->H4 * f->NG * f->H16;
-    f->pwfl = q; q += Ks * f->H4 * f->Co16;
-    f->bwfl = q; q += Ks * f->Co4 * f->H16;
-    f->bwh = q; q += Ks * f->NG * f->H4 * f->H16;
-    f->bwz = q; q += Ks * f->NG * f->H4 * f->Ch16;
+    f->pW = q; q += Ks * f->C16 * f->C16;
+    f->pWt = q; q += Ks * f->C16 * f->C16;
+    f->pwz = q; q += Ks * f->Ch16 * f->NG * f->H16;
+    f->pwh = q; q += Ks * f->H16 * f->NG * f->H16;
+    f->pwfl = q; q += Ks * f->H16 * f->Co16;
+    f->bwfl = q; q += Ks * f->Co16 * f->H16;
+    f->bwh = q; q += Ks * f->NG * f->H16 * f->H16;
+    f->bwz = q; q += Ks * f->NG * f->H16 * f->Ch16;
   }
   return LFI_OK;
 }
@@ -1605,6 +1654,13 @@ int set_flow_lds(Kf kernel, size_t bytes, const char* who) {
 }  // namespace
 
 // =================================================================================================== C ABI
+// Diagnostics: device buffer of >= 16 * Ks 64-bit slots that the register-resident forward cells stamp with s_memtime at
+// their phase boundaries (workgroup column 0 only); NULL switches it off. Process-global, not for production use.
+extern "C" int lfi_debug_set_stamps(void* device_buffer) {
+  g_flow_stamps = (unsigned long long*)device_buffer;
+  return LFI_OK;
+}
+
 extern "C" long lfi_flow_prep_floats(const lfi_flow_dims* d) {
   if (!d) return 0;
   const int Ch = d->C / 2, C2 = d->C - Ch, Cout = d->affine ? 2 * C2 : C2, G = (d->lstm ? 4 : 3) * d->H;
@@ -1687,7 +1743,7 @@ extern "C" int lfi_flow_seq_fwd(const lfi_flow_dims* d, const lfi_flow_params* p
   hipStream_t st = (hipStream_t)stream;
   const bool fast = flow_fast_ok(f.C, f.H, f.Cout) && !flow_force_generic();
   const Carve cv = carve_fwd(f.C, f.H, f.Ch, f.C2, f.Cout);
-  const CarveF cf = carve_fast_fwd(f.C, f.C4, f.H4, f.Ch4, f.Cout);
+  const CarveF cf = carve_fast_fwd(f.C, f.C16, f.H16, f.Ch16, f.Cout);
   const size_t lds = (size_t)(fast ? cf.total : cv.total) * sizeof(float);
   rc = fast ? (f.lstm ? set_flow_lds(flow_diag_fwd_fast_kernel<4>, lds, "lfi_flow_seq_fwd")
                       : set_flow_lds(flow_diag_fwd_fast_kernel<3>, lds, "lfi_flow_seq_fwd"))
@@ -1719,7 +1775,7 @@ extern "C" int lfi_flow_seq_bwd(const lfi_flow_dims* d, const lfi_flow_params* p
   hipStream_t st = (hipStream_t)stream;
   const bool fast = flow_fast_ok(f.C, f.H, f.Cout) && !flow_force_generic();
   const CarveB cv = carve_bwd(f.C, f.H, f.Cout, f.G);
-  const CarveFB cf = carve_fast_bwd(f.C4, f.H4, f.Co4, f.Cout, f.NG);
+  const CarveFB cf = carve_fast_bwd(f.C16, f.H16, f.Co16, f.Cout, f.NG);
   const size_t lds = (size_t)(fast ? cf.total : cv.total) * sizeof(float);
   rc = fast ? (f.lstm ? set_flow_lds(flow_diag_bwd_fast_kernel<4>, lds, "lfi_flow_seq_bwd")
                       : set_flow_lds(flow_diag_bwd_fast_kernel<3>, lds, "lfi_flow_seq_bwd"))
