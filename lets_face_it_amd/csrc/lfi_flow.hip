@@ -38,7 +38,7 @@ struct FlowK {
   // prep
   const float *W, *Wt, *Winv, *wz_t, *whh_t, *wfl_t, *wc, *ldconst;
   // prep, zero-padded images for the register-resident cell kernels (k rows padded to 4, columns to 16)
-  const float *pW, *pWt, *pwz, *pwh, *pwfl, *bwfl, *bwh, *bwz;
+  const float *pW, *pWt, *pwz, *pwh, *pwfl, *bwfl, *bwh, *bwz, *pWinv;
   int C16, Ch16, H16, Co16, NG;
   // forward stash
   float *sA, *sY, *sX, *sH, *sG, *sO, *sL, *sC;   // sC: LSTM cell state (lstm only)
@@ -732,6 +732,106 @@ __device__ __forceinline__ void load_frag(f32x4 (&w)[MAXB], const float* __restr
     if (on && b < nb) w[b] = p[(long)b * 4 * J];
 }
 
+// P2 of a register-resident cell: the coupling net's recurrent cell on this wave's 16 hidden units. Zt / Ht: z1 and
+// h_prev in LDS (k-major), Hn: new state (LDS), h_out / c_out / g_out: row-0 pointers of the (rows x H) / (rows x 4H) outputs
+// (g_out may be null).
+template <int NG>
+__device__ __forceinline__ void fast_cell_p2(const FlowK& f, const float* Zt, const float* Ht, float* Hn,
+                                             const f32x4 (&wz)[NG][FB_Z], const f32x4 (&wh)[NG][FB_H], const float (&gc)[4][NG],
+                                             const float (&bh)[NG], const float (&cprev)[4], int nbZ, int nbH, int j2, int kq,
+                                             int l15, int b0, int rows, float* h_out, float* c_out, float* g_out) {
+  const int H = f.H;
+  f32x4 az[NG], ah[NG];
+#pragma unroll
+  for (int g = 0; g < NG; ++g) {
+    az[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    ah[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+  const float* zl = Zt + kq * LT + l15;
+  const float* hl = Ht + kq * LT + l15;
+#pragma unroll
+  for (int b = 0; b < FB_Z; ++b)
+    if (b < nbZ) {
+      const float* ab = zl + b * 16 * LT;
+      const float a0 = ab[0], a1 = ab[4 * LT], a2 = ab[8 * LT], a3 = ab[12 * LT];
+#pragma unroll
+      for (int g = 0; g < NG; ++g) az[g] = mfma16(a0, wz[g][b][0], az[g]);
+#pragma unroll
+      for (int g = 0; g < NG; ++g) az[g] = mfma16(a1, wz[g][b][1], az[g]);
+#pragma unroll
+      for (int g = 0; g < NG; ++g) az[g] = mfma16(a2, wz[g][b][2], az[g]);
+#pragma unroll
+      for (int g = 0; g < NG; ++g) az[g] = mfma16(a3, wz[g][b][3], az[g]);
+    }
+#pragma unroll
+  for (int b = 0; b < FB_H; ++b)
+    if (b < nbH) {
+      const float* ab = hl + b * 16 * LT;
+      const float a0 = ab[0], a1 = ab[4 * LT], a2 = ab[8 * LT], a3 = ab[12 * LT];
+#pragma unroll
+      for (int g = 0; g < NG; ++g) ah[g] = mfma16(a0, wh[g][b][0], ah[g]);
+#pragma unroll
+      for (int g = 0; g < NG; ++g) ah[g] = mfma16(a1, wh[g][b][1], ah[g]);
+#pragma unroll
+      for (int g = 0; g < NG; ++g) ah[g] = mfma16(a2, wh[g][b][2], ah[g]);
+#pragma unroll
+      for (int g = 0; g < NG; ++g) ah[g] = mfma16(a3, wh[g][b][3], ah[g]);
+    }
+  if (j2 < H) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = kq * 4 + r;
+      const int row = b0 + i;
+      float hnew;
+      float gs0, gs1, gs2, gs3;
+      if (NG == 3) {  // torch.nn.GRUCell, gate order r, z, n
+        const float rr = sigmoidf_(az[0][r] + ah[0][r] + gc[r][0] + bh[0]);
+        const float uu = sigmoidf_(az[1][r] + ah[1][r] + gc[r][1] + bh[1]);
+        const float ghn = ah[2][r] + bh[2];
+        const float nn = tanhf_(az[2][r] + gc[r][2] + rr * ghn);
+        const float hp = Ht[j2 * LT + i];
+        hnew = (1.0f - uu) * nn + uu * hp;
+        gs0 = rr; gs1 = uu; gs2 = nn; gs3 = ghn;
+      } else {        // torch.nn.LSTMCell, gate order i, f, g, o; zero (h, c) at the first modelled frame
+        const float ii = sigmoidf_(az[0][r] + ah[0][r] + gc[r][0] + bh[0]);
+        const float ff = sigmoidf_(az[1][r] + ah[1][r] + gc[r][1] + bh[1]);
+        const float gg = tanhf_(az[2][r] + ah[2][r] + gc[r][2] + bh[2]);
+        const float oo = sigmoidf_(az[NG - 1][r] + ah[NG - 1][r] + gc[r][NG - 1] + bh[NG - 1]);
+        const float c2 = ff * cprev[r] + ii * gg;
+        hnew = oo * tanhf_(c2);
+        if (row < rows) c_out[(long)row * H + j2] = c2;
+        gs0 = ii; gs1 = ff; gs2 = gg; gs3 = oo;
+      }
+      Hn[j2 * LT + i] = hnew;
+      if (row < rows) {
+        h_out[(long)row * H + j2] = hnew;
+        if (g_out) {
+          float* gs = g_out + (long)row * 4 * H + j2;
+          gs[0] = gs0; gs[H] = gs1; gs[2 * H] = gs2; gs[3 * H] = gs3;
+        }
+      }
+    }
+  }
+}
+
+// P3: o = (h' Wfl^T + b) exp(3 logs) on this wave's 16 outputs   (LinearZeros, glow/modules.py:93-95); o_out may be null
+__device__ __forceinline__ void fast_cell_p3(const FlowK& f, int k, const float* Hn, float* Orm, const f32x4 (&w3)[FB_H], int nbH,
+                                             int col, int kq, int l15, int b0, int rows, float* o_out) {
+  const int Cout = f.Cout, ldo = Cout + 1;
+  const f32x4 acc = mma16_reg<FB_H>(Hn + kq * LT + l15, w3, nbH);
+  if (col < Cout) {
+    const float bb = f.p.b_fl[(long)k * Cout + col], sc = expf(3.0f * f.p.l_fl[(long)k * Cout + col]);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = kq * 4 + r;
+      const int row = b0 + i;
+      const float o = (acc[r] + bb) * sc;
+      Orm[i * ldo + col] = o;
+      if (o_out && row < rows) o_out[(long)row * Cout + col] = o;
+    }
+  }
+}
+
 template <int NG>
 __global__ __launch_bounds__(NT) void flow_diag_fwd_fast_kernel(FlowK f, int d, int klo) {
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -834,96 +934,13 @@ __global__ __launch_bounds__(NT) void flow_diag_fwd_fast_kernel(FlowK f, int d, 
   LFI_STAMP(3);
 
   // ---- P2: recurrent cell of the coupling net (f_seq.forward, glow/models.py:204-214)
-  if (t2) {
-    f32x4 az[NG], ah[NG];
-#pragma unroll
-    for (int g = 0; g < NG; ++g) {
-      az[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      ah[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    }
-    const float* zl = Zt + kq * LT + l15;
-    const float* hl = Ht + kq * LT + l15;
-#pragma unroll
-    for (int b = 0; b < FB_Z; ++b)
-      if (b < nbZ) {
-        const float* ab = zl + b * 16 * LT;
-        const float a0 = ab[0], a1 = ab[4 * LT], a2 = ab[8 * LT], a3 = ab[12 * LT];
-#pragma unroll
-        for (int g = 0; g < NG; ++g) az[g] = mfma16(a0, wz[g][b][0], az[g]);
-#pragma unroll
-        for (int g = 0; g < NG; ++g) az[g] = mfma16(a1, wz[g][b][1], az[g]);
-#pragma unroll
-        for (int g = 0; g < NG; ++g) az[g] = mfma16(a2, wz[g][b][2], az[g]);
-#pragma unroll
-        for (int g = 0; g < NG; ++g) az[g] = mfma16(a3, wz[g][b][3], az[g]);
-      }
-#pragma unroll
-    for (int b = 0; b < FB_H; ++b)
-      if (b < nbH) {
-        const float* ab = hl + b * 16 * LT;
-        const float a0 = ab[0], a1 = ab[4 * LT], a2 = ab[8 * LT], a3 = ab[12 * LT];
-#pragma unroll
-        for (int g = 0; g < NG; ++g) ah[g] = mfma16(a0, wh[g][b][0], ah[g]);
-#pragma unroll
-        for (int g = 0; g < NG; ++g) ah[g] = mfma16(a1, wh[g][b][1], ah[g]);
-#pragma unroll
-        for (int g = 0; g < NG; ++g) ah[g] = mfma16(a2, wh[g][b][2], ah[g]);
-#pragma unroll
-        for (int g = 0; g < NG; ++g) ah[g] = mfma16(a3, wh[g][b][3], ah[g]);
-      }
-    if (j2ok) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int i = kq * 4 + r;
-        const int row = b0 + i;
-        float hnew;
-        float gs0, gs1, gs2, gs3;
-        if (NG == 3) {  // torch.nn.GRUCell, gate order r, z, n
-          const float rr = sigmoidf_(az[0][r] + ah[0][r] + gc[r][0] + bh[0]);
-          const float uu = sigmoidf_(az[1][r] + ah[1][r] + gc[r][1] + bh[1]);
-          const float ghn = ah[2][r] + bh[2];
-          const float nn = tanhf_(az[2][r] + gc[r][2] + rr * ghn);
-          const float hp = Ht[j2 * LT + i];
-          hnew = (1.0f - uu) * nn + uu * hp;
-          gs0 = rr; gs1 = uu; gs2 = nn; gs3 = ghn;
-        } else {        // torch.nn.LSTMCell, gate order i, f, g, o; zero (h, c) at the first modelled frame
-          const float ii = sigmoidf_(az[0][r] + ah[0][r] + gc[r][0] + bh[0]);
-          const float ff = sigmoidf_(az[1][r] + ah[1][r] + gc[r][1] + bh[1]);
-          const float gg = tanhf_(az[2][r] + ah[2][r] + gc[r][2] + bh[2]);
-          const float oo = sigmoidf_(az[NG - 1][r] + ah[NG - 1][r] + gc[r][NG - 1] + bh[NG - 1]);
-          const float c2 = ff * cprev[r] + ii * gg;
-          hnew = oo * tanhf_(c2);
-          if (row < B) f.sC[(kf + row) * H + j2] = c2;
-          gs0 = ii; gs1 = ff; gs2 = gg; gs3 = oo;
-        }
-        Hn[j2 * LT + i] = hnew;
-        if (row < B) {
-          f.sH[(kf + row) * H + j2] = hnew;
-          float* gs = f.sG + (kf + row) * 4 * H + j2;
-          gs[0] = gs0; gs[H] = gs1; gs[2 * H] = gs2; gs[3 * H] = gs3;
-        }
-      }
-    }
-  }
+  if (t2) fast_cell_p2<NG>(f, Zt, Ht, Hn, wz, wh, gc, bh, cprev, nbZ, nbH, tcol, kq, l15, b0, B,
+                           f.sH + kf * H, NG == 4 ? f.sC + kf * H : nullptr, f.sG + kf * 4 * H);
   __syncthreads();
   LFI_STAMP(4);
 
   // ---- P3: o = (h' Wfl^T + b) exp(3 logs)   (LinearZeros, glow/modules.py:93-95)
-  if (t3) {
-    const f32x4 acc = mma16_reg<FB_H>(Hn + kq * LT + l15, w3, nbH);
-    const int col = tcol;
-    if (col < Cout) {
-      const float bb = f.p.b_fl[(long)k * Cout + col], sc = expf(3.0f * f.p.l_fl[(long)k * Cout + col]);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int i = kq * 4 + r;
-        const int row = b0 + i;
-        const float o = (acc[r] + bb) * sc;
-        Orm[i * ldo + col] = o;
-        if (row < B) f.sO[(kf + row) * Cout + col] = o;
-      }
-    }
-  }
+  if (t3) fast_cell_p3(f, k, Hn, Orm, w3, nbH, tcol, kq, l15, b0, B, f.sO + kf * Cout);
   __syncthreads();
   LFI_STAMP(5);
 
@@ -952,6 +969,114 @@ __global__ __launch_bounds__(NT) void flow_diag_fwd_fast_kernel(FlowK f, int d, 
     if (cl == 0 && rok) f.sL[kf + row] = lg;
   }
   LFI_STAMP(6);
+}
+
+// FlowStep.reverse_flow (glow/models.py:345-373) with explicit state, register-resident weights: the sampler's and
+// SeqGlow.invert's cell. coupling^-1 -> invconv^-1 (W^-1 image) -> actnorm^-1.
+template <int NG>
+__global__ __launch_bounds__(NT) void flow_step_rev_fast_kernel(FlowK f, CellIO io) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, kq = lane >> 4;
+  const int ri = tid >> 5, cl = tid & 31;
+  const int k = io.k, rows = io.rows;
+  const int b0 = blockIdx.x * MB;
+  const int C = f.C, H = f.H, Ch = f.Ch, C2 = f.C2, Cout = f.Cout, G = f.G;
+  const int C16 = f.C16, Ch16 = f.Ch16, H16 = f.H16, Co16 = f.Co16;
+  const CarveF cv = carve_fast_fwd(C, C16, H16, Ch16, Cout);
+  float* Yt = flow_smem + cv.At;   // y = [z1 | z2] k-major for the W^-1 product
+  float* Ht = flow_smem + cv.Ht;
+  float* Zt = flow_smem + cv.Zt;
+  float* Hn = flow_smem + cv.Hn;
+  float* Yrm = flow_smem + cv.Yrm;
+  float* Orm = flow_smem + cv.Orm;
+  const int ldy = C + 1, ldo = Cout + 1;
+  const int nbC = C16 >> 4, nbZ = Ch16 >> 4, nbH = H16 >> 4;
+  const bool t1 = wave * 16 < C, t2 = wave * 16 < H, t3 = wave * 16 < Cout;
+  const int tcol = wave * 16 + l15;
+  f32x4 wz[NG][FB_Z], wh[NG][FB_H], w3[FB_H];
+#pragma unroll
+  for (int g = 0; g < NG; ++g) {
+    load_frag<FB_Z>(wz[g], f.pwz + (long)k * Ch16 * NG * H16, NG * H16, g * H16 + tcol, kq, nbZ, t2);
+    load_frag<FB_H>(wh[g], f.pwh + (long)k * H16 * NG * H16, NG * H16, g * H16 + tcol, kq, nbH, t2);
+  }
+  load_frag<FB_H>(w3, f.pwfl + (long)k * H16 * Co16, Co16, tcol, kq, nbH, t3);
+  float gc[4][NG], bh[NG], cprev[4];
+  {
+    const float* bhh = f.p.b_hh + (long)k * G;
+    const int jc = tcol < H ? tcol : 0;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) bh[g] = bhh[g * H + jc];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = min(b0 + kq * 4 + r, rows - 1);
+#pragma unroll
+      for (int g = 0; g < NG; ++g) gc[r][g] = io.gic[(long)row * G + g * H + jc];
+      cprev[r] = (NG == 4 && io.c_prev) ? io.c_prev[(long)row * H + jc] : 0.0f;
+    }
+  }
+  // ---- R0: stage [z1 | z2'] and h_prev
+  {
+    const int row = b0 + ri;
+    const bool rok = row < rows;
+    for (int c = cl; c < C16; c += 32) {
+      const float v = (c < C && rok) ? io.x_in[(long)row * io.ldx + c] : 0.0f;
+      if (c < C) Yrm[ri * ldy + c] = v;
+      if (c < Ch) Zt[c * LT + ri] = v;
+      if (c < Ch || c >= C) Yt[c * LT + ri] = v;   // z1 rows and the zero k padding; z2 rows come from R3
+    }
+    for (int j = cl; j < H16; j += 32) {
+      Ht[j * LT + ri] = (io.h_prev && rok && j < H) ? io.h_prev[(long)row * H + j] : 0.0f;
+      if (j >= H) Hn[j * LT + ri] = 0.0f;
+    }
+    for (int c = Ch + cl; c < Ch16; c += 32) Zt[c * LT + ri] = 0.0f;
+  }
+  // W^-1 slice of this wave's 16 output channels: in flight under the coupling net
+  f32x4 w1[FB_C];
+  load_frag<FB_C>(w1, f.pWinv + (long)k * C16 * C16, C16, tcol, kq, nbC, t1);
+  __syncthreads();
+  if (t2) fast_cell_p2<NG>(f, Zt, Ht, Hn, wz, wh, gc, bh, cprev, nbZ, nbH, tcol, kq, l15, b0, rows, io.h_out, io.c_out, nullptr);
+  __syncthreads();
+  if (t3) fast_cell_p3(f, k, Hn, Orm, w3, nbH, tcol, kq, l15, b0, rows, nullptr);
+  __syncthreads();
+  // ---- R3: coupling inverse (glow/models.py:356-365)
+  {
+    const int row = b0 + ri;
+    float lg = 0.0f;
+    if (cl < C2) {
+      const float z2n = Yrm[ri * ldy + Ch + cl];
+      float z2;
+      if (f.affine) {
+        const float shift = Orm[ri * ldo + 2 * cl];
+        const float sraw = sigmoidf_(Orm[ri * ldo + 2 * cl + 1] + 2.0f);
+        const float sc = fmaxf(sraw, f.eps);
+        z2 = z2n / sc;
+        z2 = z2 - shift;
+        lg = -logf(sc);
+      } else {
+        z2 = z2n - Orm[ri * ldo + cl];
+      }
+      Yt[(Ch + cl) * LT + ri] = z2;
+    }
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) lg += __shfl_xor(lg, o, 64);
+    if (cl == 0 && row < rows && io.l_out) {
+      if (io.l_accumulate) io.l_out[row] += lg; else io.l_out[row] = lg;
+    }
+  }
+  __syncthreads();
+  // ---- R4: x = (y W^-1) exp(-logs) - bias   (scale then center, glow/modules.py:76-79)
+  if (t1) {
+    const f32x4 acc = mma16_reg<FB_C>(Yt + kq * LT + l15, w1, nbC);
+    const int c = tcol;
+    if (c < C) {
+      const float es = expf(-f.p.an_logs[(long)k * C + c]), bb = f.p.an_bias[(long)k * C + c];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = b0 + kq * 4 + r;
+        if (row < rows) io.x_out[(long)row * io.ldxo + c] = acc[r] * es - bb;
+      }
+    }
+  }
 }
 
 struct CarveFB {
@@ -1234,7 +1359,7 @@ __global__ __launch_bounds__(NT) void flow_diag_bwd_fast_kernel(FlowK f, int d, 
 // 3 pwh (k = hidden in), 4 pwfl (k = hidden, col = output), 5 bwfl (k = output, col = hidden),
 // 6 bwh [g] (k = hidden of gate g, col = hidden), 7 bwz [g] (k = hidden of gate g, col = z channel)
 __global__ __launch_bounds__(256) void flow_prep_pad_kernel(FlowK f, float* pW, float* pWt, float* pwz, float* pwh, float* pwfl,
-                                                            float* bwfl, float* bwh, float* bwz) {
+                                                            float* bwfl, float* bwh, float* bwz, float* pWinv) {
   const int k = blockIdx.y, which = blockIdx.z;
   const int C = f.C, H = f.H, Ch = f.Ch, Cout = f.Cout, I = f.I, NG = f.NG;
   const int C16 = f.C16, Ch16 = f.Ch16, H16 = f.H16, Co16 = f.Co16;
@@ -1252,8 +1377,10 @@ __global__ __launch_bounds__(256) void flow_prep_pad_kernel(FlowK f, float* pW, 
     case 4: K = H16; J = Co16; dst = pwfl; break;
     case 5: K = Co16; J = H16; dst = bwfl; break;
     case 6: K = H16; J = H16; nimg = NG; dst = bwh; break;
-    default: K = H16; J = Ch16; nimg = NG; dst = bwz; break;
+    case 7: K = H16; J = Ch16; nimg = NG; dst = bwz; break;
+    default: K = C16; J = C16; dst = pWinv; break;   // 8: reverse weight (only when lfi_flow_prep built it)
   }
+  if (which == 8 && !pWinv) return;
   const long per = (long)K * J;
   dst += (long)k * nimg * per;
   for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < nimg * per; idx += (long)gridDim.x * 256) {
@@ -1269,7 +1396,8 @@ __global__ __launch_bounds__(256) void flow_prep_pad_kernel(FlowK f, float* pW, 
       case 4: if (kk < H && col < Cout) v = wfl[(long)col * H + kk]; break;
       case 5: if (kk < Cout && col < H) v = wfl[(long)kk * H + col]; break;
       case 6: if (kk < H && col < H) v = whh[((long)g * H + kk) * H + col]; break;
-      default: if (kk < H && col < Ch) v = wih[((long)g * H + kk) * I + col]; break;
+      case 7: if (kk < H && col < Ch) v = wih[((long)g * H + kk) * I + col]; break;
+      default: if (kk < C && col < C) v = f.Winv[(long)k * C * C + kk * C + col]; break;
     }
     dst[g * per + flow_img_index(kk, col, J)] = v;
   }
@@ -1546,7 +1674,7 @@ long prep_padded_floats(const lfi_flow_dims* d) {
   const int Ch = d->C / 2, C2 = d->C - Ch, Cout = d->affine ? 2 * C2 : C2, NG = d->lstm ? 4 : 3;
   auto r16 = [](int x) { return (long)((x + 15) & ~15); };
   const long C16 = r16(d->C), Ch16 = Ch ? r16(Ch) : 16, H16 = r16(d->H), Co16 = r16(Cout);
-  return d->Ks * (2 * C16 * C16 + Ch16 * NG * H16 + H16 * NG * H16 + 2 * H16 * Co16 + NG * H16 * H16 + NG * H16 * Ch16);
+  return d->Ks * (3 * C16 * C16 + Ch16 * NG * H16 + H16 * NG * H16 + 2 * H16 * Co16 + NG * H16 * H16 + NG * H16 * Ch16);
 }
 
 unsigned long long* g_flow_stamps = nullptr;  // diagnostics only
@@ -1585,6 +1713,7 @@ int fill_flow(const lfi_flow_dims* d, const lfi_flow_params* p, const float* pre
     f->bwfl = q; q += Ks * f->Co16 * f->H16;
     f->bwh = q; q += Ks * f->NG * f->H16 * f->H16;
     f->bwz = q; q += Ks * f->NG * f->H16 * f->Ch16;
+    f->pWinv = q; q += Ks * f->C16 * f->C16;
   }
   return LFI_OK;
 }
@@ -1693,8 +1822,9 @@ extern "C" int lfi_flow_prep(const lfi_flow_dims* d, const lfi_flow_params* p, f
                      (float*)f.wfl_t, (float*)f.wc, ldpart, ldconst);
   LFI_LAUNCH_CHECK("lfi_flow_prep transpose");
   if (flow_fast_ok(f.C, f.H, f.Cout)) {
-    hipLaunchKernelGGL(flow_prep_pad_kernel, dim3(8, d->Ks, 8), dim3(256), 0, st, f, (float*)f.pW, (float*)f.pWt, (float*)f.pwz,
-                       (float*)f.pwh, (float*)f.pwfl, (float*)f.bwfl, (float*)f.bwh, (float*)f.bwz);
+    hipLaunchKernelGGL(flow_prep_pad_kernel, dim3(8, d->Ks, 9), dim3(256), 0, st, f, (float*)f.pW, (float*)f.pWt, (float*)f.pwz,
+                       (float*)f.pwh, (float*)f.pwfl, (float*)f.bwfl, (float*)f.bwh, (float*)f.bwz,
+                       (with_inverse || p->inv_w) ? (float*)f.pWinv : nullptr);
     LFI_LAUNCH_CHECK("lfi_flow_prep pad");
   }
   return LFI_OK;
@@ -1901,7 +2031,16 @@ extern "C" int lfi_flow_step(const lfi_flow_dims* d, const lfi_flow_params* p, c
   io.c_prev = d->lstm ? c_prev : nullptr; io.c_out = d->lstm ? c_out : nullptr;
   io.x_out = x_out; io.ldxo = ldxo; io.h_out = h_out; io.l_out = ldc_acc; io.l_accumulate = 1;
   const Carve cv = carve_fwd(f.C, f.H, f.Ch, f.C2, f.Cout);
-  const size_t lds = (size_t)cv.total * sizeof(float);
+  size_t lds = (size_t)cv.total * sizeof(float);
+  if (reverse && flow_fast_ok(f.C, f.H, f.Cout) && !flow_force_generic()) {
+    lds = (size_t)carve_fast_fwd(f.C, f.C16, f.H16, f.Ch16, f.Cout).total * sizeof(float);
+    rc = f.lstm ? set_flow_lds(flow_step_rev_fast_kernel<4>, lds, "lfi_flow_step") : set_flow_lds(flow_step_rev_fast_kernel<3>, lds, "lfi_flow_step");
+    if (rc) return rc;
+    if (f.lstm) hipLaunchKernelGGL(flow_step_rev_fast_kernel<4>, dim3(lfi_cdiv(rows, MB)), dim3(NT), lds, (hipStream_t)stream, f, io);
+    else hipLaunchKernelGGL(flow_step_rev_fast_kernel<3>, dim3(lfi_cdiv(rows, MB)), dim3(NT), lds, (hipStream_t)stream, f, io);
+    LFI_LAUNCH_CHECK("lfi_flow_step");
+    return LFI_OK;
+  }
   rc = reverse ? set_flow_lds(flow_step_kernel<true>, lds, "lfi_flow_step")
                : set_flow_lds(flow_step_kernel<false>, lds, "lfi_flow_step");
   if (rc) return rc;
@@ -1936,9 +2075,12 @@ extern "C" int lfi_flow_sample_seq(const lfi_flow_dims* d, const lfi_flow_params
   float* xa = gic + (long)Ks * B * G;          // B x C ping
   float* xb = xa + (long)B * C;                // B x C pong
   hipStream_t st = (hipStream_t)stream;
+  const bool fast = flow_fast_ok(f.C, f.H, f.Cout) && !flow_force_generic();
   const Carve cv = carve_fwd(f.C, f.H, f.Ch, f.C2, f.Cout);
-  const size_t lds = (size_t)cv.total * sizeof(float);
-  rc = set_flow_lds(flow_step_kernel<true>, lds, "lfi_flow_sample_seq");
+  const size_t lds = (size_t)(fast ? carve_fast_fwd(f.C, f.C16, f.H16, f.Ch16, f.Cout).total : cv.total) * sizeof(float);
+  rc = !fast ? set_flow_lds(flow_step_kernel<true>, lds, "lfi_flow_sample_seq")
+             : (f.lstm ? set_flow_lds(flow_step_rev_fast_kernel<4>, lds, "lfi_flow_sample_seq")
+                       : set_flow_lds(flow_step_rev_fast_kernel<3>, lds, "lfi_flow_sample_seq"));
   if (rc) return rc;
   for (int n = 0; n < nframes; ++n) {
     const int t = start + n;
@@ -1975,7 +2117,9 @@ extern "C" int lfi_flow_sample_seq(const lfi_flow_dims* d, const lfi_flow_params
       if (f.lstm) { io.c_prev = n > 0 ? cstate + (long)k * B * H : nullptr; io.c_out = cstate + (long)k * B * H; }
       if (k == 0) { io.x_out = faces + (long)t * C; io.ldxo = (long)seq_len * C; }
       else { io.x_out = (k & 1) ? xa : xb; io.ldxo = C; }
-      hipLaunchKernelGGL(flow_step_kernel<true>, dim3(f.nbt), dim3(NT), lds, st, f, io);
+      if (!fast) hipLaunchKernelGGL(flow_step_kernel<true>, dim3(f.nbt), dim3(NT), lds, st, f, io);
+      else if (f.lstm) hipLaunchKernelGGL(flow_step_rev_fast_kernel<4>, dim3(f.nbt), dim3(NT), lds, st, f, io);
+      else hipLaunchKernelGGL(flow_step_rev_fast_kernel<3>, dim3(f.nbt), dim3(NT), lds, st, f, io);
       xin = io.x_out; ldx = io.ldxo;
     }
   }

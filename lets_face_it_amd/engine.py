@@ -15,6 +15,7 @@ What the reference does instead: SeqGlow.forward's Python loop over timesteps an
 """
 import ctypes as C
 import math
+import os
 
 import torch
 
@@ -164,6 +165,8 @@ class GlowEngine:
         self.unfold = torch.tensor(spec.unfold, **i32)
         self.wct_f = torch.zeros(spec.Ks * spec.D, spec.ldf, **f32)  # folded cond_transform weights, rebuilt by run_prep
         self._ws = {}
+        self._sample_graphs = {}
+        self._sample_seen = {}
         self.prep = None
         self._last = None
         self.timers = None  # {tag: [(start_event, end_event), ...]} when kernel timing is switched on (bench.py)
@@ -513,7 +516,8 @@ class GlowEngine:
             raise ValueError("noise must be a contiguous float32 (%d, %d, %d) tensor" % (nframes, B, s.C))
         F = nframes * B
         KD = s.Ks * s.D
-        faces = torch.zeros(B, seq_len, s.C, dtype=torch.float32, device=self.device)
+        faces = self._buf("sample_faces", B * seq_len * s.C)[:B * seq_len * s.C].view(B, seq_len, s.C)
+        faces.zero_()
         faces[:, :s.start].copy_(seed[:, :s.start])
         self.run_prep(with_inverse=True)
         # everything of the features that does not depend on generated frames, through cond_transform (no activation yet)
@@ -530,12 +534,33 @@ class GlowEngine:
         h = self._buf("sample_h", s.Ks * B * s.H, zero=True)
         cs = self._buf("sample_c", s.Ks * B * s.H, zero=True) if s.rnn_type == "lstm" else None
         work = self._buf("scratch.sample", self.L.lfi_flow_sample_work_floats(C.byref(dims)))
+        nz = self._buf("sample_noise", nframes * B * s.C)   # engine-owned copy: the captured graph reads a stable address
+        nz[:nframes * B * s.C].view_as(noise).copy_(noise)
         p = self._flow_params()
         hist1 = s.encoders[0].hist
-        check(self.L.lfi_flow_sample_seq(C.byref(dims), C.byref(p), self.prep.data_ptr(), self.wct_f.data_ptr(),
-                                         s.ldf, hist1, pre.data_ptr(), noise.data_ptr(), faces.data_ptr(), seq_len, s.start,
-                                         nframes, h.data_ptr(), ptr(cs), work.data_ptr(), _stream()), "lfi_flow_sample_seq")
-        return faces[:, s.start:]
+
+        def launch():
+            check(self.L.lfi_flow_sample_seq(C.byref(dims), C.byref(p), self.prep.data_ptr(), self.wct_f.data_ptr(),
+                                             s.ldf, hist1, pre.data_ptr(), nz.data_ptr(), faces.data_ptr(), seq_len, s.start,
+                                             nframes, h.data_ptr(), ptr(cs), work.data_ptr(), _stream()), "lfi_flow_sample_seq")
+
+        # The per-frame chain (2 small GEMMs + Ks reverse cells, ~19 launches x nframes) is launch-bound on the host at
+        # small batch: from the second call of a shape on, it is replayed as ONE hipGraph (captured once; every buffer it
+        # touches is engine-owned and keeps its address). LFI_NO_GRAPH=1 keeps eager launches.
+        key = (B, seq_len, self.precision, faces.data_ptr(), pre.data_ptr(), nz.data_ptr(), h.data_ptr(), self.prep.data_ptr())
+        graph = self._sample_graphs.get(key)
+        if graph is None and os.environ.get("LFI_NO_GRAPH") != "1" and self._sample_seen.get(key):
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                launch()
+            self._sample_graphs = {key: graph}   # one shape at a time: buffers are shared between shapes
+        elif graph is None:
+            self._sample_seen = {key: True}
+            launch()
+        if graph is not None:
+            graph.replay()
+        return faces[:, s.start:].clone()
 
     def invert(self, z_seq, batch, masks=None):
         """SeqGlow.invert (models.py:617-645): teacher-forced reverse pass. z_seq (N, B, C) -> x (N, B, C), logdet (N, B)."""
