@@ -116,8 +116,22 @@ def _roofline(spec, F, timing, precision):
         peak, kern, mult = BF16_MFMA_PEAK_TFLOPS, "gemm_bf16x3_kernel<128,128,k32>", 3.0
     else:
         peak, kern, mult = F32_MFMA_PEAK_TFLOPS, "gemm_f32_kernel<128,128,k16>", 1.0
+    # HBM bytes per launch of that kernel from the PMC passes of the same command (tools/pmc_bench.sh -> profiles/):
+    # bench.py cannot collect counters itself; null when no committed measurement matches this kernel and grid
+    traffic, traffic_src = None, None
+    try:
+        tiles = ((F + 127) // 128) * ((KD + 127) // 128)
+        tj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_%s.json" % precision)))
+        for name, v in tj["kernels"].items():
+            if ("bf16x3_kernel<true, true>" in name if precision == "bf16x3" else "gemm_f32_kernel<128, 128, 2, 2, true, true" in name) \
+                    and name.endswith("grid=%d" % (tiles * 256)):
+                traffic, traffic_src = v["hbm_bytes"], "profiles/pmc_traffic_%s.json (%s)" % (precision, tj["source"])
+    except (OSError, ValueError, KeyError):
+        pass
     return {"bound": "mfma", "kernel": kern + " cond_transform forward (F x Ks*D x Ef)",
-            "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
+            "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic,
+            "traffic_unit": "bytes per launch (HBM read + write)", "traffic_source": traffic_src,
+            "algorithmic_bytes_per_launch": 4.0 * (F * spec.ldf + KD * spec.ldf + F * KD),
             "mfma_flops_multiplier": mult, "frac_of_mfma_issue": mult * ach / peak,
             "flops_per_launch": flops, "flops_per_launch_algorithmic": flops_alg,
             "achieved_algorithmic": flops_alg / (ms * 1e-3) / 1e12 if n_launch else None,

@@ -14,6 +14,6 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "GRBM_GUI_ACTIVE
   i=$((i+1))
   timeout 600 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d $OUT/p$i -- python3 bench.py --cpu-baseline-seconds 0 --steps 2 --warmup 2 "$@" > $OUT/p$i.log 2>&1
 done
-python3 tools/pmc_summary.py $OUT > $OUT/summary.md
+python3 tools/pmc_summary.py $OUT $OUT/traffic.json > $OUT/summary.md
 find $OUT -name "*.csv" -size +8M -delete
 head -60 $OUT/summary.md

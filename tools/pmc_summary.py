@@ -13,10 +13,25 @@ import sys
 def main():
     root = sys.argv[1]
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    bygrid = collections.defaultdict(lambda: collections.defaultdict(list))
     for f in glob.glob(root + "/p*/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
             name = r["Kernel_Name"].replace("(anonymous namespace)::", "")
             agg[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            bygrid[(name, int(r["Grid_Size"]))][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    if len(sys.argv) > 2:
+        # per (kernel, grid) HBM bytes per dispatch as JSON: bench.py looks its dominant kernel up here for roofline.traffic
+        import json
+        out = {}
+        for (name, grid), cs in bygrid.items():
+            if "FETCH_SIZE" in cs and "WRITE_SIZE" in cs:
+                rd = 2.0 * 1024 * sum(cs["FETCH_SIZE"]) / len(cs["FETCH_SIZE"])
+                wr = 1024.0 * sum(cs["WRITE_SIZE"]) / len(cs["WRITE_SIZE"])
+                out["%s|grid=%d" % (name, grid)] = {"hbm_read_bytes": rd, "hbm_write_bytes": wr, "hbm_bytes": rd + wr,
+                                                     "dispatches": len(cs["FETCH_SIZE"])}
+        json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), read bytes = 2 x FETCH_SIZE KiB "
+                             "(gfx950 128-byte requests tallied as 64), write bytes = WRITE_SIZE KiB; per dispatch means",
+                   "kernels": out}, open(sys.argv[2], "w"), indent=1)
     rows = []
     for k, cs in agg.items():
         m = {c: sum(v) / len(v) for c, v in cs.items()}
