@@ -99,7 +99,13 @@ int lfi_encode_windows_fwd(const lfi_enc_desc* d, const float* Xp, const float* 
  * dgh ([hist][F][3*hid]: on the hidden side). Weight gradients follow from those with lfi_gemm_f32/lfi_colsum:
  * dW_hh = dgh[1:]^T hseq[:-1], db_hh = colsum(dgh), db_ih = colsum(dgi), dW_ih = scatter(dgi)^T X. */
 int lfi_encode_windows_bwd(const lfi_enc_desc* d, const float* dcond, int lddcond, const float* whh /* 3hid x hid */,
-                           const float* gates, const float* hseq, float* dgi, float* dgh, float* work, void* stream);
+                           const float* gates, const float* hseq, float* dgi, float* dgh,
+                           float* bias_part /* [lfi_encode_windows_bias_rows][4][hid] or NULL */, float* work, void* stream);
+/* The fused backward (hid <= 256) also leaves per-workgroup partial sums over windows and steps of the four distinct
+ * pre-activation gradients (d r, d z, d n, d n * r) in bias_part: db_ih = colsum of blocks {0, 1, 2}, db_hh = colsum of
+ * blocks {0, 1, 3} - no second pass over dgi / dgh. Returns the number of partial rows, 0 when the unfused path runs
+ * (then bias_part is not written and the biases follow from lfi_colsum_f32 over dgi / dgh). */
+long lfi_encode_windows_bias_rows(const lfi_enc_desc* d);
 /* dXp[b*T + p] = sum over the windows (n, s) that read row p of mask * dgi[(n*B+b)*hist + s]   (B*T x 3*hid) */
 int lfi_encode_windows_scatter(const lfi_enc_desc* d, const float* dgi, const float* mask, float* dXp, void* stream);
 /* "enc: none" modality (glow/models.py:76-77) and the flattened p1_face history (glow/models.py:601-603):

@@ -29,6 +29,7 @@ struct EncArgs {
   const float* dcond; int lddcond;
   float* dgi;          // [hist][F][3hid]
   float* dgh;          // [hist][F][3hid]
+  float* bias_part;    // fused backward only: [workgroups * row groups][4][hid] partial sums of dar, dau, dan, dan*r (or null)
 };
 
 // One GRU step for every window. gh: F x 3hid = h_{s-1} W_hh^T (no bias), or null at s = 0 (h = 0).
@@ -98,22 +99,48 @@ __global__ __launch_bounds__(256) void enc_gate_bwd_kernel(EncArgs a, int s, con
 }
 
 // dXp[b*T + p][c] = sum_{s} mask[w(n,b)][s] * dgi[s][w][c],  n = p - pos0 - s in [0, N)
+// One workgroup per frame row; every (step, window) row of dgi is read exactly once over the grid (HBM-bound stream).
+// Branch-free: steps whose window falls outside [0, N) read row 0 with weight 0, so eight 16-byte loads per thread are
+// in flight at a time.
 __global__ __launch_bounds__(256) void enc_scatter_kernel(EncArgs a, float* __restrict__ dXp) {
   const int G3 = 3 * a.hid;
   const int row = blockIdx.x;  // b*T + p
   const int b = row / a.T, p = row - b * a.T;
   const int pos0 = a.start - a.hist + 1;
-  for (int c = threadIdx.x; c < G3; c += 256) {
-    float acc = 0.0f;
-    for (int s = 0; s < a.hist; ++s) {
-      const int n = p - pos0 - s;
-      if (n < 0 || n >= a.N) continue;
-      const long w = (long)n * a.B + b;
-      const float mk = a.mask ? a.mask[w * a.hist + s] : 1.0f;
-      acc += mk * a.dgi[((long)s * a.F + w) * G3 + c];
+  const bool vec = (G3 & 3) == 0;
+  const int nvec = vec ? G3 >> 2 : 0;
+  for (int c4 = threadIdx.x; c4 < nvec; c4 += 256) {
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int s0 = 0; s0 < a.hist; s0 += 8) {
+      f32x4 v[8];
+      float wgt[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int s = s0 + u;
+        const int n = p - pos0 - s;
+        const bool ok = s < a.hist && n >= 0 && n < a.N;
+        const long w = ok ? (long)n * a.B + b : 0;
+        const int sc = ok ? s : 0;
+        wgt[u] = ok ? (a.mask ? a.mask[w * a.hist + sc] : 1.0f) : 0.0f;
+        v[u] = *reinterpret_cast<const f32x4*>(a.dgi + ((long)sc * a.F + w) * G3 + 4 * c4);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc += wgt[u] * v[u];
     }
-    dXp[(long)row * G3 + c] = acc;
+    *reinterpret_cast<f32x4*>(dXp + (long)row * G3 + 4 * c4) = acc;
   }
+  if (!vec)
+    for (int c = threadIdx.x; c < G3; c += 256) {
+      float acc = 0.0f;
+      for (int s = 0; s < a.hist; ++s) {
+        const int n = p - pos0 - s;
+        if (n < 0 || n >= a.N) continue;
+        const long w = (long)n * a.B + b;
+        const float mk = a.mask ? a.mask[w * a.hist + s] : 1.0f;
+        acc += mk * a.dgi[((long)s * a.F + w) * G3 + c];
+      }
+      dXp[(long)row * G3 + c] = acc;
+    }
 }
 
 __global__ __launch_bounds__(256) void gather_windows_kernel(const float* __restrict__ X, int B, int T, int dim, int N, int start,
@@ -418,8 +445,11 @@ __global__ __launch_bounds__(ENC_NT, 2) void enc_gru_bwd_fused_kernel(EncArgs a,
     }
   }
   __syncthreads();
+  // bias gradients db_ih = sum (dar, dau, dan), db_hh = sum (dar, dau, dan*r) over windows and steps: every lane sums its own
+  // column over its rows and all steps in a fixed order; the column sums of the per-(workgroup, row group) partials finish it
+  float bsum[4][2] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
   for (int s = a.hist - 1; s >= 0; --s) {
-    float dg[3][2][16];
+    float dg[2][2][16];  // gates 1 and 2; gate 0 goes straight into the LDS operand image (free since the last barrier)
     f32x16 acc[2];
     const float hp_on = s > 0 ? 1.0f : 0.0f;
     const int sp = s > 0 ? s - 1 : 0;
@@ -448,7 +478,9 @@ __global__ __launch_bounds__(ENC_NT, 2) void enc_gru_bwd_fused_kernel(EncArgs a,
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
             const int r = rh * 8 + e;
-            const unsigned w = (unsigned)min(wbase + enc_rowl(rg, r, halfv), a.F - 1);
+            const int wr = wbase + enc_rowl(rg, r, halfv);
+            const unsigned w = (unsigned)min(wr, a.F - 1);
+            const float live = wr < a.F ? 1.0f : 0.0f;   // clamped duplicate rows do not count in the bias sums
             const float rr = gr[e], uu = gu[e], nn = gn[e], ghn = gg[e];
             const float dhn = dh[t][r];
             const float du = dhn * (hp[e] * hp_on - nn);
@@ -460,19 +492,31 @@ __global__ __launch_bounds__(ENC_NT, 2) void enc_gru_bwd_fused_kernel(EncArgs a,
             const unsigned o = w * (unsigned)G3 + (unsigned)j;
             gib[o] = dar; (gib + hid)[o] = dau; (gib + 2 * hid)[o] = dan;
             ghb[o] = dar; (ghb + hid)[o] = dau; (ghb + 2 * hid)[o] = danr;
-            dg[0][t][r] = dar; dg[1][t][r] = dau; dg[2][t][r] = danr;
+            dg[0][t][r] = dau; dg[1][t][r] = danr;
+            if (s > 0) {
+              const int rl = enc_rowl(rg, r, halfv);
+              if (X3) {
+                const __bf16 hi = (__bf16)dar;
+                Xhi[rl * ldx + j] = hi;
+                Xlo[rl * ldx + j] = (__bf16)(dar - (float)hi);
+              } else {
+                Dls[j * ldk + rl] = dar;
+              }
+            }
             acc[t][r] = dhn * uu;
+            bsum[0][t] += live * dar; bsum[1][t] += live * dau; bsum[2][t] += live * dan; bsum[3][t] += live * danr;
           }
           __builtin_amdgcn_sched_barrier(0);
         }
       } else {
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { dg[0][t][r] = 0.f; dg[1][t][r] = 0.f; dg[2][t][r] = 0.f; acc[t][r] = 0.f; }
+        for (int r = 0; r < 16; ++r) { dg[0][t][r] = 0.f; dg[1][t][r] = 0.f; acc[t][r] = 0.f; }
       }
     }
     if (s == 0) break;
 #pragma unroll
     for (int g = 0; g < 3; ++g) {
+      if (g > 0)
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int rl = enc_rowl(rg, r, halfv);
@@ -480,14 +524,14 @@ __global__ __launch_bounds__(ENC_NT, 2) void enc_gru_bwd_fused_kernel(EncArgs a,
 #pragma unroll
           for (int t = 0; t < 2; ++t)
             if (t ? jok1 : jok0) {
-              const float v = dg[g][t][r];
+              const float v = dg[g - 1][t][r];
               const __bf16 hi = (__bf16)v;
               Xhi[rl * ldx + jv + 32 * t] = hi;
               Xlo[rl * ldx + jv + 32 * t] = (__bf16)(v - (float)hi);
             }
         } else {
-          if (jok0) Dls[jv * ldk + rl] = dg[g][0][r];
-          if (jok1) Dls[(jv + 32) * ldk + rl] = dg[g][1][r];
+          if (jok0) Dls[jv * ldk + rl] = dg[g - 1][0][r];
+          if (jok1) Dls[(jv + 32) * ldk + rl] = dg[g - 1][1][r];
         }
       }
       __syncthreads();
@@ -555,6 +599,17 @@ __global__ __launch_bounds__(ENC_NT, 2) void enc_gru_bwd_fused_kernel(EncArgs a,
     }
     dh[0] = acc[0];
     dh[1] = acc[1];
+  }
+  if (a.bias_part) {
+    float* bp = a.bias_part + ((long)blockIdx.x * (4 / q.ncg) + rg) * 4 * hid;
+#pragma unroll
+    for (int qq = 0; qq < 4; ++qq)
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const float v = bsum[qq][t] + __shfl_xor(bsum[qq][t], 32, 64);
+        const int j = jb + 32 * t;
+        if (half == 0 && j < hid) bp[qq * hid + j] = v;
+      }
   }
 }
 
@@ -664,14 +719,21 @@ extern "C" int lfi_encode_windows_fwd(const lfi_enc_desc* d, const float* Xp, co
   return LFI_OK;
 }
 
+extern "C" long lfi_encode_windows_bias_rows(const lfi_enc_desc* d) {
+  EncFused q = {};
+  if (!d || !enc_fused_shape(d->hid, &q)) return 0;
+  return (long)lfi_cdiv((long)d->N * d->B, q.R) * (4 / q.ncg);
+}
+
 extern "C" int lfi_encode_windows_bwd(const lfi_enc_desc* d, const float* dcond, int lddcond, const float* whh,
-                                      const float* gates, const float* hseq, float* dgi, float* dgh, float* work,
-                                      void* stream) {
+                                      const float* gates, const float* hseq, float* dgi, float* dgh, float* bias_part,
+                                      float* work, void* stream) {
   EncArgs a = {};
   int rc = fill_args(d, &a, "lfi_encode_windows_bwd");
   if (rc) return rc;
   LFI_REQUIRE(dcond && whh && gates && hseq && dgi && dgh && work, "lfi_encode_windows_bwd: null pointer");
   a.dcond = dcond; a.lddcond = lddcond; a.gates = (float*)gates; a.hseq = (float*)hseq; a.dgi = dgi; a.dgh = dgh;
+  a.bias_part = bias_part;
   hipStream_t st = (hipStream_t)stream;
   const int hid = d->hid, F = a.F;
   EncFused q = {};

@@ -56,6 +56,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, const f32x16 (&
   const long ldc = partial ? g.N : g.ldc;
   const float* bias = g.bias ? g.bias + batch * g.strideBias : nullptr;
   const float* G = g.G ? g.G + batch * g.strideG : nullptr;
+  const bool need_c = !partial && g.accumulate != 0, need_g = !partial && g.act == 2;
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -63,6 +64,15 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, const f32x16 (&
       const int col = n0 + wn * 64 + nt * 32 + l31;
       if (col >= g.N) continue;
       const float bv = (!partial && bias) ? bias[col] : 0.0f;
+      // operands of the epilogue first, all 16 in flight (C may alias G - the in-place dpre product - so the compiler
+      // cannot hoist these loads over the stores below by itself: one exposed HBM round trip per element otherwise)
+      float cold[16], gold[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = min(m0 + wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half, g.M - 1);
+        cold[r] = need_c ? Cb[(long)row * ldc + col] : 0.0f;
+        gold[r] = need_g ? G[(long)row * g.ldg + col] : 1.0f;
+      }
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = m0 + wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
@@ -70,24 +80,35 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, const f32x16 (&
         float v = acc[mt][nt][r];
         if (!partial) {
           v += bv;
-          if (g.accumulate == 2) v += Cb[(long)row * ldc + col];
-          v = apply_act(v, g.act, g.slope, G, (long)row * g.ldg + col);
-          if (g.accumulate == 1) v += Cb[(long)row * ldc + col];
+          if (g.accumulate == 2) v += cold[r];
+          if (g.act == 1) v = v > 0.0f ? v : v * g.slope;
+          else if (g.act == 2) v = gold[r] > 0.0f ? v : v * g.slope;
+          if (g.accumulate == 1) v += cold[r];
         }
         Cb[(long)row * ldc + col] = v;
       }
     }
 }
 
-// XCD-aware, grouped tile order shared by both GEMM kernels: blocks b, b+8, ... share an XCD (round-robin dispatch);
-// each XCD gets a contiguous run of tiles (bijective also when the tile count is not a multiple of 8), walked in groups
-// of GM tile-rows column by column so the ~100 tiles an XCD has in flight form a compact GM x 12 patch.
-__device__ __forceinline__ void gemm_tile_of_block(const GemmArgs& g, int bid, int* tm, int* tn) {
+// XCD-aware, grouped work order shared by both GEMM kernels: workgroups b, b+8, ... share an XCD (round-robin dispatch over
+// the linearised grid). Each XCD gets a contiguous run of (split, batch, tile) work items (bijective for any grid size),
+// so that all tiles of one K-split / one batch entry - which re-read the same operand panels - meet in ONE 4 MB L2 instead
+// of fetching them from HBM once per XCD (the long-K weight-gradient products have 12 tiles per split: spread over the
+// XCDs their B panel was fetched up to 6 times). Inside a batch entry tiles are walked in groups of GM tile-rows column by
+// column so the ~100 tiles an XCD has in flight form a compact GM x 12 patch.
+__device__ __forceinline__ void gemm_tile_of_block(const GemmArgs& g, int* tm, int* tn, int* batch, int* split) {
   const int ntile = g.tiles_m * g.tiles_n;
+  const long total = (long)gridDim.x * gridDim.y * gridDim.z;
+  long lin = blockIdx.x + (long)gridDim.x * (blockIdx.y + (long)gridDim.y * blockIdx.z);
   {
-    const int q = ntile >> 3, r = ntile & 7, xcd = bid & 7, idx = bid >> 3;
-    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    const long q = total >> 3, idx = lin >> 3;
+    const int r = (int)(total & 7), xcd = (int)(lin & 7);
+    lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
+  int bid = (int)(lin % ntile);
+  const long rest = lin / ntile;
+  *batch = (int)(rest % gridDim.y);
+  *split = (int)(rest / gridDim.y);
   constexpr int GM = 8;
   const int per_group = GM * g.tiles_n;
   const int grp = bid / per_group, in_grp = bid - grp * per_group;
@@ -174,10 +195,9 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, half = lane >> 5;
 
-  int tm, tn;
-  gemm_tile_of_block(g, blockIdx.x, &tm, &tn);
+  int tm, tn, batch, split;
+  gemm_tile_of_block(g, &tm, &tn, &batch, &split);
   const int m0 = tm * BM, n0 = tn * BN;
-  const int batch = blockIdx.y, split = blockIdx.z;
   const float* __restrict__ A = g.A + batch * g.strideA;
   const float* __restrict__ B = g.B + batch * g.strideB;
   const int kbeg = split * g.kchunk;
@@ -349,10 +369,9 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(GemmArgs g) {
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, half = lane >> 5;
-  int tm, tn;
-  gemm_tile_of_block(g, blockIdx.x, &tm, &tn);
+  int tm, tn, batch, split;
+  gemm_tile_of_block(g, &tm, &tn, &batch, &split);
   const int m0 = tm * 128, n0 = tn * 128;
-  const int batch = blockIdx.y, split = blockIdx.z;
   const float* __restrict__ A = g.A + batch * g.strideA;
   const float* __restrict__ B = g.B + batch * g.strideB;
   const int kbeg = split * g.kchunk;

@@ -270,6 +270,22 @@ class GlowEngine:
         tiles = ((M + 127) // 128) * ((N + 127) // 128) * batch
         return max(1, min(16, 768 // max(tiles, 1), K // 1024))
 
+    @staticmethod
+    def _tail_splitk(M, N, K, batch=1, slots=512):
+        """Smallest K split (<= 8) that wastes < 15 % of the last round of `slots` co-resident workgroups."""
+        tiles = ((M + 127) // 128) * ((N + 127) // 128) * batch
+        best, best_eff = 1, 0.0
+        for sk in (1, 2, 3, 4, 6, 8):
+            if K // sk < 512:
+                break
+            wg = tiles * sk
+            eff = wg / (math.ceil(wg / slots) * slots)
+            if eff > best_eff + 0.02:
+                best, best_eff = sk, eff
+            if eff > 0.85:
+                break
+        return best
+
     def colsum(self, X, ldx, strideX, rows, cols, batch, out, strideOut, scale=1.0, accumulate=0, x_off=0):
         w = self._buf("scratch.colsum", self.L.lfi_colsum_work_floats(rows, cols, batch))
         check(self.L.lfi_colsum_f32(X.data_ptr() + 4 * x_off, ldx, strideX, rows, cols, batch, out.data_ptr(), strideOut,
@@ -444,7 +460,9 @@ class GlowEngine:
             W = s.Ef - col0
             ldd = (W + 3) // 4 * 4
             dcond = self._buf("dcond", F * ldd)
-            self.gemm(F, W, KD, dpre, KD, 1, self.wct_f, s.ldf, 0, dcond, ldd, b_off=col0, tag="gemm_cond_dgrad")
+            # 112 x 5 tiles = 1.09 rounds of the 512 resident workgroups: split K so the tail round is full too
+            self.gemm(F, W, KD, dpre, KD, 1, self.wct_f, s.ldf, 0, dcond, ldd, b_off=col0, tag="gemm_cond_dgrad",
+                      splitk=self._tail_splitk(F, W, KD))
             for e in rnn:
                 self._encoder_backward(e, ctx, dcond, ldd, e.fcol - col0)
 
@@ -461,8 +479,10 @@ class GlowEngine:
         dgh = self._buf("enc_dgh." + e.name, e.hist * F * G3)
         work = self._buf("scratch.enc", self.L.lfi_encode_windows_work_floats(C.byref(d)))
         whh = self.view("enc.%s.weight_hh" % e.name)
+        prow = self.L.lfi_encode_windows_bias_rows(C.byref(d))
+        part = self._buf("enc_bias_part." + e.name, prow * 4 * hid) if prow else None
         check(self.L.lfi_encode_windows_bwd(C.byref(d), dcond.data_ptr(), lddcond, whh.data_ptr(), gates.data_ptr(),
-                                            hseq.data_ptr(), dgi.data_ptr(), dgh.data_ptr(), work.data_ptr(), st),
+                                            hseq.data_ptr(), dgi.data_ptr(), dgh.data_ptr(), ptr(part), work.data_ptr(), st),
               "lfi_encode_windows_bwd")
         mk = None if ctx.masks is None else ctx.masks.get(e.name)
         dxp = self._buf("dxp." + e.name, B * Tx * G3)
@@ -472,14 +492,21 @@ class GlowEngine:
         rows = B * Tx
         self.gemm(G3, e.in_dim, rows, dxp, G3, 0, x, e.in_dim, 0, self.view(gname + "weight_ih", self.grads), e.in_dim,
                   splitk=max(1, min(32, rows // 1024)))
-        self.colsum(dgi, G3, 0, e.hist * F, G3, 1, self.view(gname + "bias_ih", self.grads), 0)
+        gbi, gbh = self.view(gname + "bias_ih", self.grads), self.view(gname + "bias_hh", self.grads)
+        if part is not None:  # per-workgroup partial sums of (d r, d z, d n, d n * r) left by the fused backward kernel
+            self.colsum(part, 4 * hid, 0, prow, G3, 1, gbi, 0)
+            self.colsum(part, 4 * hid, 0, prow, 2 * hid, 1, gbh, 0)
+            self.colsum(part, 4 * hid, 0, prow, hid, 1, gbh[2 * hid:], 0, x_off=3 * hid)
+        else:
+            self.colsum(dgi, G3, 0, e.hist * F, G3, 1, gbi, 0)
         if e.hist > 1:
             kk = (e.hist - 1) * F
             self.gemm(G3, hid, kk, dgh, G3, 0, hseq, hid, 0, self.view(gname + "weight_hh", self.grads), hid,
                       splitk=max(1, min(64, kk // 2048)), a_off=F * G3)
         else:
             self.view(gname + "weight_hh", self.grads).zero_()
-        self.colsum(dgh, G3, 0, e.hist * F, G3, 1, self.view(gname + "bias_hh", self.grads), 0)
+        if part is None:
+            self.colsum(dgh, G3, 0, e.hist * F, G3, 1, gbh, 0)
 
     # ------------------------------------------------------------------ optimiser
     def optimizer_step(self, lr, beta1, beta2, eps, clip=0.0, gmul=1.0):
