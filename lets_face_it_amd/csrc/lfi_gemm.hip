@@ -39,6 +39,7 @@ struct GemmArgs {
   float* work;
   int tiles_m, tiles_n;
   int vecA, vecB;  // operand rows are 16-byte aligned and 4-float granular: 16-byte global loads are legal
+  int vecC;        // the same for C (and G): the epilogue goes through LDS with 16-byte row-wise loads / stores
 };
 
 __device__ __forceinline__ float apply_act(float v, int act, float slope, const float* G, long gidx) {
@@ -88,6 +89,84 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, const f32x16 (&
         Cb[(long)row * ldc + col] = v;
       }
     }
+}
+
+// Wide epilogue. The accumulator layout gives a lane 32-bit elements two rows apart: written straight from registers, a
+// 128 x 128 tile costs 64 four-byte store instructions per lane, and an epilogue operand (G of the in-place dpre product, C
+// when accumulating) as many four-byte loads - measured: the G loads alone doubled the dpre product's time. Instead the
+// tile goes through LDS (free after the main loop): operand tile in with 16-byte row-wise loads, each lane combines its own
+// elements in place, result tile out with 16-byte row-wise stores (512 contiguous bytes per 32 lanes).
+// `rows` rows of the block tile per pass (the LDS image is rows x (BN + 4) floats); waves whose 64-row patch is in the pass
+// take part in the register phase, all 256 threads in the row-wise phases.
+constexpr int WLD = 128 + 4;
+
+template <int BN>
+__device__ __forceinline__ void gemm_epilogue_wide(const GemmArgs& g, const f32x16 (&acc)[2][2], float* lds, int rows_per_pass,
+                                                   int m0, int n0, int wm, int wn, int l31, int half, int batch, int split, int bm) {
+  static_assert(BN == 128, "row-wise phases assume 32 float4 per tile row");
+  const int tid = threadIdx.x;
+  const bool partial = g.splitk > 1;
+  float* __restrict__ Cb = partial ? g.work + ((long)batch * g.splitk + split) * (long)g.M * g.N : g.C + batch * g.strideC;
+  const long ldc = partial ? g.N : g.ldc;
+  const float* bias = g.bias ? g.bias + batch * g.strideBias : nullptr;
+  const float* G = g.G ? g.G + batch * g.strideG : nullptr;
+  const bool need_c = !partial && g.accumulate != 0, need_g = !partial && g.act == 2;
+  const int rrow = tid >> 5, c4 = (tid & 31) * 4;  // row-wise phases: 8 rows x 32 float4 per sweep
+  const int col_g = n0 + c4;
+  for (int p0 = 0; p0 < bm; p0 += rows_per_pass) {
+    if (need_c || need_g) {  // operand tile in (never both: the host keeps act 2 + accumulate on the narrow path)
+      const float* src = need_g ? G : Cb;
+      const long lds_src = need_g ? g.ldg : ldc;
+      for (int r = rrow; r < rows_per_pass; r += 8) {
+        const int row = m0 + p0 + r;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (row < g.M && col_g < g.N) {
+          if (col_g + 3 < g.N) v = *reinterpret_cast<const f32x4*>(src + (long)row * lds_src + col_g);
+          else
+            for (int j = 0; j < 4; ++j)
+              if (col_g + j < g.N) v[j] = src[(long)row * lds_src + col_g + j];
+        }
+        *reinterpret_cast<f32x4*>(lds + r * WLD + c4) = v;
+      }
+      __syncthreads();
+    }
+    if (wm * 64 >= p0 && wm * 64 < p0 + rows_per_pass) {
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+          const int cl = wn * 64 + nt * 32 + l31;
+          const int col = n0 + cl;
+          const float bv = (!partial && bias && col < g.N) ? bias[col] : 0.0f;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int rl = wm * 64 - p0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            float v = acc[mt][nt][r];
+            if (!partial) {
+              v += bv;
+              const float o = (need_c || need_g) ? lds[rl * WLD + cl] : 0.0f;
+              if (g.accumulate == 2) v += o;
+              if (g.act == 1) v = v > 0.0f ? v : v * g.slope;
+              else if (g.act == 2) v = o > 0.0f ? v : v * g.slope;
+              if (g.accumulate == 1) v += o;
+            }
+            lds[rl * WLD + cl] = v;
+          }
+        }
+    }
+    __syncthreads();
+    for (int r = rrow; r < rows_per_pass; r += 8) {  // result tile out
+      const int row = m0 + p0 + r;
+      if (row < g.M && col_g < g.N) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(lds + r * WLD + c4);
+        if (col_g + 3 < g.N) *reinterpret_cast<f32x4*>(Cb + (long)row * ldc + col_g) = v;
+        else
+          for (int j = 0; j < 4; ++j)
+            if (col_g + j < g.N) Cb[(long)row * ldc + col_g + j] = v[j];
+      }
+    }
+    if (p0 + rows_per_pass < bm) __syncthreads();
+  }
 }
 
 // XCD-aware, grouped work order shared by both GEMM kernels: workgroups b, b+8, ... share an XCD (round-robin dispatch over
@@ -188,8 +267,11 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
   static_assert(BKT == 16, "fragment reads assume two groups of 8 k per tile");
   using SA = Stager<BM, AKC>;
   using SB = Stager<BN, BKC>;
-  __shared__ __attribute__((aligned(16))) float As[2][SA::LDS_FLOATS];
-  __shared__ __attribute__((aligned(16))) float Bs[2][SB::LDS_FLOATS];
+  constexpr int MAIN_FLOATS = 2 * (SA::LDS_FLOATS + SB::LDS_FLOATS);
+  constexpr int EPI_FLOATS = (BM == 128 && BN == 128) ? 64 * WLD : 0;   // wide epilogue: two passes of 64 rows
+  __shared__ __attribute__((aligned(16))) float smem_f32[MAIN_FLOATS > EPI_FLOATS ? MAIN_FLOATS : EPI_FLOATS];
+  float (*As)[SA::LDS_FLOATS] = reinterpret_cast<float (*)[SA::LDS_FLOATS]>(smem_f32);
+  float (*Bs)[SB::LDS_FLOATS] = reinterpret_cast<float (*)[SB::LDS_FLOATS]>(smem_f32 + 2 * SA::LDS_FLOATS);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -275,7 +357,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
     __syncthreads();
   }
 
-  gemm_epilogue(g, acc, m0, n0, wm, wn, l31, half, batch, split);
+  if (BM == 128 && BN == 128 && g.vecC) gemm_epilogue_wide<128>(g, acc, smem_f32, 64, m0, n0, wm, wn, l31, half, batch, split, 128);
+  else gemm_epilogue(g, acc, m0, n0, wm, wn, l31, half, batch, split);
 }
 
 // ---------------------------------------------------------------------------------------------- bf16 x 3
@@ -441,7 +524,9 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(GemmArgs g) {
     if (kt + 1 < nkt) store_tiles(kt + 1, buf ^ 1);
     __syncthreads();
   }
-  gemm_epilogue(g, acc, m0, n0, wm, wn, l31, half, batch, split);
+  // 80 KB of dynamic LDS: the whole 128 x 132 fp32 tile image (67.6 KB) fits, one pass
+  if (g.vecC) gemm_epilogue_wide<128>(g, acc, reinterpret_cast<float*>(xsmem), 128, m0, n0, wm, wn, l31, half, batch, split, 128);
+  else gemm_epilogue(g, acc, m0, n0, wm, wn, l31, half, batch, split);
 }
 
 __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(GemmArgs g) {
@@ -519,6 +604,14 @@ extern "C" int lfi_gemm_f32(const lfi_gemm_desc* d, void* stream) {
   };
   a.vecA = vec_ok(d->A, d->lda, d->strideA, d->a_kcontig, d->M, d->K);
   a.vecB = vec_ok(d->B, d->ldb, d->strideB, d->b_kcontig, d->N, d->K);
+  {
+    // C (or the split-K workspace) and G rows 16-byte aligned; act 2 together with accumulate stays on the narrow path
+    const bool partial = splitk > 1;
+    const bool c_ok = partial ? (((long)d->M * d->N) % 4 == 0 && d->N % 4 == 0 && (reinterpret_cast<uintptr_t>(d->work) & 15) == 0)
+                              : ((reinterpret_cast<uintptr_t>(d->C) & 15) == 0 && d->ldc % 4 == 0 && d->strideC % 4 == 0);
+    const bool g_ok = d->act != 2 || ((reinterpret_cast<uintptr_t>(d->G) & 15) == 0 && d->ldg % 4 == 0 && d->strideG % 4 == 0);
+    a.vecC = (c_ok && g_ok && !(d->act == 2 && d->accumulate != 0)) ? 1 : 0;
+  }
   const bool use_x3 = d->precision == 1 && a.vecA && a.vecB;
   // tile shape: narrow outputs get the tall tile, short outputs the wide one (the bf16x3 kernel has one shape)
   int shape = 0;  // 128 x 128
