@@ -12,6 +12,7 @@
 // blocks that share an A panel share an L2.
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 #include "lfi_common.h"
 
@@ -100,10 +101,12 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, const f32x16 (&
 // take part in the register phase, all 256 threads in the row-wise phases.
 constexpr int WLD = 128 + 4;
 
-template <int BN>
+template <int BN, int NTH = 256>
 __device__ __forceinline__ void gemm_epilogue_wide(const GemmArgs& g, const f32x16 (&acc)[2][2], float* lds, int rows_per_pass,
-                                                   int m0, int n0, int wm, int wn, int l31, int half, int batch, int split, int bm) {
+                                                   int m0, int n0, int wm, int wn, int l31, int half, int batch, int split, int bm,
+                                                   bool has_acc = true) {
   static_assert(BN == 128, "row-wise phases assume 32 float4 per tile row");
+  constexpr int SWEEP = NTH / 32;   // tile rows per row-wise sweep
   const int tid = threadIdx.x;
   const bool partial = g.splitk > 1;
   float* __restrict__ Cb = partial ? g.work + ((long)batch * g.splitk + split) * (long)g.M * g.N : g.C + batch * g.strideC;
@@ -111,13 +114,13 @@ __device__ __forceinline__ void gemm_epilogue_wide(const GemmArgs& g, const f32x
   const float* bias = g.bias ? g.bias + batch * g.strideBias : nullptr;
   const float* G = g.G ? g.G + batch * g.strideG : nullptr;
   const bool need_c = !partial && g.accumulate != 0, need_g = !partial && g.act == 2;
-  const int rrow = tid >> 5, c4 = (tid & 31) * 4;  // row-wise phases: 8 rows x 32 float4 per sweep
+  const int rrow = tid >> 5, c4 = (tid & 31) * 4;  // row-wise phases: SWEEP rows x 32 float4 per sweep
   const int col_g = n0 + c4;
   for (int p0 = 0; p0 < bm; p0 += rows_per_pass) {
     if (need_c || need_g) {  // operand tile in (never both: the host keeps act 2 + accumulate on the narrow path)
       const float* src = need_g ? G : Cb;
       const long lds_src = need_g ? g.ldg : ldc;
-      for (int r = rrow; r < rows_per_pass; r += 8) {
+      for (int r = rrow; r < rows_per_pass; r += SWEEP) {
         const int row = m0 + p0 + r;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (row < g.M && col_g < g.N) {
@@ -130,7 +133,7 @@ __device__ __forceinline__ void gemm_epilogue_wide(const GemmArgs& g, const f32x
       }
       __syncthreads();
     }
-    if (wm * 64 >= p0 && wm * 64 < p0 + rows_per_pass) {
+    if (has_acc && wm * 64 >= p0 && wm * 64 < p0 + rows_per_pass) {
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -155,7 +158,7 @@ __device__ __forceinline__ void gemm_epilogue_wide(const GemmArgs& g, const f32x
         }
     }
     __syncthreads();
-    for (int r = rrow; r < rows_per_pass; r += 8) {  // result tile out
+    for (int r = rrow; r < rows_per_pass; r += SWEEP) {  // result tile out
       const int row = m0 + p0 + r;
       if (row < g.M && col_g < g.N) {
         const f32x4 v = *reinterpret_cast<const f32x4*>(lds + r * WLD + c4);
@@ -529,6 +532,186 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(GemmArgs g) {
   else gemm_epilogue(g, acc, m0, n0, wm, wn, l31, half, batch, split);
 }
 
+// Warp-specialised variant. In the kernel above one wave alternates between its 24 MFMAs (768 cycles) and ~200 VALU
+// instructions of operand splitting per k-tile, so the matrix pipe idles during the split (31 % of the bf16 peak with two
+// workgroups per CU trading places). Here a workgroup has 8 waves with fixed roles: waves 0-3 only read fragments and
+// issue MFMAs (each a 64 x 64 patch of the 128 x 128 tile), waves 4-7 only load, split and write the next k-tile. Wave w
+// and w + 4 share a SIMD (a workgroup's waves go to SIMDs 0, 2, 1, 3 in turn), where the VALU and matrix pipes run
+// concurrently: the split of tile t + 1 executes under the MFMAs of tile t. One barrier per k-tile as before; loads run
+// two tiles ahead (two register sets); full k-tiles take a predicate-free path (rows past M / N are clamped: they only
+// feed outputs that are never stored), only the last partial k-tile masks.
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float float2_t __attribute__((ext_vector_type(2)));
+
+// (hi, lo) bf16 pairs of (a, b): 6 VALU instructions (cvt_pk, shift, and, 2 sub, cvt_pk)
+__device__ __forceinline__ void split2(float a, float b, unsigned* hi, unsigned* lo) {
+  const bf16x2 h = __builtin_convertvector((float2_t){a, b}, bf16x2);
+  const unsigned hb = __builtin_bit_cast(unsigned, h);
+  const float ha = __builtin_bit_cast(float, hb << 16), hbv = __builtin_bit_cast(float, hb & 0xffff0000u);
+  const bf16x2 l = __builtin_convertvector((float2_t){a - ha, b - hbv}, bf16x2);
+  *hi = hb;
+  *lo = __builtin_bit_cast(unsigned, l);
+}
+
+template <bool KC>
+struct WStager {
+  int off[4];     // element offset of each float4 from the tile origin
+  int lds[4];     // KC: bf16 offset of the 4 values in the image
+  int kk[4];      // first k of the float4 (KC) / its k row (!KC)
+  int mn_l, kg4;
+  __device__ __forceinline__ void init(int ptid, int mn0, int MN, long ld) {
+    if (KC) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int f = ptid + 256 * i;
+        const int k = (f & 7) * 4, mn = f >> 3;
+        kk[i] = k;
+        off[i] = (min(mn0 + mn, MN - 1) - mn0) * (int)ld + k;
+        lds[i] = mn * XROW + k;
+      }
+    } else {
+      kg4 = (ptid & 7) * 4;
+      mn_l = (ptid >> 3) * 4;
+      const int mnc = mn0 + mn_l < MN ? mn_l : 0;   // a float4 wholly outside the matrix re-reads the tile's first columns
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        kk[j] = kg4 + j;
+        off[j] = (kg4 + j) * (int)ld + mnc;
+        lds[j] = 0;
+      }
+    }
+  }
+  __device__ __forceinline__ void load_full(const float* __restrict__ p, f32x4 (&r)[4]) const {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r[i] = *reinterpret_cast<const f32x4*>(p + off[i]);
+  }
+  // last, partial k-tile: whole float4s past K are not read, elements past K are zeroed
+  __device__ __forceinline__ void load_tail(const float* __restrict__ p, int krem, f32x4 (&r)[4]) const {
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      r[i] = kk[i] < krem ? *reinterpret_cast<const f32x4*>(p + off[i]) : z;
+      if (KC) {
+#pragma unroll
+        for (int j = 1; j < 4; ++j) r[i][j] = (kk[i] + j < krem) ? r[i][j] : 0.0f;
+      }
+    }
+  }
+  __device__ __forceinline__ void store(__bf16* hi_img, __bf16* lo_img, const f32x4 (&r)[4]) const {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      uint2 h, l;
+      if (KC) {
+        split2(r[i][0], r[i][1], &h.x, &l.x);
+        split2(r[i][2], r[i][3], &h.y, &l.y);
+        *reinterpret_cast<uint2*>(hi_img + lds[i]) = h;
+        *reinterpret_cast<uint2*>(lo_img + lds[i]) = l;
+      } else {  // r[j][i] = element (k = kg4 + j, mn = mn_l + i): each LDS row gets 4 consecutive k
+        split2(r[0][i], r[1][i], &h.x, &l.x);
+        split2(r[2][i], r[3][i], &h.y, &l.y);
+        *reinterpret_cast<uint2*>(hi_img + (mn_l + i) * XROW + kg4) = h;
+        *reinterpret_cast<uint2*>(lo_img + (mn_l + i) * XROW + kg4) = l;
+      }
+    }
+  }
+};
+
+template <bool AKC, bool BKC>
+__global__ __launch_bounds__(512, 4) void gemm_bf16x3_ws_kernel(GemmArgs g) {
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, half = lane >> 5;
+  const bool producer = wave >= 4;
+  int tm, tn, batch, split;
+  gemm_tile_of_block(g, &tm, &tn, &batch, &split);
+  const int m0 = tm * 128, n0 = tn * 128;
+  const int kbeg = split * g.kchunk;
+  const int kend = min(g.K, kbeg + g.kchunk);
+  const int nkt = (kend - kbeg + XBK - 1) / XBK;
+  const int wm = (wave & 3) >> 1, wn = wave & 1;
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+  if (producer) {
+    const float* __restrict__ A = g.A + batch * g.strideA;
+    const float* __restrict__ B = g.B + batch * g.strideB;
+    WStager<AKC> sa;
+    WStager<BKC> sb;
+    sa.init(tid - 256, m0, g.M, g.lda);
+    sb.init(tid - 256, n0, g.N, g.ldb);
+    const float* __restrict__ tA = AKC ? A + (long)m0 * g.lda + kbeg : A + (long)kbeg * g.lda + m0;
+    const float* __restrict__ tB = BKC ? B + (long)n0 * g.ldb + kbeg : B + (long)kbeg * g.ldb + n0;
+    const long stepA = AKC ? XBK : (long)XBK * g.lda, stepB = BKC ? XBK : (long)XBK * g.ldb;
+    f32x4 ra0[4], rb0[4], ra1[4], rb1[4];
+    auto load = [&](int kt, f32x4 (&ra)[4], f32x4 (&rb)[4]) {
+      const int krem = kend - (kbeg + kt * XBK);
+      if (krem >= XBK) {
+        sa.load_full(tA + kt * stepA, ra);
+        sb.load_full(tB + kt * stepB, rb);
+      } else {
+        sa.load_tail(tA + kt * stepA, krem, ra);
+        sb.load_tail(tB + kt * stepB, krem, rb);
+      }
+    };
+    auto store = [&](int buf, const f32x4 (&ra)[4], const f32x4 (&rb)[4]) {
+      __bf16* base = xsmem + buf * 4 * XIMG;
+      sa.store(base, base + XIMG, ra);
+      sb.store(base + 2 * XIMG, base + 3 * XIMG, rb);
+    };
+    if (nkt > 0) {
+      load(0, ra0, rb0);
+      if (nkt > 1) load(1, ra1, rb1);
+      store(0, ra0, rb0);
+    }
+    __syncthreads();
+    for (int kt = 0; kt < nkt; kt += 2) {
+      if (kt + 2 < nkt) load(kt + 2, ra0, rb0);
+      if (kt + 1 < nkt) store(1, ra1, rb1);
+      __syncthreads();
+      if (kt + 1 >= nkt) break;
+      if (kt + 3 < nkt) load(kt + 3, ra1, rb1);
+      if (kt + 2 < nkt) store(0, ra0, rb0);
+      __syncthreads();
+    }
+  } else {
+    __syncthreads();
+    for (int kt = 0; kt < nkt; ++kt) {
+      const __bf16* base = xsmem + (kt & 1) * 4 * XIMG;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        bf16x8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+        for (int t2 = 0; t2 < 2; ++t2) {
+          const int ro = (wm * 64 + t2 * 32 + l31) * XROW + ks * 16 + half * 8;
+          const int co = (wn * 64 + t2 * 32 + l31) * XROW + ks * 16 + half * 8;
+          ah[t2] = *reinterpret_cast<const bf16x8*>(base + ro);
+          al[t2] = *reinterpret_cast<const bf16x8*>(base + XIMG + ro);
+          bh[t2] = *reinterpret_cast<const bf16x8*>(base + 2 * XIMG + co);
+          bl[t2] = *reinterpret_cast<const bf16x8*>(base + 3 * XIMG + co);
+        }
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt) {
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt], bl[nt], acc[mt][nt], 0, 0, 0);
+            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+          }
+      }
+      __syncthreads();
+    }
+  }
+  if (g.vecC)
+    gemm_epilogue_wide<128, 512>(g, acc, reinterpret_cast<float*>(xsmem), 128, m0, n0, wm, wn, l31, half, batch, split, 128, !producer);
+  else if (!producer)
+    gemm_epilogue(g, acc, m0, n0, wm, wn, l31, half, batch, split);
+}
+
 __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(GemmArgs g) {
   const long mn = (long)g.M * g.N;
   const int batch = blockIdx.y;
@@ -641,7 +824,23 @@ extern "C" int lfi_gemm_f32(const lfi_gemm_desc* d, void* stream) {
       }
       attr_set = true;
     }
-    if (d->a_kcontig && d->b_kcontig) hipLaunchKernelGGL((gemm_bf16x3_kernel<true, true>), grid, dim3(256), lds, st, a);
+    static int use_ws = -1;
+    if (use_ws < 0) {
+      const char* e = getenv("LFI_GEMM_WS");
+      use_ws = (e && e[0] == '1') ? 1 : 0;  // measured: 0.86 / 1.05 / 1.00 ms vs 0.93 / 0.99 / 0.90 ms on the three cond_transform
+                                           // products - no gain, so the split is not what idles the matrix pipe; opt-in only
+      hipError_t w1 = hipFuncSetAttribute((const void*)gemm_bf16x3_ws_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipError_t w2 = hipFuncSetAttribute((const void*)gemm_bf16x3_ws_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipError_t w3 = hipFuncSetAttribute((const void*)gemm_bf16x3_ws_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipError_t w4 = hipFuncSetAttribute((const void*)gemm_bf16x3_ws_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (w1 != hipSuccess || w2 != hipSuccess || w3 != hipSuccess || w4 != hipSuccess) use_ws = 0;
+    }
+    if (use_ws) {
+      if (d->a_kcontig && d->b_kcontig) hipLaunchKernelGGL((gemm_bf16x3_ws_kernel<true, true>), grid, dim3(512), lds, st, a);
+      else if (d->a_kcontig) hipLaunchKernelGGL((gemm_bf16x3_ws_kernel<true, false>), grid, dim3(512), lds, st, a);
+      else if (d->b_kcontig) hipLaunchKernelGGL((gemm_bf16x3_ws_kernel<false, true>), grid, dim3(512), lds, st, a);
+      else hipLaunchKernelGGL((gemm_bf16x3_ws_kernel<false, false>), grid, dim3(512), lds, st, a);
+    } else if (d->a_kcontig && d->b_kcontig) hipLaunchKernelGGL((gemm_bf16x3_kernel<true, true>), grid, dim3(256), lds, st, a);
     else if (d->a_kcontig) hipLaunchKernelGGL((gemm_bf16x3_kernel<true, false>), grid, dim3(256), lds, st, a);
     else if (d->b_kcontig) hipLaunchKernelGGL((gemm_bf16x3_kernel<false, true>), grid, dim3(256), lds, st, a);
     else hipLaunchKernelGGL((gemm_bf16x3_kernel<false, false>), grid, dim3(256), lds, st, a);

@@ -34,14 +34,23 @@ class LetsFaceItGlow(nn.Module):
         self.logged = {}
         self.global_step = 0
         self.nll_sync_hook = None  # data-parallel trainer: averages the mismatched NLL over ranks
+        self._mm_host = None
+        self.register_load_state_dict_post_hook(lambda module, incompatible: setattr(module, "_mm_host", None))
 
     # Lightning's self.log, reduced to a dict of the latest values
     def log(self, name, value, **kwargs):
         self.logged[name] = value.detach() if torch.is_tensor(value) else value
 
+    def _last_mm(self):
+        """Host copy of the `last_missmatched_nll` buffer: reading the device tensor every step (`buffer > 0`) is a device
+        synchronisation per step, which stops the host from queueing the next step's launches under the current one."""
+        if self._mm_host is None:
+            self._mm_host = float(self.last_missmatched_nll)
+        return self._mm_host
+
     def _negative_branch(self):
         """lets_face_it_glow.py:40-45: only while the last mismatched NLL is > 0, with probability 0.1 (Python RNG)."""
-        return bool(self.hparams.Train["use_negative_nll_loss"] and self.last_missmatched_nll > 0
+        return bool(self.hparams.Train["use_negative_nll_loss"] and self._last_mm() > 0
                     and random.random() < 0.1 and self.missmatched_modalities)
 
     def training_step(self, batch, batch_idx):
@@ -61,6 +70,7 @@ class LetsFaceItGlow(nn.Module):
         if self.nll_sync_hook is not None:
             value = self.nll_sync_hook(value)
         self.last_missmatched_nll.copy_(value)
+        self._mm_host = None  # re-read (one synchronisation, on negative steps only)
 
     def fused_training_step(self, batch, lr, world_size=1, allreduce=None):
         """One optimiser step entirely in the engine. Returns the (detached) loss of this rank.
