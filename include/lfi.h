@@ -50,7 +50,8 @@ typedef struct {
   int batch; long strideA, strideB, strideC, strideBias, strideG;
   int accumulate;             /* 1: C = act(..) + C ; 2: C = act(.. + C) (pre-activation add) */
   int act; float slope;
-  int splitk; float* work;
+  int splitk; float* work;    /* splitk 0 = let the library pick the split (needs work of lfi_gemm_work_floats floats; a NULL
+                                 work then means no split) */
   int precision;              /* 0: exact fp32 (f32-input MFMA). 1: bf16x3 — operands split into bf16 hi + lo on the fly,
                                  three bf16 MFMAs per step into fp32 accumulators (~2^-16 relative); needs 16-byte aligned
                                  operands, otherwise the exact kernel runs */

@@ -92,6 +92,12 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, const f32x16 (&
     }
 }
 
+template <int BN>
+__device__ __forceinline__ void gemm_epilogue_n(const GemmArgs& g, const f32x16 (&acc)[2][2], int m0, int n0, int wm, int wn,
+                                                int l31, int half, int batch, int split) {
+  gemm_epilogue(g, acc, m0, n0, wm, wn, l31, half, batch, split);
+}
+
 // Wide epilogue. The accumulator layout gives a lane 32-bit elements two rows apart: written straight from registers, a
 // 128 x 128 tile costs 64 four-byte store instructions per lane, and an epilogue operand (G of the in-place dpre product, C
 // when accumulating) as many four-byte loads - measured: the G loads alone doubled the dpre product's time. Instead the
@@ -99,14 +105,13 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, const f32x16 (&
 // elements in place, result tile out with 16-byte row-wise stores (512 contiguous bytes per 32 lanes).
 // `rows` rows of the block tile per pass (the LDS image is rows x (BN + 4) floats); waves whose 64-row patch is in the pass
 // take part in the register phase, all 256 threads in the row-wise phases.
-constexpr int WLD = 128 + 4;
-
 template <int BN, int NTH = 256>
 __device__ __forceinline__ void gemm_epilogue_wide(const GemmArgs& g, const f32x16 (&acc)[2][2], float* lds, int rows_per_pass,
                                                    int m0, int n0, int wm, int wn, int l31, int half, int batch, int split, int bm,
                                                    bool has_acc = true) {
-  static_assert(BN == 128, "row-wise phases assume 32 float4 per tile row");
-  constexpr int SWEEP = NTH / 32;   // tile rows per row-wise sweep
+  constexpr int WLD = BN + 4;       // LDS row pitch (floats)
+  constexpr int F4 = BN / 4;        // float4 per tile row
+  constexpr int SWEEP = NTH / F4;   // tile rows per row-wise sweep
   const int tid = threadIdx.x;
   const bool partial = g.splitk > 1;
   float* __restrict__ Cb = partial ? g.work + ((long)batch * g.splitk + split) * (long)g.M * g.N : g.C + batch * g.strideC;
@@ -114,7 +119,7 @@ __device__ __forceinline__ void gemm_epilogue_wide(const GemmArgs& g, const f32x
   const float* bias = g.bias ? g.bias + batch * g.strideBias : nullptr;
   const float* G = g.G ? g.G + batch * g.strideG : nullptr;
   const bool need_c = !partial && g.accumulate != 0, need_g = !partial && g.act == 2;
-  const int rrow = tid >> 5, c4 = (tid & 31) * 4;  // row-wise phases: SWEEP rows x 32 float4 per sweep
+  const int rrow = tid / F4, c4 = (tid % F4) * 4;  // row-wise phases: SWEEP rows x F4 float4 per sweep
   const int col_g = n0 + c4;
   for (int p0 = 0; p0 < bm; p0 += rows_per_pass) {
     if (need_c || need_g) {  // operand tile in (never both: the host keeps act 2 + accumulate on the narrow path)
@@ -271,7 +276,7 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
   using SA = Stager<BM, AKC>;
   using SB = Stager<BN, BKC>;
   constexpr int MAIN_FLOATS = 2 * (SA::LDS_FLOATS + SB::LDS_FLOATS);
-  constexpr int EPI_FLOATS = (BM == 128 && BN == 128) ? 64 * WLD : 0;   // wide epilogue: two passes of 64 rows
+  constexpr int EPI_FLOATS = (BM == 128 && BN == 128) ? 64 * (128 + 4) : 0;   // wide epilogue: two passes of 64 rows
   __shared__ __attribute__((aligned(16))) float smem_f32[MAIN_FLOATS > EPI_FLOATS ? MAIN_FLOATS : EPI_FLOATS];
   float (*As)[SA::LDS_FLOATS] = reinterpret_cast<float (*)[SA::LDS_FLOATS]>(smem_f32);
   float (*Bs)[SB::LDS_FLOATS] = reinterpret_cast<float (*)[SB::LDS_FLOATS]>(smem_f32 + 2 * SA::LDS_FLOATS);
@@ -519,8 +524,10 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(GemmArgs g) {
       for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
+#ifndef LFI_DEBUG_X1
           acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mt], bh[nt], acc[mt][nt], 0, 0, 0);
           acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt], bl[nt], acc[mt][nt], 0, 0, 0);
+#endif
           acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt], bh[nt], acc[mt][nt], 0, 0, 0);
         }
     }
@@ -712,6 +719,199 @@ __global__ __launch_bounds__(512, 4) void gemm_bf16x3_ws_kernel(GemmArgs g) {
     gemm_epilogue(g, acc, m0, n0, wm, wn, l31, half, batch, split);
 }
 
+// ---------------------------------------------------------------------------------------------- bf16 x 3, 256 x 256 tiles
+// The 128 x 128 kernel above is bound by operand delivery, not by the matrix pipe: with only the hi*hi MFMA left (1/3 of
+// the matrix work) the cond_transform product ran 0.73 ms instead of 0.93 ms. Each workgroup has one k-tile of loads in
+// flight (64 KB per CU) against ~1-2 us of L2/HBM latency, and at full MFMA rate a 128 x 128 tile consumes 43 B/clk/CU of
+// fp32 operands. This variant halves the bytes per MFMA (256 x 256 block tile: 21 B/clk/CU) and quadruples the depth:
+// 1024 threads (16 waves x 64 x 64 patches), k-tile 16, FOUR k-tiles of loads in flight per thread (128 KB per CU),
+// register-staged, split to bf16 hi/lo on the way into a double-buffered LDS image (48-byte rows: 16-byte aligned
+// fragment reads, conflict-free since 3 is odd).
+constexpr int YBK = 16;
+constexpr int YROW = YBK + 8;            // bf16 per LDS row
+constexpr int YIMG = 256 * YROW;         // bf16 per image (one operand, one plane)
+constexpr int YDEPTH = 2;                // k-tiles of loads in flight
+
+constexpr int YPIT = 256 + 32;           // bf16 per k row of a k-major (mn-contiguous operand) image: 576 B, = 64 mod 256
+
+// One float4 per thread and k-tile for either operand orientation.
+//  KC (k contiguous in memory): 4 float4 per row of 16 k; LDS image row-major [mn][YROW], fragments by ds_read_b128.
+//  !KC (mn contiguous in memory): 64 float4 per k row; LDS image k-major [k][YPIT] exactly as loaded (8-byte writes, 512
+//  contiguous bytes per wave), fragments by the transposing ds_read_b64_tr_b16 (two reads of 4 k each per fragment).
+template <bool KC>
+struct YStager {
+  int off, lds, kk;
+  __device__ __forceinline__ void init(int tid, int mn0, int MN, long ld) {
+    if (KC) {
+      const int k4 = (tid & 3) * 4, mn = tid >> 2;
+      kk = k4;
+      off = (min(mn0 + mn, MN - 1) - mn0) * (int)ld + k4;
+      lds = mn * YROW + k4;
+    } else {
+      const int k = tid >> 6, mn4 = (tid & 63) * 4;
+      kk = k;
+      off = k * (int)ld + (mn0 + mn4 < MN ? mn4 : 0);   // a float4 wholly outside the matrix re-reads the tile's first columns
+      lds = k * YPIT + mn4;
+    }
+  }
+  __device__ __forceinline__ void load(const float* __restrict__ p, int krem, f32x4& r) const {
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    if (krem >= YBK) {
+      r = *reinterpret_cast<const f32x4*>(p + off);
+    } else {  // last, partial k-tile
+      r = kk < krem ? *reinterpret_cast<const f32x4*>(p + off) : z;
+      if (KC) {
+#pragma unroll
+        for (int j = 1; j < 4; ++j) r[j] = (kk + j < krem) ? r[j] : 0.0f;
+      }
+    }
+  }
+  __device__ __forceinline__ void store(__bf16* hi_img, __bf16* lo_img, const f32x4& r) const {
+    uint2 h, l;
+    split2(r[0], r[1], &h.x, &l.x);
+    split2(r[2], r[3], &h.y, &l.y);
+    *reinterpret_cast<uint2*>(hi_img + lds) = h;
+    *reinterpret_cast<uint2*>(lo_img + lds) = l;
+  }
+};
+
+typedef __bf16 ybf16x4 __attribute__((ext_vector_type(4)));
+
+// MFMA 32x32x16 operand fragment (lane: row/col l & 31, k = 8 (l >> 5) .. + 7) of the 32-wide tile starting at `mn` of an image
+template <bool KC>
+__device__ __forceinline__ bf16x8 yfrag(const __bf16* img, int mn, int lane) {
+  if (KC) {
+    return *reinterpret_cast<const bf16x8*>(img + (mn + (lane & 31)) * YROW + (lane >> 5) * 8);
+  } else {
+    // 16-lane group g = lane >> 4 covers columns mn + 16 (g & 1) .. + 15 and k rows 8 (g >> 1) .. + 7; lane 4q + p of the
+    // group supplies the address of row q, columns 4p .. 4p + 3 and receives column (lane & 15) of the four rows
+    const int i = lane & 15, q = i >> 2, pp = i & 3;
+    const __bf16* ptr = img + (8 * (lane >> 5) + q) * YPIT + mn + 16 * ((lane >> 4) & 1) + 4 * pp;
+    typedef __attribute__((address_space(3))) ybf16x4 lds_v4;
+    const ybf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4*)ptr);
+    const ybf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4*)(ptr + 4 * YPIT));
+    bf16x8 r;
+    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+    r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+    return r;
+  }
+}
+
+template <bool AKC, bool BKC>
+__global__ __launch_bounds__(1024, 4) void gemm_bf16x3_256_kernel(GemmArgs g) {
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, half = lane >> 5;
+  int tm, tn, batch, split;
+  gemm_tile_of_block(g, &tm, &tn, &batch, &split);
+  const int m0 = tm * 256, n0 = tn * 256;
+  const float* __restrict__ A = g.A + batch * g.strideA;
+  const float* __restrict__ B = g.B + batch * g.strideB;
+  const int kbeg = split * g.kchunk;
+  const int kend = min(g.K, kbeg + g.kchunk);
+  const int nkt = (kend - kbeg + YBK - 1) / YBK;
+
+  YStager<AKC> sa;
+  YStager<BKC> sb;
+  sa.init(tid, m0, g.M, g.lda);
+  sb.init(tid, n0, g.N, g.ldb);
+  const float* __restrict__ tA = AKC ? A + (long)m0 * g.lda + kbeg : A + (long)kbeg * g.lda + m0;
+  const float* __restrict__ tB = BKC ? B + (long)n0 * g.ldb + kbeg : B + (long)kbeg * g.ldb + n0;
+  const long stepA = AKC ? YBK : (long)YBK * g.lda, stepB = BKC ? YBK : (long)YBK * g.ldb;
+
+  f32x4 ra[YDEPTH], rb[YDEPTH];
+  auto load = [&](int kt, f32x4& xa, f32x4& xb) {
+    const int krem = kend - (kbeg + kt * YBK);
+    sa.load(tA + kt * stepA, krem, xa);
+    sb.load(tB + kt * stepB, krem, xb);
+  };
+  auto load_full = [&](int kt, f32x4& xa, f32x4& xb) {   // a k-tile known to be complete: no predicates at all
+    xa = *reinterpret_cast<const f32x4*>(tA + kt * stepA + sa.off);
+    xb = *reinterpret_cast<const f32x4*>(tB + kt * stepB + sb.off);
+  };
+  auto store = [&](int buf, const f32x4& xa, const f32x4& xb) {
+    __bf16* base = xsmem + buf * 4 * YIMG;
+    sa.store(base, base + YIMG, xa);
+    sb.store(base + 2 * YIMG, base + 3 * YIMG, xb);
+  };
+
+  const int wm = wave >> 2, wn = wave & 3;
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+  auto mma = [&](int buf) {
+    const __bf16* base = xsmem + buf * 4 * YIMG;
+    bf16x8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+    for (int t2 = 0; t2 < 2; ++t2) {
+      ah[t2] = yfrag<AKC>(base, wm * 64 + t2 * 32, lane);
+      al[t2] = yfrag<AKC>(base + YIMG, wm * 64 + t2 * 32, lane);
+      bh[t2] = yfrag<BKC>(base + 2 * YIMG, wn * 64 + t2 * 32, lane);
+      bl[t2] = yfrag<BKC>(base + 3 * YIMG, wn * 64 + t2 * 32, lane);
+    }
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt], bl[nt], acc[mt][nt], 0, 0, 0);
+        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+      }
+  };
+
+  // tile t lives in register set t % YDEPTH; at the top of iteration kt tile kt is already in LDS buffer kt & 1.
+  // Long K (the common case): prologue and steady state without a single conditional load, so that the compiler's
+  // s_waitcnt insertion can count the loads in flight (a conditional load anywhere on the path into the loop makes it fall
+  // back to vmcnt(0) before every store: the whole memory latency exposed once per k-tile, measured 6k cycles per
+  // iteration instead of 1.5k). The last YDEPTH + 1 .. 2 YDEPTH tiles and short products take the generic loop.
+  int kt0 = 0;
+  if (nkt > 2 * YDEPTH) {
+#pragma unroll
+    for (int t = 0; t < YDEPTH; ++t) load_full(t, ra[t], rb[t]);
+    store(0, ra[0], rb[0]);
+    __syncthreads();
+    for (; kt0 + 2 * YDEPTH < nkt; kt0 += YDEPTH) {   // strict: the last (possibly partial) k-tile is left to the drain loop
+#pragma unroll
+      for (int u = 0; u < YDEPTH; ++u) {
+        const int kt = kt0 + u;
+        load_full(kt + YDEPTH, ra[u], rb[u]);   // set u held tile kt: converted one iteration ago
+        __builtin_amdgcn_sched_barrier(0);      // keep the loads first: the scheduler otherwise sinks them below the store
+        mma(kt & 1);
+        __builtin_amdgcn_sched_barrier(0);
+        store((kt + 1) & 1, ra[(u + 1) % YDEPTH], rb[(u + 1) % YDEPTH]);
+        __syncthreads();
+      }
+    }
+  } else {
+#pragma unroll
+    for (int t = 0; t < YDEPTH; ++t)
+      if (t < nkt) load(t, ra[t], rb[t]);
+    if (nkt > 0) store(0, ra[0], rb[0]);
+    __syncthreads();
+  }
+  // drain / short products: loads only while tiles remain
+  for (; kt0 < nkt; kt0 += YDEPTH) {
+#pragma unroll
+    for (int u = 0; u < YDEPTH; ++u) {
+      const int kt = kt0 + u;
+      if (kt < nkt) {
+        if (kt + YDEPTH < nkt) load(kt + YDEPTH, ra[u], rb[u]);
+        mma(kt & 1);
+        if (kt + 1 < nkt) store((kt + 1) & 1, ra[(u + 1) % YDEPTH], rb[(u + 1) % YDEPTH]);
+        __syncthreads();
+      }
+    }
+  }
+  // 96 KB of LDS: 64 rows x 260 floats (66.5 KB) per pass of the wide epilogue
+  if (g.vecC) gemm_epilogue_wide<256, 1024>(g, acc, reinterpret_cast<float*>(xsmem), 64, m0, n0, wm, wn, l31, half, batch, split, 256);
+  else gemm_epilogue_n<256>(g, acc, m0, n0, wm, wn, l31, half, batch, split);
+}
+
 __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(GemmArgs g) {
   const long mn = (long)g.M * g.N;
   const int batch = blockIdx.y;
@@ -751,8 +951,44 @@ int kchunk_for(int K, int splitk) {
 
 }  // namespace
 
+// Tile shape and K split of a product. splitk_req > 0 is taken as given; 0 lets the library fill the chip: the score is
+// (share of the last round of co-resident workgroups that is used) x (relative rate of the tile shape) / (padding waste),
+// less 3 % per extra split for the reduce pass. shape: 0 = 128 x 128 (two workgroups per CU), 3 = 256 x 256 (bf16x3 only,
+// one per CU, ~12 % faster per MFMA on long products).
+struct GemmPlan { int shape, splitk; };
+GemmPlan gemm_plan(int M, int N, int K, int batch, int splitk_req, bool x3) {
+  static int allow256 = -1;
+  if (allow256 < 0) {
+    const char* e = getenv("LFI_GEMM_256");
+    allow256 = (e && e[0] == '0') ? 0 : 1;
+  }
+  GemmPlan best = {0, splitk_req > 0 ? splitk_req : 1};
+  double best_score = -1.0;
+  const int cand[6] = {1, 2, 3, 4, 6, 8};
+  for (int pass = 0; pass < 2; ++pass) {
+    const int shape = pass ? 3 : 0;
+    if (shape == 3 && !(x3 && allow256)) continue;
+    const int tile = shape == 3 ? 256 : 128;
+    const double slots = shape == 3 ? 256.0 : 512.0, rate = shape == 3 ? 1.12 : 1.0;
+    const double tiles = (double)lfi_cdiv(M, tile) * lfi_cdiv(N, tile) * batch;
+    const double waste = tiles * tile * tile / ((double)M * N * batch);
+    for (int ci = 0; ci < 6; ++ci) {
+      const int sk = splitk_req > 0 ? splitk_req : cand[ci];
+      if (splitk_req <= 0 && sk > 1 && K / sk < 512) break;
+      const double wg = tiles * sk;
+      const double rounds = (double)(long)((wg + slots - 1) / slots);
+      const double score = wg / (rounds * slots) * rate / waste * (1.0 - 0.03 * (sk - 1) * (splitk_req > 0 ? 0.0 : 1.0));
+      if (score > best_score + 1e-9) { best_score = score; best.shape = shape; best.splitk = sk; }
+      if (splitk_req > 0) break;
+    }
+  }
+  return best;
+}
+
 extern "C" long lfi_gemm_work_floats(const lfi_gemm_desc* d) {
-  if (!d || d->splitk <= 1) return 0;
+  if (!d) return 0;
+  if (d->splitk == 0) return 8L * d->batch * d->M * d->N;   // automatic split: room for the largest one
+  if (d->splitk <= 1) return 0;
   return (long)d->batch * d->splitk * d->M * d->N;
 }
 
@@ -765,7 +1001,16 @@ extern "C" int lfi_gemm_f32(const lfi_gemm_desc* d, void* stream) {
   LFI_REQUIRE(d->act >= 0 && d->act <= 2, "lfi_gemm_f32: bad act %d", d->act);
   LFI_REQUIRE(d->act != 2 || d->G, "lfi_gemm_f32: act 2 needs G");
   LFI_REQUIRE(d->batch <= 65535, "lfi_gemm_f32: batch %d too large", d->batch);
-  int splitk = d->splitk < 1 ? 1 : d->splitk;
+  auto vec_ok = [](const float* p, long ld, long stride, int kcontig, int mn, int K) {
+    if ((reinterpret_cast<uintptr_t>(p) & 15) || (ld & 3) || (stride & 3)) return 0;
+    const long need = kcontig ? K : mn;
+    return ld >= (need + 3) / 4 * 4 ? 1 : 0;
+  };
+  const int vecA = vec_ok(d->A, d->lda, d->strideA, d->a_kcontig, d->M, d->K);
+  const int vecB = vec_ok(d->B, d->ldb, d->strideB, d->b_kcontig, d->N, d->K);
+  const bool use_x3 = d->precision == 1 && vecA && vecB;
+  const GemmPlan plan = gemm_plan(d->M, d->N, d->K, d->batch, (d->splitk == 0 && !d->work) ? 1 : d->splitk, use_x3);
+  int splitk = plan.splitk < 1 ? 1 : plan.splitk;
   if (splitk > d->K / BKT) splitk = d->K / BKT < 1 ? 1 : d->K / BKT;
   LFI_REQUIRE(splitk == 1 || d->work, "lfi_gemm_f32: splitk needs a workspace");
   hipStream_t st = (hipStream_t)stream;
@@ -780,13 +1025,8 @@ extern "C" int lfi_gemm_f32(const lfi_gemm_desc* d, void* stream) {
   if (a.kchunk & 31) a.kchunk = (a.kchunk + 31) & ~31;  // also a whole number of bf16x3 k-tiles
   // the chunking may leave trailing splits empty: they still write zeros, which keeps the reduce simple
   a.work = d->work;
-  auto vec_ok = [](const float* p, long ld, long stride, int kcontig, int mn, int K) {
-    if ((reinterpret_cast<uintptr_t>(p) & 15) || (ld & 3) || (stride & 3)) return 0;
-    const long need = kcontig ? K : mn;
-    return ld >= (need + 3) / 4 * 4 ? 1 : 0;
-  };
-  a.vecA = vec_ok(d->A, d->lda, d->strideA, d->a_kcontig, d->M, d->K);
-  a.vecB = vec_ok(d->B, d->ldb, d->strideB, d->b_kcontig, d->N, d->K);
+  a.vecA = vecA;
+  a.vecB = vecB;
   {
     // C (or the split-K workspace) and G rows 16-byte aligned; act 2 together with accumulate stays on the narrow path
     const bool partial = splitk > 1;
@@ -795,14 +1035,14 @@ extern "C" int lfi_gemm_f32(const lfi_gemm_desc* d, void* stream) {
     const bool g_ok = d->act != 2 || ((reinterpret_cast<uintptr_t>(d->G) & 15) == 0 && d->ldg % 4 == 0 && d->strideG % 4 == 0);
     a.vecC = (c_ok && g_ok && !(d->act == 2 && d->accumulate != 0)) ? 1 : 0;
   }
-  const bool use_x3 = d->precision == 1 && a.vecA && a.vecB;
-  // tile shape: narrow outputs get the tall tile, short outputs the wide one (the bf16x3 kernel has one shape)
-  int shape = 0;  // 128 x 128
+  // tile shape: narrow outputs get the tall tile, short outputs the wide one; bf16x3: 128 x 128 or 256 x 256 by the plan
+  int shape = use_x3 ? plan.shape : 0;
   if (!use_x3) {
     if (d->N <= 64 && d->M > 128) shape = 1;       // 256 x 64
     else if (d->M <= 64 && d->N > 128) shape = 2;  // 64 x 256
   }
-  const int bm = shape == 0 ? 128 : (shape == 1 ? 256 : 64), bn = shape == 0 ? 128 : (shape == 1 ? 64 : 256);
+  const int bm = shape == 0 ? 128 : (shape == 1 ? 256 : (shape == 3 ? 256 : 64)),
+            bn = shape == 0 ? 128 : (shape == 1 ? 64 : 256);
   a.tiles_m = lfi_cdiv(d->M, bm);
   a.tiles_n = lfi_cdiv(d->N, bn);
   // (16-byte loads need: base pointer 16-byte aligned, leading dimension and batch stride multiples of 4 floats, every k
@@ -810,7 +1050,25 @@ extern "C" int lfi_gemm_f32(const lfi_gemm_desc* d, void* stream) {
   // floats past K (k-contiguous; zeroed before it reaches LDS) or past M/N (mn-contiguous; those LDS columns only feed
   // output rows/columns that are never stored) — see vec_ok above.)
   dim3 grid(a.tiles_m * a.tiles_n, d->batch, splitk);
-  if (use_x3) {
+  if (use_x3 && shape == 3) {
+    const size_t lds = (size_t)2 * 4 * YIMG * sizeof(__bf16);
+    static bool attr256 = false;
+    if (!attr256) {
+      hipError_t e1 = hipFuncSetAttribute((const void*)gemm_bf16x3_256_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipError_t e2 = hipFuncSetAttribute((const void*)gemm_bf16x3_256_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipError_t e3 = hipFuncSetAttribute((const void*)gemm_bf16x3_256_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipError_t e4 = hipFuncSetAttribute((const void*)gemm_bf16x3_256_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess) {
+        lfi_set_error("lfi_gemm_f32: cannot reserve %zu bytes of LDS for the 256 x 256 bf16x3 kernel", lds);
+        return LFI_ERR_LAUNCH;
+      }
+      attr256 = true;
+    }
+    if (d->a_kcontig && d->b_kcontig) hipLaunchKernelGGL((gemm_bf16x3_256_kernel<true, true>), grid, dim3(1024), lds, st, a);
+    else if (d->a_kcontig) hipLaunchKernelGGL((gemm_bf16x3_256_kernel<true, false>), grid, dim3(1024), lds, st, a);
+    else if (d->b_kcontig) hipLaunchKernelGGL((gemm_bf16x3_256_kernel<false, true>), grid, dim3(1024), lds, st, a);
+    else hipLaunchKernelGGL((gemm_bf16x3_256_kernel<false, false>), grid, dim3(1024), lds, st, a);
+  } else if (use_x3) {
     const size_t lds = (size_t)2 * 4 * XIMG * sizeof(__bf16);
     static bool attr_set = false;  // idempotent, per process: raise the dynamic-LDS cap of the four instantiations once
     if (!attr_set) {

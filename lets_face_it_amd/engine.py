@@ -258,8 +258,8 @@ class GlowEngine:
         g.accumulate, g.act, g.slope = accumulate, act, slope
         g.splitk = splitk
         g.precision = self.precision
-        if splitk > 1:
-            g.work = self._buf("scratch.gemm_splitk", batch * splitk * M * N).data_ptr()
+        if splitk > 1 or splitk == 0:  # 0: the library picks the split (and the tile shape) that fills the chip
+            g.work = self._buf("scratch.gemm_splitk", batch * max(splitk, 8) * M * N).data_ptr()
         ev = self._tic(tag)
         check(self.L.lfi_gemm_f32(C.byref(g), _stream()), "lfi_gemm_f32")
         self._toc(tag, ev)
@@ -447,8 +447,7 @@ class GlowEngine:
         dpre = ctx.cbuf
         # cond_transform weight / bias gradients for all steps at once
         dwf = self._buf("dwct_f", KD * s.ldf)
-        self.gemm(KD, s.Ef, F, dpre, KD, 0, ctx.cond, s.ldf, 0, dwf, s.ldf, tag="gemm_cond_wgrad",
-                  splitk=self._fill_splitk(KD, s.Ef, F))
+        self.gemm(KD, s.Ef, F, dpre, KD, 0, ctx.cond, s.ldf, 0, dwf, s.ldf, tag="gemm_cond_wgrad", splitk=0)
         # both copies of a duplicated input column receive the folded column's gradient
         check(self.L.lfi_cols_fold(dwf.data_ptr(), s.ldf, KD, self.unfold.data_ptr(), None, s.E,
                                    self.fview("wct", self.grads).data_ptr(), s.E, st), "lfi_cols_fold")
@@ -462,7 +461,7 @@ class GlowEngine:
             dcond = self._buf("dcond", F * ldd)
             # 112 x 5 tiles = 1.09 rounds of the 512 resident workgroups: split K so the tail round is full too
             self.gemm(F, W, KD, dpre, KD, 1, self.wct_f, s.ldf, 0, dcond, ldd, b_off=col0, tag="gemm_cond_dgrad",
-                      splitk=self._tail_splitk(F, W, KD))
+                      splitk=0)
             for e in rnn:
                 self._encoder_backward(e, ctx, dcond, ldd, e.fcol - col0)
 
