@@ -223,6 +223,21 @@ __global__ __launch_bounds__(256) void enc_pad_weights_kernel(const float* __res
 
 __device__ __forceinline__ int enc_rowl(int rg, int r, int half) { return rg * 32 + (r & 3) + 8 * (r >> 2) + 4 * half; }
 
+// Raw buffer access for the gate epilogues: a uniform 128-bit resource (base + size) in SGPRs, one 32-bit byte offset per
+// lane and a uniform SGPR offset on top. The plain-pointer form cost ~20 VALU instructions of 64-bit address arithmetic
+// per access (60 % of the epilogue's instructions; rocprof: these kernels are VALU-issue bound, not HBM or MFMA bound).
+// Accesses past `bytes` read 0 / are dropped by the hardware.
+typedef __amdgpu_buffer_rsrc_t enc_rsrc;
+__device__ __forceinline__ enc_rsrc enc_buf(const void* p, long bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)(bytes > 0xfffffff0L ? 0xfffffff0L : bytes), 0x00020000);
+}
+__device__ __forceinline__ float enc_ld(enc_rsrc r, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+__device__ __forceinline__ void enc_st(float v, enc_rsrc r, unsigned voff, unsigned soff) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, voff, soff, 0);
+}
+
 template <bool STASH, bool MASK, bool X3>
 __global__ __launch_bounds__(ENC_NT, 2) void enc_gru_fwd_fused_kernel(EncArgs a, EncFused q) {
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -240,6 +255,18 @@ __global__ __launch_bounds__(ENC_NT, 2) void enc_gru_fwd_fused_kernel(EncArgs a,
   __bf16* Xlo = Xhi + q.R * ldx;
   if (X3)
     for (int i = tid; i < q.R * ldx; i += ENC_NT) { Xhi[i] = (__bf16)0.0f; Xlo[i] = (__bf16)0.0f; }
+  // per-row byte offsets (rows past F are clamped to the last window: they recompute and re-store its values):
+  // rowx = start of the window's step-0 input projection row in Xp, roww = w * hid * 4
+  unsigned* rowx = reinterpret_cast<unsigned*>(X3 ? reinterpret_cast<float*>(Xlo + q.R * ldx) : enc_smem + q.Kp * ldk);
+  unsigned* roww = rowx + q.R;
+  unsigned* rowm = roww + q.R;   // w * hist * 4 (dropout mask row)
+  for (int i = tid; i < q.R; i += ENC_NT) {
+    const int w = min(wbase + i, a.F - 1);
+    const int n = w / a.B, b = w - n * a.B;
+    rowx[i] = (unsigned)(b * a.T + pos0 + n) * (unsigned)(G3 * 4);
+    roww[i] = (unsigned)w * (unsigned)(hid * 4);
+    rowm[i] = (unsigned)w * (unsigned)(a.hist * 4);
+  }
 
   float bi[2][3], bh[2][3];
 #pragma unroll
@@ -293,12 +320,25 @@ __global__ __launch_bounds__(ENC_NT, 2) void enc_gru_fwd_fused_kernel(EncArgs a,
             acc[t][g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, f[t][g][0].v, acc[t][g], 0, 0, 0);
           }
       };
+      // every load in the steady-state loop is unconditional: with a conditional load the compiler cannot count the loads
+      // in flight and waits for ALL of them (vmcnt(0)) before the MFMAs, i.e. for the fragments it has just requested
       load(0, ah0, al0, f0);
-      for (int kt = 0; kt < nkt; kt += 2) {
-        if (kt + 1 < nkt) load(kt + 1, ah1, al1, f1);
+      int kt = 0;
+      for (; kt + 2 < nkt; kt += 2) {
+        load(kt + 1, ah1, al1, f1);
+        __builtin_amdgcn_sched_barrier(0);
         mma(ah0, al0, f0);
-        if (kt + 2 < nkt) load(kt + 2, ah0, al0, f0);
-        if (kt + 1 < nkt) mma(ah1, al1, f1);
+        load(kt + 2, ah0, al0, f0);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(ah1, al1, f1);
+      }
+      if (kt + 1 < nkt) {
+        load(kt + 1, ah1, al1, f1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(ah0, al0, f0);
+        mma(ah1, al1, f1);
+      } else {
+        mma(ah0, al0, f0);
       }
     }
     if (!X3 && s > 0) {
@@ -327,39 +367,47 @@ __global__ __launch_bounds__(ENC_NT, 2) void enc_gru_fwd_fused_kernel(EncArgs a,
           }
       };
       load(0, a0, b0);
-      for (int kp = 0; kp < nkp; kp += 2 * ENC_KC) {
+      int kp = 0;
+      for (; kp + 2 * ENC_KC < nkp; kp += 2 * ENC_KC) {   // unconditional loads (see the bf16x3 loop)
         load(kp + ENC_KC, a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
         mma(a0, b0);
-        if (kp + 2 * ENC_KC < nkp) load(kp + 2 * ENC_KC, a0, b0);
+        load(kp + 2 * ENC_KC, a0, b0);
+        __builtin_amdgcn_sched_barrier(0);
         mma(a1, b1);
       }
+      load(kp + ENC_KC, a1, b1);
+      __builtin_amdgcn_sched_barrier(0);
+      mma(a0, b0);
+      mma(a1, b1);
     }
     __syncthreads();  // every wave has finished reading h_{s-1}
     // gate math on the accumulators in four straight-line groups (one hidden sub-tile x 8 registers each: 40 loads in
-    // flight per lane). Rows past F are clamped to the last window (they recompute and re-store its values). The lane
-    // coordinates are laundered through an empty asm so that the per-register address arithmetic stays inside the step
-    // loop instead of being hoisted into ~100 loop-invariant registers (which spilled).
+    // flight per lane). The lane coordinates are laundered through an empty asm so that the per-register address arithmetic
+    // stays inside the step loop instead of being hoisted into ~100 loop-invariant registers (which spilled).
     int halfv = half, jv = jb;
     asm volatile("" : "+v"(halfv), "+v"(jv));
-    const float* __restrict__ xs = a.Xp + (long)(pos0 + s) * G3;                 // uniform bases of this step
-    float* __restrict__ hs = STASH ? a.hseq + (long)s * a.F * hid : nullptr;
-    float* __restrict__ gsb = STASH ? a.gates + (long)s * a.F * 4 * hid : nullptr;
-    const float* __restrict__ ms = MASK ? a.mask + s : nullptr;
+    const enc_rsrc bx = enc_buf(a.Xp, (long)a.B * a.T * G3 * 4);
+    const enc_rsrc bhs = enc_buf(STASH ? a.hseq + (long)s * a.F * hid : nullptr, STASH ? (long)a.F * hid * 4 : 0);
+    const enc_rsrc bgs = enc_buf(STASH ? a.gates + (long)s * a.F * 4 * hid : nullptr, STASH ? (long)a.F * hid * 16 : 0);
+    const enc_rsrc bms = enc_buf(MASK ? a.mask : nullptr, MASK ? (long)a.F * a.hist * 4 : 0);
+    const unsigned sx = (unsigned)s * (unsigned)(G3 * 4), h4 = (unsigned)hid * 4u;
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       const int j = jv + 32 * t;
       if (j < hid) {
+        const unsigned j4 = (unsigned)j * 4u;
 #pragma unroll
         for (int rh = 0; rh < 2; ++rh) {
           float xr[8], xu[8], xn[8], mk[8], hp[8];
+          unsigned wo[8];
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
             const int rl = enc_rowl(rg, rh * 8 + e, halfv);
-            const int w = min(wbase + rl, a.F - 1);
-            const int n = w / a.B, b = w - n * a.B;
-            const unsigned xo = (unsigned)(b * a.T + n) * (unsigned)G3 + (unsigned)j;
-            xr[e] = xs[xo]; xu[e] = (xs + hid)[xo]; xn[e] = (xs + 2 * hid)[xo];
-            mk[e] = MASK ? ms[(unsigned)(w * a.hist)] : 1.0f;
+            const unsigned xo = rowx[rl] + j4;
+            wo[e] = roww[rl];
+            xr[e] = enc_ld(bx, xo, sx); xu[e] = enc_ld(bx, xo, sx + h4); xn[e] = enc_ld(bx, xo, sx + 2 * h4);
+            mk[e] = MASK ? enc_ld(bms, rowm[rl], (unsigned)s * 4u) : 1.0f;
             hp[e] = Als[j * ldk + rl];  // zero at s = 0
           }
 #pragma unroll
@@ -372,10 +420,9 @@ __global__ __launch_bounds__(ENC_NT, 2) void enc_gru_fwd_fused_kernel(EncArgs a,
             const float nn = tanhf_(mk[e] * xn[e] + bi[t][2] + rr * ghn);
             const float hnew = (1.0f - uu) * nn + uu * hp[e];
             if (STASH) {
-              const unsigned w = (unsigned)min(wbase + rl, a.F - 1);
-              hs[w * (unsigned)hid + (unsigned)j] = hnew;
-              const unsigned go = w * (unsigned)(4 * hid) + (unsigned)j;
-              gsb[go] = rr; (gsb + hid)[go] = uu; (gsb + 2 * hid)[go] = nn; (gsb + 3 * hid)[go] = ghn;
+              enc_st(hnew, bhs, wo[e] + j4, 0);
+              const unsigned go = 4u * wo[e] + j4;
+              enc_st(rr, bgs, go, 0); enc_st(uu, bgs, go, h4); enc_st(nn, bgs, go, 2 * h4); enc_st(ghn, bgs, go, 3 * h4);
             }
             Als[j * ldk + rl] = hnew;
             if (X3) {
@@ -425,6 +472,13 @@ __global__ __launch_bounds__(ENC_NT, 2) void enc_gru_bwd_fused_kernel(EncArgs a,
   } else {
     for (int i = tid; i < q.Kp * ldk; i += ENC_NT) Dls[i] = 0.0f;
   }
+  // roww[row] = w * hid * 4 (rows past F clamped), live[row] = 1 for real windows (bias sums skip the clamped duplicates)
+  unsigned* roww = X3 ? reinterpret_cast<unsigned*>(Xlo + q.R * ldx) : reinterpret_cast<unsigned*>(enc_smem + q.Kp * ldk);
+  float* rlive = reinterpret_cast<float*>(roww + q.R);
+  for (int i = tid; i < q.R; i += ENC_NT) {
+    roww[i] = (unsigned)min(wbase + i, a.F - 1) * (unsigned)(hid * 4);
+    rlive[i] = wbase + i < a.F ? 1.0f : 0.0f;
+  }
   const int boff = half * Jp + jb;
   const int aoff = half * ldk + rg * 32 + l31;
   const int nkp = q.Kp >> 1;
@@ -453,34 +507,36 @@ __global__ __launch_bounds__(ENC_NT, 2) void enc_gru_bwd_fused_kernel(EncArgs a,
     f32x16 acc[2];
     const float hp_on = s > 0 ? 1.0f : 0.0f;
     const int sp = s > 0 ? s - 1 : 0;
-    // uniform bases of this step + 32-bit per-lane offsets (saddr addressing); lane coordinates laundered so that the
+    // uniform buffer resources of this step + 32-bit per-lane byte offsets; lane coordinates laundered so that the
     // per-register address arithmetic is not hoisted out of the step loop (see the forward kernel)
     int halfv = half, jv = jb;
     asm volatile("" : "+v"(halfv), "+v"(jv));
-    const float* __restrict__ gsb = a.gates + (long)s * a.F * 4 * hid;
-    const float* __restrict__ hpb = a.hseq + (long)sp * a.F * hid;
-    float* __restrict__ gib = a.dgi + (long)s * a.F * G3;
-    float* __restrict__ ghb = a.dgh + (long)s * a.F * G3;
+    const enc_rsrc bgs = enc_buf(a.gates + (long)s * a.F * 4 * hid, (long)a.F * hid * 16);
+    const enc_rsrc bhp = enc_buf(a.hseq + (long)sp * a.F * hid, (long)a.F * hid * 4);
+    const enc_rsrc bgi = enc_buf(a.dgi + (long)s * a.F * G3, (long)a.F * G3 * 4);
+    const enc_rsrc bgh = enc_buf(a.dgh + (long)s * a.F * G3, (long)a.F * G3 * 4);
+    const unsigned h4 = (unsigned)hid * 4u;
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       const int j = jv + 32 * t;
       if (j < hid) {
+        const unsigned j4 = (unsigned)j * 4u;
 #pragma unroll
         for (int rh = 0; rh < 2; ++rh) {
-          float gr[8], gu[8], gn[8], gg[8], hp[8];
+          float gr[8], gu[8], gn[8], gg[8], hp[8], live[8];
+          unsigned wo[8];
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
-            const unsigned w = (unsigned)min(wbase + enc_rowl(rg, rh * 8 + e, halfv), a.F - 1);
-            const unsigned go = w * (unsigned)(4 * hid) + (unsigned)j;
-            gr[e] = gsb[go]; gu[e] = (gsb + hid)[go]; gn[e] = (gsb + 2 * hid)[go]; gg[e] = (gsb + 3 * hid)[go];
-            hp[e] = hpb[w * (unsigned)hid + (unsigned)j];
+            const int rl = enc_rowl(rg, rh * 8 + e, halfv);
+            wo[e] = roww[rl];
+            live[e] = rlive[rl];
+            const unsigned go = 4u * wo[e] + j4;
+            gr[e] = enc_ld(bgs, go, 0); gu[e] = enc_ld(bgs, go, h4); gn[e] = enc_ld(bgs, go, 2 * h4); gg[e] = enc_ld(bgs, go, 3 * h4);
+            hp[e] = enc_ld(bhp, wo[e] + j4, 0);
           }
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
             const int r = rh * 8 + e;
-            const int wr = wbase + enc_rowl(rg, r, halfv);
-            const unsigned w = (unsigned)min(wr, a.F - 1);
-            const float live = wr < a.F ? 1.0f : 0.0f;   // clamped duplicate rows do not count in the bias sums
             const float rr = gr[e], uu = gu[e], nn = gn[e], ghn = gg[e];
             const float dhn = dh[t][r];
             const float du = dhn * (hp[e] * hp_on - nn);
@@ -489,9 +545,9 @@ __global__ __launch_bounds__(ENC_NT, 2) void enc_gru_bwd_fused_kernel(EncArgs a,
             const float dau = du * uu * (1.0f - uu);
             const float dar = dan * ghn * rr * (1.0f - rr);
             const float danr = dan * rr;
-            const unsigned o = w * (unsigned)G3 + (unsigned)j;
-            gib[o] = dar; (gib + hid)[o] = dau; (gib + 2 * hid)[o] = dan;
-            ghb[o] = dar; (ghb + hid)[o] = dau; (ghb + 2 * hid)[o] = danr;
+            const unsigned o = 3u * wo[e] + j4;
+            enc_st(dar, bgi, o, 0); enc_st(dau, bgi, o, h4); enc_st(dan, bgi, o, 2 * h4);
+            enc_st(dar, bgh, o, 0); enc_st(dau, bgh, o, h4); enc_st(danr, bgh, o, 2 * h4);
             dg[0][t][r] = dau; dg[1][t][r] = danr;
             if (s > 0) {
               const int rl = enc_rowl(rg, r, halfv);
@@ -504,7 +560,7 @@ __global__ __launch_bounds__(ENC_NT, 2) void enc_gru_bwd_fused_kernel(EncArgs a,
               }
             }
             acc[t][r] = dhn * uu;
-            bsum[0][t] += live * dar; bsum[1][t] += live * dau; bsum[2][t] += live * dan; bsum[3][t] += live * danr;
+            bsum[0][t] += live[e] * dar; bsum[1][t] += live[e] * dau; bsum[2][t] += live[e] * dan; bsum[3][t] += live[e] * danr;
           }
           __builtin_amdgcn_sched_barrier(0);
         }
@@ -560,11 +616,22 @@ __global__ __launch_bounds__(ENC_NT, 2) void enc_gru_bwd_fused_kernel(EncArgs a,
           }
         };
         load(0, ah0, al0, f0);
-        for (int kt = 0; kt < nkt; kt += 2) {
-          if (kt + 1 < nkt) load(kt + 1, ah1, al1, f1);
+        int kt = 0;
+        for (; kt + 2 < nkt; kt += 2) {   // unconditional loads (see the forward kernel)
+          load(kt + 1, ah1, al1, f1);
+          __builtin_amdgcn_sched_barrier(0);
           mma(ah0, al0, f0);
-          if (kt + 2 < nkt) load(kt + 2, ah0, al0, f0);
-          if (kt + 1 < nkt) mma(ah1, al1, f1);
+          load(kt + 2, ah0, al0, f0);
+          __builtin_amdgcn_sched_barrier(0);
+          mma(ah1, al1, f1);
+        }
+        if (kt + 1 < nkt) {
+          load(kt + 1, ah1, al1, f1);
+          __builtin_amdgcn_sched_barrier(0);
+          mma(ah0, al0, f0);
+          mma(ah1, al1, f1);
+        } else {
+          mma(ah0, al0, f0);
         }
       } else {
         float a0[ENC_KC], a1[ENC_KC], b0[ENC_KC][2], b1[ENC_KC][2];
@@ -588,12 +655,19 @@ __global__ __launch_bounds__(ENC_NT, 2) void enc_gru_bwd_fused_kernel(EncArgs a,
           }
         };
         load(0, a0, b0);
-        for (int kp = 0; kp < nkp; kp += 2 * ENC_KC) {
+        int kp = 0;
+        for (; kp + 2 * ENC_KC < nkp; kp += 2 * ENC_KC) {
           load(kp + ENC_KC, a1, b1);
+          __builtin_amdgcn_sched_barrier(0);
           mma(a0, b0);
-          if (kp + 2 * ENC_KC < nkp) load(kp + 2 * ENC_KC, a0, b0);
+          load(kp + 2 * ENC_KC, a0, b0);
+          __builtin_amdgcn_sched_barrier(0);
           mma(a1, b1);
         }
+        load(kp + ENC_KC, a1, b1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(a0, b0);
+        mma(a1, b1);
       }
       __syncthreads();  // before the next gate overwrites Dls
     }
@@ -679,7 +753,8 @@ extern "C" int lfi_encode_windows_fwd(const lfi_enc_desc* d, const float* Xp, co
                             1, work);
     q.wpad = work;
     q.wfrag = reinterpret_cast<const uint4*>(work);
-    const size_t lds = (size_t)q.Kp * (q.R + 1) * sizeof(float) + (x3 ? (size_t)2 * q.R * (q.Kp + 8) * sizeof(__bf16) : 0);
+    const size_t lds = (size_t)q.Kp * (q.R + 1) * sizeof(float) + (x3 ? (size_t)2 * q.R * (q.Kp + 8) * sizeof(__bf16) : 0) +
+                       (size_t)3 * q.R * sizeof(unsigned);   // state images + per-row offset tables
     const dim3 grid(lfi_cdiv(F, q.R));
     const int variant = (gates ? 4 : 0) | (mask ? 2 : 0) | (x3 ? 1 : 0);
     rc = LFI_OK;
@@ -745,7 +820,8 @@ extern "C" int lfi_encode_windows_bwd(const lfi_enc_desc* d, const float* dcond,
                             0, work);
     q.wpad = work;
     q.wfrag = reinterpret_cast<const uint4*>(work);
-    const size_t ldsf = (size_t)q.Kp * (q.R + 1) * sizeof(float), ldsx = (size_t)2 * q.R * (q.Kp + 8) * sizeof(__bf16);
+    const size_t tab = (size_t)2 * q.R * sizeof(unsigned);   // per-row offset / liveness tables
+    const size_t ldsf = (size_t)q.Kp * (q.R + 1) * sizeof(float) + tab, ldsx = (size_t)2 * q.R * (q.Kp + 8) * sizeof(__bf16) + tab;
     if (x3) {
       if ((rc = enc_set_lds(enc_gru_bwd_fused_kernel<true>, ldsx))) return rc;
       hipLaunchKernelGGL(enc_gru_bwd_fused_kernel<true>, dim3(lfi_cdiv(F, q.R)), dim3(ENC_NT), ldsx, st, a, q);
