@@ -109,10 +109,15 @@ int lfi_encode_windows_bwd(const lfi_enc_desc* d, const float* dcond, int lddcon
 long lfi_encode_windows_bias_rows(const lfi_enc_desc* d);
 /* dXp[b*T + p] = sum over the windows (n, s) that read row p of mask * dgi[(n*B+b)*hist + s]   (B*T x 3*hid) */
 int lfi_encode_windows_scatter(const lfi_enc_desc* d, const float* dgi, const float* mask, float* dXp, void* stream);
-/* "enc: none" modality (glow/models.py:76-77) and the flattened p1_face history (glow/models.py:601-603):
- * cond[f, col + s*dim + c] = X[b, start + n - hist + s + incl, c]   (incl = 0 for prev_p1_face, 1 otherwise) */
-int lfi_gather_windows(const float* X, int B, int T, int dim, int N, int start, int hist, int incl,
+/* "enc: none" modality (glow/models.py:76-77), the flattened p1_face history (glow/models.py:601-603) and the input of an
+ * "enc: mlp" modality (glow/models.py:70-71):
+ * cond[f, col + s*dim + c] = mask[f, s] * X[b, start + n - hist + s + incl, c]   (incl = 0 for prev_p1_face, 1 otherwise;
+ * mask (F x hist) = the dropout multipliers of glow/models.py:56-58, or NULL) */
+int lfi_gather_windows(const float* X, int B, int T, int dim, int N, int start, int hist, int incl, const float* mask,
                        float* cond, int ldcond, int col, void* stream);
+/* d[r, c] *= (y[r, c] > 0 ? 1 : slope): backward of the LeakyReLU of an "enc: mlp" modality, in place on the feature
+ * gradient block (its weight / bias gradients then follow from lfi_gemm_f32 / lfi_colsum_f32). */
+int lfi_leaky_grad(float* d, long ldd, const float* y, long ldy, int rows, int cols, float slope, void* stream);
 
 /* ---------------------------------------------------------------- flow (FlowStep / FlowNet / Glow, glow/models.py:217-521)
  * Parameters of the Ks = K*L flow steps are struct-of-arrays, step-major: e.g. whh is [Ks][3H][H].
@@ -198,12 +203,26 @@ int lfi_flow_step(const lfi_flow_dims* d, const lfi_flow_params* p, const float*
  * (nframes*B) x (Ks*D), frame-major), gic = c W_ih[:, Ch:]^T + b_ih, then the Ks reverse flow steps from the
  * injected prior noise (nframes x B x C, already scaled by eps_std). h: [Ks][B][H] recurrent state, zero on entry.
  * Only "enc: none" for p1_face (all shipped hparams). work: lfi_flow_sample_work_floats floats. */
+/* The autoregressive prev_p1_face window may itself go through a ModalityEncoder (the reference's hparam search draws
+ * p1_face "enc" from {rnn, mlp, none}, hparam_tuning_configs/large_hparam_search.py:45-62): then its features are
+ * recomputed for every generated frame. kind 0: "none" (raw window); 1: "mlp" = LeakyReLU(window W1^T + b1);
+ * 2: "rnn" = GRU from h0 = 0 over the window (output folded: the hidden state once). `col` = first column of the
+ * p1_face block in the (folded) feature layout / in wct; eval mode (no dropout), as SeqGlow.inference runs. */
+typedef struct {
+  int kind, hid;
+  const float *w1, *b1;                        /* mlp: [hid][hist1*C], [hid] */
+  const float *w_ih, *w_hh, *b_ih, *b_hh;      /* rnn: [3hid][C], [3hid][hid], [3hid], [3hid] */
+  int col;
+} lfi_p1enc;
+
 long lfi_flow_sample_work_floats(const lfi_flow_dims* d);
+long lfi_flow_sample_p1_work_floats(const lfi_flow_dims* d, const lfi_p1enc* e, int hist1);
 int lfi_flow_sample_seq(const lfi_flow_dims* d, const lfi_flow_params* p, const float* prep,
                         const float* wct /* [Ks*D][E] */, long E, int hist1,
                         const float* pre_static, const float* noise,
                         float* faces, int seq_len, int start, int nframes,
                         float* h, float* cstate /* [Ks][B][H] LSTM cell state, zero on entry; NULL for GRU */,
+                        const lfi_p1enc* p1 /* NULL = "none" */, float* p1work /* lfi_flow_sample_p1_work_floats */,
                         float* work, void* stream);
 
 /* ---------------------------------------------------------------- optimiser (configure_optimizers, glow/lets_face_it_glow.py:61-72)

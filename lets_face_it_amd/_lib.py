@@ -47,6 +47,11 @@ _FLOW_GRAD_FIELDS = ["an_bias", "an_logs", "inv_l", "inv_u", "inv_logs", "inv_w"
                      "w_ih", "w_hh", "b_ih", "b_hh", "w_fl", "b_fl", "l_fl"]
 
 
+class P1Enc(C.Structure):
+    _fields_ = [("kind", C.c_int), ("hid", C.c_int), ("w1", C.c_void_p), ("b1", C.c_void_p), ("w_ih", C.c_void_p),
+                ("w_hh", C.c_void_p), ("b_ih", C.c_void_p), ("b_hh", C.c_void_p), ("col", C.c_int)]
+
+
 class FlowParams(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in _FLOW_PARAM_FIELDS]
 
@@ -87,7 +92,8 @@ def lib():
         "lfi_encode_windows_bwd": (i, [P(EncDesc), vp, i, vp, vp, vp, vp, vp, vp, vp, vp]),
         "lfi_encode_windows_bias_rows": (l, [P(EncDesc)]),
         "lfi_encode_windows_scatter": (i, [P(EncDesc), vp, vp, vp, vp]),
-        "lfi_gather_windows": (i, [vp, i, i, i, i, i, i, i, vp, i, i, vp]),
+        "lfi_gather_windows": (i, [vp, i, i, i, i, i, i, i, vp, vp, i, i, vp]),
+        "lfi_leaky_grad": (i, [vp, l, vp, l, i, i, f, vp]),
         "lfi_flow_prep_floats": (l, [P(FlowDims)]),
         "lfi_flow_prep": (i, [P(FlowDims), P(FlowParams), vp, i, vp]),
         "lfi_flow_stash_floats": (l, [P(FlowDims)]),
@@ -102,7 +108,9 @@ def lib():
         "lfi_actnorm_init_apply": (i, [vp, d, i, f, vp, vp, vp]),
         "lfi_flow_step": (i, [P(FlowDims), P(FlowParams), vp, i, i, vp, l, vp, vp, vp, vp, l, vp, vp, vp, i, vp]),
         "lfi_flow_sample_work_floats": (l, [P(FlowDims)]),
-        "lfi_flow_sample_seq": (i, [P(FlowDims), P(FlowParams), vp, vp, l, i, vp, vp, vp, i, i, i, vp, vp, vp, vp]),
+        "lfi_flow_sample_p1_work_floats": (l, [P(FlowDims), P(P1Enc), i]),
+        "lfi_flow_sample_seq": (i, [P(FlowDims), P(FlowParams), vp, vp, l, i, vp, vp, vp, i, i, i, vp, vp, P(P1Enc), vp, vp,
+                                    vp]),
         "lfi_grad_sumsq": (i, [vp, l, vp, vp, vp]),
         "lfi_adam_clip_step": (i, [vp, vp, vp, vp, l, vp, f, f, f, f, f, f, i, vp]),
         "lfi_selftest_mfma": (i, [vp, vp]),
@@ -120,11 +128,11 @@ EXPORTS = [
     "lfi_last_error", "lfi_version", "lfi_gemm_work_floats", "lfi_gemm_f32", "lfi_colsum_work_floats",
     "lfi_colsum_f32", "lfi_cols_fold", "lfi_encode_windows_work_floats", "lfi_encode_windows_fwd", "lfi_encode_windows_bwd",
     "lfi_encode_windows_bias_rows",
-    "lfi_encode_windows_scatter", "lfi_gather_windows", "lfi_flow_prep_floats", "lfi_flow_prep",
+    "lfi_encode_windows_scatter", "lfi_gather_windows", "lfi_leaky_grad", "lfi_flow_prep_floats", "lfi_flow_prep",
     "lfi_flow_stash_floats", "lfi_flow_bstash_floats", "lfi_flow_stash_ptr", "lfi_flow_bstash_ptr",
     "lfi_flow_seq_fwd", "lfi_flow_seq_bwd", "lfi_flow_param_grads_work_floats", "lfi_flow_param_grads",
     "lfi_actnorm_init_stats", "lfi_actnorm_init_apply", "lfi_flow_step", "lfi_flow_sample_work_floats",
-    "lfi_flow_sample_seq", "lfi_grad_sumsq", "lfi_adam_clip_step", "lfi_selftest_mfma", "lfi_debug_set_stamps",
+    "lfi_flow_sample_p1_work_floats", "lfi_flow_sample_seq", "lfi_grad_sumsq", "lfi_adam_clip_step", "lfi_selftest_mfma", "lfi_debug_set_stamps",
 ]
 
 

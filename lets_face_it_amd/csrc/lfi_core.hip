@@ -13,6 +13,8 @@ void lfi_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
+unsigned long long* g_lfi_stamps = nullptr;
+
 extern "C" const char* lfi_last_error(void) { return g_err; }
 extern "C" int lfi_version(void) { return 100; }
 

@@ -30,7 +30,12 @@ struct EncArgs {
   float* dgi;          // [hist][F][3hid]
   float* dgh;          // [hist][F][3hid]
   float* bias_part;    // fused backward only: [workgroups * row groups][4][hid] partial sums of dar, dau, dan, dan*r (or null)
+  unsigned long long* stamps;  // diagnostics only
 };
+#define ENC_STAMP(slot)                                                                                          \
+  do {                                                                                                           \
+    if (a.stamps && tid == 0 && blockIdx.x == 0 && s == 5) a.stamps[128 + (slot)] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
 
 // One GRU step for every window. gh: F x 3hid = h_{s-1} W_hh^T (no bias), or null at s = 0 (h = 0).
 __global__ __launch_bounds__(256) void enc_gate_fwd_kernel(EncArgs a, int s, const float* __restrict__ gh) {
@@ -144,7 +149,8 @@ __global__ __launch_bounds__(256) void enc_scatter_kernel(EncArgs a, float* __re
 }
 
 __global__ __launch_bounds__(256) void gather_windows_kernel(const float* __restrict__ X, int B, int T, int dim, int N, int start,
-                                                             int hist, int incl, float* __restrict__ cond, int ldcond, int col) {
+                                                             int hist, int incl, const float* __restrict__ mask,
+                                                             float* __restrict__ cond, int ldcond, int col) {
   const int f = blockIdx.x;  // n*B + b
   const int n = f / B, b = f - n * B;
   const int t0 = start + n - hist + incl;
@@ -152,7 +158,22 @@ __global__ __launch_bounds__(256) void gather_windows_kernel(const float* __rest
   // window rows are consecutive frames of one sample: one contiguous run of hist*dim floats
   const float* src = X + ((long)b * T + t0) * dim;
   float* dst = cond + (long)f * ldcond + col;
-  for (int i = threadIdx.x; i < tot; i += 256) dst[i] = src[i];
+  if (mask) {  // dropout multiplier per (window, history step) (glow/models.py:56-58)
+    const float* mk = mask + (long)f * hist;
+    for (int i = threadIdx.x; i < tot; i += 256) dst[i] = src[i] * mk[i / dim];
+  } else {
+    for (int i = threadIdx.x; i < tot; i += 256) dst[i] = src[i];
+  }
+}
+
+__global__ __launch_bounds__(256) void leaky_grad_kernel(float* __restrict__ d, long ldd, const float* __restrict__ y, long ldy, int rows,
+                                                         int cols, float slope) {
+  const long total = (long)rows * cols;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const long r = idx / cols;
+    const int c = (int)(idx - r * cols);
+    if (!(y[r * ldy + c] > 0.0f)) d[r * ldd + c] *= slope;
+  }
 }
 
 
@@ -284,6 +305,7 @@ __global__ __launch_bounds__(ENC_NT, 2) void enc_gru_fwd_fused_kernel(EncArgs a,
   __syncthreads();
 
   for (int s = 0; s < a.hist; ++s) {
+    ENC_STAMP(0);
     f32x16 acc[2][3];
 #pragma unroll
     for (int t = 0; t < 2; ++t)
@@ -381,7 +403,9 @@ __global__ __launch_bounds__(ENC_NT, 2) void enc_gru_fwd_fused_kernel(EncArgs a,
       mma(a0, b0);
       mma(a1, b1);
     }
+    ENC_STAMP(1);
     __syncthreads();  // every wave has finished reading h_{s-1}
+    ENC_STAMP(2);
     // gate math on the accumulators in four straight-line groups (one hidden sub-tile x 8 registers each: 40 loads in
     // flight per lane). The lane coordinates are laundered through an empty asm so that the per-register address arithmetic
     // stays inside the step loop instead of being hoisted into ~100 loop-invariant registers (which spilled).
@@ -432,10 +456,12 @@ __global__ __launch_bounds__(ENC_NT, 2) void enc_gru_fwd_fused_kernel(EncArgs a,
             }
           }
           __builtin_amdgcn_sched_barrier(0);
+          ENC_STAMP(3 + t * 2 + rh);
         }
       }
     }
     __syncthreads();
+    ENC_STAMP(7);
   }
   // cat(seq[:, -1], h_n[0]): the final state, once or twice (glow/models.py:63-64), straight from LDS
   for (int idx = tid; idx < q.R * hid; idx += ENC_NT) {
@@ -740,6 +766,7 @@ extern "C" int lfi_encode_windows_fwd(const lfi_enc_desc* d, const float* Xp, co
   if (rc) return rc;
   LFI_REQUIRE(Xp && whh && b_ih && b_hh && cond && work, "lfi_encode_windows_fwd: null pointer");
   a.Xp = Xp; a.b_ih = b_ih; a.b_hh = b_hh; a.mask = mask; a.cond = cond; a.gates = gates; a.hseq = hseq;
+  a.stamps = g_lfi_stamps;
   hipStream_t st = (hipStream_t)stream;
   const int hid = d->hid, F = a.F;
   EncFused q = {};
@@ -863,13 +890,22 @@ extern "C" int lfi_encode_windows_scatter(const lfi_enc_desc* d, const float* dg
   return LFI_OK;
 }
 
-extern "C" int lfi_gather_windows(const float* X, int B, int T, int dim, int N, int start, int hist, int incl, float* cond,
-                                  int ldcond, int col, void* stream) {
+extern "C" int lfi_gather_windows(const float* X, int B, int T, int dim, int N, int start, int hist, int incl,
+                                  const float* mask, float* cond, int ldcond, int col, void* stream) {
   LFI_REQUIRE(X && cond, "lfi_gather_windows: null pointer");
   LFI_REQUIRE(B > 0 && T > 0 && dim > 0 && N > 0 && hist > 0 && (incl == 0 || incl == 1), "lfi_gather_windows: bad dims");
   LFI_REQUIRE(start - hist + incl >= 0 && start + N - 1 + incl <= T, "lfi_gather_windows: window out of range");
   hipLaunchKernelGGL(gather_windows_kernel, dim3(N * B), dim3(256), 0, (hipStream_t)stream, X, B, T, dim, N, start, hist,
-                     incl, cond, ldcond, col);
+                     incl, mask, cond, ldcond, col);
   LFI_LAUNCH_CHECK("lfi_gather_windows");
+  return LFI_OK;
+}
+
+extern "C" int lfi_leaky_grad(float* d, long ldd, const float* y, long ldy, int rows, int cols, float slope, void* stream) {
+  LFI_REQUIRE(d && y && rows >= 0 && cols >= 0, "lfi_leaky_grad: bad arguments");
+  if (rows == 0 || cols == 0) return LFI_OK;
+  hipLaunchKernelGGL(leaky_grad_kernel, dim3(ew_blocks((long)rows * cols)), dim3(256), 0, (hipStream_t)stream, d, ldd, y, ldy,
+                     rows, cols, slope);
+  LFI_LAUNCH_CHECK("lfi_leaky_grad");
   return LFI_OK;
 }

@@ -1677,8 +1677,6 @@ long prep_padded_floats(const lfi_flow_dims* d) {
   return d->Ks * (3 * C16 * C16 + Ch16 * NG * H16 + H16 * NG * H16 + 2 * H16 * Co16 + NG * H16 * H16 + NG * H16 * Ch16);
 }
 
-unsigned long long* g_flow_stamps = nullptr;  // diagnostics only
-
 int fill_flow(const lfi_flow_dims* d, const lfi_flow_params* p, const float* prep, FlowK* f, const char* who) {
   LFI_REQUIRE(d && p, "%s: null dims/params", who);
   LFI_REQUIRE(d->B > 0 && d->N > 0 && d->C >= 2 && d->H > 0 && d->D > 0 && d->Ks > 0, "%s: bad dims", who);
@@ -1687,7 +1685,7 @@ int fill_flow(const lfi_flow_dims* d, const lfi_flow_params* p, const float* pre
   f->Ch = d->C / 2; f->C2 = d->C - f->Ch; f->Cout = d->affine ? 2 * f->C2 : f->C2;
   f->G = (d->lstm ? 4 : 3) * d->H; f->I = f->Ch + d->D; f->F = d->N * d->B; f->nbt = lfi_cdiv(d->B, MB);
   f->p = *p;
-  f->stamps = g_flow_stamps;
+  f->stamps = g_lfi_stamps;
   f->NG = d->lstm ? 4 : 3;
   f->C16 = (f->C + 15) & ~15; f->Ch16 = (f->Ch + 15) & ~15; f->H16 = (f->H + 15) & ~15; f->Co16 = (f->Cout + 15) & ~15;
   if (f->Ch16 == 0) f->Ch16 = 16;
@@ -1786,7 +1784,7 @@ int set_flow_lds(Kf kernel, size_t bytes, const char* who) {
 // Diagnostics: device buffer of >= 16 * Ks 64-bit slots that the register-resident forward cells stamp with s_memtime at
 // their phase boundaries (workgroup column 0 only); NULL switches it off. Process-global, not for production use.
 extern "C" int lfi_debug_set_stamps(void* device_buffer) {
-  g_flow_stamps = (unsigned long long*)device_buffer;
+  g_lfi_stamps = (unsigned long long*)device_buffer;
   return LFI_OK;
 }
 
@@ -2053,6 +2051,18 @@ extern "C" int lfi_flow_step(const lfi_flow_dims* d, const lfi_flow_params* p, c
 // SeqGlow.inference (glow/models.py:567-596): everything that does not depend on generated frames was hoisted by the
 // caller into pre_static; per frame two small GEMMs (window part of cond_transform, then W_ih[:, Ch:] c) and Ks
 // reverse cells. The growing torch.cat history of the reference (:591, O(T^2) copies) is a preallocated buffer here.
+extern "C" long lfi_flow_sample_p1_work_floats(const lfi_flow_dims* d, const lfi_p1enc* e, int hist1) {
+  if (!d || !e || e->kind == 0) return 0;
+  const long hid4 = (e->hid + 3) & ~3;
+  long n = (long)d->B * hid4 + 16;
+  if (e->kind == 2) {
+    lfi_enc_desc ed = {};
+    ed.B = d->B; ed.T = hist1; ed.N = 1; ed.start = hist1 - 1; ed.hist = hist1; ed.hid = e->hid;
+    n += (long)d->B * hist1 * 3 * e->hid + lfi_encode_windows_work_floats(&ed) + (long)hist1 * d->B * e->hid;
+  }
+  return n;
+}
+
 extern "C" long lfi_flow_sample_work_floats(const lfi_flow_dims* d) {
   if (!d) return 0;
   const int G = (d->lstm ? 4 : 3) * d->H;
@@ -2061,7 +2071,8 @@ extern "C" long lfi_flow_sample_work_floats(const lfi_flow_dims* d) {
 
 extern "C" int lfi_flow_sample_seq(const lfi_flow_dims* d, const lfi_flow_params* p, const float* prep, const float* wct,
                                    long E, int hist1, const float* pre_static, const float* noise, float* faces, int seq_len,
-                                   int start, int nframes, float* h, float* cstate, float* work, void* stream) {
+                                   int start, int nframes, float* h, float* cstate, const lfi_p1enc* p1, float* p1work,
+                                   float* work, void* stream) {
   FlowK f = {};
   int rc = fill_flow(d, p, prep, &f, "lfi_flow_sample_seq");
   if (rc) return rc;
@@ -2069,6 +2080,10 @@ extern "C" int lfi_flow_sample_seq(const lfi_flow_dims* d, const lfi_flow_params
   LFI_REQUIRE(hist1 >= 0 && hist1 <= start && start + nframes <= seq_len, "lfi_flow_sample_seq: bad frame range");
   LFI_REQUIRE((long)hist1 * d->C <= E, "lfi_flow_sample_seq: window wider than the feature vector");
   LFI_REQUIRE(!d->lstm || cstate, "lfi_flow_sample_seq: the LSTM cell needs cstate");
+  const int p1kind = p1 ? p1->kind : 0;
+  LFI_REQUIRE(p1kind >= 0 && p1kind <= 2, "lfi_flow_sample_seq: bad p1_face encoder kind %d", p1kind);
+  LFI_REQUIRE(p1kind == 0 || (p1work && p1->hid > 0), "lfi_flow_sample_seq: encoded p1_face window needs p1work");
+  const int p1col = p1 ? p1->col : 0;
   const int B = f.B, C = f.C, H = f.H, D = f.D, Ks = f.Ks, G = f.G;
   float* cbuf = work;                          // B x Ks*D
   float* gic = cbuf + (long)B * Ks * D;        // [Ks][B][G]
@@ -2094,8 +2109,38 @@ extern "C" int lfi_flow_sample_seq(const lfi_flow_dims* d, const lfi_flow_params
     lfi_gemm_desc q = {};
     q.batch = 1; q.M = B; q.N = Ks * D; q.K = hist1 * C;
     q.A = faces + (long)(t - hist1) * C; q.lda = (long)seq_len * C; q.a_kcontig = 1;
-    q.B = wct; q.ldb = E; q.b_kcontig = 1;
+    q.B = wct + p1col; q.ldb = E; q.b_kcontig = 1;
     q.C = cbuf; q.ldc = (long)Ks * D; q.accumulate = 2; q.act = 1; q.slope = 0.01f; q.precision = d->gemm_precision;
+    if (p1kind != 0) {
+      // features of the window first: e (B x hid4), then c = LeakyReLU(pre_static + e Wct[:, col : col + hid]^T)
+      const int hid = p1->hid, hid4 = (hid + 3) & ~3;
+      float* ebuf = p1work;                       // B x hid4
+      if (p1kind == 1) {
+        lfi_gemm_desc m = {};
+        m.batch = 1; m.M = B; m.N = hid; m.K = hist1 * C;
+        m.A = q.A; m.lda = q.lda; m.a_kcontig = 1;
+        m.B = p1->w1; m.ldb = (long)hist1 * C; m.b_kcontig = 1;
+        m.C = ebuf; m.ldc = hid4; m.bias = p1->b1; m.act = 1; m.slope = 0.01f; m.precision = d->gemm_precision;
+        if ((rc = lfi_gemm_f32(&m, stream))) return rc;
+      } else {
+        // GRU over the window: input projections of its hist1 frames (batched over the step), then the fused recurrence
+        float* xp = ebuf + (long)B * hid4;          // [B][hist1][3hid]
+        float* ework = xp + (long)B * hist1 * 3 * hid;
+        lfi_gemm_desc m = {};
+        m.batch = hist1; m.M = B; m.N = 3 * hid; m.K = C;
+        m.A = q.A; m.lda = q.lda; m.a_kcontig = 1; m.strideA = C;
+        m.B = p1->w_ih; m.ldb = C; m.b_kcontig = 1;
+        m.C = xp; m.ldc = (long)hist1 * 3 * hid; m.strideC = 3 * hid; m.precision = d->gemm_precision;
+        if ((rc = lfi_gemm_f32(&m, stream))) return rc;
+        lfi_enc_desc ed = {};
+        ed.B = B; ed.T = hist1; ed.N = 1; ed.start = hist1 - 1; ed.hist = hist1; ed.hid = hid;
+        ed.ldcond = hid4; ed.col = 0; ed.precision = d->gemm_precision; ed.dup = 0;
+        float* hs = ework + lfi_encode_windows_work_floats(&ed);   // unfused path only: state sequence
+        if ((rc = lfi_encode_windows_fwd(&ed, xp, p1->w_hh, p1->b_ih, p1->b_hh, nullptr, ebuf, nullptr, hs, ework, stream)))
+          return rc;
+      }
+      q.K = hid; q.A = ebuf; q.lda = hid4;
+    }
     if ((rc = lfi_gemm_f32(&q, stream))) return rc;
     // gic[k] = c[:, kD:(k+1)D] @ W_ih[k][:, Ch:]^T + b_ih[k]
     lfi_gemm_desc r = {};

@@ -20,7 +20,7 @@ import os
 import torch
 
 from . import _lib
-from ._lib import EncDesc, FlowDims, FlowGrads, FlowParams, GemmDesc, check, ptr
+from ._lib import EncDesc, FlowDims, FlowGrads, FlowParams, GemmDesc, P1Enc, check, ptr
 
 ENC_ORDER = ("p1_face", "p2_face", "p1_speech", "p2_speech")  # FeatureEncoder concat order (models.py:127-143)
 FLOW_FIELDS = ("an_bias", "an_logs", "inv_l", "inv_u", "inv_logs", "inv_w", "w_ih", "w_hh", "b_ih", "b_hh",
@@ -39,12 +39,17 @@ class EncoderSpec:
         self.name, self.enc, self.in_dim, self.hist, self.hid, self.dropout = name, enc, in_dim, hist, hid, dropout
         if enc == "rnn":
             self.dim = 2 * hid
+        elif enc == "mlp":
+            self.dim = hid
         elif enc == "none":
             self.dim = in_dim * hist
         else:
             raise NotImplementedError(
-                "encoder type %r for %s: only 'rnn' (GRU) and 'none' have HIP kernels in this build" % (enc, name))
+                "encoder type %r for %s: 'rnn' (GRU), 'mlp' and 'none' have HIP kernels in this build ('lstm' is in no "
+                "shipped hparams file nor in the hparam search space; 'cnn' has a broken output size in the reference, "
+                "models.py:48)" % (enc, name))
         self.col = 0
+        self.win = (in_dim * hist + 3) // 4 * 4  # row stride of the flattened-window matrix of an mlp encoder
 
 
 class ModelSpec:
@@ -141,6 +146,11 @@ class GlowEngine:
         for e in spec.encoders:
             if e.enc == "rnn":
                 for leaf, shape in zip(ENC_LEAVES, ((3 * e.hid, e.in_dim), (3 * e.hid, e.hid), (3 * e.hid,), (3 * e.hid,))):
+                    self.layout["enc.%s.%s" % (e.name, leaf)] = (off, shape)
+                    off += math.prod(shape)
+            elif e.enc == "mlp":
+                for leaf, shape in (("mlp_weight", (e.hid, e.in_dim * e.hist)), ("mlp_bias", (e.hid,))):
+                    off = (off + 3) // 4 * 4  # 16-byte aligned: GEMM operand
                     self.layout["enc.%s.%s" % (e.name, leaf)] = (off, shape)
                     off += math.prod(shape)
         shapes = spec.flow_shapes()
@@ -318,38 +328,42 @@ class GlowEngine:
         F = N * B
         st = _stream()
         for e in s.encoders:
-            if e.name == "p1_face":
-                if e.enc != "none":
-                    raise NotImplementedError("p1_face encoder %r: the autoregressive input is only supported as "
-                                              "'none' (all shipped hparams)" % e.enc)
-                if skip_p1:
-                    continue
-                self._check_input(faces, "p1_face", B, T, s.C)
-                check(self.L.lfi_gather_windows(faces.data_ptr(), B, faces.shape[1], s.C, N, s.start, e.hist, 0,
-                                                cond.data_ptr(), s.ldf, e.fcol, st), "lfi_gather_windows")
+            p1 = e.name == "p1_face"
+            if p1 and skip_p1:
                 continue
-            x = data.get(e.name)
+            # prev_p1_face is the window [t - hist, t) of the model's own output (models.py:601-603); every other modality
+            # (t - hist, t] of its input stream (:607-610): same kernels, window end shifted by one frame
+            x = faces if p1 else data.get(e.name)
             if x is None:
                 raise KeyError("batch is missing modality %r" % e.name)
             self._check_input(x, e.name, B, T, e.in_dim)
             Tx = x.shape[1]
+            incl = 0 if p1 else 1
+            mk = None if masks is None else masks.get(e.name)
+            if mk is not None and not (tuple(mk.shape) == (N, B, e.hist) and mk.is_contiguous()
+                                       and mk.dtype == torch.float32 and mk.is_cuda):
+                raise ValueError("mask for %s must be a contiguous float32 GPU tensor (N, B, hist)" % e.name)
             if e.enc == "none":
-                check(self.L.lfi_gather_windows(x.data_ptr(), B, Tx, e.in_dim, N, s.start, e.hist, 1,
+                check(self.L.lfi_gather_windows(x.data_ptr(), B, Tx, e.in_dim, N, s.start, e.hist, incl, ptr(mk),
                                                 cond.data_ptr(), s.ldf, e.fcol, st), "lfi_gather_windows")
                 continue
             hid = e.hid
+            if e.enc == "mlp":  # Linear(hist * in -> hid) + LeakyReLU on the flattened (masked) window (models.py:70-71)
+                win = self._buf("enc_win." + e.name, F * e.win, zero=False)
+                check(self.L.lfi_gather_windows(x.data_ptr(), B, Tx, e.in_dim, N, s.start, e.hist, incl, ptr(mk),
+                                                win.data_ptr(), e.win, 0, st), "lfi_gather_windows")
+                self.gemm(F, hid, e.in_dim * e.hist, win, e.win, 1, self.view("enc.%s.mlp_weight" % e.name),
+                          e.in_dim * e.hist, 1, cond, s.ldf, bias=self.view("enc.%s.mlp_bias" % e.name), act=1, slope=0.01,
+                          c_off=e.fcol)
+                continue
             # input projection hoisted over the B*Tx distinct frames (no bias: it is added after the dropout mask)
             xp = self._buf("xp." + e.name, B * Tx * 3 * hid)
             self.gemm(B * Tx, 3 * hid, e.in_dim, x, e.in_dim, 1, self.view("enc.%s.weight_ih" % e.name), e.in_dim, 1,
                       xp, 3 * hid)
             gates = self._buf("enc_gates." + e.name, e.hist * F * 4 * hid) if with_stash else None
             hseq = self._buf("enc_hseq." + e.name, e.hist * F * hid)
-            d = EncDesc(B, Tx, N, s.start, e.hist, hid, s.ldf, e.fcol, self.precision, 0)
+            d = EncDesc(B, Tx, N, s.start - 1 + incl, e.hist, hid, s.ldf, e.fcol, self.precision, 0)
             work = self._buf("scratch.enc", self.L.lfi_encode_windows_work_floats(C.byref(d)))
-            mk = None if masks is None else masks.get(e.name)
-            if mk is not None and not (tuple(mk.shape) == (N, B, e.hist) and mk.is_contiguous()
-                                       and mk.dtype == torch.float32 and mk.is_cuda):
-                raise ValueError("mask for %s must be a contiguous float32 GPU tensor (N, B, hist)" % e.name)
             check(self.L.lfi_encode_windows_fwd(
                 C.byref(d), xp.data_ptr(), self.view("enc.%s.weight_hh" % e.name).data_ptr(),
                 self.view("enc.%s.bias_ih" % e.name).data_ptr(), self.view("enc.%s.bias_hh" % e.name).data_ptr(),
@@ -452,8 +466,8 @@ class GlowEngine:
         check(self.L.lfi_cols_fold(dwf.data_ptr(), s.ldf, KD, self.unfold.data_ptr(), None, s.E,
                                    self.fview("wct", self.grads).data_ptr(), s.E, st), "lfi_cols_fold")
         self.colsum(dpre, KD, 0, F, KD, 1, self.fview("bct", self.grads), 0)
-        # gradient of the feature matrix, encoder columns only (prev_p1_face is data)
-        rnn = [e for e in s.encoders if e.enc == "rnn"]
+        # gradient of the feature matrix, columns of the trainable encoders only (raw windows are data)
+        rnn = [e for e in s.encoders if e.enc in ("rnn", "mlp")]
         if rnn:
             col0 = min(e.fcol for e in rnn)
             W = s.Ef - col0
@@ -463,7 +477,23 @@ class GlowEngine:
             self.gemm(F, W, KD, dpre, KD, 1, self.wct_f, s.ldf, 0, dcond, ldd, b_off=col0, tag="gemm_cond_dgrad",
                       splitk=0)
             for e in rnn:
-                self._encoder_backward(e, ctx, dcond, ldd, e.fcol - col0)
+                if e.enc == "mlp":
+                    self._mlp_backward(e, ctx, dcond, ldd, e.fcol - col0)
+                else:
+                    self._encoder_backward(e, ctx, dcond, ldd, e.fcol - col0)
+
+    def _mlp_backward(self, e, ctx, dcond, lddcond, col):
+        """Linear + LeakyReLU window encoder: dpre = dfeat * leaky'(feat); dW = dpre^T window, db = colsum(dpre)."""
+        s = self.spec
+        F = ctx.F
+        K = e.in_dim * e.hist
+        check(self.L.lfi_leaky_grad(dcond.data_ptr() + 4 * col, lddcond, ctx.cond.data_ptr() + 4 * e.fcol, s.ldf, F, e.hid,
+                                    0.01, _stream()), "lfi_leaky_grad")
+        win = self._ws["enc_win." + e.name]
+        gname = "enc.%s." % e.name
+        self.gemm(e.hid, K, F, dcond, lddcond, 0, win, e.win, 0, self.view(gname + "mlp_weight", self.grads), K,
+                  splitk=max(1, min(32, F // 1024)), a_off=col)
+        self.colsum(dcond, lddcond, 0, F, e.hid, 1, self.view(gname + "mlp_bias", self.grads), 0, x_off=col)
 
     def _encoder_backward(self, e, ctx, dcond, lddcond, col):
         s = self.spec
@@ -471,7 +501,7 @@ class GlowEngine:
         x = ctx.batch[e.name]
         Tx, hid, G3 = x.shape[1], e.hid, 3 * e.hid
         st = _stream()
-        d = EncDesc(B, Tx, N, s.start, e.hist, hid, lddcond, col, self.precision, 0)
+        d = EncDesc(B, Tx, N, s.start - (1 if e.name == "p1_face" else 0), e.hist, hid, lddcond, col, self.precision, 0)
         gates = self._ws["enc_gates." + e.name]
         hseq = self._ws["enc_hseq." + e.name]
         dgi = self._buf("enc_dgi." + e.name, e.hist * F * G3)
@@ -549,7 +579,8 @@ class GlowEngine:
         # everything of the features that does not depend on generated frames, through cond_transform (no activation yet)
         cond = self._buf("cond", F * s.ldf)
         self.build_features(data, None, B, seq_len, masks, cond, with_stash=False, skip_p1=True)
-        c1 = (s.p1_cols + 3) // 4 * 4  # first column after the prev_p1_face block (blocks start on 4-float boundaries)
+        e1 = s.encoders[0]             # prev_p1_face: the only autoregressive input
+        c1 = (e1.fdim + 3) // 4 * 4    # first column after its block (blocks start on 4-float boundaries)
         pre = self._buf("pre_static", F * KD)
         if s.Ef > c1:
             self.gemm(F, KD, s.Ef - c1, cond, s.ldf, 1, self.wct_f, s.ldf, 1, pre, KD, bias=self.fview("bct"),
@@ -563,12 +594,23 @@ class GlowEngine:
         nz = self._buf("sample_noise", nframes * B * s.C)   # engine-owned copy: the captured graph reads a stable address
         nz[:nframes * B * s.C].view_as(noise).copy_(noise)
         p = self._flow_params()
-        hist1 = s.encoders[0].hist
+        hist1 = e1.hist
+        # an encoded prev_p1_face window (enc: mlp / rnn) is re-encoded for every generated frame inside the sampler
+        p1 = P1Enc()
+        p1.kind, p1.hid, p1.col = {"none": 0, "mlp": 1, "rnn": 2}[e1.enc], e1.hid, e1.fcol
+        if e1.enc == "mlp":
+            p1.w1, p1.b1 = self.view("enc.p1_face.mlp_weight").data_ptr(), self.view("enc.p1_face.mlp_bias").data_ptr()
+        elif e1.enc == "rnn":
+            for leaf in ENC_LEAVES:
+                setattr(p1, {"weight_ih": "w_ih", "weight_hh": "w_hh", "bias_ih": "b_ih", "bias_hh": "b_hh"}[leaf],
+                        self.view("enc.p1_face." + leaf).data_ptr())
+        p1work = self._buf("scratch.sample_p1", self.L.lfi_flow_sample_p1_work_floats(C.byref(dims), C.byref(p1), hist1))
 
         def launch():
             check(self.L.lfi_flow_sample_seq(C.byref(dims), C.byref(p), self.prep.data_ptr(), self.wct_f.data_ptr(),
                                              s.ldf, hist1, pre.data_ptr(), nz.data_ptr(), faces.data_ptr(), seq_len, s.start,
-                                             nframes, h.data_ptr(), ptr(cs), work.data_ptr(), _stream()), "lfi_flow_sample_seq")
+                                             nframes, h.data_ptr(), ptr(cs), C.byref(p1), p1work.data_ptr(), work.data_ptr(),
+                                             _stream()), "lfi_flow_sample_seq")
 
         # The per-frame chain (2 small GEMMs + Ks reverse cells, ~19 launches x nframes) is launch-bound on the host at
         # small batch: from the second call of a shape on, it is replayed as ONE hipGraph (captured once; every buffer it

@@ -228,6 +228,10 @@ class SeqGlow(nn.Module):
                 gru = getattr(fe, e.name + "_encoder").encoder
                 for leaf in _engine.ENC_LEAVES:
                     out.append(("enc.%s.%s" % (e.name, leaf), None, getattr(gru, leaf + "_l0")))
+            elif e.enc == "mlp":
+                lin = getattr(fe, e.name + "_encoder").encoder[0]
+                out.append(("enc.%s.mlp_weight" % e.name, None, lin.weight))
+                out.append(("enc.%s.mlp_bias" % e.name, None, lin.bias))
         for k, layer in enumerate(self.glow.flow.layers):
             out.append(("flow.an_bias", k, layer.actnorm.bias))
             out.append(("flow.an_logs", k, layer.actnorm.logs))
@@ -307,7 +311,7 @@ class SeqGlow(nn.Module):
             return None
         masks = {}
         for e in self.spec.encoders:
-            if e.name != "p1_face" and e.dropout > 0:  # nn.Dropout on ones(B, hist) per timestep (models.py:56-58)
+            if e.dropout > 0:  # nn.Dropout on ones(B, hist) per timestep (models.py:56-58)
                 keep = 1.0 - e.dropout
                 masks[e.name] = torch.bernoulli(torch.full((N, B, e.hist), keep, device=device)) / keep
         return masks or None

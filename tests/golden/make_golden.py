@@ -88,6 +88,34 @@ def make_config(name):
         g.update(K=3, hidden_channels=44)
         hp["Train"]["seq_len"] = 28
         dims = dict(B=8, T=28)
+    elif name in ("mlp", "p1enc"):
+        # the encoder types the reference's hparam search draws for EVERY modality, p1_face included
+        # (hparam_tuning_configs/large_hparam_search.py:45-72): "mlp", a raw window with dropout, an encoded p1_face window
+        c["cond_dim"] = 32
+        hp["Data"]["speech_dim"] = 8
+        g.update(K=2, L=1, hidden_channels=32)
+        hp["Train"]["seq_len"] = 20
+        dims = dict(B=4, T=20)
+        if name == "mlp":
+            c["p1_face"].update(history=3, dim=16)
+            c["p2_face"].update(history=4, dim=16, hidden_dim=24, enc="mlp")
+            c["p1_speech"].update(history=2, hidden_dim=16, enc="none")          # raw window, dropout 0.5 kept
+            c["p2_speech"].update(history=4, hidden_dim=20, enc="mlp")
+        else:
+            c["p1_face"].update(history=3, dim=16, hidden_dim=12, enc="rnn", dropout=0.4)
+            c["p2_face"].update(history=4, dim=16, hidden_dim=24)
+            c["p1_speech"].update(history=2, hidden_dim=16, enc="mlp")
+            c["p2_speech"].update(history=3, hidden_dim=20, enc="none")
+    elif name == "p1mlp":
+        c["cond_dim"] = 32
+        hp["Data"]["speech_dim"] = 8
+        g.update(K=2, L=1, hidden_channels=32)
+        hp["Train"]["seq_len"] = 20
+        dims = dict(B=4, T=20)
+        c["p1_face"].update(history=3, dim=16, hidden_dim=20, enc="mlp", dropout=0.3)
+        c["p2_face"].update(history=4, dim=16, hidden_dim=24)
+        c["p1_speech"].update(history=0, hidden_dim=16)
+        c["p2_speech"].update(history=4, hidden_dim=24)
     else:
         raise KeyError(name)
     dims["C"] = c["p1_face"]["dim"]
@@ -214,7 +242,7 @@ def build(name, models, modules, oracle):
 
     # ---- 2. train-mode forward + backward with injected dropout masks
     masks = {}
-    for mname in ("p2_face", "p1_speech", "p2_speech"):
+    for mname in ("p1_face", "p2_face", "p1_speech", "p2_speech"):
         cfg = hp["Conditioning"][mname]
         if cfg["history"] and cfg["dropout"] > 0:
             keep = 1.0 - cfg["dropout"]
@@ -336,7 +364,8 @@ def main():
     from oracle import seqglow_oracle as oracle
     models, modules, utils = import_reference()
     lstm_shim(models)
-    for name in ("tiny", "tiny_lstm", "tiny_additive", "odd", "mid"):
+    names = sys.argv[1:] or ("tiny", "tiny_lstm", "tiny_additive", "odd", "mid", "mlp", "p1enc", "p1mlp")
+    for name in names:
         out = build(name, models, modules, oracle)
         path = os.path.join(HERE, name + ".npz")
         np.savez_compressed(path, **out)
