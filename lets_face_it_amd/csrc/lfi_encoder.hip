@@ -32,10 +32,15 @@ struct EncArgs {
   float* bias_part;    // fused backward only: [workgroups * row groups][4][hid] partial sums of dar, dau, dan, dan*r (or null)
   unsigned long long* stamps;  // diagnostics only
 };
+// phase stamps of the fused forward kernel: compiled in only with -DLFI_ENC_STAMPS (they cost registers: 321 spills)
+#ifdef LFI_ENC_STAMPS
 #define ENC_STAMP(slot)                                                                                          \
   do {                                                                                                           \
     if (a.stamps && tid == 0 && blockIdx.x == 0 && s == 5) a.stamps[128 + (slot)] = __builtin_amdgcn_s_memtime(); \
   } while (0)
+#else
+#define ENC_STAMP(slot) do { } while (0)
+#endif
 
 // One GRU step for every window. gh: F x 3hid = h_{s-1} W_hh^T (no bias), or null at s = 0 (h = 0).
 __global__ __launch_bounds__(256) void enc_gate_fwd_kernel(EncArgs a, int s, const float* __restrict__ gh) {

@@ -33,6 +33,8 @@ struct FlowK {
   int B, N, C, H, D, Ks, affine, lstm;
   float eps;
   int Ch, C2, Cout, G, I, F, nbt;
+  int ldc, ldo;   // row strides of the (rows x C) and (rows x Cout) stash arrays: C and Cout rounded up to 4 floats, so that the
+                  // deferred weight-gradient products over them read 16-byte aligned rows (bf16x3 / vector-load paths)
   // params
   lfi_flow_params p;
   // prep
@@ -61,6 +63,7 @@ struct CellIO {
   const float* gic;       // rows x G
   float *a_out, *y_out, *x_out, *h_out, *g_out, *o_out, *l_out;  // nullable stashes; x_out/h_out required
   long ldxo;              // leading dimension of x_out
+  long ld_c, ld_o;        // leading dimensions of a_out / y_out and of o_out
   int l_accumulate;       // l_out += instead of =
 };
 
@@ -164,7 +167,7 @@ __device__ __forceinline__ void coupling_net_phase(const FlowK& f, const CellIO&
         const int row = b0 + i;
         const float o = (acc[r] + bb) * sc;
         Orm[i * ldo + col] = o;
-        if (io.o_out && row < io.rows) io.o_out[(long)row * Cout + col] = o;
+        if (io.o_out && row < io.rows) io.o_out[(long)row * io.ld_o + col] = o;
       }
     }
   }
@@ -213,7 +216,7 @@ __device__ void cell_forward(const FlowK& f, const CellIO& io, int b0) {
     float a = 0.0f;
     if (row < io.rows) {
       a = (io.x_in[(long)row * io.ldx + c] + anb[c]) * expf(anl[c]);
-      if (io.a_out) io.a_out[(long)row * C + c] = a;
+      if (io.a_out) io.a_out[(long)row * io.ld_c + c] = a;
     }
     At[c * LT + i] = a;
   }
@@ -240,7 +243,7 @@ __device__ void cell_forward(const FlowK& f, const CellIO& io, int b0) {
           const float v = acc[r];
           Yrm[i * ldy + c] = v;
           if (c < Ch) Zt[c * LT + i] = v;
-          if (io.y_out && row < io.rows) io.y_out[(long)row * C + c] = v;
+          if (io.y_out && row < io.rows) io.y_out[(long)row * io.ld_c + c] = v;
         }
       }
     }
@@ -367,17 +370,18 @@ __global__ __launch_bounds__(NT) void flow_diag_fwd_kernel(FlowK f, int d, int k
   CellIO io;
   io.k = k; io.rows = f.B;
   if (k == 0) { io.x_in = f.x0 + (long)(f.start + n) * f.C; io.ldx = (long)f.T * f.C; }
-  else { io.x_in = f.sX + ((long)(k - 1) * f.F + fr) * f.C; io.ldx = f.C; }
+  else { io.x_in = f.sX + ((long)(k - 1) * f.F + fr) * f.ldc; io.ldx = f.ldc; }
   io.h_prev = n > 0 ? f.sH + ((long)k * f.F + fr - f.B) * f.H : nullptr;
   io.c_prev = (f.lstm && n > 0) ? f.sC + ((long)k * f.F + fr - f.B) * f.H : nullptr;
   io.c_out = f.lstm ? f.sC + ((long)k * f.F + fr) * f.H : nullptr;
   io.gic = f.gic + ((long)k * f.F + fr) * f.G;
-  io.a_out = f.sA + ((long)k * f.F + fr) * f.C;
-  io.y_out = f.sY + ((long)k * f.F + fr) * f.C;
-  io.x_out = f.sX + ((long)k * f.F + fr) * f.C; io.ldxo = f.C;
+  io.a_out = f.sA + ((long)k * f.F + fr) * f.ldc;
+  io.y_out = f.sY + ((long)k * f.F + fr) * f.ldc;
+  io.x_out = f.sX + ((long)k * f.F + fr) * f.ldc; io.ldxo = f.ldc;
+  io.ld_c = f.ldc; io.ld_o = f.ldo;
   io.h_out = f.sH + ((long)k * f.F + fr) * f.H;
   io.g_out = f.sG + ((long)k * f.F + fr) * 4 * f.H;
-  io.o_out = f.sO + ((long)k * f.F + fr) * f.Cout;
+  io.o_out = f.sO + ((long)k * f.F + fr) * f.ldo;
   io.l_out = f.sL + (long)k * f.F + fr;
   io.l_accumulate = 0;
   cell_forward(f, io, blockIdx.x * MB);
@@ -395,7 +399,7 @@ __global__ __launch_bounds__(256) void flow_nll_kernel(FlowK f, float* __restric
   if (fr >= f.F) return;
   float ld = f.ldconst[0];
   for (int k = 0; k < f.Ks; ++k) ld += f.sL[(long)k * f.F + fr];
-  const float* zz = f.sX + ((long)(f.Ks - 1) * f.F + fr) * f.C;
+  const float* zz = f.sX + ((long)(f.Ks - 1) * f.F + fr) * f.ldc;
   float lp = 0.0f;
   for (int c = 0; c < f.C; ++c) {
     const float v = zz[c];
@@ -428,6 +432,7 @@ __global__ __launch_bounds__(NT) void flow_diag_bwd_kernel(FlowK f, int d, int k
   const int k = klo + blockIdx.y, n = d - k;
   const int b0 = blockIdx.x * MB;
   const int B = f.B, C = f.C, H = f.H, Ch = f.Ch, C2 = f.C2, Cout = f.Cout, G = f.G, I = f.I;
+  const long LC = f.ldc, LO = f.ldo;   // stash row strides
   const long fr = (long)n * B;
   const long kf = (long)k * f.F + fr;
   const CarveB cv = carve_bwd(C, H, Cout, G);
@@ -441,24 +446,24 @@ __global__ __launch_bounds__(NT) void flow_diag_bwd_kernel(FlowK f, int d, int k
   const bool last = k == f.Ks - 1;
   const float gz = f.gscale / LN2_F;   // d loss / d z = z * gz   (prior term)
   const float dl = -f.gscale / LN2_F;  // d loss / d logdet
-  const float* dxo = last ? f.sX + kf * C : f.bDx + ((long)(k + 1) * f.F + fr) * C;
+  const float* dxo = last ? f.sX + kf * LC : f.bDx + ((long)(k + 1) * f.F + fr) * LC;
   const float dxs = last ? gz : 1.0f;
 
   // Q0: coupling backward + LinearZeros scale
-  const float* Y = f.sY + kf * C;
-  const float* O = f.sO + kf * Cout;
+  const float* Y = f.sY + kf * LC;
+  const float* O = f.sO + kf * LO;
   const float* lfl = f.p.l_fl + (long)k * Cout;
   for (int idx = tid; idx < MB * C2; idx += NT) {
     const int i = idx / C2, jj = idx - i * C2;
     const int row = b0 + i;
     float dz2 = 0.0f, d0 = 0.0f, d1 = 0.0f, p0 = 0.0f, p1 = 0.0f;
     if (row < B) {
-      const float dz2n = dxo[(long)row * C + Ch + jj] * dxs;
+      const float dz2n = dxo[(long)row * LC + Ch + jj] * dxs;
       if (f.affine) {
-        const float oe = O[(long)row * Cout + 2 * jj], oo = O[(long)row * Cout + 2 * jj + 1];
+        const float oe = O[(long)row * LO + 2 * jj], oo = O[(long)row * LO + 2 * jj + 1];
         const float sraw = sigmoidf_(oo + 2.0f);
         const float sc = fmaxf(sraw, f.eps);
-        const float z2 = Y[(long)row * C + Ch + jj];
+        const float z2 = Y[(long)row * LC + Ch + jj];
         dz2 = dz2n * sc;
         const float dsc = dz2n * (z2 + oe) + dl / sc;
         const float dsr = sraw >= f.eps ? dsc : 0.0f;
@@ -466,23 +471,23 @@ __global__ __launch_bounds__(NT) void flow_diag_bwd_kernel(FlowK f, int d, int k
         d1 = dsr * sraw * (1.0f - sraw);      // d o_odd
         p0 = d0 * oe * 3.0f; p1 = d1 * oo * 3.0f;
       } else {
-        const float oe = O[(long)row * Cout + jj];
+        const float oe = O[(long)row * LO + jj];
         dz2 = dz2n; d0 = dz2n; p0 = d0 * oe * 3.0f;
       }
     }
     Dy[(Ch + jj) * LT + i] = dz2;
-    if (row < B) f.bDy[kf * C + (long)row * C + Ch + jj] = dz2;
+    if (row < B) f.bDy[kf * LC + (long)row * LC + Ch + jj] = dz2;
     if (f.affine) {
       const int c0 = 2 * jj, c1 = 2 * jj + 1;
       const float dl0 = d0 * expf(3.0f * lfl[c0]), dl1 = d1 * expf(3.0f * lfl[c1]);
       Dl[c0 * LT + i] = dl0; Dl[c1 * LT + i] = dl1;
       Pl[i * ldp + c0] = p0; Pl[i * ldp + c1] = p1;
-      if (row < B) { f.bDlin[kf * Cout + (long)row * Cout + c0] = dl0; f.bDlin[kf * Cout + (long)row * Cout + c1] = dl1; }
+      if (row < B) { f.bDlin[kf * LO + (long)row * LO + c0] = dl0; f.bDlin[kf * LO + (long)row * LO + c1] = dl1; }
     } else {
       const float dl0 = d0 * expf(3.0f * lfl[jj]);
       Dl[jj * LT + i] = dl0;
       Pl[i * ldp + jj] = p0;
-      if (row < B) f.bDlin[kf * Cout + (long)row * Cout + jj] = dl0;
+      if (row < B) f.bDlin[kf * LO + (long)row * LO + jj] = dl0;
     }
   }
   __syncthreads();
@@ -606,8 +611,8 @@ __global__ __launch_bounds__(NT) void flow_diag_bwd_kernel(FlowK f, int d, int k
           const int row = b0 + i;
           float v = 0.0f;
           if (row < B) {
-            v = acc[r] + dxo[(long)row * C + c] * dxs;
-            f.bDy[kf * C + (long)row * C + c] = v;
+            v = acc[r] + dxo[(long)row * LC + c] * dxs;
+            f.bDy[kf * LC + (long)row * LC + c] = v;
           }
           Dy[c * LT + i] = v;
         }
@@ -620,8 +625,8 @@ __global__ __launch_bounds__(NT) void flow_diag_bwd_kernel(FlowK f, int d, int k
   {
     const float* Wt = f.Wt + (long)k * C * C;
     const float* anl = f.p.an_logs + (long)k * C;
-    const float* A = f.sA + kf * C;
-    float* dxi = k > 0 ? f.bDx + kf * C : nullptr;
+    const float* A = f.sA + kf * LC;
+    float* dxi = k > 0 ? f.bDx + kf * LC : nullptr;
     float* pan = f.bPan + (((long)k * f.N + n) * f.nbt + blockIdx.x) * 2 * C;
     const int nt = (C + 15) >> 4;
     for (int t = wave; t < nt; t += NW) {
@@ -636,9 +641,9 @@ __global__ __launch_bounds__(NT) void flow_diag_bwd_kernel(FlowK f, int d, int k
           const int row = b0 + lq * 4 + r;
           if (row < B) {
             const float da = acc[r];
-            sl += da * A[(long)row * C + c];
+            sl += da * A[(long)row * LC + c];
             sb += da * es;
-            if (dxi) dxi[(long)row * C + c] = da * es;
+            if (dxi) dxi[(long)row * LC + c] = da * es;
           }
         }
       }
@@ -816,7 +821,7 @@ __device__ __forceinline__ void fast_cell_p2(const FlowK& f, const float* Zt, co
 
 // P3: o = (h' Wfl^T + b) exp(3 logs) on this wave's 16 outputs   (LinearZeros, glow/modules.py:93-95); o_out may be null
 __device__ __forceinline__ void fast_cell_p3(const FlowK& f, int k, const float* Hn, float* Orm, const f32x4 (&w3)[FB_H], int nbH,
-                                             int col, int kq, int l15, int b0, int rows, float* o_out) {
+                                             int col, int kq, int l15, int b0, int rows, float* o_out, long ld_out) {
   const int Cout = f.Cout, ldo = Cout + 1;
   const f32x4 acc = mma16_reg<FB_H>(Hn + kq * LT + l15, w3, nbH);
   if (col < Cout) {
@@ -827,7 +832,7 @@ __device__ __forceinline__ void fast_cell_p3(const FlowK& f, int k, const float*
       const int row = b0 + i;
       const float o = (acc[r] + bb) * sc;
       Orm[i * ldo + col] = o;
-      if (o_out && row < rows) o_out[(long)row * Cout + col] = o;
+      if (o_out && row < rows) o_out[(long)row * ld_out + col] = o;
     }
   }
 }
@@ -843,6 +848,7 @@ __global__ __launch_bounds__(NT) void flow_diag_fwd_fast_kernel(FlowK f, int d, 
   const int b0 = bt * MB;
   const int B = f.B, C = f.C, H = f.H, Ch = f.Ch, C2 = f.C2, Cout = f.Cout, G = f.G;
   const int C16 = f.C16, Ch16 = f.Ch16, H16 = f.H16, Co16 = f.Co16;
+  const long LC = f.ldc, LO = f.ldo;   // stash row strides
   const long fr = (long)n * B;
   const long kf = (long)k * f.F + fr;
   const CarveF cv = carve_fast_fwd(C, C16, H16, Ch16, Cout);
@@ -890,14 +896,14 @@ __global__ __launch_bounds__(NT) void flow_diag_fwd_fast_kernel(FlowK f, int d, 
   {
     const int row = b0 + ri;
     const bool rok = row < B;
-    const float* xin = (k == 0) ? f.x0 + ((long)row * f.T + f.start + n) * C : f.sX + (kf - f.F + row) * C;
+    const float* xin = (k == 0) ? f.x0 + ((long)row * f.T + f.start + n) * C : f.sX + (kf - f.F + row) * LC;
     const float* anb = f.p.an_bias + (long)k * C;
     const float* anl = f.p.an_logs + (long)k * C;
     for (int c = cl; c < C16; c += 32) {
       float a = 0.0f;
       if (c < C && rok) {
         a = (xin[c] + anb[c]) * expf(anl[c]);
-        f.sA[(kf + row) * C + c] = a;
+        f.sA[(kf + row) * LC + c] = a;
       }
       At[c * LT + ri] = a;
     }
@@ -923,7 +929,7 @@ __global__ __launch_bounds__(NT) void flow_diag_fwd_fast_kernel(FlowK f, int d, 
         const float v = acc[r];
         Yrm[i * ldy + c] = v;
         if (c < Ch) Zt[c * LT + i] = v;
-        if (row < B) f.sY[(kf + row) * C + c] = v;
+        if (row < B) f.sY[(kf + row) * LC + c] = v;
       }
     }
   }
@@ -940,7 +946,7 @@ __global__ __launch_bounds__(NT) void flow_diag_fwd_fast_kernel(FlowK f, int d, 
   LFI_STAMP(4);
 
   // ---- P3: o = (h' Wfl^T + b) exp(3 logs)   (LinearZeros, glow/modules.py:93-95)
-  if (t3) fast_cell_p3(f, k, Hn, Orm, w3, nbH, tcol, kq, l15, b0, B, f.sO + kf * Cout);
+  if (t3) fast_cell_p3(f, k, Hn, Orm, w3, nbH, tcol, kq, l15, b0, B, f.sO + kf * LO, LO);
   __syncthreads();
   LFI_STAMP(5);
 
@@ -961,9 +967,9 @@ __global__ __launch_bounds__(NT) void flow_diag_fwd_fast_kernel(FlowK f, int d, 
       } else {
         z2n = z2 + Orm[ri * ldo + cl];
       }
-      if (rok) f.sX[(kf + row) * C + Ch + cl] = z2n;
+      if (rok) f.sX[(kf + row) * LC + Ch + cl] = z2n;
     }
-    if (cl < Ch && rok) f.sX[(kf + row) * C + cl] = Yrm[ri * ldy + cl];
+    if (cl < Ch && rok) f.sX[(kf + row) * LC + cl] = Yrm[ri * ldy + cl];
 #pragma unroll
     for (int o = 16; o > 0; o >>= 1) lg += __shfl_xor(lg, o, 64);  // the 32 lanes of one row
     if (cl == 0 && rok) f.sL[kf + row] = lg;
@@ -1036,7 +1042,7 @@ __global__ __launch_bounds__(NT) void flow_step_rev_fast_kernel(FlowK f, CellIO 
   __syncthreads();
   if (t2) fast_cell_p2<NG>(f, Zt, Ht, Hn, wz, wh, gc, bh, cprev, nbZ, nbH, tcol, kq, l15, b0, rows, io.h_out, io.c_out, nullptr);
   __syncthreads();
-  if (t3) fast_cell_p3(f, k, Hn, Orm, w3, nbH, tcol, kq, l15, b0, rows, nullptr);
+  if (t3) fast_cell_p3(f, k, Hn, Orm, w3, nbH, tcol, kq, l15, b0, rows, nullptr, 0);
   __syncthreads();
   // ---- R3: coupling inverse (glow/models.py:356-365)
   {
@@ -1124,6 +1130,7 @@ __global__ __launch_bounds__(NT) void flow_diag_bwd_fast_kernel(FlowK f, int d, 
   const int b0 = bt * MB;
   const int B = f.B, C = f.C, H = f.H, Ch = f.Ch, C2 = f.C2, Cout = f.Cout, G = f.G;
   const int C16 = f.C16, Ch16 = f.Ch16, H16 = f.H16, Co16 = f.Co16;
+  const long LC = f.ldc, LO = f.ldo;   // stash row strides
   const long fr = (long)n * B;
   const long kf = (long)k * f.F + fr;
   const CarveFB cv = carve_fast_bwd(C16, H16, Co16, Cout, NG);
@@ -1138,7 +1145,7 @@ __global__ __launch_bounds__(NT) void flow_diag_bwd_fast_kernel(FlowK f, int d, 
   const bool last = k == f.Ks - 1;
   const float gz = f.gscale / LN2_F;   // d loss / d z = z * gz   (prior term)
   const float dl = -f.gscale / LN2_F;  // d loss / d logdet
-  const float* dxo = last ? f.sX + kf * C : f.bDx + (kf + f.F) * C;
+  const float* dxo = last ? f.sX + kf * LC : f.bDx + (kf + f.F) * LC;
   const float dxs = last ? gz : 1.0f;
 
   // which tiles this wave owns: hidden tile `wave` (Q1, Q2), z tile `wave` (Q2, waves < Ch16/16), channel tile `wave` (Q3)
@@ -1173,8 +1180,8 @@ __global__ __launch_bounds__(NT) void flow_diag_bwd_fast_kernel(FlowK f, int d, 
         scp[r] = hasp ? f.sC[(kf - B + row) * H + j] : 0.0f;
         sdcf[r] = hasn ? f.bDc[(kf + B + row) * H + j] : 0.0f;
       }
-      sdxo[r] = dxo[row * C + cz] * dxs;
-      sa[r] = f.sA[(kf + row) * C + cc];
+      sdxo[r] = dxo[row * LC + cz] * dxs;
+      sa[r] = f.sA[(kf + row) * LC + cc];
     }
   }
 
@@ -1186,13 +1193,13 @@ __global__ __launch_bounds__(NT) void flow_diag_bwd_fast_kernel(FlowK f, int d, 
     float dz2 = 0.0f, dl0 = 0.0f, dl1 = 0.0f, p0 = 0.0f, p1 = 0.0f;
     if (cl < C2) {
       if (rok) {
-        const float dz2n = dxo[(long)row * C + Ch + cl] * dxs;
-        const float* O = f.sO + (kf + row) * Cout;
+        const float dz2n = dxo[(long)row * LC + Ch + cl] * dxs;
+        const float* O = f.sO + (kf + row) * LO;
         if (f.affine) {
           const float oe = O[2 * cl], oo = O[2 * cl + 1];
           const float sraw = sigmoidf_(oo + 2.0f);
           const float sc = fmaxf(sraw, f.eps);
-          const float z2 = f.sY[(kf + row) * C + Ch + cl];
+          const float z2 = f.sY[(kf + row) * LC + Ch + cl];
           dz2 = dz2n * sc;
           const float dsc = dz2n * (z2 + oe) + dl / sc;
           const float dsr = sraw >= f.eps ? dsc : 0.0f;
@@ -1200,14 +1207,14 @@ __global__ __launch_bounds__(NT) void flow_diag_bwd_fast_kernel(FlowK f, int d, 
           const float d1 = dsr * sraw * (1.0f - sraw);      // d o_odd
           p0 = d0 * oe * 3.0f; p1 = d1 * oo * 3.0f;
           dl0 = d0 * expf(3.0f * lfl[2 * cl]); dl1 = d1 * expf(3.0f * lfl[2 * cl + 1]);
-          f.bDlin[(kf + row) * Cout + 2 * cl] = dl0; f.bDlin[(kf + row) * Cout + 2 * cl + 1] = dl1;
+          f.bDlin[(kf + row) * LO + 2 * cl] = dl0; f.bDlin[(kf + row) * LO + 2 * cl + 1] = dl1;
         } else {
           const float oe = O[cl];
           dz2 = dz2n; p0 = dz2n * oe * 3.0f;
           dl0 = dz2n * expf(3.0f * lfl[cl]);
-          f.bDlin[(kf + row) * Cout + cl] = dl0;
+          f.bDlin[(kf + row) * LO + cl] = dl0;
         }
-        f.bDy[(kf + row) * C + Ch + cl] = dz2;
+        f.bDy[(kf + row) * LC + Ch + cl] = dz2;
       }
       Dy[(Ch + cl) * LT + ri] = dz2;
       if (f.affine) {
@@ -1313,7 +1320,7 @@ __global__ __launch_bounds__(NT) void flow_diag_bwd_fast_kernel(FlowK f, int d, 
         float v = 0.0f;
         if (row < B) {
           v = acc[r] + sdxo[r];
-          f.bDy[(kf + row) * C + c] = v;
+          f.bDy[(kf + row) * LC + c] = v;
         }
         Dy[c * LT + i] = v;
       }
@@ -1340,7 +1347,7 @@ __global__ __launch_bounds__(NT) void flow_diag_bwd_fast_kernel(FlowK f, int d, 
           const float da = acc[r];
           sl += da * sa[r];
           sb += da * es;
-          if (k > 0) f.bDx[(kf + row) * C + c] = da * es;
+          if (k > 0) f.bDx[(kf + row) * LC + c] = da * es;
         }
       }
     }
@@ -1687,6 +1694,7 @@ int fill_flow(const lfi_flow_dims* d, const lfi_flow_params* p, const float* pre
   f->p = *p;
   f->stamps = g_lfi_stamps;
   f->NG = d->lstm ? 4 : 3;
+  f->ldc = (f->C + 3) & ~3; f->ldo = (f->Cout + 3) & ~3;
   f->C16 = (f->C + 15) & ~15; f->Ch16 = (f->Ch + 15) & ~15; f->H16 = (f->H + 15) & ~15; f->Co16 = (f->Cout + 15) & ~15;
   if (f->Ch16 == 0) f->Ch16 = 16;
   if (prep) {
@@ -1719,12 +1727,12 @@ int fill_flow(const lfi_flow_dims* d, const lfi_flow_params* p, const float* pre
 long stash_offsets(const FlowK& f, long* off) {
   const long KF = (long)f.Ks * f.F;
   long o = 0;
-  off[0] = o; o += KF * f.C;         // a
-  off[1] = o; o += KF * f.C;         // y
-  off[2] = o; o += KF * f.C;         // x_out
+  off[0] = o; o += KF * f.ldc;       // a      (rows of ldc = C rounded up to 4 floats)
+  off[1] = o; o += KF * f.ldc;       // y
+  off[2] = o; o += KF * f.ldc;       // x_out
   off[3] = o; o += KF * f.H;         // h
   off[4] = o; o += KF * 4 * f.H;     // gates
-  off[5] = o; o += KF * f.Cout;      // o
+  off[5] = o; o += KF * f.ldo;       // o      (rows of ldo = Cout rounded up to 4 floats)
   off[6] = o; o += KF;               // coupling log-det
   off[7] = o; o += f.lstm ? KF * f.H : 0;  // LSTM cell state
   return o;
@@ -1732,11 +1740,11 @@ long stash_offsets(const FlowK& f, long* off) {
 long bstash_offsets(const FlowK& f, long* off) {
   const long KF = (long)f.Ks * f.F;
   long o = 0;
-  off[0] = o; o += KF * f.Cout;      // dlin
+  off[0] = o; o += KF * f.ldo;       // dlin
   off[1] = o; o += KF * f.G;         // dgi
   off[2] = o; o += KF * f.G;         // dgh
-  off[3] = o; o += KF * f.C;         // dy
-  off[4] = o; o += KF * f.C;         // dx
+  off[3] = o; o += KF * f.ldc;       // dy
+  off[4] = o; o += KF * f.ldc;       // dx
   off[5] = o; o += KF * f.H;         // dh
   off[6] = o; o += (long)f.Ks * f.N * f.nbt * f.Cout;   // partial sums for l_fl
   off[7] = o; o += (long)f.Ks * f.N * f.nbt * 2 * f.C;  // partial sums for actnorm logs | bias
@@ -1952,7 +1960,7 @@ extern "C" int lfi_flow_param_grads(const lfi_flow_dims* d, const lfi_flow_param
   q.batch = Ks; q.accumulate = accumulate; q.splitk = splitk; q.work = gws; q.precision = d->gemm_precision;
   q.a_kcontig = 0; q.b_kcontig = 0; q.K = F;
   // w_fl[k] (Cout x H) = dlin[k]^T h[k]
-  q.M = Cout; q.N = H; q.A = f.bDlin; q.lda = Cout; q.strideA = (long)F * Cout; q.B = f.sH; q.ldb = H; q.strideB = (long)F * H;
+  q.M = Cout; q.N = H; q.A = f.bDlin; q.lda = f.ldo; q.strideA = (long)F * f.ldo; q.B = f.sH; q.ldb = H; q.strideB = (long)F * H;
   q.C = g->w_fl; q.ldc = H; q.strideC = (long)Cout * H;
   if ((rc = lfi_gemm_f32(&q, stream))) return rc;
   // w_hh[k] (G x H) = dgh[k][n >= 1]^T h[k][n - 1]
@@ -1966,7 +1974,7 @@ extern "C" int lfi_flow_param_grads(const lfi_flow_dims* d, const lfi_flow_param
   q.K = F;
   // w_ih[k][:, :Ch] (G x Ch) = dgi[k]^T z1[k]
   if (Ch > 0) {
-    q.M = G; q.N = Ch; q.A = f.bDgi; q.lda = G; q.strideA = (long)F * G; q.B = f.sY; q.ldb = C; q.strideB = (long)F * C;
+    q.M = G; q.N = Ch; q.A = f.bDgi; q.lda = G; q.strideA = (long)F * G; q.B = f.sY; q.ldb = f.ldc; q.strideB = (long)F * f.ldc;
     q.C = g->w_ih; q.ldc = I; q.strideC = (long)G * I;
     if ((rc = lfi_gemm_f32(&q, stream))) return rc;
   }
@@ -1976,7 +1984,7 @@ extern "C" int lfi_flow_param_grads(const lfi_flow_dims* d, const lfi_flow_param
   if ((rc = lfi_gemm_f32(&q, stream))) return rc;
   // dW[k] (C x C) = a[k]^T dy[k]  -> LU parameter gradients
   q.accumulate = 0;
-  q.M = C; q.N = C; q.A = f.sA; q.lda = C; q.strideA = (long)F * C; q.B = f.bDy; q.ldb = C; q.strideB = (long)F * C;
+  q.M = C; q.N = C; q.A = f.sA; q.lda = f.ldc; q.strideA = (long)F * f.ldc; q.B = f.bDy; q.ldb = f.ldc; q.strideB = (long)F * f.ldc;
   q.C = dW; q.ldc = C; q.strideC = (long)C * C;
   if ((rc = lfi_gemm_f32(&q, stream))) return rc;
   // constant log-det terms: nll has -(C sum(logs))/ln2 per frame -> d/dlogs = -C/ln2 * gscale * F
@@ -1989,7 +1997,7 @@ extern "C" int lfi_flow_param_grads(const lfi_flow_dims* d, const lfi_flow_param
     LFI_LAUNCH_CHECK("lfi_flow_param_grads invconv");
   }
   // biases and the per-tile partial sums
-  if ((rc = lfi_colsum_f32(f.bDlin, Cout, (long)F * Cout, F, Cout, Ks, g->b_fl, Cout, 1.0f, accumulate, cws, stream))) return rc;
+  if ((rc = lfi_colsum_f32(f.bDlin, f.ldo, (long)F * f.ldo, F, Cout, Ks, g->b_fl, Cout, 1.0f, accumulate, cws, stream))) return rc;
   if ((rc = lfi_colsum_f32(f.bDgh, G, (long)F * G, F, G, Ks, g->b_hh, G, 1.0f, accumulate, cws, stream))) return rc;
   if ((rc = lfi_colsum_f32(f.bDgi, G, (long)F * G, F, G, Ks, g->b_ih, G, 1.0f, accumulate, cws, stream))) return rc;
   const int prow = f.N * f.nbt;

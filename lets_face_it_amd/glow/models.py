@@ -356,7 +356,8 @@ class SeqGlow(nn.Module):
             return
         off = (eng.L.lfi_flow_stash_ptr(C.byref(dims), stash.data_ptr(), 5) - stash.data_ptr()) // 4
         s = self.spec
-        o = stash[off:off + s.Ks * N * B * s.Cout].view(s.Ks, N, B, s.Cout)
+        ldo = (s.Cout + 3) // 4 * 4  # stash rows are padded to 4 floats (lfi.h, lfi_flow_stash_floats)
+        o = stash[off:off + s.Ks * N * B * ldo].view(s.Ks, N, B, ldo)[..., :s.Cout]
         for k, layer in enumerate(self.glow.flow.layers):
             layer.scale = torch.sigmoid(o[k, N - 1, :, 1::2] + 2.0).clamp(min=s.scale_eps)
 
