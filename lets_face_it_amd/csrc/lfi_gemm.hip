@@ -1008,8 +1008,9 @@ extern "C" int lfi_gemm_f32(const lfi_gemm_desc* d, void* stream) {
   };
   const int vecA = vec_ok(d->A, d->lda, d->strideA, d->a_kcontig, d->M, d->K);
   const int vecB = vec_ok(d->B, d->ldb, d->strideB, d->b_kcontig, d->N, d->K);
-  const bool use_x3 = d->precision == 1 && vecA && vecB;
-  const GemmPlan plan = gemm_plan(d->M, d->N, d->K, d->batch, (d->splitk == 0 && !d->work) ? 1 : d->splitk, use_x3);
+  const bool use_x3 = (d->precision & 1) && vecA && vecB;
+  GemmPlan plan = gemm_plan(d->M, d->N, d->K, d->batch, (d->splitk == 0 && !d->work) ? 1 : d->splitk, use_x3);
+  if (use_x3 && (d->precision & 0x30)) plan.shape = (d->precision & 0x10) ? 3 : 0;  // tests pin the tile shape (lfi.h)
   int splitk = plan.splitk < 1 ? 1 : plan.splitk;
   if (splitk > d->K / BKT) splitk = d->K / BKT < 1 ? 1 : d->K / BKT;
   LFI_REQUIRE(splitk == 1 || d->work, "lfi_gemm_f32: splitk needs a workspace");

@@ -146,6 +146,102 @@ def test_gemm_bf16x3(eng, gpu_device, akc, bkc, shape):
     assert err < 3e-5, err
 
 
+@pytest.mark.parametrize("akc,bkc", [(1, 1), (1, 0), (0, 1), (0, 0)])
+@pytest.mark.parametrize("shape,splitk", [((700, 520, 330), 1), ((256, 300, 2100), 0), ((513, 257, 75), 1)])
+def test_gemm_bf16x3_256_tile(eng, gpu_device, akc, bkc, shape, splitk):
+    """The 256 x 256 kernel (transposing LDS reads for mn-contiguous operands, 2-deep register prefetch, wide epilogue),
+    pinned with precision | 0x10: ragged edges, a partial last k-tile, short K (drain loop only), library-chosen split."""
+    M, N, K = shape
+    g = torch.Generator().manual_seed(7 * M + N + K + 2 * akc + bkc)
+    r4 = lambda v: (v + 3) // 4 * 4  # noqa: E731
+    lda, ldb = (r4(K) + 4 if akc else r4(M) + 4), (r4(K) + 8 if bkc else r4(N))
+    A = torch.full((M, lda) if akc else (K, lda), float("nan"))
+    Bm = torch.full((N, ldb) if bkc else (K, ldb), float("nan"))
+    if akc:
+        A[:, :K] = torch.randn(M, K, generator=g)
+    else:
+        A[:, :M] = torch.randn(K, M, generator=g)
+    if bkc:
+        Bm[:, :K] = torch.randn(N, K, generator=g)
+    else:
+        Bm[:, :N] = torch.randn(K, N, generator=g)
+    # the padding is NaN only where no load may touch it: rows are read up to the next multiple of 4 columns
+    if not akc:
+        A[:, M:r4(M)] = 0.0
+    if not bkc:
+        Bm[:, N:r4(N)] = 0.0
+    if akc:
+        A[:, K:r4(K)] = 0.0
+    if bkc:
+        Bm[:, K:r4(K)] = 0.0
+    A, Bm = A.to(gpu_device), Bm.to(gpu_device)
+    bias = torch.randn(N, generator=g).to(gpu_device)
+    ldc = r4(N) + 4
+    Cm = torch.full((M, ldc), 7.0, device=gpu_device)
+    eng.precision = 0x11
+    try:
+        eng.gemm(M, N, K, A, lda, akc, Bm, ldb, bkc, Cm, ldc, bias=bias, act=1, slope=0.01, splitk=splitk)
+    finally:
+        eng.precision = 0
+    torch.cuda.synchronize()
+    Ad = (A[:, :K] if akc else A[:, :M].t()).double()
+    Bd = (Bm[:, :K].t() if bkc else Bm[:, :N]).double()
+    ref = torch.nn.functional.leaky_relu(Ad @ Bd + bias.double(), 0.01)
+    assert torch.isfinite(Cm).all() and bool((Cm[:, N:] == 7.0).all()), "wrote outside the N columns"
+    err = rel_err(Cm[:, :N], ref)
+    assert err < 3e-5, err
+
+
+def test_gemm_in_place_leaky_grad_epilogue(eng, gpu_device):
+    """act = 2 with G == C (the in-place dpre product of the backward pass), batched, through the wide epilogue."""
+    g = torch.Generator().manual_seed(11)
+    F, D, G, Ks = 300, 128, 96, 3
+    dgi = torch.randn(Ks, F, G, generator=g).to(gpu_device)
+    wc = torch.randn(Ks, G, D, generator=g).to(gpu_device)
+    c = torch.randn(F, Ks * D, generator=g).to(gpu_device)
+    ref = c.double().clone()
+    for k in range(Ks):
+        prod = dgi[k].double() @ wc[k].double()
+        blk = ref[:, k * D:(k + 1) * D]
+        ref[:, k * D:(k + 1) * D] = torch.where(blk > 0, prod, 0.01 * prod)
+    for prec in (0, 1, 0x11):
+        cc = c.clone()
+        eng.precision = prec
+        try:
+            eng.gemm(F, D, G, dgi, G, 1, wc, D, 0, cc, Ks * D, act=2, slope=0.01, G=cc, ldg=Ks * D, batch=Ks, sA=F * G,
+                     sB=G * D, sC=D, sG=D)
+        finally:
+            eng.precision = 0
+        torch.cuda.synchronize()
+        assert rel_err(cc, ref) < (2e-6 if prec == 0 else 3e-5), prec
+
+
+def test_masked_window_gather_and_leaky_grad(eng, gpu_device):
+    import ctypes as C
+    from lets_face_it_amd._lib import check
+    g = torch.Generator().manual_seed(5)
+    B, T, dim, start, hist = 6, 14, 7, 5, 3
+    N = T - start
+    x = torch.randn(B, T, dim, generator=g).to(gpu_device)
+    mask = (torch.rand(N, B, hist, generator=g) < 0.5).float().mul(2.0).to(gpu_device)
+    ld = 24
+    out = torch.zeros(N * B, ld, device=gpu_device)
+    st = torch.cuda.current_stream().cuda_stream
+    check(eng.L.lfi_gather_windows(x.data_ptr(), B, T, dim, N, start, hist, 1, mask.data_ptr(), out.data_ptr(), ld, 0, st))
+    torch.cuda.synchronize()
+    for n in (0, 3, N - 1):
+        for b in (0, B - 1):
+            win = x[b, start + n - hist + 1:start + n + 1] * mask[n, b].unsqueeze(-1)
+            assert torch.equal(out[n * B + b, :hist * dim], win.reshape(-1))
+    y = torch.randn(9, 5, generator=g).to(gpu_device)
+    d = torch.randn(9, 8, generator=g).to(gpu_device)
+    want = d.clone()
+    want[:, :5] = torch.where(y > 0, d[:, :5], 0.01 * d[:, :5])
+    check(eng.L.lfi_leaky_grad(d.data_ptr(), 8, y.data_ptr(), 5, 9, 5, 0.01, st))
+    torch.cuda.synchronize()
+    assert torch.equal(d, want)
+
+
 def test_colsum(eng, gpu_device):
     g = torch.Generator().manual_seed(3)
     X = torch.randn(3, 1000, 90, generator=g).to(gpu_device)

@@ -280,6 +280,57 @@ def test_final_model_width_gradients_against_oracle(gpu_device):
     print("final-width gradients: worst relative L2 error %.3e (%s)" % worst[::-1])
 
 
+def test_generic_and_register_resident_cells_agree(gpu_device, monkeypatch):
+    """LFI_FLOW_GENERIC=1 keeps the streaming cell kernels (the path of H > 128 or C > 64): same NLL, same gradients."""
+    fxm = Fixture("mid")
+    outs = []
+    for generic in ("0", "1"):
+        monkeypatch.setenv("LFI_FLOW_GENERIC", generic)
+        m = build(fxm, gpu_device, train=True)
+        m.injected_masks = fxm.masks(torch.float32)
+        z_seq, loss, losses = m(to_dev(fxm.batch(), gpu_device))
+        loss.sum().backward()
+        outs.append((torch.stack(losses), {n: p.grad.clone() for n, p in m.named_parameters()}))
+    assert max_rel(outs[0][0], outs[1][0], floor=1.0) < 2e-6
+    for n in outs[0][1]:
+        assert rel_err(outs[0][1][n], outs[1][1][n]) < 2e-5, n
+    assert max_rel(outs[1][0], fxm.get("train/nll"), floor=1.0) < 1e-4
+
+
+def test_wide_hidden_sizes_take_the_generic_paths(gpu_device):
+    """hidden_channels 160 (> 128: streaming flow cells) and a 320-wide GRU window encoder (> 256: unfused recurrence), both
+    in the reference's hparam search space (large_hparam_search.py:33,57): NLL and gradients against the fp64 oracle."""
+    hp = final_model_hparams(50, 27, K=2)
+    hp["Glow"]["hidden_channels"] = 160
+    hp["Conditioning"]["p2_face"]["hidden_dim"] = 320
+    hp["Conditioning"]["cond_dim"] = 64
+    m, sd = perturbed_model(hp, gpu_device)
+    m.precision = "f32"
+    m.train()
+    B, T = 5, 30
+    batch = oracle.synthetic_batch(B, T, 50, 27, seed=3)
+    N = T - 24
+    g = torch.Generator().manual_seed(5)
+    masks = {}
+    for name in ("p2_face", "p1_speech", "p2_speech"):
+        cfg = hp["Conditioning"][name]
+        keep = 1.0 - cfg["dropout"]
+        masks[name] = (torch.rand(N, B, cfg["history"], generator=g) < keep).float() / keep
+    m.injected_masks = masks
+    _, loss, losses = m(to_dev(batch, gpu_device))
+    loss.sum().backward()
+    sdg = {k: v.double().requires_grad_(v.dtype.is_floating_point and not k.endswith((".p", ".sign_s")))
+           for k, v in sd.items()}
+    _, oloss, onll = oracle.seqglow_forward(hp, sdg, {k: v.double() for k, v in batch.items()},
+                                            {k: v.double() for k, v in masks.items()})
+    oloss.sum().backward()
+    assert max_rel(torch.stack(losses), onll.detach(), floor=1.0) < 1e-4
+    for name, p in m.named_parameters():
+        ref = sdg[name].grad
+        rel = float((p.grad.double().cpu() - ref).norm() / max(float(ref.norm()), 1e-12))
+        assert rel < 2e-3, (name, rel)
+
+
 def test_full_size_properties(gpu_device):
     """BASELINE configs[1] size (B=256, T=80, K=16): size-independent properties instead of an oracle run."""
     hp = final_model_hparams(50, 27)
