@@ -112,19 +112,24 @@ def _roofline(spec, F, timing, precision):
     flops = 2.0 * F * KD * spec.Ef
     n_launch, ms = timing.get("gemm_cond_fwd", (0, float("nan")))
     ach = flops / (ms * 1e-3) / 1e12 if n_launch else float("nan")
+    # which kernel lfi_gemm_f32 picks for this product: bf16x3 takes the 256 x 256 tile (1024 threads) unless
+    # LFI_GEMM_256=0, f32 the 128 x 128 tile (256 threads); the rocprof kernel names below are what --kernel-trace prints
     if precision == "bf16x3":
-        peak, kern, mult = BF16_MFMA_PEAK_TFLOPS, "gemm_bf16x3_kernel<128,128,k32>", 3.0
+        big = os.environ.get("LFI_GEMM_256", "1") != "0"
+        peak, mult = BF16_MFMA_PEAK_TFLOPS, 3.0
+        kern = "gemm_bf16x3_256_kernel<true, true>" if big else "gemm_bf16x3_kernel<true, true>"
+        tile, threads = (256, 1024) if big else (128, 256)
     else:
-        peak, kern, mult = F32_MFMA_PEAK_TFLOPS, "gemm_f32_kernel<128,128,k16>", 1.0
+        peak, kern, mult = F32_MFMA_PEAK_TFLOPS, "gemm_f32_kernel<128, 128, 2, 2, true, true", 1.0
+        tile, threads = 128, 256
     # HBM bytes per launch of that kernel from the PMC passes of the same command (tools/pmc_bench.sh -> profiles/):
     # bench.py cannot collect counters itself; null when no committed measurement matches this kernel and grid
     traffic, traffic_src = None, None
     try:
-        tiles = ((F + 127) // 128) * ((KD + 127) // 128)
+        tiles = ((F + tile - 1) // tile) * ((KD + tile - 1) // tile)
         tj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_%s.json" % precision)))
         for name, v in tj["kernels"].items():
-            if ("bf16x3_kernel<true, true>" in name if precision == "bf16x3" else "gemm_f32_kernel<128, 128, 2, 2, true, true" in name) \
-                    and name.endswith("grid=%d" % (tiles * 256)):
+            if kern in name and name.endswith("grid=%d" % (tiles * threads)):
                 traffic, traffic_src = v["hbm_bytes"], "profiles/pmc_traffic_%s.json (%s)" % (precision, tj["source"])
     except (OSError, ValueError, KeyError):
         pass

@@ -116,6 +116,10 @@ int lfi_encode_windows_scatter(const lfi_enc_desc* d, const float* dgi, const fl
  * mask (F x hist) = the dropout multipliers of glow/models.py:56-58, or NULL) */
 int lfi_gather_windows(const float* X, int B, int T, int dim, int N, int start, int hist, int incl, const float* mask,
                        float* cond, int ldcond, int col, void* stream);
+/* Conditioning.use_frame_nb (glow/models.py:89,116-117,143-144): one extra feature column holding a frame counter,
+ * cond[n*B + b, col] = base[b] + offset + 2n. SeqGlow.forward / invert pass base = batch["frame_nb"] (B floats) and
+ * offset = 2 * start (glow/models.py:539-542,557-558,623-625); SeqGlow.inference starts from ones: base = NULL (:572-575). */
+int lfi_fill_frame_nb(const float* base, float offset, int B, int N, float* cond, int ldcond, int col, void* stream);
 /* d[r, c] *= (y[r, c] > 0 ? 1 : slope): backward of the LeakyReLU of an "enc: mlp" modality, in place on the feature
  * gradient block (its weight / bias gradients then follow from lfi_gemm_f32 / lfi_colsum_f32). */
 int lfi_leaky_grad(float* d, long ldd, const float* y, long ldy, int rows, int cols, float slope, void* stream);

@@ -171,6 +171,17 @@ __global__ __launch_bounds__(256) void gather_windows_kernel(const float* __rest
   }
 }
 
+// FeatureEncoder's optional frame-counter column (glow/models.py:89,116-117,143-144): frame f = n*B + b gets base[b] + offset + 2n
+// (SeqGlow.forward / invert: base = batch["frame_nb"], offset = 2 * start, :539-542,557-558; inference: base = 1, offset 0, :572-575)
+__global__ __launch_bounds__(256) void fill_frame_nb_kernel(const float* __restrict__ base, float offset, int B, long F,
+                                                            float* __restrict__ cond, int ldcond, int col) {
+  for (long f = (long)blockIdx.x * 256 + threadIdx.x; f < F; f += (long)gridDim.x * 256) {
+    const long n = f / B;
+    const int b = (int)(f - n * B);
+    cond[f * ldcond + col] = (base ? base[b] : 1.0f) + offset + 2.0f * (float)n;
+  }
+}
+
 __global__ __launch_bounds__(256) void leaky_grad_kernel(float* __restrict__ d, long ldd, const float* __restrict__ y, long ldy, int rows,
                                                          int cols, float slope) {
   const long total = (long)rows * cols;
@@ -903,6 +914,14 @@ extern "C" int lfi_gather_windows(const float* X, int B, int T, int dim, int N, 
   hipLaunchKernelGGL(gather_windows_kernel, dim3(N * B), dim3(256), 0, (hipStream_t)stream, X, B, T, dim, N, start, hist,
                      incl, mask, cond, ldcond, col);
   LFI_LAUNCH_CHECK("lfi_gather_windows");
+  return LFI_OK;
+}
+
+extern "C" int lfi_fill_frame_nb(const float* base, float offset, int B, int N, float* cond, int ldcond, int col, void* stream) {
+  LFI_REQUIRE(cond && B > 0 && N > 0 && col >= 0 && col < ldcond, "lfi_fill_frame_nb: bad arguments");
+  hipLaunchKernelGGL(fill_frame_nb_kernel, dim3(ew_blocks((long)N * B)), dim3(256), 0, (hipStream_t)stream, base, offset, B,
+                     (long)N * B, cond, ldcond, col);
+  LFI_LAUNCH_CHECK("lfi_fill_frame_nb");
   return LFI_OK;
 }
 

@@ -43,6 +43,8 @@ class EncoderSpec:
             self.dim = hid
         elif enc == "none":
             self.dim = in_dim * hist
+        elif enc == "frame_nb":  # FeatureEncoder's frame-counter column (models.py:116-117,143-144), not a ModalityEncoder
+            self.dim = 1
         else:
             raise NotImplementedError(
                 "encoder type %r for %s: 'rnn' (GRU), 'mlp' and 'none' have HIP kernels in this build ('lstm' is in no "
@@ -70,8 +72,7 @@ class ModelSpec:
         if glow["flow_permutation"] != "invconv":
             raise NotImplementedError("flow_permutation %r: only 'invconv' works in the reference too "
                                       "(Permute2d is broken, modules.py:98-118)" % glow["flow_permutation"])
-        if cond.get("use_frame_nb"):
-            raise NotImplementedError("use_frame_nb is off in every shipped hparams file; not implemented")
+        self.use_frame_nb = bool(cond.get("use_frame_nb"))
         self.start = max(cond[m]["history"] for m in ENC_ORDER)
         self.encoders = []
         col = 0
@@ -84,6 +85,11 @@ class ModelSpec:
             e = EncoderSpec(m, cfg["enc"], in_dim, hist, int(cfg["hidden_dim"] or 0), float(cfg["dropout"] or 0))
             e.col = col
             col += e.dim
+            self.encoders.append(e)
+        if self.use_frame_nb:  # last column of the feature vector (models.py:143-144)
+            e = EncoderSpec("frame_nb", "frame_nb", 1, 1, 0, 0.0)
+            e.col = col
+            col += 1
             self.encoders.append(e)
         self.E = col
         self.Ch = self.C // 2
@@ -321,7 +327,7 @@ class GlowEngine:
             raise ValueError("%s: expected contiguous float32 GPU tensor (B=%d, T>=%d, %d), got %s %s on %s"
                              % (name, B, Tmin, dim, tuple(x.shape), x.dtype, x.device))
 
-    def build_features(self, data, faces, B, T, masks, cond, with_stash, skip_p1=False):
+    def build_features(self, data, faces, B, T, masks, cond, with_stash, skip_p1=False, sampling=False):
         """FeatureEncoder.forward for every timestep at once (models.py:127-145): fills cond (F x ldf, folded layout)."""
         s = self.spec
         N = T - s.start
@@ -330,6 +336,21 @@ class GlowEngine:
         for e in s.encoders:
             p1 = e.name == "p1_face"
             if p1 and skip_p1:
+                continue
+            if e.enc == "frame_nb":
+                # forward / invert count from batch["frame_nb"] + 2 * start (models.py:539-542,623-625); inference from
+                # ones (:572-575); +2 per timestep either way
+                base = None
+                if not sampling:
+                    base = data.get("frame_nb")
+                    if base is None:
+                        raise KeyError("Conditioning.use_frame_nb is set but the batch has no 'frame_nb' entry")
+                    if not (base.is_cuda and base.dtype == torch.float32 and base.numel() == B):
+                        raise ValueError("frame_nb: expected a float32 GPU tensor of shape (B, 1), got %s %s on %s"
+                                         % (tuple(base.shape), base.dtype, base.device))
+                    base = base.contiguous()
+                check(self.L.lfi_fill_frame_nb(ptr(base), 0.0 if sampling else 2.0 * s.start, B, N, cond.data_ptr(), s.ldf,
+                                               e.fcol, st), "lfi_fill_frame_nb")
                 continue
             # prev_p1_face is the window [t - hist, t) of the model's own output (models.py:601-603); every other modality
             # (t - hist, t] of its input stream (:607-610): same kernels, window end shifted by one frame
@@ -578,7 +599,7 @@ class GlowEngine:
         self.run_prep(with_inverse=True)
         # everything of the features that does not depend on generated frames, through cond_transform (no activation yet)
         cond = self._buf("cond", F * s.ldf)
-        self.build_features(data, None, B, seq_len, masks, cond, with_stash=False, skip_p1=True)
+        self.build_features(data, None, B, seq_len, masks, cond, with_stash=False, skip_p1=True, sampling=True)
         e1 = s.encoders[0]             # prev_p1_face: the only autoregressive input
         c1 = (e1.fdim + 3) // 4 * 4    # first column after its block (blocks start on 4-float boundaries)
         pre = self._buf("pre_static", F * KD)

@@ -50,7 +50,7 @@ def base_hparams():
 def make_config(name):
     hp = base_hparams()
     c, g = hp["Conditioning"], hp["Glow"]
-    if name in ("tiny", "tiny_lstm", "tiny_additive"):
+    if name in ("tiny", "tiny_lstm", "tiny_additive", "framenb"):
         # BASELINE.json configs[0]: 2-step/1-level, 16-d, seq_len 20, batch 4
         c["cond_dim"] = 32
         c["p1_face"].update(history=2, dim=16)
@@ -65,6 +65,8 @@ def make_config(name):
             g["rnn_type"] = "lstm"
         if name == "tiny_additive":
             g["flow_coupling"] = "additive"
+        if name == "framenb":  # Conditioning.use_frame_nb: one frame-counter column appended to the features
+            c["use_frame_nb"] = True
     elif name == "odd":
         # odd channel count (C=15 -> z1 7, z2 8, coupling output C+1), L=2, one modality switched off
         c["cond_dim"] = 40
@@ -215,6 +217,16 @@ def build(name, models, modules, oracle):
     sd32 = {k: v.clone() for k, v in model.state_dict().items()}
     sd64 = {k: v.double() for k, v in sd32.items()}
     batch32 = oracle.synthetic_batch(B, T, C, S, seed=1234)
+    use_nb = bool(hp["Conditioning"]["use_frame_nb"])
+
+    def with_frame_nb(b, first):
+        # MimicryDataset would supply the index of the window's first frame; any (B, 1) float works for parity. Kept small
+        # (a real counter of several thousand saturates LeakyReLU(cond_transform) and hides every other column)
+        if use_nb:
+            b["frame_nb"] = (torch.arange(b["p1_face"].shape[0], dtype=torch.float32).view(-1, 1) * 0.25 + first) * 0.1
+        return b
+
+    batch32 = with_frame_nb(batch32, 1.0)
     batch64 = {k: v.double() for k, v in batch32.items()}
     start = oracle.longest_history(hp["Conditioning"])
     N = T - start
@@ -301,7 +313,7 @@ def build(name, models, modules, oracle):
     # ---- 5. sampling with injected prior noise (models.py:567-596)
     seq_len = T + 6
     eps_std = 0.7
-    long_batch = oracle.synthetic_batch(B, seq_len, C, S, seed=99)
+    long_batch = with_frame_nb(oracle.synthetic_batch(B, seq_len, C, S, seed=99), 3.0)
     data32 = {k: v for k, v in long_batch.items()}
     data32["p1_face"] = data32["p1_face"][:, :start].clone()
     data64 = {k: v.double() for k, v in data32.items()}
@@ -331,7 +343,7 @@ def build(name, models, modules, oracle):
 
     # ---- 7. ActNorm data-dependent init on a larger batch (modules.py:32-43)
     Bi = 32
-    init_batch = {k: v.double() for k, v in oracle.synthetic_batch(Bi, T, C, S, seed=7).items()}
+    init_batch = {k: v.double() for k, v in with_frame_nb(oracle.synthetic_batch(Bi, T, C, S, seed=7), 2.0).items()}
     m_init = to_double(model)
     m_init.glow.set_actnorm_init(False)
     m_init.train()
@@ -364,7 +376,7 @@ def main():
     from oracle import seqglow_oracle as oracle
     models, modules, utils = import_reference()
     lstm_shim(models)
-    names = sys.argv[1:] or ("tiny", "tiny_lstm", "tiny_additive", "odd", "mid", "mlp", "p1enc", "p1mlp")
+    names = sys.argv[1:] or ("tiny", "tiny_lstm", "tiny_additive", "odd", "mid", "mlp", "p1enc", "p1mlp", "framenb")
     for name in names:
         out = build(name, models, modules, oracle)
         path = os.path.join(HERE, name + ".npz")

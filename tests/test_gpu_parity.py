@@ -15,7 +15,7 @@ from oracle import seqglow_oracle as oracle
 
 pytestmark = pytest.mark.gpu
 
-GPU_FIXTURES = ("tiny", "tiny_lstm", "tiny_additive", "odd", "mid", "mlp", "p1enc", "p1mlp")
+GPU_FIXTURES = ("tiny", "tiny_lstm", "tiny_additive", "odd", "mid", "mlp", "p1enc", "p1mlp", "framenb")
 
 
 def build(fx, device, train=False, precision="f32"):
@@ -354,3 +354,77 @@ def test_full_size_properties(gpu_device):
         # (3) a sub-batch reproduces its rows (no cross-sample coupling, tiles of 16 vs ragged 40)
         _, _, losses_s = m({k: v[:40].contiguous() for k, v in batch.items()})
         assert torch.equal(torch.stack(losses_s), nll[:, :40])
+
+
+def test_config4_deep_flow_properties(gpu_device):
+    """BASELINE configs[4]: K=32 x L=3 (96 flow steps), seq_len 512, batch 128 - too large for the CPU oracle, so
+    size-independent properties: finite NLL, decode(encode(x)) = x, forward/backward NLL identity, sub-batch invariance, and
+    additivity of the gradient over a split of the batch (the loss is a batch mean: grad(B) = (grad(B1) + grad(B2)) / 2)."""
+    hp = final_model_hparams(50, 27, K=32)
+    hp["Glow"]["L"] = 3
+    hp["Train"]["seq_len"] = 512
+    m, _ = perturbed_model(hp, gpu_device)
+    assert m.spec.Ks == 96
+    m.eval()  # no dropout: the three passes below see the same function
+    B, T = 128, 512
+    batch = to_dev(oracle.synthetic_batch(B, T, 50, 27, seed=1234), gpu_device)
+    with torch.no_grad():
+        z_seq, loss, losses = m(batch)
+        nll = torch.stack(losses)
+        assert nll.shape == (T - 24, B) and torch.isfinite(nll).all()
+        short = {k: v[:, :24 + 40].contiguous() for k, v in batch.items()}   # invert walks (n, k) cell by cell: keep it short
+        z_short, loss_s, _ = m(short)
+        assert torch.equal(torch.stack(z_short), torch.stack(z_seq[:40]))    # causal: a prefix reproduces its timesteps
+        rec, bl = m.invert(z_short, short)
+        assert rel_err(torch.stack(rec), short["p1_face"][:, 24:].transpose(0, 1)) < 5e-4
+        logp = (-0.5 * (torch.stack(z_short) ** 2 + oracle.LOG2PI)).sum(-1)
+        assert rel_err(bl + loss_s, -2.0 * logp.mean().reshape(1) / oracle.LN2) < 1e-4
+        _, _, losses_s = m({k: v[:24].contiguous() for k, v in batch.items()})
+        assert torch.equal(torch.stack(losses_s), nll[:, :24])
+
+    def grads(b):
+        m.zero_grad(set_to_none=True)
+        _, l, _ = m(b)
+        l.sum().backward()
+        return {n: p.grad.detach().clone() for n, p in m.named_parameters()}
+
+    g_all = grads(batch)
+    g_a = grads({k: v[:64].contiguous() for k, v in batch.items()})
+    g_b = grads({k: v[64:].contiguous() for k, v in batch.items()})
+    worst = 0.0
+    for n, g in g_all.items():
+        assert torch.isfinite(g).all(), n
+        ref = 0.5 * (g_a[n] + g_b[n])
+        worst = max(worst, float((g - ref).norm() / max(float(ref.norm()), 1e-20)))
+    print("config[4] 96 flow steps x 488 timesteps x batch 128: gradient additivity over a batch split, worst rel L2 %.3e" % worst)
+    assert worst < 1e-4
+
+
+def test_config3_sampling_full_size(gpu_device):
+    """BASELINE configs[3]: autoregressive sampling, batch 1024, seq_len 300. Properties: finite; the hipGraph replay (second
+    call of a shape) is bit-identical to the eager first call; a sub-batch reproduces its rows; and the teacher-forced
+    forward pass maps the generated frames back to the injected prior noise (encode(decode(z)) = z)."""
+    hp = final_model_hparams(50, 27)
+    m, _ = perturbed_model(hp, gpu_device)
+    m.eval()
+    B, T = 1024, 300
+    g = torch.Generator().manual_seed(11)
+    data = {"p1_face": torch.zeros(B, T, 50)}
+    for name, d in (("p2_face", 50), ("p1_speech", 27), ("p2_speech", 27)):
+        data[name] = torch.randn(B, T, d, generator=g)
+    data = to_dev(data, gpu_device)
+    noise = (torch.randn(T - 24, B, 50, generator=g) * 0.8).to(gpu_device)
+    out1 = m.inference(T, data, noise=noise)   # eager launches
+    out2 = m.inference(T, data, noise=noise)   # captured + replayed
+    out3 = m.inference(T, data, noise=noise)   # replayed
+    assert out1.shape == (B, T - 24, 50) and torch.isfinite(out1).all()
+    assert torch.equal(out1, out2) and torch.equal(out1, out3)
+    sub = m.inference(T, {k: v[:48].contiguous() for k, v in data.items()}, noise=noise[:, :48].contiguous())
+    assert torch.equal(sub, out1[:48])
+    full = dict(data)
+    full["p1_face"] = torch.cat([data["p1_face"][:, :24], out1], dim=1).contiguous()
+    with torch.no_grad():
+        z_seq, _, _ = m(full)
+    err = float((torch.stack(z_seq) - noise).abs().max())
+    print("config[3] batch 1024 x 276 generated frames: |encode(decode(z)) - z| max %.3e" % err)
+    assert err < 2e-3
