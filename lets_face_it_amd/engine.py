@@ -119,6 +119,25 @@ class ModelSpec:
         self.Ef = fcol
         self.ldf = (fcol + 15) // 16 * 16  # row stride of the folded feature matrix / weights (16-float aligned)
 
+    @classmethod
+    def flow_only(cls, C, H, D, Ks, E, affine, rnn_type, lu, scale_eps, actnorm_scale):
+        """Shapes of a stand-alone FlowNet / FlowStep (the module-level API the reference's test_modules.py exercises):
+        no window encoders, the feature vector is whatever the caller passes as `condition` (B x E)."""
+        s = object.__new__(cls)
+        s.C, s.S, s.D, s.H, s.Ks, s.E = int(C), 0, int(D), int(H), int(Ks), int(E)
+        s.affine, s.rnn_type, s.lu = int(bool(affine)), rnn_type or "gru", bool(lu)
+        s.scale_eps, s.actnorm_scale = float(scale_eps), float(actnorm_scale)
+        s.use_frame_nb, s.start, s.encoders, s.p1_cols = False, 0, [], 0
+        s.Ch = s.C // 2
+        s.C2 = s.C - s.Ch
+        s.Cout = 2 * s.C2 if s.affine else s.C2
+        s.G = (4 if s.rnn_type == "lstm" else 3) * s.H
+        s.I = s.Ch + s.D
+        s.fold_a, s.fold_b, s.unfold = list(range(s.E)), [-1] * s.E, list(range(s.E))
+        s.Ef = s.E
+        s.ldf = (s.E + 15) // 16 * 16
+        return s
+
     def flow_shapes(self):
         Ks, C, H, D, E, G, I, Cout = self.Ks, self.C, self.H, self.D, self.E, self.G, self.I, self.Cout
         shapes = {
@@ -327,10 +346,13 @@ class GlowEngine:
             raise ValueError("%s: expected contiguous float32 GPU tensor (B=%d, T>=%d, %d), got %s %s on %s"
                              % (name, B, Tmin, dim, tuple(x.shape), x.dtype, x.device))
 
-    def build_features(self, data, faces, B, T, masks, cond, with_stash, skip_p1=False, sampling=False):
-        """FeatureEncoder.forward for every timestep at once (models.py:127-145): fills cond (F x ldf, folded layout)."""
+    def build_features(self, data, faces, B, T, masks, cond, with_stash, skip_p1=False, sampling=False, windows=False):
+        """FeatureEncoder.forward for every timestep at once (models.py:127-145): fills cond (F x ldf, folded layout).
+
+        windows=True: `data` holds ONE conditioning window per modality, (B, hist, dim) each, as create_conditioning
+        cuts them (models.py:598-615), and `data["frame_nb"]` the counter itself: one timestep, N = 1."""
         s = self.spec
-        N = T - s.start
+        N = 1 if windows else T - s.start
         F = N * B
         st = _stream()
         for e in s.encoders:
@@ -349,29 +371,32 @@ class GlowEngine:
                         raise ValueError("frame_nb: expected a float32 GPU tensor of shape (B, 1), got %s %s on %s"
                                          % (tuple(base.shape), base.dtype, base.device))
                     base = base.contiguous()
-                check(self.L.lfi_fill_frame_nb(ptr(base), 0.0 if sampling else 2.0 * s.start, B, N, cond.data_ptr(), s.ldf,
-                                               e.fcol, st), "lfi_fill_frame_nb")
+                check(self.L.lfi_fill_frame_nb(ptr(base), 0.0 if (sampling or windows) else 2.0 * s.start, B, N,
+                                               cond.data_ptr(), s.ldf, e.fcol, st), "lfi_fill_frame_nb")
                 continue
             # prev_p1_face is the window [t - hist, t) of the model's own output (models.py:601-603); every other modality
             # (t - hist, t] of its input stream (:607-610): same kernels, window end shifted by one frame
             x = faces if p1 else data.get(e.name)
             if x is None:
                 raise KeyError("batch is missing modality %r" % e.name)
-            self._check_input(x, e.name, B, T, e.in_dim)
+            self._check_input(x, e.name, B, e.hist if windows else T, e.in_dim)
             Tx = x.shape[1]
             incl = 0 if p1 else 1
+            start = (e.hist - incl) if windows else s.start   # a lone window ends at its own last row
+            if windows and Tx != e.hist:
+                raise ValueError("%s: a conditioning window has %d frames, got %d" % (e.name, e.hist, Tx))
             mk = None if masks is None else masks.get(e.name)
             if mk is not None and not (tuple(mk.shape) == (N, B, e.hist) and mk.is_contiguous()
                                        and mk.dtype == torch.float32 and mk.is_cuda):
                 raise ValueError("mask for %s must be a contiguous float32 GPU tensor (N, B, hist)" % e.name)
             if e.enc == "none":
-                check(self.L.lfi_gather_windows(x.data_ptr(), B, Tx, e.in_dim, N, s.start, e.hist, incl, ptr(mk),
+                check(self.L.lfi_gather_windows(x.data_ptr(), B, Tx, e.in_dim, N, start, e.hist, incl, ptr(mk),
                                                 cond.data_ptr(), s.ldf, e.fcol, st), "lfi_gather_windows")
                 continue
             hid = e.hid
             if e.enc == "mlp":  # Linear(hist * in -> hid) + LeakyReLU on the flattened (masked) window (models.py:70-71)
                 win = self._buf("enc_win." + e.name, F * e.win, zero=False)
-                check(self.L.lfi_gather_windows(x.data_ptr(), B, Tx, e.in_dim, N, s.start, e.hist, incl, ptr(mk),
+                check(self.L.lfi_gather_windows(x.data_ptr(), B, Tx, e.in_dim, N, start, e.hist, incl, ptr(mk),
                                                 win.data_ptr(), e.win, 0, st), "lfi_gather_windows")
                 self.gemm(F, hid, e.in_dim * e.hist, win, e.win, 1, self.view("enc.%s.mlp_weight" % e.name),
                           e.in_dim * e.hist, 1, cond, s.ldf, bias=self.view("enc.%s.mlp_bias" % e.name), act=1, slope=0.01,
@@ -383,7 +408,7 @@ class GlowEngine:
                       xp, 3 * hid)
             gates = self._buf("enc_gates." + e.name, e.hist * F * 4 * hid) if with_stash else None
             hseq = self._buf("enc_hseq." + e.name, e.hist * F * hid)
-            d = EncDesc(B, Tx, N, s.start - 1 + incl, e.hist, hid, s.ldf, e.fcol, self.precision, 0)
+            d = EncDesc(B, Tx, N, start - 1 + incl, e.hist, hid, s.ldf, e.fcol, self.precision, 0)
             work = self._buf("scratch.enc", self.L.lfi_encode_windows_work_floats(C.byref(d)))
             check(self.L.lfi_encode_windows_fwd(
                 C.byref(d), xp.data_ptr(), self.view("enc.%s.weight_hh" % e.name).data_ptr(),
@@ -557,6 +582,79 @@ class GlowEngine:
             self.view(gname + "weight_hh", self.grads).zero_()
         if part is None:
             self.colsum(dgh, G3, 0, e.hist * F, G3, 1, gbh, 0)
+
+    def encode_condition(self, condition, masks=None):
+        """FeatureEncoder.forward on ONE timestep's conditioning dict (models.py:127-145): {"prev_p1_face": (B, h1, C),
+        "p2_face": (B, h, C), "p1_speech" / "p2_speech": (B, h, S), "frame_nb": (B, 1)} -> (B, E) features in the
+        reference's layout (a GRU encoder's output twice)."""
+        s = self.spec
+        data = {("p1_face" if k == "prev_p1_face" else k): v for k, v in condition.items()}
+        faces = data["p1_face"]
+        B = faces.shape[0]
+        cond = self._buf("step_cond", B * s.ldf, zero=True)
+        self.build_features(data, faces, B, 0, masks, cond, with_stash=False, windows=True)
+        return cond[:B * s.ldf].view(B, s.ldf).index_select(1, self.unfold.long())
+
+    # ------------------------------------------------------------------ module-level FlowNet / FlowStep / Glow calls
+    def flow_net(self, x, cond, h_prev, c_prev, reverse, init_actnorm=None):
+        """FlowNet.encode / decode (models.py:444-462) on ONE (B, C) batch with explicit recurrent state.
+
+        cond: (B, E) feature vector in the reference's layout (what FeatureEncoder.forward returns). h_prev / c_prev:
+        per flow step a (B, H) tensor or None (= the zero state of the first call after init_rnn_hidden).
+        init_actnorm: None, or the all-reduce callable of the data-dependent ActNorm init (modules.py:32-43): each layer
+        is initialised from its own input before it runs, as ActNorm2d.forward does on its first training-mode call.
+        -> out (B, C), logdet (B,) (actnorm + invconv + coupling; the reverse pass returns the negated sum),
+           h_new (Ks, B, H), c_new (Ks, B, H) or None."""
+        s = self.spec
+        B = x.shape[0]
+        for t, name, w in ((x, "input", s.C), (cond, "condition", s.E)):
+            if not (t.is_cuda and t.dtype == torch.float32 and t.dim() == 2 and t.shape == (B, w)):
+                raise ValueError("%s: expected a float32 GPU tensor of shape (%d, %d), got %s %s on %s"
+                                 % (name, B, w, tuple(t.shape), t.dtype, t.device))
+        x, cond = x.contiguous(), cond.contiguous()
+        st = _stream()
+        self.run_prep(with_inverse=bool(reverse))
+        KD = s.Ks * s.D
+        cb = self._buf("step_c", B * KD)
+        # the UNfolded cond_transform weights: a caller's feature vector need not repeat the GRU halves
+        self.gemm(B, KD, s.E, cond, s.E, 1, self.fview("wct"), s.E, 1, cb, KD, bias=self.fview("bct"), act=1, slope=0.01)
+        gic = self._buf("step_gic", s.Ks * B * s.G)
+        self.gemm(B, s.G, s.D, cb, KD, 1, self.prep, s.D, 1, gic, s.G, bias=self.fview("b_ih"),
+                  batch=s.Ks, sA=s.D, sB=s.G * s.D, sC=B * s.G, sBias=s.G, b_off=self._wc_offset())
+        dims = self._flow_dims(B, 1)
+        p = self._flow_params()
+        lstm = s.rnn_type == "lstm"
+        f32 = dict(dtype=torch.float32, device=self.device)
+        h_new = torch.empty(s.Ks, B, s.H, **f32)
+        c_new = torch.empty(s.Ks, B, s.H, **f32) if lstm else None
+        ld = torch.zeros(B, **f32)
+        bufs = (torch.empty(B, s.C, **f32), torch.empty(B, s.C, **f32))
+        sums = torch.zeros(2 * s.C, dtype=torch.float64, device=self.device) if init_actnorm is not None else None
+        src = x
+        order = range(s.Ks - 1, -1, -1) if reverse else range(s.Ks)
+        for i, k in enumerate(order):
+            if sums is not None:
+                sums.zero_()
+                check(self.L.lfi_actnorm_init_stats(src.data_ptr(), B, s.C, sums.data_ptr(), st), "lfi_actnorm_init_stats")
+                world = init_actnorm(sums)
+                check(self.L.lfi_actnorm_init_apply(sums.data_ptr(), float(B * world), s.C, s.actnorm_scale,
+                                                    self.fview("an_bias")[k].data_ptr(), self.fview("an_logs")[k].data_ptr(),
+                                                    st), "lfi_actnorm_init_apply")
+            hp = None if h_prev is None else h_prev[k]
+            cp = None if (c_prev is None or not lstm) else c_prev[k]
+            for t in (hp, cp):
+                if t is not None and not (t.is_cuda and t.dtype == torch.float32 and t.shape == (B, s.H) and t.is_contiguous()):
+                    raise ValueError("recurrent state of flow step %d: expected a contiguous float32 GPU (%d, %d) tensor" % (k, B, s.H))
+            dst = bufs[i & 1]
+            check(self.L.lfi_flow_step(C.byref(dims), C.byref(p), self.prep.data_ptr(), k, B, src.data_ptr(), s.C, ptr(hp),
+                                       ptr(cp), gic.data_ptr() + 4 * k * B * s.G, dst.data_ptr(), s.C, h_new[k].data_ptr(),
+                                       ptr(None if c_new is None else c_new[k]), ld.data_ptr(), 1 if reverse else 0, st),
+                  "lfi_flow_step")
+            src = dst
+        if sums is not None:
+            self.run_prep(with_inverse=bool(reverse))  # the constant log-det term depends on the new actnorm logs
+        const = self.prep[self._ldconst_offset()]
+        return src, (ld - const if reverse else ld + const), h_new, c_new
 
     # ------------------------------------------------------------------ optimiser
     def optimizer_step(self, lr, beta1, beta2, eps, clip=0.0, gmul=1.0):

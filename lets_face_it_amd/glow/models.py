@@ -69,6 +69,14 @@ class FeatureEncoder(nn.Module):
             self.dim += self.p2_speech_encoder.dim
         if self.use_frame_nb:
             self.dim += 1
+        self._encode = None  # set by the owning SeqGlow: the engine call behind forward()
+
+    def forward(self, condition):
+        """One timestep's conditioning dict -> (B, dim) feature vector (models.py:127-145), through the same HIP window
+        encoders as the fused path (dropout: fresh masks in training mode, as ModalityEncoder.forward draws them)."""
+        if self._encode is None:
+            raise RuntimeError("FeatureEncoder.forward needs its SeqGlow (the window encoders run on that model's engine)")
+        return self._encode(condition)
 
 
 class f_seq(nn.Module):  # noqa: N801 - reference class name
@@ -91,7 +99,115 @@ class f_seq(nn.Module):  # noqa: N801 - reference class name
         self.cell = None
 
 
-class FlowStep(nn.Module):
+def _flow_named_flat(layers):
+    """(engine layout name, flow-step index, tensor) for the parameters of a list of FlowStep modules."""
+    out = []
+    for k, layer in enumerate(layers):
+        out.append(("flow.an_bias", k, layer.actnorm.bias))
+        out.append(("flow.an_logs", k, layer.actnorm.logs))
+        if layer.invconv.LU:
+            out.append(("flow.inv_l", k, layer.invconv.l))
+            out.append(("flow.inv_u", k, layer.invconv.u))
+            out.append(("flow.inv_logs", k, layer.invconv.log_s))
+        else:
+            out.append(("flow.inv_w", k, layer.invconv.weight))
+        f = layer.f
+        out.append(("flow.w_ih", k, f.rnn.weight_ih))
+        out.append(("flow.w_hh", k, f.rnn.weight_hh))
+        out.append(("flow.b_ih", k, f.rnn.bias_ih))
+        out.append(("flow.b_hh", k, f.rnn.bias_hh))
+        out.append(("flow.wct", k, f.cond_transform[0].weight))
+        out.append(("flow.bct", k, f.cond_transform[0].bias))
+        out.append(("flow.w_fl", k, f.final_linear.weight))
+        out.append(("flow.b_fl", k, f.final_linear.bias))
+        out.append(("flow.l_fl", k, f.final_linear.logs))
+    return out
+
+
+def _bind_flat(eng, named, layers, device):
+    """Move the listed tensors into the engine's flat parameter buffer (values kept) and alias the module tensors to it."""
+    for name, k, t in named:
+        v = eng.view(name)
+        dst = v if k is None else v[k]
+        dst.view(-1).copy_(t.detach().reshape(-1).to(device=device, dtype=torch.float32))
+        t.data = dst.view(t.shape)
+    for k, layer in enumerate(layers):
+        if layer.invconv.LU:
+            eng.inv_p[k].copy_(layer.invconv.p.to(device))
+            eng.inv_sign[k].copy_(layer.invconv.sign_s.to(device))
+            layer.invconv.p.data = eng.inv_p[k]
+            layer.invconv.sign_s.data = eng.inv_sign[k]
+
+
+def _is_bound(eng, named):
+    lo, hi = eng.params.data_ptr(), eng.params.data_ptr() + 4 * eng.n_params
+    return all(lo <= t.data_ptr() < hi for _, _, t in named)
+
+
+class _FlowRuntime:
+    """Module-level calls of FlowStep / FlowNet (what the reference's test_modules.py exercises, models.py:304-308,
+    436-462): the same HIP cells as SeqGlow's fused walk, one (B, C) batch and one timestep per call through
+    lfi_flow_step, with the recurrent state kept on the modules (f_seq.hidden / .cell) as the reference keeps it.
+    Inference-only: gradients flow through SeqGlow.forward (the training path), not through these calls."""
+
+    _engine = None
+    allreduce_hook = None
+
+    def _flow_layers(self):
+        raise NotImplementedError
+
+    def _apply(self, fn, *args, **kwargs):
+        out = super()._apply(fn, *args, **kwargs)
+        self._engine = None  # .to() / .cuda() re-create parameter storage: re-bind lazily
+        return out
+
+    def _runtime(self, device):
+        device = torch.device(device)
+        if device.type != "cuda":
+            raise RuntimeError("%s (lets_face_it_amd) runs on the GPU only; got a %s tensor (there is no CPU fallback by "
+                               "design)" % (type(self).__name__, device.type))
+        layers = self._flow_layers()
+        named = _flow_named_flat(layers)
+        eng = self._engine
+        if eng is None or eng.device != device or eng.spec.Ks != len(layers) or not _is_bound(eng, named):
+            l0 = layers[0]
+            lin = l0.f.cond_transform[0]
+            spec = _engine.ModelSpec.flow_only(
+                C=l0.actnorm.num_features, H=l0.f.hidden_size, D=lin.out_features, Ks=len(layers), E=lin.in_features,
+                affine=l0.flow_coupling == "affine", rnn_type=l0.f.rnn_type, lu=l0.invconv.LU, scale_eps=l0.scale_eps,
+                actnorm_scale=l0.actnorm.scale)
+            eng = _engine.GlowEngine(spec, device)
+            _bind_flat(eng, named, layers, device)
+            self._engine = eng
+        return eng
+
+    def _run_flow(self, input_, condition, logdet, reverse):
+        eng = self._runtime(input_.device)
+        layers = self._flow_layers()
+        lstm = eng.spec.rnn_type == "lstm"
+        h_prev = [l.f.hidden for l in layers]
+        c_prev = [l.f.cell for l in layers] if lstm else None
+        if all(h is None for h in h_prev):
+            h_prev = c_prev = None
+        elif any(h is None for h in h_prev):
+            raise RuntimeError("some flow steps carry a recurrent state and others do not: call init_rnn_hidden() first")
+        init = None
+        if self.training and not reverse and not all(l.actnorm.inited for l in layers):
+            hook = self.allreduce_hook
+            init = hook if hook is not None else (lambda sums: 1)
+        with torch.no_grad():
+            out, ld, h_new, c_new = eng.flow_net(input_.float(), condition.float(), h_prev, c_prev, reverse, init)
+        for k, l in enumerate(layers):
+            l.f.hidden = h_new[k]
+            l.f.cell = c_new[k] if lstm else None
+            if init is not None:
+                l.actnorm.inited = True
+        if logdet is None:
+            return out, None
+        return out, ld + logdet
+
+
+class FlowStep(_FlowRuntime, nn.Module):
     FlowCoupling = ["additive", "affine"]
     FlowPermutation = ["reverse", "shuffle", "invconv"]
 
@@ -118,8 +234,22 @@ class FlowStep(nn.Module):
     def init_rnn_hidden(self):
         self.f.init_rnn_hidden()
 
+    def _flow_layers(self):
+        return [self]
 
-class FlowNet(nn.Module):
+    def forward(self, input_, audio_features, logdet=None, reverse=False):
+        """One flow step on a (B, C) batch (models.py:304-376): actnorm -> invconv -> coupling, or its inverse."""
+        assert audio_features is not None  # "Require some conditioning" (models.py:326)
+        return self._run_flow(input_, audio_features, logdet, reverse)
+
+    def normal_flow(self, input_, condition, logdet):
+        return self.forward(input_, condition, logdet, reverse=False)
+
+    def reverse_flow(self, input_, condition, logdet):
+        return self.forward(input_, condition, logdet, reverse=True)
+
+
+class FlowNet(_FlowRuntime, nn.Module):
     def __init__(self, C, hidden_channels, cond_dim, K, L, actnorm_scale=1.0, flow_permutation="invconv",
                  flow_coupling="additive", LU_decomposed=False, scale_eps=1e-6, scale_logging=False,
                  feature_encoder_dim=0, glow_rnn_type=None):
@@ -140,6 +270,22 @@ class FlowNet(nn.Module):
         for layer in self.layers:
             layer.init_rnn_hidden()
 
+    def _flow_layers(self):
+        return list(self.layers)
+
+    def forward(self, input_, condition, logdet=0.0, reverse=False, eps_std=None):
+        if not reverse:
+            return self.encode(input_, condition, logdet)
+        return self.decode(input_, condition, eps_std)
+
+    def encode(self, z, condition, logdet=0.0):
+        """All K*L flow steps forward on one (B, C) batch (models.py:444-451)."""
+        return self._run_flow(z, condition, logdet, reverse=False)
+
+    def decode(self, z, condition, eps_std=None):
+        """All flow steps in reverse order (models.py:453-462); the returned log-det starts from 0."""
+        return self._run_flow(z, condition, 0.0, reverse=True)
+
 
 class Glow(nn.Module):
     def __init__(self, hparams, feature_encoder_dim=0):
@@ -151,6 +297,21 @@ class Glow(nn.Module):
             flow_permutation=g["flow_permutation"], flow_coupling=g["flow_coupling"], LU_decomposed=g["LU_decomposed"],
             scale_eps=g["scale_eps"], scale_logging=hparams.Validation["scale_logging"],
             feature_encoder_dim=feature_encoder_dim, glow_rnn_type=g["rnn_type"])
+
+    def forward(self, x=None, condition=None, z=None, eps_std=None, reverse=False, output_shape=None):
+        """One timestep of the flow (models.py:489-513): (z, log-det) forward; (x, log-det) from z / a prior draw in reverse."""
+        if not reverse:
+            return self.normal_flow(x, condition)
+        return self.reverse_flow(z, condition, eps_std, output_shape)
+
+    def normal_flow(self, x, condition):
+        return self.flow(x, condition, logdet=torch.zeros_like(x[:, 0]), reverse=False)
+
+    def reverse_flow(self, z, condition, eps_std, output_shape):
+        with torch.no_grad():
+            if z is None:
+                z = modules.GaussianDiag.sample(output_shape, eps_std)
+            return self.flow(z, condition, eps_std=eps_std, reverse=True)
 
     def set_actnorm_init(self, inited=True):
         for m in self.modules():
@@ -201,6 +362,7 @@ class SeqGlow(nn.Module):
             hparams.Glow["rnn_type"] = "gru"  # get_hparams default (utils.py:32-33)
         self.feature_encoder = FeatureEncoder(hparams.Conditioning, hparams.Data)
         self.glow = Glow(hparams, self.feature_encoder.dim)
+        object.__setattr__(self.feature_encoder, "_encode", self._encode_condition)  # not a submodule / parameter
         self.spec = _engine.ModelSpec(hparams)
         assert self.spec.E == self.feature_encoder.dim
         self.engine = None
@@ -232,25 +394,7 @@ class SeqGlow(nn.Module):
                 lin = getattr(fe, e.name + "_encoder").encoder[0]
                 out.append(("enc.%s.mlp_weight" % e.name, None, lin.weight))
                 out.append(("enc.%s.mlp_bias" % e.name, None, lin.bias))
-        for k, layer in enumerate(self.glow.flow.layers):
-            out.append(("flow.an_bias", k, layer.actnorm.bias))
-            out.append(("flow.an_logs", k, layer.actnorm.logs))
-            if layer.invconv.LU:
-                out.append(("flow.inv_l", k, layer.invconv.l))
-                out.append(("flow.inv_u", k, layer.invconv.u))
-                out.append(("flow.inv_logs", k, layer.invconv.log_s))
-            else:
-                out.append(("flow.inv_w", k, layer.invconv.weight))
-            f = layer.f
-            out.append(("flow.w_ih", k, f.rnn.weight_ih))
-            out.append(("flow.w_hh", k, f.rnn.weight_hh))
-            out.append(("flow.b_ih", k, f.rnn.bias_ih))
-            out.append(("flow.b_hh", k, f.rnn.bias_hh))
-            out.append(("flow.wct", k, f.cond_transform[0].weight))
-            out.append(("flow.bct", k, f.cond_transform[0].bias))
-            out.append(("flow.w_fl", k, f.final_linear.weight))
-            out.append(("flow.b_fl", k, f.final_linear.bias))
-            out.append(("flow.l_fl", k, f.final_linear.logs))
+        out.extend(_flow_named_flat(self.glow.flow.layers))
         return out
 
     def _bind(self, device):
@@ -260,21 +404,9 @@ class SeqGlow(nn.Module):
                                       % self.spec.rnn_type)
         eng = _engine.GlowEngine(self.spec, device)
 
-        def slot(name, k, buf):
-            v = eng.view(name, buf)
-            return v if k is None else v[k]
-
-        for name, k, t in self._named_flat():
-            dst = slot(name, k, eng.params)
-            dst.view(-1).copy_(t.detach().reshape(-1).to(device=device, dtype=torch.float32))
-            t.data = dst.view(t.shape)
-        for k, layer in enumerate(self.glow.flow.layers):
-            if layer.invconv.LU:
-                eng.inv_p[k].copy_(layer.invconv.p.to(device))
-                eng.inv_sign[k].copy_(layer.invconv.sign_s.to(device))
-                layer.invconv.p.data = eng.inv_p[k]
-                layer.invconv.sign_s.data = eng.inv_sign[k]
+        _bind_flat(eng, self._named_flat(), self.glow.flow.layers, device)
         self.engine = eng
+        self.glow.flow._engine = eng  # module-level Glow / FlowNet calls (one timestep) run on the same buffers
         # autograd sees each Parameter; map them to gradient views of the flat gradient buffer
         self._param_map = []
         for name, k, t in self._named_flat():
@@ -293,9 +425,7 @@ class SeqGlow(nn.Module):
         return eng
 
     def _still_bound(self):
-        eng = self.engine
-        lo, hi = eng.params.data_ptr(), eng.params.data_ptr() + 4 * eng.n_params
-        return all(lo <= t.data_ptr() < hi for _, _, t in self._named_flat())
+        return _is_bound(self.engine, self._named_flat())
 
     def _apply(self, fn, *args, **kwargs):
         # .to()/.cuda()/.float() re-create parameter storage: drop the binding, it is rebuilt lazily
@@ -389,8 +519,28 @@ class SeqGlow(nn.Module):
             backward_loss = (-(logdet + logp) / _LN2).mean().reshape(1)
         return list(rec.unbind(0)), backward_loss
 
-    def create_conditioning(self, data, time_st, frame_nb=None, prev_p1_faces=None):
-        raise NotImplementedError("per-timestep conditioning is fused into SeqGlow.forward/inference in this build")
+    def create_conditioning(self, data, time_st, frame_nb, prev_p1_faces):
+        """The conditioning windows of ONE timestep, encoded (models.py:598-615). SeqGlow.forward / inference do this for
+        all timesteps at once; this is the reference's per-timestep call for callers that drive Glow.forward themselves."""
+        c = self.hparams.Conditioning
+        h1 = c["p1_face"]["history"]
+        output = {"prev_p1_face": prev_p1_faces[:, time_st - h1:time_st]}
+        for modality in ("p1_speech", "p2_speech", "p2_face"):
+            history = c[modality]["history"]
+            if history:
+                output[modality] = data[modality][:, (time_st - history) + 1:time_st + 1]
+        if c["use_frame_nb"]:
+            output["frame_nb"] = frame_nb
+        return self.feature_encoder(output)
+
+    def _encode_condition(self, condition):
+        dev = condition["prev_p1_face"].device
+        eng = self._ensure_engine(dev)
+        cond = {k: v.to(dtype=torch.float32).contiguous() for k, v in condition.items()}
+        B = cond["prev_p1_face"].shape[0]
+        masks = self._draw_masks(B, 1, dev)
+        with torch.no_grad():
+            return eng.encode_condition(cond, masks)
 
 
 class _SlotName(str):
