@@ -145,6 +145,10 @@ def derange_batch(batch_data, modalities, shuffle_time=False, permutation=None):
             mixed[m] = mixed[m].contiguous()
         elif batch_data.get(m) is not None:
             mixed[m] = batch_data[m]
+    # the reference drops every other key here, so with Conditioning.use_frame_nb its negative-example step dies on
+    # batch["frame_nb"] (models.py:541); the counter belongs to the p1 stream and is carried over unchanged
+    if batch_data.get("frame_nb") is not None:
+        mixed["frame_nb"] = batch_data["frame_nb"]
     return mixed
 
 
