@@ -183,8 +183,11 @@ int lfi_flow_param_grads(const lfi_flow_dims* d, const lfi_flow_params* p, const
                          const lfi_flow_grads* g, int accumulate, float* work, void* stream);
 
 /* Pointers into the stashes (host-side address arithmetic only). which: 0 a, 1 y, 2 x_out, 3 h, 4 gates, 5 o, 6 ldc,
- * 7 LSTM cell state (empty for GRU) for the forward stash; 0 dlin, 1 dgi, 2 dgh, 3 dy, 4 dx, 5 dh, 6/7 per-tile
- * partial sums, 8 carried d cell state (LSTM) for the backward stash. */
+ * 7 LSTM cell state (empty for GRU), 8 pipeline state for the forward stash; 0 dlin, 1 dgi, 2 dgh, 3 dy, 4 dx, 5 dh,
+ * 6/7 per-tile partial sums, 8 carried d cell state (LSTM), 9 pipeline state for the backward stash.
+ * Pipeline state = 32-bit words of the persistent walk (lfi_flow_seq_fwd / _bwd zero it before every launch): word 1 is
+ * non-zero afterwards iff a bounded spin timed out and the walk was abandoned - the results are then invalid; callers
+ * check it at their next synchronisation point. */
 float* lfi_flow_stash_ptr(const lfi_flow_dims* d, float* stash, int which);
 float* lfi_flow_bstash_ptr(const lfi_flow_dims* d, float* bstash, int which);
 

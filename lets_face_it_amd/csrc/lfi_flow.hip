@@ -51,6 +51,7 @@ struct FlowK {
   const float* gic;
   float gscale;
   unsigned long long* stamps;  // diagnostics only (lfi_debug_set_stamps): s_memtime at phase boundaries, else null
+  unsigned* pipe;              // persistent-pipeline state (flow_pipe_*_kernel): [0] ticket, [1] abort, [4 + k * nbt + bt] progress
 };
 
 // Everything one forward cell touches, resolved to pointers for its (k, frame block).
@@ -406,7 +407,9 @@ __global__ __launch_bounds__(256) void flow_nll_kernel(FlowK f, float* __restric
     lp += -0.5f * (v * v + LOG2PI_F);
     if (z) z[fr * f.C + c] = v;
   }
-  nll[fr] = -(ld + lp) / LN2_F;
+  // a persistent walk that gave up (bounded spin timed out, abort word set) must not pass for a result: poison it
+  const bool aborted = f.pipe && f.pipe[1] != 0u;
+  nll[fr] = aborted ? __builtin_nanf("") : -(ld + lp) / LN2_F;
 }
 
 // ------------------------------------------------------------------------------------------- backward cell
@@ -744,7 +747,8 @@ template <int NG>
 __device__ __forceinline__ void fast_cell_p2(const FlowK& f, const float* Zt, const float* Ht, float* Hn,
                                              const f32x4 (&wz)[NG][FB_Z], const f32x4 (&wh)[NG][FB_H], const float (&gc)[4][NG],
                                              const float (&bh)[NG], const float (&cprev)[4], int nbZ, int nbH, int j2, int kq,
-                                             int l15, int b0, int rows, float* h_out, float* c_out, float* g_out) {
+                                             int l15, int b0, int rows, float* h_out, float* c_out, float* g_out,
+                                             float* cnew = nullptr) {
   const int H = f.H;
   f32x4 az[NG], ah[NG];
 #pragma unroll
@@ -805,6 +809,7 @@ __device__ __forceinline__ void fast_cell_p2(const FlowK& f, const float* Zt, co
         const float c2 = ff * cprev[r] + ii * gg;
         hnew = oo * tanhf_(c2);
         if (row < rows) c_out[(long)row * H + j2] = c2;
+        if (cnew) cnew[r] = c2;
         gs0 = ii; gs1 = ff; gs2 = gg; gs3 = oo;
       }
       Hn[j2 * LT + i] = hnew;
@@ -975,6 +980,270 @@ __global__ __launch_bounds__(NT) void flow_diag_fwd_fast_kernel(FlowK f, int d, 
     if (cl == 0 && rok) f.sL[kf + row] = lg;
   }
   LFI_STAMP(6);
+}
+
+// ------------------------------------------------------------------------------------------- persistent pipeline
+// The diagonal walk above pays one launch + one reload of 270 KB of weights per workgroup for every one of the N + Ks - 1
+// diagonals, although a workgroup's weights never change: cell (n, k) of batch tile bt always needs flow step k's. Here
+// workgroup (k, bt) is PERSISTENT: it loads step k's weights into registers once, then walks n = 0 .. N-1 for its 16
+// samples; the recurrent state h (and the LSTM cell state) never leaves the workgroup (LDS / registers), and the only
+// inter-workgroup traffic is the 16 x C output tile handed from (k, bt) to (k + 1, bt): a systolic pipeline over the flow
+// steps, N + Ks - 1 cell times end to end, one launch. Hand-off (MI355X_MICROARCH.md, inter-workgroup visibility, form R1):
+// the producer stores the tile write-through (sc1), every wave drains its stores, workgroup barrier, ONE lane publishes
+// the progress counter with an agent-scope atomic store; the consumer polls that one word relaxed, ONE agent-scope acquire,
+// barrier, then plain loads. Deadlock-free for ANY grid size and dispatch order: logical (k, bt) ids are dealt by an atomic
+// ticket in arrival order and a workgroup only ever waits on a smaller ticket, i.e. on a workgroup that is already
+// running (more workgroups than CUs simply run as successive groups of flow steps). Every spin is bounded: on timeout
+// the abort word is set, every workgroup leaves its loop, and the host reports LFI_ERR_LAUNCH.
+constexpr unsigned PIPE_HDR = 4;                 // ticket, abort, 2 reserved words
+constexpr unsigned PIPE_SPIN_LIMIT = 1u << 23;   // polls (each >= ~0.5 us) before giving up
+
+__device__ __forceinline__ unsigned ld_agent(const unsigned* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void st_agent(unsigned* p, unsigned v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// write-through (sc1) store of one payload element
+__device__ __forceinline__ void st_sc1(float* p, float v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// ONE lane: wait until *flag >= need. false = aborted (timeout here or in another workgroup).
+__device__ __forceinline__ bool pipe_wait(const unsigned* flag, unsigned need, unsigned* abort_w) {
+  unsigned spins = 0;
+  while (ld_agent(flag) < need) {
+    if ((++spins & 31u) == 0u) {
+      if (ld_agent(abort_w) != 0u) return false;
+      if (spins > PIPE_SPIN_LIMIT) {
+        st_agent(abort_w, 1u);
+        return false;
+      }
+    }
+    __builtin_amdgcn_s_sleep(4);
+  }
+  return true;
+}
+// consumer side of a hand-off, all threads: thread 0 polls + acquires, the rest learn the outcome through LDS
+__device__ __forceinline__ bool pipe_acquire(const unsigned* flag, unsigned need, unsigned* abort_w, int tid, int* s_ok) {
+  if (tid == 0) {
+    const bool ok = pipe_wait(flag, need, abort_w);
+    if (ok) {
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    *s_ok = ok ? 1 : 0;
+  }
+  __syncthreads();
+  return *s_ok != 0;
+}
+// producer side, all threads: drain this wave's stores, barrier, one lane publishes
+__device__ __forceinline__ void pipe_publish(unsigned* flag, unsigned value, int tid, bool signal) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (signal && tid == 0) st_agent(flag, value);
+}
+
+// as mma16_reg with the B fragments of this wave in LDS: wl[b * 64] is this lane's float4 of k block b (consecutive lanes
+// read consecutive 16 bytes: conflict-free ds_read_b128)
+__device__ __forceinline__ f32x4 mma16_lds(const float* a_lane, const f32x4* wl, int nb) {
+  f32x4 e = {0.f, 0.f, 0.f, 0.f}, o = {0.f, 0.f, 0.f, 0.f};
+  for (int b = 0; b < nb; ++b) {
+    const float* ab = a_lane + b * 16 * LT;
+    const f32x4 w = wl[b * 64];
+    const float a0 = ab[0], a1 = ab[4 * LT], a2 = ab[8 * LT], a3 = ab[12 * LT];
+    e = mfma16(a0, w[0], e);
+    o = mfma16(a1, w[1], o);
+    e = mfma16(a2, w[2], e);
+    o = mfma16(a3, w[3], o);
+  }
+  return e + o;
+}
+// LDS floats of the pipeline kernel: the cell's operands, then the W fragments of the C16/16 P1 waves and the Wfl fragments
+// of the Co16/16 P3 waves (the recurrent weights W_ih[:, :Ch] and W_hh stay in registers: 120 VGPRs at H = 128)
+__host__ __device__ inline int pipe_fwd_lds_floats(int C, int C16, int H16, int Ch16, int Cout, int Co16) {
+  const int base = (carve_fast_fwd(C, C16, H16, Ch16, Cout).total + 3) & ~3;
+  return base + (C16 >> 4) * (C16 >> 4) * 256 + (Co16 >> 4) * (H16 >> 4) * 256;
+}
+
+template <int NG>
+__global__ __launch_bounds__(NT) void flow_pipe_fwd_kernel(FlowK f) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15 = lane & 15, kq = lane >> 4;
+  const int ri = tid >> 5, cl = tid & 31;  // elementwise thread map
+  __shared__ int s_id, s_ok;
+  if (tid == 0) s_id = (int)atomicAdd(f.pipe, 1u);
+  __syncthreads();
+  const int id = s_id;
+  const int nbt = f.nbt;
+  const int k = id / nbt, bt = id - k * nbt;   // tickets in arrival order: (k - 1, bt) always started before (k, bt)
+  if (k >= f.Ks) return;
+  unsigned* abort_w = f.pipe + 1;
+  unsigned* prog = f.pipe + PIPE_HDR;
+  const int b0 = bt * MB;
+  const int B = f.B, C = f.C, H = f.H, Ch = f.Ch, C2 = f.C2, Cout = f.Cout, G = f.G;
+  const int C16 = f.C16, Ch16 = f.Ch16, H16 = f.H16, Co16 = f.Co16;
+  const long LC = f.ldc, LO = f.ldo;
+  const CarveF cv = carve_fast_fwd(C, C16, H16, Ch16, Cout);
+  float* At = flow_smem + cv.At;
+  float* Ht = flow_smem + cv.Ht;   // h of the previous timestep
+  float* Zt = flow_smem + cv.Zt;
+  float* Hn = flow_smem + cv.Hn;   // h of this timestep (the two swap every iteration)
+  float* Yrm = flow_smem + cv.Yrm;
+  float* Orm = flow_smem + cv.Orm;
+  const int ldy = C + 1, ldo = Cout + 1;
+  const int nbC = C16 >> 4, nbZ = Ch16 >> 4, nbH = H16 >> 4;
+
+  // ---- this workgroup's weights, once: P1 (16 output channels of W), P2 (16 hidden units, NG gates), P3 (16 outputs)
+  const bool t1 = wave * 16 < C, t2 = wave * 16 < H, t3 = wave * 16 < Cout;
+  const int tcol = wave * 16 + l15;
+  f32x4 wz[NG][FB_Z], wh[NG][FB_H];
+#pragma unroll
+  for (int g = 0; g < NG; ++g) {
+    load_frag<FB_Z>(wz[g], f.pwz + (long)k * Ch16 * NG * H16, NG * H16, g * H16 + tcol, kq, nbZ, t2);
+    load_frag<FB_H>(wh[g], f.pwh + (long)k * H16 * NG * H16, NG * H16, g * H16 + tcol, kq, nbH, t2);
+  }
+  // P1 / P3 weights: each owning wave parks its fragments in LDS (its own region, its own lanes: no barrier needed)
+  f32x4* w1s = reinterpret_cast<f32x4*>(flow_smem + ((cv.total + 3) & ~3)) + wave * nbC * 64 + lane;
+  f32x4* w3s = reinterpret_cast<f32x4*>(flow_smem + ((cv.total + 3) & ~3)) + nbC * nbC * 64 + wave * nbH * 64 + lane;
+  if (t1) {
+    const f32x4* p = reinterpret_cast<const f32x4*>(f.pW + (long)k * C16 * C16) + (long)kq * C16 + tcol;
+    for (int b = 0; b < nbC; ++b) w1s[b * 64] = p[(long)b * 4 * C16];
+  }
+  if (t3) {
+    const f32x4* p = reinterpret_cast<const f32x4*>(f.pwfl + (long)k * H16 * Co16) + (long)kq * Co16 + tcol;
+    for (int b = 0; b < nbH; ++b) w3s[b * 64] = p[(long)b * 4 * Co16];
+  }
+  const int j2 = tcol;
+  const int jc = j2 < H ? j2 : 0;
+  float bh[NG], cprev[4] = {0.f, 0.f, 0.f, 0.f};
+  {
+    const float* bhh = f.p.b_hh + (long)k * G;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) bh[g] = bhh[g * H + jc];
+  }
+  const float flb = tcol < Cout ? f.p.b_fl[(long)k * Cout + tcol] : 0.0f;              // LinearZeros bias and scale
+  const float fls = tcol < Cout ? expf(3.0f * f.p.l_fl[(long)k * Cout + tcol]) : 0.0f;
+  // actnorm of this flow step for the (at most two) channels this thread handles in P0
+  float anb[2], ans[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int c = cl + 32 * u;
+    anb[u] = c < C ? f.p.an_bias[(long)k * C + c] : 0.0f;
+    ans[u] = c < C ? expf(f.p.an_logs[(long)k * C + c]) : 0.0f;
+  }
+  // zero state and the k padding of the LDS operands (never written again)
+  for (int j = cl; j < H16; j += 32) {
+    Ht[j * LT + ri] = 0.0f;
+    Hn[j * LT + ri] = 0.0f;
+  }
+  for (int c = Ch + cl; c < Ch16; c += 32) Zt[c * LT + ri] = 0.0f;
+  __syncthreads();
+
+  const int row = b0 + ri;          // elementwise phases: this thread's sample
+  const bool rok = row < B;
+  for (int n = 0; n < f.N; ++n) {
+    const long fr = (long)n * B;
+    const long kf = (long)k * f.F + fr;
+    // conditioning part of the gates for this timestep (written by the GEMM before this launch): in flight under the wait
+    float gc[4][NG];
+    {
+      const float* gicb = f.gic + kf * G;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int rw = min(b0 + kq * 4 + r, B - 1);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) gc[r][g] = gicb[(long)rw * G + g * H + jc];
+      }
+    }
+    if (k > 0 && !pipe_acquire(prog + (k - 1) * nbt + bt, (unsigned)n + 1u, abort_w, tid, &s_ok)) break;
+
+    // ---- P0: actnorm (glow/modules.py:45-52); stage a k-major
+    {
+      const float* xin = (k == 0) ? f.x0 + ((long)row * f.T + f.start + n) * C : f.sX + (kf - f.F + row) * LC;
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int c = cl + 32 * u;
+        if (c < C16) {
+          float a = 0.0f;
+          if (c < C && rok) {
+            a = (xin[c] + anb[u]) * ans[u];
+            f.sA[(kf + row) * LC + c] = a;
+          }
+          At[c * LT + ri] = a;
+        }
+      }
+    }
+    __syncthreads();
+
+    // ---- P1: y = a W   (InvertibleConv1x1.forward, glow/modules.py:186)
+    if (t1) {
+      const f32x4 acc = mma16_lds(At + kq * LT + l15, w1s, nbC);
+      const int c = tcol;
+      if (c < C) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int i = kq * 4 + r;
+          const int rw = b0 + i;
+          const float v = acc[r];
+          Yrm[i * ldy + c] = v;
+          if (c < Ch) Zt[c * LT + i] = v;
+          if (rw < B) f.sY[(kf + rw) * LC + c] = v;
+        }
+      }
+    }
+    __syncthreads();
+
+    // ---- P2: recurrent cell of the coupling net (f_seq.forward, glow/models.py:204-214); state stays in LDS / registers
+    if (t2) {
+      float cnew[4] = {0.f, 0.f, 0.f, 0.f};
+      fast_cell_p2<NG>(f, Zt, Ht, Hn, wz, wh, gc, bh, cprev, nbZ, nbH, tcol, kq, l15, b0, B, f.sH + kf * H,
+                       NG == 4 ? f.sC + kf * H : nullptr, f.sG + kf * 4 * H, cnew);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) cprev[r] = cnew[r];
+    }
+    __syncthreads();
+
+    // ---- P3: o = (h' Wfl^T + b) exp(3 logs)   (LinearZeros, glow/modules.py:93-95)
+    if (t3) {
+      const f32x4 acc = mma16_lds(Hn + kq * LT + l15, w3s, nbH);
+      if (tcol < Cout) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int i = kq * 4 + r;
+          const int rw = b0 + i;
+          const float o = (acc[r] + flb) * fls;
+          Orm[i * ldo + tcol] = o;
+          if (rw < B) f.sO[(kf + rw) * LO + tcol] = o;
+        }
+      }
+    }
+    __syncthreads();
+
+    // ---- P4: coupling (glow/models.py:330-341), pass-through half, log-det; the output tile is the hand-off payload
+    {
+      float lg = 0.0f;
+      if (cl < C2) {
+        const float z2 = Yrm[ri * ldy + Ch + cl];
+        float z2n;
+        if (f.affine) {
+          const float shift = Orm[ri * ldo + 2 * cl];
+          const float sraw = sigmoidf_(Orm[ri * ldo + 2 * cl + 1] + 2.0f);
+          const float sc = fmaxf(sraw, f.eps);
+          z2n = (z2 + shift) * sc;
+          lg = logf(sc);
+        } else {
+          z2n = z2 + Orm[ri * ldo + cl];
+        }
+        if (rok) st_sc1(f.sX + (kf + row) * LC + Ch + cl, z2n);
+      }
+      if (cl < Ch && rok) st_sc1(f.sX + (kf + row) * LC + cl, Yrm[ri * ldy + cl]);
+#pragma unroll
+      for (int o = 16; o > 0; o >>= 1) lg += __shfl_xor(lg, o, 64);  // the 32 lanes of one row
+      if (cl == 0 && rok) f.sL[kf + row] = lg;
+    }
+    pipe_publish(prog + k * nbt + bt, (unsigned)n + 1u, tid, k + 1 < f.Ks);
+    float* t = Ht; Ht = Hn; Hn = t;
+  }
 }
 
 // FlowStep.reverse_flow (glow/models.py:345-373) with explicit state, register-resident weights: the sampler's and
@@ -1751,6 +2020,9 @@ long bstash_offsets(const FlowK& f, long* off) {
   off[8] = o; o += f.lstm ? KF * f.H : 0;               // carried d cell state (LSTM)
   return o;
 }
+// persistent-pipeline state appended to either stash: header + one progress word per (flow step, batch tile), padded to 16 bytes
+long pipe_words(const FlowK& f) { return ((long)PIPE_HDR + (long)f.Ks * f.nbt + 3) & ~3L; }
+long align4(long x) { return (x + 3) & ~3L; }
 void bind_stash(FlowK* f, float* stash) {
   long off[8];
   stash_offsets(*f, off);
@@ -1768,6 +2040,12 @@ void bind_bstash(FlowK* f, float* b) {
 bool flow_force_generic() {
   const char* e = getenv("LFI_FLOW_GENERIC");
   return e && e[0] == '1';
+}
+
+// LFI_FLOW_PIPE=0 keeps one launch per anti-diagonal instead of the persistent pipeline (tests cover both)
+bool flow_pipe_enabled() {
+  const char* e = getenv("LFI_FLOW_PIPE");
+  return !(e && e[0] == '0');
 }
 
 template <typename Kf>
@@ -1841,29 +2119,31 @@ extern "C" long lfi_flow_stash_floats(const lfi_flow_dims* d) {
   lfi_flow_params p = {};
   if (fill_flow(d, &p, nullptr, &f, "lfi_flow_stash_floats")) return -1;
   long off[8];
-  return stash_offsets(f, off);
+  return align4(stash_offsets(f, off)) + pipe_words(f);
 }
 extern "C" long lfi_flow_bstash_floats(const lfi_flow_dims* d) {
   FlowK f = {};
   lfi_flow_params p = {};
   if (fill_flow(d, &p, nullptr, &f, "lfi_flow_bstash_floats")) return -1;
   long off[9];
-  return bstash_offsets(f, off);
+  return align4(bstash_offsets(f, off)) + pipe_words(f);
 }
 extern "C" float* lfi_flow_stash_ptr(const lfi_flow_dims* d, float* stash, int which) {
   FlowK f = {};
   lfi_flow_params p = {};
-  if (which < 0 || which > 7 || fill_flow(d, &p, nullptr, &f, "lfi_flow_stash_ptr")) return nullptr;
+  if (which < 0 || which > 8 || fill_flow(d, &p, nullptr, &f, "lfi_flow_stash_ptr")) return nullptr;
   long off[8];
-  stash_offsets(f, off);
+  const long end = stash_offsets(f, off);
+  if (which == 8) return stash + align4(end);
   return stash + off[which];
 }
 extern "C" float* lfi_flow_bstash_ptr(const lfi_flow_dims* d, float* bstash, int which) {
   FlowK f = {};
   lfi_flow_params p = {};
-  if (which < 0 || which > 8 || fill_flow(d, &p, nullptr, &f, "lfi_flow_bstash_ptr")) return nullptr;
+  if (which < 0 || which > 9 || fill_flow(d, &p, nullptr, &f, "lfi_flow_bstash_ptr")) return nullptr;
   long off[9];
-  bstash_offsets(f, off);
+  const long end = bstash_offsets(f, off);
+  if (which == 9) return bstash + align4(end);
   return bstash + off[which];
 }
 
@@ -1885,7 +2165,20 @@ extern "C" int lfi_flow_seq_fwd(const lfi_flow_dims* d, const lfi_flow_params* p
                       : set_flow_lds(flow_diag_fwd_fast_kernel<3>, lds, "lfi_flow_seq_fwd"))
             : set_flow_lds(flow_diag_fwd_kernel, lds, "lfi_flow_seq_fwd");
   if (rc) return rc;
-  for (int dg = 0; dg < f.N + f.Ks - 1; ++dg) {
+  const bool pipe = fast && flow_pipe_enabled();
+  if (pipe) {
+    long off[8];
+    f.pipe = reinterpret_cast<unsigned*>(stash + align4(stash_offsets(f, off)));
+    const size_t plds = (size_t)pipe_fwd_lds_floats(f.C, f.C16, f.H16, f.Ch16, f.Cout, f.Co16) * sizeof(float);
+    rc = f.lstm ? set_flow_lds(flow_pipe_fwd_kernel<4>, plds, "lfi_flow_seq_fwd") : set_flow_lds(flow_pipe_fwd_kernel<3>, plds, "lfi_flow_seq_fwd");
+    if (rc) return rc;
+    hipError_t me = hipMemsetAsync(f.pipe, 0, (size_t)pipe_words(f) * sizeof(unsigned), st);
+    LFI_REQUIRE(me == hipSuccess, "lfi_flow_seq_fwd: hipMemsetAsync: %s", hipGetErrorString(me));
+    const dim3 grid(f.Ks * f.nbt);
+    if (f.lstm) hipLaunchKernelGGL(flow_pipe_fwd_kernel<4>, grid, dim3(NT), plds, st, f);
+    else hipLaunchKernelGGL(flow_pipe_fwd_kernel<3>, grid, dim3(NT), plds, st, f);
+  }
+  for (int dg = 0; !pipe && dg < f.N + f.Ks - 1; ++dg) {
     const int klo = dg - (f.N - 1) > 0 ? dg - (f.N - 1) : 0;
     const int khi = dg < f.Ks - 1 ? dg : f.Ks - 1;
     const dim3 grid(f.nbt, khi - klo + 1);
