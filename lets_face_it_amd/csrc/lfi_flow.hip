@@ -1068,8 +1068,8 @@ __host__ __device__ inline int pipe_fwd_lds_floats(int C, int C16, int H16, int 
 template <int NG>
 __global__ __launch_bounds__(NT) void flow_pipe_fwd_kernel(FlowK f) {
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int l15 = lane & 15, kq = lane >> 4;
-  const int ri = tid >> 5, cl = tid & 31;  // elementwise thread map
+  const int l15_0 = lane & 15, kq_0 = lane >> 4;
+  const int ri_0 = tid >> 5, cl_0 = tid & 31;  // elementwise thread map
   __shared__ int s_id, s_ok;
   if (tid == 0) s_id = (int)atomicAdd(f.pipe, 1u);
   __syncthreads();
@@ -1095,25 +1095,25 @@ __global__ __launch_bounds__(NT) void flow_pipe_fwd_kernel(FlowK f) {
 
   // ---- this workgroup's weights, once: P1 (16 output channels of W), P2 (16 hidden units, NG gates), P3 (16 outputs)
   const bool t1 = wave * 16 < C, t2 = wave * 16 < H, t3 = wave * 16 < Cout;
-  const int tcol = wave * 16 + l15;
+  const int tcol_0 = wave * 16 + l15_0;
   f32x4 wz[NG][FB_Z], wh[NG][FB_H];
 #pragma unroll
   for (int g = 0; g < NG; ++g) {
-    load_frag<FB_Z>(wz[g], f.pwz + (long)k * Ch16 * NG * H16, NG * H16, g * H16 + tcol, kq, nbZ, t2);
-    load_frag<FB_H>(wh[g], f.pwh + (long)k * H16 * NG * H16, NG * H16, g * H16 + tcol, kq, nbH, t2);
+    load_frag<FB_Z>(wz[g], f.pwz + (long)k * Ch16 * NG * H16, NG * H16, g * H16 + tcol_0, kq_0, nbZ, t2);
+    load_frag<FB_H>(wh[g], f.pwh + (long)k * H16 * NG * H16, NG * H16, g * H16 + tcol_0, kq_0, nbH, t2);
   }
   // P1 / P3 weights: each owning wave parks its fragments in LDS (its own region, its own lanes: no barrier needed)
   f32x4* w1s = reinterpret_cast<f32x4*>(flow_smem + ((cv.total + 3) & ~3)) + wave * nbC * 64 + lane;
   f32x4* w3s = reinterpret_cast<f32x4*>(flow_smem + ((cv.total + 3) & ~3)) + nbC * nbC * 64 + wave * nbH * 64 + lane;
   if (t1) {
-    const f32x4* p = reinterpret_cast<const f32x4*>(f.pW + (long)k * C16 * C16) + (long)kq * C16 + tcol;
+    const f32x4* p = reinterpret_cast<const f32x4*>(f.pW + (long)k * C16 * C16) + (long)kq_0 * C16 + tcol_0;
     for (int b = 0; b < nbC; ++b) w1s[b * 64] = p[(long)b * 4 * C16];
   }
   if (t3) {
-    const f32x4* p = reinterpret_cast<const f32x4*>(f.pwfl + (long)k * H16 * Co16) + (long)kq * Co16 + tcol;
+    const f32x4* p = reinterpret_cast<const f32x4*>(f.pwfl + (long)k * H16 * Co16) + (long)kq_0 * Co16 + tcol_0;
     for (int b = 0; b < nbH; ++b) w3s[b * 64] = p[(long)b * 4 * Co16];
   }
-  const int j2 = tcol;
+  const int j2 = tcol_0;
   const int jc = j2 < H ? j2 : 0;
   float bh[NG], cprev[4] = {0.f, 0.f, 0.f, 0.f};
   {
@@ -1121,27 +1121,32 @@ __global__ __launch_bounds__(NT) void flow_pipe_fwd_kernel(FlowK f) {
 #pragma unroll
     for (int g = 0; g < NG; ++g) bh[g] = bhh[g * H + jc];
   }
-  const float flb = tcol < Cout ? f.p.b_fl[(long)k * Cout + tcol] : 0.0f;              // LinearZeros bias and scale
-  const float fls = tcol < Cout ? expf(3.0f * f.p.l_fl[(long)k * Cout + tcol]) : 0.0f;
+  const float flb = tcol_0 < Cout ? f.p.b_fl[(long)k * Cout + tcol_0] : 0.0f;              // LinearZeros bias and scale
+  const float fls = tcol_0 < Cout ? expf(3.0f * f.p.l_fl[(long)k * Cout + tcol_0]) : 0.0f;
   // actnorm of this flow step for the (at most two) channels this thread handles in P0
   float anb[2], ans[2];
 #pragma unroll
   for (int u = 0; u < 2; ++u) {
-    const int c = cl + 32 * u;
+    const int c = cl_0 + 32 * u;
     anb[u] = c < C ? f.p.an_bias[(long)k * C + c] : 0.0f;
     ans[u] = c < C ? expf(f.p.an_logs[(long)k * C + c]) : 0.0f;
   }
   // zero state and the k padding of the LDS operands (never written again)
-  for (int j = cl; j < H16; j += 32) {
-    Ht[j * LT + ri] = 0.0f;
-    Hn[j * LT + ri] = 0.0f;
+  for (int j = cl_0; j < H16; j += 32) {
+    Ht[j * LT + ri_0] = 0.0f;
+    Hn[j * LT + ri_0] = 0.0f;
   }
-  for (int c = Ch + cl; c < Ch16; c += 32) Zt[c * LT + ri] = 0.0f;
+  for (int c = Ch + cl_0; c < Ch16; c += 32) Zt[c * LT + ri_0] = 0.0f;
   __syncthreads();
 
-  const int row = b0 + ri;          // elementwise phases: this thread's sample
+  const int row = b0 + ri_0;          // elementwise phases: this thread's sample
   const bool rok = row < B;
   for (int n = 0; n < f.N; ++n) {
+    // lane coordinates laundered per iteration: otherwise every per-lane stash address (a dozen arrays x 4 rows, 64-bit) is
+    // hoisted out of the timestep loop and the kernel spills ~150 VGPRs
+    int l15 = l15_0, kq = kq_0, ri = ri_0, cl = cl_0, tcol = tcol_0;
+    asm volatile("" : "+v"(l15), "+v"(kq), "+v"(ri), "+v"(cl), "+v"(tcol));
+
     const long fr = (long)n * B;
     const long kf = (long)k * f.F + fr;
     // conditioning part of the gates for this timestep (written by the GEMM before this launch): in flight under the wait
@@ -1628,6 +1633,293 @@ __global__ __launch_bounds__(NT) void flow_diag_bwd_fast_kernel(FlowK f, int d, 
     }
   }
   if (tz) dh_prev_tile(wq2);
+}
+
+// Backward twin of flow_pipe_fwd_kernel: workgroup (k, bt) keeps flow step k's backward weights, walks n = N-1 .. 0, carries
+// d h (and the LSTM's d c) from timestep n + 1 in registers and receives d x of flow step k + 1 through the same write-through
+// hand-off (bDx tile + progress counter). The z-tile waves need two weight slices (W_ih[:, :Ch] and W_hh): the second one is
+// re-read from L2 every timestep, requested before the wait.
+template <int NG>
+__global__ __launch_bounds__(NT) void flow_pipe_bwd_kernel(FlowK f) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l15_0 = lane & 15, kq_0 = lane >> 4;
+  const int ri_0 = tid >> 5, cl_0 = tid & 31;
+  __shared__ int s_id, s_ok;
+  if (tid == 0) s_id = (int)atomicAdd(f.pipe, 1u);
+  __syncthreads();
+  const int nbt = f.nbt;
+  const int kk = s_id / nbt, bt = s_id - kk * nbt;
+  if (kk >= f.Ks) return;
+  const int k = f.Ks - 1 - kk;   // tickets in arrival order: (k + 1, bt) always started before (k, bt)
+  unsigned* abort_w = f.pipe + 1;
+  unsigned* prog = f.pipe + PIPE_HDR;
+  const int b0 = bt * MB;
+  const int B = f.B, C = f.C, H = f.H, Ch = f.Ch, C2 = f.C2, Cout = f.Cout, G = f.G;
+  const int C16 = f.C16, Ch16 = f.Ch16, H16 = f.H16, Co16 = f.Co16;
+  const long LC = f.ldc, LO = f.ldo;   // stash row strides
+  const CarveFB cv = carve_fast_bwd(C16, H16, Co16, Cout, NG);
+  float* Dl = flow_smem + cv.Dl;
+  float* Gi = flow_smem + cv.Gi;
+  float* Gh = Gi + NG * H16 * LT;
+  float* Dy = flow_smem + cv.Dy;
+  float* Cy = flow_smem + cv.Cy;
+  float* Pl = flow_smem + cv.Pl;
+  const int ldp = Cout + 1;
+  const int nbC = C16 >> 4, nbH = H16 >> 4, nbO = Co16 >> 4;
+  const bool last = k == f.Ks - 1;
+  const float gz = f.gscale / LN2_F;   // d loss / d z = z * gz   (prior term)
+  const float dl = -f.gscale / LN2_F;  // d loss / d logdet
+  const float dxs = last ? gz : 1.0f;
+
+  // which tiles this wave owns: hidden tile `wave` (Q1, Q2), z tile `wave` (Q2, waves < Ch16/16), channel tile `wave` (Q3)
+  const bool th = wave * 16 < H, tz = wave * 16 < Ch, tc = wave * 16 < C;
+  const int tcol_0 = wave * 16 + l15_0;
+  // ---- weights of Q1 (dlin Wfl: K = Cout) for this wave's hidden tile
+  f32x4 wq1[FB_O];
+  load_frag<FB_O>(wq1, f.bwfl + (long)k * Co16 * H16, H16, tcol_0, kq_0, nbO, th);
+  // W_hh slice of this wave's hidden tile: resident, except in the z-tile waves, which need two slices (W_ih[:, :Ch] for
+  // d z1, then W_hh) and stream both through the same registers every timestep, as the per-diagonal kernel does
+  f32x4 wq2[NG][FB_H];
+  if (!tz) {
+#pragma unroll
+    for (int g = 0; g < NG; ++g) load_frag<FB_H>(wq2[g], f.bwh + ((long)k * NG + g) * H16 * H16, H16, tcol_0, kq_0, nbH, th);
+  }
+  // weights of Q3 (dy W^T) for this wave's channel tile
+  f32x4 wq3[FB_C];
+  load_frag<FB_C>(wq3, f.pWt + (long)k * C16 * C16, C16, tcol_0, kq_0, nbC, tc);
+  const float es_an = tcol_0 < C ? expf(f.p.an_logs[(long)k * C + tcol_0]) : 0.0f;
+  float dhc[4] = {0.f, 0.f, 0.f, 0.f}, dcc[4] = {0.f, 0.f, 0.f, 0.f};   // d h / d c carried from timestep n + 1 (registers)
+
+  for (int n = f.N - 1; n >= 0; --n) {
+    // lane coordinates laundered per iteration: otherwise every per-lane stash address (a dozen arrays x 4 rows, 64-bit) is
+    // hoisted out of the timestep loop and the kernel spills ~150 VGPRs
+    int l15 = l15_0, kq = kq_0, ri = ri_0, cl = cl_0, tcol = tcol_0;
+    asm volatile("" : "+v"(l15), "+v"(kq), "+v"(ri), "+v"(cl), "+v"(tcol));
+
+  const long fr = (long)n * B;
+  const long kf = (long)k * f.F + fr;
+  const float* dxo = last ? f.sX + kf * LC : f.bDx + (kf + f.F) * LC;
+  // ---- forward-stash operands of Q1 / Q2 / Q3 (written before this launch): in flight under the wait for flow step k + 1
+  float sg[4][4], shp[4], sdhf[4], sc2[4], scp[4], sdcf[4], sdxo[4], sa[4];
+  {
+    const int j = tcol < H ? tcol : 0, cc = tcol < C ? tcol : 0;
+    const bool hasp = n > 0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const long row = min(b0 + kq * 4 + r, B - 1);
+      const float* gs = f.sG + (kf + row) * 4 * H + j;
+      sg[r][0] = gs[0]; sg[r][1] = gs[H]; sg[r][2] = gs[2 * H]; sg[r][3] = gs[3 * H];
+      shp[r] = hasp ? f.sH[(kf - B + row) * H + j] : 0.0f;
+      sdhf[r] = dhc[r];
+      if (NG == 4) {
+        sc2[r] = f.sC[(kf + row) * H + j];
+        scp[r] = hasp ? f.sC[(kf - B + row) * H + j] : 0.0f;
+        sdcf[r] = dcc[r];
+      }
+      sa[r] = f.sA[(kf + row) * LC + cc];
+    }
+  }
+  if (tz) {
+#pragma unroll
+    for (int g = 0; g < NG; ++g) load_frag<FB_H>(wq2[g], f.bwz + ((long)k * NG + g) * H16 * Ch16, Ch16, tcol, kq, nbH, true);
+  }
+  if (!last && !pipe_acquire(prog + (k + 1) * nbt + bt, (unsigned)(f.N - n), abort_w, tid, &s_ok)) break;
+  {
+    const int cz = tcol < Ch ? tcol : 0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const long row = min(b0 + kq * 4 + r, B - 1);
+      sdxo[r] = dxo[row * LC + cz] * dxs;
+    }
+  }
+
+  // ---- Q0: coupling backward + LinearZeros scale; zero the k padding of the LDS operands
+  {
+    const int row = b0 + ri;
+    const bool rok = row < B;
+    const float* lfl = f.p.l_fl + (long)k * Cout;
+    float dz2 = 0.0f, dl0 = 0.0f, dl1 = 0.0f, p0 = 0.0f, p1 = 0.0f;
+    if (cl < C2) {
+      if (rok) {
+        const float dz2n = dxo[(long)row * LC + Ch + cl] * dxs;
+        const float* O = f.sO + (kf + row) * LO;
+        if (f.affine) {
+          const float oe = O[2 * cl], oo = O[2 * cl + 1];
+          const float sraw = sigmoidf_(oo + 2.0f);
+          const float sc = fmaxf(sraw, f.eps);
+          const float z2 = f.sY[(kf + row) * LC + Ch + cl];
+          dz2 = dz2n * sc;
+          const float dsc = dz2n * (z2 + oe) + dl / sc;
+          const float dsr = sraw >= f.eps ? dsc : 0.0f;
+          const float d0 = dz2;                             // d o_even (shift)
+          const float d1 = dsr * sraw * (1.0f - sraw);      // d o_odd
+          p0 = d0 * oe * 3.0f; p1 = d1 * oo * 3.0f;
+          dl0 = d0 * expf(3.0f * lfl[2 * cl]); dl1 = d1 * expf(3.0f * lfl[2 * cl + 1]);
+          f.bDlin[(kf + row) * LO + 2 * cl] = dl0; f.bDlin[(kf + row) * LO + 2 * cl + 1] = dl1;
+        } else {
+          const float oe = O[cl];
+          dz2 = dz2n; p0 = dz2n * oe * 3.0f;
+          dl0 = dz2n * expf(3.0f * lfl[cl]);
+          f.bDlin[(kf + row) * LO + cl] = dl0;
+        }
+        f.bDy[(kf + row) * LC + Ch + cl] = dz2;
+      }
+      Dy[(Ch + cl) * LT + ri] = dz2;
+      if (f.affine) {
+        Dl[(2 * cl) * LT + ri] = dl0; Dl[(2 * cl + 1) * LT + ri] = dl1;
+        Pl[ri * ldp + 2 * cl] = p0; Pl[ri * ldp + 2 * cl + 1] = p1;
+      } else {
+        Dl[cl * LT + ri] = dl0;
+        Pl[ri * ldp + cl] = p0;
+      }
+    }
+    for (int c = Cout + cl; c < Co16; c += 32) Dl[c * LT + ri] = 0.0f;
+    for (int c = C + cl; c < C16; c += 32) Dy[c * LT + ri] = 0.0f;
+    for (int j = H + cl; j < H16; j += 32) {
+#pragma unroll
+      for (int g = 0; g < NG; ++g) { Gi[(g * H16 + j) * LT + ri] = 0.0f; Gh[(g * H16 + j) * LT + ri] = 0.0f; }
+    }
+  }
+  __syncthreads();
+  if (tid < Cout) {
+    float sum = 0.0f;
+    for (int i = 0; i < MB; ++i) sum += Pl[i * ldp + tid];
+    f.bPlfl[(((long)k * f.N + n) * f.nbt + bt) * Cout + tid] = sum;
+  }
+
+  // ---- Q1: d h' = dlin Wfl + dh carried from timestep n + 1; recurrent cell backward
+  if (th) {
+    const f32x4 acc = mma16_reg<FB_O>(Dl + kq * LT + l15, wq1, nbO);
+    const int j = tcol;
+    if (j < H) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = kq * 4 + r;
+        const int row = b0 + i;
+        float gi_[4] = {0.f, 0.f, 0.f, 0.f}, gh_[4] = {0.f, 0.f, 0.f, 0.f}, cy = 0.0f;
+        if (row < B) {
+          const float dhn = acc[r] + sdhf[r];
+          const float g0 = sg[r][0], g1 = sg[r][1], g2 = sg[r][2], g3 = sg[r][3];
+          if (NG == 3) {
+            const float rr = g0, uu = g1, nn = g2, ghn = g3;
+            const float hp = shp[r];
+            const float du = dhn * (hp - nn);
+            const float dn = dhn * (1.0f - uu);
+            cy = dhn * uu;
+            const float dan = dn * (1.0f - nn * nn);
+            const float dau = du * uu * (1.0f - uu);
+            const float dar = dan * ghn * rr * (1.0f - rr);
+            gi_[0] = dar; gi_[1] = dau; gi_[2] = dan;
+            gh_[0] = dar; gh_[1] = dau; gh_[2] = dan * rr;
+          } else {
+            const float ii = g0, ff = g1, gg = g2, oo = g3;
+            const float tcv = tanhf_(sc2[r]);
+            const float cp = scp[r];
+            const float dcf = sdcf[r];
+            const float dc2 = dhn * oo * (1.0f - tcv * tcv) + dcf;
+            gi_[0] = dc2 * gg * ii * (1.0f - ii);
+            gi_[1] = dc2 * cp * ff * (1.0f - ff);
+            gi_[2] = dc2 * ii * (1.0f - gg * gg);
+            gi_[NG - 1] = dhn * tcv * oo * (1.0f - oo);
+#pragma unroll
+            for (int g = 0; g < NG; ++g) gh_[g] = gi_[g];
+            dcc[r] = dc2 * ff;
+          }
+          float* go = f.bDgi + (kf + row) * G + j;
+          float* ho = f.bDgh + (kf + row) * G + j;
+#pragma unroll
+          for (int g = 0; g < NG; ++g) { go[g * H] = gi_[g]; ho[g * H] = gh_[g]; }
+        }
+#pragma unroll
+        for (int g = 0; g < NG; ++g) { Gi[(g * H16 + j) * LT + i] = gi_[g]; Gh[(g * H16 + j) * LT + i] = gh_[g]; }
+        Cy[j * LT + i] = cy;
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- Q2: d z1 = dgi W_ih[:, :Ch] + pass-through (z-tile waves, before the barrier: Q3 needs it);
+  //          d h_prev = dgh W_hh + carry (to timestep n - 1; not needed inside this cell)
+  auto dh_prev_tile = [&](const f32x4 (&w)[NG][FB_H]) {
+    if (n > 0 && th) {
+      const f32x4 acc = mma16_reg_gates<NG, FB_H>(Gh + kq * LT + l15, H16 * LT, w, nbH);
+      const int j = tcol;
+      if (j < H) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int i = kq * 4 + r;
+          const int row = b0 + i;
+          (void)row;
+          dhc[r] = acc[r] + Cy[j * LT + i];
+        }
+      }
+    }
+  };
+  if (tz) {
+    const f32x4 acc = mma16_reg_gates<NG, FB_H>(Gi + kq * LT + l15, H16 * LT, wq2, nbH);
+    const int c = tcol;
+    if (c < Ch) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int i = kq * 4 + r;
+        const int row = b0 + i;
+        float v = 0.0f;
+        if (row < B) {
+          v = acc[r] + sdxo[r];
+          f.bDy[(kf + row) * LC + c] = v;
+        }
+        Dy[c * LT + i] = v;
+      }
+    }
+    // now fetch this wave's W_hh slice for its d h_prev tile (runs after Q3)
+#pragma unroll
+    for (int g = 0; g < NG; ++g) load_frag<FB_H>(wq2[g], f.bwh + ((long)k * NG + g) * H16 * H16, H16, tcol, kq, nbH, n > 0 && th);
+  } else {
+    dh_prev_tile(wq2);
+  }
+  __syncthreads();
+
+  // ---- Q3: d a = dy W^T ; actnorm backward ; d x_in to flow step k - 1
+  if (tc) {
+    const f32x4 acc = mma16_reg<FB_C>(Dy + kq * LT + l15, wq3, nbC);
+    const int c = tcol;
+    float sl = 0.0f, sb = 0.0f;
+    if (c < C) {
+      const float es = es_an;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = b0 + kq * 4 + r;
+        if (row < B) {
+          const float da = acc[r];
+          sl += da * sa[r];
+          sb += da * es;
+          if (k > 0) st_sc1(f.bDx + (kf + row) * LC + c, da * es);
+        }
+      }
+    }
+    sl += __shfl_xor(sl, 16, 64); sl += __shfl_xor(sl, 32, 64);
+    sb += __shfl_xor(sb, 16, 64); sb += __shfl_xor(sb, 32, 64);
+    if (kq == 0 && c < C) {
+      float* pan = f.bPan + (((long)k * f.N + n) * f.nbt + bt) * 2 * C;
+      pan[c] = sl; pan[C + c] = sb;
+    }
+  }
+  if (tz) dh_prev_tile(wq2);
+  pipe_publish(prog + k * nbt + bt, (unsigned)(f.N - n), tid, k > 0);
+  }  // timestep loop
+}
+
+// A backward walk that gave up must not pass for a result: NaN into one frame of every flow step's stashed gradients, which
+// every parameter gradient (and, through dgi, the encoder gradients) sums over.
+__global__ __launch_bounds__(64) void flow_pipe_poison_kernel(FlowK f) {
+  if (f.pipe[1] == 0u) return;
+  const float nan = __builtin_nanf("");
+  for (int k = threadIdx.x; k < f.Ks; k += 64) {
+    f.bDlin[(long)k * f.F * f.ldo] = nan;
+    f.bDgi[(long)k * f.F * f.G] = nan;
+    f.bDgh[(long)k * f.F * f.G] = nan;
+    f.bDy[(long)k * f.F * f.ldc] = nan;
+  }
 }
 
 // Zero-padded fragment-order weight images for the register-resident cells (layout: flow_img_index).
@@ -2210,7 +2502,20 @@ extern "C" int lfi_flow_seq_bwd(const lfi_flow_dims* d, const lfi_flow_params* p
                       : set_flow_lds(flow_diag_bwd_fast_kernel<3>, lds, "lfi_flow_seq_bwd"))
             : set_flow_lds(flow_diag_bwd_kernel, lds, "lfi_flow_seq_bwd");
   if (rc) return rc;
-  for (int dg = f.N + f.Ks - 2; dg >= 0; --dg) {
+  const bool pipe = fast && flow_pipe_enabled();
+  if (pipe) {
+    long off[9];
+    f.pipe = reinterpret_cast<unsigned*>(bstash + align4(bstash_offsets(f, off)));
+    rc = f.lstm ? set_flow_lds(flow_pipe_bwd_kernel<4>, lds, "lfi_flow_seq_bwd") : set_flow_lds(flow_pipe_bwd_kernel<3>, lds, "lfi_flow_seq_bwd");
+    if (rc) return rc;
+    hipError_t me = hipMemsetAsync(f.pipe, 0, (size_t)pipe_words(f) * sizeof(unsigned), st);
+    LFI_REQUIRE(me == hipSuccess, "lfi_flow_seq_bwd: hipMemsetAsync: %s", hipGetErrorString(me));
+    const dim3 grid(f.Ks * f.nbt);
+    if (f.lstm) hipLaunchKernelGGL(flow_pipe_bwd_kernel<4>, grid, dim3(NT), lds, st, f);
+    else hipLaunchKernelGGL(flow_pipe_bwd_kernel<3>, grid, dim3(NT), lds, st, f);
+    hipLaunchKernelGGL(flow_pipe_poison_kernel, dim3(1), dim3(64), 0, st, f);
+  }
+  for (int dg = f.N + f.Ks - 2; !pipe && dg >= 0; --dg) {
     const int klo = dg - (f.N - 1) > 0 ? dg - (f.N - 1) : 0;
     const int khi = dg < f.Ks - 1 ? dg : f.Ks - 1;
     const dim3 grid(f.nbt, khi - klo + 1);
