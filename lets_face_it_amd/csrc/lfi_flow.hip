@@ -51,6 +51,8 @@ struct FlowK {
   const float* gic;
   float gscale;
   unsigned long long* stamps;  // diagnostics only (lfi_debug_set_stamps): s_memtime at phase boundaries, else null
+  int pipe_fence;              // 1: consumers run an agent-scope acquire after the poll and read the tile with plain loads
+                               // 0: no fence, every load of a handed-off tile is an sc1 load (L1 bypass)
   unsigned* pipe;              // persistent-pipeline state (flow_pipe_*_kernel): [0] ticket, [1] abort, [4 + k * nbt + bt] progress
 };
 
@@ -1008,6 +1010,10 @@ __device__ __forceinline__ void st_agent(unsigned* p, unsigned v) {
 __device__ __forceinline__ void st_sc1(float* p, float v) {
   __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// load of one handed-off payload element: L1-bypassing (sc1) when the consumer did not fence
+__device__ __forceinline__ float ld_tile(const float* p, bool fenced) {
+  return fenced ? *p : __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 // ONE lane: wait until *flag >= need. false = aborted (timeout here or in another workgroup).
 __device__ __forceinline__ bool pipe_wait(const unsigned* flag, unsigned need, unsigned* abort_w) {
   unsigned spins = 0;
@@ -1024,10 +1030,11 @@ __device__ __forceinline__ bool pipe_wait(const unsigned* flag, unsigned need, u
   return true;
 }
 // consumer side of a hand-off, all threads: thread 0 polls + acquires, the rest learn the outcome through LDS
-__device__ __forceinline__ bool pipe_acquire(const unsigned* flag, unsigned need, unsigned* abort_w, int tid, int* s_ok) {
+__device__ __forceinline__ bool pipe_acquire(const unsigned* flag, unsigned need, unsigned* abort_w, int tid, int* s_ok,
+                                             bool fence) {
   if (tid == 0) {
     const bool ok = pipe_wait(flag, need, abort_w);
-    if (ok) {
+    if (ok && fence) {
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
@@ -1065,6 +1072,14 @@ __host__ __device__ inline int pipe_fwd_lds_floats(int C, int C16, int H16, int 
   return base + (C16 >> 4) * (C16 >> 4) * 256 + (Co16 >> 4) * (H16 >> 4) * 256;
 }
 
+// diagnostics (lfi_debug_set_stamps): s_memtime of workgroup (Ks / 2, tile 0) at the phase boundaries of every timestep, in
+// slots [4096 + 2048 * backward + 16 * n + phase] of the stamp buffer
+#define PIPE_STAMP(dir, slot)                                                                                              \
+  do {                                                                                                                     \
+    if (f.stamps && tid == 0 && bt == 0 && k == f.Ks / 2 && n < 128)                                                       \
+      f.stamps[4096 + 2048 * (dir) + 16 * n + (slot)] = __builtin_amdgcn_s_memtime();                                      \
+  } while (0)
+
 template <int NG>
 __global__ __launch_bounds__(NT) void flow_pipe_fwd_kernel(FlowK f) {
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1079,6 +1094,7 @@ __global__ __launch_bounds__(NT) void flow_pipe_fwd_kernel(FlowK f) {
   if (k >= f.Ks) return;
   unsigned* abort_w = f.pipe + 1;
   unsigned* prog = f.pipe + PIPE_HDR;
+  const bool fenced = f.pipe_fence != 0;
   const int b0 = bt * MB;
   const int B = f.B, C = f.C, H = f.H, Ch = f.Ch, C2 = f.C2, Cout = f.Cout, G = f.G;
   const int C16 = f.C16, Ch16 = f.Ch16, H16 = f.H16, Co16 = f.Co16;
@@ -1149,6 +1165,7 @@ __global__ __launch_bounds__(NT) void flow_pipe_fwd_kernel(FlowK f) {
 
     const long fr = (long)n * B;
     const long kf = (long)k * f.F + fr;
+    PIPE_STAMP(0, 0);
     // conditioning part of the gates for this timestep (written by the GEMM before this launch): in flight under the wait
     float gc[4][NG];
     {
@@ -1160,8 +1177,9 @@ __global__ __launch_bounds__(NT) void flow_pipe_fwd_kernel(FlowK f) {
         for (int g = 0; g < NG; ++g) gc[r][g] = gicb[(long)rw * G + g * H + jc];
       }
     }
-    if (k > 0 && !pipe_acquire(prog + (k - 1) * nbt + bt, (unsigned)n + 1u, abort_w, tid, &s_ok)) break;
+    if (k > 0 && !pipe_acquire(prog + (k - 1) * nbt + bt, (unsigned)n + 1u, abort_w, tid, &s_ok, fenced)) break;
 
+    PIPE_STAMP(0, 1);
     // ---- P0: actnorm (glow/modules.py:45-52); stage a k-major
     {
       const float* xin = (k == 0) ? f.x0 + ((long)row * f.T + f.start + n) * C : f.sX + (kf - f.F + row) * LC;
@@ -1171,7 +1189,7 @@ __global__ __launch_bounds__(NT) void flow_pipe_fwd_kernel(FlowK f) {
         if (c < C16) {
           float a = 0.0f;
           if (c < C && rok) {
-            a = (xin[c] + anb[u]) * ans[u];
+            a = ((k == 0 ? xin[c] : ld_tile(xin + c, fenced)) + anb[u]) * ans[u];
             f.sA[(kf + row) * LC + c] = a;
           }
           At[c * LT + ri] = a;
@@ -1179,6 +1197,7 @@ __global__ __launch_bounds__(NT) void flow_pipe_fwd_kernel(FlowK f) {
       }
     }
     __syncthreads();
+    PIPE_STAMP(0, 2);
 
     // ---- P1: y = a W   (InvertibleConv1x1.forward, glow/modules.py:186)
     if (t1) {
@@ -1197,6 +1216,7 @@ __global__ __launch_bounds__(NT) void flow_pipe_fwd_kernel(FlowK f) {
       }
     }
     __syncthreads();
+    PIPE_STAMP(0, 3);
 
     // ---- P2: recurrent cell of the coupling net (f_seq.forward, glow/models.py:204-214); state stays in LDS / registers
     if (t2) {
@@ -1207,6 +1227,7 @@ __global__ __launch_bounds__(NT) void flow_pipe_fwd_kernel(FlowK f) {
       for (int r = 0; r < 4; ++r) cprev[r] = cnew[r];
     }
     __syncthreads();
+    PIPE_STAMP(0, 4);
 
     // ---- P3: o = (h' Wfl^T + b) exp(3 logs)   (LinearZeros, glow/modules.py:93-95)
     if (t3) {
@@ -1223,6 +1244,7 @@ __global__ __launch_bounds__(NT) void flow_pipe_fwd_kernel(FlowK f) {
       }
     }
     __syncthreads();
+    PIPE_STAMP(0, 5);
 
     // ---- P4: coupling (glow/models.py:330-341), pass-through half, log-det; the output tile is the hand-off payload
     {
@@ -1246,7 +1268,9 @@ __global__ __launch_bounds__(NT) void flow_pipe_fwd_kernel(FlowK f) {
       for (int o = 16; o > 0; o >>= 1) lg += __shfl_xor(lg, o, 64);  // the 32 lanes of one row
       if (cl == 0 && rok) f.sL[kf + row] = lg;
     }
+    PIPE_STAMP(0, 6);
     pipe_publish(prog + k * nbt + bt, (unsigned)n + 1u, tid, k + 1 < f.Ks);
+    PIPE_STAMP(0, 7);
     float* t = Ht; Ht = Hn; Hn = t;
   }
 }
@@ -1653,6 +1677,7 @@ __global__ __launch_bounds__(NT) void flow_pipe_bwd_kernel(FlowK f) {
   const int k = f.Ks - 1 - kk;   // tickets in arrival order: (k + 1, bt) always started before (k, bt)
   unsigned* abort_w = f.pipe + 1;
   unsigned* prog = f.pipe + PIPE_HDR;
+  const bool fenced = f.pipe_fence != 0;
   const int b0 = bt * MB;
   const int B = f.B, C = f.C, H = f.H, Ch = f.Ch, C2 = f.C2, Cout = f.Cout, G = f.G;
   const int C16 = f.C16, Ch16 = f.Ch16, H16 = f.H16, Co16 = f.Co16;
@@ -1699,6 +1724,7 @@ __global__ __launch_bounds__(NT) void flow_pipe_bwd_kernel(FlowK f) {
   const long fr = (long)n * B;
   const long kf = (long)k * f.F + fr;
   const float* dxo = last ? f.sX + kf * LC : f.bDx + (kf + f.F) * LC;
+  PIPE_STAMP(1, 0);
   // ---- forward-stash operands of Q1 / Q2 / Q3 (written before this launch): in flight under the wait for flow step k + 1
   float sg[4][4], shp[4], sdhf[4], sc2[4], scp[4], sdcf[4], sdxo[4], sa[4];
   {
@@ -1723,16 +1749,28 @@ __global__ __launch_bounds__(NT) void flow_pipe_bwd_kernel(FlowK f) {
 #pragma unroll
     for (int g = 0; g < NG; ++g) load_frag<FB_H>(wq2[g], f.bwz + ((long)k * NG + g) * H16 * Ch16, Ch16, tcol, kq, nbH, true);
   }
-  if (!last && !pipe_acquire(prog + (k + 1) * nbt + bt, (unsigned)(f.N - n), abort_w, tid, &s_ok)) break;
+  // Q0's forward-stash operands (o of the coupling net, z2) for this thread's element
+  float q_oe = 0.0f, q_oo = 0.0f, q_z2 = 0.0f;
+  if (cl < C2 && b0 + ri < B) {
+    const float* O = f.sO + (kf + b0 + ri) * LO;
+    if (f.affine) {
+      q_oe = O[2 * cl]; q_oo = O[2 * cl + 1];
+      q_z2 = f.sY[(kf + b0 + ri) * LC + Ch + cl];
+    } else {
+      q_oe = O[cl];
+    }
+  }
+  if (!last && !pipe_acquire(prog + (k + 1) * nbt + bt, (unsigned)(f.N - n), abort_w, tid, &s_ok, fenced)) break;
   {
     const int cz = tcol < Ch ? tcol : 0;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const long row = min(b0 + kq * 4 + r, B - 1);
-      sdxo[r] = dxo[row * LC + cz] * dxs;
+      sdxo[r] = (last ? dxo[row * LC + cz] : ld_tile(dxo + row * LC + cz, fenced)) * dxs;
     }
   }
 
+  PIPE_STAMP(1, 1);
   // ---- Q0: coupling backward + LinearZeros scale; zero the k padding of the LDS operands
   {
     const int row = b0 + ri;
@@ -1741,13 +1779,12 @@ __global__ __launch_bounds__(NT) void flow_pipe_bwd_kernel(FlowK f) {
     float dz2 = 0.0f, dl0 = 0.0f, dl1 = 0.0f, p0 = 0.0f, p1 = 0.0f;
     if (cl < C2) {
       if (rok) {
-        const float dz2n = dxo[(long)row * LC + Ch + cl] * dxs;
-        const float* O = f.sO + (kf + row) * LO;
+        const float dz2n = (last ? dxo[(long)row * LC + Ch + cl] : ld_tile(dxo + (long)row * LC + Ch + cl, fenced)) * dxs;
         if (f.affine) {
-          const float oe = O[2 * cl], oo = O[2 * cl + 1];
+          const float oe = q_oe, oo = q_oo;
           const float sraw = sigmoidf_(oo + 2.0f);
           const float sc = fmaxf(sraw, f.eps);
-          const float z2 = f.sY[(kf + row) * LC + Ch + cl];
+          const float z2 = q_z2;
           dz2 = dz2n * sc;
           const float dsc = dz2n * (z2 + oe) + dl / sc;
           const float dsr = sraw >= f.eps ? dsc : 0.0f;
@@ -1757,7 +1794,7 @@ __global__ __launch_bounds__(NT) void flow_pipe_bwd_kernel(FlowK f) {
           dl0 = d0 * expf(3.0f * lfl[2 * cl]); dl1 = d1 * expf(3.0f * lfl[2 * cl + 1]);
           f.bDlin[(kf + row) * LO + 2 * cl] = dl0; f.bDlin[(kf + row) * LO + 2 * cl + 1] = dl1;
         } else {
-          const float oe = O[cl];
+          const float oe = q_oe;
           dz2 = dz2n; p0 = dz2n * oe * 3.0f;
           dl0 = dz2n * expf(3.0f * lfl[cl]);
           f.bDlin[(kf + row) * LO + cl] = dl0;
@@ -1781,6 +1818,7 @@ __global__ __launch_bounds__(NT) void flow_pipe_bwd_kernel(FlowK f) {
     }
   }
   __syncthreads();
+  PIPE_STAMP(1, 2);
   if (tid < Cout) {
     float sum = 0.0f;
     for (int i = 0; i < MB; ++i) sum += Pl[i * ldp + tid];
@@ -1837,6 +1875,7 @@ __global__ __launch_bounds__(NT) void flow_pipe_bwd_kernel(FlowK f) {
     }
   }
   __syncthreads();
+  PIPE_STAMP(1, 3);
 
   // ---- Q2: d z1 = dgi W_ih[:, :Ch] + pass-through (z-tile waves, before the barrier: Q3 needs it);
   //          d h_prev = dgh W_hh + carry (to timestep n - 1; not needed inside this cell)
@@ -1878,6 +1917,7 @@ __global__ __launch_bounds__(NT) void flow_pipe_bwd_kernel(FlowK f) {
     dh_prev_tile(wq2);
   }
   __syncthreads();
+  PIPE_STAMP(1, 4);
 
   // ---- Q3: d a = dy W^T ; actnorm backward ; d x_in to flow step k - 1
   if (tc) {
@@ -1904,8 +1944,13 @@ __global__ __launch_bounds__(NT) void flow_pipe_bwd_kernel(FlowK f) {
       pan[c] = sl; pan[C + c] = sb;
     }
   }
-  if (tz) dh_prev_tile(wq2);
+  PIPE_STAMP(1, 5);
   pipe_publish(prog + k * nbt + bt, (unsigned)(f.N - n), tid, k > 0);
+  PIPE_STAMP(1, 6);
+  // the z-tile waves' own d h_prev tile is only needed by the next timestep of THIS workgroup: after the hand-off, off the
+  // pipeline's latency path (it reads Gh / Cy, which the next timestep rewrites only behind its first barrier)
+  if (tz) dh_prev_tile(wq2);
+  PIPE_STAMP(1, 7);
   }  // timestep loop
 }
 
@@ -2339,6 +2384,12 @@ bool flow_pipe_enabled() {
   const char* e = getenv("LFI_FLOW_PIPE");
   return !(e && e[0] == '0');
 }
+// LFI_PIPE_FENCE=1: consumers of a hand-off run an agent-scope acquire and read the tile with plain loads, instead of the
+// fence-free form (every store and load of the tile sc1; MI355X_MICROARCH.md, hand-offs measured without the acquire, row 1)
+int flow_pipe_fence() {
+  const char* e = getenv("LFI_PIPE_FENCE");
+  return (e && e[0] == '1') ? 1 : 0;
+}
 
 template <typename Kf>
 int set_flow_lds(Kf kernel, size_t bytes, const char* who) {
@@ -2461,6 +2512,7 @@ extern "C" int lfi_flow_seq_fwd(const lfi_flow_dims* d, const lfi_flow_params* p
   if (pipe) {
     long off[8];
     f.pipe = reinterpret_cast<unsigned*>(stash + align4(stash_offsets(f, off)));
+    f.pipe_fence = flow_pipe_fence();
     const size_t plds = (size_t)pipe_fwd_lds_floats(f.C, f.C16, f.H16, f.Ch16, f.Cout, f.Co16) * sizeof(float);
     rc = f.lstm ? set_flow_lds(flow_pipe_fwd_kernel<4>, plds, "lfi_flow_seq_fwd") : set_flow_lds(flow_pipe_fwd_kernel<3>, plds, "lfi_flow_seq_fwd");
     if (rc) return rc;
@@ -2506,6 +2558,7 @@ extern "C" int lfi_flow_seq_bwd(const lfi_flow_dims* d, const lfi_flow_params* p
   if (pipe) {
     long off[9];
     f.pipe = reinterpret_cast<unsigned*>(bstash + align4(bstash_offsets(f, off)));
+    f.pipe_fence = flow_pipe_fence();
     rc = f.lstm ? set_flow_lds(flow_pipe_bwd_kernel<4>, lds, "lfi_flow_seq_bwd") : set_flow_lds(flow_pipe_bwd_kernel<3>, lds, "lfi_flow_seq_bwd");
     if (rc) return rc;
     hipError_t me = hipMemsetAsync(f.pipe, 0, (size_t)pipe_words(f) * sizeof(unsigned), st);

@@ -462,5 +462,8 @@ def test_pipeline_walk_matches_diagonal_walk(gpu_device, monkeypatch, case):
         outs.append((torch.stack(losses), torch.stack(z_seq), {n: p.grad.clone() for n, p in m.named_parameters()}))
     assert torch.isfinite(outs[0][0]).all()
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
-    for n in outs[0][2]:  # (the deferred split-K weight-gradient GEMMs pick their split per launch: not bitwise)
-        assert rel_err(outs[0][2][n], outs[1][2][n]) < 1e-5, n
+    for n in outs[0][2]:
+        if case == "tiny_lstm":  # the d c carry lives in a register there and its product is contracted into the consumer's fma
+            assert rel_err(outs[0][2][n], outs[1][2][n]) < 1e-6, n
+        else:
+            assert torch.equal(outs[0][2][n], outs[1][2][n]), n
