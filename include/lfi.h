@@ -242,6 +242,16 @@ int lfi_adam_clip_step(float* p, const float* g, float* m, float* v, long n, con
                        float clip, float gmul, float lr, float beta1, float beta2, float eps, int step_count,
                        void* stream);
 
+/* ---------------------------------------------------------------- callers either side of the flow (SURVEY.md par. 8f)
+ * Window sampler, replaces MimicryDataset.__getitem__ + DataLoader collation (code/glow_pytorch/mimicry_data_module.py:45-78):
+ * one modality of a split lives in HBM as ONE (rows x dim) matrix, the recording bins back to back; a training window is T
+ * consecutive rows of one bin. dst[b, t, :] = src[starts[b] + t, :] for b < B (starts: B row indices, int64, on the device;
+ * the host-side index table guarantees starts[b] + T does not cross a bin boundary). dst: (B x T x dim), batch-first. */
+int lfi_gather_sequences(const float* src, long rows, int dim, const long* starts, int B, int T, float* dst, void* stream);
+/* calc_jerk (code/glow_pytorch/glow/utils.py:53-58; MimicryLogger, mimicry_logger.py:187-196): out[0] = mean over (B, T-3, C)
+ * of |third difference along time| of x (B x T x C, batch-first, fp32 differences as the reference). work: 1024 doubles. */
+int lfi_jerk_mean(const float* x, int B, int T, int C, float* out, double* work /* 1024 doubles */, void* stream);
+
 /* ---------------------------------------------------------------- diagnostics */
 /* Timing probe of the register-resident forward cells: a device buffer of >= 16 * Ks 64-bit slots stamped with s_memtime
  * (100 MHz) at the phase boundaries of the cells in workgroup column 0; NULL switches it off. Process-global. */

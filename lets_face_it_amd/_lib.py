@@ -114,6 +114,8 @@ def lib():
                                     vp]),
         "lfi_grad_sumsq": (i, [vp, l, vp, vp, vp]),
         "lfi_adam_clip_step": (i, [vp, vp, vp, vp, l, vp, f, f, f, f, f, f, i, vp]),
+        "lfi_gather_sequences": (i, [vp, l, i, vp, i, i, vp, vp]),
+        "lfi_jerk_mean": (i, [vp, i, i, i, vp, vp, vp]),
         "lfi_selftest_mfma": (i, [vp, vp]),
         "lfi_debug_set_stamps": (i, [vp]),
     }
@@ -134,6 +136,7 @@ EXPORTS = [
     "lfi_flow_seq_fwd", "lfi_flow_seq_bwd", "lfi_flow_param_grads_work_floats", "lfi_flow_param_grads",
     "lfi_actnorm_init_stats", "lfi_actnorm_init_apply", "lfi_flow_step", "lfi_flow_sample_work_floats",
     "lfi_flow_sample_p1_work_floats", "lfi_flow_sample_seq", "lfi_grad_sumsq", "lfi_adam_clip_step", "lfi_selftest_mfma", "lfi_debug_set_stamps",
+    "lfi_gather_sequences", "lfi_jerk_mean",
 ]
 
 
