@@ -140,6 +140,28 @@ EXPORTS = [
 ]
 
 
+def translate_oom(fn):
+    """Decorator for the engine's entry points. The reference's Optuna harness halves the batch size when a trial dies with
+    a RuntimeError whose text starts with "CUDA out of memory" (hparams_tuning.py:162-166,194-199); PyTorch-ROCm words
+    its allocator error "HIP out of memory...", which that test would silently miss. Re-raise it in the expected wording
+    (torch.OutOfMemoryError is a RuntimeError subclass, and so is this)."""
+    import functools
+
+    import torch
+
+    @functools.wraps(fn)
+    def wrapper(*args, **kwargs):
+        try:
+            return fn(*args, **kwargs)
+        except torch.OutOfMemoryError as e:
+            msg = str(e)
+            if msg.startswith("CUDA out of memory"):
+                raise
+            raise torch.OutOfMemoryError("CUDA out of memory. [ROCm: " + msg + "]") from e
+
+    return wrapper
+
+
 def check(rc, what=""):
     if rc != 0:
         msg = lib().lfi_last_error()

@@ -20,7 +20,7 @@ import os
 import torch
 
 from . import _lib
-from ._lib import EncDesc, FlowDims, FlowGrads, FlowParams, GemmDesc, P1Enc, check, ptr
+from ._lib import EncDesc, FlowDims, FlowGrads, FlowParams, GemmDesc, P1Enc, check, ptr, translate_oom
 
 ENC_ORDER = ("p1_face", "p2_face", "p1_speech", "p2_speech")  # FeatureEncoder concat order (models.py:127-143)
 FLOW_FIELDS = ("an_bias", "an_logs", "inv_l", "inv_u", "inv_logs", "inv_w", "w_ih", "w_hh", "b_ih", "b_hh",
@@ -160,6 +160,7 @@ class _Ctx:
 class GlowEngine:
     """Owns the flat parameter / gradient / optimiser buffers and the workspaces of one model on one GPU."""
 
+    @translate_oom
     def __init__(self, spec, device):
         self.spec = spec
         self.device = torch.device(device)
@@ -428,6 +429,7 @@ class GlowEngine:
         return cbuf, gic
 
     # ------------------------------------------------------------------ forward / backward
+    @translate_oom
     def forward(self, batch, masks=None, with_stash=True, init_actnorm=None):
         """Teacher-forced NLL of a batch dict of (B, T, dim) tensors. Returns z (N, B, C), nll (N, B)."""
         s = self.spec
@@ -482,6 +484,7 @@ class GlowEngine:
             xa, xb = xb, xa
         self.run_prep()  # the constant log-det term depends on the new actnorm logs
 
+    @translate_oom
     def backward(self, gscale):
         """Gradients of gscale * sum(nll) w.r.t. every parameter, written into self.grads (overwritten)."""
         ctx = self._last
@@ -583,6 +586,7 @@ class GlowEngine:
         if part is None:
             self.colsum(dgh, G3, 0, e.hist * F, G3, 1, gbh, 0)
 
+    @translate_oom
     def encode_condition(self, condition, masks=None):
         """FeatureEncoder.forward on ONE timestep's conditioning dict (models.py:127-145): {"prev_p1_face": (B, h1, C),
         "p2_face": (B, h, C), "p1_speech" / "p2_speech": (B, h, S), "frame_nb": (B, 1)} -> (B, E) features in the
@@ -596,6 +600,7 @@ class GlowEngine:
         return cond[:B * s.ldf].view(B, s.ldf).index_select(1, self.unfold.long())
 
     # ------------------------------------------------------------------ module-level FlowNet / FlowStep / Glow calls
+    @translate_oom
     def flow_net(self, x, cond, h_prev, c_prev, reverse, init_actnorm=None):
         """FlowNet.encode / decode (models.py:444-462) on ONE (B, C) batch with explicit recurrent state.
 
@@ -657,6 +662,7 @@ class GlowEngine:
         return src, (ld - const if reverse else ld + const), h_new, c_new
 
     # ------------------------------------------------------------------ optimiser
+    @translate_oom
     def optimizer_step(self, lr, beta1, beta2, eps, clip=0.0, gmul=1.0):
         """clip_grad_norm_(clip) + Adam on the flat buffers (lets_face_it_glow.py:61-72; final_model.yaml:126)."""
         if self.adam_m is None:
@@ -678,6 +684,7 @@ class GlowEngine:
         return float(self.sumsq.sqrt().item())
 
     # ------------------------------------------------------------------ sampling / inversion
+    @translate_oom
     def sample(self, seq_len, data, noise, masks=None):
         """SeqGlow.inference (models.py:567-596) with the prior noise given: (seq_len - start, B, C), already * eps."""
         s = self.spec
@@ -749,6 +756,7 @@ class GlowEngine:
             graph.replay()
         return faces[:, s.start:].clone()
 
+    @translate_oom
     def invert(self, z_seq, batch, masks=None):
         """SeqGlow.invert (models.py:617-645): teacher-forced reverse pass. z_seq (N, B, C) -> x (N, B, C), logdet (N, B)."""
         s = self.spec

@@ -1,8 +1,9 @@
 """python -m lets_face_it_amd.train <hparams.yaml> [--key value ...]   (the reference's train.py:14-38)
 
-Needs the reference's HDF5 dataset (Data.file_name under dataset_root) and h5py for the unchanged
-MimicryDataModule of the reference repository; for a self-contained run pass --synthetic true, which trains on
-random (batch, T, dim) tensors of the configured shapes.
+Reads the reference's HDF5 dataset (Data.file_name under dataset_root; h5py, or an .npz export of the same tree) through the
+GPU-resident lets_face_it_amd.mimicry_data_module.MimicryDataModule; `--data_module reference` keeps the reference
+repository's own glow_pytorch.mimicry_data_module instead (it must be importable). For a self-contained run pass
+--synthetic true, which trains on random (batch, T, dim) tensors of the configured shapes.
 """
 import random
 
@@ -47,12 +48,15 @@ def main(argv=None):
     model = LetsFaceItGlow(hparams)
     if getattr(hparams, "synthetic", False):
         dm = SyntheticDataModule(hparams, steps=int(getattr(hparams, "synthetic_steps", 100)))
-    else:
+    elif getattr(hparams, "data_module", "") == "reference":
         try:
             from glow_pytorch.mimicry_data_module import MimicryDataModule  # the reference's data pipeline, untouched
         except ImportError as e:
-            raise SystemExit("the reference's glow_pytorch.mimicry_data_module (and h5py) must be importable to train on "
-                             "lets_face_it.h5, or pass --synthetic true: %s" % e)
+            raise SystemExit("the reference's glow_pytorch.mimicry_data_module (and h5py) must be importable for "
+                             "--data_module reference: %s" % e)
+        dm = MimicryDataModule(hparams)
+    else:
+        from lets_face_it_amd.mimicry_data_module import MimicryDataModule  # same surface, corpus resident in HBM
         dm = MimicryDataModule(hparams)
     Trainer(hparams).fit(model, dm)
 

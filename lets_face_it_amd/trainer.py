@@ -13,8 +13,9 @@ import torch.distributed as dist
 
 
 class Trainer:
-    def __init__(self, hparams, device=None, log_every=10):
+    def __init__(self, hparams, device=None, log_every=10, callbacks=None):
         self.hparams = hparams
+        self.callbacks = list(callbacks or [])   # objects with on_validation_batch_end(...), e.g. MimicryLogger
         self.world_size = int(os.environ.get("WORLD_SIZE", "1"))
         self.rank = int(os.environ.get("RANK", "0"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -105,7 +106,10 @@ class Trainer:
         with torch.no_grad():
             for i, batch in enumerate(loader()):
                 batch = {k: v.to(self.device).float().contiguous() for k, v in batch.items()}
-                total += float(model.validation_step(batch, i))
+                out = model.validation_step(batch, i)
+                for cb in self.callbacks:   # Lightning's hook order: after each validation batch (mimicry_logger.py:154)
+                    cb.on_validation_batch_end(self, model, out, batch, i, 0)
+                total += float(out)
                 count += 1
         model.train()
         val = total / max(count, 1)

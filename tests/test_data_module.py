@@ -1,0 +1,228 @@
+"""The window sampler and I/O helpers around the hot path (SURVEY.md par. 8f): CPU tests pin the numpy restatement
+(oracle/mimicry_oracle.py) to hand-built expectations; the GPU tests compare lets_face_it_amd.mimicry_data_module /
+generate_motion / mimicry_logger with it."""
+import random
+from argparse import Namespace
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import mimicry_oracle as mo
+
+DATA_HP = {"expression_dim": 5, "jaw_dim": 3, "neck_dim": 3, "speech_dim": 6, "file_name": "unused"}
+COND_HP = {"p1_face": {"history": 2}, "p2_face": {"history": 3}, "p1_speech": {"history": 2}, "p2_speech": {"history": 0},
+           "use_frame_nb": False}
+
+
+def make_store(lens=(7, 3, 12), seed=0):
+    """A tiny HDF5-shaped tree: bins of different lengths, expression wider than expression_dim (the file stores 100)."""
+    rng = np.random.RandomState(seed)
+    dims = {"flame_expression": 8, "flame_jaw": 3, "flame_neck": 3, "mfcc": 4, "prosody": 2}
+    store = {"train": {k: {} for k in dims}}
+    for i, n in enumerate(lens):
+        for kind, d in dims.items():
+            store["train"][kind][str(i)] = {who: rng.randn(n, d).astype(np.float32) for who in ("agent", "interlocutor")}
+    return store
+
+
+def test_window_index_enumeration():
+    store = make_store()
+    idx = mo.window_index(store, "train", 5)
+    # bins of 7, 3, 12 frames at seq_len 5: 3 + 0 + 8 stride-1 windows, bin order then start order
+    assert idx == [("0", s) for s in range(3)] + [("2", s) for s in range(8)]
+    assert mo.window_index(store, "train", 13) == []
+
+
+def test_get_item_layout():
+    store = make_store()
+    d = mo.get_item(store, "train", "2", 4, 5, DATA_HP["expression_dim"],
+                    {"p1_speech": 2, "p2_speech": 0, "p2_face": 3})
+    assert set(d) == {"p1_face", "p1_speech", "p2_face"}            # p2_speech history 0: stream absent
+    t = store["train"]
+    assert d["p1_face"].shape == (5, 11) and d["p1_speech"].shape == (5, 6)
+    np.testing.assert_array_equal(d["p1_face"][:, :5], t["flame_expression"]["2"]["agent"][4:9, :5])
+    np.testing.assert_array_equal(d["p1_face"][:, 5:8], t["flame_jaw"]["2"]["agent"][4:9])
+    np.testing.assert_array_equal(d["p1_face"][:, 8:], t["flame_neck"]["2"]["agent"][4:9])
+    np.testing.assert_array_equal(d["p1_speech"][:, :4], t["mfcc"]["2"]["agent"][4:9])
+    np.testing.assert_array_equal(d["p2_face"][:, 5:8], t["flame_jaw"]["2"]["interlocutor"][4:9])
+
+
+def test_calc_jerk_oracle():
+    t = np.arange(10, dtype=np.float32)
+    x = np.stack([t ** 3, t ** 2], axis=-1)[None]      # third difference of t^3 is 6, of t^2 is 0
+    assert abs(mo.calc_jerk(x) - 3.0) < 1e-5
+
+
+def test_face_layout_helpers():
+    hp = {"expression_dim": 50, "jaw_dim": 3, "neck_dim": 3, "speech_dim": 30}
+    frames = np.arange(4 * 272, dtype=np.float32).reshape(4, 272)
+    d = mo.dictify_frames(frames, hp)
+    assert d["p1_face"].shape == (4, 56) and d["p2_speech"].shape == (4, 30)
+    assert d["p1_face"][0, 50] == 100 and d["p1_face"][0, 53] == 103 and d["p2_face"][0, 0] == 136 and d["p2_face"][0, 50] == 236
+    assert d["p1_speech"][0, 0] == 106 and d["p2_speech"][0, 0] == 242
+    out = mo.expand_face_dim(d["p1_face"][None], hp)
+    assert out.shape == (1, 4, 106)
+    np.testing.assert_array_equal(out[0, :, :50], frames[:, :50])
+    np.testing.assert_array_equal(out[0, :, 100:106], frames[:, 100:106])
+    assert (out[0, :, 50:100] == 0).all()
+
+
+# ---------------------------------------------------------------------------------------------------------- GPU
+@pytest.mark.gpu
+@pytest.mark.parametrize("source", ["dict", "npz"])
+def test_window_sampler_matches_reference_dataset(gpu_device, tmp_path, source):
+    from lets_face_it_amd.mimicry_data_module import MimicryDataset, WindowLoader
+    store = make_store(lens=(7, 3, 12, 5, 40))
+    src = store
+    if source == "npz":
+        flat = {"train/%s/%s/%s" % (k, b, w): a for k, bins in store["train"].items() for b, d in bins.items() for w, a in d.items()}
+        np.savez(tmp_path / "corpus.npz", **flat)
+        src = tmp_path / "corpus.npz"
+    random.seed(3)
+    ds = MimicryDataset(src, "train", data_hparams=DATA_HP, conditioning_hparams=COND_HP, seq_len=5, device=gpu_device)
+    ref = mo.window_index(store, "train", 5)
+    assert len(ds) == len(ref) == 3 + 8 + 1 + 36
+    assert sorted(ds.indicies) == sorted(ref)                      # same windows, shuffled once like the reference
+    hist = {"p1_speech": 2, "p2_speech": 0, "p2_face": 3}
+    idx = list(range(len(ds)))
+    batch = ds.batch(idx)
+    assert set(batch) == {"p1_face", "p1_speech", "p2_face"}
+    for i in idx:
+        key, start = ds.indicies[i]
+        want = mo.get_item(store, "train", key, start, 5, DATA_HP["expression_dim"], hist)
+        for name, arr in want.items():
+            assert torch.equal(batch[name][i].cpu(), torch.from_numpy(arr)), (i, name)     # a copy: bit-exact
+    item = ds[4]
+    assert item["p1_face"].shape == (5, 11) and torch.equal(item["p1_face"], batch["p1_face"][4])
+    # loader: every window exactly once per epoch, ragged last batch kept (drop_last=False), ranks split the batches
+    seen = []
+    for rank in (0, 1):
+        for b in WindowLoader(ds, 7, shuffle=True, rank=rank, world_size=2, generator=torch.Generator().manual_seed(1)):
+            assert b["p1_face"].is_cuda and b["p1_face"].shape[1:] == (5, 11)
+            seen.append(b["p1_face"].cpu())
+    got = torch.cat(seen)
+    assert got.shape[0] == len(ds)
+    allw = batch["p1_face"].cpu()
+    assert sorted(map(lambda t: t.flatten().tolist(), got)) == sorted(map(lambda t: t.flatten().tolist(), allw))
+    with pytest.raises(IndexError):
+        ds.batch([len(ds)])
+
+
+@pytest.mark.gpu
+def test_window_sampler_feeds_the_model(gpu_device):
+    """End to end at the boundary: batches from the sampler go straight into SeqGlow.forward (final widths, tiny corpus)."""
+    from helpers import Fixture
+    from lets_face_it_amd.glow.models import SeqGlow
+    from lets_face_it_amd.mimicry_data_module import MimicryDataModule
+    fx = Fixture("tiny")
+    hp = fx.hp
+    hp["Data"].update(expression_dim=10, jaw_dim=3, neck_dim=3, speech_dim=fx.S)
+    hp["batch_size"] = 6
+    hp["Train"]["seq_len"] = fx.T
+    rng = np.random.RandomState(1)
+    dims = {"flame_expression": 100, "flame_jaw": 3, "flame_neck": 3, "mfcc": fx.S - 2, "prosody": 2}
+    store = {"train": {k: {str(i): {w: rng.randn(n, d).astype(np.float32) for w in ("agent", "interlocutor")}
+                           for i, n in enumerate((30, 25))} for k, d in dims.items()}}
+    dm = MimicryDataModule(Namespace(**hp), device=gpu_device, source=store)
+    m = SeqGlow(Namespace(**hp))
+    m.load_state_dict(fx.state_dict(torch.float32))
+    m.to(gpu_device).eval()
+    m.glow.set_actnorm_init(True)
+    n = 0
+    for batch in dm.train_dataloader():
+        with torch.no_grad():
+            _, loss, _ = m(batch)
+        assert torch.isfinite(loss).all() and batch["p1_face"].shape[1:] == (fx.T, 16)
+        n += batch["p1_face"].shape[0]
+    assert n == (30 - fx.T + 1) + (25 - fx.T + 1)
+
+
+@pytest.mark.gpu
+def test_jerk_kernel_matches_reference_formula(gpu_device):
+    from lets_face_it_amd.glow.utils import calc_jerk
+    g = torch.Generator().manual_seed(0)
+    for shape in ((3, 7, 5), (64, 276, 50), (1, 4, 1)):
+        x = torch.randn(*shape, generator=g)
+        got = float(calc_jerk(x.to(gpu_device)))
+        want = mo.calc_jerk(x.numpy())
+        assert abs(got - want) < 1e-6 * max(1.0, want), (shape, got, want)
+        assert abs(float(calc_jerk(x)) - want) < 1e-5 * max(1.0, want)
+
+
+@pytest.mark.gpu
+def test_generate_motion_io_contract(gpu_device):
+    """272-d frames -> model streams -> inference -> de-standardised 106-d FLAME vector, against the numpy restatement of the
+    layout helpers and the engine's own sampler on the standardised streams."""
+    from helpers import Fixture
+    from lets_face_it_amd import generate_motion as gm
+    from lets_face_it_amd.glow.lets_face_it_glow import LetsFaceItGlow
+    fx = Fixture("tiny")
+    hp = fx.hp
+    hp["Data"].update(expression_dim=10, jaw_dim=3, neck_dim=3, speech_dim=fx.S)   # 16-d face, as the fixture's model
+    model = LetsFaceItGlow(Namespace(**hp))
+    model.seq_glow.load_state_dict(fx.state_dict(torch.float32))
+    model.to(gpu_device)
+    model.seq_glow.glow.set_actnorm_init(True)
+    g = torch.Generator().manual_seed(2)
+    T = 30
+    frames = torch.randn(T, 272, generator=g)
+    stats = {"face_means": torch.randn(16, generator=g), "face_stds": torch.rand(16, generator=g) + 0.5,
+             "speech_means": torch.randn(fx.S, generator=g), "speech_stds": torch.rand(fx.S, generator=g) + 0.5}
+    d_ref = mo.dictify_frames(frames.numpy(), hp["Data"])
+    d = gm.dictify_frames(frames.to(gpu_device), hp["Data"])
+    for k in d_ref:
+        assert torch.equal(d[k].cpu(), torch.from_numpy(d_ref[k])), k
+    stats_d = {k: v.to(gpu_device) for k, v in stats.items()}
+    noise = torch.randn(T - fx.start, 1, 16, generator=g).to(gpu_device)
+    out = gm.generate_motion(frames.to(gpu_device), model, stats_d, eps=1, noise=noise)
+    assert out.shape == (1, T - fx.start, 106)
+    # the same thing by hand: standardise, sample, de-standardise, expand
+    cond = {"p1_face": torch.zeros(1, fx.start, 16, device=gpu_device)}
+    for k, m, s in (("p2_face", "face_means", "face_stds"), ("p1_speech", "speech_means", "speech_stds"),
+                    ("p2_speech", "speech_means", "speech_stds")):
+        cond[k] = ((torch.from_numpy(d_ref[k]) - stats[m]) / stats[s]).unsqueeze(0).to(gpu_device).contiguous()
+    pred = model.seq_glow.inference(T, data=cond, noise=noise)
+    want = mo.expand_face_dim((pred.cpu() * stats["face_stds"] + stats["face_means"]).numpy(), hp["Data"])
+    assert np.abs(out.cpu().numpy() - want).max() < 1e-5
+    assert (out[..., 10:100] == 0).all()
+
+
+@pytest.mark.gpu
+def test_mimicry_logger_metrics(gpu_device):
+    """on_validation_batch_end logs what the reference's callback logs (mimicry_logger.py:154-239): jerk, the invertibility
+    error (~0 for a bijection) and one mismatched-NLL probe per Mismatch entry whose modalities are all switched on."""
+    from helpers import Fixture
+    from lets_face_it_amd.glow.lets_face_it_glow import LetsFaceItGlow
+    from lets_face_it_amd.glow.utils import calc_jerk
+    from lets_face_it_amd.mimicry_logger import MimicryLogger
+    fx = Fixture("tiny")
+    hp = fx.hp
+    hp["Validation"].update(inference=True, check_invertion=True, wrong_context_test=True, scale_logging=True, render=False,
+                            seq_len=fx.T)
+    model = LetsFaceItGlow(Namespace(**hp))
+    model.seq_glow.load_state_dict(fx.state_dict(torch.float32))
+    model.to(gpu_device).eval()
+    model.seq_glow.glow.set_actnorm_init(True)
+    batch = {k: v.to(device=gpu_device, dtype=torch.float32).contiguous() for k, v in fx.batch().items()}
+    out = model.validation_step(batch, 0)
+    random.seed(0)
+    torch.manual_seed(0)
+    MimicryLogger().on_validation_batch_end(None, model, out, batch, 0, 0)
+    L = model.logged
+    assert float(L["reconstruction/error_percentage"]) < 1e-4
+    assert abs(float(L["jerk/gt_mean"]) - mo.calc_jerk(fx.batch()["p1_face"][:, -(fx.T - fx.start):].numpy())) < 1e-5
+    assert float(L["jerk/generated_mean"]) > 0 and abs(float(L["jerk/generated_mean_ratio"])
+                                                      - float(L["jerk/generated_mean"]) / float(L["jerk/gt_mean"])) < 1e-5
+    assert abs(float(L["mismatched_nll/actual_nll"]) - float(fx.get("eval/loss"))) < 1e-3 * abs(float(fx.get("eval/loss")))
+    probes = [k for k in L if k.startswith("mismatched_nll/shuffle_")]
+    want = sum(all(hp["Conditioning"][m]["history"] > 0 for m in mods)
+               for kind in ("shuffle_batch", "shuffle_time") for mods in hp["Mismatch"][kind].values())
+    assert len(probes) == want and want >= 6
+    for k in probes:
+        assert torch.isfinite(L[k]).all()
+        ratio = L["mismatched_nll_ratios/" + k.split("/", 1)[1]]
+        assert abs(float(ratio) - (float(L["mismatched_nll/actual_nll"]) - float(L[k]))) < 1e-3
+    MimicryLogger().on_validation_batch_end(None, model, out, batch, 1, 0)   # only the first batch is probed
+    stats = MimicryLogger().log_scales(model)
+    assert any(k.startswith("ActNorm/") for k in stats) and any(k.startswith("FlowStepScale/") for k in stats)

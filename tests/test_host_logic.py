@@ -135,3 +135,23 @@ def test_oracle_is_not_imported_by_the_product():
             if f.endswith(".py"):
                 text = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle", text, re.M), f
+
+
+def test_oom_is_reported_in_the_wording_the_tuning_harness_matches():
+    """hparams_tuning.py:162-166 halves the batch on `str(e).startswith("CUDA out of memory")`; ROCm says "HIP out of memory"."""
+    from lets_face_it_amd._lib import translate_oom
+
+    @translate_oom
+    def alloc():
+        raise torch.OutOfMemoryError("HIP out of memory. Tried to allocate 20.00 GiB. GPU 0 has a total capacity of 287.98 GiB")
+
+    with pytest.raises(RuntimeError) as ei:
+        alloc()
+    assert str(ei.value).startswith("CUDA out of memory") and "Tried to allocate 20.00 GiB" in str(ei.value)
+
+    @translate_oom
+    def other():
+        raise RuntimeError("something else")
+
+    with pytest.raises(RuntimeError, match="something else"):
+        other()
