@@ -1960,10 +1960,12 @@ __global__ __launch_bounds__(64) void flow_pipe_poison_kernel(FlowK f) {
   if (f.pipe[1] == 0u) return;
   const float nan = __builtin_nanf("");
   for (int k = threadIdx.x; k < f.Ks; k += 64) {
-    f.bDlin[(long)k * f.F * f.ldo] = nan;
-    f.bDgi[(long)k * f.F * f.G] = nan;
-    f.bDgh[(long)k * f.F * f.G] = nan;
-    f.bDy[(long)k * f.F * f.ldc] = nan;
+    for (long fr = 0; fr < f.F; fr += (f.F > 1 ? f.F - 1 : 1)) {   // first and last frame (the W_hh gradient skips timestep 0)
+      f.bDlin[((long)k * f.F + fr) * f.ldo] = nan;
+      f.bDgi[((long)k * f.F + fr) * f.G] = nan;
+      f.bDgh[((long)k * f.F + fr) * f.G] = nan;
+      f.bDy[((long)k * f.F + fr) * f.ldc] = nan;
+    }
   }
 }
 
@@ -2386,6 +2388,11 @@ bool flow_pipe_enabled() {
 }
 // LFI_PIPE_FENCE=1: consumers of a hand-off run an agent-scope acquire and read the tile with plain loads, instead of the
 // fence-free form (every store and load of the tile sc1; MI355X_MICROARCH.md, hand-offs measured without the acquire, row 1)
+// LFI_PIPE_FORCE_ABORT=1 (tests): start the walk with the abort word already set, as if a spin had timed out
+bool flow_pipe_force_abort() {
+  const char* e = getenv("LFI_PIPE_FORCE_ABORT");
+  return e && e[0] == '1';
+}
 int flow_pipe_fence() {
   const char* e = getenv("LFI_PIPE_FENCE");
   return (e && e[0] == '1') ? 1 : 0;
@@ -2518,6 +2525,7 @@ extern "C" int lfi_flow_seq_fwd(const lfi_flow_dims* d, const lfi_flow_params* p
     if (rc) return rc;
     hipError_t me = hipMemsetAsync(f.pipe, 0, (size_t)pipe_words(f) * sizeof(unsigned), st);
     LFI_REQUIRE(me == hipSuccess, "lfi_flow_seq_fwd: hipMemsetAsync: %s", hipGetErrorString(me));
+    if (flow_pipe_force_abort()) (void)hipMemsetAsync(f.pipe + 1, 1, sizeof(unsigned), st);
     const dim3 grid(f.Ks * f.nbt);
     if (f.lstm) hipLaunchKernelGGL(flow_pipe_fwd_kernel<4>, grid, dim3(NT), plds, st, f);
     else hipLaunchKernelGGL(flow_pipe_fwd_kernel<3>, grid, dim3(NT), plds, st, f);
@@ -2563,6 +2571,7 @@ extern "C" int lfi_flow_seq_bwd(const lfi_flow_dims* d, const lfi_flow_params* p
     if (rc) return rc;
     hipError_t me = hipMemsetAsync(f.pipe, 0, (size_t)pipe_words(f) * sizeof(unsigned), st);
     LFI_REQUIRE(me == hipSuccess, "lfi_flow_seq_bwd: hipMemsetAsync: %s", hipGetErrorString(me));
+    if (flow_pipe_force_abort()) (void)hipMemsetAsync(f.pipe + 1, 1, sizeof(unsigned), st);
     const dim3 grid(f.Ks * f.nbt);
     if (f.lstm) hipLaunchKernelGGL(flow_pipe_bwd_kernel<4>, grid, dim3(NT), lds, st, f);
     else hipLaunchKernelGGL(flow_pipe_bwd_kernel<3>, grid, dim3(NT), lds, st, f);

@@ -467,3 +467,24 @@ def test_pipeline_walk_matches_diagonal_walk(gpu_device, monkeypatch, case):
             assert rel_err(outs[0][2][n], outs[1][2][n]) < 1e-6, n
         else:
             assert torch.equal(outs[0][2][n], outs[1][2][n]), n
+
+
+def test_abandoned_walk_is_loud(gpu_device, monkeypatch):
+    """A persistent walk whose bounded spin times out sets the abort word; every workgroup then leaves its loop and the
+    results are poisoned on the device (NaN NLL, NaN gradients) instead of passing for numbers. LFI_PIPE_FORCE_ABORT=1
+    starts the walk with the word already set."""
+    fxm = Fixture("mid")
+    m = build(fxm, gpu_device, train=True)
+    m.injected_masks = fxm.masks(torch.float32)
+    batch = to_dev(fxm.batch(), gpu_device)
+    monkeypatch.setenv("LFI_PIPE_FORCE_ABORT", "1")
+    _, loss, losses = m(batch)
+    assert torch.isnan(torch.stack(losses)).all() and torch.isnan(loss).all()
+    m.engine.backward(1.0)
+    torch.cuda.synchronize()
+    for name in ("w_hh", "w_ih", "w_fl", "wct"):
+        assert torch.isnan(m.engine.fview(name, m.engine.grads)).any(), name
+    assert torch.isnan(m.engine.view("enc.p2_face.weight_hh", m.engine.grads)).any()
+    monkeypatch.delenv("LFI_PIPE_FORCE_ABORT")
+    _, loss, losses = m(batch)          # the next call is clean again: the state block is re-zeroed by every walk
+    assert max_rel(torch.stack(losses), fxm.get("train/nll"), floor=1.0) < 1e-4
