@@ -204,6 +204,20 @@ int lfi_flow_step(const lfi_flow_dims* d, const lfi_flow_params* p, const float*
                   const float* x_in, long ldx, const float* h_prev, const float* c_prev, const float* gic_k,
                   float* x_out, long ldxo, float* h_out, float* c_out, float* ldc_acc, int reverse, void* stream);
 
+/* Stand-alone module calls (what code/glow_pytorch/test_modules.py:9-29 exercises outside any flow).
+ * lfi_actnorm_forward: ActNorm2d.forward (glow/modules.py:45-80) on a (rows x C) batch: out = (x + bias) exp(logs), or with
+ * reverse = 1 x exp(-logs) - bias; dlogdet[0] (nullable) = +-C * sum(logs).
+ * lfi_invconv_weights: InvertibleConv1x1.get_weight (glow/modules.py:147-178): W (C x C) from the LU parameters or the dense
+ * weight inv_w, optionally the reverse weight Winv (fp64 inverses cast to fp32; required when with_inverse, and written
+ * whenever inv_w is given), dlogdet[0] = C * sum(inv_logs) resp. C * log|det inv_w|. z = x W is then one lfi_gemm_f32.
+ * work: lfi_invconv_work_floats(C) floats, 8-byte aligned. */
+int lfi_actnorm_forward(const float* x, int rows, int C, const float* bias, const float* logs, int reverse, float* out,
+                        float* dlogdet, void* stream);
+long lfi_invconv_work_floats(int C);
+int lfi_invconv_weights(int C, const float* inv_l, const float* inv_u, const float* inv_logs, const float* inv_p,
+                        const float* inv_sign, const float* inv_w, int with_inverse, float* W, float* Winv, float* dlogdet,
+                        float* work, void* stream);
+
 /* ---------------------------------------------------------------- autoregressive sampling (SeqGlow.inference, glow/models.py:567-596)
  * Whole sequence in one call. faces (B x seq_len x C, batch-first) holds the `start` seed frames and receives the
  * generated ones. Per frame t: c = LeakyReLU(pre_static[n] + faces[:, t-hist1:t] Wct[:, :hist1*C]^T) for all Ks steps

@@ -114,6 +114,9 @@ def lib():
                                     vp]),
         "lfi_grad_sumsq": (i, [vp, l, vp, vp, vp]),
         "lfi_adam_clip_step": (i, [vp, vp, vp, vp, l, vp, f, f, f, f, f, f, i, vp]),
+        "lfi_actnorm_forward": (i, [vp, i, i, vp, vp, i, vp, vp, vp]),
+        "lfi_invconv_work_floats": (l, [i]),
+        "lfi_invconv_weights": (i, [i, vp, vp, vp, vp, vp, vp, i, vp, vp, vp, vp, vp]),
         "lfi_gather_sequences": (i, [vp, l, i, vp, i, i, vp, vp]),
         "lfi_jerk_mean": (i, [vp, i, i, i, vp, vp, vp]),
         "lfi_selftest_mfma": (i, [vp, vp]),
@@ -136,7 +139,7 @@ EXPORTS = [
     "lfi_flow_seq_fwd", "lfi_flow_seq_bwd", "lfi_flow_param_grads_work_floats", "lfi_flow_param_grads",
     "lfi_actnorm_init_stats", "lfi_actnorm_init_apply", "lfi_flow_step", "lfi_flow_sample_work_floats",
     "lfi_flow_sample_p1_work_floats", "lfi_flow_sample_seq", "lfi_grad_sumsq", "lfi_adam_clip_step", "lfi_selftest_mfma", "lfi_debug_set_stamps",
-    "lfi_gather_sequences", "lfi_jerk_mean",
+    "lfi_gather_sequences", "lfi_jerk_mean", "lfi_actnorm_forward", "lfi_invconv_work_floats", "lfi_invconv_weights",
 ]
 
 

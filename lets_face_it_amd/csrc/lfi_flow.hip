@@ -2018,6 +2018,23 @@ __global__ __launch_bounds__(256) void flow_prep_pad_kernel(FlowK f, float* pW, 
   }
 }
 
+// ActNorm2d.forward as a stand-alone module call (glow/modules.py:45-80): out = (x + bias) exp(logs), or its inverse
+// x exp(-logs) - bias; dlogdet[0] = +-C * sum(logs) (the x C factor of modules.py:62)
+__global__ __launch_bounds__(256) void actnorm_module_kernel(const float* __restrict__ x, long rows, int C, const float* __restrict__ bias,
+                                                             const float* __restrict__ logs, int reverse, float* __restrict__ out,
+                                                             float* __restrict__ dlogdet) {
+  const long total = rows * C;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int c = (int)(i % C);
+    out[i] = reverse ? x[i] * expf(-logs[c]) - bias[c] : (x[i] + bias[c]) * expf(logs[c]);
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0 && dlogdet) {
+    float s = 0.0f;
+    for (int c = 0; c < C; ++c) s += logs[c];
+    dlogdet[0] = (reverse ? -(float)C : (float)C) * s;
+  }
+}
+
 // ------------------------------------------------------------------------------------------- prep
 // One workgroup per flow step: W = P (L*mask + I)(U*mask^T + diag(sign exp(log_s)))  (glow/modules.py:167-173),
 // its transpose, and (optionally) the reverse weight U^-1 L^-1 P^-1 with fp64 triangular inverses (:175-177).
@@ -2837,5 +2854,49 @@ extern "C" int lfi_flow_sample_seq(const lfi_flow_dims* d, const lfi_flow_params
     }
   }
   LFI_LAUNCH_CHECK("lfi_flow_sample_seq");
+  return LFI_OK;
+}
+
+// ---------------------------------------------------------------------------------------------- stand-alone module calls
+// What the reference's test_modules.py:9-29 pokes directly: ActNorm2d and InvertibleConv1x1 outside any flow.
+extern "C" int lfi_actnorm_forward(const float* x, int rows, int C, const float* bias, const float* logs, int reverse, float* out,
+                                   float* dlogdet, void* stream) {
+  LFI_REQUIRE(x && bias && logs && out && rows > 0 && C > 0, "lfi_actnorm_forward: bad arguments");
+  const long total = (long)rows * C;
+  const int blocks = (int)(lfi_cdiv(total, 256) < 2048 ? lfi_cdiv(total, 256) : 2048);
+  hipLaunchKernelGGL(actnorm_module_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, (long)rows, C, bias, logs, reverse, out,
+                     dlogdet);
+  LFI_LAUNCH_CHECK("lfi_actnorm_forward");
+  return LFI_OK;
+}
+
+extern "C" long lfi_invconv_work_floats(int C) {
+  if (C <= 0) return 0;
+  return 2L * (2L * C * C + C) + (long)C * C + C + 16;   // fp64 scratch (as floats), W^T, a zero ActNorm row
+}
+
+extern "C" int lfi_invconv_weights(int C, const float* inv_l, const float* inv_u, const float* inv_logs, const float* inv_p,
+                                   const float* inv_sign, const float* inv_w, int with_inverse, float* W, float* Winv,
+                                   float* dlogdet, float* work, void* stream) {
+  LFI_REQUIRE(C >= 2 && W && dlogdet && work, "lfi_invconv_weights: bad arguments");
+  LFI_REQUIRE(inv_w || (inv_l && inv_u && inv_logs && inv_p && inv_sign), "lfi_invconv_weights: invconv parameters missing");
+  LFI_REQUIRE(!with_inverse || Winv, "lfi_invconv_weights: with_inverse needs Winv");
+  LFI_REQUIRE(((uintptr_t)work & 7) == 0, "lfi_invconv_weights: work must be 8-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  double* dscratch = reinterpret_cast<double*>(work);
+  float* Wt = work + 2L * (2L * C * C + C);
+  float* zeros = Wt + (long)C * C;
+  hipError_t me = hipMemsetAsync(zeros, 0, sizeof(float) * (size_t)C, st);
+  LFI_REQUIRE(me == hipSuccess, "lfi_invconv_weights: hipMemsetAsync: %s", hipGetErrorString(me));
+  FlowK f = {};
+  f.C = C; f.Ks = 1;
+  f.p.inv_l = inv_l; f.p.inv_u = inv_u; f.p.inv_logs = inv_logs; f.p.inv_p = inv_p; f.p.inv_sign = inv_sign; f.p.inv_w = inv_w;
+  f.p.an_logs = zeros;   // the kernel adds the ActNorm part of the constant log-det: none here
+  const size_t lds = (size_t)3 * C * C * sizeof(float);
+  int rc = set_flow_lds(flow_prep_invconv_kernel, lds, "lfi_invconv_weights");
+  if (rc) return rc;
+  hipLaunchKernelGGL(flow_prep_invconv_kernel, dim3(1), dim3(256), lds, st, f, W, Wt, (with_inverse || inv_w) ? Winv : nullptr, dscratch,
+                     dlogdet);
+  LFI_LAUNCH_CHECK("lfi_invconv_weights");
   return LFI_OK;
 }

@@ -4,14 +4,19 @@ GaussianDiag :197-235).
 
 Inside SeqGlow these modules only HOLD parameters: the fused engine reads them through one flat buffer and never
 calls their forward(). The forward() methods below exist for the stand-alone module API (what the reference's
-test_modules.py exercises) and are thin torch expressions of the same formulas — they are not the product path.
+test_modules.py:9-29 exercises): they run on the GPU through the same library (lfi_actnorm_forward, lfi_actnorm_init_*,
+lfi_invconv_weights + lfi_gemm_f32); a CPU tensor raises, as everywhere else in this package. Inference-only (no autograd).
 """
 import math
 
 import numpy as np
 import scipy.linalg
+import ctypes as C_
+
 import torch
 import torch.nn as nn
+
+from .. import _lib
 
 
 class ActNorm2d(nn.Module):
@@ -26,27 +31,43 @@ class ActNorm2d(nn.Module):
         self.inited = False  # plain attribute, not saved with the state dict (modules.py:27)
 
     def initialize_parameters(self, input):
+        """Data-dependent init (modules.py:32-43): bias = -mean, logs = log(scale / (std + 1e-6)) over the batch."""
         if not self.training:
             return
-        with torch.no_grad():
-            bias = -input.mean(dim=0, keepdim=True)
-            var = ((input + bias) ** 2).mean(dim=0, keepdim=True)
-            self.bias.data.copy_(bias)
-            self.logs.data.copy_(torch.log(self.scale / (var.sqrt() + 1e-6)))
-            self.inited = True
+        L, x, st = _gpu_call(input, "ActNorm2d")
+        B, C = x.shape
+        sums = torch.zeros(2 * C, dtype=torch.float64, device=x.device)
+        _lib.check(L.lfi_actnorm_init_stats(x.data_ptr(), B, C, sums.data_ptr(), st), "lfi_actnorm_init_stats")
+        bias, logs = self.bias.data.contiguous(), self.logs.data.contiguous()
+        _lib.check(L.lfi_actnorm_init_apply(sums.data_ptr(), float(B), C, self.scale, bias.data_ptr(), logs.data_ptr(), st),
+                   "lfi_actnorm_init_apply")
+        self.bias.data.copy_(bias)
+        self.logs.data.copy_(logs)
+        self.inited = True
 
     def forward(self, input, logdet=None, reverse=False):
         if not self.inited:
             self.initialize_parameters(input)
-        dlogdet = self.logs.sum() * input.size(1)
-        if not reverse:
-            out = (input + self.bias) * torch.exp(self.logs)
-        else:
-            out = input * torch.exp(-self.logs) - self.bias
-            dlogdet = -dlogdet
+        L, x, st = _gpu_call(input, "ActNorm2d")
+        B, C = x.shape
+        out = torch.empty_like(x)
+        dlogdet = torch.empty(1, dtype=torch.float32, device=x.device)
+        bias, logs = self.bias.data.contiguous(), self.logs.data.contiguous()
+        _lib.check(L.lfi_actnorm_forward(x.data_ptr(), B, C, bias.data_ptr(), logs.data_ptr(), 1 if reverse else 0,
+                                         out.data_ptr(), dlogdet.data_ptr(), st), "lfi_actnorm_forward")
         if logdet is not None:
-            logdet = logdet + dlogdet
+            logdet = logdet + dlogdet[0]      # input.size(1) = C is already in it (modules.py:62)
         return out, logdet
+
+
+def _gpu_call(input, who):
+    """(library, contiguous fp32 (B, C) view of the input, stream) for a stand-alone module call; CPU tensors raise."""
+    if not input.is_cuda:
+        raise RuntimeError("%s (lets_face_it_amd) runs on the GPU only; got a %s tensor (there is no CPU fallback by design)"
+                           % (who, input.device.type))
+    if input.dim() != 2:
+        raise ValueError("%s: expected a (batch, channels) tensor, got %s" % (who, tuple(input.shape)))
+    return _lib.lib(), input.detach().float().contiguous(), torch.cuda.current_stream().cuda_stream
 
 
 class LinearZeros(nn.Linear):
@@ -84,24 +105,38 @@ class InvertibleConv1x1(nn.Module):
         self.u = nn.Parameter(torch.tensor(np.triu(upper, k=1).astype(np.float32)))
 
     def get_weight(self, input, reverse):
+        """-> (W or its fp64-inverted, fp32-cast reverse weight, dlogdet = log|det W| * input.size(1))   (modules.py:147-178)"""
+        L, x, st = _gpu_call(input, "InvertibleConv1x1")
         C = self.w_shape[0]
-        if not self.LU:
-            dlogdet = torch.slogdet(self.weight)[1] * input.size(1)
-            w = self.weight if not reverse else torch.inverse(self.weight.double()).float()
-            return w, dlogdet
-        mask = torch.tril(torch.ones(C, C, device=self.l.device, dtype=self.l.dtype), -1)
-        lower = self.l * mask + torch.eye(C, device=self.l.device, dtype=self.l.dtype)
-        upper = self.u * mask.t() + torch.diag(self.sign_s * torch.exp(self.log_s))
-        dlogdet = self.log_s.sum() * input.size(1)
-        if not reverse:
-            return self.p @ (lower @ upper), dlogdet
-        li = torch.inverse(lower.double()).float()
-        ui = torch.inverse(upper.double()).float()
-        return ui @ (li @ self.p.t()), dlogdet
+        dev = x.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        W, Winv, dlogdet = torch.empty(C, C, **f32), torch.empty(C, C, **f32), torch.empty(1, **f32)
+        work = torch.empty(L.lfi_invconv_work_floats(C) + 2, **f32)
+
+        def p(t):
+            return t.detach().to(**f32).contiguous()
+
+        if self.LU:
+            args = [p(self.l), p(self.u), p(self.log_s), p(self.p), p(self.sign_s), None]
+        else:
+            args = [None, None, None, None, None, p(self.weight)]
+        _lib.check(L.lfi_invconv_weights(C, *[_lib.ptr(a) for a in args], 1 if reverse else 0, W.data_ptr(), Winv.data_ptr(),
+                                         dlogdet.data_ptr(), work.data_ptr(), st), "lfi_invconv_weights")
+        # the kernel's log-det already carries the x C of modules.py:171 (input.size(1) == C for this repo's (B, C) tensors)
+        return (Winv if reverse else W), dlogdet[0]
 
     def forward(self, input, logdet=None, reverse=False):
         w, dlogdet = self.get_weight(input, reverse)
-        z = input @ w
+        L, x, st = _gpu_call(input, "InvertibleConv1x1")
+        B, C = x.shape
+        z = torch.empty_like(x)
+        g = _lib.GemmDesc()
+        g.M, g.N, g.K = B, C, C
+        g.A, g.lda, g.a_kcontig = x.data_ptr(), C, 1          # z = x @ w: A (B x C) k-contiguous
+        g.B, g.ldb, g.b_kcontig = w.data_ptr(), C, 0          # B element (k, n) at w[k * C + n]
+        g.C, g.ldc = z.data_ptr(), C
+        g.batch, g.splitk = 1, 1
+        _lib.check(L.lfi_gemm_f32(C_.byref(g), st), "lfi_gemm_f32")
         if logdet is not None:
             logdet = logdet - dlogdet if reverse else logdet + dlogdet
         return z, logdet

@@ -104,22 +104,19 @@ def get_longest_history(cond_params):
 
 
 def calc_jerk(x):
-    """Mean absolute third difference along time of a (B, T, C) sequence (utils.py:53-58). A GPU tensor is reduced on
-    the device by lfi_jerk_mean (fp32 differences as the reference, fixed-order fp64 sum); a CPU tensor takes the
-    reference's own four torch lines (it moves everything to the CPU first: `x = x.cpu()`)."""
-    if x.is_cuda:
-        from .. import _lib
-        x = x.detach().float().contiguous()
-        B, T, C = x.shape
-        out = torch.empty(1, dtype=torch.float32, device=x.device)
-        work = torch.empty(1024, dtype=torch.float64, device=x.device)
-        _lib.check(_lib.lib().lfi_jerk_mean(x.data_ptr(), B, T, C, out.data_ptr(), work.data_ptr(),
-                                            torch.cuda.current_stream().cuda_stream), "lfi_jerk_mean")
-        return out[0]
-    d1 = x[:, 1:] - x[:, :-1]
-    d2 = d1[:, 1:] - d1[:, :-1]
-    d3 = d2[:, 1:] - d2[:, :-1]
-    return d3.abs().mean()
+    """Mean absolute third difference along time of a (B, T, C) sequence (utils.py:53-58), reduced on the device by
+    lfi_jerk_mean (fp32 differences as the reference, fixed-order fp64 sum). Returns a 0-dim device tensor; a CPU tensor
+    raises (the reference moves its input to the CPU first; here the metric stays where the sequence was generated)."""
+    if not x.is_cuda:
+        raise RuntimeError("calc_jerk (lets_face_it_amd) runs on the GPU only; got a %s tensor" % x.device.type)
+    from .. import _lib
+    x = x.detach().float().contiguous()
+    B, T, C = x.shape
+    out = torch.empty(1, dtype=torch.float32, device=x.device)
+    work = torch.empty(1024, dtype=torch.float64, device=x.device)
+    _lib.check(_lib.lib().lfi_jerk_mean(x.data_ptr(), B, T, C, out.data_ptr(), work.data_ptr(),
+                                        torch.cuda.current_stream().cuda_stream), "lfi_jerk_mean")
+    return out[0]
 
 
 def lambda1(val):

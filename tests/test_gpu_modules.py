@@ -17,23 +17,35 @@ pytestmark = pytest.mark.gpu
 def test_actnorm(gpu_device):  # test_modules.py:9-18
     from lets_face_it_amd.glow import modules
     actnorm = modules.ActNorm2d(54).to(gpu_device)
-    x = torch.tensor(np.random.RandomState(0).rand(2, 54), dtype=torch.float32, device=gpu_device)
+    x = torch.tensor(np.random.RandomState(0).rand(6, 54), dtype=torch.float32, device=gpu_device)
     actnorm.initialize_parameters(x)
+    assert actnorm.inited
     y, det = actnorm(x, 0)
-    x_, _ = actnorm(y, None, True)
-    assert float((x_ - x).abs().max()) < 1e-5
-    assert torch.isfinite(torch.as_tensor(det)).all()
+    x_, det2 = actnorm(y, det, True)
+    assert float((x_ - x).abs().max()) < 1e-5 and abs(float(det2)) < 1e-4
+    assert float(y.mean(0).abs().max()) < 1e-5                      # data-dependent init: zero mean, unit scale
+    assert float((y.std(0, unbiased=False) - 1.0).abs().max()) < 1e-3
+    # against the formulas of modules.py:45-66 in torch
+    want = (x + actnorm.bias) * torch.exp(actnorm.logs)
+    assert rel_err(y, want) < 1e-6 and abs(float(det) - float(actnorm.logs.sum()) * 54) < 1e-3
 
 
-def test_conv1x1(gpu_device):  # test_modules.py:21-29
+@pytest.mark.parametrize("lu", [False, True])
+def test_conv1x1(gpu_device, lu):  # test_modules.py:21-29
     from lets_face_it_amd.glow import modules
     np.random.seed(0)
-    conv = modules.InvertibleConv1x1(96).to(gpu_device)
-    x = torch.tensor(np.random.rand(2, 96), dtype=torch.float32, device=gpu_device)
+    conv = modules.InvertibleConv1x1(96, LU_decomposed=lu).to(gpu_device)
+    with torch.no_grad():   # leave the orthogonal initialisation so that the log-det is not trivially 0
+        (conv.log_s if lu else conv.weight).add_(0.05 * torch.randn_like(conv.log_s if lu else conv.weight))
+    x = torch.tensor(np.random.rand(5, 96), dtype=torch.float32, device=gpu_device)
     y, det = conv(x, 0)
-    x_, _ = conv(y, None, True)
-    assert float((x_ - x).abs().max()) < 1e-4
-    assert abs(float(det)) < 1e-2  # orthogonal initialisation: log|det W| = 0
+    x_, det2 = conv(y, det, True)
+    assert float((x_ - x).abs().max()) < 1e-4 and abs(float(det2)) < 1e-3
+    # against the fp64 oracle's weight (P L U resp. the dense matrix; log-det x C, modules.py:171)
+    sd = {"w." + k: v.detach().cpu().double() for k, v in conv.state_dict().items()}
+    W, ld = oracle.invconv_weight(sd, "w.")
+    assert rel_err(y, x.cpu().double() @ W) < 1e-5
+    assert abs(float(det) - float(ld) * 96) < 1e-3 * max(1.0, abs(float(ld) * 96))
 
 
 def _perturb(mod, seed=3):
