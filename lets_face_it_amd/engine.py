@@ -185,6 +185,9 @@ class GlowEngine:
                 self.layout["flow." + name] = (off, shapes[name])
                 off += math.prod(shapes[name])
         self.n_params = off
+        # first float of the flow block of the flat buffers (the encoder leaves come first): the data-parallel trainer
+        # all-reduces [flow_offset:) while the encoder BPTT still runs
+        self.flow_offset = min(o for n, (o, _) in self.layout.items() if n.startswith("flow."))
         f32 = dict(dtype=torch.float32, device=self.device)
         self.params = torch.zeros(off, **f32)
         self.grads = torch.zeros(off, **f32)
@@ -485,8 +488,11 @@ class GlowEngine:
         self.run_prep()  # the constant log-det term depends on the new actnorm logs
 
     @translate_oom
-    def backward(self, gscale):
-        """Gradients of gscale * sum(nll) w.r.t. every parameter, written into self.grads (overwritten)."""
+    def backward(self, gscale, after_flow=None):
+        """Gradients of gscale * sum(nll) w.r.t. every parameter, written into self.grads (overwritten).
+
+        after_flow: optional callable, invoked once every gradient of the flow block (self.grads[self.flow_offset:]) has
+        been enqueued and before the window encoders' BPTT starts (the trainer launches that bucket's all-reduce there)."""
         ctx = self._last
         if ctx is None or not ctx.with_stash:
             raise _lib.LfiError("backward() needs a preceding forward(with_stash=True)")
@@ -515,6 +521,8 @@ class GlowEngine:
         check(self.L.lfi_cols_fold(dwf.data_ptr(), s.ldf, KD, self.unfold.data_ptr(), None, s.E,
                                    self.fview("wct", self.grads).data_ptr(), s.E, st), "lfi_cols_fold")
         self.colsum(dpre, KD, 0, F, KD, 1, self.fview("bct", self.grads), 0)
+        if after_flow is not None:
+            after_flow()
         # gradient of the feature matrix, columns of the trainable encoders only (raw windows are data)
         rnn = [e for e in s.encoders if e.enc in ("rnn", "mlp")]
         if rnn:

@@ -75,7 +75,8 @@ class LetsFaceItGlow(nn.Module):
     def fused_training_step(self, batch, lr, world_size=1, allreduce=None):
         """One optimiser step entirely in the engine. Returns the (detached) loss of this rank.
 
-        allreduce: callable(flat fp32 gradient tensor) summing it over ranks in place (RCCL), or None.
+        allreduce: callable(fp32 gradient tensor, async_op=False) summing it over ranks in place (RCCL) and returning
+        the torch.distributed work handle when async_op, or None.
         """
         sg = self.seq_glow
         negative = self._negative_branch()
@@ -98,9 +99,19 @@ class LetsFaceItGlow(nn.Module):
             self._store_mismatched(-loss)
             sign = -0.1
             loss = loss * -0.1
-        eng.backward(sign / nll.numel())
         if allreduce is not None and world_size > 1:
-            allreduce(eng.grads)
+            # two buckets: the flow block (>95 % of the floats) is all-reduced asynchronously as soon as its gradients are
+            # enqueued and travels over xGMI under the window encoders' BPTT; the encoder block follows on the main stream
+            off = eng.flow_offset
+            pending = []
+            eng.backward(sign / nll.numel(), after_flow=lambda: pending.append(allreduce(eng.grads[off:], async_op=True)))
+            if off > 0:
+                allreduce(eng.grads[:off])
+            for work in pending:
+                if work is not None:
+                    work.wait()
+        else:
+            eng.backward(sign / nll.numel())
         opt = self.hparams.Optim
         if opt["name"] != "adam":
             raise NotImplementedError("fused_training_step implements Adam (final_model.yaml); use training_step with "

@@ -35,8 +35,9 @@ class Trainer:
                 torch.cuda.set_device(self.device)
             dist.init_process_group(backend, rank=self.rank, world_size=self.world_size)
 
-    def allreduce_grads(self, flat):
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+    def allreduce_grads(self, flat, async_op=False):
+        """Sum a (slice of the) flat gradient buffer over ranks in place; async_op=True returns the work handle."""
+        return dist.all_reduce(flat, op=dist.ReduceOp.SUM, async_op=async_op)
 
     def allreduce_stats(self, sums):
         if self.world_size > 1:

@@ -45,7 +45,11 @@ def _worker(rank, world, port, out):
     oracle.seqglow_forward(fx.hp, sd, shard)[1].sum().backward()
     names = [k for k, v in sd.items() if v.requires_grad]
     flat = torch.cat([sd[k].grad.reshape(-1) for k in names])
-    tr.allreduce_grads(flat)
+    # the trainer's two-bucket protocol (fused_training_step): tail bucket asynchronously, head bucket, then wait
+    off = flat.numel() // 20
+    work = tr.allreduce_grads(flat[off:], async_op=True)
+    tr.allreduce_grads(flat[:off])
+    work.wait()
     flat /= world
     full = {k: v.detach().clone().requires_grad_(v.requires_grad) for k, v in sd.items()}
     oracle.seqglow_forward(fx.hp, full, batch)[1].sum().backward()

@@ -488,3 +488,45 @@ def test_abandoned_walk_is_loud(gpu_device, monkeypatch):
     monkeypatch.delenv("LFI_PIPE_FORCE_ABORT")
     _, loss, losses = m(batch)          # the next call is clean again: the state block is re-zeroed by every walk
     assert max_rel(torch.stack(losses), fxm.get("train/nll"), floor=1.0) < 1e-4
+
+
+def test_two_bucket_allreduce_protocol(gpu_device):
+    """fused_training_step under data parallelism hands the gradient to the all-reduce callable in two buckets (flow block
+    asynchronously before the encoder BPTT, encoder block after): every float exactly once, and with a stand-in that behaves
+    like two identical ranks (sum = 2 g, then the optimiser's 1/world) the step is bit-identical to the single-rank step."""
+    from lets_face_it_amd.glow.lets_face_it_glow import LetsFaceItGlow
+    fxm = Fixture("mid")
+
+    def make():
+        torch.manual_seed(0)
+        m = LetsFaceItGlow(Namespace(**fxm.hp))
+        m.seq_glow.load_state_dict(fxm.state_dict(torch.float32))
+        m.to(gpu_device).train()
+        m.seq_glow.glow.set_actnorm_init(True)
+        m.seq_glow.injected_masks = fxm.masks(torch.float32)
+        return m
+
+    batch = to_dev(fxm.batch(), gpu_device)
+    m1 = make()
+    m1.fused_training_step(batch, 1e-3, 1, None)
+    calls = []
+
+    class Work:
+        waited = False
+
+        def wait(self):
+            Work.waited = True
+
+    def fake_allreduce(t, async_op=False):
+        calls.append((t.data_ptr(), t.numel(), async_op))
+        t.mul_(2.0)          # two identical ranks
+        return Work() if async_op else None
+
+    m2 = make()
+    m2.fused_training_step(batch, 1e-3, 2, fake_allreduce)
+    eng = m2.seq_glow.engine
+    base = eng.grads.data_ptr()
+    assert len(calls) == 2 and calls[0][2] is True and calls[1][2] is False and Work.waited
+    assert calls[0][0] == base + 4 * eng.flow_offset and calls[0][1] == eng.n_params - eng.flow_offset
+    assert calls[1][0] == base and calls[1][1] == eng.flow_offset and eng.flow_offset > 0
+    assert torch.equal(m1.seq_glow.engine.params, eng.params)
