@@ -105,8 +105,8 @@ __device__ __forceinline__ void gemm_epilogue_n(const GemmArgs& g, const f32x16 
 // elements in place, result tile out with 16-byte row-wise stores (512 contiguous bytes per 32 lanes).
 // `rows` rows of the block tile per pass (the LDS image is rows x (BN + 4) floats); waves whose 64-row patch is in the pass
 // take part in the register phase, all 256 threads in the row-wise phases.
-template <int BN, int NTH = 256>
-__device__ __forceinline__ void gemm_epilogue_wide(const GemmArgs& g, const f32x16 (&acc)[2][2], float* lds, int rows_per_pass,
+template <int BN, int NTH = 256, int MT = 2>
+__device__ __forceinline__ void gemm_epilogue_wide(const GemmArgs& g, const f32x16 (&acc)[MT][2], float* lds, int rows_per_pass,
                                                    int m0, int n0, int wm, int wn, int l31, int half, int batch, int split, int bm,
                                                    bool has_acc = true) {
   constexpr int WLD = BN + 4;       // LDS row pitch (floats)
@@ -138,9 +138,10 @@ __device__ __forceinline__ void gemm_epilogue_wide(const GemmArgs& g, const f32x
       }
       __syncthreads();
     }
-    if (has_acc && wm * 64 >= p0 && wm * 64 < p0 + rows_per_pass) {
+    if (has_acc) {   // a wave's patch is MT x 32 rows from wm * MT * 32: the row tiles that lie in this pass take part
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
+      for (int mt = 0; mt < MT; ++mt)
+        if (wm * MT * 32 + mt * 32 >= p0 && wm * MT * 32 + mt * 32 < p0 + rows_per_pass)
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) {
           const int cl = wn * 64 + nt * 32 + l31;
@@ -148,7 +149,7 @@ __device__ __forceinline__ void gemm_epilogue_wide(const GemmArgs& g, const f32x
           const float bv = (!partial && bias && col < g.N) ? bias[col] : 0.0f;
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
-            const int rl = wm * 64 - p0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            const int rl = wm * MT * 32 - p0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
             float v = acc[mt][nt][r];
             if (!partial) {
               v += bv;
@@ -912,6 +913,269 @@ __global__ __launch_bounds__(1024, 4) void gemm_bf16x3_256_kernel(GemmArgs g) {
   else gemm_epilogue_n<256>(g, acc, m0, n0, wm, wn, l31, half, batch, split);
 }
 
+// ---------------------------------------------------------------------------------------------- bf16 x 3, 256 x 256, 8 wide waves
+// What idles the matrix pipe in the 16-wave kernel above is its phase structure: after the per-k-tile barrier every wave
+// first reads its 8 operand fragments from LDS (128 KB per CU and k-tile: ~1000 cycles of LDS bandwidth with the pipe idle),
+// then all issue their MFMAs (1536 cycles with LDS idle), then all convert and store: ~4400 cycles per k-tile against 1546
+// of MFMA time (35 % of peak), and with 128 VGPRs per wave there is no room to hold the next tile's fragments.
+// Here a workgroup is 8 waves (2 per SIMD, 256 VGPRs each) and a wave owns a 128 x 64 patch (4 x 2 tiles, 128 accumulator
+// registers): 12 fragment reads feed 24 MFMAs (0.5 instead of 0.67 LDS reads per MFMA, 96 KB per CU and k-tile), and the
+// reads run UNDER the MFMAs: the B fragments of k-tile t+1 are requested before the MFMAs of tile t start (double-buffered
+// registers), each A row-tile fragment of t+1 right after the six MFMAs that consumed its predecessor. That needs tile t+1
+// in LDS one barrier early, so the LDS image is triple-buffered (144 KB, one workgroup per CU): iteration t computes tile t
+// from registers, reads tile t+1 from buffer (t+1) % 3 and converts tile t+2 into buffer (t+2) % 3, one barrier per k-tile.
+// Global loads run four k-tiles ahead in two register sets. Same operand images and fragment reads as above (YStager
+// geometry for 512 threads: two float4 per thread, operand and k-tile).
+// MEASURED (tools/build_variants.sh + tools/gemm_probe.py, cond_transform product 14336 x 8192 x 890, MI355X): the schedule
+// comes out as written (fragment reads interleaved with the MFMAs, loads counted, no vmcnt(0)), and the kernel is NOT
+// faster than the 16-wave one: 0.82 ms either way in the probe. Removing one ingredient at a time: MFMAs -0.39 ms,
+// convert + LDS store -0.21, fragment reads -0.13, global loads -0.07, epilogue -0.15 - they add up to the kernel: nothing
+// overlaps. s_memtime stamps (-DY2_STAMPS): 2750 cycles per k-tile (MFMA phase ~1300-1550 with the SIMD's two waves
+// contending, staging ~700, barrier + loop top ~400) at an effective clock of ~1.63 GHz under this load (1.69 us per
+// k-tile), i.e. the matrix pipe's ceiling here is ~1.7 PFLOP/s, not the nominal 2.5. Running the two waves of a SIMD in
+// opposite phase (waves 4-7 stage first; -DY2_NO_SKEW restores lockstep) moves time from one wave's barrier wait to the
+// other's staging (1680 cycles while its partner streams MFMAs) and nets nothing, with or without s_setprio on the
+// staging half - the same zero-sum the microarchitecture notes report for two waves per SIMD. Kept opt-in
+// (LFI_GEMM_WIDE=1) as the base for the next step: operands pre-split to bf16 planes by their producers (no VALU in the
+// loop) and an epilogue that does not hold the CU (0.15 ms of this product).
+constexpr int Y2NT = 512;
+constexpr int Y2BUFS = 3;
+
+template <bool KC>
+struct Y2Stager {
+  int off[2], lds[2], kk[2];
+  __device__ __forceinline__ void init(int tid, int mn0, int MN, long ld) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      if (KC) {
+        const int k4 = (tid & 3) * 4, mn = (tid >> 2) + 128 * h;
+        kk[h] = k4;
+        off[h] = (min(mn0 + mn, MN - 1) - mn0) * (int)ld + k4;
+        lds[h] = mn * YROW + k4;
+      } else {
+        const int k = (tid >> 6) + 8 * h, mn4 = (tid & 63) * 4;
+        kk[h] = k;
+        off[h] = k * (int)ld + (mn0 + mn4 < MN ? mn4 : 0);
+        lds[h] = k * YPIT + mn4;
+      }
+    }
+  }
+  __device__ __forceinline__ void load_full(const float* __restrict__ p, f32x4 (&r)[2]) const {
+    r[0] = *reinterpret_cast<const f32x4*>(p + off[0]);
+    r[1] = *reinterpret_cast<const f32x4*>(p + off[1]);
+  }
+  __device__ __forceinline__ void load(const float* __restrict__ p, int krem, f32x4 (&r)[2]) const {
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      if (krem >= YBK) {
+        r[h] = *reinterpret_cast<const f32x4*>(p + off[h]);
+      } else {  // last, partial k-tile (or none at all: krem <= 0 gives zeros)
+        r[h] = kk[h] < krem ? *reinterpret_cast<const f32x4*>(p + off[h]) : z;
+        if (KC) {
+#pragma unroll
+          for (int j = 1; j < 4; ++j) r[h][j] = (kk[h] + j < krem) ? r[h][j] : 0.0f;
+        }
+      }
+    }
+  }
+  __device__ __forceinline__ void store(__bf16* hi_img, __bf16* lo_img, const f32x4 (&r)[2]) const {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      uint2 hh, ll;
+      split2(r[h][0], r[h][1], &hh.x, &ll.x);
+      split2(r[h][2], r[h][3], &hh.y, &ll.y);
+      *reinterpret_cast<uint2*>(hi_img + lds[h]) = hh;
+      *reinterpret_cast<uint2*>(lo_img + lds[h]) = ll;
+    }
+  }
+};
+
+template <bool AKC, bool BKC>
+__global__ __launch_bounds__(Y2NT) void gemm_bf16x3_256w_kernel(GemmArgs g) {
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, half = lane >> 5;
+  int tm, tn, batch, split;
+  gemm_tile_of_block(g, &tm, &tn, &batch, &split);
+  const int m0 = tm * 256, n0 = tn * 256;
+  const float* __restrict__ A = g.A + batch * g.strideA;
+  const float* __restrict__ B = g.B + batch * g.strideB;
+  const int kbeg = split * g.kchunk;
+  const int kend = min(g.K, kbeg + g.kchunk);
+  const int nkt = (kend - kbeg + YBK - 1) / YBK;
+  const int nfull = (kend - kbeg) / YBK;   // k-tiles that are complete
+
+  Y2Stager<AKC> sa;
+  Y2Stager<BKC> sb;
+  sa.init(tid, m0, g.M, g.lda);
+  sb.init(tid, n0, g.N, g.ldb);
+  const float* __restrict__ tA = AKC ? A + (long)m0 * g.lda + kbeg : A + (long)kbeg * g.lda + m0;
+  const float* __restrict__ tB = BKC ? B + (long)n0 * g.ldb + kbeg : B + (long)kbeg * g.ldb + n0;
+  const long stepA = AKC ? YBK : (long)YBK * g.lda, stepB = BKC ? YBK : (long)YBK * g.ldb;
+
+  f32x4 ra[2][2], rb[2][2];   // [register set][float4]
+  auto load_any = [&](int kt, f32x4 (&xa)[2], f32x4 (&xb)[2]) {   // any tile index: partial tiles masked, tiles past the end zero
+    const int krem = kend - (kbeg + kt * YBK);
+    sa.load(tA + kt * stepA, krem, xa);
+    sb.load(tB + kt * stepB, krem, xb);
+  };
+  auto store = [&](int buf, const f32x4 (&xa)[2], const f32x4 (&xb)[2]) {
+    __bf16* base = xsmem + buf * 4 * YIMG;
+    sa.store(base, base + YIMG, xa);
+    sb.store(base + 2 * YIMG, base + 3 * YIMG, xb);
+  };
+
+  const int wm = wave >> 2, wn = wave & 3;   // 2 x 4 waves, each 128 rows x 64 columns
+#ifdef Y2_NO_SKEW
+  const bool late = false;
+#else
+  const bool late = wave >= 4;               // waves w and w + 4 share a SIMD
+#endif
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+  bf16x8 ah[4], al[4], bh[2], bl[2], bhn[2], bln[2];
+  auto read_a = [&](int buf, int mt) {
+    const __bf16* base = xsmem + buf * 4 * YIMG;
+    ah[mt] = yfrag<AKC>(base, wm * 128 + mt * 32, lane);
+    al[mt] = yfrag<AKC>(base + YIMG, wm * 128 + mt * 32, lane);
+  };
+  auto read_b = [&](int buf, bf16x8 (&xh)[2], bf16x8 (&xl)[2]) {
+    const __bf16* base = xsmem + buf * 4 * YIMG;
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      xh[nt] = yfrag<BKC>(base + 2 * YIMG, wn * 64 + nt * 32, lane);
+      xl[nt] = yfrag<BKC>(base + 3 * YIMG, wn * 64 + nt * 32, lane);
+    }
+  };
+  auto mma_row = [&](int mt) {   // the six MFMAs of row tile mt, the two column tiles interleaved (dependent distance 2)
+#ifdef Y2_NO_MMA
+    return;
+#endif
+    acc[mt][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mt], bh[0], acc[mt][0], 0, 0, 0);
+    acc[mt][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mt], bh[1], acc[mt][1], 0, 0, 0);
+    acc[mt][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt], bl[0], acc[mt][0], 0, 0, 0);
+    acc[mt][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt], bl[1], acc[mt][1], 0, 0, 0);
+    acc[mt][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt], bh[0], acc[mt][0], 0, 0, 0);
+    acc[mt][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt], bh[1], acc[mt][1], 0, 0, 0);
+  };
+
+  // prologue: tiles 0 and 1 into LDS buffers 0 and 1, tiles 2 and 3 into the two register sets, fragments of tile 0
+  load_any(0, ra[0], rb[0]);
+  load_any(1, ra[1], rb[1]);
+  store(0, ra[0], rb[0]);
+  store(1, ra[1], rb[1]);
+  load_any(2, ra[0], rb[0]);
+  load_any(3, ra[1], rb[1]);
+  __syncthreads();
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) read_a(0, mt);
+  read_b(0, bh, bl);
+
+#ifdef Y2_STAMPS
+  unsigned long long st_acc[6] = {0, 0, 0, 0, 0, 0}, st_prev = __builtin_amdgcn_s_memtime();
+#define Y2_STAMP(i) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); st_acc[i] += now_ - st_prev; st_prev = now_; } while (0)
+#else
+#define Y2_STAMP(i)
+#endif
+  int cur = 0, nxt = 1, nn = 2;   // LDS buffers of tiles t, t + 1, t + 2
+  // one k-tile; STEADY: tile t + 4 is a complete tile (unconditional loads, so that s_waitcnt can count them)
+  auto iteration = [&](int t, f32x4 (&xa)[2], f32x4 (&xb)[2], bool steady) {
+    // The two waves of a SIMD run their halves of the iteration in opposite order: the first (waves 0-3) issues its 24 MFMAs,
+    // then converts and stores tile t + 2; the second (waves 4-7) converts first. So one wave's VALU / LDS-write work runs
+    // in the shadow of the other's MFMAs instead of both queueing on the matrix pipe and then both on the vector pipe
+    // (measured with the phases aligned: MFMA 0.39 + convert 0.21 + fragment reads 0.13 + loads 0.07 ms, summing to the
+    // kernel's 0.83 ms - no overlap at all).
+    auto stage = [&]() {
+#ifndef Y2_NO_CVT
+      store(nn, xa, xb);                       // tile t + 2 (zeros past the end) into the buffer tile t - 1 left
+#endif
+      if (steady) {
+#ifndef Y2_NO_GLOAD
+        sa.load_full(tA + (t + 4) * stepA, xa);
+        sb.load_full(tB + (t + 4) * stepB, xb);
+#endif
+      } else {
+        load_any(t + 4, xa, xb);
+      }
+    };
+    Y2_STAMP(0);
+#ifdef Y2_PRIO
+    if (late) { __builtin_amdgcn_s_setprio(Y2_PRIO); stage(); __builtin_amdgcn_s_setprio(0); }
+#else
+    if (late) stage();
+#endif
+    __builtin_amdgcn_sched_barrier(0);
+    Y2_STAMP(1);
+#ifndef Y2_NO_LDSREAD
+    read_b(nxt, bhn, bln);                     // tile t + 1 (garbage past the end: never used)
+#endif
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      mma_row(mt);
+      __builtin_amdgcn_sched_barrier(0);
+#ifndef Y2_NO_LDSREAD
+      read_a(nxt, mt);                         // this row tile's fragment of tile t + 1 replaces the one just consumed
+#endif
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    Y2_STAMP(2);
+    if (!late) stage();
+    Y2_STAMP(3);
+    __syncthreads();
+    Y2_STAMP(4);
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) { bh[nt] = bhn[nt]; bl[nt] = bln[nt]; }
+    const int f = cur; cur = nxt; nxt = nn; nn = f;
+  };
+  int t = 0;
+  for (; t + 5 < nfull; t += 2) {   // both tiles t + 4 and t + 5 complete
+    iteration(t, ra[0], rb[0], true);
+    iteration(t + 1, ra[1], rb[1], true);
+  }
+  for (; t < nkt; t += 2) {
+    iteration(t, ra[0], rb[0], false);
+    if (t + 1 < nkt) iteration(t + 1, ra[1], rb[1], false);
+  }
+  __syncthreads();
+  Y2_STAMP(5);
+#ifdef Y2_NO_EPI
+  {
+    float keep = 0.0f;   // keeps every accumulator alive
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) keep += acc[i][j][r];
+    if (keep == 123.456f) g.C[0] = 1.0f;
+  }
+  return;
+#endif
+  if (g.vecC) gemm_epilogue_wide<256, Y2NT, 4>(g, acc, reinterpret_cast<float*>(xsmem), 64, m0, n0, wm, wn, l31, half, batch, split, 256);
+  else {
+    // narrow path: the two 64-row halves of the patch through the register epilogue
+    const f32x16 (&lo2)[2][2] = *reinterpret_cast<const f32x16 (*)[2][2]>(&acc[0]);
+    const f32x16 (&hi2)[2][2] = *reinterpret_cast<const f32x16 (*)[2][2]>(&acc[2]);
+    gemm_epilogue_n<256>(g, lo2, m0, n0, wm * 2, wn, l31, half, batch, split);
+    gemm_epilogue_n<256>(g, hi2, m0, n0, wm * 2 + 1, wn, l31, half, batch, split);
+  }
+#ifdef Y2_STAMPS
+  __syncthreads();
+  if (blockIdx.x == 8 && blockIdx.y == 0 && blockIdx.z == 0 && lane == 0 && (wave == 0 || wave == 4)) {
+    Y2_STAMP(5);   // epilogue
+    for (int i = 0; i < 6; ++i) g.C[(wave ? 8 : 0) + i] = (float)st_acc[i];
+    g.C[(wave ? 8 : 0) + 6] = (float)nkt;
+  }
+#endif
+}
+
 __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(GemmArgs g) {
   const long mn = (long)g.M * g.N;
   const int batch = blockIdx.y;
@@ -1051,7 +1315,32 @@ extern "C" int lfi_gemm_f32(const lfi_gemm_desc* d, void* stream) {
   // floats past K (k-contiguous; zeroed before it reaches LDS) or past M/N (mn-contiguous; those LDS columns only feed
   // output rows/columns that are never stored) — see vec_ok above.)
   dim3 grid(a.tiles_m * a.tiles_n, d->batch, splitk);
-  if (use_x3 && shape == 3) {
+  // opt-in (LFI_GEMM_WIDE=1): the 8-wave / 128 x 64-patch variant is numerically identical and, as measured, no faster
+  // than the 16-wave kernel (0.75 vs 0.74 ms on the cond_transform product) - see the notes above gemm_bf16x3_256w_kernel
+  int use_wide = 0;
+  {
+    const char* e = getenv("LFI_GEMM_WIDE");
+    use_wide = (e && e[0] == '1') ? 1 : 0;
+  }
+  if (use_x3 && shape == 3 && use_wide) {
+    const size_t lds = (size_t)Y2BUFS * 4 * YIMG * sizeof(__bf16);
+    static bool attrw = false;
+    if (!attrw) {
+      hipError_t e1 = hipFuncSetAttribute((const void*)gemm_bf16x3_256w_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipError_t e2 = hipFuncSetAttribute((const void*)gemm_bf16x3_256w_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipError_t e3 = hipFuncSetAttribute((const void*)gemm_bf16x3_256w_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipError_t e4 = hipFuncSetAttribute((const void*)gemm_bf16x3_256w_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess) {
+        lfi_set_error("lfi_gemm_f32: cannot reserve %zu bytes of LDS for the wide-wave 256 x 256 bf16x3 kernel", lds);
+        return LFI_ERR_LAUNCH;
+      }
+      attrw = true;
+    }
+    if (d->a_kcontig && d->b_kcontig) hipLaunchKernelGGL((gemm_bf16x3_256w_kernel<true, true>), grid, dim3(Y2NT), lds, st, a);
+    else if (d->a_kcontig) hipLaunchKernelGGL((gemm_bf16x3_256w_kernel<true, false>), grid, dim3(Y2NT), lds, st, a);
+    else if (d->b_kcontig) hipLaunchKernelGGL((gemm_bf16x3_256w_kernel<false, true>), grid, dim3(Y2NT), lds, st, a);
+    else hipLaunchKernelGGL((gemm_bf16x3_256w_kernel<false, false>), grid, dim3(Y2NT), lds, st, a);
+  } else if (use_x3 && shape == 3) {
     const size_t lds = (size_t)2 * 4 * YIMG * sizeof(__bf16);
     static bool attr256 = false;
     if (!attr256) {

@@ -271,3 +271,32 @@ def test_adam_clip_step_matches_oracle(gpu_device):
     assert rel_err(e.params, ps[0]) < 1e-6
     e.grads.copy_(gr)
     assert abs(e.grad_norm() - float(gr.double().norm())) < 1e-6 * float(gr.double().norm())
+
+
+@pytest.mark.parametrize("akc,bkc", [(1, 1), (1, 0), (0, 1), (0, 0)])
+def test_wide_wave_256_tile_kernel(gpu_device, monkeypatch, akc, bkc):
+    """The opt-in 8-wave / 128 x 64-patch variant of the 256 x 256 bf16x3 kernel (LFI_GEMM_WIDE=1): same products as the
+    default kernel bit for bit (same operand images, same MFMA order per accumulator), ragged M / N / K, bias + LeakyReLU."""
+    from argparse import Namespace
+    from helpers import Fixture
+    from lets_face_it_amd.engine import GlowEngine, ModelSpec
+    eng = GlowEngine(ModelSpec(Namespace(**Fixture("tiny").hp)), gpu_device)
+    eng.precision = 1 | 0x10   # bf16x3, 256 x 256 tiles pinned
+    g = torch.Generator().manual_seed(1)
+    M, N, K = 600, 520, 1000
+    r16 = lambda v: (v + 15) // 16 * 16  # noqa: E731
+    lda, ldb = (r16(K) if akc else r16(M)), (r16(K) if bkc else r16(N))
+    A = torch.randn((M, lda) if akc else (K, lda), generator=g).to(gpu_device)
+    Bm = torch.randn((N, ldb) if bkc else (K, ldb), generator=g).to(gpu_device)
+    bias = torch.randn(N, generator=g).to(gpu_device)
+    outs = []
+    for wide in ("0", "1"):
+        monkeypatch.setenv("LFI_GEMM_WIDE", wide)
+        Cm = torch.zeros(M, N, device=gpu_device)
+        eng.gemm(M, N, K, A, lda, akc, Bm, ldb, bkc, Cm, N, bias=bias, act=1, slope=0.01)
+        outs.append(Cm)
+    a = (A[:, :K] if akc else A[:K, :M].t()).double()
+    b = (Bm[:, :K].t() if bkc else Bm[:K, :N]).double()
+    ref = torch.nn.functional.leaky_relu(a @ b + bias.double(), 0.01)
+    assert float((outs[1].double() - ref).abs().max() / ref.abs().max()) < 1e-5
+    assert torch.equal(outs[0], outs[1])

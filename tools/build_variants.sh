@@ -8,6 +8,6 @@ while [ $# -ge 2 ]; do
   name=$1; flags=$2; shift 2
   hipcc -O3 --offload-arch=gfx950 -fPIC -std=c++17 -I$ROOT/include $flags -c $ROOT/lets_face_it_amd/csrc/lfi_gemm.hip -o $ROOT/build/variants/gemm_$name.o
   hipcc --offload-arch=gfx950 -shared -fPIC -o $ROOT/build/variants/liblfi_$name.so $ROOT/build/variants/gemm_$name.o \
-     $ROOT/build/csrc/lfi_core.o $ROOT/build/csrc/lfi_encoder.o $ROOT/build/csrc/lfi_flow.o
+     $ROOT/build/csrc/lfi_core.o $ROOT/build/csrc/lfi_encoder.o $ROOT/build/csrc/lfi_flow.o $ROOT/build/csrc/lfi_data.o
   echo built $name
 done

@@ -50,6 +50,12 @@ def main():
         torch.cuda.synchronize()
         ms = s.elapsed_time(e) / args.reps
         print("%-11s M=%d N=%d K=%d akc=%d bkc=%d: %.3f ms  %.1f TFLOP/s" % (name, M, N, K, akc, bkc, ms, 2.0 * M * N * K / ms / 1e9))
+        if os.environ.get("LFI_GEMM_STAMPS"):   # -DY2_STAMPS build: per-phase s_memtime sums of waves 0 and 4 of workgroup 8
+            c = Cm.view(-1)[:16].cpu().tolist()
+            for w, v in ((0, c[:8]), (4, c[8:16])):
+                n = max(v[6], 1.0)
+                print("    wave %d, cycles per k-tile: top->stage(late) %.0f | stage(late) %.0f | mfma+frag reads %.0f | stage(early) %.0f | "
+                      "barrier %.0f | (epilogue total %.0f), k-tiles %d" % (w, v[0] / n, v[1] / n, v[2] / n, v[3] / n, v[4] / n, v[5], n))
 
 
 if __name__ == "__main__":
