@@ -271,8 +271,13 @@ __device__ __forceinline__ enc_rsrc enc_buf(const void* p, long bytes) {
 __device__ __forceinline__ float enc_ld(enc_rsrc r, unsigned voff, unsigned soff) {
   return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
 }
+// The stashes are written once and read by a much later kernel (BPTT, the weight-gradient GEMMs): non-temporal (aux 2), so
+// 1.5 GB of them per launch do not sweep the weights and the projected inputs out of L2.
+#ifndef LFI_ENC_ST_AUX
+#define LFI_ENC_ST_AUX 2
+#endif
 __device__ __forceinline__ void enc_st(float v, enc_rsrc r, unsigned voff, unsigned soff) {
-  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, voff, soff, 0);
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), r, voff, soff, LFI_ENC_ST_AUX);
 }
 
 template <bool STASH, bool MASK, bool X3>
