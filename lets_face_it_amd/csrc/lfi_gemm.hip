@@ -170,7 +170,14 @@ __device__ __forceinline__ void gemm_epilogue_wide(const GemmArgs& g, const f32x
         const f32x4 v = *reinterpret_cast<const f32x4*>(lds + r * WLD + c4);
         // written once, read by a later kernel: non-temporal, so the result tile does not push the operand panels the other
         // workgroups are re-reading out of L2 (measured -1.5 .. -2 % on the three cond_transform products)
-        if (col_g + 3 < g.N) __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(Cb + (long)row * ldc + col_g));
+        // (split-K partial sums are read back at once by the reduce kernel: those stay cacheable)
+        if (col_g + 3 < g.N) {
+#ifndef LFI_EPI_NT_MODE
+#define LFI_EPI_NT_MODE 2   // 0 never, 1 always, 2 final results only
+#endif
+          if (LFI_EPI_NT_MODE == 0 || (LFI_EPI_NT_MODE == 2 && partial)) *reinterpret_cast<f32x4*>(Cb + (long)row * ldc + col_g) = v;
+          else __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(Cb + (long)row * ldc + col_g));
+        }
         else
           for (int j = 0; j < 4; ++j)
             if (col_g + j < g.N) Cb[(long)row * ldc + col_g + j] = v[j];
