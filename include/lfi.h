@@ -90,6 +90,8 @@ typedef struct {
   int precision;        /* lfi_gemm_desc.precision of the per-step recurrent GEMMs */
   int dup;              /* 1: write the state twice, columns [col, col+hid) and [col+hid, col+2*hid) as the reference's
                            cat(seq[:, -1], h_n[0]) does; 0: once (folded feature layout, see lfi_cols_fold) */
+  int lstm;             /* 1: "enc: lstm" (nn.LSTM from zero (h, c), gate blocks i, f, g, o; glow/models.py:27-33,65-69): every
+                           "3*hid" below reads 4*hid, the gate stash row is 5*hid (i, f, g, o, c) and is required, dgi = dgh */
 } lfi_enc_desc;
 
 long lfi_encode_windows_work_floats(const lfi_enc_desc* d);

@@ -18,6 +18,7 @@ namespace {
 
 struct EncArgs {
   int B, T, N, start, hist, hid, ldcond, col, dup;
+  int lstm, G;         // LSTM window encoder (gate blocks i, f, g, o); G = (lstm ? 4 : 3) * hid
   int F;
   const float* Xp;     // (B*T) x 3hid
   const float* b_ih;
@@ -108,12 +109,83 @@ __global__ __launch_bounds__(256) void enc_gate_bwd_kernel(EncArgs a, int s, con
   }
 }
 
+// ---- "enc: lstm" modality (glow/models.py:27-33,65-69): nn.LSTM from zero (h, c) over the window, gate blocks i, f, g, o
+// (torch.nn.LSTM weight layout). Per step one GEMM gh = h_{s-1} W_hh^T (F x 4hid) + this kernel. The stash row of a
+// (step, window) is 5 * hid floats: i, f, g, o, c_s.
+__global__ __launch_bounds__(256) void enc_lstm_gate_fwd_kernel(EncArgs a, int s, const float* __restrict__ gh) {
+  const int hid = a.hid, G = 4 * hid;
+  const long total = (long)a.F * hid;
+  const int pos0 = a.start - a.hist + 1;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const int w = (int)(idx / hid), j = (int)(idx - (long)w * hid);
+    const int n = w / a.B, b = w - n * a.B;
+    const float* xp = a.Xp + ((long)b * a.T + (pos0 + n + s)) * G;
+    const float mk = a.mask ? a.mask[(long)w * a.hist + s] : 1.0f;
+    float pre[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) pre[q] = mk * xp[q * hid + j] + a.b_ih[q * hid + j] + a.b_hh[q * hid + j];
+    float cp = 0.0f;
+    if (gh) {
+      const float* g = gh + (long)w * G;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) pre[q] += g[q * hid + j];
+      cp = a.gates[(((long)(s - 1) * a.F + w) * 5 + 4) * hid + j];
+    }
+    const float ii = sigmoidf_(pre[0]), ff = sigmoidf_(pre[1]), gg = tanhf_(pre[2]), oo = sigmoidf_(pre[3]);
+    const float c = ff * cp + ii * gg;
+    const float hnew = oo * tanhf_(c);
+    const long sw = (long)s * a.F + w;
+    a.hseq[sw * hid + j] = hnew;
+    float* gs = a.gates + sw * 5 * hid;
+    gs[j] = ii; gs[hid + j] = ff; gs[2 * hid + j] = gg; gs[3 * hid + j] = oo; gs[4 * hid + j] = c;
+    if (s == a.hist - 1) {  // cat(seq[:, -1], h_n[0]): the same vector twice (glow/models.py:68-69)
+      float* cc = a.cond + (long)w * a.ldcond + a.col;
+      cc[j] = hnew;
+      if (a.dup) cc[hid + j] = hnew;
+    }
+  }
+}
+
+// Gate derivatives of LSTM step s. dh_in / dc_in: F x hid gradients w.r.t. h_s / c_s carried from step s + 1 (null at the last
+// step: d h from dcond, d c = 0). Writes dgi[s] = dgh[s] (the pre-activation is a plain sum of both sides), the carried d c
+// and zeroes dh_out, onto which the GEMM dgh_s W_hh then accumulates d h_{s-1}.
+__global__ __launch_bounds__(256) void enc_lstm_gate_bwd_kernel(EncArgs a, int s, const float* __restrict__ dh_in,
+                                                                const float* __restrict__ dc_in, float* __restrict__ dh_out,
+                                                                float* __restrict__ dc_out) {
+  const int hid = a.hid, G = 4 * hid;
+  const long total = (long)a.F * hid;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    const int w = (int)(idx / hid), j = (int)(idx - (long)w * hid);
+    float dhn;
+    if (dh_in) dhn = dh_in[idx];
+    else {
+      const float* dc = a.dcond + (long)w * a.lddcond + a.col;
+      dhn = a.dup ? dc[j] + dc[hid + j] : dc[j];
+    }
+    const long sw = (long)s * a.F + w;
+    const float* gs = a.gates + sw * 5 * hid;
+    const float ii = gs[j], ff = gs[hid + j], gg = gs[2 * hid + j], oo = gs[3 * hid + j], c = gs[4 * hid + j];
+    const float cp = s > 0 ? a.gates[(((long)(s - 1) * a.F + w) * 5 + 4) * hid + j] : 0.0f;
+    const float tc = tanhf_(c);
+    const float dc = dhn * oo * (1.0f - tc * tc) + (dc_in ? dc_in[idx] : 0.0f);
+    const float d0 = dc * gg * ii * (1.0f - ii);
+    const float d1 = dc * cp * ff * (1.0f - ff);
+    const float d2 = dc * ii * (1.0f - gg * gg);
+    const float d3 = dhn * tc * oo * (1.0f - oo);
+    float* gi = a.dgi + sw * G;
+    float* gh = a.dgh + sw * G;
+    gi[j] = d0; gi[hid + j] = d1; gi[2 * hid + j] = d2; gi[3 * hid + j] = d3;
+    gh[j] = d0; gh[hid + j] = d1; gh[2 * hid + j] = d2; gh[3 * hid + j] = d3;
+    if (dh_out) { dh_out[idx] = 0.0f; dc_out[idx] = dc * ff; }
+  }
+}
+
 // dXp[b*T + p][c] = sum_{s} mask[w(n,b)][s] * dgi[s][w][c],  n = p - pos0 - s in [0, N)
 // One workgroup per frame row; every (step, window) row of dgi is read exactly once over the grid (HBM-bound stream).
 // Branch-free: steps whose window falls outside [0, N) read row 0 with weight 0, so eight 16-byte loads per thread are
 // in flight at a time.
 __global__ __launch_bounds__(256) void enc_scatter_kernel(EncArgs a, float* __restrict__ dXp) {
-  const int G3 = 3 * a.hid;
+  const int G3 = a.G;   // 3 * hid (GRU) or 4 * hid (LSTM)
   const int row = blockIdx.x;  // b*T + p
   const int b = row / a.T, p = row - b * a.T;
   const int pos0 = a.start - a.hist + 1;
@@ -768,6 +840,7 @@ int fill_args(const lfi_enc_desc* d, EncArgs* a, const char* who) {
   LFI_REQUIRE(d->hist <= d->start + 1, "%s: window longer than start+1", who);
   a->B = d->B; a->T = d->T; a->N = d->N; a->start = d->start; a->hist = d->hist; a->hid = d->hid;
   a->ldcond = d->ldcond; a->col = d->col; a->dup = d->dup;
+  a->lstm = d->lstm ? 1 : 0; a->G = (d->lstm ? 4 : 3) * d->hid;
   a->F = d->N * d->B;
   return LFI_OK;
 }
@@ -778,7 +851,7 @@ int ew_blocks(long total) { return (int)(lfi_cdiv(total, 256) < 4096 ? lfi_cdiv(
 
 extern "C" long lfi_encode_windows_work_floats(const lfi_enc_desc* d) {
   if (!d) return 0;
-  const long unfused = (long)d->N * d->B * 3 * d->hid;  // fwd: gh (F x 3hid); bwd: two F x hid gradient buffers
+  const long unfused = (long)d->N * d->B * (d->lstm ? 4 : 3) * d->hid;  // fwd: gh (F x G); bwd: two (LSTM: four) F x hid buffers
   const long fused = 3L * 256 * 256;                    // fused path: zero-padded weight image
   return unfused > fused ? unfused : fused;
 }
@@ -794,6 +867,23 @@ extern "C" int lfi_encode_windows_fwd(const lfi_enc_desc* d, const float* Xp, co
   a.stamps = g_lfi_stamps;
   hipStream_t st = (hipStream_t)stream;
   const int hid = d->hid, F = a.F;
+  if (d->lstm) {   // "enc: lstm": one GEMM + one gate kernel per history step (in no shipped hparams file: not fused)
+    LFI_REQUIRE(gates && hseq, "lfi_encode_windows_fwd: the LSTM encoder keeps its cell state in the gate stash (5 * hid per row)");
+    const int blocks = ew_blocks((long)F * hid);
+    for (int s = 0; s < d->hist; ++s) {
+      if (s > 0) {
+        lfi_gemm_desc g = {};
+        g.M = F; g.N = 4 * hid; g.K = hid; g.batch = 1;
+        g.A = hseq + (long)(s - 1) * F * hid; g.lda = hid; g.a_kcontig = 1;
+        g.B = whh; g.ldb = hid; g.b_kcontig = 1;
+        g.C = work; g.ldc = 4 * hid; g.precision = d->precision;
+        if ((rc = lfi_gemm_f32(&g, stream))) return rc;
+      }
+      hipLaunchKernelGGL(enc_lstm_gate_fwd_kernel, dim3(blocks), dim3(256), 0, st, a, s, s > 0 ? work : nullptr);
+    }
+    LFI_LAUNCH_CHECK("lfi_encode_windows_fwd (lstm)");
+    return LFI_OK;
+  }
   EncFused q = {};
   if (enc_fused_shape(hid, &q)) {
     LFI_REQUIRE(!gates || hseq, "lfi_encode_windows_fwd: the gate stash needs the state stash too");
@@ -848,7 +938,7 @@ extern "C" int lfi_encode_windows_fwd(const lfi_enc_desc* d, const float* Xp, co
 
 extern "C" long lfi_encode_windows_bias_rows(const lfi_enc_desc* d) {
   EncFused q = {};
-  if (!d || !enc_fused_shape(d->hid, &q)) return 0;
+  if (!d || d->lstm || !enc_fused_shape(d->hid, &q)) return 0;
   return (long)lfi_cdiv((long)d->N * d->B, q.R) * (4 / q.ncg);
 }
 
@@ -863,6 +953,28 @@ extern "C" int lfi_encode_windows_bwd(const lfi_enc_desc* d, const float* dcond,
   a.bias_part = bias_part;
   hipStream_t st = (hipStream_t)stream;
   const int hid = d->hid, F = a.F;
+  if (d->lstm) {
+    const int blocks = ew_blocks((long)F * hid);
+    float* dhb[2] = {work, work + (long)F * hid};
+    float* dcb[2] = {work + 2L * F * hid, work + 3L * F * hid};
+    const float *dh_in = nullptr, *dc_in = nullptr;
+    for (int s = d->hist - 1; s >= 0; --s) {
+      float* dh_out = s > 0 ? dhb[s & 1] : nullptr;
+      float* dc_out = s > 0 ? dcb[s & 1] : nullptr;
+      hipLaunchKernelGGL(enc_lstm_gate_bwd_kernel, dim3(blocks), dim3(256), 0, st, a, s, dh_in, dc_in, dh_out, dc_out);
+      if (s > 0) {
+        lfi_gemm_desc g = {};
+        g.M = F; g.N = hid; g.K = 4 * hid; g.batch = 1;
+        g.A = dgh + (long)s * F * 4 * hid; g.lda = 4 * hid; g.a_kcontig = 1;
+        g.B = whh; g.ldb = hid; g.b_kcontig = 0;
+        g.C = dh_out; g.ldc = hid; g.accumulate = 1; g.precision = d->precision;
+        if ((rc = lfi_gemm_f32(&g, stream))) return rc;
+      }
+      dh_in = dh_out; dc_in = dc_out;
+    }
+    LFI_LAUNCH_CHECK("lfi_encode_windows_bwd (lstm)");
+    return LFI_OK;
+  }
   EncFused q = {};
   if (enc_fused_shape(hid, &q)) {
     const bool x3 = d->precision == 1;

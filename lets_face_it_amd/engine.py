@@ -37,7 +37,8 @@ class EncoderSpec:
 
     def __init__(self, name, enc, in_dim, hist, hid, dropout):
         self.name, self.enc, self.in_dim, self.hist, self.hid, self.dropout = name, enc, in_dim, hist, hid, dropout
-        if enc == "rnn":
+        self.ng = 4 if enc == "lstm" else 3   # gate blocks of the recurrent window encoders (nn.LSTM: i, f, g, o)
+        if enc in ("rnn", "lstm"):       # nn.GRU / nn.LSTM: cat(seq[:, -1], h_n[0]), the same vector twice (models.py:60-69)
             self.dim = 2 * hid
         elif enc == "mlp":
             self.dim = hid
@@ -47,9 +48,8 @@ class EncoderSpec:
             self.dim = 1
         else:
             raise NotImplementedError(
-                "encoder type %r for %s: 'rnn' (GRU), 'mlp' and 'none' have HIP kernels in this build ('lstm' is in no "
-                "shipped hparams file nor in the hparam search space; 'cnn' has a broken output size in the reference, "
-                "models.py:48)" % (enc, name))
+                "encoder type %r for %s: 'rnn' (GRU), 'lstm', 'mlp' and 'none' have HIP kernels in this build ('cnn' has a "
+                "broken output size in the reference, models.py:48)" % (enc, name))
         self.col = 0
         self.win = (in_dim * hist + 3) // 4 * 4  # row stride of the flattened-window matrix of an mlp encoder
 
@@ -110,10 +110,10 @@ class ModelSpec:
                 self.fold_b.append(-1)
                 fcol += 1
             e.fcol = fcol
-            e.fdim = e.hid if e.enc == "rnn" else e.dim
+            e.fdim = e.hid if e.enc in ("rnn", "lstm") else e.dim
             for j in range(e.fdim):
                 self.fold_a.append(e.col + j)
-                self.fold_b.append(e.col + e.hid + j if e.enc == "rnn" else -1)
+                self.fold_b.append(e.col + e.hid + j if e.enc in ("rnn", "lstm") else -1)
             self.unfold += [fcol + (j % e.fdim) for j in range(e.dim)]
             fcol += e.fdim
         self.Ef = fcol
@@ -170,8 +170,9 @@ class GlowEngine:
         self.layout = {}  # name -> (offset, shape)
         off = 0
         for e in spec.encoders:
-            if e.enc == "rnn":
-                for leaf, shape in zip(ENC_LEAVES, ((3 * e.hid, e.in_dim), (3 * e.hid, e.hid), (3 * e.hid,), (3 * e.hid,))):
+            if e.enc in ("rnn", "lstm"):
+                g = e.ng * e.hid
+                for leaf, shape in zip(ENC_LEAVES, ((g, e.in_dim), (g, e.hid), (g,), (g,))):
                     self.layout["enc.%s.%s" % (e.name, leaf)] = (off, shape)
                     off += math.prod(shape)
             elif e.enc == "mlp":
@@ -407,12 +408,14 @@ class GlowEngine:
                           c_off=e.fcol)
                 continue
             # input projection hoisted over the B*Tx distinct frames (no bias: it is added after the dropout mask)
-            xp = self._buf("xp." + e.name, B * Tx * 3 * hid)
-            self.gemm(B * Tx, 3 * hid, e.in_dim, x, e.in_dim, 1, self.view("enc.%s.weight_ih" % e.name), e.in_dim, 1,
-                      xp, 3 * hid)
-            gates = self._buf("enc_gates." + e.name, e.hist * F * 4 * hid) if with_stash else None
+            lstm = e.enc == "lstm"
+            G = e.ng * hid
+            xp = self._buf("xp." + e.name, B * Tx * G)
+            self.gemm(B * Tx, G, e.in_dim, x, e.in_dim, 1, self.view("enc.%s.weight_ih" % e.name), e.in_dim, 1, xp, G)
+            # gate stash: r, z, n, W_hn h + b_hn (GRU; only kept for a backward pass) / i, f, g, o, c (LSTM: it is the cell state)
+            gates = self._buf("enc_gates." + e.name, e.hist * F * (5 if lstm else 4) * hid) if (with_stash or lstm) else None
             hseq = self._buf("enc_hseq." + e.name, e.hist * F * hid)
-            d = EncDesc(B, Tx, N, start - 1 + incl, e.hist, hid, s.ldf, e.fcol, self.precision, 0)
+            d = EncDesc(B, Tx, N, start - 1 + incl, e.hist, hid, s.ldf, e.fcol, self.precision, 0, 1 if lstm else 0)
             work = self._buf("scratch.enc", self.L.lfi_encode_windows_work_floats(C.byref(d)))
             check(self.L.lfi_encode_windows_fwd(
                 C.byref(d), xp.data_ptr(), self.view("enc.%s.weight_hh" % e.name).data_ptr(),
@@ -524,7 +527,7 @@ class GlowEngine:
         if after_flow is not None:
             after_flow()
         # gradient of the feature matrix, columns of the trainable encoders only (raw windows are data)
-        rnn = [e for e in s.encoders if e.enc in ("rnn", "mlp")]
+        rnn = [e for e in s.encoders if e.enc in ("rnn", "lstm", "mlp")]
         if rnn:
             col0 = min(e.fcol for e in rnn)
             W = s.Ef - col0
@@ -556,9 +559,10 @@ class GlowEngine:
         s = self.spec
         B, N, F = ctx.B, ctx.N, ctx.F
         x = ctx.batch[e.name]
-        Tx, hid, G3 = x.shape[1], e.hid, 3 * e.hid
+        Tx, hid, G3 = x.shape[1], e.hid, e.ng * e.hid
         st = _stream()
-        d = EncDesc(B, Tx, N, s.start - (1 if e.name == "p1_face" else 0), e.hist, hid, lddcond, col, self.precision, 0)
+        d = EncDesc(B, Tx, N, s.start - (1 if e.name == "p1_face" else 0), e.hist, hid, lddcond, col, self.precision, 0,
+                    1 if e.enc == "lstm" else 0)
         gates = self._ws["enc_gates." + e.name]
         hseq = self._ws["enc_hseq." + e.name]
         dgi = self._buf("enc_dgi." + e.name, e.hist * F * G3)
@@ -731,6 +735,10 @@ class GlowEngine:
         hist1 = e1.hist
         # an encoded prev_p1_face window (enc: mlp / rnn) is re-encoded for every generated frame inside the sampler
         p1 = P1Enc()
+        if e1.enc == "lstm":
+            raise NotImplementedError("sampling with an LSTM-encoded prev_p1_face window: the per-frame re-encoding inside the "
+                                      "sampler covers enc 'none', 'mlp' and 'rnn' (the hparam search space, "
+                                      "hparam_tuning_configs/large_hparam_search.py:45-62)")
         p1.kind, p1.hid, p1.col = {"none": 0, "mlp": 1, "rnn": 2}[e1.enc], e1.hid, e1.fcol
         if e1.enc == "mlp":
             p1.w1, p1.b1 = self.view("enc.p1_face.mlp_weight").data_ptr(), self.view("enc.p1_face.mlp_bias").data_ptr()

@@ -386,8 +386,8 @@ class SeqGlow(nn.Module):
         out = []
         fe = self.feature_encoder
         for e in self.spec.encoders:
-            if e.enc == "rnn":
-                gru = getattr(fe, e.name + "_encoder").encoder
+            if e.enc in ("rnn", "lstm"):
+                gru = getattr(fe, e.name + "_encoder").encoder   # nn.GRU / nn.LSTM: same leaf names
                 for leaf in _engine.ENC_LEAVES:
                     out.append(("enc.%s.%s" % (e.name, leaf), None, getattr(gru, leaf + "_l0")))
             elif e.enc == "mlp":

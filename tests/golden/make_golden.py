@@ -108,6 +108,17 @@ def make_config(name):
             c["p2_face"].update(history=4, dim=16, hidden_dim=24)
             c["p1_speech"].update(history=2, hidden_dim=16, enc="mlp")
             c["p2_speech"].update(history=3, hidden_dim=20, enc="none")
+    elif name == "lstmenc":
+        # "enc: lstm" window encoders (ModalityEncoder's nn.LSTM branch, models.py:27-33,65-69), with dropout on one of them
+        c["cond_dim"] = 32
+        hp["Data"]["speech_dim"] = 8
+        g.update(K=2, L=1, hidden_channels=32)
+        hp["Train"]["seq_len"] = 20
+        dims = dict(B=4, T=20)
+        c["p1_face"].update(history=3, dim=16)
+        c["p2_face"].update(history=5, dim=16, hidden_dim=24, enc="lstm")
+        c["p1_speech"].update(history=2, hidden_dim=16)
+        c["p2_speech"].update(history=4, hidden_dim=20, enc="lstm")
     elif name == "p1mlp":
         c["cond_dim"] = 32
         hp["Data"]["speech_dim"] = 8
@@ -376,7 +387,7 @@ def main():
     from oracle import seqglow_oracle as oracle
     models, modules, utils = import_reference()
     lstm_shim(models)
-    names = sys.argv[1:] or ("tiny", "tiny_lstm", "tiny_additive", "odd", "mid", "mlp", "p1enc", "p1mlp", "framenb")
+    names = sys.argv[1:] or ("tiny", "tiny_lstm", "tiny_additive", "odd", "mid", "mlp", "p1enc", "p1mlp", "framenb", "lstmenc")
     for name in names:
         out = build(name, models, modules, oracle)
         path = os.path.join(HERE, name + ".npz")

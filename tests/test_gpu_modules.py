@@ -127,7 +127,7 @@ def test_actnorm_init_through_module_call(gpu_device):
     assert rel_err(a0.logs.view(-1), torch.log(1.0 / (var.sqrt() + 1e-6))) < 1e-5
 
 
-@pytest.mark.parametrize("name", ["tiny", "tiny_lstm", "odd", "p1enc", "mlp", "framenb"])
+@pytest.mark.parametrize("name", ["tiny", "tiny_lstm", "odd", "p1enc", "mlp", "framenb", "lstmenc"])
 def test_per_timestep_loop_matches_reference(gpu_device, name):
     """The reference's own loop body (SeqGlow.forward, models.py:546-559; invert, :630-641), one timestep per call."""
     from lets_face_it_amd.glow.models import SeqGlow
