@@ -742,9 +742,99 @@ __device__ __forceinline__ void load_frag(f32x4 (&w)[MAXB], const float* __restr
     if (on && b < nb) w[b] = p[(long)b * 4 * J];
 }
 
+// ---- bf16 x 3 form of the recurrent products (persistent walk, engine_precision bf16x3). The f32-input MFMA the cells use
+// everywhere else runs at 1/16 of the bf16 rate, and with flow step k's weights resident the recurrent cell's
+// (z1, h) x (W_ih[:, :Ch], W_hh) product is what a pipeline step waits for (46 % of a forward step, tools/pipe_stamps.py).
+// Same split as the GEMMs: x = hi + lo in bf16, hi*hi + hi*lo + lo*hi on v_mfma_f32_16x16x32_bf16 into fp32 accumulators.
+// No new weight images: two consecutive 16-k blocks of the f32 fragment registers (components e: k = 16 b + 4 e + kq) are
+// split in registers once per launch into one 32-k bf16 fragment, slot i of lane group kq standing for
+// k = 32 B + 16 (i >> 2) + 4 (i & 3) + kq - any bijection does as long as the A operand uses the same one, and this one
+// makes the A side exactly the LDS reads the f32 path already does.
+typedef __bf16 fbf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 fbf16x2 __attribute__((ext_vector_type(2)));
+typedef float ffloat2 __attribute__((ext_vector_type(2)));
+struct X3Frag { fbf16x8 hi, lo; };
+__device__ __forceinline__ void x3_split2(float a, float b, unsigned* hi, unsigned* lo) {
+  const fbf16x2 h = __builtin_convertvector((ffloat2){a, b}, fbf16x2);
+  const unsigned hb = __builtin_bit_cast(unsigned, h);
+  const float ha = __builtin_bit_cast(float, hb << 16), hbv = __builtin_bit_cast(float, hb & 0xffff0000u);
+  const fbf16x2 l = __builtin_convertvector((ffloat2){a - ha, b - hbv}, fbf16x2);
+  *hi = hb;
+  *lo = __builtin_bit_cast(unsigned, l);
+}
+__device__ __forceinline__ X3Frag x3_pack(const f32x4& b0, const f32x4& b1) {
+  uint4 h, l;
+  x3_split2(b0[0], b0[1], &h.x, &l.x);
+  x3_split2(b0[2], b0[3], &h.y, &l.y);
+  x3_split2(b1[0], b1[1], &h.z, &l.z);
+  x3_split2(b1[2], b1[3], &h.w, &l.w);
+  X3Frag r;
+  r.hi = __builtin_bit_cast(fbf16x8, h);
+  r.lo = __builtin_bit_cast(fbf16x8, l);
+  return r;
+}
+// A fragment of 32 k from a k-major LDS operand: the eight reads of two f32 blocks
+__device__ __forceinline__ X3Frag x3_a(const float* ab) {
+  f32x4 b0 = {ab[0], ab[4 * LT], ab[8 * LT], ab[12 * LT]};
+  const float* a1 = ab + 16 * LT;
+  f32x4 b1 = {a1[0], a1[4 * LT], a1[8 * LT], a1[12 * LT]};
+  return x3_pack(b0, b1);
+}
+__device__ __forceinline__ f32x4 x3_mma(const X3Frag& a, const X3Frag& w, f32x4 acc) {
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.lo, w.hi, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.hi, w.lo, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.hi, w.hi, acc, 0, 0, 0);
+  return acc;
+}
+
 // P2 of a register-resident cell: the coupling net's recurrent cell on this wave's 16 hidden units. Zt / Ht: z1 and
 // h_prev in LDS (k-major), Hn: new state (LDS), h_out / c_out / g_out: row-0 pointers of the (rows x H) / (rows x 4H) outputs
 // (g_out may be null).
+// gate math + stores of P2 on this wave's 16 hidden units, given the two accumulated products (az: z1 side, ah: h side)
+template <int NG>
+__device__ __forceinline__ void fast_cell_p2_gates(const FlowK& f, const float* Ht, float* Hn, const f32x4 (&az)[NG],
+                                                   const f32x4 (&ah)[NG], const float (&gc)[4][NG], const float (&bh)[NG],
+                                                   const float (&cprev)[4], int j2, int kq, int b0, int rows, float* h_out,
+                                                   float* c_out, float* g_out, float* cnew) {
+  const int H = f.H;
+  if (j2 < H) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int i = kq * 4 + r;
+      const int row = b0 + i;
+      float hnew;
+      float gs0, gs1, gs2, gs3;
+      if (NG == 3) {  // torch.nn.GRUCell, gate order r, z, n
+        const float rr = sigmoidf_(az[0][r] + ah[0][r] + gc[r][0] + bh[0]);
+        const float uu = sigmoidf_(az[1][r] + ah[1][r] + gc[r][1] + bh[1]);
+        const float ghn = ah[2][r] + bh[2];
+        const float nn = tanhf_(az[2][r] + gc[r][2] + rr * ghn);
+        const float hp = Ht[j2 * LT + i];
+        hnew = (1.0f - uu) * nn + uu * hp;
+        gs0 = rr; gs1 = uu; gs2 = nn; gs3 = ghn;
+      } else {        // torch.nn.LSTMCell, gate order i, f, g, o; zero (h, c) at the first modelled frame
+        const float ii = sigmoidf_(az[0][r] + ah[0][r] + gc[r][0] + bh[0]);
+        const float ff = sigmoidf_(az[1][r] + ah[1][r] + gc[r][1] + bh[1]);
+        const float gg = tanhf_(az[2][r] + ah[2][r] + gc[r][2] + bh[2]);
+        const float oo = sigmoidf_(az[NG - 1][r] + ah[NG - 1][r] + gc[r][NG - 1] + bh[NG - 1]);
+        const float c2 = ff * cprev[r] + ii * gg;
+        hnew = oo * tanhf_(c2);
+        if (row < rows) c_out[(long)row * H + j2] = c2;
+        if (cnew) cnew[r] = c2;
+        gs0 = ii; gs1 = ff; gs2 = gg; gs3 = oo;
+      }
+      Hn[j2 * LT + i] = hnew;
+      if (row < rows) {
+        h_out[(long)row * H + j2] = hnew;
+        if (g_out) {
+          float* gs = g_out + (long)row * 4 * H + j2;
+          gs[0] = gs0; gs[H] = gs1; gs[2 * H] = gs2; gs[3 * H] = gs3;
+        }
+      }
+    }
+  }
+}
+
 template <int NG>
 __device__ __forceinline__ void fast_cell_p2(const FlowK& f, const float* Zt, const float* Ht, float* Hn,
                                              const f32x4 (&wz)[NG][FB_Z], const f32x4 (&wh)[NG][FB_H], const float (&gc)[4][NG],
@@ -788,42 +878,39 @@ __device__ __forceinline__ void fast_cell_p2(const FlowK& f, const float* Zt, co
 #pragma unroll
       for (int g = 0; g < NG; ++g) ah[g] = mfma16(a3, wh[g][b][3], ah[g]);
     }
-  if (j2 < H) {
+  fast_cell_p2_gates<NG>(f, Ht, Hn, az, ah, gc, bh, cprev, j2, kq, b0, rows, h_out, c_out, g_out, cnew);
+}
+
+// bf16 x 3 form: weights as packed 32-k fragments (x3_pack), nbZ2 / nbH2 = number of 32-k blocks
+template <int NG>
+__device__ __forceinline__ void fast_cell_p2_x3(const FlowK& f, const float* Zt, const float* Ht, float* Hn,
+                                                const X3Frag (&wz)[NG][FB_Z / 2], const X3Frag (&wh)[NG][FB_H / 2],
+                                                const float (&gc)[4][NG], const float (&bh)[NG], const float (&cprev)[4], int nbZ2,
+                                                int nbH2, int j2, int kq, int l15, int b0, int rows, float* h_out, float* c_out,
+                                                float* g_out, float* cnew) {
+  f32x4 az[NG], ah[NG];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int i = kq * 4 + r;
-      const int row = b0 + i;
-      float hnew;
-      float gs0, gs1, gs2, gs3;
-      if (NG == 3) {  // torch.nn.GRUCell, gate order r, z, n
-        const float rr = sigmoidf_(az[0][r] + ah[0][r] + gc[r][0] + bh[0]);
-        const float uu = sigmoidf_(az[1][r] + ah[1][r] + gc[r][1] + bh[1]);
-        const float ghn = ah[2][r] + bh[2];
-        const float nn = tanhf_(az[2][r] + gc[r][2] + rr * ghn);
-        const float hp = Ht[j2 * LT + i];
-        hnew = (1.0f - uu) * nn + uu * hp;
-        gs0 = rr; gs1 = uu; gs2 = nn; gs3 = ghn;
-      } else {        // torch.nn.LSTMCell, gate order i, f, g, o; zero (h, c) at the first modelled frame
-        const float ii = sigmoidf_(az[0][r] + ah[0][r] + gc[r][0] + bh[0]);
-        const float ff = sigmoidf_(az[1][r] + ah[1][r] + gc[r][1] + bh[1]);
-        const float gg = tanhf_(az[2][r] + ah[2][r] + gc[r][2] + bh[2]);
-        const float oo = sigmoidf_(az[NG - 1][r] + ah[NG - 1][r] + gc[r][NG - 1] + bh[NG - 1]);
-        const float c2 = ff * cprev[r] + ii * gg;
-        hnew = oo * tanhf_(c2);
-        if (row < rows) c_out[(long)row * H + j2] = c2;
-        if (cnew) cnew[r] = c2;
-        gs0 = ii; gs1 = ff; gs2 = gg; gs3 = oo;
-      }
-      Hn[j2 * LT + i] = hnew;
-      if (row < rows) {
-        h_out[(long)row * H + j2] = hnew;
-        if (g_out) {
-          float* gs = g_out + (long)row * 4 * H + j2;
-          gs[0] = gs0; gs[H] = gs1; gs[2 * H] = gs2; gs[3 * H] = gs3;
-        }
-      }
-    }
+  for (int g = 0; g < NG; ++g) {
+    az[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    ah[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
   }
+  const float* zl = Zt + kq * LT + l15;
+  const float* hl = Ht + kq * LT + l15;
+#pragma unroll
+  for (int b = 0; b < FB_Z / 2; ++b)
+    if (b < nbZ2) {
+      const X3Frag a = x3_a(zl + b * 32 * LT);
+#pragma unroll
+      for (int g = 0; g < NG; ++g) az[g] = x3_mma(a, wz[g][b], az[g]);
+    }
+#pragma unroll
+  for (int b = 0; b < FB_H / 2; ++b)
+    if (b < nbH2) {
+      const X3Frag a = x3_a(hl + b * 32 * LT);
+#pragma unroll
+      for (int g = 0; g < NG; ++g) ah[g] = x3_mma(a, wh[g][b], ah[g]);
+    }
+  fast_cell_p2_gates<NG>(f, Ht, Hn, az, ah, gc, bh, cprev, j2, kq, b0, rows, h_out, c_out, g_out, cnew);
 }
 
 // P3: o = (h' Wfl^T + b) exp(3 logs) on this wave's 16 outputs   (LinearZeros, glow/modules.py:93-95); o_out may be null
@@ -1080,7 +1167,7 @@ __host__ __device__ inline int pipe_fwd_lds_floats(int C, int C16, int H16, int 
       f.stamps[4096 + 2048 * (dir) + 16 * n + (slot)] = __builtin_amdgcn_s_memtime();                                      \
   } while (0)
 
-template <int NG>
+template <int NG, bool X3>
 __global__ __launch_bounds__(NT) void flow_pipe_fwd_kernel(FlowK f) {
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l15_0 = lane & 15, kq_0 = lane >> 4;
@@ -1112,11 +1199,31 @@ __global__ __launch_bounds__(NT) void flow_pipe_fwd_kernel(FlowK f) {
   // ---- this workgroup's weights, once: P1 (16 output channels of W), P2 (16 hidden units, NG gates), P3 (16 outputs)
   const bool t1 = wave * 16 < C, t2 = wave * 16 < H, t3 = wave * 16 < Cout;
   const int tcol_0 = wave * 16 + l15_0;
-  f32x4 wz[NG][FB_Z], wh[NG][FB_H];
+  f32x4 wz[X3 ? 1 : NG][FB_Z], wh[X3 ? 1 : NG][FB_H];          // exact f32 form
+  X3Frag wzx[X3 ? NG : 1][FB_Z / 2], whx[X3 ? NG : 1][FB_H / 2];  // bf16 x 3 form: the same fragments, split once
+  {
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int g = 0; g < NG; ++g) {
-    load_frag<FB_Z>(wz[g], f.pwz + (long)k * Ch16 * NG * H16, NG * H16, g * H16 + tcol_0, kq_0, nbZ, t2);
-    load_frag<FB_H>(wh[g], f.pwh + (long)k * H16 * NG * H16, NG * H16, g * H16 + tcol_0, kq_0, nbH, t2);
+    for (int g = 0; g < NG; ++g) {
+      f32x4 tz[FB_Z], th[FB_H];
+#pragma unroll
+      for (int b = 0; b < FB_Z; ++b) tz[b] = zero4;
+#pragma unroll
+      for (int b = 0; b < FB_H; ++b) th[b] = zero4;
+      load_frag<FB_Z>(tz, f.pwz + (long)k * Ch16 * NG * H16, NG * H16, g * H16 + tcol_0, kq_0, nbZ, t2);
+      load_frag<FB_H>(th, f.pwh + (long)k * H16 * NG * H16, NG * H16, g * H16 + tcol_0, kq_0, nbH, t2);
+      if (X3) {
+#pragma unroll
+        for (int b = 0; b < FB_Z / 2; ++b) wzx[g][b] = x3_pack(tz[2 * b], tz[2 * b + 1]);
+#pragma unroll
+        for (int b = 0; b < FB_H / 2; ++b) whx[g][b] = x3_pack(th[2 * b], th[2 * b + 1]);
+      } else {
+#pragma unroll
+        for (int b = 0; b < FB_Z; ++b) wz[X3 ? 0 : g][b] = tz[b];
+#pragma unroll
+        for (int b = 0; b < FB_H; ++b) wh[X3 ? 0 : g][b] = th[b];
+      }
+    }
   }
   // P1 / P3 weights: each owning wave parks its fragments in LDS (its own region, its own lanes: no barrier needed)
   f32x4* w1s = reinterpret_cast<f32x4*>(flow_smem + ((cv.total + 3) & ~3)) + wave * nbC * 64 + lane;
@@ -1221,8 +1328,12 @@ __global__ __launch_bounds__(NT) void flow_pipe_fwd_kernel(FlowK f) {
     // ---- P2: recurrent cell of the coupling net (f_seq.forward, glow/models.py:204-214); state stays in LDS / registers
     if (t2) {
       float cnew[4] = {0.f, 0.f, 0.f, 0.f};
-      fast_cell_p2<NG>(f, Zt, Ht, Hn, wz, wh, gc, bh, cprev, nbZ, nbH, tcol, kq, l15, b0, B, f.sH + kf * H,
-                       NG == 4 ? f.sC + kf * H : nullptr, f.sG + kf * 4 * H, cnew);
+      if constexpr (X3)
+        fast_cell_p2_x3<NG>(f, Zt, Ht, Hn, wzx, whx, gc, bh, cprev, (nbZ + 1) >> 1, (nbH + 1) >> 1, tcol, kq, l15, b0, B,
+                            f.sH + kf * H, NG == 4 ? f.sC + kf * H : nullptr, f.sG + kf * 4 * H, cnew);
+      else
+        fast_cell_p2<NG>(f, Zt, Ht, Hn, wz, wh, gc, bh, cprev, nbZ, nbH, tcol, kq, l15, b0, B, f.sH + kf * H,
+                         NG == 4 ? f.sC + kf * H : nullptr, f.sG + kf * 4 * H, cnew);
 #pragma unroll
       for (int r = 0; r < 4; ++r) cprev[r] = cnew[r];
     }
@@ -2405,6 +2516,11 @@ bool flow_pipe_enabled() {
 }
 // LFI_PIPE_FENCE=1: consumers of a hand-off run an agent-scope acquire and read the tile with plain loads, instead of the
 // fence-free form (every store and load of the tile sc1; MI355X_MICROARCH.md, hand-offs measured without the acquire, row 1)
+// LFI_PIPE_X3=0: keep the exact f32 MFMA for the recurrent products of the persistent walk in bf16x3 mode too
+bool flow_pipe_x3_enabled() {
+  const char* e = getenv("LFI_PIPE_X3");
+  return !(e && e[0] == '0');
+}
 // LFI_PIPE_FORCE_ABORT=1 (tests): start the walk with the abort word already set, as if a spin had timed out
 bool flow_pipe_force_abort() {
   const char* e = getenv("LFI_PIPE_FORCE_ABORT");
@@ -2538,14 +2654,19 @@ extern "C" int lfi_flow_seq_fwd(const lfi_flow_dims* d, const lfi_flow_params* p
     f.pipe = reinterpret_cast<unsigned*>(stash + align4(stash_offsets(f, off)));
     f.pipe_fence = flow_pipe_fence();
     const size_t plds = (size_t)pipe_fwd_lds_floats(f.C, f.C16, f.H16, f.Ch16, f.Cout, f.Co16) * sizeof(float);
-    rc = f.lstm ? set_flow_lds(flow_pipe_fwd_kernel<4>, plds, "lfi_flow_seq_fwd") : set_flow_lds(flow_pipe_fwd_kernel<3>, plds, "lfi_flow_seq_fwd");
+    // bf16 x 3 recurrent products (GRU cells, hidden and z widths whose 16-k padding is a whole number of 32-k blocks)
+    const bool x3 = (d->gemm_precision & 1) && !f.lstm && (f.H16 % 32 == 0) && (f.Ch16 % 32 == 0) && flow_pipe_x3_enabled();
+    rc = f.lstm ? set_flow_lds(flow_pipe_fwd_kernel<4, false>, plds, "lfi_flow_seq_fwd")
+                : (x3 ? set_flow_lds(flow_pipe_fwd_kernel<3, true>, plds, "lfi_flow_seq_fwd")
+                      : set_flow_lds(flow_pipe_fwd_kernel<3, false>, plds, "lfi_flow_seq_fwd"));
     if (rc) return rc;
     hipError_t me = hipMemsetAsync(f.pipe, 0, (size_t)pipe_words(f) * sizeof(unsigned), st);
     LFI_REQUIRE(me == hipSuccess, "lfi_flow_seq_fwd: hipMemsetAsync: %s", hipGetErrorString(me));
     if (flow_pipe_force_abort()) (void)hipMemsetAsync(f.pipe + 1, 1, sizeof(unsigned), st);
     const dim3 grid(f.Ks * f.nbt);
-    if (f.lstm) hipLaunchKernelGGL(flow_pipe_fwd_kernel<4>, grid, dim3(NT), plds, st, f);
-    else hipLaunchKernelGGL(flow_pipe_fwd_kernel<3>, grid, dim3(NT), plds, st, f);
+    if (f.lstm) hipLaunchKernelGGL((flow_pipe_fwd_kernel<4, false>), grid, dim3(NT), plds, st, f);
+    else if (x3) hipLaunchKernelGGL((flow_pipe_fwd_kernel<3, true>), grid, dim3(NT), plds, st, f);
+    else hipLaunchKernelGGL((flow_pipe_fwd_kernel<3, false>), grid, dim3(NT), plds, st, f);
   }
   for (int dg = 0; !pipe && dg < f.N + f.Ks - 1; ++dg) {
     const int klo = dg - (f.N - 1) > 0 ? dg - (f.N - 1) : 0;

@@ -453,8 +453,11 @@ def test_pipeline_walk_matches_diagonal_walk(gpu_device, monkeypatch, case):
             keep = 1.0 - cfg["dropout"]
             masks[name] = (torch.rand(T - 24, B, cfg["history"], generator=g) < keep).float() / keep
     outs = []
-    for pipe in ("1", "0"):
-        monkeypatch.setenv("LFI_FLOW_PIPE", pipe)
+    monkeypatch.setenv("LFI_PIPE_X3", "0")   # same arithmetic in both walks: the recurrent products on the exact f32 MFMA
+    for pipe in ("1", "0", "x3"):
+        monkeypatch.setenv("LFI_FLOW_PIPE", "0" if pipe == "0" else "1")
+        if pipe == "x3":
+            monkeypatch.setenv("LFI_PIPE_X3", "1")
         m = mk()
         m.injected_masks = masks
         z_seq, loss, losses = m(batch)
@@ -467,6 +470,12 @@ def test_pipeline_walk_matches_diagonal_walk(gpu_device, monkeypatch, case):
             assert rel_err(outs[0][2][n], outs[1][2][n]) < 1e-6, n
         else:
             assert torch.equal(outs[0][2][n], outs[1][2][n]), n
+    # default of the bf16x3 engine mode: the recurrent products of the walk as three bf16 MFMAs (2^-16 relative per product)
+    err = max_rel(outs[2][0], outs[1][0], floor=1.0)
+    print("%s: persistent walk with bf16x3 recurrent products vs exact f32 cells: per-frame NLL max rel diff %.2e" % (case, err))
+    assert err < 2e-5
+    for n in outs[2][2]:
+        assert rel_err(outs[2][2][n], outs[1][2][n]) < 2e-4, n
 
 
 def test_abandoned_walk_is_loud(gpu_device, monkeypatch):
