@@ -41,6 +41,9 @@ struct FlowK {
   const float *W, *Wt, *Winv, *wz_t, *whh_t, *wfl_t, *wc, *ldconst;
   // prep, zero-padded images for the register-resident cell kernels (k rows padded to 4, columns to 16)
   const float *pW, *pWt, *pwz, *pwh, *pwfl, *bwfl, *bwh, *bwz, *pWinv;
+  // backward recurrent weights pre-split into bf16 hi / lo 32-k fragments (bf16 x 3 walk): [Ks][NG][H16/32][J][4 lane groups],
+  // one uint4 per entry and plane; the lo plane follows the hi plane of an image
+  const uint4 *xbwh, *xbwz;
   int C16, Ch16, H16, Co16, NG;
   // forward stash
   float *sA, *sY, *sX, *sH, *sG, *sO, *sL, *sC;   // sC: LSTM cell state (lstm only)
@@ -787,6 +790,34 @@ __device__ __forceinline__ f32x4 x3_mma(const X3Frag& a, const X3Frag& w, f32x4 
   return acc;
 }
 
+// this lane's fragments of one 16-column tile of a pre-split backward image: nb2 32-k blocks of gate g
+template <int MAXB2>
+__device__ __forceinline__ void x3_load(X3Frag (&w)[MAXB2], const uint4* __restrict__ img, long per, int g, int nB, int J, int col,
+                                        int kq, int nb2, bool on) {
+  const uint4* p = img + (((long)g * nB) * J + col) * 4 + kq;
+#pragma unroll
+  for (int b = 0; b < MAXB2; ++b)
+    if (on && b < nb2) {
+      w[b].hi = __builtin_bit_cast(fbf16x8, p[(long)b * J * 4]);
+      w[b].lo = __builtin_bit_cast(fbf16x8, p[(long)b * J * 4 + per]);
+    }
+}
+// sum over NG gate blocks of nb2 32-k blocks each (A: k-major LDS operand, gate stride blk floats)
+template <int NG, int MAXB2>
+__device__ __forceinline__ f32x4 x3_mma_gates(const float* a_lane, int blk, const X3Frag (&w)[NG][MAXB2], int nb2) {
+  f32x4 e = {0.f, 0.f, 0.f, 0.f}, o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int g = 0; g < NG; ++g)
+#pragma unroll
+    for (int b = 0; b < MAXB2; ++b)
+      if (b < nb2) {
+        const X3Frag a = x3_a(a_lane + g * blk + b * 32 * LT);
+        if ((g * MAXB2 + b) & 1) o = x3_mma(a, w[g][b], o);
+        else e = x3_mma(a, w[g][b], e);
+      }
+  return e + o;
+}
+
 // P2 of a register-resident cell: the coupling net's recurrent cell on this wave's 16 hidden units. Zt / Ht: z1 and
 // h_prev in LDS (k-major), Hn: new state (LDS), h_out / c_out / g_out: row-0 pointers of the (rows x H) / (rows x 4H) outputs
 // (g_out may be null).
@@ -841,7 +872,6 @@ __device__ __forceinline__ void fast_cell_p2(const FlowK& f, const float* Zt, co
                                              const float (&bh)[NG], const float (&cprev)[4], int nbZ, int nbH, int j2, int kq,
                                              int l15, int b0, int rows, float* h_out, float* c_out, float* g_out,
                                              float* cnew = nullptr) {
-  const int H = f.H;
   f32x4 az[NG], ah[NG];
 #pragma unroll
   for (int g = 0; g < NG; ++g) {
@@ -1774,7 +1804,7 @@ __global__ __launch_bounds__(NT) void flow_diag_bwd_fast_kernel(FlowK f, int d, 
 // d h (and the LSTM's d c) from timestep n + 1 in registers and receives d x of flow step k + 1 through the same write-through
 // hand-off (bDx tile + progress counter). The z-tile waves need two weight slices (W_ih[:, :Ch] and W_hh): the second one is
 // re-read from L2 every timestep, requested before the wait.
-template <int NG>
+template <int NG, bool X3>
 __global__ __launch_bounds__(NT) void flow_pipe_bwd_kernel(FlowK f) {
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l15_0 = lane & 15, kq_0 = lane >> 4;
@@ -1815,10 +1845,18 @@ __global__ __launch_bounds__(NT) void flow_pipe_bwd_kernel(FlowK f) {
   load_frag<FB_O>(wq1, f.bwfl + (long)k * Co16 * H16, H16, tcol_0, kq_0, nbO, th);
   // W_hh slice of this wave's hidden tile: resident, except in the z-tile waves, which need two slices (W_ih[:, :Ch] for
   // d z1, then W_hh) and stream both through the same registers every timestep, as the per-diagonal kernel does
-  f32x4 wq2[NG][FB_H];
+  f32x4 wq2[X3 ? 1 : NG][X3 ? 1 : FB_H];      // exact f32 form
+  X3Frag wq2x[X3 ? NG : 1][FB_H / 2];         // bf16 x 3 form: pre-split 32-k fragments (flow_prep_x3_kernel)
+  const int nB = H16 >> 5, nbH2 = (nbH + 1) >> 1;
+  const long perH = (long)NG * nB * H16 * 4, perZ = (long)NG * nB * Ch16 * 4;   // uint4 entries per plane and flow step
+  const uint4* xh = f.xbwh + (long)k * 2 * perH;
+  const uint4* xz = f.xbwz + (long)k * 2 * perZ;
   if (!tz) {
 #pragma unroll
-    for (int g = 0; g < NG; ++g) load_frag<FB_H>(wq2[g], f.bwh + ((long)k * NG + g) * H16 * H16, H16, tcol_0, kq_0, nbH, th);
+    for (int g = 0; g < NG; ++g) {
+      if constexpr (X3) x3_load<FB_H / 2>(wq2x[g], xh, perH, g, nB, H16, tcol_0, kq_0, nbH2, th);
+      else load_frag<FB_H>(wq2[g], f.bwh + ((long)k * NG + g) * H16 * H16, H16, tcol_0, kq_0, nbH, th);
+    }
   }
   // weights of Q3 (dy W^T) for this wave's channel tile
   f32x4 wq3[FB_C];
@@ -1858,7 +1896,10 @@ __global__ __launch_bounds__(NT) void flow_pipe_bwd_kernel(FlowK f) {
   }
   if (tz) {
 #pragma unroll
-    for (int g = 0; g < NG; ++g) load_frag<FB_H>(wq2[g], f.bwz + ((long)k * NG + g) * H16 * Ch16, Ch16, tcol, kq, nbH, true);
+    for (int g = 0; g < NG; ++g) {
+      if constexpr (X3) x3_load<FB_H / 2>(wq2x[g], xz, perZ, g, nB, Ch16, tcol, kq, nbH2, true);
+      else load_frag<FB_H>(wq2[g], f.bwz + ((long)k * NG + g) * H16 * Ch16, Ch16, tcol, kq, nbH, true);
+    }
   }
   // Q0's forward-stash operands (o of the coupling net, z2) for this thread's element
   float q_oe = 0.0f, q_oo = 0.0f, q_z2 = 0.0f;
@@ -1990,9 +2031,11 @@ __global__ __launch_bounds__(NT) void flow_pipe_bwd_kernel(FlowK f) {
 
   // ---- Q2: d z1 = dgi W_ih[:, :Ch] + pass-through (z-tile waves, before the barrier: Q3 needs it);
   //          d h_prev = dgh W_hh + carry (to timestep n - 1; not needed inside this cell)
-  auto dh_prev_tile = [&](const f32x4 (&w)[NG][FB_H]) {
+  auto dh_prev_tile = [&]() {
     if (n > 0 && th) {
-      const f32x4 acc = mma16_reg_gates<NG, FB_H>(Gh + kq * LT + l15, H16 * LT, w, nbH);
+      f32x4 acc;
+      if constexpr (X3) acc = x3_mma_gates<NG, FB_H / 2>(Gh + kq * LT + l15, H16 * LT, wq2x, nbH2);
+      else acc = mma16_reg_gates<NG, FB_H>(Gh + kq * LT + l15, H16 * LT, wq2, nbH);
       const int j = tcol;
       if (j < H) {
 #pragma unroll
@@ -2006,7 +2049,9 @@ __global__ __launch_bounds__(NT) void flow_pipe_bwd_kernel(FlowK f) {
     }
   };
   if (tz) {
-    const f32x4 acc = mma16_reg_gates<NG, FB_H>(Gi + kq * LT + l15, H16 * LT, wq2, nbH);
+    f32x4 acc;
+    if constexpr (X3) acc = x3_mma_gates<NG, FB_H / 2>(Gi + kq * LT + l15, H16 * LT, wq2x, nbH2);
+    else acc = mma16_reg_gates<NG, FB_H>(Gi + kq * LT + l15, H16 * LT, wq2, nbH);
     const int c = tcol;
     if (c < Ch) {
 #pragma unroll
@@ -2023,9 +2068,12 @@ __global__ __launch_bounds__(NT) void flow_pipe_bwd_kernel(FlowK f) {
     }
     // now fetch this wave's W_hh slice for its d h_prev tile (runs after Q3)
 #pragma unroll
-    for (int g = 0; g < NG; ++g) load_frag<FB_H>(wq2[g], f.bwh + ((long)k * NG + g) * H16 * H16, H16, tcol, kq, nbH, n > 0 && th);
+    for (int g = 0; g < NG; ++g) {
+      if constexpr (X3) x3_load<FB_H / 2>(wq2x[g], xh, perH, g, nB, H16, tcol, kq, nbH2, n > 0 && th);
+      else load_frag<FB_H>(wq2[g], f.bwh + ((long)k * NG + g) * H16 * H16, H16, tcol, kq, nbH, n > 0 && th);
+    }
   } else {
-    dh_prev_tile(wq2);
+    dh_prev_tile();
   }
   __syncthreads();
   PIPE_STAMP(1, 4);
@@ -2060,7 +2108,7 @@ __global__ __launch_bounds__(NT) void flow_pipe_bwd_kernel(FlowK f) {
   PIPE_STAMP(1, 6);
   // the z-tile waves' own d h_prev tile is only needed by the next timestep of THIS workgroup: after the hand-off, off the
   // pipeline's latency path (it reads Gh / Cy, which the next timestep rewrites only behind its first barrier)
-  if (tz) dh_prev_tile(wq2);
+  if (tz) dh_prev_tile();
   PIPE_STAMP(1, 7);
   }  // timestep loop
 }
@@ -2126,6 +2174,44 @@ __global__ __launch_bounds__(256) void flow_prep_pad_kernel(FlowK f, float* pW, 
       default: if (kk < C && col < C) v = f.Winv[(long)k * C * C + kk * C + col]; break;
     }
     dst[g * per + flow_img_index(kk, col, J)] = v;
+  }
+}
+
+// bf16 hi / lo fragment images of the backward recurrent weights for the bf16 x 3 walk. which 0: bwh (k = hidden of gate g,
+// col = hidden: W_hh[g*H + k][col]); 1: bwz (col = z channel: W_ih[g*H + k][col]). Entry (g, B, col, kq) holds the eight k of
+// slot order k = 32 B + 16 (i >> 2) + 4 (i & 3) + kq (x3_a reads the LDS operand in the same order).
+__global__ __launch_bounds__(256) void flow_prep_x3_kernel(FlowK f, uint4* xbwh, uint4* xbwz) {
+  const int k = blockIdx.y, which = blockIdx.z;
+  const int H = f.H, Ch = f.Ch, I = f.I, NG = f.NG, H16 = f.H16;
+  const int J = which ? f.Ch16 : H16, nB = H16 >> 5;
+  const float* whh = f.p.w_hh + (long)k * f.G * H;
+  const float* wih = f.p.w_ih + (long)k * f.G * I;
+  const long per = (long)NG * nB * J * 4;              // uint4 entries per flow step and plane
+  uint4* hi = (which ? xbwz : xbwh) + (long)k * 2 * per;
+  uint4* lo = hi + per;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < per; idx += (long)gridDim.x * 256) {
+    const int kq = (int)(idx & 3);
+    long r = idx >> 2;
+    const int col = (int)(r % J); r /= J;
+    const int B = (int)(r % nB), g = (int)(r / nB);
+    float v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int kk = 32 * B + 16 * (i >> 2) + 4 * (i & 3) + kq;
+      float x = 0.0f;
+      if (kk < H) {
+        if (which == 0) { if (col < H) x = whh[((long)g * H + kk) * H + col]; }
+        else if (col < Ch) x = wih[((long)g * H + kk) * I + col];
+      }
+      v[i] = x;
+    }
+    uint4 h, l;
+    x3_split2(v[0], v[1], &h.x, &l.x);
+    x3_split2(v[2], v[3], &h.y, &l.y);
+    x3_split2(v[4], v[5], &h.z, &l.z);
+    x3_split2(v[6], v[7], &h.w, &l.w);
+    hi[idx] = h;
+    lo[idx] = l;
   }
 }
 
@@ -2417,7 +2503,8 @@ long prep_padded_floats(const lfi_flow_dims* d) {
   const int Ch = d->C / 2, C2 = d->C - Ch, Cout = d->affine ? 2 * C2 : C2, NG = d->lstm ? 4 : 3;
   auto r16 = [](int x) { return (long)((x + 15) & ~15); };
   const long C16 = r16(d->C), Ch16 = Ch ? r16(Ch) : 16, H16 = r16(d->H), Co16 = r16(Cout);
-  return d->Ks * (3 * C16 * C16 + Ch16 * NG * H16 + H16 * NG * H16 + 2 * H16 * Co16 + NG * H16 * H16 + NG * H16 * Ch16);
+  return d->Ks * (3 * C16 * C16 + Ch16 * NG * H16 + H16 * NG * H16 + 2 * H16 * Co16 + NG * H16 * H16 + NG * H16 * Ch16)
+         + d->Ks * (NG * H16 * H16 + NG * H16 * Ch16) + 8;   // + the bf16 hi/lo fragment images of bwh / bwz (same byte counts)
 }
 
 int fill_flow(const lfi_flow_dims* d, const lfi_flow_params* p, const float* prep, FlowK* f, const char* who) {
@@ -2456,6 +2543,9 @@ int fill_flow(const lfi_flow_dims* d, const lfi_flow_params* p, const float* pre
     f->bwh = q; q += Ks * f->NG * f->H16 * f->H16;
     f->bwz = q; q += Ks * f->NG * f->H16 * f->Ch16;
     f->pWinv = q; q += Ks * f->C16 * f->C16;
+    q = reinterpret_cast<const float*>((reinterpret_cast<uintptr_t>(q) + 15) & ~(uintptr_t)15);
+    f->xbwh = reinterpret_cast<const uint4*>(q); q += Ks * f->NG * f->H16 * f->H16;
+    f->xbwz = reinterpret_cast<const uint4*>(q); q += Ks * f->NG * f->H16 * f->Ch16;
   }
   return LFI_OK;
 }
@@ -2593,6 +2683,11 @@ extern "C" int lfi_flow_prep(const lfi_flow_dims* d, const lfi_flow_params* p, f
                        (float*)f.pwh, (float*)f.pwfl, (float*)f.bwfl, (float*)f.bwh, (float*)f.bwz,
                        (with_inverse || p->inv_w) ? (float*)f.pWinv : nullptr);
     LFI_LAUNCH_CHECK("lfi_flow_prep pad");
+    if ((d->gemm_precision & 1) && !f.lstm && f.H16 % 32 == 0) {
+      hipLaunchKernelGGL(flow_prep_x3_kernel, dim3(16, d->Ks, 2), dim3(256), 0, st, f, const_cast<uint4*>(f.xbwh),
+                         const_cast<uint4*>(f.xbwz));
+      LFI_LAUNCH_CHECK("lfi_flow_prep x3");
+    }
   }
   return LFI_OK;
 }
@@ -2705,14 +2800,18 @@ extern "C" int lfi_flow_seq_bwd(const lfi_flow_dims* d, const lfi_flow_params* p
     long off[9];
     f.pipe = reinterpret_cast<unsigned*>(bstash + align4(bstash_offsets(f, off)));
     f.pipe_fence = flow_pipe_fence();
-    rc = f.lstm ? set_flow_lds(flow_pipe_bwd_kernel<4>, lds, "lfi_flow_seq_bwd") : set_flow_lds(flow_pipe_bwd_kernel<3>, lds, "lfi_flow_seq_bwd");
+    const bool x3 = (d->gemm_precision & 1) && !f.lstm && (f.H16 % 32 == 0) && flow_pipe_x3_enabled();
+    rc = f.lstm ? set_flow_lds(flow_pipe_bwd_kernel<4, false>, lds, "lfi_flow_seq_bwd")
+                : (x3 ? set_flow_lds(flow_pipe_bwd_kernel<3, true>, lds, "lfi_flow_seq_bwd")
+                      : set_flow_lds(flow_pipe_bwd_kernel<3, false>, lds, "lfi_flow_seq_bwd"));
     if (rc) return rc;
     hipError_t me = hipMemsetAsync(f.pipe, 0, (size_t)pipe_words(f) * sizeof(unsigned), st);
     LFI_REQUIRE(me == hipSuccess, "lfi_flow_seq_bwd: hipMemsetAsync: %s", hipGetErrorString(me));
     if (flow_pipe_force_abort()) (void)hipMemsetAsync(f.pipe + 1, 1, sizeof(unsigned), st);
     const dim3 grid(f.Ks * f.nbt);
-    if (f.lstm) hipLaunchKernelGGL(flow_pipe_bwd_kernel<4>, grid, dim3(NT), lds, st, f);
-    else hipLaunchKernelGGL(flow_pipe_bwd_kernel<3>, grid, dim3(NT), lds, st, f);
+    if (f.lstm) hipLaunchKernelGGL((flow_pipe_bwd_kernel<4, false>), grid, dim3(NT), lds, st, f);
+    else if (x3) hipLaunchKernelGGL((flow_pipe_bwd_kernel<3, true>), grid, dim3(NT), lds, st, f);
+    else hipLaunchKernelGGL((flow_pipe_bwd_kernel<3, false>), grid, dim3(NT), lds, st, f);
     hipLaunchKernelGGL(flow_pipe_poison_kernel, dim3(1), dim3(64), 0, st, f);
   }
   for (int dg = f.N + f.Ks - 2; !pipe && dg >= 0; --dg) {
