@@ -818,6 +818,34 @@ __device__ __forceinline__ f32x4 x3_mma_gates(const float* a_lane, int blk, cons
   return e + o;
 }
 
+// The backward cell's MFMA operands d(gate pre-activations) are needed by all eight waves: instead of every wave splitting the
+// same fp32 LDS values again (24 blocks x ~30 VALU per wave and timestep - it bound Q2 once the MFMAs were bf16), the wave
+// that computes a value stores its bf16 hi and lo ONCE, row-major [16 rows][NG * H16 + 8], the column of hidden unit j of
+// gate g at g * H16 + x3_pos(j): within a 32-k block the slot order of x3_a, so a lane's 8 k are one 16-byte read.
+__device__ __forceinline__ int x3_pos(int j) { return (j & ~31) | ((j & 3) << 3) | ((j >> 2) & 7); }
+__device__ __forceinline__ void x3_put(__bf16* hi_img, __bf16* lo_img, int idx, float v) {
+  const __bf16 h = (__bf16)v;
+  hi_img[idx] = h;
+  lo_img[idx] = (__bf16)(v - (float)h);
+}
+template <int NG, int MAXB2>
+__device__ __forceinline__ f32x4 x3_mma_gates_img(const __bf16* hi_row, const __bf16* lo_row, int H16, const X3Frag (&w)[NG][MAXB2],
+                                                  int nb2) {
+  f32x4 e = {0.f, 0.f, 0.f, 0.f}, o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int g = 0; g < NG; ++g)
+#pragma unroll
+    for (int b = 0; b < MAXB2; ++b)
+      if (b < nb2) {
+        X3Frag a;
+        a.hi = *reinterpret_cast<const fbf16x8*>(hi_row + g * H16 + b * 32);
+        a.lo = *reinterpret_cast<const fbf16x8*>(lo_row + g * H16 + b * 32);
+        if ((g * MAXB2 + b) & 1) o = x3_mma(a, w[g][b], o);
+        else e = x3_mma(a, w[g][b], e);
+      }
+  return e + o;
+}
+
 // P2 of a register-resident cell: the coupling net's recurrent cell on this wave's 16 hidden units. Zt / Ht: z1 and
 // h_prev in LDS (k-major), Hn: new state (LDS), h_out / c_out / g_out: row-0 pointers of the (rows x H) / (rows x 4H) outputs
 // (g_out may be null).
@@ -1827,6 +1855,12 @@ __global__ __launch_bounds__(NT) void flow_pipe_bwd_kernel(FlowK f) {
   float* Dl = flow_smem + cv.Dl;
   float* Gi = flow_smem + cv.Gi;
   float* Gh = Gi + NG * H16 * LT;
+  // bf16 x 3: the Gi / Gh regions hold bf16 hi + lo images instead ([16][ldx], see x3_put); 64 (NG H16 + 8) <= 68 NG H16 bytes
+  const int ldx = NG * H16 + 8;
+  __bf16* GiH = reinterpret_cast<__bf16*>(Gi);
+  __bf16* GiL = GiH + MB * ldx;
+  __bf16* GhH = reinterpret_cast<__bf16*>(Gh);
+  __bf16* GhL = GhH + MB * ldx;
   float* Dy = flow_smem + cv.Dy;
   float* Cy = flow_smem + cv.Cy;
   float* Pl = flow_smem + cv.Pl;
@@ -1864,6 +1898,10 @@ __global__ __launch_bounds__(NT) void flow_pipe_bwd_kernel(FlowK f) {
   const float es_an = tcol_0 < C ? expf(f.p.an_logs[(long)k * C + tcol_0]) : 0.0f;
   float dhc[4] = {0.f, 0.f, 0.f, 0.f}, dcc[4] = {0.f, 0.f, 0.f, 0.f};   // d h / d c carried from timestep n + 1 (registers)
 
+  if constexpr (X3) {   // padding columns (hidden units >= H) are never written: zero the images once
+    for (int q = tid; q < 2 * MB * ldx; q += NT) { GiH[q] = (__bf16)0.0f; GhH[q] = (__bf16)0.0f; }
+    __syncthreads();
+  }
   for (int n = f.N - 1; n >= 0; --n) {
     // lane coordinates laundered per iteration: otherwise every per-lane stash address (a dozen arrays x 4 rows, 64-bit) is
     // hoisted out of the timestep loop and the kernel spills ~150 VGPRs
@@ -1966,7 +2004,8 @@ __global__ __launch_bounds__(NT) void flow_pipe_bwd_kernel(FlowK f) {
     for (int c = C + cl; c < C16; c += 32) Dy[c * LT + ri] = 0.0f;
     for (int j = H + cl; j < H16; j += 32) {
 #pragma unroll
-      for (int g = 0; g < NG; ++g) { Gi[(g * H16 + j) * LT + ri] = 0.0f; Gh[(g * H16 + j) * LT + ri] = 0.0f; }
+      for (int g = 0; g < NG; ++g)
+        if (!X3) { Gi[(g * H16 + j) * LT + ri] = 0.0f; Gh[(g * H16 + j) * LT + ri] = 0.0f; }
     }
   }
   __syncthreads();
@@ -2021,7 +2060,15 @@ __global__ __launch_bounds__(NT) void flow_pipe_bwd_kernel(FlowK f) {
           for (int g = 0; g < NG; ++g) { go[g * H] = gi_[g]; ho[g * H] = gh_[g]; }
         }
 #pragma unroll
-        for (int g = 0; g < NG; ++g) { Gi[(g * H16 + j) * LT + i] = gi_[g]; Gh[(g * H16 + j) * LT + i] = gh_[g]; }
+        for (int g = 0; g < NG; ++g) {
+          if constexpr (X3) {
+            const int at = i * ldx + g * H16 + x3_pos(j);
+            x3_put(GiH, GiL, at, gi_[g]);
+            x3_put(GhH, GhL, at, gh_[g]);
+          } else {
+            Gi[(g * H16 + j) * LT + i] = gi_[g]; Gh[(g * H16 + j) * LT + i] = gh_[g];
+          }
+        }
         Cy[j * LT + i] = cy;
       }
     }
@@ -2034,7 +2081,7 @@ __global__ __launch_bounds__(NT) void flow_pipe_bwd_kernel(FlowK f) {
   auto dh_prev_tile = [&]() {
     if (n > 0 && th) {
       f32x4 acc;
-      if constexpr (X3) acc = x3_mma_gates<NG, FB_H / 2>(Gh + kq * LT + l15, H16 * LT, wq2x, nbH2);
+      if constexpr (X3) acc = x3_mma_gates_img<NG, FB_H / 2>(GhH + l15 * ldx + 8 * kq, GhL + l15 * ldx + 8 * kq, H16, wq2x, nbH2);
       else acc = mma16_reg_gates<NG, FB_H>(Gh + kq * LT + l15, H16 * LT, wq2, nbH);
       const int j = tcol;
       if (j < H) {
@@ -2050,7 +2097,7 @@ __global__ __launch_bounds__(NT) void flow_pipe_bwd_kernel(FlowK f) {
   };
   if (tz) {
     f32x4 acc;
-    if constexpr (X3) acc = x3_mma_gates<NG, FB_H / 2>(Gi + kq * LT + l15, H16 * LT, wq2x, nbH2);
+    if constexpr (X3) acc = x3_mma_gates_img<NG, FB_H / 2>(GiH + l15 * ldx + 8 * kq, GiL + l15 * ldx + 8 * kq, H16, wq2x, nbH2);
     else acc = mma16_reg_gates<NG, FB_H>(Gi + kq * LT + l15, H16 * LT, wq2, nbH);
     const int c = tcol;
     if (c < Ch) {
@@ -2800,7 +2847,8 @@ extern "C" int lfi_flow_seq_bwd(const lfi_flow_dims* d, const lfi_flow_params* p
     long off[9];
     f.pipe = reinterpret_cast<unsigned*>(bstash + align4(bstash_offsets(f, off)));
     f.pipe_fence = flow_pipe_fence();
-    const bool x3 = (d->gemm_precision & 1) && !f.lstm && (f.H16 % 32 == 0) && flow_pipe_x3_enabled();
+    // (NG * H16 >= 128: the bf16 operand images, 64 (NG H16 + 8) bytes each, must fit the fp32 regions they replace)
+    const bool x3 = (d->gemm_precision & 1) && !f.lstm && (f.H16 % 32 == 0) && f.NG * f.H16 >= 128 && flow_pipe_x3_enabled();
     rc = f.lstm ? set_flow_lds(flow_pipe_bwd_kernel<4, false>, lds, "lfi_flow_seq_bwd")
                 : (x3 ? set_flow_lds(flow_pipe_bwd_kernel<3, true>, lds, "lfi_flow_seq_bwd")
                       : set_flow_lds(flow_pipe_bwd_kernel<3, false>, lds, "lfi_flow_seq_bwd"));
