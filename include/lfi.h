@@ -99,7 +99,8 @@ int lfi_encode_windows_fwd(const lfi_enc_desc* d, const float* Xp, const float* 
                            const float* b_ih, const float* b_hh, const float* mask,
                            float* cond, float* gates, float* hseq, float* work, void* stream);
 /* BPTT of the above. dcond (F x lddcond): gradient of the feature matrix; the two output halves are summed.
- * Writes dgi ([hist][F][3*hid]: grads of the pre-activations on the input side, before the dropout mask) and
+ * Writes dgi ([hist][F][3*hid], or compact - see lfi_encode_windows_scatter: grads of the pre-activations on the input side,
+ * before the dropout mask) and
  * dgh ([hist][F][3*hid]: on the hidden side). Weight gradients follow from those with lfi_gemm_f32/lfi_colsum:
  * dW_hh = dgh[1:]^T hseq[:-1], db_hh = colsum(dgh), db_ih = colsum(dgi), dW_ih = scatter(dgi)^T X. */
 int lfi_encode_windows_bwd(const lfi_enc_desc* d, const float* dcond, int lddcond, const float* whh /* 3hid x hid */,
@@ -110,8 +111,13 @@ int lfi_encode_windows_bwd(const lfi_enc_desc* d, const float* dcond, int lddcon
  * blocks {0, 1, 3} - no second pass over dgi / dgh. Returns the number of partial rows, 0 when the unfused path runs
  * (then bias_part is not written and the biases follow from lfi_colsum_f32 over dgi / dgh). */
 long lfi_encode_windows_bias_rows(const lfi_enc_desc* d);
-/* dXp[b*T + p] = sum over the windows (n, s) that read row p of mask * dgi[(n*B+b)*hist + s]   (B*T x 3*hid) */
-int lfi_encode_windows_scatter(const lfi_enc_desc* d, const float* dgi, const float* mask, float* dXp, void* stream);
+/* dXp[b*T + p] = sum over the windows (n, s) that read row p of mask * dgi[(n*B+b)*hist + s]   (B*T x 3*hid)
+ * Compact dgi: the input-side and hidden-side gate derivatives of a GRU differ only in the n block (d n vs d n * r), so the
+ * fused backward (lfi_encode_windows_compact_dgi(d) == 1: hid <= 256, not lstm) writes dgi as that block alone,
+ * [hist][F][hid], and the scatter takes the r and z blocks from dgh (then required; db_ih comes from bias_part). */
+int lfi_encode_windows_compact_dgi(const lfi_enc_desc* d);
+int lfi_encode_windows_scatter(const lfi_enc_desc* d, const float* dgi, const float* dgh, const float* mask, float* dXp,
+                               void* stream);
 /* "enc: none" modality (glow/models.py:76-77), the flattened p1_face history (glow/models.py:601-603) and the input of an
  * "enc: mlp" modality (glow/models.py:70-71):
  * cond[f, col + s*dim + c] = mask[f, s] * X[b, start + n - hist + s + incl, c]   (incl = 0 for prev_p1_face, 1 otherwise;

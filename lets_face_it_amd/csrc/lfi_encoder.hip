@@ -19,6 +19,7 @@ namespace {
 struct EncArgs {
   int B, T, N, start, hist, hid, ldcond, col, dup;
   int lstm, G;         // LSTM window encoder (gate blocks i, f, g, o); G = (lstm ? 4 : 3) * hid
+  int compact;         // fused GRU backward: dgi holds only its n-gate block ([hist][F][hid]); its r and z blocks equal dgh's
   int F;
   const float* Xp;     // (B*T) x 3hid
   const float* b_ih;
@@ -189,7 +190,7 @@ __global__ __launch_bounds__(256) void enc_scatter_kernel(EncArgs a, float* __re
   const int row = blockIdx.x;  // b*T + p
   const int b = row / a.T, p = row - b * a.T;
   const int pos0 = a.start - a.hist + 1;
-  const bool vec = (G3 & 3) == 0;
+  const bool vec = (G3 & 3) == 0 && (a.hid & 3) == 0;
   const int nvec = vec ? G3 >> 2 : 0;
   for (int c4 = threadIdx.x; c4 < nvec; c4 += 256) {
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -204,7 +205,10 @@ __global__ __launch_bounds__(256) void enc_scatter_kernel(EncArgs a, float* __re
         const long w = ok ? (long)n * a.B + b : 0;
         const int sc = ok ? s : 0;
         wgt[u] = ok ? (a.mask ? a.mask[w * a.hist + sc] : 1.0f) : 0.0f;
-        v[u] = *reinterpret_cast<const f32x4*>(a.dgi + ((long)sc * a.F + w) * G3 + 4 * c4);
+        const long r = (long)sc * a.F + w;
+        const float* src = !a.compact ? a.dgi + r * G3 + 4 * c4
+                                      : (4 * c4 < 2 * a.hid ? a.dgh + r * G3 + 4 * c4 : a.dgi + r * a.hid + (4 * c4 - 2 * a.hid));
+        v[u] = *reinterpret_cast<const f32x4*>(src);
       }
 #pragma unroll
       for (int u = 0; u < 8; ++u) acc += wgt[u] * v[u];
@@ -219,7 +223,8 @@ __global__ __launch_bounds__(256) void enc_scatter_kernel(EncArgs a, float* __re
         if (n < 0 || n >= a.N) continue;
         const long w = (long)n * a.B + b;
         const float mk = a.mask ? a.mask[w * a.hist + s] : 1.0f;
-        acc += mk * a.dgi[((long)s * a.F + w) * G3 + c];
+        const long r = (long)s * a.F + w;
+        acc += mk * (!a.compact ? a.dgi[r * G3 + c] : (c < 2 * a.hid ? a.dgh[r * G3 + c] : a.dgi[r * a.hid + (c - 2 * a.hid)]));
       }
       dXp[(long)row * G3 + c] = acc;
     }
@@ -632,7 +637,9 @@ __global__ __launch_bounds__(ENC_NT, 2) void enc_gru_bwd_fused_kernel(EncArgs a,
     asm volatile("" : "+v"(halfv), "+v"(jv));
     const enc_rsrc bgs = enc_buf(a.gates + (long)s * a.F * 4 * hid, (long)a.F * hid * 16);
     const enc_rsrc bhp = enc_buf(a.hseq + (long)sp * a.F * hid, (long)a.F * hid * 4);
-    const enc_rsrc bgi = enc_buf(a.dgi + (long)s * a.F * G3, (long)a.F * G3 * 4);
+    // d(pre-activation) on the input side differs from the hidden side only in the n gate (dan vs dan * r): dgi keeps that
+    // one block ([hist][F][hid]); the scatter and the bias sums take d r, d z from dgh - a third less to write
+    const enc_rsrc bgi = enc_buf(a.dgi + (long)s * a.F * hid, (long)a.F * hid * 4);
     const enc_rsrc bgh = enc_buf(a.dgh + (long)s * a.F * G3, (long)a.F * G3 * 4);
     const unsigned h4 = (unsigned)hid * 4u;
 #pragma unroll
@@ -665,7 +672,7 @@ __global__ __launch_bounds__(ENC_NT, 2) void enc_gru_bwd_fused_kernel(EncArgs a,
             const float dar = dan * ghn * rr * (1.0f - rr);
             const float danr = dan * rr;
             const unsigned o = 3u * wo[e] + j4;
-            enc_st(dar, bgi, o, 0); enc_st(dau, bgi, o, h4); enc_st(dan, bgi, o, 2 * h4);
+            enc_st(dan, bgi, wo[e] + j4, 0);
 #ifdef LFI_DEBUG_HP
             enc_st(dar, bgh, o, 0); enc_st(hp[e] * hp_on, bgh, o, h4); enc_st(dhn, bgh, o, 2 * h4);
 #else
@@ -1015,13 +1022,20 @@ extern "C" int lfi_encode_windows_bwd(const lfi_enc_desc* d, const float* dcond,
   return LFI_OK;
 }
 
-extern "C" int lfi_encode_windows_scatter(const lfi_enc_desc* d, const float* dgi, const float* mask, float* dXp,
+extern "C" int lfi_encode_windows_compact_dgi(const lfi_enc_desc* d) {
+  EncFused q = {};
+  return (d && !d->lstm && enc_fused_shape(d->hid, &q)) ? 1 : 0;
+}
+
+extern "C" int lfi_encode_windows_scatter(const lfi_enc_desc* d, const float* dgi, const float* dgh, const float* mask, float* dXp,
                                           void* stream) {
   EncArgs a = {};
   int rc = fill_args(d, &a, "lfi_encode_windows_scatter");
   if (rc) return rc;
   LFI_REQUIRE(dgi && dXp, "lfi_encode_windows_scatter: null pointer");
-  a.dgi = (float*)dgi; a.mask = mask;
+  a.compact = lfi_encode_windows_compact_dgi(d);
+  LFI_REQUIRE(!a.compact || dgh, "lfi_encode_windows_scatter: the compact dgi of the fused backward needs dgh too");
+  a.dgi = (float*)dgi; a.dgh = (float*)dgh; a.mask = mask;
   hipLaunchKernelGGL(enc_scatter_kernel, dim3(d->B * d->T), dim3(256), 0, (hipStream_t)stream, a, dXp);
   LFI_LAUNCH_CHECK("lfi_encode_windows_scatter");
   return LFI_OK;

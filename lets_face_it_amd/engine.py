@@ -565,7 +565,8 @@ class GlowEngine:
                     1 if e.enc == "lstm" else 0)
         gates = self._ws["enc_gates." + e.name]
         hseq = self._ws["enc_hseq." + e.name]
-        dgi = self._buf("enc_dgi." + e.name, e.hist * F * G3)
+        compact = bool(self.L.lfi_encode_windows_compact_dgi(C.byref(d)))   # fused GRU backward: dgi = its n block only
+        dgi = self._buf("enc_dgi." + e.name, e.hist * F * (hid if compact else G3))
         dgh = self._buf("enc_dgh." + e.name, e.hist * F * G3)
         work = self._buf("scratch.enc", self.L.lfi_encode_windows_work_floats(C.byref(d)))
         whh = self.view("enc.%s.weight_hh" % e.name)
@@ -576,7 +577,7 @@ class GlowEngine:
               "lfi_encode_windows_bwd")
         mk = None if ctx.masks is None else ctx.masks.get(e.name)
         dxp = self._buf("dxp." + e.name, B * Tx * G3)
-        check(self.L.lfi_encode_windows_scatter(C.byref(d), dgi.data_ptr(), ptr(mk), dxp.data_ptr(), st),
+        check(self.L.lfi_encode_windows_scatter(C.byref(d), dgi.data_ptr(), dgh.data_ptr(), ptr(mk), dxp.data_ptr(), st),
               "lfi_encode_windows_scatter")
         gname = "enc.%s." % e.name
         rows = B * Tx
