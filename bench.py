@@ -143,6 +143,33 @@ def _roofline(spec, F, timing, precision):
             "ms_per_launch": ms, "launches_timed": n_launch}
 
 
+def _roofline_hbm(spec, B, T, timing, precision):
+    """Second roofline, for the largest HBM-bound kernel: the fused GRU window encoder of p2_face, forward
+    (enc_gru_fwd_fused_kernel). Algorithmic bytes per launch = what must cross HBM once: the BPTT stash it writes (r, z, n,
+    W_hn h + b_hn and h: 5 * hid floats per window and history step), the projected inputs it reads (B*T x 3*hid, shared by the
+    overlapping windows) and the feature block it writes (F x hid). Launch time: HIP events on the launch stream."""
+    e = next((x for x in spec.encoders if x.name == "p2_face" and x.enc == "rnn"), None)
+    n_launch, ms = timing.get("enc_fwd.p2_face", (0, float("nan")))
+    if e is None or not n_launch:
+        return None
+    F = B * (T - spec.start)
+    alg = 4.0 * (e.hist * F * 5 * e.hid + B * T * 3 * e.hid + F * e.hid)
+    traffic = None
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_%s.json" % precision)))
+        for name, v in tj["kernels"].items():
+            if "enc_gru_fwd_fused_kernel" in name and name.endswith("grid=%d" % (((F + 31) // 32) * 256)):
+                traffic = max(traffic or 0.0, v["hbm_bytes"])   # p2_face (24 steps) is the larger of the two 256-wide launches
+    except (OSError, ValueError, KeyError):
+        pass
+    ach = alg / (ms * 1e-3) / 1e9
+    return {"bound": "hbm", "kernel": "enc_gru_fwd_fused_kernel, p2_face windows (hist %d, hid %d)" % (e.hist, e.hid),
+            "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0, "traffic": traffic,
+            "traffic_note": "PMC bytes per launch of this kernel name and grid: the mean over the p2_face (24 steps) and p2_speech "
+                            "(16 steps) launches, which share them",
+            "algorithmic_bytes_per_launch": alg, "ms_per_launch": ms, "launches_timed": n_launch}
+
+
 def bench_train(args, model, trainer, spec, device, world, rank, hp):
     C, S, T, B = spec.C, spec.S, args.seq_len, args.batch
     N = T - spec.start
@@ -176,6 +203,7 @@ def bench_train(args, model, trainer, spec, device, world, rank, hp):
                    "parallelism": "dp%d" % world, "params": eng.n_params, "gemm_precision": args.precision},
         "final_loss": float(loss),
         "roofline": _roofline(spec, F, timing, args.precision),
+        "roofline_hbm": _roofline_hbm(spec, B, T, timing, args.precision),
         "kernel_timing": {t: {"launches": n, "ms": round(m_, 4)} for t, (n, m_) in timing.items()},
     }
     if world == 1 and args.cpu_baseline_seconds > 0:

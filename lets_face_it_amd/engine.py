@@ -418,10 +418,12 @@ class GlowEngine:
             hseq = self._buf("enc_hseq." + e.name, e.hist * F * hid)
             d = EncDesc(B, Tx, N, start - 1 + incl, e.hist, hid, s.ldf, e.fcol, self.precision, 0, 1 if lstm else 0)
             work = self._buf("scratch.enc", self.L.lfi_encode_windows_work_floats(C.byref(d)))
+            ev = self._tic("enc_fwd." + e.name)
             check(self.L.lfi_encode_windows_fwd(
                 C.byref(d), xp.data_ptr(), self.view("enc.%s.weight_hh" % e.name).data_ptr(),
                 self.view("enc.%s.bias_ih" % e.name).data_ptr(), self.view("enc.%s.bias_hh" % e.name).data_ptr(),
                 ptr(mk), cond.data_ptr(), ptr(gates), hseq.data_ptr(), work.data_ptr(), st), "lfi_encode_windows_fwd")
+            self._toc("enc_fwd." + e.name, ev)   # (includes the small weight-fragment kernel in front of the recurrence)
 
     def _aligned_input(self, e, x, rows, G):
         """Input stream and W_ih of a recurrent window encoder with 16-byte aligned rows. BASELINE's 50-d faces / 27-d speech
