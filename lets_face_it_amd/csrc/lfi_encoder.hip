@@ -283,7 +283,11 @@ __global__ __launch_bounds__(256) void leaky_grad_kernel(float* __restrict__ d, 
 //   overlaps the other's MFMAs.
 // The weights are re-laid once per call into a zero-padded image (Kp = hid rounded up to 16 rows of k, Jp = 64 ncg
 // columns) so the k loop carries no bounds checks: every load in it is unconditional.
-constexpr int ENC_NT = 256;
+#ifndef LFI_ENC_NT
+#define LFI_ENC_NT 256   // (512 = one 64-window workgroup per CU: measured slower, 0.90 vs 0.78 ms on the p2_face forward launch - no L1 sharing of the weight stream)
+#endif
+constexpr int ENC_NT = LFI_ENC_NT;   // threads per workgroup of the fused kernels
+constexpr int ENC_NW = ENC_NT / 64;  // waves: ncg column groups x ENC_NW / ncg row groups of 32 windows
 constexpr int ENC_KC = 4;  // k-pairs per prefetch chunk (two chunks in flight)
 extern __shared__ __attribute__((aligned(16))) float enc_smem[];
 
@@ -805,7 +809,7 @@ __global__ __launch_bounds__(ENC_NT, 2) void enc_gru_bwd_fused_kernel(EncArgs a,
     dh[1] = acc[1];
   }
   if (a.bias_part) {
-    float* bp = a.bias_part + ((long)blockIdx.x * (4 / q.ncg) + rg) * 4 * hid;
+    float* bp = a.bias_part + ((long)blockIdx.x * (ENC_NW / q.ncg) + rg) * 4 * hid;
 #pragma unroll
     for (int qq = 0; qq < 4; ++qq)
 #pragma unroll
@@ -834,7 +838,7 @@ int enc_fused_shape(int hid, EncFused* q) {
   int tiles = lfi_cdiv(hid, 64), ncg = 1;
   while (ncg < tiles) ncg <<= 1;
   q->ncg = ncg;
-  q->R = 32 * (4 / ncg);
+  q->R = 32 * (ENC_NW / ncg);
   q->Kp = (hid + 15) & ~15;
   q->Jp = 64 * ncg;
   return 1;
@@ -946,7 +950,7 @@ extern "C" int lfi_encode_windows_fwd(const lfi_enc_desc* d, const float* Xp, co
 extern "C" long lfi_encode_windows_bias_rows(const lfi_enc_desc* d) {
   EncFused q = {};
   if (!d || d->lstm || !enc_fused_shape(d->hid, &q)) return 0;
-  return (long)lfi_cdiv((long)d->N * d->B, q.R) * (4 / q.ncg);
+  return (long)lfi_cdiv((long)d->N * d->B, q.R) * (ENC_NW / q.ncg);
 }
 
 extern "C" int lfi_encode_windows_bwd(const lfi_enc_desc* d, const float* dcond, int lddcond, const float* whh,
