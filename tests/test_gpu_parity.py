@@ -539,3 +539,38 @@ def test_two_bucket_allreduce_protocol(gpu_device):
     assert calls[0][0] == base + 4 * eng.flow_offset and calls[0][1] == eng.n_params - eng.flow_offset
     assert calls[1][0] == base and calls[1][1] == eng.flow_offset and eng.flow_offset > 0
     assert torch.equal(m1.seq_glow.engine.params, eng.params)
+
+
+@pytest.mark.parametrize("fname", ["final_model.yaml", "final_model_synthetic.yaml", "no_speech.yaml", "no_nll_trick.yaml"])
+def test_every_shipped_hparams_file_trains(gpu_device, fname):
+    """The runnable hparams files of the reference (hparams/*.yaml: the final model, no_speech, no_nll_trick; its no_face.yaml sets
+    p1_face.dim = 0, a 0-channel flow that the reference cannot construct either) plus BASELINE's synthetic
+    dims, through LetsFaceItGlow.fused_training_step on random data: ActNorm data-dependent init on the first step, finite
+    loss, parameters move, and the loss of a fixed batch goes down over a few steps."""
+    import os
+    import random
+    import numpy as np
+    from lets_face_it_amd.glow.lets_face_it_glow import LetsFaceItGlow
+    from lets_face_it_amd.glow.utils import load_hparams_file
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hp = load_hparams_file(os.path.join(root, "lets_face_it_amd", "hparams", fname))
+    hp["batch_size"] = 32
+    hp["gradient_clip_val"] = 20
+    random.seed(0)
+    np.random.seed(0)
+    torch.manual_seed(0)
+    m = LetsFaceItGlow(Namespace(**hp)).to(gpu_device).train()
+    spec = m.seq_glow.spec
+    T = spec.start + 12
+    g = torch.Generator().manual_seed(1)
+    batch = {"p1_face": torch.randn(32, T, spec.C, generator=g)}
+    for e in spec.encoders:
+        if e.name != "p1_face":
+            batch[e.name] = torch.randn(32, T, e.in_dim, generator=g)
+    batch = to_dev(batch, gpu_device)
+    before = m.seq_glow._ensure_engine(gpu_device).params.clone()
+    losses = [float(m.fused_training_step(batch, 1e-3)) for _ in range(6)]
+    assert all(np.isfinite(losses)), losses
+    assert m.seq_glow.glow.actnorm_inited()
+    assert not torch.equal(before, m.seq_glow.engine.params)
+    assert losses[-1] < losses[1], losses     # (step 0 includes the ActNorm init; the negative-example branch needs mm_nll > 0)
