@@ -946,7 +946,9 @@ __global__ __launch_bounds__(1024, 4) void gemm_bf16x3_256_kernel(GemmArgs g) {
 // other's staging (1680 cycles while its partner streams MFMAs) and nets nothing, with or without s_setprio on the
 // staging half - the same zero-sum the microarchitecture notes report for two waves per SIMD. Kept opt-in
 // (LFI_GEMM_WIDE=1) as the base for the next step: operands pre-split to bf16 planes by their producers (no VALU in the
-// loop) and an epilogue that does not hold the CU (0.15 ms of this product).
+// loop) and an epilogue that does not hold the CU (0.15 ms of this product). Also tried on the 16-wave kernel and dropped:
+// delaying the workgroups of XCD x by x * d cycles at launch, to de-phase the eight XCDs' epilogue write bursts - slower for
+// every d (cond_transform 0.71 ms at d = 0, 0.77 at 3000, 0.86 at 8000, 1.00 at 16000).
 constexpr int Y2NT = 512;
 constexpr int Y2BUFS = 3;
 
