@@ -1446,13 +1446,16 @@ __global__ __launch_bounds__(NT) void flow_pipe_fwd_kernel(FlowK f) {
 
 // FlowStep.reverse_flow (glow/models.py:345-373) with explicit state, register-resident weights: the sampler's and
 // SeqGlow.invert's cell. coupling^-1 -> invconv^-1 (W^-1 image) -> actnorm^-1.
+// wait_flag / pub_flag: hand-off words of the per-frame reverse chain (flow_rev_chain_kernel), or null for a stand-alone launch:
+// the input tile is then read with sc1 loads after the producer's progress word is seen, and the output tile is stored sc1,
+// drained and published (the hand-off of the persistent walks).
 template <int NG>
-__global__ __launch_bounds__(NT) void flow_step_rev_fast_kernel(FlowK f, CellIO io) {
+__device__ __forceinline__ void rev_fast_cell(const FlowK& f, const CellIO& io, int b0, const unsigned* wait_flag,
+                                              unsigned* abort_w, unsigned* pub_flag, int* s_ok) {
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l15 = lane & 15, kq = lane >> 4;
   const int ri = tid >> 5, cl = tid & 31;
   const int k = io.k, rows = io.rows;
-  const int b0 = blockIdx.x * MB;
   const int C = f.C, H = f.H, Ch = f.Ch, C2 = f.C2, Cout = f.Cout, G = f.G;
   const int C16 = f.C16, Ch16 = f.Ch16, H16 = f.H16, Co16 = f.Co16;
   const CarveF cv = carve_fast_fwd(C, C16, H16, Ch16, Cout);
@@ -1487,12 +1490,13 @@ __global__ __launch_bounds__(NT) void flow_step_rev_fast_kernel(FlowK f, CellIO 
       cprev[r] = (NG == 4 && io.c_prev) ? io.c_prev[(long)row * H + jc] : 0.0f;
     }
   }
+  if (wait_flag && !pipe_acquire(wait_flag, 1u, abort_w, tid, s_ok, false)) return;
   // ---- R0: stage [z1 | z2'] and h_prev
   {
     const int row = b0 + ri;
     const bool rok = row < rows;
     for (int c = cl; c < C16; c += 32) {
-      const float v = (c < C && rok) ? io.x_in[(long)row * io.ldx + c] : 0.0f;
+      const float v = (c < C && rok) ? ld_tile(io.x_in + (long)row * io.ldx + c, wait_flag == nullptr) : 0.0f;
       if (c < C) Yrm[ri * ldy + c] = v;
       if (c < Ch) Zt[c * LT + ri] = v;
       if (c < Ch || c >= C) Yt[c * LT + ri] = v;   // z1 rows and the zero k padding; z2 rows come from R3
@@ -1546,11 +1550,65 @@ __global__ __launch_bounds__(NT) void flow_step_rev_fast_kernel(FlowK f, CellIO 
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int row = b0 + kq * 4 + r;
-        if (row < rows) io.x_out[(long)row * io.ldxo + c] = acc[r] * es - bb;
+        if (row < rows) {
+          if (pub_flag) st_sc1(io.x_out + (long)row * io.ldxo + c, acc[r] * es - bb);
+          else io.x_out[(long)row * io.ldxo + c] = acc[r] * es - bb;
+        }
       }
     }
   }
+  if (pub_flag) pipe_publish(pub_flag, 1u, tid, true);
 }
+
+template <int NG>
+__global__ __launch_bounds__(NT) void flow_step_rev_fast_kernel(FlowK f, CellIO io) {
+  rev_fast_cell<NG>(f, io, blockIdx.x * MB, nullptr, nullptr, nullptr, nullptr);
+}
+
+// One generated frame of the sampler: all Ks reverse flow steps of all batch tiles in ONE launch instead of Ks launches of
+// B / 16 workgroups each (64 of 256 CUs at batch 1024, 270 KB of weights fetched behind every launch boundary). Workgroup
+// (k, tile) - ids by ticket, k descending, so a workgroup only waits on one that already runs - requests its weights, its
+// part of gic and its recurrent state, then waits for the tile of step k + 1 (the prior noise for k = Ks - 1), runs the
+// cell and hands its tile to step k - 1 (step 0 writes the frame). Tiles of one sample block chain strictly, so the two
+// ping-pong tile buffers of the per-step launches still do.
+struct RevChain {
+  const float* noise;     // B x C prior draws of this frame
+  float *xa, *xb;         // B x C tile buffers: step k writes (k & 1) ? xa : xb
+  float* frame; long ld_frame;   // output rows of this frame in faces (row stride seq_len * C)
+  const float* gic;       // [Ks][B][G]
+  float *h, *cstate;      // [Ks][B][H] recurrent state, updated in place
+  int has_prev;           // 0 at the first generated frame (zero state)
+  unsigned* pipe;         // ticket, abort, progress words (zeroed before every launch)
+};
+template <int NG>
+__global__ __launch_bounds__(NT) void flow_rev_chain_kernel(FlowK f, RevChain rc) {
+  __shared__ int s_id, s_ok;
+  if (threadIdx.x == 0) s_id = (int)atomicAdd(rc.pipe, 1u);
+  __syncthreads();
+  const int nbt = f.nbt;
+  const int kk = s_id / nbt, bt = s_id - kk * nbt;
+  if (kk >= f.Ks) return;
+  const int k = f.Ks - 1 - kk;
+  unsigned* prog = rc.pipe + PIPE_HDR;
+  CellIO io = {};
+  io.k = k; io.rows = f.B;
+  if (k == f.Ks - 1) { io.x_in = rc.noise; io.ldx = f.C; }
+  else { io.x_in = ((k + 1) & 1) ? rc.xa : rc.xb; io.ldx = f.C; }
+  if (k == 0) { io.x_out = rc.frame; io.ldxo = rc.ld_frame; }
+  else { io.x_out = (k & 1) ? rc.xa : rc.xb; io.ldxo = f.C; }
+  io.h_prev = rc.has_prev ? rc.h + (long)k * f.B * f.H : nullptr;
+  io.h_out = rc.h + (long)k * f.B * f.H;
+  if (NG == 4) { io.c_prev = rc.has_prev ? rc.cstate + (long)k * f.B * f.H : nullptr; io.c_out = rc.cstate + (long)k * f.B * f.H; }
+  io.gic = rc.gic + (long)k * f.B * f.G;
+  rev_fast_cell<NG>(f, io, bt * MB, k + 1 < f.Ks ? prog + (k + 1) * nbt + bt : nullptr, rc.pipe + 1,
+                    k > 0 ? prog + k * nbt + bt : nullptr, &s_ok);
+  if (k == 0 && ld_agent(rc.pipe + 1) != 0u) {   // an abandoned chain must not pass for a frame
+    const int row = bt * MB + (int)(threadIdx.x >> 5);
+    if (row < f.B)
+      for (int c = threadIdx.x & 31; c < f.C; c += 32) rc.frame[(long)row * rc.ld_frame + c] = __builtin_nanf("");
+  }
+}
+
 
 struct CarveFB {
   int Dl, Gi, Dy, Cy, Pl, total;
@@ -3019,7 +3077,9 @@ extern "C" long lfi_flow_sample_p1_work_floats(const lfi_flow_dims* d, const lfi
 extern "C" long lfi_flow_sample_work_floats(const lfi_flow_dims* d) {
   if (!d) return 0;
   const int G = (d->lstm ? 4 : 3) * d->H;
-  return (long)d->B * d->Ks * d->D + (long)d->Ks * d->B * G + 2L * d->B * d->C + 16;
+  const long tiles = (d->B + MB - 1) / MB;
+  return (long)d->B * d->Ks * d->D + (long)d->Ks * d->B * G + 2L * d->B * d->C + 16
+         + (((long)PIPE_HDR + d->Ks * tiles + 3) & ~3L) + 4;   // + the hand-off words of the per-frame reverse chain
 }
 
 extern "C" int lfi_flow_sample_seq(const lfi_flow_dims* d, const lfi_flow_params* p, const float* prep, const float* wct,
@@ -3050,6 +3110,15 @@ extern "C" int lfi_flow_sample_seq(const lfi_flow_dims* d, const lfi_flow_params
              : (f.lstm ? set_flow_lds(flow_step_rev_fast_kernel<4>, lds, "lfi_flow_sample_seq")
                        : set_flow_lds(flow_step_rev_fast_kernel<3>, lds, "lfi_flow_sample_seq"));
   if (rc) return rc;
+  // LFI_SAMPLE_CHAIN=0 keeps one launch per flow step
+  const char* ce = getenv("LFI_SAMPLE_CHAIN");
+  const bool chain = fast && !(ce && ce[0] == '0');
+  unsigned* chain_state = reinterpret_cast<unsigned*>((reinterpret_cast<uintptr_t>(xb + (long)B * C) + 15) & ~(uintptr_t)15);
+  const size_t chain_words = (size_t)(((long)PIPE_HDR + (long)Ks * f.nbt + 3) & ~3L);
+  if (chain) {
+    rc = f.lstm ? set_flow_lds(flow_rev_chain_kernel<4>, lds, "lfi_flow_sample_seq") : set_flow_lds(flow_rev_chain_kernel<3>, lds, "lfi_flow_sample_seq");
+    if (rc) return rc;
+  }
   for (int n = 0; n < nframes; ++n) {
     const int t = start + n;
     // c = LeakyReLU(pre_static[n] + window @ Wct[:, :hist1*C]^T)
@@ -3104,6 +3173,17 @@ extern "C" int lfi_flow_sample_seq(const lfi_flow_dims* d, const lfi_flow_params
     r.bias = p->b_ih; r.strideBias = G; r.precision = d->gemm_precision;
     if ((rc = lfi_gemm_f32(&r, stream))) return rc;
     // reverse flow: z -> x through steps Ks-1 .. 0
+    if (chain) {   // one launch for the whole chain of this frame
+      RevChain rcn = {};
+      rcn.noise = noise + (long)n * B * C; rcn.xa = xa; rcn.xb = xb;
+      rcn.frame = faces + (long)t * C; rcn.ld_frame = (long)seq_len * C;
+      rcn.gic = gic; rcn.h = h; rcn.cstate = cstate; rcn.has_prev = n > 0 ? 1 : 0; rcn.pipe = chain_state;
+      hipError_t me = hipMemsetAsync(chain_state, 0, chain_words * sizeof(unsigned), st);
+      LFI_REQUIRE(me == hipSuccess, "lfi_flow_sample_seq: hipMemsetAsync: %s", hipGetErrorString(me));
+      if (f.lstm) hipLaunchKernelGGL(flow_rev_chain_kernel<4>, dim3(Ks * f.nbt), dim3(NT), lds, st, f, rcn);
+      else hipLaunchKernelGGL(flow_rev_chain_kernel<3>, dim3(Ks * f.nbt), dim3(NT), lds, st, f, rcn);
+      continue;
+    }
     const float* xin = noise + (long)n * B * C;
     long ldx = C;
     for (int k = Ks - 1; k >= 0; --k) {
