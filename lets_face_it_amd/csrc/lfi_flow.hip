@@ -1449,7 +1449,7 @@ __global__ __launch_bounds__(NT) void flow_pipe_fwd_kernel(FlowK f) {
 // wait_flag / pub_flag: hand-off words of the per-frame reverse chain (flow_rev_chain_kernel), or null for a stand-alone launch:
 // the input tile is then read with sc1 loads after the producer's progress word is seen, and the output tile is stored sc1,
 // drained and published (the hand-off of the persistent walks).
-template <int NG>
+template <int NG, bool X3 = false>
 __device__ __forceinline__ void rev_fast_cell(const FlowK& f, const CellIO& io, int b0, const unsigned* wait_flag,
                                               unsigned* abort_w, unsigned* pub_flag, int* s_ok) {
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1470,10 +1470,17 @@ __device__ __forceinline__ void rev_fast_cell(const FlowK& f, const CellIO& io, 
   const bool t1 = wave * 16 < C, t2 = wave * 16 < H, t3 = wave * 16 < Cout;
   const int tcol = wave * 16 + l15;
   f32x4 wz[NG][FB_Z], wh[NG][FB_H], w3[FB_H];
+  {
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int g = 0; g < NG; ++g) {
-    load_frag<FB_Z>(wz[g], f.pwz + (long)k * Ch16 * NG * H16, NG * H16, g * H16 + tcol, kq, nbZ, t2);
-    load_frag<FB_H>(wh[g], f.pwh + (long)k * H16 * NG * H16, NG * H16, g * H16 + tcol, kq, nbH, t2);
+    for (int g = 0; g < NG; ++g) {
+#pragma unroll
+      for (int b = 0; b < FB_Z; ++b) wz[g][b] = zero4;
+#pragma unroll
+      for (int b = 0; b < FB_H; ++b) wh[g][b] = zero4;
+      load_frag<FB_Z>(wz[g], f.pwz + (long)k * Ch16 * NG * H16, NG * H16, g * H16 + tcol, kq, nbZ, t2);
+      load_frag<FB_H>(wh[g], f.pwh + (long)k * H16 * NG * H16, NG * H16, g * H16 + tcol, kq, nbH, t2);
+    }
   }
   load_frag<FB_H>(w3, f.pwfl + (long)k * H16 * Co16, Co16, tcol, kq, nbH, t3);
   float gc[4][NG], bh[NG], cprev[4];
@@ -1511,7 +1518,22 @@ __device__ __forceinline__ void rev_fast_cell(const FlowK& f, const CellIO& io, 
   f32x4 w1[FB_C];
   load_frag<FB_C>(w1, f.pWinv + (long)k * C16 * C16, C16, tcol, kq, nbC, t1);
   __syncthreads();
-  if (t2) fast_cell_p2<NG>(f, Zt, Ht, Hn, wz, wh, gc, bh, cprev, nbZ, nbH, tcol, kq, l15, b0, rows, io.h_out, io.c_out, nullptr);
+  if (t2) {
+    if constexpr (X3) {   // bf16 x 3 recurrent products: the fragments split in registers (this launch's weights, used once)
+      X3Frag wzx[NG][FB_Z / 2], whx[NG][FB_H / 2];
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+#pragma unroll
+        for (int b = 0; b < FB_Z / 2; ++b) wzx[g][b] = x3_pack(wz[g][2 * b], wz[g][2 * b + 1]);
+#pragma unroll
+        for (int b = 0; b < FB_H / 2; ++b) whx[g][b] = x3_pack(wh[g][2 * b], wh[g][2 * b + 1]);
+      }
+      fast_cell_p2_x3<NG>(f, Zt, Ht, Hn, wzx, whx, gc, bh, cprev, (nbZ + 1) >> 1, (nbH + 1) >> 1, tcol, kq, l15, b0, rows, io.h_out,
+                          io.c_out, nullptr, nullptr);
+    } else {
+      fast_cell_p2<NG>(f, Zt, Ht, Hn, wz, wh, gc, bh, cprev, nbZ, nbH, tcol, kq, l15, b0, rows, io.h_out, io.c_out, nullptr);
+    }
+  }
   __syncthreads();
   if (t3) fast_cell_p3(f, k, Hn, Orm, w3, nbH, tcol, kq, l15, b0, rows, nullptr, 0);
   __syncthreads();
@@ -1580,7 +1602,7 @@ struct RevChain {
   int has_prev;           // 0 at the first generated frame (zero state)
   unsigned* pipe;         // ticket, abort, progress words (zeroed before every launch)
 };
-template <int NG>
+template <int NG, bool X3>
 __global__ __launch_bounds__(NT) void flow_rev_chain_kernel(FlowK f, RevChain rc) {
   __shared__ int s_id, s_ok;
   if (threadIdx.x == 0) s_id = (int)atomicAdd(rc.pipe, 1u);
@@ -1600,7 +1622,7 @@ __global__ __launch_bounds__(NT) void flow_rev_chain_kernel(FlowK f, RevChain rc
   io.h_out = rc.h + (long)k * f.B * f.H;
   if (NG == 4) { io.c_prev = rc.has_prev ? rc.cstate + (long)k * f.B * f.H : nullptr; io.c_out = rc.cstate + (long)k * f.B * f.H; }
   io.gic = rc.gic + (long)k * f.B * f.G;
-  rev_fast_cell<NG>(f, io, bt * MB, k + 1 < f.Ks ? prog + (k + 1) * nbt + bt : nullptr, rc.pipe + 1,
+  rev_fast_cell<NG, X3>(f, io, bt * MB, k + 1 < f.Ks ? prog + (k + 1) * nbt + bt : nullptr, rc.pipe + 1,
                     k > 0 ? prog + k * nbt + bt : nullptr, &s_ok);
   if (k == 0 && ld_agent(rc.pipe + 1) != 0u) {   // an abandoned chain must not pass for a frame
     const int row = bt * MB + (int)(threadIdx.x >> 5);
@@ -3079,7 +3101,8 @@ extern "C" long lfi_flow_sample_work_floats(const lfi_flow_dims* d) {
   const int G = (d->lstm ? 4 : 3) * d->H;
   const long tiles = (d->B + MB - 1) / MB;
   return (long)d->B * d->Ks * d->D + (long)d->Ks * d->B * G + 2L * d->B * d->C + 16
-         + (((long)PIPE_HDR + d->Ks * tiles + 3) & ~3L) + 4;   // + the hand-off words of the per-frame reverse chain
+         + (((long)PIPE_HDR + d->Ks * tiles + 3) & ~3L) + 4    // + the hand-off words of the per-frame reverse chain
+         + (long)d->B * 64 * ((d->C + 3) & ~3) + 4;            // + the aligned copy of the raw prev_p1_face window (hist1 <= 64)
 }
 
 extern "C" int lfi_flow_sample_seq(const lfi_flow_dims* d, const lfi_flow_params* p, const float* prep, const float* wct,
@@ -3113,10 +3136,18 @@ extern "C" int lfi_flow_sample_seq(const lfi_flow_dims* d, const lfi_flow_params
   // LFI_SAMPLE_CHAIN=0 keeps one launch per flow step
   const char* ce = getenv("LFI_SAMPLE_CHAIN");
   const bool chain = fast && !(ce && ce[0] == '0');
+  const bool x3 = (d->gemm_precision & 1) && !f.lstm && (f.H16 % 32 == 0) && (f.Ch16 % 32 == 0) && flow_pipe_x3_enabled();
   unsigned* chain_state = reinterpret_cast<unsigned*>((reinterpret_cast<uintptr_t>(xb + (long)B * C) + 15) & ~(uintptr_t)15);
   const size_t chain_words = (size_t)(((long)PIPE_HDR + (long)Ks * f.nbt + 3) & ~3L);
+  // raw prev_p1_face windows start (t - hist1) * C floats into a row: 16-byte aligned only on every other frame at C = 50,
+  // which sent half of the window products to the exact-f32 kernel (91 vs 35 us). A gather into an aligned buffer first.
+  float* wstage = reinterpret_cast<float*>(chain_state + chain_words);
+  const int ldw = (hist1 * C + 3) & ~3;
+  const bool stage_win = p1kind == 0 && hist1 <= 64;
   if (chain) {
-    rc = f.lstm ? set_flow_lds(flow_rev_chain_kernel<4>, lds, "lfi_flow_sample_seq") : set_flow_lds(flow_rev_chain_kernel<3>, lds, "lfi_flow_sample_seq");
+    rc = f.lstm ? set_flow_lds(flow_rev_chain_kernel<4, false>, lds, "lfi_flow_sample_seq")
+                : (x3 ? set_flow_lds(flow_rev_chain_kernel<3, true>, lds, "lfi_flow_sample_seq")
+                      : set_flow_lds(flow_rev_chain_kernel<3, false>, lds, "lfi_flow_sample_seq"));
     if (rc) return rc;
   }
   for (int n = 0; n < nframes; ++n) {
@@ -3163,6 +3194,10 @@ extern "C" int lfi_flow_sample_seq(const lfi_flow_dims* d, const lfi_flow_params
       }
       q.K = hid; q.A = ebuf; q.lda = hid4;
     }
+    if (stage_win) {
+      if ((rc = lfi_gather_windows(faces, B, seq_len, C, 1, t, hist1, 0, nullptr, wstage, ldw, 0, stream))) return rc;
+      q.A = wstage; q.lda = ldw;
+    }
     if ((rc = lfi_gemm_f32(&q, stream))) return rc;
     // gic[k] = c[:, kD:(k+1)D] @ W_ih[k][:, Ch:]^T + b_ih[k]
     lfi_gemm_desc r = {};
@@ -3180,8 +3215,9 @@ extern "C" int lfi_flow_sample_seq(const lfi_flow_dims* d, const lfi_flow_params
       rcn.gic = gic; rcn.h = h; rcn.cstate = cstate; rcn.has_prev = n > 0 ? 1 : 0; rcn.pipe = chain_state;
       hipError_t me = hipMemsetAsync(chain_state, 0, chain_words * sizeof(unsigned), st);
       LFI_REQUIRE(me == hipSuccess, "lfi_flow_sample_seq: hipMemsetAsync: %s", hipGetErrorString(me));
-      if (f.lstm) hipLaunchKernelGGL(flow_rev_chain_kernel<4>, dim3(Ks * f.nbt), dim3(NT), lds, st, f, rcn);
-      else hipLaunchKernelGGL(flow_rev_chain_kernel<3>, dim3(Ks * f.nbt), dim3(NT), lds, st, f, rcn);
+      if (f.lstm) hipLaunchKernelGGL((flow_rev_chain_kernel<4, false>), dim3(Ks * f.nbt), dim3(NT), lds, st, f, rcn);
+      else if (x3) hipLaunchKernelGGL((flow_rev_chain_kernel<3, true>), dim3(Ks * f.nbt), dim3(NT), lds, st, f, rcn);
+      else hipLaunchKernelGGL((flow_rev_chain_kernel<3, false>), dim3(Ks * f.nbt), dim3(NT), lds, st, f, rcn);
       continue;
     }
     const float* xin = noise + (long)n * B * C;

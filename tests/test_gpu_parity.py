@@ -574,3 +574,27 @@ def test_every_shipped_hparams_file_trains(gpu_device, fname):
     assert m.seq_glow.glow.actnorm_inited()
     assert not torch.equal(before, m.seq_glow.engine.params)
     assert losses[-1] < losses[1], losses     # (step 0 includes the ActNorm init; the negative-example branch needs mm_nll > 0)
+
+
+@pytest.mark.parametrize("precision", ["f32", "bf16x3"])
+def test_final_width_sampling_against_oracle(gpu_device, precision):
+    """SeqGlow.inference at final_model widths (H = 128, D = 512, 256-wide GRU windows; K = 4 so that the CPU oracle takes
+    seconds) with injected prior noise against the fp64 oracle: in bf16x3 mode this runs the per-frame reverse chain with
+    the recurrent products as three bf16 MFMAs."""
+    hp = final_model_hparams(50, 27, K=4)
+    m, sd = perturbed_model(hp, gpu_device)
+    m.precision = precision
+    m.eval()
+    B, seq_len = 6, 24 + 14
+    g = torch.Generator().manual_seed(3)
+    data = {"p1_face": torch.randn(B, 24, 50, generator=g)}
+    for name, d in (("p2_face", 50), ("p1_speech", 27), ("p2_speech", 27)):
+        data[name] = torch.randn(B, seq_len, d, generator=g)
+    noise = torch.randn(seq_len - 24, B, 50, generator=g) * 0.8
+    out = m.inference(seq_len, to_dev(data, gpu_device), noise=noise.to(gpu_device))
+    out2 = m.inference(seq_len, to_dev(data, gpu_device), noise=noise.to(gpu_device))   # graph replay
+    ref = oracle.seqglow_inference(hp, {k: v.double() for k, v in sd.items()}, seq_len, {k: v.double() for k, v in data.items()},
+                                   noise.double())
+    err = float((out.cpu().double() - ref).abs().max())
+    print("final-width sampling (%s): max abs err vs fp64 oracle %.2e" % (precision, err))
+    assert err < 1e-4 and torch.equal(out, out2)
