@@ -1,0 +1,94 @@
+"""Two (or more) ranks on ONE GPU over gloo: the engine's data-parallel step. Launch with
+  timeout 120 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29511 tools/dp_gloo_check.py
+Every rank prints a checksum of its parameters after ActNorm init + 4 Adam steps; rank 0 also steps ONE process' worth of the
+concatenated batch and prints the relative difference."""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+
+
+def _make(fx_name, device):
+    from argparse import Namespace
+    import random
+    import numpy as np
+    from helpers import Fixture
+    from lets_face_it_amd.glow.lets_face_it_glow import LetsFaceItGlow
+    fx = Fixture(fx_name)
+    hp = fx.hp
+    hp["gradient_clip_val"] = 20
+    hp["Train"]["use_negative_nll_loss"] = False
+    random.seed(0)
+    np.random.seed(0)
+    torch.manual_seed(0)
+    m = LetsFaceItGlow(Namespace(**hp))
+    m.seq_glow.load_state_dict(fx.state_dict(torch.float32))
+    m.to(device).train()
+    m.seq_glow.precision = "f32"
+    return fx, hp, m
+
+
+def _batches(fx, steps, B):
+    g = torch.Generator().manual_seed(7)
+    return [{k: torch.randn(B, fx.T, d, generator=g) for k, d in
+             (("p1_face", fx.C), ("p2_face", fx.C), ("p1_speech", fx.S), ("p2_speech", fx.S))} for _ in range(steps)]
+
+
+def run(rank, world, dev, tr):
+    from argparse import Namespace
+    fx, hp, m = _make("mid", dev)
+    if tr is None and world > 1:
+        from lets_face_it_amd.trainer import Trainer
+        tr = Trainer(Namespace(**hp), device=dev)
+        m.seq_glow.allreduce_hook = tr.allreduce_stats
+        m.nll_sync_hook = tr.sync_scalar
+        tr.broadcast_parameters(m)
+    B = 16
+    for step, full in enumerate(_batches(fx, 4, max(world, 1) * B if world > 1 else 2 * B)):
+        nb = full["p1_face"].shape[0]
+        lo, hi = (rank * B, (rank + 1) * B) if world > 1 else (0, nb)
+        shard = {k: v[lo:hi].to(dev).contiguous() for k, v in full.items()}
+        gm = torch.Generator().manual_seed(100 + step)
+        masks = {}
+        for e in m.seq_glow.spec.encoders:
+            if e.dropout > 0:
+                keep = 1.0 - e.dropout
+                mk = (torch.rand(fx.T - fx.start, nb, e.hist, generator=gm) < keep).float() / keep
+                masks[e.name] = mk[:, lo:hi].contiguous().to(dev)
+        m.seq_glow.injected_masks = masks
+        if world > 1:
+            m.fused_training_step(shard, 1e-3, world, tr.allreduce_grads)
+        else:
+            m.fused_training_step(shard, 1e-3)
+        print("rank %d step %d done" % (rank, step), flush=True)
+    torch.cuda.synchronize()
+    return m.seq_glow.engine.params.detach().cpu()
+
+
+def main():
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    print("rank %d of %d up" % (rank, world), flush=True)
+    p = run(rank, world, dev, None)
+    print("rank %d params checksum %.9e" % (rank, float(p.double().sum())), flush=True)
+    gathered = [torch.zeros_like(p) for _ in range(world)]
+    dist.all_gather(gathered, p)
+    if rank == 0:
+        same = all(torch.equal(gathered[0], g) for g in gathered)
+        ref = run(0, 1, dev, None)
+        err = float((p - ref).abs().max() / ref.abs().max())
+        print("ranks identical: %s; vs one process on the concatenated batch: max rel diff %.2e" % (same, err), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
