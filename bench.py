@@ -270,11 +270,15 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d" % (args.gpus, args.gpus))
-    device = torch.device("cuda", local_rank)
+    # LFI_DIST_BACKEND=gloo rehearses the N > 1 path on a box with fewer GPUs than ranks (ranks share cards, tensors travel
+    # through the host): same code path, barriers and timing; the default is RCCL with one GPU per rank
+    backend = os.environ.get("LFI_DIST_BACKEND", "nccl")
+    ndev = torch.cuda.device_count()
+    device = torch.device("cuda", local_rank % ndev if (backend != "nccl" and ndev > 0) else local_rank)
     torch.cuda.set_device(device)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)
+        dist.init_process_group(backend, rank=rank, world_size=world)
 
     import random
     import numpy as np
