@@ -236,12 +236,13 @@ int lfi_invconv_weights(int C, const float* inv_l, const float* inv_u, const flo
 /* The autoregressive prev_p1_face window may itself go through a ModalityEncoder (the reference's hparam search draws
  * p1_face "enc" from {rnn, mlp, none}, hparam_tuning_configs/large_hparam_search.py:45-62): then its features are
  * recomputed for every generated frame. kind 0: "none" (raw window); 1: "mlp" = LeakyReLU(window W1^T + b1);
- * 2: "rnn" = GRU from h0 = 0 over the window (output folded: the hidden state once). `col` = first column of the
+ * 2: "rnn" = GRU from h0 = 0 over the window (output folded: the hidden state once); 3: "lstm" = nn.LSTM likewise
+ * (glow/models.py:27-33,65-69; four gate blocks in w_ih / w_hh / b_ih / b_hh). `col` = first column of the
  * p1_face block in the (folded) feature layout / in wct; eval mode (no dropout), as SeqGlow.inference runs. */
 typedef struct {
   int kind, hid;
   const float *w1, *b1;                        /* mlp: [hid][hist1*C], [hid] */
-  const float *w_ih, *w_hh, *b_ih, *b_hh;      /* rnn: [3hid][C], [3hid][hid], [3hid], [3hid] */
+  const float *w_ih, *w_hh, *b_ih, *b_hh;      /* rnn: [3hid][C], [3hid][hid], [3hid], [3hid]; lstm: 4hid */
   int col;
 } lfi_p1enc;
 

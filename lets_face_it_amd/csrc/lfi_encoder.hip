@@ -677,11 +677,7 @@ __global__ __launch_bounds__(ENC_NT, 2) void enc_gru_bwd_fused_kernel(EncArgs a,
             const float danr = dan * rr;
             const unsigned o = 3u * wo[e] + j4;
             enc_st(dan, bgi, wo[e] + j4, 0);
-#ifdef LFI_DEBUG_HP
-            enc_st(dar, bgh, o, 0); enc_st(hp[e] * hp_on, bgh, o, h4); enc_st(dhn, bgh, o, 2 * h4);
-#else
             enc_st(dar, bgh, o, 0); enc_st(dau, bgh, o, h4); enc_st(danr, bgh, o, 2 * h4);
-#endif
             dg[0][t][r] = dau; dg[1][t][r] = danr;
             if (s > 0) {
               const int rl = enc_rowl(rg, r, halfv);

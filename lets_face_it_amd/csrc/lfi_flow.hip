@@ -2984,13 +2984,26 @@ extern "C" int lfi_flow_param_grads(const lfi_flow_dims* d, const lfi_flow_param
   lfi_gemm_desc q = {};
   q.batch = Ks; q.accumulate = accumulate; q.splitk = splitk; q.work = gws; q.precision = d->gemm_precision;
   q.a_kcontig = 0; q.b_kcontig = 0; q.K = F;
+  // K split (<= 16, what the workspace holds) of a K = F product with Ks x few 128 x 128 output tiles: the one that best
+  // fills whole rounds of the 512 co-resident workgroups, less 3 % per extra partial for the reduce pass
+  auto fill_split = [&](int M, int N, int K) {
+    const double tiles = (double)lfi_cdiv(M, 128) * lfi_cdiv(N, 128) * Ks;
+    int best = 1;
+    double best_score = -1.0;
+    for (int sk = 1; sk <= splitk && K / sk >= 512; ++sk) {
+      const double wg = tiles * sk, rounds = (double)(long)((wg + 511.0) / 512.0);
+      const double score = wg / (rounds * 512.0) * (1.0 - 0.03 * (sk - 1));
+      if (score > best_score + 1e-9) { best_score = score; best = sk; }
+    }
+    return best;
+  };
   // w_fl[k] (Cout x H) = dlin[k]^T h[k]
-  q.M = Cout; q.N = H; q.A = f.bDlin; q.lda = f.ldo; q.strideA = (long)F * f.ldo; q.B = f.sH; q.ldb = H; q.strideB = (long)F * H;
+  q.M = Cout; q.N = H; q.splitk = fill_split(Cout, H, F); q.A = f.bDlin; q.lda = f.ldo; q.strideA = (long)F * f.ldo; q.B = f.sH; q.ldb = H; q.strideB = (long)F * H;
   q.C = g->w_fl; q.ldc = H; q.strideC = (long)Cout * H;
   if ((rc = lfi_gemm_f32(&q, stream))) return rc;
   // w_hh[k] (G x H) = dgh[k][n >= 1]^T h[k][n - 1]
   if (f.N > 1) {
-    q.K = F - B; q.M = G; q.N = H; q.A = f.bDgh + (long)B * G; q.lda = G; q.strideA = (long)F * G; q.B = f.sH; q.ldb = H;
+    q.K = F - B; q.M = G; q.N = H; q.splitk = fill_split(G, H, F - B); q.A = f.bDgh + (long)B * G; q.lda = G; q.strideA = (long)F * G; q.B = f.sH; q.ldb = H;
     q.strideB = (long)F * H; q.C = g->w_hh; q.ldc = H; q.strideC = (long)G * H;
     if ((rc = lfi_gemm_f32(&q, stream))) return rc;
   } else if (!accumulate) {
@@ -2999,17 +3012,17 @@ extern "C" int lfi_flow_param_grads(const lfi_flow_dims* d, const lfi_flow_param
   q.K = F;
   // w_ih[k][:, :Ch] (G x Ch) = dgi[k]^T z1[k]
   if (Ch > 0) {
-    q.M = G; q.N = Ch; q.A = f.bDgi; q.lda = G; q.strideA = (long)F * G; q.B = f.sY; q.ldb = f.ldc; q.strideB = (long)F * f.ldc;
+    q.M = G; q.N = Ch; q.splitk = fill_split(G, Ch, F); q.A = f.bDgi; q.lda = G; q.strideA = (long)F * G; q.B = f.sY; q.ldb = f.ldc; q.strideB = (long)F * f.ldc;
     q.C = g->w_ih; q.ldc = I; q.strideC = (long)G * I;
     if ((rc = lfi_gemm_f32(&q, stream))) return rc;
   }
   // w_ih[k][:, Ch:] (G x D) = dgi[k]^T c[:, kD:(k+1)D]
-  q.M = G; q.N = D; q.A = f.bDgi; q.lda = G; q.strideA = (long)F * G; q.B = c; q.ldb = ldc; q.strideB = D;
+  q.M = G; q.N = D; q.splitk = fill_split(G, D, F); q.A = f.bDgi; q.lda = G; q.strideA = (long)F * G; q.B = c; q.ldb = ldc; q.strideB = D;
   q.C = g->w_ih + Ch; q.ldc = I; q.strideC = (long)G * I;
   if ((rc = lfi_gemm_f32(&q, stream))) return rc;
   // dW[k] (C x C) = a[k]^T dy[k]  -> LU parameter gradients
   q.accumulate = 0;
-  q.M = C; q.N = C; q.A = f.sA; q.lda = f.ldc; q.strideA = (long)F * f.ldc; q.B = f.bDy; q.ldb = f.ldc; q.strideB = (long)F * f.ldc;
+  q.M = C; q.N = C; q.splitk = fill_split(C, C, F); q.A = f.sA; q.lda = f.ldc; q.strideA = (long)F * f.ldc; q.B = f.bDy; q.ldb = f.ldc; q.strideB = (long)F * f.ldc;
   q.C = dW; q.ldc = C; q.strideC = (long)C * C;
   if ((rc = lfi_gemm_f32(&q, stream))) return rc;
   // constant log-det terms: nll has -(C sum(logs))/ln2 per frame -> d/dlogs = -C/ln2 * gscale * F
@@ -3088,10 +3101,12 @@ extern "C" long lfi_flow_sample_p1_work_floats(const lfi_flow_dims* d, const lfi
   if (!d || !e || e->kind == 0) return 0;
   const long hid4 = (e->hid + 3) & ~3;
   long n = (long)d->B * hid4 + 16;
-  if (e->kind == 2) {
+  if (e->kind == 2 || e->kind == 3) {
+    const int ng = e->kind == 3 ? 4 : 3;
     lfi_enc_desc ed = {};
-    ed.B = d->B; ed.T = hist1; ed.N = 1; ed.start = hist1 - 1; ed.hist = hist1; ed.hid = e->hid;
-    n += (long)d->B * hist1 * 3 * e->hid + lfi_encode_windows_work_floats(&ed) + (long)hist1 * d->B * e->hid;
+    ed.B = d->B; ed.T = hist1; ed.N = 1; ed.start = hist1 - 1; ed.hist = hist1; ed.hid = e->hid; ed.lstm = e->kind == 3;
+    n += (long)d->B * hist1 * ng * e->hid + lfi_encode_windows_work_floats(&ed) + (long)hist1 * d->B * e->hid;
+    if (e->kind == 3) n += (long)hist1 * d->B * 5 * e->hid;   // the LSTM encoder keeps its cell state in the gate stash
   }
   return n;
 }
@@ -3117,7 +3132,7 @@ extern "C" int lfi_flow_sample_seq(const lfi_flow_dims* d, const lfi_flow_params
   LFI_REQUIRE((long)hist1 * d->C <= E, "lfi_flow_sample_seq: window wider than the feature vector");
   LFI_REQUIRE(!d->lstm || cstate, "lfi_flow_sample_seq: the LSTM cell needs cstate");
   const int p1kind = p1 ? p1->kind : 0;
-  LFI_REQUIRE(p1kind >= 0 && p1kind <= 2, "lfi_flow_sample_seq: bad p1_face encoder kind %d", p1kind);
+  LFI_REQUIRE(p1kind >= 0 && p1kind <= 3, "lfi_flow_sample_seq: bad p1_face encoder kind %d", p1kind);
   LFI_REQUIRE(p1kind == 0 || (p1work && p1->hid > 0), "lfi_flow_sample_seq: encoded p1_face window needs p1work");
   const int p1col = p1 ? p1->col : 0;
   const int B = f.B, C = f.C, H = f.H, D = f.D, Ks = f.Ks, G = f.G;
@@ -3176,20 +3191,22 @@ extern "C" int lfi_flow_sample_seq(const lfi_flow_dims* d, const lfi_flow_params
         m.C = ebuf; m.ldc = hid4; m.bias = p1->b1; m.act = 1; m.slope = 0.01f; m.precision = d->gemm_precision;
         if ((rc = lfi_gemm_f32(&m, stream))) return rc;
       } else {
-        // GRU over the window: input projections of its hist1 frames (batched over the step), then the fused recurrence
-        float* xp = ebuf + (long)B * hid4;          // [B][hist1][3hid]
-        float* ework = xp + (long)B * hist1 * 3 * hid;
+        // GRU / LSTM over the window: input projections of its hist1 frames (batched over the step), then the recurrence
+        const int ng = p1kind == 3 ? 4 : 3;
+        float* xp = ebuf + (long)B * hid4;          // [B][hist1][ng * hid]
+        float* ework = xp + (long)B * hist1 * ng * hid;
         lfi_gemm_desc m = {};
-        m.batch = hist1; m.M = B; m.N = 3 * hid; m.K = C;
+        m.batch = hist1; m.M = B; m.N = ng * hid; m.K = C;
         m.A = q.A; m.lda = q.lda; m.a_kcontig = 1; m.strideA = C;
         m.B = p1->w_ih; m.ldb = C; m.b_kcontig = 1;
-        m.C = xp; m.ldc = (long)hist1 * 3 * hid; m.strideC = 3 * hid; m.precision = d->gemm_precision;
+        m.C = xp; m.ldc = (long)hist1 * ng * hid; m.strideC = ng * hid; m.precision = d->gemm_precision;
         if ((rc = lfi_gemm_f32(&m, stream))) return rc;
         lfi_enc_desc ed = {};
         ed.B = B; ed.T = hist1; ed.N = 1; ed.start = hist1 - 1; ed.hist = hist1; ed.hid = hid;
-        ed.ldcond = hid4; ed.col = 0; ed.precision = d->gemm_precision; ed.dup = 0;
-        float* hs = ework + lfi_encode_windows_work_floats(&ed);   // unfused path only: state sequence
-        if ((rc = lfi_encode_windows_fwd(&ed, xp, p1->w_hh, p1->b_ih, p1->b_hh, nullptr, ebuf, nullptr, hs, ework, stream)))
+        ed.ldcond = hid4; ed.col = 0; ed.precision = d->gemm_precision; ed.dup = 0; ed.lstm = p1kind == 3;
+        float* hs = ework + lfi_encode_windows_work_floats(&ed);   // unfused path / LSTM: state sequence
+        float* gst = p1kind == 3 ? hs + (long)hist1 * B * hid : nullptr;   // LSTM: gate + cell stash, 5 * hid per (step, row)
+        if ((rc = lfi_encode_windows_fwd(&ed, xp, p1->w_hh, p1->b_ih, p1->b_hh, nullptr, ebuf, gst, hs, ework, stream)))
           return rc;
       }
       q.K = hid; q.A = ebuf; q.lda = hid4;

@@ -1206,6 +1206,35 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(GemmArgs g) {
   }
 }
 
+// Four columns per thread (N, ldc, ldg multiples of 4; work, C, G 16-byte aligned): same sums in the same order as above.
+__global__ __launch_bounds__(256) void gemm_splitk_reduce4_kernel(GemmArgs g) {
+  const long mn = (long)g.M * g.N, mn4 = mn >> 2;
+  const int n4 = g.N >> 2;
+  const int batch = blockIdx.y;
+  const float* bias = g.bias ? g.bias + batch * g.strideBias : nullptr;
+  const float* G = g.G ? g.G + batch * g.strideG : nullptr;
+  float* C = g.C + batch * g.strideC;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < mn4; i += (long)gridDim.x * 256) {
+    const int row = (int)(i / n4), col = (int)(i - (long)row * n4) * 4;
+    const float* w = g.work + (long)batch * g.splitk * mn + 4 * i;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    for (int s = 0; s < g.splitk; ++s) v += __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(w + (long)s * mn));
+    f32x4* cp = reinterpret_cast<f32x4*>(C + (long)row * g.ldc + col);
+    f32x4 c0 = {0.f, 0.f, 0.f, 0.f};
+    if (g.accumulate) c0 = *cp;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float x = v[j];
+      if (bias) x += bias[col + j];
+      if (g.accumulate == 2) x += c0[j];
+      x = apply_act(x, g.act, g.slope, G, (long)row * g.ldg + col + j);
+      if (g.accumulate == 1) x += c0[j];
+      v[j] = x;
+    }
+    *cp = v;
+  }
+}
+
 template <int BM, int BN, int WM, int WN, bool VEC>
 void launch_gemm_v(const GemmArgs& a, int akc, int bkc, dim3 grid, hipStream_t st) {
   if (akc && bkc) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, true, true, VEC>), grid, dim3(256), 0, st, a);
@@ -1409,8 +1438,16 @@ extern "C" int lfi_gemm_f32(const lfi_gemm_desc* d, void* stream) {
   LFI_LAUNCH_CHECK("lfi_gemm_f32");
   if (splitk > 1) {
     const long mn = (long)d->M * d->N;
-    dim3 rgrid((unsigned)min((long)lfi_cdiv(mn, 256), 2048L), d->batch);
-    hipLaunchKernelGGL(gemm_splitk_reduce_kernel, rgrid, dim3(256), 0, st, a);
+    auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    const bool red4 = d->N % 4 == 0 && al16(d->work) && al16(d->C) && d->ldc % 4 == 0 && d->strideC % 4 == 0 &&
+                      (!d->G || (al16(d->G) && d->ldg % 4 == 0 && d->strideG % 4 == 0));
+    if (red4) {
+      dim3 rgrid((unsigned)min((long)lfi_cdiv(mn / 4, 256), 2048L), d->batch);
+      hipLaunchKernelGGL(gemm_splitk_reduce4_kernel, rgrid, dim3(256), 0, st, a);
+    } else {
+      dim3 rgrid((unsigned)min((long)lfi_cdiv(mn, 256), 2048L), d->batch);
+      hipLaunchKernelGGL(gemm_splitk_reduce_kernel, rgrid, dim3(256), 0, st, a);
+    }
     LFI_LAUNCH_CHECK("lfi_gemm_f32 split-k reduce");
   }
   return LFI_OK;

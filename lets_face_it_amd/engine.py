@@ -311,6 +311,17 @@ class GlowEngine:
         return max(1, min(16, 768 // max(tiles, 1), K // 1024))
 
     @staticmethod
+    def _long_k_splitk(M, N, K, kmin=1024):
+        """K split of a long-K product with a handful of output tiles (the BPTT weight gradients: K = steps x windows): as many
+        splits as fill one round of co-resident workgroups of the tile shape the library's plan will pick (256 x 256: one per CU,
+        rate 1.12; 128 x 128: two per CU), each keeping at least kmin of K."""
+        t256 = ((M + 255) // 256) * ((N + 255) // 256)
+        t128 = ((M + 127) // 128) * ((N + 127) // 128)
+        wide = 1.12 * M * N / (t256 * 65536.0) >= M * N / (t128 * 16384.0)
+        sk = 256 // t256 if wide else 512 // t128
+        return max(1, min(sk, K // kmin))
+
+    @staticmethod
     def _tail_splitk(M, N, K, batch=1, slots=512):
         """Smallest K split (<= 8) that wastes < 15 % of the last round of `slots` co-resident workgroups."""
         tiles = ((M + 127) // 128) * ((N + 127) // 128) * batch
@@ -602,7 +613,7 @@ class GlowEngine:
         if e.in_dim % 4 == 0 or xa is None or os.environ.get("LFI_NO_XPAD") == "1":
             xa, ldi = x, e.in_dim
         self.gemm(G3, e.in_dim, rows, dxp, G3, 0, xa, ldi, 0, self.view(gname + "weight_ih", self.grads), e.in_dim,
-                  splitk=max(1, min(32, rows // 1024)))
+                  splitk=self._long_k_splitk(G3, e.in_dim, rows, kmin=512))
         gbi, gbh = self.view(gname + "bias_ih", self.grads), self.view(gname + "bias_hh", self.grads)
         if part is not None:  # per-workgroup partial sums of (d r, d z, d n, d n * r) left by the fused backward kernel
             self.colsum(part, 4 * hid, 0, prow, G3, 1, gbi, 0)
@@ -613,7 +624,7 @@ class GlowEngine:
         if e.hist > 1:
             kk = (e.hist - 1) * F
             self.gemm(G3, hid, kk, dgh, G3, 0, hseq, hid, 0, self.view(gname + "weight_hh", self.grads), hid,
-                      splitk=max(1, min(64, kk // 2048)), a_off=F * G3)
+                      splitk=self._long_k_splitk(G3, hid, kk), a_off=F * G3)
         else:
             self.view(gname + "weight_hh", self.grads).zero_()
         if part is None:
@@ -754,16 +765,12 @@ class GlowEngine:
         nz[:nframes * B * s.C].view_as(noise).copy_(noise)
         p = self._flow_params()
         hist1 = e1.hist
-        # an encoded prev_p1_face window (enc: mlp / rnn) is re-encoded for every generated frame inside the sampler
+        # an encoded prev_p1_face window (enc: mlp / rnn / lstm) is re-encoded for every generated frame inside the sampler
         p1 = P1Enc()
-        if e1.enc == "lstm":
-            raise NotImplementedError("sampling with an LSTM-encoded prev_p1_face window: the per-frame re-encoding inside the "
-                                      "sampler covers enc 'none', 'mlp' and 'rnn' (the hparam search space, "
-                                      "hparam_tuning_configs/large_hparam_search.py:45-62)")
-        p1.kind, p1.hid, p1.col = {"none": 0, "mlp": 1, "rnn": 2}[e1.enc], e1.hid, e1.fcol
+        p1.kind, p1.hid, p1.col = {"none": 0, "mlp": 1, "rnn": 2, "lstm": 3}[e1.enc], e1.hid, e1.fcol
         if e1.enc == "mlp":
             p1.w1, p1.b1 = self.view("enc.p1_face.mlp_weight").data_ptr(), self.view("enc.p1_face.mlp_bias").data_ptr()
-        elif e1.enc == "rnn":
+        elif e1.enc in ("rnn", "lstm"):
             for leaf in ENC_LEAVES:
                 setattr(p1, {"weight_ih": "w_ih", "weight_hh": "w_hh", "bias_ih": "b_ih", "bias_hh": "b_hh"}[leaf],
                         self.view("enc.p1_face." + leaf).data_ptr())

@@ -119,6 +119,17 @@ def make_config(name):
         c["p2_face"].update(history=5, dim=16, hidden_dim=24, enc="lstm")
         c["p1_speech"].update(history=2, hidden_dim=16)
         c["p2_speech"].update(history=4, hidden_dim=20, enc="lstm")
+    elif name == "p1lstm":
+        # an LSTM-encoded prev_p1_face window: re-encoded for every generated frame in SeqGlow.inference
+        c["cond_dim"] = 32
+        hp["Data"]["speech_dim"] = 8
+        g.update(K=2, L=1, hidden_channels=32)
+        hp["Train"]["seq_len"] = 20
+        dims = dict(B=4, T=20)
+        c["p1_face"].update(history=4, dim=16, hidden_dim=12, enc="lstm", dropout=0.3)
+        c["p2_face"].update(history=4, dim=16, hidden_dim=24)
+        c["p1_speech"].update(history=2, hidden_dim=16, enc="lstm")
+        c["p2_speech"].update(history=3, hidden_dim=20, enc="none")
     elif name == "p1mlp":
         c["cond_dim"] = 32
         hp["Data"]["speech_dim"] = 8
@@ -387,7 +398,7 @@ def main():
     from oracle import seqglow_oracle as oracle
     models, modules, utils = import_reference()
     lstm_shim(models)
-    names = sys.argv[1:] or ("tiny", "tiny_lstm", "tiny_additive", "odd", "mid", "mlp", "p1enc", "p1mlp", "framenb", "lstmenc")
+    names = sys.argv[1:] or ("tiny", "tiny_lstm", "tiny_additive", "odd", "mid", "mlp", "p1enc", "p1mlp", "framenb", "lstmenc", "p1lstm")
     for name in names:
         out = build(name, models, modules, oracle)
         path = os.path.join(HERE, name + ".npz")

@@ -6,7 +6,7 @@ import numpy as np
 import torch
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-FIXTURES = ("tiny", "tiny_lstm", "tiny_additive", "odd", "mid", "mlp", "p1enc", "p1mlp", "framenb", "lstmenc")
+FIXTURES = ("tiny", "tiny_lstm", "tiny_additive", "odd", "mid", "mlp", "p1enc", "p1mlp", "framenb", "lstmenc", "p1lstm")
 
 
 class Fixture:

@@ -37,6 +37,11 @@ GEMM_CASES = [
     (1000, 512, 96, 1, 0, 2, 1, False, 2, 0),
     (33, 1, 7, 1, 1, 1, 1, True, 0, 2),
     (16, 520, 280, 1, 1, 1, 1, False, 1, 2),
+    # the split-K reduce pass: four columns per thread with bias + activation + accumulate, the scalar form (N % 4 != 0),
+    # the leaky-gradient gate G read by the reduce
+    (260, 132, 1100, 1, 0, 2, 4, True, 1, 2),
+    (130, 70, 1200, 0, 1, 1, 3, True, 0, 1),
+    (256, 64, 2048, 1, 1, 2, 4, False, 2, 0),
 ]
 
 

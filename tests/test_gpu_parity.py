@@ -15,7 +15,7 @@ from oracle import seqglow_oracle as oracle
 
 pytestmark = pytest.mark.gpu
 
-GPU_FIXTURES = ("tiny", "tiny_lstm", "tiny_additive", "odd", "mid", "mlp", "p1enc", "p1mlp", "framenb", "lstmenc")
+GPU_FIXTURES = ("tiny", "tiny_lstm", "tiny_additive", "odd", "mid", "mlp", "p1enc", "p1mlp", "framenb", "lstmenc", "p1lstm")
 
 
 def build(fx, device, train=False, precision="f32"):

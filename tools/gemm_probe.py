@@ -57,6 +57,36 @@ def main():
                 print("    wave %d, cycles per k-tile: top->stage(late) %.0f | stage(late) %.0f | mfma+frag reads %.0f | stage(early) %.0f | "
                       "barrier %.0f | (epilogue total %.0f), k-tiles %d" % (w, v[0] / n, v[1] / n, v[2] / n, v[3] / n, v[4] / n, v[5], n))
 
+    # the two batched (one product per flow step) short-K shapes of the training step, with each tile shape pinned
+    Ks, F, D, G3 = 16, 14336, 512, 384
+    c = torch.randn(F, Ks * D, generator=g).to(dev)
+    dgi = torch.randn(Ks, F, G3, generator=g).to(dev)
+    wc = torch.randn(Ks, G3, D, generator=g).to(dev)
+    gic = torch.empty(Ks, F, G3, device=dev)
+    bias = torch.randn(Ks, G3, generator=g).to(dev)
+    for pin, label in ((0, "plan"), (0x10, "256 x 256"), (0x20, "128 x 128")):
+        eng.precision = args.precision | pin
+        runs = (
+            ("flow_gic  (c W_c^T + b)", 2.0 * F * G3 * D * Ks,
+             lambda: eng.gemm(F, G3, D, c, Ks * D, 1, wc, D, 1, gic, G3, bias=bias, batch=Ks, sA=D, sB=G3 * D, sC=F * G3, sBias=G3)),
+            ("flow_dpre (dgi W_c * leaky'(c), in place)", 2.0 * F * G3 * D * Ks,
+             lambda: eng.gemm(F, D, G3, dgi, G3, 1, wc, D, 0, c, Ks * D, act=2, slope=0.01, G=c, ldg=Ks * D, batch=Ks,
+                              sA=F * G3, sB=G3 * D, sC=D, sG=D)),
+        )
+        for name, flops, run in runs:
+            for _ in range(3):
+                run()
+            torch.cuda.synchronize()
+            s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            s.record()
+            for _ in range(args.reps):
+                run()
+            e.record()
+            torch.cuda.synchronize()
+            ms = s.elapsed_time(e) / args.reps
+            print("%-45s tiles %-9s: %.3f ms  %.1f TFLOP/s" % (name, label, ms, flops / ms / 1e9))
+    eng.precision = args.precision
+
 
 if __name__ == "__main__":
     main()
