@@ -918,7 +918,17 @@ __global__ __launch_bounds__(1024, 4) void gemm_bf16x3_256_kernel(GemmArgs g) {
     }
   }
   // 96 KB of LDS: 64 rows x 260 floats (66.5 KB) per pass of the wide epilogue
-  if (g.vecC) gemm_epilogue_wide<256, 1024>(g, acc, reinterpret_cast<float*>(xsmem), 64, m0, n0, wm, wn, l31, half, batch, split, 256);
+  // Two passes of 128 rows (133 KB of LDS) rather than four of 64: half the barriers and operand round trips, and 8 instead
+  // of 4 waves in the register phase. Measured (tools/gemm_probe.py, same box): cond_transform forward 0.804 -> 0.767 ms, the
+  // in-place dpre product (K = 384, epilogue-heavy: reads G, writes C) 0.561 -> 0.501 ms. Tried on top and dropped: requesting
+  // pass p + 1's operand rows (8 float4 per thread) before pass p's register phase - the kernel then spills (64 - 76 bytes
+  // of scratch per lane) and is slower (0.537 vs 0.483 ms on dpre); starting the first round of workgroups in 8 phases so
+  // that the rounds' epilogue bursts do not coincide (s_memtime-timed start delays of 0 .. 7 x 3000 - 24000 ticks) - no effect
+  // for any spacing.
+#ifndef LFI_EPI_ROWS
+#define LFI_EPI_ROWS 128
+#endif
+  if (g.vecC) gemm_epilogue_wide<256, 1024>(g, acc, reinterpret_cast<float*>(xsmem), LFI_EPI_ROWS, m0, n0, wm, wn, l31, half, batch, split, 256);
   else gemm_epilogue_n<256>(g, acc, m0, n0, wm, wn, l31, half, batch, split);
 }
 
@@ -1381,7 +1391,9 @@ extern "C" int lfi_gemm_f32(const lfi_gemm_desc* d, void* stream) {
     else if (d->b_kcontig) hipLaunchKernelGGL((gemm_bf16x3_256w_kernel<false, true>), grid, dim3(Y2NT), lds, st, a);
     else hipLaunchKernelGGL((gemm_bf16x3_256w_kernel<false, false>), grid, dim3(Y2NT), lds, st, a);
   } else if (use_x3 && shape == 3) {
-    const size_t lds = (size_t)2 * 4 * YIMG * sizeof(__bf16);
+    // main loop: two buffers of four 256 x 16 bf16 planes (96 KB); the wide epilogue: LFI_EPI_ROWS rows x 260 floats per pass
+    const size_t lds_loop = (size_t)2 * 4 * YIMG * sizeof(__bf16), lds_epi = (size_t)LFI_EPI_ROWS * 260 * sizeof(float);
+    const size_t lds = lds_loop > lds_epi ? lds_loop : lds_epi;
     static bool attr256 = false;
     if (!attr256) {
       hipError_t e1 = hipFuncSetAttribute((const void*)gemm_bf16x3_256_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
