@@ -111,6 +111,9 @@ int lfi_encode_windows_bwd(const lfi_enc_desc* d, const float* dcond, int lddcon
  * blocks {0, 1, 3} - no second pass over dgi / dgh. Returns the number of partial rows, 0 when the unfused path runs
  * (then bias_part is not written and the biases follow from lfi_colsum_f32 over dgi / dgh). */
 long lfi_encode_windows_bias_rows(const lfi_enc_desc* d);
+/* Folds bias_part ([rows][4][hid]) into both bias gradients in one launch: db_ih ([3hid]) = column sums of blocks {0, 1, 2},
+ * db_hh ([3hid]) = those of blocks {0, 1, 3}; rows are added in a fixed order (bit-reproducible). */
+int lfi_encode_windows_bias_grads(const float* bias_part, long rows, int hid, float* db_ih, float* db_hh, void* stream);
 /* dXp[b*T + p] = sum over the windows (n, s) that read row p of mask * dgi[(n*B+b)*hist + s]   (B*T x 3*hid)
  * Compact dgi: the input-side and hidden-side gate derivatives of a GRU differ only in the n block (d n vs d n * r), so the
  * fused backward (lfi_encode_windows_compact_dgi(d) == 1: hid <= 256, not lstm) writes dgi as that block alone,

@@ -91,6 +91,7 @@ def lib():
         "lfi_encode_windows_fwd": (i, [P(EncDesc), vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
         "lfi_encode_windows_bwd": (i, [P(EncDesc), vp, i, vp, vp, vp, vp, vp, vp, vp, vp]),
         "lfi_encode_windows_bias_rows": (l, [P(EncDesc)]),
+        "lfi_encode_windows_bias_grads": (i, [vp, l, i, vp, vp, vp]),
         "lfi_encode_windows_compact_dgi": (i, [P(EncDesc)]),
         "lfi_encode_windows_scatter": (i, [P(EncDesc), vp, vp, vp, vp, vp]),
         "lfi_gather_windows": (i, [vp, i, i, i, i, i, i, i, vp, vp, i, i, vp]),
@@ -134,7 +135,7 @@ def lib():
 EXPORTS = [
     "lfi_last_error", "lfi_version", "lfi_gemm_work_floats", "lfi_gemm_f32", "lfi_colsum_work_floats",
     "lfi_colsum_f32", "lfi_cols_fold", "lfi_encode_windows_work_floats", "lfi_encode_windows_fwd", "lfi_encode_windows_bwd",
-    "lfi_encode_windows_bias_rows",
+    "lfi_encode_windows_bias_rows", "lfi_encode_windows_bias_grads",
     "lfi_encode_windows_scatter", "lfi_encode_windows_compact_dgi", "lfi_gather_windows", "lfi_leaky_grad", "lfi_fill_frame_nb", "lfi_flow_prep_floats", "lfi_flow_prep",
     "lfi_flow_stash_floats", "lfi_flow_bstash_floats", "lfi_flow_stash_ptr", "lfi_flow_bstash_ptr",
     "lfi_flow_seq_fwd", "lfi_flow_seq_bwd", "lfi_flow_param_grads_work_floats", "lfi_flow_param_grads",

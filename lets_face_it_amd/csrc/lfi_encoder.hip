@@ -852,6 +852,29 @@ int fill_args(const lfi_enc_desc* d, EncArgs* a, const char* who) {
   return LFI_OK;
 }
 
+// part [rows][4 * hid] -> column sums; 32 columns per workgroup, 8 row groups added in a fixed order.
+// Blocks 0, 1 (d r, d z) go to both bias gradients, block 2 (d n) to db_ih, block 3 (d n * r) to db_hh's n block.
+__global__ __launch_bounds__(256) void enc_bias_fold_kernel(const float* __restrict__ part, long rows, int hid,
+                                                           float* __restrict__ db_ih, float* __restrict__ db_hh) {
+  __shared__ float red[8][33];
+  const int c = threadIdx.x & 31, rg = threadIdx.x >> 5;
+  const int col = blockIdx.x * 32 + c, W = 4 * hid;
+  float acc = 0.0f;
+  if (col < W)
+    for (long r = rg; r < rows; r += 8) acc += part[r * W + col];
+  red[rg][c] = acc;
+  __syncthreads();
+  if (rg == 0 && col < W) {
+    float v = red[0][c];
+#pragma unroll
+    for (int i = 1; i < 8; ++i) v += red[i][c];
+    const int blk = col / hid, j = col - blk * hid;
+    if (blk < 2) { db_ih[col] = v; db_hh[col] = v; }
+    else if (blk == 2) db_ih[col] = v;
+    else db_hh[2 * hid + j] = v;
+  }
+}
+
 int ew_blocks(long total) { return (int)(lfi_cdiv(total, 256) < 4096 ? lfi_cdiv(total, 256) : 4096); }
 
 }  // namespace
@@ -947,6 +970,15 @@ extern "C" long lfi_encode_windows_bias_rows(const lfi_enc_desc* d) {
   EncFused q = {};
   if (!d || d->lstm || !enc_fused_shape(d->hid, &q)) return 0;
   return (long)lfi_cdiv((long)d->N * d->B, q.R) * (ENC_NW / q.ncg);
+}
+
+extern "C" int lfi_encode_windows_bias_grads(const float* bias_part, long rows, int hid, float* db_ih, float* db_hh,
+                                             void* stream) {
+  LFI_REQUIRE(bias_part && db_ih && db_hh && rows > 0 && hid > 0, "lfi_encode_windows_bias_grads: bad arguments");
+  hipLaunchKernelGGL(enc_bias_fold_kernel, dim3(lfi_cdiv(4 * hid, 32)), dim3(256), 0, (hipStream_t)stream, bias_part, rows, hid,
+                     db_ih, db_hh);
+  LFI_LAUNCH_CHECK("lfi_encode_windows_bias_grads");
+  return LFI_OK;
 }
 
 extern "C" int lfi_encode_windows_bwd(const lfi_enc_desc* d, const float* dcond, int lddcond, const float* whh,

@@ -204,6 +204,7 @@ class GlowEngine:
         self.fold_b = torch.tensor(spec.fold_b, **i32)
         self.unfold = torch.tensor(spec.unfold, **i32)
         self.wct_f = torch.zeros(spec.Ks * spec.D, spec.ldf, **f32)  # folded cond_transform weights, rebuilt by run_prep
+        self._prep_stream = None
         self._ws = {}
         self._sample_graphs = {}
         self._sample_seen = {}
@@ -473,9 +474,23 @@ class GlowEngine:
         if N <= 0:
             raise ValueError("sequence length %d does not exceed the longest history %d" % (T, s.start))
         F = N * B
-        self.run_prep()
+        # W = P L U, its transposes / bf16 images and the folded cond_transform weights (~0.11 ms of small launches) depend on
+        # the parameters only: on a second stream they run under the window encoders (LFI_NO_PREP_OVERLAP=1: in line)
+        overlap = os.environ.get("LFI_NO_PREP_OVERLAP") != "1"
+        if overlap:
+            cur = torch.cuda.current_stream(self.device)
+            if self._prep_stream is None:
+                self._prep_stream = torch.cuda.Stream(device=self.device)
+            self._prep_stream.wait_stream(cur)
+            with torch.cuda.stream(self._prep_stream):
+                self.run_prep()
+                prep_done = self._prep_stream.record_event()
+        else:
+            self.run_prep()
         cond = self._buf("cond", F * s.ldf)
         self.build_features(batch, x, B, T, masks, cond, with_stash)
+        if overlap:
+            cur.wait_event(prep_done)
         cbuf, gic = self._project(cond, F)
         dims = self._flow_dims(B, N)
         if init_actnorm is not None:
@@ -547,7 +562,8 @@ class GlowEngine:
         dpre = ctx.cbuf
         # cond_transform weight / bias gradients for all steps at once
         dwf = self._buf("dwct_f", KD * s.ldf)
-        self.gemm(KD, s.Ef, F, dpre, KD, 0, ctx.cond, s.ldf, 0, dwf, s.ldf, tag="gemm_cond_wgrad", splitk=0)
+        # (all ldf columns: the padding columns of cond are zero, and a 4-float granular N keeps the split-K reduce on 16-byte rows)
+        self.gemm(KD, s.ldf, F, dpre, KD, 0, ctx.cond, s.ldf, 0, dwf, s.ldf, tag="gemm_cond_wgrad", splitk=0)
         # both copies of a duplicated input column receive the folded column's gradient
         check(self.L.lfi_cols_fold(dwf.data_ptr(), s.ldf, KD, self.unfold.data_ptr(), None, s.E,
                                    self.fview("wct", self.grads).data_ptr(), s.E, st), "lfi_cols_fold")
@@ -616,9 +632,8 @@ class GlowEngine:
                   splitk=self._long_k_splitk(G3, e.in_dim, rows, kmin=512))
         gbi, gbh = self.view(gname + "bias_ih", self.grads), self.view(gname + "bias_hh", self.grads)
         if part is not None:  # per-workgroup partial sums of (d r, d z, d n, d n * r) left by the fused backward kernel
-            self.colsum(part, 4 * hid, 0, prow, G3, 1, gbi, 0)
-            self.colsum(part, 4 * hid, 0, prow, 2 * hid, 1, gbh, 0)
-            self.colsum(part, 4 * hid, 0, prow, hid, 1, gbh[2 * hid:], 0, x_off=3 * hid)
+            check(self.L.lfi_encode_windows_bias_grads(part.data_ptr(), prow, hid, gbi.data_ptr(), gbh.data_ptr(), st),
+                  "lfi_encode_windows_bias_grads")
         else:
             self.colsum(dgi, G3, 0, e.hist * F, G3, 1, gbi, 0)
         if e.hist > 1:

@@ -443,7 +443,7 @@ class SeqGlow(nn.Module):
         for e in self.spec.encoders:
             if e.dropout > 0:  # nn.Dropout on ones(B, hist) per timestep (models.py:56-58)
                 keep = 1.0 - e.dropout
-                masks[e.name] = torch.bernoulli(torch.full((N, B, e.hist), keep, device=device)) / keep
+                masks[e.name] = torch.empty((N, B, e.hist), device=device).bernoulli_(keep).mul_(1.0 / keep)
         return masks or None
 
     def _allreduce(self):
