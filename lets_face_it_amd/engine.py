@@ -15,6 +15,7 @@ What the reference does instead: SeqGlow.forward's Python loop over timesteps an
 """
 import ctypes as C
 import math
+import contextlib
 import os
 
 import torch
@@ -204,7 +205,7 @@ class GlowEngine:
         self.fold_b = torch.tensor(spec.fold_b, **i32)
         self.unfold = torch.tensor(spec.unfold, **i32)
         self.wct_f = torch.zeros(spec.Ks * spec.D, spec.ldf, **f32)  # folded cond_transform weights, rebuilt by run_prep
-        self._prep_stream = None
+        self._side_stream = None
         self._ws = {}
         self._sample_graphs = {}
         self._sample_seen = {}
@@ -283,10 +284,31 @@ class GlowEngine:
             t.zero_()
         return t
 
+    # ------------------------------------------------------------------ second stream
+    # Launch-latency-bound and HBM-streaming side work (parameter preparation; the encoders' window scatter + dW_ih) runs on a
+    # second stream next to the MFMA-bound products it does not depend on (same-box A/B: -0.05 .. -0.14 ms per step).
+    # _fork(): the side stream, ordered after everything enqueued on the current stream so far (None with LFI_NO_OVERLAP=1:
+    # everything in line); _join(): the current stream waits for it. Side work gets its own scratch buffers (ws=...).
+    def _fork(self):
+        if os.environ.get("LFI_NO_OVERLAP") == "1":
+            return None
+        if self._side_stream is None:
+            self._side_stream = torch.cuda.Stream(device=self.device)
+        self._side_stream.wait_stream(torch.cuda.current_stream(self.device))
+        return self._side_stream
+
+    @staticmethod
+    def _on(side):
+        return torch.cuda.stream(side) if side is not None else contextlib.nullcontext()
+
+    def _join(self):
+        if self._side_stream is not None:
+            torch.cuda.current_stream(self.device).wait_stream(self._side_stream)
+
     # ------------------------------------------------------------------ low-level wrappers
     def gemm(self, M, N, K, A, lda, akc, Bm, ldb, bkc, Cm, ldc, bias=None, act=0, slope=0.01, G=None, ldg=0,
              batch=1, sA=0, sB=0, sC=0, sBias=0, sG=0, accumulate=0, splitk=1, a_off=0, b_off=0, c_off=0, bias_off=0,
-             tag=None):
+             tag=None, ws="scratch.gemm_splitk"):
         """Offsets are in floats relative to the tensors' data pointers."""
         g = GemmDesc()
         g.M, g.N, g.K = M, N, K
@@ -300,7 +322,7 @@ class GlowEngine:
         g.splitk = splitk
         g.precision = self.precision
         if splitk > 1 or splitk == 0:  # 0: the library picks the split (and the tile shape) that fills the chip
-            g.work = self._buf("scratch.gemm_splitk", batch * max(splitk, 8) * M * N).data_ptr()
+            g.work = self._buf(ws, batch * max(splitk, 8) * M * N).data_ptr()
         ev = self._tic(tag)
         check(self.L.lfi_gemm_f32(C.byref(g), _stream()), "lfi_gemm_f32")
         self._toc(tag, ev)
@@ -338,8 +360,8 @@ class GlowEngine:
                 break
         return best
 
-    def colsum(self, X, ldx, strideX, rows, cols, batch, out, strideOut, scale=1.0, accumulate=0, x_off=0):
-        w = self._buf("scratch.colsum", self.L.lfi_colsum_work_floats(rows, cols, batch))
+    def colsum(self, X, ldx, strideX, rows, cols, batch, out, strideOut, scale=1.0, accumulate=0, x_off=0, ws="scratch.colsum"):
+        w = self._buf(ws, self.L.lfi_colsum_work_floats(rows, cols, batch))
         check(self.L.lfi_colsum_f32(X.data_ptr() + 4 * x_off, ldx, strideX, rows, cols, batch, out.data_ptr(), strideOut,
                                     scale, accumulate, w.data_ptr(), _stream()), "lfi_colsum_f32")
 
@@ -475,22 +497,13 @@ class GlowEngine:
             raise ValueError("sequence length %d does not exceed the longest history %d" % (T, s.start))
         F = N * B
         # W = P L U, its transposes / bf16 images and the folded cond_transform weights (~0.11 ms of small launches) depend on
-        # the parameters only: on a second stream they run under the window encoders (LFI_NO_PREP_OVERLAP=1: in line)
-        overlap = os.environ.get("LFI_NO_PREP_OVERLAP") != "1"
-        if overlap:
-            cur = torch.cuda.current_stream(self.device)
-            if self._prep_stream is None:
-                self._prep_stream = torch.cuda.Stream(device=self.device)
-            self._prep_stream.wait_stream(cur)
-            with torch.cuda.stream(self._prep_stream):
-                self.run_prep()
-                prep_done = self._prep_stream.record_event()
-        else:
+        # the parameters only: on the second stream they run under the window encoders
+        side = self._fork()
+        with self._on(side):
             self.run_prep()
         cond = self._buf("cond", F * s.ldf)
         self.build_features(batch, x, B, T, masks, cond, with_stash)
-        if overlap:
-            cur.wait_event(prep_done)
+        self._join()
         cbuf, gic = self._project(cond, F)
         dims = self._flow_dims(B, N)
         if init_actnorm is not None:
@@ -567,6 +580,8 @@ class GlowEngine:
         # both copies of a duplicated input column receive the folded column's gradient
         check(self.L.lfi_cols_fold(dwf.data_ptr(), s.ldf, KD, self.unfold.data_ptr(), None, s.E,
                                    self.fview("wct", self.grads).data_ptr(), s.E, st), "lfi_cols_fold")
+        # (not on the second stream: streaming dpre for the bias sums next to the weight-gradient product that reads it too was
+        # measured 0.1 ms slower per step than in line)
         self.colsum(dpre, KD, 0, F, KD, 1, self.fview("bct", self.grads), 0)
         if after_flow is not None:
             after_flow()
@@ -585,6 +600,7 @@ class GlowEngine:
                     self._mlp_backward(e, ctx, dcond, ldd, e.fcol - col0)
                 else:
                     self._encoder_backward(e, ctx, dcond, ldd, e.fcol - col0)
+            self._join()
 
     def _mlp_backward(self, e, ctx, dcond, lddcond, col):
         """Linear + LeakyReLU window encoder: dpre = dfeat * leaky'(feat); dW = dpre^T window, db = colsum(dpre)."""
@@ -621,15 +637,19 @@ class GlowEngine:
               "lfi_encode_windows_bwd")
         mk = None if ctx.masks is None else ctx.masks.get(e.name)
         dxp = self._buf("dxp." + e.name, B * Tx * G3)
-        check(self.L.lfi_encode_windows_scatter(C.byref(d), dgi.data_ptr(), dgh.data_ptr(), ptr(mk), dxp.data_ptr(), st),
-              "lfi_encode_windows_scatter")
         gname = "enc.%s." % e.name
         rows = B * Tx
         xa, ldi = self._ws.get("xpad." + e.name), (e.in_dim + 3) // 4 * 4   # the padded copy the forward pass made
         if e.in_dim % 4 == 0 or xa is None or os.environ.get("LFI_NO_XPAD") == "1":
             xa, ldi = x, e.in_dim
-        self.gemm(G3, e.in_dim, rows, dxp, G3, 0, xa, ldi, 0, self.view(gname + "weight_ih", self.grads), e.in_dim,
-                  splitk=self._long_k_splitk(G3, e.in_dim, rows, kmin=512))
+        # the input side (window scatter: one HBM pass over dgi / dgh, then the thin dW_ih product) on the second stream, next
+        # to the MFMA-bound dW_hh product of the hidden side - and to the next modality's backward recurrence
+        side = self._fork()
+        with self._on(side):
+            check(self.L.lfi_encode_windows_scatter(C.byref(d), dgi.data_ptr(), dgh.data_ptr(), ptr(mk), dxp.data_ptr(),
+                                                    _stream()), "lfi_encode_windows_scatter")
+            self.gemm(G3, e.in_dim, rows, dxp, G3, 0, xa, ldi, 0, self.view(gname + "weight_ih", self.grads), e.in_dim,
+                      splitk=self._long_k_splitk(G3, e.in_dim, rows, kmin=512), ws="scratch.gemm_splitk.side")
         gbi, gbh = self.view(gname + "bias_ih", self.grads), self.view(gname + "bias_hh", self.grads)
         if part is not None:  # per-workgroup partial sums of (d r, d z, d n, d n * r) left by the fused backward kernel
             check(self.L.lfi_encode_windows_bias_grads(part.data_ptr(), prow, hid, gbi.data_ptr(), gbh.data_ptr(), st),
