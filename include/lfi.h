@@ -55,7 +55,8 @@ typedef struct {
   int precision;              /* 0: exact fp32 (f32-input MFMA). 1: bf16x3 — operands split into bf16 hi + lo on the fly,
                                  three bf16 MFMAs per step into fp32 accumulators (~2^-16 relative); needs 16-byte aligned
                                  operands, otherwise the exact kernel runs. Tests may OR in 0x10 (force the 256 x 256 tile
-                                 kernel) or 0x20 (force 128 x 128) instead of the library's own choice */
+                                 kernel) or 0x20 (force 128 x 128) instead of the library's own choice, and 0x40 (the opt-in 32-k
+                                 variant of the 256 x 256 kernel instead of the 16-k one) */
 } lfi_gemm_desc;
 
 long lfi_gemm_work_floats(const lfi_gemm_desc* d);

@@ -932,6 +932,186 @@ __global__ __launch_bounds__(1024, 4) void gemm_bf16x3_256_kernel(GemmArgs g) {
   else gemm_epilogue_n<256>(g, acc, m0, n0, wm, wn, l31, half, batch, split);
 }
 
+// ---------------------------------------------------------------------------------------------- bf16 x 3, 256 x 256, k-tile 32
+// The 16-wave kernel above with 32 k per barrier instead of 16 (two MFMA k-steps, 24 MFMAs per wave between barriers): half
+// the barriers and loop tops per unit of K. Two buffers of four 256 x 40 bf16 planes are exactly the CU's 160 KB of LDS, so
+// this is the largest k-tile the 256 x 256 shape can double-buffer. One k-tile of loads (two float4 per thread and operand)
+// is in flight: requested right after the previous one has been converted, consumed after the next tile's MFMAs.
+// Measured against the 16-k kernel: in isolation (tools/gemm_probe.py, same box, twice) cond_transform forward 0.78 -> 0.76 ms,
+// dgrad 0.74 -> 0.71, wgrad (both operands mn-contiguous) and the short-K batched products unchanged; inside the training
+// step (bench.py, same box, twice each) no gain: 9.86 / 10.02 ms per step with the 16-k kernel, 9.92 / 10.05 with this one,
+// the cond_transform forward launch 0.653 vs 0.659 ms. So the barrier is not what holds the loop back either, and the 16-k
+// kernel stays the default; this one is opt-in (LFI_GEMM_K32=1, or precision bit 0x40 in the tests).
+constexpr int ZBK = 32;
+constexpr int ZROW = ZBK + 8;            // bf16 per LDS row of a k-contiguous image: 80 B, 5 x 16 B: conflict-free b128 reads
+constexpr int ZIMG = 256 * ZROW;         // bf16 per plane (the k-major image, 32 x YPIT, is smaller)
+
+template <bool KC>
+struct ZStager {
+  int off, lds, kk;
+  long step2;   // floats between the thread's two float4 of a k-tile (k + 16)
+  __device__ __forceinline__ void init(int tid, int mn0, int MN, long ld) {
+    if (KC) {
+      const int k4 = (tid & 3) * 4, mn = tid >> 2;
+      kk = k4;
+      off = (min(mn0 + mn, MN - 1) - mn0) * (int)ld + k4;
+      lds = mn * ZROW + k4;
+      step2 = 16;
+    } else {
+      const int k = tid >> 6, mn4 = (tid & 63) * 4;
+      kk = k;
+      off = k * (int)ld + (mn0 + mn4 < MN ? mn4 : 0);
+      lds = k * YPIT + mn4;
+      step2 = 16 * ld;
+    }
+  }
+  __device__ __forceinline__ void load_full(const float* __restrict__ p, f32x4 (&r)[2]) const {
+    r[0] = *reinterpret_cast<const f32x4*>(p + off);
+    r[1] = *reinterpret_cast<const f32x4*>(p + off + step2);
+  }
+  __device__ __forceinline__ void load(const float* __restrict__ p, int krem, f32x4 (&r)[2]) const {
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int kh = kk + 16 * h;
+      r[h] = kh < krem ? *reinterpret_cast<const f32x4*>(p + off + h * step2) : z;
+      if (KC) {
+#pragma unroll
+        for (int j = 1; j < 4; ++j) r[h][j] = (kh + j < krem) ? r[h][j] : 0.0f;
+      }
+    }
+  }
+  __device__ __forceinline__ void store(__bf16* hi_img, __bf16* lo_img, const f32x4 (&r)[2]) const {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      uint2 hv, lv;
+      split2(r[h][0], r[h][1], &hv.x, &lv.x);
+      split2(r[h][2], r[h][3], &hv.y, &lv.y);
+      const int o = lds + (KC ? 16 * h : 16 * h * YPIT);
+      *reinterpret_cast<uint2*>(hi_img + o) = hv;
+      *reinterpret_cast<uint2*>(lo_img + o) = lv;
+    }
+  }
+};
+
+// fragment of MFMA k-step ks (0, 1) of a 32-k image; lane mapping as yfrag
+template <bool KC>
+__device__ __forceinline__ bf16x8 zfrag(const __bf16* img, int mn, int lane, int ks) {
+  if (KC) {
+    return *reinterpret_cast<const bf16x8*>(img + (mn + (lane & 31)) * ZROW + ks * 16 + (lane >> 5) * 8);
+  } else {
+    const int i = lane & 15, q = i >> 2, pp = i & 3;
+    const __bf16* ptr = img + (ks * 16 + 8 * (lane >> 5) + q) * YPIT + mn + 16 * ((lane >> 4) & 1) + 4 * pp;
+    typedef __attribute__((address_space(3))) ybf16x4 lds_v4;
+    const ybf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4*)ptr);
+    const ybf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4*)(ptr + 4 * YPIT));
+    bf16x8 r;
+    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+    r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+    return r;
+  }
+}
+
+template <bool AKC, bool BKC>
+__global__ __launch_bounds__(1024, 4) void gemm_bf16x3_256k_kernel(GemmArgs g) {
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, half = lane >> 5;
+  int tm, tn, batch, split;
+  gemm_tile_of_block(g, &tm, &tn, &batch, &split);
+  const int m0 = tm * 256, n0 = tn * 256;
+  const float* __restrict__ A = g.A + batch * g.strideA;
+  const float* __restrict__ B = g.B + batch * g.strideB;
+  const int kbeg = split * g.kchunk;
+  const int kend = min(g.K, kbeg + g.kchunk);
+  const int nkt = (kend - kbeg + ZBK - 1) / ZBK;
+
+  ZStager<AKC> sa;
+  ZStager<BKC> sb;
+  sa.init(tid, m0, g.M, g.lda);
+  sb.init(tid, n0, g.N, g.ldb);
+  const float* __restrict__ tA = AKC ? A + (long)m0 * g.lda + kbeg : A + (long)kbeg * g.lda + m0;
+  const float* __restrict__ tB = BKC ? B + (long)n0 * g.ldb + kbeg : B + (long)kbeg * g.ldb + n0;
+  const long stepA = AKC ? ZBK : (long)ZBK * g.lda, stepB = BKC ? ZBK : (long)ZBK * g.ldb;
+
+  f32x4 ra[2], rb[2];
+  auto load = [&](int kt) {
+    const int krem = kend - (kbeg + kt * ZBK);
+    sa.load(tA + kt * stepA, krem, ra);
+    sb.load(tB + kt * stepB, krem, rb);
+  };
+  auto load_full = [&](int kt) {
+    sa.load_full(tA + kt * stepA, ra);
+    sb.load_full(tB + kt * stepB, rb);
+  };
+  auto store = [&](int buf) {
+    __bf16* base = xsmem + buf * 4 * ZIMG;
+    sa.store(base, base + ZIMG, ra);
+    sb.store(base + 2 * ZIMG, base + 3 * ZIMG, rb);
+  };
+
+  const int wm = wave >> 2, wn = wave & 3;
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+  auto mma = [&](int buf) {
+    const __bf16* base = xsmem + buf * 4 * ZIMG;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+      for (int t2 = 0; t2 < 2; ++t2) {
+        ah[t2] = zfrag<AKC>(base, wm * 64 + t2 * 32, lane, ks);
+        al[t2] = zfrag<AKC>(base + ZIMG, wm * 64 + t2 * 32, lane, ks);
+        bh[t2] = zfrag<BKC>(base + 2 * ZIMG, wn * 64 + t2 * 32, lane, ks);
+        bl[t2] = zfrag<BKC>(base + 3 * ZIMG, wn * 64 + t2 * 32, lane, ks);
+      }
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt], bl[nt], acc[mt][nt], 0, 0, 0);
+          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+        }
+    }
+  };
+
+  // At the top of iteration kt: tile kt is in LDS buffer kt & 1, tile kt + 1 (raw fp32) in the registers.
+  // Long K: prologue and steady state without a conditional load (see the 16-k kernel); the last three tiles drain.
+  int kt = 0;
+  if (nkt > 3) {
+    load_full(0);
+    store(0);
+    load_full(1);
+    __syncthreads();
+    for (; kt + 3 < nkt; ++kt) {   // tile kt + 2 <= nkt - 2 is a complete one
+      mma(kt & 1);
+      __builtin_amdgcn_sched_barrier(0);
+      store((kt + 1) & 1);
+      load_full(kt + 2);
+      __syncthreads();
+    }
+  } else {
+    if (nkt > 0) { load(0); store(0); }
+    if (nkt > 1) load(1);
+    __syncthreads();
+  }
+  for (; kt < nkt; ++kt) {
+    mma(kt & 1);
+    if (kt + 1 < nkt) store((kt + 1) & 1);
+    if (kt + 2 < nkt) load(kt + 2);
+    __syncthreads();
+  }
+  if (g.vecC) gemm_epilogue_wide<256, 1024>(g, acc, reinterpret_cast<float*>(xsmem), LFI_EPI_ROWS, m0, n0, wm, wn, l31, half, batch, split, 256);
+  else gemm_epilogue_n<256>(g, acc, m0, n0, wm, wn, l31, half, batch, split);
+}
+
 // ---------------------------------------------------------------------------------------------- bf16 x 3, 256 x 256, 8 wide waves
 // What idles the matrix pipe in the 16-wave kernel above is its phase structure: after the per-k-tile barrier every wave
 // first reads its 8 operand fragments from LDS (128 KB per CU and k-tile: ~1000 cycles of LDS bandwidth with the pipe idle),
@@ -1258,6 +1438,15 @@ void launch_gemm(const GemmArgs& a, int akc, int bkc, dim3 grid, hipStream_t st)
   else launch_gemm_v<BM, BN, WM, WN, false>(a, akc, bkc, grid, st);
 }
 
+int gemm_use_k32() {   // LFI_GEMM_K32=1: the 32-k variant of the 256 x 256 bf16x3 kernel (also precision bit 0x40)
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("LFI_GEMM_K32");
+    v = (e && e[0] == '1') ? 1 : 0;
+  }
+  return v;
+}
+
 int kchunk_for(int K, int splitk) {
   int c = lfi_cdiv(K, splitk);
   return lfi_cdiv(c, BKT) * BKT;
@@ -1390,6 +1579,24 @@ extern "C" int lfi_gemm_f32(const lfi_gemm_desc* d, void* stream) {
     else if (d->a_kcontig) hipLaunchKernelGGL((gemm_bf16x3_256w_kernel<true, false>), grid, dim3(Y2NT), lds, st, a);
     else if (d->b_kcontig) hipLaunchKernelGGL((gemm_bf16x3_256w_kernel<false, true>), grid, dim3(Y2NT), lds, st, a);
     else hipLaunchKernelGGL((gemm_bf16x3_256w_kernel<false, false>), grid, dim3(Y2NT), lds, st, a);
+  } else if (use_x3 && shape == 3 && (gemm_use_k32() || (d->precision & 0x40))) {
+    const size_t lds = (size_t)2 * 4 * ZIMG * sizeof(__bf16);   // 160 KB; the epilogue's 133 KB fit inside
+    static bool attrk = false;
+    if (!attrk) {
+      hipError_t e1 = hipFuncSetAttribute((const void*)gemm_bf16x3_256k_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipError_t e2 = hipFuncSetAttribute((const void*)gemm_bf16x3_256k_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipError_t e3 = hipFuncSetAttribute((const void*)gemm_bf16x3_256k_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipError_t e4 = hipFuncSetAttribute((const void*)gemm_bf16x3_256k_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess) {
+        lfi_set_error("lfi_gemm_f32: cannot reserve %zu bytes of LDS for the 32-k 256 x 256 bf16x3 kernel", lds);
+        return LFI_ERR_LAUNCH;
+      }
+      attrk = true;
+    }
+    if (d->a_kcontig && d->b_kcontig) hipLaunchKernelGGL((gemm_bf16x3_256k_kernel<true, true>), grid, dim3(1024), lds, st, a);
+    else if (d->a_kcontig) hipLaunchKernelGGL((gemm_bf16x3_256k_kernel<true, false>), grid, dim3(1024), lds, st, a);
+    else if (d->b_kcontig) hipLaunchKernelGGL((gemm_bf16x3_256k_kernel<false, true>), grid, dim3(1024), lds, st, a);
+    else hipLaunchKernelGGL((gemm_bf16x3_256k_kernel<false, false>), grid, dim3(1024), lds, st, a);
   } else if (use_x3 && shape == 3) {
     // main loop: two buffers of four 256 x 16 bf16 planes (96 KB); the wide epilogue: LFI_EPI_ROWS rows x 260 floats per pass
     const size_t lds_loop = (size_t)2 * 4 * YIMG * sizeof(__bf16), lds_epi = (size_t)LFI_EPI_ROWS * 260 * sizeof(float);

@@ -152,10 +152,12 @@ def test_gemm_bf16x3(eng, gpu_device, akc, bkc, shape):
 
 
 @pytest.mark.parametrize("akc,bkc", [(1, 1), (1, 0), (0, 1), (0, 0)])
-@pytest.mark.parametrize("shape,splitk", [((700, 520, 330), 1), ((256, 300, 2100), 0), ((513, 257, 75), 1)])
-def test_gemm_bf16x3_256_tile(eng, gpu_device, akc, bkc, shape, splitk):
-    """The 256 x 256 kernel (transposing LDS reads for mn-contiguous operands, 2-deep register prefetch, wide epilogue),
-    pinned with precision | 0x10: ragged edges, a partial last k-tile, short K (drain loop only), library-chosen split."""
+@pytest.mark.parametrize("shape,splitk", [((700, 520, 330), 1), ((256, 300, 2100), 0), ((513, 257, 75), 1), ((300, 260, 128), 1)])
+@pytest.mark.parametrize("pin", [0x11, 0x51], ids=["k16", "k32"])
+def test_gemm_bf16x3_256_tile(eng, gpu_device, akc, bkc, shape, splitk, pin):
+    """The 256 x 256 kernels (k-tile 16, the default, and the opt-in k-tile 32: transposing LDS reads for mn-contiguous operands, register
+    prefetch, wide epilogue), pinned with precision | 0x10 (| 0x40): ragged edges, a partial last k-tile, short K (drain loop
+    only), one steady iteration, library-chosen split."""
     M, N, K = shape
     g = torch.Generator().manual_seed(7 * M + N + K + 2 * akc + bkc)
     r4 = lambda v: (v + 3) // 4 * 4  # noqa: E731
@@ -183,7 +185,7 @@ def test_gemm_bf16x3_256_tile(eng, gpu_device, akc, bkc, shape, splitk):
     bias = torch.randn(N, generator=g).to(gpu_device)
     ldc = r4(N) + 4
     Cm = torch.full((M, ldc), 7.0, device=gpu_device)
-    eng.precision = 0x11
+    eng.precision = pin
     try:
         eng.gemm(M, N, K, A, lda, akc, Bm, ldb, bkc, Cm, ldc, bias=bias, act=1, slope=0.01, splitk=splitk)
     finally:
