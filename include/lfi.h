@@ -192,7 +192,10 @@ typedef struct {
 long lfi_flow_param_grads_work_floats(const lfi_flow_dims* d);
 int lfi_flow_param_grads(const lfi_flow_dims* d, const lfi_flow_params* p, const float* prep,
                          const float* stash, const float* bstash, const float* c, long ldc, float gscale,
-                         const lfi_flow_grads* g, int accumulate, float* work, void* stream);
+                         const lfi_flow_grads* g, int accumulate, float* work, void* stream,
+                         void* bias_stream /* NULL = stream. Otherwise the bias / ActNorm column sums (streams over the
+                                              backward stash, independent of the weight-gradient products) are enqueued
+                                              there: the caller orders it after lfi_flow_seq_bwd and joins it */);
 
 /* Pointers into the stashes (host-side address arithmetic only). which: 0 a, 1 y, 2 x_out, 3 h, 4 gates, 5 o, 6 ldc,
  * 7 LSTM cell state (empty for GRU), 8 pipeline state for the forward stash; 0 dlin, 1 dgi, 2 dgh, 3 dy, 4 dx, 5 dh,

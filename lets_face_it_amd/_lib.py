@@ -106,7 +106,7 @@ def lib():
         "lfi_flow_seq_fwd": (i, [P(FlowDims), P(FlowParams), vp, vp, i, i, vp, vp, vp, vp, vp]),
         "lfi_flow_seq_bwd": (i, [P(FlowDims), P(FlowParams), vp, vp, f, vp, vp]),
         "lfi_flow_param_grads_work_floats": (l, [P(FlowDims)]),
-        "lfi_flow_param_grads": (i, [P(FlowDims), P(FlowParams), vp, vp, vp, vp, l, f, P(FlowGrads), i, vp, vp]),
+        "lfi_flow_param_grads": (i, [P(FlowDims), P(FlowParams), vp, vp, vp, vp, l, f, P(FlowGrads), i, vp, vp, vp]),
         "lfi_actnorm_init_stats": (i, [vp, i, i, vp, vp]),
         "lfi_actnorm_init_apply": (i, [vp, d, i, f, vp, vp, vp]),
         "lfi_flow_step": (i, [P(FlowDims), P(FlowParams), vp, i, i, vp, l, vp, vp, vp, vp, l, vp, vp, vp, i, vp]),

@@ -2961,25 +2961,28 @@ extern "C" long lfi_flow_param_grads_work_floats(const lfi_flow_dims* d) {
   const int splitk = 16;
   long gemm_ws = (long)f.Ks * splitk * ((long)f.G * f.I > (long)f.C * f.C ? (long)f.G * f.I : (long)f.C * f.C);
   long cs = lfi_colsum_work_floats(f.F > f.N * f.nbt ? f.F : f.N * f.nbt, f.G > 2 * f.C ? f.G : 2 * f.C, f.Ks);
-  return (long)f.Ks * f.C * f.C + gemm_ws + cs + 16;
+  // + a second split-K workspace for the products that run on bias_stream
+  return (long)f.Ks * f.C * f.C + gemm_ws + cs + 16 + gemm_ws + 16;
 }
 
 extern "C" int lfi_flow_param_grads(const lfi_flow_dims* d, const lfi_flow_params* p, const float* prep, const float* stash,
                                     const float* bstash, const float* c, long ldc, float gscale, const lfi_flow_grads* g,
-                                    int accumulate, float* work, void* stream) {
+                                    int accumulate, float* work, void* stream, void* bias_stream) {
   FlowK f = {};
   int rc = fill_flow(d, p, prep, &f, "lfi_flow_param_grads");
   if (rc) return rc;
   LFI_REQUIRE(prep && stash && bstash && c && g && work, "lfi_flow_param_grads: null pointer");
   bind_stash(&f, (float*)stash);
   bind_bstash(&f, (float*)bstash);
-  hipStream_t st = (hipStream_t)stream;
   const int Ks = f.Ks, F = f.F, B = f.B, C = f.C, H = f.H, G = f.G, I = f.I, Cout = f.Cout, Ch = f.Ch, D = f.D;
   float* dW = work;                       // [Ks][C][C]
   float* gws = dW + (long)Ks * C * C;     // split-k workspace
   const int splitk = 16;
   const long gws_floats = (long)Ks * splitk * ((long)G * I > (long)C * C ? (long)G * I : (long)C * C);
   float* cws = gws + gws_floats;          // colsum workspace
+  const long cws_floats = lfi_colsum_work_floats(F > f.N * f.nbt ? F : f.N * f.nbt, G > 2 * C ? G : 2 * C, Ks);
+  float* gws2 = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(cws + cws_floats) + 63) & ~(uintptr_t)63);  // dW split-K partials
+  void* bs = bias_stream ? bias_stream : stream;
 
   lfi_gemm_desc q = {};
   q.batch = Ks; q.accumulate = accumulate; q.splitk = splitk; q.work = gws; q.precision = d->gemm_precision;
@@ -2997,6 +3000,14 @@ extern "C" int lfi_flow_param_grads(const lfi_flow_dims* d, const lfi_flow_param
     }
     return best;
   };
+  // w_ih[k][:, Ch:] (G x D) = dgi[k]^T c[:, kD:(k+1)D]: the one MFMA-bound product (it reads c: before the caller's dpre
+  // product overwrites it)
+  q.M = G; q.N = D; q.splitk = fill_split(G, D, F); q.A = f.bDgi; q.lda = G; q.strideA = (long)F * G; q.B = c; q.ldb = ldc; q.strideB = D;
+  q.C = g->w_ih + Ch; q.ldc = I; q.strideC = (long)G * I;
+  if ((rc = lfi_gemm_f32(&q, stream))) return rc;
+  // The other products are thin (K = F frames, a few output tiles per step), HBM-bound at 3 - 4 TB/s. (Moving them to
+  // bias_stream as well, next to the caller's MFMA-bound products, was measured no better than leaving them here: same-box
+  // A/B 0.18 ms per step gained with them there, 0.21 ms without.)
   // w_fl[k] (Cout x H) = dlin[k]^T h[k]
   q.M = Cout; q.N = H; q.splitk = fill_split(Cout, H, F); q.A = f.bDlin; q.lda = f.ldo; q.strideA = (long)F * f.ldo; q.B = f.sH; q.ldb = H; q.strideB = (long)F * H;
   q.C = g->w_fl; q.ldc = H; q.strideC = (long)Cout * H;
@@ -3007,7 +3018,7 @@ extern "C" int lfi_flow_param_grads(const lfi_flow_dims* d, const lfi_flow_param
     q.strideB = (long)F * H; q.C = g->w_hh; q.ldc = H; q.strideC = (long)G * H;
     if ((rc = lfi_gemm_f32(&q, stream))) return rc;
   } else if (!accumulate) {
-    (void)hipMemsetAsync(g->w_hh, 0, sizeof(float) * (size_t)Ks * G * H, st);
+    (void)hipMemsetAsync(g->w_hh, 0, sizeof(float) * (size_t)Ks * G * H, (hipStream_t)stream);
   }
   q.K = F;
   // w_ih[k][:, :Ch] (G x Ch) = dgi[k]^T z1[k]
@@ -3016,33 +3027,31 @@ extern "C" int lfi_flow_param_grads(const lfi_flow_dims* d, const lfi_flow_param
     q.C = g->w_ih; q.ldc = I; q.strideC = (long)G * I;
     if ((rc = lfi_gemm_f32(&q, stream))) return rc;
   }
-  // w_ih[k][:, Ch:] (G x D) = dgi[k]^T c[:, kD:(k+1)D]
-  q.M = G; q.N = D; q.splitk = fill_split(G, D, F); q.A = f.bDgi; q.lda = G; q.strideA = (long)F * G; q.B = c; q.ldb = ldc; q.strideB = D;
-  q.C = g->w_ih + Ch; q.ldc = I; q.strideC = (long)G * I;
-  if ((rc = lfi_gemm_f32(&q, stream))) return rc;
-  // dW[k] (C x C) = a[k]^T dy[k]  -> LU parameter gradients
-  q.accumulate = 0;
+  // dW[k] (C x C) = a[k]^T dy[k]  -> LU parameter gradients, then a 16-workgroup kernel: on bias_stream (with a split-K
+  // workspace of their own) they run next to the products above instead of holding the chip for 0.14 ms
+  q.accumulate = 0; q.work = gws2;
   q.M = C; q.N = C; q.splitk = fill_split(C, C, F); q.A = f.sA; q.lda = f.ldc; q.strideA = (long)F * f.ldc; q.B = f.bDy; q.ldb = f.ldc; q.strideB = (long)F * f.ldc;
   q.C = dW; q.ldc = C; q.strideC = (long)C * C;
-  if ((rc = lfi_gemm_f32(&q, stream))) return rc;
+  if ((rc = lfi_gemm_f32(&q, bs))) return rc;
   // constant log-det terms: nll has -(C sum(logs))/ln2 per frame -> d/dlogs = -C/ln2 * gscale * F
   const float cconst = -(float)((double)gscale * (double)F * (double)C / 0.6931471805599453);
   {
     const size_t lds = (size_t)3 * C * C * sizeof(float);
     rc = set_flow_lds(flow_invconv_bwd_kernel, lds, "lfi_flow_param_grads");
     if (rc) return rc;
-    hipLaunchKernelGGL(flow_invconv_bwd_kernel, dim3(Ks), dim3(256), lds, st, f, dW, *g, cconst, accumulate);
+    hipLaunchKernelGGL(flow_invconv_bwd_kernel, dim3(Ks), dim3(256), lds, (hipStream_t)bs, f, dW, *g, cconst, accumulate);
     LFI_LAUNCH_CHECK("lfi_flow_param_grads invconv");
   }
-  // biases and the per-tile partial sums
-  if ((rc = lfi_colsum_f32(f.bDlin, f.ldo, (long)F * f.ldo, F, Cout, Ks, g->b_fl, Cout, 1.0f, accumulate, cws, stream))) return rc;
-  if ((rc = lfi_colsum_f32(f.bDgh, G, (long)F * G, F, G, Ks, g->b_hh, G, 1.0f, accumulate, cws, stream))) return rc;
-  if ((rc = lfi_colsum_f32(f.bDgi, G, (long)F * G, F, G, Ks, g->b_ih, G, 1.0f, accumulate, cws, stream))) return rc;
+  // biases and the per-tile partial sums: column sums over the backward stash only (HBM streams), independent of the
+  // products above - on bias_stream when the caller has forked one after the backward walk
+  if ((rc = lfi_colsum_f32(f.bDlin, f.ldo, (long)F * f.ldo, F, Cout, Ks, g->b_fl, Cout, 1.0f, accumulate, cws, bs))) return rc;
+  if ((rc = lfi_colsum_f32(f.bDgh, G, (long)F * G, F, G, Ks, g->b_hh, G, 1.0f, accumulate, cws, bs))) return rc;
+  if ((rc = lfi_colsum_f32(f.bDgi, G, (long)F * G, F, G, Ks, g->b_ih, G, 1.0f, accumulate, cws, bs))) return rc;
   const int prow = f.N * f.nbt;
-  if ((rc = lfi_colsum_f32(f.bPlfl, Cout, (long)prow * Cout, prow, Cout, Ks, g->l_fl, Cout, 1.0f, accumulate, cws, stream))) return rc;
-  if ((rc = lfi_colsum_f32(f.bPan, 2 * C, (long)prow * 2 * C, prow, C, Ks, g->an_logs, C, 1.0f, accumulate, cws, stream))) return rc;
-  if ((rc = lfi_colsum_f32(f.bPan + C, 2 * C, (long)prow * 2 * C, prow, C, Ks, g->an_bias, C, 1.0f, accumulate, cws, stream))) return rc;
-  hipLaunchKernelGGL(add_const_kernel, dim3(lfi_cdiv((long)Ks * C, 256)), dim3(256), 0, st, g->an_logs, (long)Ks * C, cconst);
+  if ((rc = lfi_colsum_f32(f.bPlfl, Cout, (long)prow * Cout, prow, Cout, Ks, g->l_fl, Cout, 1.0f, accumulate, cws, bs))) return rc;
+  if ((rc = lfi_colsum_f32(f.bPan, 2 * C, (long)prow * 2 * C, prow, C, Ks, g->an_logs, C, 1.0f, accumulate, cws, bs))) return rc;
+  if ((rc = lfi_colsum_f32(f.bPan + C, 2 * C, (long)prow * 2 * C, prow, C, Ks, g->an_bias, C, 1.0f, accumulate, cws, bs))) return rc;
+  hipLaunchKernelGGL(add_const_kernel, dim3(lfi_cdiv((long)Ks * C, 256)), dim3(256), 0, (hipStream_t)bs, g->an_logs, (long)Ks * C, cconst);
   LFI_LAUNCH_CHECK("lfi_flow_param_grads const");
   return LFI_OK;
 }
