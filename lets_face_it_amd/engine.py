@@ -762,6 +762,23 @@ class GlowEngine:
                                         float(clip or 0.0), gmul, lr, beta1, beta2, eps, self.step_count, st),
               "lfi_adam_clip_step")
 
+    def optimizer_state(self):
+        """Adam's moments and step count (checkpoints, engine re-binds). Moments are None before the first step."""
+        return {"step_count": int(self.step_count),
+                "adam_m": None if self.adam_m is None else self.adam_m.detach().clone(),
+                "adam_v": None if self.adam_v is None else self.adam_v.detach().clone()}
+
+    def load_optimizer_state(self, state):
+        self.step_count = int(state.get("step_count", 0))
+        for name in ("adam_m", "adam_v"):
+            t = state.get(name)
+            if t is None:
+                setattr(self, name, None)
+                continue
+            if t.numel() != self.n_params:
+                raise ValueError("optimizer state holds %d floats, the model has %d parameters" % (t.numel(), self.n_params))
+            setattr(self, name, t.to(device=self.device, dtype=torch.float32).reshape(-1).clone())
+
     def grad_norm(self):
         check(self.L.lfi_grad_sumsq(self.grads.data_ptr(), self.n_params, self.sumsq.data_ptr(),
                                     self.sumsq_work.data_ptr(), _stream()), "lfi_grad_sumsq")
@@ -782,6 +799,7 @@ class GlowEngine:
             raise ValueError("noise must be a contiguous float32 (%d, %d, %d) tensor" % (nframes, B, s.C))
         F = nframes * B
         KD = s.Ks * s.D
+        ev_static = self._tic("sample_static")
         faces = self._buf("sample_faces", B * seq_len * s.C)[:B * seq_len * s.C].view(B, seq_len, s.C)
         faces.zero_()
         faces[:, :s.start].copy_(seed[:, :s.start])
@@ -836,8 +854,11 @@ class GlowEngine:
         elif graph is None:
             self._sample_seen = {key: True}
             launch()
+        self._toc("sample_static", ev_static)
         if graph is not None:
+            ev = self._tic("sample_graph")
             graph.replay()
+            self._toc("sample_graph", ev)
         return faces[:, s.start:].clone()
 
     @translate_oom

@@ -405,6 +405,9 @@ class SeqGlow(nn.Module):
         eng = _engine.GlowEngine(self.spec, device)
 
         _bind_flat(eng, self._named_flat(), self.glow.flow.layers, device)
+        old, self._stale_engine = getattr(self, "_stale_engine", None), None
+        if old is not None and old.n_params == eng.n_params:
+            eng.load_optimizer_state(old.optimizer_state())   # .to()/.float() mid-training keeps Adam's moments and step count
         self.engine = eng
         self.glow.flow._engine = eng  # module-level Glow / FlowNet calls (one timestep) run on the same buffers
         # autograd sees each Parameter; map them to gradient views of the flat gradient buffer
@@ -428,9 +431,14 @@ class SeqGlow(nn.Module):
         return _is_bound(self.engine, self._named_flat())
 
     def _apply(self, fn, *args, **kwargs):
-        # .to()/.cuda()/.float() re-create parameter storage: drop the binding, it is rebuilt lazily
+        # .to()/.cuda()/.float() may re-create parameter storage: then the binding is dropped and rebuilt lazily, with the
+        # optimiser state carried over. A no-op move (same device, same dtype: Trainer.fit's model.to(device) on a second
+        # fit()) leaves the parameters aliased to the flat buffer and the engine — Adam moments, step count, captured
+        # sampling graphs — stays as it is.
         out = super()._apply(fn, *args, **kwargs)
-        self.engine = None
+        if self.engine is not None and not self._still_bound():
+            self._stale_engine = self.engine
+            self.engine = None
         return out
 
     # ------------------------------------------------------------------ helpers

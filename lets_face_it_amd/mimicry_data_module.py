@@ -132,22 +132,50 @@ class MimicryDataset:
 
 class WindowLoader:
     """Stands in for torch.utils.data.DataLoader(dataset, batch_size, shuffle, drop_last=False): iterating yields batch
-    dicts already on the device. Under data parallelism rank r takes batches r, r + world, ... of the same permutation."""
+    dicts already on the device.
 
-    def __init__(self, dataset, batch_size, shuffle=True, rank=0, world_size=1, generator=None):
+    Under data parallelism it behaves as DataLoader + DistributedSampler do under Lightning's DDP: ONE permutation shared by
+    all ranks (seeded by `seed + epoch`, set_epoch() as the sampler's), padded by wrapping around to a multiple of
+    world_size, rank r taking elements r, r + world, ...; every rank therefore runs the SAME number of batches of the SAME
+    sizes (the last one may be ragged, equally on all ranks). Each optimiser step issues gradient all-reduces, so ranks with
+    different step counts would pair collectives of different steps and finally hang."""
+
+    def __init__(self, dataset, batch_size, shuffle=True, rank=0, world_size=1, generator=None, seed=0):
         self.dataset, self.batch_size, self.shuffle = dataset, int(batch_size), shuffle
-        self.rank, self.world_size, self.generator = rank, world_size, generator
+        self.rank, self.world_size, self.generator = int(rank), int(world_size), generator
+        self.seed, self.epoch = int(seed), 0
+        if not 0 <= self.rank < self.world_size:
+            raise ValueError("rank %d outside world of %d" % (self.rank, self.world_size))
+
+    def set_epoch(self, epoch):
+        self.epoch = int(epoch)
+
+    def _per_rank(self):
+        return (len(self.dataset) + self.world_size - 1) // self.world_size
 
     def __len__(self):
-        nb = (len(self.dataset) + self.batch_size - 1) // self.batch_size
-        return (nb - self.rank + self.world_size - 1) // self.world_size
+        return (self._per_rank() + self.batch_size - 1) // self.batch_size
+
+    def _order(self):
+        n = len(self.dataset)
+        if not self.shuffle:
+            return torch.arange(n)
+        if self.world_size == 1:
+            return torch.randperm(n, generator=self.generator)     # the global torch RNG, as DataLoader(shuffle=True)
+        g = self.generator if self.generator is not None else torch.Generator().manual_seed(self.seed + self.epoch)
+        return torch.randperm(n, generator=g)                      # identical on every rank
 
     def __iter__(self):
-        n = len(self.dataset)
-        order = torch.randperm(n, generator=self.generator) if self.shuffle else torch.arange(n)
-        nb = (n + self.batch_size - 1) // self.batch_size
-        for b in range(self.rank, nb, self.world_size):
-            yield self.dataset.batch(order[b * self.batch_size:(b + 1) * self.batch_size])
+        order = self._order()
+        if self.world_size > 1:
+            n, total = order.numel(), self._per_rank() * self.world_size
+            if n == 0:
+                return
+            if total > n:
+                order = torch.cat([order] * ((total + n - 1) // n))[:total]
+            order = order[self.rank:total:self.world_size]
+        for b in range(0, order.numel(), self.batch_size):
+            yield self.dataset.batch(order[b:b + self.batch_size])
 
 
 class MimicryDataModule:
@@ -166,7 +194,8 @@ class MimicryDataModule:
                                              conditioning_hparams=self.hparams.Conditioning, device=self.device)
         import os
         return WindowLoader(self._sets[key], self.hparams.batch_size, shuffle=shuffle,
-                            rank=int(os.environ.get("RANK", "0")), world_size=int(os.environ.get("WORLD_SIZE", "1")))
+                            rank=int(os.environ.get("RANK", "0")), world_size=int(os.environ.get("WORLD_SIZE", "1")),
+                            seed=int(getattr(self.hparams, "seed", 1234) or 1234))
 
     def train_dataloader(self):
         return self._data_loader("train", seq_len=self.hparams.Train["seq_len"])

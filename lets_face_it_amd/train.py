@@ -28,9 +28,10 @@ class SyntheticDataModule:
         self.hp, self.steps = hparams, steps
 
     def _loader(self, seq_len, steps, seed):
+        import os
         hp = self.hp
         C, S, B = hp.Conditioning["p1_face"]["dim"], hp.Data["speech_dim"], hp.batch_size
-        g = torch.Generator().manual_seed(seed)
+        g = torch.Generator().manual_seed(seed + 7919 * int(os.environ.get("RANK", "0")))   # another shard per rank
         for _ in range(steps):
             yield {"p1_face": torch.randn(B, seq_len, C, generator=g), "p2_face": torch.randn(B, seq_len, C, generator=g),
                    "p1_speech": torch.randn(B, seq_len, S, generator=g), "p2_speech": torch.randn(B, seq_len, S, generator=g)}
@@ -58,7 +59,12 @@ def main(argv=None):
     else:
         from lets_face_it_amd.mimicry_data_module import MimicryDataModule  # same surface, corpus resident in HBM
         dm = MimicryDataModule(hparams)
-    Trainer(hparams).fit(model, dm)
+    from lets_face_it_amd.mimicry_logger import MimicryLogger   # the callback the reference's train.py:33-37 registers
+    trainer = Trainer(hparams, callbacks=[MimicryLogger()])
+    resume = getattr(hparams, "resume_from_checkpoint", None)
+    if resume:
+        trainer.resume(model, resume)
+    trainer.fit(model, dm)
 
 
 if __name__ == "__main__":

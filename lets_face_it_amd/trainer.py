@@ -13,8 +13,15 @@ import torch.distributed as dist
 
 
 class Trainer:
-    def __init__(self, hparams, device=None, log_every=10, callbacks=None):
+    def __init__(self, hparams, device=None, log_every=10, callbacks=None, checkpoint_dir=None):
         self.hparams = hparams
+        # Lightning's `checkpoint_callback: true` default (final_model.yaml:120): rank 0 writes <dir>/last.ckpt after every
+        # epoch (and at max_steps). None -> hparams.default_root_dir or ./checkpoints; "" switches checkpointing off.
+        if checkpoint_dir is None:
+            checkpoint_dir = getattr(hparams, "checkpoint_dir", None) or os.path.join(
+                getattr(hparams, "default_root_dir", None) or os.getcwd(), "checkpoints")
+        self.checkpoint_dir = checkpoint_dir if getattr(hparams, "checkpoint_callback", True) else ""
+        self.global_step = 0
         self.callbacks = list(callbacks or [])   # objects with on_validation_batch_end(...), e.g. MimicryLogger
         self.world_size = int(os.environ.get("WORLD_SIZE", "1"))
         self.rank = int(os.environ.get("RANK", "0"))
@@ -79,24 +86,40 @@ class Trainer:
         model.nll_sync_hook = self.sync_scalar
         self.broadcast_parameters(model)
         allreduce = self.allreduce_grads if self.world_size > 1 else None
-        step = 0
+        # dropout masks differ per rank (each rank sees other samples), while Python's `random` — which decides the
+        # negative-example branch (lets_face_it_glow.py:40-45) — stays identical on all ranks so that they take the same branch
+        if self.world_size > 1:
+            torch.cuda.manual_seed(torch.initial_seed() + self.rank)
+        step = self.global_step
         for epoch in range(self.epoch, self.max_epochs):
             self.epoch = epoch
             lr = self.lr_at(epoch)
             t0, frames = time.time(), 0
-            for batch in datamodule.train_dataloader():
+            loader = datamodule.train_dataloader()
+            if hasattr(loader, "set_epoch"):
+                loader.set_epoch(epoch)     # DistributedSampler.set_epoch: one shared permutation per epoch on every rank
+            for batch in loader:
                 batch = {k: v.to(self.device, non_blocking=True).float().contiguous() for k, v in batch.items()}
                 loss = model.fused_training_step(batch, lr, self.world_size, allreduce)
                 x = batch["p1_face"]
                 frames += x.shape[0] * (x.shape[1] - model.seq_glow.spec.start) * self.world_size
                 step += 1
+                self.global_step = step
                 if self.rank == 0 and step % self.log_every == 0:
                     torch.cuda.synchronize()
                     print("epoch %d step %d lr %.3e loss %.4f  %.0f frames/s" %
                           (epoch, step, lr, float(loss), frames / (time.time() - t0)), flush=True)
                 if self.max_steps and step >= int(self.max_steps):
+                    self._checkpoint(model)
                     return
             self.validate(model, datamodule)
+            self.epoch = epoch + 1          # a checkpoint written now resumes with the next epoch
+            self._checkpoint(model)
+
+    def _checkpoint(self, model):
+        if self.checkpoint_dir and self.rank == 0:
+            os.makedirs(self.checkpoint_dir, exist_ok=True)
+            self.save_checkpoint(model, os.path.join(self.checkpoint_dir, "last.ckpt"))
 
     def validate(self, model, datamodule):
         loader = getattr(datamodule, "val_dataloader", None)
@@ -119,7 +142,30 @@ class Trainer:
         return val
 
     def save_checkpoint(self, model, path):
+        """Weights (state_dict incl. the `last_missmatched_nll` buffer), hparams, epoch / step counters and the fused
+        optimiser's state (Adam moments over the flat parameter buffer + step count: with betas[1] = 0.9999 a resumed run
+        that restarted them would take ~10^4 steps to get its second moments back)."""
         if self.rank == 0:
+            eng = model.seq_glow.engine
+            opt = None
+            if eng is not None:
+                opt = {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in eng.optimizer_state().items()}
+            tmp = path + ".tmp"
             torch.save({"state_dict": {k: v.detach().cpu() for k, v in model.state_dict().items()},
-                        "hparams": vars(self.hparams), "epoch": self.epoch,
-                        "global_step": model.global_step}, path)
+                        "hparams": vars(self.hparams), "epoch": self.epoch, "global_step": self.global_step,
+                        "optimizer_state": opt, "actnorm_inited": bool(model.seq_glow.glow.actnorm_inited())}, tmp)
+            os.replace(tmp, path)
+
+    def resume(self, model, path):
+        """Continue a run from a checkpoint of save_checkpoint: weights, ActNorm's inited flag, Adam state, epoch and step."""
+        ckpt = torch.load(path, map_location="cpu", weights_only=False)
+        model.load_state_dict(ckpt["state_dict"])
+        model.to(self.device)
+        if ckpt.get("actnorm_inited", True):
+            model.seq_glow.glow.set_actnorm_init(True)
+        if ckpt.get("optimizer_state") is not None:
+            model.seq_glow._ensure_engine(self.device).load_optimizer_state(ckpt["optimizer_state"])
+        self.epoch = int(ckpt.get("epoch", 0))
+        self.global_step = int(ckpt.get("global_step", 0))
+        model.global_step = self.global_step
+        return model

@@ -9,10 +9,12 @@ Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import 
   expand_face_dim / dictify_frames         /root/reference/code/glow_pytorch/generate_motion_from_model.py:39-51,73-87
   get_face_indicies                        /root/reference/code/misc/utils.py:38-43
 
-Pinning: the reference module itself cannot be imported here (h5py is not in the image and its Dataset opens the file with
-h5py on every item), and the reference holds no fixtures or tests for it: "parity unpinned" for this file — the
-restatement is checked against hand-built expectations on tiny arrays (tests/test_data_module.py). A `store` below is the
-HDF5 tree as nested dicts: store[split][kind][bin_key][who] -> (len, dim) float array.
+Pinning: PINNED against the reference itself. tests/golden/make_golden.py (`mimicry`) imports the reference's
+mimicry_data_module.py / glow/utils.py / misc/utils.py / generate_motion_from_model.py in the build container (h5py.File is
+replaced by a dict-backed stand-in: the dataset only does `File(name)[split][kind][key][who][rows]`), runs them on a small
+seeded corpus, asserts this restatement equal (bit-exact for the copies and index lists, 1e-6 for the jerk mean) and writes
+tests/golden/mimicry.npz; tests/test_data_module.py re-checks the restatement against that file everywhere. A `store` below
+is the HDF5 tree as nested dicts: store[split][kind][bin_key][who] -> (len, dim) float array.
 """
 import numpy as np
 

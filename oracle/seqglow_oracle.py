@@ -7,7 +7,11 @@ of ``bench.py`` use it, and there only as the checker / the timed CPU port.
 It is a functional restatement (plain torch CPU ops on a ``state_dict``; any
 float dtype, fp64 for goldens) of the reference algorithm, one timestep and one
 flow step at a time exactly as the reference walks them.  Citations are
-``path:line`` relative to ``/root/reference/code/glow_pytorch/``.
+``path:line`` relative to ``/root/reference/code/glow_pytorch/``.  Every tensor it
+creates lives on its inputs' device, so the same op sequence also runs through
+stock PyTorch-ROCm on a GPU: that is ``bench.py``'s ``torch_gpu_baseline`` leg
+(the "reference single-GPU PyTorch" figure of BASELINE.md par. 3), a timed
+baseline like ``cpu_baseline``, never the product.
 
 Parity pin: the reference holds no golden vectors for this path,
 so the oracle is pinned against outputs of the reference itself, imported in
@@ -118,8 +122,8 @@ def invconv_weight(sd, prefix, reverse=False):
     l, u, log_s = sd[prefix + "l"], sd[prefix + "u"], sd[prefix + "log_s"]
     p, sign_s = sd[prefix + "p"].to(l.dtype), sd[prefix + "sign_s"].to(l.dtype)
     C = l.shape[0]
-    l_mask = torch.tril(torch.ones(C, C, dtype=l.dtype), -1)
-    lm = l * l_mask + torch.eye(C, dtype=l.dtype)
+    l_mask = torch.tril(torch.ones(C, C, dtype=l.dtype, device=l.device), -1)
+    lm = l * l_mask + torch.eye(C, dtype=l.dtype, device=l.device)
     um = u * l_mask.t() + torch.diag(sign_s * torch.exp(log_s))
     if not reverse:
         return p @ (lm @ um), log_s.sum()
@@ -264,7 +268,7 @@ def seqglow_inference(hp, sd, seq_len, data, noise):
     faces = data["p1_face"]
     frame_nb = None
     if hp["Conditioning"]["use_frame_nb"]:
-        frame_nb = torch.ones(faces.shape[0], 1, dtype=faces.dtype)
+        frame_nb = torch.ones(faces.shape[0], 1, dtype=faces.dtype, device=faces.device)
     for n, t in enumerate(range(start, seq_len)):
         cv = conditioning(hp, sd, data, t, faces, None, None, frame_nb)
         x, _ = flow_reverse(hp, sd, noise[n], cv, state)

@@ -32,11 +32,27 @@ def import_reference():
     pl = sys.modules["pytorch_lightning"]
     pl.Trainer = type("Trainer", (), {"add_argparse_args": staticmethod(lambda p: p)})
     pl.LightningModule = torch.nn.Module
+    pl.LightningDataModule = object
     pl.seed_everything = lambda s: None
-    sys.modules["misc"] = types.ModuleType("misc")
+    # `misc` stays a namespace whose `shared` is a stub (the real one reads config.toml through `toml`), while
+    # `misc.utils` (get_face_indicies, misc/utils.py:38-43) is the reference's own file
+    misc = types.ModuleType("misc")
+    misc.__path__ = [os.path.join(REF, "misc")]
+    sys.modules["misc"] = misc
     ms = types.ModuleType("misc.shared")
     ms.DATA_DIR = "/data"
+    ms.BASE_DIR = "/data"
+    ms.RANDOM_SEED = 1234
     sys.modules["misc.shared"] = ms
+    misc.shared = ms
+    # modules generate_motion_from_model.py imports that do not exist in the reference tree itself (SURVEY.md par. 2 #11)
+    for n, attrs in (("data_segments", ()), ("data_segments.find_test_segments", ("get_frames",)), ("visualize", ()),
+                     ("visualize.faces", ("get_vert", "render_double_face_video"))):
+        if n not in sys.modules:
+            mod = types.ModuleType(n)
+            for a in attrs:
+                setattr(mod, a, None)
+            sys.modules[n] = mod
     sys.path.insert(0, REF)
     from glow_pytorch.glow import models, modules, utils  # noqa
     return models, modules, utils
@@ -50,7 +66,7 @@ def base_hparams():
 def make_config(name):
     hp = base_hparams()
     c, g = hp["Conditioning"], hp["Glow"]
-    if name in ("tiny", "tiny_lstm", "tiny_additive", "framenb"):
+    if name in ("tiny", "tiny_lstm", "tiny_additive", "framenb", "dense"):
         # BASELINE.json configs[0]: 2-step/1-level, 16-d, seq_len 20, batch 4
         c["cond_dim"] = 32
         c["p1_face"].update(history=2, dim=16)
@@ -65,6 +81,8 @@ def make_config(name):
             g["rnn_type"] = "lstm"
         if name == "tiny_additive":
             g["flow_coupling"] = "additive"
+        if name == "dense":  # InvertibleConv1x1 with a dense weight: slogdet / inverse branch (modules.py:151-161)
+            g["LU_decomposed"] = False
         if name == "framenb":  # Conditioning.use_frame_nb: one frame-counter column appended to the features
             c["use_frame_nb"] = True
     elif name == "odd":
@@ -199,6 +217,8 @@ def perturb(model, gen):
             elif "actnorm" in name:
                 p.add_(torch.randn(p.shape, generator=gen) * 0.1)
             elif name.endswith("invconv.log_s"):
+                p.add_(torch.randn(p.shape, generator=gen) * 0.05)
+            elif name.endswith("invconv.weight"):  # dense mode: off the orthogonal init, so that log|det W| != 0
                 p.add_(torch.randn(p.shape, generator=gen) * 0.05)
 
 
@@ -348,6 +368,17 @@ def build(name, models, modules, oracle):
         samp = m64.inference(seq_len, data64)
     modules.GaussianDiag.sample = orig_sample
     close(oracle.seqglow_inference(hp, sd64, seq_len, data64, noise), samp, 1e-10, name + " inference")
+    # the fp32 reference itself on the same injected noise: its distance from the fp64 result is the floor any fp32
+    # implementation of this autoregressive chain sits on (SURVEY.md par. 7, "hard parts")
+    feed32 = list(noise.float())
+    modules.GaussianDiag.sample = staticmethod(lambda shape, eps_std=1: feed32.pop(0))
+    model.hparams.Infer["eps"] = eps_std
+    model.eval()
+    clean(model)
+    with torch.no_grad():
+        samp32 = model.inference(seq_len, data32)
+    modules.GaussianDiag.sample = orig_sample
+    out["infer/out_ref_fp32"] = samp32.numpy()
     for k, v in data32.items():
         out["infer/data/" + k] = v.numpy()
     out.update({"infer/noise": noise.numpy(), "infer/out": samp.numpy(), "infer/seq_len": np.array(seq_len)})
@@ -393,14 +424,101 @@ def build(name, models, modules, oracle):
     return out
 
 
+class DictFile(dict):
+    """What MimicryDataset needs of h5py.File (mimicry_data_module.py:33,48): `File(name, "r")[split][kind][key][who][rows]`,
+    `.items()`, `len()`, use as a context manager. Backed by nested dicts of numpy arrays (`rows` is a list of ints: numpy
+    fancy indexing, which is what h5py does for an increasing index list)."""
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
+
+
+def build_mimicry(utils):
+    """SURVEY.md par. 8(f): the reference's MimicryDataset (mimicry_data_module.py:12-81), calc_jerk (glow/utils.py:53-58),
+    get_face_indicies (misc/utils.py:38-43), dictify_frames / expand_face_dim (generate_motion_from_model.py:39-51,73-87),
+    run on a small seeded corpus; the numpy restatement oracle/mimicry_oracle.py is asserted equal before anything is written."""
+    import random
+    from oracle import mimicry_oracle as mo
+    import glow_pytorch.mimicry_data_module as ref_dm
+    import glow_pytorch.generate_motion_from_model as ref_gm
+    from misc.utils import get_face_indicies
+
+    data_hp = {"expression_dim": 5, "jaw_dim": 3, "neck_dim": 3, "speech_dim": 6, "file_name": "unused"}
+    cond_hp = {"p1_face": {"history": 2}, "p2_face": {"history": 3}, "p1_speech": {"history": 2}, "p2_speech": {"history": 0},
+               "use_frame_nb": False}
+    seq_len, seed = 5, 1234
+    rng = np.random.RandomState(0)
+    dims = {"flame_expression": 8, "flame_jaw": 3, "flame_neck": 3, "mfcc": 4, "prosody": 2}
+    store = {"train": {k: {} for k in dims}}
+    for i, n in enumerate((7, 3, 12, 5, 40)):
+        for kind, d in dims.items():
+            store["train"][kind][str(i)] = {who: rng.randn(n, d).astype(np.float32) for who in ("agent", "interlocutor")}
+    out = {"hparams_json": np.array(json.dumps({"Data": data_hp, "Conditioning": cond_hp})), "seq_len": np.array(seq_len),
+           "seed": np.array(seed)}
+    for kind, bins in store["train"].items():
+        for key, d in bins.items():
+            for who, a in d.items():
+                out["store/train/%s/%s/%s" % (kind, key, who)] = a
+
+    sys.modules["h5py"].File = lambda name, mode="r": DictFile(store)
+    random.seed(seed)
+    ds = ref_dm.MimicryDataset("unused", "train", data_hparams=data_hp, conditioning_hparams=cond_hp, seq_len=seq_len)
+    keys = [k for k, _ in ds.indicies]
+    starts = [rows[0] for _, rows in ds.indicies]
+    assert all(rows == list(range(rows[0], rows[0] + seq_len)) for _, rows in ds.indicies)
+    # oracle: same enumeration, then the reference's one-off shuffle (random.sample of the whole list, :43)
+    enum = mo.window_index(store, "train", seq_len)
+    random.seed(seed)
+    assert random.sample(enum, len(enum)) == list(zip(keys, starts))
+    out["index/keys"], out["index/starts"] = np.array(keys), np.array(starts, dtype=np.int64)
+    hist = {m: cond_hp[m]["history"] for m in ("p1_speech", "p2_speech", "p2_face")}
+    for i in range(len(ds)):
+        item = ds[i]
+        want = mo.get_item(store, "train", keys[i], starts[i], seq_len, data_hp["expression_dim"], hist)
+        assert set(item) == set(want)
+        for name, t in item.items():
+            assert t.dtype == torch.float32 and np.array_equal(t.numpy(), want[name]), (i, name)
+            out["item/%d/%s" % (i, name)] = t.numpy()
+
+    g = torch.Generator().manual_seed(5)
+    for j, shape in enumerate(((3, 7, 5), (16, 76, 50), (1, 4, 1))):
+        x = torch.randn(*shape, generator=g)
+        jr = utils.calc_jerk(x)
+        assert abs(mo.calc_jerk(x.numpy()) - float(jr)) < 1e-6 * max(1.0, float(jr))
+        out["jerk/%d/x" % j], out["jerk/%d/out" % j] = x.numpy(), jr.numpy()
+
+    for j, args in enumerate(((50, 3, 3, 0), (50, 3, 3, 136), (5, 3, 3, 0), (100, 3, 3, 136))):
+        idx = get_face_indicies(*args[:3], offset=args[3])
+        assert idx == mo.get_face_indicies(*args[:3], offset=args[3])
+        out["face_idx/%d/args" % j], out["face_idx/%d/out" % j] = np.array(args), np.array(idx)
+
+    gm_hp = {"expression_dim": 50, "jaw_dim": 3, "neck_dim": 3, "speech_dim": 30}
+    frames = torch.randn(6, 272, generator=g)
+    d = ref_gm.dictify_frames(frames, gm_hp)
+    d_o = mo.dictify_frames(frames.numpy(), gm_hp)
+    out["gm/hparams_json"], out["gm/frames"] = np.array(json.dumps(gm_hp)), frames.numpy()
+    for k, v in d.items():
+        assert np.array_equal(v.numpy(), d_o[k]), k
+        out["gm/dictify/" + k] = v.numpy()
+    seq = torch.randn(2, 6, 56, generator=g)
+    ex = ref_gm.expand_face_dim(seq, gm_hp)
+    assert np.array_equal(ex.numpy(), mo.expand_face_dim(seq.numpy(), gm_hp))
+    out["gm/expand/seq"], out["gm/expand/out"] = seq.numpy(), ex.numpy()
+    return out
+
+
 def main():
     sys.path.insert(0, ROOT)
     from oracle import seqglow_oracle as oracle
     models, modules, utils = import_reference()
     lstm_shim(models)
-    names = sys.argv[1:] or ("tiny", "tiny_lstm", "tiny_additive", "odd", "mid", "mlp", "p1enc", "p1mlp", "framenb", "lstmenc", "p1lstm")
+    names = sys.argv[1:] or ("tiny", "tiny_lstm", "tiny_additive", "odd", "mid", "mlp", "p1enc", "p1mlp", "framenb", "lstmenc", "p1lstm",
+                             "dense", "mimicry")
     for name in names:
-        out = build(name, models, modules, oracle)
+        out = build_mimicry(utils) if name == "mimicry" else build(name, models, modules, oracle)
         path = os.path.join(HERE, name + ".npz")
         np.savez_compressed(path, **out)
         print("wrote", path, "%.1f KB" % (os.path.getsize(path) / 1024))

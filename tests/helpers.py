@@ -6,7 +6,7 @@ import numpy as np
 import torch
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-FIXTURES = ("tiny", "tiny_lstm", "tiny_additive", "odd", "mid", "mlp", "p1enc", "p1mlp", "framenb", "lstmenc", "p1lstm")
+FIXTURES = ("tiny", "tiny_lstm", "tiny_additive", "odd", "mid", "mlp", "p1enc", "p1mlp", "framenb", "lstmenc", "p1lstm", "dense")
 
 
 class Fixture:
@@ -60,3 +60,13 @@ def max_rel(a, b, floor=1e-3):
     a = torch.as_tensor(a, dtype=torch.float64).cpu()
     b = torch.as_tensor(b, dtype=torch.float64).cpu()
     return ((a - b).abs() / b.abs().clamp(min=floor)).max().item()
+
+
+def report(line):
+    """Print a measured-error line and, when LFI_PARITY_REPORT names a file, append it there: the GPU run's numbers end up in
+    profiles/parity_report_*.txt instead of being swallowed by `pytest -q`."""
+    print(line)
+    path = os.environ.get("LFI_PARITY_REPORT")
+    if path:
+        with open(path, "a") as f:
+            f.write(line + "\n")

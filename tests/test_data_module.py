@@ -1,6 +1,7 @@
 """The window sampler and I/O helpers around the hot path (SURVEY.md par. 8f): CPU tests pin the numpy restatement
-(oracle/mimicry_oracle.py) to hand-built expectations; the GPU tests compare lets_face_it_amd.mimicry_data_module /
-generate_motion / mimicry_logger with it."""
+(oracle/mimicry_oracle.py) to tests/golden/mimicry.npz — outputs of the reference's own MimicryDataset, calc_jerk,
+get_face_indicies, dictify_frames and expand_face_dim, captured by tests/golden/make_golden.py — and to hand-built
+expectations; the GPU tests compare lets_face_it_amd.mimicry_data_module / generate_motion / mimicry_logger with both."""
 import random
 from argparse import Namespace
 
@@ -24,6 +25,67 @@ def make_store(lens=(7, 3, 12), seed=0):
         for kind, d in dims.items():
             store["train"][kind][str(i)] = {who: rng.randn(n, d).astype(np.float32) for who in ("agent", "interlocutor")}
     return store
+
+
+class MimicryGolden:
+    """tests/golden/mimicry.npz: the corpus tree, the reference dataset's shuffled window list and every item, jerk values,
+    FLAME index lists and the generate_motion layout helpers' outputs."""
+
+    def __init__(self):
+        import json
+        import os
+        self.raw = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "mimicry.npz"))
+        hp = json.loads(str(self.raw["hparams_json"]))
+        self.data_hp, self.cond_hp = hp["Data"], hp["Conditioning"]
+        self.seq_len, self.seed = int(self.raw["seq_len"]), int(self.raw["seed"])
+        self.store = {}
+        for name in self.raw.files:
+            parts = name.split("/")
+            if parts[0] == "store":
+                self.store.setdefault(parts[1], {}).setdefault(parts[2], {}).setdefault(parts[3], {})[parts[4]] = self.raw[name]
+        # np.savez keeps insertion order per key, but the tree above is rebuilt in file order: bins sorted as written
+        self.keys = [str(k) for k in self.raw["index/keys"]]
+        self.starts = [int(v) for v in self.raw["index/starts"]]
+        self.hist = {m: self.cond_hp[m]["history"] for m in ("p1_speech", "p2_speech", "p2_face")}
+
+    def item(self, i):
+        pre = "item/%d/" % i
+        return {k[len(pre):]: self.raw[k] for k in self.raw.files if k.startswith(pre)}
+
+
+@pytest.fixture(scope="module")
+def mg():
+    return MimicryGolden()
+
+
+def test_oracle_dataset_matches_reference_capture(mg):
+    """mimicry_oracle.window_index + the reference's one-off random.sample shuffle (mimicry_data_module.py:33-43) and
+    get_item (:45-78) against what the reference's MimicryDataset produced on the same tree and seed."""
+    enum = mo.window_index(mg.store, "train", mg.seq_len)
+    random.seed(mg.seed)
+    order = random.sample(enum, len(enum))
+    assert order == list(zip(mg.keys, mg.starts)) and len(order) == 3 + 8 + 1 + 36
+    for i, (key, start) in enumerate(order):
+        got = mo.get_item(mg.store, "train", key, start, mg.seq_len, mg.data_hp["expression_dim"], mg.hist)
+        want = mg.item(i)
+        assert set(got) == set(want) == {"p1_face", "p1_speech", "p2_face"}
+        for name in want:
+            assert got[name].dtype == np.float32 and np.array_equal(got[name], want[name]), (i, name)
+
+
+def test_oracle_helpers_match_reference_capture(mg):
+    r = mg.raw
+    for j in range(3):
+        assert abs(mo.calc_jerk(r["jerk/%d/x" % j]) - float(r["jerk/%d/out" % j])) < 1e-6 * max(1.0, float(r["jerk/%d/out" % j]))
+    for j in range(4):
+        a = [int(v) for v in r["face_idx/%d/args" % j]]
+        assert mo.get_face_indicies(a[0], a[1], a[2], offset=a[3]) == [int(v) for v in r["face_idx/%d/out" % j]]
+    import json
+    hp = json.loads(str(r["gm/hparams_json"]))
+    d = mo.dictify_frames(r["gm/frames"], hp)
+    for k in ("p1_face", "p1_speech", "p2_face", "p2_speech"):
+        assert np.array_equal(d[k], r["gm/dictify/" + k]), k
+    assert np.array_equal(mo.expand_face_dim(r["gm/expand/seq"], hp), r["gm/expand/out"])
 
 
 def test_window_index_enumeration():
@@ -107,6 +169,47 @@ def test_window_sampler_matches_reference_dataset(gpu_device, tmp_path, source):
     assert sorted(map(lambda t: t.flatten().tolist(), got)) == sorted(map(lambda t: t.flatten().tolist(), allw))
     with pytest.raises(IndexError):
         ds.batch([len(ds)])
+
+
+@pytest.mark.gpu
+def test_window_sampler_matches_reference_capture(gpu_device, mg):
+    """The GPU-resident sampler against the reference's own MimicryDataset output (tests/golden/mimicry.npz): same seed ->
+    the same shuffled window list, and every item bit-identical (one lfi_gather_sequences launch per modality)."""
+    from lets_face_it_amd.mimicry_data_module import MimicryDataset
+    random.seed(mg.seed)
+    ds = MimicryDataset(mg.store, "train", data_hparams=mg.data_hp, conditioning_hparams=mg.cond_hp, seq_len=mg.seq_len,
+                        device=gpu_device)
+    assert ds.indicies == list(zip(mg.keys, mg.starts))
+    batch = ds.batch(list(range(len(ds))))
+    for i in range(len(ds)):
+        want = mg.item(i)
+        assert set(batch) == set(want)
+        for name, arr in want.items():
+            assert torch.equal(batch[name][i].cpu(), torch.from_numpy(arr)), (i, name)
+    one = ds[7]
+    for name, arr in mg.item(7).items():
+        assert torch.equal(one[name].cpu(), torch.from_numpy(arr))
+
+
+@pytest.mark.gpu
+def test_jerk_and_layout_helpers_match_reference_capture(gpu_device, mg):
+    import json
+    from lets_face_it_amd import generate_motion as gm
+    from lets_face_it_amd.glow.utils import calc_jerk
+    r = mg.raw
+    for j in range(3):
+        got = float(calc_jerk(torch.from_numpy(r["jerk/%d/x" % j]).to(gpu_device)))
+        want = float(r["jerk/%d/out" % j])
+        assert abs(got - want) < 1e-6 * max(1.0, want), (j, got, want)
+    hp = json.loads(str(r["gm/hparams_json"]))
+    d = gm.dictify_frames(torch.from_numpy(r["gm/frames"]).to(gpu_device), hp)
+    for k in ("p1_face", "p1_speech", "p2_face", "p2_speech"):
+        assert torch.equal(d[k].cpu(), torch.from_numpy(r["gm/dictify/" + k])), k
+    ex = gm.expand_face_dim(torch.from_numpy(r["gm/expand/seq"]).to(gpu_device), hp)
+    assert torch.equal(ex.cpu(), torch.from_numpy(r["gm/expand/out"]))
+    for j in range(4):
+        a = [int(v) for v in r["face_idx/%d/args" % j]]
+        assert gm.get_face_indicies(a[0], a[1], a[2], offset=a[3]) == [int(v) for v in r["face_idx/%d/out" % j]]
 
 
 @pytest.mark.gpu

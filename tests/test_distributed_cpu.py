@@ -65,6 +65,31 @@ def _worker(rank, world, port, out):
 
     # (3) scalar sync used for the mismatched-NLL switch
     v = tr.sync_scalar(torch.tensor(float(rank + 1)))
+
+    # (4) an epoch over a window count that is NOT a multiple of world * batch: one collective per
+    # optimiser step, as fused_training_step issues; unequal step counts would leave one rank waiting in all_reduce
+    from lets_face_it_amd.mimicry_data_module import WindowLoader
+
+    class Windows:
+        def __len__(self):
+            return 53
+
+        def batch(self, idx):
+            return {"idx": torch.as_tensor(idx).clone()}
+
+    steps, seen = 0, []
+    for epoch in range(2):
+        ld = WindowLoader(Windows(), 6, shuffle=True, rank=rank, world_size=world, seed=5)
+        ld.set_epoch(epoch)
+        for b in ld:
+            size = torch.tensor([float(b["idx"].numel())])
+            dist.all_reduce(size)                       # the step's collective
+            assert float(size) == world * b["idx"].numel()   # same batch size on every rank
+            seen.append(b["idx"])
+            steps += 1
+    count = torch.tensor([float(steps)])
+    dist.all_reduce(count)
+    assert float(count) == world * steps == world * 2 * 5     # ceil(ceil(53 / 2) / 6) = 5 batches per rank and epoch
     if rank == 0:
         out.put((err_grad, err_stats, n, float(v)))
     dist.barrier()

@@ -147,3 +147,84 @@ def test_oom_is_reported_in_the_wording_the_tuning_harness_matches():
 
     with pytest.raises(RuntimeError, match="something else"):
         other()
+
+
+def test_bench_refuses_multi_gpu_without_a_launcher():
+    """`bench.py --gpus N` outside torch.distributed.run must exit non-zero before it touches the GPU (a HIP poison that makes
+    hipInit fail proves the order: the error text is bench.py's own, not a HIP failure)."""
+    import subprocess
+    import sys
+    env = dict(os.environ, HIP_VISIBLE_DEVICES="-1", ROCR_VISIBLE_DEVICES="-1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "1", "--warmup", "0"],
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    assert r.returncode != 0
+    assert "torch.distributed.run" in r.stdout and "--nproc-per-node 4" in r.stdout, r.stdout[-500:]
+
+
+def test_trainer_picks_rccl_on_cuda(monkeypatch):
+    """Trainer.setup_distributed(): backend "nccl" (= RCCL on ROCm) for a cuda device, gloo for the CPU rehearsal; rendezvous
+    on 127.0.0.1; HSA_ENABLE_IPC_MODE_LEGACY=0 kept in the environment (dmabuf IPC only on these hosts)."""
+    from argparse import Namespace
+    import torch.distributed as dist
+    from lets_face_it_amd import trainer as tr_mod
+    calls = []
+    monkeypatch.setenv("WORLD_SIZE", "2")
+    monkeypatch.setenv("RANK", "1")
+    monkeypatch.setenv("LOCAL_RANK", "1")
+    monkeypatch.delenv("MASTER_ADDR", raising=False)
+    monkeypatch.delenv("HSA_ENABLE_IPC_MODE_LEGACY", raising=False)
+    monkeypatch.setattr(dist, "is_initialized", lambda: False)
+    monkeypatch.setattr(dist, "init_process_group", lambda backend, **kw: calls.append((backend, kw)))
+    monkeypatch.setattr(torch.cuda, "set_device", lambda d: calls.append(("set_device", str(d))))
+    hp = Namespace(**Fixture("tiny").hp)
+    t = tr_mod.Trainer(hp)                       # default device: cuda:<LOCAL_RANK>
+    assert str(t.device) == "cuda:1"
+    t.setup_distributed()
+    assert calls[0] == ("set_device", "cuda:1")
+    assert calls[1][0] == "nccl" and calls[1][1] == {"rank": 1, "world_size": 2}
+    assert os.environ["MASTER_ADDR"] == "127.0.0.1" and os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    calls.clear()
+    tr_mod.Trainer(hp, device="cpu").setup_distributed()
+    assert calls[0][0] == "gloo"
+
+
+class _FakeWindows:
+    """len() + batch(): what WindowLoader needs of a dataset (no GPU)."""
+
+    def __init__(self, n):
+        self.n = n
+
+    def __len__(self):
+        return self.n
+
+    def batch(self, idx):
+        return {"idx": torch.as_tensor(idx).clone()}
+
+
+@pytest.mark.parametrize("n,batch,world", [(50, 7, 3), (48, 7, 2), (5, 4, 8), (64, 8, 4), (1, 3, 2)])
+def test_window_loader_gives_every_rank_the_same_steps(n, batch, world):
+    """every rank must run the same number of equally sized batches per epoch, else the per-step gradient
+    all-reduces pair up across different steps and hang. DistributedSampler semantics: shared permutation, wrapped to a
+    multiple of the world size, rank r takes r, r + world, ..."""
+    from lets_face_it_amd.mimicry_data_module import WindowLoader
+    ds = _FakeWindows(n)
+    per_rank = []
+    for rank in range(world):
+        ld = WindowLoader(ds, batch, shuffle=True, rank=rank, world_size=world, seed=11)
+        ld.set_epoch(3)
+        got = [b["idx"] for b in ld]
+        assert len(got) == len(ld)
+        per_rank.append(got)
+    sizes = [[int(b.numel()) for b in got] for got in per_rank]
+    assert all(sz == sizes[0] for sz in sizes)                       # same step count, same batch sizes
+    total = -(-n // world) * world
+    allidx = torch.cat([torch.cat(g) for g in per_rank])
+    assert allidx.numel() == total and set(allidx.tolist()) == set(range(n))    # everything seen, <= world - 1 repeats
+    again = [b["idx"] for b in WindowLoader(ds, batch, True, 0, world, seed=11)]            # epoch 0: another permutation
+    if n > 3:
+        assert not all(torch.equal(a, b) for a, b in zip(again, per_rank[0]))
+    # single process: DataLoader(drop_last=False) semantics, ragged last batch kept
+    one = [b["idx"] for b in WindowLoader(ds, batch, shuffle=False)]
+    assert torch.equal(torch.cat(one), torch.arange(n)) and len(one) == -(-n // batch)
