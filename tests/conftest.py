@@ -18,3 +18,16 @@ def gpu_device():
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     return torch.device("cuda:0")
+
+
+@pytest.fixture(autouse=True)
+def _release_gpu_memory():
+    """Models and their engines form reference cycles (module <-> bound methods), so a finished test's workspaces (tens of GB
+    at BASELINE sizes) stay allocated until the cyclic collector happens to run: collect after every test."""
+    yield
+    import gc
+    gc.collect()
+    if "torch" in sys.modules:
+        import torch
+        if torch.cuda.is_initialized():     # a Python-side flag: never touches HIP itself (tests/test_a_gpu_dp.py relies on that)
+            torch.cuda.empty_cache()
