@@ -62,6 +62,31 @@ typedef struct {
 long lfi_gemm_work_floats(const lfi_gemm_desc* d);
 int lfi_gemm_f32(const lfi_gemm_desc* d, void* stream);
 
+/* ---- bf16x3 GEMM on PRE-SPLIT operands. lfi_gemm_f32's bf16x3 kernels split every fp32 operand element into bf16 hi + lo
+ * inside every workgroup that touches it; for the big products of the step (cond_transform of all flow steps,
+ * glow/models.py:187-190: each A element is used by 32 column tiles, each B element by 56 row tiles) the split is done ONCE
+ * instead, by lfi_planes_from_f32, into "planes": per 32-row tile rt and 16-deep k-tile kt two 1-KB blocks (hi, lo) in MFMA
+ * operand-fragment order (lane l holds row rt*32 + (l & 31), k = kt*16 + 8*(l >> 5) .. + 7), zero padded to whole 256-row
+ * panels and whole k-tiles: block ((rt * nkt + kt) * 2 + plane) * 512 bf16. lfi_planes_elems(rows, cols) bf16 elements
+ * (2 bytes each), 16-byte aligned. Same products, same accumulation order as lfi_gemm_f32's 256 x 256 bf16x3 kernel
+ * (results bit-identical). Both operands k-contiguous: C[b] (+)= act(A[b] B[b]^T + bias[b]), A: M x K, B: N x K.
+ * A workgroup reads whole 256-row panels from a batch entry's first row tile: when batch entries start inside one buffer,
+ * keep that buffer one panel (256 rows) longer than lfi_planes_elems says (what is read there only feeds rows / columns
+ * past M / N, which are never stored). */
+long lfi_planes_elems(long rows, int cols);
+int lfi_planes_from_f32(const float* X, long ldx, long rows, int cols, void* planes, void* stream);
+typedef struct {
+  int M, N, K;
+  const void* Ap; int a_nkt; long a_stride;   /* planes of A; k-tiles per row tile in that buffer; bf16 elements between batch
+                                                 entries (a batch entry may be a k-tile range of one buffer: stride kt0 * 1024) */
+  const void* Bp; int b_nkt; long b_stride;
+  float* C; long ldc;
+  const float* bias; const float* G; long ldg;   /* as lfi_gemm_desc */
+  int batch; long strideC, strideBias, strideG;
+  int accumulate, act; float slope;
+} lfi_pgemm_desc;
+int lfi_gemm_planes(const lfi_pgemm_desc* d, void* stream);
+
 /* out[c] (+)= scale * sum_r X[r*ldx + c]  for r < rows, c < cols; batched. Deterministic two-stage reduction.
  * (bias gradients: autograd of the nn.Linear / GRU biases.) work: lfi_colsum_work_floats floats. */
 long lfi_colsum_work_floats(int rows, int cols, int batch);

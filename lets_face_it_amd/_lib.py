@@ -30,6 +30,18 @@ class GemmDesc(C.Structure):
     ]
 
 
+class PGemmDesc(C.Structure):
+    _fields_ = [
+        ("M", C.c_int), ("N", C.c_int), ("K", C.c_int),
+        ("Ap", C.c_void_p), ("a_nkt", C.c_int), ("a_stride", C.c_long),
+        ("Bp", C.c_void_p), ("b_nkt", C.c_int), ("b_stride", C.c_long),
+        ("C", C.c_void_p), ("ldc", C.c_long),
+        ("bias", C.c_void_p), ("G", C.c_void_p), ("ldg", C.c_long),
+        ("batch", C.c_int), ("strideC", C.c_long), ("strideBias", C.c_long), ("strideG", C.c_long),
+        ("accumulate", C.c_int), ("act", C.c_int), ("slope", C.c_float),
+    ]
+
+
 class EncDesc(C.Structure):
     _fields_ = [("B", C.c_int), ("T", C.c_int), ("N", C.c_int), ("start", C.c_int),
                 ("hist", C.c_int), ("hid", C.c_int), ("ldcond", C.c_int), ("col", C.c_int), ("precision", C.c_int),
@@ -84,6 +96,9 @@ def lib():
         "lfi_version": (i, []),
         "lfi_gemm_work_floats": (l, [P(GemmDesc)]),
         "lfi_gemm_f32": (i, [P(GemmDesc), vp]),
+        "lfi_planes_elems": (l, [l, i]),
+        "lfi_planes_from_f32": (i, [vp, l, l, i, vp, vp]),
+        "lfi_gemm_planes": (i, [P(PGemmDesc), vp]),
         "lfi_colsum_work_floats": (l, [i, i, i]),
         "lfi_colsum_f32": (i, [vp, l, l, i, i, i, vp, l, f, i, vp, vp]),
         "lfi_cols_fold": (i, [vp, l, l, vp, vp, i, vp, l, vp]),
@@ -133,7 +148,8 @@ def lib():
 
 
 EXPORTS = [
-    "lfi_last_error", "lfi_version", "lfi_gemm_work_floats", "lfi_gemm_f32", "lfi_colsum_work_floats",
+    "lfi_last_error", "lfi_version", "lfi_gemm_work_floats", "lfi_gemm_f32", "lfi_planes_elems", "lfi_planes_from_f32",
+    "lfi_gemm_planes", "lfi_colsum_work_floats",
     "lfi_colsum_f32", "lfi_cols_fold", "lfi_encode_windows_work_floats", "lfi_encode_windows_fwd", "lfi_encode_windows_bwd",
     "lfi_encode_windows_bias_rows", "lfi_encode_windows_bias_grads",
     "lfi_encode_windows_scatter", "lfi_encode_windows_compact_dgi", "lfi_gather_windows", "lfi_leaky_grad", "lfi_fill_frame_nb", "lfi_flow_prep_floats", "lfi_flow_prep",

@@ -41,6 +41,10 @@ struct GemmArgs {
   int tiles_m, tiles_n;
   int vecA, vecB;  // operand rows are 16-byte aligned and 4-float granular: 16-byte global loads are legal
   int vecC;        // the same for C (and G): the epilogue goes through LDS with 16-byte row-wise loads / stores
+  // gemm_planes_256_kernel only: operands as pre-split bf16 hi / lo planes in MFMA fragment order (lfi_planes_from_f32)
+  const __bf16* Ap; const __bf16* Bp;   // block ((rt * nkt_op + kt) * 2 + plane) * 512 bf16, rt = 32-row tile, kt = 16-k tile
+  int nkt, nktA, nktB;                  // k-tiles of this product; k-tiles per row tile in either plane buffer
+  long pstrideA, pstrideB;              // bf16 elements between batch entries
 };
 
 __device__ __forceinline__ float apply_act(float v, int act, float slope, const float* G, long gidx) {
@@ -1377,6 +1381,140 @@ __global__ __launch_bounds__(Y2NT) void gemm_bf16x3_256w_kernel(GemmArgs g) {
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------- bf16 x 3 on pre-split planes
+// The kernels above redo the fp32 -> bf16 hi / lo split of every operand element in EVERY workgroup that touches it (the
+// cond_transform forward product converts its A panel 32 times and its B panel 56 times), through VGPRs and ds_write, and a
+// k-tile's phases (global load, convert + LDS store, fragment reads, MFMA) do not overlap: 2750 cycles per k-tile against
+// 1536 of MFMA issue (profiles/, round 1). Here the operands arrive ALREADY split (lfi_planes_from_f32: once per operand, by a
+// streaming kernel) and ALREADY in MFMA fragment order, so a k-tile of a 256-row panel is 16 contiguous 1-KB blocks that go
+// global -> LDS by LDS-DMA (global_load_lds_dwordx4: no VGPR, no VALU, no ds_write) and every fragment read is a linear,
+// conflict-free ds_read_b128 (block base + lane * 16).
+//   workgroup = 256 x 256 tile, 16 waves x (64 x 64) patches (as gemm_bf16x3_256_kernel, so the wide epilogue is shared);
+//   ring of PRING = 4 slots of one 16-deep k-tile each: [A: 8 row tiles x {hi, lo} x 1 KB][B: the same] = 32 KB;
+//   wave w fetches blocks 2w, 2w + 1 of a slot (one row tile of one operand, both planes: 2 KB contiguous in memory).
+// Phase t (one barrier per k-tile; rules of cdna_hip_programming.md par. 5, "Pipelining across barriers"):
+//     DMA tile t + 4 -> slot t % 4 (whose fragments were read in phase t - 1, retired by that phase's lgkmcnt(0) + barrier)
+//     MFMAs of tile t on fragments already in registers; the fragments of tile t + 1 are read under them, each register
+//       group as soon as its last MFMA of tile t has issued (A of row tile 0, then A of row tile 1, then B)
+//     s_waitcnt vmcnt(4): this wave's DMAs of tile t + 2 have landed (t + 3, t + 4 stay in flight);  lgkmcnt(0);  s_barrier
+//   so a tile is read one phase after the wait + barrier that retired it, and restaged one phase after its last read.
+// Tiles past the end are fetched again from the last real tile (never used): the counted waits then need no tail cases.
+constexpr int PRING = 4;
+constexpr int PSLOT = 32 * 1024;   // bytes
+
+typedef __attribute__((address_space(3))) void plds_void;
+typedef __attribute__((address_space(1))) const void pglb_void;
+
+__global__ __launch_bounds__(1024) void gemm_planes_256_kernel(GemmArgs g) {
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, half = lane >> 5;
+  int tm, tn, batch, split;
+  gemm_tile_of_block(g, &tm, &tn, &batch, &split);
+  const int m0 = tm * 256, n0 = tn * 256;
+  const int nkt = g.nkt;
+  char* lds = reinterpret_cast<char*>(xsmem);
+  // this wave's DMA source: operand `op`, row tile `rtl` of the workgroup's panel, k-tile 0, plane 0, + lane * 16 bytes
+  const int op = wave >> 3, rtl = wave & 7;
+  const char* src = op ? reinterpret_cast<const char*>(g.Bp + batch * g.pstrideB) + (long)(tn * 8 + rtl) * g.nktB * 2048
+                       : reinterpret_cast<const char*>(g.Ap + batch * g.pstrideA) + (long)(tm * 8 + rtl) * g.nktA * 2048;
+  src += lane * 16;
+  const int dma_off = (op * 16 + rtl * 2) * 1024;
+  auto dma = [&](int kt, int slot) {
+    const char* p = src + (long)min(kt, nkt - 1) * 2048;
+    char* d = lds + slot * PSLOT + dma_off;   // wave-uniform
+    __builtin_amdgcn_global_load_lds((pglb_void*)p, (plds_void*)d, 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((pglb_void*)(p + 1024), (plds_void*)(d + 1024), 16, 0, 0);
+  };
+  const int wm = wave >> 2, wn = wave & 3;
+  const int fa = (wm * 4) * 1024 + lane * 16;              // A fragment (mt, plane) at fa + (mt * 2 + plane) * 1024
+  const int fb = 16 * 1024 + (wn * 4) * 1024 + lane * 16;  // B fragment (nt, plane) at fb + (nt * 2 + plane) * 1024
+  auto frag = [&](int slot, int off) { return *reinterpret_cast<const bf16x8*>(lds + slot * PSLOT + off); };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+  bf16x8 ah[2], al[2], bh[2], bl[2];
+  dma(0, 0); dma(1, 1); dma(2, 2); dma(3, 3);
+  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+#pragma unroll
+  for (int t2 = 0; t2 < 2; ++t2) {
+    ah[t2] = frag(0, fa + (t2 * 2) * 1024); al[t2] = frag(0, fa + (t2 * 2 + 1) * 1024);
+    bh[t2] = frag(0, fb + (t2 * 2) * 1024); bl[t2] = frag(0, fb + (t2 * 2 + 1) * 1024);
+  }
+  asm volatile("s_waitcnt vmcnt(4)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+
+  for (int t = 0; t < nkt; ++t) {
+    const int cur = t & 3, nxt = (t + 1) & 3;
+    dma(t + 4, cur);
+    __builtin_amdgcn_sched_barrier(0);
+    bf16x8 nah[2], nal[2], nbh[2], nbl[2];
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[0], bh[nt], acc[0][nt], 0, 0, 0);
+      acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[0], bl[nt], acc[0][nt], 0, 0, 0);
+      acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[0], bh[nt], acc[0][nt], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    nah[0] = frag(nxt, fa); nal[0] = frag(nxt, fa + 1024);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      acc[1][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[1], bh[nt], acc[1][nt], 0, 0, 0);
+      acc[1][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[1], bl[nt], acc[1][nt], 0, 0, 0);
+      acc[1][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[1], bh[nt], acc[1][nt], 0, 0, 0);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    nah[1] = frag(nxt, fa + 2048); nal[1] = frag(nxt, fa + 3072);
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) { nbh[nt] = frag(nxt, fb + (nt * 2) * 1024); nbl[nt] = frag(nxt, fb + (nt * 2 + 1) * 1024); }
+    asm volatile("s_waitcnt vmcnt(4)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { ah[i] = nah[i]; al[i] = nal[i]; bh[i] = nbh[i]; bl[i] = nbl[i]; }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the re-fetched tail tiles: landed before the epilogue reuses the ring
+  __syncthreads();
+  if (g.vecC) gemm_epilogue_wide<256, 1024>(g, acc, reinterpret_cast<float*>(xsmem), LFI_EPI_ROWS, m0, n0, wm, wn, l31, half, batch, split, 256);
+  else gemm_epilogue_n<256>(g, acc, m0, n0, wm, wn, l31, half, batch, split);
+}
+
+// fp32 (rows x cols, row pitch ldx) -> bf16 hi / lo planes in fragment order, zero padded to rows_pad x 16 nkt:
+// block ((rt * nkt + kt) * 2 + plane), lane l of a block holds row rt * 32 + (l & 31), k = kt * 16 + 8 (l >> 5) .. + 7.
+// One thread per (block pair, lane): 8 floats in (two 16-byte loads when the row allows), 16 + 16 bytes out.
+__global__ __launch_bounds__(256) void planes_from_f32_kernel(const float* __restrict__ X, long ldx, int rows, int cols, long nblk,
+                                                             int nkt, int vec, __bf16* __restrict__ out) {
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < nblk * 64; idx += (long)gridDim.x * 256) {
+    const int l = (int)(idx & 63);
+    const long q = idx >> 6;
+    const int kt = (int)(q % nkt);
+    const long rt = q / nkt;
+    const long row = rt * 32 + (l & 31);
+    const int k0 = kt * 16 + 8 * (l >> 5);
+    float v[8];
+    if (row < rows && vec && k0 + 8 <= cols) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(X + row * ldx + k0), b = *reinterpret_cast<const f32x4*>(X + row * ldx + k0 + 4);
+      v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = (row < rows && k0 + e < cols) ? X[row * ldx + k0 + e] : 0.0f;
+    }
+    uint4 h, lo;
+    split2(v[0], v[1], &h.x, &lo.x); split2(v[2], v[3], &h.y, &lo.y);
+    split2(v[4], v[5], &h.z, &lo.z); split2(v[6], v[7], &h.w, &lo.w);
+    uint4* dst = reinterpret_cast<uint4*>(out) + q * 128 + l;
+    dst[0] = h;
+    dst[64] = lo;
+  }
+}
+
 __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(GemmArgs g) {
   const long mn = (long)g.M * g.N;
   const int batch = blockIdx.y;
@@ -1669,5 +1807,69 @@ extern "C" int lfi_gemm_f32(const lfi_gemm_desc* d, void* stream) {
     }
     LFI_LAUNCH_CHECK("lfi_gemm_f32 split-k reduce");
   }
+  return LFI_OK;
+}
+
+
+/* ---- pre-split operand planes + the GEMM that consumes them (include/lfi.h) */
+extern "C" long lfi_planes_elems(long rows, int cols) {
+  if (rows <= 0 || cols <= 0) return 0;
+  return ((rows + 255) / 256 * 256) * (long)((cols + 15) / 16 * 16) * 2;
+}
+
+extern "C" int lfi_planes_from_f32(const float* X, long ldx, long rows, int cols, void* planes, void* stream) {
+  LFI_REQUIRE(rows >= 0 && cols >= 0, "lfi_planes_from_f32: bad dims %ld x %d", rows, cols);
+  if (rows == 0 || cols == 0) return LFI_OK;
+  LFI_REQUIRE(X && planes, "lfi_planes_from_f32: null pointer");
+  LFI_REQUIRE((reinterpret_cast<uintptr_t>(planes) & 15) == 0, "lfi_planes_from_f32: planes must be 16-byte aligned");
+  const int nkt = (cols + 15) / 16;
+  const long nblk = (rows + 255) / 256 * 8 * nkt;   // (row tile, k-tile) block pairs, rows padded to whole 256-row panels
+  const int vec = ((reinterpret_cast<uintptr_t>(X) & 15) == 0 && (ldx & 3) == 0) ? 1 : 0;
+  const long threads = nblk * 64;
+  hipLaunchKernelGGL(planes_from_f32_kernel, dim3((unsigned)min((threads + 255) / 256, 65535L * 8)), dim3(256), 0, (hipStream_t)stream,
+                     X, ldx, (int)rows, cols, nblk, nkt, vec, reinterpret_cast<__bf16*>(planes));
+  LFI_LAUNCH_CHECK("lfi_planes_from_f32");
+  return LFI_OK;
+}
+
+extern "C" int lfi_gemm_planes(const lfi_pgemm_desc* d, void* stream) {
+  LFI_REQUIRE(d, "lfi_gemm_planes: null descriptor");
+  LFI_REQUIRE(d->M >= 0 && d->N >= 0 && d->K >= 0 && d->batch >= 1 && d->batch <= 65535, "lfi_gemm_planes: bad dims M=%d N=%d K=%d batch=%d",
+              d->M, d->N, d->K, d->batch);
+  if (d->M == 0 || d->N == 0) return LFI_OK;
+  LFI_REQUIRE(d->Ap && d->Bp && d->C, "lfi_gemm_planes: null operand");
+  LFI_REQUIRE(d->K > 0, "lfi_gemm_planes: K = 0");
+  LFI_REQUIRE(d->act >= 0 && d->act <= 2 && (d->act != 2 || d->G), "lfi_gemm_planes: bad act %d", d->act);
+  const int nkt = (d->K + 15) / 16;
+  LFI_REQUIRE(d->a_nkt >= nkt && d->b_nkt >= nkt, "lfi_gemm_planes: plane buffers hold %d / %d k-tiles per row tile, the product needs %d",
+              d->a_nkt, d->b_nkt, nkt);
+  LFI_REQUIRE((reinterpret_cast<uintptr_t>(d->Ap) & 15) == 0 && (reinterpret_cast<uintptr_t>(d->Bp) & 15) == 0 &&
+              (d->a_stride & 7) == 0 && (d->b_stride & 7) == 0, "lfi_gemm_planes: planes must be 16-byte aligned");
+  GemmArgs a = {};
+  a.M = d->M; a.N = d->N; a.K = d->K;
+  a.C = d->C; a.ldc = d->ldc; a.bias = d->bias; a.G = d->G; a.ldg = d->ldg;
+  a.strideC = d->strideC; a.strideBias = d->strideBias; a.strideG = d->strideG;
+  a.accumulate = d->accumulate; a.act = d->act; a.slope = d->slope;
+  a.splitk = 1; a.kchunk = d->K; a.work = nullptr;
+  a.Ap = reinterpret_cast<const __bf16*>(d->Ap); a.Bp = reinterpret_cast<const __bf16*>(d->Bp);
+  a.nkt = nkt; a.nktA = d->a_nkt; a.nktB = d->b_nkt; a.pstrideA = d->a_stride; a.pstrideB = d->b_stride;
+  const bool c_ok = (reinterpret_cast<uintptr_t>(d->C) & 15) == 0 && d->ldc % 4 == 0 && d->strideC % 4 == 0;
+  const bool g_ok = d->act != 2 || ((reinterpret_cast<uintptr_t>(d->G) & 15) == 0 && d->ldg % 4 == 0 && d->strideG % 4 == 0);
+  a.vecC = (c_ok && g_ok && !(d->act == 2 && d->accumulate != 0)) ? 1 : 0;
+  a.tiles_m = lfi_cdiv(d->M, 256);
+  a.tiles_n = lfi_cdiv(d->N, 256);
+  const size_t lds_loop = (size_t)PRING * PSLOT, lds_epi = (size_t)LFI_EPI_ROWS * 260 * sizeof(float);
+  const size_t lds = lds_loop > lds_epi ? lds_loop : lds_epi;
+  static bool attr = false;
+  if (!attr) {
+    if (hipFuncSetAttribute((const void*)gemm_planes_256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+      lfi_set_error("lfi_gemm_planes: cannot reserve %zu bytes of LDS", lds);
+      return LFI_ERR_LAUNCH;
+    }
+    attr = true;
+  }
+  dim3 grid(a.tiles_m * a.tiles_n, d->batch, 1);
+  hipLaunchKernelGGL(gemm_planes_256_kernel, grid, dim3(1024), lds, (hipStream_t)stream, a);
+  LFI_LAUNCH_CHECK("lfi_gemm_planes");
   return LFI_OK;
 }

@@ -21,7 +21,7 @@ import os
 import torch
 
 from . import _lib
-from ._lib import EncDesc, FlowDims, FlowGrads, FlowParams, GemmDesc, P1Enc, check, ptr, translate_oom
+from ._lib import EncDesc, FlowDims, FlowGrads, FlowParams, GemmDesc, P1Enc, PGemmDesc, check, ptr, translate_oom
 
 ENC_ORDER = ("p1_face", "p2_face", "p1_speech", "p2_speech")  # FeatureEncoder concat order (models.py:127-143)
 FLOW_FIELDS = ("an_bias", "an_logs", "inv_l", "inv_u", "inv_logs", "inv_w", "w_ih", "w_hh", "b_ih", "b_hh",
@@ -325,6 +325,35 @@ class GlowEngine:
             g.work = self._buf(ws, batch * max(splitk, 8) * M * N).data_ptr()
         ev = self._tic(tag)
         check(self.L.lfi_gemm_f32(C.byref(g), _stream()), "lfi_gemm_f32")
+        self._toc(tag, ev)
+
+    # ---- bf16 hi / lo operand planes in MFMA fragment order (include/lfi.h, lfi_planes_from_f32 / lfi_gemm_planes)
+    def planes(self, name, X, ldx, rows, cols, x_off=0):
+        """Split the fp32 matrix X (rows x cols, row pitch ldx) once into planes kept in workspace `name`. -> (tensor, nkt)"""
+        # + one 256-row panel of slack: a batch entry that starts inside the buffer (lfi_pgemm_desc.a_stride / b_stride) reads
+        # whole 256-row panels from its own first row (rows past its M / N only feed outputs that are never stored)
+        elems = self.L.lfi_planes_elems(rows, cols) + 256 * ((cols + 15) // 16 * 16) * 2
+        buf = self._ws.get(name)
+        if buf is None or buf.numel() < elems:
+            buf = torch.empty(elems, dtype=torch.bfloat16, device=self.device)
+            self._ws[name] = buf
+        check(self.L.lfi_planes_from_f32(X.data_ptr() + 4 * x_off, ldx, rows, cols, buf.data_ptr(), _stream()),
+              "lfi_planes_from_f32")
+        return buf, (cols + 15) // 16
+
+    def gemm_planes(self, M, N, K, Ap, a_nkt, Bp, b_nkt, Cm, ldc, bias=None, act=0, slope=0.01, G=None, ldg=0, batch=1,
+                    a_stride=0, b_stride=0, sC=0, sBias=0, sG=0, accumulate=0, c_off=0, bias_off=0, tag=None):
+        g = PGemmDesc()
+        g.M, g.N, g.K = M, N, K
+        g.Ap, g.a_nkt, g.a_stride = Ap.data_ptr(), a_nkt, a_stride
+        g.Bp, g.b_nkt, g.b_stride = Bp.data_ptr(), b_nkt, b_stride
+        g.C, g.ldc = Cm.data_ptr() + 4 * c_off, ldc
+        g.bias = None if bias is None else bias.data_ptr() + 4 * bias_off
+        g.G, g.ldg = ptr(G), ldg
+        g.batch, g.strideC, g.strideBias, g.strideG = batch, sC, sBias, sG
+        g.accumulate, g.act, g.slope = accumulate, act, slope
+        ev = self._tic(tag)
+        check(self.L.lfi_gemm_planes(C.byref(g), _stream()), "lfi_gemm_planes")
         self._toc(tag, ev)
 
     @staticmethod

@@ -199,6 +199,68 @@ def test_gemm_bf16x3_256_tile(eng, gpu_device, akc, bkc, shape, splitk, pin):
     assert err < 3e-5, err
 
 
+@pytest.mark.parametrize("shape", [(700, 520, 330), (256, 256, 16), (513, 257, 75), (300, 260, 128), (1024, 768, 896), (40, 33, 7)])
+@pytest.mark.parametrize("epi", ["bias_leaky", "plain", "accumulate"])
+def test_gemm_on_presplit_planes(eng, gpu_device, shape, epi):
+    """lfi_planes_from_f32 + lfi_gemm_planes (operands split to bf16 hi / lo ONCE, in MFMA fragment order, streamed to LDS by
+    LDS-DMA through a four-slot ring) against the fp64 product and, bit for bit, against lfi_gemm_f32's 256 x 256 bf16x3
+    kernel (same split, same products, same accumulation order): ragged M / N / K, fewer k-tiles than ring slots, many tiles."""
+    M, N, K = shape
+    g = torch.Generator().manual_seed(M + 3 * N + 7 * K)
+    r4 = lambda v: (v + 3) // 4 * 4  # noqa: E731
+    lda, ldb, ldc = r4(K) + 4, r4(K), r4(N) + 4
+    A = torch.full((M, lda), float("nan"))
+    Bm = torch.full((N, ldb), float("nan"))
+    A[:, :K] = torch.randn(M, K, generator=g)
+    Bm[:, :K] = torch.randn(N, K, generator=g)
+    A[:, K:r4(K)] = 0.0
+    Bm[:, K:r4(K)] = 0.0
+    A, Bm = A.to(gpu_device), Bm.to(gpu_device)
+    bias = torch.randn(N, generator=g).to(gpu_device) if epi == "bias_leaky" else None
+    act = 1 if epi == "bias_leaky" else 0
+    acc = 1 if epi == "accumulate" else 0
+    C0 = torch.randn(M, ldc, generator=g).to(gpu_device)
+    Ap, nka = eng.planes("test.pa", A, lda, M, K)
+    Bp, nkb = eng.planes("test.pb", Bm, ldb, N, K)
+    C1 = C0.clone()
+    eng.gemm_planes(M, N, K, Ap, nka, Bp, nkb, C1, ldc, bias=bias, act=act, accumulate=acc)
+    C2 = C0.clone()
+    eng.precision = 0x11
+    try:
+        eng.gemm(M, N, K, A, lda, 1, Bm, ldb, 1, C2, ldc, bias=bias, act=act, slope=0.01, accumulate=acc)
+    finally:
+        eng.precision = 0
+    torch.cuda.synchronize()
+    ref = A[:, :K].double() @ Bm[:, :K].double().t()
+    if bias is not None:
+        ref = torch.nn.functional.leaky_relu(ref + bias.double(), 0.01)
+    if acc:
+        ref = ref + C0[:, :N].double()
+    assert torch.equal(C1[:, N:], C0[:, N:]), "wrote outside the N columns"
+    assert rel_err(C1[:, :N], ref) < 3e-5
+    assert torch.equal(C1, C2)
+
+
+def test_gemm_on_presplit_planes_batched_k_ranges(eng, gpu_device):
+    """Batch entries that are k-tile ranges of ONE plane buffer (the gic product: flow step k multiplies columns
+    [k D, (k + 1) D) of c) against separate per-step weight planes."""
+    g = torch.Generator().manual_seed(5)
+    F, D, G, Ks = 300, 64, 96, 3
+    c = torch.randn(F, Ks * D, generator=g).to(gpu_device)
+    W = torch.randn(Ks, G, D, generator=g).to(gpu_device)
+    bias = torch.randn(Ks, G, generator=g).to(gpu_device)
+    out = torch.zeros(Ks, F, G, device=gpu_device)
+    cp, nkc = eng.planes("test.pc", c, Ks * D, F, Ks * D)
+    wp, nkw = eng.planes("test.pw", W.view(Ks * G, D), D, Ks * G, D)   # 288 rows -> padded to 512: per-step offset below
+    # step k's weight rows start at row k * G = row tile 3 k: a whole number of 32-row tiles, so a batch stride works
+    eng.gemm_planes(F, G, D, cp, nkc, wp, nkw, out, G, bias=bias, batch=Ks, a_stride=(D // 16) * 1024,
+                    b_stride=(G // 32) * nkw * 1024, sC=F * G, sBias=G)
+    torch.cuda.synchronize()
+    for k in range(Ks):
+        ref = c[:, k * D:(k + 1) * D].double() @ W[k].double().t() + bias[k].double()
+        assert rel_err(out[k], ref) < 3e-5, k
+
+
 def test_gemm_in_place_leaky_grad_epilogue(eng, gpu_device):
     """act = 2 with G == C (the in-place dpre product of the backward pass), batched, through the wide epilogue."""
     g = torch.Generator().manual_seed(11)
