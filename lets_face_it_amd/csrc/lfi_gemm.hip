@@ -1421,15 +1421,26 @@ __global__ __launch_bounds__(1024) void gemm_planes_256_kernel(GemmArgs g) {
   src += lane * 16;
   const int dma_off = (op * 16 + rtl * 2) * 1024;
   auto dma = [&](int kt, int slot) {
+#ifndef PG_NO_DMA
     const char* p = src + (long)min(kt, nkt - 1) * 2048;
     char* d = lds + slot * PSLOT + dma_off;   // wave-uniform
     __builtin_amdgcn_global_load_lds((pglb_void*)p, (plds_void*)d, 16, 0, 0);
     __builtin_amdgcn_global_load_lds((pglb_void*)(p + 1024), (plds_void*)(d + 1024), 16, 0, 0);
+#endif
   };
   const int wm = wave >> 2, wn = wave & 3;
   const int fa = (wm * 4) * 1024 + lane * 16;              // A fragment (mt, plane) at fa + (mt * 2 + plane) * 1024
   const int fb = 16 * 1024 + (wn * 4) * 1024 + lane * 16;  // B fragment (nt, plane) at fb + (nt * 2 + plane) * 1024
+#ifdef PG_NO_READ
+  auto frag = [&](int slot, int off) { bf16x8 z; for (int e = 0; e < 8; ++e) z[e] = (__bf16)(float)(slot + off); asm volatile("" : "+v"(z)); return z; };
+#else
   auto frag = [&](int slot, int off) { return *reinterpret_cast<const bf16x8*>(lds + slot * PSLOT + off); };
+#endif
+#ifdef PG_NO_MMA
+#define PG_MFMA(a, b, c) (c)
+#else
+#define PG_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
+#endif
 
   f32x16 acc[2][2];
 #pragma unroll
@@ -1451,38 +1462,184 @@ __global__ __launch_bounds__(1024) void gemm_planes_256_kernel(GemmArgs g) {
   asm volatile("s_waitcnt vmcnt(4)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
 
+#ifdef PG_STAMPS
+  unsigned long long pg_issue = 0, pg_vm = 0, pg_lgkm = 0, pg_bar = 0;
+  const unsigned long long pg_t0 = __builtin_amdgcn_s_memtime(), pg_r0 = __builtin_amdgcn_s_memrealtime();
+  unsigned long long pg_top = pg_t0;
+#endif
+  // The four waves that share a SIMD (waves w, w + 4, w + 8, w + 12: wm = 0 .. 3) issue their two DMA pieces at four different
+  // points of the phase, one before each quarter of the MFMAs: a piece costs its wave 100 - 200 cycles of issue, and with all
+  // sixteen waves issuing theirs right after the barrier the matrix pipe sat idle that long every phase (ingredient-removal
+  // builds, tools/pgemm_ablate.sh: the DMA cost 0.22 of 0.67 ms that way).
   for (int t = 0; t < nkt; ++t) {
     const int cur = t & 3, nxt = (t + 1) & 3;
-    dma(t + 4, cur);
-    __builtin_amdgcn_sched_barrier(0);
     bf16x8 nah[2], nal[2], nbh[2], nbl[2];
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-      acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[0], bh[nt], acc[0][nt], 0, 0, 0);
-      acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[0], bl[nt], acc[0][nt], 0, 0, 0);
-      acc[0][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[0], bh[nt], acc[0][nt], 0, 0, 0);
-    }
+    if (wm == 0) dma(t + 4, cur);
     __builtin_amdgcn_sched_barrier(0);
+    acc[0][0] = PG_MFMA(al[0], bh[0], acc[0][0]);
+    acc[0][0] = PG_MFMA(ah[0], bl[0], acc[0][0]);
+    acc[0][0] = PG_MFMA(ah[0], bh[0], acc[0][0]);
+    __builtin_amdgcn_sched_barrier(0);
+    if (wm == 1) dma(t + 4, cur);
+    __builtin_amdgcn_sched_barrier(0);
+    acc[0][1] = PG_MFMA(al[0], bh[1], acc[0][1]);
+    acc[0][1] = PG_MFMA(ah[0], bl[1], acc[0][1]);
+    acc[0][1] = PG_MFMA(ah[0], bh[1], acc[0][1]);
+    __builtin_amdgcn_sched_barrier(0);
+    // tile t + 1: A fragments of row tile 0 into the registers just freed, B fragments into a second set
     nah[0] = frag(nxt, fa); nal[0] = frag(nxt, fa + 1024);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-      acc[1][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[1], bh[nt], acc[1][nt], 0, 0, 0);
-      acc[1][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[1], bl[nt], acc[1][nt], 0, 0, 0);
-      acc[1][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[1], bh[nt], acc[1][nt], 0, 0, 0);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    nah[1] = frag(nxt, fa + 2048); nal[1] = frag(nxt, fa + 3072);
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) { nbh[nt] = frag(nxt, fb + (nt * 2) * 1024); nbl[nt] = frag(nxt, fb + (nt * 2 + 1) * 1024); }
+    __builtin_amdgcn_sched_barrier(0);
+    if (wm == 2) dma(t + 4, cur);
+    __builtin_amdgcn_sched_barrier(0);
+    acc[1][0] = PG_MFMA(al[1], bh[0], acc[1][0]);
+    acc[1][0] = PG_MFMA(ah[1], bl[0], acc[1][0]);
+    acc[1][0] = PG_MFMA(ah[1], bh[0], acc[1][0]);
+    __builtin_amdgcn_sched_barrier(0);
+    if (wm == 3) dma(t + 4, cur);
+    __builtin_amdgcn_sched_barrier(0);
+    acc[1][1] = PG_MFMA(al[1], bh[1], acc[1][1]);
+    acc[1][1] = PG_MFMA(ah[1], bl[1], acc[1][1]);
+    acc[1][1] = PG_MFMA(ah[1], bh[1], acc[1][1]);
+    __builtin_amdgcn_sched_barrier(0);
+    nah[1] = frag(nxt, fa + 2048); nal[1] = frag(nxt, fa + 3072);
+#ifdef PG_STAMPS
+    const unsigned long long s0 = __builtin_amdgcn_s_memtime();
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    const unsigned long long s1 = __builtin_amdgcn_s_memtime();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    const unsigned long long s2 = __builtin_amdgcn_s_memtime();
+    __builtin_amdgcn_s_barrier();
+    const unsigned long long s3 = __builtin_amdgcn_s_memtime();
+    pg_issue += s0 - pg_top; pg_vm += s1 - s0; pg_lgkm += s2 - s1; pg_bar += s3 - s2; pg_top = s3;
+#else
     asm volatile("s_waitcnt vmcnt(4)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+#endif
 #pragma unroll
     for (int i = 0; i < 2; ++i) { ah[i] = nah[i]; al[i] = nal[i]; bh[i] = nbh[i]; bl[i] = nbl[i]; }
   }
+#ifdef PG_STAMPS
+  if (g.work && lane == 0 && (wave == 0 || wave == 13) && blockIdx.x == 300) {
+    const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
+    float* o = g.work + (wave ? 8 : 0);
+    o[0] = (float)pg_issue; o[1] = (float)pg_vm; o[2] = (float)pg_lgkm; o[3] = (float)pg_bar; o[4] = (float)nkt;
+    o[5] = (float)(pg_top - pg_t0); o[6] = (float)(r1 - pg_r0);
+  }
+#endif
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the re-fetched tail tiles: landed before the epilogue reuses the ring
   __syncthreads();
+#ifdef PG_NO_EPI
+  if (acc[0][0][0] + acc[0][1][3] + acc[1][0][5] + acc[1][1][7] == 12345.678f) g.C[tid] = 1.0f;
+  return;
+#endif
   if (g.vecC) gemm_epilogue_wide<256, 1024>(g, acc, reinterpret_cast<float*>(xsmem), LFI_EPI_ROWS, m0, n0, wm, wn, l31, half, batch, split, 256);
+  else gemm_epilogue_n<256>(g, acc, m0, n0, wm, wn, l31, half, batch, split);
+}
+
+// 128 x 256 variant, TWO workgroups per CU: 512 threads = 8 waves x (64 x 64) patches (wm = wave >> 2 in 0 .. 1, wn = wave & 3),
+// ring of 3 slots of [A: 4 row tiles x {hi, lo} x 1 KB][B: 8 x 2 x 1 KB] = 24 KB (72 KB; the wide epilogue's 64-row passes
+// of 66.5 KB fit inside), three DMA pieces per wave and k-tile. What the 256 x 256 kernel loses per k-tile to its one barrier
+// (stamps: 2060 cycles per phase against 1536 of MFMA issue; the last-dispatched waves of a SIMD wait 180, the first 1160) and
+// per tile to its epilogue (the CU's matrix pipe idle for ~16 us of every ~96 us) is filled by the other workgroup here.
+//   phase t:  DMA tile t + 3 -> slot t % 3 (its fragments were read in phase t - 1)
+//             MFMAs of tile t from registers, fragments of tile t + 1 read under them
+//             s_waitcnt vmcnt(3) (this wave's pieces of tile t + 2 landed; t + 3 in flight), lgkmcnt(0), s_barrier
+constexpr int QRING = 3;
+constexpr int QSLOT = 24 * 1024;
+
+__global__ __launch_bounds__(512, 4) void gemm_planes_128_kernel(GemmArgs g) {
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, half = lane >> 5;
+  int tm, tn, batch, split;
+  gemm_tile_of_block(g, &tm, &tn, &batch, &split);
+  const int m0 = tm * 128, n0 = tn * 256;
+  const int nkt = g.nkt;
+  char* lds = reinterpret_cast<char*>(xsmem);
+  // the slot's 24 blocks (A: 4 row tiles x 2 planes, then B: 8 x 2) are dealt to the 8 waves three at a time; a block's two
+  // planes are adjacent in memory and in the slot, so block j of the slot comes from panel-relative byte offset src_off(j)
+  const char* baseA = reinterpret_cast<const char*>(g.Ap + batch * g.pstrideA) + (long)(tm * 4) * g.nktA * 2048 + lane * 16;
+  const char* baseB = reinterpret_cast<const char*>(g.Bp + batch * g.pstrideB) + (long)(tn * 8) * g.nktB * 2048 + lane * 16;
+  const char* src[3];
+  int doff[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int j = wave * 3 + i;                       // block 0 .. 23
+    const int isB = j >= 8, jj = isB ? j - 8 : j;     // (row tile, plane) = (jj >> 1, jj & 1)
+    src[i] = (isB ? baseB + (long)(jj >> 1) * g.nktB * 2048 : baseA + (long)(jj >> 1) * g.nktA * 2048) + (jj & 1) * 1024;
+    doff[i] = j * 1024;
+  }
+  auto dma = [&](int kt, int slot) {
+    const long ko = (long)min(kt, nkt - 1) * 2048;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+      __builtin_amdgcn_global_load_lds((pglb_void*)(src[i] + ko), (plds_void*)(lds + slot * QSLOT + doff[i]), 16, 0, 0);
+  };
+  const int wm = wave >> 2, wn = wave & 3;
+  const int fa = (wm * 4) * 1024 + lane * 16;             // A fragment (mt, plane) at fa + (mt * 2 + plane) * 1024
+  const int fb = 8 * 1024 + (wn * 4) * 1024 + lane * 16;  // B fragment (nt, plane) at fb + (nt * 2 + plane) * 1024
+  auto frag = [&](int slot, int off) { return *reinterpret_cast<const bf16x8*>(lds + slot * QSLOT + off); };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+  bf16x8 ah[2], al[2], bh[2], bl[2];
+  dma(0, 0); dma(1, 1); dma(2, 2);
+  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+#pragma unroll
+  for (int t2 = 0; t2 < 2; ++t2) {
+    ah[t2] = frag(0, fa + (t2 * 2) * 1024); al[t2] = frag(0, fa + (t2 * 2 + 1) * 1024);
+    bh[t2] = frag(0, fb + (t2 * 2) * 1024); bl[t2] = frag(0, fb + (t2 * 2 + 1) * 1024);
+  }
+  asm volatile("s_waitcnt vmcnt(3)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+
+  int cur = 0;
+  for (int t = 0; t < nkt; ++t) {
+    const int nxt = cur == 2 ? 0 : cur + 1;
+    bf16x8 nah[2], nal[2], nbh[2], nbl[2];
+    dma(t + 3, cur);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      acc[0][nt] = PG_MFMA(al[0], bh[nt], acc[0][nt]);
+      acc[0][nt] = PG_MFMA(ah[0], bl[nt], acc[0][nt]);
+      acc[0][nt] = PG_MFMA(ah[0], bh[nt], acc[0][nt]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    nah[0] = frag(nxt, fa); nal[0] = frag(nxt, fa + 1024);
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) { nbh[nt] = frag(nxt, fb + (nt * 2) * 1024); nbl[nt] = frag(nxt, fb + (nt * 2 + 1) * 1024); }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+      acc[1][nt] = PG_MFMA(al[1], bh[nt], acc[1][nt]);
+      acc[1][nt] = PG_MFMA(ah[1], bl[nt], acc[1][nt]);
+      acc[1][nt] = PG_MFMA(ah[1], bh[nt], acc[1][nt]);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    nah[1] = frag(nxt, fa + 2048); nal[1] = frag(nxt, fa + 3072);
+    asm volatile("s_waitcnt vmcnt(3)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { ah[i] = nah[i]; al[i] = nal[i]; bh[i] = nbh[i]; bl[i] = nbl[i]; }
+    cur = nxt;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the re-fetched tail tiles: landed before the epilogue reuses the ring
+  __syncthreads();
+#ifdef PG_NO_EPI
+  if (acc[0][0][0] + acc[0][1][3] + acc[1][0][5] + acc[1][1][7] == 12345.678f) g.C[tid] = 1.0f;
+  return;
+#endif
+  if (g.vecC) gemm_epilogue_wide<256, 512>(g, acc, reinterpret_cast<float*>(xsmem), 64, m0, n0, wm, wn, l31, half, batch, split, 128);
   else gemm_epilogue_n<256>(g, acc, m0, n0, wm, wn, l31, half, batch, split);
 }
 
@@ -1851,25 +2008,49 @@ extern "C" int lfi_gemm_planes(const lfi_pgemm_desc* d, void* stream) {
   a.strideC = d->strideC; a.strideBias = d->strideBias; a.strideG = d->strideG;
   a.accumulate = d->accumulate; a.act = d->act; a.slope = d->slope;
   a.splitk = 1; a.kchunk = d->K; a.work = nullptr;
+#ifdef PG_STAMPS
+  a.work = reinterpret_cast<float*>(g_lfi_stamps);   // diagnostics build only (lfi_debug_set_stamps)
+#endif
   a.Ap = reinterpret_cast<const __bf16*>(d->Ap); a.Bp = reinterpret_cast<const __bf16*>(d->Bp);
   a.nkt = nkt; a.nktA = d->a_nkt; a.nktB = d->b_nkt; a.pstrideA = d->a_stride; a.pstrideB = d->b_stride;
   const bool c_ok = (reinterpret_cast<uintptr_t>(d->C) & 15) == 0 && d->ldc % 4 == 0 && d->strideC % 4 == 0;
   const bool g_ok = d->act != 2 || ((reinterpret_cast<uintptr_t>(d->G) & 15) == 0 && d->ldg % 4 == 0 && d->strideG % 4 == 0);
   a.vecC = (c_ok && g_ok && !(d->act == 2 && d->accumulate != 0)) ? 1 : 0;
-  a.tiles_m = lfi_cdiv(d->M, 256);
-  a.tiles_n = lfi_cdiv(d->N, 256);
-  const size_t lds_loop = (size_t)PRING * PSLOT, lds_epi = (size_t)LFI_EPI_ROWS * 260 * sizeof(float);
-  const size_t lds = lds_loop > lds_epi ? lds_loop : lds_epi;
-  static bool attr = false;
-  if (!attr) {
-    if (hipFuncSetAttribute((const void*)gemm_planes_256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
-      lfi_set_error("lfi_gemm_planes: cannot reserve %zu bytes of LDS", lds);
-      return LFI_ERR_LAUNCH;
-    }
-    attr = true;
+  static int tile256 = -1;   // LFI_PGEMM_256=1: the one-workgroup-per-CU 256 x 256 kernel instead of two 128 x 256 per CU
+  if (tile256 < 0) {
+    const char* e = getenv("LFI_PGEMM_256");
+    tile256 = (e && e[0] == '1') ? 1 : 0;
   }
-  dim3 grid(a.tiles_m * a.tiles_n, d->batch, 1);
-  hipLaunchKernelGGL(gemm_planes_256_kernel, grid, dim3(1024), lds, (hipStream_t)stream, a);
+  if (tile256) {
+    a.tiles_m = lfi_cdiv(d->M, 256);
+    a.tiles_n = lfi_cdiv(d->N, 256);
+    const size_t lds_loop = (size_t)PRING * PSLOT, lds_epi = (size_t)LFI_EPI_ROWS * 260 * sizeof(float);
+    const size_t lds = lds_loop > lds_epi ? lds_loop : lds_epi;
+    static bool attr = false;
+    if (!attr) {
+      if (hipFuncSetAttribute((const void*)gemm_planes_256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+        lfi_set_error("lfi_gemm_planes: cannot reserve %zu bytes of LDS", lds);
+        return LFI_ERR_LAUNCH;
+      }
+      attr = true;
+    }
+    dim3 grid(a.tiles_m * a.tiles_n, d->batch, 1);
+    hipLaunchKernelGGL(gemm_planes_256_kernel, grid, dim3(1024), lds, (hipStream_t)stream, a);
+  } else {
+    a.tiles_m = lfi_cdiv(d->M, 128);
+    a.tiles_n = lfi_cdiv(d->N, 256);
+    const size_t lds = (size_t)QRING * QSLOT;   // 72 KB: two workgroups per CU; the epilogue's 64 x 260 floats fit inside
+    static bool attr = false;
+    if (!attr) {
+      if (hipFuncSetAttribute((const void*)gemm_planes_128_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+        lfi_set_error("lfi_gemm_planes: cannot reserve %zu bytes of LDS", lds);
+        return LFI_ERR_LAUNCH;
+      }
+      attr = true;
+    }
+    dim3 grid(a.tiles_m * a.tiles_n, d->batch, 1);
+    hipLaunchKernelGGL(gemm_planes_128_kernel, grid, dim3(512), lds, (hipStream_t)stream, a);
+  }
   LFI_LAUNCH_CHECK("lfi_gemm_planes");
   return LFI_OK;
 }

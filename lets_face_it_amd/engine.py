@@ -406,6 +406,10 @@ class GlowEngine:
         s = self.spec
         check(self.L.lfi_cols_fold(self.fview("wct").data_ptr(), s.E, s.Ks * s.D, self.fold_a.data_ptr(),
                                    self.fold_b.data_ptr(), s.Ef, self.wct_f.data_ptr(), s.ldf, _stream()), "lfi_cols_fold")
+        if self.precision == 1:
+            # bf16 hi / lo planes of the folded weights for the cond_transform forward product: split once per parameter state
+            # here instead of once per row tile (56 times) inside the GEMM
+            self._wct_planes = self.planes("wct_planes", self.wct_f, s.ldf, s.Ks * s.D, s.Ef)
 
     # ------------------------------------------------------------------ conditioning
     def _check_input(self, x, name, B, Tmin, dim):
@@ -507,8 +511,16 @@ class GlowEngine:
         s = self.spec
         KD = s.Ks * s.D
         cbuf = self._buf("c", F * KD)
-        self.gemm(F, KD, s.Ef, cond, s.ldf, 1, self.wct_f, s.ldf, 1, cbuf, KD, bias=self.fview("bct"), act=1, slope=0.01,
-                  tag="gemm_cond_fwd")
+        if self.precision == 1 and os.environ.get("LFI_PGEMM", "1") != "0":
+            # operands pre-split into bf16 hi / lo planes in MFMA fragment order, streamed to LDS by LDS-DMA: same products
+            # and accumulation order as the fp32-operand bf16x3 kernel (bit-identical results; LFI_PGEMM=0 keeps that one)
+            cp, nkc = self.planes("cond_planes", cond, s.ldf, F, s.Ef)
+            wp, nkw = self._wct_planes
+            self.gemm_planes(F, KD, s.Ef, cp, nkc, wp, nkw, cbuf, KD, bias=self.fview("bct"), act=1, slope=0.01,
+                             tag="gemm_cond_fwd")
+        else:
+            self.gemm(F, KD, s.Ef, cond, s.ldf, 1, self.wct_f, s.ldf, 1, cbuf, KD, bias=self.fview("bct"), act=1, slope=0.01,
+                      tag="gemm_cond_fwd")
         gic = self._buf("gic", s.Ks * F * s.G)
         self.gemm(F, s.G, s.D, cbuf, KD, 1, self.prep, s.D, 1, gic, s.G, bias=self.fview("b_ih"),
                   batch=s.Ks, sA=s.D, sB=s.G * s.D, sC=F * s.G, sBias=s.G, b_off=self._wc_offset())

@@ -57,6 +57,46 @@ def main():
                 print("    wave %d, cycles per k-tile: top->stage(late) %.0f | stage(late) %.0f | mfma+frag reads %.0f | stage(early) %.0f | "
                       "barrier %.0f | (epilogue total %.0f), k-tiles %d" % (w, v[0] / n, v[1] / n, v[2] / n, v[3] / n, v[4] / n, v[5], n))
 
+    # the same k-contiguous products on pre-split planes (lfi_planes_from_f32 + lfi_gemm_planes), split time reported apart
+    def timeit(run):
+        for _ in range(3):
+            run()
+        torch.cuda.synchronize()
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        for _ in range(args.reps):
+            run()
+        e.record()
+        torch.cuda.synchronize()
+        return s.elapsed_time(e) / args.reps
+
+    for name, M, N, K in (("cond_fwd", 14336, 8192, 890), ("enc_step", 14336, 768, 256)):
+        ld = r16(K)
+        A = torch.randn(M, ld, generator=g).to(dev)
+        Bm = torch.randn(N, ld, generator=g).to(dev)
+        if os.environ.get("LFI_PROBE_ZEROS"):   # power check: all-zero operands toggle nothing (MI355X_MICROARCH.md, DVFS give-back)
+            A.zero_()
+            Bm.zero_()
+        Cm = torch.empty(M, N, device=dev)
+        bias = torch.randn(N, generator=g).to(dev)
+        t_sa = timeit(lambda: eng.planes("probe.pa", A, ld, M, K))
+        t_sb = timeit(lambda: eng.planes("probe.pb", Bm, ld, N, K))
+        Ap, nka = eng.planes("probe.pa", A, ld, M, K)
+        Bp, nkb = eng.planes("probe.pb", Bm, ld, N, K)
+        stamps = torch.zeros(64, device=dev)
+        if os.environ.get("LFI_PG_STAMPS"):   # -DPG_STAMPS build: per-phase s_memtime sums of waves 0 and 13 of workgroup 300
+            eng.L.lfi_debug_set_stamps(stamps.data_ptr())
+        ms = timeit(lambda: eng.gemm_planes(M, N, K, Ap, nka, Bp, nkb, Cm, N, bias=bias, act=1))
+        if os.environ.get("LFI_PG_STAMPS"):
+            eng.L.lfi_debug_set_stamps(None)
+            v = stamps.cpu().tolist()
+            for w, o in ((0, v[:8]), (13, v[8:16])):
+                n = max(o[4], 1.0)
+                print("    wave %2d: cycles per k-tile: issue+mfma %.0f | vmcnt wait %.0f | lgkm wait %.0f | barrier %.0f | total %.0f; "
+                      "clock %.2f GHz" % (w, o[0] / n, o[1] / n, o[2] / n, o[3] / n, o[5] / n, o[5] / max(o[6], 1.0) * 0.1))
+        print("%-11s planes M=%d N=%d K=%d: %.3f ms  %.1f TFLOP/s   (split A %.3f ms, split B %.3f ms)"
+              % (name, M, N, K, ms, 2.0 * M * N * K / ms / 1e9, t_sa, t_sb))
+
     # the two batched (one product per flow step) short-K shapes of the training step, with each tile shape pinned
     Ks, F, D, G3 = 16, 14336, 512, 384
     c = torch.randn(F, Ks * D, generator=g).to(dev)
@@ -86,6 +126,12 @@ def main():
             ms = s.elapsed_time(e) / args.reps
             print("%-45s tiles %-9s: %.3f ms  %.1f TFLOP/s" % (name, label, ms, flops / ms / 1e9))
     eng.precision = args.precision
+    cp, nkc = eng.planes("probe.pc", c, Ks * D, F, Ks * D)
+    wp, nkw = eng.planes("probe.pw", wc.view(Ks * G3, D), D, Ks * G3, D)
+    t_split = timeit(lambda: eng.planes("probe.pc", c, Ks * D, F, Ks * D))
+    ms = timeit(lambda: eng.gemm_planes(F, G3, D, cp, nkc, wp, nkw, gic, G3, bias=bias, batch=Ks, a_stride=(D // 16) * 1024,
+                                        b_stride=(G3 // 32) * nkw * 1024, sC=F * G3, sBias=G3))
+    print("flow_gic on planes: %.3f ms  %.1f TFLOP/s   (split of c, F x Ks D: %.3f ms)" % (ms, 2.0 * F * G3 * D * Ks / ms / 1e9, t_split))
 
 
 if __name__ == "__main__":
