@@ -304,6 +304,17 @@ struct EncFused {
 // contiguous bytes, a wave's fragment 1 KB: one coalesced global_load_dwordx4 per (k-tile, column tile, plane).
 typedef __bf16 ebf16x8 __attribute__((ext_vector_type(8)));
 union EncFrag { uint4 u; ebf16x8 v; };
+// (hi, lo) bf16 pairs of (a, b), packed low / high half: hi = RNE(v), lo = RNE(v - hi) - as `(__bf16)v` element by element
+typedef __bf16 ebf16x2 __attribute__((ext_vector_type(2)));
+typedef float efloat2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void split2(float a, float b, unsigned* hi, unsigned* lo) {
+  const ebf16x2 h = __builtin_convertvector((efloat2){a, b}, ebf16x2);
+  const unsigned hb = __builtin_bit_cast(unsigned, h);
+  const float ha = __builtin_bit_cast(float, hb << 16), hbv = __builtin_bit_cast(float, hb & 0xffff0000u);
+  const ebf16x2 l = __builtin_convertvector((efloat2){a - ha, b - hbv}, ebf16x2);
+  *hi = hb;
+  *lo = __builtin_bit_cast(unsigned, l);
+}
 
 // element ((((kt*3 + g)*nct + ct)*2 + plane)*64 + lane)*8 + e  (fwd)  /  ((((g*nkt + kt)*nct + ct)*2 + plane)*64 + lane)*8 + e (bwd)
 // holds k = kt*16 + 8*(lane>>5) + e, column j = ct*32 + (lane&31) of W_hh^T[k][g*hid + j] (fwd) / W_hh[g*hid + k][j] (bwd)
@@ -575,6 +586,424 @@ __global__ __launch_bounds__(ENC_NT, 2) void enc_gru_fwd_fused_kernel(EncArgs a,
       c[0] = v;
       if (a.dup) c[hid] = v;
     }
+  }
+}
+
+// ---- the same forward recurrence (bf16x3 products) with a ROW-LAYOUT gate epilogue.
+// What paced enc_gru_fwd_fused_kernel<.., true> was not HBM, L2 or the matrix pipe but the number of vector-memory
+// INSTRUCTIONS: in the accumulator layout a lane holds one column of 16 different rows, so every projected input, mask,
+// stash value is its own 4-byte access - 9 wave instructions per (row, 32 columns) and step, 37 k cycles of address
+// processing per CU and step next to 25 k for the weight fragments, against 18 k of MFMA issue (round-2 notes in DESIGN.md).
+// Here each gate's accumulators go through a wave-private LDS tile (32 rows x 64 columns, written in accumulator order,
+// read back row-wise) so that a lane owns 4 CONSECUTIVE columns of 8 rows: projected inputs come in and h, r, z, n, W_hn h
+// leave as 16-byte accesses (4.5x fewer instructions), the state images are refreshed with 8-byte LDS stores, and h_{s-1}
+// waits in that same tile during the MFMA phase (no k-major fp32 state image: 34 KB of LDS less, two workgroups per CU stay).
+typedef __attribute__((ext_vector_type(4))) unsigned enc_u32x4;
+__device__ __forceinline__ f32x4 enc_ld4(enc_rsrc r, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+__device__ __forceinline__ void enc_st4(f32x4 v, enc_rsrc r, unsigned voff, unsigned soff) {
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(enc_u32x4, v), r, voff, soff, LFI_ENC_ST_AUX);
+}
+constexpr int ENC_TP = 68;   // floats per row of the transpose tile: 272 B (16-byte aligned rows, 4-bank skew per row)
+
+template <bool STASH, bool MASK>
+__global__ __launch_bounds__(ENC_NT, 2) void enc_gru_fwd_wide_kernel(EncArgs a, EncFused q) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, half = lane >> 5;
+  const int cg = wave % q.ncg, rg = wave / q.ncg;
+  const int hid = a.hid, G3 = 3 * hid, Jp = q.Jp;
+  const int wbase = blockIdx.x * q.R;
+  const int pos0 = a.start - a.hist + 1;
+  const int ldx = q.Kp + 8;
+  // LDS: bf16 hi / lo images of h_{s-1} (row-major [R][Kp + 8]) | per-wave transpose tiles | biases [6][Jp] | per-row tables
+  __bf16* Xhi = reinterpret_cast<__bf16*>(enc_smem);
+  __bf16* Xlo = Xhi + q.R * ldx;
+  float* T = reinterpret_cast<float*>(Xlo + q.R * ldx) + wave * (32 * ENC_TP);
+  float* bias = reinterpret_cast<float*>(Xlo + q.R * ldx) + ENC_NW * (32 * ENC_TP);   // [0..2][Jp] = b_ih, [3..5][Jp] = b_hh
+  unsigned* rowx = reinterpret_cast<unsigned*>(bias + 6 * Jp);
+  unsigned* roww = rowx + q.R;
+  float* mk_tab = reinterpret_cast<float*>(roww + q.R);                                 // [R][hist] (MASK only)
+  for (int i = tid; i < q.R * ldx; i += ENC_NT) { Xhi[i] = (__bf16)0.0f; Xlo[i] = (__bf16)0.0f; }
+  for (int i = tid; i < 6 * Jp; i += ENC_NT) {
+    const int g = i / Jp, j = i - g * Jp;
+    bias[i] = j < hid ? (g < 3 ? a.b_ih[g * hid + j] : a.b_hh[(g - 3) * hid + j]) : 0.0f;
+  }
+  for (int i = tid; i < q.R; i += ENC_NT) {
+    const int w = min(wbase + i, a.F - 1);   // rows past F recompute and re-store the last window
+    const int n = w / a.B, b = w - n * a.B;
+    rowx[i] = (unsigned)(b * a.T + pos0 + n) * (unsigned)(G3 * 4);
+    roww[i] = (unsigned)w * (unsigned)(hid * 4);
+  }
+  if (MASK)
+    for (int i = tid; i < q.R * a.hist; i += ENC_NT) {
+      const int rl = i / a.hist, s = i - rl * a.hist;
+      mk_tab[i] = a.mask[(long)min(wbase + rl, a.F - 1) * a.hist + s];
+    }
+  // row layout of this wave's 32 x 64 tile: lane owns columns c4 .. c4 + 3 of rows 4 i + rsub, i = 0 .. 7
+  const int rsub = lane >> 4, c4 = (lane & 15) * 4;
+  const int j0 = cg * 64 + c4;            // first hidden index of the lane's four
+  const bool jok = j0 < hid;              // hid % 4 == 0: the four are all inside or all outside
+  {
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 8; ++i) *reinterpret_cast<f32x4*>(T + (4 * i + rsub) * ENC_TP + c4) = z;   // h_{-1} = 0
+  }
+  const enc_rsrc bx = enc_buf(a.Xp, (long)a.B * a.T * G3 * 4);
+  const unsigned h4 = (unsigned)hid * 4u;
+  __syncthreads();
+
+  for (int s = 0; s < a.hist; ++s) {
+    f32x16 acc[2][3];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int g = 0; g < 3; ++g)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][g][r] = 0.0f;
+    if (s > 0) {
+      const int nkt = q.Kp >> 4, nct = Jp >> 5;
+      const __bf16* xh = Xhi + (rg * 32 + l31) * ldx + 8 * half;
+      const __bf16* xl = Xlo + (rg * 32 + l31) * ldx + 8 * half;
+      ebf16x8 ah0, al0, ah1, al1;
+      EncFrag f0[2][3][2], f1[2][3][2];  // [t][g][plane]
+      auto load = [&](int kt, ebf16x8& ah, ebf16x8& al, EncFrag (&f)[2][3][2]) {
+        ah = *reinterpret_cast<const ebf16x8*>(xh + kt * 16);
+        al = *reinterpret_cast<const ebf16x8*>(xl + kt * 16);
+#pragma unroll
+        for (int g = 0; g < 3; ++g)
+#pragma unroll
+          for (int t = 0; t < 2; ++t) {
+            const uint4* __restrict__ wf = q.wfrag + ((long)((kt * 3 + g) * nct + cg * 2 + t) * 2) * 64;  // uniform
+            f[t][g][0].u = wf[(unsigned)lane];
+            f[t][g][1].u = (wf + 64)[(unsigned)lane];
+          }
+      };
+      auto mma = [&](const ebf16x8& ah, const ebf16x8& al, const EncFrag (&f)[2][3][2]) {
+#pragma unroll
+        for (int g = 0; g < 3; ++g)
+#pragma unroll
+          for (int t = 0; t < 2; ++t) {
+            acc[t][g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, f[t][g][0].v, acc[t][g], 0, 0, 0);
+            acc[t][g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, f[t][g][1].v, acc[t][g], 0, 0, 0);
+            acc[t][g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, f[t][g][0].v, acc[t][g], 0, 0, 0);
+          }
+      };
+      load(0, ah0, al0, f0);   // every load in the steady-state loop is unconditional (see enc_gru_fwd_fused_kernel)
+      int kt = 0;
+      for (; kt + 2 < nkt; kt += 2) {
+        load(kt + 1, ah1, al1, f1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(ah0, al0, f0);
+        load(kt + 2, ah0, al0, f0);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(ah1, al1, f1);
+      }
+      if (kt + 1 < nkt) {
+        load(kt + 1, ah1, al1, f1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(ah0, al0, f0);
+        mma(ah1, al1, f1);
+      } else {
+        mma(ah0, al0, f0);
+      }
+    }
+    // ---- gate epilogue in the row layout
+    int rsv = rsub, cv = c4, jv = j0;
+    asm volatile("" : "+v"(rsv), "+v"(cv), "+v"(jv));   // keep the per-row address arithmetic inside the step loop (registers)
+    const unsigned sx = (unsigned)s * (unsigned)(G3 * 4), j4 = (unsigned)jv * 4u;
+    const unsigned oob = jv < hid ? 0u : 0x80000000u;
+    const enc_rsrc bhs = enc_buf(STASH ? a.hseq + (long)s * a.F * hid : nullptr, STASH ? (long)a.F * hid * 4 : 0);
+    const enc_rsrc bgs = enc_buf(STASH ? a.gates + (long)s * a.F * 4 * hid : nullptr, STASH ? (long)a.F * hid * 16 : 0);
+    float* Trow = T + rsv * ENC_TP + cv;                 // + 4 i * ENC_TP per row
+    float* Tacc = T + (4 * half) * ENC_TP + l31;         // accumulator (t, r) at + ((r & 3) + 8 (r >> 2)) * ENC_TP + 32 t
+    f32x4 hp[8], xin[8];
+    unsigned xo[8], wo[8];
+    float mk[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int rl = rg * 32 + 4 * i + rsv;
+      xo[i] = rowx[rl] + j4 + oob;   // columns past hid: an offset outside every buffer (loads return 0, stores are dropped)
+      wo[i] = roww[rl];
+      mk[i] = MASK ? mk_tab[rl * a.hist + s] : 1.0f;
+      hp[i] = *reinterpret_cast<const f32x4*>(Trow + 4 * i * ENC_TP);   // h_{s-1}, parked here by the previous step
+      xin[i] = enc_ld4(bx, xo[i], sx);
+    }
+    auto transpose = [&](int g, f32x4 (&out)[8]) {   // gate g of this wave's tile: accumulator layout -> row layout
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // earlier reads of the tile are done
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Tacc[((r & 3) + 8 * (r >> 2)) * ENC_TP + 32 * t] = acc[t][g][r];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int i = 0; i < 8; ++i) out[i] = *reinterpret_cast<const f32x4*>(Trow + 4 * i * ENC_TP);
+    };
+    const f32x4 bir = *reinterpret_cast<const f32x4*>(bias + 0 * Jp + jv), bhr = *reinterpret_cast<const f32x4*>(bias + 3 * Jp + jv);
+    const f32x4 biu = *reinterpret_cast<const f32x4*>(bias + 1 * Jp + jv), bhu = *reinterpret_cast<const f32x4*>(bias + 4 * Jp + jv);
+    const f32x4 bin = *reinterpret_cast<const f32x4*>(bias + 2 * Jp + jv), bhn = *reinterpret_cast<const f32x4*>(bias + 5 * Jp + jv);
+    f32x4 rr[8], uu[8], gh[8];
+    transpose(0, gh);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) rr[i][e] = sigmoidf_(mk[i] * xin[i][e] + bir[e] + (gh[i][e] + bhr[e]));
+      if (STASH) enc_st4(rr[i], bgs, 4u * wo[i] + j4 + oob, 0);
+      xin[i] = enc_ld4(bx, xo[i], sx + h4);
+    }
+    transpose(1, gh);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) uu[i][e] = sigmoidf_(mk[i] * xin[i][e] + biu[e] + (gh[i][e] + bhu[e]));
+      if (STASH) enc_st4(uu[i], bgs, 4u * wo[i] + j4 + oob, h4);
+      xin[i] = enc_ld4(bx, xo[i], sx + 2 * h4);
+    }
+    transpose(2, gh);
+    __syncthreads();   // every wave has finished the MFMA phase: the state images may be overwritten
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int rl = rg * 32 + 4 * i + rsv;
+      f32x4 ghn, nn, hn;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        ghn[e] = gh[i][e] + bhn[e];
+        nn[e] = tanhf_(mk[i] * xin[i][e] + bin[e] + rr[i][e] * ghn[e]);
+        hn[e] = (1.0f - uu[i][e]) * nn[e] + uu[i][e] * hp[i][e];
+      }
+      if (STASH) {
+        enc_st4(nn, bgs, 4u * wo[i] + j4 + oob, 2 * h4);
+        enc_st4(ghn, bgs, 4u * wo[i] + j4 + oob, 3 * h4);
+        enc_st4(hn, bhs, wo[i] + j4 + oob, 0);
+      }
+      if (jok) {
+        uint2 h, l;
+        split2(hn[0], hn[1], &h.x, &l.x);
+        split2(hn[2], hn[3], &h.y, &l.y);
+        *reinterpret_cast<uint2*>(Xhi + rl * ldx + jv) = h;
+        *reinterpret_cast<uint2*>(Xlo + rl * ldx + jv) = l;
+      }
+      hp[i] = hn;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the tile's last row-wise reads are done
+#pragma unroll
+    for (int i = 0; i < 8; ++i) *reinterpret_cast<f32x4*>(Trow + 4 * i * ENC_TP) = hp[i];   // park h_s for the next step
+    if (s == a.hist - 1 && jok) {   // cat(seq[:, -1], h_n[0]): the final state, once or twice (glow/models.py:63-64)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int w = wbase + rg * 32 + 4 * i + rsv;
+        if (w < a.F) {
+          float* c = a.cond + (long)w * a.ldcond + a.col + jv;
+          *reinterpret_cast<f32x4*>(c) = hp[i];
+          if (a.dup) *reinterpret_cast<f32x4*>(c + hid) = hp[i];
+        }
+      }
+    }
+    __syncthreads();   // the new state images are complete
+  }
+}
+
+// ---- 64 windows per workgroup, ONE workgroup per CU. With 32 windows per workgroup every workgroup streams all of W_hh
+// (786 KB as bf16 hi + lo) from L2 per history step, twice per CU: 12 sixteen-byte loads per wave and k-tile, 1536 cycles of
+// address processing per k-tile and CU against 1152 of MFMA issue - the recurrent product ran at half the matrix rate
+// (stamps: ~126 cycles per MFMA) however cheap the epilogue became. Here wave w owns hidden columns [32 w, 32 w + 32) of ALL
+// 64 rows: it streams only its own eighth of the weights (6 loads per k-tile, 768 cycles per CU), reads both row tiles'
+// state fragments from LDS, and the epilogue is the row-layout one above on a 64 x 32 tile.
+template <bool STASH, bool MASK>
+__global__ __launch_bounds__(512, 2) void enc_gru_fwd_r64_kernel(EncArgs a, EncFused q) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, half = lane >> 5;
+  constexpr int NT = 512, NWV = 8, R = 64, TP = 36;   // one workgroup per CU: 64 windows, wave = all 64 rows x 32 hidden columns
+  const int cg = wave;
+  const int hid = a.hid, G3 = 3 * hid, Jp = q.Jp;
+  const int wbase = blockIdx.x * R;
+  const int pos0 = a.start - a.hist + 1;
+  const int ldx = q.Kp + 8;
+  // LDS: bf16 hi / lo images of h_{s-1} (row-major [R][Kp + 8]) | per-wave transpose tiles | biases [6][Jp] | per-row tables
+  __bf16* Xhi = reinterpret_cast<__bf16*>(enc_smem);
+  __bf16* Xlo = Xhi + R * ldx;
+  float* T = reinterpret_cast<float*>(Xlo + R * ldx) + wave * (64 * TP);
+  float* bias = reinterpret_cast<float*>(Xlo + R * ldx) + NWV * (64 * TP);   // [0..2][Jp] = b_ih, [3..5][Jp] = b_hh
+  unsigned* rowx = reinterpret_cast<unsigned*>(bias + 6 * Jp);
+  unsigned* roww = rowx + R;
+  float* mk_tab = reinterpret_cast<float*>(roww + R);                                 // [R][hist] (MASK only)
+  for (int i = tid; i < R * ldx; i += NT) { Xhi[i] = (__bf16)0.0f; Xlo[i] = (__bf16)0.0f; }
+  for (int i = tid; i < 6 * Jp; i += NT) {
+    const int g = i / Jp, j = i - g * Jp;
+    bias[i] = j < hid ? (g < 3 ? a.b_ih[g * hid + j] : a.b_hh[(g - 3) * hid + j]) : 0.0f;
+  }
+  for (int i = tid; i < R; i += NT) {
+    const int w = min(wbase + i, a.F - 1);   // rows past F recompute and re-store the last window
+    const int n = w / a.B, b = w - n * a.B;
+    rowx[i] = (unsigned)(b * a.T + pos0 + n) * (unsigned)(G3 * 4);
+    roww[i] = (unsigned)w * (unsigned)(hid * 4);
+  }
+  if (MASK)
+    for (int i = tid; i < R * a.hist; i += NT) {
+      const int rl = i / a.hist, s = i - rl * a.hist;
+      mk_tab[i] = a.mask[(long)min(wbase + rl, a.F - 1) * a.hist + s];
+    }
+  // row layout of this wave's 64 x 32 tile: lane owns columns c4 .. c4 + 3 of rows 8 i + rsub, i = 0 .. 7
+  const int rsub = lane >> 3, c4 = (lane & 7) * 4;
+  const int j0 = cg * 32 + c4;            // first hidden index of the lane's four
+  const bool jok = j0 < hid;              // hid % 4 == 0: the four are all inside or all outside
+  {
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 8; ++i) *reinterpret_cast<f32x4*>(T + (8 * i + rsub) * TP + c4) = z;   // h_{-1} = 0
+  }
+  const enc_rsrc bx = enc_buf(a.Xp, (long)a.B * a.T * G3 * 4);
+  const unsigned h4 = (unsigned)hid * 4u;
+  __syncthreads();
+
+  for (int s = 0; s < a.hist; ++s) {
+    f32x16 acc[2][3];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int g = 0; g < 3; ++g)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][g][r] = 0.0f;
+    if (s > 0 && cg * 32 < hid) {
+      const int nkt = q.Kp >> 4, nct = Jp >> 5;
+      const __bf16* xh = Xhi + l31 * ldx + 8 * half;   // row tile t at + 32 t ldx
+      const __bf16* xl = Xlo + l31 * ldx + 8 * half;
+      ebf16x8 ah0[2], al0[2], ah1[2], al1[2];
+      EncFrag f0[3][2], f1[3][2];  // [g][plane]
+      auto load = [&](int kt, ebf16x8 (&ah)[2], ebf16x8 (&al)[2], EncFrag (&f)[3][2]) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          ah[t] = *reinterpret_cast<const ebf16x8*>(xh + t * 32 * ldx + kt * 16);
+          al[t] = *reinterpret_cast<const ebf16x8*>(xl + t * 32 * ldx + kt * 16);
+        }
+#pragma unroll
+        for (int g = 0; g < 3; ++g) {
+          const uint4* __restrict__ wf = q.wfrag + ((long)((kt * 3 + g) * nct + cg) * 2) * 64;  // uniform
+          f[g][0].u = wf[(unsigned)lane];
+          f[g][1].u = (wf + 64)[(unsigned)lane];
+        }
+      };
+      auto mma = [&](const ebf16x8 (&ah)[2], const ebf16x8 (&al)[2], const EncFrag (&f)[3][2]) {
+#pragma unroll
+        for (int g = 0; g < 3; ++g)
+#pragma unroll
+          for (int t = 0; t < 2; ++t) {
+            acc[t][g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[t], f[g][0].v, acc[t][g], 0, 0, 0);
+            acc[t][g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[t], f[g][1].v, acc[t][g], 0, 0, 0);
+            acc[t][g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[t], f[g][0].v, acc[t][g], 0, 0, 0);
+          }
+      };
+      load(0, ah0, al0, f0);   // every load in the steady-state loop is unconditional (see enc_gru_fwd_fused_kernel)
+      int kt = 0;
+      for (; kt + 2 < nkt; kt += 2) {
+        load(kt + 1, ah1, al1, f1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(ah0, al0, f0);
+        load(kt + 2, ah0, al0, f0);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(ah1, al1, f1);
+      }
+      if (kt + 1 < nkt) {
+        load(kt + 1, ah1, al1, f1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(ah0, al0, f0);
+        mma(ah1, al1, f1);
+      } else {
+        mma(ah0, al0, f0);
+      }
+    }
+    // ---- gate epilogue in the row layout
+    int rsv = rsub, cv = c4, jv = j0;
+    asm volatile("" : "+v"(rsv), "+v"(cv), "+v"(jv));   // keep the per-row address arithmetic inside the step loop (registers)
+    const unsigned sx = (unsigned)s * (unsigned)(G3 * 4), j4 = (unsigned)jv * 4u;
+    const unsigned oob = jv < hid ? 0u : 0x80000000u;
+    const enc_rsrc bhs = enc_buf(STASH ? a.hseq + (long)s * a.F * hid : nullptr, STASH ? (long)a.F * hid * 4 : 0);
+    const enc_rsrc bgs = enc_buf(STASH ? a.gates + (long)s * a.F * 4 * hid : nullptr, STASH ? (long)a.F * hid * 16 : 0);
+    float* Trow = T + rsv * TP + cv;                 // + 8 i * TP per row
+    float* Tacc = T + (4 * half) * TP + l31;         // accumulator (t, r) at + (32 t + (r & 3) + 8 (r >> 2)) * TP
+    f32x4 hp[8], xin[8];
+    unsigned xo[8], wo[8];
+    float mk[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int rl = 8 * i + rsv;
+      xo[i] = rowx[rl] + j4 + oob;   // columns past hid: an offset outside every buffer (loads return 0, stores are dropped)
+      wo[i] = roww[rl];
+      mk[i] = MASK ? mk_tab[rl * a.hist + s] : 1.0f;
+      hp[i] = *reinterpret_cast<const f32x4*>(Trow + 8 * i * TP);   // h_{s-1}, parked here by the previous step
+      xin[i] = enc_ld4(bx, xo[i], sx);
+    }
+    auto transpose = [&](int g, f32x4 (&out)[8]) {   // gate g of this wave's tile: accumulator layout -> row layout
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // earlier reads of the tile are done
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Tacc[(32 * t + (r & 3) + 8 * (r >> 2)) * TP] = acc[t][g][r];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int i = 0; i < 8; ++i) out[i] = *reinterpret_cast<const f32x4*>(Trow + 8 * i * TP);
+    };
+    const f32x4 bir = *reinterpret_cast<const f32x4*>(bias + 0 * Jp + jv), bhr = *reinterpret_cast<const f32x4*>(bias + 3 * Jp + jv);
+    const f32x4 biu = *reinterpret_cast<const f32x4*>(bias + 1 * Jp + jv), bhu = *reinterpret_cast<const f32x4*>(bias + 4 * Jp + jv);
+    const f32x4 bin = *reinterpret_cast<const f32x4*>(bias + 2 * Jp + jv), bhn = *reinterpret_cast<const f32x4*>(bias + 5 * Jp + jv);
+    f32x4 rr[8], uu[8], gh[8];
+    transpose(0, gh);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) rr[i][e] = sigmoidf_(mk[i] * xin[i][e] + bir[e] + (gh[i][e] + bhr[e]));
+      if (STASH) enc_st4(rr[i], bgs, 4u * wo[i] + j4 + oob, 0);
+      xin[i] = enc_ld4(bx, xo[i], sx + h4);
+    }
+    transpose(1, gh);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) uu[i][e] = sigmoidf_(mk[i] * xin[i][e] + biu[e] + (gh[i][e] + bhu[e]));
+      if (STASH) enc_st4(uu[i], bgs, 4u * wo[i] + j4 + oob, h4);
+      xin[i] = enc_ld4(bx, xo[i], sx + 2 * h4);
+    }
+    transpose(2, gh);
+    __syncthreads();   // every wave has finished the MFMA phase: the state images may be overwritten
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int rl = 8 * i + rsv;
+      f32x4 ghn, nn, hn;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        ghn[e] = gh[i][e] + bhn[e];
+        nn[e] = tanhf_(mk[i] * xin[i][e] + bin[e] + rr[i][e] * ghn[e]);
+        hn[e] = (1.0f - uu[i][e]) * nn[e] + uu[i][e] * hp[i][e];
+      }
+      if (STASH) {
+        enc_st4(nn, bgs, 4u * wo[i] + j4 + oob, 2 * h4);
+        enc_st4(ghn, bgs, 4u * wo[i] + j4 + oob, 3 * h4);
+        enc_st4(hn, bhs, wo[i] + j4 + oob, 0);
+      }
+      if (jok) {
+        uint2 h, l;
+        split2(hn[0], hn[1], &h.x, &l.x);
+        split2(hn[2], hn[3], &h.y, &l.y);
+        *reinterpret_cast<uint2*>(Xhi + rl * ldx + jv) = h;
+        *reinterpret_cast<uint2*>(Xlo + rl * ldx + jv) = l;
+      }
+      hp[i] = hn;
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the tile's last row-wise reads are done
+#pragma unroll
+    for (int i = 0; i < 8; ++i) *reinterpret_cast<f32x4*>(Trow + 8 * i * TP) = hp[i];   // park h_s for the next step
+    if (s == a.hist - 1 && jok) {   // cat(seq[:, -1], h_n[0]): the final state, once or twice (glow/models.py:63-64)
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int w = wbase + 8 * i + rsv;
+        if (w < a.F) {
+          float* c = a.cond + (long)w * a.ldcond + a.col + jv;
+          *reinterpret_cast<f32x4*>(c) = hp[i];
+          if (a.dup) *reinterpret_cast<f32x4*>(c + hid) = hp[i];
+        }
+      }
+    }
+    __syncthreads();   // the new state images are complete
   }
 }
 
@@ -928,6 +1357,63 @@ extern "C" int lfi_encode_windows_fwd(const lfi_enc_desc* d, const float* Xp, co
     const size_t lds = (size_t)q.Kp * (q.R + 1) * sizeof(float) + (x3 ? (size_t)2 * q.R * (q.Kp + 8) * sizeof(__bf16) : 0) +
                        (size_t)3 * q.R * sizeof(unsigned);   // state images + per-row offset tables
     const dim3 grid(lfi_cdiv(F, q.R));
+    {
+      // row-layout epilogue variant (16-byte accesses): needs 4-float granular rows everywhere it vectorises
+      static int wide = -1;
+      if (wide < 0) {
+        const char* e = getenv("LFI_ENC_WIDE");
+        wide = (e && e[0] == '0') ? 0 : 1;
+      }
+      auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+      const size_t ldsw = (size_t)2 * q.R * (q.Kp + 8) * sizeof(__bf16) + (size_t)ENC_NW * 32 * ENC_TP * sizeof(float) +
+                          (size_t)6 * q.Jp * sizeof(float) + (size_t)2 * q.R * sizeof(unsigned) +
+                          (mask ? (size_t)q.R * d->hist * sizeof(float) : 0);
+      const bool vec_ok = x3 && hid % 4 == 0 && d->ldcond % 4 == 0 && d->col % 4 == 0 && al16(Xp) && al16(cond) &&
+                          (!gates || (al16(gates) && al16(hseq)));
+      static int r64 = -1;
+      if (r64 < 0) {
+        const char* e = getenv("LFI_ENC_R64");
+        r64 = (e && e[0] == '0') ? 0 : 1;
+      }
+      const size_t lds64 = (size_t)2 * 64 * (q.Kp + 8) * sizeof(__bf16) + (size_t)8 * 64 * 36 * sizeof(float) +
+                           (size_t)6 * q.Jp * sizeof(float) + (size_t)2 * 64 * sizeof(unsigned) +
+                           (mask ? (size_t)64 * d->hist * sizeof(float) : 0);
+      if (wide && r64 && vec_ok && hid > 128 && lds64 <= 160 * 1024 && F >= 64 * 64) {   // wide recurrences with enough windows to fill the chip
+        rc = LFI_OK;
+        const dim3 grid64(lfi_cdiv(F, 64));
+        switch ((gates ? 2 : 0) | (mask ? 1 : 0)) {
+#define LFI_ENC_FWD64(ST, MK)                                                                                \
+  rc = enc_set_lds(enc_gru_fwd_r64_kernel<ST, MK>, lds64);                                                   \
+  if (!rc) hipLaunchKernelGGL((enc_gru_fwd_r64_kernel<ST, MK>), grid64, dim3(512), lds64, st, a, q);        \
+  break
+          case 3: LFI_ENC_FWD64(true, true);
+          case 2: LFI_ENC_FWD64(true, false);
+          case 1: LFI_ENC_FWD64(false, true);
+          default: LFI_ENC_FWD64(false, false);
+#undef LFI_ENC_FWD64
+        }
+        if (rc) return rc;
+        LFI_LAUNCH_CHECK("lfi_encode_windows_fwd (fused, 64 windows per workgroup)");
+        return LFI_OK;
+      }
+      if (wide && vec_ok && ldsw <= 80 * 1024) {
+        rc = LFI_OK;
+        switch ((gates ? 2 : 0) | (mask ? 1 : 0)) {
+#define LFI_ENC_FWDW(ST, MK)                                                                                  \
+  rc = enc_set_lds(enc_gru_fwd_wide_kernel<ST, MK>, ldsw);                                                    \
+  if (!rc) hipLaunchKernelGGL((enc_gru_fwd_wide_kernel<ST, MK>), grid, dim3(ENC_NT), ldsw, st, a, q);        \
+  break
+          case 3: LFI_ENC_FWDW(true, true);
+          case 2: LFI_ENC_FWDW(true, false);
+          case 1: LFI_ENC_FWDW(false, true);
+          default: LFI_ENC_FWDW(false, false);
+#undef LFI_ENC_FWDW
+        }
+        if (rc) return rc;
+        LFI_LAUNCH_CHECK("lfi_encode_windows_fwd (fused, row-layout epilogue)");
+        return LFI_OK;
+      }
+    }
     const int variant = (gates ? 4 : 0) | (mask ? 2 : 0) | (x3 ? 1 : 0);
     rc = LFI_OK;
     switch (variant) {
