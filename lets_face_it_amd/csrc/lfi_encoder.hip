@@ -809,6 +809,13 @@ __global__ __launch_bounds__(ENC_NT, 2) void enc_gru_fwd_wide_kernel(EncArgs a, 
 // (stamps: ~126 cycles per MFMA) however cheap the epilogue became. Here wave w owns hidden columns [32 w, 32 w + 32) of ALL
 // 64 rows: it streams only its own eighth of the weights (6 loads per k-tile, 768 cycles per CU), reads both row tiles'
 // state fragments from LDS, and the epilogue is the row-layout one above on a 64 x 32 tile.
+// MEASURED (round 2, same box): 0.757 ms against 0.729 ms for the 32-window kernel on the p2_face launch - not faster, so it
+// is opt-in (LFI_ENC_R64=1). Stamps (tools/enc_stamps.py, -DLFI_ENC_STAMPS): per history step the recurrent product takes
+// 21 k cycles in the first-dispatched wave of a SIMD and 32 k in the second (18.4 k would be MFMA-bound), the epilogue 11 k;
+// with the weight loads removed (-DENC_NO_BLOAD) 18 k / 28 k, with the MFMAs removed (-DENC_NO_MMA) 22 k / 26 k: streaming
+// 786 KB of fragments per CU and step from L2 alone takes longer than the MFMAs (33 B/clk/CU, 17 TB/s chip-wide: every CU
+// reads the same lines at the same time), the two do not overlap well, and the single workgroup per CU serialises the
+// epilogue behind them. Four k-tiles of fragments in flight instead of two made it slower (30 k / 42 k).
 template <bool STASH, bool MASK>
 __global__ __launch_bounds__(512, 2) void enc_gru_fwd_r64_kernel(EncArgs a, EncFused q) {
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -856,7 +863,14 @@ __global__ __launch_bounds__(512, 2) void enc_gru_fwd_r64_kernel(EncArgs a, EncF
   const unsigned h4 = (unsigned)hid * 4u;
   __syncthreads();
 
+#ifdef LFI_ENC_STAMPS
+  unsigned long long st_mfma = 0, st_e1 = 0, st_b1 = 0, st_e2 = 0, st_b2 = 0;
+  const unsigned long long st_t0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
   for (int s = 0; s < a.hist; ++s) {
+#ifdef LFI_ENC_STAMPS
+    const unsigned long long c0 = __builtin_amdgcn_s_memtime();
+#endif
     f32x16 acc[2][3];
 #pragma unroll
     for (int t = 0; t < 2; ++t)
@@ -912,6 +926,10 @@ __global__ __launch_bounds__(512, 2) void enc_gru_fwd_r64_kernel(EncArgs a, EncF
         mma(ah0, al0, f0);
       }
     }
+#ifdef LFI_ENC_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime();
+#endif
     // ---- gate epilogue in the row layout
     int rsv = rsub, cv = c4, jv = j0;
     asm volatile("" : "+v"(rsv), "+v"(cv), "+v"(jv));   // keep the per-row address arithmetic inside the step loop (registers)
@@ -964,7 +982,13 @@ __global__ __launch_bounds__(512, 2) void enc_gru_fwd_r64_kernel(EncArgs a, EncF
       xin[i] = enc_ld4(bx, xo[i], sx + 2 * h4);
     }
     transpose(2, gh);
+#ifdef LFI_ENC_STAMPS
+    const unsigned long long c2 = __builtin_amdgcn_s_memtime();
+#endif
     __syncthreads();   // every wave has finished the MFMA phase: the state images may be overwritten
+#ifdef LFI_ENC_STAMPS
+    const unsigned long long c3 = __builtin_amdgcn_s_memtime();
+#endif
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int rl = 8 * i + rsv;
@@ -1003,8 +1027,22 @@ __global__ __launch_bounds__(512, 2) void enc_gru_fwd_r64_kernel(EncArgs a, EncF
         }
       }
     }
+#ifdef LFI_ENC_STAMPS
+    const unsigned long long c4s = __builtin_amdgcn_s_memtime();
+#endif
     __syncthreads();   // the new state images are complete
+#ifdef LFI_ENC_STAMPS
+    const unsigned long long c5 = __builtin_amdgcn_s_memtime();
+    if (s > 0) { st_mfma += c1 - c0; st_e1 += c2 - c1; st_b1 += c3 - c2; st_e2 += c4s - c3; st_b2 += c5 - c4s; }
+#endif
   }
+#ifdef LFI_ENC_STAMPS
+  if (a.stamps && lane == 0 && (wave == 0 || wave == 5) && blockIdx.x == 100) {
+    unsigned long long* o = a.stamps + 256 + (wave ? 8 : 0);
+    o[0] = st_mfma; o[1] = st_e1; o[2] = st_b1; o[3] = st_e2; o[4] = st_b2; o[5] = a.hist - 1;
+    o[6] = __builtin_amdgcn_s_memtime() - st_t0; o[7] = __builtin_amdgcn_s_memrealtime() - st_r0;
+  }
+#endif
 }
 
 // BPTT of the same block of windows in one workgroup: dh lives in the accumulator layout of the wave that owns
@@ -1373,7 +1411,7 @@ extern "C" int lfi_encode_windows_fwd(const lfi_enc_desc* d, const float* Xp, co
       static int r64 = -1;
       if (r64 < 0) {
         const char* e = getenv("LFI_ENC_R64");
-        r64 = (e && e[0] == '0') ? 0 : 1;
+        r64 = (e && e[0] == '1') ? 1 : 0;   // opt-in: same-box 0.757 vs 0.729 ms on the p2_face launch (notes above the kernel)
       }
       const size_t lds64 = (size_t)2 * 64 * (q.Kp + 8) * sizeof(__bf16) + (size_t)8 * 64 * 36 * sizeof(float) +
                            (size_t)6 * q.Jp * sizeof(float) + (size_t)2 * 64 * sizeof(unsigned) +
