@@ -56,7 +56,10 @@ typedef struct {
                                  three bf16 MFMAs per step into fp32 accumulators (~2^-16 relative); needs 16-byte aligned
                                  operands, otherwise the exact kernel runs. Tests may OR in 0x10 (force the 256 x 256 tile
                                  kernel) or 0x20 (force 128 x 128) instead of the library's own choice, and 0x40 (the opt-in 32-k
-                                 variant of the 256 x 256 kernel instead of the 16-k one) */
+                                 variant of the 256 x 256 kernel instead of the 16-k one). Bits 8 / 9 (0x100 / 0x200) DROP the
+                                 a_lo * b_hi / a_hi * b_lo product of the bf16x3 kernels (a measurement switch: what each GEMM
+                                 class loses with one or two bf16 passes, tools/precision_sweep.py -> profiles/precision_sweep.md;
+                                 never set by the engine's default configuration) */
 } lfi_gemm_desc;
 
 long lfi_gemm_work_floats(const lfi_gemm_desc* d);
@@ -84,6 +87,7 @@ typedef struct {
   const float* bias; const float* G; long ldg;   /* as lfi_gemm_desc */
   int batch; long strideC, strideBias, strideG;
   int accumulate, act; float slope;
+  int skip;                                      /* bit 0 drops a_lo * b_hi, bit 1 a_hi * b_lo (as lfi_gemm_desc.precision bits 8 / 9) */
 } lfi_pgemm_desc;
 int lfi_gemm_planes(const lfi_pgemm_desc* d, void* stream);
 

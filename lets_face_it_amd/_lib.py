@@ -38,7 +38,7 @@ class PGemmDesc(C.Structure):
         ("C", C.c_void_p), ("ldc", C.c_long),
         ("bias", C.c_void_p), ("G", C.c_void_p), ("ldg", C.c_long),
         ("batch", C.c_int), ("strideC", C.c_long), ("strideBias", C.c_long), ("strideG", C.c_long),
-        ("accumulate", C.c_int), ("act", C.c_int), ("slope", C.c_float),
+        ("accumulate", C.c_int), ("act", C.c_int), ("slope", C.c_float), ("skip", C.c_int),
     ]
 
 

@@ -45,6 +45,8 @@ struct GemmArgs {
   const __bf16* Ap; const __bf16* Bp;   // block ((rt * nkt_op + kt) * 2 + plane) * 512 bf16, rt = 32-row tile, kt = 16-k tile
   int nkt, nktA, nktB;                  // k-tiles of this product; k-tiles per row tile in either plane buffer
   long pstrideA, pstrideB;              // bf16 elements between batch entries
+  int skip;   // bf16x3 kernels: bit 0 drops the a_lo * b_hi product, bit 1 the a_hi * b_lo product (lfi_gemm_desc.precision
+              // bits 8 / 9; tools/precision_sweep.py). 0 = all three products.
 };
 
 __device__ __forceinline__ float apply_act(float v, int act, float slope, const float* G, long gidx) {
@@ -534,16 +536,24 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(GemmArgs g) {
         bh[t2] = *reinterpret_cast<const bf16x8*>(base + 2 * XIMG + co);
         bl[t2] = *reinterpret_cast<const bf16x8*>(base + 3 * XIMG + co);
       }
+      // three products per accumulator and k-step, in the order lo*hi, hi*lo, hi*hi (each accumulator sees them in that
+      // order whichever are switched on: results with skip = 0 are what they always were)
+      if (!(g.skip & 1)) {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+      }
+      if (!(g.skip & 2)) {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt], bl[nt], acc[mt][nt], 0, 0, 0);
+      }
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
-#ifndef LFI_DEBUG_X1
-          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mt], bh[nt], acc[mt][nt], 0, 0, 0);
-          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt], bl[nt], acc[mt][nt], 0, 0, 0);
-#endif
-          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt], bh[nt], acc[mt][nt], 0, 0, 0);
-        }
+        for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt], bh[nt], acc[mt][nt], 0, 0, 0);
     }
     if (kt + 1 < nkt) store_tiles(kt + 1, buf ^ 1);
     __syncthreads();
@@ -868,14 +878,22 @@ __global__ __launch_bounds__(1024, 4) void gemm_bf16x3_256_kernel(GemmArgs g) {
       bh[t2] = yfrag<BKC>(base + 2 * YIMG, wn * 64 + t2 * 32, lane);
       bl[t2] = yfrag<BKC>(base + 3 * YIMG, wn * 64 + t2 * 32, lane);
     }
+    if (!(g.skip & 1)) {
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+    }
+    if (!(g.skip & 2)) {
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt], bl[nt], acc[mt][nt], 0, 0, 0);
+    }
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-      for (int nt = 0; nt < 2; ++nt) {
-        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mt], bh[nt], acc[mt][nt], 0, 0, 0);
-        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt], bl[nt], acc[mt][nt], 0, 0, 0);
-        acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt], bh[nt], acc[mt][nt], 0, 0, 0);
-      }
+      for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt], bh[nt], acc[mt][nt], 0, 0, 0);
   };
 
   // tile t lives in register set t % YDEPTH; at the top of iteration kt tile kt is already in LDS buffer kt & 1.
@@ -1476,14 +1494,14 @@ __global__ __launch_bounds__(1024) void gemm_planes_256_kernel(GemmArgs g) {
     bf16x8 nah[2], nal[2], nbh[2], nbl[2];
     if (wm == 0) dma(t + 4, cur);
     __builtin_amdgcn_sched_barrier(0);
-    acc[0][0] = PG_MFMA(al[0], bh[0], acc[0][0]);
-    acc[0][0] = PG_MFMA(ah[0], bl[0], acc[0][0]);
+    if (!(g.skip & 1)) acc[0][0] = PG_MFMA(al[0], bh[0], acc[0][0]);
+    if (!(g.skip & 2)) acc[0][0] = PG_MFMA(ah[0], bl[0], acc[0][0]);
     acc[0][0] = PG_MFMA(ah[0], bh[0], acc[0][0]);
     __builtin_amdgcn_sched_barrier(0);
     if (wm == 1) dma(t + 4, cur);
     __builtin_amdgcn_sched_barrier(0);
-    acc[0][1] = PG_MFMA(al[0], bh[1], acc[0][1]);
-    acc[0][1] = PG_MFMA(ah[0], bl[1], acc[0][1]);
+    if (!(g.skip & 1)) acc[0][1] = PG_MFMA(al[0], bh[1], acc[0][1]);
+    if (!(g.skip & 2)) acc[0][1] = PG_MFMA(ah[0], bl[1], acc[0][1]);
     acc[0][1] = PG_MFMA(ah[0], bh[1], acc[0][1]);
     __builtin_amdgcn_sched_barrier(0);
     // tile t + 1: A fragments of row tile 0 into the registers just freed, B fragments into a second set
@@ -1493,14 +1511,14 @@ __global__ __launch_bounds__(1024) void gemm_planes_256_kernel(GemmArgs g) {
     __builtin_amdgcn_sched_barrier(0);
     if (wm == 2) dma(t + 4, cur);
     __builtin_amdgcn_sched_barrier(0);
-    acc[1][0] = PG_MFMA(al[1], bh[0], acc[1][0]);
-    acc[1][0] = PG_MFMA(ah[1], bl[0], acc[1][0]);
+    if (!(g.skip & 1)) acc[1][0] = PG_MFMA(al[1], bh[0], acc[1][0]);
+    if (!(g.skip & 2)) acc[1][0] = PG_MFMA(ah[1], bl[0], acc[1][0]);
     acc[1][0] = PG_MFMA(ah[1], bh[0], acc[1][0]);
     __builtin_amdgcn_sched_barrier(0);
     if (wm == 3) dma(t + 4, cur);
     __builtin_amdgcn_sched_barrier(0);
-    acc[1][1] = PG_MFMA(al[1], bh[1], acc[1][1]);
-    acc[1][1] = PG_MFMA(ah[1], bl[1], acc[1][1]);
+    if (!(g.skip & 1)) acc[1][1] = PG_MFMA(al[1], bh[1], acc[1][1]);
+    if (!(g.skip & 2)) acc[1][1] = PG_MFMA(ah[1], bl[1], acc[1][1]);
     acc[1][1] = PG_MFMA(ah[1], bh[1], acc[1][1]);
     __builtin_amdgcn_sched_barrier(0);
     nah[1] = frag(nxt, fa + 2048); nal[1] = frag(nxt, fa + 3072);
@@ -1608,23 +1626,31 @@ __global__ __launch_bounds__(512, 4) void gemm_planes_128_kernel(GemmArgs g) {
     bf16x8 nah[2], nal[2], nbh[2], nbl[2];
     dma(t + 3, cur);
     __builtin_amdgcn_sched_barrier(0);
+    if (!(g.skip & 1)) {
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-      acc[0][nt] = PG_MFMA(al[0], bh[nt], acc[0][nt]);
-      acc[0][nt] = PG_MFMA(ah[0], bl[nt], acc[0][nt]);
-      acc[0][nt] = PG_MFMA(ah[0], bh[nt], acc[0][nt]);
+      for (int nt = 0; nt < 2; ++nt) acc[0][nt] = PG_MFMA(al[0], bh[nt], acc[0][nt]);
     }
+    if (!(g.skip & 2)) {
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) acc[0][nt] = PG_MFMA(ah[0], bl[nt], acc[0][nt]);
+    }
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) acc[0][nt] = PG_MFMA(ah[0], bh[nt], acc[0][nt]);
     __builtin_amdgcn_sched_barrier(0);
     nah[0] = frag(nxt, fa); nal[0] = frag(nxt, fa + 1024);
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) { nbh[nt] = frag(nxt, fb + (nt * 2) * 1024); nbl[nt] = frag(nxt, fb + (nt * 2 + 1) * 1024); }
     __builtin_amdgcn_sched_barrier(0);
+    if (!(g.skip & 1)) {
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-      acc[1][nt] = PG_MFMA(al[1], bh[nt], acc[1][nt]);
-      acc[1][nt] = PG_MFMA(ah[1], bl[nt], acc[1][nt]);
-      acc[1][nt] = PG_MFMA(ah[1], bh[nt], acc[1][nt]);
+      for (int nt = 0; nt < 2; ++nt) acc[1][nt] = PG_MFMA(al[1], bh[nt], acc[1][nt]);
     }
+    if (!(g.skip & 2)) {
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) acc[1][nt] = PG_MFMA(ah[1], bl[nt], acc[1][nt]);
+    }
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) acc[1][nt] = PG_MFMA(ah[1], bh[nt], acc[1][nt]);
     __builtin_amdgcn_sched_barrier(0);
     nah[1] = frag(nxt, fa + 2048); nal[1] = frag(nxt, fa + 3072);
     asm volatile("s_waitcnt vmcnt(3)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1826,6 +1852,7 @@ extern "C" int lfi_gemm_f32(const lfi_gemm_desc* d, void* stream) {
   a.work = d->work;
   a.vecA = vecA;
   a.vecB = vecB;
+  a.skip = (d->precision >> 8) & 3;
   {
     // C (or the split-K workspace) and G rows 16-byte aligned; act 2 together with accumulate stays on the narrow path
     const bool partial = splitk > 1;
@@ -2013,6 +2040,7 @@ extern "C" int lfi_gemm_planes(const lfi_pgemm_desc* d, void* stream) {
 #endif
   a.Ap = reinterpret_cast<const __bf16*>(d->Ap); a.Bp = reinterpret_cast<const __bf16*>(d->Bp);
   a.nkt = nkt; a.nktA = d->a_nkt; a.nktB = d->b_nkt; a.pstrideA = d->a_stride; a.pstrideB = d->b_stride;
+  a.skip = d->skip & 3;
   const bool c_ok = (reinterpret_cast<uintptr_t>(d->C) & 15) == 0 && d->ldc % 4 == 0 && d->strideC % 4 == 0;
   const bool g_ok = d->act != 2 || ((reinterpret_cast<uintptr_t>(d->G) & 15) == 0 && d->ldg % 4 == 0 && d->strideG % 4 == 0);
   a.vecC = (c_ok && g_ok && !(d->act == 2 && d->accumulate != 0)) ? 1 : 0;

@@ -215,6 +215,10 @@ class GlowEngine:
         # GEMM arithmetic: 0 = exact fp32 on the f32-input MFMA; 1 = bf16x3 (fp32 operands split into bf16 hi + lo on the
         # fly, three bf16 MFMAs per step, fp32 accumulation: ~2^-16 relative, 16x the MFMA rate)
         self.precision = 0
+        self.pass_skip = {}   # measurement only (tools/precision_sweep.py): GEMM class -> bf16x3 products to drop
+        for item in filter(None, os.environ.get("LFI_PASS_SKIP", "").split(",")):   # e.g. "cond_fwd=3,gic=3": timing runs
+            name, bits = item.split("=")
+            self.pass_skip[name.strip()] = int(bits)
 
     # ------------------------------------------------------------------ per-kernel timing (HIP events on the launch stream)
     def enable_timing(self, on=True):
@@ -308,8 +312,9 @@ class GlowEngine:
     # ------------------------------------------------------------------ low-level wrappers
     def gemm(self, M, N, K, A, lda, akc, Bm, ldb, bkc, Cm, ldc, bias=None, act=0, slope=0.01, G=None, ldg=0,
              batch=1, sA=0, sB=0, sC=0, sBias=0, sG=0, accumulate=0, splitk=1, a_off=0, b_off=0, c_off=0, bias_off=0,
-             tag=None, ws="scratch.gemm_splitk"):
-        """Offsets are in floats relative to the tensors' data pointers."""
+             tag=None, ws="scratch.gemm_splitk", cls=None):
+        """Offsets are in floats relative to the tensors' data pointers. cls: GEMM class name for tools/precision_sweep.py
+        (self.pass_skip maps a class to the bf16x3 products to drop; empty in normal operation)."""
         g = GemmDesc()
         g.M, g.N, g.K = M, N, K
         g.A, g.lda, g.a_kcontig = A.data_ptr() + 4 * a_off, lda, akc
@@ -320,7 +325,7 @@ class GlowEngine:
         g.batch, g.strideA, g.strideB, g.strideC, g.strideBias, g.strideG = batch, sA, sB, sC, sBias, sG
         g.accumulate, g.act, g.slope = accumulate, act, slope
         g.splitk = splitk
-        g.precision = self.precision
+        g.precision = self.precision | ((self.pass_skip.get(cls, 0) & 3) << 8 if (self.precision & 1) else 0)
         if splitk > 1 or splitk == 0:  # 0: the library picks the split (and the tile shape) that fills the chip
             g.work = self._buf(ws, batch * max(splitk, 8) * M * N).data_ptr()
         ev = self._tic(tag)
@@ -342,8 +347,9 @@ class GlowEngine:
         return buf, (cols + 15) // 16
 
     def gemm_planes(self, M, N, K, Ap, a_nkt, Bp, b_nkt, Cm, ldc, bias=None, act=0, slope=0.01, G=None, ldg=0, batch=1,
-                    a_stride=0, b_stride=0, sC=0, sBias=0, sG=0, accumulate=0, c_off=0, bias_off=0, tag=None):
+                    a_stride=0, b_stride=0, sC=0, sBias=0, sG=0, accumulate=0, c_off=0, bias_off=0, tag=None, cls=None):
         g = PGemmDesc()
+        g.skip = self.pass_skip.get(cls, 0) & 3
         g.M, g.N, g.K = M, N, K
         g.Ap, g.a_nkt, g.a_stride = Ap.data_ptr(), a_nkt, a_stride
         g.Bp, g.b_nkt, g.b_stride = Bp.data_ptr(), b_nkt, b_stride
@@ -479,7 +485,7 @@ class GlowEngine:
             G = e.ng * hid
             xp = self._buf("xp." + e.name, B * Tx * G)
             xa, wa, ldi = self._aligned_input(e, x, B * Tx, G)
-            self.gemm(B * Tx, G, e.in_dim, xa, ldi, 1, wa, ldi, 1, xp, G)
+            self.gemm(B * Tx, G, e.in_dim, xa, ldi, 1, wa, ldi, 1, xp, G, cls="enc_xproj")
             # gate stash: r, z, n, W_hn h + b_hn (GRU; only kept for a backward pass) / i, f, g, o, c (LSTM: it is the cell state)
             gates = self._buf("enc_gates." + e.name, e.hist * F * (5 if lstm else 4) * hid) if (with_stash or lstm) else None
             hseq = self._buf("enc_hseq." + e.name, e.hist * F * hid)
@@ -517,13 +523,13 @@ class GlowEngine:
             cp, nkc = self.planes("cond_planes", cond, s.ldf, F, s.Ef)
             wp, nkw = self._wct_planes
             self.gemm_planes(F, KD, s.Ef, cp, nkc, wp, nkw, cbuf, KD, bias=self.fview("bct"), act=1, slope=0.01,
-                             tag="gemm_cond_fwd")
+                             tag="gemm_cond_fwd", cls="cond_fwd")
         else:
             self.gemm(F, KD, s.Ef, cond, s.ldf, 1, self.wct_f, s.ldf, 1, cbuf, KD, bias=self.fview("bct"), act=1, slope=0.01,
-                      tag="gemm_cond_fwd")
+                      tag="gemm_cond_fwd", cls="cond_fwd")
         gic = self._buf("gic", s.Ks * F * s.G)
         self.gemm(F, s.G, s.D, cbuf, KD, 1, self.prep, s.D, 1, gic, s.G, bias=self.fview("b_ih"),
-                  batch=s.Ks, sA=s.D, sB=s.G * s.D, sC=F * s.G, sBias=s.G, b_off=self._wc_offset())
+                  batch=s.Ks, sA=s.D, sB=s.G * s.D, sC=F * s.G, sBias=s.G, b_off=self._wc_offset(), cls="gic")
         return cbuf, gic
 
     # ------------------------------------------------------------------ forward / backward
@@ -610,18 +616,22 @@ class GlowEngine:
         # gradient kernel: on the second stream, next to the weight-gradient products and the dpre / cond_transform products
         # (same-box A/B: -0.2 ms per step)
         side = self._fork()
-        check(self.L.lfi_flow_param_grads(C.byref(dims), C.byref(p), self.prep.data_ptr(), ctx.stash.data_ptr(),
+        pg_dims = dims
+        if self.pass_skip.get("flow_pgrads") and (self.precision & 1):
+            pg_dims = self._flow_dims(B, N)
+            pg_dims.gemm_precision = self.precision | ((self.pass_skip["flow_pgrads"] & 3) << 8)
+        check(self.L.lfi_flow_param_grads(C.byref(pg_dims), C.byref(p), self.prep.data_ptr(), ctx.stash.data_ptr(),
                                           bst.data_ptr(), ctx.cbuf.data_ptr(), KD, gscale, C.byref(g), 0, work.data_ptr(),
                                           st, side.cuda_stream if side is not None else None), "lfi_flow_param_grads")
         # d pre-activation of cond_transform, in place over c: dpre = (dgi[k] W_ih[k][:, Ch:]) * leaky'(c)
         dgi_off = (self.L.lfi_flow_bstash_ptr(C.byref(dims), bst.data_ptr(), 1) - bst.data_ptr()) // 4
         self.gemm(F, s.D, s.G, bst, s.G, 1, self.prep, s.D, 0, ctx.cbuf, KD, act=2, slope=0.01, G=ctx.cbuf, ldg=KD,
-                  batch=s.Ks, sA=F * s.G, sB=s.G * s.D, sC=s.D, sG=s.D, a_off=dgi_off, b_off=self._wc_offset())
+                  batch=s.Ks, sA=F * s.G, sB=s.G * s.D, sC=s.D, sG=s.D, a_off=dgi_off, b_off=self._wc_offset(), cls="dpre")
         dpre = ctx.cbuf
         # cond_transform weight / bias gradients for all steps at once
         dwf = self._buf("dwct_f", KD * s.ldf)
         # (all ldf columns: the padding columns of cond are zero, and a 4-float granular N keeps the split-K reduce on 16-byte rows)
-        self.gemm(KD, s.ldf, F, dpre, KD, 0, ctx.cond, s.ldf, 0, dwf, s.ldf, tag="gemm_cond_wgrad", splitk=0)
+        self.gemm(KD, s.ldf, F, dpre, KD, 0, ctx.cond, s.ldf, 0, dwf, s.ldf, tag="gemm_cond_wgrad", splitk=0, cls="cond_wgrad")
         # both copies of a duplicated input column receive the folded column's gradient
         check(self.L.lfi_cols_fold(dwf.data_ptr(), s.ldf, KD, self.unfold.data_ptr(), None, s.E,
                                    self.fview("wct", self.grads).data_ptr(), s.E, st), "lfi_cols_fold")
@@ -640,7 +650,7 @@ class GlowEngine:
             dcond = self._buf("dcond", F * ldd)
             # 112 x 5 tiles = 1.09 rounds of the 512 resident workgroups: split K so the tail round is full too
             self.gemm(F, W, KD, dpre, KD, 1, self.wct_f, s.ldf, 0, dcond, ldd, b_off=col0, tag="gemm_cond_dgrad",
-                      splitk=0)
+                      splitk=0, cls="cond_dgrad")
             for e in rnn:
                 if e.enc == "mlp":
                     self._mlp_backward(e, ctx, dcond, ldd, e.fcol - col0)
@@ -695,7 +705,7 @@ class GlowEngine:
             check(self.L.lfi_encode_windows_scatter(C.byref(d), dgi.data_ptr(), dgh.data_ptr(), ptr(mk), dxp.data_ptr(),
                                                     _stream()), "lfi_encode_windows_scatter")
             self.gemm(G3, e.in_dim, rows, dxp, G3, 0, xa, ldi, 0, self.view(gname + "weight_ih", self.grads), e.in_dim,
-                      splitk=self._long_k_splitk(G3, e.in_dim, rows, kmin=512), ws="scratch.gemm_splitk.side")
+                      splitk=self._long_k_splitk(G3, e.in_dim, rows, kmin=512), ws="scratch.gemm_splitk.side", cls="enc_dwih")
         gbi, gbh = self.view(gname + "bias_ih", self.grads), self.view(gname + "bias_hh", self.grads)
         if part is not None:  # per-workgroup partial sums of (d r, d z, d n, d n * r) left by the fused backward kernel
             check(self.L.lfi_encode_windows_bias_grads(part.data_ptr(), prow, hid, gbi.data_ptr(), gbh.data_ptr(), st),
@@ -705,7 +715,7 @@ class GlowEngine:
         if e.hist > 1:
             kk = (e.hist - 1) * F
             self.gemm(G3, hid, kk, dgh, G3, 0, hseq, hid, 0, self.view(gname + "weight_hh", self.grads), hid,
-                      splitk=self._long_k_splitk(G3, hid, kk), a_off=F * G3)
+                      splitk=self._long_k_splitk(G3, hid, kk), a_off=F * G3, cls="enc_dwhh")
         else:
             self.view(gname + "weight_hh", self.grads).zero_()
         if part is None:
