@@ -216,12 +216,12 @@ class GlowEngine:
         # fly, three bf16 MFMAs per step, fp32 accumulation: ~2^-16 relative, 16x the MFMA rate)
         self.precision = 0
         # GEMM class -> bf16x3 products to drop (bit 0: a_lo b_hi, bit 1: a_hi b_lo; 3 = plain bf16 operands, one product).
-        # profiles/precision_sweep.md (tools/precision_sweep.py, final widths, against the fp64 oracle): with ONE product the
-        # gradient of the feature matrix and the window encoders' two weight gradients leave the per-frame NLL untouched and
-        # every gradient tensor within 7e-4 relative L2 (gate 2e-3; whole gradient 1e-6), so they run that way; the forward
-        # classes (NLL 1e-5 ... 4e-5 of the 1e-4 gate with fewer products) and the cond_transform / flow weight gradients and
-        # dpre (1.3e-3 ... 1.9e-3 of 2e-3) keep all three. LFI_PASS_SKIP=none restores three everywhere; "cls=bits,..." sets others.
-        self.pass_skip = {"cond_dgrad": 3, "enc_dwih": 3, "enc_dwhh": 3}
+        # Measurement switch only: profiles/precision_sweep.md (tools/precision_sweep.py, final widths, against the fp64
+        # oracle) shows NO class that keeps the test bounds with fewer than three products - the forward classes cost
+        # 1e-5 ... 4e-5 of the 1e-4 NLL gate EACH, the backward classes leave the NLL alone but put single gradient tensors at
+        # 1.3e-3 ... 3.3e-3 relative L2 (gate 2e-3; the encoders' dW_hh, the mildest, still 1.9e-3 on its smallest tensor) -
+        # so the default is empty: three products everywhere. LFI_PASS_SKIP="cls=bits,..." sets entries for timing runs.
+        self.pass_skip = {}
         env = os.environ.get("LFI_PASS_SKIP", "")
         if env.strip() == "none":
             self.pass_skip = {}
