@@ -7,7 +7,7 @@ Adam) of final_model.yaml at BASELINE.json's synthetic dims (50-d FLAME + 27-d s
 
 Rank 0 prints ONE JSON line. `value` = frames processed by all ranks / max-over-ranks wall time of the K timed steps
 (inputs resident in HBM before the timed region). `roofline` is for the dominant kernel, the cond_transform GEMM
-(F x Ks*D x E on the f32 MFMA), timed with HIP events on its launch stream inside the timed region. `cpu_baseline`
+(F x Ks*D x Ef, bf16 hi/lo operand planes, three bf16 MFMA products per k-step), timed with HIP events on its launch stream inside the timed region. `cpu_baseline`
 (N = 1 only) times the CPU oracle — a plain-PyTorch port of the reference's per-timestep loop — on the host cores on a
 bounded sample of the same workload; it is a reported baseline, not the thing measured above.
 """
@@ -173,21 +173,31 @@ def _roofline(spec, F, timing, precision):
     ach = flops / (ms * 1e-3) / 1e12 if n_launch else float("nan")
     # which kernel lfi_gemm_f32 picks for this product: bf16x3 takes the 256 x 256 tile (1024 threads) unless
     # LFI_GEMM_256=0, f32 the 128 x 128 tile (256 threads); the rocprof kernel names below are what --kernel-trace prints
-    if precision == "bf16x3":
+    if precision == "bf16x3" and os.environ.get("LFI_PGEMM", "1") != "0":
+        # the product runs on pre-split operand planes (lfi_gemm_planes): 128 x 256 tiles, 512 threads, two workgroups per CU
+        # (LFI_PGEMM_256=1: 256 x 256 tiles, 1024 threads)
+        peak, mult = BF16_MFMA_PEAK_TFLOPS, 3.0
+        big = os.environ.get("LFI_PGEMM_256", "0") == "1"
+        kern = "gemm_planes_256_kernel" if big else "gemm_planes_128_kernel"
+        tile, threads = (256, 1024) if big else (128, 512)
+        tile_n = 256
+    elif precision == "bf16x3":
         big = os.environ.get("LFI_GEMM_256", "1") != "0"
         peak, mult = BF16_MFMA_PEAK_TFLOPS, 3.0
         k32 = os.environ.get("LFI_GEMM_K32", "0") == "1"   # the opt-in 32-k variant of the 256 x 256 kernel
         kern = ("gemm_bf16x3_256k_kernel<true, true>" if k32 else "gemm_bf16x3_256_kernel<true, true>") if big \
             else "gemm_bf16x3_kernel<true, true>"
         tile, threads = (256, 1024) if big else (128, 256)
+        tile_n = tile
     else:
         peak, kern, mult = F32_MFMA_PEAK_TFLOPS, "gemm_f32_kernel<128, 128, 2, 2, true, true", 1.0
         tile, threads = 128, 256
+        tile_n = tile
     # HBM bytes per launch of that kernel from the PMC passes of the same command (tools/pmc_bench.sh -> profiles/):
     # bench.py cannot collect counters itself; null when no committed measurement matches this kernel and grid
     traffic, traffic_src = None, None
     try:
-        tiles = ((F + tile - 1) // tile) * ((KD + tile - 1) // tile)
+        tiles = ((F + tile - 1) // tile) * ((KD + tile_n - 1) // tile_n)
         tj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_%s.json" % precision)))
         for name, v in tj["kernels"].items():
             if kern in name and name.endswith("grid=%d" % (tiles * threads)):
@@ -198,6 +208,7 @@ def _roofline(spec, F, timing, precision):
             "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic,
             "traffic_unit": "bytes per launch (HBM read + write)", "traffic_source": traffic_src,
             "algorithmic_bytes_per_launch": 4.0 * (F * spec.ldf + KD * spec.ldf + F * KD),
+            "algorithmic_bytes_note": "A (F x ldf) and B (Ks D x ldf) once as bf16 hi + lo planes (4 B per element, as fp32), C (F x Ks D) fp32 once",
             "mfma_flops_multiplier": mult, "frac_of_mfma_issue": mult * ach / peak,
             "flops_per_launch": flops, "flops_per_launch_algorithmic": flops_alg,
             "achieved_algorithmic": flops_alg / (ms * 1e-3) / 1e12 if n_launch else None,

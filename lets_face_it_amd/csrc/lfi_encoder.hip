@@ -1319,22 +1319,24 @@ int fill_args(const lfi_enc_desc* d, EncArgs* a, const char* who) {
   return LFI_OK;
 }
 
-// part [rows][4 * hid] -> column sums; 32 columns per workgroup, 8 row groups added in a fixed order.
+// part [rows][4 * hid] -> column sums; 32 columns per workgroup, 32 row groups (each a strided run of rows, added in order),
+// then the 32 partial sums in a fixed order: bit-reproducible. (8 row groups of one 256-thread workgroup took 20 - 28 us per
+// modality on 448 rows: a chain of 56 dependent loads per thread.)
 // Blocks 0, 1 (d r, d z) go to both bias gradients, block 2 (d n) to db_ih, block 3 (d n * r) to db_hh's n block.
-__global__ __launch_bounds__(256) void enc_bias_fold_kernel(const float* __restrict__ part, long rows, int hid,
-                                                           float* __restrict__ db_ih, float* __restrict__ db_hh) {
-  __shared__ float red[8][33];
+__global__ __launch_bounds__(1024) void enc_bias_fold_kernel(const float* __restrict__ part, long rows, int hid,
+                                                            float* __restrict__ db_ih, float* __restrict__ db_hh) {
+  __shared__ float red[32][33];
   const int c = threadIdx.x & 31, rg = threadIdx.x >> 5;
   const int col = blockIdx.x * 32 + c, W = 4 * hid;
   float acc = 0.0f;
   if (col < W)
-    for (long r = rg; r < rows; r += 8) acc += part[r * W + col];
+    for (long r = rg; r < rows; r += 32) acc += part[r * W + col];
   red[rg][c] = acc;
   __syncthreads();
   if (rg == 0 && col < W) {
     float v = red[0][c];
 #pragma unroll
-    for (int i = 1; i < 8; ++i) v += red[i][c];
+    for (int i = 1; i < 32; ++i) v += red[i][c];
     const int blk = col / hid, j = col - blk * hid;
     if (blk < 2) { db_ih[col] = v; db_hh[col] = v; }
     else if (blk == 2) db_ih[col] = v;
@@ -1499,7 +1501,7 @@ extern "C" long lfi_encode_windows_bias_rows(const lfi_enc_desc* d) {
 extern "C" int lfi_encode_windows_bias_grads(const float* bias_part, long rows, int hid, float* db_ih, float* db_hh,
                                              void* stream) {
   LFI_REQUIRE(bias_part && db_ih && db_hh && rows > 0 && hid > 0, "lfi_encode_windows_bias_grads: bad arguments");
-  hipLaunchKernelGGL(enc_bias_fold_kernel, dim3(lfi_cdiv(4 * hid, 32)), dim3(256), 0, (hipStream_t)stream, bias_part, rows, hid,
+  hipLaunchKernelGGL(enc_bias_fold_kernel, dim3(lfi_cdiv(4 * hid, 32)), dim3(1024), 0, (hipStream_t)stream, bias_part, rows, hid,
                      db_ih, db_hh);
   LFI_LAUNCH_CHECK("lfi_encode_windows_bias_grads");
   return LFI_OK;
