@@ -45,6 +45,7 @@ struct GemmArgs {
   const __bf16* Ap; const __bf16* Bp;   // block ((rt * nkt_op + kt) * 2 + plane) * 512 bf16, rt = 32-row tile, kt = 16-k tile
   int nkt, nktA, nktB;                  // k-tiles of this product; k-tiles per row tile in either plane buffer
   long pstrideA, pstrideB;              // bf16 elements between batch entries
+  int gm;     // tile rows per group of the XCD-contiguous tile walk (gemm_tile_of_block); 0 = 8
   int skip;   // bf16x3 kernels: bit 0 drops the a_lo * b_hi product, bit 1 the a_hi * b_lo product (lfi_gemm_desc.precision
               // bits 8 / 9; tools/precision_sweep.py). 0 = all three products.
 };
@@ -212,7 +213,7 @@ __device__ __forceinline__ void gemm_tile_of_block(const GemmArgs& g, int* tm, i
   const long rest = lin / ntile;
   *batch = (int)(rest % gridDim.y);
   *split = (int)(rest / gridDim.y);
-  constexpr int GM = 8;
+  const int GM = g.gm > 0 ? g.gm : 8;
   const int per_group = GM * g.tiles_n;
   const int grp = bid / per_group, in_grp = bid - grp * per_group;
   const int rows_here = min(GM, g.tiles_m - grp * GM);
@@ -1853,6 +1854,7 @@ extern "C" int lfi_gemm_f32(const lfi_gemm_desc* d, void* stream) {
   a.vecA = vecA;
   a.vecB = vecB;
   a.skip = (d->precision >> 8) & 3;
+  a.gm = 0; a.Ap = nullptr; a.Bp = nullptr; a.nkt = a.nktA = a.nktB = 0; a.pstrideA = a.pstrideB = 0;
   {
     // C (or the split-K workspace) and G rows 16-byte aligned; act 2 together with accumulate stays on the narrow path
     const bool partial = splitk > 1;
@@ -2067,6 +2069,19 @@ extern "C" int lfi_gemm_planes(const lfi_pgemm_desc* d, void* stream) {
   } else {
     a.tiles_m = lfi_cdiv(d->M, 128);
     a.tiles_n = lfi_cdiv(d->N, 256);
+    {
+      // an XCD walks its run of tiles in groups of `gm` tile rows, column by column: the group's A panels stay in its L2
+      // while each B panel passes through once per group. One group per XCD when its share of the rows allows (<= 16 row
+      // tiles = 7.3 MB of A planes at K = 896: served from L2 / Infinity Cache), so B is fetched once per XCD, not once per
+      // 8 tile rows (PMC, cond_transform forward: 790 MB of reads per launch with groups of 8)
+      static int gm_env = -1;
+      if (gm_env < 0) {
+        const char* e = getenv("LFI_PGEMM_GM");
+        gm_env = e ? atoi(e) : 0;
+      }
+      const int share = lfi_cdiv(a.tiles_m, 8);
+      a.gm = gm_env > 0 ? gm_env : (share <= 16 ? (share > 8 ? share : 8) : 8);
+    }
     const size_t lds = (size_t)QRING * QSLOT;   // 72 KB: two workgroups per CU; the epilogue's 64 x 260 floats fit inside
     static bool attr = false;
     if (!attr) {
