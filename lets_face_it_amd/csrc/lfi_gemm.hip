@@ -2070,17 +2070,16 @@ extern "C" int lfi_gemm_planes(const lfi_pgemm_desc* d, void* stream) {
     a.tiles_m = lfi_cdiv(d->M, 128);
     a.tiles_n = lfi_cdiv(d->N, 256);
     {
-      // an XCD walks its run of tiles in groups of `gm` tile rows, column by column: the group's A panels stay in its L2
-      // while each B panel passes through once per group. One group per XCD when its share of the rows allows (<= 16 row
-      // tiles = 7.3 MB of A planes at K = 896: served from L2 / Infinity Cache), so B is fetched once per XCD, not once per
-      // 8 tile rows (PMC, cond_transform forward: 790 MB of reads per launch with groups of 8)
+      // an XCD walks its run of tiles in groups of `gm` tile rows, column by column. PMC (cond_transform forward, 80 MB of
+      // operand planes): groups of 8 rows fetch 790 MB per launch into the L2s, one group of 14 per XCD (B once per XCD, but
+      // 6.4 MB of A panels per 4 MB L2) 1033 MB; the launch time is the same either way (0.571 / 0.574 ms): L2 misses are
+      // served by the Infinity Cache at ~2 TB/s and are not what bounds the kernel. LFI_PGEMM_GM overrides.
       static int gm_env = -1;
       if (gm_env < 0) {
         const char* e = getenv("LFI_PGEMM_GM");
         gm_env = e ? atoi(e) : 0;
       }
-      const int share = lfi_cdiv(a.tiles_m, 8);
-      a.gm = gm_env > 0 ? gm_env : (share <= 16 ? (share > 8 ? share : 8) : 8);
+      a.gm = gm_env > 0 ? gm_env : 8;
     }
     const size_t lds = (size_t)QRING * QSLOT;   // 72 KB: two workgroups per CU; the epilogue's 64 x 260 floats fit inside
     static bool attr = false;
