@@ -28,7 +28,7 @@ def _free_port():
     return port
 
 
-def _launch(extra, limit=240):
+def _launch(extra, limit=240, nproc=2):
     """Start tools/dp_gloo_check.py under torch.distributed.run. Nothing here may initialise HIP in the pytest process (the
     boxes refuse to start another program from a process that has): the GPU is detected through /dev/kfd, not through
     torch.cuda.device_count() (which falls through to hipGetDeviceCount on builds without amdsmi)."""
@@ -37,7 +37,7 @@ def _launch(extra, limit=240):
     if not os.path.exists("/dev/kfd"):
         pytest.skip("no GPU")
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = ["timeout", "-k", "10", str(limit), sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+    cmd = ["timeout", "-k", "10", str(limit), sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc),
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "tools", "dp_gloo_check.py")] + extra
     return subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=limit + 60)
 
@@ -66,3 +66,16 @@ def test_two_rank_data_parallel_at_final_widths():
     # process sums all 512 samples in one order; Adam's g / (sqrt(v) + eps) turns that rounding difference into a parameter
     # difference of a few 1e-5 of max |p| at 17.3 M parameters (6.5e-5 measured); the ranks themselves must agree bit for bit
     assert m.group(1) == "True" and float(m.group(2)) < 2e-4
+
+
+def test_rccl_launch_path_with_one_rank():
+    """RCCL itself, as far as one card allows: ONE rank on torch.distributed backend "nccl" runs fused_training_step with the
+    trainer's real all-reduce hooks at final widths (the asynchronous flow bucket travels on RCCL's stream under the encoders'
+    BPTT kernels and the side-stream work, the encoder bucket on the main stream, ActNorm statistics, the parameter
+    broadcast) and must leave bit-identical parameters to the same steps without collectives (the stand-in doubles the
+    gradient as a second identical rank would; the optimiser divides by world = 2). No transport is exercised - that needs the
+    8-GPU node - but library load, communicator init, stream ordering and the work handles are."""
+    r = _launch(["--nccl1"], limit=300, nproc=1)
+    tail = "\n".join(r.stdout.splitlines()[-15:])
+    assert r.returncode == 0, tail
+    assert "(nccl)" in r.stdout and "parameters identical to the collective-free steps: True" in r.stdout, tail

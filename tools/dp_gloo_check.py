@@ -13,7 +13,8 @@ import torch.distributed as dist  # noqa: E402
 
 
 
-FINAL = "--final" in sys.argv   # final_model.yaml widths at BASELINE's synthetic dims, batch 256 per rank, T = 80
+NCCL1 = "--nccl1" in sys.argv   # ONE rank on backend "nccl" (= RCCL): the collectives' launch path on this ROCm, no transport
+FINAL = "--final" in sys.argv or NCCL1   # final_model.yaml widths at BASELINE's synthetic dims, batch 256 per rank, T = 80
 
 
 class _Dims:
@@ -100,8 +101,32 @@ def main():
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(dev)
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    print("rank %d of %d up" % (rank, world), flush=True)
+    dist.init_process_group("nccl" if NCCL1 else "gloo", rank=rank, world_size=world)
+    print("rank %d of %d up (%s)" % (rank, world, dist.get_backend()), flush=True)
+    if NCCL1:
+        # world size 1 on RCCL: fused_training_step with the trainer's real hooks (two-bucket asynchronous all-reduce on the
+        # flat gradient, ActNorm statistics, parameter broadcast) against the same steps without any collective
+        from argparse import Namespace
+        from lets_face_it_amd.trainer import Trainer
+        fx, hp, m = _make("mid", dev)
+        tr = Trainer(Namespace(**hp), device=dev)
+        m.seq_glow.allreduce_hook = lambda sums: (dist.all_reduce(sums), 1)[1]
+        dist.broadcast(m.seq_glow._ensure_engine(dev).params, src=0)
+        fx2, hp2, m2 = _make("mid", dev)
+        g = torch.Generator().manual_seed(3)
+        for step in range(3):
+            batch = {k: torch.randn(256, fx.T, d, generator=g).to(dev) for k, d in
+                     (("p1_face", fx.C), ("p2_face", fx.C), ("p1_speech", fx.S), ("p2_speech", fx.S))}
+            torch.manual_seed(50 + step)
+            m.fused_training_step(batch, 1e-3, 2, lambda t, async_op=False: (t.mul_(2.0), tr.allreduce_grads(t, async_op))[1])
+            torch.manual_seed(50 + step)
+            m2.fused_training_step(batch, 1e-3)
+        torch.cuda.synchronize()
+        same = torch.equal(m.seq_glow.engine.params, m2.seq_glow.engine.params)
+        print("nccl world-1 rehearsal: parameters identical to the collective-free steps: %s" % same, flush=True)
+        dist.barrier()
+        dist.destroy_process_group()
+        sys.exit(0 if same else 1)
     p = run(rank, world, dev, None)
     print("rank %d params checksum %.9e" % (rank, float(p.double().sum())), flush=True)
     gathered = [torch.zeros_like(p) for _ in range(world)]
