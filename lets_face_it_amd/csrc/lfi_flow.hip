@@ -49,6 +49,7 @@ struct FlowK {
   float *sA, *sY, *sX, *sH, *sG, *sO, *sL, *sC;   // sC: LSTM cell state (lstm only)
   // backward stash
   float *bDlin, *bDgi, *bDgh, *bDy, *bDx, *bDh, *bPlfl, *bPan, *bDc;   // bDc: carried d cell state (lstm only)
+  float* bPbias;   // [Ks][nbt][2][G]: per-workgroup sums over timesteps and the tile's rows of dgi | dgh (persistent walk only)
   // sequence inputs
   const float* x0; int T, start;
   const float* gic;
@@ -1982,6 +1983,11 @@ __global__ __launch_bounds__(NT) void flow_pipe_bwd_kernel(FlowK f) {
     for (int q = tid; q < 2 * MB * ldx; q += NT) { GiH[q] = (__bf16)0.0f; GhH[q] = (__bf16)0.0f; }
     __syncthreads();
   }
+  // b_ih / b_hh gradients = column sums of dgi / dgh over all frames: every thread of the Q1 tile sums its own hidden unit
+  // over its 4 rows and all timesteps here (fixed order), instead of two 350 MB passes over the stash afterwards
+  float bsi[NG], bsh[NG];
+#pragma unroll
+  for (int g = 0; g < NG; ++g) { bsi[g] = 0.0f; bsh[g] = 0.0f; }
   for (int n = f.N - 1; n >= 0; --n) {
     // lane coordinates laundered per iteration: otherwise every per-lane stash address (a dozen arrays x 4 rows, 64-bit) is
     // hoisted out of the timestep loop and the kernel spills ~150 VGPRs
@@ -2137,7 +2143,7 @@ __global__ __launch_bounds__(NT) void flow_pipe_bwd_kernel(FlowK f) {
           float* go = f.bDgi + (kf + row) * G + j;
           float* ho = f.bDgh + (kf + row) * G + j;
 #pragma unroll
-          for (int g = 0; g < NG; ++g) { go[g * H] = gi_[g]; ho[g * H] = gh_[g]; }
+          for (int g = 0; g < NG; ++g) { go[g * H] = gi_[g]; ho[g * H] = gh_[g]; bsi[g] += gi_[g]; bsh[g] += gh_[g]; }
         }
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
@@ -2238,6 +2244,16 @@ __global__ __launch_bounds__(NT) void flow_pipe_bwd_kernel(FlowK f) {
   if (tz) dh_prev_tile();
   PIPE_STAMP(1, 7);
   }  // timestep loop
+  if (th) {   // (an abandoned walk leaves these incomplete: flow_pipe_poison_kernel overwrites them with NaN)
+    float* pb = f.bPbias + ((long)k * nbt + bt) * 2 * G;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+      float vi = bsi[g], vh = bsh[g];
+      vi += __shfl_xor(vi, 16, 64); vi += __shfl_xor(vi, 32, 64);
+      vh += __shfl_xor(vh, 16, 64); vh += __shfl_xor(vh, 32, 64);
+      if ((lane >> 4) == 0 && tcol_0 < H) { pb[g * H + tcol_0] = vi; pb[G + g * H + tcol_0] = vh; }
+    }
+  }
 }
 
 // A backward walk that gave up must not pass for a result: NaN into one frame of every flow step's stashed gradients, which
@@ -2245,6 +2261,7 @@ __global__ __launch_bounds__(NT) void flow_pipe_bwd_kernel(FlowK f) {
 __global__ __launch_bounds__(64) void flow_pipe_poison_kernel(FlowK f) {
   if (f.pipe[1] == 0u) return;
   const float nan = __builtin_nanf("");
+  for (long i = threadIdx.x; i < (long)f.Ks * 2 * f.G; i += 64) f.bPbias[(i / (2 * f.G)) * f.nbt * 2 * f.G + i % (2 * f.G)] = nan;
   for (int k = threadIdx.x; k < f.Ks; k += 64) {
     for (long fr = 0; fr < f.F; fr += (f.F > 1 ? f.F - 1 : 1)) {   // first and last frame (the W_hh gradient skips timestep 0)
       f.bDlin[((long)k * f.F + fr) * f.ldo] = nan;
@@ -2702,6 +2719,7 @@ long bstash_offsets(const FlowK& f, long* off) {
   off[6] = o; o += (long)f.Ks * f.N * f.nbt * f.Cout;   // partial sums for l_fl
   off[7] = o; o += (long)f.Ks * f.N * f.nbt * 2 * f.C;  // partial sums for actnorm logs | bias
   off[8] = o; o += f.lstm ? KF * f.H : 0;               // carried d cell state (LSTM)
+  off[9] = o; o += (long)f.Ks * f.nbt * 2 * f.G;        // partial sums for b_ih | b_hh (persistent walk)
   return o;
 }
 // persistent-pipeline state appended to either stash: header + one progress word per (flow step, batch tile), padded to 16 bytes
@@ -2714,10 +2732,11 @@ void bind_stash(FlowK* f, float* stash) {
   f->sG = stash + off[4]; f->sO = stash + off[5]; f->sL = stash + off[6]; f->sC = stash + off[7];
 }
 void bind_bstash(FlowK* f, float* b) {
-  long off[9];
+  long off[10];
   bstash_offsets(*f, off);
   f->bDlin = b + off[0]; f->bDgi = b + off[1]; f->bDgh = b + off[2]; f->bDy = b + off[3];
   f->bDx = b + off[4]; f->bDh = b + off[5]; f->bPlfl = b + off[6]; f->bPan = b + off[7]; f->bDc = b + off[8];
+  f->bPbias = b + off[9];
 }
 
 // LFI_FLOW_GENERIC=1 keeps the streaming cell kernels (tests cover both paths at sizes where either applies)
@@ -2830,7 +2849,7 @@ extern "C" long lfi_flow_bstash_floats(const lfi_flow_dims* d) {
   FlowK f = {};
   lfi_flow_params p = {};
   if (fill_flow(d, &p, nullptr, &f, "lfi_flow_bstash_floats")) return -1;
-  long off[9];
+  long off[10];
   return align4(bstash_offsets(f, off)) + pipe_words(f);
 }
 extern "C" float* lfi_flow_stash_ptr(const lfi_flow_dims* d, float* stash, int which) {
@@ -2846,7 +2865,7 @@ extern "C" float* lfi_flow_bstash_ptr(const lfi_flow_dims* d, float* bstash, int
   FlowK f = {};
   lfi_flow_params p = {};
   if (which < 0 || which > 9 || fill_flow(d, &p, nullptr, &f, "lfi_flow_bstash_ptr")) return nullptr;
-  long off[9];
+  long off[10];
   const long end = bstash_offsets(f, off);
   if (which == 9) return bstash + align4(end);
   return bstash + off[which];
@@ -2924,7 +2943,7 @@ extern "C" int lfi_flow_seq_bwd(const lfi_flow_dims* d, const lfi_flow_params* p
   if (rc) return rc;
   const bool pipe = fast && flow_pipe_enabled();
   if (pipe) {
-    long off[9];
+    long off[10];
     f.pipe = reinterpret_cast<unsigned*>(bstash + align4(bstash_offsets(f, off)));
     f.pipe_fence = flow_pipe_fence();
     // (NG * H16 >= 128: the bf16 operand images, 64 (NG H16 + 8) bytes each, must fit the fp32 regions they replace)
@@ -3045,8 +3064,14 @@ extern "C" int lfi_flow_param_grads(const lfi_flow_dims* d, const lfi_flow_param
   // biases and the per-tile partial sums: column sums over the backward stash only (HBM streams), independent of the
   // products above - on bias_stream when the caller has forked one after the backward walk
   if ((rc = lfi_colsum_f32(f.bDlin, f.ldo, (long)F * f.ldo, F, Cout, Ks, g->b_fl, Cout, 1.0f, accumulate, cws, bs))) return rc;
-  if ((rc = lfi_colsum_f32(f.bDgh, G, (long)F * G, F, G, Ks, g->b_hh, G, 1.0f, accumulate, cws, bs))) return rc;
-  if ((rc = lfi_colsum_f32(f.bDgi, G, (long)F * G, F, G, Ks, g->b_ih, G, 1.0f, accumulate, cws, bs))) return rc;
+  if (flow_fast_ok(f.C, f.H, f.Cout) && !flow_force_generic() && flow_pipe_enabled()) {
+    // the persistent backward walk left per-workgroup sums of dgi | dgh: [Ks][nbt][2][G]
+    if ((rc = lfi_colsum_f32(f.bPbias, 2 * G, (long)f.nbt * 2 * G, f.nbt, G, Ks, g->b_ih, G, 1.0f, accumulate, cws, bs))) return rc;
+    if ((rc = lfi_colsum_f32(f.bPbias + G, 2 * G, (long)f.nbt * 2 * G, f.nbt, G, Ks, g->b_hh, G, 1.0f, accumulate, cws, bs))) return rc;
+  } else {
+    if ((rc = lfi_colsum_f32(f.bDgh, G, (long)F * G, F, G, Ks, g->b_hh, G, 1.0f, accumulate, cws, bs))) return rc;
+    if ((rc = lfi_colsum_f32(f.bDgi, G, (long)F * G, F, G, Ks, g->b_ih, G, 1.0f, accumulate, cws, bs))) return rc;
+  }
   const int prow = f.N * f.nbt;
   if ((rc = lfi_colsum_f32(f.bPlfl, Cout, (long)prow * Cout, prow, Cout, Ks, g->l_fl, Cout, 1.0f, accumulate, cws, bs))) return rc;
   if ((rc = lfi_colsum_f32(f.bPan, 2 * C, (long)prow * 2 * C, prow, C, Ks, g->an_logs, C, 1.0f, accumulate, cws, bs))) return rc;

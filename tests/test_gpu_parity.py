@@ -522,6 +522,10 @@ def test_pipeline_walk_matches_diagonal_walk(gpu_device, monkeypatch, case):
     for n in outs[0][2]:
         if case == "tiny_lstm":  # the d c carry lives in a register there and its product is contracted into the consumer's fma
             assert rel_err(outs[0][2][n], outs[1][2][n]) < 1e-6, n
+        elif n.endswith(("f.rnn.bias_ih", "f.rnn.bias_hh")):
+            # the persistent walk sums dgi / dgh per workgroup while it walks (timesteps in walk order, then tiles); the
+            # diagonal walk leaves them to a column-sum pass over the stash: same addends, another order
+            assert rel_err(outs[0][2][n], outs[1][2][n]) < 2e-6, n
         else:
             assert torch.equal(outs[0][2][n], outs[1][2][n]), n
     # default of the bf16x3 engine mode: the recurrent products of the walk as three bf16 MFMAs (2^-16 relative per product)
