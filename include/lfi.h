@@ -60,9 +60,16 @@ typedef struct {
                                  a_lo * b_hi / a_hi * b_lo product of the bf16x3 kernels (a measurement switch: what each GEMM
                                  class loses with one or two bf16 passes, tools/precision_sweep.py -> profiles/precision_sweep.md;
                                  never set by the engine's default configuration) */
+  float* colsum_part; long ld_part;  /* optional: the epilogue also leaves column sums of the STORED result over each block of
+                                 rows it handles, row r of a (lfi_gemm_colpart_rows(d) x ld_part) matrix, columns as in C (batch
+                                 entries side by side: strideC * batch <= ldc). Summing its rows (lfi_colsum_f32) gives the bias
+                                 gradient of a Linear without a second pass over C (autograd of nn.Linear.bias,
+                                 glow/models.py:187-190). NULL: off. lfi_gemm_colpart_rows returns 0 when the product would not
+                                 run on a kernel that can do it (then leave colsum_part NULL) */
 } lfi_gemm_desc;
 
 long lfi_gemm_work_floats(const lfi_gemm_desc* d);
+long lfi_gemm_colpart_rows(const lfi_gemm_desc* d);
 int lfi_gemm_f32(const lfi_gemm_desc* d, void* stream);
 
 /* ---- bf16x3 GEMM on PRE-SPLIT operands. lfi_gemm_f32's bf16x3 kernels split every fp32 operand element into bf16 hi + lo

@@ -27,6 +27,7 @@ class GemmDesc(C.Structure):
         ("act", C.c_int), ("slope", C.c_float),
         ("splitk", C.c_int), ("work", C.c_void_p),
         ("precision", C.c_int),
+        ("colsum_part", C.c_void_p), ("ld_part", C.c_long),
     ]
 
 
@@ -96,6 +97,7 @@ def lib():
         "lfi_version": (i, []),
         "lfi_gemm_work_floats": (l, [P(GemmDesc)]),
         "lfi_gemm_f32": (i, [P(GemmDesc), vp]),
+        "lfi_gemm_colpart_rows": (l, [P(GemmDesc)]),
         "lfi_planes_elems": (l, [l, i]),
         "lfi_planes_from_f32": (i, [vp, l, l, i, vp, vp]),
         "lfi_gemm_planes": (i, [P(PGemmDesc), vp]),
@@ -148,7 +150,7 @@ def lib():
 
 
 EXPORTS = [
-    "lfi_last_error", "lfi_version", "lfi_gemm_work_floats", "lfi_gemm_f32", "lfi_planes_elems", "lfi_planes_from_f32",
+    "lfi_last_error", "lfi_version", "lfi_gemm_work_floats", "lfi_gemm_f32", "lfi_gemm_colpart_rows", "lfi_planes_elems", "lfi_planes_from_f32",
     "lfi_gemm_planes", "lfi_colsum_work_floats",
     "lfi_colsum_f32", "lfi_cols_fold", "lfi_encode_windows_work_floats", "lfi_encode_windows_fwd", "lfi_encode_windows_bwd",
     "lfi_encode_windows_bias_rows", "lfi_encode_windows_bias_grads",

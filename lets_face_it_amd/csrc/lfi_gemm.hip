@@ -45,6 +45,7 @@ struct GemmArgs {
   const __bf16* Ap; const __bf16* Bp;   // block ((rt * nkt_op + kt) * 2 + plane) * 512 bf16, rt = 32-row tile, kt = 16-k tile
   int nkt, nktA, nktB;                  // k-tiles of this product; k-tiles per row tile in either plane buffer
   long pstrideA, pstrideB;              // bf16 elements between batch entries
+  float* colpart; long ldpart;   // wide epilogue only: per (row tile, pass) column sums of the stored result (lfi_gemm_desc)
   int gm;     // tile rows per group of the XCD-contiguous tile walk (gemm_tile_of_block); 0 = 8
   int skip;   // bf16x3 kernels: bit 0 drops the a_lo * b_hi product, bit 1 the a_hi * b_lo product (lfi_gemm_desc.precision
               // bits 8 / 9; tools/precision_sweep.py). 0 = all three products.
@@ -171,10 +172,12 @@ __device__ __forceinline__ void gemm_epilogue_wide(const GemmArgs& g, const f32x
         }
     }
     __syncthreads();
+    f32x4 csum = {0.f, 0.f, 0.f, 0.f};
     for (int r = rrow; r < rows_per_pass; r += SWEEP) {  // result tile out
       const int row = m0 + p0 + r;
       if (row < g.M && col_g < g.N) {
         const f32x4 v = *reinterpret_cast<const f32x4*>(lds + r * WLD + c4);
+        csum += v;
         // written once, read by a later kernel: non-temporal, so the result tile does not push the operand panels the other
         // workgroups are re-reading out of L2 (measured -1.5 .. -2 % on the three cond_transform products)
         // (split-K partial sums are read back at once by the reduce kernel: those stay cacheable)
@@ -190,7 +193,20 @@ __device__ __forceinline__ void gemm_epilogue_wide(const GemmArgs& g, const f32x
             if (col_g + j < g.N) Cb[(long)row * ldc + col_g + j] = v[j];
       }
     }
-    if (p0 + rows_per_pass < bm) __syncthreads();
+    if (g.colpart && !partial) {
+      // column sums of this pass's rows (bias gradients without a second pass over C): SWEEP partial rows through LDS, added
+      // in a fixed order; row (tile row * passes + pass) of the partial matrix, columns as in C (batch entries side by side)
+      __syncthreads();
+      *reinterpret_cast<f32x4*>(lds + rrow * WLD + c4) = csum;
+      __syncthreads();
+      if (tid < BN && n0 + tid < g.N) {
+        float v = 0.0f;
+        for (int i = 0; i < SWEEP; ++i) v += lds[i * WLD + tid];
+        const int npass = (bm + rows_per_pass - 1) / rows_per_pass;
+        g.colpart[((long)(m0 / bm) * npass + p0 / rows_per_pass) * g.ldpart + batch * g.strideC + n0 + tid] = v;
+      }
+      __syncthreads();
+    } else if (p0 + rows_per_pass < bm) __syncthreads();
   }
 }
 
@@ -1817,6 +1833,27 @@ extern "C" long lfi_gemm_work_floats(const lfi_gemm_desc* d) {
   return (long)d->batch * d->splitk * d->M * d->N;
 }
 
+// Rows of the partial column-sum matrix lfi_gemm_f32 fills when lfi_gemm_desc.colsum_part is set, or 0 when this product does
+// not take a path that can (it needs the bf16x3 kernels' wide epilogue, no K split, column-batched or unbatched C).
+extern "C" long lfi_gemm_colpart_rows(const lfi_gemm_desc* d) {
+  if (!d || d->M <= 0 || d->N <= 0 || !(d->precision & 1) || (d->precision & 0x40)) return 0;
+  if (d->splitk != 1 || (d->batch > 1 && !(d->strideC > 0 && d->strideC * d->batch <= d->ldc))) return 0;
+  auto vec_ok = [](const float* p, long ld, long stride, int kcontig, int mn, int K) {
+    if ((reinterpret_cast<uintptr_t>(p) & 15) || (ld & 3) || (stride & 3)) return 0;
+    const long need = kcontig ? K : mn;
+    return ld >= (need + 3) / 4 * 4 ? 1 : 0;
+  };
+  if (!vec_ok(d->A, d->lda, d->strideA, d->a_kcontig, d->M, d->K) || !vec_ok(d->B, d->ldb, d->strideB, d->b_kcontig, d->N, d->K)) return 0;
+  const bool c_ok = (reinterpret_cast<uintptr_t>(d->C) & 15) == 0 && d->ldc % 4 == 0 && d->strideC % 4 == 0;
+  const bool g_ok = d->act != 2 || ((reinterpret_cast<uintptr_t>(d->G) & 15) == 0 && d->ldg % 4 == 0 && d->strideG % 4 == 0);
+  if (!(c_ok && g_ok && !(d->act == 2 && d->accumulate != 0))) return 0;
+  const char* w = getenv("LFI_GEMM_WIDE");
+  if ((w && w[0] == '1') || gemm_use_k32()) return 0;
+  GemmPlan plan = gemm_plan(d->M, d->N, d->K, d->batch, 1, true);
+  if (d->precision & 0x30) plan.shape = (d->precision & 0x10) ? 3 : 0;
+  return plan.shape == 3 ? (long)lfi_cdiv(d->M, 256) * (256 / LFI_EPI_ROWS) : (long)lfi_cdiv(d->M, 128);
+}
+
 extern "C" int lfi_gemm_f32(const lfi_gemm_desc* d, void* stream) {
   LFI_REQUIRE(d, "lfi_gemm_f32: null descriptor");
   LFI_REQUIRE(d->M >= 0 && d->N >= 0 && d->K >= 0 && d->batch >= 1, "lfi_gemm_f32: bad dims M=%d N=%d K=%d batch=%d",
@@ -1855,6 +1892,7 @@ extern "C" int lfi_gemm_f32(const lfi_gemm_desc* d, void* stream) {
   a.vecB = vecB;
   a.skip = (d->precision >> 8) & 3;
   a.gm = 0; a.Ap = nullptr; a.Bp = nullptr; a.nkt = a.nktA = a.nktB = 0; a.pstrideA = a.pstrideB = 0;
+  a.colpart = d->colsum_part; a.ldpart = d->ld_part;
   {
     // C (or the split-K workspace) and G rows 16-byte aligned; act 2 together with accumulate stays on the narrow path
     const bool partial = splitk > 1;
@@ -2043,6 +2081,7 @@ extern "C" int lfi_gemm_planes(const lfi_pgemm_desc* d, void* stream) {
   a.Ap = reinterpret_cast<const __bf16*>(d->Ap); a.Bp = reinterpret_cast<const __bf16*>(d->Bp);
   a.nkt = nkt; a.nktA = d->a_nkt; a.nktB = d->b_nkt; a.pstrideA = d->a_stride; a.pstrideB = d->b_stride;
   a.skip = d->skip & 3;
+  a.colpart = nullptr; a.ldpart = 0;
   const bool c_ok = (reinterpret_cast<uintptr_t>(d->C) & 15) == 0 && d->ldc % 4 == 0 && d->strideC % 4 == 0;
   const bool g_ok = d->act != 2 || ((reinterpret_cast<uintptr_t>(d->G) & 15) == 0 && d->ldg % 4 == 0 && d->strideG % 4 == 0);
   a.vecC = (c_ok && g_ok && !(d->act == 2 && d->accumulate != 0)) ? 1 : 0;

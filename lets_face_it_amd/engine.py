@@ -321,9 +321,12 @@ class GlowEngine:
     # ------------------------------------------------------------------ low-level wrappers
     def gemm(self, M, N, K, A, lda, akc, Bm, ldb, bkc, Cm, ldc, bias=None, act=0, slope=0.01, G=None, ldg=0,
              batch=1, sA=0, sB=0, sC=0, sBias=0, sG=0, accumulate=0, splitk=1, a_off=0, b_off=0, c_off=0, bias_off=0,
-             tag=None, ws="scratch.gemm_splitk", cls=None):
+             tag=None, ws="scratch.gemm_splitk", cls=None, colsum_into=None):
         """Offsets are in floats relative to the tensors' data pointers. cls: GEMM class name for tools/precision_sweep.py
-        (self.pass_skip maps a class to the bf16x3 products to drop; empty in normal operation)."""
+        (self.pass_skip maps a class to the bf16x3 products to drop; empty in normal operation).
+        colsum_into: optional (ncols,) tensor that receives the column sums of the stored result (all batch entries side by
+        side, as they lie in C): taken from per-tile partial sums the GEMM epilogue leaves, without a second pass over C.
+        Returns False when this product cannot do that (the caller then sums C itself)."""
         g = GemmDesc()
         g.M, g.N, g.K = M, N, K
         g.A, g.lda, g.a_kcontig = A.data_ptr() + 4 * a_off, lda, akc
@@ -337,9 +340,18 @@ class GlowEngine:
         g.precision = self.precision | ((self.pass_skip.get(cls, 0) & 3) << 8 if (self.precision & 1) else 0)
         if splitk > 1 or splitk == 0:  # 0: the library picks the split (and the tile shape) that fills the chip
             g.work = self._buf(ws, batch * max(splitk, 8) * M * N).data_ptr()
+        part, prow = None, 0
+        if colsum_into is not None:
+            prow = int(self.L.lfi_gemm_colpart_rows(C.byref(g)))
+            if prow > 0:
+                part = self._buf("scratch.colpart", prow * ldc)
+                g.colsum_part, g.ld_part = part.data_ptr(), ldc
         ev = self._tic(tag)
         check(self.L.lfi_gemm_f32(C.byref(g), _stream()), "lfi_gemm_f32")
         self._toc(tag, ev)
+        if part is not None:
+            self.colsum(part, ldc, 0, prow, colsum_into.numel(), 1, colsum_into, 0, ws="scratch.colsum.part")
+        return part is not None
 
     # ---- bf16 hi / lo operand planes in MFMA fragment order (include/lfi.h, lfi_planes_from_f32 / lfi_gemm_planes)
     def planes(self, name, X, ldx, rows, cols, x_off=0):
@@ -634,8 +646,10 @@ class GlowEngine:
                                           st, side.cuda_stream if side is not None else None), "lfi_flow_param_grads")
         # d pre-activation of cond_transform, in place over c: dpre = (dgi[k] W_ih[k][:, Ch:]) * leaky'(c)
         dgi_off = (self.L.lfi_flow_bstash_ptr(C.byref(dims), bst.data_ptr(), 1) - bst.data_ptr()) // 4
-        self.gemm(F, s.D, s.G, bst, s.G, 1, self.prep, s.D, 0, ctx.cbuf, KD, act=2, slope=0.01, G=ctx.cbuf, ldg=KD,
-                  batch=s.Ks, sA=F * s.G, sB=s.G * s.D, sC=s.D, sG=s.D, a_off=dgi_off, b_off=self._wc_offset(), cls="dpre")
+        # (its epilogue also leaves per-tile column sums of dpre: the cond_transform bias gradient without a 470 MB pass)
+        bct_done = self.gemm(F, s.D, s.G, bst, s.G, 1, self.prep, s.D, 0, ctx.cbuf, KD, act=2, slope=0.01, G=ctx.cbuf, ldg=KD,
+                             batch=s.Ks, sA=F * s.G, sB=s.G * s.D, sC=s.D, sG=s.D, a_off=dgi_off, b_off=self._wc_offset(),
+                             cls="dpre", colsum_into=self.fview("bct", self.grads))
         dpre = ctx.cbuf
         # cond_transform weight / bias gradients for all steps at once
         dwf = self._buf("dwct_f", KD * s.ldf)
@@ -646,7 +660,8 @@ class GlowEngine:
                                    self.fview("wct", self.grads).data_ptr(), s.E, st), "lfi_cols_fold")
         # (not on the second stream: streaming dpre for the bias sums next to the weight-gradient product that reads it too was
         # measured 0.1 ms slower per step than in line)
-        self.colsum(dpre, KD, 0, F, KD, 1, self.fview("bct", self.grads), 0)
+        if not bct_done:
+            self.colsum(dpre, KD, 0, F, KD, 1, self.fview("bct", self.grads), 0)
         self._join()
         if after_flow is not None:
             after_flow()

@@ -261,6 +261,32 @@ def test_gemm_on_presplit_planes_batched_k_ranges(eng, gpu_device):
         assert rel_err(out[k], ref) < 3e-5, k
 
 
+@pytest.mark.parametrize("pin,M", [(0x11, 700), (0x21, 300), (0x11, 256)])
+def test_gemm_epilogue_column_sums(eng, gpu_device, pin, M):
+    """lfi_gemm_desc.colsum_part: the wide epilogue leaves per-(row tile, pass) column sums of the stored result (the in-place
+    dpre product, batched side by side in C, with its LeakyReLU-gradient gate); summed they are the bias gradient."""
+    g = torch.Generator().manual_seed(M + pin)
+    D, G, Ks = 128, 96, 3
+    c = torch.randn(M, Ks * D, generator=g).to(gpu_device)
+    dgi = torch.randn(Ks, M, G, generator=g).to(gpu_device)
+    wc = torch.randn(Ks, G, D, generator=g).to(gpu_device)
+    ref = torch.stack([(dgi[k].double() @ wc[k].double()) * torch.where(c[:, k * D:(k + 1) * D] > 0, 1.0, 0.01).double()
+                       for k in range(Ks)], dim=1).reshape(M, Ks * D)
+    sums = torch.full((Ks * D,), 7.0, device=gpu_device)
+    eng.precision = pin
+    try:
+        done = eng.gemm(M, D, G, dgi, G, 1, wc, D, 0, c, Ks * D, act=2, slope=0.01, G=c, ldg=Ks * D, batch=Ks, sA=M * G, sB=G * D,
+                        sC=D, sG=D, colsum_into=sums)
+    finally:
+        eng.precision = 0
+    torch.cuda.synchronize()
+    assert done
+    assert rel_err(c, ref) < 3e-5
+    assert rel_err(sums, c.double().sum(0)) < 1e-5
+    eng.precision = 0   # exact-f32 kernels have no such epilogue: the caller is told to sum C itself
+    assert eng.gemm(64, D, G, dgi, G, 1, wc, D, 0, c, Ks * D, colsum_into=sums) is False
+
+
 def test_gemm_in_place_leaky_grad_epilogue(eng, gpu_device):
     """act = 2 with G == C (the in-place dpre product of the backward pass), batched, through the wide epilogue."""
     g = torch.Generator().manual_seed(11)
