@@ -25,6 +25,11 @@ namespace {
 #define LFI_GEMM_LDSPIPE 1
 #endif
 constexpr int BKT = LFI_GEMM_BKT;  // k-tile
+// XT (template parameter of the bf16x3 kernels): 0 = lean; 1 = + per-tile column sums in the wide epilogue (colpart);
+// 2 = + runtime skipping of the a_lo b_hi / a_hi b_lo products (measurement builds of the precision sweep). Compiled in
+// unconditionally, the skip branches alone cost the 256 x 256 kernels 16 - 148 bytes of scratch per lane at their 128-VGPR cap
+// (the sampler's F x 8192 x 640 product ran 4x slower): they are their own instantiations.
+#define LFI_GSKIP(bit) (XT >= 2 && (g.skip & (bit)))
 
 struct GemmArgs {
   int M, N, K;
@@ -113,7 +118,7 @@ __device__ __forceinline__ void gemm_epilogue_n(const GemmArgs& g, const f32x16 
 // elements in place, result tile out with 16-byte row-wise stores (512 contiguous bytes per 32 lanes).
 // `rows` rows of the block tile per pass (the LDS image is rows x (BN + 4) floats); waves whose 64-row patch is in the pass
 // take part in the register phase, all 256 threads in the row-wise phases.
-template <int BN, int NTH = 256, int MT = 2>
+template <int BN, int NTH = 256, int MT = 2, bool COLP = false>
 __device__ __forceinline__ void gemm_epilogue_wide(const GemmArgs& g, const f32x16 (&acc)[MT][2], float* lds, int rows_per_pass,
                                                    int m0, int n0, int wm, int wn, int l31, int half, int batch, int split, int bm,
                                                    bool has_acc = true) {
@@ -172,12 +177,12 @@ __device__ __forceinline__ void gemm_epilogue_wide(const GemmArgs& g, const f32x
         }
     }
     __syncthreads();
-    f32x4 csum = {0.f, 0.f, 0.f, 0.f};
+    f32x4 csum = {0.f, 0.f, 0.f, 0.f};   // (dead code unless COLP)
     for (int r = rrow; r < rows_per_pass; r += SWEEP) {  // result tile out
       const int row = m0 + p0 + r;
       if (row < g.M && col_g < g.N) {
         const f32x4 v = *reinterpret_cast<const f32x4*>(lds + r * WLD + c4);
-        csum += v;
+        if (COLP) csum += v;
         // written once, read by a later kernel: non-temporal, so the result tile does not push the operand panels the other
         // workgroups are re-reading out of L2 (measured -1.5 .. -2 % on the three cond_transform products)
         // (split-K partial sums are read back at once by the reduce kernel: those stay cacheable)
@@ -193,7 +198,7 @@ __device__ __forceinline__ void gemm_epilogue_wide(const GemmArgs& g, const f32x
             if (col_g + j < g.N) Cb[(long)row * ldc + col_g + j] = v[j];
       }
     }
-    if (g.colpart && !partial) {
+    if (COLP && g.colpart && !partial) {
       // column sums of this pass's rows (bias gradients without a second pass over C): SWEEP partial rows through LDS, added
       // in a fixed order; row (tile row * passes + pass) of the partial matrix, columns as in C (batch entries side by side)
       __syncthreads();
@@ -488,7 +493,7 @@ struct XStager {
   }
 };
 
-template <bool AKC, bool BKC>
+template <bool AKC, bool BKC, int XT = 0>
 __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(GemmArgs g) {
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -555,13 +560,13 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(GemmArgs g) {
       }
       // three products per accumulator and k-step, in the order lo*hi, hi*lo, hi*hi (each accumulator sees them in that
       // order whichever are switched on: results with skip = 0 are what they always were)
-      if (!(g.skip & 1)) {
+      if (!LFI_GSKIP(1)) {
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
           for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mt], bh[nt], acc[mt][nt], 0, 0, 0);
       }
-      if (!(g.skip & 2)) {
+      if (!LFI_GSKIP(2)) {
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -576,7 +581,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(GemmArgs g) {
     __syncthreads();
   }
   // 80 KB of dynamic LDS: the whole 128 x 132 fp32 tile image (67.6 KB) fits, one pass
-  if (g.vecC) gemm_epilogue_wide<128>(g, acc, reinterpret_cast<float*>(xsmem), 128, m0, n0, wm, wn, l31, half, batch, split, 128);
+  if (g.vecC) gemm_epilogue_wide<128, 256, 2, (XT >= 1)>(g, acc, reinterpret_cast<float*>(xsmem), 128, m0, n0, wm, wn, l31, half, batch, split, 128);
   else gemm_epilogue(g, acc, m0, n0, wm, wn, l31, half, batch, split);
 }
 
@@ -838,7 +843,7 @@ __device__ __forceinline__ bf16x8 yfrag(const __bf16* img, int mn, int lane) {
   }
 }
 
-template <bool AKC, bool BKC>
+template <bool AKC, bool BKC, int XT = 0>
 __global__ __launch_bounds__(1024, 4) void gemm_bf16x3_256_kernel(GemmArgs g) {
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -895,13 +900,13 @@ __global__ __launch_bounds__(1024, 4) void gemm_bf16x3_256_kernel(GemmArgs g) {
       bh[t2] = yfrag<BKC>(base + 2 * YIMG, wn * 64 + t2 * 32, lane);
       bl[t2] = yfrag<BKC>(base + 3 * YIMG, wn * 64 + t2 * 32, lane);
     }
-    if (!(g.skip & 1)) {
+    if (!LFI_GSKIP(1)) {
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mt], bh[nt], acc[mt][nt], 0, 0, 0);
     }
-    if (!(g.skip & 2)) {
+    if (!LFI_GSKIP(2)) {
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -967,7 +972,7 @@ __global__ __launch_bounds__(1024, 4) void gemm_bf16x3_256_kernel(GemmArgs g) {
 #ifndef LFI_EPI_ROWS
 #define LFI_EPI_ROWS 128
 #endif
-  if (g.vecC) gemm_epilogue_wide<256, 1024>(g, acc, reinterpret_cast<float*>(xsmem), LFI_EPI_ROWS, m0, n0, wm, wn, l31, half, batch, split, 256);
+  if (g.vecC) gemm_epilogue_wide<256, 1024, 2, (XT >= 1)>(g, acc, reinterpret_cast<float*>(xsmem), LFI_EPI_ROWS, m0, n0, wm, wn, l31, half, batch, split, 256);
   else gemm_epilogue_n<256>(g, acc, m0, n0, wm, wn, l31, half, batch, split);
 }
 
@@ -1441,6 +1446,7 @@ typedef __attribute__((address_space(3))) void plds_void;
 typedef __attribute__((address_space(1))) const void pglb_void;
 
 __global__ __launch_bounds__(1024) void gemm_planes_256_kernel(GemmArgs g) {
+  constexpr int XT = 2;   // skip switch compiled in (no register cost here)
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, half = lane >> 5;
@@ -1511,14 +1517,14 @@ __global__ __launch_bounds__(1024) void gemm_planes_256_kernel(GemmArgs g) {
     bf16x8 nah[2], nal[2], nbh[2], nbl[2];
     if (wm == 0) dma(t + 4, cur);
     __builtin_amdgcn_sched_barrier(0);
-    if (!(g.skip & 1)) acc[0][0] = PG_MFMA(al[0], bh[0], acc[0][0]);
-    if (!(g.skip & 2)) acc[0][0] = PG_MFMA(ah[0], bl[0], acc[0][0]);
+    if (!LFI_GSKIP(1)) acc[0][0] = PG_MFMA(al[0], bh[0], acc[0][0]);
+    if (!LFI_GSKIP(2)) acc[0][0] = PG_MFMA(ah[0], bl[0], acc[0][0]);
     acc[0][0] = PG_MFMA(ah[0], bh[0], acc[0][0]);
     __builtin_amdgcn_sched_barrier(0);
     if (wm == 1) dma(t + 4, cur);
     __builtin_amdgcn_sched_barrier(0);
-    if (!(g.skip & 1)) acc[0][1] = PG_MFMA(al[0], bh[1], acc[0][1]);
-    if (!(g.skip & 2)) acc[0][1] = PG_MFMA(ah[0], bl[1], acc[0][1]);
+    if (!LFI_GSKIP(1)) acc[0][1] = PG_MFMA(al[0], bh[1], acc[0][1]);
+    if (!LFI_GSKIP(2)) acc[0][1] = PG_MFMA(ah[0], bl[1], acc[0][1]);
     acc[0][1] = PG_MFMA(ah[0], bh[1], acc[0][1]);
     __builtin_amdgcn_sched_barrier(0);
     // tile t + 1: A fragments of row tile 0 into the registers just freed, B fragments into a second set
@@ -1528,14 +1534,14 @@ __global__ __launch_bounds__(1024) void gemm_planes_256_kernel(GemmArgs g) {
     __builtin_amdgcn_sched_barrier(0);
     if (wm == 2) dma(t + 4, cur);
     __builtin_amdgcn_sched_barrier(0);
-    if (!(g.skip & 1)) acc[1][0] = PG_MFMA(al[1], bh[0], acc[1][0]);
-    if (!(g.skip & 2)) acc[1][0] = PG_MFMA(ah[1], bl[0], acc[1][0]);
+    if (!LFI_GSKIP(1)) acc[1][0] = PG_MFMA(al[1], bh[0], acc[1][0]);
+    if (!LFI_GSKIP(2)) acc[1][0] = PG_MFMA(ah[1], bl[0], acc[1][0]);
     acc[1][0] = PG_MFMA(ah[1], bh[0], acc[1][0]);
     __builtin_amdgcn_sched_barrier(0);
     if (wm == 3) dma(t + 4, cur);
     __builtin_amdgcn_sched_barrier(0);
-    if (!(g.skip & 1)) acc[1][1] = PG_MFMA(al[1], bh[1], acc[1][1]);
-    if (!(g.skip & 2)) acc[1][1] = PG_MFMA(ah[1], bl[1], acc[1][1]);
+    if (!LFI_GSKIP(1)) acc[1][1] = PG_MFMA(al[1], bh[1], acc[1][1]);
+    if (!LFI_GSKIP(2)) acc[1][1] = PG_MFMA(ah[1], bl[1], acc[1][1]);
     acc[1][1] = PG_MFMA(ah[1], bh[1], acc[1][1]);
     __builtin_amdgcn_sched_barrier(0);
     nah[1] = frag(nxt, fa + 2048); nal[1] = frag(nxt, fa + 3072);
@@ -1585,6 +1591,7 @@ constexpr int QRING = 3;
 constexpr int QSLOT = 24 * 1024;
 
 __global__ __launch_bounds__(512, 4) void gemm_planes_128_kernel(GemmArgs g) {
+  constexpr int XT = 2;   // skip switch compiled in (no register cost here)
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, half = lane >> 5;
@@ -1643,11 +1650,11 @@ __global__ __launch_bounds__(512, 4) void gemm_planes_128_kernel(GemmArgs g) {
     bf16x8 nah[2], nal[2], nbh[2], nbl[2];
     dma(t + 3, cur);
     __builtin_amdgcn_sched_barrier(0);
-    if (!(g.skip & 1)) {
+    if (!LFI_GSKIP(1)) {
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt) acc[0][nt] = PG_MFMA(al[0], bh[nt], acc[0][nt]);
     }
-    if (!(g.skip & 2)) {
+    if (!LFI_GSKIP(2)) {
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt) acc[0][nt] = PG_MFMA(ah[0], bl[nt], acc[0][nt]);
     }
@@ -1658,11 +1665,11 @@ __global__ __launch_bounds__(512, 4) void gemm_planes_128_kernel(GemmArgs g) {
 #pragma unroll
     for (int nt = 0; nt < 2; ++nt) { nbh[nt] = frag(nxt, fb + (nt * 2) * 1024); nbl[nt] = frag(nxt, fb + (nt * 2 + 1) * 1024); }
     __builtin_amdgcn_sched_barrier(0);
-    if (!(g.skip & 1)) {
+    if (!LFI_GSKIP(1)) {
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt) acc[1][nt] = PG_MFMA(al[1], bh[nt], acc[1][nt]);
     }
-    if (!(g.skip & 2)) {
+    if (!LFI_GSKIP(2)) {
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt) acc[1][nt] = PG_MFMA(ah[1], bl[nt], acc[1][nt]);
     }
@@ -1833,6 +1840,52 @@ extern "C" long lfi_gemm_work_floats(const lfi_gemm_desc* d) {
   return (long)d->batch * d->splitk * d->M * d->N;
 }
 
+
+namespace {
+// instantiations of the two default bf16x3 kernels by operand orientation and extras (XT, see LFI_GSKIP)
+template <int XT>
+int launch_x3_256(const GemmArgs& a, int akc, int bkc, dim3 grid, size_t lds, hipStream_t st) {
+  static bool attr = false;
+  if (!attr) {
+    hipError_t e1 = hipFuncSetAttribute((const void*)gemm_bf16x3_256_kernel<true, true, XT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e2 = hipFuncSetAttribute((const void*)gemm_bf16x3_256_kernel<true, false, XT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e3 = hipFuncSetAttribute((const void*)gemm_bf16x3_256_kernel<false, true, XT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e4 = hipFuncSetAttribute((const void*)gemm_bf16x3_256_kernel<false, false, XT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess) {
+      lfi_set_error("lfi_gemm_f32: cannot reserve %zu bytes of LDS for the 256 x 256 bf16x3 kernel", lds);
+      return LFI_ERR_LAUNCH;
+    }
+    attr = true;
+  }
+  if (akc && bkc) hipLaunchKernelGGL((gemm_bf16x3_256_kernel<true, true, XT>), grid, dim3(1024), lds, st, a);
+  else if (akc) hipLaunchKernelGGL((gemm_bf16x3_256_kernel<true, false, XT>), grid, dim3(1024), lds, st, a);
+  else if (bkc) hipLaunchKernelGGL((gemm_bf16x3_256_kernel<false, true, XT>), grid, dim3(1024), lds, st, a);
+  else hipLaunchKernelGGL((gemm_bf16x3_256_kernel<false, false, XT>), grid, dim3(1024), lds, st, a);
+  return LFI_OK;
+}
+template <int XT>
+int launch_x3_128(const GemmArgs& a, int akc, int bkc, dim3 grid, size_t lds, hipStream_t st) {
+  static bool attr = false;
+  if (!attr) {
+    hipError_t e1 = hipFuncSetAttribute((const void*)gemm_bf16x3_kernel<true, true, XT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e2 = hipFuncSetAttribute((const void*)gemm_bf16x3_kernel<true, false, XT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e3 = hipFuncSetAttribute((const void*)gemm_bf16x3_kernel<false, true, XT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e4 = hipFuncSetAttribute((const void*)gemm_bf16x3_kernel<false, false, XT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess) {
+      lfi_set_error("lfi_gemm_f32: cannot reserve %zu bytes of LDS for the bf16x3 kernel", lds);
+      return LFI_ERR_LAUNCH;
+    }
+    attr = true;
+  }
+  if (akc && bkc) hipLaunchKernelGGL((gemm_bf16x3_kernel<true, true, XT>), grid, dim3(256), lds, st, a);
+  else if (akc) hipLaunchKernelGGL((gemm_bf16x3_kernel<true, false, XT>), grid, dim3(256), lds, st, a);
+  else if (bkc) hipLaunchKernelGGL((gemm_bf16x3_kernel<false, true, XT>), grid, dim3(256), lds, st, a);
+  else hipLaunchKernelGGL((gemm_bf16x3_kernel<false, false, XT>), grid, dim3(256), lds, st, a);
+  return LFI_OK;
+}
+
+}  // namespace
+
 // Rows of the partial column-sum matrix lfi_gemm_f32 fills when lfi_gemm_desc.colsum_part is set, or 0 when this product does
 // not take a path that can (it needs the bf16x3 kernels' wide epilogue, no K split, column-batched or unbatched C).
 extern "C" long lfi_gemm_colpart_rows(const lfi_gemm_desc* d) {
@@ -1963,36 +2016,12 @@ extern "C" int lfi_gemm_f32(const lfi_gemm_desc* d, void* stream) {
     // main loop: two buffers of four 256 x 16 bf16 planes (96 KB); the wide epilogue: LFI_EPI_ROWS rows x 260 floats per pass
     const size_t lds_loop = (size_t)2 * 4 * YIMG * sizeof(__bf16), lds_epi = (size_t)LFI_EPI_ROWS * 260 * sizeof(float);
     const size_t lds = lds_loop > lds_epi ? lds_loop : lds_epi;
-    static bool attr256 = false;
-    if (!attr256) {
-      hipError_t e1 = hipFuncSetAttribute((const void*)gemm_bf16x3_256_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      hipError_t e2 = hipFuncSetAttribute((const void*)gemm_bf16x3_256_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      hipError_t e3 = hipFuncSetAttribute((const void*)gemm_bf16x3_256_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      hipError_t e4 = hipFuncSetAttribute((const void*)gemm_bf16x3_256_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess) {
-        lfi_set_error("lfi_gemm_f32: cannot reserve %zu bytes of LDS for the 256 x 256 bf16x3 kernel", lds);
-        return LFI_ERR_LAUNCH;
-      }
-      attr256 = true;
-    }
-    if (d->a_kcontig && d->b_kcontig) hipLaunchKernelGGL((gemm_bf16x3_256_kernel<true, true>), grid, dim3(1024), lds, st, a);
-    else if (d->a_kcontig) hipLaunchKernelGGL((gemm_bf16x3_256_kernel<true, false>), grid, dim3(1024), lds, st, a);
-    else if (d->b_kcontig) hipLaunchKernelGGL((gemm_bf16x3_256_kernel<false, true>), grid, dim3(1024), lds, st, a);
-    else hipLaunchKernelGGL((gemm_bf16x3_256_kernel<false, false>), grid, dim3(1024), lds, st, a);
+    const int rcl = a.skip ? launch_x3_256<2>(a, d->a_kcontig, d->b_kcontig, grid, lds, st)
+                           : (a.colpart ? launch_x3_256<1>(a, d->a_kcontig, d->b_kcontig, grid, lds, st)
+                                        : launch_x3_256<0>(a, d->a_kcontig, d->b_kcontig, grid, lds, st));
+    if (rcl) return rcl;
   } else if (use_x3) {
     const size_t lds = (size_t)2 * 4 * XIMG * sizeof(__bf16);
-    static bool attr_set = false;  // idempotent, per process: raise the dynamic-LDS cap of the four instantiations once
-    if (!attr_set) {
-      hipError_t e1 = hipFuncSetAttribute((const void*)gemm_bf16x3_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      hipError_t e2 = hipFuncSetAttribute((const void*)gemm_bf16x3_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      hipError_t e3 = hipFuncSetAttribute((const void*)gemm_bf16x3_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      hipError_t e4 = hipFuncSetAttribute((const void*)gemm_bf16x3_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess) {
-        lfi_set_error("lfi_gemm_f32: cannot reserve %zu bytes of LDS for the bf16x3 kernel", lds);
-        return LFI_ERR_LAUNCH;
-      }
-      attr_set = true;
-    }
     static int use_ws = -1;
     if (use_ws < 0) {
       const char* e = getenv("LFI_GEMM_WS");
@@ -2009,10 +2038,12 @@ extern "C" int lfi_gemm_f32(const lfi_gemm_desc* d, void* stream) {
       else if (d->a_kcontig) hipLaunchKernelGGL((gemm_bf16x3_ws_kernel<true, false>), grid, dim3(512), lds, st, a);
       else if (d->b_kcontig) hipLaunchKernelGGL((gemm_bf16x3_ws_kernel<false, true>), grid, dim3(512), lds, st, a);
       else hipLaunchKernelGGL((gemm_bf16x3_ws_kernel<false, false>), grid, dim3(512), lds, st, a);
-    } else if (d->a_kcontig && d->b_kcontig) hipLaunchKernelGGL((gemm_bf16x3_kernel<true, true>), grid, dim3(256), lds, st, a);
-    else if (d->a_kcontig) hipLaunchKernelGGL((gemm_bf16x3_kernel<true, false>), grid, dim3(256), lds, st, a);
-    else if (d->b_kcontig) hipLaunchKernelGGL((gemm_bf16x3_kernel<false, true>), grid, dim3(256), lds, st, a);
-    else hipLaunchKernelGGL((gemm_bf16x3_kernel<false, false>), grid, dim3(256), lds, st, a);
+    } else {
+      const int rcl = a.skip ? launch_x3_128<2>(a, d->a_kcontig, d->b_kcontig, grid, lds, st)
+                             : (a.colpart ? launch_x3_128<1>(a, d->a_kcontig, d->b_kcontig, grid, lds, st)
+                                          : launch_x3_128<0>(a, d->a_kcontig, d->b_kcontig, grid, lds, st));
+      if (rcl) return rcl;
+    }
   } else if (shape == 0) launch_gemm<128, 128, 2, 2>(a, d->a_kcontig, d->b_kcontig, grid, st);
   else if (shape == 1) launch_gemm<256, 64, 4, 1>(a, d->a_kcontig, d->b_kcontig, grid, st);
   else launch_gemm<64, 256, 1, 4>(a, d->a_kcontig, d->b_kcontig, grid, st);
