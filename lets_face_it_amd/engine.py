@@ -341,7 +341,7 @@ class GlowEngine:
         if splitk > 1 or splitk == 0:  # 0: the library picks the split (and the tile shape) that fills the chip
             g.work = self._buf(ws, batch * max(splitk, 8) * M * N).data_ptr()
         part, prow = None, 0
-        if colsum_into is not None:
+        if colsum_into is not None and os.environ.get("LFI_NO_COLPART") != "1":
             prow = int(self.L.lfi_gemm_colpart_rows(C.byref(g)))
             if prow > 0:
                 part = self._buf("scratch.colpart", prow * ldc)
