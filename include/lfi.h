@@ -164,6 +164,16 @@ int lfi_encode_windows_scatter(const lfi_enc_desc* d, const float* dgi, const fl
  * mask (F x hist) = the dropout multipliers of glow/models.py:56-58, or NULL) */
 int lfi_gather_windows(const float* X, int B, int T, int dim, int N, int start, int hist, int incl, const float* mask,
                        float* cond, int ldcond, int col, void* stream);
+/* Zero-padded copy of a (rows x cols) matrix with row pitch lds into row pitch ldd >= cols (the padding columns are written as
+ * zeros): the engine's 4-float granular copies of 50-d face / 27-d speech inputs and of W_ih, so that x W_ih^T (nn.GRU's input
+ * projection, glow/models.py:63) and its weight gradient take the vector-load GEMM kernels. */
+int lfi_pad_rows(const float* src, long rows, int cols, long lds, float* dst, long ldd, void* stream);
+/* Dropout multipliers of ModalityEncoder.forward (glow/models.py:56-58: nn.Dropout(p) on ones(B, hist), one scalar per (sample,
+ * history step) and timestep): out[i] = 1 / keep with probability keep, else 0, for up to 4 modalities in one launch. Philox4x32-10
+ * keyed on (seed, offset): reproducible from those two numbers; same law as the reference's, another stream (tests inject
+ * masks for parity). */
+int lfi_dropout_masks(int count, float* const* out, const long* n, const float* keep, unsigned long long seed,
+                      unsigned long long offset, void* stream);
 /* Conditioning.use_frame_nb (glow/models.py:89,116-117,143-144): one extra feature column holding a frame counter,
  * cond[n*B + b, col] = base[b] + offset + 2n. SeqGlow.forward / invert pass base = batch["frame_nb"] (B floats) and
  * offset = 2 * start (glow/models.py:539-542,557-558,623-625); SeqGlow.inference starts from ones: base = NULL (:572-575). */

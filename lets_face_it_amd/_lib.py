@@ -112,6 +112,8 @@ def lib():
         "lfi_encode_windows_compact_dgi": (i, [P(EncDesc)]),
         "lfi_encode_windows_scatter": (i, [P(EncDesc), vp, vp, vp, vp, vp]),
         "lfi_gather_windows": (i, [vp, i, i, i, i, i, i, i, vp, vp, i, i, vp]),
+        "lfi_pad_rows": (i, [vp, l, i, l, vp, l, vp]),
+        "lfi_dropout_masks": (i, [i, P(vp), P(l), P(f), C.c_ulonglong, C.c_ulonglong, vp]),
         "lfi_leaky_grad": (i, [vp, l, vp, l, i, i, f, vp]),
         "lfi_fill_frame_nb": (i, [vp, f, i, i, vp, i, i, vp]),
         "lfi_flow_prep_floats": (l, [P(FlowDims)]),
@@ -154,7 +156,7 @@ EXPORTS = [
     "lfi_gemm_planes", "lfi_colsum_work_floats",
     "lfi_colsum_f32", "lfi_cols_fold", "lfi_encode_windows_work_floats", "lfi_encode_windows_fwd", "lfi_encode_windows_bwd",
     "lfi_encode_windows_bias_rows", "lfi_encode_windows_bias_grads",
-    "lfi_encode_windows_scatter", "lfi_encode_windows_compact_dgi", "lfi_gather_windows", "lfi_leaky_grad", "lfi_fill_frame_nb", "lfi_flow_prep_floats", "lfi_flow_prep",
+    "lfi_encode_windows_scatter", "lfi_encode_windows_compact_dgi", "lfi_gather_windows", "lfi_pad_rows", "lfi_dropout_masks", "lfi_leaky_grad", "lfi_fill_frame_nb", "lfi_flow_prep_floats", "lfi_flow_prep",
     "lfi_flow_stash_floats", "lfi_flow_bstash_floats", "lfi_flow_stash_ptr", "lfi_flow_bstash_ptr",
     "lfi_flow_seq_fwd", "lfi_flow_seq_bwd", "lfi_flow_param_grads_work_floats", "lfi_flow_param_grads",
     "lfi_actnorm_init_stats", "lfi_actnorm_init_apply", "lfi_flow_step", "lfi_flow_sample_work_floats",

@@ -60,6 +60,51 @@ __global__ __launch_bounds__(64) void jerk_stage2(const double* __restrict__ par
   out[0] = (float)(s / count);
 }
 
+
+// dst[r][0 .. cols) = src[r][0 .. cols), dst[r][cols .. ldd) = 0: zero-padded copy of a matrix whose rows are not 4-float
+// granular (50-d faces, 27-d speech), so that the input projection takes the vector-load GEMM paths.
+__global__ __launch_bounds__(256) void pad_rows_kernel(const float* __restrict__ src, long rows, int cols, long lds,
+                                                       float* __restrict__ dst, long ldd) {
+  const long total = rows * ldd;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long r = i / ldd;
+    const int c = (int)(i - r * ldd);
+    dst[i] = c < cols ? src[r * lds + c] : 0.0f;
+  }
+}
+
+// Dropout multipliers of the window encoders (nn.Dropout on ones(B, hist), glow/models.py:56-58): out[i] = 1 / keep with
+// probability keep, else 0. Counter-based Philox4x32-10 keyed on (seed, call offset): element i is output (i & 3) of counter
+// (i >> 2, segment, offset), so a launch is reproducible from (seed, offset) alone and all modalities share one launch.
+struct MaskSegs { float* out[4]; long n[4]; float keep[4]; int count; };
+__device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1, unsigned (&o)[4]) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const unsigned h0 = __umulhi(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
+    const unsigned h1 = __umulhi(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
+    c0 = h1 ^ c1 ^ k0; c1 = l1; c2 = h0 ^ c3 ^ k1; c3 = l0;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  o[0] = c0; o[1] = c1; o[2] = c2; o[3] = c3;
+}
+__global__ __launch_bounds__(256) void dropout_masks_kernel(MaskSegs m, unsigned long long seed, unsigned long long offset) {
+  const int seg = blockIdx.y;
+  if (seg >= m.count) return;
+  const long n4 = (m.n[seg] + 3) >> 2;
+  const float keep = m.keep[seg], inv = 1.0f / keep;
+  for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < n4; q += (long)gridDim.x * 256) {
+    unsigned o[4];
+    philox4x32_10((unsigned)q, (unsigned)(q >> 32) ^ ((unsigned)seg << 28), (unsigned)offset, (unsigned)(offset >> 32),
+                  (unsigned)seed, (unsigned)(seed >> 32), o);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const long i = 4 * q + e;
+      // 24 random bits -> u in [0, 1): exact in fp32, P(u < keep) = ceil(keep * 2^24) / 2^24
+      if (i < m.n[seg]) m.out[seg][i] = (float)(o[e] >> 8) * (1.0f / 16777216.0f) < keep ? inv : 0.0f;
+    }
+  }
+}
+
 }  // namespace
 
 extern "C" int lfi_gather_sequences(const float* src, long rows, int dim, const long* starts, int B, int T, float* dst,
@@ -80,5 +125,35 @@ extern "C" int lfi_jerk_mean(const float* x, int B, int T, int C, float* out, do
   hipLaunchKernelGGL(jerk_stage1, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, (long)B, T, C, work);
   hipLaunchKernelGGL(jerk_stage2, dim3(1), dim3(64), 0, (hipStream_t)stream, work, blocks, (double)total, out);
   LFI_LAUNCH_CHECK("lfi_jerk_mean");
+  return LFI_OK;
+}
+
+extern "C" int lfi_pad_rows(const float* src, long rows, int cols, long lds, float* dst, long ldd, void* stream) {
+  LFI_REQUIRE(rows >= 0 && cols > 0 && lds >= cols && ldd >= cols, "lfi_pad_rows: bad dims rows=%ld cols=%d lds=%ld ldd=%ld", rows, cols, lds, ldd);
+  if (rows == 0) return LFI_OK;
+  LFI_REQUIRE(src && dst, "lfi_pad_rows: null pointer");
+  const long blocks = (rows * ldd + 255) / 256;
+  hipLaunchKernelGGL(pad_rows_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, (hipStream_t)stream, src, rows, cols, lds, dst, ldd);
+  LFI_LAUNCH_CHECK("lfi_pad_rows");
+  return LFI_OK;
+}
+
+extern "C" int lfi_dropout_masks(int count, float* const* out, const long* n, const float* keep, unsigned long long seed,
+                                 unsigned long long offset, void* stream) {
+  LFI_REQUIRE(count >= 0 && count <= 4, "lfi_dropout_masks: %d segments (at most 4)", count);
+  if (count == 0) return LFI_OK;
+  LFI_REQUIRE(out && n && keep, "lfi_dropout_masks: null pointer");
+  MaskSegs m = {};
+  long nmax = 0;
+  for (int i = 0; i < count; ++i) {
+    LFI_REQUIRE(n[i] >= 0 && (n[i] == 0 || out[i]) && keep[i] > 0.0f && keep[i] <= 1.0f, "lfi_dropout_masks: segment %d: n=%ld keep=%g", i, n[i], (double)keep[i]);
+    m.out[i] = out[i]; m.n[i] = n[i]; m.keep[i] = keep[i];
+    nmax = n[i] > nmax ? n[i] : nmax;
+  }
+  m.count = count;
+  if (nmax == 0) return LFI_OK;
+  const long blocks = ((nmax + 3) / 4 + 255) / 256;
+  hipLaunchKernelGGL(dropout_masks_kernel, dim3((unsigned)(blocks < 2048 ? blocks : 2048), count), dim3(256), 0, (hipStream_t)stream, m, seed, offset);
+  LFI_LAUNCH_CHECK("lfi_dropout_masks");
   return LFI_OK;
 }

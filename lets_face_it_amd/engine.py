@@ -215,6 +215,7 @@ class GlowEngine:
         # GEMM arithmetic: 0 = exact fp32 on the f32-input MFMA; 1 = bf16x3 (fp32 operands split into bf16 hi + lo on the
         # fly, three bf16 MFMAs per step, fp32 accumulation: ~2^-16 relative, 16x the MFMA rate)
         self.precision = 0
+        self._mask_calls = 0
         # GEMM class -> bf16x3 products to drop (bit 0: a_lo b_hi, bit 1: a_hi b_lo; 3 = plain bf16 operands, one product).
         # Measurement switch only: profiles/precision_sweep.md (tools/precision_sweep.py, final widths, against the fp64
         # oracle) shows NO class that keeps the test bounds with fewer than three products - the forward classes cost
@@ -296,6 +297,26 @@ class GlowEngine:
         elif zero:
             t.zero_()
         return t
+
+    def draw_masks(self, B, N, seed):
+        """{modality: (N, B, hist)} dropout multipliers of the window encoders in ONE launch (lfi_dropout_masks); the call
+        counter makes successive calls independent, (seed, counter) reproduces a call."""
+        segs = [e for e in self.spec.encoders if e.dropout > 0]
+        if not segs:
+            return None
+        self._mask_calls += 1
+        total = sum(N * B * e.hist for e in segs)
+        flat = self._buf("dropout_masks", total)
+        outs, ns, keeps, masks, off = (C.c_void_p * 4)(), (C.c_long * 4)(), (C.c_float * 4)(), {}, 0
+        for i, e in enumerate(segs):
+            n = N * B * e.hist
+            view = flat[off:off + n].view(N, B, e.hist)
+            outs[i], ns[i], keeps[i] = view.data_ptr(), n, 1.0 - e.dropout
+            masks[e.name] = view
+            off += n
+        check(self.L.lfi_dropout_masks(len(segs), outs, ns, keeps, int(seed) & (2 ** 64 - 1), self._mask_calls, _stream()),
+              "lfi_dropout_masks")
+        return masks
 
     # ------------------------------------------------------------------ second stream
     # Launch-latency-bound and HBM-streaming side work (parameter preparation; the encoders' window scatter + dW_ih) runs on a
@@ -527,10 +548,11 @@ class GlowEngine:
         if e.in_dim % 4 == 0 or os.environ.get("LFI_NO_XPAD") == "1":
             return x, self.view("enc.%s.weight_ih" % e.name), e.in_dim
         ldi = (e.in_dim + 3) // 4 * 4
-        xa = self._buf("xpad." + e.name, rows * ldi)          # born zeroed: the padding columns stay zero
-        xa[:rows * ldi].view(rows, ldi)[:, :e.in_dim].copy_(x.reshape(rows, e.in_dim))
+        xa = self._buf("xpad." + e.name, rows * ldi)
+        check(self.L.lfi_pad_rows(x.data_ptr(), rows, e.in_dim, e.in_dim, xa.data_ptr(), ldi, _stream()), "lfi_pad_rows")
         wa = self._buf("wihpad." + e.name, G * ldi)
-        wa[:G * ldi].view(G, ldi)[:, :e.in_dim].copy_(self.view("enc.%s.weight_ih" % e.name))
+        check(self.L.lfi_pad_rows(self.view("enc.%s.weight_ih" % e.name).data_ptr(), G, e.in_dim, e.in_dim, wa.data_ptr(), ldi,
+                                  _stream()), "lfi_pad_rows")
         return xa, wa, ldi
 
     def _project(self, cond, F):

@@ -376,6 +376,7 @@ class SeqGlow(nn.Module):
         if self.precision not in ("f32", "bf16x3"):
             raise ValueError("engine_precision must be 'f32' or 'bf16x3', got %r" % self.precision)
         self.injected_masks = None  # {modality: (N, B, hist)} overrides the random dropout masks (tests)
+        self.mask_seed_offset = 0   # data parallelism: the rank, so that every rank draws other masks
         self.allreduce_hook = None  # set by the data-parallel trainer: sums ActNorm init statistics over ranks
         self._param_map = []
         self._fwd_counter = 0
@@ -447,12 +448,10 @@ class SeqGlow(nn.Module):
             return {k: v.to(device=device, dtype=torch.float32).contiguous() for k, v in self.injected_masks.items()}
         if not self.training:
             return None
-        masks = {}
-        for e in self.spec.encoders:
-            if e.dropout > 0:  # nn.Dropout on ones(B, hist) per timestep (models.py:56-58)
-                keep = 1.0 - e.dropout
-                masks[e.name] = torch.empty((N, B, e.hist), device=device).bernoulli_(keep).mul_(1.0 / keep)
-        return masks or None
+        # nn.Dropout on ones(B, hist) per timestep (models.py:56-58): all modalities in one HIP launch, Philox keyed on torch's
+        # seed (torch.manual_seed / seed_everything) + this module's rank offset (the data-parallel trainer sets it) + a call counter
+        eng = self._ensure_engine(device)
+        return eng.draw_masks(B, N, torch.initial_seed() + self.mask_seed_offset)
 
     def _allreduce(self):
         hook = self.allreduce_hook

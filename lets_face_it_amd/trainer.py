@@ -90,6 +90,7 @@ class Trainer:
         # negative-example branch (lets_face_it_glow.py:40-45) — stays identical on all ranks so that they take the same branch
         if self.world_size > 1:
             torch.cuda.manual_seed(torch.initial_seed() + self.rank)
+            model.seq_glow.mask_seed_offset = self.rank
         step = self.global_step
         for epoch in range(self.epoch, self.max_epochs):
             self.epoch = epoch

@@ -52,6 +52,8 @@ def test_struct_layouts_match_header_field_order():
     text = open(os.path.join(ROOT, "include", "lfi.h")).read()
     names = re.findall(r"[\s\*,]([A-Za-z_][A-Za-z0-9_]*)\s*[;,]", _struct_body(text, "lfi_gemm_desc"))
     assert names == [f[0] for f in _lib.GemmDesc._fields_]
+    names = re.findall(r"[\s\*,]([A-Za-z_][A-Za-z0-9_]*)\s*[;,]", _struct_body(text, "lfi_pgemm_desc"))
+    assert names == [f[0] for f in _lib.PGemmDesc._fields_]
     names = re.findall(r"[\s\*,]([A-Za-z_][A-Za-z0-9_]*)\s*[;,]", _struct_body(text, "lfi_enc_desc"))
     assert names == [f[0] for f in _lib.EncDesc._fields_]
     names = re.findall(r"[\s\*,]([A-Za-z_][A-Za-z0-9_]*)\s*[;,]", _struct_body(text, "lfi_flow_dims"))

@@ -395,3 +395,39 @@ def test_wide_wave_256_tile_kernel(gpu_device, monkeypatch, akc, bkc):
     ref = torch.nn.functional.leaky_relu(a @ b + bias.double(), 0.01)
     assert float((outs[1].double() - ref).abs().max() / ref.abs().max()) < 1e-5
     assert torch.equal(outs[0], outs[1])
+
+
+def test_dropout_masks_and_padded_copies(gpu_device):
+    """lfi_dropout_masks (nn.Dropout on ones(B, hist), glow/models.py:56-58; all modalities in one launch): values in {0, 1 / keep},
+    keep-rate within 5 sigma, reproducible from (seed, call counter), different per call and per seed; lfi_pad_rows: exact
+    copy + zero padding."""
+    from argparse import Namespace
+    from helpers import Fixture
+    from lets_face_it_amd.engine import GlowEngine, ModelSpec
+    hp = Fixture("mid").hp           # final_model.yaml histories and dropouts (0.6 / 0.5 / 0.3)
+    e1, e2 = GlowEngine(ModelSpec(Namespace(**hp)), gpu_device), GlowEngine(ModelSpec(Namespace(**hp)), gpu_device)
+    B, N = 64, 56
+    a = {k: v.clone() for k, v in e1.draw_masks(B, N, 1234).items()}
+    b = {k: v.clone() for k, v in e2.draw_masks(B, N, 1234).items()}
+    c = {k: v.clone() for k, v in e1.draw_masks(B, N, 1234).items()}      # second call of e1: another counter
+    d = {k: v.clone() for k, v in GlowEngine(ModelSpec(Namespace(**hp)), gpu_device).draw_masks(B, N, 99).items()}
+    drops = {e.name: e.dropout for e in e1.spec.encoders if e.dropout > 0}
+    assert set(a) == set(drops) and len(a) == 3
+    for name, p in drops.items():
+        keep = 1.0 - p
+        m = a[name]
+        assert m.shape == (N, B, hp["Conditioning"][name]["history"])
+        on = m != 0
+        assert torch.allclose(m[on], torch.full_like(m[on], 1.0 / keep))
+        n = m.numel()
+        assert abs(float(on.float().mean()) - keep) < 5.0 * (keep * (1 - keep) / n) ** 0.5
+        assert torch.equal(m, b[name])                       # same seed, same call number
+        assert not torch.equal(m, c[name]) and not torch.equal(m, d[name])
+        assert abs(float((on & (c[name] != 0)).float().mean()) - keep * keep) < 0.02   # calls look independent
+    from lets_face_it_amd import _lib
+    L = _lib.lib()
+    x = torch.randn(37, 50, device=gpu_device)
+    out = torch.full((37, 52), float("nan"), device=gpu_device)
+    _lib.check(L.lfi_pad_rows(x.data_ptr(), 37, 50, 50, out.data_ptr(), 52, torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    assert torch.equal(out[:, :50], x) and bool((out[:, 50:] == 0).all())
