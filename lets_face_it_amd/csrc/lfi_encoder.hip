@@ -363,6 +363,14 @@ __device__ __forceinline__ enc_rsrc enc_buf(const void* p, long bytes) {
 __device__ __forceinline__ float enc_ld(enc_rsrc r, unsigned voff, unsigned soff) {
   return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
 }
+// read-once stash values in the backward kernel (1.76 GB per p2_face launch): streamed (aux 2 = non-temporal), so that they do
+// not sweep the weight fragments every workgroup re-reads each step out of L2
+#ifndef LFI_ENC_LDS_AUX
+#define LFI_ENC_LDS_AUX 2
+#endif
+__device__ __forceinline__ float enc_ld_stream(enc_rsrc r, unsigned voff, unsigned soff) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, LFI_ENC_LDS_AUX));
+}
 // The stashes are written once and read by a much later kernel (BPTT, the weight-gradient GEMMs): non-temporal (aux 2), so
 // 1.5 GB of them per launch do not sweep the weights and the projected inputs out of L2.
 #ifndef LFI_ENC_ST_AUX
@@ -1128,8 +1136,9 @@ __global__ __launch_bounds__(ENC_NT, 2) void enc_gru_bwd_fused_kernel(EncArgs a,
             wo[e] = roww[rl];
             live[e] = rlive[rl];
             const unsigned go = 4u * wo[e] + j4;
-            gr[e] = enc_ld(bgs, go, 0); gu[e] = enc_ld(bgs, go, h4); gn[e] = enc_ld(bgs, go, 2 * h4); gg[e] = enc_ld(bgs, go, 3 * h4);
-            hp[e] = enc_ld(bhp, wo[e] + j4, 0);
+            gr[e] = enc_ld_stream(bgs, go, 0); gu[e] = enc_ld_stream(bgs, go, h4); gn[e] = enc_ld_stream(bgs, go, 2 * h4);
+            gg[e] = enc_ld_stream(bgs, go, 3 * h4);
+            hp[e] = enc_ld_stream(bhp, wo[e] + j4, 0);
           }
 #pragma unroll
           for (int e = 0; e < 8; ++e) {

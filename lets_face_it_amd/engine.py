@@ -907,7 +907,13 @@ class GlowEngine:
         e1 = s.encoders[0]             # prev_p1_face: the only autoregressive input
         c1 = (e1.fdim + 3) // 4 * 4    # first column after its block (blocks start on 4-float boundaries)
         pre = self._buf("pre_static", F * KD)
-        if s.Ef > c1:
+        if s.Ef > c1 and self.precision == 1 and os.environ.get("LFI_PGEMM", "1") != "0":
+            # the static columns of cond_transform for every frame of the call (F x Ks D x 640 at final widths: the largest
+            # product of a sampling call) on pre-split planes, as the training step's cond_transform forward
+            cp, nkc = self.planes("cond_planes", cond, s.ldf, F, s.Ef - c1, x_off=c1)
+            wp, nkw = self.planes("wct_planes_static", self.wct_f, s.ldf, KD, s.Ef - c1, x_off=c1)
+            self.gemm_planes(F, KD, s.Ef - c1, cp, nkc, wp, nkw, pre, KD, bias=self.fview("bct"), cls="cond_fwd")
+        elif s.Ef > c1:
             self.gemm(F, KD, s.Ef - c1, cond, s.ldf, 1, self.wct_f, s.ldf, 1, pre, KD, bias=self.fview("bct"),
                       a_off=c1, b_off=c1)
         else:
