@@ -610,6 +610,9 @@ typedef __attribute__((ext_vector_type(4))) unsigned enc_u32x4;
 __device__ __forceinline__ f32x4 enc_ld4(enc_rsrc r, unsigned voff, unsigned soff) {
   return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
 }
+__device__ __forceinline__ f32x4 enc_ld4s(enc_rsrc r, unsigned voff, unsigned soff) {   // read-once stash values: streamed
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 2));
+}
 __device__ __forceinline__ void enc_st4(f32x4 v, enc_rsrc r, unsigned voff, unsigned soff) {
   __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(enc_u32x4, v), r, voff, soff, LFI_ENC_ST_AUX);
 }
@@ -1293,6 +1296,219 @@ __global__ __launch_bounds__(ENC_NT, 2) void enc_gru_bwd_fused_kernel(EncArgs a,
   }
 }
 
+// ---- BPTT with the row-layout epilogue (the counterpart of enc_gru_fwd_wide_kernel; bf16x3 products).
+// The accumulator-layout kernel above moves every stash value with its own 4-byte access (gates r, z, n, W_hn h and h_{s-1}
+// in; d n, d r, d z, d n * r out: 9 wave instructions per (row, 32 columns) and step) and writes the three gate images for
+// the MFMA A operand with 2-byte LDS stores (192 per lane and step). Here d h comes out of the accumulators through the
+// wave-private transpose tile, a lane owns 4 consecutive hidden units of 8 windows, everything above is a 16-byte access,
+// the images are written 8 bytes at a time, and the tile region doubles as a SECOND image pair while no transpose is in
+// flight, so that the r and z gate products run back to back: four workgroup barriers per step instead of six.
+__global__ __launch_bounds__(ENC_NT, 2) void enc_gru_bwd_wide_kernel(EncArgs a, EncFused q) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, half = lane >> 5;
+  const int cg = wave % q.ncg, rg = wave / q.ncg;
+  const int hid = a.hid, G3 = 3 * hid, Jp = q.Jp;
+  const int wbase = blockIdx.x * q.R;
+  const int ldx = q.Kp + 8;
+  const int img = q.R * ldx;                                   // bf16 elements of one image
+  __bf16* Xhi = reinterpret_cast<__bf16*>(enc_smem);
+  __bf16* Xlo = Xhi + img;
+  float* Treg = reinterpret_cast<float*>(Xlo + img);           // transpose tiles | second image pair (Yhi, Ylo)
+  const int tfloats = max(ENC_NW * 32 * ENC_TP, img);          // (2 * img bf16 = img floats)
+  float* T = Treg + wave * (32 * ENC_TP);
+  __bf16* Yhi = reinterpret_cast<__bf16*>(Treg);
+  __bf16* Ylo = Yhi + img;
+  unsigned* roww = reinterpret_cast<unsigned*>(Treg + tfloats);
+  float* rlive = reinterpret_cast<float*>(roww + q.R);
+  for (int i = tid; i < img; i += ENC_NT) { Xhi[i] = (__bf16)0.0f; Xlo[i] = (__bf16)0.0f; }
+  for (int i = tid; i < tfloats; i += ENC_NT) Treg[i] = 0.0f;   // (also the k padding of the second image pair)
+  for (int i = tid; i < q.R; i += ENC_NT) {
+    roww[i] = (unsigned)min(wbase + i, a.F - 1) * (unsigned)(hid * 4);
+    rlive[i] = wbase + i < a.F ? 1.0f : 0.0f;
+  }
+  const int rsub = lane >> 4, c4 = (lane & 15) * 4;
+  const int j0 = cg * 64 + c4;
+  const bool jok = j0 < hid;
+  const unsigned h4 = (unsigned)hid * 4u;
+  const enc_rsrc bdc = enc_buf(a.dcond, ((long)a.F * a.lddcond) * 4);
+  f32x4 dhu[8];          // d h_s * z_s: the part of d h_{s-1} that does not go through W_hh (row layout)
+  f32x4 bsum[4];         // column sums of d r, d z, d n, d n * r over this lane's rows and all steps
+#pragma unroll
+  for (int i = 0; i < 8; ++i) dhu[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int qq = 0; qq < 4; ++qq) bsum[qq] = f32x4{0.f, 0.f, 0.f, 0.f};
+  f32x16 acc[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+  __syncthreads();
+
+  for (int s = a.hist - 1; s >= 0; --s) {
+    int rsv = rsub, cv = c4, jv = j0;
+    asm volatile("" : "+v"(rsv), "+v"(cv), "+v"(jv));
+    const unsigned j4 = (unsigned)jv * 4u, oob = jv < hid ? 0u : 0x80000000u;
+    float* Trow = T + rsv * ENC_TP + cv;
+    float* Tacc = T + (4 * half) * ENC_TP + l31;
+    // ---- d h_s in the row layout
+    f32x4 dh[8];
+    if (s == a.hist - 1) {
+      const unsigned cb = (unsigned)a.col * 4u + j4 + oob;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const unsigned wrow = (roww[rg * 32 + 4 * i + rsv] / h4) * (unsigned)(a.lddcond * 4);
+        dh[i] = enc_ld4(bdc, wrow + cb, 0);
+        if (a.dup) dh[i] += enc_ld4(bdc, wrow + cb, h4);
+      }
+    } else {
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) Tacc[((r & 3) + 8 * (r >> 2)) * ENC_TP + 32 * t] = acc[t][r];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+      for (int i = 0; i < 8; ++i) dh[i] = *reinterpret_cast<const f32x4*>(Trow + 4 * i * ENC_TP) + dhu[i];
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    __syncthreads();   // B0: every wave is done with its transpose tile (the second image pair overlays those) and with the
+                       // previous step's n-gate product (which read the first image pair)
+    if (q.Kp > hid) {   // the transposes left accumulator bits in the second pair's k padding: NaN patterns x 0 would poison the product
+      const int pad = q.Kp - hid;
+      for (int i = tid; i < q.R * pad; i += ENC_NT) {
+        const int rl = i / pad, c = hid + (i - rl * pad);
+        Yhi[rl * ldx + c] = (__bf16)0.0f; Ylo[rl * ldx + c] = (__bf16)0.0f;
+      }
+    }
+    const int sp = s > 0 ? s - 1 : 0;
+    const float hp_on = s > 0 ? 1.0f : 0.0f;
+    const enc_rsrc bgs = enc_buf(a.gates + (long)s * a.F * 4 * hid, (long)a.F * hid * 16);
+    const enc_rsrc bhp = enc_buf(a.hseq + (long)sp * a.F * hid, (long)a.F * hid * 4);
+    const enc_rsrc bgi = enc_buf(a.dgi + (long)s * a.F * hid, (long)a.F * hid * 4);
+    const enc_rsrc bgh = enc_buf(a.dgh + (long)s * a.F * G3, (long)a.F * G3 * 4);
+    f32x4 danr[8];
+#pragma unroll
+    for (int ih = 0; ih < 2; ++ih) {
+      f32x4 gr[4], gu[4], gn[4], gg[4], hp[4];
+      unsigned wo[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int rl = rg * 32 + 4 * (4 * ih + u) + rsv;
+        wo[u] = roww[rl];
+        const unsigned go = 4u * wo[u] + j4 + oob;
+        gr[u] = enc_ld4s(bgs, go, 0); gu[u] = enc_ld4s(bgs, go, h4); gn[u] = enc_ld4s(bgs, go, 2 * h4); gg[u] = enc_ld4s(bgs, go, 3 * h4);
+        hp[u] = enc_ld4s(bhp, wo[u] + j4 + oob, 0);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = 4 * ih + u;
+        const int rl = rg * 32 + 4 * i + rsv;
+        const float live = rlive[rl];
+        f32x4 dan, dau, dar, dnr;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float rr = gr[u][e], uu = gu[u][e], nn = gn[u][e], ghn = gg[u][e];
+          const float dhn = dh[i][e];
+          const float du = dhn * (hp[u][e] * hp_on - nn);
+          const float dn = dhn * (1.0f - uu);
+          dan[e] = dn * (1.0f - nn * nn);
+          dau[e] = du * uu * (1.0f - uu);
+          dar[e] = dan[e] * ghn * rr * (1.0f - rr);
+          dnr[e] = dan[e] * rr;
+          dhu[i][e] = dhn * uu;
+        }
+        enc_st4(dan, bgi, wo[u] + j4 + oob, 0);
+        const unsigned o = 3u * wo[u] + j4 + oob;
+        enc_st4(dar, bgh, o, 0); enc_st4(dau, bgh, o, h4); enc_st4(dnr, bgh, o, 2 * h4);
+        bsum[0] += live * dar; bsum[1] += live * dau; bsum[2] += live * dan; bsum[3] += live * dnr;
+        danr[i] = dnr;
+        if (s > 0 && jok) {   // gate images for the products: d r -> first pair, d z -> second pair
+          uint2 h, l;
+          split2(dar[0], dar[1], &h.x, &l.x); split2(dar[2], dar[3], &h.y, &l.y);
+          *reinterpret_cast<uint2*>(Xhi + rl * ldx + jv) = h; *reinterpret_cast<uint2*>(Xlo + rl * ldx + jv) = l;
+          split2(dau[0], dau[1], &h.x, &l.x); split2(dau[2], dau[3], &h.y, &l.y);
+          *reinterpret_cast<uint2*>(Yhi + rl * ldx + jv) = h; *reinterpret_cast<uint2*>(Ylo + rl * ldx + jv) = l;
+        }
+      }
+    }
+    if (s == 0) break;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[t][r] = 0.0f;
+    auto product = [&](int g, const __bf16* Ih, const __bf16* Il) {   // acc += image_g (R x hid) W_hh[g] (hid x hid)
+      const int nkt = q.Kp >> 4, nct = Jp >> 5;
+      const __bf16* xh = Ih + (rg * 32 + l31) * ldx + 8 * half;
+      const __bf16* xl = Il + (rg * 32 + l31) * ldx + 8 * half;
+      ebf16x8 ah0, al0, ah1, al1;
+      EncFrag f0[2][2], f1[2][2];  // [t][plane]
+      auto load = [&](int kt, ebf16x8& ah, ebf16x8& al, EncFrag (&f)[2][2]) {
+        ah = *reinterpret_cast<const ebf16x8*>(xh + kt * 16);
+        al = *reinterpret_cast<const ebf16x8*>(xl + kt * 16);
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          const uint4* __restrict__ wf = q.wfrag + ((long)((g * nkt + kt) * nct + cg * 2 + t) * 2) * 64;  // uniform
+          f[t][0].u = wf[(unsigned)lane];
+          f[t][1].u = (wf + 64)[(unsigned)lane];
+        }
+      };
+      auto mma = [&](const ebf16x8& ah, const ebf16x8& al, const EncFrag (&f)[2][2]) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, f[t][0].v, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, f[t][1].v, acc[t], 0, 0, 0);
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, f[t][0].v, acc[t], 0, 0, 0);
+        }
+      };
+      load(0, ah0, al0, f0);
+      int kt = 0;
+      for (; kt + 2 < nkt; kt += 2) {   // unconditional loads (see the forward kernel)
+        load(kt + 1, ah1, al1, f1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(ah0, al0, f0);
+        load(kt + 2, ah0, al0, f0);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(ah1, al1, f1);
+      }
+      if (kt + 1 < nkt) {
+        load(kt + 1, ah1, al1, f1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(ah0, al0, f0);
+        mma(ah1, al1, f1);
+      } else {
+        mma(ah0, al0, f0);
+      }
+    };
+    __syncthreads();   // B1: both image pairs complete
+    product(0, Xhi, Xlo);
+    product(1, Yhi, Ylo);
+    __syncthreads();   // B2: every wave has read the first pair
+    if (jok) {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int rl = rg * 32 + 4 * i + rsv;
+        uint2 h, l;
+        split2(danr[i][0], danr[i][1], &h.x, &l.x); split2(danr[i][2], danr[i][3], &h.y, &l.y);
+        *reinterpret_cast<uint2*>(Xhi + rl * ldx + jv) = h; *reinterpret_cast<uint2*>(Xlo + rl * ldx + jv) = l;
+      }
+    }
+    __syncthreads();   // B3
+    product(2, Xhi, Xlo);
+  }
+  if (a.bias_part && jok) {
+    float* bp = a.bias_part + ((long)blockIdx.x * (ENC_NW / q.ncg) + rg) * 4 * hid;
+#pragma unroll
+    for (int qq = 0; qq < 4; ++qq) {
+      f32x4 v = bsum[qq];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        v[e] += __shfl_xor(v[e], 16, 64);
+        v[e] += __shfl_xor(v[e], 32, 64);
+      }
+      if (rsub == 0) *reinterpret_cast<f32x4*>(bp + qq * hid + j0) = v;
+    }
+  }
+}
+
 template <typename Kf>
 int enc_set_lds(Kf kernel, size_t bytes) {
   if (bytes <= 48 * 1024) return LFI_OK;
@@ -1560,7 +1776,20 @@ extern "C" int lfi_encode_windows_bwd(const lfi_enc_desc* d, const float* dcond,
     q.wfrag = reinterpret_cast<const uint4*>(work);
     const size_t tab = (size_t)2 * q.R * sizeof(unsigned);   // per-row offset / liveness tables
     const size_t ldsf = (size_t)q.Kp * (q.R + 1) * sizeof(float) + tab, ldsx = (size_t)2 * q.R * (q.Kp + 8) * sizeof(__bf16) + tab;
-    if (x3) {
+    static int widebw = -1;
+    if (widebw < 0) {
+      const char* e = getenv("LFI_ENC_WIDE_BWD");
+      widebw = (e && e[0] == '0') ? 0 : 1;
+    }
+    auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    const long imgf = (long)q.R * (q.Kp + 8);   // floats of one image pair
+    const size_t ldsw = (size_t)2 * q.R * (q.Kp + 8) * sizeof(__bf16) +
+                        (size_t)(ENC_NW * 32 * ENC_TP > imgf ? ENC_NW * 32 * ENC_TP : imgf) * sizeof(float) + tab;
+    if (x3 && widebw && hid % 4 == 0 && lddcond % 4 == 0 && d->col % 4 == 0 && al16(dcond) && al16(gates) && al16(hseq) &&
+        al16(dgi) && al16(dgh) && (!bias_part || al16(bias_part)) && ldsw <= 80 * 1024) {
+      if ((rc = enc_set_lds(enc_gru_bwd_wide_kernel, ldsw))) return rc;
+      hipLaunchKernelGGL(enc_gru_bwd_wide_kernel, dim3(lfi_cdiv(F, q.R)), dim3(ENC_NT), ldsw, st, a, q);
+    } else if (x3) {
       if ((rc = enc_set_lds(enc_gru_bwd_fused_kernel<true>, ldsx))) return rc;
       hipLaunchKernelGGL(enc_gru_bwd_fused_kernel<true>, dim3(lfi_cdiv(F, q.R)), dim3(ENC_NT), ldsx, st, a, q);
     } else {
