@@ -217,7 +217,7 @@ def _roofline(spec, F, timing, precision):
 
 def _roofline_hbm(spec, B, T, timing, precision):
     """Second roofline, for the largest HBM-bound kernel: the fused GRU window encoder of p2_face, forward
-    (enc_gru_fwd_fused_kernel). Algorithmic bytes per launch = what must cross HBM once: the BPTT stash it writes (r, z, n,
+    (enc_gru_fwd_wide_kernel). Algorithmic bytes per launch = what must cross HBM once: the BPTT stash it writes (r, z, n,
     W_hn h + b_hn and h: 5 * hid floats per window and history step), the projected inputs it reads (B*T x 3*hid, shared by the
     overlapping windows) and the feature block it writes (F x hid). Launch time: HIP events on the launch stream."""
     e = next((x for x in spec.encoders if x.name == "p2_face" and x.enc == "rnn"), None)
@@ -230,12 +230,12 @@ def _roofline_hbm(spec, B, T, timing, precision):
     try:
         tj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_%s.json" % precision)))
         for name, v in tj["kernels"].items():
-            if "enc_gru_fwd_fused_kernel" in name and name.endswith("grid=%d" % (((F + 31) // 32) * 256)):
+            if ("enc_gru_fwd_wide_kernel" in name or "enc_gru_fwd_fused_kernel" in name) and name.endswith("grid=%d" % (((F + 31) // 32) * 256)):
                 traffic = max(traffic or 0.0, v["hbm_bytes"])   # p2_face (24 steps) is the larger of the two 256-wide launches
     except (OSError, ValueError, KeyError):
         pass
     ach = alg / (ms * 1e-3) / 1e9
-    return {"bound": "hbm", "kernel": "enc_gru_fwd_fused_kernel, p2_face windows (hist %d, hid %d)" % (e.hist, e.hid),
+    return {"bound": "hbm", "kernel": "enc_gru_fwd_wide_kernel, p2_face windows (hist %d, hid %d)" % (e.hist, e.hid),
             "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0, "traffic": traffic,
             "traffic_note": "PMC bytes per launch of this kernel name and grid: the mean over the p2_face (24 steps) and p2_speech "
                             "(16 steps) launches, which share them",
