@@ -1845,42 +1845,61 @@ namespace {
 // instantiations of the two default bf16x3 kernels by operand orientation and extras (XT, see LFI_GSKIP)
 template <int XT>
 int launch_x3_256(const GemmArgs& a, int akc, int bkc, dim3 grid, size_t lds, hipStream_t st) {
+  // XT = 1 (epilogue column sums, no skip switch) is instantiated for the one orientation that uses it - A k-contiguous, B
+  // n-contiguous: the in-place dpre product - and hands every other orientation to XT = 2 (compile time: each instantiation
+  // of this kernel costs ~8 s of hipcc)
+  if (XT == 1 && !(akc && !bkc)) return launch_x3_256<2>(a, akc, bkc, grid, lds, st);
   static bool attr = false;
   if (!attr) {
-    hipError_t e1 = hipFuncSetAttribute((const void*)gemm_bf16x3_256_kernel<true, true, XT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipError_t e2 = hipFuncSetAttribute((const void*)gemm_bf16x3_256_kernel<true, false, XT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipError_t e3 = hipFuncSetAttribute((const void*)gemm_bf16x3_256_kernel<false, true, XT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipError_t e4 = hipFuncSetAttribute((const void*)gemm_bf16x3_256_kernel<false, false, XT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e1 = hipSuccess, e2, e3 = hipSuccess, e4 = hipSuccess;
+    e2 = hipFuncSetAttribute((const void*)gemm_bf16x3_256_kernel<true, false, XT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if constexpr (XT != 1) {
+      e1 = hipFuncSetAttribute((const void*)gemm_bf16x3_256_kernel<true, true, XT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      e3 = hipFuncSetAttribute((const void*)gemm_bf16x3_256_kernel<false, true, XT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      e4 = hipFuncSetAttribute((const void*)gemm_bf16x3_256_kernel<false, false, XT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    }
     if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess) {
       lfi_set_error("lfi_gemm_f32: cannot reserve %zu bytes of LDS for the 256 x 256 bf16x3 kernel", lds);
       return LFI_ERR_LAUNCH;
     }
     attr = true;
   }
-  if (akc && bkc) hipLaunchKernelGGL((gemm_bf16x3_256_kernel<true, true, XT>), grid, dim3(1024), lds, st, a);
-  else if (akc) hipLaunchKernelGGL((gemm_bf16x3_256_kernel<true, false, XT>), grid, dim3(1024), lds, st, a);
-  else if (bkc) hipLaunchKernelGGL((gemm_bf16x3_256_kernel<false, true, XT>), grid, dim3(1024), lds, st, a);
-  else hipLaunchKernelGGL((gemm_bf16x3_256_kernel<false, false, XT>), grid, dim3(1024), lds, st, a);
+  if constexpr (XT == 1) {
+    hipLaunchKernelGGL((gemm_bf16x3_256_kernel<true, false, XT>), grid, dim3(1024), lds, st, a);
+  } else {
+    if (akc && bkc) hipLaunchKernelGGL((gemm_bf16x3_256_kernel<true, true, XT>), grid, dim3(1024), lds, st, a);
+    else if (akc) hipLaunchKernelGGL((gemm_bf16x3_256_kernel<true, false, XT>), grid, dim3(1024), lds, st, a);
+    else if (bkc) hipLaunchKernelGGL((gemm_bf16x3_256_kernel<false, true, XT>), grid, dim3(1024), lds, st, a);
+    else hipLaunchKernelGGL((gemm_bf16x3_256_kernel<false, false, XT>), grid, dim3(1024), lds, st, a);
+  }
   return LFI_OK;
 }
 template <int XT>
 int launch_x3_128(const GemmArgs& a, int akc, int bkc, dim3 grid, size_t lds, hipStream_t st) {
+  if (XT == 1 && !(akc && !bkc)) return launch_x3_128<2>(a, akc, bkc, grid, lds, st);   // as launch_x3_256
   static bool attr = false;
   if (!attr) {
-    hipError_t e1 = hipFuncSetAttribute((const void*)gemm_bf16x3_kernel<true, true, XT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipError_t e2 = hipFuncSetAttribute((const void*)gemm_bf16x3_kernel<true, false, XT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipError_t e3 = hipFuncSetAttribute((const void*)gemm_bf16x3_kernel<false, true, XT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipError_t e4 = hipFuncSetAttribute((const void*)gemm_bf16x3_kernel<false, false, XT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e1 = hipSuccess, e2, e3 = hipSuccess, e4 = hipSuccess;
+    e2 = hipFuncSetAttribute((const void*)gemm_bf16x3_kernel<true, false, XT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if constexpr (XT != 1) {
+      e1 = hipFuncSetAttribute((const void*)gemm_bf16x3_kernel<true, true, XT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      e3 = hipFuncSetAttribute((const void*)gemm_bf16x3_kernel<false, true, XT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      e4 = hipFuncSetAttribute((const void*)gemm_bf16x3_kernel<false, false, XT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    }
     if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess) {
       lfi_set_error("lfi_gemm_f32: cannot reserve %zu bytes of LDS for the bf16x3 kernel", lds);
       return LFI_ERR_LAUNCH;
     }
     attr = true;
   }
-  if (akc && bkc) hipLaunchKernelGGL((gemm_bf16x3_kernel<true, true, XT>), grid, dim3(256), lds, st, a);
-  else if (akc) hipLaunchKernelGGL((gemm_bf16x3_kernel<true, false, XT>), grid, dim3(256), lds, st, a);
-  else if (bkc) hipLaunchKernelGGL((gemm_bf16x3_kernel<false, true, XT>), grid, dim3(256), lds, st, a);
-  else hipLaunchKernelGGL((gemm_bf16x3_kernel<false, false, XT>), grid, dim3(256), lds, st, a);
+  if constexpr (XT == 1) {
+    hipLaunchKernelGGL((gemm_bf16x3_kernel<true, false, XT>), grid, dim3(256), lds, st, a);
+  } else {
+    if (akc && bkc) hipLaunchKernelGGL((gemm_bf16x3_kernel<true, true, XT>), grid, dim3(256), lds, st, a);
+    else if (akc) hipLaunchKernelGGL((gemm_bf16x3_kernel<true, false, XT>), grid, dim3(256), lds, st, a);
+    else if (bkc) hipLaunchKernelGGL((gemm_bf16x3_kernel<false, true, XT>), grid, dim3(256), lds, st, a);
+    else hipLaunchKernelGGL((gemm_bf16x3_kernel<false, false, XT>), grid, dim3(256), lds, st, a);
+  }
   return LFI_OK;
 }
 
@@ -2018,7 +2037,7 @@ extern "C" int lfi_gemm_f32(const lfi_gemm_desc* d, void* stream) {
     const size_t lds = lds_loop > lds_epi ? lds_loop : lds_epi;
     const int rcl = a.skip ? launch_x3_256<2>(a, d->a_kcontig, d->b_kcontig, grid, lds, st)
                            : (a.colpart ? launch_x3_256<1>(a, d->a_kcontig, d->b_kcontig, grid, lds, st)
-                                        : launch_x3_256<0>(a, d->a_kcontig, d->b_kcontig, grid, lds, st));
+                                        : launch_x3_256<0>(a, d->a_kcontig, d->b_kcontig, grid, lds, st));   // (<1>: see launch_x3_256)
     if (rcl) return rcl;
   } else if (use_x3) {
     const size_t lds = (size_t)2 * 4 * XIMG * sizeof(__bf16);
