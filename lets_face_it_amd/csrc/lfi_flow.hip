@@ -55,6 +55,7 @@ struct FlowK {
   const float* gic;
   float gscale;
   unsigned long long* stamps;  // diagnostics only (lfi_debug_set_stamps): s_memtime at phase boundaries, else null
+  int stamp_k;                 // flow step whose workgroup (tile 0) stamps (LFI_STAMP_K, default Ks / 2)
   int pipe_fence;              // 1: consumers run an agent-scope acquire after the poll and read the tile with plain loads
                                // 0: no fence, every load of a handed-off tile is an sc1 load (L1 bypass)
   unsigned* pipe;              // persistent-pipeline state (flow_pipe_*_kernel): [0] ticket, [1] abort, [4 + k * nbt + bt] progress
@@ -1222,7 +1223,7 @@ __host__ __device__ inline int pipe_fwd_lds_floats(int C, int C16, int H16, int 
 // slots [4096 + 2048 * backward + 16 * n + phase] of the stamp buffer
 #define PIPE_STAMP(dir, slot)                                                                                              \
   do {                                                                                                                     \
-    if (f.stamps && tid == 0 && bt == 0 && k == f.Ks / 2 && n < 128)                                                       \
+    if (f.stamps && tid == 0 && bt == 0 && k == f.stamp_k && n < 128)                                                       \
       f.stamps[4096 + 2048 * (dir) + 16 * n + (slot)] = __builtin_amdgcn_s_memtime();                                      \
   } while (0)
 
@@ -1231,7 +1232,7 @@ __global__ __launch_bounds__(NT) void flow_pipe_fwd_kernel(FlowK f) {
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l15_0 = lane & 15, kq_0 = lane >> 4;
   const int ri_0 = tid >> 5, cl_0 = tid & 31;  // elementwise thread map
-  __shared__ int s_id, s_ok;
+  __shared__ int s_id, s_ok, s_rdy;
   if (tid == 0) s_id = (int)atomicAdd(f.pipe, 1u);
   __syncthreads();
   const int id = s_id;
@@ -1323,6 +1324,15 @@ __global__ __launch_bounds__(NT) void flow_pipe_fwd_kernel(FlowK f) {
 
   const int row = b0 + ri_0;          // elementwise phases: this thread's sample
   const bool rok = row < B;
+  // Look-ahead acquire. Every cell paid two dependent L2 round trips at its top - the poll of the predecessor's progress
+  // word, then (behind a barrier) the sc1 loads of the tile: 3.6 k of a 20 k-cycle timestep (stamps: 0.5 k in step 0, which
+  // has no predecessor, 4.1 k in step 1). Now thread 0 peeks at the word for cell n + 1 at the start of P4 of cell n (the
+  // load returns under P4 and the store drain); if that cell is already published, every thread fetches its elements of
+  // the tile right behind the publish barrier (poll -> barrier -> sc1 loads, the order of the blocking form) and the next
+  // iteration starts with them in flight instead of polling. A step settles ~0.15 cell + one hand-off behind its
+  // predecessor, where the peek succeeds every time; a miss just takes the blocking path.
+  bool have_next = false;
+  float xnext[2] = {0.0f, 0.0f};
   for (int n = 0; n < f.N; ++n) {
     // lane coordinates laundered per iteration: otherwise every per-lane stash address (a dozen arrays x 4 rows, 64-bit) is
     // hoisted out of the timestep loop and the kernel spills ~150 VGPRs
@@ -1343,7 +1353,7 @@ __global__ __launch_bounds__(NT) void flow_pipe_fwd_kernel(FlowK f) {
         for (int g = 0; g < NG; ++g) gc[r][g] = gicb[(long)rw * G + g * H + jc];
       }
     }
-    if (k > 0 && !pipe_acquire(prog + (k - 1) * nbt + bt, (unsigned)n + 1u, abort_w, tid, &s_ok, fenced)) break;
+    if (k > 0 && !have_next && !pipe_acquire(prog + (k - 1) * nbt + bt, (unsigned)n + 1u, abort_w, tid, &s_ok, fenced)) break;
 
     PIPE_STAMP(0, 1);
     // ---- P0: actnorm (glow/modules.py:45-52); stage a k-major
@@ -1355,7 +1365,7 @@ __global__ __launch_bounds__(NT) void flow_pipe_fwd_kernel(FlowK f) {
         if (c < C16) {
           float a = 0.0f;
           if (c < C && rok) {
-            a = ((k == 0 ? xin[c] : ld_tile(xin + c, fenced)) + anb[u]) * ans[u];
+            a = ((k == 0 ? xin[c] : (have_next ? xnext[u] : ld_tile(xin + c, fenced))) + anb[u]) * ans[u];
             f.sA[(kf + row) * LC + c] = a;
           }
           At[c * LT + ri] = a;
@@ -1417,6 +1427,9 @@ __global__ __launch_bounds__(NT) void flow_pipe_fwd_kernel(FlowK f) {
     PIPE_STAMP(0, 5);
 
     // ---- P4: coupling (glow/models.py:330-341), pass-through half, log-det; the output tile is the hand-off payload
+    const bool peek = k > 0 && !fenced && n + 1 < f.N;
+    unsigned pk = 0u;
+    if (peek && tid == 0) pk = ld_agent(prog + (k - 1) * nbt + bt);
     {
       float lg = 0.0f;
       if (cl < C2) {
@@ -1439,7 +1452,20 @@ __global__ __launch_bounds__(NT) void flow_pipe_fwd_kernel(FlowK f) {
       if (cl == 0 && rok) f.sL[kf + row] = lg;
     }
     PIPE_STAMP(0, 6);
-    pipe_publish(prog + k * nbt + bt, (unsigned)n + 1u, tid, k + 1 < f.Ks);
+    // (pipe_publish, with the outcome of the peek riding on its barrier)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (peek && tid == 0) s_rdy = pk >= (unsigned)n + 2u ? 1 : 0;
+    __syncthreads();
+    if (k + 1 < f.Ks && tid == 0) st_agent(prog + k * nbt + bt, (unsigned)n + 1u);
+    have_next = peek && s_rdy != 0;
+    if (have_next) {
+      const float* xn = f.sX + (kf + B - f.F + row) * LC;   // cell n + 1 of step k - 1
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int c = cl + 32 * u;
+        xnext[u] = (c < C && rok) ? ld_tile(xn + c, false) : 0.0f;
+      }
+    }
     PIPE_STAMP(0, 7);
     float* t = Ht; Ht = Hn; Hn = t;
   }
@@ -2660,6 +2686,10 @@ int fill_flow(const lfi_flow_dims* d, const lfi_flow_params* p, const float* pre
   f->G = (d->lstm ? 4 : 3) * d->H; f->I = f->Ch + d->D; f->F = d->N * d->B; f->nbt = lfi_cdiv(d->B, MB);
   f->p = *p;
   f->stamps = g_lfi_stamps;
+  {
+    const char* e = getenv("LFI_STAMP_K");
+    f->stamp_k = e ? atoi(e) : f->Ks / 2;
+  }
   f->NG = d->lstm ? 4 : 3;
   f->ldc = (f->C + 3) & ~3; f->ldo = (f->Cout + 3) & ~3;
   f->C16 = (f->C + 15) & ~15; f->Ch16 = (f->Ch + 15) & ~15; f->H16 = (f->H + 15) & ~15; f->Co16 = (f->Cout + 15) & ~15;
