@@ -1944,7 +1944,7 @@ __global__ __launch_bounds__(NT) void flow_pipe_bwd_kernel(FlowK f) {
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l15_0 = lane & 15, kq_0 = lane >> 4;
   const int ri_0 = tid >> 5, cl_0 = tid & 31;
-  __shared__ int s_id, s_ok;
+  __shared__ int s_id, s_ok, s_rdy;
   if (tid == 0) s_id = (int)atomicAdd(f.pipe, 1u);
   __syncthreads();
   const int nbt = f.nbt;
@@ -2014,6 +2014,10 @@ __global__ __launch_bounds__(NT) void flow_pipe_bwd_kernel(FlowK f) {
   float bsi[NG], bsh[NG];
 #pragma unroll
   for (int g = 0; g < NG; ++g) { bsi[g] = 0.0f; bsh[g] = 0.0f; }
+  // look-ahead acquire, as in the forward walk: thread 0 peeks at flow step k + 1's progress word for cell n - 1 at the start
+  // of Q3 of cell n; if it is published, every thread fetches its elements of that d x tile behind the publish barrier
+  bool have_next = false;
+  float nx_dxo[4] = {0.f, 0.f, 0.f, 0.f}, nx_dz2 = 0.0f;
   for (int n = f.N - 1; n >= 0; --n) {
     // lane coordinates laundered per iteration: otherwise every per-lane stash address (a dozen arrays x 4 rows, 64-bit) is
     // hoisted out of the timestep loop and the kernel spills ~150 VGPRs
@@ -2062,13 +2066,13 @@ __global__ __launch_bounds__(NT) void flow_pipe_bwd_kernel(FlowK f) {
       q_oe = O[cl];
     }
   }
-  if (!last && !pipe_acquire(prog + (k + 1) * nbt + bt, (unsigned)(f.N - n), abort_w, tid, &s_ok, fenced)) break;
+  if (!last && !have_next && !pipe_acquire(prog + (k + 1) * nbt + bt, (unsigned)(f.N - n), abort_w, tid, &s_ok, fenced)) break;
   {
     const int cz = tcol < Ch ? tcol : 0;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const long row = min(b0 + kq * 4 + r, B - 1);
-      sdxo[r] = (last ? dxo[row * LC + cz] : ld_tile(dxo + row * LC + cz, fenced)) * dxs;
+      sdxo[r] = (last ? dxo[row * LC + cz] : (have_next ? nx_dxo[r] : ld_tile(dxo + row * LC + cz, fenced))) * dxs;
     }
   }
 
@@ -2081,7 +2085,8 @@ __global__ __launch_bounds__(NT) void flow_pipe_bwd_kernel(FlowK f) {
     float dz2 = 0.0f, dl0 = 0.0f, dl1 = 0.0f, p0 = 0.0f, p1 = 0.0f;
     if (cl < C2) {
       if (rok) {
-        const float dz2n = (last ? dxo[(long)row * LC + Ch + cl] : ld_tile(dxo + (long)row * LC + Ch + cl, fenced)) * dxs;
+        const float dz2n = (last ? dxo[(long)row * LC + Ch + cl]
+                                 : (have_next ? nx_dz2 : ld_tile(dxo + (long)row * LC + Ch + cl, fenced))) * dxs;
         if (f.affine) {
           const float oe = q_oe, oo = q_oo;
           const float sraw = sigmoidf_(oo + 2.0f);
@@ -2238,6 +2243,9 @@ __global__ __launch_bounds__(NT) void flow_pipe_bwd_kernel(FlowK f) {
   PIPE_STAMP(1, 4);
 
   // ---- Q3: d a = dy W^T ; actnorm backward ; d x_in to flow step k - 1
+  const bool peek = !last && !fenced && n > 0;
+  unsigned pk = 0u;
+  if (peek && tid == 0) pk = ld_agent(prog + (k + 1) * nbt + bt);
   if (tc) {
     const f32x4 acc = mma16_reg<FB_C>(Dy + kq * LT + l15, wq3, nbC);
     const int c = tcol;
@@ -2263,7 +2271,19 @@ __global__ __launch_bounds__(NT) void flow_pipe_bwd_kernel(FlowK f) {
     }
   }
   PIPE_STAMP(1, 5);
-  pipe_publish(prog + k * nbt + bt, (unsigned)(f.N - n), tid, k > 0);
+  // (pipe_publish, with the outcome of the peek riding on its barrier)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (peek && tid == 0) s_rdy = pk >= (unsigned)(f.N - n) + 1u ? 1 : 0;
+  __syncthreads();
+  if (k > 0 && tid == 0) st_agent(prog + k * nbt + bt, (unsigned)(f.N - n));
+  have_next = peek && s_rdy != 0;
+  if (have_next) {
+    const float* dxn = f.bDx + (kf - B + f.F) * LC;   // cell n - 1 of flow step k + 1
+    const int cz = tcol < Ch ? tcol : 0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) nx_dxo[r] = ld_tile(dxn + (long)min(b0 + kq * 4 + r, B - 1) * LC + cz, false);
+    nx_dz2 = (cl < C2 && b0 + ri < B) ? ld_tile(dxn + (long)(b0 + ri) * LC + Ch + cl, false) : 0.0f;
+  }
   PIPE_STAMP(1, 6);
   // the z-tile waves' own d h_prev tile is only needed by the next timestep of THIS workgroup: after the hand-off, off the
   // pipeline's latency path (it reads Gh / Cy, which the next timestep rewrites only behind its first barrier)
