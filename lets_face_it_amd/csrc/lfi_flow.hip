@@ -856,7 +856,8 @@ template <int NG>
 __device__ __forceinline__ void fast_cell_p2_gates(const FlowK& f, const float* Ht, float* Hn, const f32x4 (&az)[NG],
                                                    const f32x4 (&ah)[NG], const float (&gc)[4][NG], const float (&bh)[NG],
                                                    const float (&cprev)[4], int j2, int kq, int b0, int rows, float* h_out,
-                                                   float* c_out, float* g_out, float* cnew) {
+                                                   float* c_out, float* g_out, float* cnew, __bf16* img_hi = nullptr,
+                                                   __bf16* img_lo = nullptr, int img_ld = 0, int img_col = 0) {
   const int H = f.H;
   if (j2 < H) {
 #pragma unroll
@@ -885,6 +886,7 @@ __device__ __forceinline__ void fast_cell_p2_gates(const FlowK& f, const float* 
         gs0 = ii; gs1 = ff; gs2 = gg; gs3 = oo;
       }
       Hn[j2 * LT + i] = hnew;
+      if (img_hi) x3_put(img_hi, img_lo, i * img_ld + img_col + x3_pos(j2), hnew);   // bf16 hi / lo image for the next cell's product
       if (row < rows) {
         h_out[(long)row * H + j2] = hnew;
         if (g_out) {
@@ -939,6 +941,45 @@ __device__ __forceinline__ void fast_cell_p2(const FlowK& f, const float* Zt, co
       for (int g = 0; g < NG; ++g) ah[g] = mfma16(a3, wh[g][b][3], ah[g]);
     }
   fast_cell_p2_gates<NG>(f, Ht, Hn, az, ah, gc, bh, cprev, j2, kq, b0, rows, h_out, c_out, g_out, cnew);
+}
+
+// The same cell with its A operand (z1 | h_{t-1}) read from bf16 hi / lo LDS images the PRODUCERS wrote (P1 for z1, the previous
+// timestep's gate epilogue for h: x3_put, slot order x3_pos): one 16-byte read per 32-k block and plane instead of eight
+// 4-byte reads of the k-major fp32 images plus a split redone by all eight waves (stamps: 2.8 k of the 5.8 k cycles of P2).
+template <int NG>
+__device__ __forceinline__ void fast_cell_p2_x3_img(const FlowK& f, const __bf16* ih, const __bf16* il, int ldx, int Ch16,
+                                                    const float* Ht, float* Hn, const X3Frag (&wz)[NG][FB_Z / 2],
+                                                    const X3Frag (&wh)[NG][FB_H / 2], const float (&gc)[4][NG],
+                                                    const float (&bh)[NG], const float (&cprev)[4], int nbZ2, int nbH2, int j2,
+                                                    int kq, int l15, int b0, int rows, float* h_out, float* c_out, float* g_out,
+                                                    float* cnew, __bf16* ihn, __bf16* iln) {
+  f32x4 az[NG], ah[NG];
+#pragma unroll
+  for (int g = 0; g < NG; ++g) {
+    az[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    ah[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+  const __bf16* rh = ih + l15 * ldx + 8 * kq;
+  const __bf16* rl = il + l15 * ldx + 8 * kq;
+#pragma unroll
+  for (int b = 0; b < FB_Z / 2; ++b)
+    if (b < nbZ2) {
+      X3Frag a;
+      a.hi = *reinterpret_cast<const fbf16x8*>(rh + b * 32);
+      a.lo = *reinterpret_cast<const fbf16x8*>(rl + b * 32);
+#pragma unroll
+      for (int g = 0; g < NG; ++g) az[g] = x3_mma(a, wz[g][b], az[g]);
+    }
+#pragma unroll
+  for (int b = 0; b < FB_H / 2; ++b)
+    if (b < nbH2) {
+      X3Frag a;
+      a.hi = *reinterpret_cast<const fbf16x8*>(rh + Ch16 + b * 32);
+      a.lo = *reinterpret_cast<const fbf16x8*>(rl + Ch16 + b * 32);
+#pragma unroll
+      for (int g = 0; g < NG; ++g) ah[g] = x3_mma(a, wh[g][b], ah[g]);
+    }
+  fast_cell_p2_gates<NG>(f, Ht, Hn, az, ah, gc, bh, cprev, j2, kq, b0, rows, h_out, c_out, g_out, cnew, ihn, iln, ldx, Ch16);
 }
 
 // bf16 x 3 form: weights as packed 32-k fragments (x3_pack), nbZ2 / nbH2 = number of 32-k blocks
@@ -1214,9 +1255,14 @@ __device__ __forceinline__ f32x4 mma16_lds(const float* a_lane, const f32x4* wl,
 }
 // LDS floats of the pipeline kernel: the cell's operands, then the W fragments of the C16/16 P1 waves and the Wfl fragments
 // of the Co16/16 P3 waves (the recurrent weights W_ih[:, :Ch] and W_hh stay in registers: 120 VGPRs at H = 128)
-__host__ __device__ inline int pipe_fwd_lds_floats(int C, int C16, int H16, int Ch16, int Cout, int Co16) {
+__host__ __device__ inline int pipe_fwd_img_offset(int C, int C16, int H16, int Ch16, int Cout, int Co16) {
   const int base = (carve_fast_fwd(C, C16, H16, Ch16, Cout).total + 3) & ~3;
   return base + (C16 >> 4) * (C16 >> 4) * 256 + (Co16 >> 4) * (H16 >> 4) * 256;
+}
+// + the bf16 x 3 cell's operand images: two buffers (h of the previous / of this timestep) x {hi, lo} x MB rows of
+// Ch16 + H16 + 8 bf16 (2 MB ldx floats)
+__host__ __device__ inline int pipe_fwd_lds_floats(int C, int C16, int H16, int Ch16, int Cout, int Co16) {
+  return pipe_fwd_img_offset(C, C16, H16, Ch16, Cout, Co16) + 2 * MB * (Ch16 + H16 + 8);
 }
 
 // diagnostics (lfi_debug_set_stamps): s_memtime of workgroup (Ks / 2, tile 0) at the phase boundaries of every timestep, in
@@ -1296,6 +1342,13 @@ __global__ __launch_bounds__(NT) void flow_pipe_fwd_kernel(FlowK f) {
     const f32x4* p = reinterpret_cast<const f32x4*>(f.pwfl + (long)k * H16 * Co16) + (long)kq_0 * Co16 + tcol_0;
     for (int b = 0; b < nbH; ++b) w3s[b * 64] = p[(long)b * 4 * Co16];
   }
+  // bf16 x 3: operand images of the recurrent cell (fast_cell_p2_x3_img)
+  const int ldxi = Ch16 + H16 + 8;
+  __bf16* imgb = reinterpret_cast<__bf16*>(flow_smem + pipe_fwd_img_offset(C, C16, H16, Ch16, Cout, Co16));
+  __bf16* ich = imgb;                       // current buffer: z1 of this timestep | h of the previous one (hi; lo at + MB * ldxi)
+  __bf16* inh = imgb + 2 * MB * ldxi;       // next buffer: receives h of this timestep
+  if (X3)
+    for (int q = tid; q < 4 * MB * ldxi; q += NT) imgb[q] = (__bf16)0.0f;
   const int j2 = tcol_0;
   const int jc = j2 < H ? j2 : 0;
   float bh[NG], cprev[4] = {0.f, 0.f, 0.f, 0.f};
@@ -1386,7 +1439,10 @@ __global__ __launch_bounds__(NT) void flow_pipe_fwd_kernel(FlowK f) {
           const int rw = b0 + i;
           const float v = acc[r];
           Yrm[i * ldy + c] = v;
-          if (c < Ch) Zt[c * LT + i] = v;
+          if (c < Ch) {
+            Zt[c * LT + i] = v;
+            if (X3) x3_put(ich, ich + MB * ldxi, i * ldxi + x3_pos(c), v);
+          }
           if (rw < B) f.sY[(kf + rw) * LC + c] = v;
         }
       }
@@ -1398,8 +1454,9 @@ __global__ __launch_bounds__(NT) void flow_pipe_fwd_kernel(FlowK f) {
     if (t2) {
       float cnew[4] = {0.f, 0.f, 0.f, 0.f};
       if constexpr (X3)
-        fast_cell_p2_x3<NG>(f, Zt, Ht, Hn, wzx, whx, gc, bh, cprev, (nbZ + 1) >> 1, (nbH + 1) >> 1, tcol, kq, l15, b0, B,
-                            f.sH + kf * H, NG == 4 ? f.sC + kf * H : nullptr, f.sG + kf * 4 * H, cnew);
+        fast_cell_p2_x3_img<NG>(f, ich, ich + MB * ldxi, ldxi, Ch16, Ht, Hn, wzx, whx, gc, bh, cprev, (nbZ + 1) >> 1, (nbH + 1) >> 1,
+                                tcol, kq, l15, b0, B, f.sH + kf * H, NG == 4 ? f.sC + kf * H : nullptr, f.sG + kf * 4 * H, cnew,
+                                inh, inh + MB * ldxi);
       else
         fast_cell_p2<NG>(f, Zt, Ht, Hn, wz, wh, gc, bh, cprev, nbZ, nbH, tcol, kq, l15, b0, B, f.sH + kf * H,
                          NG == 4 ? f.sC + kf * H : nullptr, f.sG + kf * 4 * H, cnew);
@@ -1468,6 +1525,7 @@ __global__ __launch_bounds__(NT) void flow_pipe_fwd_kernel(FlowK f) {
     }
     PIPE_STAMP(0, 7);
     float* t = Ht; Ht = Hn; Hn = t;
+    __bf16* ti = ich; ich = inh; inh = ti;
   }
 }
 
