@@ -35,7 +35,8 @@ class LetsFaceItGlow(nn.Module):
         self.global_step = 0
         self.nll_sync_hook = None  # data-parallel trainer: averages the mismatched NLL over ranks
         self._mm_host = None
-        self.register_load_state_dict_post_hook(lambda module, incompatible: setattr(module, "_mm_host", None))
+        self._mm_pending = None  # (pinned host scalar, event): the value of the last negative step on its way to the host
+        self.register_load_state_dict_post_hook(lambda module, incompatible: module.__dict__.update(_mm_host=None, _mm_pending=None))
 
     # Lightning's self.log, reduced to a dict of the latest values
     def log(self, name, value, **kwargs):
@@ -45,7 +46,15 @@ class LetsFaceItGlow(nn.Module):
         """Host copy of the `last_missmatched_nll` buffer: reading the device tensor every step (`buffer > 0`) is a device
         synchronisation per step, which stops the host from queueing the next step's launches under the current one."""
         if self._mm_host is None:
-            self._mm_host = float(self.last_missmatched_nll)
+            if self._mm_pending is not None:
+                # the value left the device on a side stream right after the negative step's forward pass: wait for THAT copy only
+                # (float(buffer) would wait for everything queued behind it - backward, optimiser - and leave the GPU idle
+                # while the next step is issued)
+                pinned, ev = self._mm_pending
+                ev.synchronize()
+                self._mm_host, self._mm_pending = float(pinned), None
+            else:
+                self._mm_host = float(self.last_missmatched_nll)
         return self._mm_host
 
     def _negative_branch(self):
@@ -70,7 +79,20 @@ class LetsFaceItGlow(nn.Module):
         if self.nll_sync_hook is not None:
             value = self.nll_sync_hook(value)
         self.last_missmatched_nll.copy_(value)
-        self._mm_host = None  # re-read (one synchronisation, on negative steps only)
+        self._mm_host = None  # re-read (one wait, after negative steps only)
+        self._mm_pending = None
+        if value.is_cuda:
+            main = torch.cuda.current_stream(value.device)
+            side = getattr(self, "_mm_stream", None)
+            if side is None or side.device != value.device:
+                side = self._mm_stream = torch.cuda.Stream(device=value.device)
+            pinned = torch.empty((), dtype=value.dtype).pin_memory()
+            side.wait_stream(main)                    # the value is complete; nothing enqueued on `main` after this is waited for
+            with torch.cuda.stream(side):
+                pinned.copy_(self.last_missmatched_nll, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(side)
+            self._mm_pending = (pinned, ev)
 
     def fused_training_step(self, batch, lr, world_size=1, allreduce=None):
         """One optimiser step entirely in the engine. Returns the (detached) loss of this rank.
