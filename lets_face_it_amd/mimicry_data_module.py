@@ -115,7 +115,9 @@ class MimicryDataset:
             raise IndexError("empty batch")
         if int(idx.min()) < 0 or int(idx.max()) >= len(self):
             raise IndexError("window index out of range (0 .. %d)" % (len(self) - 1))
-        starts = self.starts[idx.to(self.device)].contiguous()
+        # (through pinned memory: a pageable host-to-device copy synchronises the host with the stream, which drains the
+        # training step queued behind it and leaves the GPU idle while the next one is issued - once per batch)
+        starts = self.starts[idx.pin_memory().to(self.device, non_blocking=True)].contiguous()
         B, T = starts.numel(), self.seq_len
         st = torch.cuda.current_stream().cuda_stream
         out = {}
