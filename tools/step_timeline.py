@@ -1,4 +1,5 @@
-"""Kernel timeline of the last training step in a rocprofv3 run_results.db (`rocprofv3 --kernel-trace -d DIR -- python3 bench.py …`):
+"""Kernel timeline of one steady-state training step (the shortest of the timed steps: bench.py's last three are issued on an
+empty queue to measure the host, and one step in ten is a negative step with its own preamble) in a rocprofv3 run_results.db (`rocprofv3 --kernel-trace -d DIR -- python3 bench.py …`):
 start offset, duration and the idle gap before every dispatch, then totals per kernel name. Usage: python tools/step_timeline.py DB"""
 import re
 import sqlite3
@@ -8,7 +9,9 @@ from collections import defaultdict
 db = sqlite3.connect(sys.argv[1])
 rows = list(db.execute("select name,start,end,grid_x,workgroup_x,stream_id from kernels order by start"))
 idx = [i for i, r in enumerate(rows) if "adam_clip" in r[0]]
-a, b = idx[-2] + 1, idx[-1] + 1
+cand = list(range(1, len(idx) - 3)) or [len(idx) - 1]
+best = min(cand, key=lambda i: rows[idx[i]][2] - rows[idx[i - 1]][2])
+a, b = idx[best - 1] + 1, idx[best] + 1
 t0 = rows[a][1]
 last_end, gaps, busy = None, 0.0, 0.0
 tot = defaultdict(lambda: [0, 0.0])
