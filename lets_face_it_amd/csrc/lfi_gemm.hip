@@ -1693,6 +1693,110 @@ __global__ __launch_bounds__(512, 4) void gemm_planes_128_kernel(GemmArgs g) {
   else gemm_epilogue_n<256>(g, acc, m0, n0, wm, wn, l31, half, batch, split);
 }
 
+// The same 128 x 256 tile with FOUR waves of 128 x 64 patches (all four row tiles x one 64-column group each). The eight-wave
+// kernel above reads 8 KB of fragments per wave and k-tile for 12 MFMAs: 16 waves per CU x 8 ds_read_b128 x 8 cycles = 1024
+// LDS cycles per k-tile, plus 384 for the 48 KB the LDS-DMA writes, against 1536 cycles of MFMA issue per SIMD - the LDS port
+// is 92 % busy, which is what holds the matrix pipe at ~59 % of its issue rate (next to the clock). A 128 x 64 patch reads
+// 12 KB for 24 MFMAs: 768 + 384 = 1152 LDS cycles per k-tile and CU for the same 1536 of MFMA issue. Two workgroups per CU =
+// two waves per SIMD (<= 256 VGPRs: 128 of accumulators); six DMA pieces per wave and k-tile; same ring, same phase
+// structure, same order of products per accumulator (bit-identical results), the wide epilogue with MT = 4.
+__global__ __launch_bounds__(256, 2) void gemm_planes_128w4_kernel(GemmArgs g) {
+  constexpr int XT = 2;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, half = lane >> 5;
+  int tm, tn, batch, split;
+  gemm_tile_of_block(g, &tm, &tn, &batch, &split);
+  const int m0 = tm * 128, n0 = tn * 256;
+  const int nkt = g.nkt;
+  char* lds = reinterpret_cast<char*>(xsmem);
+  const char* baseA = reinterpret_cast<const char*>(g.Ap + batch * g.pstrideA) + (long)(tm * 4) * g.nktA * 2048 + lane * 16;
+  const char* baseB = reinterpret_cast<const char*>(g.Bp + batch * g.pstrideB) + (long)(tn * 8) * g.nktB * 2048 + lane * 16;
+  const char* src[6];
+  int doff[6];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    const int j = wave * 6 + i;                       // block 0 .. 23 of the slot
+    const int isB = j >= 8, jj = isB ? j - 8 : j;     // (row tile, plane) = (jj >> 1, jj & 1)
+    src[i] = (isB ? baseB + (long)(jj >> 1) * g.nktB * 2048 : baseA + (long)(jj >> 1) * g.nktA * 2048) + (jj & 1) * 1024;
+    doff[i] = j * 1024;
+  }
+  auto dma = [&](int kt, int slot) {
+    const long ko = (long)min(kt, nkt - 1) * 2048;
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+      __builtin_amdgcn_global_load_lds((pglb_void*)(src[i] + ko), (plds_void*)(lds + slot * QSLOT + doff[i]), 16, 0, 0);
+  };
+  const int wm = 0, wn = wave;
+  const int fa = lane * 16;                               // A fragment (mt, plane) at fa + (mt * 2 + plane) * 1024
+  const int fb = 8 * 1024 + (wn * 4) * 1024 + lane * 16;  // B fragment (nt, plane) at fb + (nt * 2 + plane) * 1024
+  auto frag = [&](int slot, int off) { return *reinterpret_cast<const bf16x8*>(lds + slot * QSLOT + off); };
+
+  f32x16 acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+  bf16x8 ah[4], al[4], bh[2], bl[2];
+  dma(0, 0); dma(1, 1); dma(2, 2);
+  asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) { ah[mt] = frag(0, fa + (mt * 2) * 1024); al[mt] = frag(0, fa + (mt * 2 + 1) * 1024); }
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt) { bh[nt] = frag(0, fb + (nt * 2) * 1024); bl[nt] = frag(0, fb + (nt * 2 + 1) * 1024); }
+  asm volatile("s_waitcnt vmcnt(6)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+
+  int cur = 0;
+  for (int t = 0; t < nkt; ++t) {
+    const int nxt = cur == 2 ? 0 : cur + 1;
+    bf16x8 nbh[2], nbl[2];
+    dma(t + 3, cur);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+      if (!LFI_GSKIP(1)) {
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = PG_MFMA(al[mt], bh[nt], acc[mt][nt]);
+      }
+      if (!LFI_GSKIP(2)) {
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = PG_MFMA(ah[mt], bl[nt], acc[mt][nt]);
+      }
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = PG_MFMA(ah[mt], bh[nt], acc[mt][nt]);
+      __builtin_amdgcn_sched_barrier(0);
+      // row tile mt of the next k-tile into the registers just released; the B fragments into a second set along the way
+      ah[mt] = frag(nxt, fa + (mt * 2) * 1024); al[mt] = frag(nxt, fa + (mt * 2 + 1) * 1024);
+      if (mt == 1) { nbh[0] = frag(nxt, fb); nbl[0] = frag(nxt, fb + 1024); }
+      if (mt == 2) { nbh[1] = frag(nxt, fb + 2048); nbl[1] = frag(nxt, fb + 3072); }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    asm volatile("s_waitcnt vmcnt(6)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { bh[i] = nbh[i]; bl[i] = nbl[i]; }
+    cur = nxt;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the re-fetched tail tiles: landed before the epilogue reuses the ring
+  __syncthreads();
+  if (g.vecC) gemm_epilogue_wide<256, 256, 4>(g, acc, reinterpret_cast<float*>(xsmem), 64, m0, n0, wm, wn, l31, half, batch, split, 128);
+  else {
+    // (the narrow epilogue takes 2 x 2 patches: two calls, rows 0 .. 63 and 64 .. 127)
+    f32x16 lo2[2][2], hi2[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) { lo2[i][j] = acc[i][j]; hi2[i][j] = acc[2 + i][j]; }
+    gemm_epilogue_n<256>(g, lo2, m0, n0, 0, wn, l31, half, batch, split);
+    gemm_epilogue_n<256>(g, hi2, m0, n0, 1, wn, l31, half, batch, split);
+  }
+}
+
 // fp32 (rows x cols, row pitch ldx) -> bf16 hi / lo planes in fragment order, zero padded to rows_pad x 16 nkt:
 // block ((rt * nkt + kt) * 2 + plane), lane l of a block holds row rt * 32 + (l & 31), k = kt * 16 + 8 (l >> 5) .. + 7.
 // One thread per (block pair, lane): 8 floats in (two 16-byte loads when the row allows), 16 + 16 bytes out.
@@ -2180,7 +2284,20 @@ extern "C" int lfi_gemm_planes(const lfi_pgemm_desc* d, void* stream) {
       attr = true;
     }
     dim3 grid(a.tiles_m * a.tiles_n, d->batch, 1);
-    hipLaunchKernelGGL(gemm_planes_128_kernel, grid, dim3(512), lds, (hipStream_t)stream, a);
+    const char* w4e = getenv("LFI_PGEMM_W4");
+    if (w4e && w4e[0] == '1') {   // four waves of 128 x 64 patches (fewer LDS fragment reads per MFMA)
+      static bool attr4 = false;
+      if (!attr4) {
+        if (hipFuncSetAttribute((const void*)gemm_planes_128w4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+          lfi_set_error("lfi_gemm_planes: cannot reserve %zu bytes of LDS", lds);
+          return LFI_ERR_LAUNCH;
+        }
+        attr4 = true;
+      }
+      hipLaunchKernelGGL(gemm_planes_128w4_kernel, grid, dim3(256), lds, (hipStream_t)stream, a);
+    } else {
+      hipLaunchKernelGGL(gemm_planes_128_kernel, grid, dim3(512), lds, (hipStream_t)stream, a);
+    }
   }
   LFI_LAUNCH_CHECK("lfi_gemm_planes");
   return LFI_OK;

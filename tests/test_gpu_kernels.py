@@ -200,12 +200,15 @@ def test_gemm_bf16x3_256_tile(eng, gpu_device, akc, bkc, shape, splitk, pin):
 
 
 @pytest.mark.parametrize("shape", [(700, 520, 330), (256, 256, 16), (513, 257, 75), (300, 260, 128), (1024, 768, 896), (40, 33, 7)])
-@pytest.mark.parametrize("epi", ["bias_leaky", "plain", "accumulate"])
-def test_gemm_on_presplit_planes(eng, gpu_device, shape, epi):
+@pytest.mark.parametrize("epi", ["bias_leaky", "plain", "accumulate", "plain_w4"])
+def test_gemm_on_presplit_planes(eng, gpu_device, shape, epi, monkeypatch):
     """lfi_planes_from_f32 + lfi_gemm_planes (operands split to bf16 hi / lo ONCE, in MFMA fragment order, streamed to LDS by
     LDS-DMA through a four-slot ring) against the fp64 product and, bit for bit, against lfi_gemm_f32's 256 x 256 bf16x3
     kernel (same split, same products, same accumulation order): ragged M / N / K, fewer k-tiles than ring slots, many tiles."""
     M, N, K = shape
+    if epi.endswith("_w4"):   # the opt-in four-wave variant (128 x 64 patches per wave): same products, same order, same bits
+        monkeypatch.setenv("LFI_PGEMM_W4", "1")
+        epi = epi[:-3]
     g = torch.Generator().manual_seed(M + 3 * N + 7 * K)
     r4 = lambda v: (v + 3) // 4 * 4  # noqa: E731
     lda, ldb, ldc = r4(K) + 4, r4(K), r4(N) + 4
