@@ -222,6 +222,7 @@ class GlowEngine:
         # 1e-5 ... 4e-5 of the 1e-4 NLL gate EACH, the backward classes leave the NLL alone but put single gradient tensors at
         # 1.3e-3 ... 3.3e-3 relative L2 (gate 2e-3; the encoders' dW_hh, the mildest, still 1.9e-3 on its smallest tensor) -
         # so the default is empty: three products everywhere. LFI_PASS_SKIP="cls=bits,..." sets entries for timing runs.
+        self.tile_pin = {k.strip(): int(v) for k, v in (it.split("=") for it in os.environ.get("LFI_TILE_PIN", "").split(",") if it)}
         self.pass_skip = {}
         env = os.environ.get("LFI_PASS_SKIP", "")
         if env.strip() == "none":
@@ -359,6 +360,8 @@ class GlowEngine:
         g.accumulate, g.act, g.slope = accumulate, act, slope
         g.splitk = splitk
         g.precision = self.precision | ((self.pass_skip.get(cls, 0) & 3) << 8 if (self.precision & 1) else 0)
+        if self.tile_pin and (self.precision & 1):   # LFI_TILE_PIN="cls=128|256,...": pin a GEMM class's tile shape (measurement)
+            g.precision |= {128: 0x20, 256: 0x10}.get(self.tile_pin.get(cls), 0)
         if splitk > 1 or splitk == 0:  # 0: the library picks the split (and the tile shape) that fills the chip
             g.work = self._buf(ws, batch * max(splitk, 8) * M * N).data_ptr()
         part, prow = None, 0
