@@ -48,9 +48,10 @@ def _oracle_state(hp):
     return {k: v.detach().clone() for k, v in m.state_dict().items()}
 
 
-def _oracle_train_steps(hp, sd, batch, budget_s, min_steps, max_steps, sync=None):
+def _oracle_train_steps(hp, sd, batch, budget_s, min_steps, max_steps, sync=None, reference_ops=False):
     """1 warm-up + up to max_steps timed forward+backward passes of the oracle (at least min_steps; stops early once the
-    budget is spent). -> (median seconds, number of timed steps)"""
+    budget is spent). reference_ops: the cells as the fused ops nn.GRU / nn.GRUCell dispatch to (oracle.reference_op_set) instead
+    of their spelled-out equations. -> (median seconds, number of timed steps)"""
     from oracle import seqglow_oracle as oracle
     for k, v in sd.items():
         if v.dtype.is_floating_point and not k.endswith((".p", ".sign_s")):
@@ -59,8 +60,9 @@ def _oracle_train_steps(hp, sd, batch, budget_s, min_steps, max_steps, sync=None
     def step():
         for v in sd.values():
             v.grad = None
-        loss = oracle.seqglow_forward(hp, sd, batch)[1]
-        loss.sum().backward()
+        with oracle.reference_op_set(reference_ops):
+            loss = oracle.seqglow_forward(hp, sd, batch)[1]
+            loss.sum().backward()
         if sync is not None:
             sync()
 
@@ -77,9 +79,10 @@ def _oracle_train_steps(hp, sd, batch, budget_s, min_steps, max_steps, sync=None
     return times[len(times) // 2], len(times)
 
 
-def cpu_baseline(hp, C, S, T, B, budget_s):
-    """The oracle (kind "port") on the host cores: forward + backward of the reference's op sequence at the metric's own
-    batch (256): ~15-25 s per step, so 1 warm-up + 3 timed steps by default (--cpu-baseline-seconds bounds it)."""
+def cpu_baseline(hp, C, S, T, B, budget_s, note=""):
+    """The oracle (kind "port") on the host cores: forward + backward of the reference's op sequence (per-timestep loop, the
+    cells through the fused ops nn.GRU / nn.GRUCell dispatch to) at the metric's own batch (256): ~7-25 s per step, so 1 warm-up
+    + 3 timed steps by default (--cpu-baseline-seconds bounds it)."""
     from oracle import seqglow_oracle as oracle
     # the per-timestep loop is made of small ops: on a many-core host the default (all cores) is far slower than a
     # modest team, so use at most 16 threads and report that count
@@ -88,11 +91,11 @@ def cpu_baseline(hp, C, S, T, B, budget_s):
     sd = _oracle_state(hp)
     batch = oracle.synthetic_batch(B, T, C, S, seed=1234)
     frames = B * (T - oracle.longest_history(hp["Conditioning"]))
-    med, n = _oracle_train_steps(hp, sd, batch, budget_s, 2, 3)
+    med, n = _oracle_train_steps(hp, sd, batch, budget_s, 2, 3, reference_ops=True)
     return {"value": frames / med, "unit": "frames/s", "cores": threads, "kind": "port",
-            "sample": "oracle/seqglow_oracle.py fwd+bwd (torch CPU fp32, per-timestep loop as the reference), "
-                      "final_model C=%d S=%d T=%d at batch %d%s, median of %d steps after 1 warm-up, "
-                      "%.1f s per step" % (C, S, T, B, " (the metric's batch)" if B == 256 else "", n, med)}
+            "sample": "oracle/seqglow_oracle.py fwd+bwd (torch CPU fp32, per-timestep loop and fused GRU ops as the reference), "
+                      "%d flow steps, C=%d S=%d T=%d at batch %d%s, median of %d steps after 1 warm-up, "
+                      "%.1f s per step" % (oracle.n_flow_steps(hp), C, S, T, B, note or (" (the metric's batch)" if B == 256 else ""), n, med)}
 
 
 def torch_gpu_baseline(hp, C, S, T, B, device, budget_s):
@@ -104,11 +107,19 @@ def torch_gpu_baseline(hp, C, S, T, B, device, budget_s):
     sd = {k: v.to(device) for k, v in _oracle_state(hp).items()}
     batch = {k: v.to(device) for k, v in oracle.synthetic_batch(B, T, C, S, seed=1234).items()}
     frames = B * (T - oracle.longest_history(hp["Conditioning"]))
-    med, n = _oracle_train_steps(hp, sd, batch, budget_s, 3, 5, sync=torch.cuda.synchronize)
+    # the reference's own op set: nn.GRU -> torch._VF.gru (MIOpen RNN), nn.GRUCell -> torch._VF.gru_cell (two addmm
+    # + one fused pointwise kernel); models.py:21-27,60-64,176-179,206-208. This is north_star's denominator.
+    med, n = _oracle_train_steps(hp, sd, batch, budget_s / 2, 3, 5, sync=torch.cuda.synchronize, reference_ops=True)
+    # for the record, the same loop with every cell spelled out as ~10 ATen ops (round 2's figure)
+    med2, n2 = _oracle_train_steps(hp, sd, batch, budget_s / 2, 2, 3, sync=torch.cuda.synchronize, reference_ops=False)
     return {"value": frames / med, "unit": "frames/s", "kind": "port",
-            "sample": "oracle/seqglow_oracle.py fwd+bwd on cuda:0 through stock PyTorch-ROCm %s (eager, fp32), final_model "
-                      "C=%d S=%d T=%d at batch %d, median of %d steps after 1 warm-up, %.2f s per step"
-                      % (torch.__version__, C, S, T, B, n, med)}
+            "sample": "oracle/seqglow_oracle.py fwd+bwd on cuda:0 through stock PyTorch-ROCm %s (eager, fp32; per-timestep loop, "
+                      "window encoders as ONE torch._VF.gru call each and coupling cells as torch._VF.gru_cell - the ops the "
+                      "reference's nn.GRU / nn.GRUCell dispatch to), final_model C=%d S=%d T=%d at batch %d, median of %d steps "
+                      "after 1 warm-up, %.2f s per step" % (torch.__version__, C, S, T, B, n, med),
+            "spelled_out_cells": {"value": frames / med2, "unit": "frames/s",
+                                  "sample": "the same loop with every GRU cell as its ~10 separate ATen ops (round 2's "
+                                            "denominator), median of %d steps, %.2f s per step" % (n2, med2)}}
 
 
 def cpu_baseline_sample(hp, C, S, B, nframes, budget_s):
@@ -256,9 +267,20 @@ def _roofline_hbm(spec, B, T, timing, precision):
             "algorithmic_bytes_per_launch": alg, "ms_per_launch": ms, "launches_timed": n_launch}
 
 
+def _time_steps_at_batch(model, trainer, spec, B, T, device, warmup, steps):
+    """Mean milliseconds of one fused training step at another batch size (single rank, engine workspaces regrown)."""
+    batches = [synthetic_batch(B, T, spec.C, spec.S, 4321 + i, device) for i in range(2)]
+    lr = trainer.lr_at(0)
+    for i in range(warmup):
+        model.fused_training_step(batches[i & 1], lr, 1, None)
+    elapsed, _ = _timed(lambda i: model.fused_training_step(batches[i & 1], lr, 1, None), steps, 1, device)
+    return 1e3 * elapsed / steps
+
+
 def bench_train(args, model, trainer, spec, device, world, rank, hp):
     C, S, T, B = spec.C, spec.S, args.seq_len, args.batch
     N = T - spec.start
+    deep = args.workload == "deep"
     batches = [synthetic_batch(B, T, C, S, 1234 + 1000 * rank + i, device) for i in range(2)]
     lr = trainer.lr_at(0)
     allreduce = trainer.allreduce_grads if world > 1 else None
@@ -278,31 +300,80 @@ def bench_train(args, model, trainer, spec, device, world, rank, hp):
         return None
     frames = world * B * N * args.steps
     F = B * N
+    if deep:
+        metric = "FLAME frames/s, full training step (fwd+bwd+clip+Adam), deep flow K=32 x L=3 (96 flow steps), batch %d per GPU" % B
+        workload = ("deep-flow training step: final_model.yaml widths with Glow K=32, L=3 (96 flow steps), synthetic 50-d FLAME + "
+                    "27-d speech, T=%d (%d timesteps), batch %d per GPU (BASELINE.json configs[4]%s)"
+                    % (T, N, B, "" if world == 1 else ", data-parallel"))
+    else:
+        metric = "FLAME frames/s, full training step (fwd+bwd+clip+Adam), final_model.yaml batch 256 per GPU"
+        workload = ("final_model.yaml training step, synthetic 50-d FLAME + 27-d speech, T=%d, batch %d per GPU "
+                    "(BASELINE.json configs[1]%s)" % (T, B, "" if world == 1 else ", data-parallel"))
     out = {
-        "metric": "FLAME frames/s, full training step (fwd+bwd+clip+Adam), final_model.yaml batch 256 per GPU",
+        "metric": metric,
         "value": frames / elapsed, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "host_issue_ms_per_step": host_issue,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32" if args.precision == "f32" else "f32 (GEMM operands split into bf16 hi+lo, f32 accumulate)",
+        "dtype": _dtype_label(args.precision, eng),
         "data": "synthetic",
-        "config": {"workload": "final_model.yaml training step, synthetic 50-d FLAME + 27-d speech, T=%d, "
-                               "batch %d per GPU (BASELINE.json configs[1]%s)" % (T, B, "" if world == 1 else ", data-parallel"),
+        "config": {"workload": workload,
                    "K": spec.Ks, "H": spec.H, "cond_dim": spec.D, "feature_dim": spec.E, "frames_per_step_per_gpu": F,
-                   "parallelism": "dp%d" % world, "params": eng.n_params, "gemm_precision": args.precision},
+                   "parallelism": "dp%d" % world, "params": eng.n_params, "gemm_precision": args.precision,
+                   "gemm_products": _products_label(args.precision, eng)},
         "final_loss": float(loss),
         "roofline": _roofline(spec, F, timing, args.precision),
         "roofline_hbm": _roofline_hbm(spec, B, T, timing, args.precision),
         "kernel_timing": {t: {"launches": n, "ms": round(m_, 4)} for t, (n, m_) in timing.items()},
     }
-    if world == 1 and args.torch_gpu_baseline_seconds > 0:
+    if world == 1 and not deep and B == 256 and args.strong_anchor_batch > 0:
+        # north_star asks for STRONG scaling at 8 GPUs (configs[2]: global batch 2048 = 8 x 256). The driver's N-GPU runs keep
+        # 256 per GPU ("scaling": "weak"); this is the missing denominator: ONE GPU stepping the global batch of the 8-GPU run,
+        # so that strong-scaling speed-up at N = 8 is strong_scaling_anchor.ms_per_step / that run's ms_per_step
+        gb = args.strong_anchor_batch
+        ms = _time_steps_at_batch(model, trainer, spec, gb, T, device, 2, 5)
+        out["strong_scaling_anchor"] = {"batch": gb, "ms_per_step": ms, "frames_per_s": gb * N / (ms * 1e-3), "n_gpus": 1,
+                                        "note": "one GPU at the global batch of BASELINE.json configs[2] (8 x 256), mean of 5 steps "
+                                                "after 2 warm-ups; strong speed-up at N GPUs = this / the N-GPU run's ms_per_step "
+                                                "at batch %d per GPU" % (gb // 8)}
+        import gc
+        eng._ws.clear()     # the 2048-batch workspaces (~80 GB) go back to the allocator before the torch baseline runs
+        eng._last = None
+        gc.collect()
+        torch.cuda.empty_cache()
+    if world == 1 and args.torch_gpu_baseline_seconds > 0 and not deep:
         # the >= 10x denominator of BASELINE.json's north_star. BASELINE.md holds no PUBLISHED number for this metric, so
         # `vs_baseline` stays null (bench contract); the measured ratio is reported under its own name
         tg = torch_gpu_baseline(hp, C, S, T, B, device, args.torch_gpu_baseline_seconds)
         out["torch_gpu_baseline"] = tg
         out["vs_torch_gpu_baseline"] = out["value"] / tg["value"]
+        out["vs_torch_gpu_baseline_spelled_out_cells"] = out["value"] / tg["spelled_out_cells"]["value"]
     if world == 1 and args.cpu_baseline_seconds > 0:
-        out["cpu_baseline"] = cpu_baseline(hp, C, S, T, B, args.cpu_baseline_seconds)
+        if deep:
+            # bounded sample of the same workload: the full batch, the first 8 of the 488 timesteps (every timestep costs the
+            # same: 96 flow steps + three window encoders), ~5 s per forward + backward on the host
+            Ts = spec.start + 8
+            out["cpu_baseline"] = cpu_baseline(hp, C, S, Ts, B, min(args.cpu_baseline_seconds, 40.0),
+                                               note=" (bounded sample: the full batch, the first 8 of %d timesteps)" % N)
+        else:
+            out["cpu_baseline"] = cpu_baseline(hp, C, S, T, B, args.cpu_baseline_seconds)
     return out
+
+
+def _products_label(precision, eng):
+    if precision != "bf16x3":
+        return "exact fp32 (f32-input MFMA)"
+    if not eng.pass_skip:
+        return "3 per GEMM class (a_hi b_hi + a_hi b_lo + a_lo b_hi)"
+    return "3, except " + ", ".join("%s: %d" % (c, 3 - bin(b & 3).count("1")) for c, b in sorted(eng.pass_skip.items()))
+
+
+def _dtype_label(precision, eng):
+    if precision == "f32":
+        return "f32"
+    base = "f32 (GEMM operands split into bf16 hi+lo, f32 accumulate"
+    if not eng.pass_skip:
+        return base + ", three products)"
+    return base + "; products per class: " + _products_label(precision, eng) + ")"
 
 
 def bench_sample(args, model, spec, device, world, rank, hp):
@@ -349,7 +420,7 @@ def bench_sample(args, model, spec, device, world, rank, hp):
         "value": frames / elapsed, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "host_issue_ms_per_step": host_issue,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32" if args.precision == "f32" else "f32 (GEMM operands split into bf16 hi+lo, f32 accumulate)",
+        "dtype": _dtype_label(args.precision, eng),
         "data": "synthetic",
         "config": {"workload": "autoregressive sampling, batch %d, seq_len %d (%d generated frames per sequence), "
                                "BASELINE.json configs[3]" % (B, T, nframes), "K": spec.Ks, "H": spec.H,
@@ -386,9 +457,13 @@ def main():
                          "0 disables it")
     ap.add_argument("--precision", choices=("f32", "bf16x3"), default=os.environ.get("LFI_PRECISION", "bf16x3"),
                     help="GEMM arithmetic: exact f32 MFMA, or bf16 hi/lo split operands (3 bf16 MFMAs per product)")
-    ap.add_argument("--workload", choices=("train", "sample"), default="train",
+    ap.add_argument("--workload", choices=("train", "sample", "deep"), default="train",
                     help="train: BASELINE.json configs[1] (the headline metric); sample: configs[3], autoregressive "
-                         "inference at --batch 1024 --seq-len 300 unless given")
+                         "inference at --batch 1024 --seq-len 300 unless given; deep: configs[4], the training step of a "
+                         "K=32 x L=3 flow at --batch 128 --seq-len 512 unless given")
+    ap.add_argument("--strong-anchor-batch", type=int, default=2048,
+                    help="N = 1, workload train: also time one GPU at this batch (the global batch of configs[2]) and report it "
+                         "as strong_scaling_anchor; 0 disables it")
     ap.add_argument("--hparams", default=os.path.join(ROOT, "lets_face_it_amd", "hparams", "final_model_synthetic.yaml"))
     args = ap.parse_args()
 
@@ -417,6 +492,14 @@ def main():
     from lets_face_it_amd.trainer import Trainer
 
     hp = load_hparams_file(args.hparams)
+    if args.workload == "deep":
+        if args.batch == 256:
+            args.batch = 128
+        if args.seq_len == 80:
+            args.seq_len = 512
+        if args.steps == 20:
+            args.steps = 5
+        hp["Glow"]["K"], hp["Glow"]["L"] = 32, 3
     hp["batch_size"] = args.batch
     hp["engine_precision"] = args.precision
     hp["Train"]["seq_len"] = args.seq_len

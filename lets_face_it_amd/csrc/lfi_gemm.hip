@@ -2027,6 +2027,9 @@ extern "C" long lfi_gemm_colpart_rows(const lfi_gemm_desc* d) {
   if ((w && w[0] == '1') || gemm_use_k32()) return 0;
   GemmPlan plan = gemm_plan(d->M, d->N, d->K, d->batch, 1, true);
   if (d->precision & 0x30) plan.shape = (d->precision & 0x10) ? 3 : 0;
+  // (mirror of lfi_gemm_f32's kernel choice: the opt-in warp-specialised 128 x 128 kernel, LFI_GEMM_WS=1, has no column-sum epilogue)
+  const char* ws = getenv("LFI_GEMM_WS");
+  if (plan.shape != 3 && ws && ws[0] == '1') return 0;
   return plan.shape == 3 ? (long)lfi_cdiv(d->M, 256) * (256 / LFI_EPI_ROWS) : (long)lfi_cdiv(d->M, 128);
 }
 
@@ -2157,6 +2160,7 @@ extern "C" int lfi_gemm_f32(const lfi_gemm_desc* d, void* stream) {
       if (w1 != hipSuccess || w2 != hipSuccess || w3 != hipSuccess || w4 != hipSuccess) use_ws = 0;
     }
     if (use_ws) {
+      LFI_REQUIRE(!a.colpart, "lfi_gemm_f32: colsum_part is set but the LFI_GEMM_WS kernel cannot fill it (lfi_gemm_colpart_rows returns 0 there)");
       if (d->a_kcontig && d->b_kcontig) hipLaunchKernelGGL((gemm_bf16x3_ws_kernel<true, true>), grid, dim3(512), lds, st, a);
       else if (d->a_kcontig) hipLaunchKernelGGL((gemm_bf16x3_ws_kernel<true, false>), grid, dim3(512), lds, st, a);
       else if (d->b_kcontig) hipLaunchKernelGGL((gemm_bf16x3_ws_kernel<false, true>), grid, dim3(512), lds, st, a);

@@ -215,6 +215,9 @@ class GlowEngine:
         # GEMM arithmetic: 0 = exact fp32 on the f32-input MFMA; 1 = bf16x3 (fp32 operands split into bf16 hi + lo on the
         # fly, three bf16 MFMAs per step, fp32 accumulation: ~2^-16 relative, 16x the MFMA rate)
         self.precision = 0
+        # arithmetic of the AUTOREGRESSIVE part of sample() (per generated frame: the window columns of cond_transform, gic and
+        # the Ks reverse cells' recurrent products); None = as self.precision. See sample().
+        self.sample_frame_precision = None
         self._mask_calls = 0
         # GEMM class -> bf16x3 products to drop (bit 0: a_lo b_hi, bit 1: a_hi b_lo; 3 = plain bf16 operands, one product).
         # Measurement switch only: profiles/precision_sweep.md (tools/precision_sweep.py, final widths, against the fp64
@@ -865,11 +868,15 @@ class GlowEngine:
     def optimizer_state(self):
         """Adam's moments and step count (checkpoints, engine re-binds). Moments are None before the first step."""
         return {"step_count": int(self.step_count),
+                # the dropout-mask stream is keyed on (seed, call counter): a resumed / re-bound run must not replay the masks
+                # of steps 1..k (ADVICE r2)
+                "mask_calls": int(self._mask_calls),
                 "adam_m": None if self.adam_m is None else self.adam_m.detach().clone(),
                 "adam_v": None if self.adam_v is None else self.adam_v.detach().clone()}
 
     def load_optimizer_state(self, state):
         self.step_count = int(state.get("step_count", 0))
+        self._mask_calls = int(state.get("mask_calls", self._mask_calls))
         for name in ("adam_m", "adam_v"):
             t = state.get(name)
             if t is None:
@@ -922,6 +929,8 @@ class GlowEngine:
         else:
             pre[:F * KD].view(F, KD).copy_(self.fview("bct").reshape(1, KD).expand(F, KD))
         dims = self._flow_dims(B, nframes)
+        if self.sample_frame_precision is not None:
+            dims.gemm_precision = int(self.sample_frame_precision)
         h = self._buf("sample_h", s.Ks * B * s.H, zero=True)
         cs = self._buf("sample_c", s.Ks * B * s.H, zero=True) if s.rnn_type == "lstm" else None
         work = self._buf("scratch.sample", self.L.lfi_flow_sample_work_floats(C.byref(dims)))
@@ -949,7 +958,8 @@ class GlowEngine:
         # The per-frame chain (2 small GEMMs + Ks reverse cells, ~19 launches x nframes) is launch-bound on the host at
         # small batch: from the second call of a shape on, it is replayed as ONE hipGraph (captured once; every buffer it
         # touches is engine-owned and keeps its address). LFI_NO_GRAPH=1 keeps eager launches.
-        key = (B, seq_len, self.precision, faces.data_ptr(), pre.data_ptr(), nz.data_ptr(), h.data_ptr(), self.prep.data_ptr())
+        key = (B, seq_len, self.precision, int(dims.gemm_precision), faces.data_ptr(), pre.data_ptr(), nz.data_ptr(), h.data_ptr(),
+               self.prep.data_ptr())
         graph = self._sample_graphs.get(key)
         if graph is None and os.environ.get("LFI_NO_GRAPH") != "1" and self._sample_seen.get(key):
             torch.cuda.synchronize()

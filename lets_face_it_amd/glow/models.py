@@ -406,9 +406,9 @@ class SeqGlow(nn.Module):
         eng = _engine.GlowEngine(self.spec, device)
 
         _bind_flat(eng, self._named_flat(), self.glow.flow.layers, device)
-        old, self._stale_engine = getattr(self, "_stale_engine", None), None
-        if old is not None and old.n_params == eng.n_params:
-            eng.load_optimizer_state(old.optimizer_state())   # .to()/.float() mid-training keeps Adam's moments and step count
+        old, self._stale_opt = getattr(self, "_stale_opt", None), None
+        if old is not None and old[0] == eng.n_params:
+            eng.load_optimizer_state(old[1])   # .to()/.float() mid-training keeps Adam's moments, step count and mask counter
         self.engine = eng
         self.glow.flow._engine = eng  # module-level Glow / FlowNet calls (one timestep) run on the same buffers
         # autograd sees each Parameter; map them to gradient views of the flat gradient buffer
@@ -438,8 +438,12 @@ class SeqGlow(nn.Module):
         # sampling graphs — stays as it is.
         out = super()._apply(fn, *args, **kwargs)
         if self.engine is not None and not self._still_bound():
-            self._stale_engine = self.engine
+            # only Adam's moments + counters survive (on the host): the dropped engine's workspaces and stashes - tens of GB
+            # at BASELINE sizes - are released now, not when the next engine is already allocated beside them
+            st = self.engine.optimizer_state()
+            self._stale_opt = (self.engine.n_params, {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in st.items()})
             self.engine = None
+            self.glow.flow._engine = None
         return out
 
     # ------------------------------------------------------------------ helpers

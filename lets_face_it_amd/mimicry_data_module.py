@@ -117,7 +117,11 @@ class MimicryDataset:
             raise IndexError("window index out of range (0 .. %d)" % (len(self) - 1))
         # (through pinned memory: a pageable host-to-device copy synchronises the host with the stream, which drains the
         # training step queued behind it and leaves the GPU idle while the next one is issued - once per batch)
-        starts = self.starts[idx.pin_memory().to(self.device, non_blocking=True)].contiguous()
+        if idx.device.type == "cpu" and self.device.type == "cuda":
+            idx = idx.pin_memory().to(self.device, non_blocking=True)
+        else:                                      # an index tensor that already lives on a device: no staging copy
+            idx = idx.to(self.device)
+        starts = self.starts[idx].contiguous()
         B, T = starts.numel(), self.seq_len
         st = torch.cuda.current_stream().cuda_stream
         out = {}

@@ -66,13 +66,41 @@ class MimicryLogger:
             if hp.Validation["wrong_context_test"]:   # is the flow listening to the other modalities? (:200-239)
                 mismatch = hp.Mismatch
                 pl_module.log("mismatched_nll/actual_nll", loss)
+                probes = []
                 for kind, shuffle_time in (("shuffle_batch", False), ("shuffle_time", True)):
                     for key, mods in mismatch[kind].items():
                         if all(hp.Conditioning[x]["history"] > 0 for x in mods):
-                            deranged = derange_batch(new_batch, mods, shuffle_time=shuffle_time)
-                            _, wrong_nll, _ = pl_module.seq_glow(deranged)
-                            pl_module.log("mismatched_nll/%s_%s" % (kind, key), wrong_nll)
-                            pl_module.log("mismatched_nll_ratios/%s_%s" % (kind, key), loss - wrong_nll)
+                            probes.append(("%s_%s" % (kind, key), derange_batch(new_batch, mods, shuffle_time=shuffle_time)))
+                # the reference runs one forward per probe (10 at final_model.yaml); samples are independent in eval mode, so the
+                # deranged batches go through the engine STACKED along the batch axis (SURVEY.md par. 8 f2: "one batched forward
+                # over stacked deranged batches") and every probe's NLL is the mean over its own columns of the per-frame NLL
+                for (name, _), wrong_nll in zip(probes, self.stacked_nll(pl_module, [b for _, b in probes])):
+                    pl_module.log("mismatched_nll/" + name, wrong_nll)
+                    pl_module.log("mismatched_nll_ratios/" + name, loss - wrong_nll)
+
+    # frames (batch x timesteps) one stacked forward may hold: 4 x the training step's 256 x 80 (its workspaces are ~0.7 MB
+    # per frame at final widths: ~40 GB of the 288 GB)
+    max_stack_frames = 4 * 256 * 80
+
+    def stacked_nll(self, pl_module, batches):
+        """[(1,) loss tensor per batch dict] = SeqGlow.forward's loss of each (eval mode, no dropout), from as few engine
+        forwards as `max_stack_frames` allows (all batches have the same shapes)."""
+        if not batches:
+            return []
+        sg = pl_module.seq_glow
+        if sg.training or sg.injected_masks is not None:       # dropout masks are per call: keep the reference's one-by-one loop
+            return [sg(b)[1] for b in batches]
+        x = batches[0]["p1_face"]
+        B, T = x.shape[0], x.shape[1]
+        per = max(1, min(len(batches), self.max_stack_frames // max(B * T, 1)))
+        out = []
+        eng = sg._ensure_engine(x.device)
+        for i in range(0, len(batches), per):
+            group = batches[i:i + per]
+            stacked = {k: torch.cat([b[k] for b in group], dim=0).contiguous() for k in group[0]}
+            _, nll = eng.forward(stacked, None, with_stash=False)          # (N, len(group) * B)
+            out += [nll[:, j * B:(j + 1) * B].mean().reshape(1) for j in range(len(group))]
+        return out
 
     # ------------------------------------------------------------------ mimicry_logger.py:241-251
     def test_invertability(self, z_seq, loss, data, pl_module):

@@ -6,8 +6,10 @@ and ActNorm's data-dependent init statistics and the mismatched-NLL switch are a
 identical parameters and takes identical branches.
 """
 import os
+import random
 import time
 
+import numpy as np
 import torch
 import torch.distributed as dist
 
@@ -16,7 +18,9 @@ class Trainer:
     def __init__(self, hparams, device=None, log_every=10, callbacks=None, checkpoint_dir=None):
         self.hparams = hparams
         # Lightning's `checkpoint_callback: true` default (final_model.yaml:120): rank 0 writes <dir>/last.ckpt after every
-        # epoch (and at max_steps). None -> hparams.default_root_dir or ./checkpoints; "" switches checkpointing off.
+        # epoch (and at max_steps) - ONE file, overwritten (the reference's ModelCheckpoint keeps one per epoch).
+        # None -> hparams.checkpoint_dir, else <hparams.default_root_dir or the current directory>/checkpoints (Lightning's own
+        # default location); "" switches checkpointing off.
         if checkpoint_dir is None:
             checkpoint_dir = getattr(hparams, "checkpoint_dir", None) or os.path.join(
                 getattr(hparams, "default_root_dir", None) or os.getcwd(), "checkpoints")
@@ -31,6 +35,7 @@ class Trainer:
         self.max_epochs = int(getattr(hparams, "max_epochs", 1) or 1)
         self.max_steps = getattr(hparams, "max_steps", None)
         self.epoch = 0
+        self.batches_into_epoch = 0   # batches of the current epoch already trained on (a max_steps checkpoint taken mid-epoch)
 
     # ------------------------------------------------------------------ distributed plumbing
     def setup_distributed(self):
@@ -99,13 +104,18 @@ class Trainer:
             loader = datamodule.train_dataloader()
             if hasattr(loader, "set_epoch"):
                 loader.set_epoch(epoch)     # DistributedSampler.set_epoch: one shared permutation per epoch on every rank
-            for batch in loader:
+            skip, self.batches_into_epoch = self.batches_into_epoch, 0
+            for bi, batch in enumerate(loader):
+                if bi < skip:     # resumed mid-epoch: these batches were trained on before the checkpoint (same shuffle: the
+                    self.batches_into_epoch = bi + 1   # RNG state the epoch's permutation was drawn from is part of it)
+                    continue
                 batch = {k: v.to(self.device, non_blocking=True).float().contiguous() for k, v in batch.items()}
                 loss = model.fused_training_step(batch, lr, self.world_size, allreduce)
                 x = batch["p1_face"]
                 frames += x.shape[0] * (x.shape[1] - model.seq_glow.spec.start) * self.world_size
                 step += 1
                 self.global_step = step
+                self.batches_into_epoch = bi + 1
                 if self.rank == 0 and step % self.log_every == 0:
                     torch.cuda.synchronize()
                     print("epoch %d step %d lr %.3e loss %.4f  %.0f frames/s" %
@@ -115,6 +125,7 @@ class Trainer:
                     return
             self.validate(model, datamodule)
             self.epoch = epoch + 1          # a checkpoint written now resumes with the next epoch
+            self.batches_into_epoch = 0
             self._checkpoint(model)
 
     def _checkpoint(self, model):
@@ -127,17 +138,23 @@ class Trainer:
         if loader is None:
             return None
         model.eval()
-        total, count = 0.0, 0
+        # under data parallelism the loader hands every rank ITS share of the validation windows (WindowLoader: one shared order,
+        # rank r takes elements r, r + world, ...); the loss is summed over ranks below. The callbacks (MimicryLogger: sampling,
+        # invertibility, the mismatched-NLL probes, rendering) issue no collective and run on rank 0 only, on rank 0's first batch
+        total = torch.zeros(2, dtype=torch.float64, device=self.device)
         with torch.no_grad():
             for i, batch in enumerate(loader()):
                 batch = {k: v.to(self.device).float().contiguous() for k, v in batch.items()}
                 out = model.validation_step(batch, i)
-                for cb in self.callbacks:   # Lightning's hook order: after each validation batch (mimicry_logger.py:154)
-                    cb.on_validation_batch_end(self, model, out, batch, i, 0)
-                total += float(out)
-                count += 1
+                if self.rank == 0:
+                    for cb in self.callbacks:   # Lightning's hook order: after each validation batch (mimicry_logger.py:154)
+                        cb.on_validation_batch_end(self, model, out, batch, i, 0)
+                total[0] += out.reshape(()).double()
+                total[1] += 1
+        if self.world_size > 1:
+            dist.all_reduce(total, op=dist.ReduceOp.SUM)
         model.train()
-        val = total / max(count, 1)
+        val = float(total[0]) / max(float(total[1]), 1.0)
         if self.rank == 0:
             print("epoch %d val_loss %.4f" % (self.epoch, val), flush=True)
         return val
@@ -154,8 +171,30 @@ class Trainer:
             tmp = path + ".tmp"
             torch.save({"state_dict": {k: v.detach().cpu() for k, v in model.state_dict().items()},
                         "hparams": vars(self.hparams), "epoch": self.epoch, "global_step": self.global_step,
-                        "optimizer_state": opt, "actnorm_inited": bool(model.seq_glow.glow.actnorm_inited())}, tmp)
+                        "optimizer_state": opt, "actnorm_inited": bool(model.seq_glow.glow.actnorm_inited()),
+                        # the negative-example branch draws from Python's `random`, derange_batch from torch's CPU generator,
+                        # the loader's shuffle too: a resumed run continues those streams instead of replaying them
+                        "rng": {"python": random.getstate(), "numpy": np.random.get_state(), "torch": torch.get_rng_state()},
+                        "batches_into_epoch": int(self.batches_into_epoch)}, tmp)
             os.replace(tmp, path)
+
+    @staticmethod
+    def _flat_adam_state(model, eng, opt_state):
+        """torch.optim.Adam state_dict ({'state': {i: {'step', 'exp_avg', 'exp_avg_sq'}}, ...}; i = index in model.parameters())
+        -> the engine's flat-buffer state. Parameters are views of the flat buffer, so a moment's place is its parameter's."""
+        m, v = torch.zeros_like(eng.params), torch.zeros_like(eng.params)
+        step, base = 0, eng.params.data_ptr()
+        for i, p in enumerate(model.parameters()):
+            st = opt_state["state"].get(i)
+            if st is None:
+                continue
+            off = (p.data_ptr() - base) // 4
+            if not (0 <= off and off + p.numel() <= eng.n_params):
+                raise ValueError("parameter %d does not live in the engine's flat buffer" % i)
+            m[off:off + p.numel()].copy_(st["exp_avg"].reshape(-1))
+            v[off:off + p.numel()].copy_(st["exp_avg_sq"].reshape(-1))
+            step = max(step, int(st["step"]))
+        return {"step_count": step, "adam_m": m, "adam_v": v}
 
     def resume(self, model, path):
         """Continue a run from a checkpoint of save_checkpoint: weights, ActNorm's inited flag, Adam state, epoch and step."""
@@ -164,8 +203,23 @@ class Trainer:
         model.to(self.device)
         if ckpt.get("actnorm_inited", True):
             model.seq_glow.glow.set_actnorm_init(True)
+        eng = model.seq_glow._ensure_engine(self.device)
         if ckpt.get("optimizer_state") is not None:
-            model.seq_glow._ensure_engine(self.device).load_optimizer_state(ckpt["optimizer_state"])
+            eng.load_optimizer_state(ckpt["optimizer_state"])
+        elif ckpt.get("optimizer_states"):
+            # a Lightning / reference checkpoint: torch.optim.Adam's per-parameter state, in model.parameters() order
+            # (configure_optimizers, lets_face_it_glow.py:61-72) -> the flat moments
+            eng.load_optimizer_state(self._flat_adam_state(model, eng, ckpt["optimizer_states"][0]))
+        else:
+            import warnings
+            warnings.warn("checkpoint %s holds no optimiser state: Adam's moments restart from zero (with betas[1] = 0.9999 "
+                          "the second moments need ~10^4 steps to recover)" % path)
+        rng = ckpt.get("rng")
+        if rng:
+            random.setstate(rng["python"])
+            np.random.set_state(rng["numpy"])
+            torch.set_rng_state(rng["torch"])
+        self.batches_into_epoch = int(ckpt.get("batches_into_epoch", 0))
         self.epoch = int(ckpt.get("epoch", 0))
         self.global_step = int(ckpt.get("global_step", 0))
         model.global_step = self.global_step

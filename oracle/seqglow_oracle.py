@@ -19,6 +19,7 @@ the build container by ``tests/golden/make_golden.py`` (which asserts
 oracle == reference to 1e-10 in fp64 before it writes the fixtures that
 ``tests/test_oracle_golden.py`` re-checks everywhere).
 """
+import contextlib
 import math
 
 import torch
@@ -34,8 +35,30 @@ def longest_history(cond):
 
 
 # --------------------------------------------------------------------------- cells
+# The cells below spell nn.GRUCell / nn.LSTMCell / nn.GRU / nn.LSTM out as their equations (~10 small ATen ops per cell). The
+# reference itself calls the modules (glow/models.py:21-27,60-64,176-185,206-213), which dispatch to ONE fused op per cell
+# (torch._VF.gru_cell / lstm_cell: a fused pointwise kernel behind two addmm on a GPU) and ONE per window (torch._VF.gru / lstm:
+# MIOpen's RNN on a ROCm GPU). `with reference_op_set():` switches this module to exactly those calls - same arithmetic
+# (tests/test_oracle_golden.py pins the two forms to each other), the reference's own kernel count: it is what bench.py's
+# `torch_gpu_baseline` times, so that the ">= 10x the reference single-GPU PyTorch" ratio is taken against the reference's
+# op set, not against a slower spelling of it.
+_REFERENCE_OPS = False
+
+
+@contextlib.contextmanager
+def reference_op_set(on=True):
+    global _REFERENCE_OPS
+    old, _REFERENCE_OPS = _REFERENCE_OPS, bool(on)
+    try:
+        yield
+    finally:
+        _REFERENCE_OPS = old
+
+
 def gru_cell(x, h, w_ih, w_hh, b_ih, b_hh):
     """torch.nn.GRUCell equations (gate order r, z, n); used by glow/models.py:176-179,206-208."""
+    if _REFERENCE_OPS:
+        return torch._VF.gru_cell(x, h, w_ih, w_hh, b_ih, b_hh)
     gi = x @ w_ih.t() + b_ih
     gh = h @ w_hh.t() + b_hh
     H = h.shape[1]
@@ -51,6 +74,8 @@ def lstm_cell(x, h, c, w_ih, w_hh, b_ih, b_hh):
     The reference branch passes (None, None) on the first step and crashes
     (SURVEY.md finding 2); the semantics pinned here are "zero initial (h, c)".
     """
+    if _REFERENCE_OPS:
+        return torch._VF.lstm_cell(x, (h, c), w_ih, w_hh, b_ih, b_hh)
     g = x @ w_ih.t() + b_ih + h @ w_hh.t() + b_hh
     H = h.shape[1]
     i = torch.sigmoid(g[:, :H])
@@ -73,6 +98,9 @@ def encode_window(x, enc, sd, prefix, mask=None):
         w_ih, w_hh = sd[prefix + "encoder.weight_ih_l0"], sd[prefix + "encoder.weight_hh_l0"]
         b_ih, b_hh = sd[prefix + "encoder.bias_ih_l0"], sd[prefix + "encoder.bias_hh_l0"]
         h = x.new_zeros(B, w_hh.shape[1])
+        if _REFERENCE_OPS:   # nn.GRU(batch_first=True): one fused call per window batch (:60-64)
+            seq, hn = torch._VF.gru(x.contiguous(), h.unsqueeze(0), [w_ih, w_hh, b_ih, b_hh], True, 1, 0.0, False, False, True)
+            return torch.cat([seq[:, -1], hn[0]], dim=1)
         for s in range(x.shape[1]):
             h = gru_cell(x[:, s], h, w_ih, w_hh, b_ih, b_hh)
         return torch.cat([h, h], dim=1)
@@ -81,6 +109,10 @@ def encode_window(x, enc, sd, prefix, mask=None):
         b_ih, b_hh = sd[prefix + "encoder.bias_ih_l0"], sd[prefix + "encoder.bias_hh_l0"]
         h = x.new_zeros(B, w_hh.shape[1])
         c = x.new_zeros(B, w_hh.shape[1])
+        if _REFERENCE_OPS:   # nn.LSTM(batch_first=True) (:65-69)
+            seq, hn, _ = torch._VF.lstm(x.contiguous(), (h.unsqueeze(0), c.unsqueeze(0)), [w_ih, w_hh, b_ih, b_hh], True, 1, 0.0,
+                                        False, False, True)
+            return torch.cat([seq[:, -1], hn[0]], dim=1)
         for s in range(x.shape[1]):
             h, c = lstm_cell(x[:, s], h, c, w_ih, w_hh, b_ih, b_hh)
         return torch.cat([h, h], dim=1)

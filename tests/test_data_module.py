@@ -333,3 +333,36 @@ def test_mimicry_logger_metrics(gpu_device):
     MimicryLogger().on_validation_batch_end(None, model, out, batch, 1, 0)   # only the first batch is probed
     stats = MimicryLogger().log_scales(model)
     assert any(k.startswith("ActNorm/") for k in stats) and any(k.startswith("FlowStepScale/") for k in stats)
+
+
+@pytest.mark.gpu
+def test_stacked_mismatched_probes_equal_one_forward_each(gpu_device):
+    """SURVEY.md par. 8 f2: the mismatched-NLL probes (mimicry_logger.py:199-238: one SeqGlow.forward per deranged batch, 10 at
+    final_model.yaml) go through the engine as ONE stacked forward; every probe's NLL must be what its own forward gives."""
+    from helpers import Fixture
+    from lets_face_it_amd.glow.lets_face_it_glow import LetsFaceItGlow
+    from lets_face_it_amd.glow.utils import derange_batch
+    from lets_face_it_amd.mimicry_logger import MimicryLogger
+    fx = Fixture("mid")
+    model = LetsFaceItGlow(Namespace(**fx.hp))
+    model.seq_glow.load_state_dict(fx.state_dict(torch.float32))
+    model.to(gpu_device).eval()
+    model.seq_glow.glow.set_actnorm_init(True)
+    batch = {k: v.to(device=gpu_device, dtype=torch.float32).contiguous() for k, v in fx.batch().items()}
+    torch.manual_seed(3)
+    probes = [derange_batch(batch, mods, shuffle_time=st)
+              for st in (False, True) for mods in (["p2_face"], ["p2_speech"], ["p1_speech"], ["p2_face", "p2_speech"])]
+    lg = MimicryLogger()
+    with torch.no_grad():
+        one_by_one = [model.seq_glow(b)[1] for b in probes]
+        calls = []
+        eng = model.seq_glow.engine
+        fwd = eng.forward
+        eng.forward = lambda *a, **k: (calls.append(a[0]["p1_face"].shape[0]), fwd(*a, **k))[1]
+        stacked = lg.stacked_nll(model, probes)
+        lg.max_stack_frames = 3 * fx.B * fx.T          # a cap that forces groups of three
+        grouped = lg.stacked_nll(model, probes)
+        eng.forward = fwd
+    assert calls == [8 * fx.B, 3 * fx.B, 3 * fx.B, 2 * fx.B]
+    for a, b, c in zip(one_by_one, stacked, grouped):
+        assert abs(float(a) - float(b)) < 1e-5 * max(1.0, abs(float(a))) and abs(float(a) - float(c)) < 1e-5 * max(1.0, abs(float(a)))

@@ -90,8 +90,49 @@ def _worker(rank, world, port, out):
     count = torch.tensor([float(steps)])
     dist.all_reduce(count)
     assert float(count) == world * steps == world * 2 * 5     # ceil(ceil(53 / 2) / 6) = 5 batches per rank and epoch
+    # (5) the step's two collectives at the real sizes: the flow bucket (66 MB here, as at final widths)
+    # is issued asynchronously and is still travelling when the encoder bucket's synchronous all-reduce is issued behind it;
+    # both ranks issue them in the same order, both complete, every float summed exactly once
+    big = torch.full((16_500_000,), float(rank + 1))
+    small = torch.full((840_000,), float(10 * (rank + 1)))
+    work = tr.allreduce_grads(big, async_op=True)
+    in_flight = not work.is_completed()
+    tr.allreduce_grads(small)
+    work.wait()
+    ok_order = bool((big == 3.0).all()) and bool((small == 30.0).all())
+
+    # (6) Trainer.validate under data parallelism: every rank scores ITS share of the validation windows, the loss is the
+    # mean over all ranks' batches, and the callbacks run on rank 0 only
+    class FakeModel:
+        def eval(self):
+            return self
+
+        def train(self):
+            return self
+
+        def validation_step(self, batch, i):
+            return batch["idx"].float().mean().reshape(1)
+
+    class FakeData:
+        def val_dataloader(self):
+            return WindowLoader(Windows(), 6, shuffle=False, rank=rank, world_size=world)
+
+    calls = []
+
+    class Cb:
+        def on_validation_batch_end(self, *a):
+            calls.append(a[4])
+
+    tr.callbacks = [Cb()]
+    val = tr.validate(FakeModel(), FakeData())
+    # 53 windows wrap to 54: rank r scores r, r + 2, ... in batches of 6 -> 5 batches per rank; the expected mean of batch means
+    order = torch.cat([torch.arange(53), torch.arange(1)])
+    means = [order[r:54:world][b:b + 6].float().mean() for r in range(world) for b in range(0, 27, 6)]
+    ok_val = abs(val - float(torch.stack(means).double().mean())) < 1e-4 and (len(calls) == 5 if rank == 0 else len(calls) == 0)
+    flags = torch.tensor([float(ok_order), float(ok_val)])
+    dist.all_reduce(flags, op=dist.ReduceOp.MIN)
     if rank == 0:
-        out.put((err_grad, err_stats, n, float(v)))
+        out.put((err_grad, err_stats, n, float(v), bool(flags[0]), bool(flags[1]), in_flight))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -104,7 +145,7 @@ def test_two_rank_gloo_data_parallel():
     for p in procs:
         p.start()
     try:
-        err_grad, err_stats, n, v = out.get(timeout=240)
+        err_grad, err_stats, n, v, ok_order, ok_val, in_flight = out.get(timeout=240)
     finally:
         for p in procs:
             p.join(timeout=60)
@@ -112,3 +153,6 @@ def test_two_rank_gloo_data_parallel():
                 p.terminate()
     assert all(p.exitcode == 0 for p in procs)
     assert err_grad < 1e-10 and err_stats < 1e-10 and n == 2 and v == 1.5
+    assert ok_order, "two collectives (async flow bucket, then the encoder bucket) did not both complete with every float summed once"
+    assert ok_val, "sharded validation: wrong global mean, or a callback ran off rank 0"
+    print("async flow-bucket all-reduce still in flight when the encoder bucket was issued: %s" % in_flight)

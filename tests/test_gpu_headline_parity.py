@@ -1,0 +1,141 @@
+"""Parity AT THE BENCHMARKED CONFIGURATION: the HIP path against the fp64 CPU oracle where bench.py
+actually runs — B = 256, T = 80, K = 16, C = 50 / S = 27, bf16x3 GEMM mode — for the per-frame NLL and EVERY parameter
+gradient, and K = 16 autoregressive sampling over 56 generated frames.
+
+Only at F = 14 336 frames do the 85-way split-K of the 768 x 256 x 330 k dW_hh product, the 3 584-workgroup planes GEMM, the
+per-tile column-sum epilogue at 112 row tiles and the XCD tile order exist at all; the small-batch oracle tests never see them.
+The oracle's fp64 forward + autograd backward at this size is ~1-2 minutes of host time (reference loop:
+glow/models.py:534-561; sampling loop :567-596).
+"""
+import time
+
+import pytest
+import torch
+
+from helpers import max_rel, report
+from oracle import seqglow_oracle as oracle
+from test_gpu_parity import final_model_hparams, perturbed_model, to_dev
+
+pytestmark = pytest.mark.gpu
+
+
+def _masks(hp, N, B, seed):
+    g = torch.Generator().manual_seed(seed)
+    masks = {}
+    for name in ("p2_face", "p1_speech", "p2_speech"):
+        cfg = hp["Conditioning"][name]
+        keep = 1.0 - cfg["dropout"]
+        masks[name] = (torch.rand(N, B, cfg["history"], generator=g) < keep).float() / keep
+    return masks
+
+
+def test_headline_config_gradients_against_oracle(gpu_device):
+    """BASELINE configs[1] itself: B=256, T=80, K=16, injected dropout masks, bf16x3. Per-frame NLL (gate 1e-4 relative,
+    north_star) and every parameter gradient (relative L2 against the fp64 oracle, gate 2e-3 as everywhere else; no
+    LeakyReLU-kink allowance is needed with 14 336 frames behind each weight row)."""
+    hp = final_model_hparams(50, 27, K=16)
+    m, sd = perturbed_model(hp, gpu_device)
+    m.precision = "bf16x3"
+    m.train()
+    B, T = 256, 80
+    N = T - 24
+    batch = oracle.synthetic_batch(B, T, 50, 27, seed=1234)
+    masks = _masks(hp, N, B, 6)
+    m.injected_masks = masks
+    _, loss, losses = m(to_dev(batch, gpu_device))
+    loss.sum().backward()
+    torch.cuda.synchronize()
+    grads = {n: p.grad.detach().double().cpu() for n, p in m.named_parameters()}
+    nll = torch.stack(losses).double().cpu()
+    del m
+    torch.cuda.empty_cache()
+
+    threads = torch.get_num_threads()
+    torch.set_num_threads(min(16, threads))
+    t0 = time.time()
+    sdg = {k: v.double().requires_grad_(v.dtype.is_floating_point and not k.endswith((".p", ".sign_s")))
+           for k, v in sd.items()}
+    _, oloss, onll = oracle.seqglow_forward(hp, sdg, {k: v.double() for k, v in batch.items()},
+                                            {k: v.double() for k, v in masks.items()})
+    oloss.sum().backward()
+    spent = time.time() - t0
+    torch.set_num_threads(threads)
+
+    err = max_rel(nll, onll.detach(), floor=1.0)
+    total = float(torch.sqrt(sum((v.grad ** 2).sum() for v in sdg.values() if v.grad is not None)))
+    worst, worst_abs = ("", 0.0), ("", 0.0)
+    for name, g in grads.items():
+        ref = sdg[name].grad
+        diff = float((g - ref).norm())
+        rel = diff / max(float(ref.norm()), 1e-3 * total)
+        if rel > worst[1]:
+            worst = (name, rel)
+        if diff / total > worst_abs[1]:
+            worst_abs = (name, diff / total)
+    report("HEADLINE config (B=256, T=80, K=16, bf16x3) vs fp64 oracle (%.0f s of host time): per-frame NLL max rel err %.3e, "
+           "worst gradient rel L2 %.3e (%s), worst share of the whole gradient's norm %.3e (%s), %d tensors"
+           % (spent, err, worst[1], worst[0], worst_abs[1], worst_abs[0], len(grads)))
+    assert err < 1e-4
+    assert worst[1] < 2e-3, worst
+
+
+def test_k16_sampling_against_oracle(gpu_device):
+    """SeqGlow.inference at the full depth (K = 16, final widths), batch 8, 56 generated frames, injected prior noise, against
+    the fp64 oracle. north_star's bar is 1e-5 absolute; SURVEY.md par. 7 puts the reference's OWN fp32-vs-fp64 spread at this
+    depth x length at ~3e-5, so the gate is max(1e-5, 1.5 x the plain-fp32-torch error on the same inputs); both are reported."""
+    hp = final_model_hparams(50, 27, K=16)
+    m, sd = perturbed_model(hp, gpu_device)
+    m.eval()
+    B, seq_len = 8, 24 + 56
+    g = torch.Generator().manual_seed(3)
+    data = {"p1_face": torch.randn(B, 24, 50, generator=g)}
+    for name, d in (("p2_face", 50), ("p1_speech", 27), ("p2_speech", 27)):
+        data[name] = torch.randn(B, seq_len, d, generator=g)
+    noise = torch.randn(seq_len - 24, B, 50, generator=g) * 0.8
+    ref = oracle.seqglow_inference(hp, {k: v.double() for k, v in sd.items()}, seq_len,
+                                   {k: v.double() for k, v in data.items()}, noise.double())
+    ref32 = oracle.seqglow_inference(hp, sd, seq_len, data, noise)    # the same op sequence in plain fp32 (CPU)
+    own = float((ref32.double() - ref).abs().max())
+    gate = max(1e-5, 1.5 * own)
+    for precision in ("f32", "bf16x3"):
+        m.precision = precision
+        out = m.inference(seq_len, to_dev(data, gpu_device), noise=noise.to(gpu_device))
+        out2 = m.inference(seq_len, to_dev(data, gpu_device), noise=noise.to(gpu_device))   # hipGraph replay
+        err = float((out.cpu().double() - ref).abs().max())
+        per_frame = (out.cpu().double() - ref).abs().amax(dim=(0, 2))
+        report("K=16 sampling, batch 8 x 56 generated frames (%s): max abs err vs fp64 oracle %.2e (first frame %.2e, last frame "
+               "%.2e); plain fp32 torch on the CPU: %.2e; gate %.2e" % (precision, err, float(per_frame[0]), float(per_frame[-1]),
+                                                                        own, gate))
+        assert torch.equal(out, out2)
+        assert err <= gate, (precision, err, gate)
+
+
+def test_strong_scaling_anchor_batch_matches_its_sub_batches(gpu_device):
+    """bench.py's strong_scaling_anchor steps ONE GPU at the global batch of BASELINE configs[2] (2048 = 8 x 256). That batch
+    must be the same function as its eight per-GPU shards: per-frame NLL bit-identical to the shards' (samples are independent),
+    and the gradient of the global-batch mean loss equal to the mean of the shards' gradients - which is exactly what the
+    data-parallel all-reduce + 1/world computes on 8 GPUs."""
+    hp = final_model_hparams(50, 27, K=16)
+    m, _ = perturbed_model(hp, gpu_device)
+    m.precision = "bf16x3"
+    m.eval()   # no dropout: every pass sees the same function
+    B, T, W = 2048, 80, 8
+    batch = to_dev(oracle.synthetic_batch(B, T, 50, 27, seed=77), gpu_device)
+
+    def grads(b):
+        m.zero_grad(set_to_none=True)
+        _, loss, losses = m(b)
+        loss.sum().backward()
+        return torch.stack(losses), torch.cat([p.grad.reshape(-1) for p in m.parameters()]).double()
+
+    nll_all, g_all = grads(batch)
+    assert torch.isfinite(nll_all).all() and nll_all.shape == (T - 24, B)
+    g_sum = torch.zeros_like(g_all)
+    for r in range(W):
+        shard = {k: v[r * (B // W):(r + 1) * (B // W)].contiguous() for k, v in batch.items()}
+        nll_r, g_r = grads(shard)
+        assert torch.equal(nll_r, nll_all[:, r * (B // W):(r + 1) * (B // W)]), r
+        g_sum += g_r
+    err = float((g_all - g_sum / W).norm() / g_all.norm())
+    report("global batch 2048 on one GPU vs the mean of its 8 shards of 256: per-frame NLL bit-identical, gradient rel L2 diff %.2e" % err)
+    assert err < 2e-5

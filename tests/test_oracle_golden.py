@@ -96,3 +96,24 @@ def test_actnorm_init(fx):
             assert rel_err(sd[key], fx.get("init/" + key)) < 1e-10, key
     nll = oracle.seqglow_forward(fx.hp, sd, batch, masks)[2]
     assert rel_err(nll, fx.get("init/nll")) < 1e-10
+
+
+def test_reference_op_set_matches_the_spelled_out_cells(fx):
+    """`oracle.reference_op_set()` (what bench.py's torch_gpu_baseline times: torch._VF.gru / gru_cell / lstm / lstm_cell, the ops
+    nn.GRU / nn.GRUCell / nn.LSTM / nn.LSTMCell dispatch to, glow/models.py:21-27,60-64,176-185,206-213) is the same function as
+    the spelled-out cell equations the fixtures pin: forward against the reference's golden NLL, gradients against its golden
+    gradients, in fp64."""
+    sd = fx.state_dict()
+    for k, v in sd.items():
+        if v.dtype.is_floating_point and not k.endswith((".p", ".sign_s")):
+            v.requires_grad_(True)
+    with oracle.reference_op_set():
+        z, loss, nll = oracle.seqglow_forward(fx.hp, sd, fx.batch(), fx.masks())
+        loss.sum().backward()
+    assert rel_err(nll.detach(), fx.get("train/nll")) < 1e-10
+    for name, g in fx.group("grad/").items():
+        assert rel_err(sd[name].grad, g) < 1e-9, name
+    with oracle.reference_op_set():
+        data = fx.group("infer/data/", torch.float64)
+        out = oracle.seqglow_inference(fx.hp, fx.state_dict(), int(fx.get("infer/seq_len")), data, fx.get("infer/noise"))
+    assert rel_err(out, fx.get("infer/out")) < 1e-10

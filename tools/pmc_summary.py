@@ -3,6 +3,10 @@
 
 HBM bytes per dispatch (MI355X_MICROARCH.md, HBM section): FETCH_SIZE and WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE
 tallies 128-byte requests as 64 bytes for wide coalesced reads, so read bytes = 2 * FETCH_SIZE * 1024; WRITE_SIZE is exact.
+
+Effective clock per kernel (MI355X_MICROARCH.md, "DVFS give-back"): GRBM_GUI_ACTIVE (summed over the 8 XCDs) / 8 / the
+dispatch's wall time (End - Start timestamp of the same row), duration-weighted over the kernel's dispatches. The guide's
+caveat applies: the quotient reads high on dispatches shorter than ~0.3 ms, so the column also gives the mean dispatch time.
 """
 import collections
 import csv
@@ -14,10 +18,16 @@ def main():
     root = sys.argv[1]
     agg = collections.defaultdict(lambda: collections.defaultdict(list))
     bygrid = collections.defaultdict(lambda: collections.defaultdict(list))
+    clk = collections.defaultdict(lambda: [0.0, 0.0, 0])   # kernel -> [sum GUI_ACTIVE / 8, sum wall ns, dispatches]
     for f in glob.glob(root + "/p*/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
             name = r["Kernel_Name"].replace("(anonymous namespace)::", "")
             agg[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
+            if r["Counter_Name"] == "GRBM_GUI_ACTIVE" and r.get("End_Timestamp"):
+                c = clk[name]
+                c[0] += float(r["Counter_Value"]) / 8.0
+                c[1] += float(r["End_Timestamp"]) - float(r["Start_Timestamp"])
+                c[2] += 1
             bygrid[(name, int(r["Grid_Size"]))][r["Counter_Name"]].append(float(r["Counter_Value"]))
     if len(sys.argv) > 2:
         # per (kernel, grid) HBM bytes per dispatch as JSON: bench.py looks its dominant kernel up here for roofline.traffic
@@ -40,16 +50,19 @@ def main():
         wr = m.get("WRITE_SIZE", float("nan")) * 1024
         rows.append((k, n, rd, wr, m))
     rows.sort(key=lambda r: -(r[4].get("SQ_BUSY_CYCLES", 0) * r[1]))
-    print("| kernel | dispatches/pass | HBM read MB (2x FETCH_SIZE) | HBM write MB | L2 hit % | MFMA busy % of SQ busy | LDS conflict % |")
-    print("|---|---|---|---|---|---|---|")
+    print("| kernel | dispatches/pass | HBM read MB (2x FETCH_SIZE) | HBM write MB | L2 hit % | MFMA busy % of SQ busy | LDS conflict % | effective clock GHz (mean dispatch ms) |")
+    print("|---|---|---|---|---|---|---|---|")
     for k, n, rd, wr, m in rows[:30]:
         hit = 100 * m.get("TCC_HIT_sum", 0) / max(m.get("TCC_HIT_sum", 0) + m.get("TCC_MISS_sum", 0), 1)
         # SQ_VALU_MFMA_BUSY_CYCLES counts cycles summed over SIMDs; SQ_BUSY_CYCLES is per-SE... report the raw ratio basis:
         mf = 100 * m.get("SQ_VALU_MFMA_BUSY_CYCLES", 0) / max(4.0 * m.get("SQ_WAVE_CYCLES", 0), 1)
         ldc = 100 * m.get("SQ_LDS_BANK_CONFLICT", 0) / max(m.get("SQ_LDS_IDX_ACTIVE", 0), 1)
-        print("| %s | %d | %.1f | %.1f | %.1f | %.1f | %.1f |" % (k[:100], n, rd / 1e6, wr / 1e6, hit, mf, ldc))
+        c = clk.get(k)
+        ck = "%.2f (%.3f)" % (c[0] / c[1], c[1] / c[2] / 1e6) if c and c[1] > 0 else "-"
+        print("| %s | %d | %.1f | %.1f | %.1f | %.1f | %.1f | %s |" % (k[:100], n, rd / 1e6, wr / 1e6, hit, mf, ldc, ck))
     print("\nMFMA column = SQ_VALU_MFMA_BUSY_CYCLES / (4 * SQ_WAVE_CYCLES) (wave-cycles are quad-cycles): the share of "
-          "wave lifetime with the MFMA pipe busy, not chip utilisation.")
+          "wave lifetime with the MFMA pipe busy, not chip utilisation. Effective clock = GRBM_GUI_ACTIVE / 8 / dispatch wall "
+          "time (reads high below ~0.3 ms per dispatch; nominal peak clock 2.4 GHz).")
 
 
 if __name__ == "__main__":

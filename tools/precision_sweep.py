@@ -9,6 +9,9 @@ pass count this prints, at final_model.yaml widths (K = 16, H = 128, D = 512, 25
   relative L2 error of the whole gradient and of the worst parameter tensor (tests/test_gpu_parity.py gate in bf16x3 mode: 2e-3).
 
     python tools/precision_sweep.py > profiles/precision_sweep.md      (GPU box; ~2 min)
+    python tools/precision_sweep.py --batch 256 --seq-len 80 --bwd-only > profiles/precision_sweep_b256.md
+        (the backward classes at the BENCHMARK's own size, 14 336 frames behind every weight row instead of
+         96; the fp64 oracle's forward + backward at that size takes 1-2 minutes of host time, once)
 Not covered (their bf16x3 products live inside the recurrence kernels, not in the GEMM library): the window encoders'
 h W_hh^T products and the flow cells' recurrent / LinearZeros / invconv products.
 """
@@ -33,6 +36,12 @@ MODES = [(0, "3 (a_lo b_hi + a_hi b_lo + a_hi b_hi)"), (1, "2, A rounded to bf16
 
 
 def main():
+    import argparse
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--seq-len", type=int, default=36)
+    ap.add_argument("--bwd-only", action="store_true", help="only the backward GEMM classes (they leave the NLL untouched)")
+    args = ap.parse_args()
     from argparse import Namespace
     from helpers import max_rel
     from oracle import seqglow_oracle as oracle
@@ -42,7 +51,7 @@ def main():
     m, sd = perturbed_model(hp, dev)
     m.precision = "bf16x3"
     m.train()
-    B, T = 8, 36
+    B, T = args.batch, args.seq_len
     batch = oracle.synthetic_batch(B, T, 50, 27, seed=17)
     N = T - 24
     g = torch.Generator().manual_seed(6)
@@ -89,12 +98,20 @@ def main():
     err, gl2, worst = run(shipped)
     print("| tried as default, reverted: enc_dwhh with 1 product, everything else 3 | mixed | %.2e | %.2e | %.2e | %s | %.2e |"
           % (err, gl2, worst[1], worst[0], worst[2]))
-    for cls, what, _ in CLASSES:
+    for cls, what, direction in CLASSES:
+        if args.bwd_only and direction != "bwd":
+            continue
         for bits, label in MODES[1:]:
             err, gl2, worst = run({cls: bits})
             print("| %s: %s | %s | %.2e | %.2e | %.2e | %s | %.2e |" % (cls, what, label, err, gl2, worst[1], worst[0], worst[2]))
     fwd = {c: 3 for c, _, d in CLASSES if d == "fwd"}
     allc = {c: 3 for c, _, _ in CLASSES}
+    if args.bwd_only:
+        bwd = [c for c, _, d in CLASSES if d == "bwd"]
+        for bits, label in MODES[1:]:
+            err, gl2, worst = run({c: bits for c in bwd})
+            print("| EVERY backward class | %s | %.2e | %.2e | %.2e | %s | %.2e |" % (label, err, gl2, worst[1], worst[0], worst[2]))
+        return
     for label, skip in (("every forward class", fwd), ("every class", allc)):
         err, gl2, worst = run(skip)
         print("| %s | 1 (plain bf16) | %.2e | %.2e | %.2e | %s | %.2e |" % (label, err, gl2, worst[1], worst[0], worst[2]))
