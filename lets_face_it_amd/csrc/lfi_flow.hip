@@ -44,6 +44,7 @@ struct FlowK {
   // backward recurrent weights pre-split into bf16 hi / lo 32-k fragments (bf16 x 3 walk): [Ks][NG][H16/32][J][4 lane groups],
   // one uint4 per entry and plane; the lo plane follows the hi plane of an image
   const uint4 *xbwh, *xbwz;
+  __bf16 *bDgiR, *bDgiT;   // backward walk (bf16x3): dgi also as row planes / k-major planes of the (Ks F x G) matrix (lfi_flow_seq_bwd_planes)
   int C16, Ch16, H16, Co16, NG;
   // forward stash
   float *sA, *sY, *sX, *sH, *sG, *sO, *sL, *sC;   // sC: LSTM cell state (lstm only)
@@ -2237,7 +2238,7 @@ __global__ __launch_bounds__(NT) void flow_pipe_bwd_kernel(FlowK f) {
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
           if constexpr (X3) {
-            const int at = i * ldx + g * H16 + x3_pos(j);
+            const int at = i * ldx + g * H16 + j;   // natural column order (weights: flow_prep_x3_kernel)
             x3_put(GiH, GiL, at, gi_[g]);
             x3_put(GhH, GhL, at, gh_[g]);
           } else {
@@ -2304,6 +2305,37 @@ __global__ __launch_bounds__(NT) void flow_pipe_bwd_kernel(FlowK f) {
   const bool peek = !last && !fenced && n > 0;
   unsigned pk = 0u;
   if (peek && tid == 0) pk = ld_agent(prog + (k + 1) * nbt + bt);
+  if constexpr (X3) {
+    // dgi of this cell as operand planes of the products that consume it (dpre = dgi W_c sums over gate columns: row planes;
+    // dW_c = dgi^T c sums over frames: k-major planes; include/lfi.h), straight from the bf16 hi / lo LDS images Q1 left: one
+    // 16-byte LDS read and one 16-byte store per 8 values and plane, by the waves that own no channel tile and idle through Q3
+    if (f.bDgiR && !tc) {
+      const int ntc = (C + 15) >> 4;                 // channel-tile waves are waves 0 .. ntc - 1
+      const int ne = NT - ntc * 64, et = tid - ntc * 64;
+      const long gr0 = kf + b0;                      // row of the (Ks F x G) matrix: flow step k, frame n B + b0 (+ i)
+      const int nktG = G >> 4;
+      const long nktKF = ((long)f.Ks * f.F) >> 4;
+      char* rbase = reinterpret_cast<char*>(f.bDgiR) + ((gr0 >> 5) * nktG * 2) * 1024 + (gr0 & 16) * 16;
+      char* tbase = reinterpret_cast<char*>(f.bDgiT) + ((gr0 >> 4) * 2) * 1024;
+      for (int u = et; u < 4 * G; u += ne) {
+        const bool isT = u >= 2 * G;
+        const int v = isT ? u - 2 * G : u;
+        const int i = v & 15, q = v >> 4;
+        int so;
+        char* dst;
+        if (!isT) {          // q = 2 kt + h: lane (row, h) of row-plane block (row tile, kt)
+          so = i * ldx + (q >> 1) * 16 + (q & 1) * 8;
+          dst = rbase + (long)(q >> 1) * 2048 + (i + 32 * (q & 1)) * 16;
+        } else {             // q = 4 mt + c4: chunk c4 of k row i of k-major block (mt, k-tile of these 16 frames)
+          so = i * ldx + (q >> 2) * 32 + (q & 3) * 8;
+          dst = tbase + (long)(q >> 2) * nktKF * 2048 + lfi_t_plane_offset(i, q & 3);
+        }
+        const uint4 h = *reinterpret_cast<const uint4*>(GiH + so), l = *reinterpret_cast<const uint4*>(GiL + so);
+        *reinterpret_cast<uint4*>(dst) = h;
+        *reinterpret_cast<uint4*>(dst + 1024) = l;
+      }
+    }
+  }
   if (tc) {
     const f32x4 acc = mma16_reg<FB_C>(Dy + kq * LT + l15, wq3, nbC);
     const int c = tcol;
@@ -2427,7 +2459,8 @@ __global__ __launch_bounds__(256) void flow_prep_pad_kernel(FlowK f, float* pW, 
 
 // bf16 hi / lo fragment images of the backward recurrent weights for the bf16 x 3 walk. which 0: bwh (k = hidden of gate g,
 // col = hidden: W_hh[g*H + k][col]); 1: bwz (col = z channel: W_ih[g*H + k][col]). Entry (g, B, col, kq) holds the eight k of
-// slot order k = 32 B + 16 (i >> 2) + 4 (i & 3) + kq (x3_a reads the LDS operand in the same order).
+// k = 32 B + 8 kq + i, the natural operand order of v_mfma_f32_16x16x32_bf16: the backward walk's d(gate) LDS images are then
+// plain row-major [16 rows][gate columns] and double as the source of the dgi operand planes it emits (lfi_flow_seq_bwd_planes).
 __global__ __launch_bounds__(256) void flow_prep_x3_kernel(FlowK f, uint4* xbwh, uint4* xbwz) {
   const int k = blockIdx.y, which = blockIdx.z;
   const int H = f.H, Ch = f.Ch, I = f.I, NG = f.NG, H16 = f.H16;
@@ -2445,7 +2478,7 @@ __global__ __launch_bounds__(256) void flow_prep_x3_kernel(FlowK f, uint4* xbwh,
     float v[8];
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      const int kk = 32 * B + 16 * (i >> 2) + 4 * (i & 3) + kq;
+      const int kk = 32 * B + 8 * kq + i;
       float x = 0.0f;
       if (kk < H) {
         if (which == 0) { if (col < H) x = whh[((long)g * H + kk) * H + col]; }
@@ -3031,14 +3064,36 @@ extern "C" int lfi_flow_seq_fwd(const lfi_flow_dims* d, const lfi_flow_params* p
   return LFI_OK;
 }
 
+// Can the backward walk of these dims leave dgi as operand planes? It takes the persistent walk with bf16x3 recurrent products
+// (whose d(gate) LDS images are the source), gate columns that are the stash's (H a multiple of 32: no padding columns) and
+// batch tiles that pair up into whole 32-row plane tiles (B a multiple of 32).
+static bool flow_bwd_planes_ok(const lfi_flow_dims* d) {
+  if (!d || d->lstm || !(d->gemm_precision & 1) || d->H % 32 != 0 || d->B % 32 != 0) return false;
+  const int Ch = d->C / 2, C2 = d->C - Ch, Cout = d->affine ? 2 * C2 : C2;
+  return flow_fast_ok(d->C, d->H, Cout) && !flow_force_generic() && flow_pipe_enabled() && flow_pipe_x3_enabled() && 3 * d->H >= 128;
+}
+extern "C" int lfi_flow_bwd_emits_planes(const lfi_flow_dims* d) { return flow_bwd_planes_ok(d) ? 1 : 0; }
+
 extern "C" int lfi_flow_seq_bwd(const lfi_flow_dims* d, const lfi_flow_params* p, const float* prep, const float* stash,
                                 float gscale, float* bstash, void* stream) {
+  return lfi_flow_seq_bwd_planes(d, p, prep, stash, gscale, bstash, nullptr, nullptr, stream);
+}
+
+extern "C" int lfi_flow_seq_bwd_planes(const lfi_flow_dims* d, const lfi_flow_params* p, const float* prep, const float* stash,
+                                       float gscale, float* bstash, void* dgi_rows, void* dgi_kmajor, void* stream) {
   FlowK f = {};
   int rc = fill_flow(d, p, prep, &f, "lfi_flow_seq_bwd");
   if (rc) return rc;
   LFI_REQUIRE(prep && stash && bstash, "lfi_flow_seq_bwd: null pointer");
+  LFI_REQUIRE((dgi_rows == nullptr) == (dgi_kmajor == nullptr), "lfi_flow_seq_bwd_planes: give both plane buffers or neither");
+  LFI_REQUIRE(!dgi_rows || flow_bwd_planes_ok(d), "lfi_flow_seq_bwd_planes: these dims / switches cannot emit planes "
+              "(lfi_flow_bwd_emits_planes returns 0)");
+  LFI_REQUIRE(((reinterpret_cast<uintptr_t>(dgi_rows) | reinterpret_cast<uintptr_t>(dgi_kmajor)) & 15) == 0,
+              "lfi_flow_seq_bwd_planes: planes must be 16-byte aligned");
   bind_stash(&f, (float*)stash);
   bind_bstash(&f, bstash);
+  f.bDgiR = reinterpret_cast<__bf16*>(dgi_rows);
+  f.bDgiT = reinterpret_cast<__bf16*>(dgi_kmajor);
   f.gscale = gscale;
   hipStream_t st = (hipStream_t)stream;
   const bool fast = flow_fast_ok(f.C, f.H, f.Cout) && !flow_force_generic();
@@ -3098,7 +3153,7 @@ extern "C" int lfi_flow_param_grads(const lfi_flow_dims* d, const lfi_flow_param
   FlowK f = {};
   int rc = fill_flow(d, p, prep, &f, "lfi_flow_param_grads");
   if (rc) return rc;
-  LFI_REQUIRE(prep && stash && bstash && c && g && work, "lfi_flow_param_grads: null pointer");
+  LFI_REQUIRE(prep && stash && bstash && g && work, "lfi_flow_param_grads: null pointer");
   bind_stash(&f, (float*)stash);
   bind_bstash(&f, (float*)bstash);
   const int Ks = f.Ks, F = f.F, B = f.B, C = f.C, H = f.H, G = f.G, I = f.I, Cout = f.Cout, Ch = f.Ch, D = f.D;
@@ -3129,9 +3184,12 @@ extern "C" int lfi_flow_param_grads(const lfi_flow_dims* d, const lfi_flow_param
   };
   // w_ih[k][:, Ch:] (G x D) = dgi[k]^T c[:, kD:(k+1)D]: the one MFMA-bound product (it reads c: before the caller's dpre
   // product overwrites it)
-  q.M = G; q.N = D; q.splitk = fill_split(G, D, F); q.A = f.bDgi; q.lda = G; q.strideA = (long)F * G; q.B = c; q.ldb = ldc; q.strideB = D;
-  q.C = g->w_ih + Ch; q.ldc = I; q.strideC = (long)G * I;
-  if ((rc = lfi_gemm_f32(&q, stream))) return rc;
+  // (c == NULL: the caller runs this product on operand planes itself - lfi_gemm_planes on the walk's dgi planes and c's)
+  if (c) {
+    q.M = G; q.N = D; q.splitk = fill_split(G, D, F); q.A = f.bDgi; q.lda = G; q.strideA = (long)F * G; q.B = c; q.ldb = ldc; q.strideB = D;
+    q.C = g->w_ih + Ch; q.ldc = I; q.strideC = (long)G * I;
+    if ((rc = lfi_gemm_f32(&q, stream))) return rc;
+  }
   // The other products are thin (K = F frames, a few output tiles per step), HBM-bound at 3 - 4 TB/s. (Moving them to
   // bias_stream as well, next to the caller's MFMA-bound products, was measured no better than leaving them here: same-box
   // A/B 0.18 ms per step gained with them there, 0.21 ms without.)

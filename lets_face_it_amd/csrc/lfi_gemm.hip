@@ -10,237 +10,10 @@
 // ds_read_b32 of 32 consecutive floats per half-wave; register-staged double buffering (global loads of tile t+1
 // in flight under the MFMAs of tile t, one barrier per k-tile). Tiles are dealt to XCDs in contiguous runs so the
 // blocks that share an A panel share an L2.
-#include <stdarg.h>
-#include <stdio.h>
-#include <stdlib.h>
-
-#include "lfi_common.h"
+#include "lfi_gemm_common.h"
 
 namespace {
 
-#ifndef LFI_GEMM_BKT
-#define LFI_GEMM_BKT 16
-#endif
-#ifndef LFI_GEMM_LDSPIPE
-#define LFI_GEMM_LDSPIPE 1
-#endif
-constexpr int BKT = LFI_GEMM_BKT;  // k-tile
-// XT (template parameter of the bf16x3 kernels): 0 = lean; 1 = + per-tile column sums in the wide epilogue (colpart);
-// 2 = + runtime skipping of the a_lo b_hi / a_hi b_lo products (measurement builds of the precision sweep). Compiled in
-// unconditionally, the skip branches alone cost the 256 x 256 kernels 16 - 148 bytes of scratch per lane at their 128-VGPR cap
-// (the sampler's F x 8192 x 640 product ran 4x slower): they are their own instantiations.
-#define LFI_GSKIP(bit) (XT >= 2 && (g.skip & (bit)))
-
-struct GemmArgs {
-  int M, N, K;
-  const float* A; long lda;
-  const float* B; long ldb;
-  float* C; long ldc;
-  const float* bias;
-  const float* G; long ldg;
-  long strideA, strideB, strideC, strideBias, strideG;
-  int accumulate, act;
-  float slope;
-  int splitk, kchunk;
-  float* work;
-  int tiles_m, tiles_n;
-  int vecA, vecB;  // operand rows are 16-byte aligned and 4-float granular: 16-byte global loads are legal
-  int vecC;        // the same for C (and G): the epilogue goes through LDS with 16-byte row-wise loads / stores
-  // gemm_planes_256_kernel only: operands as pre-split bf16 hi / lo planes in MFMA fragment order (lfi_planes_from_f32)
-  const __bf16* Ap; const __bf16* Bp;   // block ((rt * nkt_op + kt) * 2 + plane) * 512 bf16, rt = 32-row tile, kt = 16-k tile
-  int nkt, nktA, nktB;                  // k-tiles of this product; k-tiles per row tile in either plane buffer
-  long pstrideA, pstrideB;              // bf16 elements between batch entries
-  float* colpart; long ldpart;   // wide epilogue only: per (row tile, pass) column sums of the stored result (lfi_gemm_desc)
-  int gm;     // tile rows per group of the XCD-contiguous tile walk (gemm_tile_of_block); 0 = 8
-  int skip;   // bf16x3 kernels: bit 0 drops the a_lo * b_hi product, bit 1 the a_hi * b_lo product (lfi_gemm_desc.precision
-              // bits 8 / 9; tools/precision_sweep.py). 0 = all three products.
-};
-
-__device__ __forceinline__ float apply_act(float v, int act, float slope, const float* G, long gidx) {
-  if (act == 1) return v > 0.0f ? v : v * slope;
-  if (act == 2) return G[gidx] > 0.0f ? v : v * slope;
-  return v;
-}
-
-// Accumulator tile -> C (or the split-K workspace): bias, activation, accumulate. acc[mt][nt] register r holds
-// (row (r&3) + 8*(r>>2) + 4*half, col l31) of the 32 x 32 tile (mt, nt) of this wave's 64 x 64 patch.
-__device__ __forceinline__ void gemm_epilogue(const GemmArgs& g, const f32x16 (&acc)[2][2], int m0, int n0, int wm, int wn,
-                                              int l31, int half, int batch, int split) {
-  const bool partial = g.splitk > 1;
-  float* __restrict__ Cb = partial ? g.work + ((long)batch * g.splitk + split) * (long)g.M * g.N : g.C + batch * g.strideC;
-  const long ldc = partial ? g.N : g.ldc;
-  const float* bias = g.bias ? g.bias + batch * g.strideBias : nullptr;
-  const float* G = g.G ? g.G + batch * g.strideG : nullptr;
-  const bool need_c = !partial && g.accumulate != 0, need_g = !partial && g.act == 2;
-#pragma unroll
-  for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-      const int col = n0 + wn * 64 + nt * 32 + l31;
-      if (col >= g.N) continue;
-      const float bv = (!partial && bias) ? bias[col] : 0.0f;
-      // operands of the epilogue first, all 16 in flight (C may alias G - the in-place dpre product - so the compiler
-      // cannot hoist these loads over the stores below by itself: one exposed HBM round trip per element otherwise)
-      float cold[16], gold[16];
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = min(m0 + wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half, g.M - 1);
-        cold[r] = need_c ? Cb[(long)row * ldc + col] : 0.0f;
-        gold[r] = need_g ? G[(long)row * g.ldg + col] : 1.0f;
-      }
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = m0 + wm * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        if (row >= g.M) continue;
-        float v = acc[mt][nt][r];
-        if (!partial) {
-          v += bv;
-          if (g.accumulate == 2) v += cold[r];
-          if (g.act == 1) v = v > 0.0f ? v : v * g.slope;
-          else if (g.act == 2) v = gold[r] > 0.0f ? v : v * g.slope;
-          if (g.accumulate == 1) v += cold[r];
-        }
-        Cb[(long)row * ldc + col] = v;
-      }
-    }
-}
-
-template <int BN>
-__device__ __forceinline__ void gemm_epilogue_n(const GemmArgs& g, const f32x16 (&acc)[2][2], int m0, int n0, int wm, int wn,
-                                                int l31, int half, int batch, int split) {
-  gemm_epilogue(g, acc, m0, n0, wm, wn, l31, half, batch, split);
-}
-
-// Wide epilogue. The accumulator layout gives a lane 32-bit elements two rows apart: written straight from registers, a
-// 128 x 128 tile costs 64 four-byte store instructions per lane, and an epilogue operand (G of the in-place dpre product, C
-// when accumulating) as many four-byte loads - measured: the G loads alone doubled the dpre product's time. Instead the
-// tile goes through LDS (free after the main loop): operand tile in with 16-byte row-wise loads, each lane combines its own
-// elements in place, result tile out with 16-byte row-wise stores (512 contiguous bytes per 32 lanes).
-// `rows` rows of the block tile per pass (the LDS image is rows x (BN + 4) floats); waves whose 64-row patch is in the pass
-// take part in the register phase, all 256 threads in the row-wise phases.
-template <int BN, int NTH = 256, int MT = 2, bool COLP = false>
-__device__ __forceinline__ void gemm_epilogue_wide(const GemmArgs& g, const f32x16 (&acc)[MT][2], float* lds, int rows_per_pass,
-                                                   int m0, int n0, int wm, int wn, int l31, int half, int batch, int split, int bm,
-                                                   bool has_acc = true) {
-  constexpr int WLD = BN + 4;       // LDS row pitch (floats)
-  constexpr int F4 = BN / 4;        // float4 per tile row
-  constexpr int SWEEP = NTH / F4;   // tile rows per row-wise sweep
-  const int tid = threadIdx.x;
-  const bool partial = g.splitk > 1;
-  float* __restrict__ Cb = partial ? g.work + ((long)batch * g.splitk + split) * (long)g.M * g.N : g.C + batch * g.strideC;
-  const long ldc = partial ? g.N : g.ldc;
-  const float* bias = g.bias ? g.bias + batch * g.strideBias : nullptr;
-  const float* G = g.G ? g.G + batch * g.strideG : nullptr;
-  const bool need_c = !partial && g.accumulate != 0, need_g = !partial && g.act == 2;
-  const int rrow = tid / F4, c4 = (tid % F4) * 4;  // row-wise phases: SWEEP rows x F4 float4 per sweep
-  const int col_g = n0 + c4;
-  for (int p0 = 0; p0 < bm; p0 += rows_per_pass) {
-    if (need_c || need_g) {  // operand tile in (never both: the host keeps act 2 + accumulate on the narrow path)
-      const float* src = need_g ? G : Cb;
-      const long lds_src = need_g ? g.ldg : ldc;
-      for (int r = rrow; r < rows_per_pass; r += SWEEP) {
-        const int row = m0 + p0 + r;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (row < g.M && col_g < g.N) {
-          if (col_g + 3 < g.N) v = *reinterpret_cast<const f32x4*>(src + (long)row * lds_src + col_g);
-          else
-            for (int j = 0; j < 4; ++j)
-              if (col_g + j < g.N) v[j] = src[(long)row * lds_src + col_g + j];
-        }
-        *reinterpret_cast<f32x4*>(lds + r * WLD + c4) = v;
-      }
-      __syncthreads();
-    }
-    if (has_acc) {   // a wave's patch is MT x 32 rows from wm * MT * 32: the row tiles that lie in this pass take part
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
-        if (wm * MT * 32 + mt * 32 >= p0 && wm * MT * 32 + mt * 32 < p0 + rows_per_pass)
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
-          const int cl = wn * 64 + nt * 32 + l31;
-          const int col = n0 + cl;
-          const float bv = (!partial && bias && col < g.N) ? bias[col] : 0.0f;
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int rl = wm * MT * 32 - p0 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            float v = acc[mt][nt][r];
-            if (!partial) {
-              v += bv;
-              const float o = (need_c || need_g) ? lds[rl * WLD + cl] : 0.0f;
-              if (g.accumulate == 2) v += o;
-              if (g.act == 1) v = v > 0.0f ? v : v * g.slope;
-              else if (g.act == 2) v = o > 0.0f ? v : v * g.slope;
-              if (g.accumulate == 1) v += o;
-            }
-            lds[rl * WLD + cl] = v;
-          }
-        }
-    }
-    __syncthreads();
-    f32x4 csum = {0.f, 0.f, 0.f, 0.f};   // (dead code unless COLP)
-    for (int r = rrow; r < rows_per_pass; r += SWEEP) {  // result tile out
-      const int row = m0 + p0 + r;
-      if (row < g.M && col_g < g.N) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(lds + r * WLD + c4);
-        if (COLP) csum += v;
-        // written once, read by a later kernel: non-temporal, so the result tile does not push the operand panels the other
-        // workgroups are re-reading out of L2 (measured -1.5 .. -2 % on the three cond_transform products)
-        // (split-K partial sums are read back at once by the reduce kernel: those stay cacheable)
-        if (col_g + 3 < g.N) {
-#ifndef LFI_EPI_NT_MODE
-#define LFI_EPI_NT_MODE 2   // 0 never, 1 always, 2 final results only
-#endif
-          if (LFI_EPI_NT_MODE == 0 || (LFI_EPI_NT_MODE == 2 && partial)) *reinterpret_cast<f32x4*>(Cb + (long)row * ldc + col_g) = v;
-          else __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(Cb + (long)row * ldc + col_g));
-        }
-        else
-          for (int j = 0; j < 4; ++j)
-            if (col_g + j < g.N) Cb[(long)row * ldc + col_g + j] = v[j];
-      }
-    }
-    if (COLP && g.colpart && !partial) {
-      // column sums of this pass's rows (bias gradients without a second pass over C): SWEEP partial rows through LDS, added
-      // in a fixed order; row (tile row * passes + pass) of the partial matrix, columns as in C (batch entries side by side)
-      __syncthreads();
-      *reinterpret_cast<f32x4*>(lds + rrow * WLD + c4) = csum;
-      __syncthreads();
-      if (tid < BN && n0 + tid < g.N) {
-        float v = 0.0f;
-        for (int i = 0; i < SWEEP; ++i) v += lds[i * WLD + tid];
-        const int npass = (bm + rows_per_pass - 1) / rows_per_pass;
-        g.colpart[((long)(m0 / bm) * npass + p0 / rows_per_pass) * g.ldpart + batch * g.strideC + n0 + tid] = v;
-      }
-      __syncthreads();
-    } else if (p0 + rows_per_pass < bm) __syncthreads();
-  }
-}
-
-// XCD-aware, grouped work order shared by both GEMM kernels: workgroups b, b+8, ... share an XCD (round-robin dispatch over
-// the linearised grid). Each XCD gets a contiguous run of (split, batch, tile) work items (bijective for any grid size),
-// so that all tiles of one K-split / one batch entry - which re-read the same operand panels - meet in ONE 4 MB L2 instead
-// of fetching them from HBM once per XCD (the long-K weight-gradient products have 12 tiles per split: spread over the
-// XCDs their B panel was fetched up to 6 times). Inside a batch entry tiles are walked in groups of GM tile-rows column by
-// column so the ~100 tiles an XCD has in flight form a compact GM x 12 patch.
-__device__ __forceinline__ void gemm_tile_of_block(const GemmArgs& g, int* tm, int* tn, int* batch, int* split) {
-  const int ntile = g.tiles_m * g.tiles_n;
-  const long total = (long)gridDim.x * gridDim.y * gridDim.z;
-  long lin = blockIdx.x + (long)gridDim.x * (blockIdx.y + (long)gridDim.y * blockIdx.z);
-  {
-    const long q = total >> 3, idx = lin >> 3;
-    const int r = (int)(total & 7), xcd = (int)(lin & 7);
-    lin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-  }
-  int bid = (int)(lin % ntile);
-  const long rest = lin / ntile;
-  *batch = (int)(rest % gridDim.y);
-  *split = (int)(rest / gridDim.y);
-  const int GM = g.gm > 0 ? g.gm : 8;
-  const int per_group = GM * g.tiles_n;
-  const int grp = bid / per_group, in_grp = bid - grp * per_group;
-  const int rows_here = min(GM, g.tiles_m - grp * GM);
-  *tm = grp * GM + in_grp % rows_here;
-  *tn = in_grp / rows_here;
-}
 
 // LDS images (floats). A k-contiguous operand keeps its rows: [mn][BKT + 4] (80-byte rows: 16-B aligned for
 // ds_write_b128 / ds_read_b128, and 5*row mod 16 distinct over any 16 rows mod 16 -> conflict-free b128 reads). An
@@ -415,12 +188,9 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(GemmArgs g) {
 // (80 bytes: 16-byte aligned fragment reads, conflict-free by the same 5*row mod 16 argument as the fp32 kernel),
 // four images per buffer (A hi, A lo, B hi, B lo), two buffers = 80 KB -> two workgroups per CU.
 // Only 16-byte aligned operands take this path (the host falls back to the exact fp32 kernel otherwise).
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 constexpr int XBK = 32;
 constexpr int XROW = XBK + 8;                 // bf16 elements per LDS row
 constexpr int XIMG = 128 * XROW;              // bf16 elements per image
-extern __shared__ __attribute__((aligned(16))) __bf16 xsmem[];
 
 __device__ __forceinline__ void split4(const f32x4 v, bf16x4* hi, bf16x4* lo) {
 #pragma unroll
@@ -593,18 +363,6 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(GemmArgs g) {
 // concurrently: the split of tile t + 1 executes under the MFMAs of tile t. One barrier per k-tile as before; loads run
 // two tiles ahead (two register sets); full k-tiles take a predicate-free path (rows past M / N are clamped: they only
 // feed outputs that are never stored), only the last partial k-tile masks.
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
-typedef float float2_t __attribute__((ext_vector_type(2)));
-
-// (hi, lo) bf16 pairs of (a, b): 6 VALU instructions (cvt_pk, shift, and, 2 sub, cvt_pk)
-__device__ __forceinline__ void split2(float a, float b, unsigned* hi, unsigned* lo) {
-  const bf16x2 h = __builtin_convertvector((float2_t){a, b}, bf16x2);
-  const unsigned hb = __builtin_bit_cast(unsigned, h);
-  const float ha = __builtin_bit_cast(float, hb << 16), hbv = __builtin_bit_cast(float, hb & 0xffff0000u);
-  const bf16x2 l = __builtin_convertvector((float2_t){a - ha, b - hbv}, bf16x2);
-  *hi = hb;
-  *lo = __builtin_bit_cast(unsigned, l);
-}
 
 template <bool KC>
 struct WStager {
@@ -1421,458 +1179,6 @@ __global__ __launch_bounds__(Y2NT) void gemm_bf16x3_256w_kernel(GemmArgs g) {
 #endif
 }
 
-// ---------------------------------------------------------------------------------------------- bf16 x 3 on pre-split planes
-// The kernels above redo the fp32 -> bf16 hi / lo split of every operand element in EVERY workgroup that touches it (the
-// cond_transform forward product converts its A panel 32 times and its B panel 56 times), through VGPRs and ds_write, and a
-// k-tile's phases (global load, convert + LDS store, fragment reads, MFMA) do not overlap: 2750 cycles per k-tile against
-// 1536 of MFMA issue (profiles/, round 1). Here the operands arrive ALREADY split (lfi_planes_from_f32: once per operand, by a
-// streaming kernel) and ALREADY in MFMA fragment order, so a k-tile of a 256-row panel is 16 contiguous 1-KB blocks that go
-// global -> LDS by LDS-DMA (global_load_lds_dwordx4: no VGPR, no VALU, no ds_write) and every fragment read is a linear,
-// conflict-free ds_read_b128 (block base + lane * 16).
-//   workgroup = 256 x 256 tile, 16 waves x (64 x 64) patches (as gemm_bf16x3_256_kernel, so the wide epilogue is shared);
-//   ring of PRING = 4 slots of one 16-deep k-tile each: [A: 8 row tiles x {hi, lo} x 1 KB][B: the same] = 32 KB;
-//   wave w fetches blocks 2w, 2w + 1 of a slot (one row tile of one operand, both planes: 2 KB contiguous in memory).
-// Phase t (one barrier per k-tile; rules of cdna_hip_programming.md par. 5, "Pipelining across barriers"):
-//     DMA tile t + 4 -> slot t % 4 (whose fragments were read in phase t - 1, retired by that phase's lgkmcnt(0) + barrier)
-//     MFMAs of tile t on fragments already in registers; the fragments of tile t + 1 are read under them, each register
-//       group as soon as its last MFMA of tile t has issued (A of row tile 0, then A of row tile 1, then B)
-//     s_waitcnt vmcnt(4): this wave's DMAs of tile t + 2 have landed (t + 3, t + 4 stay in flight);  lgkmcnt(0);  s_barrier
-//   so a tile is read one phase after the wait + barrier that retired it, and restaged one phase after its last read.
-// Tiles past the end are fetched again from the last real tile (never used): the counted waits then need no tail cases.
-constexpr int PRING = 4;
-constexpr int PSLOT = 32 * 1024;   // bytes
-
-typedef __attribute__((address_space(3))) void plds_void;
-typedef __attribute__((address_space(1))) const void pglb_void;
-
-__global__ __launch_bounds__(1024) void gemm_planes_256_kernel(GemmArgs g) {
-  constexpr int XT = 2;   // skip switch compiled in (no register cost here)
-  const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int l31 = lane & 31, half = lane >> 5;
-  int tm, tn, batch, split;
-  gemm_tile_of_block(g, &tm, &tn, &batch, &split);
-  const int m0 = tm * 256, n0 = tn * 256;
-  const int nkt = g.nkt;
-  char* lds = reinterpret_cast<char*>(xsmem);
-  // this wave's DMA source: operand `op`, row tile `rtl` of the workgroup's panel, k-tile 0, plane 0, + lane * 16 bytes
-  const int op = wave >> 3, rtl = wave & 7;
-  const char* src = op ? reinterpret_cast<const char*>(g.Bp + batch * g.pstrideB) + (long)(tn * 8 + rtl) * g.nktB * 2048
-                       : reinterpret_cast<const char*>(g.Ap + batch * g.pstrideA) + (long)(tm * 8 + rtl) * g.nktA * 2048;
-  src += lane * 16;
-  const int dma_off = (op * 16 + rtl * 2) * 1024;
-  auto dma = [&](int kt, int slot) {
-#ifndef PG_NO_DMA
-    const char* p = src + (long)min(kt, nkt - 1) * 2048;
-    char* d = lds + slot * PSLOT + dma_off;   // wave-uniform
-    __builtin_amdgcn_global_load_lds((pglb_void*)p, (plds_void*)d, 16, 0, 0);
-    __builtin_amdgcn_global_load_lds((pglb_void*)(p + 1024), (plds_void*)(d + 1024), 16, 0, 0);
-#endif
-  };
-  const int wm = wave >> 2, wn = wave & 3;
-  const int fa = (wm * 4) * 1024 + lane * 16;              // A fragment (mt, plane) at fa + (mt * 2 + plane) * 1024
-  const int fb = 16 * 1024 + (wn * 4) * 1024 + lane * 16;  // B fragment (nt, plane) at fb + (nt * 2 + plane) * 1024
-#ifdef PG_NO_READ
-  auto frag = [&](int slot, int off) { bf16x8 z; for (int e = 0; e < 8; ++e) z[e] = (__bf16)(float)(slot + off); asm volatile("" : "+v"(z)); return z; };
-#else
-  auto frag = [&](int slot, int off) { return *reinterpret_cast<const bf16x8*>(lds + slot * PSLOT + off); };
-#endif
-#ifdef PG_NO_MMA
-#define PG_MFMA(a, b, c) (c)
-#else
-#define PG_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
-#endif
-
-  f32x16 acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-
-  bf16x8 ah[2], al[2], bh[2], bl[2];
-  dma(0, 0); dma(1, 1); dma(2, 2); dma(3, 3);
-  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-#pragma unroll
-  for (int t2 = 0; t2 < 2; ++t2) {
-    ah[t2] = frag(0, fa + (t2 * 2) * 1024); al[t2] = frag(0, fa + (t2 * 2 + 1) * 1024);
-    bh[t2] = frag(0, fb + (t2 * 2) * 1024); bl[t2] = frag(0, fb + (t2 * 2 + 1) * 1024);
-  }
-  asm volatile("s_waitcnt vmcnt(4)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-
-#ifdef PG_STAMPS
-  unsigned long long pg_issue = 0, pg_vm = 0, pg_lgkm = 0, pg_bar = 0;
-  const unsigned long long pg_t0 = __builtin_amdgcn_s_memtime(), pg_r0 = __builtin_amdgcn_s_memrealtime();
-  unsigned long long pg_top = pg_t0;
-#endif
-  // The four waves that share a SIMD (waves w, w + 4, w + 8, w + 12: wm = 0 .. 3) issue their two DMA pieces at four different
-  // points of the phase, one before each quarter of the MFMAs: a piece costs its wave 100 - 200 cycles of issue, and with all
-  // sixteen waves issuing theirs right after the barrier the matrix pipe sat idle that long every phase (ingredient-removal
-  // builds, tools/pgemm_ablate.sh: the DMA cost 0.22 of 0.67 ms that way).
-  for (int t = 0; t < nkt; ++t) {
-    const int cur = t & 3, nxt = (t + 1) & 3;
-    bf16x8 nah[2], nal[2], nbh[2], nbl[2];
-    if (wm == 0) dma(t + 4, cur);
-    __builtin_amdgcn_sched_barrier(0);
-    if (!LFI_GSKIP(1)) acc[0][0] = PG_MFMA(al[0], bh[0], acc[0][0]);
-    if (!LFI_GSKIP(2)) acc[0][0] = PG_MFMA(ah[0], bl[0], acc[0][0]);
-    acc[0][0] = PG_MFMA(ah[0], bh[0], acc[0][0]);
-    __builtin_amdgcn_sched_barrier(0);
-    if (wm == 1) dma(t + 4, cur);
-    __builtin_amdgcn_sched_barrier(0);
-    if (!LFI_GSKIP(1)) acc[0][1] = PG_MFMA(al[0], bh[1], acc[0][1]);
-    if (!LFI_GSKIP(2)) acc[0][1] = PG_MFMA(ah[0], bl[1], acc[0][1]);
-    acc[0][1] = PG_MFMA(ah[0], bh[1], acc[0][1]);
-    __builtin_amdgcn_sched_barrier(0);
-    // tile t + 1: A fragments of row tile 0 into the registers just freed, B fragments into a second set
-    nah[0] = frag(nxt, fa); nal[0] = frag(nxt, fa + 1024);
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt) { nbh[nt] = frag(nxt, fb + (nt * 2) * 1024); nbl[nt] = frag(nxt, fb + (nt * 2 + 1) * 1024); }
-    __builtin_amdgcn_sched_barrier(0);
-    if (wm == 2) dma(t + 4, cur);
-    __builtin_amdgcn_sched_barrier(0);
-    if (!LFI_GSKIP(1)) acc[1][0] = PG_MFMA(al[1], bh[0], acc[1][0]);
-    if (!LFI_GSKIP(2)) acc[1][0] = PG_MFMA(ah[1], bl[0], acc[1][0]);
-    acc[1][0] = PG_MFMA(ah[1], bh[0], acc[1][0]);
-    __builtin_amdgcn_sched_barrier(0);
-    if (wm == 3) dma(t + 4, cur);
-    __builtin_amdgcn_sched_barrier(0);
-    if (!LFI_GSKIP(1)) acc[1][1] = PG_MFMA(al[1], bh[1], acc[1][1]);
-    if (!LFI_GSKIP(2)) acc[1][1] = PG_MFMA(ah[1], bl[1], acc[1][1]);
-    acc[1][1] = PG_MFMA(ah[1], bh[1], acc[1][1]);
-    __builtin_amdgcn_sched_barrier(0);
-    nah[1] = frag(nxt, fa + 2048); nal[1] = frag(nxt, fa + 3072);
-#ifdef PG_STAMPS
-    const unsigned long long s0 = __builtin_amdgcn_s_memtime();
-    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    const unsigned long long s1 = __builtin_amdgcn_s_memtime();
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    const unsigned long long s2 = __builtin_amdgcn_s_memtime();
-    __builtin_amdgcn_s_barrier();
-    const unsigned long long s3 = __builtin_amdgcn_s_memtime();
-    pg_issue += s0 - pg_top; pg_vm += s1 - s0; pg_lgkm += s2 - s1; pg_bar += s3 - s2; pg_top = s3;
-#else
-    asm volatile("s_waitcnt vmcnt(4)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-#endif
-#pragma unroll
-    for (int i = 0; i < 2; ++i) { ah[i] = nah[i]; al[i] = nal[i]; bh[i] = nbh[i]; bl[i] = nbl[i]; }
-  }
-#ifdef PG_STAMPS
-  if (g.work && lane == 0 && (wave == 0 || wave == 13) && blockIdx.x == 300) {
-    const unsigned long long r1 = __builtin_amdgcn_s_memrealtime();
-    float* o = g.work + (wave ? 8 : 0);
-    o[0] = (float)pg_issue; o[1] = (float)pg_vm; o[2] = (float)pg_lgkm; o[3] = (float)pg_bar; o[4] = (float)nkt;
-    o[5] = (float)(pg_top - pg_t0); o[6] = (float)(r1 - pg_r0);
-  }
-#endif
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the re-fetched tail tiles: landed before the epilogue reuses the ring
-  __syncthreads();
-#ifdef PG_NO_EPI
-  if (acc[0][0][0] + acc[0][1][3] + acc[1][0][5] + acc[1][1][7] == 12345.678f) g.C[tid] = 1.0f;
-  return;
-#endif
-  if (g.vecC) gemm_epilogue_wide<256, 1024>(g, acc, reinterpret_cast<float*>(xsmem), LFI_EPI_ROWS, m0, n0, wm, wn, l31, half, batch, split, 256);
-  else gemm_epilogue_n<256>(g, acc, m0, n0, wm, wn, l31, half, batch, split);
-}
-
-// 128 x 256 variant, TWO workgroups per CU: 512 threads = 8 waves x (64 x 64) patches (wm = wave >> 2 in 0 .. 1, wn = wave & 3),
-// ring of 3 slots of [A: 4 row tiles x {hi, lo} x 1 KB][B: 8 x 2 x 1 KB] = 24 KB (72 KB; the wide epilogue's 64-row passes
-// of 66.5 KB fit inside), three DMA pieces per wave and k-tile. What the 256 x 256 kernel loses per k-tile to its one barrier
-// (stamps: 2060 cycles per phase against 1536 of MFMA issue; the last-dispatched waves of a SIMD wait 180, the first 1160) and
-// per tile to its epilogue (the CU's matrix pipe idle for ~16 us of every ~96 us) is filled by the other workgroup here.
-//   phase t:  DMA tile t + 3 -> slot t % 3 (its fragments were read in phase t - 1)
-//             MFMAs of tile t from registers, fragments of tile t + 1 read under them
-//             s_waitcnt vmcnt(3) (this wave's pieces of tile t + 2 landed; t + 3 in flight), lgkmcnt(0), s_barrier
-constexpr int QRING = 3;
-constexpr int QSLOT = 24 * 1024;
-
-__global__ __launch_bounds__(512, 4) void gemm_planes_128_kernel(GemmArgs g) {
-  constexpr int XT = 2;   // skip switch compiled in (no register cost here)
-  const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int l31 = lane & 31, half = lane >> 5;
-  int tm, tn, batch, split;
-  gemm_tile_of_block(g, &tm, &tn, &batch, &split);
-  const int m0 = tm * 128, n0 = tn * 256;
-  const int nkt = g.nkt;
-  char* lds = reinterpret_cast<char*>(xsmem);
-  // the slot's 24 blocks (A: 4 row tiles x 2 planes, then B: 8 x 2) are dealt to the 8 waves three at a time; a block's two
-  // planes are adjacent in memory and in the slot, so block j of the slot comes from panel-relative byte offset src_off(j)
-  const char* baseA = reinterpret_cast<const char*>(g.Ap + batch * g.pstrideA) + (long)(tm * 4) * g.nktA * 2048 + lane * 16;
-  const char* baseB = reinterpret_cast<const char*>(g.Bp + batch * g.pstrideB) + (long)(tn * 8) * g.nktB * 2048 + lane * 16;
-  const char* src[3];
-  int doff[3];
-#pragma unroll
-  for (int i = 0; i < 3; ++i) {
-    const int j = wave * 3 + i;                       // block 0 .. 23
-    const int isB = j >= 8, jj = isB ? j - 8 : j;     // (row tile, plane) = (jj >> 1, jj & 1)
-    src[i] = (isB ? baseB + (long)(jj >> 1) * g.nktB * 2048 : baseA + (long)(jj >> 1) * g.nktA * 2048) + (jj & 1) * 1024;
-    doff[i] = j * 1024;
-  }
-  auto dma = [&](int kt, int slot) {
-    const long ko = (long)min(kt, nkt - 1) * 2048;
-#pragma unroll
-    for (int i = 0; i < 3; ++i)
-      __builtin_amdgcn_global_load_lds((pglb_void*)(src[i] + ko), (plds_void*)(lds + slot * QSLOT + doff[i]), 16, 0, 0);
-  };
-  const int wm = wave >> 2, wn = wave & 3;
-  const int fa = (wm * 4) * 1024 + lane * 16;             // A fragment (mt, plane) at fa + (mt * 2 + plane) * 1024
-  const int fb = 8 * 1024 + (wn * 4) * 1024 + lane * 16;  // B fragment (nt, plane) at fb + (nt * 2 + plane) * 1024
-  auto frag = [&](int slot, int off) { return *reinterpret_cast<const bf16x8*>(lds + slot * QSLOT + off); };
-
-  f32x16 acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-
-  bf16x8 ah[2], al[2], bh[2], bl[2];
-  dma(0, 0); dma(1, 1); dma(2, 2);
-  asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-#pragma unroll
-  for (int t2 = 0; t2 < 2; ++t2) {
-    ah[t2] = frag(0, fa + (t2 * 2) * 1024); al[t2] = frag(0, fa + (t2 * 2 + 1) * 1024);
-    bh[t2] = frag(0, fb + (t2 * 2) * 1024); bl[t2] = frag(0, fb + (t2 * 2 + 1) * 1024);
-  }
-  asm volatile("s_waitcnt vmcnt(3)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-
-  int cur = 0;
-  for (int t = 0; t < nkt; ++t) {
-    const int nxt = cur == 2 ? 0 : cur + 1;
-    bf16x8 nah[2], nal[2], nbh[2], nbl[2];
-    dma(t + 3, cur);
-    __builtin_amdgcn_sched_barrier(0);
-    if (!LFI_GSKIP(1)) {
-#pragma unroll
-      for (int nt = 0; nt < 2; ++nt) acc[0][nt] = PG_MFMA(al[0], bh[nt], acc[0][nt]);
-    }
-    if (!LFI_GSKIP(2)) {
-#pragma unroll
-      for (int nt = 0; nt < 2; ++nt) acc[0][nt] = PG_MFMA(ah[0], bl[nt], acc[0][nt]);
-    }
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt) acc[0][nt] = PG_MFMA(ah[0], bh[nt], acc[0][nt]);
-    __builtin_amdgcn_sched_barrier(0);
-    nah[0] = frag(nxt, fa); nal[0] = frag(nxt, fa + 1024);
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt) { nbh[nt] = frag(nxt, fb + (nt * 2) * 1024); nbl[nt] = frag(nxt, fb + (nt * 2 + 1) * 1024); }
-    __builtin_amdgcn_sched_barrier(0);
-    if (!LFI_GSKIP(1)) {
-#pragma unroll
-      for (int nt = 0; nt < 2; ++nt) acc[1][nt] = PG_MFMA(al[1], bh[nt], acc[1][nt]);
-    }
-    if (!LFI_GSKIP(2)) {
-#pragma unroll
-      for (int nt = 0; nt < 2; ++nt) acc[1][nt] = PG_MFMA(ah[1], bl[nt], acc[1][nt]);
-    }
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt) acc[1][nt] = PG_MFMA(ah[1], bh[nt], acc[1][nt]);
-    __builtin_amdgcn_sched_barrier(0);
-    nah[1] = frag(nxt, fa + 2048); nal[1] = frag(nxt, fa + 3072);
-    asm volatile("s_waitcnt vmcnt(3)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-#pragma unroll
-    for (int i = 0; i < 2; ++i) { ah[i] = nah[i]; al[i] = nal[i]; bh[i] = nbh[i]; bl[i] = nbl[i]; }
-    cur = nxt;
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the re-fetched tail tiles: landed before the epilogue reuses the ring
-  __syncthreads();
-#ifdef PG_NO_EPI
-  if (acc[0][0][0] + acc[0][1][3] + acc[1][0][5] + acc[1][1][7] == 12345.678f) g.C[tid] = 1.0f;
-  return;
-#endif
-  if (g.vecC) gemm_epilogue_wide<256, 512>(g, acc, reinterpret_cast<float*>(xsmem), 64, m0, n0, wm, wn, l31, half, batch, split, 128);
-  else gemm_epilogue_n<256>(g, acc, m0, n0, wm, wn, l31, half, batch, split);
-}
-
-// The same 128 x 256 tile with FOUR waves of 128 x 64 patches (all four row tiles x one 64-column group each). The eight-wave
-// kernel above reads 8 KB of fragments per wave and k-tile for 12 MFMAs: 16 waves per CU x 8 ds_read_b128 x 8 cycles = 1024
-// LDS cycles per k-tile, plus 384 for the 48 KB the LDS-DMA writes, against 1536 cycles of MFMA issue per SIMD - the LDS port
-// is 92 % busy, which is what holds the matrix pipe at ~59 % of its issue rate (next to the clock). A 128 x 64 patch reads
-// 12 KB for 24 MFMAs: 768 + 384 = 1152 LDS cycles per k-tile and CU for the same 1536 of MFMA issue. Two workgroups per CU =
-// two waves per SIMD (<= 256 VGPRs: 128 of accumulators); six DMA pieces per wave and k-tile; same ring, same phase
-// structure, same order of products per accumulator (bit-identical results), the wide epilogue with MT = 4.
-__global__ __launch_bounds__(256, 2) void gemm_planes_128w4_kernel(GemmArgs g) {
-  constexpr int XT = 2;
-  const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int l31 = lane & 31, half = lane >> 5;
-  int tm, tn, batch, split;
-  gemm_tile_of_block(g, &tm, &tn, &batch, &split);
-  const int m0 = tm * 128, n0 = tn * 256;
-  const int nkt = g.nkt;
-  char* lds = reinterpret_cast<char*>(xsmem);
-  const char* baseA = reinterpret_cast<const char*>(g.Ap + batch * g.pstrideA) + (long)(tm * 4) * g.nktA * 2048 + lane * 16;
-  const char* baseB = reinterpret_cast<const char*>(g.Bp + batch * g.pstrideB) + (long)(tn * 8) * g.nktB * 2048 + lane * 16;
-  const char* src[6];
-  int doff[6];
-#pragma unroll
-  for (int i = 0; i < 6; ++i) {
-    const int j = wave * 6 + i;                       // block 0 .. 23 of the slot
-    const int isB = j >= 8, jj = isB ? j - 8 : j;     // (row tile, plane) = (jj >> 1, jj & 1)
-    src[i] = (isB ? baseB + (long)(jj >> 1) * g.nktB * 2048 : baseA + (long)(jj >> 1) * g.nktA * 2048) + (jj & 1) * 1024;
-    doff[i] = j * 1024;
-  }
-  auto dma = [&](int kt, int slot) {
-    const long ko = (long)min(kt, nkt - 1) * 2048;
-#pragma unroll
-    for (int i = 0; i < 6; ++i)
-      __builtin_amdgcn_global_load_lds((pglb_void*)(src[i] + ko), (plds_void*)(lds + slot * QSLOT + doff[i]), 16, 0, 0);
-  };
-  const int wm = 0, wn = wave;
-  const int fa = lane * 16;                               // A fragment (mt, plane) at fa + (mt * 2 + plane) * 1024
-  const int fb = 8 * 1024 + (wn * 4) * 1024 + lane * 16;  // B fragment (nt, plane) at fb + (nt * 2 + plane) * 1024
-  auto frag = [&](int slot, int off) { return *reinterpret_cast<const bf16x8*>(lds + slot * QSLOT + off); };
-
-  f32x16 acc[4][2];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-
-  bf16x8 ah[4], al[4], bh[2], bl[2];
-  dma(0, 0); dma(1, 1); dma(2, 2);
-  asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-#pragma unroll
-  for (int mt = 0; mt < 4; ++mt) { ah[mt] = frag(0, fa + (mt * 2) * 1024); al[mt] = frag(0, fa + (mt * 2 + 1) * 1024); }
-#pragma unroll
-  for (int nt = 0; nt < 2; ++nt) { bh[nt] = frag(0, fb + (nt * 2) * 1024); bl[nt] = frag(0, fb + (nt * 2 + 1) * 1024); }
-  asm volatile("s_waitcnt vmcnt(6)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
-  __builtin_amdgcn_s_barrier();
-
-  int cur = 0;
-  for (int t = 0; t < nkt; ++t) {
-    const int nxt = cur == 2 ? 0 : cur + 1;
-    bf16x8 nbh[2], nbl[2];
-    dma(t + 3, cur);
-    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-      if (!LFI_GSKIP(1)) {
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = PG_MFMA(al[mt], bh[nt], acc[mt][nt]);
-      }
-      if (!LFI_GSKIP(2)) {
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = PG_MFMA(ah[mt], bl[nt], acc[mt][nt]);
-      }
-#pragma unroll
-      for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = PG_MFMA(ah[mt], bh[nt], acc[mt][nt]);
-      __builtin_amdgcn_sched_barrier(0);
-      // row tile mt of the next k-tile into the registers just released; the B fragments into a second set along the way
-      ah[mt] = frag(nxt, fa + (mt * 2) * 1024); al[mt] = frag(nxt, fa + (mt * 2 + 1) * 1024);
-      if (mt == 1) { nbh[0] = frag(nxt, fb); nbl[0] = frag(nxt, fb + 1024); }
-      if (mt == 2) { nbh[1] = frag(nxt, fb + 2048); nbl[1] = frag(nxt, fb + 3072); }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    asm volatile("s_waitcnt vmcnt(6)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-#pragma unroll
-    for (int i = 0; i < 2; ++i) { bh[i] = nbh[i]; bl[i] = nbl[i]; }
-    cur = nxt;
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the re-fetched tail tiles: landed before the epilogue reuses the ring
-  __syncthreads();
-  if (g.vecC) gemm_epilogue_wide<256, 256, 4>(g, acc, reinterpret_cast<float*>(xsmem), 64, m0, n0, wm, wn, l31, half, batch, split, 128);
-  else {
-    // (the narrow epilogue takes 2 x 2 patches: two calls, rows 0 .. 63 and 64 .. 127)
-    f32x16 lo2[2][2], hi2[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j) { lo2[i][j] = acc[i][j]; hi2[i][j] = acc[2 + i][j]; }
-    gemm_epilogue_n<256>(g, lo2, m0, n0, 0, wn, l31, half, batch, split);
-    gemm_epilogue_n<256>(g, hi2, m0, n0, 1, wn, l31, half, batch, split);
-  }
-}
-
-// fp32 (rows x cols, row pitch ldx) -> bf16 hi / lo planes in fragment order, zero padded to rows_pad x 16 nkt:
-// block ((rt * nkt + kt) * 2 + plane), lane l of a block holds row rt * 32 + (l & 31), k = kt * 16 + 8 (l >> 5) .. + 7.
-// One thread per (block pair, lane): 8 floats in (two 16-byte loads when the row allows), 16 + 16 bytes out.
-__global__ __launch_bounds__(256) void planes_from_f32_kernel(const float* __restrict__ X, long ldx, int rows, int cols, long nblk,
-                                                             int nkt, int vec, __bf16* __restrict__ out) {
-  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < nblk * 64; idx += (long)gridDim.x * 256) {
-    const int l = (int)(idx & 63);
-    const long q = idx >> 6;
-    const int kt = (int)(q % nkt);
-    const long rt = q / nkt;
-    const long row = rt * 32 + (l & 31);
-    const int k0 = kt * 16 + 8 * (l >> 5);
-    float v[8];
-    if (row < rows && vec && k0 + 8 <= cols) {
-      const f32x4 a = *reinterpret_cast<const f32x4*>(X + row * ldx + k0), b = *reinterpret_cast<const f32x4*>(X + row * ldx + k0 + 4);
-      v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
-    } else {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = (row < rows && k0 + e < cols) ? X[row * ldx + k0 + e] : 0.0f;
-    }
-    uint4 h, lo;
-    split2(v[0], v[1], &h.x, &lo.x); split2(v[2], v[3], &h.y, &lo.y);
-    split2(v[4], v[5], &h.z, &lo.z); split2(v[6], v[7], &h.w, &lo.w);
-    uint4* dst = reinterpret_cast<uint4*>(out) + q * 128 + l;
-    dst[0] = h;
-    dst[64] = lo;
-  }
-}
-
-__global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(GemmArgs g) {
-  const long mn = (long)g.M * g.N;
-  const int batch = blockIdx.y;
-  const float* bias = g.bias ? g.bias + batch * g.strideBias : nullptr;
-  const float* G = g.G ? g.G + batch * g.strideG : nullptr;
-  float* C = g.C + batch * g.strideC;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < mn; i += (long)gridDim.x * 256) {
-    const int row = (int)(i / g.N), col = (int)(i % g.N);
-    const float* w = g.work + (long)batch * g.splitk * mn + i;
-    float v = 0.0f;
-    for (int s = 0; s < g.splitk; ++s) v += w[(long)s * mn];
-    if (bias) v += bias[col];
-    if (g.accumulate == 2) v += C[(long)row * g.ldc + col];
-    v = apply_act(v, g.act, g.slope, G, (long)row * g.ldg + col);
-    if (g.accumulate == 1) v += C[(long)row * g.ldc + col];
-    C[(long)row * g.ldc + col] = v;
-  }
-}
-
-// Four columns per thread (N, ldc, ldg multiples of 4; work, C, G 16-byte aligned): same sums in the same order as above.
-__global__ __launch_bounds__(256) void gemm_splitk_reduce4_kernel(GemmArgs g) {
-  const long mn = (long)g.M * g.N, mn4 = mn >> 2;
-  const int n4 = g.N >> 2;
-  const int batch = blockIdx.y;
-  const float* bias = g.bias ? g.bias + batch * g.strideBias : nullptr;
-  const float* G = g.G ? g.G + batch * g.strideG : nullptr;
-  float* C = g.C + batch * g.strideC;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < mn4; i += (long)gridDim.x * 256) {
-    const int row = (int)(i / n4), col = (int)(i - (long)row * n4) * 4;
-    const float* w = g.work + (long)batch * g.splitk * mn + 4 * i;
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    for (int s = 0; s < g.splitk; ++s) v += __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(w + (long)s * mn));
-    f32x4* cp = reinterpret_cast<f32x4*>(C + (long)row * g.ldc + col);
-    f32x4 c0 = {0.f, 0.f, 0.f, 0.f};
-    if (g.accumulate) c0 = *cp;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      float x = v[j];
-      if (bias) x += bias[col + j];
-      if (g.accumulate == 2) x += c0[j];
-      x = apply_act(x, g.act, g.slope, G, (long)row * g.ldg + col + j);
-      if (g.accumulate == 1) x += c0[j];
-      v[j] = x;
-    }
-    *cp = v;
-  }
-}
 
 template <int BM, int BN, int WM, int WN, bool VEC>
 void launch_gemm_v(const GemmArgs& a, int akc, int bkc, dim3 grid, hipStream_t st) {
@@ -2193,116 +1499,3 @@ extern "C" int lfi_gemm_f32(const lfi_gemm_desc* d, void* stream) {
 }
 
 
-/* ---- pre-split operand planes + the GEMM that consumes them (include/lfi.h) */
-extern "C" long lfi_planes_elems(long rows, int cols) {
-  if (rows <= 0 || cols <= 0) return 0;
-  return ((rows + 255) / 256 * 256) * (long)((cols + 15) / 16 * 16) * 2;
-}
-
-extern "C" int lfi_planes_from_f32(const float* X, long ldx, long rows, int cols, void* planes, void* stream) {
-  LFI_REQUIRE(rows >= 0 && cols >= 0, "lfi_planes_from_f32: bad dims %ld x %d", rows, cols);
-  if (rows == 0 || cols == 0) return LFI_OK;
-  LFI_REQUIRE(X && planes, "lfi_planes_from_f32: null pointer");
-  LFI_REQUIRE((reinterpret_cast<uintptr_t>(planes) & 15) == 0, "lfi_planes_from_f32: planes must be 16-byte aligned");
-  const int nkt = (cols + 15) / 16;
-  const long nblk = (rows + 255) / 256 * 8 * nkt;   // (row tile, k-tile) block pairs, rows padded to whole 256-row panels
-  const int vec = ((reinterpret_cast<uintptr_t>(X) & 15) == 0 && (ldx & 3) == 0) ? 1 : 0;
-  const long threads = nblk * 64;
-  hipLaunchKernelGGL(planes_from_f32_kernel, dim3((unsigned)min((threads + 255) / 256, 65535L * 8)), dim3(256), 0, (hipStream_t)stream,
-                     X, ldx, (int)rows, cols, nblk, nkt, vec, reinterpret_cast<__bf16*>(planes));
-  LFI_LAUNCH_CHECK("lfi_planes_from_f32");
-  return LFI_OK;
-}
-
-extern "C" int lfi_gemm_planes(const lfi_pgemm_desc* d, void* stream) {
-  LFI_REQUIRE(d, "lfi_gemm_planes: null descriptor");
-  LFI_REQUIRE(d->M >= 0 && d->N >= 0 && d->K >= 0 && d->batch >= 1 && d->batch <= 65535, "lfi_gemm_planes: bad dims M=%d N=%d K=%d batch=%d",
-              d->M, d->N, d->K, d->batch);
-  if (d->M == 0 || d->N == 0) return LFI_OK;
-  LFI_REQUIRE(d->Ap && d->Bp && d->C, "lfi_gemm_planes: null operand");
-  LFI_REQUIRE(d->K > 0, "lfi_gemm_planes: K = 0");
-  LFI_REQUIRE(d->act >= 0 && d->act <= 2 && (d->act != 2 || d->G), "lfi_gemm_planes: bad act %d", d->act);
-  const int nkt = (d->K + 15) / 16;
-  LFI_REQUIRE(d->a_nkt >= nkt && d->b_nkt >= nkt, "lfi_gemm_planes: plane buffers hold %d / %d k-tiles per row tile, the product needs %d",
-              d->a_nkt, d->b_nkt, nkt);
-  LFI_REQUIRE((reinterpret_cast<uintptr_t>(d->Ap) & 15) == 0 && (reinterpret_cast<uintptr_t>(d->Bp) & 15) == 0 &&
-              (d->a_stride & 7) == 0 && (d->b_stride & 7) == 0, "lfi_gemm_planes: planes must be 16-byte aligned");
-  GemmArgs a = {};
-  a.M = d->M; a.N = d->N; a.K = d->K;
-  a.C = d->C; a.ldc = d->ldc; a.bias = d->bias; a.G = d->G; a.ldg = d->ldg;
-  a.strideC = d->strideC; a.strideBias = d->strideBias; a.strideG = d->strideG;
-  a.accumulate = d->accumulate; a.act = d->act; a.slope = d->slope;
-  a.splitk = 1; a.kchunk = d->K; a.work = nullptr;
-#ifdef PG_STAMPS
-  a.work = reinterpret_cast<float*>(g_lfi_stamps);   // diagnostics build only (lfi_debug_set_stamps)
-#endif
-  a.Ap = reinterpret_cast<const __bf16*>(d->Ap); a.Bp = reinterpret_cast<const __bf16*>(d->Bp);
-  a.nkt = nkt; a.nktA = d->a_nkt; a.nktB = d->b_nkt; a.pstrideA = d->a_stride; a.pstrideB = d->b_stride;
-  a.skip = d->skip & 3;
-  a.colpart = nullptr; a.ldpart = 0;
-  const bool c_ok = (reinterpret_cast<uintptr_t>(d->C) & 15) == 0 && d->ldc % 4 == 0 && d->strideC % 4 == 0;
-  const bool g_ok = d->act != 2 || ((reinterpret_cast<uintptr_t>(d->G) & 15) == 0 && d->ldg % 4 == 0 && d->strideG % 4 == 0);
-  a.vecC = (c_ok && g_ok && !(d->act == 2 && d->accumulate != 0)) ? 1 : 0;
-  static int tile256 = -1;   // LFI_PGEMM_256=1: the one-workgroup-per-CU 256 x 256 kernel instead of two 128 x 256 per CU
-  if (tile256 < 0) {
-    const char* e = getenv("LFI_PGEMM_256");
-    tile256 = (e && e[0] == '1') ? 1 : 0;
-  }
-  if (tile256) {
-    a.tiles_m = lfi_cdiv(d->M, 256);
-    a.tiles_n = lfi_cdiv(d->N, 256);
-    const size_t lds_loop = (size_t)PRING * PSLOT, lds_epi = (size_t)LFI_EPI_ROWS * 260 * sizeof(float);
-    const size_t lds = lds_loop > lds_epi ? lds_loop : lds_epi;
-    static bool attr = false;
-    if (!attr) {
-      if (hipFuncSetAttribute((const void*)gemm_planes_256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
-        lfi_set_error("lfi_gemm_planes: cannot reserve %zu bytes of LDS", lds);
-        return LFI_ERR_LAUNCH;
-      }
-      attr = true;
-    }
-    dim3 grid(a.tiles_m * a.tiles_n, d->batch, 1);
-    hipLaunchKernelGGL(gemm_planes_256_kernel, grid, dim3(1024), lds, (hipStream_t)stream, a);
-  } else {
-    a.tiles_m = lfi_cdiv(d->M, 128);
-    a.tiles_n = lfi_cdiv(d->N, 256);
-    {
-      // an XCD walks its run of tiles in groups of `gm` tile rows, column by column. PMC (cond_transform forward, 80 MB of
-      // operand planes): groups of 8 rows fetch 790 MB per launch into the L2s, one group of 14 per XCD (B once per XCD, but
-      // 6.4 MB of A panels per 4 MB L2) 1033 MB; the launch time is the same either way (0.571 / 0.574 ms): L2 misses are
-      // served by the Infinity Cache at ~2 TB/s and are not what bounds the kernel. LFI_PGEMM_GM overrides.
-      static int gm_env = -1;
-      if (gm_env < 0) {
-        const char* e = getenv("LFI_PGEMM_GM");
-        gm_env = e ? atoi(e) : 0;
-      }
-      a.gm = gm_env > 0 ? gm_env : 8;
-    }
-    const size_t lds = (size_t)QRING * QSLOT;   // 72 KB: two workgroups per CU; the epilogue's 64 x 260 floats fit inside
-    static bool attr = false;
-    if (!attr) {
-      if (hipFuncSetAttribute((const void*)gemm_planes_128_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
-        lfi_set_error("lfi_gemm_planes: cannot reserve %zu bytes of LDS", lds);
-        return LFI_ERR_LAUNCH;
-      }
-      attr = true;
-    }
-    dim3 grid(a.tiles_m * a.tiles_n, d->batch, 1);
-    const char* w4e = getenv("LFI_PGEMM_W4");
-    if (w4e && w4e[0] == '1') {   // four waves of 128 x 64 patches (fewer LDS fragment reads per MFMA)
-      static bool attr4 = false;
-      if (!attr4) {
-        if (hipFuncSetAttribute((const void*)gemm_planes_128w4_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
-          lfi_set_error("lfi_gemm_planes: cannot reserve %zu bytes of LDS", lds);
-          return LFI_ERR_LAUNCH;
-        }
-        attr4 = true;
-      }
-      hipLaunchKernelGGL(gemm_planes_128w4_kernel, grid, dim3(256), lds, (hipStream_t)stream, a);
-    } else {
-      hipLaunchKernelGGL(gemm_planes_128_kernel, grid, dim3(512), lds, (hipStream_t)stream, a);
-    }
-  }
-  LFI_LAUNCH_CHECK("lfi_gemm_planes");
-  return LFI_OK;
-}

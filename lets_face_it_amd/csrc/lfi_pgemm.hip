@@ -1,0 +1,388 @@
+// bf16 x 3 GEMM on PRE-SPLIT operand planes (include/lfi.h: lfi_planes_from_f32 / lfi_planes_t_from_f32 / lfi_gemm_planes), gfx950.
+//
+// lfi_gemm.hip's bf16x3 kernels redo the fp32 -> bf16 hi / lo split of every operand element in EVERY workgroup that touches
+// it, through VGPRs and ds_write, and a k-tile's phases (global load, convert + LDS store, fragment reads, MFMA) do not overlap.
+// Here the operands arrive ALREADY split - once, by a streaming kernel or by the epilogue of the product that made them - and
+// in 1-KB blocks that go global -> LDS by LDS-DMA (global_load_lds_dwordx4: no VGPR, no VALU, no ds_write).
+//
+// Two block formats, one per operand orientation of the fp32 matrix the planes stand for (both: block of 32 "mn" indices x 16 k,
+// hi block then lo block, index ((mn tile * nkt + k tile) * 2 + plane) * 512 bf16):
+//   row planes ("R", lfi_planes_from_f32): the matrix is [mn][k] (k contiguous). Lane l of a block holds mn = l & 31,
+//     k = 8 (l >> 5) .. + 7: exactly the v_mfma_f32_32x32x16_bf16 operand fragment, so a fragment is ONE linear, conflict-free
+//     ds_read_b128 (block base + 16 l).
+//   k-major planes ("T", lfi_planes_t_from_f32): the matrix is [k][mn] (mn contiguous: weight gradients sum over frames, which
+//     are the ROWS of every stored activation). Four 256-byte sub-tiles [8 k][16 mn] per block, sub-tile (k >> 3, mn >> 4), the
+//     sub-tiles of the upper mn half with their k rows 0-3 <-> 4-7 swapped; a fragment is TWO ds_read_b64_tr_b16 (the hardware
+//     transposing read: 4 k rows x 16 mn per 16 lanes) at byte offsets toff and toff ^ 128 - the two 16-lane groups of a
+//     32-lane half land in opposite 128-byte halves of the 256-byte bank row, conflict-free (cdna_hip_programming.md T10).
+//
+// Kernel: 128 x 256 tile, TWO workgroups per CU: 512 threads = 8 waves x (64 x 64) patches (wm = wave >> 2, wn = wave & 3),
+// ring of 3 slots of one 16-deep k-tile each, [A: 4 mn tiles x {hi, lo} x 1 KB][B: 8 x 2 x 1 KB] = 24 KB (72 KB; the wide
+// epilogue's 64-row passes of 66.5 KB fit inside), three DMA pieces per wave and k-tile.
+//   phase t:  DMA tile t + 3 -> slot t % 3 (its fragments were read in phase t - 1)
+//             MFMAs of tile t from registers, fragments of tile t + 1 read under them
+//             s_waitcnt vmcnt(3) (this wave's pieces of tile t + 2 landed; t + 3 in flight), lgkmcnt(0), s_barrier
+// Tiles past the end are fetched again from the last real tile (never used): the counted waits then need no tail cases.
+// Split K (grid.z): every split walks its own range of k-tiles and leaves a partial tile in the workspace, reduced (with bias /
+// activation) by gemm_splitk_reduce4_kernel - the long-K weight-gradient products have too few output tiles to fill the chip.
+// Epilogue (gemm_epilogue_wide<.., PL = true>): besides / instead of fp32 rows the result tile can leave as planes of either
+// format, and the act == 2 operand (cond_transform's LeakyReLU mask) can be read from the hi plane of its row planes.
+// History (rounds 1-2: 256 x 256 one-per-CU and four-wave 128 x 64-patch variants, ingredient-removal builds, stamps): DESIGN.md.
+#include "lfi_gemm_common.h"
+
+namespace {
+
+constexpr int QRING = 3;
+constexpr int QSLOT = 24 * 1024;
+
+typedef __attribute__((address_space(3))) void plds_void;
+typedef __attribute__((address_space(1))) const void pglb_void;
+typedef __bf16 pbf16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) pbf16x4 plds_v4;
+
+template <bool TF>
+__device__ __forceinline__ bf16x8 pg_frag(const char* blk, int lane, int toff) {
+  if (!TF) return *reinterpret_cast<const bf16x8*>(blk + lane * 16);
+  const pbf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((plds_v4*)(blk + toff));
+  const pbf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((plds_v4*)(blk + (toff ^ 128)));
+  bf16x8 r;
+  r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
+  r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
+  return r;
+}
+
+#define PG_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
+
+template <bool AT, bool BT, bool COLP>
+__global__ __launch_bounds__(512, 4) void gemm_planes_kernel(GemmArgs g) {
+  constexpr int XT = 2;   // skip switch compiled in (no register cost here)
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, half = lane >> 5;
+  int tm, tn, batch, split;
+  gemm_tile_of_block(g, &tm, &tn, &batch, &split);
+  const int m0 = tm * 128, n0 = tn * 256;
+  // this split's k-tiles: [kt0, kt0 + nkt)
+  const int ktc = g.kchunk >> 4;
+  const int kt0 = split * ktc;
+  const int nkt = max(min(g.nkt - kt0, ktc), 0);
+  char* lds = reinterpret_cast<char*>(xsmem);
+  // the slot's 24 blocks (A: 4 mn tiles x 2 planes, then B: 8 x 2) are dealt to the 8 waves three at a time; a tile's two
+  // planes are adjacent in memory and in the slot
+  const char* baseA = reinterpret_cast<const char*>(g.Ap + batch * g.pstrideA) + ((long)(tm * 4) * g.nktA + kt0) * 2048 + lane * 16;
+  const char* baseB = reinterpret_cast<const char*>(g.Bp + batch * g.pstrideB) + ((long)(tn * 8) * g.nktB + kt0) * 2048 + lane * 16;
+  const char* src[3];
+  int doff[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int j = wave * 3 + i;                       // block 0 .. 23
+    const int isB = j >= 8, jj = isB ? j - 8 : j;     // (mn tile, plane) = (jj >> 1, jj & 1)
+    src[i] = (isB ? baseB + (long)(jj >> 1) * g.nktB * 2048 : baseA + (long)(jj >> 1) * g.nktA * 2048) + (jj & 1) * 1024;
+    doff[i] = j * 1024;
+  }
+  auto dma = [&](int kt, int slot) {
+    const long ko = (long)max(min(kt, nkt - 1), 0) * 2048;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+      __builtin_amdgcn_global_load_lds((pglb_void*)(src[i] + ko), (plds_void*)(lds + slot * QSLOT + doff[i]), 16, 0, 0);
+  };
+  const int wm = wave >> 2, wn = wave & 3;
+  // k-major blocks: lane 16 g + 4 q + p addresses k row q (of 4), mn columns 4 p .. + 3 of sub-tile (k half g >> 1, mn half g & 1)
+  const int tg = lane >> 4, tq = (lane >> 2) & 3, tp = lane & 3;
+  const int toff = ((tg >> 1) * 2 + (tg & 1)) * 256 + ((tq ^ ((tg & 1) << 2)) * 32) + tp * 8;
+  const int fa = (wm * 4) * 1024;             // A fragment (mt, plane) in block fa + (mt * 2 + plane) * 1024
+  const int fb = 8 * 1024 + (wn * 4) * 1024;  // B fragment (nt, plane) in block fb + (nt * 2 + plane) * 1024
+  auto fragA = [&](int slot, int off) { return pg_frag<AT>(lds + slot * QSLOT + fa + off, lane, toff); };
+  auto fragB = [&](int slot, int off) { return pg_frag<BT>(lds + slot * QSLOT + fb + off, lane, toff); };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+  if (nkt > 0) {
+    bf16x8 ah[2], al[2], bh[2], bl[2];
+    dma(0, 0); dma(1, 1); dma(2, 2);
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int t2 = 0; t2 < 2; ++t2) {
+      ah[t2] = fragA(0, (t2 * 2) * 1024); al[t2] = fragA(0, (t2 * 2 + 1) * 1024);
+      bh[t2] = fragB(0, (t2 * 2) * 1024); bl[t2] = fragB(0, (t2 * 2 + 1) * 1024);
+    }
+    asm volatile("s_waitcnt vmcnt(3)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    int cur = 0;
+    for (int t = 0; t < nkt; ++t) {
+      const int nxt = cur == 2 ? 0 : cur + 1;
+      bf16x8 nah[2], nal[2], nbh[2], nbl[2];
+      dma(t + 3, cur);
+      __builtin_amdgcn_sched_barrier(0);
+      if (!LFI_GSKIP(1)) {
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) acc[0][nt] = PG_MFMA(al[0], bh[nt], acc[0][nt]);
+      }
+      if (!LFI_GSKIP(2)) {
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) acc[0][nt] = PG_MFMA(ah[0], bl[nt], acc[0][nt]);
+      }
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) acc[0][nt] = PG_MFMA(ah[0], bh[nt], acc[0][nt]);
+      __builtin_amdgcn_sched_barrier(0);
+      nah[0] = fragA(nxt, 0); nal[0] = fragA(nxt, 1024);
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) { nbh[nt] = fragB(nxt, (nt * 2) * 1024); nbl[nt] = fragB(nxt, (nt * 2 + 1) * 1024); }
+      __builtin_amdgcn_sched_barrier(0);
+      if (!LFI_GSKIP(1)) {
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) acc[1][nt] = PG_MFMA(al[1], bh[nt], acc[1][nt]);
+      }
+      if (!LFI_GSKIP(2)) {
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) acc[1][nt] = PG_MFMA(ah[1], bl[nt], acc[1][nt]);
+      }
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) acc[1][nt] = PG_MFMA(ah[1], bh[nt], acc[1][nt]);
+      __builtin_amdgcn_sched_barrier(0);
+      nah[1] = fragA(nxt, 2048); nal[1] = fragA(nxt, 3072);
+      asm volatile("s_waitcnt vmcnt(3)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+#pragma unroll
+      for (int i = 0; i < 2; ++i) { ah[i] = nah[i]; al[i] = nal[i]; bh[i] = nbh[i]; bl[i] = nbl[i]; }
+      cur = nxt;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the re-fetched tail tiles: landed before the epilogue reuses the ring
+  }
+  __syncthreads();
+  if (g.vecC) gemm_epilogue_wide<256, 512, 2, COLP, true>(g, acc, reinterpret_cast<float*>(xsmem), 64, m0, n0, wm, wn, l31, half, batch, split, 128);
+  else gemm_epilogue_n<256>(g, acc, m0, n0, wm, wn, l31, half, batch, split);
+}
+
+// fp32 (rows x cols, row pitch ldx) -> bf16 hi / lo ROW planes, zero padded to rows_pad x 16 nkt:
+// block ((rt * nkt + kt) * 2 + plane), lane l of a block holds row rt * 32 + (l & 31), k = kt * 16 + 8 (l >> 5) .. + 7.
+// One thread per (block pair, lane): 8 floats in (two 16-byte loads when the row allows), 16 + 16 bytes out.
+__global__ __launch_bounds__(256) void planes_from_f32_kernel(const float* __restrict__ X, long ldx, int rows, int cols, long nblk,
+                                                             int nkt, int vec, __bf16* __restrict__ out) {
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < nblk * 64; idx += (long)gridDim.x * 256) {
+    const int l = (int)(idx & 63);
+    const long q = idx >> 6;
+    const int kt = (int)(q % nkt);
+    const long rt = q / nkt;
+    const long row = rt * 32 + (l & 31);
+    const int k0 = kt * 16 + 8 * (l >> 5);
+    float v[8];
+    if (row < rows && vec && k0 + 8 <= cols) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(X + row * ldx + k0), b = *reinterpret_cast<const f32x4*>(X + row * ldx + k0 + 4);
+      v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = (row < rows && k0 + e < cols) ? X[row * ldx + k0 + e] : 0.0f;
+    }
+    uint4 h, lo;
+    split2(v[0], v[1], &h.x, &lo.x); split2(v[2], v[3], &h.y, &lo.y);
+    split2(v[4], v[5], &h.z, &lo.z); split2(v[6], v[7], &h.w, &lo.w);
+    uint4* dst = reinterpret_cast<uint4*>(out) + q * 128 + l;
+    dst[0] = h;
+    dst[64] = lo;
+  }
+}
+
+// fp32 (krows x mncols, row pitch ldx: mn contiguous) -> bf16 hi / lo K-MAJOR planes: block ((mt * nkt + kt) * 2 + plane) holds
+// mn = mt * 32 .. + 31, k = kt * 16 .. + 15 in the sub-tile layout of pgemm_t_offset; mn zero padded to whole 256-wide panels,
+// k to whole k-tiles. One thread per (block pair, 16-byte chunk): chunk c = l >> 4 of k row l & 15 (8 consecutive mn).
+__global__ __launch_bounds__(256) void planes_t_from_f32_kernel(const float* __restrict__ X, long ldx, long krows, int mncols, long nblk,
+                                                               long nkt, int vec, __bf16* __restrict__ out) {
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < nblk * 64; idx += (long)gridDim.x * 256) {
+    const int l = (int)(idx & 63);
+    const long q = idx >> 6;
+    const long kt = q % nkt, mt = q / nkt;
+    const int c4 = l >> 4, r = l & 15;
+    const long row = kt * 16 + r;
+    const int c0 = (int)mt * 32 + c4 * 8;
+    float v[8];
+    if (row < krows && vec && c0 + 8 <= mncols) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(X + row * ldx + c0), b = *reinterpret_cast<const f32x4*>(X + row * ldx + c0 + 4);
+      v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = (row < krows && c0 + e < mncols) ? X[row * ldx + c0 + e] : 0.0f;
+    }
+    uint4 h, lo;
+    split2(v[0], v[1], &h.x, &lo.x); split2(v[2], v[3], &h.y, &lo.y);
+    split2(v[4], v[5], &h.z, &lo.z); split2(v[6], v[7], &h.w, &lo.w);
+    char* dst = reinterpret_cast<char*>(out) + q * 2048 + pgemm_t_offset(r, c4);
+    *reinterpret_cast<uint4*>(dst) = h;
+    *reinterpret_cast<uint4*>(dst + 1024) = lo;
+  }
+}
+
+template <bool COLP>
+int launch_planes(const GemmArgs& a, int at, int bt, dim3 grid, size_t lds, hipStream_t st) {
+  static bool attr = false;
+  if (!attr) {
+    hipError_t e1 = hipFuncSetAttribute((const void*)gemm_planes_kernel<false, false, COLP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e2 = hipFuncSetAttribute((const void*)gemm_planes_kernel<false, true, COLP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e3 = hipFuncSetAttribute((const void*)gemm_planes_kernel<true, false, COLP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e4 = hipFuncSetAttribute((const void*)gemm_planes_kernel<true, true, COLP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess) {
+      lfi_set_error("lfi_gemm_planes: cannot reserve %zu bytes of LDS", lds);
+      return LFI_ERR_LAUNCH;
+    }
+    attr = true;
+  }
+  if (!at && !bt) hipLaunchKernelGGL((gemm_planes_kernel<false, false, COLP>), grid, dim3(512), lds, st, a);
+  else if (!at) hipLaunchKernelGGL((gemm_planes_kernel<false, true, COLP>), grid, dim3(512), lds, st, a);
+  else if (!bt) hipLaunchKernelGGL((gemm_planes_kernel<true, false, COLP>), grid, dim3(512), lds, st, a);
+  else hipLaunchKernelGGL((gemm_planes_kernel<true, true, COLP>), grid, dim3(512), lds, st, a);
+  return LFI_OK;
+}
+
+}  // namespace
+
+extern "C" long lfi_planes_elems(long rows, int cols) {
+  if (rows <= 0 || cols <= 0) return 0;
+  return ((rows + 255) / 256 * 256) * (long)((cols + 15) / 16 * 16) * 2;
+}
+
+extern "C" int lfi_planes_from_f32(const float* X, long ldx, long rows, int cols, void* planes, void* stream) {
+  LFI_REQUIRE(rows >= 0 && cols >= 0, "lfi_planes_from_f32: bad dims %ld x %d", rows, cols);
+  if (rows == 0 || cols == 0) return LFI_OK;
+  LFI_REQUIRE(X && planes, "lfi_planes_from_f32: null pointer");
+  LFI_REQUIRE((reinterpret_cast<uintptr_t>(planes) & 15) == 0, "lfi_planes_from_f32: planes must be 16-byte aligned");
+  const int nkt = (cols + 15) / 16;
+  const long nblk = (rows + 255) / 256 * 8 * nkt;   // (row tile, k-tile) block pairs, rows padded to whole 256-row panels
+  const int vec = ((reinterpret_cast<uintptr_t>(X) & 15) == 0 && (ldx & 3) == 0) ? 1 : 0;
+  const long threads = nblk * 64;
+  hipLaunchKernelGGL(planes_from_f32_kernel, dim3((unsigned)min((threads + 255) / 256, 65535L * 8)), dim3(256), 0, (hipStream_t)stream,
+                     X, ldx, (int)rows, cols, nblk, nkt, vec, reinterpret_cast<__bf16*>(planes));
+  LFI_LAUNCH_CHECK("lfi_planes_from_f32");
+  return LFI_OK;
+}
+
+extern "C" long lfi_planes_t_elems(long krows, long mncols) {
+  if (krows <= 0 || mncols <= 0) return 0;
+  return ((mncols + 255) / 256 * 256) * ((krows + 15) / 16 * 16) * 2;
+}
+
+extern "C" int lfi_planes_t_from_f32(const float* X, long ldx, long krows, long mncols, void* planes, void* stream) {
+  LFI_REQUIRE(krows >= 0 && mncols >= 0 && mncols < (1L << 30), "lfi_planes_t_from_f32: bad dims %ld x %ld", krows, mncols);
+  if (krows == 0 || mncols == 0) return LFI_OK;
+  LFI_REQUIRE(X && planes, "lfi_planes_t_from_f32: null pointer");
+  LFI_REQUIRE((reinterpret_cast<uintptr_t>(planes) & 15) == 0, "lfi_planes_t_from_f32: planes must be 16-byte aligned");
+  const long nkt = (krows + 15) / 16;
+  const long nblk = (mncols + 255) / 256 * 8 * nkt;   // (mn tile, k-tile) block pairs, mn padded to whole 256-wide panels
+  const int vec = ((reinterpret_cast<uintptr_t>(X) & 15) == 0 && (ldx & 3) == 0) ? 1 : 0;
+  const long threads = nblk * 64;
+  hipLaunchKernelGGL(planes_t_from_f32_kernel, dim3((unsigned)min((threads + 255) / 256, 65535L * 8)), dim3(256), 0, (hipStream_t)stream,
+                     X, ldx, krows, (int)mncols, nblk, nkt, vec, reinterpret_cast<__bf16*>(planes));
+  LFI_LAUNCH_CHECK("lfi_planes_t_from_f32");
+  return LFI_OK;
+}
+
+extern "C" long lfi_gemm_planes_work_floats(const lfi_pgemm_desc* d) {
+  if (!d || d->splitk <= 1) return 0;
+  return (long)d->batch * d->splitk * d->M * d->N;
+}
+
+// Rows of the partial column-sum matrix lfi_gemm_planes fills when colsum_part is set (one per 64-row epilogue pass), or 0 when
+// this product cannot (split K, or a batch that is not laid side by side in C's columns).
+extern "C" long lfi_gemm_planes_colpart_rows(const lfi_pgemm_desc* d) {
+  if (!d || d->M <= 0 || d->N <= 0 || d->splitk > 1) return 0;
+  if (d->batch > 1 && !(d->strideC > 0 && d->strideC * d->batch <= d->ldc)) return 0;
+  if (d->ldc % 4 != 0 || d->strideC % 4 != 0 || (d->act == 2 && d->accumulate != 0)) return 0;
+  return (long)lfi_cdiv(d->M, 128) * 2;
+}
+
+extern "C" int lfi_gemm_planes(const lfi_pgemm_desc* d, void* stream) {
+  LFI_REQUIRE(d, "lfi_gemm_planes: null descriptor");
+  LFI_REQUIRE(d->M >= 0 && d->N >= 0 && d->K >= 0 && d->batch >= 1 && d->batch <= 65535, "lfi_gemm_planes: bad dims M=%d N=%d K=%d batch=%d",
+              d->M, d->N, d->K, d->batch);
+  if (d->M == 0 || d->N == 0) return LFI_OK;
+  const bool store = d->store_f32 != 0;
+  LFI_REQUIRE(d->Ap && d->Bp && (d->C || !store), "lfi_gemm_planes: null operand");
+  LFI_REQUIRE(store || d->Cr || d->Ct, "lfi_gemm_planes: store_f32 = 0 and no plane output: the result would go nowhere");
+  LFI_REQUIRE(d->K > 0, "lfi_gemm_planes: K = 0");
+  LFI_REQUIRE(d->act >= 0 && d->act <= 2 && (d->act != 2 || d->G || d->Gr), "lfi_gemm_planes: bad act %d", d->act);
+  const int nkt = (d->K + 15) / 16;
+  LFI_REQUIRE(d->a_nkt >= nkt && d->b_nkt >= nkt, "lfi_gemm_planes: plane buffers hold %ld / %ld k-tiles per mn tile, the product needs %d",
+              (long)d->a_nkt, (long)d->b_nkt, nkt);
+  LFI_REQUIRE((reinterpret_cast<uintptr_t>(d->Ap) & 15) == 0 && (reinterpret_cast<uintptr_t>(d->Bp) & 15) == 0 &&
+              (d->a_stride & 7) == 0 && (d->b_stride & 7) == 0, "lfi_gemm_planes: planes must be 16-byte aligned");
+  int splitk = d->splitk < 1 ? 1 : d->splitk;
+  if (splitk > nkt) splitk = nkt;
+  LFI_REQUIRE(splitk == 1 || d->work, "lfi_gemm_planes: splitk needs a workspace");
+  LFI_REQUIRE(splitk == 1 || (!d->Cr && !d->Ct && !d->colsum_part && store), "lfi_gemm_planes: plane outputs / column sums need splitk = 1");
+  const bool planes_io = d->Cr || d->Ct || d->Gr;
+  if (planes_io) {
+    LFI_REQUIRE(d->batch == 1 || (d->strideC > 0 && d->strideC * d->batch <= (d->C ? d->ldc : d->strideC * d->batch) && d->strideC % 32 == 0),
+                "lfi_gemm_planes: plane outputs need batch entries side by side in C's columns, 32-column granular");
+    LFI_REQUIRE(d->cr_col0 % 16 == 0 && d->gr_col0 % 16 == 0 && d->ct_col0 % 32 == 0 && d->ct_row0 % 16 == 0,
+                "lfi_gemm_planes: plane outputs must start on block boundaries");
+    LFI_REQUIRE((!d->Cr || (reinterpret_cast<uintptr_t>(d->Cr) & 15) == 0) && (!d->Ct || (reinterpret_cast<uintptr_t>(d->Ct) & 15) == 0) &&
+                (!d->Gr || (reinterpret_cast<uintptr_t>(d->Gr) & 15) == 0), "lfi_gemm_planes: planes must be 16-byte aligned");
+  }
+  GemmArgs a = {};
+  a.M = d->M; a.N = d->N; a.K = d->K;
+  a.C = d->C; a.ldc = d->ldc; a.bias = d->bias; a.G = d->G; a.ldg = d->ldg;
+  a.strideC = d->strideC; a.strideBias = d->strideBias; a.strideG = d->strideG;
+  a.accumulate = d->accumulate; a.act = d->act; a.slope = d->slope;
+  a.splitk = splitk;
+  a.kchunk = splitk > 1 ? lfi_cdiv(nkt, splitk) * 16 : nkt * 16;
+  a.work = d->work;
+  a.Ap = reinterpret_cast<const __bf16*>(d->Ap); a.Bp = reinterpret_cast<const __bf16*>(d->Bp);
+  a.nkt = nkt; a.nktA = (int)d->a_nkt; a.nktB = (int)d->b_nkt; a.pstrideA = d->a_stride; a.pstrideB = d->b_stride;
+  a.skip = d->skip & 3;
+  a.colpart = d->colsum_part; a.ldpart = d->ld_part;
+  a.storeC = store ? 1 : 0;
+  a.Cr = reinterpret_cast<__bf16*>(d->Cr); a.nktCr = d->cr_nkt; a.colCr = d->cr_col0;
+  a.Ct = reinterpret_cast<__bf16*>(d->Ct); a.nktCt = d->ct_nkt; a.rowCt = d->ct_row0; a.colCt = d->ct_col0;
+  a.Gr = reinterpret_cast<const __bf16*>(d->Gr); a.nktGr = d->gr_nkt; a.colGr = d->gr_col0;
+  {
+    // the wide (through-LDS) epilogue needs 16-byte granular fp32 rows; it is also the only one that can emit / read planes
+    const bool partial = splitk > 1;
+    const bool c_ok = partial ? (((long)d->M * d->N) % 4 == 0 && d->N % 4 == 0 && (reinterpret_cast<uintptr_t>(d->work) & 15) == 0)
+                              : (!store || ((reinterpret_cast<uintptr_t>(d->C) & 15) == 0 && d->ldc % 4 == 0 && d->strideC % 4 == 0));
+    const bool g_ok = d->act != 2 || d->Gr || ((reinterpret_cast<uintptr_t>(d->G) & 15) == 0 && d->ldg % 4 == 0 && d->strideG % 4 == 0);
+    a.vecC = (c_ok && g_ok && !(d->act == 2 && d->accumulate != 0)) ? 1 : 0;
+    LFI_REQUIRE(a.vecC || !(planes_io || d->colsum_part), "lfi_gemm_planes: plane outputs / column sums need 16-byte granular C rows");
+  }
+  a.tiles_m = lfi_cdiv(d->M, 128);
+  a.tiles_n = lfi_cdiv(d->N, 256);
+  {
+    // an XCD walks its run of tiles in groups of `gm` tile rows, column by column. PMC (cond_transform forward, 80 MB of
+    // operand planes): groups of 8 rows fetch 790 MB per launch into the L2s, one group of 14 per XCD (B once per XCD, but
+    // 6.4 MB of A panels per 4 MB L2) 1033 MB; the launch time is the same either way (0.571 / 0.574 ms): L2 misses are
+    // served by the Infinity Cache at ~2 TB/s and are not what bounds the kernel. LFI_PGEMM_GM overrides.
+    static int gm_env = -1;
+    if (gm_env < 0) {
+      const char* e = getenv("LFI_PGEMM_GM");
+      gm_env = e ? atoi(e) : 0;
+    }
+    a.gm = gm_env > 0 ? gm_env : 8;
+  }
+  const size_t lds = (size_t)QRING * QSLOT;   // 72 KB: two workgroups per CU; the epilogue's 64 x 260 floats fit inside
+  dim3 grid(a.tiles_m * a.tiles_n, d->batch, splitk);
+  const int rc = a.colpart ? launch_planes<true>(a, d->a_fmt, d->b_fmt, grid, lds, (hipStream_t)stream)
+                           : launch_planes<false>(a, d->a_fmt, d->b_fmt, grid, lds, (hipStream_t)stream);
+  if (rc) return rc;
+  LFI_LAUNCH_CHECK("lfi_gemm_planes");
+  if (splitk > 1) {
+    const long mn = (long)d->M * d->N;
+    auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    const bool red4 = d->N % 4 == 0 && al16(d->work) && al16(d->C) && d->ldc % 4 == 0 && d->strideC % 4 == 0 &&
+                      (!d->G || (al16(d->G) && d->ldg % 4 == 0 && d->strideG % 4 == 0));
+    if (red4) {
+      dim3 rgrid((unsigned)min((long)lfi_cdiv(mn / 4, 256), 2048L), d->batch);
+      hipLaunchKernelGGL(gemm_splitk_reduce4_kernel, rgrid, dim3(256), 0, (hipStream_t)stream, a);
+    } else {
+      dim3 rgrid((unsigned)min((long)lfi_cdiv(mn, 256), 2048L), d->batch);
+      hipLaunchKernelGGL(gemm_splitk_reduce_kernel, rgrid, dim3(256), 0, (hipStream_t)stream, a);
+    }
+    LFI_LAUNCH_CHECK("lfi_gemm_planes split-k reduce");
+  }
+  return LFI_OK;
+}

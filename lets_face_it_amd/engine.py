@@ -216,8 +216,13 @@ class GlowEngine:
         # fly, three bf16 MFMAs per step, fp32 accumulation: ~2^-16 relative, 16x the MFMA rate)
         self.precision = 0
         # arithmetic of the AUTOREGRESSIVE part of sample() (per generated frame: the window columns of cond_transform, gic and
-        # the Ks reverse cells' recurrent products); None = as self.precision. See sample().
-        self.sample_frame_precision = None
+        # the Ks reverse cells' recurrent products): exact f32 by default. At full depth (K = 16 x 56 generated frames) plain fp32
+        # torch is itself 2.4e-5 from the fp64 oracle; with this part in bf16x3 the sampler lands at 5.6e-5, in f32 at 2.7e-5 (gate:
+        # 1.5 x the fp32 floor) whatever the static part uses - every frame's error feeds all later frames through the
+        # prev_p1_face window (profiles/round3_sample_precision.md: 95.7 -> 123 ms per 1024 x 300 call; the static part - window
+        # encoders, non-autoregressive cond_transform columns - stays in the engine's mode). LFI_SAMPLE_FRAME_PRECISION=bf16x3
+        # (or this attribute = 1) buys the 29 % back for callers that do not need the last 3e-5.
+        self.sample_frame_precision = 1 if os.environ.get("LFI_SAMPLE_FRAME_PRECISION") == "bf16x3" else 0
         self._mask_calls = 0
         # GEMM class -> bf16x3 products to drop (bit 0: a_lo b_hi, bit 1: a_hi b_lo; 3 = plain bf16 operands, one product).
         # Measurement switch only: profiles/precision_sweep.md (tools/precision_sweep.py, final widths, against the fp64
@@ -394,21 +399,64 @@ class GlowEngine:
               "lfi_planes_from_f32")
         return buf, (cols + 15) // 16
 
+    def planes_t(self, name, X, ldx, krows, mncols, x_off=0):
+        """K-major planes (format 1) of the fp32 matrix X (krows x mncols, mn contiguous, row pitch ldx): the operand form of a
+        matrix whose ROWS are the contraction index. -> (tensor, nkt)"""
+        elems = self.L.lfi_planes_t_elems(krows, mncols) + 256 * ((krows + 15) // 16 * 16) * 2
+        buf = self._ws.get(name)
+        if buf is None or buf.numel() < elems:
+            buf = torch.empty(elems, dtype=torch.bfloat16, device=self.device)
+            self._ws[name] = buf
+        check(self.L.lfi_planes_t_from_f32(X.data_ptr() + 4 * x_off, ldx, krows, mncols, buf.data_ptr(), _stream()),
+              "lfi_planes_t_from_f32")
+        return buf, (krows + 15) // 16
+
+    def plane_buf(self, name, elems):
+        """An (uninitialised) bf16 workspace for planes that a kernel's epilogue writes."""
+        buf = self._ws.get(name)
+        if buf is None or buf.numel() < elems:
+            buf = torch.empty(int(elems), dtype=torch.bfloat16, device=self.device)
+            self._ws[name] = buf
+        return buf
+
     def gemm_planes(self, M, N, K, Ap, a_nkt, Bp, b_nkt, Cm, ldc, bias=None, act=0, slope=0.01, G=None, ldg=0, batch=1,
-                    a_stride=0, b_stride=0, sC=0, sBias=0, sG=0, accumulate=0, c_off=0, bias_off=0, tag=None, cls=None):
+                    a_stride=0, b_stride=0, sC=0, sBias=0, sG=0, accumulate=0, c_off=0, bias_off=0, tag=None, cls=None,
+                    a_fmt=0, b_fmt=0, a_off=0, b_off=0, splitk=1, ws="scratch.pgemm_splitk", store=True,
+                    Cr=None, cr_nkt=0, cr_col0=0, Ct=None, ct_nkt=0, ct_row0=0, ct_col0=0, Gr=None, gr_nkt=0, gr_col0=0,
+                    colsum_into=None):
+        """lfi_gemm_planes. a_off / b_off: bf16 elements into the plane buffers (a k-tile range: kt0 * 1024; an mn-tile range:
+        tile * nkt * 1024). Cr / Ct: bf16 tensors that receive the result as row / k-major planes; Gr: row planes whose hi plane's
+        sign stands in for G (act 2). colsum_into: as gemm(). Returns True when the column sums were taken in the epilogue."""
         g = PGemmDesc()
         g.skip = self.pass_skip.get(cls, 0) & 3
         g.M, g.N, g.K = M, N, K
-        g.Ap, g.a_nkt, g.a_stride = Ap.data_ptr(), a_nkt, a_stride
-        g.Bp, g.b_nkt, g.b_stride = Bp.data_ptr(), b_nkt, b_stride
-        g.C, g.ldc = Cm.data_ptr() + 4 * c_off, ldc
+        g.Ap, g.a_nkt, g.a_stride = Ap.data_ptr() + 2 * a_off, a_nkt, a_stride
+        g.Bp, g.b_nkt, g.b_stride = Bp.data_ptr() + 2 * b_off, b_nkt, b_stride
+        g.C, g.ldc = (None if Cm is None else Cm.data_ptr() + 4 * c_off), ldc
         g.bias = None if bias is None else bias.data_ptr() + 4 * bias_off
         g.G, g.ldg = ptr(G), ldg
         g.batch, g.strideC, g.strideBias, g.strideG = batch, sC, sBias, sG
         g.accumulate, g.act, g.slope = accumulate, act, slope
+        g.a_fmt, g.b_fmt = a_fmt, b_fmt
+        g.splitk = splitk
+        g.store_f32 = 1 if store else 0
+        if splitk > 1:
+            g.work = self._buf(ws, batch * splitk * M * N).data_ptr()
+        g.Cr, g.cr_nkt, g.cr_col0 = ptr(Cr), cr_nkt, cr_col0
+        g.Ct, g.ct_nkt, g.ct_row0, g.ct_col0 = ptr(Ct), ct_nkt, ct_row0, ct_col0
+        g.Gr, g.gr_nkt, g.gr_col0 = ptr(Gr), gr_nkt, gr_col0
+        part, prow = None, 0
+        if colsum_into is not None and os.environ.get("LFI_NO_COLPART") != "1":
+            prow = int(self.L.lfi_gemm_planes_colpart_rows(C.byref(g)))
+            if prow > 0:
+                part = self._buf("scratch.colpart", prow * ldc)
+                g.colsum_part, g.ld_part = part.data_ptr(), ldc
         ev = self._tic(tag)
         check(self.L.lfi_gemm_planes(C.byref(g), _stream()), "lfi_gemm_planes")
         self._toc(tag, ev)
+        if part is not None:
+            self.colsum(part, ldc, 0, prow, colsum_into.numel(), 1, colsum_into, 0, ws="scratch.colsum.part")
+        return part is not None
 
     @staticmethod
     def _fill_splitk(M, N, K, batch=1):

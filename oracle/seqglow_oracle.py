@@ -98,8 +98,9 @@ def encode_window(x, enc, sd, prefix, mask=None):
         w_ih, w_hh = sd[prefix + "encoder.weight_ih_l0"], sd[prefix + "encoder.weight_hh_l0"]
         b_ih, b_hh = sd[prefix + "encoder.bias_ih_l0"], sd[prefix + "encoder.bias_hh_l0"]
         h = x.new_zeros(B, w_hh.shape[1])
-        if _REFERENCE_OPS:   # nn.GRU(batch_first=True): one fused call per window batch (:60-64)
-            seq, hn = torch._VF.gru(x.contiguous(), h.unsqueeze(0), [w_ih, w_hh, b_ih, b_hh], True, 1, 0.0, False, False, True)
+        if _REFERENCE_OPS:   # nn.GRU(batch_first=True): one fused call per window batch (:60-64); `train` as module.training:
+            # dropout is 0 either way, but MIOpen's RNN backward insists on a training-mode forward
+            seq, hn = torch._VF.gru(x.contiguous(), h.unsqueeze(0), [w_ih, w_hh, b_ih, b_hh], True, 1, 0.0, torch.is_grad_enabled(), False, True)
             return torch.cat([seq[:, -1], hn[0]], dim=1)
         for s in range(x.shape[1]):
             h = gru_cell(x[:, s], h, w_ih, w_hh, b_ih, b_hh)
@@ -111,7 +112,7 @@ def encode_window(x, enc, sd, prefix, mask=None):
         c = x.new_zeros(B, w_hh.shape[1])
         if _REFERENCE_OPS:   # nn.LSTM(batch_first=True) (:65-69)
             seq, hn, _ = torch._VF.lstm(x.contiguous(), (h.unsqueeze(0), c.unsqueeze(0)), [w_ih, w_hh, b_ih, b_hh], True, 1, 0.0,
-                                        False, False, True)
+                                        torch.is_grad_enabled(), False, True)
             return torch.cat([seq[:, -1], hn[0]], dim=1)
         for s in range(x.shape[1]):
             h, c = lstm_cell(x[:, s], h, c, w_ih, w_hh, b_ih, b_hh)

@@ -200,15 +200,12 @@ def test_gemm_bf16x3_256_tile(eng, gpu_device, akc, bkc, shape, splitk, pin):
 
 
 @pytest.mark.parametrize("shape", [(700, 520, 330), (256, 256, 16), (513, 257, 75), (300, 260, 128), (1024, 768, 896), (40, 33, 7)])
-@pytest.mark.parametrize("epi", ["bias_leaky", "plain", "accumulate", "plain_w4"])
-def test_gemm_on_presplit_planes(eng, gpu_device, shape, epi, monkeypatch):
+@pytest.mark.parametrize("epi", ["bias_leaky", "plain", "accumulate"])
+def test_gemm_on_presplit_planes(eng, gpu_device, shape, epi):
     """lfi_planes_from_f32 + lfi_gemm_planes (operands split to bf16 hi / lo ONCE, in MFMA fragment order, streamed to LDS by
-    LDS-DMA through a four-slot ring) against the fp64 product and, bit for bit, against lfi_gemm_f32's 256 x 256 bf16x3
+    LDS-DMA through a three-slot ring) against the fp64 product and, bit for bit, against lfi_gemm_f32's 256 x 256 bf16x3
     kernel (same split, same products, same accumulation order): ragged M / N / K, fewer k-tiles than ring slots, many tiles."""
     M, N, K = shape
-    if epi.endswith("_w4"):   # the opt-in four-wave variant (128 x 64 patches per wave): same products, same order, same bits
-        monkeypatch.setenv("LFI_PGEMM_W4", "1")
-        epi = epi[:-3]
     g = torch.Generator().manual_seed(M + 3 * N + 7 * K)
     r4 = lambda v: (v + 3) // 4 * 4  # noqa: E731
     lda, ldb, ldc = r4(K) + 4, r4(K), r4(N) + 4
@@ -262,6 +259,96 @@ def test_gemm_on_presplit_planes_batched_k_ranges(eng, gpu_device):
     for k in range(Ks):
         ref = c[:, k * D:(k + 1) * D].double() @ W[k].double().t() + bias[k].double()
         assert rel_err(out[k], ref) < 3e-5, k
+
+
+@pytest.mark.parametrize("shape", [(700, 520, 330), (384, 512, 14336), (513, 257, 75), (130, 40, 16), (1024, 896, 2048)])
+@pytest.mark.parametrize("fmt", ["RT", "TR", "TT"])
+@pytest.mark.parametrize("splitk", [1, 3])
+def test_gemm_planes_kmajor_operands_and_split_k(eng, gpu_device, shape, fmt, splitk):
+    """K-major planes (lfi_planes_t_from_f32: the operand form of an fp32 matrix whose ROWS are the contraction index - every
+    weight-gradient product sums over frames) in either operand slot, read with ds_read_b64_tr_b16, with and without a K split:
+    against the fp64 product and, bit for bit, against lfi_gemm_f32's bf16x3 kernel on the same fp32 operands (same split, same
+    products, same order - with a K split only when both split the same way, so that case is checked against fp64 alone)."""
+    M, N, K = shape
+    g = torch.Generator().manual_seed(M + 3 * N + 7 * K)
+    r4 = lambda v: (v + 3) // 4 * 4  # noqa: E731
+    at, bt = fmt[0] == "T", fmt[1] == "T"
+    # a k-contiguous operand is (mn x K), an mn-contiguous one (K x mn)
+    lda, ldb = (r4(M) + 4 if at else r4(K) + 4), (r4(N) if bt else r4(K))
+    A = torch.zeros((K, lda) if at else (M, lda))
+    Bm = torch.zeros((K, ldb) if bt else (N, ldb))
+    if at:
+        A[:, :M] = torch.randn(K, M, generator=g)
+    else:
+        A[:, :K] = torch.randn(M, K, generator=g)
+    if bt:
+        Bm[:, :N] = torch.randn(K, N, generator=g)
+    else:
+        Bm[:, :K] = torch.randn(N, K, generator=g)
+    A, Bm = A.to(gpu_device), Bm.to(gpu_device)
+    ldc = r4(N) + 4
+    bias = torch.randn(N, generator=g).to(gpu_device)
+    C1 = torch.full((M, ldc), 7.0, device=gpu_device)
+    Ap, nka = eng.planes_t("test.pa", A, lda, K, M) if at else eng.planes("test.pa", A, lda, M, K)
+    Bp, nkb = eng.planes_t("test.pb", Bm, ldb, K, N) if bt else eng.planes("test.pb", Bm, ldb, N, K)
+    eng.gemm_planes(M, N, K, Ap, nka, Bp, nkb, C1, ldc, bias=bias, act=1, a_fmt=int(at), b_fmt=int(bt), splitk=splitk)
+    C2 = torch.full((M, ldc), 7.0, device=gpu_device)
+    eng.precision = 0x11
+    try:
+        eng.gemm(M, N, K, A, lda, 0 if at else 1, Bm, ldb, 0 if bt else 1, C2, ldc, bias=bias, act=1, slope=0.01)
+    finally:
+        eng.precision = 0
+    torch.cuda.synchronize()
+    Ad = (A[:, :M].t() if at else A[:, :K]).double()
+    Bd = (Bm[:, :N] if bt else Bm[:, :K].t()).double()
+    ref = torch.nn.functional.leaky_relu(Ad @ Bd + bias.double(), 0.01)
+    assert bool((C1[:, N:] == 7.0).all()), "wrote outside the N columns"
+    assert rel_err(C1[:, :N], ref) < 3e-5
+    if splitk == 1:
+        assert torch.equal(C1, C2)
+
+
+@pytest.mark.parametrize("M,N,K,batch", [(700, 512, 96, 1), (14336 // 8, 128, 384, 4), (333, 96, 64, 2)])
+def test_gemm_planes_emits_its_result_as_planes(eng, gpu_device, M, N, K, batch):
+    """Plane outputs of lfi_gemm_planes: the result leaves the epilogue as row planes and k-major planes - bit for bit what
+    lfi_planes_from_f32 / lfi_planes_t_from_f32 make of the fp32 result (zero padding included) - with the fp32 store on or off,
+    batch entries side by side in C's columns (the in-place dpre product, glow/models.py:187-190 backward), the act-2 operand
+    read from the hi plane of another product's row planes, and per-pass column sums (the bias gradient)."""
+    g = torch.Generator().manual_seed(M + N + K)
+    Ncols = batch * N
+    ldc = Ncols + 32
+    A = torch.randn(M, batch * K, generator=g).to(gpu_device)        # batch entry b: columns [b K, (b + 1) K)
+    W = torch.randn(batch * N, K, generator=g).to(gpu_device)        # batch entry b: rows [b N, (b + 1) N)
+    Gm = torch.randn(M, ldc, generator=g).to(gpu_device)             # the LeakyReLU input whose sign gates the result
+    Gp, nkg = eng.planes("test.pg", Gm, ldc, M, Ncols)
+    Ap, nka = eng.planes("test.pa", A, batch * K, M, batch * K)
+    Wp, nkw = eng.planes("test.pw", W, K, batch * N, K)
+    ref_c = torch.empty(M, ldc, device=gpu_device).fill_(3.0)
+    kw = dict(act=2, batch=batch, a_stride=(K // 16) * 1024, b_stride=(N // 32) * nkw * 1024, sC=N)
+    eng.gemm_planes(M, N, K, Ap, nka, Wp, nkw, ref_c, ldc, G=Gm, ldg=ldc, sG=N, **kw)              # fp32 reference path
+    want_r, nkr = eng.planes("test.wr", ref_c, ldc, M, Ncols)
+    want_t, nkt = eng.planes_t("test.wt", ref_c, ldc, M, Ncols)
+    want_r, want_t = want_r.clone(), want_t.clone()
+    n_r, n_t = eng.L.lfi_planes_elems(M, Ncols), eng.L.lfi_planes_t_elems(M, Ncols)
+    for store in (True, False):
+        Cr = torch.full((want_r.numel(),), float("nan"), dtype=torch.bfloat16, device=gpu_device)
+        Ct = torch.full((want_t.numel(),), float("nan"), dtype=torch.bfloat16, device=gpu_device)
+        out = torch.empty(M, ldc, device=gpu_device).fill_(3.0)
+        sums = torch.zeros(Ncols, device=gpu_device)
+        done = eng.gemm_planes(M, N, K, Ap, nka, Wp, nkw, out, ldc, Gr=Gp, gr_nkt=nkg, store=store, Cr=Cr, cr_nkt=nkr, Ct=Ct,
+                               ct_nkt=nkt, colsum_into=sums, **kw)
+        torch.cuda.synchronize()
+        assert done
+        if store:
+            assert torch.equal(out, ref_c)
+        else:
+            assert bool((out == 3.0).all())
+        # every block the consumers read: whole row tiles x k-tiles that hold real rows / columns
+        r_blocks = Cr[:n_r].view(-1, nkr, 2, 512)[:(M + 31) // 32]
+        assert torch.equal(r_blocks.view(torch.int16), want_r[:n_r].view(-1, nkr, 2, 512)[:(M + 31) // 32].view(torch.int16))
+        t_blocks = Ct[:n_t].view(-1, nkt, 2, 512)[:(Ncols + 31) // 32]
+        assert torch.equal(t_blocks.view(torch.int16), want_t[:n_t].view(-1, nkt, 2, 512)[:(Ncols + 31) // 32].view(torch.int16))
+        assert rel_err(sums, ref_c[:, :Ncols].double().sum(0)) < 1e-5
 
 
 @pytest.mark.parametrize("pin,M", [(0x11, 700), (0x21, 300), (0x11, 256)])
