@@ -199,12 +199,11 @@ def _roofline(spec, F, timing, precision):
     # which kernel lfi_gemm_f32 picks for this product: bf16x3 takes the 256 x 256 tile (1024 threads) unless
     # LFI_GEMM_256=0, f32 the 128 x 128 tile (256 threads); the rocprof kernel names below are what --kernel-trace prints
     if precision == "bf16x3" and os.environ.get("LFI_PGEMM", "1") != "0":
-        # the product runs on pre-split operand planes (lfi_gemm_planes): 128 x 256 tiles, 512 threads, two workgroups per CU
-        # (LFI_PGEMM_256=1: 256 x 256 tiles, 1024 threads)
+        # the product runs on pre-split operand planes (lfi_gemm_planes, lfi_pgemm.hip): 128 x 256 tiles, 512 threads, two
+        # workgroups per CU; both operands as row planes, no column-sum epilogue
         peak, mult = BF16_MFMA_PEAK_TFLOPS, 3.0
-        big = os.environ.get("LFI_PGEMM_256", "0") == "1"
-        kern = "gemm_planes_256_kernel" if big else "gemm_planes_128_kernel"
-        tile, threads = (256, 1024) if big else (128, 512)
+        kern = "gemm_planes_kernel<false, false, false>"
+        tile, threads = 128, 512
         tile_n = 256
     elif precision == "bf16x3":
         big = os.environ.get("LFI_GEMM_256", "1") != "0"
@@ -296,6 +295,19 @@ def bench_train(args, model, trainer, spec, device, world, rank, hp):
     host_issue = _host_issue_ms(step)
     timing = eng.timing_summary()
     eng.enable_timing(False)
+    graph_line = None
+    if world == 1 and args.graph_steps > 0:
+        # the same step as ONE replayed hipGraph (opt-in: LetsFaceItGlow.step_graph; bit-identical parameters): two more eager calls
+        # of the shape, the capture, then K timed replays. Reported beside the headline, which stays with eager launches.
+        model.step_graph = True
+        for i in range(4):
+            step(i)
+        el_g, _ = _timed(step, args.graph_steps, 1, device)
+        graphed = any(isinstance(v, dict) for v in getattr(model, "_step_graphs", {}).values())
+        graph_line = {"captured": graphed, "ms_per_step": 1e3 * el_g / args.graph_steps, "host_issue_ms_per_step": _host_issue_ms(step),
+                      "steps": args.graph_steps, "note": "fused_training_step replayed as one hipGraph per step (forward, backward, "
+                      "clip, Adam on both streams; dropout key and Adam step size read from device memory)"}
+        model.step_graph = False
     if rank != 0:
         return None
     frames = world * B * N * args.steps
@@ -313,18 +325,29 @@ def bench_train(args, model, trainer, spec, device, world, rank, hp):
         "metric": metric,
         "value": frames / elapsed, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "host_issue_ms_per_step": host_issue,
+        "step_launch": "eager (~100 launches per step on two streams)", "hipgraph_replay": graph_line,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": _dtype_label(args.precision, eng),
+        "dtype": _dtype_label(args.precision, eng, F),
         "data": "synthetic",
         "config": {"workload": workload,
                    "K": spec.Ks, "H": spec.H, "cond_dim": spec.D, "feature_dim": spec.E, "frames_per_step_per_gpu": F,
                    "parallelism": "dp%d" % world, "params": eng.n_params, "gemm_precision": args.precision,
-                   "gemm_products": _products_label(args.precision, eng)},
+                   "gemm_products": _products_label(args.precision, eng, F)},
         "final_loss": float(loss),
         "roofline": _roofline(spec, F, timing, args.precision),
         "roofline_hbm": _roofline_hbm(spec, B, T, timing, args.precision),
         "kernel_timing": {t: {"launches": n, "ms": round(m_, 4)} for t, (n, m_) in timing.items()},
     }
+    if world == 1 and args.precision == "bf16x3" and eng.backward_product_count(F) == 2:
+        # the same step with three products in the backward GEMMs too (round 2's arithmetic), timed in the same process
+        keep = eng.backward_products
+        eng.backward_products = 3
+        for i in range(3):
+            step(i)
+        el3, _ = _timed(step, args.steps, 1, device)
+        eng.backward_products = keep
+        out["three_products_everywhere"] = {"ms_per_step": 1e3 * el3 / args.steps, "value": frames / el3, "unit": "frames/s",
+                                            "note": "engine_backward_products=3; same process, same batches, %d steps" % args.steps}
     if world == 1 and not deep and B == 256 and args.strong_anchor_batch > 0:
         # north_star asks for STRONG scaling at 8 GPUs (configs[2]: global batch 2048 = 8 x 256). The driver's N-GPU runs keep
         # 256 per GPU ("scaling": "weak"); this is the missing denominator: ONE GPU stepping the global batch of the 8-GPU run,
@@ -359,21 +382,25 @@ def bench_train(args, model, trainer, spec, device, world, rank, hp):
     return out
 
 
-def _products_label(precision, eng):
+def _products_label(precision, eng, frames):
     if precision != "bf16x3":
         return "exact fp32 (f32-input MFMA)"
-    if not eng.pass_skip:
-        return "3 per GEMM class (a_hi b_hi + a_hi b_lo + a_lo b_hi)"
-    return "3, except " + ", ".join("%s: %d" % (c, 3 - bin(b & 3).count("1")) for c, b in sorted(eng.pass_skip.items()))
+    bwd = eng.backward_product_count(frames)
+    txt = "forward classes 3 (a_hi b_hi + a_hi b_lo + a_lo b_hi); backward classes %d%s" % (
+        bwd, " (A operand - a gradient - rounded to bf16: a_lo b_hi not issued; engine_backward_products=%s)"
+        % eng.backward_products if bwd == 2 else "")
+    if eng.pass_skip:
+        txt += "; overrides: " + ", ".join("%s: %d" % (c, 3 - bin(b & 3).count("1")) for c, b in sorted(eng.pass_skip.items()))
+    return txt
 
 
-def _dtype_label(precision, eng):
+def _dtype_label(precision, eng, frames):
     if precision == "f32":
         return "f32"
-    base = "f32 (GEMM operands split into bf16 hi+lo, f32 accumulate"
-    if not eng.pass_skip:
-        return base + ", three products)"
-    return base + "; products per class: " + _products_label(precision, eng) + ")"
+    bwd = eng.backward_product_count(frames)
+    return "f32 (GEMM operands split into bf16 hi+lo, f32 accumulate; %s)" % (
+        "three products in every GEMM" if bwd == 3 and not eng.pass_skip else
+        "three products in the forward GEMMs, two in the backward GEMMs" if not eng.pass_skip else _products_label(precision, eng, frames))
 
 
 def bench_sample(args, model, spec, device, world, rank, hp):
@@ -420,7 +447,7 @@ def bench_sample(args, model, spec, device, world, rank, hp):
         "value": frames / elapsed, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps, "host_issue_ms_per_step": host_issue,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": _dtype_label(args.precision, eng),
+        "dtype": _dtype_label(args.precision, eng, 0),
         "data": "synthetic",
         "config": {"workload": "autoregressive sampling, batch %d, seq_len %d (%d generated frames per sequence), "
                                "BASELINE.json configs[3]" % (B, T, nframes), "K": spec.Ks, "H": spec.H,
@@ -461,6 +488,8 @@ def main():
                     help="train: BASELINE.json configs[1] (the headline metric); sample: configs[3], autoregressive "
                          "inference at --batch 1024 --seq-len 300 unless given; deep: configs[4], the training step of a "
                          "K=32 x L=3 flow at --batch 128 --seq-len 512 unless given")
+    ap.add_argument("--graph-steps", type=int, default=20,
+                    help="N = 1: also time this many steps replayed as a captured hipGraph (reported as hipgraph_replay); 0 disables it")
     ap.add_argument("--strong-anchor-batch", type=int, default=2048,
                     help="N = 1, workload train: also time one GPU at this batch (the global batch of configs[2]) and report it "
                          "as strong_scaling_anchor; 0 disables it")

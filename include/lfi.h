@@ -115,6 +115,10 @@ typedef struct {
    * of the hi plane is used), same indexing as Cr. NULL: the fp32 G above. */
   const void* Gr; int gr_nkt; long gr_col0;
   float* colsum_part; long ld_part;              /* as lfi_gemm_desc: lfi_gemm_planes_colpart_rows(d) rows of per-pass column sums */
+  int out_hi_only;                               /* plane outputs: write the hi planes only - enough for a consumer that takes them
+                                                    as its A operand with skip bit 0 (two products, A rounded to bf16), which never
+                                                    fetches A's lo planes */
+  int tile;                                      /* 0: the library picks 128 x 256 or 256 x 128 tiles by N; 1 / 2 pin them (tests) */
 } lfi_pgemm_desc;
 long lfi_gemm_planes_work_floats(const lfi_pgemm_desc* d);
 long lfi_gemm_planes_colpart_rows(const lfi_pgemm_desc* d);
@@ -258,7 +262,8 @@ int lfi_flow_seq_bwd(const lfi_flow_dims* d, const lfi_flow_params* p, const flo
  * lfi_flow_bwd_emits_planes(d) = 1 when the dims allow it (bf16x3 persistent walk, H and B multiples of 32). */
 int lfi_flow_bwd_emits_planes(const lfi_flow_dims* d);
 int lfi_flow_seq_bwd_planes(const lfi_flow_dims* d, const lfi_flow_params* p, const float* prep,
-                            const float* stash, float gscale, float* bstash, void* dgi_rows, void* dgi_kmajor, void* stream);
+                            const float* stash, float gscale, float* bstash, void* dgi_rows, void* dgi_kmajor,
+                            int hi_only /* 1: the hi planes only (lfi_pgemm_desc.out_hi_only) */, void* stream);
 
 typedef struct {
   float *an_bias, *an_logs, *inv_l, *inv_u, *inv_logs, *inv_w;
@@ -349,6 +354,18 @@ int lfi_grad_sumsq(const float* g, long n, double* sumsq, double* work /* 1024 d
 int lfi_adam_clip_step(float* p, const float* g, float* m, float* v, long n, const double* sumsq,
                        float clip, float gmul, float lr, float beta1, float beta2, float eps, int step_count,
                        void* stream);
+
+/* The training step as a captured hipGraph (lets_face_it_amd/glow/lets_face_it_glow.py, fused_training_step): what changes from
+ * one optimiser step to the next - the dropout-mask key, Adam's bias-corrected step size - lives in a 32-byte device block
+ * (u64 seed, u64 mask offset, f32 step_size = lr / (1 - beta1^t), f32 1 / sqrt(1 - beta2^t)) that lfi_set_step_params fills with
+ * an ordinary launch before every replay; the _dev variants of the two kernels read it instead of taking the values as
+ * arguments. The host computes the two floats exactly as lfi_adam_clip_step does (bit-identical parameters, tested). */
+int lfi_set_step_params(void* params, unsigned long long seed, unsigned long long offset, float step_size, float inv_sqrt_bc2,
+                        void* stream);
+int lfi_dropout_masks_dev(int count, float* const* out, const long* n, const float* keep, const unsigned long long* seed_offset,
+                          void* stream);
+int lfi_adam_clip_step_dev(float* p, const float* g, float* m, float* v, long n, const double* sumsq, float clip, float gmul,
+                           float beta1, float beta2, float eps, const float* hyper /* = params + 16 bytes */, void* stream);
 
 /* ---------------------------------------------------------------- callers either side of the flow (SURVEY.md par. 8f)
  * Window sampler, replaces MimicryDataset.__getitem__ + DataLoader collation (code/glow_pytorch/mimicry_data_module.py:45-78):

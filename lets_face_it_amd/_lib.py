@@ -47,6 +47,7 @@ class PGemmDesc(C.Structure):
         ("Ct", C.c_void_p), ("ct_nkt", C.c_long), ("ct_row0", C.c_long), ("ct_col0", C.c_long),
         ("Gr", C.c_void_p), ("gr_nkt", C.c_int), ("gr_col0", C.c_long),
         ("colsum_part", C.c_void_p), ("ld_part", C.c_long),
+        ("out_hi_only", C.c_int), ("tile", C.c_int),
     ]
 
 
@@ -109,7 +110,7 @@ def lib():
         "lfi_planes_from_f32": (i, [vp, l, l, i, vp, vp]),
         "lfi_gemm_planes": (i, [P(PGemmDesc), vp]),
         "lfi_flow_bwd_emits_planes": (i, [P(FlowDims)]),
-        "lfi_flow_seq_bwd_planes": (i, [P(FlowDims), P(FlowParams), vp, vp, f, vp, vp, vp, vp]),
+        "lfi_flow_seq_bwd_planes": (i, [P(FlowDims), P(FlowParams), vp, vp, f, vp, vp, vp, i, vp]),
         "lfi_planes_t_elems": (l, [l, l]),
         "lfi_planes_t_from_f32": (i, [vp, l, l, l, vp, vp]),
         "lfi_gemm_planes_work_floats": (l, [P(PGemmDesc)]),
@@ -127,6 +128,9 @@ def lib():
         "lfi_gather_windows": (i, [vp, i, i, i, i, i, i, i, vp, vp, i, i, vp]),
         "lfi_pad_rows": (i, [vp, l, i, l, vp, l, vp]),
         "lfi_dropout_masks": (i, [i, P(vp), P(l), P(f), C.c_ulonglong, C.c_ulonglong, vp]),
+        "lfi_dropout_masks_dev": (i, [i, P(vp), P(l), P(f), vp, vp]),
+        "lfi_set_step_params": (i, [vp, C.c_ulonglong, C.c_ulonglong, f, f, vp]),
+        "lfi_adam_clip_step_dev": (i, [vp, vp, vp, vp, l, vp, f, f, f, f, f, vp, vp]),
         "lfi_leaky_grad": (i, [vp, l, vp, l, i, i, f, vp]),
         "lfi_fill_frame_nb": (i, [vp, f, i, i, vp, i, i, vp]),
         "lfi_flow_prep_floats": (l, [P(FlowDims)]),
@@ -174,7 +178,8 @@ EXPORTS = [
     "lfi_flow_stash_floats", "lfi_flow_bstash_floats", "lfi_flow_stash_ptr", "lfi_flow_bstash_ptr",
     "lfi_flow_seq_fwd", "lfi_flow_seq_bwd", "lfi_flow_param_grads_work_floats", "lfi_flow_param_grads",
     "lfi_actnorm_init_stats", "lfi_actnorm_init_apply", "lfi_flow_step", "lfi_flow_sample_work_floats",
-    "lfi_flow_sample_p1_work_floats", "lfi_flow_sample_seq", "lfi_grad_sumsq", "lfi_adam_clip_step", "lfi_selftest_mfma", "lfi_debug_set_stamps",
+    "lfi_flow_sample_p1_work_floats", "lfi_flow_sample_seq", "lfi_grad_sumsq", "lfi_adam_clip_step",
+    "lfi_set_step_params", "lfi_dropout_masks_dev", "lfi_adam_clip_step_dev", "lfi_selftest_mfma", "lfi_debug_set_stamps",
     "lfi_gather_sequences", "lfi_jerk_mean", "lfi_actnorm_forward", "lfi_invconv_work_floats", "lfi_invconv_weights",
 ]
 

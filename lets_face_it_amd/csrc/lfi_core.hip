@@ -192,7 +192,8 @@ __global__ __launch_bounds__(256) void sumsq_stage2(const double* __restrict__ p
 __global__ __launch_bounds__(256) void adam_clip_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                         float* __restrict__ v, long n, const double* __restrict__ sumsq, float clip,
                                                         float gmul, float step_size, float beta1, float beta2, float eps,
-                                                        float inv_sqrt_bc2) {
+                                                        float inv_sqrt_bc2, const float* __restrict__ hyper) {
+  if (hyper) { step_size = hyper[0]; inv_sqrt_bc2 = hyper[1]; }   // device-resident (lfi_adam_clip_step_dev: captured steps)
   float coef = gmul;
   if (clip > 0.0f) {
     const double total = sqrt(sumsq[0]) * (double)fabsf(gmul);
@@ -232,7 +233,18 @@ extern "C" int lfi_adam_clip_step(float* p, const float* g, float* m, float* v, 
   const float inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
   int blocks = (int)min(2048L, (long)lfi_cdiv(n > 0 ? n : 1, 256));
   hipLaunchKernelGGL(adam_clip_kernel, dim3(blocks), dim3(256), 0, st, p, g, m, v, n, sumsq, clip, gmul, step_size, beta1,
-                     beta2, eps, inv_sqrt_bc2);
+                     beta2, eps, inv_sqrt_bc2, (const float*)nullptr);
   LFI_LAUNCH_CHECK("lfi_adam_clip_step");
+  return LFI_OK;
+}
+
+extern "C" int lfi_adam_clip_step_dev(float* p, const float* g, float* m, float* v, long n, const double* sumsq, float clip,
+                                      float gmul, float beta1, float beta2, float eps, const float* hyper, void* stream) {
+  LFI_REQUIRE(p && g && m && v && n >= 0 && hyper, "lfi_adam_clip_step_dev: bad arguments");
+  LFI_REQUIRE(clip <= 0.0f || sumsq, "lfi_adam_clip_step_dev: clipping needs sumsq");
+  int blocks = (int)min(2048L, (long)lfi_cdiv(n > 0 ? n : 1, 256));
+  hipLaunchKernelGGL(adam_clip_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, sumsq, clip, gmul, 0.0f, beta1,
+                     beta2, eps, 0.0f, hyper);
+  LFI_LAUNCH_CHECK("lfi_adam_clip_step_dev");
   return LFI_OK;
 }

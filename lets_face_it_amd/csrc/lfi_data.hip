@@ -87,9 +87,13 @@ __device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned
   }
   o[0] = c0; o[1] = c1; o[2] = c2; o[3] = c3;
 }
-__global__ __launch_bounds__(256) void dropout_masks_kernel(MaskSegs m, unsigned long long seed, unsigned long long offset) {
+// key: a DEVICE pair (seed, offset) when non-null (lfi_dropout_masks_dev: a captured hipGraph replays the launch with the
+// values the host put there before the replay), else the two arguments
+__global__ __launch_bounds__(256) void dropout_masks_kernel(MaskSegs m, unsigned long long seed, unsigned long long offset,
+                                                            const unsigned long long* __restrict__ key) {
   const int seg = blockIdx.y;
   if (seg >= m.count) return;
+  if (key) { seed = key[0]; offset = key[1]; }
   const long n4 = (m.n[seg] + 3) >> 2;
   const float keep = m.keep[seg], inv = 1.0f / keep;
   for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < n4; q += (long)gridDim.x * 256) {
@@ -138,8 +142,37 @@ extern "C" int lfi_pad_rows(const float* src, long rows, int cols, long lds, flo
   return LFI_OK;
 }
 
+static int dropout_masks_launch(int count, float* const* out, const long* n, const float* keep, unsigned long long seed,
+                                unsigned long long offset, const unsigned long long* key, void* stream);
 extern "C" int lfi_dropout_masks(int count, float* const* out, const long* n, const float* keep, unsigned long long seed,
                                  unsigned long long offset, void* stream) {
+  return dropout_masks_launch(count, out, n, keep, seed, offset, nullptr, stream);
+}
+extern "C" int lfi_dropout_masks_dev(int count, float* const* out, const long* n, const float* keep,
+                                     const unsigned long long* seed_offset, void* stream) {
+  LFI_REQUIRE(seed_offset, "lfi_dropout_masks_dev: null key");
+  return dropout_masks_launch(count, out, n, keep, 0ull, 0ull, seed_offset, stream);
+}
+// step_params (device, 32 bytes): [0] mask seed, [1] mask call offset (u64 each), then step_size, 1 / sqrt(1 - beta2^t) (fp32): what
+// changes from one optimiser step to the next when the step itself is a captured hipGraph. One 1-thread launch, values by value.
+namespace {
+__global__ void set_step_params_kernel(unsigned long long* p, unsigned long long seed, unsigned long long offset, float step_size,
+                                       float inv_sqrt_bc2) {
+  p[0] = seed; p[1] = offset;
+  float* f = reinterpret_cast<float*>(p + 2);
+  f[0] = step_size; f[1] = inv_sqrt_bc2;
+}
+}  // namespace
+extern "C" int lfi_set_step_params(void* params, unsigned long long seed, unsigned long long offset, float step_size,
+                                   float inv_sqrt_bc2, void* stream) {
+  LFI_REQUIRE(params && (reinterpret_cast<uintptr_t>(params) & 7) == 0, "lfi_set_step_params: null / misaligned buffer");
+  hipLaunchKernelGGL(set_step_params_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, reinterpret_cast<unsigned long long*>(params), seed,
+                     offset, step_size, inv_sqrt_bc2);
+  LFI_LAUNCH_CHECK("lfi_set_step_params");
+  return LFI_OK;
+}
+static int dropout_masks_launch(int count, float* const* out, const long* n, const float* keep, unsigned long long seed,
+                                unsigned long long offset, const unsigned long long* key, void* stream) {
   LFI_REQUIRE(count >= 0 && count <= 4, "lfi_dropout_masks: %d segments (at most 4)", count);
   if (count == 0) return LFI_OK;
   LFI_REQUIRE(out && n && keep, "lfi_dropout_masks: null pointer");
@@ -153,7 +186,7 @@ extern "C" int lfi_dropout_masks(int count, float* const* out, const long* n, co
   m.count = count;
   if (nmax == 0) return LFI_OK;
   const long blocks = ((nmax + 3) / 4 + 255) / 256;
-  hipLaunchKernelGGL(dropout_masks_kernel, dim3((unsigned)(blocks < 2048 ? blocks : 2048), count), dim3(256), 0, (hipStream_t)stream, m, seed, offset);
+  hipLaunchKernelGGL(dropout_masks_kernel, dim3((unsigned)(blocks < 2048 ? blocks : 2048), count), dim3(256), 0, (hipStream_t)stream, m, seed, offset, key);
   LFI_LAUNCH_CHECK("lfi_dropout_masks");
   return LFI_OK;
 }

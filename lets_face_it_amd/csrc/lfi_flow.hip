@@ -44,6 +44,7 @@ struct FlowK {
   // backward recurrent weights pre-split into bf16 hi / lo 32-k fragments (bf16 x 3 walk): [Ks][NG][H16/32][J][4 lane groups],
   // one uint4 per entry and plane; the lo plane follows the hi plane of an image
   const uint4 *xbwh, *xbwz;
+  int dgi_hi_only;         // the dgi planes' hi halves only (their consumers take them as a rounded A operand: two products)
   __bf16 *bDgiR, *bDgiT;   // backward walk (bf16x3): dgi also as row planes / k-major planes of the (Ks F x G) matrix (lfi_flow_seq_bwd_planes)
   int C16, Ch16, H16, Co16, NG;
   // forward stash
@@ -2330,9 +2331,8 @@ __global__ __launch_bounds__(NT) void flow_pipe_bwd_kernel(FlowK f) {
           so = i * ldx + (q >> 2) * 32 + (q & 3) * 8;
           dst = tbase + (long)(q >> 2) * nktKF * 2048 + lfi_t_plane_offset(i, q & 3);
         }
-        const uint4 h = *reinterpret_cast<const uint4*>(GiH + so), l = *reinterpret_cast<const uint4*>(GiL + so);
-        *reinterpret_cast<uint4*>(dst) = h;
-        *reinterpret_cast<uint4*>(dst + 1024) = l;
+        *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(GiH + so);
+        if (!f.dgi_hi_only) *reinterpret_cast<uint4*>(dst + 1024) = *reinterpret_cast<const uint4*>(GiL + so);
       }
     }
   }
@@ -3076,11 +3076,11 @@ extern "C" int lfi_flow_bwd_emits_planes(const lfi_flow_dims* d) { return flow_b
 
 extern "C" int lfi_flow_seq_bwd(const lfi_flow_dims* d, const lfi_flow_params* p, const float* prep, const float* stash,
                                 float gscale, float* bstash, void* stream) {
-  return lfi_flow_seq_bwd_planes(d, p, prep, stash, gscale, bstash, nullptr, nullptr, stream);
+  return lfi_flow_seq_bwd_planes(d, p, prep, stash, gscale, bstash, nullptr, nullptr, 0, stream);
 }
 
 extern "C" int lfi_flow_seq_bwd_planes(const lfi_flow_dims* d, const lfi_flow_params* p, const float* prep, const float* stash,
-                                       float gscale, float* bstash, void* dgi_rows, void* dgi_kmajor, void* stream) {
+                                       float gscale, float* bstash, void* dgi_rows, void* dgi_kmajor, int hi_only, void* stream) {
   FlowK f = {};
   int rc = fill_flow(d, p, prep, &f, "lfi_flow_seq_bwd");
   if (rc) return rc;
@@ -3094,6 +3094,7 @@ extern "C" int lfi_flow_seq_bwd_planes(const lfi_flow_dims* d, const lfi_flow_pa
   bind_bstash(&f, bstash);
   f.bDgiR = reinterpret_cast<__bf16*>(dgi_rows);
   f.bDgiT = reinterpret_cast<__bf16*>(dgi_kmajor);
+  f.dgi_hi_only = hi_only ? 1 : 0;
   f.gscale = gscale;
   hipStream_t st = (hipStream_t)stream;
   const bool fast = flow_fast_ok(f.C, f.H, f.Cout) && !flow_force_generic();

@@ -52,6 +52,7 @@ struct GemmArgs {
   __bf16* Cr; int nktCr; long colCr;        // row planes of the result: rows = C rows, k = colCr + batch * strideC + C column
   __bf16* Ct; long nktCt; long rowCt, colCt;  // k-major planes: mn = colCt + batch * strideC + C column, k = rowCt + C row
   const __bf16* Gr; int nktGr; long colGr;  // act == 2: row planes of G (hi plane read) instead of g.G
+  int hiOnly;                               // plane outputs: the hi planes only (their consumer takes them as a rounded A operand)
 };
 
 __device__ __forceinline__ float apply_act(float v, int act, float slope, const float* G, long gidx) {
@@ -171,7 +172,7 @@ __device__ __forceinline__ void gemm_emit_planes(const GemmArgs& g, const float*
       const long rt = (row0 + rtl * 32) >> 5, kt = (g.colCr + gcol0 + ktl * 16) >> 4;
       u32x4* dst = reinterpret_cast<u32x4*>(g.Cr + ((rt * g.nktCr + kt) * 2) * 512) + lane;
       __builtin_nontemporal_store(pg_u4(h), dst);
-      __builtin_nontemporal_store(pg_u4(l), dst + 64);
+      if (!g.hiOnly) __builtin_nontemporal_store(pg_u4(l), dst + 64);
     }
   }
   if (g.Ct) {
@@ -187,7 +188,7 @@ __device__ __forceinline__ void gemm_emit_planes(const GemmArgs& g, const float*
       const long mt = (g.colCt + gcol0 + mtl * 32) >> 5, kt = (g.rowCt + row0 + ktl * 16) >> 4;
       char* dst = reinterpret_cast<char*>(g.Ct) + ((mt * g.nktCt + kt) * 2) * 1024 + off;
       __builtin_nontemporal_store(pg_u4(h), reinterpret_cast<u32x4*>(dst));
-      __builtin_nontemporal_store(pg_u4(l), reinterpret_cast<u32x4*>(dst + 1024));
+      if (!g.hiOnly) __builtin_nontemporal_store(pg_u4(l), reinterpret_cast<u32x4*>(dst + 1024));
     }
   }
 }

@@ -16,7 +16,7 @@
 //     transposing read: 4 k rows x 16 mn per 16 lanes) at byte offsets toff and toff ^ 128 - the two 16-lane groups of a
 //     32-lane half land in opposite 128-byte halves of the 256-byte bank row, conflict-free (cdna_hip_programming.md T10).
 //
-// Kernel: 128 x 256 tile, TWO workgroups per CU: 512 threads = 8 waves x (64 x 64) patches (wm = wave >> 2, wn = wave & 3),
+// Kernel: 128 x 256 tile (or 256 x 128: template WMT x WNT), TWO workgroups per CU: 512 threads = 8 waves x (64 x 64) patches (wm = wave >> 2, wn = wave & 3),
 // ring of 3 slots of one 16-deep k-tile each, [A: 4 mn tiles x {hi, lo} x 1 KB][B: 8 x 2 x 1 KB] = 24 KB (72 KB; the wide
 // epilogue's 64-row passes of 66.5 KB fit inside), three DMA pieces per wave and k-tile.
 //   phase t:  DMA tile t + 3 -> slot t % 3 (its fragments were read in phase t - 1)
@@ -53,15 +53,24 @@ __device__ __forceinline__ bf16x8 pg_frag(const char* blk, int lane, int toff) {
 
 #define PG_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
 
-template <bool AT, bool BT, bool COLP>
+// WMT x WNT waves of 64 x 64 patches (WMT * WNT = 8): 2 x 4 = the 128 x 256 tile, 4 x 2 = a 256 x 128 tile for products whose N
+// fills 128-wide tiles better than 256-wide ones (gic: N = 3 H = 384; the cond_transform weight gradient: N = 896). Same slot
+// size (2 (WMT + WNT) mn tiles x 2 planes = 24 blocks), same phases.
+template <bool AT, bool BT, bool COLP, int WMT, int WNT>
 __global__ __launch_bounds__(512, 4) void gemm_planes_kernel(GemmArgs g) {
   constexpr int XT = 2;   // skip switch compiled in (no register cost here)
+  constexpr int NA = 4 * WMT;   // A blocks per slot (2 WMT mn tiles x 2 planes); B: 4 WNT
+  static_assert(WMT * WNT == 8 && NA + 4 * WNT == 24, "eight waves, 24 blocks per slot");
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, half = lane >> 5;
   int tm, tn, batch, split;
   gemm_tile_of_block(g, &tm, &tn, &batch, &split);
-  const int m0 = tm * 128, n0 = tn * 256;
+  const int m0 = tm * 64 * WMT, n0 = tn * 64 * WNT;
+  // two products per k-step with A rounded to bf16 (skip bit 0: a_lo * b_hi never issued): A's lo planes are not fetched (their
+  // slot blocks are filled from the hi planes again - an L2 hit, which keeps every wave at three DMA pieces per k-tile and the
+  // counted waits as they are) and not read, so the producer of A need not even write them (lfi_pgemm_desc.out_hi_only)
+  const bool noalo = LFI_GSKIP(1);
   // this split's k-tiles: [kt0, kt0 + nkt)
   const int ktc = g.kchunk >> 4;
   const int kt0 = split * ktc;
@@ -69,15 +78,16 @@ __global__ __launch_bounds__(512, 4) void gemm_planes_kernel(GemmArgs g) {
   char* lds = reinterpret_cast<char*>(xsmem);
   // the slot's 24 blocks (A: 4 mn tiles x 2 planes, then B: 8 x 2) are dealt to the 8 waves three at a time; a tile's two
   // planes are adjacent in memory and in the slot
-  const char* baseA = reinterpret_cast<const char*>(g.Ap + batch * g.pstrideA) + ((long)(tm * 4) * g.nktA + kt0) * 2048 + lane * 16;
-  const char* baseB = reinterpret_cast<const char*>(g.Bp + batch * g.pstrideB) + ((long)(tn * 8) * g.nktB + kt0) * 2048 + lane * 16;
+  const char* baseA = reinterpret_cast<const char*>(g.Ap + batch * g.pstrideA) + ((long)(tm * 2 * WMT) * g.nktA + kt0) * 2048 + lane * 16;
+  const char* baseB = reinterpret_cast<const char*>(g.Bp + batch * g.pstrideB) + ((long)(tn * 2 * WNT) * g.nktB + kt0) * 2048 + lane * 16;
   const char* src[3];
   int doff[3];
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
     const int j = wave * 3 + i;                       // block 0 .. 23
-    const int isB = j >= 8, jj = isB ? j - 8 : j;     // (mn tile, plane) = (jj >> 1, jj & 1)
-    src[i] = (isB ? baseB + (long)(jj >> 1) * g.nktB * 2048 : baseA + (long)(jj >> 1) * g.nktA * 2048) + (jj & 1) * 1024;
+    const int isB = j >= NA, jj = isB ? j - NA : j;   // (mn tile, plane) = (jj >> 1, jj & 1)
+    const int plane = (!isB && noalo) ? 0 : (jj & 1);
+    src[i] = (isB ? baseB + (long)(jj >> 1) * g.nktB * 2048 : baseA + (long)(jj >> 1) * g.nktA * 2048) + plane * 1024;
     doff[i] = j * 1024;
   }
   auto dma = [&](int kt, int slot) {
@@ -86,12 +96,12 @@ __global__ __launch_bounds__(512, 4) void gemm_planes_kernel(GemmArgs g) {
     for (int i = 0; i < 3; ++i)
       __builtin_amdgcn_global_load_lds((pglb_void*)(src[i] + ko), (plds_void*)(lds + slot * QSLOT + doff[i]), 16, 0, 0);
   };
-  const int wm = wave >> 2, wn = wave & 3;
+  const int wm = wave / WNT, wn = wave % WNT;
   // k-major blocks: lane 16 g + 4 q + p addresses k row q (of 4), mn columns 4 p .. + 3 of sub-tile (k half g >> 1, mn half g & 1)
   const int tg = lane >> 4, tq = (lane >> 2) & 3, tp = lane & 3;
   const int toff = ((tg >> 1) * 2 + (tg & 1)) * 256 + ((tq ^ ((tg & 1) << 2)) * 32) + tp * 8;
   const int fa = (wm * 4) * 1024;             // A fragment (mt, plane) in block fa + (mt * 2 + plane) * 1024
-  const int fb = 8 * 1024 + (wn * 4) * 1024;  // B fragment (nt, plane) in block fb + (nt * 2 + plane) * 1024
+  const int fb = NA * 1024 + (wn * 4) * 1024;  // B fragment (nt, plane) in block fb + (nt * 2 + plane) * 1024
   auto fragA = [&](int slot, int off) { return pg_frag<AT>(lds + slot * QSLOT + fa + off, lane, toff); };
   auto fragB = [&](int slot, int off) { return pg_frag<BT>(lds + slot * QSLOT + fb + off, lane, toff); };
 
@@ -110,7 +120,9 @@ __global__ __launch_bounds__(512, 4) void gemm_planes_kernel(GemmArgs g) {
     __builtin_amdgcn_s_barrier();
 #pragma unroll
     for (int t2 = 0; t2 < 2; ++t2) {
-      ah[t2] = fragA(0, (t2 * 2) * 1024); al[t2] = fragA(0, (t2 * 2 + 1) * 1024);
+      ah[t2] = fragA(0, (t2 * 2) * 1024);
+      if (!noalo) al[t2] = fragA(0, (t2 * 2 + 1) * 1024);
+      else al[t2] = ah[t2];
       bh[t2] = fragB(0, (t2 * 2) * 1024); bl[t2] = fragB(0, (t2 * 2 + 1) * 1024);
     }
     asm volatile("s_waitcnt vmcnt(3)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
@@ -133,7 +145,9 @@ __global__ __launch_bounds__(512, 4) void gemm_planes_kernel(GemmArgs g) {
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt) acc[0][nt] = PG_MFMA(ah[0], bh[nt], acc[0][nt]);
       __builtin_amdgcn_sched_barrier(0);
-      nah[0] = fragA(nxt, 0); nal[0] = fragA(nxt, 1024);
+      nah[0] = fragA(nxt, 0);
+      if (!noalo) nal[0] = fragA(nxt, 1024);
+      else nal[0] = nah[0];
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt) { nbh[nt] = fragB(nxt, (nt * 2) * 1024); nbl[nt] = fragB(nxt, (nt * 2 + 1) * 1024); }
       __builtin_amdgcn_sched_barrier(0);
@@ -148,7 +162,9 @@ __global__ __launch_bounds__(512, 4) void gemm_planes_kernel(GemmArgs g) {
 #pragma unroll
       for (int nt = 0; nt < 2; ++nt) acc[1][nt] = PG_MFMA(ah[1], bh[nt], acc[1][nt]);
       __builtin_amdgcn_sched_barrier(0);
-      nah[1] = fragA(nxt, 2048); nal[1] = fragA(nxt, 3072);
+      nah[1] = fragA(nxt, 2048);
+      if (!noalo) nal[1] = fragA(nxt, 3072);
+      else nal[1] = nah[1];
       asm volatile("s_waitcnt vmcnt(3)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
 #pragma unroll
@@ -158,8 +174,10 @@ __global__ __launch_bounds__(512, 4) void gemm_planes_kernel(GemmArgs g) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the re-fetched tail tiles: landed before the epilogue reuses the ring
   }
   __syncthreads();
-  if (g.vecC) gemm_epilogue_wide<256, 512, 2, COLP, true>(g, acc, reinterpret_cast<float*>(xsmem), 64, m0, n0, wm, wn, l31, half, batch, split, 128);
-  else gemm_epilogue_n<256>(g, acc, m0, n0, wm, wn, l31, half, batch, split);
+  // the tile passes through LDS in blocks of rows that fit the ring's 72 KB: 64 rows of 256 columns, 128 rows of 128
+  if (g.vecC) gemm_epilogue_wide<64 * WNT, 512, 2, COLP, true>(g, acc, reinterpret_cast<float*>(xsmem), WNT == 4 ? 64 : 128, m0, n0, wm, wn,
+                                                             l31, half, batch, split, 64 * WMT);
+  else gemm_epilogue_n<64 * WNT>(g, acc, m0, n0, wm, wn, l31, half, batch, split);
 }
 
 // fp32 (rows x cols, row pitch ldx) -> bf16 hi / lo ROW planes, zero padded to rows_pad x 16 nkt:
@@ -220,25 +238,34 @@ __global__ __launch_bounds__(256) void planes_t_from_f32_kernel(const float* __r
   }
 }
 
-template <bool COLP>
+template <bool COLP, int WMT, int WNT>
 int launch_planes(const GemmArgs& a, int at, int bt, dim3 grid, size_t lds, hipStream_t st) {
   static bool attr = false;
   if (!attr) {
-    hipError_t e1 = hipFuncSetAttribute((const void*)gemm_planes_kernel<false, false, COLP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipError_t e2 = hipFuncSetAttribute((const void*)gemm_planes_kernel<false, true, COLP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipError_t e3 = hipFuncSetAttribute((const void*)gemm_planes_kernel<true, false, COLP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipError_t e4 = hipFuncSetAttribute((const void*)gemm_planes_kernel<true, true, COLP>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e1 = hipFuncSetAttribute((const void*)gemm_planes_kernel<false, false, COLP, WMT, WNT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e2 = hipFuncSetAttribute((const void*)gemm_planes_kernel<false, true, COLP, WMT, WNT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e3 = hipFuncSetAttribute((const void*)gemm_planes_kernel<true, false, COLP, WMT, WNT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e4 = hipFuncSetAttribute((const void*)gemm_planes_kernel<true, true, COLP, WMT, WNT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess) {
       lfi_set_error("lfi_gemm_planes: cannot reserve %zu bytes of LDS", lds);
       return LFI_ERR_LAUNCH;
     }
     attr = true;
   }
-  if (!at && !bt) hipLaunchKernelGGL((gemm_planes_kernel<false, false, COLP>), grid, dim3(512), lds, st, a);
-  else if (!at) hipLaunchKernelGGL((gemm_planes_kernel<false, true, COLP>), grid, dim3(512), lds, st, a);
-  else if (!bt) hipLaunchKernelGGL((gemm_planes_kernel<true, false, COLP>), grid, dim3(512), lds, st, a);
-  else hipLaunchKernelGGL((gemm_planes_kernel<true, true, COLP>), grid, dim3(512), lds, st, a);
+  if (!at && !bt) hipLaunchKernelGGL((gemm_planes_kernel<false, false, COLP, WMT, WNT>), grid, dim3(512), lds, st, a);
+  else if (!at) hipLaunchKernelGGL((gemm_planes_kernel<false, true, COLP, WMT, WNT>), grid, dim3(512), lds, st, a);
+  else if (!bt) hipLaunchKernelGGL((gemm_planes_kernel<true, false, COLP, WMT, WNT>), grid, dim3(512), lds, st, a);
+  else hipLaunchKernelGGL((gemm_planes_kernel<true, true, COLP, WMT, WNT>), grid, dim3(512), lds, st, a);
   return LFI_OK;
+}
+
+// 128 x 256 tiles unless 128-wide column tiles waste at least 10 % less of the matrix pipe on padding columns (lfi_pgemm_desc.tile
+// pins it: 1 = 128 x 256, 2 = 256 x 128)
+bool planes_tall_tile(const lfi_pgemm_desc* d) {
+  if (d->tile == 1) return false;
+  if (d->tile == 2) return true;
+  const double w256 = (double)lfi_cdiv(d->N, 256) * 256.0 / d->N, w128 = (double)lfi_cdiv(d->N, 128) * 128.0 / d->N;
+  return w128 < 0.9 * w256;
 }
 
 }  // namespace
@@ -294,7 +321,7 @@ extern "C" long lfi_gemm_planes_colpart_rows(const lfi_pgemm_desc* d) {
   if (!d || d->M <= 0 || d->N <= 0 || d->splitk > 1) return 0;
   if (d->batch > 1 && !(d->strideC > 0 && d->strideC * d->batch <= d->ldc)) return 0;
   if (d->ldc % 4 != 0 || d->strideC % 4 != 0 || (d->act == 2 && d->accumulate != 0)) return 0;
-  return (long)lfi_cdiv(d->M, 128) * 2;
+  return planes_tall_tile(d) ? (long)lfi_cdiv(d->M, 256) * 2 : (long)lfi_cdiv(d->M, 128) * 2;   // two passes per tile either way
 }
 
 extern "C" int lfi_gemm_planes(const lfi_pgemm_desc* d, void* stream) {
@@ -350,8 +377,10 @@ extern "C" int lfi_gemm_planes(const lfi_pgemm_desc* d, void* stream) {
     a.vecC = (c_ok && g_ok && !(d->act == 2 && d->accumulate != 0)) ? 1 : 0;
     LFI_REQUIRE(a.vecC || !(planes_io || d->colsum_part), "lfi_gemm_planes: plane outputs / column sums need 16-byte granular C rows");
   }
-  a.tiles_m = lfi_cdiv(d->M, 128);
-  a.tiles_n = lfi_cdiv(d->N, 256);
+  a.hiOnly = d->out_hi_only ? 1 : 0;
+  const bool tall = planes_tall_tile(d);
+  a.tiles_m = lfi_cdiv(d->M, tall ? 256 : 128);
+  a.tiles_n = lfi_cdiv(d->N, tall ? 128 : 256);
   {
     // an XCD walks its run of tiles in groups of `gm` tile rows, column by column. PMC (cond_transform forward, 80 MB of
     // operand planes): groups of 8 rows fetch 790 MB per launch into the L2s, one group of 14 per XCD (B once per XCD, but
@@ -366,8 +395,10 @@ extern "C" int lfi_gemm_planes(const lfi_pgemm_desc* d, void* stream) {
   }
   const size_t lds = (size_t)QRING * QSLOT;   // 72 KB: two workgroups per CU; the epilogue's 64 x 260 floats fit inside
   dim3 grid(a.tiles_m * a.tiles_n, d->batch, splitk);
-  const int rc = a.colpart ? launch_planes<true>(a, d->a_fmt, d->b_fmt, grid, lds, (hipStream_t)stream)
-                           : launch_planes<false>(a, d->a_fmt, d->b_fmt, grid, lds, (hipStream_t)stream);
+  const int rc = tall ? (a.colpart ? launch_planes<true, 4, 2>(a, d->a_fmt, d->b_fmt, grid, lds, (hipStream_t)stream)
+                                   : launch_planes<false, 4, 2>(a, d->a_fmt, d->b_fmt, grid, lds, (hipStream_t)stream))
+                      : (a.colpart ? launch_planes<true, 2, 4>(a, d->a_fmt, d->b_fmt, grid, lds, (hipStream_t)stream)
+                                   : launch_planes<false, 2, 4>(a, d->a_fmt, d->b_fmt, grid, lds, (hipStream_t)stream));
   if (rc) return rc;
   LFI_LAUNCH_CHECK("lfi_gemm_planes");
   if (splitk > 1) {

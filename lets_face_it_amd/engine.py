@@ -27,6 +27,8 @@ ENC_ORDER = ("p1_face", "p2_face", "p1_speech", "p2_speech")  # FeatureEncoder c
 FLOW_FIELDS = ("an_bias", "an_logs", "inv_l", "inv_u", "inv_logs", "inv_w", "w_ih", "w_hh", "b_ih", "b_hh",
                "wct", "bct", "w_fl", "b_fl", "l_fl")
 ENC_LEAVES = ("weight_ih", "weight_hh", "bias_ih", "bias_hh")
+# GEMM classes of the backward pass (tools/precision_sweep.py): they leave the NLL untouched
+BWD_CLASSES = ("dpre", "cond_wgrad", "cond_dgrad", "flow_pgrads", "enc_dwih", "enc_dwhh")
 
 
 def _stream():
@@ -230,6 +232,17 @@ class GlowEngine:
         # 1e-5 ... 4e-5 of the 1e-4 NLL gate EACH, the backward classes leave the NLL alone but put single gradient tensors at
         # 1.3e-3 ... 3.3e-3 relative L2 (gate 2e-3; the encoders' dW_hh, the mildest, still 1.9e-3 on its smallest tensor) -
         # so the default is empty: three products everywhere. LFI_PASS_SKIP="cls=bits,..." sets entries for timing runs.
+        # bf16 products per k-step in the BACKWARD GEMM classes (BWD_CLASSES): 3, 2 (the A operand - always a gradient: dgi,
+        # dpre, dgh, scattered dgi - rounded to bf16, i.e. the a_lo b_hi product not issued) or "auto" = 2 once a step holds
+        # >= 8192 frames, else 3. Evidence (profiles/precision_sweep_b256.md, profiles/round3_loss_curve_ab.md): at the benchmark's
+        # 14 336 frames every backward class with two products keeps the per-tensor gradient gate (worst tensor 8.7e-4 of 2e-3
+        # relative L2 against the fp64 oracle; three products: 4.7e-4), the per-frame NLL is untouched (forward classes keep three),
+        # and a 200-step loss curve is indistinguishable from the three-product one (parameter distance 8.5e-6 against 1.4e-3 for
+        # another dropout seed). At a few hundred frames single small tensors exceed the gate (1.3e-3 .. 1.9e-3 per class), hence
+        # the threshold. hparams `engine_backward_products` / LFI_BWD_PRODUCTS override.
+        bp = os.environ.get("LFI_BWD_PRODUCTS", "auto")
+        self.backward_products = bp if bp == "auto" else int(bp)
+        self._bwd_skip = 0   # skip bits of the backward classes for the backward pass in progress (set by backward())
         self.tile_pin = {k.strip(): int(v) for k, v in (it.split("=") for it in os.environ.get("LFI_TILE_PIN", "").split(",") if it)}
         self.pass_skip = {}
         env = os.environ.get("LFI_PASS_SKIP", "")
@@ -238,6 +251,19 @@ class GlowEngine:
         for item in filter(None, [] if env.strip() == "none" else env.split(",")):
             name, bits = item.split("=")
             self.pass_skip[name.strip()] = int(bits)
+
+    def _skip_bits(self, cls):
+        """bf16x3 products to drop for GEMM class `cls` (bit 0: a_lo b_hi, bit 1: a_hi b_lo): an explicit pass_skip entry
+        (measurement runs), else the backward pass's product count for the backward classes, else none."""
+        if cls in self.pass_skip:
+            return self.pass_skip[cls] & 3
+        return self._bwd_skip if cls in BWD_CLASSES else 0
+
+    def backward_product_count(self, frames):
+        bp = self.backward_products
+        if not (self.precision & 1):
+            return 3
+        return (2 if frames >= 8192 else 3) if bp == "auto" else int(bp)
 
     # ------------------------------------------------------------------ per-kernel timing (HIP events on the launch stream)
     def enable_timing(self, on=True):
@@ -307,13 +333,15 @@ class GlowEngine:
             t.zero_()
         return t
 
-    def draw_masks(self, B, N, seed):
+    def draw_masks(self, B, N, seed, key_dev=None):
         """{modality: (N, B, hist)} dropout multipliers of the window encoders in ONE launch (lfi_dropout_masks); the call
-        counter makes successive calls independent, (seed, counter) reproduces a call."""
+        counter makes successive calls independent, (seed, counter) reproduces a call. key_dev: a device (seed, offset) pair the
+        kernel reads instead (a captured training step: the caller sets it before every replay and keeps the counter)."""
         segs = [e for e in self.spec.encoders if e.dropout > 0]
         if not segs:
             return None
-        self._mask_calls += 1
+        if key_dev is None:
+            self._mask_calls += 1
         total = sum(N * B * e.hist for e in segs)
         flat = self._buf("dropout_masks", total)
         outs, ns, keeps, masks, off = (C.c_void_p * 4)(), (C.c_long * 4)(), (C.c_float * 4)(), {}, 0
@@ -323,9 +351,15 @@ class GlowEngine:
             outs[i], ns[i], keeps[i] = view.data_ptr(), n, 1.0 - e.dropout
             masks[e.name] = view
             off += n
-        check(self.L.lfi_dropout_masks(len(segs), outs, ns, keeps, int(seed) & (2 ** 64 - 1), self._mask_calls, _stream()),
-              "lfi_dropout_masks")
+        if key_dev is not None:
+            check(self.L.lfi_dropout_masks_dev(len(segs), outs, ns, keeps, key_dev.data_ptr(), _stream()), "lfi_dropout_masks_dev")
+        else:
+            check(self.L.lfi_dropout_masks(len(segs), outs, ns, keeps, int(seed) & (2 ** 64 - 1), self._mask_calls, _stream()),
+                  "lfi_dropout_masks")
         return masks
+
+    def has_dropout(self):
+        return any(e.dropout > 0 for e in self.spec.encoders)
 
     # ------------------------------------------------------------------ second stream
     # Launch-latency-bound and HBM-streaming side work (parameter preparation; the encoders' window scatter + dW_ih) runs on a
@@ -367,7 +401,7 @@ class GlowEngine:
         g.batch, g.strideA, g.strideB, g.strideC, g.strideBias, g.strideG = batch, sA, sB, sC, sBias, sG
         g.accumulate, g.act, g.slope = accumulate, act, slope
         g.splitk = splitk
-        g.precision = self.precision | ((self.pass_skip.get(cls, 0) & 3) << 8 if (self.precision & 1) else 0)
+        g.precision = self.precision | (self._skip_bits(cls) << 8 if (self.precision & 1) else 0)
         if self.tile_pin and (self.precision & 1):   # LFI_TILE_PIN="cls=128|256,...": pin a GEMM class's tile shape (measurement)
             g.precision |= {128: 0x20, 256: 0x10}.get(self.tile_pin.get(cls), 0)
         if splitk > 1 or splitk == 0:  # 0: the library picks the split (and the tile shape) that fills the chip
@@ -423,12 +457,12 @@ class GlowEngine:
                     a_stride=0, b_stride=0, sC=0, sBias=0, sG=0, accumulate=0, c_off=0, bias_off=0, tag=None, cls=None,
                     a_fmt=0, b_fmt=0, a_off=0, b_off=0, splitk=1, ws="scratch.pgemm_splitk", store=True,
                     Cr=None, cr_nkt=0, cr_col0=0, Ct=None, ct_nkt=0, ct_row0=0, ct_col0=0, Gr=None, gr_nkt=0, gr_col0=0,
-                    colsum_into=None):
+                    colsum_into=None, hi_only=False, tile=0):
         """lfi_gemm_planes. a_off / b_off: bf16 elements into the plane buffers (a k-tile range: kt0 * 1024; an mn-tile range:
         tile * nkt * 1024). Cr / Ct: bf16 tensors that receive the result as row / k-major planes; Gr: row planes whose hi plane's
         sign stands in for G (act 2). colsum_into: as gemm(). Returns True when the column sums were taken in the epilogue."""
         g = PGemmDesc()
-        g.skip = self.pass_skip.get(cls, 0) & 3
+        g.skip = self._skip_bits(cls)
         g.M, g.N, g.K = M, N, K
         g.Ap, g.a_nkt, g.a_stride = Ap.data_ptr() + 2 * a_off, a_nkt, a_stride
         g.Bp, g.b_nkt, g.b_stride = Bp.data_ptr() + 2 * b_off, b_nkt, b_stride
@@ -445,6 +479,7 @@ class GlowEngine:
         g.Cr, g.cr_nkt, g.cr_col0 = ptr(Cr), cr_nkt, cr_col0
         g.Ct, g.ct_nkt, g.ct_row0, g.ct_col0 = ptr(Ct), ct_nkt, ct_row0, ct_col0
         g.Gr, g.gr_nkt, g.gr_col0 = ptr(Gr), gr_nkt, gr_col0
+        g.out_hi_only, g.tile = (1 if hi_only else 0), tile
         part, prow = None, 0
         if colsum_into is not None and os.environ.get("LFI_NO_COLPART") != "1":
             prow = int(self.L.lfi_gemm_planes_colpart_rows(C.byref(g)))
@@ -496,6 +531,37 @@ class GlowEngine:
         check(self.L.lfi_colsum_f32(X.data_ptr() + 4 * x_off, ldx, strideX, rows, cols, batch, out.data_ptr(), strideOut,
                                     scale, accumulate, w.data_ptr(), _stream()), "lfi_colsum_f32")
 
+    # ---- the cond_transform / coupling-input products on operand planes end to end ("the chain", bf16x3 mode): every big
+    # operand of the step's GEMMs is split into bf16 hi / lo ONCE, by the kernel that produces it - c by the cond_transform
+    # product's epilogue, d pre-activation by the dpre product's, dgi by the backward walk - and never exists as fp32
+    def _chain_fwd_ok(self):
+        s = self.spec
+        return (self.precision == 1 and os.environ.get("LFI_PGEMM", "1") != "0" and os.environ.get("LFI_PCHAIN", "1") != "0"
+                and s.D % 32 == 0 and s.G % 32 == 0)
+
+    def _chain_ok(self, dims, with_stash):
+        if not self._chain_fwd_ok():
+            return False
+        if not with_stash:
+            return True
+        F = dims.B * dims.N
+        return F % 32 == 0 and bool(self.L.lfi_flow_bwd_emits_planes(C.byref(dims)))
+
+    @staticmethod
+    def _planes_splitk(M, N, K, batch=1, kmin=1024, slots=512):
+        """K split (<= 8) of a product on the 128 x 256-tile planes kernel that best fills whole rounds of its 512 co-resident
+        workgroups, less 3 % per extra partial for the reduce pass."""
+        tiles = ((M + 127) // 128) * ((N + 255) // 256) * batch
+        best, best_score = 1, -1.0
+        for sk in range(1, 9):
+            if sk > 1 and K // sk < kmin:
+                break
+            wg = tiles * sk
+            score = wg / (math.ceil(wg / slots) * slots) * (1.0 - 0.03 * (sk - 1))
+            if score > best_score + 1e-9:
+                best, best_score = sk, score
+        return best
+
     def run_prep(self, with_inverse=False):
         """W = P L U (+ transposes, optional fp64 inverse) once per parameter state, not per call (modules.py:147-178)."""
         d = self._flow_dims(1, 1)
@@ -512,6 +578,14 @@ class GlowEngine:
             # bf16 hi / lo planes of the folded weights for the cond_transform forward product: split once per parameter state
             # here instead of once per row tile (56 times) inside the GEMM
             self._wct_planes = self.planes("wct_planes", self.wct_f, s.ldf, s.Ks * s.D, s.Ef)
+            if self._chain_fwd_ok():
+                # the same weights as k-major planes (the feature-gradient product sums over the Ks D output units), and
+                # W_c = W_ih[:, Ch:] of every flow step both ways: row planes for gic = c W_c^T (sums over D), k-major planes for
+                # d pre-activation = dgi W_c (sums over the gate rows)
+                KD = s.Ks * s.D
+                self._wct_t = self.planes_t("wct_t", self.wct_f, s.ldf, KD, s.ldf)
+                self._wc_r = self.planes("wc_r", self.prep, s.D, s.Ks * s.G, s.D, x_off=self._wc_offset())
+                self._wc_t = self.planes_t("wc_t", self.prep, s.D, s.Ks * s.G, s.D, x_off=self._wc_offset())
 
     # ------------------------------------------------------------------ conditioning
     def _check_input(self, x, name, B, Tmin, dim):
@@ -609,10 +683,26 @@ class GlowEngine:
                                   _stream()), "lfi_pad_rows")
         return xa, wa, ldi
 
-    def _project(self, cond, F):
-        """c = LeakyReLU(cond Wct^T + b) for all Ks steps (one GEMM), gic = c W_ih[:, Ch:]^T + b_ih (batched GEMM)."""
+    def _project(self, cond, F, chain=False, with_stash=False):
+        """c = LeakyReLU(cond Wct^T + b) for all Ks steps (one GEMM), gic = c W_ih[:, Ch:]^T + b_ih (batched GEMM).
+        chain: c leaves the first product as operand planes only (row planes for gic and the backward mask, k-major planes for
+        dW_c when a backward pass follows) -> ((c_r, c_t), gic); otherwise (c as fp32, gic)."""
         s = self.spec
         KD = s.Ks * s.D
+        if chain:
+            cp, nkc = self.planes("cond_planes", cond, s.ldf, F, s.Ef)
+            wp, nkw = self._wct_planes
+            nkKD, nktF = KD // 16, (F + 15) // 16
+            c_r = self.plane_buf("c_r", self.L.lfi_planes_elems(F, KD) + 256 * KD * 2)
+            c_t = self.plane_buf("c_t", self.L.lfi_planes_t_elems(F, KD) + 256 * nktF * 16 * 2) if with_stash else None
+            self.gemm_planes(F, KD, s.Ef, cp, nkc, wp, nkw, None, KD, bias=self.fview("bct"), act=1, slope=0.01, store=False,
+                             Cr=c_r, cr_nkt=nkKD, Ct=c_t, ct_nkt=nktF, tag="gemm_cond_fwd", cls="cond_fwd")
+            gic = self._buf("gic", s.Ks * F * s.G)
+            wr, nkwr = self._wc_r
+            self.gemm_planes(F, s.G, s.D, c_r, nkKD, wr, nkwr, gic, s.G, bias=self.fview("b_ih"), batch=s.Ks,
+                             a_stride=(s.D // 16) * 1024, b_stride=(s.G // 32) * nkwr * 1024, sC=F * s.G, sBias=s.G,
+                             tag="gemm_gic", cls="gic")
+            return (c_r, c_t), gic
         cbuf = self._buf("c", F * KD)
         if self.precision == 1 and os.environ.get("LFI_PGEMM", "1") != "0":
             # operands pre-split into bf16 hi / lo planes in MFMA fragment order, streamed to LDS by LDS-DMA: same products
@@ -648,8 +738,9 @@ class GlowEngine:
         cond = self._buf("cond", F * s.ldf)
         self.build_features(batch, x, B, T, masks, cond, with_stash)
         self._join()
-        cbuf, gic = self._project(cond, F)
         dims = self._flow_dims(B, N)
+        chain = self._chain_ok(dims, with_stash)
+        cbuf, gic = self._project(cond, F, chain, with_stash)
         if init_actnorm is not None:
             self._actnorm_init_walk(x, B, T, F, gic, dims, init_actnorm)
         stash = self._buf("flow_stash", self.L.lfi_flow_stash_floats(C.byref(dims)))
@@ -661,7 +752,7 @@ class GlowEngine:
               "lfi_flow_seq_fwd")
         ctx = _Ctx()
         ctx.batch, ctx.masks, ctx.B, ctx.T, ctx.N, ctx.F = batch, masks, B, T, N, F
-        ctx.cond, ctx.cbuf, ctx.gic, ctx.stash, ctx.dims, ctx.with_stash = cond, cbuf, gic, stash, dims, with_stash
+        ctx.cond, ctx.cbuf, ctx.gic, ctx.stash, ctx.dims, ctx.with_stash, ctx.chain = cond, cbuf, gic, stash, dims, with_stash, chain
         self._last = ctx
         return z, nll
 
@@ -704,7 +795,10 @@ class GlowEngine:
         KD = s.Ks * s.D
         st = _stream()
         dims, p = ctx.dims, self._flow_params()
+        self._bwd_skip = 1 if self.backward_product_count(F) == 2 else 0
         bst = self._buf("flow_bstash", self.L.lfi_flow_bstash_floats(C.byref(dims)))
+        if ctx.chain:
+            return self._backward_chain(ctx, gscale, after_flow, bst)
         check(self.L.lfi_flow_seq_bwd(C.byref(dims), C.byref(p), self.prep.data_ptr(), ctx.stash.data_ptr(), gscale,
                                       bst.data_ptr(), st), "lfi_flow_seq_bwd")
         work = self._buf("scratch.pg", self.L.lfi_flow_param_grads_work_floats(C.byref(dims)))
@@ -714,9 +808,9 @@ class GlowEngine:
         # (same-box A/B: -0.2 ms per step)
         side = self._fork()
         pg_dims = dims
-        if self.pass_skip.get("flow_pgrads") and (self.precision & 1):
+        if self._skip_bits("flow_pgrads") and (self.precision & 1):
             pg_dims = self._flow_dims(B, N)
-            pg_dims.gemm_precision = self.precision | ((self.pass_skip["flow_pgrads"] & 3) << 8)
+            pg_dims.gemm_precision = self.precision | (self._skip_bits("flow_pgrads") << 8)
         check(self.L.lfi_flow_param_grads(C.byref(pg_dims), C.byref(p), self.prep.data_ptr(), ctx.stash.data_ptr(),
                                           bst.data_ptr(), ctx.cbuf.data_ptr(), KD, gscale, C.byref(g), 0, work.data_ptr(),
                                           st, side.cuda_stream if side is not None else None), "lfi_flow_param_grads")
@@ -751,6 +845,80 @@ class GlowEngine:
             # 112 x 5 tiles = 1.09 rounds of the 512 resident workgroups: split K so the tail round is full too
             self.gemm(F, W, KD, dpre, KD, 1, self.wct_f, s.ldf, 0, dcond, ldd, b_off=col0, tag="gemm_cond_dgrad",
                       splitk=0, cls="cond_dgrad")
+            for e in rnn:
+                if e.enc == "mlp":
+                    self._mlp_backward(e, ctx, dcond, ldd, e.fcol - col0)
+                else:
+                    self._encoder_backward(e, ctx, dcond, ldd, e.fcol - col0)
+            self._join()
+
+    def _backward_chain(self, ctx, gscale, after_flow, bst):
+        """backward() with every big GEMM operand on planes (see _chain_fwd_ok): the walk leaves dgi as row + k-major planes,
+        dW_c = dgi^T c, d pre-activation = dgi W_c (masked by the sign of c's planes, emitted as planes in their place), the
+        cond_transform weight gradient and the feature gradient all run on lfi_gemm_planes."""
+        s = self.spec
+        B, T, N, F = ctx.B, ctx.T, ctx.N, ctx.F
+        KD, G, D, Ks = s.Ks * s.D, s.G, s.D, s.Ks
+        st = _stream()
+        dims, p = ctx.dims, self._flow_params()
+        c_r, c_t = ctx.cbuf
+        nkKD, nktF, nktKF, nkG = KD // 16, F // 16, Ks * F // 16, G // 16
+        dgi_r = self.plane_buf("dgi_r", self.L.lfi_planes_elems(Ks * F, G) + 256 * G * 2)
+        dgi_t = self.plane_buf("dgi_t", self.L.lfi_planes_t_elems(Ks * F, G) + 256 * nktKF * 16 * 2)
+        # with two products in their consumers (A rounded to bf16) the lo planes of dgi and of d pre-activation are never
+        # fetched: the walk / the dpre epilogue then write the hi planes only (half the plane traffic)
+        dgi_hi = all(self._skip_bits(c) & 1 for c in ("dpre", "flow_pgrads"))
+        dpre_hi = all(self._skip_bits(c) & 1 for c in ("cond_wgrad", "cond_dgrad"))
+        check(self.L.lfi_flow_seq_bwd_planes(C.byref(dims), C.byref(p), self.prep.data_ptr(), ctx.stash.data_ptr(), gscale,
+                                             bst.data_ptr(), dgi_r.data_ptr(), dgi_t.data_ptr(), 1 if dgi_hi else 0, st),
+              "lfi_flow_seq_bwd_planes")
+        work = self._buf("scratch.pg", self.L.lfi_flow_param_grads_work_floats(C.byref(dims)))
+        g = self._flow_grads()
+        side = self._fork()
+        # k-major planes of the feature matrix for the weight-gradient product below: a 50 MB streaming pass, on the side stream
+        with self._on(side):
+            cond_t, _ = self.planes_t("cond_t", ctx.cond, s.ldf, F, s.ldf)
+        # w_ih[k][:, Ch:] (G x D) = dgi[k]^T c[:, k D:(k + 1) D]: the MFMA-bound flow weight gradient, both operands k-major
+        self.gemm_planes(G, D, F, dgi_t, nktKF, c_t, nktF, self.fview("w_ih", self.grads), s.I, batch=Ks, a_fmt=1, b_fmt=1,
+                         a_stride=(F // 16) * 1024, b_stride=(D // 32) * nktF * 1024, sC=G * s.I, c_off=s.Ch,
+                         splitk=self._planes_splitk(G, D, F, Ks), tag="gemm_dwc", cls="flow_pgrads")
+        pg_dims = dims
+        if self._skip_bits("flow_pgrads") and (self.precision & 1):
+            pg_dims = self._flow_dims(B, N)
+            pg_dims.gemm_precision = self.precision | (self._skip_bits("flow_pgrads") << 8)
+        check(self.L.lfi_flow_param_grads(C.byref(pg_dims), C.byref(p), self.prep.data_ptr(), ctx.stash.data_ptr(),
+                                          bst.data_ptr(), None, KD, gscale, C.byref(g), 0, work.data_ptr(),
+                                          st, side.cuda_stream if side is not None else None), "lfi_flow_param_grads")
+        # d pre-activation of cond_transform = (dgi[k] W_c[k]) * leaky'(c), written as planes IN PLACE of c's (row planes: same
+        # blocks, read for the mask and rewritten by the same workgroup; k-major planes: dW_c above was their last reader); its
+        # epilogue also leaves per-pass column sums: the cond_transform bias gradient
+        wt, nkwt = self._wc_t
+        bct_done = self.gemm_planes(F, D, G, dgi_r, nkG, wt, nkwt, None, KD, act=2, slope=0.01, batch=Ks, b_fmt=1,
+                                    a_stride=(F // 32) * nkG * 1024, b_stride=nkG * 1024, sC=D, store=False,
+                                    Gr=c_r, gr_nkt=nkKD, Cr=c_r, cr_nkt=nkKD, Ct=c_t, ct_nkt=nktF, hi_only=dpre_hi,
+                                    colsum_into=self.fview("bct", self.grads), tag="gemm_dpre", cls="dpre")
+        if not bct_done:
+            raise _lib.LfiError("the dpre product on planes did not take the column-sum epilogue")
+        dpre_r, dpre_t = c_r, c_t
+        # cond_transform weight gradient for all steps at once: dwf (Ks D x ldf) = dpre^T cond, both operands k-major
+        self._join()
+        dwf = self._buf("dwct_f", KD * s.ldf)
+        self.gemm_planes(KD, s.ldf, F, dpre_t, nktF, cond_t, nktF, dwf, s.ldf, a_fmt=1, b_fmt=1,
+                         splitk=self._planes_splitk(KD, s.ldf, F), tag="gemm_cond_wgrad", cls="cond_wgrad")
+        check(self.L.lfi_cols_fold(dwf.data_ptr(), s.ldf, KD, self.unfold.data_ptr(), None, s.E,
+                                   self.fview("wct", self.grads).data_ptr(), s.E, st), "lfi_cols_fold")
+        if after_flow is not None:
+            after_flow()
+        rnn = [e for e in s.encoders if e.enc in ("rnn", "lstm", "mlp")]
+        if rnn:
+            # gradient of the feature matrix, from the 32-column block that holds the first trainable encoder's first column
+            col0 = min(e.fcol for e in rnn) // 32 * 32
+            W = s.Ef - col0
+            ldd = (W + 3) // 4 * 4
+            dcond = self._buf("dcond", F * ldd)
+            wtt, nkwtt = self._wct_t
+            self.gemm_planes(F, W, KD, dpre_r, nkKD, wtt, nkwtt, dcond, ldd, b_fmt=1, b_off=(col0 // 32) * nkwtt * 1024,
+                             splitk=self._planes_splitk(F, W, KD), tag="gemm_cond_dgrad", cls="cond_dgrad")
             for e in rnn:
                 if e.enc == "mlp":
                     self._mlp_backward(e, ctx, dcond, ldd, e.fcol - col0)
@@ -897,17 +1065,32 @@ class GlowEngine:
         return src, (ld - const if reverse else ld + const), h_new, c_new
 
     # ------------------------------------------------------------------ optimiser
+    @staticmethod
+    def adam_step_floats(lr, beta1, beta2, step_count):
+        """(step_size, 1 / sqrt(1 - beta2^t)) exactly as lfi_adam_clip_step derives them from its float arguments (doubles, then
+        rounded to fp32): what a captured step reads from the device block lfi_set_step_params fills."""
+        import numpy as np
+        b1, b2, lr64 = float(np.float32(beta1)), float(np.float32(beta2)), float(np.float32(lr))
+        bc1, bc2 = 1.0 - b1 ** int(step_count), 1.0 - b2 ** int(step_count)
+        return float(np.float32(lr64 / bc1)), float(np.float32(1.0 / math.sqrt(bc2)))
+
     @translate_oom
-    def optimizer_step(self, lr, beta1, beta2, eps, clip=0.0, gmul=1.0):
-        """clip_grad_norm_(clip) + Adam on the flat buffers (lets_face_it_glow.py:61-72; final_model.yaml:126)."""
+    def optimizer_step(self, lr, beta1, beta2, eps, clip=0.0, gmul=1.0, hyper_dev=None):
+        """clip_grad_norm_(clip) + Adam on the flat buffers (lets_face_it_glow.py:61-72; final_model.yaml:126).
+        hyper_dev: device pointer to (step_size, 1 / sqrt(1 - beta2^t)) - a captured step; the caller keeps step_count."""
         if self.adam_m is None:
             self.adam_m = torch.zeros_like(self.params)
             self.adam_v = torch.zeros_like(self.params)
-        self.step_count += 1
         st = _stream()
         if clip and clip > 0:
             check(self.L.lfi_grad_sumsq(self.grads.data_ptr(), self.n_params, self.sumsq.data_ptr(),
                                         self.sumsq_work.data_ptr(), st), "lfi_grad_sumsq")
+        if hyper_dev is not None:
+            check(self.L.lfi_adam_clip_step_dev(self.params.data_ptr(), self.grads.data_ptr(), self.adam_m.data_ptr(),
+                                                self.adam_v.data_ptr(), self.n_params, self.sumsq.data_ptr(),
+                                                float(clip or 0.0), gmul, beta1, beta2, eps, hyper_dev, st), "lfi_adam_clip_step_dev")
+            return
+        self.step_count += 1
         check(self.L.lfi_adam_clip_step(self.params.data_ptr(), self.grads.data_ptr(), self.adam_m.data_ptr(),
                                         self.adam_v.data_ptr(), self.n_params, self.sumsq.data_ptr(),
                                         float(clip or 0.0), gmul, lr, beta1, beta2, eps, self.step_count, st),

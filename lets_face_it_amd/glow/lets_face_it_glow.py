@@ -94,6 +94,78 @@ class LetsFaceItGlow(nn.Module):
                 ev.record(side)
             self._mm_pending = (pinned, ev)
 
+    # ------------------------------------------------------------------ the step as a hipGraph (opt-in: step_graph / LFI_STEP_GRAPH=1)
+    # One optimiser step is ~100 kernel launches issued through Python + ctypes: 1.4-1.6 ms of host time per 8.6 ms step. With
+    # step_graph on, from the third step of a (shape, branch) a single-GPU step is captured ONCE - dropout masks, forward,
+    # backward, grad norm, Adam, on both of the engine's streams - and replayed: the host then issues three launches per step (the
+    # batch copy into the graph's input buffers, lfi_set_step_params, the replay). What differs between steps lives in device
+    # memory: the dropout key and Adam's bias-corrected step size (include/lfi.h, lfi_set_step_params); the ordinary and the
+    # negative-example step (loss x -0.1, lets_face_it_glow.py:40-50) are two graphs. Parameters after replayed steps are
+    # bit-identical to eager steps' (tests/test_gpu_headline_parity.py). Measured on MI355X / ROCm 7.0 (profiles/round3_*): host
+    # issue 1.49 -> 0.80 ms per step (hipGraphLaunch of ~100 nodes on two streams is not free), GPU step time 8.58 -> 8.69 ms: the
+    # eager step's queue is already kept full by the host running ahead (0.1 ms of idle gaps per step), so the replay buys
+    # nothing on one GPU and stays OFF by default; bench.py reports both. Always eager: data-parallel steps (the collectives stay
+    # outside any graph), injected masks, ActNorm's data-dependent init, per-kernel timing (HIP events cannot bracket a kernel
+    # inside a replay).
+    def _graph_key(self, batch, negative, eng):
+        return (bool(negative), eng.precision, str(eng.backward_products), tuple(sorted(eng.pass_skip.items())),
+                tuple((k, tuple(v.shape)) for k, v in sorted(batch.items())))
+
+    def _graph_allowed(self, sg, eng, world_size, allreduce):
+        import os
+        on = self.__dict__.get("step_graph")
+        if on is None:
+            on = os.environ.get("LFI_STEP_GRAPH", "0") == "1"
+        return (bool(on) and (allreduce is None or world_size == 1)
+                and sg.injected_masks is None and sg.training and sg.glow.actnorm_inited() and eng.timers is None
+                and self.hparams.Optim["name"] == "adam")
+
+    def _capture_step(self, key, batch, negative, eng):
+        from .. import _lib
+        sg = self.seq_glow
+        dev = batch["p1_face"].device
+        st = {"in": {k: torch.empty_like(v) for k, v in batch.items()},
+              "params": torch.zeros(4, dtype=torch.int64, device=dev), "graph": torch.cuda.CUDAGraph()}
+        x = batch["p1_face"]
+        B, N = x.shape[0], x.shape[1] - sg.spec.start
+        a = self.hparams.Optim["args"]["adam"]
+        clip = float(getattr(self.hparams, "gradient_clip_val", 0) or 0)
+        sign = -0.1 if negative else 1.0
+        torch.cuda.synchronize(dev)
+        with torch.cuda.graph(st["graph"]):
+            masks = eng.draw_masks(B, N, 0, key_dev=st["params"]) if eng.has_dropout() else None
+            _, nll = eng.forward(st["in"], masks, with_stash=True)
+            st["mean"] = nll.mean().reshape(1)
+            eng.backward(sign / nll.numel())
+            eng.optimizer_step(0.0, float(a["betas"][0]), float(a["betas"][1]), float(a["eps"]), clip=clip, gmul=1.0,
+                               hyper_dev=st["params"].data_ptr() + 16)
+        st["dropout"] = masks is not None
+        return st
+
+    def _replay_step(self, st, batch, lr, negative, eng):
+        from .. import _lib
+        sg = self.seq_glow
+        for k, v in st["in"].items():
+            v.copy_(batch[k], non_blocking=True)
+        a = self.hparams.Optim["args"]["adam"]
+        step_size, inv_sqrt_bc2 = eng.adam_step_floats(lr, float(a["betas"][0]), float(a["betas"][1]), eng.step_count + 1)
+        seed = (torch.initial_seed() + sg.mask_seed_offset) & (2 ** 64 - 1)
+        _lib.check(eng.L.lfi_set_step_params(st["params"].data_ptr(), seed, eng._mask_calls + 1, step_size, inv_sqrt_bc2,
+                                             torch.cuda.current_stream().cuda_stream), "lfi_set_step_params")
+        st["graph"].replay()
+        eng.step_count += 1
+        if st["dropout"]:
+            eng._mask_calls += 1
+        sg._fwd_counter += 1
+        mean = st["mean"].clone()          # the graph's own output buffer is rewritten by the next replay
+        if negative:
+            self.log("Loss/missmatched_nll", -mean)
+            self._store_mismatched(-mean)
+            mean = mean * -0.1
+        self.global_step += 1
+        self.log("train_loss", mean)
+        return mean.detach()
+
     def fused_training_step(self, batch, lr, world_size=1, allreduce=None):
         """One optimiser step entirely in the engine. Returns the (detached) loss of this rank.
 
@@ -108,6 +180,31 @@ class LetsFaceItGlow(nn.Module):
         eng = sg._ensure_engine(x.device)
         B, T = x.shape[0], x.shape[1]
         N = T - sg.spec.start
+        if self._graph_allowed(sg, eng, world_size, allreduce):
+            graphs = self.__dict__.setdefault("_step_graphs", {})
+            if graphs.get("engine") is not eng:      # a re-bound engine (.to() / .float()): its buffers are gone
+                graphs.clear()
+                graphs["engine"] = eng
+            key = self._graph_key(batch, negative, eng)
+            st = graphs.get(key)
+            if st is None and graphs.get(("seen",) + key, 0) >= 2 and not graphs.get("broken"):
+                try:
+                    st = graphs[key] = self._capture_step(key, batch, negative, eng)
+                    # the other branch's graph now too (same shapes, same kernels; capturing executes nothing): a negative step
+                    # turns up once in ten steps, and its capture should not land in the middle of somebody's timed region
+                    if self.hparams.Train["use_negative_nll_loss"] and self.missmatched_modalities:
+                        other = self._graph_key(batch, not negative, eng)
+                        if other not in graphs:
+                            graphs[other] = self._capture_step(other, batch, not negative, eng)
+                except Exception as e:   # a runtime that cannot capture this step keeps launching it eagerly
+                    import warnings
+                    warnings.warn("hipGraph capture of the training step failed (%s: %s); staying with eager launches"
+                                  % (type(e).__name__, e))
+                    graphs["broken"] = True
+                    torch.cuda.synchronize(x.device)
+            if st is not None:
+                return self._replay_step(st, batch, lr, negative, eng)
+            graphs[("seen",) + key] = graphs.get(("seen",) + key, 0) + 1
         masks = sg._draw_masks(B, N, x.device)
         init = sg._allreduce() if (sg.training and not sg.glow.actnorm_inited()) else None
         sg._fwd_counter += 1

@@ -426,6 +426,9 @@ class SeqGlow(nn.Module):
         if eng is None or eng.device != device or not self._still_bound():
             eng = self._bind(device)
         eng.precision = 1 if self.precision == "bf16x3" else 0
+        bp = getattr(self.hparams, "engine_backward_products", None)
+        if bp is not None:
+            eng.backward_products = bp if bp == "auto" else int(bp)
         return eng
 
     def _still_bound(self):

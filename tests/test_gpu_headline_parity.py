@@ -8,6 +8,7 @@ The oracle's fp64 forward + autograd backward at this size is ~1-2 minutes of ho
 glow/models.py:534-561; sampling loop :567-596).
 """
 import time
+from argparse import Namespace
 
 import pytest
 import torch
@@ -32,23 +33,29 @@ def _masks(hp, N, B, seed):
 def test_headline_config_gradients_against_oracle(gpu_device):
     """BASELINE configs[1] itself: B=256, T=80, K=16, injected dropout masks, bf16x3. Per-frame NLL (gate 1e-4 relative,
     north_star) and every parameter gradient (relative L2 against the fp64 oracle, gate 2e-3 as everywhere else; no
-    LeakyReLU-kink allowance is needed with 14 336 frames behind each weight row)."""
+    LeakyReLU-kink allowance is needed with 14 336 frames behind each weight row) - in the engine's default arithmetic at this
+    size (engine_backward_products "auto": two bf16 products in the backward GEMM classes from 8192 frames up) and with three
+    products everywhere."""
     hp = final_model_hparams(50, 27, K=16)
-    m, sd = perturbed_model(hp, gpu_device)
-    m.precision = "bf16x3"
-    m.train()
     B, T = 256, 80
     N = T - 24
     batch = oracle.synthetic_batch(B, T, 50, 27, seed=1234)
     masks = _masks(hp, N, B, 6)
-    m.injected_masks = masks
-    _, loss, losses = m(to_dev(batch, gpu_device))
-    loss.sum().backward()
-    torch.cuda.synchronize()
-    grads = {n: p.grad.detach().double().cpu() for n, p in m.named_parameters()}
-    nll = torch.stack(losses).double().cpu()
-    del m
-    torch.cuda.empty_cache()
+    got = {}
+    for products in ("auto", 3):
+        m, sd = perturbed_model(hp, gpu_device)
+        m.precision = "bf16x3"
+        m.train()
+        m.injected_masks = masks
+        eng = m._ensure_engine(gpu_device)
+        eng.backward_products = products
+        _, loss, losses = m(to_dev(batch, gpu_device))
+        loss.sum().backward()
+        torch.cuda.synchronize()
+        assert eng.backward_product_count(B * N) == (2 if products == "auto" else 3) and bool(eng._last.chain)
+        got[products] = (torch.stack(losses).double().cpu(), {n: p.grad.detach().double().cpu() for n, p in m.named_parameters()})
+        del m, eng
+        torch.cuda.empty_cache()
 
     threads = torch.get_num_threads()
     torch.set_num_threads(min(16, threads))
@@ -60,23 +67,25 @@ def test_headline_config_gradients_against_oracle(gpu_device):
     oloss.sum().backward()
     spent = time.time() - t0
     torch.set_num_threads(threads)
-
-    err = max_rel(nll, onll.detach(), floor=1.0)
     total = float(torch.sqrt(sum((v.grad ** 2).sum() for v in sdg.values() if v.grad is not None)))
-    worst, worst_abs = ("", 0.0), ("", 0.0)
-    for name, g in grads.items():
-        ref = sdg[name].grad
-        diff = float((g - ref).norm())
-        rel = diff / max(float(ref.norm()), 1e-3 * total)
-        if rel > worst[1]:
-            worst = (name, rel)
-        if diff / total > worst_abs[1]:
-            worst_abs = (name, diff / total)
-    report("HEADLINE config (B=256, T=80, K=16, bf16x3) vs fp64 oracle (%.0f s of host time): per-frame NLL max rel err %.3e, "
-           "worst gradient rel L2 %.3e (%s), worst share of the whole gradient's norm %.3e (%s), %d tensors"
-           % (spent, err, worst[1], worst[0], worst_abs[1], worst_abs[0], len(grads)))
-    assert err < 1e-4
-    assert worst[1] < 2e-3, worst
+    for products, (nll, grads) in got.items():
+        err = max_rel(nll, onll.detach(), floor=1.0)
+        worst, raw, num = ("", 0.0), ("", 0.0), 0.0
+        for name, g in grads.items():
+            ref = sdg[name].grad
+            diff = float((g - ref).norm())
+            num += diff ** 2
+            rel = diff / max(float(ref.norm()), 1e-3 * total)
+            if rel > worst[1]:
+                worst = (name, rel)
+            if diff / max(float(ref.norm()), 1e-30) > raw[1]:
+                raw = (name, diff / max(float(ref.norm()), 1e-30))
+        report("HEADLINE config (B=256, T=80, K=16, bf16x3, planes chain, backward products %s) vs fp64 oracle (%.0f s of host "
+               "time): per-frame NLL max rel err %.3e; gradient rel L2: whole %.3e, worst tensor %.3e (%s), worst tensor without "
+               "the norm floor %.3e (%s); %d tensors" % (products, spent, err, num ** 0.5 / total, worst[1], worst[0], raw[1],
+                                                         raw[0], len(grads)))
+        assert err < 1e-4
+        assert raw[1] < 2e-3, (products, raw)
 
 
 def test_k16_sampling_against_oracle(gpu_device):
@@ -139,3 +148,40 @@ def test_strong_scaling_anchor_batch_matches_its_sub_batches(gpu_device):
     err = float((g_all - g_sum / W).norm() / g_all.norm())
     report("global batch 2048 on one GPU vs the mean of its 8 shards of 256: per-frame NLL bit-identical, gradient rel L2 diff %.2e" % err)
     assert err < 2e-5
+
+
+def test_graphed_training_step_is_bit_identical_to_eager(gpu_device, monkeypatch):
+    """with step_graph on (LFI_STEP_GRAPH=1), from its third call a single-GPU fused_training_step is ONE replayed hipGraph (dropout masks,
+    forward, backward, clip, Adam; the dropout key and Adam's step size read from a device block set before every replay; the
+    negative-example step a second graph). Twelve steps at the benchmark's shape with the negative branch forced on steps 4 and
+    9: parameters, Adam moments, the loss of every step and the mismatched-NLL buffer are bit-identical to eager launches."""
+    import random
+    import numpy as np
+    from lets_face_it_amd.glow.lets_face_it_glow import LetsFaceItGlow
+    from lets_face_it_amd.glow.utils import load_hparams_file
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    hp = load_hparams_file(os.path.join(root, "lets_face_it_amd", "hparams", "final_model_synthetic.yaml"))
+    hp["batch_size"] = 64
+    hp["gradient_clip_val"] = 20
+    batches = [to_dev(oracle.synthetic_batch(64, 48, 50, 27, seed=100 + i), gpu_device) for i in range(3)]
+    runs = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("LFI_STEP_GRAPH", mode)   # "1": opt in
+        random.seed(7)
+        np.random.seed(7)
+        torch.manual_seed(7)
+        m = LetsFaceItGlow(Namespace(**__import__("copy").deepcopy(hp))).to(gpu_device).train()
+        forced = iter([False, False, False, False, True, False, False, False, False, True, False, False])
+        m._negative_branch = lambda: next(forced)
+        losses = [m.fused_training_step(batches[i % 3], 1e-4 * (1 + i % 2)).clone() for i in range(12)]
+        eng = m.seq_glow.engine
+        graphs = [v for v in getattr(m, "_step_graphs", {}).values() if isinstance(v, dict)]
+        assert len(graphs) == (2 if mode == "1" else 0), "expected the ordinary and the negative-example graph"
+        runs[mode] = (torch.stack(losses).cpu(), eng.params.clone(), eng.adam_m.clone(), eng.adam_v.clone(), eng.step_count,
+                      eng._mask_calls, m.last_missmatched_nll.clone())
+    a, b = runs["0"], runs["1"]
+    assert a[4] == b[4] == 12 and a[5] == b[5]
+    assert torch.equal(a[0], b[0]), (a[0], b[0])
+    assert torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]) and torch.equal(a[3], b[3]) and torch.equal(a[6], b[6])
+    report("hipGraph-replayed training step vs eager launches, 12 steps (2 negative): losses, parameters, Adam moments bit-identical")

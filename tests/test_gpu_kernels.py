@@ -263,8 +263,8 @@ def test_gemm_on_presplit_planes_batched_k_ranges(eng, gpu_device):
 
 @pytest.mark.parametrize("shape", [(700, 520, 330), (384, 512, 14336), (513, 257, 75), (130, 40, 16), (1024, 896, 2048)])
 @pytest.mark.parametrize("fmt", ["RT", "TR", "TT"])
-@pytest.mark.parametrize("splitk", [1, 3])
-def test_gemm_planes_kmajor_operands_and_split_k(eng, gpu_device, shape, fmt, splitk):
+@pytest.mark.parametrize("splitk,tile", [(1, 1), (3, 1), (1, 2), (2, 2)])
+def test_gemm_planes_kmajor_operands_and_split_k(eng, gpu_device, shape, fmt, splitk, tile):
     """K-major planes (lfi_planes_t_from_f32: the operand form of an fp32 matrix whose ROWS are the contraction index - every
     weight-gradient product sums over frames) in either operand slot, read with ds_read_b64_tr_b16, with and without a K split:
     against the fp64 product and, bit for bit, against lfi_gemm_f32's bf16x3 kernel on the same fp32 operands (same split, same
@@ -291,7 +291,8 @@ def test_gemm_planes_kmajor_operands_and_split_k(eng, gpu_device, shape, fmt, sp
     C1 = torch.full((M, ldc), 7.0, device=gpu_device)
     Ap, nka = eng.planes_t("test.pa", A, lda, K, M) if at else eng.planes("test.pa", A, lda, M, K)
     Bp, nkb = eng.planes_t("test.pb", Bm, ldb, K, N) if bt else eng.planes("test.pb", Bm, ldb, N, K)
-    eng.gemm_planes(M, N, K, Ap, nka, Bp, nkb, C1, ldc, bias=bias, act=1, a_fmt=int(at), b_fmt=int(bt), splitk=splitk)
+    # tile 1: 128 x 256 tiles, 2: 256 x 128 (what the library picks for N = 384 or 896)
+    eng.gemm_planes(M, N, K, Ap, nka, Bp, nkb, C1, ldc, bias=bias, act=1, a_fmt=int(at), b_fmt=int(bt), splitk=splitk, tile=tile)
     C2 = torch.full((M, ldc), 7.0, device=gpu_device)
     eng.precision = 0x11
     try:
@@ -306,6 +307,37 @@ def test_gemm_planes_kmajor_operands_and_split_k(eng, gpu_device, shape, fmt, sp
     assert rel_err(C1[:, :N], ref) < 3e-5
     if splitk == 1:
         assert torch.equal(C1, C2)
+
+
+@pytest.mark.parametrize("fmt", ["RR", "TT"])
+def test_gemm_planes_two_products_never_touch_a_lo(eng, gpu_device, fmt):
+    """Skip bit 0 (two products per k-step, A rounded to bf16): A's lo planes are neither fetched nor read - poisoned with NaN
+    they leave the result unchanged - and the result equals lfi_gemm_f32's two-product kernel bit for bit. That is what lets the
+    producers of A (the backward walk's dgi, the dpre product) write hi planes only (lfi_pgemm_desc.out_hi_only)."""
+    M, N, K = 384, 512, 2048
+    g = torch.Generator().manual_seed(1)
+    at = fmt[0] == "T"
+    A = torch.randn((K, M) if at else (M, K), generator=g).to(gpu_device)
+    Bm = torch.randn((K, N) if at else (N, K), generator=g).to(gpu_device)
+    Ap, nka = eng.planes_t("test.pa", A, M, K, M) if at else eng.planes("test.pa", A, K, M, K)
+    Bp, nkb = eng.planes_t("test.pb", Bm, N, K, N) if at else eng.planes("test.pb", Bm, K, N, K)
+    eng.pass_skip = {"t": 1}
+    try:
+        C1 = torch.zeros(M, N, device=gpu_device)
+        eng.gemm_planes(M, N, K, Ap, nka, Bp, nkb, C1, N, a_fmt=int(at), b_fmt=int(at), cls="t")
+        Ap.view(-1, 2, 512)[:, 1] = float("nan")          # every lo block of A
+        C2 = torch.zeros(M, N, device=gpu_device)
+        eng.gemm_planes(M, N, K, Ap, nka, Bp, nkb, C2, N, a_fmt=int(at), b_fmt=int(at), cls="t")
+        C3 = torch.zeros(M, N, device=gpu_device)
+        eng.precision = 0x11
+        eng.gemm(M, N, K, A, M if at else K, 0 if at else 1, Bm, N if at else K, 0 if at else 1, C3, N, cls="t")
+    finally:
+        eng.precision = 0
+        eng.pass_skip = {}
+    torch.cuda.synchronize()
+    assert torch.isfinite(C2).all() and torch.equal(C1, C2) and torch.equal(C1, C3)
+    ref = (A.t() if at else A).double() @ (Bm if at else Bm.t()).double()
+    assert 1e-5 < rel_err(C1, ref) < 3e-3       # a rounded operand: 2^-9 per element, averaged over K
 
 
 @pytest.mark.parametrize("M,N,K,batch", [(700, 512, 96, 1), (14336 // 8, 128, 384, 4), (333, 96, 64, 2)])
@@ -330,13 +362,13 @@ def test_gemm_planes_emits_its_result_as_planes(eng, gpu_device, M, N, K, batch)
     want_t, nkt = eng.planes_t("test.wt", ref_c, ldc, M, Ncols)
     want_r, want_t = want_r.clone(), want_t.clone()
     n_r, n_t = eng.L.lfi_planes_elems(M, Ncols), eng.L.lfi_planes_t_elems(M, Ncols)
-    for store in (True, False):
+    for store, hi_only, tile in ((True, False, 1), (False, False, 1), (False, True, 2), (True, False, 2)):
         Cr = torch.full((want_r.numel(),), float("nan"), dtype=torch.bfloat16, device=gpu_device)
         Ct = torch.full((want_t.numel(),), float("nan"), dtype=torch.bfloat16, device=gpu_device)
         out = torch.empty(M, ldc, device=gpu_device).fill_(3.0)
         sums = torch.zeros(Ncols, device=gpu_device)
         done = eng.gemm_planes(M, N, K, Ap, nka, Wp, nkw, out, ldc, Gr=Gp, gr_nkt=nkg, store=store, Cr=Cr, cr_nkt=nkr, Ct=Ct,
-                               ct_nkt=nkt, colsum_into=sums, **kw)
+                               ct_nkt=nkt, colsum_into=sums, hi_only=hi_only, tile=tile, **kw)
         torch.cuda.synchronize()
         assert done
         if store:
@@ -344,10 +376,15 @@ def test_gemm_planes_emits_its_result_as_planes(eng, gpu_device, M, N, K, batch)
         else:
             assert bool((out == 3.0).all())
         # every block the consumers read: whole row tiles x k-tiles that hold real rows / columns
+        npl = 1 if hi_only else 2            # hi_only: the lo blocks stay as they were (NaN here)
         r_blocks = Cr[:n_r].view(-1, nkr, 2, 512)[:(M + 31) // 32]
-        assert torch.equal(r_blocks.view(torch.int16), want_r[:n_r].view(-1, nkr, 2, 512)[:(M + 31) // 32].view(torch.int16))
+        assert torch.equal(r_blocks[:, :, :npl].view(torch.int16),
+                           want_r[:n_r].view(-1, nkr, 2, 512)[:(M + 31) // 32][:, :, :npl].view(torch.int16))
         t_blocks = Ct[:n_t].view(-1, nkt, 2, 512)[:(Ncols + 31) // 32]
-        assert torch.equal(t_blocks.view(torch.int16), want_t[:n_t].view(-1, nkt, 2, 512)[:(Ncols + 31) // 32].view(torch.int16))
+        assert torch.equal(t_blocks[:, :, :npl].view(torch.int16),
+                           want_t[:n_t].view(-1, nkt, 2, 512)[:(Ncols + 31) // 32][:, :, :npl].view(torch.int16))
+        if hi_only:
+            assert bool(torch.isnan(r_blocks[:, :, 1].float()).all()) and bool(torch.isnan(t_blocks[:, :, 1].float()).all())
         assert rel_err(sums, ref_c[:, :Ncols].double().sum(0)) < 1e-5
 
 

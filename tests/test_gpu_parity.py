@@ -334,6 +334,37 @@ def test_full_model_k16_gradients_against_oracle(gpu_device, precision):
     assert err < 1e-4 and worst[1] < 2e-3, worst
 
 
+@pytest.mark.parametrize("B,T,K", [(64, 40, 4), (32, 33, 2)])
+def test_planes_chain_matches_the_fp32_operand_path(gpu_device, monkeypatch, B, T, K):
+    """LFI_PCHAIN=0 keeps round 2's data flow (c, dgi and d pre-activation exist as fp32 and every product but cond_transform
+    forward splits its operands itself); the default chain has the producing kernels emit bf16 hi / lo operand planes and runs
+    gic, dW_c, dpre, the cond_transform weight gradient and the feature gradient on lfi_gemm_planes. Same split, same three
+    products per k-step: NLL and every gradient agree to rounding (the K splits of the long products differ)."""
+    hp = final_model_hparams(50, 27, K=K)
+    batch = to_dev(oracle.synthetic_batch(B, T, 50, 27, seed=B), gpu_device)
+    g = torch.Generator().manual_seed(5)
+    masks = {}
+    for name in ("p2_face", "p1_speech", "p2_speech"):
+        cfg = hp["Conditioning"][name]
+        keep = 1.0 - cfg["dropout"]
+        masks[name] = (torch.rand(T - 24, B, cfg["history"], generator=g) < keep).float() / keep
+    outs = []
+    for chain in ("1", "0"):
+        monkeypatch.setenv("LFI_PCHAIN", chain)
+        m, _ = perturbed_model(hp, gpu_device)
+        m.precision = "bf16x3"
+        m.train()
+        m.injected_masks = masks
+        _, loss, losses = m(batch)
+        loss.sum().backward()
+        assert bool(m.engine._last.chain) == (chain == "1")
+        outs.append((torch.stack(losses), {n: p.grad.clone() for n, p in m.named_parameters()}))
+    err = max_rel(outs[0][0], outs[1][0], floor=1.0)
+    worst = max(rel_err(outs[0][1][n], outs[1][1][n]) for n in outs[0][1])
+    report("planes chain vs fp32-operand path (B=%d, T=%d, K=%d): per-frame NLL max rel diff %.2e, worst gradient diff %.2e" % (B, T, K, err, worst))
+    assert err < 2e-6 and worst < 2e-5
+
+
 def test_generic_and_register_resident_cells_agree(gpu_device, monkeypatch):
     """LFI_FLOW_GENERIC=1 keeps the streaming cell kernels (the path of H > 128 or C > 64): same NLL, same gradients."""
     fxm = Fixture("mid")

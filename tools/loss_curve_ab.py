@@ -33,6 +33,7 @@ def run(hp, batches, steps, skip, seed):
     torch.manual_seed(seed)          # the dropout-mask stream is keyed on torch's seed + the engine's call counter
     random.seed(99)                  # the negative-example branch
     eng = m.seq_glow._ensure_engine(dev)
+    eng.backward_products = 3     # the arms differ by their explicit pass_skip entries only
     eng.pass_skip = dict(skip)
     losses = []
     for i in range(steps):
