@@ -292,9 +292,9 @@ def bench_train(args, model, trainer, spec, device, world, rank, hp):
     eng = model.seq_glow.engine
     eng.enable_timing(True)
     elapsed, loss = _timed(step, args.steps, world, device)
-    host_issue = _host_issue_ms(step)
     timing = eng.timing_summary()
     eng.enable_timing(False)
+    host_issue = _host_issue_ms(step, reps=5)   # (without the per-kernel events of the timed region)
     graph_line = None
     if world == 1 and args.graph_steps > 0:
         # the same step as ONE replayed hipGraph (opt-in: LetsFaceItGlow.step_graph; bit-identical parameters): two more eager calls

@@ -155,6 +155,8 @@ typedef struct {
                            cat(seq[:, -1], h_n[0]) does; 0: once (folded feature layout, see lfi_cols_fold) */
   int lstm;             /* 1: "enc: lstm" (nn.LSTM from zero (h, c), gate blocks i, f, g, o; glow/models.py:27-33,65-69): every
                            "3*hid" below reads 4*hid, the gate stash row is 5*hid (i, f, g, o, c) and is required, dgi = dgh */
+  int bwd_two_products; /* lfi_encode_windows_bwd, bf16x3 fused GRU path: 1 = two bf16 products per k-step in the d gates x W_hh
+                           recurrence (d gates rounded to bf16), as lfi_gemm_desc.precision bit 8 does for a GEMM; 0 = three */
 } lfi_enc_desc;
 
 long lfi_encode_windows_work_floats(const lfi_enc_desc* d);

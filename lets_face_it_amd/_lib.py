@@ -54,7 +54,7 @@ class PGemmDesc(C.Structure):
 class EncDesc(C.Structure):
     _fields_ = [("B", C.c_int), ("T", C.c_int), ("N", C.c_int), ("start", C.c_int),
                 ("hist", C.c_int), ("hid", C.c_int), ("ldcond", C.c_int), ("col", C.c_int), ("precision", C.c_int),
-                ("dup", C.c_int), ("lstm", C.c_int)]
+                ("dup", C.c_int), ("lstm", C.c_int), ("bwd_two_products", C.c_int)]
 
 
 class FlowDims(C.Structure):

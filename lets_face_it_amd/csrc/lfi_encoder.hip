@@ -1672,6 +1672,10 @@ __global__ __launch_bounds__(256, 1) void enc_gru_fwd_ws_kernel(EncArgs a, EncWs
 // wave-private transpose tile, a lane owns 4 consecutive hidden units of 8 windows, everything above is a 16-byte access,
 // the images are written 8 bytes at a time, and the tile region doubles as a SECOND image pair while no transpose is in
 // flight, so that the r and z gate products run back to back: four workgroup barriers per step instead of six.
+// A2 (lfi_enc_desc.bwd_two_products): two bf16 products per k-step instead of three - the A operand, d(gate pre-activations),
+// enters rounded to bf16 (its lo image is neither written nor read, the a_lo * w_hi MFMA not issued), as the backward GEMM
+// classes do from 8192 frames up (profiles/precision_sweep_b256.md: this recurrence is one of them, class enc_bptt).
+template <bool A2>
 __global__ __launch_bounds__(ENC_NT, 2) void enc_gru_bwd_wide_kernel(EncArgs a, EncFused q) {
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, half = lane >> 5;
@@ -1793,9 +1797,11 @@ __global__ __launch_bounds__(ENC_NT, 2) void enc_gru_bwd_wide_kernel(EncArgs a, 
         if (s > 0 && jok) {   // gate images for the products: d r -> first pair, d z -> second pair
           uint2 h, l;
           split2(dar[0], dar[1], &h.x, &l.x); split2(dar[2], dar[3], &h.y, &l.y);
-          *reinterpret_cast<uint2*>(Xhi + rl * ldx + jv) = h; *reinterpret_cast<uint2*>(Xlo + rl * ldx + jv) = l;
+          *reinterpret_cast<uint2*>(Xhi + rl * ldx + jv) = h;
+          if (!A2) *reinterpret_cast<uint2*>(Xlo + rl * ldx + jv) = l;
           split2(dau[0], dau[1], &h.x, &l.x); split2(dau[2], dau[3], &h.y, &l.y);
-          *reinterpret_cast<uint2*>(Yhi + rl * ldx + jv) = h; *reinterpret_cast<uint2*>(Ylo + rl * ldx + jv) = l;
+          *reinterpret_cast<uint2*>(Yhi + rl * ldx + jv) = h;
+          if (!A2) *reinterpret_cast<uint2*>(Ylo + rl * ldx + jv) = l;
         }
       }
     }
@@ -1812,7 +1818,8 @@ __global__ __launch_bounds__(ENC_NT, 2) void enc_gru_bwd_wide_kernel(EncArgs a, 
       EncFrag f0[2][2], f1[2][2];  // [t][plane]
       auto load = [&](int kt, ebf16x8& ah, ebf16x8& al, EncFrag (&f)[2][2]) {
         ah = *reinterpret_cast<const ebf16x8*>(xh + kt * 16);
-        al = *reinterpret_cast<const ebf16x8*>(xl + kt * 16);
+        if (!A2) al = *reinterpret_cast<const ebf16x8*>(xl + kt * 16);
+        else al = ah;
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
           const uint4* __restrict__ wf = q.wfrag + ((long)((g * nkt + kt) * nct + cg * 2 + t) * 2) * 64;  // uniform
@@ -1823,7 +1830,7 @@ __global__ __launch_bounds__(ENC_NT, 2) void enc_gru_bwd_wide_kernel(EncArgs a, 
       auto mma = [&](const ebf16x8& ah, const ebf16x8& al, const EncFrag (&f)[2][2]) {
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, f[t][0].v, acc[t], 0, 0, 0);
+          if (!A2) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, f[t][0].v, acc[t], 0, 0, 0);
           acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, f[t][1].v, acc[t], 0, 0, 0);
           acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, f[t][0].v, acc[t], 0, 0, 0);
         }
@@ -1857,7 +1864,8 @@ __global__ __launch_bounds__(ENC_NT, 2) void enc_gru_bwd_wide_kernel(EncArgs a, 
         const int rl = rg * 32 + 4 * i + rsv;
         uint2 h, l;
         split2(danr[i][0], danr[i][1], &h.x, &l.x); split2(danr[i][2], danr[i][3], &h.y, &l.y);
-        *reinterpret_cast<uint2*>(Xhi + rl * ldx + jv) = h; *reinterpret_cast<uint2*>(Xlo + rl * ldx + jv) = l;
+        *reinterpret_cast<uint2*>(Xhi + rl * ldx + jv) = h;
+        if (!A2) *reinterpret_cast<uint2*>(Xlo + rl * ldx + jv) = l;
       }
     }
     __syncthreads();   // B3
@@ -2210,8 +2218,13 @@ extern "C" int lfi_encode_windows_bwd(const lfi_enc_desc* d, const float* dcond,
                         (size_t)(ENC_NW * 32 * ENC_TP > imgf ? ENC_NW * 32 * ENC_TP : imgf) * sizeof(float) + tab;
     if (x3 && widebw && hid % 4 == 0 && lddcond % 4 == 0 && d->col % 4 == 0 && al16(dcond) && al16(gates) && al16(hseq) &&
         al16(dgi) && al16(dgh) && (!bias_part || al16(bias_part)) && ldsw <= 80 * 1024) {
-      if ((rc = enc_set_lds(enc_gru_bwd_wide_kernel, ldsw))) return rc;
-      hipLaunchKernelGGL(enc_gru_bwd_wide_kernel, dim3(lfi_cdiv(F, q.R)), dim3(ENC_NT), ldsw, st, a, q);
+      if (d->bwd_two_products) {
+        if ((rc = enc_set_lds(enc_gru_bwd_wide_kernel<true>, ldsw))) return rc;
+        hipLaunchKernelGGL(enc_gru_bwd_wide_kernel<true>, dim3(lfi_cdiv(F, q.R)), dim3(ENC_NT), ldsw, st, a, q);
+      } else {
+        if ((rc = enc_set_lds(enc_gru_bwd_wide_kernel<false>, ldsw))) return rc;
+        hipLaunchKernelGGL(enc_gru_bwd_wide_kernel<false>, dim3(lfi_cdiv(F, q.R)), dim3(ENC_NT), ldsw, st, a, q);
+      }
     } else if (x3) {
       if ((rc = enc_set_lds(enc_gru_bwd_fused_kernel<true>, ldsx))) return rc;
       hipLaunchKernelGGL(enc_gru_bwd_fused_kernel<true>, dim3(lfi_cdiv(F, q.R)), dim3(ENC_NT), ldsx, st, a, q);

@@ -28,7 +28,8 @@ FLOW_FIELDS = ("an_bias", "an_logs", "inv_l", "inv_u", "inv_logs", "inv_w", "w_i
                "wct", "bct", "w_fl", "b_fl", "l_fl")
 ENC_LEAVES = ("weight_ih", "weight_hh", "bias_ih", "bias_hh")
 # GEMM classes of the backward pass (tools/precision_sweep.py): they leave the NLL untouched
-BWD_CLASSES = ("dpre", "cond_wgrad", "cond_dgrad", "flow_pgrads", "enc_dwih", "enc_dwhh")
+BWD_CLASSES = ("dpre", "cond_wgrad", "cond_dgrad", "flow_pgrads", "enc_dwih", "enc_dwhh", "enc_bptt")   # enc_bptt: the d gates x W_hh
+# recurrence of the window encoders' BPTT (inside lfi_encode_windows_bwd)
 
 
 def _stream():
@@ -946,7 +947,7 @@ class GlowEngine:
         Tx, hid, G3 = x.shape[1], e.hid, e.ng * e.hid
         st = _stream()
         d = EncDesc(B, Tx, N, s.start - (1 if e.name == "p1_face" else 0), e.hist, hid, lddcond, col, self.precision, 0,
-                    1 if e.enc == "lstm" else 0)
+                    1 if e.enc == "lstm" else 0, 1 if (self._skip_bits("enc_bptt") & 1) else 0)
         gates = self._ws["enc_gates." + e.name]
         hseq = self._ws["enc_hseq." + e.name]
         compact = bool(self.L.lfi_encode_windows_compact_dgi(C.byref(d)))   # fused GRU backward: dgi = its n block only

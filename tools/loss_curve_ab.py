@@ -17,7 +17,7 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
-BWD = ("dpre", "cond_wgrad", "cond_dgrad", "flow_pgrads", "enc_dwih", "enc_dwhh")
+BWD = ("dpre", "cond_wgrad", "cond_dgrad", "flow_pgrads", "enc_dwih", "enc_dwhh", "enc_bptt")
 
 
 def run(hp, batches, steps, skip, seed):

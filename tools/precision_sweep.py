@@ -31,7 +31,8 @@ CLASSES = [("enc_xproj", "x W_ih^T of the window encoders (B T x 3 hid x in)", "
            ("cond_dgrad", "gradient of the feature matrix (F x 640 x 8192)", "bwd"),
            ("flow_pgrads", "flow weight gradients: W_ih, W_hh, LinearZeros, invconv (long-K split-K products)", "bwd"),
            ("enc_dwih", "window encoders' dW_ih (3 hid x in x B T)", "bwd"),
-           ("enc_dwhh", "window encoders' dW_hh (3 hid x hid x 23 F)", "bwd")]
+           ("enc_dwhh", "window encoders' dW_hh (3 hid x hid x 23 F)", "bwd"),
+           ("enc_bptt", "window encoders' BPTT recurrence d gates x W_hh (inside the fused kernel; only 'A rounded' exists)", "bwd")]
 MODES = [(0, "3 (a_lo b_hi + a_hi b_lo + a_hi b_hi)"), (1, "2, A rounded to bf16"), (2, "2, B rounded to bf16"), (3, "1 (plain bf16)")]
 
 
@@ -102,7 +103,7 @@ def main():
     for cls, what, direction in CLASSES:
         if args.bwd_only and direction != "bwd":
             continue
-        for bits, label in MODES[1:]:
+        for bits, label in (MODES[1:2] if cls == "enc_bptt" else MODES[1:]):
             err, gl2, worst = run({cls: bits})
             print("| %s: %s | %s | %.2e | %.2e | %.2e | %s | %.2e |" % (cls, what, label, err, gl2, worst[1], worst[0], worst[2]))
     fwd = {c: 3 for c, _, d in CLASSES if d == "fwd"}
