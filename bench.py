@@ -202,7 +202,7 @@ def _roofline(spec, F, timing, precision):
         # the product runs on pre-split operand planes (lfi_gemm_planes, lfi_pgemm.hip): 128 x 256 tiles, 512 threads, two
         # workgroups per CU; both operands as row planes, no column-sum epilogue
         peak, mult = BF16_MFMA_PEAK_TFLOPS, 3.0
-        kern = "gemm_planes_kernel<false, false, false>"
+        kern = "gemm_planes_kernel<false, false, false, 2, 4>"
         tile, threads = 128, 512
         tile_n = 256
     elif precision == "bf16x3":
@@ -231,8 +231,10 @@ def _roofline(spec, F, timing, precision):
     return {"bound": "mfma", "kernel": kern + " cond_transform forward (F x Ks*D x Ef)",
             "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic,
             "traffic_unit": "bytes per launch (HBM read + write)", "traffic_source": traffic_src,
-            "algorithmic_bytes_per_launch": 4.0 * (F * spec.ldf + KD * spec.ldf + F * KD),
-            "algorithmic_bytes_note": "A (F x ldf) and B (Ks D x ldf) once as bf16 hi + lo planes (4 B per element, as fp32), C (F x Ks D) fp32 once",
+            "algorithmic_bytes_per_launch": 4.0 * (F * spec.ldf + KD * spec.ldf + 2 * F * KD),
+            "algorithmic_bytes_note": "A (F x ldf) and B (Ks D x ldf) once as bf16 hi + lo planes (4 B per element, as fp32); the result c "
+                                      "(F x Ks D) leaves TWICE as bf16 hi + lo planes (row planes for gic and the backward mask, k-major planes "
+                                      "for dW_c = dgi^T c), 4 B per element each, and never as fp32",
             "mfma_flops_multiplier": mult, "frac_of_mfma_issue": mult * ach / peak,
             "flops_per_launch": flops, "flops_per_launch_algorithmic": flops_alg,
             "achieved_algorithmic": flops_alg / (ms * 1e-3) / 1e12 if n_launch else None,

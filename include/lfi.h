@@ -60,6 +60,9 @@ typedef struct {
                                  a_lo * b_hi / a_hi * b_lo product of the bf16x3 kernels (a measurement switch: what each GEMM
                                  class loses with one or two bf16 passes, tools/precision_sweep.py -> profiles/precision_sweep.md;
                                  never set by the engine's default configuration) */
+  int a_bf16;                 /* 1: A points at bf16 values (same lda / strides, in elements) that stand for an operand already rounded
+                                 to bf16 - the encoders' bf16 gradient stash. Needs precision bit 8 (two products: a_lo is never
+                                 used), a_kcontig = b_kcontig = 0 and 8-byte aligned rows; runs the 256 x 256 bf16x3 kernel */
   float* colsum_part; long ld_part;  /* optional: the epilogue also leaves column sums of the STORED result over each block of
                                  rows it handles, row r of a (lfi_gemm_colpart_rows(d) x ld_part) matrix, columns as in C (batch
                                  entries side by side: strideC * batch <= ldc). Summing its rows (lfi_colsum_f32) gives the bias
@@ -184,6 +187,9 @@ int lfi_encode_windows_bias_grads(const float* bias_part, long rows, int hid, fl
  * fused backward (lfi_encode_windows_compact_dgi(d) == 1: hid <= 256, not lstm) writes dgi as that block alone,
  * [hist][F][hid], and the scatter takes the r and z blocks from dgh (then required; db_ih comes from bias_part). */
 int lfi_encode_windows_compact_dgi(const lfi_enc_desc* d);
+/* 1 when lfi_encode_windows_bwd (d->bwd_two_products set, fused GRU path, d->ldcond = lddcond) writes dgi / dgh as bf16 arrays of
+ * the same shapes: the dW_hh product then takes dgh with lfi_gemm_desc.a_bf16 and lfi_encode_windows_scatter reads bf16. */
+int lfi_encode_windows_grad_stash_bf16(const lfi_enc_desc* d);
 int lfi_encode_windows_scatter(const lfi_enc_desc* d, const float* dgi, const float* dgh, const float* mask, float* dXp,
                                void* stream);
 /* "enc: none" modality (glow/models.py:76-77), the flattened p1_face history (glow/models.py:601-603) and the input of an

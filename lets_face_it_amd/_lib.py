@@ -26,7 +26,7 @@ class GemmDesc(C.Structure):
         ("accumulate", C.c_int),
         ("act", C.c_int), ("slope", C.c_float),
         ("splitk", C.c_int), ("work", C.c_void_p),
-        ("precision", C.c_int),
+        ("precision", C.c_int), ("a_bf16", C.c_int),
         ("colsum_part", C.c_void_p), ("ld_part", C.c_long),
     ]
 
@@ -111,6 +111,7 @@ def lib():
         "lfi_gemm_planes": (i, [P(PGemmDesc), vp]),
         "lfi_flow_bwd_emits_planes": (i, [P(FlowDims)]),
         "lfi_flow_seq_bwd_planes": (i, [P(FlowDims), P(FlowParams), vp, vp, f, vp, vp, vp, i, vp]),
+        "lfi_encode_windows_grad_stash_bf16": (i, [P(EncDesc)]),
         "lfi_planes_t_elems": (l, [l, l]),
         "lfi_planes_t_from_f32": (i, [vp, l, l, l, vp, vp]),
         "lfi_gemm_planes_work_floats": (l, [P(PGemmDesc)]),
@@ -171,7 +172,7 @@ def lib():
 EXPORTS = [
     "lfi_last_error", "lfi_version", "lfi_gemm_work_floats", "lfi_gemm_f32", "lfi_gemm_colpart_rows", "lfi_planes_elems", "lfi_planes_from_f32",
     "lfi_gemm_planes", "lfi_planes_t_elems", "lfi_planes_t_from_f32", "lfi_gemm_planes_work_floats", "lfi_gemm_planes_colpart_rows",
-    "lfi_flow_bwd_emits_planes", "lfi_flow_seq_bwd_planes", "lfi_colsum_work_floats",
+    "lfi_flow_bwd_emits_planes", "lfi_flow_seq_bwd_planes", "lfi_encode_windows_grad_stash_bf16", "lfi_colsum_work_floats",
     "lfi_colsum_f32", "lfi_cols_fold", "lfi_encode_windows_work_floats", "lfi_encode_windows_fwd", "lfi_encode_windows_bwd",
     "lfi_encode_windows_bias_rows", "lfi_encode_windows_bias_grads",
     "lfi_encode_windows_scatter", "lfi_encode_windows_compact_dgi", "lfi_gather_windows", "lfi_pad_rows", "lfi_dropout_masks", "lfi_leaky_grad", "lfi_fill_frame_nb", "lfi_flow_prep_floats", "lfi_flow_prep",

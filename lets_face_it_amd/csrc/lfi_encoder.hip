@@ -20,6 +20,7 @@ struct EncArgs {
   int B, T, N, start, hist, hid, ldcond, col, dup;
   int lstm, G;         // LSTM window encoder (gate blocks i, f, g, o); G = (lstm ? 4 : 3) * hid
   int compact;         // fused GRU backward: dgi holds only its n-gate block ([hist][F][hid]); its r and z blocks equal dgh's
+  int g16;             // dgi / dgh are bf16 arrays of the same shapes (lfi_enc_desc.bwd_two_products with the wide fused backward)
   int F;
   const float* Xp;     // (B*T) x 3hid
   const float* b_ih;
@@ -206,9 +207,17 @@ __global__ __launch_bounds__(256) void enc_scatter_kernel(EncArgs a, float* __re
         const int sc = ok ? s : 0;
         wgt[u] = ok ? (a.mask ? a.mask[w * a.hist + sc] : 1.0f) : 0.0f;
         const long r = (long)sc * a.F + w;
-        const float* src = !a.compact ? a.dgi + r * G3 + 4 * c4
-                                      : (4 * c4 < 2 * a.hid ? a.dgh + r * G3 + 4 * c4 : a.dgi + r * a.hid + (4 * c4 - 2 * a.hid));
-        v[u] = *reinterpret_cast<const f32x4*>(src);
+        if (a.g16) {   // bf16 stash (compact): 4 values = one 8-byte load
+          const __bf16* gh16 = reinterpret_cast<const __bf16*>(a.dgh), *gi16 = reinterpret_cast<const __bf16*>(a.dgi);
+          const __bf16* src = 4 * c4 < 2 * a.hid ? gh16 + r * G3 + 4 * c4 : gi16 + r * a.hid + (4 * c4 - 2 * a.hid);
+          const uint2 w2 = *reinterpret_cast<const uint2*>(src);
+          v[u] = f32x4{__builtin_bit_cast(float, w2.x << 16), __builtin_bit_cast(float, w2.x & 0xffff0000u),
+                       __builtin_bit_cast(float, w2.y << 16), __builtin_bit_cast(float, w2.y & 0xffff0000u)};
+        } else {
+          const float* src = !a.compact ? a.dgi + r * G3 + 4 * c4
+                                        : (4 * c4 < 2 * a.hid ? a.dgh + r * G3 + 4 * c4 : a.dgi + r * a.hid + (4 * c4 - 2 * a.hid));
+          v[u] = *reinterpret_cast<const f32x4*>(src);
+        }
       }
 #pragma unroll
       for (int u = 0; u < 8; ++u) acc += wgt[u] * v[u];
@@ -615,6 +624,13 @@ __device__ __forceinline__ f32x4 enc_ld4s(enc_rsrc r, unsigned voff, unsigned so
 }
 __device__ __forceinline__ void enc_st4(f32x4 v, enc_rsrc r, unsigned voff, unsigned soff) {
   __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(enc_u32x4, v), r, voff, soff, LFI_ENC_ST_AUX);
+}
+typedef __attribute__((ext_vector_type(2))) unsigned enc_u32x2;
+// four fp32 values rounded to bf16 (round to nearest even, as the GEMMs' operand split rounds the hi part), one 8-byte store
+__device__ __forceinline__ void enc_st2h(f32x4 v, enc_rsrc r, unsigned voff, unsigned soff) {
+  uint2 h, l;
+  split2(v[0], v[1], &h.x, &l.x); split2(v[2], v[3], &h.y, &l.y);
+  __builtin_amdgcn_raw_buffer_store_b64((enc_u32x2){h.x, h.y}, r, voff, soff, LFI_ENC_ST_AUX);
 }
 constexpr int ENC_TP = 68;   // floats per row of the transpose tile: 272 B (16-byte aligned rows, 4-bank skew per row)
 
@@ -1756,8 +1772,12 @@ __global__ __launch_bounds__(ENC_NT, 2) void enc_gru_bwd_wide_kernel(EncArgs a, 
     const float hp_on = s > 0 ? 1.0f : 0.0f;
     const enc_rsrc bgs = enc_buf(a.gates + (long)s * a.F * 4 * hid, (long)a.F * hid * 16);
     const enc_rsrc bhp = enc_buf(a.hseq + (long)sp * a.F * hid, (long)a.F * hid * 4);
-    const enc_rsrc bgi = enc_buf(a.dgi + (long)s * a.F * hid, (long)a.F * hid * 4);
-    const enc_rsrc bgh = enc_buf(a.dgh + (long)s * a.F * G3, (long)a.F * G3 * 4);
+    // A2: the gradient stash leaves as bf16 (what its consumers - the dW_hh product's rounded A operand, the window scatter in
+    // front of dW_ih's - use of it): half the bytes out here and half the bytes into both of them
+    const enc_rsrc bgi = A2 ? enc_buf(reinterpret_cast<const __bf16*>(a.dgi) + (long)s * a.F * hid, (long)a.F * hid * 2)
+                            : enc_buf(a.dgi + (long)s * a.F * hid, (long)a.F * hid * 4);
+    const enc_rsrc bgh = A2 ? enc_buf(reinterpret_cast<const __bf16*>(a.dgh) + (long)s * a.F * G3, (long)a.F * G3 * 2)
+                            : enc_buf(a.dgh + (long)s * a.F * G3, (long)a.F * G3 * 4);
     f32x4 danr[8];
 #pragma unroll
     for (int ih = 0; ih < 2; ++ih) {
@@ -1789,9 +1809,16 @@ __global__ __launch_bounds__(ENC_NT, 2) void enc_gru_bwd_wide_kernel(EncArgs a, 
           dnr[e] = dan[e] * rr;
           dhu[i][e] = dhn * uu;
         }
-        enc_st4(dan, bgi, wo[u] + j4 + oob, 0);
-        const unsigned o = 3u * wo[u] + j4 + oob;
-        enc_st4(dar, bgh, o, 0); enc_st4(dau, bgh, o, h4); enc_st4(dnr, bgh, o, 2 * h4);
+        if (A2) {
+          const unsigned j2 = j4 >> 1, h2 = h4 >> 1;
+          enc_st2h(dan, bgi, (wo[u] >> 1) + j2 + oob, 0);
+          const unsigned o = 3u * (wo[u] >> 1) + j2 + oob;
+          enc_st2h(dar, bgh, o, 0); enc_st2h(dau, bgh, o, h2); enc_st2h(dnr, bgh, o, 2 * h2);
+        } else {
+          enc_st4(dan, bgi, wo[u] + j4 + oob, 0);
+          const unsigned o = 3u * wo[u] + j4 + oob;
+          enc_st4(dar, bgh, o, 0); enc_st4(dau, bgh, o, h4); enc_st4(dnr, bgh, o, 2 * h4);
+        }
         bsum[0] += live * dar; bsum[1] += live * dau; bsum[2] += live * dan; bsum[3] += live * dnr;
         danr[i] = dnr;
         if (s > 0 && jok) {   // gate images for the products: d r -> first pair, d z -> second pair
@@ -2163,6 +2190,24 @@ extern "C" int lfi_encode_windows_bias_grads(const float* bias_part, long rows, 
   return LFI_OK;
 }
 
+// Does lfi_encode_windows_bwd leave dgi / dgh as bf16 arrays (same shapes, half the bytes)? Only the row-layout fused GRU kernel
+// in two-product mode does: its consumers - the dW_hh product (A operand rounded to bf16) and the window scatter - then read
+// bf16 (lfi_gemm_desc.a_bf16; lfi_encode_windows_scatter looks the same answer up itself).
+static bool enc_wide_bwd_shape_ok(const lfi_enc_desc* d, int lddcond, EncFused* q) {
+  if (!d || d->lstm || d->precision != 1 || !enc_fused_shape(d->hid, q)) return false;
+  const char* e = getenv("LFI_ENC_WIDE_BWD");
+  if (e && e[0] == '0') return false;
+  const size_t tab = (size_t)2 * q->R * sizeof(unsigned);
+  const long imgf = (long)q->R * (q->Kp + 8);
+  const size_t ldsw = (size_t)2 * q->R * (q->Kp + 8) * sizeof(__bf16) +
+                      (size_t)(ENC_NW * 32 * ENC_TP > imgf ? ENC_NW * 32 * ENC_TP : imgf) * sizeof(float) + tab;
+  return d->hid % 4 == 0 && lddcond % 4 == 0 && d->col % 4 == 0 && ldsw <= 80 * 1024;
+}
+extern "C" int lfi_encode_windows_grad_stash_bf16(const lfi_enc_desc* d) {
+  EncFused q = {};
+  return (d && d->bwd_two_products && enc_wide_bwd_shape_ok(d, d->ldcond, &q)) ? 1 : 0;
+}
+
 extern "C" int lfi_encode_windows_bwd(const lfi_enc_desc* d, const float* dcond, int lddcond, const float* whh,
                                       const float* gates, const float* hseq, float* dgi, float* dgh, float* bias_part,
                                       float* work, void* stream) {
@@ -2216,9 +2261,13 @@ extern "C" int lfi_encode_windows_bwd(const lfi_enc_desc* d, const float* dcond,
     const long imgf = (long)q.R * (q.Kp + 8);   // floats of one image pair
     const size_t ldsw = (size_t)2 * q.R * (q.Kp + 8) * sizeof(__bf16) +
                         (size_t)(ENC_NW * 32 * ENC_TP > imgf ? ENC_NW * 32 * ENC_TP : imgf) * sizeof(float) + tab;
-    if (x3 && widebw && hid % 4 == 0 && lddcond % 4 == 0 && d->col % 4 == 0 && al16(dcond) && al16(gates) && al16(hseq) &&
-        al16(dgi) && al16(dgh) && (!bias_part || al16(bias_part)) && ldsw <= 80 * 1024) {
-      if (d->bwd_two_products) {
+    const bool want16 = d->bwd_two_products && lddcond == d->ldcond && lfi_encode_windows_grad_stash_bf16(d);
+    const bool wide_ok = x3 && widebw && hid % 4 == 0 && lddcond % 4 == 0 && d->col % 4 == 0 && al16(dcond) && al16(gates) && al16(hseq) &&
+                         al16(dgi) && al16(dgh) && (!bias_part || al16(bias_part)) && ldsw <= 80 * 1024;
+    LFI_REQUIRE(!want16 || wide_ok, "lfi_encode_windows_bwd: lfi_encode_windows_grad_stash_bf16 promised a bf16 gradient stash but the "
+                "buffers are not 16-byte aligned");
+    if (wide_ok) {
+      if (want16) {
         if ((rc = enc_set_lds(enc_gru_bwd_wide_kernel<true>, ldsw))) return rc;
         hipLaunchKernelGGL(enc_gru_bwd_wide_kernel<true>, dim3(lfi_cdiv(F, q.R)), dim3(ENC_NT), ldsw, st, a, q);
       } else {
@@ -2268,6 +2317,7 @@ extern "C" int lfi_encode_windows_scatter(const lfi_enc_desc* d, const float* dg
   a.compact = lfi_encode_windows_compact_dgi(d);
   LFI_REQUIRE(!a.compact || dgh, "lfi_encode_windows_scatter: the compact dgi of the fused backward needs dgh too");
   a.dgi = (float*)dgi; a.dgh = (float*)dgh; a.mask = mask;
+  a.g16 = lfi_encode_windows_grad_stash_bf16(d);
   hipLaunchKernelGGL(enc_scatter_kernel, dim3(d->B * d->T), dim3(256), 0, (hipStream_t)stream, a, dXp);
   LFI_LAUNCH_CHECK("lfi_encode_windows_scatter");
   return LFI_OK;

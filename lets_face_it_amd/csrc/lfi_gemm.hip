@@ -734,6 +734,116 @@ __global__ __launch_bounds__(1024, 4) void gemm_bf16x3_256_kernel(GemmArgs g) {
   else gemm_epilogue_n<256>(g, acc, m0, n0, wm, wn, l31, half, batch, split);
 }
 
+// The same 256 x 256 kernel for a product whose A operand ARRIVES rounded to bf16 (lfi_gemm_desc.a_bf16: the window encoders'
+// bf16 gradient stash, mn-contiguous as every weight-gradient operand) and whose B operand is fp32, mn-contiguous: two products per
+// k-step (a_hi b_lo + a_hi b_hi - exactly what the three-product kernel computes with skip bit 0 on the fp32 form of the same
+// values), A's 8-byte loads go straight into the hi image (no split, no lo image), B is split as everywhere. Half the A bytes.
+__global__ __launch_bounds__(1024, 4) void gemm_bf16a_256_kernel(GemmArgs g) {
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, half = lane >> 5;
+  int tm, tn, batch, split;
+  gemm_tile_of_block(g, &tm, &tn, &batch, &split);
+  const int m0 = tm * 256, n0 = tn * 256;
+  const __bf16* __restrict__ A = reinterpret_cast<const __bf16*>(g.A) + batch * g.strideA;
+  const float* __restrict__ B = g.B + batch * g.strideB;
+  const int kbeg = split * g.kchunk;
+  const int kend = min(g.K, kbeg + g.kchunk);
+  const int nkt = (kend - kbeg + YBK - 1) / YBK;
+
+  YStager<false> sa, sb;     // same thread -> (k row, 4 mn) map for both operands; A's 4 values are 8 bytes
+  sa.init(tid, m0, g.M, g.lda);
+  sb.init(tid, n0, g.N, g.ldb);
+  const __bf16* __restrict__ tA = A + (long)kbeg * g.lda + m0;
+  const float* __restrict__ tB = B + (long)kbeg * g.ldb + n0;
+  const long stepA = (long)YBK * g.lda, stepB = (long)YBK * g.ldb;
+
+  uint2 ra[YDEPTH];
+  f32x4 rb[YDEPTH];
+  auto load = [&](int kt, uint2& xa, f32x4& xb) {
+    const int krem = kend - (kbeg + kt * YBK);
+    xa = sa.kk < krem ? *reinterpret_cast<const uint2*>(tA + kt * stepA + sa.off) : uint2{0u, 0u};
+    sb.load(tB + kt * stepB, krem, xb);
+  };
+  auto load_full = [&](int kt, uint2& xa, f32x4& xb) {
+    xa = *reinterpret_cast<const uint2*>(tA + kt * stepA + sa.off);
+    xb = *reinterpret_cast<const f32x4*>(tB + kt * stepB + sb.off);
+  };
+  auto store = [&](int buf, const uint2& xa, const f32x4& xb) {
+    __bf16* base = xsmem + buf * 4 * YIMG;
+    *reinterpret_cast<uint2*>(base + sa.lds) = xa;
+    sb.store(base + 2 * YIMG, base + 3 * YIMG, xb);
+  };
+
+  const int wm = wave >> 2, wn = wave & 3;
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
+
+  auto mma = [&](int buf) {
+    const __bf16* base = xsmem + buf * 4 * YIMG;
+    bf16x8 ah[2], bh[2], bl[2];
+#pragma unroll
+    for (int t2 = 0; t2 < 2; ++t2) {
+      ah[t2] = yfrag<false>(base, wm * 64 + t2 * 32, lane);
+      bh[t2] = yfrag<false>(base + 2 * YIMG, wn * 64 + t2 * 32, lane);
+      bl[t2] = yfrag<false>(base + 3 * YIMG, wn * 64 + t2 * 32, lane);
+    }
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt], bl[nt], acc[mt][nt], 0, 0, 0);
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+  };
+
+  int kt0 = 0;
+  if (nkt > 2 * YDEPTH) {
+#pragma unroll
+    for (int t = 0; t < YDEPTH; ++t) load_full(t, ra[t], rb[t]);
+    store(0, ra[0], rb[0]);
+    __syncthreads();
+    for (; kt0 + 2 * YDEPTH < nkt; kt0 += YDEPTH) {
+#pragma unroll
+      for (int u = 0; u < YDEPTH; ++u) {
+        const int kt = kt0 + u;
+        load_full(kt + YDEPTH, ra[u], rb[u]);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(kt & 1);
+        __builtin_amdgcn_sched_barrier(0);
+        store((kt + 1) & 1, ra[(u + 1) % YDEPTH], rb[(u + 1) % YDEPTH]);
+        __syncthreads();
+      }
+    }
+  } else {
+#pragma unroll
+    for (int t = 0; t < YDEPTH; ++t)
+      if (t < nkt) load(t, ra[t], rb[t]);
+    if (nkt > 0) store(0, ra[0], rb[0]);
+    __syncthreads();
+  }
+  for (; kt0 < nkt; kt0 += YDEPTH) {
+#pragma unroll
+    for (int u = 0; u < YDEPTH; ++u) {
+      const int kt = kt0 + u;
+      if (kt < nkt) {
+        if (kt + YDEPTH < nkt) load(kt + YDEPTH, ra[u], rb[u]);
+        mma(kt & 1);
+        if (kt + 1 < nkt) store((kt + 1) & 1, ra[(u + 1) % YDEPTH], rb[(u + 1) % YDEPTH]);
+        __syncthreads();
+      }
+    }
+  }
+  if (g.vecC) gemm_epilogue_wide<256, 1024, 2, false>(g, acc, reinterpret_cast<float*>(xsmem), LFI_EPI_ROWS, m0, n0, wm, wn, l31, half, batch, split, 256);
+  else gemm_epilogue_n<256>(g, acc, m0, n0, wm, wn, l31, half, batch, split);
+}
+
 // ---------------------------------------------------------------------------------------------- bf16 x 3, 256 x 256, k-tile 32
 // The 16-wave kernel above with 32 k per barrier instead of 16 (two MFMA k-steps, 24 MFMAs per wave between barriers): half
 // the barriers and loop tops per unit of K. Two buffers of four 256 x 40 bf16 planes are exactly the CU's 160 KB of LDS, so
@@ -1356,8 +1466,15 @@ extern "C" int lfi_gemm_f32(const lfi_gemm_desc* d, void* stream) {
   const int vecA = vec_ok(d->A, d->lda, d->strideA, d->a_kcontig, d->M, d->K);
   const int vecB = vec_ok(d->B, d->ldb, d->strideB, d->b_kcontig, d->N, d->K);
   const bool use_x3 = (d->precision & 1) && vecA && vecB;
-  GemmPlan plan = gemm_plan(d->M, d->N, d->K, d->batch, (d->splitk == 0 && !d->work) ? 1 : d->splitk, use_x3);
+  if (d->a_bf16) {
+    LFI_REQUIRE((d->precision & 1) && (d->precision & 0x100) && !(d->precision & 0x200) && !d->a_kcontig && !d->b_kcontig && vecB &&
+                (reinterpret_cast<uintptr_t>(d->A) & 7) == 0 && (d->lda & 3) == 0 && (d->strideA & 3) == 0 && !d->colsum_part,
+                "lfi_gemm_f32: a_bf16 needs bf16x3 mode with skip bit 0 (two products), both operands mn-contiguous, 8-byte aligned "
+                "A rows and a 16-byte aligned B");
+  }
+  GemmPlan plan = gemm_plan(d->M, d->N, d->K, d->batch, (d->splitk == 0 && !d->work) ? 1 : d->splitk, use_x3 || d->a_bf16);
   if (use_x3 && (d->precision & 0x30)) plan.shape = (d->precision & 0x10) ? 3 : 0;  // tests pin the tile shape (lfi.h)
+  if (d->a_bf16) plan.shape = 3;
   int splitk = plan.splitk < 1 ? 1 : plan.splitk;
   if (splitk > d->K / BKT) splitk = d->K / BKT < 1 ? 1 : d->K / BKT;
   LFI_REQUIRE(splitk == 1 || d->work, "lfi_gemm_f32: splitk needs a workspace");
@@ -1387,8 +1504,8 @@ extern "C" int lfi_gemm_f32(const lfi_gemm_desc* d, void* stream) {
     a.vecC = (c_ok && g_ok && !(d->act == 2 && d->accumulate != 0)) ? 1 : 0;
   }
   // tile shape: narrow outputs get the tall tile, short outputs the wide one; bf16x3: 128 x 128 or 256 x 256 by the plan
-  int shape = use_x3 ? plan.shape : 0;
-  if (!use_x3) {
+  int shape = (use_x3 || d->a_bf16) ? plan.shape : 0;
+  if (!use_x3 && !d->a_bf16) {
     if (d->N <= 64 && d->M > 128) shape = 1;       // 256 x 64
     else if (d->M <= 64 && d->N > 128) shape = 2;  // 64 x 256
   }
@@ -1444,6 +1561,18 @@ extern "C" int lfi_gemm_f32(const lfi_gemm_desc* d, void* stream) {
     else if (d->a_kcontig) hipLaunchKernelGGL((gemm_bf16x3_256k_kernel<true, false>), grid, dim3(1024), lds, st, a);
     else if (d->b_kcontig) hipLaunchKernelGGL((gemm_bf16x3_256k_kernel<false, true>), grid, dim3(1024), lds, st, a);
     else hipLaunchKernelGGL((gemm_bf16x3_256k_kernel<false, false>), grid, dim3(1024), lds, st, a);
+  } else if (d->a_bf16) {
+    const size_t lds_loop = (size_t)2 * 4 * YIMG * sizeof(__bf16), lds_epi = (size_t)LFI_EPI_ROWS * 260 * sizeof(float);
+    const size_t lds = lds_loop > lds_epi ? lds_loop : lds_epi;
+    static bool attra = false;
+    if (!attra) {
+      if (hipFuncSetAttribute((const void*)gemm_bf16a_256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+        lfi_set_error("lfi_gemm_f32: cannot reserve %zu bytes of LDS for the bf16-A kernel", lds);
+        return LFI_ERR_LAUNCH;
+      }
+      attra = true;
+    }
+    hipLaunchKernelGGL(gemm_bf16a_256_kernel, grid, dim3(1024), lds, st, a);
   } else if (use_x3 && shape == 3) {
     // main loop: two buffers of four 256 x 16 bf16 planes (96 KB); the wide epilogue: LFI_EPI_ROWS rows x 260 floats per pass
     const size_t lds_loop = (size_t)2 * 4 * YIMG * sizeof(__bf16), lds_epi = (size_t)LFI_EPI_ROWS * 260 * sizeof(float);

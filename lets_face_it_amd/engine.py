@@ -386,7 +386,7 @@ class GlowEngine:
     # ------------------------------------------------------------------ low-level wrappers
     def gemm(self, M, N, K, A, lda, akc, Bm, ldb, bkc, Cm, ldc, bias=None, act=0, slope=0.01, G=None, ldg=0,
              batch=1, sA=0, sB=0, sC=0, sBias=0, sG=0, accumulate=0, splitk=1, a_off=0, b_off=0, c_off=0, bias_off=0,
-             tag=None, ws="scratch.gemm_splitk", cls=None, colsum_into=None):
+             tag=None, ws="scratch.gemm_splitk", cls=None, colsum_into=None, a_bf16=False):
         """Offsets are in floats relative to the tensors' data pointers. cls: GEMM class name for tools/precision_sweep.py
         (self.pass_skip maps a class to the bf16x3 products to drop; empty in normal operation).
         colsum_into: optional (ncols,) tensor that receives the column sums of the stored result (all batch entries side by
@@ -394,7 +394,8 @@ class GlowEngine:
         Returns False when this product cannot do that (the caller then sums C itself)."""
         g = GemmDesc()
         g.M, g.N, g.K = M, N, K
-        g.A, g.lda, g.a_kcontig = A.data_ptr() + 4 * a_off, lda, akc
+        g.A, g.lda, g.a_kcontig = A.data_ptr() + (2 if a_bf16 else 4) * a_off, lda, akc
+        g.a_bf16 = 1 if a_bf16 else 0
         g.B, g.ldb, g.b_kcontig = Bm.data_ptr() + 4 * b_off, ldb, bkc
         g.C, g.ldc = Cm.data_ptr() + 4 * c_off, ldc
         g.bias = None if bias is None else bias.data_ptr() + 4 * bias_off
@@ -947,7 +948,10 @@ class GlowEngine:
         Tx, hid, G3 = x.shape[1], e.hid, e.ng * e.hid
         st = _stream()
         d = EncDesc(B, Tx, N, s.start - (1 if e.name == "p1_face" else 0), e.hist, hid, lddcond, col, self.precision, 0,
-                    1 if e.enc == "lstm" else 0, 1 if (self._skip_bits("enc_bptt") & 1) else 0)
+                    1 if e.enc == "lstm" else 0,
+                    # two-product BPTT recurrence + bf16 gradient stash: only together with a two-product (A rounded) dW_hh
+                    # product, the stash's other reader
+                    1 if ((self._skip_bits("enc_bptt") & 1) and (self._skip_bits("enc_dwhh") & 3) == 1) else 0)
         gates = self._ws["enc_gates." + e.name]
         hseq = self._ws["enc_hseq." + e.name]
         compact = bool(self.L.lfi_encode_windows_compact_dgi(C.byref(d)))   # fused GRU backward: dgi = its n block only
@@ -983,8 +987,10 @@ class GlowEngine:
             self.colsum(dgi, G3, 0, e.hist * F, G3, 1, gbi, 0)
         if e.hist > 1:
             kk = (e.hist - 1) * F
+            # (a bf16 gradient stash: dgh holds bf16 values in the same [hist][F][3 hid] order - the two-product kernel's A operand)
+            g16 = bool(self.L.lfi_encode_windows_grad_stash_bf16(C.byref(d)))
             self.gemm(G3, hid, kk, dgh, G3, 0, hseq, hid, 0, self.view(gname + "weight_hh", self.grads), hid,
-                      splitk=self._long_k_splitk(G3, hid, kk), a_off=F * G3, cls="enc_dwhh")
+                      splitk=self._long_k_splitk(G3, hid, kk), a_off=F * G3, cls="enc_dwhh", a_bf16=g16)
         else:
             self.view(gname + "weight_hh", self.grads).zero_()
         if part is None:

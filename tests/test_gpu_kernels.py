@@ -388,6 +388,28 @@ def test_gemm_planes_emits_its_result_as_planes(eng, gpu_device, M, N, K, batch)
         assert rel_err(sums, ref_c[:, :Ncols].double().sum(0)) < 1e-5
 
 
+@pytest.mark.parametrize("M,N,K,splitk", [(768, 256, 9000, 4), (384, 128, 2049, 1), (768, 52, 4100, 3)])
+def test_gemm_with_a_bf16_operand(eng, gpu_device, M, N, K, splitk):
+    """lfi_gemm_desc.a_bf16 (the window encoders' bf16 gradient stash as the A operand of dW_hh = dgh^T hseq, glow/models.py:60-64
+    autograd): bit-identical to the three-product kernel with skip bit 0 on the fp32 form of the same bf16 values."""
+    g = torch.Generator().manual_seed(M + K)
+    A16 = torch.randn(K, M, generator=g).to(torch.bfloat16).to(gpu_device)       # mn-contiguous: (K x M)
+    Bm = torch.randn(K, N + 4, generator=g).to(gpu_device)
+    C1 = torch.zeros(M, N, device=gpu_device)
+    C2 = torch.zeros(M, N, device=gpu_device)
+    eng.precision = 0x11
+    eng.pass_skip = {"t": 1}
+    try:
+        eng.gemm(M, N, K, A16, M, 0, Bm, N + 4, 0, C1, N, splitk=splitk, cls="t", a_bf16=True)
+        eng.gemm(M, N, K, A16.float(), M, 0, Bm, N + 4, 0, C2, N, splitk=splitk, cls="t")
+    finally:
+        eng.precision = 0
+        eng.pass_skip = {}
+    torch.cuda.synchronize()
+    assert torch.equal(C1, C2)
+    assert rel_err(C1, A16.double().t() @ Bm[:, :N].double()) < 1e-4      # B's lo x A's hi is kept: only the dropped b_lo a_lo term
+
+
 @pytest.mark.parametrize("pin,M", [(0x11, 700), (0x21, 300), (0x11, 256)])
 def test_gemm_epilogue_column_sums(eng, gpu_device, pin, M):
     """lfi_gemm_desc.colsum_part: the wide epilogue leaves per-(row tile, pass) column sums of the stored result (the in-place

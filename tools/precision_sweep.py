@@ -32,7 +32,8 @@ CLASSES = [("enc_xproj", "x W_ih^T of the window encoders (B T x 3 hid x in)", "
            ("flow_pgrads", "flow weight gradients: W_ih, W_hh, LinearZeros, invconv (long-K split-K products)", "bwd"),
            ("enc_dwih", "window encoders' dW_ih (3 hid x in x B T)", "bwd"),
            ("enc_dwhh", "window encoders' dW_hh (3 hid x hid x 23 F)", "bwd"),
-           ("enc_bptt", "window encoders' BPTT recurrence d gates x W_hh (inside the fused kernel; only 'A rounded' exists)", "bwd")]
+           ("enc_bptt", "window encoders' BPTT recurrence d gates x W_hh (inside the fused kernel; only 'A rounded' exists, and only "
+                        "together with enc_dwhh 'A rounded': the gradient stash between them is then bf16)", "bwd")]
 MODES = [(0, "3 (a_lo b_hi + a_hi b_lo + a_hi b_hi)"), (1, "2, A rounded to bf16"), (2, "2, B rounded to bf16"), (3, "1 (plain bf16)")]
 
 
@@ -104,7 +105,7 @@ def main():
         if args.bwd_only and direction != "bwd":
             continue
         for bits, label in (MODES[1:2] if cls == "enc_bptt" else MODES[1:]):
-            err, gl2, worst = run({cls: bits})
+            err, gl2, worst = run({cls: bits, "enc_dwhh": 1} if cls == "enc_bptt" else {cls: bits})
             print("| %s: %s | %s | %.2e | %.2e | %.2e | %s | %.2e |" % (cls, what, label, err, gl2, worst[1], worst[0], worst[2]))
     fwd = {c: 3 for c, _, d in CLASSES if d == "fwd"}
     allc = {c: 3 for c, _, _ in CLASSES}
