@@ -208,9 +208,7 @@ def _roofline(spec, F, timing, precision):
     elif precision == "bf16x3":
         big = os.environ.get("LFI_GEMM_256", "1") != "0"
         peak, mult = BF16_MFMA_PEAK_TFLOPS, 3.0
-        k32 = os.environ.get("LFI_GEMM_K32", "0") == "1"   # the opt-in 32-k variant of the 256 x 256 kernel
-        kern = ("gemm_bf16x3_256k_kernel<true, true>" if k32 else "gemm_bf16x3_256_kernel<true, true>") if big \
-            else "gemm_bf16x3_kernel<true, true>"
+        kern = "gemm_bf16x3_256_kernel<true, true>" if big else "gemm_bf16x3_kernel<true, true>"
         tile, threads = (256, 1024) if big else (128, 256)
         tile_n = tile
     else:

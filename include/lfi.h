@@ -55,8 +55,7 @@ typedef struct {
   int precision;              /* 0: exact fp32 (f32-input MFMA). 1: bf16x3 — operands split into bf16 hi + lo on the fly,
                                  three bf16 MFMAs per step into fp32 accumulators (~2^-16 relative); needs 16-byte aligned
                                  operands, otherwise the exact kernel runs. Tests may OR in 0x10 (force the 256 x 256 tile
-                                 kernel) or 0x20 (force 128 x 128) instead of the library's own choice, and 0x40 (the opt-in 32-k
-                                 variant of the 256 x 256 kernel instead of the 16-k one). Bits 8 / 9 (0x100 / 0x200) DROP the
+                                 kernel) or 0x20 (force 128 x 128) instead of the library's own choice. Bits 8 / 9 (0x100 / 0x200) DROP the
                                  a_lo * b_hi / a_hi * b_lo product of the bf16x3 kernels (a measurement switch: what each GEMM
                                  class loses with one or two bf16 passes, tools/precision_sweep.py -> profiles/precision_sweep.md;
                                  never set by the engine's default configuration) */

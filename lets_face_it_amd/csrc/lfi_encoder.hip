@@ -830,248 +830,6 @@ __global__ __launch_bounds__(ENC_NT, 2) void enc_gru_fwd_wide_kernel(EncArgs a, 
   }
 }
 
-// ---- 64 windows per workgroup, ONE workgroup per CU. With 32 windows per workgroup every workgroup streams all of W_hh
-// (786 KB as bf16 hi + lo) from L2 per history step, twice per CU: 12 sixteen-byte loads per wave and k-tile, 1536 cycles of
-// address processing per k-tile and CU against 1152 of MFMA issue - the recurrent product ran at half the matrix rate
-// (stamps: ~126 cycles per MFMA) however cheap the epilogue became. Here wave w owns hidden columns [32 w, 32 w + 32) of ALL
-// 64 rows: it streams only its own eighth of the weights (6 loads per k-tile, 768 cycles per CU), reads both row tiles'
-// state fragments from LDS, and the epilogue is the row-layout one above on a 64 x 32 tile.
-// MEASURED (round 2, same box): 0.757 ms against 0.729 ms for the 32-window kernel on the p2_face launch - not faster, so it
-// is opt-in (LFI_ENC_R64=1). Stamps (tools/enc_stamps.py, -DLFI_ENC_STAMPS): per history step the recurrent product takes
-// 21 k cycles in the first-dispatched wave of a SIMD and 32 k in the second (18.4 k would be MFMA-bound), the epilogue 11 k;
-// with the weight loads removed (-DENC_NO_BLOAD) 18 k / 28 k, with the MFMAs removed (-DENC_NO_MMA) 22 k / 26 k: streaming
-// 786 KB of fragments per CU and step from L2 alone takes longer than the MFMAs (33 B/clk/CU, 17 TB/s chip-wide: every CU
-// reads the same lines at the same time), the two do not overlap well, and the single workgroup per CU serialises the
-// epilogue behind them. Four k-tiles of fragments in flight instead of two made it slower (30 k / 42 k).
-template <bool STASH, bool MASK>
-__global__ __launch_bounds__(512, 2) void enc_gru_fwd_r64_kernel(EncArgs a, EncFused q) {
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int l31 = lane & 31, half = lane >> 5;
-  constexpr int NT = 512, NWV = 8, R = 64, TP = 36;   // one workgroup per CU: 64 windows, wave = all 64 rows x 32 hidden columns
-  const int cg = wave;
-  const int hid = a.hid, G3 = 3 * hid, Jp = q.Jp;
-  const int wbase = blockIdx.x * R;
-  const int pos0 = a.start - a.hist + 1;
-  const int ldx = q.Kp + 8;
-  // LDS: bf16 hi / lo images of h_{s-1} (row-major [R][Kp + 8]) | per-wave transpose tiles | biases [6][Jp] | per-row tables
-  __bf16* Xhi = reinterpret_cast<__bf16*>(enc_smem);
-  __bf16* Xlo = Xhi + R * ldx;
-  float* T = reinterpret_cast<float*>(Xlo + R * ldx) + wave * (64 * TP);
-  float* bias = reinterpret_cast<float*>(Xlo + R * ldx) + NWV * (64 * TP);   // [0..2][Jp] = b_ih, [3..5][Jp] = b_hh
-  unsigned* rowx = reinterpret_cast<unsigned*>(bias + 6 * Jp);
-  unsigned* roww = rowx + R;
-  float* mk_tab = reinterpret_cast<float*>(roww + R);                                 // [R][hist] (MASK only)
-  for (int i = tid; i < R * ldx; i += NT) { Xhi[i] = (__bf16)0.0f; Xlo[i] = (__bf16)0.0f; }
-  for (int i = tid; i < 6 * Jp; i += NT) {
-    const int g = i / Jp, j = i - g * Jp;
-    bias[i] = j < hid ? (g < 3 ? a.b_ih[g * hid + j] : a.b_hh[(g - 3) * hid + j]) : 0.0f;
-  }
-  for (int i = tid; i < R; i += NT) {
-    const int w = min(wbase + i, a.F - 1);   // rows past F recompute and re-store the last window
-    const int n = w / a.B, b = w - n * a.B;
-    rowx[i] = (unsigned)(b * a.T + pos0 + n) * (unsigned)(G3 * 4);
-    roww[i] = (unsigned)w * (unsigned)(hid * 4);
-  }
-  if (MASK)
-    for (int i = tid; i < R * a.hist; i += NT) {
-      const int rl = i / a.hist, s = i - rl * a.hist;
-      mk_tab[i] = a.mask[(long)min(wbase + rl, a.F - 1) * a.hist + s];
-    }
-  // row layout of this wave's 64 x 32 tile: lane owns columns c4 .. c4 + 3 of rows 8 i + rsub, i = 0 .. 7
-  const int rsub = lane >> 3, c4 = (lane & 7) * 4;
-  const int j0 = cg * 32 + c4;            // first hidden index of the lane's four
-  const bool jok = j0 < hid;              // hid % 4 == 0: the four are all inside or all outside
-  {
-    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int i = 0; i < 8; ++i) *reinterpret_cast<f32x4*>(T + (8 * i + rsub) * TP + c4) = z;   // h_{-1} = 0
-  }
-  const enc_rsrc bx = enc_buf(a.Xp, (long)a.B * a.T * G3 * 4);
-  const unsigned h4 = (unsigned)hid * 4u;
-  __syncthreads();
-
-#ifdef LFI_ENC_STAMPS
-  unsigned long long st_mfma = 0, st_e1 = 0, st_b1 = 0, st_e2 = 0, st_b2 = 0;
-  const unsigned long long st_t0 = __builtin_amdgcn_s_memtime(), st_r0 = __builtin_amdgcn_s_memrealtime();
-#endif
-  for (int s = 0; s < a.hist; ++s) {
-#ifdef LFI_ENC_STAMPS
-    const unsigned long long c0 = __builtin_amdgcn_s_memtime();
-#endif
-    f32x16 acc[2][3];
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int g = 0; g < 3; ++g)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[t][g][r] = 0.0f;
-    if (s > 0 && cg * 32 < hid) {
-      const int nkt = q.Kp >> 4, nct = Jp >> 5;
-      const __bf16* xh = Xhi + l31 * ldx + 8 * half;   // row tile t at + 32 t ldx
-      const __bf16* xl = Xlo + l31 * ldx + 8 * half;
-      ebf16x8 ah0[2], al0[2], ah1[2], al1[2];
-      EncFrag f0[3][2], f1[3][2];  // [g][plane]
-      auto load = [&](int kt, ebf16x8 (&ah)[2], ebf16x8 (&al)[2], EncFrag (&f)[3][2]) {
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-          ah[t] = *reinterpret_cast<const ebf16x8*>(xh + t * 32 * ldx + kt * 16);
-          al[t] = *reinterpret_cast<const ebf16x8*>(xl + t * 32 * ldx + kt * 16);
-        }
-#pragma unroll
-        for (int g = 0; g < 3; ++g) {
-          const uint4* __restrict__ wf = q.wfrag + ((long)((kt * 3 + g) * nct + cg) * 2) * 64;  // uniform
-          f[g][0].u = wf[(unsigned)lane];
-          f[g][1].u = (wf + 64)[(unsigned)lane];
-        }
-      };
-      auto mma = [&](const ebf16x8 (&ah)[2], const ebf16x8 (&al)[2], const EncFrag (&f)[3][2]) {
-#pragma unroll
-        for (int g = 0; g < 3; ++g)
-#pragma unroll
-          for (int t = 0; t < 2; ++t) {
-            acc[t][g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[t], f[g][0].v, acc[t][g], 0, 0, 0);
-            acc[t][g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[t], f[g][1].v, acc[t][g], 0, 0, 0);
-            acc[t][g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[t], f[g][0].v, acc[t][g], 0, 0, 0);
-          }
-      };
-      load(0, ah0, al0, f0);   // every load in the steady-state loop is unconditional (see enc_gru_fwd_fused_kernel)
-      int kt = 0;
-      for (; kt + 2 < nkt; kt += 2) {
-        load(kt + 1, ah1, al1, f1);
-        __builtin_amdgcn_sched_barrier(0);
-        mma(ah0, al0, f0);
-        load(kt + 2, ah0, al0, f0);
-        __builtin_amdgcn_sched_barrier(0);
-        mma(ah1, al1, f1);
-      }
-      if (kt + 1 < nkt) {
-        load(kt + 1, ah1, al1, f1);
-        __builtin_amdgcn_sched_barrier(0);
-        mma(ah0, al0, f0);
-        mma(ah1, al1, f1);
-      } else {
-        mma(ah0, al0, f0);
-      }
-    }
-#ifdef LFI_ENC_STAMPS
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    const unsigned long long c1 = __builtin_amdgcn_s_memtime();
-#endif
-    // ---- gate epilogue in the row layout
-    int rsv = rsub, cv = c4, jv = j0;
-    asm volatile("" : "+v"(rsv), "+v"(cv), "+v"(jv));   // keep the per-row address arithmetic inside the step loop (registers)
-    const unsigned sx = (unsigned)s * (unsigned)(G3 * 4), j4 = (unsigned)jv * 4u;
-    const unsigned oob = jv < hid ? 0u : 0x80000000u;
-    const enc_rsrc bhs = enc_buf(STASH ? a.hseq + (long)s * a.F * hid : nullptr, STASH ? (long)a.F * hid * 4 : 0);
-    const enc_rsrc bgs = enc_buf(STASH ? a.gates + (long)s * a.F * 4 * hid : nullptr, STASH ? (long)a.F * hid * 16 : 0);
-    float* Trow = T + rsv * TP + cv;                 // + 8 i * TP per row
-    float* Tacc = T + (4 * half) * TP + l31;         // accumulator (t, r) at + (32 t + (r & 3) + 8 (r >> 2)) * TP
-    f32x4 hp[8], xin[8];
-    unsigned xo[8], wo[8];
-    float mk[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int rl = 8 * i + rsv;
-      xo[i] = rowx[rl] + j4 + oob;   // columns past hid: an offset outside every buffer (loads return 0, stores are dropped)
-      wo[i] = roww[rl];
-      mk[i] = MASK ? mk_tab[rl * a.hist + s] : 1.0f;
-      hp[i] = *reinterpret_cast<const f32x4*>(Trow + 8 * i * TP);   // h_{s-1}, parked here by the previous step
-      xin[i] = enc_ld4(bx, xo[i], sx);
-    }
-    auto transpose = [&](int g, f32x4 (&out)[8]) {   // gate g of this wave's tile: accumulator layout -> row layout
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // earlier reads of the tile are done
-#pragma unroll
-      for (int t = 0; t < 2; ++t)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) Tacc[(32 * t + (r & 3) + 8 * (r >> 2)) * TP] = acc[t][g][r];
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-      for (int i = 0; i < 8; ++i) out[i] = *reinterpret_cast<const f32x4*>(Trow + 8 * i * TP);
-    };
-    const f32x4 bir = *reinterpret_cast<const f32x4*>(bias + 0 * Jp + jv), bhr = *reinterpret_cast<const f32x4*>(bias + 3 * Jp + jv);
-    const f32x4 biu = *reinterpret_cast<const f32x4*>(bias + 1 * Jp + jv), bhu = *reinterpret_cast<const f32x4*>(bias + 4 * Jp + jv);
-    const f32x4 bin = *reinterpret_cast<const f32x4*>(bias + 2 * Jp + jv), bhn = *reinterpret_cast<const f32x4*>(bias + 5 * Jp + jv);
-    f32x4 rr[8], uu[8], gh[8];
-    transpose(0, gh);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) rr[i][e] = sigmoidf_(mk[i] * xin[i][e] + bir[e] + (gh[i][e] + bhr[e]));
-      if (STASH) enc_st4(rr[i], bgs, 4u * wo[i] + j4 + oob, 0);
-      xin[i] = enc_ld4(bx, xo[i], sx + h4);
-    }
-    transpose(1, gh);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) uu[i][e] = sigmoidf_(mk[i] * xin[i][e] + biu[e] + (gh[i][e] + bhu[e]));
-      if (STASH) enc_st4(uu[i], bgs, 4u * wo[i] + j4 + oob, h4);
-      xin[i] = enc_ld4(bx, xo[i], sx + 2 * h4);
-    }
-    transpose(2, gh);
-#ifdef LFI_ENC_STAMPS
-    const unsigned long long c2 = __builtin_amdgcn_s_memtime();
-#endif
-    __syncthreads();   // every wave has finished the MFMA phase: the state images may be overwritten
-#ifdef LFI_ENC_STAMPS
-    const unsigned long long c3 = __builtin_amdgcn_s_memtime();
-#endif
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int rl = 8 * i + rsv;
-      f32x4 ghn, nn, hn;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        ghn[e] = gh[i][e] + bhn[e];
-        nn[e] = tanhf_(mk[i] * xin[i][e] + bin[e] + rr[i][e] * ghn[e]);
-        hn[e] = (1.0f - uu[i][e]) * nn[e] + uu[i][e] * hp[i][e];
-      }
-      if (STASH) {
-        enc_st4(nn, bgs, 4u * wo[i] + j4 + oob, 2 * h4);
-        enc_st4(ghn, bgs, 4u * wo[i] + j4 + oob, 3 * h4);
-        enc_st4(hn, bhs, wo[i] + j4 + oob, 0);
-      }
-      if (jok) {
-        uint2 h, l;
-        split2(hn[0], hn[1], &h.x, &l.x);
-        split2(hn[2], hn[3], &h.y, &l.y);
-        *reinterpret_cast<uint2*>(Xhi + rl * ldx + jv) = h;
-        *reinterpret_cast<uint2*>(Xlo + rl * ldx + jv) = l;
-      }
-      hp[i] = hn;
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the tile's last row-wise reads are done
-#pragma unroll
-    for (int i = 0; i < 8; ++i) *reinterpret_cast<f32x4*>(Trow + 8 * i * TP) = hp[i];   // park h_s for the next step
-    if (s == a.hist - 1 && jok) {   // cat(seq[:, -1], h_n[0]): the final state, once or twice (glow/models.py:63-64)
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int w = wbase + 8 * i + rsv;
-        if (w < a.F) {
-          float* c = a.cond + (long)w * a.ldcond + a.col + jv;
-          *reinterpret_cast<f32x4*>(c) = hp[i];
-          if (a.dup) *reinterpret_cast<f32x4*>(c + hid) = hp[i];
-        }
-      }
-    }
-#ifdef LFI_ENC_STAMPS
-    const unsigned long long c4s = __builtin_amdgcn_s_memtime();
-#endif
-    __syncthreads();   // the new state images are complete
-#ifdef LFI_ENC_STAMPS
-    const unsigned long long c5 = __builtin_amdgcn_s_memtime();
-    if (s > 0) { st_mfma += c1 - c0; st_e1 += c2 - c1; st_b1 += c3 - c2; st_e2 += c4s - c3; st_b2 += c5 - c4s; }
-#endif
-  }
-#ifdef LFI_ENC_STAMPS
-  if (a.stamps && lane == 0 && (wave == 0 || wave == 5) && blockIdx.x == 100) {
-    unsigned long long* o = a.stamps + 256 + (wave ? 8 : 0);
-    o[0] = st_mfma; o[1] = st_e1; o[2] = st_b1; o[3] = st_e2; o[4] = st_b2; o[5] = a.hist - 1;
-    o[6] = __builtin_amdgcn_s_memtime() - st_t0; o[7] = __builtin_amdgcn_s_memrealtime() - st_r0;
-  }
-#endif
-}
-
 // BPTT of the same block of windows in one workgroup: dh lives in the accumulator layout of the wave that owns
 // (rows, hidden) tile (rg, cg); per step the gate derivatives are taken in registers, written to dgi / dgh (the
 // deferred weight-gradient GEMMs read those) and fed gate by gate through LDS as the A operand of
@@ -1308,375 +1066,6 @@ __global__ __launch_bounds__(ENC_NT, 2) void enc_gru_bwd_fused_kernel(EncArgs a,
         const float v = bsum[qq][t] + __shfl_xor(bsum[qq][t], 32, 64);
         const int j = jb + 32 * t;
         if (half == 0 && j < hid) bp[qq * hid + j] = v;
-      }
-  }
-}
-
-// ---- WEIGHT-STATIONARY forward recurrence (hid 256, bf16x3, training pass with stashes).
-// Every kernel above re-reads all of W_hh (786 KB as bf16 hi + lo) per workgroup and history step out of L2: 1.4 MB per CU and
-// step at 32 windows per workgroup, which is what paces them (notes above enc_gru_fwd_r64_kernel). Here the WEIGHTS stay put
-// and the STATE travels: a CLUSTER of four workgroups (one per CU, 256 threads, one wave per SIMD) owns W_hh between them -
-// wave (m, v) keeps the three gate rows of hidden units [64 m + 16 v, + 16) over all 256 k as 48 MFMA A fragments in 192
-// VGPRs for the whole launch - and walks its share of the windows (F / clusters, in chunks of 32) through all history steps.
-// Per chunk and step a workgroup computes gh^T = W_hh(own 64 units x 3 gates) h_{s-1}^T with v_mfma_f32_16x16x32_bf16
-// (units x windows: a lane ends up with FOUR CONSECUTIVE units of one window, so projected inputs, stashes and the new state
-// are 16-byte accesses without any transpose), does the gate math for its 64 units, and hands its slice of h_s to the other
-// three members as bf16 hi / lo planes ALREADY in B-fragment order (exchange buffer hx, 32 KB per chunk, two step parities):
-// the consumer side is eight LDS-DMA instructions per wave and chunk, no VALU, no ds_write.
-// Traffic per CU and step: 229 KB of exchanged state instead of 1.4 MB of weights.
-// Hand-off as in the persistent flow walk (lfi_flow.hip): payload stored write-through (sc1), s_waitcnt vmcnt(0), then the
-// wave stores its own progress word (agent scope); the consumer looks at the chunk's sixteen words (4 members x 4 waves) and
-// reads with sc1 LDS-DMA. A workgroup visits its cluster's chunks round-robin, so the counter it polls was completed several
-// chunk times ago (cpc >= 4 chunks per cluster is required: the prefetch runs two chunks ahead, publishing two behind). Logical (cluster, member)
-// ids are dealt by an atomic ticket in arrival order: the workgroups that are resident always form complete clusters, so the
-// launch makes progress whatever else occupies the CUs; every spin is bounded, a timeout sets the abort word, every wave
-// then runs its loop out without waiting and the output is poisoned with NaN.
-// MEASURED (round 2, final_model.yaml batch 256, same box): 1.02 - 1.18 ms on the p2_face launch against 0.76 ms for
-// enc_gru_fwd_wide_kernel, so it is OPT-IN (LFI_ENC_WS=1) and the streaming kernel stays the default. What the stamps and
-// ingredient-removal builds (tools/ws_stamps.py, tools/build_enc_variant.sh) showed, in the order it was found:
-//  * one agent-scope atomic add per wave and chunk as the publish cost 0.6 ms of 1.0: the acknowledgement takes a memory round
-//    trip and vmcnt retires in order, so the next wait sat it out - replaced by a plain store to a per-wave progress word;
-//  * a poll on the spot costs ~4 k cycles per iteration - replaced by a peek issued one iteration early;
-//  * 16-byte accesses in the MFMA lane layout are 64 separate transactions per instruction - the accumulators go through a
-//    wave-private LDS transpose first;
-//  * s_waitcnt vmcnt(0) once per iteration made every iteration as long as the store latency (~8 k cycles) - replaced by a
-//    counted wait that leaves the newest stores in flight; inline-asm waits are invisible to the compiler's own wait
-//    insertion, which answered with vmcnt(0) in front of every MFMA phase until the waits became builtins;
-//  * after all that the MFMA phase is 3.1 - 4.2 k cycles of a 14 k-cycle iteration and the rest is the ISSUE of ~33 vector
-//    memory instructions per wave and iteration (250 - 500 cycles each, whatever is removed: stash, projected inputs or
-//    exchange alone change little, all three together halve it). One wave per SIMD - what 192 VGPRs of weights allow - is
-//    four waves of memory-level parallelism per CU against the streaming kernel's eight, for 1.75 x its traffic (4.9 GB
-//    against 2.8 GB per launch: the exchange is read four times). Register-resident W_hh for hid 256 in bf16 hi + lo and
-//    enough waves to keep HBM busy do not fit one CU together; that, not L2 weight streaming alone, bounds this recurrence.
-struct EncWs {
-  int ncl, cpc, nchk;   // clusters, chunks per cluster, chunks (of 32 windows) that hold windows
-  int skew;             // start-up skew between clusters, in s_sleep(8) units (512 cycles) per (cluster % 8)
-  const uint4* wfrag;   // [16 unit tiles][3 gates][8 k32][2 planes][64 lanes]: A fragments of W_hh
-  uint4* hx;            // [2 parities][ncl * cpc chunks][2 window tiles][8 k32][2 planes][64 lanes]: B fragments of h
-  unsigned* sync;       // [0] ticket, [1] abort, [8 + 16 chunk + 4 member + wave] progress words (zeroed before every launch)
-};
-#ifndef WS_AUX_LD
-#define WS_AUX_LD 16
-#endif
-#ifndef WS_AUX_ST
-#define WS_AUX_ST 16
-#endif
-constexpr int WS_CHUNK_U4 = 2 * 8 * 2 * 64;        // uint4 per chunk of the exchange buffer (32 KB)
-constexpr unsigned WS_SPIN_LIMIT = 1u << 22;
-
-// element ((((ut*3 + g)*8 + kt)*2 + plane)*64 + lane)*8 + e = W_hh[g*256 + ut*16 + (lane & 15)][kt*32 + 8*(lane >> 4) + e]
-__global__ __launch_bounds__(256) void enc_frag_weights_ws_kernel(const float* __restrict__ whh, __bf16* __restrict__ dst) {
-  const long n = 3L * 256 * 256 * 2;
-  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < n; idx += (long)gridDim.x * 256) {
-    const int e = (int)(idx & 7), l = (int)((idx >> 3) & 63), plane = (int)((idx >> 9) & 1);
-    int q = (int)(idx >> 10);
-    const int kt = q & 7; q >>= 3;
-    const int g = q % 3, ut = q / 3;
-    const float v = whh[((long)g * 256 + ut * 16 + (l & 15)) * 256 + kt * 32 + 8 * (l >> 4) + e];
-    const __bf16 hi = (__bf16)v;
-    dst[idx] = plane ? (__bf16)(v - (float)hi) : hi;
-  }
-}
-
-__device__ __forceinline__ unsigned ws_ld_agent(const unsigned* p) {
-  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-typedef __attribute__((address_space(1))) void ws_glb_void;
-typedef __attribute__((address_space(3))) void ws_lds_void;
-typedef __attribute__((ext_vector_type(2))) unsigned enc_u32x2;
-
-template <bool MASK>
-__global__ __launch_bounds__(256, 1) void enc_gru_fwd_ws_kernel(EncArgs a, EncWs q) {
-  constexpr int HID = 256, NK = 8, G3 = 768;
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  __shared__ unsigned s_ticket;
-  if (tid == 0) s_ticket = __hip_atomic_fetch_add(q.sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  __syncthreads();
-  const unsigned ticket = s_ticket;
-  int cl, m;
-  if ((q.ncl & 7) == 0) { cl = (int)((ticket & 7u) + 8u * (ticket >> 5)); m = (int)((ticket >> 3) & 3u); }   // members 8 apart:
-  else { cl = (int)(ticket >> 2); m = (int)(ticket & 3u); }                               // same XCD under round-robin dispatch
-  const int chunk0 = cl * q.cpc;
-  if (cl >= q.ncl || chunk0 >= q.nchk) return;   // a whole cluster without windows (the four members agree)
-  unsigned* abort_w = q.sync + 1;
-  unsigned* flags = q.sync + 8;
-  char* ring = reinterpret_cast<char*>(enc_smem);   // three slots of one chunk (32 KB) each | 4 x 6 KB transpose tiles
-  const unsigned ring_addr = (unsigned)(unsigned long)(ws_lds_void*)ring + (unsigned)lane * 16u;
-
-  // this wave's 16 hidden units x 3 gates x 256 k of W_hh: resident in registers for the whole launch
-  ebf16x8 W[3][NK][2];
-  {
-    const uint4* wf = q.wfrag + (long)((m * 4 + wave) * 3 * NK * 2) * 64 + lane;
-#pragma unroll
-    for (int g = 0; g < 3; ++g)
-#pragma unroll
-      for (int kt = 0; kt < NK; ++kt)
-#pragma unroll
-        for (int p = 0; p < 2; ++p) {
-          EncFrag f;
-          f.u = wf[((g * NK + kt) * 2 + p) * 64];
-          W[g][kt][p] = f.v;
-        }
-  }
-  // (seen by the compiler's wait insertion: otherwise it assumes the fragments may still be in flight at their first use
-  // inside the loop and puts a vmcnt(0) - a wait for the stores just issued - in front of every MFMA phase)
-  __builtin_amdgcn_s_waitcnt(0x0F70);
-  // Every cluster runs the same schedule, so without a skew all 256 CUs store their gate stashes in the same microsecond and
-  // then all go quiet for the MFMA phase: the stores queue behind each other (stamps: 250 cycles per store instruction).
-  // Clusters start an eighth of an iteration apart instead; nothing couples them afterwards.
-  for (int i = 0; i < (cl & 7) * q.skew; ++i) __builtin_amdgcn_s_sleep(8);
-  // The MFMA leaves lane l with window (l & 15), units 4 (l >> 4) .. + 3 of a 16 x 16 tile: lanes 16 apart share a window, so a
-  // 16-byte access per lane would be 64 separate 16-byte transactions (measured: the gate stash stores alone cost 0.43 ms of
-  // a 1.15 ms launch). The accumulators therefore go through a wave-private LDS tile once per gate (ds_write_b128 at slot
-  // 4 window + quad, ds_read_b128 at slot lane) into the EPILOGUE layout: lane l = window (l >> 2), units 4 (l & 3) .. + 3 -
-  // four adjacent lanes cover 64 contiguous bytes of a window's row, in every load and store below.
-  const int wl = lane >> 2, cq = lane & 3;
-  const int u0 = 64 * m + 16 * wave + 4 * cq;   // the lane's four hidden units
-  const unsigned tr_w = (unsigned)(unsigned long)(ws_lds_void*)ring + 3u * 32768u + (unsigned)wave * 6144u + (unsigned)((lane & 15) * 4 + (lane >> 4)) * 16u;
-  const unsigned tr_r = (unsigned)(unsigned long)(ws_lds_void*)ring + 3u * 32768u + (unsigned)wave * 6144u + (unsigned)lane * 16u;
-  f32x4 bi[3], bh[3];
-#pragma unroll
-  for (int g = 0; g < 3; ++g)
-#pragma unroll
-    for (int e = 0; e < 4; ++e) { bi[g][e] = a.b_ih[g * HID + u0 + e]; bh[g][e] = a.b_hh[g * HID + u0 + e]; }
-  // where this lane's four units sit in a B fragment of the exchange planes (byte offset inside a 16-window tile, hi plane)
-  const unsigned hx_off = (unsigned)((((2 * m + (wave >> 1)) * 2) * 64 + wl + 16 * (2 * (wave & 1) + (cq >> 1))) * 16 + 8 * (cq & 1));
-  const int pos0 = a.start - a.hist + 1;
-  const enc_rsrc bx = enc_buf(a.Xp, (long)a.B * a.T * G3 * 4);
-  const enc_rsrc bms = enc_buf(MASK ? a.mask : nullptr, MASK ? (long)a.F * a.hist * 4 : 0);
-  const long nchunks = (long)q.ncl * q.cpc;
-  const int Q = a.hist * q.cpc;
-  bool dead = false;
-
-  // progress words: flags[chunk * 16 + member * 4 + wave] = 1 + the last history step whose state slice that wave has stored
-  // (a plain write-through store per wave; an agent-scope atomic add on one shared counter took a memory round trip of
-  // several microseconds to acknowledge, and the next s_waitcnt vmcnt(0) - every iteration has one - sat it out: 0.6 ms of a
-  // 1.0 ms launch). A reader loads all sixteen words of a chunk with one instruction (lane & 15).
-  auto behind = [&](unsigned seen, unsigned need) { return __builtin_amdgcn_ballot_w64(seen < need) != 0ull; };
-  auto wait_flag = [&](const unsigned* f, unsigned need) {
-    if (dead) return;
-    unsigned spins = 0;
-    while (behind(ws_ld_agent(f + (lane & 15)), need)) {
-      if ((++spins & 31u) == 0u) {
-        if (__builtin_amdgcn_readfirstlane(ws_ld_agent(abort_w)) != 0u) { dead = true; return; }
-        if (spins > WS_SPIN_LIMIT) {
-          if (lane == 0) __hip_atomic_store(abort_w, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          dead = true;
-          return;
-        }
-      }
-      __builtin_amdgcn_s_sleep(2);
-    }
-  };
-  // the counter DMA(qq) depends on, read one iteration early (with the epilogue inputs): a poll on the spot costs a memory
-  // round trip of ~4 k cycles per iteration (stamps), and in steady state the counter was complete several iterations ago
-  auto peek_flag = [&](int qq) -> unsigned {
-    qq = min(qq, Q - 1);
-    const int s2 = qq / q.cpc, j2 = qq - s2 * q.cpc;
-    return ws_ld_agent(flags + (chunk0 + j2) * 16 + (lane & 15));
-  };
-  auto issue_dma = [&](int qq, unsigned seen) {
-    qq = min(qq, Q - 1);
-    const int s2 = qq / q.cpc, j2 = qq - s2 * q.cpc;
-    if (s2 > 0 && behind(seen, (unsigned)s2)) wait_flag(flags + (chunk0 + j2) * 16, (unsigned)s2);
-    const uint4* src = q.hx + ((long)((s2 + 1) & 1) * nchunks + chunk0 + j2) * WS_CHUNK_U4 + lane;
-    char* dst = ring + (qq % 3) * 32768;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int blk = i * 4 + wave;
-      __builtin_amdgcn_global_load_lds((ws_glb_void*)(src + blk * 64), (ws_lds_void*)(dst + blk * 1024), 16, 0, WS_AUX_LD /* sc1 */);
-    }
-  };
-  // inputs of the gate epilogue of iteration qq
-  auto issue_loads = [&](int qq, unsigned (&wo)[2], f32x4 (&xr)[2], f32x4 (&xz)[2], f32x4 (&xn)[2], f32x4 (&hp)[2], float (&mk)[2]) {
-    qq = min(qq, Q - 1);
-    const int s2 = qq / q.cpc, j2 = qq - s2 * q.cpc;
-    const enc_rsrc bhp = enc_buf(s2 > 0 ? a.hseq + (long)(s2 - 1) * a.F * HID : nullptr, s2 > 0 ? (long)a.F * HID * 4 : 0);
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      const int w0 = (chunk0 + j2) * 32 + 16 * t + wl;
-      const int w = min(w0, a.F - 1);   // windows past F recompute the last one; their stores are dropped
-      const int n = w / a.B, b = w - n * a.B;
-      const unsigned xo = (unsigned)((b * a.T + pos0 + n + s2) * G3 + u0) * 4u;
-      wo[t] = w0 < a.F ? (unsigned)(w * HID + u0) * 4u : 0x80000000u;
-      xr[t] = enc_ld4(bx, xo, 0);
-      xz[t] = enc_ld4(bx, xo, HID * 4);
-      xn[t] = enc_ld4(bx, xo, 2 * HID * 4);
-      hp[t] = enc_ld4(bhp, (unsigned)(w * HID + u0) * 4u, 0);   // step 0: a null buffer, reads 0
-      mk[t] = MASK ? enc_ld(bms, (unsigned)(w * a.hist + s2) * 4u, 0) : 1.0f;
-    }
-  };
-
-  // One iteration = one chunk of one history step:
-  //   barrier | MFMA(qi) | s_waitcnt vmcnt(10) | publish(qi - 2) | DMA(qi + 2), peek(qi + 3) | loads(qi + 1) | epilogue(qi), stores(qi)
-  // The ONE wait on vector memory leaves the newest ten operations - stores of the previous epilogue - in flight (vmcnt
-  // retires in order): what it does wait for was issued a whole iteration earlier or, the inputs of this epilogue, ahead of
-  // the previous epilogue's stores. (With vmcnt(0) here every iteration sat out the latency of the stores issued just before:
-  // stamps, 13 k cycles per iteration against 3.1 k of MFMA.) Stores of iteration qi - 2 are complete at that point, so
-  // publishing lags two iterations; the counter DMA(qi + 2) needs includes this workgroup's own publish of iteration
-  // qi + 2 - cpc, made at iteration qi + 4 - cpc: cpc >= 4 (>= 5 for the peeked value, one iteration old, to show it).
-  // DMA(qi + 2) overwrites the slot MFMA(qi - 1) read (every wave is past the barrier); DMA(qi + 1), older than everything
-  // the wait of iteration qi leaves in flight, has landed at the barrier that opens iteration qi + 1.
-  // Inside the epilogue the order is: gate math for both window tiles (results in registers) | loads(qi + 1) into the input
-  // registers the math has just released | stores(qi) - at least ten of them on every path, which is what the counted wait
-  // relies on.
-  unsigned wo[2];
-  f32x4 xr[2], xz[2], xn[2], hp[2];
-  float mk[2];
-  issue_dma(1, 0u);
-  issue_loads(0, wo, xr, xz, xn, hp, mk);
-  unsigned seen = peek_flag(2);
-  // the loop's counted wait assumes ten younger operations behind whatever it needs; there are none yet (and the compiler,
-  // which merges this path with the back edge, would otherwise answer with a vmcnt(0) inside the loop)
-  __builtin_amdgcn_s_waitcnt(0x0F70);
-  int s = 0, j = 0;
-#ifdef LFI_WS_STAMPS   // diagnostics build only (tools/ws_stamps.py): s_memtime sums per phase, one wave of one workgroup
-  unsigned long long ws_t[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ws_c = 0, ws_n = 0;
-#define WS_STAMP(i) do { const unsigned long long t_ = __builtin_amdgcn_s_memtime(); if (s > 0) ws_t[i] += t_ - ws_c; ws_c = t_; } while (0)
-#else
-#define WS_STAMP(i) do { } while (0)
-#endif
-  for (int qi = 0; qi < Q; ++qi) {
-    WS_STAMP(1);
-    __builtin_amdgcn_s_barrier();
-    WS_STAMP(7);
-    // ---- gh^T = W_hh h_{s-1}^T for the chunk's two window tiles
-    const int chunk = chunk0 + j;
-    f32x4 acc[2][3];
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int g = 0; g < 3; ++g) acc[t][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if (s > 0) {
-      // The fragment reads are inline asm: the compiler cannot tell that the LDS-DMA a plain LDS load might alias is long
-      // complete, and would put s_waitcnt vmcnt(0) - i.e. a wait for the stores just issued - in front of the MFMA phase.
-      const unsigned slot = ring_addr + (unsigned)(qi % 3) * 32768u;
-      ebf16x8 hh[2][2], hl[2][2];   // [k-tile parity][window tile]
-#define WS_READ(kt, set)                                                                                     \
-  asm volatile("ds_read_b128 %0, %4 offset:%5\n\tds_read_b128 %1, %4 offset:%6\n\t"                          \
-               "ds_read_b128 %2, %4 offset:%7\n\tds_read_b128 %3, %4 offset:%8"                              \
-               : "=&v"(hh[set][0]), "=&v"(hl[set][0]), "=&v"(hh[set][1]), "=&v"(hl[set][1])                  \
-               : "v"(slot), "n"(((0 * NK + (kt)) * 2 + 0) * 1024), "n"(((0 * NK + (kt)) * 2 + 1) * 1024),    \
-                 "n"(((1 * NK + (kt)) * 2 + 0) * 1024), "n"(((1 * NK + (kt)) * 2 + 1) * 1024))
-      WS_READ(0, 0);
-#pragma unroll
-      for (int kt = 0; kt < NK; ++kt) {
-        const int c = kt & 1;
-        // this k-tile's fragments have arrived (the dependence on the registers keeps the MFMAs behind the wait)
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(hh[c][0]), "+v"(hl[c][0]), "+v"(hh[c][1]), "+v"(hl[c][1]));
-        if (kt + 1 < NK) {
-          if (c == 0) { switch (kt + 1) { case 1: WS_READ(1, 1); break; case 3: WS_READ(3, 1); break; case 5: WS_READ(5, 1); break; default: WS_READ(7, 1); break; } }
-          else { switch (kt + 1) { case 2: WS_READ(2, 0); break; case 4: WS_READ(4, 0); break; default: WS_READ(6, 0); break; } }
-        }
-#pragma unroll
-        for (int g = 0; g < 3; ++g)
-#pragma unroll
-          for (int t = 0; t < 2; ++t) acc[t][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(W[g][kt][1], hh[c][t], acc[t][g], 0, 0, 0);
-#pragma unroll
-        for (int g = 0; g < 3; ++g)
-#pragma unroll
-          for (int t = 0; t < 2; ++t) acc[t][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(W[g][kt][0], hl[c][t], acc[t][g], 0, 0, 0);
-#pragma unroll
-        for (int g = 0; g < 3; ++g)
-#pragma unroll
-          for (int t = 0; t < 2; ++t) acc[t][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(W[g][kt][0], hh[c][t], acc[t][g], 0, 0, 0);
-      }
-#undef WS_READ
-    }
-    // ---- accumulators -> epilogue layout (inline asm for the reason given at the fragment reads)
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int g = 0; g < 3; ++g)
-        asm volatile("ds_write_b128 %0, %1 offset:%2" :: "v"(tr_w), "v"(acc[t][g]), "n"((t * 3 + g) * 1024));
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int g = 0; g < 3; ++g)
-        asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(acc[t][g]) : "v"(tr_r), "n"((t * 3 + g) * 1024));
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[0][2]), "+v"(acc[1][0]), "+v"(acc[1][1]), "+v"(acc[1][2]));
-    WS_STAMP(2);
-    __builtin_amdgcn_s_waitcnt(0x0F7A);   // vmcnt(10) (as the builtin: the compiler's own wait insertion sees it)
-    WS_STAMP(3);
-    if (qi > 1 && lane == 0) {   // iteration qi - 2 = (step sp, chunk jp)
-      const int jp = j >= 2 ? j - 2 : j + q.cpc - 2, sp = j >= 2 ? s : s - 1;
-      __hip_atomic_store(flags + (chunk0 + jp) * 16 + m * 4 + wave, (unsigned)sp + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    issue_dma(qi + 2, seen);
-    seen = peek_flag(qi + 3);   // for the DMA issued at this point of the next iteration
-    WS_STAMP(4);
-    // ---- gates, new state, stashes
-    const enc_rsrc bhs = enc_buf(a.hseq + (long)s * a.F * HID, (long)a.F * HID * 4);
-    const enc_rsrc bgs = enc_buf(a.gates + (long)s * a.F * 4 * HID, (long)a.F * HID * 16);
-    const enc_rsrc bxc = enc_buf(q.hx + ((long)(s & 1) * nchunks + chunk) * WS_CHUNK_U4, 32768);
-    const bool last = s == a.hist - 1;
-    f32x4 rr[2], uu[2], nn[2], ghn[2], hn[2];
-    unsigned so[2];
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        ghn[t][e] = acc[t][2][e] + bh[2][e];
-        rr[t][e] = sigmoidf_(mk[t] * xr[t][e] + bi[0][e] + (acc[t][0][e] + bh[0][e]));
-        uu[t][e] = sigmoidf_(mk[t] * xz[t][e] + bi[1][e] + (acc[t][1][e] + bh[1][e]));
-        nn[t][e] = tanhf_(mk[t] * xn[t][e] + bi[2][e] + rr[t][e] * ghn[t][e]);
-        hn[t][e] = (1.0f - uu[t][e]) * nn[t][e] + uu[t][e] * hp[t][e];
-      }
-      so[t] = wo[t];
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    WS_STAMP(5);
-    issue_loads(qi + 1, wo, xr, xz, xn, hp, mk);
-    __builtin_amdgcn_sched_barrier(0);
-    WS_STAMP(6);
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      const unsigned go = so[t] == 0x80000000u ? so[t] : 4u * so[t] - 12u * (unsigned)u0;   // (w * 4 HID + u0) * 4
-      enc_st4(rr[t], bgs, go, 0);
-      enc_st4(uu[t], bgs, go, HID * 4);
-      enc_st4(nn[t], bgs, go, 2 * HID * 4);
-      enc_st4(ghn[t], bgs, go, 3 * HID * 4);
-      enc_st4(hn[t], bhs, so[t], 0);
-    }
-    WS_STAMP(0);
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      if (!last) {
-        unsigned h0, h1, l0, l1;
-        split2(hn[t][0], hn[t][1], &h0, &l0);
-        split2(hn[t][2], hn[t][3], &h1, &l1);
-        const enc_u32x2 h = {h0, h1}, l = {l0, l1};
-        __builtin_amdgcn_raw_buffer_store_b64(h, bxc, hx_off + (unsigned)t * 16384u, 0, WS_AUX_ST /* sc1: write-through */);
-        __builtin_amdgcn_raw_buffer_store_b64(l, bxc, hx_off + (unsigned)t * 16384u + 1024u, 0, WS_AUX_ST);
-      } else if (so[t] != 0x80000000u) {   // cat(seq[:, -1], h_n[0]): the final state, once or twice (glow/models.py:63-64)
-        const int w = chunk * 32 + 16 * t + wl;
-        float* c = a.cond + (long)w * a.ldcond + a.col + u0;
-        *reinterpret_cast<f32x4*>(c) = hn[t];
-        if (a.dup) *reinterpret_cast<f32x4*>(c + HID) = hn[t];
-      }
-    }
-#ifdef LFI_WS_STAMPS
-    if (s > 0) ++ws_n;
-#endif
-    if (++j == q.cpc) { j = 0; ++s; }
-  }
-#ifdef LFI_WS_STAMPS
-  if (a.stamps && ticket == 40 && wave == 1 && lane == 0) {
-    for (int i = 0; i < 8; ++i) a.stamps[256 + i] = ws_t[i];
-    a.stamps[264] = ws_n;
-  }
-#endif
-  // a walk that gave up must not pass for a result
-  if (__builtin_amdgcn_readfirstlane(ws_ld_agent(abort_w)) != 0u) {
-    for (int jj = 0; jj < q.cpc; ++jj)
-#pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        const int w = (chunk0 + jj) * 32 + 16 * t + wl;
-        if (w < a.F) {
-          float* c = a.cond + (long)w * a.ldcond + a.col + u0;
-          for (int e = 0; e < 4; ++e) c[e] = __builtin_nanf("");
-        }
       }
   }
 }
@@ -1973,29 +1362,6 @@ __global__ __launch_bounds__(1024) void enc_bias_fold_kernel(const float* __rest
   }
 }
 
-// weight-stationary forward (enc_gru_fwd_ws_kernel): clusters x chunks per cluster for F windows, or false if it does not apply
-bool enc_ws_plan(int F, int hid, int* ncl, int* cpc, int* nchk) {
-  static int cus = 0;
-  if (!cus) {
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n < 4)
-      n = 256;
-    cus = n;
-  }
-  if (hid != 256) return false;
-  const int chunks = (int)lfi_cdiv(F, 32);
-  int c = cus / 4 < chunks / 4 ? cus / 4 : chunks / 4;   // one workgroup per CU, at least four chunks per cluster
-  if (c >= 8) c &= ~7;
-  if (c < 1) return false;
-  *ncl = c; *cpc = (int)lfi_cdiv(chunks, c); *nchk = chunks;
-  return true;
-}
-long enc_ws_work_floats(int F, int hid) {
-  int ncl, cpc, nchk;
-  if (!enc_ws_plan(F, hid, &ncl, &cpc, &nchk)) return 0;
-  return 3L * 256 * 256 + 2L * ncl * cpc * WS_CHUNK_U4 * 4 + 64 + 16L * ncl * cpc;   // fragments | exchange planes | sync words
-}
-
 int ew_blocks(long total) { return (int)(lfi_cdiv(total, 256) < 4096 ? lfi_cdiv(total, 256) : 4096); }
 
 }  // namespace
@@ -2004,9 +1370,7 @@ extern "C" long lfi_encode_windows_work_floats(const lfi_enc_desc* d) {
   if (!d) return 0;
   const long unfused = (long)d->N * d->B * (d->lstm ? 4 : 3) * d->hid;  // fwd: gh (F x G); bwd: two (LSTM: four) F x hid buffers
   const long fused = 3L * 256 * 256;                    // fused path: zero-padded weight image
-  const long ws = d->lstm || d->precision != 1 ? 0 : enc_ws_work_floats(d->N * d->B, d->hid);
-  const long m = unfused > fused ? unfused : fused;
-  return m > ws ? m : ws;
+  return unfused > fused ? unfused : fused;
 }
 
 extern "C" int lfi_encode_windows_fwd(const lfi_enc_desc* d, const float* Xp, const float* whh, const float* b_ih,
@@ -2064,61 +1428,6 @@ extern "C" int lfi_encode_windows_fwd(const lfi_enc_desc* d, const float* Xp, co
                           (mask ? (size_t)q.R * d->hist * sizeof(float) : 0);
       const bool vec_ok = x3 && hid % 4 == 0 && d->ldcond % 4 == 0 && d->col % 4 == 0 && al16(Xp) && al16(cond) &&
                           (!gates || (al16(gates) && al16(hseq)));
-      // weight-stationary clusters (hid 256, training pass): opt-in, LFI_ENC_WS=1 (measured slower than the streaming kernel
-      // below: notes above enc_gru_fwd_ws_kernel)
-      {
-        const char* e = getenv("LFI_ENC_WS");
-        EncWs w = {};
-        if (e && e[0] == '1' && wide && vec_ok && gates && hseq && enc_ws_plan(F, hid, &w.ncl, &w.cpc, &w.nchk)) {
-          float* wsb = work;
-          { const char* k = getenv("LFI_ENC_WS_SKEW"); w.skew = k ? atoi(k) : 2; }
-          w.wfrag = reinterpret_cast<const uint4*>(wsb);
-          w.hx = reinterpret_cast<uint4*>(wsb + 3L * 256 * 256);
-          w.sync = reinterpret_cast<unsigned*>(wsb + 3L * 256 * 256 + 2L * w.ncl * w.cpc * WS_CHUNK_U4 * 4);
-          hipLaunchKernelGGL(enc_frag_weights_ws_kernel, dim3(1536), dim3(256), 0, st, whh, reinterpret_cast<__bf16*>(wsb));
-          if (hipMemsetAsync(w.sync, 0, (size_t)(64 + 16 * w.ncl * w.cpc) * sizeof(unsigned), st) != hipSuccess) {
-            lfi_set_error("lfi_encode_windows_fwd: hipMemsetAsync of the cluster counters failed");
-            return LFI_ERR_LAUNCH;
-          }
-          const size_t ldsc = 3 * 32768 + 4 * 6144;   // ring | per-wave transpose tiles
-          if (mask) {
-            rc = enc_set_lds(enc_gru_fwd_ws_kernel<true>, ldsc);
-            if (!rc) hipLaunchKernelGGL((enc_gru_fwd_ws_kernel<true>), dim3(4 * w.ncl), dim3(256), ldsc, st, a, w);
-          } else {
-            rc = enc_set_lds(enc_gru_fwd_ws_kernel<false>, ldsc);
-            if (!rc) hipLaunchKernelGGL((enc_gru_fwd_ws_kernel<false>), dim3(4 * w.ncl), dim3(256), ldsc, st, a, w);
-          }
-          if (rc) return rc;
-          LFI_LAUNCH_CHECK("lfi_encode_windows_fwd (weight-stationary clusters)");
-          return LFI_OK;
-        }
-      }
-      static int r64 = -1;
-      if (r64 < 0) {
-        const char* e = getenv("LFI_ENC_R64");
-        r64 = (e && e[0] == '1') ? 1 : 0;   // opt-in: same-box 0.757 vs 0.729 ms on the p2_face launch (notes above the kernel)
-      }
-      const size_t lds64 = (size_t)2 * 64 * (q.Kp + 8) * sizeof(__bf16) + (size_t)8 * 64 * 36 * sizeof(float) +
-                           (size_t)6 * q.Jp * sizeof(float) + (size_t)2 * 64 * sizeof(unsigned) +
-                           (mask ? (size_t)64 * d->hist * sizeof(float) : 0);
-      if (wide && r64 && vec_ok && hid > 128 && lds64 <= 160 * 1024 && F >= 64 * 64) {   // wide recurrences with enough windows to fill the chip
-        rc = LFI_OK;
-        const dim3 grid64(lfi_cdiv(F, 64));
-        switch ((gates ? 2 : 0) | (mask ? 1 : 0)) {
-#define LFI_ENC_FWD64(ST, MK)                                                                                \
-  rc = enc_set_lds(enc_gru_fwd_r64_kernel<ST, MK>, lds64);                                                   \
-  if (!rc) hipLaunchKernelGGL((enc_gru_fwd_r64_kernel<ST, MK>), grid64, dim3(512), lds64, st, a, q);        \
-  break
-          case 3: LFI_ENC_FWD64(true, true);
-          case 2: LFI_ENC_FWD64(true, false);
-          case 1: LFI_ENC_FWD64(false, true);
-          default: LFI_ENC_FWD64(false, false);
-#undef LFI_ENC_FWD64
-        }
-        if (rc) return rc;
-        LFI_LAUNCH_CHECK("lfi_encode_windows_fwd (fused, 64 windows per workgroup)");
-        return LFI_OK;
-      }
       if (wide && vec_ok && ldsw <= 80 * 1024) {
         rc = LFI_OK;
         switch ((gates ? 2 : 0) | (mask ? 1 : 0)) {

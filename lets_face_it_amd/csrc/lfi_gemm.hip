@@ -364,165 +364,6 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(GemmArgs g) {
 // two tiles ahead (two register sets); full k-tiles take a predicate-free path (rows past M / N are clamped: they only
 // feed outputs that are never stored), only the last partial k-tile masks.
 
-template <bool KC>
-struct WStager {
-  int off[4];     // element offset of each float4 from the tile origin
-  int lds[4];     // KC: bf16 offset of the 4 values in the image
-  int kk[4];      // first k of the float4 (KC) / its k row (!KC)
-  int mn_l, kg4;
-  __device__ __forceinline__ void init(int ptid, int mn0, int MN, long ld) {
-    if (KC) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int f = ptid + 256 * i;
-        const int k = (f & 7) * 4, mn = f >> 3;
-        kk[i] = k;
-        off[i] = (min(mn0 + mn, MN - 1) - mn0) * (int)ld + k;
-        lds[i] = mn * XROW + k;
-      }
-    } else {
-      kg4 = (ptid & 7) * 4;
-      mn_l = (ptid >> 3) * 4;
-      const int mnc = mn0 + mn_l < MN ? mn_l : 0;   // a float4 wholly outside the matrix re-reads the tile's first columns
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        kk[j] = kg4 + j;
-        off[j] = (kg4 + j) * (int)ld + mnc;
-        lds[j] = 0;
-      }
-    }
-  }
-  __device__ __forceinline__ void load_full(const float* __restrict__ p, f32x4 (&r)[4]) const {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) r[i] = *reinterpret_cast<const f32x4*>(p + off[i]);
-  }
-  // last, partial k-tile: whole float4s past K are not read, elements past K are zeroed
-  __device__ __forceinline__ void load_tail(const float* __restrict__ p, int krem, f32x4 (&r)[4]) const {
-    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      r[i] = kk[i] < krem ? *reinterpret_cast<const f32x4*>(p + off[i]) : z;
-      if (KC) {
-#pragma unroll
-        for (int j = 1; j < 4; ++j) r[i][j] = (kk[i] + j < krem) ? r[i][j] : 0.0f;
-      }
-    }
-  }
-  __device__ __forceinline__ void store(__bf16* hi_img, __bf16* lo_img, const f32x4 (&r)[4]) const {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      uint2 h, l;
-      if (KC) {
-        split2(r[i][0], r[i][1], &h.x, &l.x);
-        split2(r[i][2], r[i][3], &h.y, &l.y);
-        *reinterpret_cast<uint2*>(hi_img + lds[i]) = h;
-        *reinterpret_cast<uint2*>(lo_img + lds[i]) = l;
-      } else {  // r[j][i] = element (k = kg4 + j, mn = mn_l + i): each LDS row gets 4 consecutive k
-        split2(r[0][i], r[1][i], &h.x, &l.x);
-        split2(r[2][i], r[3][i], &h.y, &l.y);
-        *reinterpret_cast<uint2*>(hi_img + (mn_l + i) * XROW + kg4) = h;
-        *reinterpret_cast<uint2*>(lo_img + (mn_l + i) * XROW + kg4) = l;
-      }
-    }
-  }
-};
-
-template <bool AKC, bool BKC>
-__global__ __launch_bounds__(512, 4) void gemm_bf16x3_ws_kernel(GemmArgs g) {
-  const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int l31 = lane & 31, half = lane >> 5;
-  const bool producer = wave >= 4;
-  int tm, tn, batch, split;
-  gemm_tile_of_block(g, &tm, &tn, &batch, &split);
-  const int m0 = tm * 128, n0 = tn * 128;
-  const int kbeg = split * g.kchunk;
-  const int kend = min(g.K, kbeg + g.kchunk);
-  const int nkt = (kend - kbeg + XBK - 1) / XBK;
-  const int wm = (wave & 3) >> 1, wn = wave & 1;
-  f32x16 acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-
-  if (producer) {
-    const float* __restrict__ A = g.A + batch * g.strideA;
-    const float* __restrict__ B = g.B + batch * g.strideB;
-    WStager<AKC> sa;
-    WStager<BKC> sb;
-    sa.init(tid - 256, m0, g.M, g.lda);
-    sb.init(tid - 256, n0, g.N, g.ldb);
-    const float* __restrict__ tA = AKC ? A + (long)m0 * g.lda + kbeg : A + (long)kbeg * g.lda + m0;
-    const float* __restrict__ tB = BKC ? B + (long)n0 * g.ldb + kbeg : B + (long)kbeg * g.ldb + n0;
-    const long stepA = AKC ? XBK : (long)XBK * g.lda, stepB = BKC ? XBK : (long)XBK * g.ldb;
-    f32x4 ra0[4], rb0[4], ra1[4], rb1[4];
-    auto load = [&](int kt, f32x4 (&ra)[4], f32x4 (&rb)[4]) {
-      const int krem = kend - (kbeg + kt * XBK);
-      if (krem >= XBK) {
-        sa.load_full(tA + kt * stepA, ra);
-        sb.load_full(tB + kt * stepB, rb);
-      } else {
-        sa.load_tail(tA + kt * stepA, krem, ra);
-        sb.load_tail(tB + kt * stepB, krem, rb);
-      }
-    };
-    auto store = [&](int buf, const f32x4 (&ra)[4], const f32x4 (&rb)[4]) {
-      __bf16* base = xsmem + buf * 4 * XIMG;
-      sa.store(base, base + XIMG, ra);
-      sb.store(base + 2 * XIMG, base + 3 * XIMG, rb);
-    };
-    if (nkt > 0) {
-      load(0, ra0, rb0);
-      if (nkt > 1) load(1, ra1, rb1);
-      store(0, ra0, rb0);
-    }
-    __syncthreads();
-    for (int kt = 0; kt < nkt; kt += 2) {
-      if (kt + 2 < nkt) load(kt + 2, ra0, rb0);
-      if (kt + 1 < nkt) store(1, ra1, rb1);
-      __syncthreads();
-      if (kt + 1 >= nkt) break;
-      if (kt + 3 < nkt) load(kt + 3, ra1, rb1);
-      if (kt + 2 < nkt) store(0, ra0, rb0);
-      __syncthreads();
-    }
-  } else {
-    __syncthreads();
-    for (int kt = 0; kt < nkt; ++kt) {
-      const __bf16* base = xsmem + (kt & 1) * 4 * XIMG;
-#pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        bf16x8 ah[2], al[2], bh[2], bl[2];
-#pragma unroll
-        for (int t2 = 0; t2 < 2; ++t2) {
-          const int ro = (wm * 64 + t2 * 32 + l31) * XROW + ks * 16 + half * 8;
-          const int co = (wn * 64 + t2 * 32 + l31) * XROW + ks * 16 + half * 8;
-          ah[t2] = *reinterpret_cast<const bf16x8*>(base + ro);
-          al[t2] = *reinterpret_cast<const bf16x8*>(base + XIMG + ro);
-          bh[t2] = *reinterpret_cast<const bf16x8*>(base + 2 * XIMG + co);
-          bl[t2] = *reinterpret_cast<const bf16x8*>(base + 3 * XIMG + co);
-        }
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-          for (int nt = 0; nt < 2; ++nt) {
-            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mt], bh[nt], acc[mt][nt], 0, 0, 0);
-            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt], bl[nt], acc[mt][nt], 0, 0, 0);
-            acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt], bh[nt], acc[mt][nt], 0, 0, 0);
-          }
-      }
-      __syncthreads();
-    }
-  }
-  if (g.vecC)
-    gemm_epilogue_wide<128, 512>(g, acc, reinterpret_cast<float*>(xsmem), 128, m0, n0, wm, wn, l31, half, batch, split, 128, !producer);
-  else if (!producer)
-    gemm_epilogue(g, acc, m0, n0, wm, wn, l31, half, batch, split);
-}
-
 // ---------------------------------------------------------------------------------------------- bf16 x 3, 256 x 256 tiles
 // The 128 x 128 kernel above is bound by operand delivery, not by the matrix pipe: with only the hi*hi MFMA left (1/3 of
 // the matrix work) the cond_transform product ran 0.73 ms instead of 0.93 ms. Each workgroup has one k-tile of loads in
@@ -844,452 +685,6 @@ __global__ __launch_bounds__(1024, 4) void gemm_bf16a_256_kernel(GemmArgs g) {
   else gemm_epilogue_n<256>(g, acc, m0, n0, wm, wn, l31, half, batch, split);
 }
 
-// ---------------------------------------------------------------------------------------------- bf16 x 3, 256 x 256, k-tile 32
-// The 16-wave kernel above with 32 k per barrier instead of 16 (two MFMA k-steps, 24 MFMAs per wave between barriers): half
-// the barriers and loop tops per unit of K. Two buffers of four 256 x 40 bf16 planes are exactly the CU's 160 KB of LDS, so
-// this is the largest k-tile the 256 x 256 shape can double-buffer. One k-tile of loads (two float4 per thread and operand)
-// is in flight: requested right after the previous one has been converted, consumed after the next tile's MFMAs.
-// Measured against the 16-k kernel: in isolation (tools/gemm_probe.py, same box, twice) cond_transform forward 0.78 -> 0.76 ms,
-// dgrad 0.74 -> 0.71, wgrad (both operands mn-contiguous) and the short-K batched products unchanged; inside the training
-// step (bench.py, same box, twice each) no gain: 9.86 / 10.02 ms per step with the 16-k kernel, 9.92 / 10.05 with this one,
-// the cond_transform forward launch 0.653 vs 0.659 ms. So the barrier is not what holds the loop back either, and the 16-k
-// kernel stays the default; this one is opt-in (LFI_GEMM_K32=1, or precision bit 0x40 in the tests).
-constexpr int ZBK = 32;
-constexpr int ZROW = ZBK + 8;            // bf16 per LDS row of a k-contiguous image: 80 B, 5 x 16 B: conflict-free b128 reads
-constexpr int ZIMG = 256 * ZROW;         // bf16 per plane (the k-major image, 32 x YPIT, is smaller)
-
-template <bool KC>
-struct ZStager {
-  int off, lds, kk;
-  long step2;   // floats between the thread's two float4 of a k-tile (k + 16)
-  __device__ __forceinline__ void init(int tid, int mn0, int MN, long ld) {
-    if (KC) {
-      const int k4 = (tid & 3) * 4, mn = tid >> 2;
-      kk = k4;
-      off = (min(mn0 + mn, MN - 1) - mn0) * (int)ld + k4;
-      lds = mn * ZROW + k4;
-      step2 = 16;
-    } else {
-      const int k = tid >> 6, mn4 = (tid & 63) * 4;
-      kk = k;
-      off = k * (int)ld + (mn0 + mn4 < MN ? mn4 : 0);
-      lds = k * YPIT + mn4;
-      step2 = 16 * ld;
-    }
-  }
-  __device__ __forceinline__ void load_full(const float* __restrict__ p, f32x4 (&r)[2]) const {
-    r[0] = *reinterpret_cast<const f32x4*>(p + off);
-    r[1] = *reinterpret_cast<const f32x4*>(p + off + step2);
-  }
-  __device__ __forceinline__ void load(const float* __restrict__ p, int krem, f32x4 (&r)[2]) const {
-    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int kh = kk + 16 * h;
-      r[h] = kh < krem ? *reinterpret_cast<const f32x4*>(p + off + h * step2) : z;
-      if (KC) {
-#pragma unroll
-        for (int j = 1; j < 4; ++j) r[h][j] = (kh + j < krem) ? r[h][j] : 0.0f;
-      }
-    }
-  }
-  __device__ __forceinline__ void store(__bf16* hi_img, __bf16* lo_img, const f32x4 (&r)[2]) const {
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      uint2 hv, lv;
-      split2(r[h][0], r[h][1], &hv.x, &lv.x);
-      split2(r[h][2], r[h][3], &hv.y, &lv.y);
-      const int o = lds + (KC ? 16 * h : 16 * h * YPIT);
-      *reinterpret_cast<uint2*>(hi_img + o) = hv;
-      *reinterpret_cast<uint2*>(lo_img + o) = lv;
-    }
-  }
-};
-
-// fragment of MFMA k-step ks (0, 1) of a 32-k image; lane mapping as yfrag
-template <bool KC>
-__device__ __forceinline__ bf16x8 zfrag(const __bf16* img, int mn, int lane, int ks) {
-  if (KC) {
-    return *reinterpret_cast<const bf16x8*>(img + (mn + (lane & 31)) * ZROW + ks * 16 + (lane >> 5) * 8);
-  } else {
-    const int i = lane & 15, q = i >> 2, pp = i & 3;
-    const __bf16* ptr = img + (ks * 16 + 8 * (lane >> 5) + q) * YPIT + mn + 16 * ((lane >> 4) & 1) + 4 * pp;
-    typedef __attribute__((address_space(3))) ybf16x4 lds_v4;
-    const ybf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4*)ptr);
-    const ybf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_v4*)(ptr + 4 * YPIT));
-    bf16x8 r;
-    r[0] = lo[0]; r[1] = lo[1]; r[2] = lo[2]; r[3] = lo[3];
-    r[4] = hi[0]; r[5] = hi[1]; r[6] = hi[2]; r[7] = hi[3];
-    return r;
-  }
-}
-
-template <bool AKC, bool BKC>
-__global__ __launch_bounds__(1024, 4) void gemm_bf16x3_256k_kernel(GemmArgs g) {
-  const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int l31 = lane & 31, half = lane >> 5;
-  int tm, tn, batch, split;
-  gemm_tile_of_block(g, &tm, &tn, &batch, &split);
-  const int m0 = tm * 256, n0 = tn * 256;
-  const float* __restrict__ A = g.A + batch * g.strideA;
-  const float* __restrict__ B = g.B + batch * g.strideB;
-  const int kbeg = split * g.kchunk;
-  const int kend = min(g.K, kbeg + g.kchunk);
-  const int nkt = (kend - kbeg + ZBK - 1) / ZBK;
-
-  ZStager<AKC> sa;
-  ZStager<BKC> sb;
-  sa.init(tid, m0, g.M, g.lda);
-  sb.init(tid, n0, g.N, g.ldb);
-  const float* __restrict__ tA = AKC ? A + (long)m0 * g.lda + kbeg : A + (long)kbeg * g.lda + m0;
-  const float* __restrict__ tB = BKC ? B + (long)n0 * g.ldb + kbeg : B + (long)kbeg * g.ldb + n0;
-  const long stepA = AKC ? ZBK : (long)ZBK * g.lda, stepB = BKC ? ZBK : (long)ZBK * g.ldb;
-
-  f32x4 ra[2], rb[2];
-  auto load = [&](int kt) {
-    const int krem = kend - (kbeg + kt * ZBK);
-    sa.load(tA + kt * stepA, krem, ra);
-    sb.load(tB + kt * stepB, krem, rb);
-  };
-  auto load_full = [&](int kt) {
-    sa.load_full(tA + kt * stepA, ra);
-    sb.load_full(tB + kt * stepB, rb);
-  };
-  auto store = [&](int buf) {
-    __bf16* base = xsmem + buf * 4 * ZIMG;
-    sa.store(base, base + ZIMG, ra);
-    sb.store(base + 2 * ZIMG, base + 3 * ZIMG, rb);
-  };
-
-  const int wm = wave >> 2, wn = wave & 3;
-  f32x16 acc[2][2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-
-  auto mma = [&](int buf) {
-    const __bf16* base = xsmem + buf * 4 * ZIMG;
-#pragma unroll
-    for (int ks = 0; ks < 2; ++ks) {
-      bf16x8 ah[2], al[2], bh[2], bl[2];
-#pragma unroll
-      for (int t2 = 0; t2 < 2; ++t2) {
-        ah[t2] = zfrag<AKC>(base, wm * 64 + t2 * 32, lane, ks);
-        al[t2] = zfrag<AKC>(base + ZIMG, wm * 64 + t2 * 32, lane, ks);
-        bh[t2] = zfrag<BKC>(base + 2 * ZIMG, wn * 64 + t2 * 32, lane, ks);
-        bl[t2] = zfrag<BKC>(base + 3 * ZIMG, wn * 64 + t2 * 32, lane, ks);
-      }
-#pragma unroll
-      for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
-          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mt], bh[nt], acc[mt][nt], 0, 0, 0);
-          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt], bl[nt], acc[mt][nt], 0, 0, 0);
-          acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt], bh[nt], acc[mt][nt], 0, 0, 0);
-        }
-    }
-  };
-
-  // At the top of iteration kt: tile kt is in LDS buffer kt & 1, tile kt + 1 (raw fp32) in the registers.
-  // Long K: prologue and steady state without a conditional load (see the 16-k kernel); the last three tiles drain.
-  int kt = 0;
-  if (nkt > 3) {
-    load_full(0);
-    store(0);
-    load_full(1);
-    __syncthreads();
-    for (; kt + 3 < nkt; ++kt) {   // tile kt + 2 <= nkt - 2 is a complete one
-      mma(kt & 1);
-      __builtin_amdgcn_sched_barrier(0);
-      store((kt + 1) & 1);
-      load_full(kt + 2);
-      __syncthreads();
-    }
-  } else {
-    if (nkt > 0) { load(0); store(0); }
-    if (nkt > 1) load(1);
-    __syncthreads();
-  }
-  for (; kt < nkt; ++kt) {
-    mma(kt & 1);
-    if (kt + 1 < nkt) store((kt + 1) & 1);
-    if (kt + 2 < nkt) load(kt + 2);
-    __syncthreads();
-  }
-  if (g.vecC) gemm_epilogue_wide<256, 1024>(g, acc, reinterpret_cast<float*>(xsmem), LFI_EPI_ROWS, m0, n0, wm, wn, l31, half, batch, split, 256);
-  else gemm_epilogue_n<256>(g, acc, m0, n0, wm, wn, l31, half, batch, split);
-}
-
-// ---------------------------------------------------------------------------------------------- bf16 x 3, 256 x 256, 8 wide waves
-// What idles the matrix pipe in the 16-wave kernel above is its phase structure: after the per-k-tile barrier every wave
-// first reads its 8 operand fragments from LDS (128 KB per CU and k-tile: ~1000 cycles of LDS bandwidth with the pipe idle),
-// then all issue their MFMAs (1536 cycles with LDS idle), then all convert and store: ~4400 cycles per k-tile against 1546
-// of MFMA time (35 % of peak), and with 128 VGPRs per wave there is no room to hold the next tile's fragments.
-// Here a workgroup is 8 waves (2 per SIMD, 256 VGPRs each) and a wave owns a 128 x 64 patch (4 x 2 tiles, 128 accumulator
-// registers): 12 fragment reads feed 24 MFMAs (0.5 instead of 0.67 LDS reads per MFMA, 96 KB per CU and k-tile), and the
-// reads run UNDER the MFMAs: the B fragments of k-tile t+1 are requested before the MFMAs of tile t start (double-buffered
-// registers), each A row-tile fragment of t+1 right after the six MFMAs that consumed its predecessor. That needs tile t+1
-// in LDS one barrier early, so the LDS image is triple-buffered (144 KB, one workgroup per CU): iteration t computes tile t
-// from registers, reads tile t+1 from buffer (t+1) % 3 and converts tile t+2 into buffer (t+2) % 3, one barrier per k-tile.
-// Global loads run four k-tiles ahead in two register sets. Same operand images and fragment reads as above (YStager
-// geometry for 512 threads: two float4 per thread, operand and k-tile).
-// MEASURED (tools/build_variants.sh + tools/gemm_probe.py, cond_transform product 14336 x 8192 x 890, MI355X): the schedule
-// comes out as written (fragment reads interleaved with the MFMAs, loads counted, no vmcnt(0)), and the kernel is NOT
-// faster than the 16-wave one: 0.82 ms either way in the probe. Removing one ingredient at a time: MFMAs -0.39 ms,
-// convert + LDS store -0.21, fragment reads -0.13, global loads -0.07, epilogue -0.15 - they add up to the kernel: nothing
-// overlaps. s_memtime stamps (-DY2_STAMPS): 2750 cycles per k-tile (MFMA phase ~1300-1550 with the SIMD's two waves
-// contending, staging ~700, barrier + loop top ~400) at an effective clock of ~1.63 GHz under this load (1.69 us per
-// k-tile), i.e. the matrix pipe's ceiling here is ~1.7 PFLOP/s, not the nominal 2.5. Running the two waves of a SIMD in
-// opposite phase (waves 4-7 stage first; -DY2_NO_SKEW restores lockstep) moves time from one wave's barrier wait to the
-// other's staging (1680 cycles while its partner streams MFMAs) and nets nothing, with or without s_setprio on the
-// staging half - the same zero-sum the microarchitecture notes report for two waves per SIMD. Kept opt-in
-// (LFI_GEMM_WIDE=1) as the base for the next step: operands pre-split to bf16 planes by their producers (no VALU in the
-// loop) and an epilogue that does not hold the CU (0.15 ms of this product). Also tried on the 16-wave kernel and dropped:
-// delaying the workgroups of XCD x by x * d cycles at launch, to de-phase the eight XCDs' epilogue write bursts - slower for
-// every d (cond_transform 0.71 ms at d = 0, 0.77 at 3000, 0.86 at 8000, 1.00 at 16000).
-constexpr int Y2NT = 512;
-constexpr int Y2BUFS = 3;
-
-template <bool KC>
-struct Y2Stager {
-  int off[2], lds[2], kk[2];
-  __device__ __forceinline__ void init(int tid, int mn0, int MN, long ld) {
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      if (KC) {
-        const int k4 = (tid & 3) * 4, mn = (tid >> 2) + 128 * h;
-        kk[h] = k4;
-        off[h] = (min(mn0 + mn, MN - 1) - mn0) * (int)ld + k4;
-        lds[h] = mn * YROW + k4;
-      } else {
-        const int k = (tid >> 6) + 8 * h, mn4 = (tid & 63) * 4;
-        kk[h] = k;
-        off[h] = k * (int)ld + (mn0 + mn4 < MN ? mn4 : 0);
-        lds[h] = k * YPIT + mn4;
-      }
-    }
-  }
-  __device__ __forceinline__ void load_full(const float* __restrict__ p, f32x4 (&r)[2]) const {
-    r[0] = *reinterpret_cast<const f32x4*>(p + off[0]);
-    r[1] = *reinterpret_cast<const f32x4*>(p + off[1]);
-  }
-  __device__ __forceinline__ void load(const float* __restrict__ p, int krem, f32x4 (&r)[2]) const {
-    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      if (krem >= YBK) {
-        r[h] = *reinterpret_cast<const f32x4*>(p + off[h]);
-      } else {  // last, partial k-tile (or none at all: krem <= 0 gives zeros)
-        r[h] = kk[h] < krem ? *reinterpret_cast<const f32x4*>(p + off[h]) : z;
-        if (KC) {
-#pragma unroll
-          for (int j = 1; j < 4; ++j) r[h][j] = (kk[h] + j < krem) ? r[h][j] : 0.0f;
-        }
-      }
-    }
-  }
-  __device__ __forceinline__ void store(__bf16* hi_img, __bf16* lo_img, const f32x4 (&r)[2]) const {
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      uint2 hh, ll;
-      split2(r[h][0], r[h][1], &hh.x, &ll.x);
-      split2(r[h][2], r[h][3], &hh.y, &ll.y);
-      *reinterpret_cast<uint2*>(hi_img + lds[h]) = hh;
-      *reinterpret_cast<uint2*>(lo_img + lds[h]) = ll;
-    }
-  }
-};
-
-template <bool AKC, bool BKC>
-__global__ __launch_bounds__(Y2NT) void gemm_bf16x3_256w_kernel(GemmArgs g) {
-  const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int l31 = lane & 31, half = lane >> 5;
-  int tm, tn, batch, split;
-  gemm_tile_of_block(g, &tm, &tn, &batch, &split);
-  const int m0 = tm * 256, n0 = tn * 256;
-  const float* __restrict__ A = g.A + batch * g.strideA;
-  const float* __restrict__ B = g.B + batch * g.strideB;
-  const int kbeg = split * g.kchunk;
-  const int kend = min(g.K, kbeg + g.kchunk);
-  const int nkt = (kend - kbeg + YBK - 1) / YBK;
-  const int nfull = (kend - kbeg) / YBK;   // k-tiles that are complete
-
-  Y2Stager<AKC> sa;
-  Y2Stager<BKC> sb;
-  sa.init(tid, m0, g.M, g.lda);
-  sb.init(tid, n0, g.N, g.ldb);
-  const float* __restrict__ tA = AKC ? A + (long)m0 * g.lda + kbeg : A + (long)kbeg * g.lda + m0;
-  const float* __restrict__ tB = BKC ? B + (long)n0 * g.ldb + kbeg : B + (long)kbeg * g.ldb + n0;
-  const long stepA = AKC ? YBK : (long)YBK * g.lda, stepB = BKC ? YBK : (long)YBK * g.ldb;
-
-  f32x4 ra[2][2], rb[2][2];   // [register set][float4]
-  auto load_any = [&](int kt, f32x4 (&xa)[2], f32x4 (&xb)[2]) {   // any tile index: partial tiles masked, tiles past the end zero
-    const int krem = kend - (kbeg + kt * YBK);
-    sa.load(tA + kt * stepA, krem, xa);
-    sb.load(tB + kt * stepB, krem, xb);
-  };
-  auto store = [&](int buf, const f32x4 (&xa)[2], const f32x4 (&xb)[2]) {
-    __bf16* base = xsmem + buf * 4 * YIMG;
-    sa.store(base, base + YIMG, xa);
-    sb.store(base + 2 * YIMG, base + 3 * YIMG, xb);
-  };
-
-  const int wm = wave >> 2, wn = wave & 3;   // 2 x 4 waves, each 128 rows x 64 columns
-#ifdef Y2_NO_SKEW
-  const bool late = false;
-#else
-  const bool late = wave >= 4;               // waves w and w + 4 share a SIMD
-#endif
-  f32x16 acc[4][2];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.0f;
-
-  bf16x8 ah[4], al[4], bh[2], bl[2], bhn[2], bln[2];
-  auto read_a = [&](int buf, int mt) {
-    const __bf16* base = xsmem + buf * 4 * YIMG;
-    ah[mt] = yfrag<AKC>(base, wm * 128 + mt * 32, lane);
-    al[mt] = yfrag<AKC>(base + YIMG, wm * 128 + mt * 32, lane);
-  };
-  auto read_b = [&](int buf, bf16x8 (&xh)[2], bf16x8 (&xl)[2]) {
-    const __bf16* base = xsmem + buf * 4 * YIMG;
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-      xh[nt] = yfrag<BKC>(base + 2 * YIMG, wn * 64 + nt * 32, lane);
-      xl[nt] = yfrag<BKC>(base + 3 * YIMG, wn * 64 + nt * 32, lane);
-    }
-  };
-  auto mma_row = [&](int mt) {   // the six MFMAs of row tile mt, the two column tiles interleaved (dependent distance 2)
-#ifdef Y2_NO_MMA
-    return;
-#endif
-    acc[mt][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mt], bh[0], acc[mt][0], 0, 0, 0);
-    acc[mt][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mt], bh[1], acc[mt][1], 0, 0, 0);
-    acc[mt][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt], bl[0], acc[mt][0], 0, 0, 0);
-    acc[mt][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt], bl[1], acc[mt][1], 0, 0, 0);
-    acc[mt][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt], bh[0], acc[mt][0], 0, 0, 0);
-    acc[mt][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt], bh[1], acc[mt][1], 0, 0, 0);
-  };
-
-  // prologue: tiles 0 and 1 into LDS buffers 0 and 1, tiles 2 and 3 into the two register sets, fragments of tile 0
-  load_any(0, ra[0], rb[0]);
-  load_any(1, ra[1], rb[1]);
-  store(0, ra[0], rb[0]);
-  store(1, ra[1], rb[1]);
-  load_any(2, ra[0], rb[0]);
-  load_any(3, ra[1], rb[1]);
-  __syncthreads();
-#pragma unroll
-  for (int mt = 0; mt < 4; ++mt) read_a(0, mt);
-  read_b(0, bh, bl);
-
-#ifdef Y2_STAMPS
-  unsigned long long st_acc[6] = {0, 0, 0, 0, 0, 0}, st_prev = __builtin_amdgcn_s_memtime();
-#define Y2_STAMP(i) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); st_acc[i] += now_ - st_prev; st_prev = now_; } while (0)
-#else
-#define Y2_STAMP(i)
-#endif
-  int cur = 0, nxt = 1, nn = 2;   // LDS buffers of tiles t, t + 1, t + 2
-  // one k-tile; STEADY: tile t + 4 is a complete tile (unconditional loads, so that s_waitcnt can count them)
-  auto iteration = [&](int t, f32x4 (&xa)[2], f32x4 (&xb)[2], bool steady) {
-    // The two waves of a SIMD run their halves of the iteration in opposite order: the first (waves 0-3) issues its 24 MFMAs,
-    // then converts and stores tile t + 2; the second (waves 4-7) converts first. So one wave's VALU / LDS-write work runs
-    // in the shadow of the other's MFMAs instead of both queueing on the matrix pipe and then both on the vector pipe
-    // (measured with the phases aligned: MFMA 0.39 + convert 0.21 + fragment reads 0.13 + loads 0.07 ms, summing to the
-    // kernel's 0.83 ms - no overlap at all).
-    auto stage = [&]() {
-#ifndef Y2_NO_CVT
-      store(nn, xa, xb);                       // tile t + 2 (zeros past the end) into the buffer tile t - 1 left
-#endif
-      if (steady) {
-#ifndef Y2_NO_GLOAD
-        sa.load_full(tA + (t + 4) * stepA, xa);
-        sb.load_full(tB + (t + 4) * stepB, xb);
-#endif
-      } else {
-        load_any(t + 4, xa, xb);
-      }
-    };
-    Y2_STAMP(0);
-#ifdef Y2_PRIO
-    if (late) { __builtin_amdgcn_s_setprio(Y2_PRIO); stage(); __builtin_amdgcn_s_setprio(0); }
-#else
-    if (late) stage();
-#endif
-    __builtin_amdgcn_sched_barrier(0);
-    Y2_STAMP(1);
-#ifndef Y2_NO_LDSREAD
-    read_b(nxt, bhn, bln);                     // tile t + 1 (garbage past the end: never used)
-#endif
-#pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-      mma_row(mt);
-      __builtin_amdgcn_sched_barrier(0);
-#ifndef Y2_NO_LDSREAD
-      read_a(nxt, mt);                         // this row tile's fragment of tile t + 1 replaces the one just consumed
-#endif
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    Y2_STAMP(2);
-    if (!late) stage();
-    Y2_STAMP(3);
-    __syncthreads();
-    Y2_STAMP(4);
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt) { bh[nt] = bhn[nt]; bl[nt] = bln[nt]; }
-    const int f = cur; cur = nxt; nxt = nn; nn = f;
-  };
-  int t = 0;
-  for (; t + 5 < nfull; t += 2) {   // both tiles t + 4 and t + 5 complete
-    iteration(t, ra[0], rb[0], true);
-    iteration(t + 1, ra[1], rb[1], true);
-  }
-  for (; t < nkt; t += 2) {
-    iteration(t, ra[0], rb[0], false);
-    if (t + 1 < nkt) iteration(t + 1, ra[1], rb[1], false);
-  }
-  __syncthreads();
-  Y2_STAMP(5);
-#ifdef Y2_NO_EPI
-  {
-    float keep = 0.0f;   // keeps every accumulator alive
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-      for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) keep += acc[i][j][r];
-    if (keep == 123.456f) g.C[0] = 1.0f;
-  }
-  return;
-#endif
-  if (g.vecC) gemm_epilogue_wide<256, Y2NT, 4>(g, acc, reinterpret_cast<float*>(xsmem), 64, m0, n0, wm, wn, l31, half, batch, split, 256);
-  else {
-    // narrow path: the two 64-row halves of the patch through the register epilogue
-    const f32x16 (&lo2)[2][2] = *reinterpret_cast<const f32x16 (*)[2][2]>(&acc[0]);
-    const f32x16 (&hi2)[2][2] = *reinterpret_cast<const f32x16 (*)[2][2]>(&acc[2]);
-    gemm_epilogue_n<256>(g, lo2, m0, n0, wm * 2, wn, l31, half, batch, split);
-    gemm_epilogue_n<256>(g, hi2, m0, n0, wm * 2 + 1, wn, l31, half, batch, split);
-  }
-#ifdef Y2_STAMPS
-  __syncthreads();
-  if (blockIdx.x == 8 && blockIdx.y == 0 && blockIdx.z == 0 && lane == 0 && (wave == 0 || wave == 4)) {
-    Y2_STAMP(5);   // epilogue
-    for (int i = 0; i < 6; ++i) g.C[(wave ? 8 : 0) + i] = (float)st_acc[i];
-    g.C[(wave ? 8 : 0) + 6] = (float)nkt;
-  }
-#endif
-}
-
-
 template <int BM, int BN, int WM, int WN, bool VEC>
 void launch_gemm_v(const GemmArgs& a, int akc, int bkc, dim3 grid, hipStream_t st) {
   if (akc && bkc) hipLaunchKernelGGL((gemm_f32_kernel<BM, BN, WM, WN, true, true, VEC>), grid, dim3(256), 0, st, a);
@@ -1301,15 +696,6 @@ template <int BM, int BN, int WM, int WN>
 void launch_gemm(const GemmArgs& a, int akc, int bkc, dim3 grid, hipStream_t st) {
   if (a.vecA && a.vecB) launch_gemm_v<BM, BN, WM, WN, true>(a, akc, bkc, grid, st);
   else launch_gemm_v<BM, BN, WM, WN, false>(a, akc, bkc, grid, st);
-}
-
-int gemm_use_k32() {   // LFI_GEMM_K32=1: the 32-k variant of the 256 x 256 bf16x3 kernel (also precision bit 0x40)
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("LFI_GEMM_K32");
-    v = (e && e[0] == '1') ? 1 : 0;
-  }
-  return v;
 }
 
 int kchunk_for(int K, int splitk) {
@@ -1428,7 +814,7 @@ int launch_x3_128(const GemmArgs& a, int akc, int bkc, dim3 grid, size_t lds, hi
 // Rows of the partial column-sum matrix lfi_gemm_f32 fills when lfi_gemm_desc.colsum_part is set, or 0 when this product does
 // not take a path that can (it needs the bf16x3 kernels' wide epilogue, no K split, column-batched or unbatched C).
 extern "C" long lfi_gemm_colpart_rows(const lfi_gemm_desc* d) {
-  if (!d || d->M <= 0 || d->N <= 0 || !(d->precision & 1) || (d->precision & 0x40)) return 0;
+  if (!d || d->M <= 0 || d->N <= 0 || !(d->precision & 1) || d->a_bf16) return 0;
   if (d->splitk != 1 || (d->batch > 1 && !(d->strideC > 0 && d->strideC * d->batch <= d->ldc))) return 0;
   auto vec_ok = [](const float* p, long ld, long stride, int kcontig, int mn, int K) {
     if ((reinterpret_cast<uintptr_t>(p) & 15) || (ld & 3) || (stride & 3)) return 0;
@@ -1439,13 +825,8 @@ extern "C" long lfi_gemm_colpart_rows(const lfi_gemm_desc* d) {
   const bool c_ok = (reinterpret_cast<uintptr_t>(d->C) & 15) == 0 && d->ldc % 4 == 0 && d->strideC % 4 == 0;
   const bool g_ok = d->act != 2 || ((reinterpret_cast<uintptr_t>(d->G) & 15) == 0 && d->ldg % 4 == 0 && d->strideG % 4 == 0);
   if (!(c_ok && g_ok && !(d->act == 2 && d->accumulate != 0))) return 0;
-  const char* w = getenv("LFI_GEMM_WIDE");
-  if ((w && w[0] == '1') || gemm_use_k32()) return 0;
   GemmPlan plan = gemm_plan(d->M, d->N, d->K, d->batch, 1, true);
   if (d->precision & 0x30) plan.shape = (d->precision & 0x10) ? 3 : 0;
-  // (mirror of lfi_gemm_f32's kernel choice: the opt-in warp-specialised 128 x 128 kernel, LFI_GEMM_WS=1, has no column-sum epilogue)
-  const char* ws = getenv("LFI_GEMM_WS");
-  if (plan.shape != 3 && ws && ws[0] == '1') return 0;
   return plan.shape == 3 ? (long)lfi_cdiv(d->M, 256) * (256 / LFI_EPI_ROWS) : (long)lfi_cdiv(d->M, 128);
 }
 
@@ -1518,50 +899,7 @@ extern "C" int lfi_gemm_f32(const lfi_gemm_desc* d, void* stream) {
   // floats past K (k-contiguous; zeroed before it reaches LDS) or past M/N (mn-contiguous; those LDS columns only feed
   // output rows/columns that are never stored) — see vec_ok above.)
   dim3 grid(a.tiles_m * a.tiles_n, d->batch, splitk);
-  // opt-in (LFI_GEMM_WIDE=1): the 8-wave / 128 x 64-patch variant is numerically identical and, as measured, no faster
-  // than the 16-wave kernel (0.75 vs 0.74 ms on the cond_transform product) - see the notes above gemm_bf16x3_256w_kernel
-  int use_wide = 0;
-  {
-    const char* e = getenv("LFI_GEMM_WIDE");
-    use_wide = (e && e[0] == '1') ? 1 : 0;
-  }
-  if (use_x3 && shape == 3 && use_wide) {
-    const size_t lds = (size_t)Y2BUFS * 4 * YIMG * sizeof(__bf16);
-    static bool attrw = false;
-    if (!attrw) {
-      hipError_t e1 = hipFuncSetAttribute((const void*)gemm_bf16x3_256w_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      hipError_t e2 = hipFuncSetAttribute((const void*)gemm_bf16x3_256w_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      hipError_t e3 = hipFuncSetAttribute((const void*)gemm_bf16x3_256w_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      hipError_t e4 = hipFuncSetAttribute((const void*)gemm_bf16x3_256w_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess) {
-        lfi_set_error("lfi_gemm_f32: cannot reserve %zu bytes of LDS for the wide-wave 256 x 256 bf16x3 kernel", lds);
-        return LFI_ERR_LAUNCH;
-      }
-      attrw = true;
-    }
-    if (d->a_kcontig && d->b_kcontig) hipLaunchKernelGGL((gemm_bf16x3_256w_kernel<true, true>), grid, dim3(Y2NT), lds, st, a);
-    else if (d->a_kcontig) hipLaunchKernelGGL((gemm_bf16x3_256w_kernel<true, false>), grid, dim3(Y2NT), lds, st, a);
-    else if (d->b_kcontig) hipLaunchKernelGGL((gemm_bf16x3_256w_kernel<false, true>), grid, dim3(Y2NT), lds, st, a);
-    else hipLaunchKernelGGL((gemm_bf16x3_256w_kernel<false, false>), grid, dim3(Y2NT), lds, st, a);
-  } else if (use_x3 && shape == 3 && (gemm_use_k32() || (d->precision & 0x40))) {
-    const size_t lds = (size_t)2 * 4 * ZIMG * sizeof(__bf16);   // 160 KB; the epilogue's 133 KB fit inside
-    static bool attrk = false;
-    if (!attrk) {
-      hipError_t e1 = hipFuncSetAttribute((const void*)gemm_bf16x3_256k_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      hipError_t e2 = hipFuncSetAttribute((const void*)gemm_bf16x3_256k_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      hipError_t e3 = hipFuncSetAttribute((const void*)gemm_bf16x3_256k_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      hipError_t e4 = hipFuncSetAttribute((const void*)gemm_bf16x3_256k_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess) {
-        lfi_set_error("lfi_gemm_f32: cannot reserve %zu bytes of LDS for the 32-k 256 x 256 bf16x3 kernel", lds);
-        return LFI_ERR_LAUNCH;
-      }
-      attrk = true;
-    }
-    if (d->a_kcontig && d->b_kcontig) hipLaunchKernelGGL((gemm_bf16x3_256k_kernel<true, true>), grid, dim3(1024), lds, st, a);
-    else if (d->a_kcontig) hipLaunchKernelGGL((gemm_bf16x3_256k_kernel<true, false>), grid, dim3(1024), lds, st, a);
-    else if (d->b_kcontig) hipLaunchKernelGGL((gemm_bf16x3_256k_kernel<false, true>), grid, dim3(1024), lds, st, a);
-    else hipLaunchKernelGGL((gemm_bf16x3_256k_kernel<false, false>), grid, dim3(1024), lds, st, a);
-  } else if (d->a_bf16) {
+  if (d->a_bf16) {
     const size_t lds_loop = (size_t)2 * 4 * YIMG * sizeof(__bf16), lds_epi = (size_t)LFI_EPI_ROWS * 260 * sizeof(float);
     const size_t lds = lds_loop > lds_epi ? lds_loop : lds_epi;
     static bool attra = false;
@@ -1583,24 +921,7 @@ extern "C" int lfi_gemm_f32(const lfi_gemm_desc* d, void* stream) {
     if (rcl) return rcl;
   } else if (use_x3) {
     const size_t lds = (size_t)2 * 4 * XIMG * sizeof(__bf16);
-    static int use_ws = -1;
-    if (use_ws < 0) {
-      const char* e = getenv("LFI_GEMM_WS");
-      use_ws = (e && e[0] == '1') ? 1 : 0;  // measured: 0.86 / 1.05 / 1.00 ms vs 0.93 / 0.99 / 0.90 ms on the three cond_transform
-                                           // products - no gain, so the split is not what idles the matrix pipe; opt-in only
-      hipError_t w1 = hipFuncSetAttribute((const void*)gemm_bf16x3_ws_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      hipError_t w2 = hipFuncSetAttribute((const void*)gemm_bf16x3_ws_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      hipError_t w3 = hipFuncSetAttribute((const void*)gemm_bf16x3_ws_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      hipError_t w4 = hipFuncSetAttribute((const void*)gemm_bf16x3_ws_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-      if (w1 != hipSuccess || w2 != hipSuccess || w3 != hipSuccess || w4 != hipSuccess) use_ws = 0;
-    }
-    if (use_ws) {
-      LFI_REQUIRE(!a.colpart, "lfi_gemm_f32: colsum_part is set but the LFI_GEMM_WS kernel cannot fill it (lfi_gemm_colpart_rows returns 0 there)");
-      if (d->a_kcontig && d->b_kcontig) hipLaunchKernelGGL((gemm_bf16x3_ws_kernel<true, true>), grid, dim3(512), lds, st, a);
-      else if (d->a_kcontig) hipLaunchKernelGGL((gemm_bf16x3_ws_kernel<true, false>), grid, dim3(512), lds, st, a);
-      else if (d->b_kcontig) hipLaunchKernelGGL((gemm_bf16x3_ws_kernel<false, true>), grid, dim3(512), lds, st, a);
-      else hipLaunchKernelGGL((gemm_bf16x3_ws_kernel<false, false>), grid, dim3(512), lds, st, a);
-    } else {
+    {
       const int rcl = a.skip ? launch_x3_128<2>(a, d->a_kcontig, d->b_kcontig, grid, lds, st)
                              : (a.colpart ? launch_x3_128<1>(a, d->a_kcontig, d->b_kcontig, grid, lds, st)
                                           : launch_x3_128<0>(a, d->a_kcontig, d->b_kcontig, grid, lds, st));

@@ -382,45 +382,6 @@ def test_generic_and_register_resident_cells_agree(gpu_device, monkeypatch):
     assert max_rel(outs[1][0], fxm.get("train/nll"), floor=1.0) < 1e-4
 
 
-@pytest.mark.parametrize("B,T", [(7, 41), (24, 40), (64, 48)])
-def test_weight_stationary_encoder_matches_the_streaming_one(gpu_device, monkeypatch, B, T):
-    """LFI_ENC_WS=1 (opt-in): the hid-256 window encoders run as clusters of four workgroups with W_hh resident in registers
-    and the state exchanged through global memory (enc_gru_fwd_ws_kernel); otherwise every workgroup streams the weights
-    (enc_gru_fwd_wide_kernel, the default). Same stashes, same features, same gradients. (7, 41): one cluster, ragged last
-    chunk; (24, 40): three clusters dealt in ticket order; (64, 48): eight clusters, members eight tickets apart."""
-    hp = final_model_hparams(50, 27, K=2)
-    batch = oracle.synthetic_batch(B, T, 50, 27, seed=B)
-    N = T - 24
-    g = torch.Generator().manual_seed(5)
-    masks = {}
-    for name in ("p2_face", "p1_speech", "p2_speech"):
-        cfg = hp["Conditioning"][name]
-        keep = 1.0 - cfg["dropout"]
-        masks[name] = (torch.rand(N, B, cfg["history"], generator=g) < keep).float() / keep
-    outs = []
-    for ws in ("0", "1"):
-        monkeypatch.setenv("LFI_ENC_WS", ws)
-        m, _ = perturbed_model(hp, gpu_device)
-        m.precision = "bf16x3"
-        m.train()
-        m.injected_masks = masks
-        _, loss, losses = m(to_dev(batch, gpu_device))
-        loss.sum().backward()
-        eng = m.engine
-        stash = {k: eng._ws[k][:n].clone() for k, n in (("enc_gates.p2_face", 24 * N * B * 1024), ("enc_hseq.p2_face", 24 * N * B * 256),
-                                                        ("enc_gates.p2_speech", 16 * N * B * 1024), ("enc_hseq.p2_speech", 16 * N * B * 256))}
-        outs.append((torch.stack(losses), {n: p.grad.clone() for n, p in m.named_parameters()}, stash))
-    for k in outs[0][2]:
-        a, b = outs[0][2][k], outs[1][2][k]
-        assert torch.isfinite(b).all(), k
-        assert float((a - b).abs().max()) < 2e-5, (k, float((a - b).abs().max()))
-    assert max_rel(outs[0][0], outs[1][0], floor=1.0) < 2e-6
-    for n in outs[0][1]:
-        assert rel_err(outs[0][1][n], outs[1][1][n]) < 5e-5, n
-    report("weight-stationary vs streaming encoders (B=%d, T=%d): stashes within %.1e, NLL within %.1e" % (
-        B, T, max(float((outs[0][2][k] - outs[1][2][k]).abs().max()) for k in outs[0][2]), max_rel(outs[0][0], outs[1][0], floor=1.0)))
-
-
 def test_wide_hidden_sizes_take_the_generic_paths(gpu_device):
     """hidden_channels 160 (> 128: streaming flow cells) and a 320-wide GRU window encoder (> 256: unfused recurrence), both
     in the reference's hparam search space (large_hparam_search.py:33,57): NLL and gradients against the fp64 oracle."""
