@@ -338,16 +338,17 @@ def bench_train(args, model, trainer, spec, device, world, rank, hp):
         "roofline_hbm": _roofline_hbm(spec, B, T, timing, args.precision),
         "kernel_timing": {t: {"launches": n, "ms": round(m_, 4)} for t, (n, m_) in timing.items()},
     }
-    if world == 1 and args.precision == "bf16x3" and eng.backward_product_count(F) == 2:
+    if world == 1 and args.precision == "bf16x3" and eng.backward_product_count(F) == 2 and args.three_products_steps > 0:
         # the same step with three products in the backward GEMMs too (round 2's arithmetic), timed in the same process
         keep = eng.backward_products
         eng.backward_products = 3
         for i in range(3):
             step(i)
-        el3, _ = _timed(step, args.steps, 1, device)
+        n3 = args.three_products_steps
+        el3, _ = _timed(step, n3, 1, device)
         eng.backward_products = keep
-        out["three_products_everywhere"] = {"ms_per_step": 1e3 * el3 / args.steps, "value": frames / el3, "unit": "frames/s",
-                                            "note": "engine_backward_products=3; same process, same batches, %d steps" % args.steps}
+        out["three_products_everywhere"] = {"ms_per_step": 1e3 * el3 / n3, "value": world * B * N * n3 / el3, "unit": "frames/s",
+                                            "note": "engine_backward_products=3; same process, same batches, %d steps" % n3}
     if world == 1 and not deep and B == 256 and args.strong_anchor_batch > 0:
         # north_star asks for STRONG scaling at 8 GPUs (configs[2]: global batch 2048 = 8 x 256). The driver's N-GPU runs keep
         # 256 per GPU ("scaling": "weak"); this is the missing denominator: ONE GPU stepping the global batch of the 8-GPU run,
@@ -488,6 +489,9 @@ def main():
                     help="train: BASELINE.json configs[1] (the headline metric); sample: configs[3], autoregressive "
                          "inference at --batch 1024 --seq-len 300 unless given; deep: configs[4], the training step of a "
                          "K=32 x L=3 flow at --batch 128 --seq-len 512 unless given")
+    ap.add_argument("--three-products-steps", type=int, default=20,
+                    help="N = 1: also time this many steps with three bf16 products in the backward GEMMs too (reported as "
+                         "three_products_everywhere); 0 disables it")
     ap.add_argument("--graph-steps", type=int, default=20,
                     help="N = 1: also time this many steps replayed as a captured hipGraph (reported as hipgraph_replay); 0 disables it")
     ap.add_argument("--strong-anchor-batch", type=int, default=2048,

@@ -973,7 +973,7 @@ class GlowEngine:
             xa, ldi = x, e.in_dim
         # the input side (window scatter: one HBM pass over dgi / dgh, then the thin dW_ih product) on the second stream, next
         # to the MFMA-bound dW_hh product of the hidden side - and to the next modality's backward recurrence
-        side = self._fork()
+        side = self._fork() if os.environ.get("LFI_ENC_BWD_OVERLAP", "1") != "0" else None
         with self._on(side):
             check(self.L.lfi_encode_windows_scatter(C.byref(d), dgi.data_ptr(), dgh.data_ptr(), ptr(mk), dxp.data_ptr(),
                                                     _stream()), "lfi_encode_windows_scatter")

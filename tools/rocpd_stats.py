@@ -19,10 +19,23 @@ def from_csv(path):
     return [(r["Name"], int(r["Calls"]), float(r["TotalDurationNs"])) for r in csv.DictReader(open(path))]
 
 
+def demangle(names):
+    """Itanium-mangled kernel symbols (rocpd keeps them raw) -> readable names, through c++filt when it is there."""
+    import shutil
+    import subprocess
+    if not shutil.which("c++filt"):
+        return names
+    raw = [n[:-3] if n.endswith(".kd") else n for n in names]
+    out = subprocess.run(["c++filt"], input="\n".join(raw), capture_output=True, text=True).stdout.split("\n")
+    return [o if o else n for o, n in zip(out, raw)]
+
+
 def main():
     path = sys.argv[1]
     top = int(sys.argv[2]) if len(sys.argv) > 2 else 30
     rows = from_db(path) if path.endswith(".db") else from_csv(path)
+    names = demangle([r[0] for r in rows])
+    rows = [(n, r[1], r[2]) for n, r in zip(names, rows)]
     tot = sum(r[2] for r in rows)
     print("| kernel | calls | total ms | avg us | % |\n|---|---|---|---|---|")
     for n, c, t in rows[:top]:
