@@ -77,22 +77,22 @@ int lfi_gemm_f32(const lfi_gemm_desc* d, void* stream);
 /* ---- bf16x3 GEMM on PRE-SPLIT operands. lfi_gemm_f32's bf16x3 kernels split every fp32 operand element into bf16 hi + lo
  * inside every workgroup that touches it; for the big products of the step (cond_transform of all flow steps and its
  * autograd, glow/models.py:187-190; the hoisted W_ih[:, Ch:] c product of the coupling cell and its autograd, :176-179,
- * 206-208) the split is done ONCE instead - by lfi_planes_from_f32 / lfi_planes_t_from_f32 for operands that exist as fp32, by
- * the producing kernel's epilogue for operands that are themselves results - into "planes": per 32-wide tile of the operand's
- * free ("mn") index and 16-deep k-tile two 1-KB blocks (hi, lo), block ((mn tile * nkt + k tile) * 2 + plane) * 512 bf16,
- * 16-byte aligned, which the kernel moves global -> LDS by LDS-DMA. Two block formats (lets_face_it_amd/csrc/lfi_pgemm.hip):
- *   format 0, row planes: the fp32 matrix is (mn x k), k contiguous (an nn.Linear input or weight in its forward product).
- *     lfi_planes_elems(rows, cols) bf16 elements; rows zero padded to whole 256-row panels, k to whole k-tiles.
- *   format 1, k-major planes: the fp32 matrix is (k x mn), mn contiguous (the same matrices in the autograd products that sum
- *     over frames or over output units). lfi_planes_t_elems(krows, mncols) elements; mn padded to 256, k to 16.
- * C[b] (+)= act(A[b] B[b]^T + bias[b]) with A: M x K, B: N x K in either format. Same products and accumulation order as
- * lfi_gemm_f32's bf16x3 kernels (results bit-identical). A workgroup reads whole 128- / 256-wide mn panels from a batch
- * entry's first tile: when batch entries start inside one buffer, keep that buffer one panel (256 mn) longer than
- * lfi_planes_*_elems says (what is read there only feeds rows / columns past M / N, which are never stored). */
+ * 206-208) the split is done ONCE instead - by lfi_planes_from_f32 for operands that exist as fp32, by the producing kernel's
+ * epilogue (or the backward walk) for operands that are themselves results - into "planes" of the fp32 matrix X (rows x cols):
+ * per 32-row tile rt and 16-column tile ct two 1-KB blocks (hi, lo), block ((rt * nct + ct) * 2 + plane) * 512 bf16, 16-byte
+ * aligned, rows zero padded to whole 256-row panels and columns to whole tiles (lfi_planes_elems(rows, cols) bf16 elements),
+ * which the kernel moves global -> LDS by LDS-DMA (block layout and both reads: lets_face_it_amd/csrc/lfi_pgemm.hip).
+ * An operand takes the planes of X in one of two uses:
+ *   use 0, row use: the operand is X (mn x k), k = X's columns: an nn.Linear input or weight in its forward product;
+ *   use 1, transposed use: the operand is X^T, k = X's ROWS: the same matrices in the autograd products that sum over frames or
+ *     over output units. The operand pointer must then address a whole 32-row tile (and a column tile that is a multiple of 2).
+ * C[b] (+)= act(A[b] B[b]^T + bias[b]) with A: M x K, B: N x K. a_nkt / b_nkt = column tiles per row tile (nct) of the plane
+ * buffers. Same products and accumulation order as lfi_gemm_f32's bf16x3 kernels (results bit-identical). A workgroup reads
+ * whole 128- / 256-wide mn panels from a batch entry's first tile: when batch entries start inside one buffer, keep that
+ * buffer one panel (256 rows) longer than lfi_planes_elems says (what is read there only feeds rows / columns past M / N,
+ * which are never stored). */
 long lfi_planes_elems(long rows, int cols);
 int lfi_planes_from_f32(const float* X, long ldx, long rows, int cols, void* planes, void* stream);
-long lfi_planes_t_elems(long krows, long mncols);
-int lfi_planes_t_from_f32(const float* X, long ldx, long krows, long mncols, void* planes, void* stream);
 typedef struct {
   int M, N, K;
   const void* Ap; int a_nkt; long a_stride;   /* planes of A; k-tiles per mn tile in that buffer; bf16 elements between batch
@@ -103,18 +103,16 @@ typedef struct {
   int batch; long strideC, strideBias, strideG;
   int accumulate, act; float slope;
   int skip;                                      /* bit 0 drops a_lo * b_hi, bit 1 a_hi * b_lo (as lfi_gemm_desc.precision bits 8 / 9) */
-  int a_fmt, b_fmt;                              /* plane format of either operand: 0 row planes, 1 k-major planes */
+  int a_fmt, b_fmt;                              /* use of either operand's planes: 0 row use, 1 transposed use */
   int splitk; float* work;                       /* K split over grid.z with a deterministic reduce, as lfi_gemm_desc (0 / 1: none);
                                                     work: lfi_gemm_planes_work_floats floats */
   int store_f32;                                 /* 1: the result goes to C as fp32 rows; 0: plane outputs only (C may be NULL) */
-  /* The result as operand planes of the products that consume it (splitk <= 1; batch entries side by side in C's columns).
-   * Cr: row planes, rows = C rows, k = cr_col0 + b * strideC + column (cr_nkt k-tiles per row tile in that buffer).
-   * Ct: k-major planes, mn = ct_col0 + b * strideC + column, k = ct_row0 + row (ct_nkt k-tiles per mn tile).
-   * Rows >= M and columns >= N are written as zeros. NULL: off. */
+  /* The result as operand planes of the products that consume it, in either use (splitk <= 1; batch entries side by side in C's
+   * columns): planes of the matrix whose rows are C's rows and whose columns are cr_col0 + b * strideC + C's columns (cr_nkt column
+   * tiles per row tile in that buffer). Rows >= M and columns >= N are written as zeros. NULL: off. */
   void* Cr; int cr_nkt; long cr_col0;
-  void* Ct; long ct_nkt; long ct_row0, ct_col0;
-  /* act == 2 (multiply by leaky_relu'(G)): G may be given as the row planes another lfi_gemm_planes call emitted (only the sign
-   * of the hi plane is used), same indexing as Cr. NULL: the fp32 G above. */
+  /* act == 2 (multiply by leaky_relu'(G)): G may be given as the planes another lfi_gemm_planes call emitted (only the sign of
+   * the hi plane is used), same indexing as Cr. NULL: the fp32 G above. */
   const void* Gr; int gr_nkt; long gr_col0;
   float* colsum_part; long ld_part;              /* as lfi_gemm_desc: lfi_gemm_planes_colpart_rows(d) rows of per-pass column sums */
   int out_hi_only;                               /* plane outputs: write the hi planes only - enough for a consumer that takes them
@@ -262,14 +260,14 @@ int lfi_flow_seq_bwd(const lfi_flow_dims* d, const lfi_flow_params* p, const flo
                      const float* stash, float gscale, float* bstash, void* stream);
 
 /* The same walk, also leaving dgi - the gradient of the hoisted W_ih[:, Ch:] c + b_ih product, (Ks F x G), flow step k in rows
- * [k F, (k + 1) F) - as the operand planes of the two products that consume it (lfi_gemm_planes): row planes
- * (lfi_planes_elems(Ks F, G) bf16: d pre-activation of cond_transform = dgi W_c sums over gate columns) and k-major planes
- * (lfi_planes_t_elems(Ks F, G): dW_c = dgi^T c sums over frames), written by the walk from its bf16 hi / lo LDS images instead
- * of by a conversion pass over the fp32 dgi (which is still written: the thin dW_ih[:, :Ch] product reads it).
- * lfi_flow_bwd_emits_planes(d) = 1 when the dims allow it (bf16x3 persistent walk, H and B multiples of 32). */
+ * [k F, (k + 1) F) - as operand planes (lfi_planes_elems(Ks F, G) bf16) for the two products that consume it (lfi_gemm_planes):
+ * d pre-activation of cond_transform = dgi W_c sums over gate columns (row use), dW_c = dgi^T c sums over frames (transposed
+ * use). Written by the walk from its bf16 hi / lo LDS images instead of by a conversion pass over the fp32 dgi (which is still
+ * written: the thin dW_ih[:, :Ch] product reads it). lfi_flow_bwd_emits_planes(d) = 1 when the dims allow it (bf16x3 persistent
+ * walk, H and B multiples of 32). */
 int lfi_flow_bwd_emits_planes(const lfi_flow_dims* d);
 int lfi_flow_seq_bwd_planes(const lfi_flow_dims* d, const lfi_flow_params* p, const float* prep,
-                            const float* stash, float gscale, float* bstash, void* dgi_rows, void* dgi_kmajor,
+                            const float* stash, float gscale, float* bstash, void* dgi_planes,
                             int hi_only /* 1: the hi planes only (lfi_pgemm_desc.out_hi_only) */, void* stream);
 
 typedef struct {

@@ -44,7 +44,6 @@ class PGemmDesc(C.Structure):
         ("splitk", C.c_int), ("work", C.c_void_p),
         ("store_f32", C.c_int),
         ("Cr", C.c_void_p), ("cr_nkt", C.c_int), ("cr_col0", C.c_long),
-        ("Ct", C.c_void_p), ("ct_nkt", C.c_long), ("ct_row0", C.c_long), ("ct_col0", C.c_long),
         ("Gr", C.c_void_p), ("gr_nkt", C.c_int), ("gr_col0", C.c_long),
         ("colsum_part", C.c_void_p), ("ld_part", C.c_long),
         ("out_hi_only", C.c_int), ("tile", C.c_int),
@@ -110,10 +109,8 @@ def lib():
         "lfi_planes_from_f32": (i, [vp, l, l, i, vp, vp]),
         "lfi_gemm_planes": (i, [P(PGemmDesc), vp]),
         "lfi_flow_bwd_emits_planes": (i, [P(FlowDims)]),
-        "lfi_flow_seq_bwd_planes": (i, [P(FlowDims), P(FlowParams), vp, vp, f, vp, vp, vp, i, vp]),
+        "lfi_flow_seq_bwd_planes": (i, [P(FlowDims), P(FlowParams), vp, vp, f, vp, vp, i, vp]),
         "lfi_encode_windows_grad_stash_bf16": (i, [P(EncDesc)]),
-        "lfi_planes_t_elems": (l, [l, l]),
-        "lfi_planes_t_from_f32": (i, [vp, l, l, l, vp, vp]),
         "lfi_gemm_planes_work_floats": (l, [P(PGemmDesc)]),
         "lfi_gemm_planes_colpart_rows": (l, [P(PGemmDesc)]),
         "lfi_colsum_work_floats": (l, [i, i, i]),
@@ -171,7 +168,7 @@ def lib():
 
 EXPORTS = [
     "lfi_last_error", "lfi_version", "lfi_gemm_work_floats", "lfi_gemm_f32", "lfi_gemm_colpart_rows", "lfi_planes_elems", "lfi_planes_from_f32",
-    "lfi_gemm_planes", "lfi_planes_t_elems", "lfi_planes_t_from_f32", "lfi_gemm_planes_work_floats", "lfi_gemm_planes_colpart_rows",
+    "lfi_gemm_planes", "lfi_gemm_planes_work_floats", "lfi_gemm_planes_colpart_rows",
     "lfi_flow_bwd_emits_planes", "lfi_flow_seq_bwd_planes", "lfi_encode_windows_grad_stash_bf16", "lfi_colsum_work_floats",
     "lfi_colsum_f32", "lfi_cols_fold", "lfi_encode_windows_work_floats", "lfi_encode_windows_fwd", "lfi_encode_windows_bwd",
     "lfi_encode_windows_bias_rows", "lfi_encode_windows_bias_grads",

@@ -32,15 +32,12 @@ extern unsigned long long* g_lfi_stamps;  // diagnostics only (lfi_debug_set_sta
 static inline int lfi_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 // ---- device side -----------------------------------------------------------
-// K-major operand planes (lfi_planes_t_from_f32, lfi_pgemm.hip): byte offset inside a 1-KB block (32 mn x 16 k, bf16) of the
-// 16-byte chunk c4 (mn columns 8 c4 .. + 7) of k row r. Four 256-byte sub-tiles [8 k][16 mn], sub-tile (r >> 3, mn >> 4); the
-// sub-tiles of the upper mn half keep their k rows 0-3 <-> 4-7 swapped, which makes the two 16-lane groups of a
-// ds_read_b64_tr_b16 half-wave hit opposite halves of the 256-byte LDS bank row.
-__device__ __forceinline__ int lfi_t_plane_offset(int r, int c4) {
-  const int mh = c4 >> 1;
-  return ((r >> 3) * 2 + mh) * 256 + ((r & 7) ^ (mh << 2)) * 32 + (c4 & 1) * 16;
-}
-
+// Operand planes (lfi_planes_from_f32, lfi_pgemm.hip): byte offset inside a 1-KB block (32 rows x 16 columns, bf16, row-major
+// 32-byte rows) of the 16-byte chunk ch (columns 8 ch .. + 7) of row r. The two chunks of a row trade places in rows 8-15 and
+// 24-31: the four 16-lane groups of a ds_read_b128 over (row l & 31, chunk l >> 5) then cover all 64 LDS banks, and the rows stay
+// 32 contiguous bytes, which is what the transposing read (ds_read_b64_tr_b16: 4 rows x 16 columns per 16 lanes) wants when the
+// same block is used with its ROWS as the contraction index.
+__device__ __forceinline__ int lfi_u_plane_offset(int r, int ch) { return r * 32 + ((ch ^ ((r >> 3) & 1)) << 4); }
 // MFMA lane maps (guide §3, checked on the device by lfi_selftest_mfma):
 //   16x16x4 f32 : A(i = l&15, k = l>>4)  B(k = l>>4, j = l&15)  D reg r -> (row (l>>4)*4 + r, col l&15)
 //   32x32x2 f32 : A(i = l&31, k = l>>5)  B(k = l>>5, j = l&31)  D reg r -> (row (r&3) + 8*(r>>2) + 4*(l>>5), col l&31)

@@ -46,7 +46,7 @@ struct FlowK {
   const uint4 *xbwh, *xbwz;
   int bwd_prefetch;        // backward walk: the next cell's forward-stash operands by LDS-DMA into a second LDS region (pf_*)
   int dgi_hi_only;         // the dgi planes' hi halves only (their consumers take them as a rounded A operand: two products)
-  __bf16 *bDgiR, *bDgiT;   // backward walk (bf16x3): dgi also as row planes / k-major planes of the (Ks F x G) matrix (lfi_flow_seq_bwd_planes)
+  __bf16* bDgiR;           // backward walk (bf16x3): dgi also as operand planes of the (Ks F x G) matrix (lfi_flow_seq_bwd_planes)
   int C16, Ch16, H16, Co16, NG;
   // forward stash
   float *sA, *sY, *sX, *sH, *sG, *sO, *sL, *sC;   // sC: LSTM cell state (lstm only)
@@ -2373,30 +2373,20 @@ __global__ __launch_bounds__(NT) void flow_pipe_bwd_kernel(FlowK f) {
   unsigned pk = 0u;
   if (peek && tid == 0) pk = ld_agent(prog + (k + 1) * nbt + bt);
   if constexpr (X3) {
-    // dgi of this cell as operand planes of the products that consume it (dpre = dgi W_c sums over gate columns: row planes;
-    // dW_c = dgi^T c sums over frames: k-major planes; include/lfi.h), straight from the bf16 hi / lo LDS images Q1 left: one
+    // dgi of this cell as operand planes (include/lfi.h) for the two products that consume it - dpre = dgi W_c sums over gate
+    // columns, dW_c = dgi^T c over frames: one set of planes serves both - straight from the bf16 hi / lo LDS images Q1 left: one
     // 16-byte LDS read and one 16-byte store per 8 values and plane, by the waves that own no channel tile and idle through Q3
     if (f.bDgiR && !tc) {
       const int ntc = (C + 15) >> 4;                 // channel-tile waves are waves 0 .. ntc - 1
       const int ne = NT - ntc * 64, et = tid - ntc * 64;
       const long gr0 = kf + b0;                      // row of the (Ks F x G) matrix: flow step k, frame n B + b0 (+ i)
       const int nktG = G >> 4;
-      const long nktKF = ((long)f.Ks * f.F) >> 4;
-      char* rbase = reinterpret_cast<char*>(f.bDgiR) + ((gr0 >> 5) * nktG * 2) * 1024 + (gr0 & 16) * 16;
-      char* tbase = reinterpret_cast<char*>(f.bDgiT) + ((gr0 >> 4) * 2) * 1024;
-      for (int u = et; u < 4 * G; u += ne) {
-        const bool isT = u >= 2 * G;
-        const int v = isT ? u - 2 * G : u;
-        const int i = v & 15, q = v >> 4;
-        int so;
-        char* dst;
-        if (!isT) {          // q = 2 kt + h: lane (row, h) of row-plane block (row tile, kt)
-          so = i * ldx + (q >> 1) * 16 + (q & 1) * 8;
-          dst = rbase + (long)(q >> 1) * 2048 + (i + 32 * (q & 1)) * 16;
-        } else {             // q = 4 mt + c4: chunk c4 of k row i of k-major block (mt, k-tile of these 16 frames)
-          so = i * ldx + (q >> 2) * 32 + (q & 3) * 8;
-          dst = tbase + (long)(q >> 2) * nktKF * 2048 + lfi_t_plane_offset(i, q & 3);
-        }
+      char* rbase = reinterpret_cast<char*>(f.bDgiR) + ((gr0 >> 5) * nktG * 2) * 1024;
+      const int r0 = (int)(gr0 & 16);                // this tile's 16 rows inside the 32-row plane tile
+      for (int u = et; u < 2 * G; u += ne) {         // u = 16 (2 ct + h) + i: chunk h of row r0 + i of block (row tile, ct)
+        const int i = u & 15, q = u >> 4;
+        const int so = i * ldx + (q >> 1) * 16 + (q & 1) * 8;
+        char* dst = rbase + (long)(q >> 1) * 2048 + lfi_u_plane_offset(r0 + i, q & 1);
         *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(GiH + so);
         if (!f.dgi_hi_only) *reinterpret_cast<uint4*>(dst + 1024) = *reinterpret_cast<const uint4*>(GiL + so);
       }
@@ -3142,24 +3132,21 @@ extern "C" int lfi_flow_bwd_emits_planes(const lfi_flow_dims* d) { return flow_b
 
 extern "C" int lfi_flow_seq_bwd(const lfi_flow_dims* d, const lfi_flow_params* p, const float* prep, const float* stash,
                                 float gscale, float* bstash, void* stream) {
-  return lfi_flow_seq_bwd_planes(d, p, prep, stash, gscale, bstash, nullptr, nullptr, 0, stream);
+  return lfi_flow_seq_bwd_planes(d, p, prep, stash, gscale, bstash, nullptr, 0, stream);
 }
 
 extern "C" int lfi_flow_seq_bwd_planes(const lfi_flow_dims* d, const lfi_flow_params* p, const float* prep, const float* stash,
-                                       float gscale, float* bstash, void* dgi_rows, void* dgi_kmajor, int hi_only, void* stream) {
+                                       float gscale, float* bstash, void* dgi_rows, int hi_only, void* stream) {
   FlowK f = {};
   int rc = fill_flow(d, p, prep, &f, "lfi_flow_seq_bwd");
   if (rc) return rc;
   LFI_REQUIRE(prep && stash && bstash, "lfi_flow_seq_bwd: null pointer");
-  LFI_REQUIRE((dgi_rows == nullptr) == (dgi_kmajor == nullptr), "lfi_flow_seq_bwd_planes: give both plane buffers or neither");
   LFI_REQUIRE(!dgi_rows || flow_bwd_planes_ok(d), "lfi_flow_seq_bwd_planes: these dims / switches cannot emit planes "
               "(lfi_flow_bwd_emits_planes returns 0)");
-  LFI_REQUIRE(((reinterpret_cast<uintptr_t>(dgi_rows) | reinterpret_cast<uintptr_t>(dgi_kmajor)) & 15) == 0,
-              "lfi_flow_seq_bwd_planes: planes must be 16-byte aligned");
+  LFI_REQUIRE((reinterpret_cast<uintptr_t>(dgi_rows) & 15) == 0, "lfi_flow_seq_bwd_planes: planes must be 16-byte aligned");
   bind_stash(&f, (float*)stash);
   bind_bstash(&f, bstash);
   f.bDgiR = reinterpret_cast<__bf16*>(dgi_rows);
-  f.bDgiT = reinterpret_cast<__bf16*>(dgi_kmajor);
   f.dgi_hi_only = hi_only ? 1 : 0;
   f.gscale = gscale;
   hipStream_t st = (hipStream_t)stream;

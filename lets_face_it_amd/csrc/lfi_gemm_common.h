@@ -49,8 +49,7 @@ struct GemmArgs {
   // lfi_pgemm.hip only (everything below is zero elsewhere): the result tile also / instead leaves the kernel as bf16 hi / lo
   // planes for the products that consume it, and the act == 2 operand may arrive as planes (only its sign is used)
   int storeC;                               // 1: fp32 rows to C as everywhere else; 0: plane outputs only
-  __bf16* Cr; int nktCr; long colCr;        // row planes of the result: rows = C rows, k = colCr + batch * strideC + C column
-  __bf16* Ct; long nktCt; long rowCt, colCt;  // k-major planes: mn = colCt + batch * strideC + C column, k = rowCt + C row
+  __bf16* Cr; int nktCr; long colCr;        // planes of the result: rows = C rows, columns = colCr + batch * strideC + C column
   const __bf16* Gr; int nktGr; long colGr;  // act == 2: row planes of G (hi plane read) instead of g.G
   int hiOnly;                               // plane outputs: the hi planes only (their consumer takes them as a rounded A operand)
 };
@@ -134,65 +133,43 @@ __device__ __forceinline__ void gemm_epilogue_n(const GemmArgs& g, const f32x16 
 // elements in place, result tile out with 16-byte row-wise stores (512 contiguous bytes per 32 lanes).
 // `rows` rows of the block tile per pass (the LDS image is rows x (BN + 4) floats); waves whose 64-row patch is in the pass
 // take part in the register phase, all 256 threads in the row-wise phases.
-// ---- plane outputs of the wide epilogue (lfi_pgemm.hip). The result tile lies in LDS as fp32 ([rows][BN + 4]); a lane reads 8
+// ---- plane output of the wide epilogue (lfi_pgemm.hip). The result tile lies in LDS as fp32 ([rows][BN + 4]); a lane reads 8
 // consecutive floats of one row (two conflict-free ds_read_b128), splits them into bf16 hi + lo and stores 16 + 16 bytes so
-// that every wave-instruction writes one whole 1-KB block of the destination planes.
-//   row planes (consumer sums over the tile's COLUMNS): block (32-row tile, 16-column k-tile), lane l = row l & 31, columns
-//     8 (l >> 5) .. + 7 - the layout of lfi_planes_from_f32;
-//   k-major planes (consumer sums over the tile's ROWS): block (32-column mn tile, 16-row k-tile) in the layout of
-//     lfi_planes_t_from_f32 (pgemm_t_offset); lane l takes 16-byte chunk c = l >> 4 of k row ((l & 15) - 2 c) & 15, which
-//     spreads each ds_read_b128 lane group over all 64 banks (row pitch 260 floats: bank = 4 row + 8 c).
-// Rows >= M and columns >= N are written as zeros: as a k index they would otherwise enter the consumer's sums.
+// that every wave-instruction writes one whole 1-KB block of the destination planes: block (32-row tile, 16-column tile), lane l
+// = row l & 31, chunk l >> 5 at lfi_u_plane_offset - the layout of lfi_planes_from_f32, which a consumer reads either way
+// (columns or rows as its contraction index). Rows >= M and columns >= N are written as zeros: as a contraction index they
+// would otherwise enter the consumer's sums.
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ u32x4 pg_u4(const uint4& v) { return (u32x4){v.x, v.y, v.z, v.w}; }
-__device__ __forceinline__ int pgemm_t_offset(int r, int c4) { return lfi_t_plane_offset(r, c4); }
 template <int BN, int NTH>
 __device__ __forceinline__ void gemm_emit_planes(const GemmArgs& g, const float* lds, int rows_per_pass, int row0, int n0, int batch) {
   constexpr int WLD = BN + 4;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   constexpr int NW = NTH / 64;
   const long gcol0 = (long)batch * g.strideC + n0;
-  auto fetch = [&](int r, int c, uint4* h, uint4* l) {
-    f32x4 a = *reinterpret_cast<const f32x4*>(lds + r * WLD + c), b = *reinterpret_cast<const f32x4*>(lds + r * WLD + c + 4);
+  if (!g.Cr) return;
+  constexpr int KT = BN / 16;
+  const int nb = (rows_per_pass / 32) * KT;
+  const int uoff = lfi_u_plane_offset(lane & 31, lane >> 5);
+  for (int b = wave; b < nb; b += NW) {
+    const int rtl = b / KT, ktl = b - rtl * KT;
+    if (row0 + rtl * 32 >= g.M || n0 + ktl * 16 >= g.N) continue;
+    const int r = rtl * 32 + (lane & 31), c = ktl * 16 + (lane >> 5) * 8;
+    const f32x4 a = *reinterpret_cast<const f32x4*>(lds + r * WLD + c), bq = *reinterpret_cast<const f32x4*>(lds + r * WLD + c + 4);
     const bool rok = row0 + r < g.M;
-    float v[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    float v[8] = {a[0], a[1], a[2], a[3], bq[0], bq[1], bq[2], bq[3]};
 #pragma unroll
     for (int e = 0; e < 8; ++e) v[e] = (rok && n0 + c + e < g.N) ? v[e] : 0.0f;
-    split2(v[0], v[1], &h->x, &l->x); split2(v[2], v[3], &h->y, &l->y);
-    split2(v[4], v[5], &h->z, &l->z); split2(v[6], v[7], &h->w, &l->w);
-  };
-  if (g.Cr) {
-    constexpr int KT = BN / 16;
-    const int nb = (rows_per_pass / 32) * KT;
-    for (int b = wave; b < nb; b += NW) {
-      const int rtl = b / KT, ktl = b - rtl * KT;
-      if (row0 + rtl * 32 >= g.M || n0 + ktl * 16 >= g.N) continue;
-      uint4 h, l;
-      fetch(rtl * 32 + (lane & 31), ktl * 16 + (lane >> 5) * 8, &h, &l);
-      const long rt = (row0 + rtl * 32) >> 5, kt = (g.colCr + gcol0 + ktl * 16) >> 4;
-      u32x4* dst = reinterpret_cast<u32x4*>(g.Cr + ((rt * g.nktCr + kt) * 2) * 512) + lane;
-      __builtin_nontemporal_store(pg_u4(h), dst);
-      if (!g.hiOnly) __builtin_nontemporal_store(pg_u4(l), dst + 64);
-    }
-  }
-  if (g.Ct) {
-    const int KT = rows_per_pass / 16;
-    const int nb = (BN / 32) * KT;
-    const int c4 = lane >> 4, r = ((lane & 15) - 2 * c4) & 15;
-    const int off = pgemm_t_offset(r, c4);
-    for (int b = wave; b < nb; b += NW) {
-      const int mtl = b / KT, ktl = b - mtl * KT;
-      if (row0 + ktl * 16 >= g.M || n0 + mtl * 32 >= g.N) continue;
-      uint4 h, l;
-      fetch(ktl * 16 + r, mtl * 32 + c4 * 8, &h, &l);
-      const long mt = (g.colCt + gcol0 + mtl * 32) >> 5, kt = (g.rowCt + row0 + ktl * 16) >> 4;
-      char* dst = reinterpret_cast<char*>(g.Ct) + ((mt * g.nktCt + kt) * 2) * 1024 + off;
-      __builtin_nontemporal_store(pg_u4(h), reinterpret_cast<u32x4*>(dst));
-      if (!g.hiOnly) __builtin_nontemporal_store(pg_u4(l), reinterpret_cast<u32x4*>(dst + 1024));
-    }
+    uint4 h, l;
+    split2(v[0], v[1], &h.x, &l.x); split2(v[2], v[3], &h.y, &l.y);
+    split2(v[4], v[5], &h.z, &l.z); split2(v[6], v[7], &h.w, &l.w);
+    const long rt = (row0 + rtl * 32) >> 5, kt = (g.colCr + gcol0 + ktl * 16) >> 4;
+    char* dst = reinterpret_cast<char*>(g.Cr) + ((rt * g.nktCr + kt) * 2) * 1024 + uoff;
+    __builtin_nontemporal_store(pg_u4(h), reinterpret_cast<u32x4*>(dst));
+    if (!g.hiOnly) __builtin_nontemporal_store(pg_u4(l), reinterpret_cast<u32x4*>(dst + 1024));
   }
 }
-// act == 2 operand from row planes: the hi plane's bf16 values (only their sign is used) into the LDS operand tile
+// act == 2 operand from planes: the hi plane's bf16 values (only their sign is used) into the LDS operand tile
 template <int BN, int NTH>
 __device__ __forceinline__ void gemm_sign_tile_from_planes(const GemmArgs& g, float* lds, int rows_per_pass, int row0, int n0, int batch) {
   constexpr int WLD = BN + 4, KT = BN / 16, NW = NTH / 64;
@@ -205,7 +182,8 @@ __device__ __forceinline__ void gemm_sign_tile_from_planes(const GemmArgs& g, fl
     uint4 h = {0u, 0u, 0u, 0u};
     if (row0 + rtl * 32 < g.M && n0 + ktl * 16 < g.N) {
       const long rt = (row0 + rtl * 32) >> 5, kt = (g.colGr + gcol0 + ktl * 16) >> 4;
-      h = *(reinterpret_cast<const uint4*>(g.Gr + ((rt * g.nktGr + kt) * 2) * 512) + lane);
+      h = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(g.Gr) + ((rt * g.nktGr + kt) * 2) * 1024 +
+                                          lfi_u_plane_offset(lane & 31, lane >> 5));
     }
     f32x4 a, bq;
     a[0] = __builtin_bit_cast(float, h.x << 16); a[1] = __builtin_bit_cast(float, h.x & 0xffff0000u);

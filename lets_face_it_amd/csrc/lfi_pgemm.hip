@@ -5,16 +5,22 @@
 // Here the operands arrive ALREADY split - once, by a streaming kernel or by the epilogue of the product that made them - and
 // in 1-KB blocks that go global -> LDS by LDS-DMA (global_load_lds_dwordx4: no VGPR, no VALU, no ds_write).
 //
-// Two block formats, one per operand orientation of the fp32 matrix the planes stand for (both: block of 32 "mn" indices x 16 k,
-// hi block then lo block, index ((mn tile * nkt + k tile) * 2 + plane) * 512 bf16):
-//   row planes ("R", lfi_planes_from_f32): the matrix is [mn][k] (k contiguous). Lane l of a block holds mn = l & 31,
-//     k = 8 (l >> 5) .. + 7: exactly the v_mfma_f32_32x32x16_bf16 operand fragment, so a fragment is ONE linear, conflict-free
-//     ds_read_b128 (block base + 16 l).
-//   k-major planes ("T", lfi_planes_t_from_f32): the matrix is [k][mn] (mn contiguous: weight gradients sum over frames, which
-//     are the ROWS of every stored activation). Four 256-byte sub-tiles [8 k][16 mn] per block, sub-tile (k >> 3, mn >> 4), the
-//     sub-tiles of the upper mn half with their k rows 0-3 <-> 4-7 swapped; a fragment is TWO ds_read_b64_tr_b16 (the hardware
-//     transposing read: 4 k rows x 16 mn per 16 lanes) at byte offsets toff and toff ^ 128 - the two 16-lane groups of a
-//     32-lane half land in opposite 128-byte halves of the 256-byte bank row, conflict-free (cdna_hip_programming.md T10).
+// ONE block format (lfi_planes_from_f32; lfi_common.h, lfi_u_plane_offset), the planes of an fp32 matrix X (rows x cols): per
+// 32-row tile rt and 16-column tile ct two 1-KB blocks (hi, lo), index ((rt * nct + ct) * 2 + plane) * 512 bf16, each a row-major
+// [32 rows][16 columns] image (32-byte rows) whose two 16-byte chunks trade places in rows 8-15 and 24-31. An operand takes them
+// in one of two USES:
+//   use 0, "row use": X's rows are the operand's free (mn) index, its columns the contraction index k (an nn.Linear input or
+//     weight in its forward product). A k-tile of an mn tile is one block, moved to LDS as it lies; the v_mfma_f32_32x32x16_bf16
+//     fragment (lane l: mn = l & 31, k = 8 (l >> 5) .. + 7) is ONE ds_read_b128 at lfi_u_plane_offset(l & 31, l >> 5) - the
+//     chunk swap makes its four 16-lane groups cover all 64 banks.
+//   use 1, "transposed use": X's ROWS are the contraction index (every weight gradient sums over frames, the rows of every
+//     stored activation; the feature gradient sums over cond_transform's output units, the rows of its weight). An operand tile of
+//     32 mn x 16 k is rows 16 j .. 16 j + 15 (j = k-tile & 1) of the two blocks (rt = k-tile >> 1, ct = 2 mn-tile, + 1): two
+//     contiguous 512-byte runs, which the LDS-DMA's per-lane source address places as two sub-images, the second with its rows
+//     0-3 <-> 4-7 swapped; the fragment is TWO ds_read_b64_tr_b16 (the hardware transposing read: 4 rows x 16 columns per 16
+//     lanes) at byte offsets toff and toff ^ 128, and the swap puts the two 16-lane groups of a 32-lane half into opposite halves of
+//     the 256-byte bank row: conflict-free (cdna_hip_programming.md T10).
+// So a matrix that is consumed both ways - c, the gradient of cond_transform's pre-activation, dgi - is written ONCE.
 //
 // Kernel: 128 x 256 tile (or 256 x 128: template WMT x WNT), TWO workgroups per CU: 512 threads = 8 waves x (64 x 64) patches (wm = wave >> 2, wn = wave & 3),
 // ring of 3 slots of one 16-deep k-tile each, [A: 4 mn tiles x {hi, lo} x 1 KB][B: 8 x 2 x 1 KB] = 24 KB (72 KB; the wide
@@ -41,8 +47,8 @@ typedef __bf16 pbf16x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) pbf16x4 plds_v4;
 
 template <bool TF>
-__device__ __forceinline__ bf16x8 pg_frag(const char* blk, int lane, int toff) {
-  if (!TF) return *reinterpret_cast<const bf16x8*>(blk + lane * 16);
+__device__ __forceinline__ bf16x8 pg_frag(const char* blk, int uoff, int toff) {
+  if (!TF) return *reinterpret_cast<const bf16x8*>(blk + uoff);
   const pbf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((plds_v4*)(blk + toff));
   const pbf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((plds_v4*)(blk + (toff ^ 128)));
   bf16x8 r;
@@ -78,32 +84,48 @@ __global__ __launch_bounds__(512, 4) void gemm_planes_kernel(GemmArgs g) {
   char* lds = reinterpret_cast<char*>(xsmem);
   // the slot's 24 blocks (A: 4 mn tiles x 2 planes, then B: 8 x 2) are dealt to the 8 waves three at a time; a tile's two
   // planes are adjacent in memory and in the slot
-  const char* baseA = reinterpret_cast<const char*>(g.Ap + batch * g.pstrideA) + ((long)(tm * 2 * WMT) * g.nktA + kt0) * 2048 + lane * 16;
-  const char* baseB = reinterpret_cast<const char*>(g.Bp + batch * g.pstrideB) + ((long)(tn * 2 * WNT) * g.nktB + kt0) * 2048 + lane * 16;
+  // source of this lane's 16 bytes of a piece (mn tile mt of the workgroup's panel, plane, k-tile kt):
+  //   row use:        block (row tile = first + mt, column tile kt), copied as it lies: + 16 lane
+  //   transposed use: column tiles first + 2 mt (+ 1 for lanes 32-63), row tile kt >> 1, rows 16 (kt & 1) + (lane & 31) / 2, the
+  //                   second sub-image's rows 0-3 <-> 4-7 swapped (see the header)
+  const int tsub = lane >> 5, trow = ((lane & 31) >> 1) ^ (tsub << 2);
+  const int lpT = tsub * 2048 + trow * 32 + (lane & 1) * 16, lpR = lane * 16;
+  const char* baseA = reinterpret_cast<const char*>(g.Ap + batch * g.pstrideA) +
+                      (AT ? (long)(tm * 2 * WMT) * 4096 + lpT : (long)(tm * 2 * WMT) * g.nktA * 2048 + lpR);
+  const char* baseB = reinterpret_cast<const char*>(g.Bp + batch * g.pstrideB) +
+                      (BT ? (long)(tn * 2 * WNT) * 4096 + lpT : (long)(tn * 2 * WNT) * g.nktB * 2048 + lpR);
   const char* src[3];
   int doff[3];
+  bool srcB[3];
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
     const int j = wave * 3 + i;                       // block 0 .. 23
     const int isB = j >= NA, jj = isB ? j - NA : j;   // (mn tile, plane) = (jj >> 1, jj & 1)
     const int plane = (!isB && noalo) ? 0 : (jj & 1);
-    src[i] = (isB ? baseB + (long)(jj >> 1) * g.nktB * 2048 : baseA + (long)(jj >> 1) * g.nktA * 2048) + plane * 1024;
+    const long mt = jj >> 1;
+    src[i] = (isB ? baseB + (BT ? mt * 4096 : mt * g.nktB * 2048) : baseA + (AT ? mt * 4096 : mt * g.nktA * 2048)) + plane * 1024;
+    srcB[i] = isB != 0;
     doff[i] = j * 1024;
   }
+  const long rowA = (long)g.nktA * 2048, rowB = (long)g.nktB * 2048;   // bytes per row tile of either plane buffer
   auto dma = [&](int kt, int slot) {
-    const long ko = (long)max(min(kt, nkt - 1), 0) * 2048;
+    const int ka = kt0 + max(min(kt, nkt - 1), 0);
+    const long koA = AT ? (long)(ka >> 1) * rowA + (ka & 1) * 512 : (long)ka * 2048;
+    const long koB = BT ? (long)(ka >> 1) * rowB + (ka & 1) * 512 : (long)ka * 2048;
 #pragma unroll
     for (int i = 0; i < 3; ++i)
-      __builtin_amdgcn_global_load_lds((pglb_void*)(src[i] + ko), (plds_void*)(lds + slot * QSLOT + doff[i]), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((pglb_void*)(src[i] + (srcB[i] ? koB : koA)), (plds_void*)(lds + slot * QSLOT + doff[i]), 16, 0, 0);
   };
   const int wm = wave / WNT, wn = wave % WNT;
-  // k-major blocks: lane 16 g + 4 q + p addresses k row q (of 4), mn columns 4 p .. + 3 of sub-tile (k half g >> 1, mn half g & 1)
-  const int tg = lane >> 4, tq = (lane >> 2) & 3, tp = lane & 3;
-  const int toff = ((tg >> 1) * 2 + (tg & 1)) * 256 + ((tq ^ ((tg & 1) << 2)) * 32) + tp * 8;
+  // row use: this lane's chunk of a block. Transposed use: lane 16 g + 4 q + p addresses k row 8 (g >> 1) + q (then + 4), mn columns
+  // 4 p .. + 3 of sub-image g & 1 (whose rows 0-3 <-> 4-7 are swapped); a row's chunks are swapped in rows 8-15 as they lie in memory
+  const int uoff = lfi_u_plane_offset(lane & 31, lane >> 5);
+  const int tg = lane >> 4, tq = (lane >> 2) & 3, tp = lane & 3, tkh = tg >> 1, tmh = tg & 1;
+  const int toff = tmh * 512 + (((tkh * 8 + tq) ^ (tmh << 2)) * 32) + (((tp >> 1) ^ tkh) << 4) + (tp & 1) * 8;
   const int fa = (wm * 4) * 1024;             // A fragment (mt, plane) in block fa + (mt * 2 + plane) * 1024
   const int fb = NA * 1024 + (wn * 4) * 1024;  // B fragment (nt, plane) in block fb + (nt * 2 + plane) * 1024
-  auto fragA = [&](int slot, int off) { return pg_frag<AT>(lds + slot * QSLOT + fa + off, lane, toff); };
-  auto fragB = [&](int slot, int off) { return pg_frag<BT>(lds + slot * QSLOT + fb + off, lane, toff); };
+  auto fragA = [&](int slot, int off) { return pg_frag<AT>(lds + slot * QSLOT + fa + off, uoff, toff); };
+  auto fragB = [&](int slot, int off) { return pg_frag<BT>(lds + slot * QSLOT + fb + off, uoff, toff); };
 
   f32x16 acc[2][2];
 #pragma unroll
@@ -180,8 +202,8 @@ __global__ __launch_bounds__(512, 4) void gemm_planes_kernel(GemmArgs g) {
   else gemm_epilogue_n<64 * WNT>(g, acc, m0, n0, wm, wn, l31, half, batch, split);
 }
 
-// fp32 (rows x cols, row pitch ldx) -> bf16 hi / lo ROW planes, zero padded to rows_pad x 16 nkt:
-// block ((rt * nkt + kt) * 2 + plane), lane l of a block holds row rt * 32 + (l & 31), k = kt * 16 + 8 (l >> 5) .. + 7.
+// fp32 (rows x cols, row pitch ldx) -> bf16 hi / lo planes, zero padded to rows_pad x 16 nkt: block ((rt * nkt + kt) * 2 + plane),
+// thread l of a block converts row rt * 32 + (l & 31), columns kt * 16 + 8 (l >> 5) .. + 7 into the chunk at lfi_u_plane_offset.
 // One thread per (block pair, lane): 8 floats in (two 16-byte loads when the row allows), 16 + 16 bytes out.
 __global__ __launch_bounds__(256) void planes_from_f32_kernel(const float* __restrict__ X, long ldx, int rows, int cols, long nblk,
                                                              int nkt, int vec, __bf16* __restrict__ out) {
@@ -203,36 +225,7 @@ __global__ __launch_bounds__(256) void planes_from_f32_kernel(const float* __res
     uint4 h, lo;
     split2(v[0], v[1], &h.x, &lo.x); split2(v[2], v[3], &h.y, &lo.y);
     split2(v[4], v[5], &h.z, &lo.z); split2(v[6], v[7], &h.w, &lo.w);
-    uint4* dst = reinterpret_cast<uint4*>(out) + q * 128 + l;
-    dst[0] = h;
-    dst[64] = lo;
-  }
-}
-
-// fp32 (krows x mncols, row pitch ldx: mn contiguous) -> bf16 hi / lo K-MAJOR planes: block ((mt * nkt + kt) * 2 + plane) holds
-// mn = mt * 32 .. + 31, k = kt * 16 .. + 15 in the sub-tile layout of pgemm_t_offset; mn zero padded to whole 256-wide panels,
-// k to whole k-tiles. One thread per (block pair, 16-byte chunk): chunk c = l >> 4 of k row l & 15 (8 consecutive mn).
-__global__ __launch_bounds__(256) void planes_t_from_f32_kernel(const float* __restrict__ X, long ldx, long krows, int mncols, long nblk,
-                                                               long nkt, int vec, __bf16* __restrict__ out) {
-  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < nblk * 64; idx += (long)gridDim.x * 256) {
-    const int l = (int)(idx & 63);
-    const long q = idx >> 6;
-    const long kt = q % nkt, mt = q / nkt;
-    const int c4 = l >> 4, r = l & 15;
-    const long row = kt * 16 + r;
-    const int c0 = (int)mt * 32 + c4 * 8;
-    float v[8];
-    if (row < krows && vec && c0 + 8 <= mncols) {
-      const f32x4 a = *reinterpret_cast<const f32x4*>(X + row * ldx + c0), b = *reinterpret_cast<const f32x4*>(X + row * ldx + c0 + 4);
-      v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
-    } else {
-#pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = (row < krows && c0 + e < mncols) ? X[row * ldx + c0 + e] : 0.0f;
-    }
-    uint4 h, lo;
-    split2(v[0], v[1], &h.x, &lo.x); split2(v[2], v[3], &h.y, &lo.y);
-    split2(v[4], v[5], &h.z, &lo.z); split2(v[6], v[7], &h.w, &lo.w);
-    char* dst = reinterpret_cast<char*>(out) + q * 2048 + pgemm_t_offset(r, c4);
+    char* dst = reinterpret_cast<char*>(out) + q * 2048 + lfi_u_plane_offset(l & 31, l >> 5);
     *reinterpret_cast<uint4*>(dst) = h;
     *reinterpret_cast<uint4*>(dst + 1024) = lo;
   }
@@ -290,26 +283,6 @@ extern "C" int lfi_planes_from_f32(const float* X, long ldx, long rows, int cols
   return LFI_OK;
 }
 
-extern "C" long lfi_planes_t_elems(long krows, long mncols) {
-  if (krows <= 0 || mncols <= 0) return 0;
-  return ((mncols + 255) / 256 * 256) * ((krows + 15) / 16 * 16) * 2;
-}
-
-extern "C" int lfi_planes_t_from_f32(const float* X, long ldx, long krows, long mncols, void* planes, void* stream) {
-  LFI_REQUIRE(krows >= 0 && mncols >= 0 && mncols < (1L << 30), "lfi_planes_t_from_f32: bad dims %ld x %ld", krows, mncols);
-  if (krows == 0 || mncols == 0) return LFI_OK;
-  LFI_REQUIRE(X && planes, "lfi_planes_t_from_f32: null pointer");
-  LFI_REQUIRE((reinterpret_cast<uintptr_t>(planes) & 15) == 0, "lfi_planes_t_from_f32: planes must be 16-byte aligned");
-  const long nkt = (krows + 15) / 16;
-  const long nblk = (mncols + 255) / 256 * 8 * nkt;   // (mn tile, k-tile) block pairs, mn padded to whole 256-wide panels
-  const int vec = ((reinterpret_cast<uintptr_t>(X) & 15) == 0 && (ldx & 3) == 0) ? 1 : 0;
-  const long threads = nblk * 64;
-  hipLaunchKernelGGL(planes_t_from_f32_kernel, dim3((unsigned)min((threads + 255) / 256, 65535L * 8)), dim3(256), 0, (hipStream_t)stream,
-                     X, ldx, krows, (int)mncols, nblk, nkt, vec, reinterpret_cast<__bf16*>(planes));
-  LFI_LAUNCH_CHECK("lfi_planes_t_from_f32");
-  return LFI_OK;
-}
-
 extern "C" long lfi_gemm_planes_work_floats(const lfi_pgemm_desc* d) {
   if (!d || d->splitk <= 1) return 0;
   return (long)d->batch * d->splitk * d->M * d->N;
@@ -331,26 +304,27 @@ extern "C" int lfi_gemm_planes(const lfi_pgemm_desc* d, void* stream) {
   if (d->M == 0 || d->N == 0) return LFI_OK;
   const bool store = d->store_f32 != 0;
   LFI_REQUIRE(d->Ap && d->Bp && (d->C || !store), "lfi_gemm_planes: null operand");
-  LFI_REQUIRE(store || d->Cr || d->Ct, "lfi_gemm_planes: store_f32 = 0 and no plane output: the result would go nowhere");
+  LFI_REQUIRE(store || d->Cr, "lfi_gemm_planes: store_f32 = 0 and no plane output: the result would go nowhere");
   LFI_REQUIRE(d->K > 0, "lfi_gemm_planes: K = 0");
   LFI_REQUIRE(d->act >= 0 && d->act <= 2 && (d->act != 2 || d->G || d->Gr), "lfi_gemm_planes: bad act %d", d->act);
   const int nkt = (d->K + 15) / 16;
-  LFI_REQUIRE(d->a_nkt >= nkt && d->b_nkt >= nkt, "lfi_gemm_planes: plane buffers hold %ld / %ld k-tiles per mn tile, the product needs %d",
-              (long)d->a_nkt, (long)d->b_nkt, nkt);
+  // (row use: the buffer's column tiles are the product's k-tiles; transposed use: they are its mn tiles, two per 32-wide mn tile)
+  LFI_REQUIRE((d->a_fmt ? 2L * d->a_nkt >= (d->M + 15) / 16 : d->a_nkt >= nkt) && (d->b_fmt ? 2L * d->b_nkt >= (d->N + 15) / 16 : d->b_nkt >= nkt),
+              "lfi_gemm_planes: plane buffers hold %ld / %ld column tiles per row tile: too few for this product", (long)d->a_nkt, (long)d->b_nkt);
+  LFI_REQUIRE(d->a_nkt > 0 && d->b_nkt > 0, "lfi_gemm_planes: a_nkt / b_nkt = column tiles per row tile of the plane buffers");
   LFI_REQUIRE((reinterpret_cast<uintptr_t>(d->Ap) & 15) == 0 && (reinterpret_cast<uintptr_t>(d->Bp) & 15) == 0 &&
               (d->a_stride & 7) == 0 && (d->b_stride & 7) == 0, "lfi_gemm_planes: planes must be 16-byte aligned");
   int splitk = d->splitk < 1 ? 1 : d->splitk;
   if (splitk > nkt) splitk = nkt;
   LFI_REQUIRE(splitk == 1 || d->work, "lfi_gemm_planes: splitk needs a workspace");
-  LFI_REQUIRE(splitk == 1 || (!d->Cr && !d->Ct && !d->colsum_part && store), "lfi_gemm_planes: plane outputs / column sums need splitk = 1");
-  const bool planes_io = d->Cr || d->Ct || d->Gr;
+  LFI_REQUIRE(splitk == 1 || (!d->Cr && !d->colsum_part && store), "lfi_gemm_planes: plane outputs / column sums need splitk = 1");
+  const bool planes_io = d->Cr || d->Gr;
   if (planes_io) {
     LFI_REQUIRE(d->batch == 1 || (d->strideC > 0 && d->strideC * d->batch <= (d->C ? d->ldc : d->strideC * d->batch) && d->strideC % 32 == 0),
                 "lfi_gemm_planes: plane outputs need batch entries side by side in C's columns, 32-column granular");
-    LFI_REQUIRE(d->cr_col0 % 16 == 0 && d->gr_col0 % 16 == 0 && d->ct_col0 % 32 == 0 && d->ct_row0 % 16 == 0,
-                "lfi_gemm_planes: plane outputs must start on block boundaries");
-    LFI_REQUIRE((!d->Cr || (reinterpret_cast<uintptr_t>(d->Cr) & 15) == 0) && (!d->Ct || (reinterpret_cast<uintptr_t>(d->Ct) & 15) == 0) &&
-                (!d->Gr || (reinterpret_cast<uintptr_t>(d->Gr) & 15) == 0), "lfi_gemm_planes: planes must be 16-byte aligned");
+    LFI_REQUIRE(d->cr_col0 % 16 == 0 && d->gr_col0 % 16 == 0, "lfi_gemm_planes: plane outputs must start on block boundaries");
+    LFI_REQUIRE((!d->Cr || (reinterpret_cast<uintptr_t>(d->Cr) & 15) == 0) && (!d->Gr || (reinterpret_cast<uintptr_t>(d->Gr) & 15) == 0),
+                "lfi_gemm_planes: planes must be 16-byte aligned");
   }
   GemmArgs a = {};
   a.M = d->M; a.N = d->N; a.K = d->K;
@@ -366,7 +340,6 @@ extern "C" int lfi_gemm_planes(const lfi_pgemm_desc* d, void* stream) {
   a.colpart = d->colsum_part; a.ldpart = d->ld_part;
   a.storeC = store ? 1 : 0;
   a.Cr = reinterpret_cast<__bf16*>(d->Cr); a.nktCr = d->cr_nkt; a.colCr = d->cr_col0;
-  a.Ct = reinterpret_cast<__bf16*>(d->Ct); a.nktCt = d->ct_nkt; a.rowCt = d->ct_row0; a.colCt = d->ct_col0;
   a.Gr = reinterpret_cast<const __bf16*>(d->Gr); a.nktGr = d->gr_nkt; a.colGr = d->gr_col0;
   {
     // the wide (through-LDS) epilogue needs 16-byte granular fp32 rows; it is also the only one that can emit / read planes

@@ -435,18 +435,6 @@ class GlowEngine:
               "lfi_planes_from_f32")
         return buf, (cols + 15) // 16
 
-    def planes_t(self, name, X, ldx, krows, mncols, x_off=0):
-        """K-major planes (format 1) of the fp32 matrix X (krows x mncols, mn contiguous, row pitch ldx): the operand form of a
-        matrix whose ROWS are the contraction index. -> (tensor, nkt)"""
-        elems = self.L.lfi_planes_t_elems(krows, mncols) + 256 * ((krows + 15) // 16 * 16) * 2
-        buf = self._ws.get(name)
-        if buf is None or buf.numel() < elems:
-            buf = torch.empty(elems, dtype=torch.bfloat16, device=self.device)
-            self._ws[name] = buf
-        check(self.L.lfi_planes_t_from_f32(X.data_ptr() + 4 * x_off, ldx, krows, mncols, buf.data_ptr(), _stream()),
-              "lfi_planes_t_from_f32")
-        return buf, (krows + 15) // 16
-
     def plane_buf(self, name, elems):
         """An (uninitialised) bf16 workspace for planes that a kernel's epilogue writes."""
         buf = self._ws.get(name)
@@ -458,11 +446,12 @@ class GlowEngine:
     def gemm_planes(self, M, N, K, Ap, a_nkt, Bp, b_nkt, Cm, ldc, bias=None, act=0, slope=0.01, G=None, ldg=0, batch=1,
                     a_stride=0, b_stride=0, sC=0, sBias=0, sG=0, accumulate=0, c_off=0, bias_off=0, tag=None, cls=None,
                     a_fmt=0, b_fmt=0, a_off=0, b_off=0, splitk=1, ws="scratch.pgemm_splitk", store=True,
-                    Cr=None, cr_nkt=0, cr_col0=0, Ct=None, ct_nkt=0, ct_row0=0, ct_col0=0, Gr=None, gr_nkt=0, gr_col0=0,
-                    colsum_into=None, hi_only=False, tile=0):
-        """lfi_gemm_planes. a_off / b_off: bf16 elements into the plane buffers (a k-tile range: kt0 * 1024; an mn-tile range:
-        tile * nkt * 1024). Cr / Ct: bf16 tensors that receive the result as row / k-major planes; Gr: row planes whose hi plane's
-        sign stands in for G (act 2). colsum_into: as gemm(). Returns True when the column sums were taken in the epilogue."""
+                    Cr=None, cr_nkt=0, cr_col0=0, Gr=None, gr_nkt=0, gr_col0=0, colsum_into=None, hi_only=False, tile=0):
+        """lfi_gemm_planes. a_fmt / b_fmt: 0 = row use of the operand's planes (k = the matrix' columns), 1 = transposed use (k = its
+        rows). a_nkt / b_nkt: column tiles per row tile of the plane buffers. a_off / b_off: bf16 elements into the plane buffers (a
+        column-tile offset: ct * 1024; a row-tile offset: rt * nkt * 1024). Cr: bf16 tensor that receives the result as planes; Gr:
+        planes whose hi plane's sign stands in for G (act 2). colsum_into: as gemm(). Returns True when the column sums were taken in
+        the epilogue."""
         g = PGemmDesc()
         g.skip = self._skip_bits(cls)
         g.M, g.N, g.K = M, N, K
@@ -479,7 +468,6 @@ class GlowEngine:
         if splitk > 1:
             g.work = self._buf(ws, batch * splitk * M * N).data_ptr()
         g.Cr, g.cr_nkt, g.cr_col0 = ptr(Cr), cr_nkt, cr_col0
-        g.Ct, g.ct_nkt, g.ct_row0, g.ct_col0 = ptr(Ct), ct_nkt, ct_row0, ct_col0
         g.Gr, g.gr_nkt, g.gr_col0 = ptr(Gr), gr_nkt, gr_col0
         g.out_hi_only, g.tile = (1 if hi_only else 0), tile
         part, prow = None, 0
@@ -581,13 +569,10 @@ class GlowEngine:
             # here instead of once per row tile (56 times) inside the GEMM
             self._wct_planes = self.planes("wct_planes", self.wct_f, s.ldf, s.Ks * s.D, s.Ef)
             if self._chain_fwd_ok():
-                # the same weights as k-major planes (the feature-gradient product sums over the Ks D output units), and
-                # W_c = W_ih[:, Ch:] of every flow step both ways: row planes for gic = c W_c^T (sums over D), k-major planes for
-                # d pre-activation = dgi W_c (sums over the gate rows)
-                KD = s.Ks * s.D
-                self._wct_t = self.planes_t("wct_t", self.wct_f, s.ldf, KD, s.ldf)
+                # W_c = W_ih[:, Ch:] of every flow step, (Ks G x D): row use in gic = c W_c^T (sums over D), transposed use in
+                # d pre-activation = dgi W_c (sums over the gate rows). (The folded cond_transform weights above serve the
+                # feature-gradient product the same way: it sums over their rows, the Ks D output units.)
                 self._wc_r = self.planes("wc_r", self.prep, s.D, s.Ks * s.G, s.D, x_off=self._wc_offset())
-                self._wc_t = self.planes_t("wc_t", self.prep, s.D, s.Ks * s.G, s.D, x_off=self._wc_offset())
 
     # ------------------------------------------------------------------ conditioning
     def _check_input(self, x, name, B, Tmin, dim):
@@ -687,24 +672,24 @@ class GlowEngine:
 
     def _project(self, cond, F, chain=False, with_stash=False):
         """c = LeakyReLU(cond Wct^T + b) for all Ks steps (one GEMM), gic = c W_ih[:, Ch:]^T + b_ih (batched GEMM).
-        chain: c leaves the first product as operand planes only (row planes for gic and the backward mask, k-major planes for
-        dW_c when a backward pass follows) -> ((c_r, c_t), gic); otherwise (c as fp32, gic)."""
+        chain: c leaves the first product as operand planes only (gic and the backward mask use them by rows, dW_c transposed)
+        -> (c planes, gic); otherwise (c as fp32, gic)."""
         s = self.spec
         KD = s.Ks * s.D
         if chain:
             cp, nkc = self.planes("cond_planes", cond, s.ldf, F, s.Ef)
             wp, nkw = self._wct_planes
-            nkKD, nktF = KD // 16, (F + 15) // 16
+            nkKD = KD // 16
             c_r = self.plane_buf("c_r", self.L.lfi_planes_elems(F, KD) + 256 * KD * 2)
-            c_t = self.plane_buf("c_t", self.L.lfi_planes_t_elems(F, KD) + 256 * nktF * 16 * 2) if with_stash else None
             self.gemm_planes(F, KD, s.Ef, cp, nkc, wp, nkw, None, KD, bias=self.fview("bct"), act=1, slope=0.01, store=False,
-                             Cr=c_r, cr_nkt=nkKD, Ct=c_t, ct_nkt=nktF, tag="gemm_cond_fwd", cls="cond_fwd")
+                             Cr=c_r, cr_nkt=nkKD, tag="gemm_cond_fwd", cls="cond_fwd")
             gic = self._buf("gic", s.Ks * F * s.G)
             wr, nkwr = self._wc_r
             self.gemm_planes(F, s.G, s.D, c_r, nkKD, wr, nkwr, gic, s.G, bias=self.fview("b_ih"), batch=s.Ks,
                              a_stride=(s.D // 16) * 1024, b_stride=(s.G // 32) * nkwr * 1024, sC=F * s.G, sBias=s.G,
                              tag="gemm_gic", cls="gic")
-            return (c_r, c_t), gic
+            self._cond_planes = (cp, nkc)
+            return c_r, gic
         cbuf = self._buf("c", F * KD)
         if self.precision == 1 and os.environ.get("LFI_PGEMM", "1") != "0":
             # operands pre-split into bf16 hi / lo planes in MFMA fragment order, streamed to LDS by LDS-DMA: same products
@@ -855,34 +840,32 @@ class GlowEngine:
             self._join()
 
     def _backward_chain(self, ctx, gscale, after_flow, bst):
-        """backward() with every big GEMM operand on planes (see _chain_fwd_ok): the walk leaves dgi as row + k-major planes,
+        """backward() with every big GEMM operand on planes (see _chain_fwd_ok): the walk leaves dgi as operand planes,
         dW_c = dgi^T c, d pre-activation = dgi W_c (masked by the sign of c's planes, emitted as planes in their place), the
-        cond_transform weight gradient and the feature gradient all run on lfi_gemm_planes."""
+        cond_transform weight gradient and the feature gradient all run on lfi_gemm_planes - every set of planes written once and
+        used by rows in one product, transposed in another."""
         s = self.spec
         B, T, N, F = ctx.B, ctx.T, ctx.N, ctx.F
         KD, G, D, Ks = s.Ks * s.D, s.G, s.D, s.Ks
         st = _stream()
         dims, p = ctx.dims, self._flow_params()
-        c_r, c_t = ctx.cbuf
-        nkKD, nktF, nktKF, nkG = KD // 16, F // 16, Ks * F // 16, G // 16
-        dgi_r = self.plane_buf("dgi_r", self.L.lfi_planes_elems(Ks * F, G) + 256 * G * 2)
-        dgi_t = self.plane_buf("dgi_t", self.L.lfi_planes_t_elems(Ks * F, G) + 256 * nktKF * 16 * 2)
+        c_r = ctx.cbuf
+        nkKD, nkG, nkD = KD // 16, G // 16, D // 16
+        dgi_p = self.plane_buf("dgi_planes", self.L.lfi_planes_elems(Ks * F, G) + 256 * G * 2)
         # with two products in their consumers (A rounded to bf16) the lo planes of dgi and of d pre-activation are never
         # fetched: the walk / the dpre epilogue then write the hi planes only (half the plane traffic)
         dgi_hi = all(self._skip_bits(c) & 1 for c in ("dpre", "flow_pgrads"))
         dpre_hi = all(self._skip_bits(c) & 1 for c in ("cond_wgrad", "cond_dgrad"))
         check(self.L.lfi_flow_seq_bwd_planes(C.byref(dims), C.byref(p), self.prep.data_ptr(), ctx.stash.data_ptr(), gscale,
-                                             bst.data_ptr(), dgi_r.data_ptr(), dgi_t.data_ptr(), 1 if dgi_hi else 0, st),
-              "lfi_flow_seq_bwd_planes")
+                                             bst.data_ptr(), dgi_p.data_ptr(), 1 if dgi_hi else 0, st), "lfi_flow_seq_bwd_planes")
         work = self._buf("scratch.pg", self.L.lfi_flow_param_grads_work_floats(C.byref(dims)))
         g = self._flow_grads()
         side = self._fork()
-        # k-major planes of the feature matrix for the weight-gradient product below: a 50 MB streaming pass, on the side stream
-        with self._on(side):
-            cond_t, _ = self.planes_t("cond_t", ctx.cond, s.ldf, F, s.ldf)
-        # w_ih[k][:, Ch:] (G x D) = dgi[k]^T c[:, k D:(k + 1) D]: the MFMA-bound flow weight gradient, both operands k-major
-        self.gemm_planes(G, D, F, dgi_t, nktKF, c_t, nktF, self.fview("w_ih", self.grads), s.I, batch=Ks, a_fmt=1, b_fmt=1,
-                         a_stride=(F // 16) * 1024, b_stride=(D // 32) * nktF * 1024, sC=G * s.I, c_off=s.Ch,
+        # w_ih[k][:, Ch:] (G x D) = dgi[k]^T c[:, k D:(k + 1) D]: the MFMA-bound flow weight gradient; both operands' planes in
+        # transposed use (the sum runs over the F frames = the rows of dgi and of c): step k = row tiles [k F / 32, ..) of dgi's
+        # planes and column tiles [k D / 16, ..) of c's
+        self.gemm_planes(G, D, F, dgi_p, nkG, c_r, nkKD, self.fview("w_ih", self.grads), s.I, batch=Ks, a_fmt=1, b_fmt=1,
+                         a_stride=(F // 32) * nkG * 1024, b_stride=nkD * 1024, sC=G * s.I, c_off=s.Ch,
                          splitk=self._planes_splitk(G, D, F, Ks), tag="gemm_dwc", cls="flow_pgrads")
         pg_dims = dims
         if self._skip_bits("flow_pgrads") and (self.precision & 1):
@@ -891,21 +874,22 @@ class GlowEngine:
         check(self.L.lfi_flow_param_grads(C.byref(pg_dims), C.byref(p), self.prep.data_ptr(), ctx.stash.data_ptr(),
                                           bst.data_ptr(), None, KD, gscale, C.byref(g), 0, work.data_ptr(),
                                           st, side.cuda_stream if side is not None else None), "lfi_flow_param_grads")
-        # d pre-activation of cond_transform = (dgi[k] W_c[k]) * leaky'(c), written as planes IN PLACE of c's (row planes: same
-        # blocks, read for the mask and rewritten by the same workgroup; k-major planes: dW_c above was their last reader); its
-        # epilogue also leaves per-pass column sums: the cond_transform bias gradient
-        wt, nkwt = self._wc_t
-        bct_done = self.gemm_planes(F, D, G, dgi_r, nkG, wt, nkwt, None, KD, act=2, slope=0.01, batch=Ks, b_fmt=1,
-                                    a_stride=(F // 32) * nkG * 1024, b_stride=nkG * 1024, sC=D, store=False,
-                                    Gr=c_r, gr_nkt=nkKD, Cr=c_r, cr_nkt=nkKD, Ct=c_t, ct_nkt=nktF, hi_only=dpre_hi,
+        # d pre-activation of cond_transform = (dgi[k] W_c[k]) * leaky'(c), written as planes IN PLACE of c's (same blocks, read
+        # for the mask and rewritten by the same workgroup; dW_c above was c's last reader); W_c's planes in transposed use (the sum
+        # runs over its G gate rows); the epilogue also leaves per-pass column sums: the cond_transform bias gradient
+        wr, nkwr = self._wc_r
+        bct_done = self.gemm_planes(F, D, G, dgi_p, nkG, wr, nkwr, None, KD, act=2, slope=0.01, batch=Ks, b_fmt=1,
+                                    a_stride=(F // 32) * nkG * 1024, b_stride=(G // 32) * nkwr * 1024, sC=D, store=False,
+                                    Gr=c_r, gr_nkt=nkKD, Cr=c_r, cr_nkt=nkKD, hi_only=dpre_hi,
                                     colsum_into=self.fview("bct", self.grads), tag="gemm_dpre", cls="dpre")
         if not bct_done:
             raise _lib.LfiError("the dpre product on planes did not take the column-sum epilogue")
-        dpre_r, dpre_t = c_r, c_t
-        # cond_transform weight gradient for all steps at once: dwf (Ks D x ldf) = dpre^T cond, both operands k-major
+        dpre_p = c_r
+        # cond_transform weight gradient for all steps at once: dwf (Ks D x ldf) = dpre^T cond, both planes in transposed use
         self._join()
+        cp, nkc = self._cond_planes
         dwf = self._buf("dwct_f", KD * s.ldf)
-        self.gemm_planes(KD, s.ldf, F, dpre_t, nktF, cond_t, nktF, dwf, s.ldf, a_fmt=1, b_fmt=1,
+        self.gemm_planes(KD, s.ldf, F, dpre_p, nkKD, cp, nkc, dwf, s.ldf, a_fmt=1, b_fmt=1,
                          splitk=self._planes_splitk(KD, s.ldf, F), tag="gemm_cond_wgrad", cls="cond_wgrad")
         check(self.L.lfi_cols_fold(dwf.data_ptr(), s.ldf, KD, self.unfold.data_ptr(), None, s.E,
                                    self.fview("wct", self.grads).data_ptr(), s.E, st), "lfi_cols_fold")
@@ -913,13 +897,14 @@ class GlowEngine:
             after_flow()
         rnn = [e for e in s.encoders if e.enc in ("rnn", "lstm", "mlp")]
         if rnn:
-            # gradient of the feature matrix, from the 32-column block that holds the first trainable encoder's first column
+            # gradient of the feature matrix, from the 32-column block that holds the first trainable encoder's first column:
+            # dpre's planes by rows, the folded weights' planes transposed (the sum runs over their Ks D rows)
             col0 = min(e.fcol for e in rnn) // 32 * 32
             W = s.Ef - col0
             ldd = (W + 3) // 4 * 4
             dcond = self._buf("dcond", F * ldd)
-            wtt, nkwtt = self._wct_t
-            self.gemm_planes(F, W, KD, dpre_r, nkKD, wtt, nkwtt, dcond, ldd, b_fmt=1, b_off=(col0 // 32) * nkwtt * 1024,
+            wp, nkw = self._wct_planes
+            self.gemm_planes(F, W, KD, dpre_p, nkKD, wp, nkw, dcond, ldd, b_fmt=1, b_off=(col0 // 16) * 1024,
                              splitk=self._planes_splitk(F, W, KD), tag="gemm_cond_dgrad", cls="cond_dgrad")
             for e in rnn:
                 if e.enc == "mlp":

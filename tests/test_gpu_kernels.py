@@ -265,8 +265,8 @@ def test_gemm_on_presplit_planes_batched_k_ranges(eng, gpu_device):
 @pytest.mark.parametrize("fmt", ["RT", "TR", "TT"])
 @pytest.mark.parametrize("splitk,tile", [(1, 1), (3, 1), (1, 2), (2, 2)])
 def test_gemm_planes_kmajor_operands_and_split_k(eng, gpu_device, shape, fmt, splitk, tile):
-    """K-major planes (lfi_planes_t_from_f32: the operand form of an fp32 matrix whose ROWS are the contraction index - every
-    weight-gradient product sums over frames) in either operand slot, read with ds_read_b64_tr_b16, with and without a K split:
+    """Planes in TRANSPOSED use (a_fmt / b_fmt = 1: the matrix' ROWS are the contraction index - every weight-gradient product sums
+    over frames) in either operand slot, read with ds_read_b64_tr_b16, with and without a K split:
     against the fp64 product and, bit for bit, against lfi_gemm_f32's bf16x3 kernel on the same fp32 operands (same split, same
     products, same order - with a K split only when both split the same way, so that case is checked against fp64 alone)."""
     M, N, K = shape
@@ -289,8 +289,9 @@ def test_gemm_planes_kmajor_operands_and_split_k(eng, gpu_device, shape, fmt, sp
     ldc = r4(N) + 4
     bias = torch.randn(N, generator=g).to(gpu_device)
     C1 = torch.full((M, ldc), 7.0, device=gpu_device)
-    Ap, nka = eng.planes_t("test.pa", A, lda, K, M) if at else eng.planes("test.pa", A, lda, M, K)
-    Bp, nkb = eng.planes_t("test.pb", Bm, ldb, K, N) if bt else eng.planes("test.pb", Bm, ldb, N, K)
+    # (the planes of the matrix as it is stored: K x M for a transposed-use operand, M x K for a row-use one)
+    Ap, nka = eng.planes("test.pa", A, lda, K, M) if at else eng.planes("test.pa", A, lda, M, K)
+    Bp, nkb = eng.planes("test.pb", Bm, ldb, K, N) if bt else eng.planes("test.pb", Bm, ldb, N, K)
     # tile 1: 128 x 256 tiles, 2: 256 x 128 (what the library picks for N = 384 or 896)
     eng.gemm_planes(M, N, K, Ap, nka, Bp, nkb, C1, ldc, bias=bias, act=1, a_fmt=int(at), b_fmt=int(bt), splitk=splitk, tile=tile)
     C2 = torch.full((M, ldc), 7.0, device=gpu_device)
@@ -319,8 +320,8 @@ def test_gemm_planes_two_products_never_touch_a_lo(eng, gpu_device, fmt):
     at = fmt[0] == "T"
     A = torch.randn((K, M) if at else (M, K), generator=g).to(gpu_device)
     Bm = torch.randn((K, N) if at else (N, K), generator=g).to(gpu_device)
-    Ap, nka = eng.planes_t("test.pa", A, M, K, M) if at else eng.planes("test.pa", A, K, M, K)
-    Bp, nkb = eng.planes_t("test.pb", Bm, N, K, N) if at else eng.planes("test.pb", Bm, K, N, K)
+    Ap, nka = eng.planes("test.pa", A, M, K, M) if at else eng.planes("test.pa", A, K, M, K)
+    Bp, nkb = eng.planes("test.pb", Bm, N, K, N) if at else eng.planes("test.pb", Bm, K, N, K)
     eng.pass_skip = {"t": 1}
     try:
         C1 = torch.zeros(M, N, device=gpu_device)
@@ -342,10 +343,11 @@ def test_gemm_planes_two_products_never_touch_a_lo(eng, gpu_device, fmt):
 
 @pytest.mark.parametrize("M,N,K,batch", [(700, 512, 96, 1), (14336 // 8, 128, 384, 4), (333, 96, 64, 2)])
 def test_gemm_planes_emits_its_result_as_planes(eng, gpu_device, M, N, K, batch):
-    """Plane outputs of lfi_gemm_planes: the result leaves the epilogue as row planes and k-major planes - bit for bit what
-    lfi_planes_from_f32 / lfi_planes_t_from_f32 make of the fp32 result (zero padding included) - with the fp32 store on or off,
-    batch entries side by side in C's columns (the in-place dpre product, glow/models.py:187-190 backward), the act-2 operand
-    read from the hi plane of another product's row planes, and per-pass column sums (the bias gradient)."""
+    """Plane output of lfi_gemm_planes: the result leaves the epilogue as operand planes - bit for bit what lfi_planes_from_f32
+    makes of the fp32 result (zero padding included) - with the fp32 store on or off, hi + lo or hi only, either tile shape, batch
+    entries side by side in C's columns (the in-place dpre product, glow/models.py:187-190 backward), the act-2 operand read from
+    the hi plane of another product's planes, and per-pass column sums (the bias gradient). And the emitted planes serve a
+    following product in BOTH uses: by rows (sum over the columns) and transposed (sum over the rows)."""
     g = torch.Generator().manual_seed(M + N + K)
     Ncols = batch * N
     ldc = Ncols + 32
@@ -359,33 +361,39 @@ def test_gemm_planes_emits_its_result_as_planes(eng, gpu_device, M, N, K, batch)
     kw = dict(act=2, batch=batch, a_stride=(K // 16) * 1024, b_stride=(N // 32) * nkw * 1024, sC=N)
     eng.gemm_planes(M, N, K, Ap, nka, Wp, nkw, ref_c, ldc, G=Gm, ldg=ldc, sG=N, **kw)              # fp32 reference path
     want_r, nkr = eng.planes("test.wr", ref_c, ldc, M, Ncols)
-    want_t, nkt = eng.planes_t("test.wt", ref_c, ldc, M, Ncols)
-    want_r, want_t = want_r.clone(), want_t.clone()
-    n_r, n_t = eng.L.lfi_planes_elems(M, Ncols), eng.L.lfi_planes_t_elems(M, Ncols)
+    want_r = want_r.clone()
+    n_r = eng.L.lfi_planes_elems(M, Ncols)
+    X = torch.randn(Ncols, 96, generator=g).to(gpu_device)           # for the row-use consumer: result (M x Ncols) times X
+    Y = torch.randn(M, 160, generator=g).to(gpu_device)              # for the transposed-use consumer: result^T (Ncols x M) times Y
+    Xp, nkx = eng.planes("test.px", X.t().contiguous(), Ncols, 96, Ncols)
+    Yp, nky = eng.planes("test.py", Y, 160, M, 160)
     for store, hi_only, tile in ((True, False, 1), (False, False, 1), (False, True, 2), (True, False, 2)):
         Cr = torch.full((want_r.numel(),), float("nan"), dtype=torch.bfloat16, device=gpu_device)
-        Ct = torch.full((want_t.numel(),), float("nan"), dtype=torch.bfloat16, device=gpu_device)
         out = torch.empty(M, ldc, device=gpu_device).fill_(3.0)
         sums = torch.zeros(Ncols, device=gpu_device)
-        done = eng.gemm_planes(M, N, K, Ap, nka, Wp, nkw, out, ldc, Gr=Gp, gr_nkt=nkg, store=store, Cr=Cr, cr_nkt=nkr, Ct=Ct,
-                               ct_nkt=nkt, colsum_into=sums, hi_only=hi_only, tile=tile, **kw)
+        done = eng.gemm_planes(M, N, K, Ap, nka, Wp, nkw, out, ldc, Gr=Gp, gr_nkt=nkg, store=store, Cr=Cr, cr_nkt=nkr,
+                               colsum_into=sums, hi_only=hi_only, tile=tile, **kw)
         torch.cuda.synchronize()
         assert done
         if store:
             assert torch.equal(out, ref_c)
         else:
             assert bool((out == 3.0).all())
-        # every block the consumers read: whole row tiles x k-tiles that hold real rows / columns
         npl = 1 if hi_only else 2            # hi_only: the lo blocks stay as they were (NaN here)
         r_blocks = Cr[:n_r].view(-1, nkr, 2, 512)[:(M + 31) // 32]
         assert torch.equal(r_blocks[:, :, :npl].view(torch.int16),
                            want_r[:n_r].view(-1, nkr, 2, 512)[:(M + 31) // 32][:, :, :npl].view(torch.int16))
-        t_blocks = Ct[:n_t].view(-1, nkt, 2, 512)[:(Ncols + 31) // 32]
-        assert torch.equal(t_blocks[:, :, :npl].view(torch.int16),
-                           want_t[:n_t].view(-1, nkt, 2, 512)[:(Ncols + 31) // 32][:, :, :npl].view(torch.int16))
         if hi_only:
-            assert bool(torch.isnan(r_blocks[:, :, 1].float()).all()) and bool(torch.isnan(t_blocks[:, :, 1].float()).all())
+            assert bool(torch.isnan(r_blocks[:, :, 1].float()).all())
         assert rel_err(sums, ref_c[:, :Ncols].double().sum(0)) < 1e-5
+        if not hi_only:
+            o1 = torch.zeros(M, 96, device=gpu_device)
+            eng.gemm_planes(M, 96, Ncols, Cr, nkr, Xp, nkx, o1, 96)                                   # by rows
+            o2 = torch.zeros(Ncols, 160, device=gpu_device)
+            eng.gemm_planes(Ncols, 160, M, Cr, nkr, Yp, nky, o2, 160, a_fmt=1, b_fmt=1)               # transposed
+            torch.cuda.synchronize()
+            rc = ref_c[:, :Ncols].double()
+            assert rel_err(o1, rc @ X.double()) < 3e-5 and rel_err(o2, rc.t() @ Y.double()) < 3e-5
 
 
 @pytest.mark.parametrize("M,N,K,splitk", [(768, 256, 9000, 4), (384, 128, 2049, 1), (768, 52, 4100, 3)])
