@@ -7,7 +7,7 @@ export TMPDIR=/tmp
 NOBASE="--cpu-baseline-seconds 0 --torch-gpu-baseline-seconds 0 --strong-anchor-batch 0 --graph-steps 0 --three-products-steps 0"
 # 1. kernel statistics + one steady step's timeline, two streams (as the step runs) and one stream (every duration its own)
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/prof2 -o run -- python3 bench.py $NOBASE --steps 12 > $O/prof2.log 2>&1; echo "prof2 rc=$?"
-python3 tools/rocpd_stats.py $O/prof2/run_results.db 45 > $O/kernel_stats_bench_steps12.md 2>&1
+python3 tools/rocpd_stats.py $O/prof2/run_results.db 45 > $O/kernel_stats.md 2>&1
 python3 tools/step_timeline.py $O/prof2/run_results.db > $O/step_timeline_2stream.txt 2>&1
 grep '^{' $O/prof2.log | tail -1 > $O/bench_under_rocprof.json
 rm -rf $O/prof2
