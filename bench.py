@@ -229,10 +229,10 @@ def _roofline(spec, F, timing, precision):
     return {"bound": "mfma", "kernel": kern + " cond_transform forward (F x Ks*D x Ef)",
             "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic,
             "traffic_unit": "bytes per launch (HBM read + write)", "traffic_source": traffic_src,
-            "algorithmic_bytes_per_launch": 4.0 * (F * spec.ldf + KD * spec.ldf + 2 * F * KD),
+            "algorithmic_bytes_per_launch": 4.0 * (F * spec.ldf + KD * spec.ldf + F * KD),
             "algorithmic_bytes_note": "A (F x ldf) and B (Ks D x ldf) once as bf16 hi + lo planes (4 B per element, as fp32); the result c "
-                                      "(F x Ks D) leaves TWICE as bf16 hi + lo planes (row planes for gic and the backward mask, k-major planes "
-                                      "for dW_c = dgi^T c), 4 B per element each, and never as fp32",
+                                      "(F x Ks D) leaves ONCE as bf16 hi + lo planes (4 B per element; one block format serves gic, the backward mask "
+                                      "and, read transposed, dW_c = dgi^T c), and never as fp32",
             "mfma_flops_multiplier": mult, "frac_of_mfma_issue": mult * ach / peak,
             "flops_per_launch": flops, "flops_per_launch_algorithmic": flops_alg,
             "achieved_algorithmic": flops_alg / (ms * 1e-3) / 1e12 if n_launch else None,

@@ -44,7 +44,6 @@ struct FlowK {
   // backward recurrent weights pre-split into bf16 hi / lo 32-k fragments (bf16 x 3 walk): [Ks][NG][H16/32][J][4 lane groups],
   // one uint4 per entry and plane; the lo plane follows the hi plane of an image
   const uint4 *xbwh, *xbwz;
-  int bwd_prefetch;        // backward walk: the next cell's forward-stash operands by LDS-DMA into a second LDS region (pf_*)
   int dgi_hi_only;         // the dgi planes' hi halves only (their consumers take them as a rounded A operand: two products)
   __bf16* bDgiR;           // backward walk (bf16x3): dgi also as operand planes of the (Ks F x G) matrix (lfi_flow_seq_bwd_planes)
   int C16, Ch16, H16, Co16, NG;
@@ -1996,25 +1995,6 @@ __global__ __launch_bounds__(NT) void flow_diag_bwd_fast_kernel(FlowK f, int d, 
   if (tz) dh_prev_tile(wq2);
 }
 
-// ---- prefetch of the backward walk's forward-stash operands. The top of every backward cell waited ~5 k cycles for HBM: the
-// gates (16 rows x 4 H floats), h of the previous timestep, a, o and y of ITS frames were requested when the cell began (keeping
-// them in flight from the cell before took ~60 loop-carried VGPRs in a kernel that sits at the 256-VGPR limit, round 2). They are
-// 16 contiguous rows each, so the cell before fetches them by LDS-DMA (global_load_lds_dwordx4: no registers) into a region of
-// their own behind the cell's LDS operands, issued right after its Q0 barrier; by the next cell's top they have long landed.
-// Image: five blocks of 16 rows, every row padded by one 16-byte chunk (row stride = 4 mod 32 banks... the four row groups of a
-// wave's lanes then read different banks); chunk p of the image comes from source chunk pf_src(p) (the pad chunks re-read
-// the block's first chunk).
-struct PfLayout { int cG, cH, cA, cO, cY, total, ninstr; };   // 16-byte chunks per block (16 padded rows each), their sum
-__host__ __device__ inline PfLayout pf_layout(int H, int LC, int LO) {
-  PfLayout L;
-  L.cG = 16 * (H + 1); L.cH = 16 * (H / 4 + 1); L.cA = 16 * (LC / 4 + 1); L.cO = 16 * (LO / 4 + 1); L.cY = 16 * (LC / 4 + 1);
-  L.total = L.cG + L.cH + L.cA + L.cO + L.cY;
-  L.ninstr = (L.total + 63) / 64;
-  return L;
-}
-typedef __attribute__((address_space(3))) void flds_void;
-typedef __attribute__((address_space(1))) const void fglb_void;
-
 // Backward twin of flow_pipe_fwd_kernel: workgroup (k, bt) keeps flow step k's backward weights, walks n = N-1 .. 0, carries
 // d h (and the LSTM's d c) from timestep n + 1 in registers and receives d x of flow step k + 1 through the same write-through
 // hand-off (bDx tile + progress counter). The z-tile waves need two weight slices (W_ih[:, :Ch] and W_hh): the second one is
@@ -2057,16 +2037,6 @@ __global__ __launch_bounds__(NT) void flow_pipe_bwd_kernel(FlowK f) {
   const float gz = f.gscale / LN2_F;   // d loss / d z = z * gz   (prior term)
   const float dl = -f.gscale / LN2_F;  // d loss / d logdet
   const float dxs = last ? gz : 1.0f;
-  // prefetch image (see pf_layout): float offsets of the five blocks behind the cell's operands
-  const bool pfon = NG == 3 && f.bwd_prefetch != 0;
-  const PfLayout pfl = pf_layout(H, (int)LC, (int)LO);
-  float* pfG = flow_smem + ((cv.total + 3) & ~3);
-  float* pfH = pfG + 4 * pfl.cG;
-  float* pfA = pfH + 4 * pfl.cH;
-  float* pfO = pfA + 4 * pfl.cA;
-  float* pfY = pfO + 4 * pfl.cO;
-  const int rsG = 4 * H + 4, rsH = H + 4, rsA = (int)LC + 4, rsO = (int)LO + 4;   // padded row strides (floats)
-  bool pf_have = false;
 
   // which tiles this wave owns: hidden tile `wave` (Q1, Q2), z tile `wave` (Q2, waves < Ch16/16), channel tile `wave` (Q3)
   const bool th = wave * 16 < H, tz = wave * 16 < Ch, tc = wave * 16 < C;
@@ -2120,21 +2090,7 @@ __global__ __launch_bounds__(NT) void flow_pipe_bwd_kernel(FlowK f) {
   PIPE_STAMP(1, 0);
   // ---- forward-stash operands of Q1 / Q2 / Q3 (written before this launch): in flight under the wait for flow step k + 1
   float sg[4][4], shp[4], sdhf[4], sc2[4], scp[4], sdcf[4], sdxo[4], sa[4];
-  if (pf_have) {   // the cell before fetched this cell's rows into the prefetch image: every wave's pieces landed, then read
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    const int j = tcol < H ? tcol : 0, cc = tcol < C ? tcol : 0;
-    const bool hasp = n > 0;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int rl = kq * 4 + r;
-      const float* gs = pfG + rl * rsG + j;
-      sg[r][0] = gs[0]; sg[r][1] = gs[H]; sg[r][2] = gs[2 * H]; sg[r][3] = gs[3 * H];
-      shp[r] = hasp ? pfH[rl * rsH + j] : 0.0f;
-      sdhf[r] = dhc[r];
-      sa[r] = pfA[rl * rsA + cc];
-    }
-  } else {
+  {
     const int j = tcol < H ? tcol : 0, cc = tcol < C ? tcol : 0;
     const bool hasp = n > 0;
 #pragma unroll
@@ -2162,10 +2118,10 @@ __global__ __launch_bounds__(NT) void flow_pipe_bwd_kernel(FlowK f) {
   // Q0's forward-stash operands (o of the coupling net, z2) for this thread's element
   float q_oe = 0.0f, q_oo = 0.0f, q_z2 = 0.0f;
   if (cl < C2 && b0 + ri < B) {
-    const float* O = pf_have ? pfO + ri * rsO : f.sO + (kf + b0 + ri) * LO;
+    const float* O = f.sO + (kf + b0 + ri) * LO;
     if (f.affine) {
       q_oe = O[2 * cl]; q_oo = O[2 * cl + 1];
-      q_z2 = pf_have ? pfY[ri * rsA + Ch + cl] : f.sY[(kf + b0 + ri) * LC + Ch + cl];
+      q_z2 = f.sY[(kf + b0 + ri) * LC + Ch + cl];
     } else {
       q_oe = O[cl];
     }
@@ -2231,28 +2187,6 @@ __global__ __launch_bounds__(NT) void flow_pipe_bwd_kernel(FlowK f) {
   }
   __syncthreads();
   PIPE_STAMP(1, 2);
-  pf_have = false;
-  if (pfon && n > 0) {   // (behind the barrier: every thread has taken this cell's values out of the image)
-    const long kfp = kf - B + b0;          // first row of cell n - 1's tile
-    const bool hp2 = n > 1;
-    const float* gG = f.sG + kfp * 4 * H;
-    const float* gH = hp2 ? f.sH + (kfp - B) * H : gG;
-    const float* gA = f.sA + kfp * LC;
-    const float* gO = f.sO + kfp * LO;
-    const float* gY = f.sY + kfp * LC;
-    for (int i = wave; i < pfl.ninstr; i += NT / 64) {
-      int c = i * 64 + lane;
-      const float* src;
-      if (c < pfl.cG) { const int r = c / (H + 1), q = c - r * (H + 1); src = gG + (long)r * 4 * H + (q < H ? q : 0) * 4; }
-      else if ((c -= pfl.cG) < pfl.cH) { const int w = H / 4 + 1, r = c / w, q = c - r * w; src = gH + (long)r * H + (q < H / 4 ? q : 0) * 4; }
-      else if ((c -= pfl.cH) < pfl.cA) { const int w = (int)LC / 4 + 1, r = c / w, q = c - r * w; src = gA + (long)r * LC + (q < LC / 4 ? q : 0) * 4; }
-      else if ((c -= pfl.cA) < pfl.cO) { const int w = (int)LO / 4 + 1, r = c / w, q = c - r * w; src = gO + (long)r * LO + (q < LO / 4 ? q : 0) * 4; }
-      else if ((c -= pfl.cO) < pfl.cY) { const int w = (int)LC / 4 + 1, r = c / w, q = c - r * w; src = gY + (long)r * LC + (q < LC / 4 ? q : 0) * 4; }
-      else src = gG;
-      __builtin_amdgcn_global_load_lds((fglb_void*)src, (flds_void*)(pfG + i * 256), 16, 0, 0);
-    }
-    pf_have = true;
-  }
   if (tid < Cout) {
     float sum = 0.0f;
     for (int i = 0; i < MB; ++i) sum += Pl[i * ldp + tid];
@@ -2383,10 +2317,14 @@ __global__ __launch_bounds__(NT) void flow_pipe_bwd_kernel(FlowK f) {
       const int nktG = G >> 4;
       char* rbase = reinterpret_cast<char*>(f.bDgiR) + ((gr0 >> 5) * nktG * 2) * 1024;
       const int r0 = (int)(gr0 & 16);                // this tile's 16 rows inside the 32-row plane tile
-      for (int u = et; u < 2 * G; u += ne) {         // u = 16 (2 ct + h) + i: chunk h of row r0 + i of block (row tile, ct)
-        const int i = u & 15, q = u >> 4;
-        const int so = i * ldx + (q >> 1) * 16 + (q & 1) * 8;
-        char* dst = rbase + (long)(q >> 1) * 2048 + lfi_u_plane_offset(r0 + i, q & 1);
+      // u = 32 ct + 2 i + hp: the chunk that lies hp-th in row r0 + i of block (row tile, ct): consecutive threads write consecutive
+      // 16 bytes, 32 threads the 512 contiguous bytes this tile owns of a block (a row's two chunks in one store instruction:
+      // the per-half mapping left every store at a 32-byte stride and the backward walk 0.11 ms longer)
+      for (int u = et; u < 2 * G; u += ne) {
+        const int hp = u & 1, i = (u >> 1) & 15, ct = u >> 5;
+        const int h = hp ^ (((r0 + i) >> 3) & 1);    // which 8 columns lie there (lfi_u_plane_offset)
+        const int so = i * ldx + ct * 16 + h * 8;
+        char* dst = rbase + (long)ct * 2048 + (r0 + i) * 32 + hp * 16;
         *reinterpret_cast<uint4*>(dst) = *reinterpret_cast<const uint4*>(GiH + so);
         if (!f.dgi_hi_only) *reinterpret_cast<uint4*>(dst + 1024) = *reinterpret_cast<const uint4*>(GiL + so);
       }
@@ -3165,30 +3103,17 @@ extern "C" int lfi_flow_seq_bwd_planes(const lfi_flow_dims* d, const lfi_flow_pa
     f.pipe_fence = flow_pipe_fence();
     // (NG * H16 >= 128: the bf16 operand images, 64 (NG H16 + 8) bytes each, must fit the fp32 regions they replace)
     const bool x3 = (d->gemm_precision & 1) && !f.lstm && (f.H16 % 32 == 0) && f.NG * f.H16 >= 128 && flow_pipe_x3_enabled();
-    // LDS-DMA prefetch of the next cell's stash rows: whole 16-row tiles (B a multiple of 16), 16-byte granular rows, room in LDS
-    size_t plds = lds;
-    {
-      const char* e = getenv("LFI_PIPE_PREFETCH");
-      const PfLayout L = pf_layout(f.H, f.ldc, f.ldo);
-      const size_t need = (((size_t)cf.total + 3) & ~(size_t)3) * sizeof(float) + (size_t)L.ninstr * 1024;
-      // OFF unless LFI_PIPE_PREFETCH=1: measured slower (round 3, gpurun_out/c10: backward timestep 27.9 k -> 33.9 k ticks, step
-      // 7.95 -> 7.98 ms). vmcnt retires in order, so the 6-7 DMA pieces a wave issues after Q0 sit in front of its Q1 / Q2 weight
-      // and tile loads and expose their HBM latency there (Q1 5.9 k -> 9.6 k ticks), and the extra wait + barrier at the cell's top
-      // costs more than the LDS reads save (top 6.9 k -> 10.2 k). Kept as a documented negative result; bit-identical either way.
-      f.bwd_prefetch = ((e && e[0] == '1') && !f.lstm && f.B % MB == 0 && f.H % 4 == 0 && need <= 160 * 1024) ? 1 : 0;
-      if (f.bwd_prefetch) plds = need;
-    }
-    rc = f.lstm ? set_flow_lds(flow_pipe_bwd_kernel<4, false>, plds, "lfi_flow_seq_bwd")
-                : (x3 ? set_flow_lds(flow_pipe_bwd_kernel<3, true>, plds, "lfi_flow_seq_bwd")
-                      : set_flow_lds(flow_pipe_bwd_kernel<3, false>, plds, "lfi_flow_seq_bwd"));
+    rc = f.lstm ? set_flow_lds(flow_pipe_bwd_kernel<4, false>, lds, "lfi_flow_seq_bwd")
+                : (x3 ? set_flow_lds(flow_pipe_bwd_kernel<3, true>, lds, "lfi_flow_seq_bwd")
+                      : set_flow_lds(flow_pipe_bwd_kernel<3, false>, lds, "lfi_flow_seq_bwd"));
     if (rc) return rc;
     hipError_t me = hipMemsetAsync(f.pipe, 0, (size_t)pipe_words(f) * sizeof(unsigned), st);
     LFI_REQUIRE(me == hipSuccess, "lfi_flow_seq_bwd: hipMemsetAsync: %s", hipGetErrorString(me));
     if (flow_pipe_force_abort()) (void)hipMemsetAsync(f.pipe + 1, 1, sizeof(unsigned), st);
     const dim3 grid(f.Ks * f.nbt);
-    if (f.lstm) hipLaunchKernelGGL((flow_pipe_bwd_kernel<4, false>), grid, dim3(NT), plds, st, f);
-    else if (x3) hipLaunchKernelGGL((flow_pipe_bwd_kernel<3, true>), grid, dim3(NT), plds, st, f);
-    else hipLaunchKernelGGL((flow_pipe_bwd_kernel<3, false>), grid, dim3(NT), plds, st, f);
+    if (f.lstm) hipLaunchKernelGGL((flow_pipe_bwd_kernel<4, false>), grid, dim3(NT), lds, st, f);
+    else if (x3) hipLaunchKernelGGL((flow_pipe_bwd_kernel<3, true>), grid, dim3(NT), lds, st, f);
+    else hipLaunchKernelGGL((flow_pipe_bwd_kernel<3, false>), grid, dim3(NT), lds, st, f);
     hipLaunchKernelGGL(flow_pipe_poison_kernel, dim3(1), dim3(64), 0, st, f);
   }
   for (int dg = f.N + f.Ks - 2; !pipe && dg >= 0; --dg) {
