@@ -119,7 +119,7 @@ __device__ __forceinline__ void coupling_net_phase(const FlowK& f, const CellIO&
           io.c_out[(long)row * H + j] = c2;
           if (io.g_out) {
             float* gs = io.g_out + (long)row * 4 * H;
-            gs[j] = ii; gs[H + j] = ff; gs[2 * H + j] = gg; gs[3 * H + j] = oo;
+            *reinterpret_cast<f32x4*>(gs + 4 * j) = (f32x4){ii, ff, gg, oo};   // gate-interleaved stash: one 16-byte store
           }
         }
         if (jok) Hn[j * LT + i] = hnew;
@@ -152,7 +152,7 @@ __device__ __forceinline__ void coupling_net_phase(const FlowK& f, const CellIO&
         io.h_out[(long)row * H + j] = hnew;
         if (io.g_out) {
           float* gs = io.g_out + (long)row * 4 * H;
-          gs[j] = rr; gs[H + j] = uu; gs[2 * H + j] = nn; gs[3 * H + j] = ghn;
+          *reinterpret_cast<f32x4*>(gs + 4 * j) = (f32x4){rr, uu, nn, ghn};
         }
       }
       if (jok) Hn[j * LT + i] = hnew;
@@ -534,7 +534,8 @@ __global__ __launch_bounds__(NT) void flow_diag_bwd_kernel(FlowK f, int d, int k
             if (row < B) {
               const float dhn = acc[r] + (dhf ? dhf[(long)row * H + j] : 0.0f);
               const float* gs = gs_base + (long)row * 4 * H;
-              const float ii = gs[j], ff = gs[H + j], gg = gs[2 * H + j], oo = gs[3 * H + j];
+              const f32x4 g4 = *reinterpret_cast<const f32x4*>(gs + 4 * j);
+              const float ii = g4[0], ff = g4[1], gg = g4[2], oo = g4[3];
               const float tc = tanhf_(c_base[(long)row * H + j]);
               const float cp = cp_base ? cp_base[(long)row * H + j] : 0.0f;
               const float dc2 = dhn * oo * (1.0f - tc * tc) + (dcf ? dcf[(long)row * H + j] : 0.0f);
@@ -568,7 +569,8 @@ __global__ __launch_bounds__(NT) void flow_diag_bwd_kernel(FlowK f, int d, int k
           if (row < B) {
             const float dhn = acc[r] + (dhf ? dhf[(long)row * H + j] : 0.0f);
             const float* gs = gs_base + (long)row * 4 * H;
-            const float rr = gs[j], uu = gs[H + j], nn = gs[2 * H + j], ghn = gs[3 * H + j];
+            const f32x4 g4 = *reinterpret_cast<const f32x4*>(gs + 4 * j);
+            const float rr = g4[0], uu = g4[1], nn = g4[2], ghn = g4[3];
             const float hp = hp_base ? hp_base[(long)row * H + j] : 0.0f;
             const float du = dhn * (hp - nn);
             const float dn = dhn * (1.0f - uu);
@@ -892,8 +894,10 @@ __device__ __forceinline__ void fast_cell_p2_gates(const FlowK& f, const float* 
       if (row < rows) {
         h_out[(long)row * H + j2] = hnew;
         if (g_out) {
-          float* gs = g_out + (long)row * 4 * H + j2;
-          gs[0] = gs0; gs[H] = gs1; gs[2 * H] = gs2; gs[3 * H] = gs3;
+          // the four stashed gate values of (row, hidden unit) lie together: ONE 16-byte store here and one 16-byte load in the
+          // backward cell instead of four dword accesses each (the walks are bound by vector-memory instruction issue:
+          // without the P2 stash stores the forward walk ran 11 % faster)
+          *reinterpret_cast<f32x4*>(g_out + (long)row * 4 * H + 4 * j2) = (f32x4){gs0, gs1, gs2, gs3};
         }
       }
     }
@@ -1188,6 +1192,12 @@ __global__ __launch_bounds__(NT) void flow_diag_fwd_fast_kernel(FlowK f, int d, 
 // running (more workgroups than CUs simply run as successive groups of flow steps). Every spin is bounded: on timeout
 // the abort word is set, every workgroup leaves its loop, and the host reports LFI_ERR_LAUNCH.
 constexpr unsigned PIPE_HDR = 4;                 // ticket, abort, 2 reserved words
+#ifndef LFI_PIPE_STRIDE
+#define LFI_PIPE_STRIDE 32
+#endif
+constexpr unsigned PIPE_STRIDE = LFI_PIPE_STRIDE;   // words between two progress words of the persistent walks: one 128-byte line each (the polls of 256 workgroups
+                                                    // on eight shared lines queued at one memory channel)
+constexpr unsigned PIPE_WALK_HDR = PIPE_STRIDE > PIPE_HDR ? PIPE_STRIDE : PIPE_HDR;
 constexpr unsigned PIPE_SPIN_LIMIT = 1u << 23;   // polls (each >= ~0.5 us) before giving up
 
 __device__ __forceinline__ unsigned ld_agent(const unsigned* p) {
@@ -1288,7 +1298,7 @@ __global__ __launch_bounds__(NT) void flow_pipe_fwd_kernel(FlowK f) {
   const int k = id / nbt, bt = id - k * nbt;   // tickets in arrival order: (k - 1, bt) always started before (k, bt)
   if (k >= f.Ks) return;
   unsigned* abort_w = f.pipe + 1;
-  unsigned* prog = f.pipe + PIPE_HDR;
+  unsigned* prog = f.pipe + PIPE_WALK_HDR;
   const bool fenced = f.pipe_fence != 0;
   const int b0 = bt * MB;
   const int B = f.B, C = f.C, H = f.H, Ch = f.Ch, C2 = f.C2, Cout = f.Cout, G = f.G;
@@ -1342,7 +1352,16 @@ __global__ __launch_bounds__(NT) void flow_pipe_fwd_kernel(FlowK f) {
   }
   if (t3) {
     const f32x4* p = reinterpret_cast<const f32x4*>(f.pwfl + (long)k * H16 * Co16) + (long)kq_0 * Co16 + tcol_0;
-    for (int b = 0; b < nbH; ++b) w3s[b * 64] = p[(long)b * 4 * Co16];
+    if constexpr (X3) {   // LinearZeros on the bf16 x 3 MFMA too: the same fragments, two 16-k blocks packed into one 32-k block (hi, lo)
+      uint4* w3x = reinterpret_cast<uint4*>(w3s);
+      for (int b2 = 0; b2 < (nbH >> 1); ++b2) {
+        const X3Frag fr = x3_pack(p[(long)(2 * b2) * 4 * Co16], p[(long)(2 * b2 + 1) * 4 * Co16]);
+        w3x[(2 * b2) * 64] = __builtin_bit_cast(uint4, fr.hi);
+        w3x[(2 * b2 + 1) * 64] = __builtin_bit_cast(uint4, fr.lo);
+      }
+    } else {
+      for (int b = 0; b < nbH; ++b) w3s[b * 64] = p[(long)b * 4 * Co16];
+    }
   }
   // bf16 x 3: operand images of the recurrent cell (fast_cell_p2_x3_img)
   const int ldxi = Ch16 + H16 + 8;
@@ -1388,6 +1407,19 @@ __global__ __launch_bounds__(NT) void flow_pipe_fwd_kernel(FlowK f) {
   // predecessor, where the peek succeeds every time; a miss just takes the blocking path.
   bool have_next = false;
   float xnext[2] = {0.0f, 0.0f};
+  // conditioning part of the gates (written by the GEMM before this launch): cell 0's here, cell n + 1's behind P2 of cell n,
+  // into the registers P2 has just finished with (at the top of the cell these loads sat in front of the tile's in the
+  // in-order vmcnt queue: -2 % on the walk)
+  float gc[4][NG];
+  {
+    const float* gicb = f.gic + (long)k * f.F * G;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int rw = min(b0 + kq_0 * 4 + r, B - 1);
+#pragma unroll
+      for (int g = 0; g < NG; ++g) gc[r][g] = gicb[(long)rw * G + g * H + jc];
+    }
+  }
   for (int n = 0; n < f.N; ++n) {
     // lane coordinates laundered per iteration: otherwise every per-lane stash address (a dozen arrays x 4 rows, 64-bit) is
     // hoisted out of the timestep loop and the kernel spills ~150 VGPRs
@@ -1397,18 +1429,7 @@ __global__ __launch_bounds__(NT) void flow_pipe_fwd_kernel(FlowK f) {
     const long fr = (long)n * B;
     const long kf = (long)k * f.F + fr;
     PIPE_STAMP(0, 0);
-    // conditioning part of the gates for this timestep (written by the GEMM before this launch): in flight under the wait
-    float gc[4][NG];
-    {
-      const float* gicb = f.gic + kf * G;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int rw = min(b0 + kq * 4 + r, B - 1);
-#pragma unroll
-        for (int g = 0; g < NG; ++g) gc[r][g] = gicb[(long)rw * G + g * H + jc];
-      }
-    }
-    if (k > 0 && !have_next && !pipe_acquire(prog + (k - 1) * nbt + bt, (unsigned)n + 1u, abort_w, tid, &s_ok, fenced)) break;
+    if (k > 0 && !have_next && !pipe_acquire(prog + ((k - 1) * nbt + bt) * PIPE_STRIDE, (unsigned)n + 1u, abort_w, tid, &s_ok, fenced)) break;
 
     PIPE_STAMP(0, 1);
     // ---- P0: actnorm (glow/modules.py:45-52); stage a k-major
@@ -1465,12 +1486,41 @@ __global__ __launch_bounds__(NT) void flow_pipe_fwd_kernel(FlowK f) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) cprev[r] = cnew[r];
     }
+    if (n + 1 < f.N) {
+      const float* gicb = f.gic + (kf + B) * G;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int rw = min(b0 + kq * 4 + r, B - 1);
+#pragma unroll
+        for (int g = 0; g < NG; ++g) gc[r][g] = gicb[(long)rw * G + g * H + jc];
+      }
+    }
     __syncthreads();
     PIPE_STAMP(0, 4);
 
     // ---- P3: o = (h' Wfl^T + b) exp(3 logs)   (LinearZeros, glow/modules.py:93-95)
     if (t3) {
-      const f32x4 acc = mma16_lds(Hn + kq * LT + l15, w3s, nbH);
+      f32x4 acc;
+      if constexpr (X3) {
+        // A = h' from the bf16 hi / lo image the gate epilogue has just written for the next cell's recurrent product (inh):
+        // one 16-byte read per plane and 32 k, three bf16 MFMAs - the exact-f32 MFMA (1/16 of the rate) was 8 % of the walk
+        const __bf16* rh = inh + l15 * ldxi + 8 * kq + Ch16;
+        const __bf16* rl = rh + MB * ldxi;
+        const uint4* w3x = reinterpret_cast<const uint4*>(w3s);
+        f32x4 e = {0.f, 0.f, 0.f, 0.f}, o = {0.f, 0.f, 0.f, 0.f};
+        for (int b2 = 0; b2 < (nbH >> 1); ++b2) {
+          X3Frag av, wv;
+          av.hi = *reinterpret_cast<const fbf16x8*>(rh + b2 * 32);
+          av.lo = *reinterpret_cast<const fbf16x8*>(rl + b2 * 32);
+          wv.hi = __builtin_bit_cast(fbf16x8, w3x[(2 * b2) * 64]);
+          wv.lo = __builtin_bit_cast(fbf16x8, w3x[(2 * b2 + 1) * 64]);
+          if (b2 & 1) o = x3_mma(av, wv, o);
+          else e = x3_mma(av, wv, e);
+        }
+        acc = e + o;
+      } else {
+        acc = mma16_lds(Hn + kq * LT + l15, w3s, nbH);
+      }
       if (tcol < Cout) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -1488,7 +1538,7 @@ __global__ __launch_bounds__(NT) void flow_pipe_fwd_kernel(FlowK f) {
     // ---- P4: coupling (glow/models.py:330-341), pass-through half, log-det; the output tile is the hand-off payload
     const bool peek = k > 0 && !fenced && n + 1 < f.N;
     unsigned pk = 0u;
-    if (peek && tid == 0) pk = ld_agent(prog + (k - 1) * nbt + bt);
+    if (peek && tid == 0) pk = ld_agent(prog + ((k - 1) * nbt + bt) * PIPE_STRIDE);
     {
       float lg = 0.0f;
       if (cl < C2) {
@@ -1515,7 +1565,7 @@ __global__ __launch_bounds__(NT) void flow_pipe_fwd_kernel(FlowK f) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (peek && tid == 0) s_rdy = pk >= (unsigned)n + 2u ? 1 : 0;
     __syncthreads();
-    if (k + 1 < f.Ks && tid == 0) st_agent(prog + k * nbt + bt, (unsigned)n + 1u);
+    if (k + 1 < f.Ks && tid == 0) st_agent(prog + (k * nbt + bt) * PIPE_STRIDE, (unsigned)n + 1u);
     have_next = peek && s_rdy != 0;
     if (have_next) {
       const float* xn = f.sX + (kf + B - f.F + row) * LC;   // cell n + 1 of step k - 1
@@ -1805,8 +1855,8 @@ __global__ __launch_bounds__(NT) void flow_diag_bwd_fast_kernel(FlowK f, int d, 
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const long row = min(b0 + kq * 4 + r, B - 1);
-      const float* gs = f.sG + (kf + row) * 4 * H + j;
-      sg[r][0] = gs[0]; sg[r][1] = gs[H]; sg[r][2] = gs[2 * H]; sg[r][3] = gs[3 * H];
+      const f32x4 g4 = *reinterpret_cast<const f32x4*>(f.sG + (kf + row) * 4 * H + 4 * j);
+      sg[r][0] = g4[0]; sg[r][1] = g4[1]; sg[r][2] = g4[2]; sg[r][3] = g4[3];
       shp[r] = hasp ? f.sH[(kf - B + row) * H + j] : 0.0f;
       sdhf[r] = hasn ? f.bDh[(kf + B + row) * H + j] : 0.0f;
       if (NG == 4) {
@@ -2012,7 +2062,7 @@ __global__ __launch_bounds__(NT) void flow_pipe_bwd_kernel(FlowK f) {
   if (kk >= f.Ks) return;
   const int k = f.Ks - 1 - kk;   // tickets in arrival order: (k + 1, bt) always started before (k, bt)
   unsigned* abort_w = f.pipe + 1;
-  unsigned* prog = f.pipe + PIPE_HDR;
+  unsigned* prog = f.pipe + PIPE_WALK_HDR;
   const bool fenced = f.pipe_fence != 0;
   const int b0 = bt * MB;
   const int B = f.B, C = f.C, H = f.H, Ch = f.Ch, C2 = f.C2, Cout = f.Cout, G = f.G;
@@ -2043,7 +2093,23 @@ __global__ __launch_bounds__(NT) void flow_pipe_bwd_kernel(FlowK f) {
   const int tcol_0 = wave * 16 + l15_0;
   // ---- weights of Q1 (dlin Wfl: K = Cout) for this wave's hidden tile
   f32x4 wq1[FB_O];
+  {
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int b = 0; b < FB_O; ++b) wq1[b] = zero4;
+  }
   load_frag<FB_O>(wq1, f.bwfl + (long)k * Co16 * H16, H16, tcol_0, kq_0, nbO, th);
+  // bf16 x 3: Q1's product too (dlin Wfl, K = Cout): the fragments packed into 32-k blocks, the A operand d lin as a bf16
+  // hi / lo image [16][ldxd] that Q0 writes (x3_put, slot order x3_pos) behind the regions of the exact path
+  X3Frag wq1x[FB_O / 2];
+  const int nbO2 = (nbO + 1) >> 1, ldxd = 32 * nbO2 + 8;
+  __bf16* DlH = reinterpret_cast<__bf16*>(flow_smem + ((cv.total + 3) & ~3));
+  __bf16* DlL = DlH + MB * ldxd;
+  if constexpr (X3) {
+#pragma unroll
+    for (int b2 = 0; b2 < FB_O / 2; ++b2) wq1x[b2] = x3_pack(wq1[2 * b2], wq1[2 * b2 + 1]);
+    for (int q = tid; q < 2 * MB * ldxd; q += NT) DlH[q] = (__bf16)0.0f;
+  }
   // W_hh slice of this wave's hidden tile: resident, except in the z-tile waves, which need two slices (W_ih[:, :Ch] for
   // d z1, then W_hh) and stream both through the same registers every timestep, as the per-diagonal kernel does
   f32x4 wq2[X3 ? 1 : NG][X3 ? 1 : FB_H];      // exact f32 form
@@ -2096,8 +2162,8 @@ __global__ __launch_bounds__(NT) void flow_pipe_bwd_kernel(FlowK f) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const long row = min(b0 + kq * 4 + r, B - 1);
-      const float* gs = f.sG + (kf + row) * 4 * H + j;
-      sg[r][0] = gs[0]; sg[r][1] = gs[H]; sg[r][2] = gs[2 * H]; sg[r][3] = gs[3 * H];
+      const f32x4 g4 = *reinterpret_cast<const f32x4*>(f.sG + (kf + row) * 4 * H + 4 * j);
+      sg[r][0] = g4[0]; sg[r][1] = g4[1]; sg[r][2] = g4[2]; sg[r][3] = g4[3];
       shp[r] = hasp ? f.sH[(kf - B + row) * H + j] : 0.0f;
       sdhf[r] = dhc[r];
       if (NG == 4) {
@@ -2126,7 +2192,7 @@ __global__ __launch_bounds__(NT) void flow_pipe_bwd_kernel(FlowK f) {
       q_oe = O[cl];
     }
   }
-  if (!last && !have_next && !pipe_acquire(prog + (k + 1) * nbt + bt, (unsigned)(f.N - n), abort_w, tid, &s_ok, fenced)) break;
+  if (!last && !have_next && !pipe_acquire(prog + ((k + 1) * nbt + bt) * PIPE_STRIDE, (unsigned)(f.N - n), abort_w, tid, &s_ok, fenced)) break;
   {
     const int cz = tcol < Ch ? tcol : 0;
 #pragma unroll
@@ -2170,14 +2236,20 @@ __global__ __launch_bounds__(NT) void flow_pipe_bwd_kernel(FlowK f) {
       }
       Dy[(Ch + cl) * LT + ri] = dz2;
       if (f.affine) {
-        Dl[(2 * cl) * LT + ri] = dl0; Dl[(2 * cl + 1) * LT + ri] = dl1;
+        if constexpr (X3) {
+          x3_put(DlH, DlL, ri * ldxd + x3_pos(2 * cl), dl0);
+          x3_put(DlH, DlL, ri * ldxd + x3_pos(2 * cl + 1), dl1);
+        } else {
+          Dl[(2 * cl) * LT + ri] = dl0; Dl[(2 * cl + 1) * LT + ri] = dl1;
+        }
         Pl[ri * ldp + 2 * cl] = p0; Pl[ri * ldp + 2 * cl + 1] = p1;
       } else {
-        Dl[cl * LT + ri] = dl0;
+        if constexpr (X3) x3_put(DlH, DlL, ri * ldxd + x3_pos(cl), dl0);
+        else Dl[cl * LT + ri] = dl0;
         Pl[ri * ldp + cl] = p0;
       }
     }
-    for (int c = Cout + cl; c < Co16; c += 32) Dl[c * LT + ri] = 0.0f;
+    if (!X3) for (int c = Cout + cl; c < Co16; c += 32) Dl[c * LT + ri] = 0.0f;
     for (int c = C + cl; c < C16; c += 32) Dy[c * LT + ri] = 0.0f;
     for (int j = H + cl; j < H16; j += 32) {
 #pragma unroll
@@ -2195,7 +2267,24 @@ __global__ __launch_bounds__(NT) void flow_pipe_bwd_kernel(FlowK f) {
 
   // ---- Q1: d h' = dlin Wfl + dh carried from timestep n + 1; recurrent cell backward
   if (th) {
-    const f32x4 acc = mma16_reg<FB_O>(Dl + kq * LT + l15, wq1, nbO);
+    f32x4 acc;
+    if constexpr (X3) {
+      const __bf16* rh = DlH + l15 * ldxd + 8 * kq;
+      const __bf16* rl = DlL + l15 * ldxd + 8 * kq;
+      f32x4 e = {0.f, 0.f, 0.f, 0.f}, o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int b2 = 0; b2 < FB_O / 2; ++b2)
+        if (b2 < nbO2) {
+          X3Frag av;
+          av.hi = *reinterpret_cast<const fbf16x8*>(rh + b2 * 32);
+          av.lo = *reinterpret_cast<const fbf16x8*>(rl + b2 * 32);
+          if (b2 & 1) o = x3_mma(av, wq1x[b2], o);
+          else e = x3_mma(av, wq1x[b2], e);
+        }
+      acc = e + o;
+    } else {
+      acc = mma16_reg<FB_O>(Dl + kq * LT + l15, wq1, nbO);
+    }
     const int j = tcol;
     if (j < H) {
 #pragma unroll
@@ -2305,7 +2394,7 @@ __global__ __launch_bounds__(NT) void flow_pipe_bwd_kernel(FlowK f) {
   // ---- Q3: d a = dy W^T ; actnorm backward ; d x_in to flow step k - 1
   const bool peek = !last && !fenced && n > 0;
   unsigned pk = 0u;
-  if (peek && tid == 0) pk = ld_agent(prog + (k + 1) * nbt + bt);
+  if (peek && tid == 0) pk = ld_agent(prog + ((k + 1) * nbt + bt) * PIPE_STRIDE);
   if constexpr (X3) {
     // dgi of this cell as operand planes (include/lfi.h) for the two products that consume it - dpre = dgi W_c sums over gate
     // columns, dW_c = dgi^T c over frames: one set of planes serves both - straight from the bf16 hi / lo LDS images Q1 left: one
@@ -2359,7 +2448,7 @@ __global__ __launch_bounds__(NT) void flow_pipe_bwd_kernel(FlowK f) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if (peek && tid == 0) s_rdy = pk >= (unsigned)(f.N - n) + 1u ? 1 : 0;
   __syncthreads();
-  if (k > 0 && tid == 0) st_agent(prog + k * nbt + bt, (unsigned)(f.N - n));
+  if (k > 0 && tid == 0) st_agent(prog + (k * nbt + bt) * PIPE_STRIDE, (unsigned)(f.N - n));
   have_next = peek && s_rdy != 0;
   if (have_next) {
     const float* dxn = f.bDx + (kf - B + f.F) * LC;   // cell n - 1 of flow step k + 1
@@ -2836,7 +2925,8 @@ long stash_offsets(const FlowK& f, long* off) {
   off[1] = o; o += KF * f.ldc;       // y
   off[2] = o; o += KF * f.ldc;       // x_out
   off[3] = o; o += KF * f.H;         // h
-  off[4] = o; o += KF * 4 * f.H;     // gates
+  o = (o + 3) & ~3L;
+  off[4] = o; o += KF * 4 * f.H;     // gates: [frame][hidden unit][4], read and written 16 bytes at a time
   off[5] = o; o += KF * f.ldo;       // o      (rows of ldo = Cout rounded up to 4 floats)
   off[6] = o; o += KF;               // coupling log-det
   off[7] = o; o += f.lstm ? KF * f.H : 0;  // LSTM cell state
@@ -2858,7 +2948,7 @@ long bstash_offsets(const FlowK& f, long* off) {
   return o;
 }
 // persistent-pipeline state appended to either stash: header + one progress word per (flow step, batch tile), padded to 16 bytes
-long pipe_words(const FlowK& f) { return ((long)PIPE_HDR + (long)f.Ks * f.nbt + 3) & ~3L; }
+long pipe_words(const FlowK& f) { return ((long)PIPE_WALK_HDR + (long)f.Ks * f.nbt * PIPE_STRIDE + 3) & ~3L; }
 long align4(long x) { return (x + 3) & ~3L; }
 void bind_stash(FlowK* f, float* stash) {
   long off[8];
@@ -3103,17 +3193,19 @@ extern "C" int lfi_flow_seq_bwd_planes(const lfi_flow_dims* d, const lfi_flow_pa
     f.pipe_fence = flow_pipe_fence();
     // (NG * H16 >= 128: the bf16 operand images, 64 (NG H16 + 8) bytes each, must fit the fp32 regions they replace)
     const bool x3 = (d->gemm_precision & 1) && !f.lstm && (f.H16 % 32 == 0) && f.NG * f.H16 >= 128 && flow_pipe_x3_enabled();
-    rc = f.lstm ? set_flow_lds(flow_pipe_bwd_kernel<4, false>, lds, "lfi_flow_seq_bwd")
-                : (x3 ? set_flow_lds(flow_pipe_bwd_kernel<3, true>, lds, "lfi_flow_seq_bwd")
-                      : set_flow_lds(flow_pipe_bwd_kernel<3, false>, lds, "lfi_flow_seq_bwd"));
+    // + the bf16 hi / lo image of d lin (Q1's bf16 x 3 operand): 2 x MB rows of 32 ceil(Co16 / 32) + 8 bf16
+    const size_t plds = x3 ? (((size_t)cf.total + 3) & ~(size_t)3) * sizeof(float) + (size_t)2 * MB * (32 * ((f.Co16 + 31) / 32) + 8) * 2 : lds;
+    rc = f.lstm ? set_flow_lds(flow_pipe_bwd_kernel<4, false>, plds, "lfi_flow_seq_bwd")
+                : (x3 ? set_flow_lds(flow_pipe_bwd_kernel<3, true>, plds, "lfi_flow_seq_bwd")
+                      : set_flow_lds(flow_pipe_bwd_kernel<3, false>, plds, "lfi_flow_seq_bwd"));
     if (rc) return rc;
     hipError_t me = hipMemsetAsync(f.pipe, 0, (size_t)pipe_words(f) * sizeof(unsigned), st);
     LFI_REQUIRE(me == hipSuccess, "lfi_flow_seq_bwd: hipMemsetAsync: %s", hipGetErrorString(me));
     if (flow_pipe_force_abort()) (void)hipMemsetAsync(f.pipe + 1, 1, sizeof(unsigned), st);
     const dim3 grid(f.Ks * f.nbt);
-    if (f.lstm) hipLaunchKernelGGL((flow_pipe_bwd_kernel<4, false>), grid, dim3(NT), lds, st, f);
-    else if (x3) hipLaunchKernelGGL((flow_pipe_bwd_kernel<3, true>), grid, dim3(NT), lds, st, f);
-    else hipLaunchKernelGGL((flow_pipe_bwd_kernel<3, false>), grid, dim3(NT), lds, st, f);
+    if (f.lstm) hipLaunchKernelGGL((flow_pipe_bwd_kernel<4, false>), grid, dim3(NT), plds, st, f);
+    else if (x3) hipLaunchKernelGGL((flow_pipe_bwd_kernel<3, true>), grid, dim3(NT), plds, st, f);
+    else hipLaunchKernelGGL((flow_pipe_bwd_kernel<3, false>), grid, dim3(NT), plds, st, f);
     hipLaunchKernelGGL(flow_pipe_poison_kernel, dim3(1), dim3(64), 0, st, f);
   }
   for (int dg = f.N + f.Ks - 2; !pipe && dg >= 0; --dg) {
