@@ -12,3 +12,4 @@ timeout -k 10 200 python __graft_entry__.py smoke > $O/smoke.log 2>&1; echo "smo
 LFI_DIST_BACKEND=gloo timeout -k 10 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 2 --steps 5 --warmup 2 > $O/bench_n2_gloo.json 2> $O/bench_n2_gloo.err; echo "n2 gloo rc=$?"
 export LFI_PARITY_REPORT=$O/parity.txt
 timeout -k 10 1100 python -m pytest tests -x -q -m gpu > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -3 $O/pytest_gpu.log
+timeout -k 10 300 python tools/pipe_stamps.py > $O/pipe_stamps.txt 2>&1; echo "stamps rc=$?"

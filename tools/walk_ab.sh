@@ -1,4 +1,6 @@
-# usage: tools/_ab.sh <outtag> <variant> [<variant> ...]: walk kernel times of build/var/liblfi_<variant>.so
+# A/B of kernel variants in ONE gpurun call: build each variant of a .hip file to build/var/liblfi_<variant>.so (it travels to the box; the
+# library is picked by LFI_LIB_PATH), then   tools/walk_ab.sh <outtag> <variant> [<variant> ...]   prints, per variant, the walk tests'
+# outcome (SKIPT=1 skips them: ingredient-removal builds compute garbage), the bench step time and the flow walks' rocprofv3 kernel times
 set -u
 TAG=$1; shift
 O=gpurun_out/$TAG; mkdir -p $O
