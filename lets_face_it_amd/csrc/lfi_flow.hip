@@ -1352,16 +1352,7 @@ __global__ __launch_bounds__(NT) void flow_pipe_fwd_kernel(FlowK f) {
   }
   if (t3) {
     const f32x4* p = reinterpret_cast<const f32x4*>(f.pwfl + (long)k * H16 * Co16) + (long)kq_0 * Co16 + tcol_0;
-    if constexpr (X3) {   // LinearZeros on the bf16 x 3 MFMA too: the same fragments, two 16-k blocks packed into one 32-k block (hi, lo)
-      uint4* w3x = reinterpret_cast<uint4*>(w3s);
-      for (int b2 = 0; b2 < (nbH >> 1); ++b2) {
-        const X3Frag fr = x3_pack(p[(long)(2 * b2) * 4 * Co16], p[(long)(2 * b2 + 1) * 4 * Co16]);
-        w3x[(2 * b2) * 64] = __builtin_bit_cast(uint4, fr.hi);
-        w3x[(2 * b2 + 1) * 64] = __builtin_bit_cast(uint4, fr.lo);
-      }
-    } else {
-      for (int b = 0; b < nbH; ++b) w3s[b * 64] = p[(long)b * 4 * Co16];
-    }
+    for (int b = 0; b < nbH; ++b) w3s[b * 64] = p[(long)b * 4 * Co16];
   }
   // bf16 x 3: operand images of the recurrent cell (fast_cell_p2_x3_img)
   const int ldxi = Ch16 + H16 + 8;
@@ -1500,27 +1491,10 @@ __global__ __launch_bounds__(NT) void flow_pipe_fwd_kernel(FlowK f) {
 
     // ---- P3: o = (h' Wfl^T + b) exp(3 logs)   (LinearZeros, glow/modules.py:93-95)
     if (t3) {
-      f32x4 acc;
-      if constexpr (X3) {
-        // A = h' from the bf16 hi / lo image the gate epilogue has just written for the next cell's recurrent product (inh):
-        // one 16-byte read per plane and 32 k, three bf16 MFMAs - the exact-f32 MFMA (1/16 of the rate) was 8 % of the walk
-        const __bf16* rh = inh + l15 * ldxi + 8 * kq + Ch16;
-        const __bf16* rl = rh + MB * ldxi;
-        const uint4* w3x = reinterpret_cast<const uint4*>(w3s);
-        f32x4 e = {0.f, 0.f, 0.f, 0.f}, o = {0.f, 0.f, 0.f, 0.f};
-        for (int b2 = 0; b2 < (nbH >> 1); ++b2) {
-          X3Frag av, wv;
-          av.hi = *reinterpret_cast<const fbf16x8*>(rh + b2 * 32);
-          av.lo = *reinterpret_cast<const fbf16x8*>(rl + b2 * 32);
-          wv.hi = __builtin_bit_cast(fbf16x8, w3x[(2 * b2) * 64]);
-          wv.lo = __builtin_bit_cast(fbf16x8, w3x[(2 * b2 + 1) * 64]);
-          if (b2 & 1) o = x3_mma(av, wv, o);
-          else e = x3_mma(av, wv, e);
-        }
-        acc = e + o;
-      } else {
-        acc = mma16_lds(Hn + kq * LT + l15, w3s, nbH);
-      }
+      // (exact f32 MFMA in every mode: o sets the coupling's scale and shift directly, and the inverse pass - sampling, invert -
+      // computes it in exact f32; with three bf16 products here decode(encode(x)) at 96 flow steps went from 7e-4 to 3e-3 of x
+      // for 20 us of a 500 us walk)
+      const f32x4 acc = mma16_lds(Hn + kq * LT + l15, w3s, nbH);
       if (tcol < Cout) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
