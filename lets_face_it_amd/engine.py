@@ -832,7 +832,7 @@ class GlowEngine:
             # 112 x 5 tiles = 1.09 rounds of the 512 resident workgroups: split K so the tail round is full too
             self.gemm(F, W, KD, dpre, KD, 1, self.wct_f, s.ldf, 0, dcond, ldd, b_off=col0, tag="gemm_cond_dgrad",
                       splitk=0, cls="cond_dgrad")
-            for e in rnn:
+            for e in self._bptt_order(rnn):
                 if e.enc == "mlp":
                     self._mlp_backward(e, ctx, dcond, ldd, e.fcol - col0)
                 else:
@@ -906,12 +906,21 @@ class GlowEngine:
             wp, nkw = self._wct_planes
             self.gemm_planes(F, W, KD, dpre_p, nkKD, wp, nkw, dcond, ldd, b_fmt=1, b_off=(col0 // 16) * 1024,
                              splitk=self._planes_splitk(F, W, KD), tag="gemm_cond_dgrad", cls="cond_dgrad")
-            for e in rnn:
+            for e in self._bptt_order(rnn):
                 if e.enc == "mlp":
                     self._mlp_backward(e, ctx, dcond, ldd, e.fcol - col0)
                 else:
                     self._encoder_backward(e, ctx, dcond, ldd, e.fcol - col0)
             self._join()
+
+    @staticmethod
+    def _bptt_order(encoders):
+        """Largest recurrence first: each encoder's window scatter + dW_ih run on the second stream under the NEXT encoder's
+        BPTT kernel, so what is left uncovered at the end of the step is the LAST encoder's - which should be the smallest
+        (the encoders' gradients are independent of each other; the order changes no value)."""
+        if os.environ.get("LFI_ENC_BWD_ORDER", "1") == "0":
+            return list(encoders)
+        return sorted(encoders, key=lambda e: -(e.hist * e.hid * e.hid))
 
     def _mlp_backward(self, e, ctx, dcond, lddcond, col):
         """Linear + LeakyReLU window encoder: dpre = dfeat * leaky'(feat); dW = dpre^T window, db = colsum(dpre)."""
