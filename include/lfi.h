@@ -55,7 +55,10 @@ typedef struct {
   int precision;              /* 0: exact fp32 (f32-input MFMA). 1: bf16x3 — operands split into bf16 hi + lo on the fly,
                                  three bf16 MFMAs per step into fp32 accumulators (~2^-16 relative); needs 16-byte aligned
                                  operands, otherwise the exact kernel runs. Tests may OR in 0x10 (force the 256 x 256 tile
-                                 kernel) or 0x20 (force 128 x 128) instead of the library's own choice. Bits 8 / 9 (0x100 / 0x200) DROP the
+                                 kernel) or 0x20 (force 128 x 128) instead of the library's own choice. Bit 2 (1 | 4 = 5): SIX bf16
+                                 products of three-piece operands (x = p0 + p1 + p2, 24 mantissa bits; what is dropped is 2^-24 relative:
+                                 fp32-grade results at 6/16 of the f32-input MFMA's cost; 128 x 128 tiles; the sampler's per-frame
+                                 products). Bits 8 / 9 (0x100 / 0x200) DROP the
                                  a_lo * b_hi / a_hi * b_lo product of the bf16x3 kernels (a measurement switch: what each GEMM
                                  class loses with one or two bf16 passes, tools/precision_sweep.py -> profiles/precision_sweep.md;
                                  never set by the engine's default configuration) */

@@ -3409,7 +3409,8 @@ extern "C" int lfi_flow_sample_seq(const lfi_flow_dims* d, const lfi_flow_params
   // LFI_SAMPLE_CHAIN=0 keeps one launch per flow step
   const char* ce = getenv("LFI_SAMPLE_CHAIN");
   const bool chain = fast && !(ce && ce[0] == '0');
-  const bool x3 = (d->gemm_precision & 1) && !f.lstm && (f.H16 % 32 == 0) && (f.Ch16 % 32 == 0) && flow_pipe_x3_enabled();
+  // (gemm_precision bit 2 - six bf16 products in the per-frame GEMMs, fp32-grade - goes with exact f32 cells)
+  const bool x3 = (d->gemm_precision & 1) && !(d->gemm_precision & 4) && !f.lstm && (f.H16 % 32 == 0) && (f.Ch16 % 32 == 0) && flow_pipe_x3_enabled();
   unsigned* chain_state = reinterpret_cast<unsigned*>((reinterpret_cast<uintptr_t>(xb + (long)B * C) + 15) & ~(uintptr_t)15);
   const size_t chain_words = (size_t)(((long)PIPE_HDR + (long)Ks * f.nbt + 3) & ~3L);
   // raw prev_p1_face windows start (t - hist1) * C floats into a row: 16-byte aligned only on every other frame at C = 50,

@@ -201,6 +201,21 @@ __device__ __forceinline__ void split4(const f32x4 v, bf16x4* hi, bf16x4* lo) {
   }
 }
 
+// x = p0 + p1 + p2 with three bf16 pieces (8 + 8 + 8 mantissa bits: all 24 of an fp32 but the last rounding): the six-product
+// form of the kernel below (XT == 3) sums p2 b0 + p0 b2 + p1 b1 + p1 b0 + p0 b1 + p0 b0 - what is dropped is 2^-24 relative, the
+// fp32 rounding itself - at 6/16 of the f32-input MFMA's cost
+__device__ __forceinline__ void split4x3(const f32x4 v, bf16x4* p0, bf16x4* p1, bf16x4* p2) {
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const __bf16 h = (__bf16)v[j];
+    const float r1 = v[j] - (float)h;
+    const __bf16 m = (__bf16)r1;
+    (*p0)[j] = h;
+    (*p1)[j] = m;
+    (*p2)[j] = (__bf16)(r1 - (float)m);
+  }
+}
+
 template <bool KC>
 struct XStager {
   // KC: four float4 along k per thread; !KC: one 4(k) x 4(mn) patch per thread (four float4 along mn)
@@ -261,6 +276,30 @@ struct XStager {
       }
     }
   }
+  __device__ __forceinline__ void store3(__bf16* img0, __bf16* img1, __bf16* img2, int krem, f32x4 (&r)[4]) const {
+    if (KC) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int j = 1; j < 4; ++j) r[i][j] = (kk[i] + j < krem) ? r[i][j] : 0.0f;
+        bf16x4 a, b, c;
+        split4x3(r[i], &a, &b, &c);
+        *reinterpret_cast<bf16x4*>(img0 + lds[i]) = a;
+        *reinterpret_cast<bf16x4*>(img1 + lds[i]) = b;
+        *reinterpret_cast<bf16x4*>(img2 + lds[i]) = c;
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const f32x4 col = {r[0][i], r[1][i], r[2][i], r[3][i]};
+        bf16x4 a, b, c;
+        split4x3(col, &a, &b, &c);
+        *reinterpret_cast<bf16x4*>(img0 + (mn_l + i) * XROW + kg4) = a;
+        *reinterpret_cast<bf16x4*>(img1 + (mn_l + i) * XROW + kg4) = b;
+        *reinterpret_cast<bf16x4*>(img2 + (mn_l + i) * XROW + kg4) = c;
+      }
+    }
+  }
 };
 
 template <bool AKC, bool BKC, int XT = 0>
@@ -291,11 +330,17 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(GemmArgs g) {
     sa.load(tA + kt * stepA, krem, ra);
     sb.load(tB + kt * stepB, krem, rb);
   };
+  constexpr int NIMG = XT == 3 ? 6 : 4;   // images per buffer: A hi, A lo, B hi, B lo - or three pieces of each (six products)
   auto store_tiles = [&](int kt, int buf) {
     const int krem = kend - (kbeg + kt * XBK);
-    __bf16* base = xsmem + buf * 4 * XIMG;
-    sa.store(base, base + XIMG, krem, ra);
-    sb.store(base + 2 * XIMG, base + 3 * XIMG, krem, rb);
+    __bf16* base = xsmem + buf * NIMG * XIMG;
+    if constexpr (XT == 3) {
+      sa.store3(base, base + XIMG, base + 2 * XIMG, krem, ra);
+      sb.store3(base + 3 * XIMG, base + 4 * XIMG, base + 5 * XIMG, krem, rb);
+    } else {
+      sa.store(base, base + XIMG, krem, ra);
+      sb.store(base + 2 * XIMG, base + 3 * XIMG, krem, rb);
+    }
   };
 
   const int wm = wave >> 1, wn = wave & 1;
@@ -315,7 +360,35 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(GemmArgs g) {
   for (int kt = 0; kt < nkt; ++kt) {
     const int buf = kt & 1;
     if (kt + 1 < nkt) load_tiles(kt + 1);
-    const __bf16* base = xsmem + buf * 4 * XIMG;
+    const __bf16* base = xsmem + buf * NIMG * XIMG;
+    if constexpr (XT == 3) {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        bf16x8 a0[2], a1[2], a2[2], b0[2], b1[2], b2[2];
+#pragma unroll
+        for (int t2 = 0; t2 < 2; ++t2) {
+          const int ro = (wm * 64 + t2 * 32 + l31) * XROW + ks * 16 + half * 8;
+          const int co = (wn * 64 + t2 * 32 + l31) * XROW + ks * 16 + half * 8;
+          a0[t2] = *reinterpret_cast<const bf16x8*>(base + ro);
+          a1[t2] = *reinterpret_cast<const bf16x8*>(base + XIMG + ro);
+          a2[t2] = *reinterpret_cast<const bf16x8*>(base + 2 * XIMG + ro);
+          b0[t2] = *reinterpret_cast<const bf16x8*>(base + 3 * XIMG + co);
+          b1[t2] = *reinterpret_cast<const bf16x8*>(base + 4 * XIMG + co);
+          b2[t2] = *reinterpret_cast<const bf16x8*>(base + 5 * XIMG + co);
+        }
+        // smallest terms first: (2,0) (0,2) (1,1) | (1,0) (0,1) | (0,0)
+#define LFI_X6(AP, BP)                                                                                                     \
+  _Pragma("unroll") for (int mt = 0; mt < 2; ++mt) _Pragma("unroll") for (int nt = 0; nt < 2; ++nt)                          \
+      acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(AP[mt], BP[nt], acc[mt][nt], 0, 0, 0)
+        LFI_X6(a2, b0);
+        LFI_X6(a0, b2);
+        LFI_X6(a1, b1);
+        LFI_X6(a1, b0);
+        LFI_X6(a0, b1);
+        LFI_X6(a0, b0);
+#undef LFI_X6
+      }
+    } else
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       bf16x8 ah[2], al[2], bh[2], bl[2];
@@ -827,6 +900,7 @@ extern "C" long lfi_gemm_colpart_rows(const lfi_gemm_desc* d) {
   if (!(c_ok && g_ok && !(d->act == 2 && d->accumulate != 0))) return 0;
   GemmPlan plan = gemm_plan(d->M, d->N, d->K, d->batch, 1, true);
   if (d->precision & 0x30) plan.shape = (d->precision & 0x10) ? 3 : 0;
+  if (d->precision & 4) plan.shape = 0;
   return plan.shape == 3 ? (long)lfi_cdiv(d->M, 256) * (256 / LFI_EPI_ROWS) : (long)lfi_cdiv(d->M, 128);
 }
 
@@ -855,6 +929,8 @@ extern "C" int lfi_gemm_f32(const lfi_gemm_desc* d, void* stream) {
   }
   GemmPlan plan = gemm_plan(d->M, d->N, d->K, d->batch, (d->splitk == 0 && !d->work) ? 1 : d->splitk, use_x3 || d->a_bf16);
   if (use_x3 && (d->precision & 0x30)) plan.shape = (d->precision & 0x10) ? 3 : 0;  // tests pin the tile shape (lfi.h)
+  const bool x6 = use_x3 && (d->precision & 4) && !d->a_bf16;   // six products: fp32-grade, 128 x 128 kernel only
+  if (x6) plan.shape = 0;
   if (d->a_bf16) plan.shape = 3;
   int splitk = plan.splitk < 1 ? 1 : plan.splitk;
   if (splitk > d->K / BKT) splitk = d->K / BKT < 1 ? 1 : d->K / BKT;
@@ -920,9 +996,10 @@ extern "C" int lfi_gemm_f32(const lfi_gemm_desc* d, void* stream) {
                                         : launch_x3_256<0>(a, d->a_kcontig, d->b_kcontig, grid, lds, st));   // (<1>: see launch_x3_256)
     if (rcl) return rcl;
   } else if (use_x3) {
-    const size_t lds = (size_t)2 * 4 * XIMG * sizeof(__bf16);
+    const size_t lds = (size_t)2 * (x6 ? 6 : 4) * XIMG * sizeof(__bf16);
     {
-      const int rcl = a.skip ? launch_x3_128<2>(a, d->a_kcontig, d->b_kcontig, grid, lds, st)
+      const int rcl = x6 ? launch_x3_128<3>(a, d->a_kcontig, d->b_kcontig, grid, lds, st)
+                      : a.skip ? launch_x3_128<2>(a, d->a_kcontig, d->b_kcontig, grid, lds, st)
                              : (a.colpart ? launch_x3_128<1>(a, d->a_kcontig, d->b_kcontig, grid, lds, st)
                                           : launch_x3_128<0>(a, d->a_kcontig, d->b_kcontig, grid, lds, st));
       if (rcl) return rcl;

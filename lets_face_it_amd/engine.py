@@ -225,7 +225,11 @@ class GlowEngine:
         # prev_p1_face window (profiles/round3_sample_precision.md: 95.7 -> 123 ms per 1024 x 300 call; the static part - window
         # encoders, non-autoregressive cond_transform columns - stays in the engine's mode). LFI_SAMPLE_FRAME_PRECISION=bf16x3
         # (or this attribute = 1) buys the 29 % back for callers that do not need the last 3e-5.
-        self.sample_frame_precision = 1 if os.environ.get("LFI_SAMPLE_FRAME_PRECISION") == "bf16x3" else 0
+        # In bf16x3 engine mode the per-frame GEMMs take SIX bf16 products of three-piece operands (lfi_gemm_desc.precision 5:
+        # fp32-grade, 6/16 of the f32-input MFMA's cost) next to exact-f32 reverse cells: same error as all-f32 (value 5);
+        # LFI_SAMPLE_FRAME_PRECISION=f32 keeps everything on the f32-input MFMA (0).
+        # (None = by engine mode: 5 in bf16x3 mode, 0 in f32 mode)
+        self.sample_frame_precision = {"bf16x3": 1, "f32": 0, "bf16x6": 5}.get(os.environ.get("LFI_SAMPLE_FRAME_PRECISION", ""))
         self._mask_calls = 0
         # GEMM class -> bf16x3 products to drop (bit 0: a_lo b_hi, bit 1: a_hi b_lo; 3 = plain bf16 operands, one product).
         # Measurement switch only: profiles/precision_sweep.md (tools/precision_sweep.py, final widths, against the fp64
@@ -1161,8 +1165,8 @@ class GlowEngine:
         else:
             pre[:F * KD].view(F, KD).copy_(self.fview("bct").reshape(1, KD).expand(F, KD))
         dims = self._flow_dims(B, nframes)
-        if self.sample_frame_precision is not None:
-            dims.gemm_precision = int(self.sample_frame_precision)
+        fp = self.sample_frame_precision
+        dims.gemm_precision = int(fp) if fp is not None else (5 if self.precision == 1 else 0)
         h = self._buf("sample_h", s.Ks * B * s.H, zero=True)
         cs = self._buf("sample_c", s.Ks * B * s.H, zero=True) if s.rnn_type == "lstm" else None
         work = self._buf("scratch.sample", self.L.lfi_flow_sample_work_floats(C.byref(dims)))

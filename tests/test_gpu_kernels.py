@@ -4,7 +4,7 @@ import ctypes as C
 import pytest
 import torch
 
-from helpers import rel_err
+from helpers import rel_err, report
 
 pytestmark = pytest.mark.gpu
 
@@ -149,6 +149,48 @@ def test_gemm_bf16x3(eng, gpu_device, akc, bkc, shape):
     assert torch.isfinite(Cm).all()
     err = rel_err(Cm, ref)
     assert err < 3e-5, err
+
+
+@pytest.mark.parametrize("akc,bkc", [(1, 1), (1, 0), (0, 1), (0, 0)])
+@pytest.mark.parametrize("shape", [(260, 136, 890), (1024, 384, 512), (1000, 96, 2500), (64, 64, 100)])
+def test_gemm_six_bf16_products_are_fp32_grade(eng, gpu_device, akc, bkc, shape):
+    """lfi_gemm_desc.precision 5: operands in three bf16 pieces, six products (the sampler's per-frame GEMMs). What is dropped
+    is 2^-24 relative - the fp32 rounding itself: its error against fp64 must be that of the exact f32-input MFMA kernel
+    (within 1.5x; both are bounded by fp32 accumulation over K) and well below the three-product kernel's."""
+    M, N, K = shape
+    g = torch.Generator().manual_seed(M + N + K + 2 * akc + bkc)
+    r4 = lambda v: (v + 3) // 4 * 4  # noqa: E731
+    lda, ldb = (r4(K) + 4 if akc else r4(M) + 4), (r4(K) + 8 if bkc else r4(N))
+    A = torch.zeros((M, lda) if akc else (K, lda))
+    Bm = torch.zeros((N, ldb) if bkc else (K, ldb))
+    if akc:
+        A[:, :K] = torch.randn(M, K, generator=g)
+    else:
+        A[:, :M] = torch.randn(K, M, generator=g)
+    if bkc:
+        Bm[:, :K] = torch.randn(N, K, generator=g)
+    else:
+        Bm[:, :N] = torch.randn(K, N, generator=g)
+    A, Bm = A.to(gpu_device), Bm.to(gpu_device)
+    bias = torch.randn(N, generator=g).to(gpu_device)
+    Ad = (A[:, :K] if akc else A[:, :M].t()).double()
+    Bd = (Bm[:, :K].t() if bkc else Bm[:, :N]).double()
+    ref = Ad @ Bd + bias.double()
+    errs = {}
+    for mode in (0, 1, 5):
+        Cm = torch.zeros(M, N, device=gpu_device)
+        eng.precision = mode
+        try:
+            eng.gemm(M, N, K, A, lda, akc, Bm, ldb, bkc, Cm, N, bias=bias, splitk=4 if K >= 2000 else 1)
+        finally:
+            eng.precision = 0
+        torch.cuda.synchronize()
+        assert torch.isfinite(Cm).all()
+        errs[mode] = rel_err(Cm, ref)
+    report("GEMM %s (A %s, B %s): rel L2 err vs fp64: exact f32 %.2e, three bf16 products %.2e, six %.2e"
+           % (shape, "k-contig" if akc else "mn-contig", "k-contig" if bkc else "mn-contig", errs[0], errs[1], errs[5]))
+    assert errs[5] < max(1.5 * errs[0], 2e-7), errs
+    assert errs[5] < 0.5 * errs[1], errs
 
 
 @pytest.mark.parametrize("akc,bkc", [(1, 1), (1, 0), (0, 1), (0, 0)])
