@@ -215,6 +215,7 @@ class GlowEngine:
         self.prep = None
         self._last = None
         self.timers = None  # {tag: [(start_event, end_event), ...]} when kernel timing is switched on (bench.py)
+        self._timer_tags = None
         # GEMM arithmetic: 0 = exact fp32 on the f32-input MFMA; 1 = bf16x3 (fp32 operands split into bf16 hi + lo on the
         # fly, three bf16 MFMAs per step, fp32 accumulation: ~2^-16 relative, 16x the MFMA rate)
         self.precision = 0
@@ -271,11 +272,15 @@ class GlowEngine:
         return (2 if frames >= 8192 else 3) if bp == "auto" else int(bp)
 
     # ------------------------------------------------------------------ per-kernel timing (HIP events on the launch stream)
-    def enable_timing(self, on=True):
+    def enable_timing(self, on=True, only=None):
+        """Per-kernel HIP events around the tagged launches (bench.py). only: an iterable of tags to restrict them to - every
+        event record is a marker packet in the stream's queue and costs the step ~6 us of dispatch gap (18 of them per step
+        with every tag on: 0.1 ms of an 8 ms step)."""
         self.timers = {} if on else None
+        self._timer_tags = None if only is None else set(only)
 
     def _tic(self, tag):
-        if self.timers is None or tag is None:
+        if self.timers is None or tag is None or (self._timer_tags is not None and tag not in self._timer_tags):
             return None
         ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
         ev[0].record()
