@@ -102,9 +102,9 @@ class LetsFaceItGlow(nn.Module):
     # memory: the dropout key and Adam's bias-corrected step size (include/lfi.h, lfi_set_step_params); the ordinary and the
     # negative-example step (loss x -0.1, lets_face_it_glow.py:40-50) are two graphs. Parameters after replayed steps are
     # bit-identical to eager steps' (tests/test_gpu_headline_parity.py). Measured on MI355X / ROCm 7.0 (profiles/round3_*): host
-    # issue 1.5 -> 0.8-1.0 ms per step (hipGraphLaunch of ~100 nodes on two streams is not free), GPU step time about 1 % shorter
-    # (7.86 -> 7.73, 7.93 -> 7.87 ms: the gaps between dependent dispatches; the eager step's queue is already kept full by the
-    # host running ahead). OFF by default; bench.py reports both. Always eager: data-parallel steps (the collectives stay
+    # issue 1.5 -> 0.8-1.0 ms per step (hipGraphLaunch of ~100 nodes on two streams is not free), GPU step time level with the
+    # eager step's (7.71 vs 7.74 ms: the eager queue is already kept full by the host running ahead).
+    # OFF by default; bench.py reports both. Always eager: data-parallel steps (the collectives stay
     # outside any graph), injected masks, ActNorm's data-dependent init, per-kernel timing (HIP events cannot bracket a kernel
     # inside a replay).
     def _graph_key(self, batch, negative, eng):
