@@ -331,6 +331,9 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(GemmArgs g) {
     sb.load(tB + kt * stepB, krem, rb);
   };
   constexpr int NIMG = XT == 3 ? 6 : 4;   // images per buffer: A hi, A lo, B hi, B lo - or three pieces of each (six products)
+  // six products: ONE LDS buffer (60 KB; with two, 120 KB, only one workgroup fits a CU and the sampler's small per-frame
+  // products - 384 and 512 tiles for 256 CUs - ran in two half-empty rounds) at the price of a second barrier per k-tile
+  constexpr int NBUF = XT == 3 ? 1 : 2;
   auto store_tiles = [&](int kt, int buf) {
     const int krem = kend - (kbeg + kt * XBK);
     __bf16* base = xsmem + buf * NIMG * XIMG;
@@ -358,7 +361,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(GemmArgs g) {
   }
   __syncthreads();
   for (int kt = 0; kt < nkt; ++kt) {
-    const int buf = kt & 1;
+    const int buf = NBUF == 2 ? (kt & 1) : 0;
     if (kt + 1 < nkt) load_tiles(kt + 1);
     const __bf16* base = xsmem + buf * NIMG * XIMG;
     if constexpr (XT == 3) {
@@ -420,7 +423,8 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(GemmArgs g) {
 #pragma unroll
         for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt], bh[nt], acc[mt][nt], 0, 0, 0);
     }
-    if (kt + 1 < nkt) store_tiles(kt + 1, buf ^ 1);
+    if (NBUF == 1) __syncthreads();   // every wave has read tile kt before it is overwritten
+    if (kt + 1 < nkt) store_tiles(kt + 1, NBUF == 2 ? (buf ^ 1) : 0);
     __syncthreads();
   }
   // 80 KB of dynamic LDS: the whole 128 x 132 fp32 tile image (67.6 KB) fits, one pass
@@ -996,7 +1000,8 @@ extern "C" int lfi_gemm_f32(const lfi_gemm_desc* d, void* stream) {
                                         : launch_x3_256<0>(a, d->a_kcontig, d->b_kcontig, grid, lds, st));   // (<1>: see launch_x3_256)
     if (rcl) return rcl;
   } else if (use_x3) {
-    const size_t lds = (size_t)2 * (x6 ? 6 : 4) * XIMG * sizeof(__bf16);
+    const size_t lds = x6 ? (size_t)128 * 132 * sizeof(float)   // one buffer of six images (60 KB) < the epilogue's tile image
+                          : (size_t)2 * 4 * XIMG * sizeof(__bf16);
     {
       const int rcl = x6 ? launch_x3_128<3>(a, d->a_kcontig, d->b_kcontig, grid, lds, st)
                       : a.skip ? launch_x3_128<2>(a, d->a_kcontig, d->b_kcontig, grid, lds, st)
