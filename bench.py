@@ -416,6 +416,16 @@ def _dtype_label(precision, eng, frames):
         "three products in the forward GEMMs, two in the backward GEMMs" if not eng.pass_skip else _products_label(precision, eng, frames))
 
 
+def _sample_frame_label(eng):
+    fp = eng.sample_frame_precision
+    if fp is None:
+        fp = 5 if eng.precision == 1 else 0
+    return {0: "per-frame GEMMs and reverse cells on the exact f32-input MFMA",
+            1: "per-frame GEMMs and the reverse cells' recurrent products as three bf16 products (2^-16 relative)",
+            5: "per-frame GEMMs as six bf16 products of three-piece operands (fp32-grade: what is dropped is 2^-24 relative); "
+               "reverse cells on the exact f32-input MFMA"}.get(int(fp), str(fp))
+
+
 def bench_sample(args, model, spec, device, world, rank, hp):
     """BASELINE.json configs[3]: SeqGlow.inference, batch 1024, seq_len 300, seed frames zeros, eps 1."""
     B = args.batch if args.batch != 256 else 1024
@@ -464,7 +474,8 @@ def bench_sample(args, model, spec, device, world, rank, hp):
         "data": "synthetic",
         "config": {"workload": "autoregressive sampling, batch %d, seq_len %d (%d generated frames per sequence), "
                                "BASELINE.json configs[3]" % (B, T, nframes), "K": spec.Ks, "H": spec.H,
-                   "parallelism": "replicas%d" % world, "gemm_precision": args.precision},
+                   "parallelism": "replicas%d" % world, "gemm_precision": args.precision,
+                   "autoregressive_part": _sample_frame_label(eng)},
         "ms_per_generated_frame": 1e3 * elapsed / args.steps / nframes,
         "finite": bool(torch.isfinite(out_faces).all()),
         "roofline": {"bound": "mfma", "kernel": "hipGraph of the per-frame sequence x %d frames: 2 conditioning GEMMs + state "
