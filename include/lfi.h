@@ -328,7 +328,7 @@ int lfi_invconv_weights(int C, const float* inv_l, const float* inv_u, const flo
  * Whole sequence in one call. faces (B x seq_len x C, batch-first) holds the `start` seed frames and receives the
  * generated ones. Per frame t: c = LeakyReLU(pre_static[n] + faces[:, t-hist1:t] Wct[:, :hist1*C]^T) for all Ks steps
  * (pre_static = everything of cond_transform that does not depend on generated frames, bias included:
- * (nframes*B) x (Ks*D), frame-major), gic = c W_ih[:, Ch:]^T + b_ih, then the Ks reverse flow steps from the
+ * (nframes*B) x (Ks*D), frame-major; CONSUMED: c of frame n is written over its rows), gic = c W_ih[:, Ch:]^T + b_ih, then the Ks reverse flow steps from the
  * injected prior noise (nframes x B x C, already scaled by eps_std). h: [Ks][B][H] recurrent state, zero on entry.
  * Only "enc: none" for p1_face (all shipped hparams). work: lfi_flow_sample_work_floats floats. */
 /* The autoregressive prev_p1_face window may itself go through a ModalityEncoder (the reference's hparam search draws
@@ -348,7 +348,7 @@ long lfi_flow_sample_work_floats(const lfi_flow_dims* d);
 long lfi_flow_sample_p1_work_floats(const lfi_flow_dims* d, const lfi_p1enc* e, int hist1);
 int lfi_flow_sample_seq(const lfi_flow_dims* d, const lfi_flow_params* p, const float* prep,
                         const float* wct /* [Ks*D][E] */, long E, int hist1,
-                        const float* pre_static, const float* noise,
+                        float* pre_static, const float* noise,
                         float* faces, int seq_len, int start, int nframes,
                         float* h, float* cstate /* [Ks][B][H] LSTM cell state, zero on entry; NULL for GRU */,
                         const lfi_p1enc* p1 /* NULL = "none" */, float* p1work /* lfi_flow_sample_p1_work_floats */,

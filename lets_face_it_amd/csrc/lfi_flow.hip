@@ -3379,7 +3379,7 @@ extern "C" long lfi_flow_sample_work_floats(const lfi_flow_dims* d) {
 }
 
 extern "C" int lfi_flow_sample_seq(const lfi_flow_dims* d, const lfi_flow_params* p, const float* prep, const float* wct,
-                                   long E, int hist1, const float* pre_static, const float* noise, float* faces, int seq_len,
+                                   long E, int hist1, float* pre_static, const float* noise, float* faces, int seq_len,
                                    int start, int nframes, float* h, float* cstate, const lfi_p1enc* p1, float* p1work,
                                    float* work, void* stream) {
   FlowK f = {};
@@ -3394,8 +3394,7 @@ extern "C" int lfi_flow_sample_seq(const lfi_flow_dims* d, const lfi_flow_params
   LFI_REQUIRE(p1kind == 0 || (p1work && p1->hid > 0), "lfi_flow_sample_seq: encoded p1_face window needs p1work");
   const int p1col = p1 ? p1->col : 0;
   const int B = f.B, C = f.C, H = f.H, D = f.D, Ks = f.Ks, G = f.G;
-  float* cbuf = work;                          // B x Ks*D
-  float* gic = cbuf + (long)B * Ks * D;        // [Ks][B][G]
+  float* gic = work + (long)B * Ks * D;        // [Ks][B][G]   (the first B x Ks*D floats: round 2's copy of c, unused now)
   float* xa = gic + (long)Ks * B * G;          // B x C ping
   float* xb = xa + (long)B * C;                // B x C pong
   hipStream_t st = (hipStream_t)stream;
@@ -3426,18 +3425,14 @@ extern "C" int lfi_flow_sample_seq(const lfi_flow_dims* d, const lfi_flow_params
   }
   for (int n = 0; n < nframes; ++n) {
     const int t = start + n;
-    // c = LeakyReLU(pre_static[n] + window @ Wct[:, :hist1*C]^T)
-    hipError_t e = hipMemcpyAsync(cbuf, pre_static + (long)n * B * Ks * D, sizeof(float) * (size_t)B * Ks * D,
-                                  hipMemcpyDeviceToDevice, st);
-    if (e != hipSuccess) {
-      lfi_set_error("lfi_flow_sample_seq: memcpy failed: %s", hipGetErrorString(e));
-      return LFI_ERR_LAUNCH;
-    }
+    // c = LeakyReLU(pre_static[n] + window @ Wct[:, :hist1*C]^T), IN PLACE: frame n's rows of pre_static are read by this product
+    // alone, so they are its pre-activation addend and its output at once (a 32 MB copy per frame into a separate c otherwise)
+    float* cfr = pre_static + (long)n * B * Ks * D;
     lfi_gemm_desc q = {};
     q.batch = 1; q.M = B; q.N = Ks * D; q.K = hist1 * C;
     q.A = faces + (long)(t - hist1) * C; q.lda = (long)seq_len * C; q.a_kcontig = 1;
     q.B = wct + p1col; q.ldb = E; q.b_kcontig = 1;
-    q.C = cbuf; q.ldc = (long)Ks * D; q.accumulate = 2; q.act = 1; q.slope = 0.01f; q.precision = d->gemm_precision;
+    q.C = cfr; q.ldc = (long)Ks * D; q.accumulate = 2; q.act = 1; q.slope = 0.01f; q.precision = d->gemm_precision;
     if (p1kind != 0) {
       // features of the window first: e (B x hid4), then c = LeakyReLU(pre_static + e Wct[:, col : col + hid]^T)
       const int hid = p1->hid, hid4 = (hid + 3) & ~3;
@@ -3478,7 +3473,7 @@ extern "C" int lfi_flow_sample_seq(const lfi_flow_dims* d, const lfi_flow_params
     // gic[k] = c[:, kD:(k+1)D] @ W_ih[k][:, Ch:]^T + b_ih[k]
     lfi_gemm_desc r = {};
     r.batch = Ks; r.M = B; r.N = G; r.K = D;
-    r.A = cbuf; r.lda = (long)Ks * D; r.a_kcontig = 1; r.strideA = D;
+    r.A = cfr; r.lda = (long)Ks * D; r.a_kcontig = 1; r.strideA = D;
     r.B = f.wc; r.ldb = D; r.b_kcontig = 1; r.strideB = (long)G * D;
     r.C = gic; r.ldc = G; r.strideC = (long)B * G;
     r.bias = p->b_ih; r.strideBias = G; r.precision = d->gemm_precision;
