@@ -421,9 +421,11 @@ def _sample_frame_label(eng):
     if fp is None:
         fp = 5 if eng.precision == 1 else 0
     return {0: "per-frame GEMMs and reverse cells on the exact f32-input MFMA",
-            1: "per-frame GEMMs and the reverse cells' recurrent products as three bf16 products (2^-16 relative)",
-            5: "per-frame GEMMs as six bf16 products of three-piece operands (fp32-grade: what is dropped is 2^-24 relative); "
-               "reverse cells on the exact f32-input MFMA"}.get(int(fp), str(fp))
+            1: "per-frame GEMMs as three bf16 products (2^-16 relative); the reverse cells' recurrent products as three fp16 "
+               "products (2^-22), their LinearZeros / W^-1 products on the f32-input MFMA",
+            5: "fp32-grade throughout: per-frame GEMMs as six bf16 products of three-piece operands (dropped terms 2^-24 relative), "
+               "the reverse cells' recurrent products as three fp16 products of two-piece operands (2^-22), their LinearZeros / "
+               "W^-1 products on the f32-input MFMA"}.get(int(fp), str(fp))
 
 
 def bench_sample(args, model, spec, device, world, rank, hp):

@@ -796,6 +796,45 @@ __device__ __forceinline__ f32x4 x3_mma(const X3Frag& a, const X3Frag& w, f32x4 
   return acc;
 }
 
+// ---- the same with fp16 pieces (11 + 11 mantissa bits: 2^-22 relative, fp32-grade) for the SAMPLER's reverse cells. Their
+// operands - h in (-1, 1), flow activations, trained weights - sit far inside fp16's range (a value beyond 65504 turns into
+// inf - inf = NaN: loud, as the exact path is at 3e38; tiny values lose nothing that matters: fp16's subnormal spacing, 6e-8,
+// is the absolute error of an fp32 near 1). Gradients do not qualify (1e-10 underflows), so every backward product and the
+// training walks keep bf16 pieces. Same MFMA rate, same register footprint as bf16 x 3.
+typedef _Float16 fh16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 fh16x2 __attribute__((ext_vector_type(2)));
+struct X3FragH { fh16x8 hi, lo; };
+__device__ __forceinline__ void x3h_split2(float a, float b, unsigned* hi, unsigned* lo) {
+  const fh16x2 h = __builtin_convertvector((ffloat2){a, b}, fh16x2);
+  const ffloat2 hf = __builtin_convertvector(h, ffloat2);
+  const fh16x2 l = __builtin_convertvector((ffloat2){a - hf[0], b - hf[1]}, fh16x2);
+  *hi = __builtin_bit_cast(unsigned, h);
+  *lo = __builtin_bit_cast(unsigned, l);
+}
+__device__ __forceinline__ X3FragH x3h_pack(const f32x4& b0, const f32x4& b1) {
+  uint4 h, l;
+  x3h_split2(b0[0], b0[1], &h.x, &l.x);
+  x3h_split2(b0[2], b0[3], &h.y, &l.y);
+  x3h_split2(b1[0], b1[1], &h.z, &l.z);
+  x3h_split2(b1[2], b1[3], &h.w, &l.w);
+  X3FragH r;
+  r.hi = __builtin_bit_cast(fh16x8, h);
+  r.lo = __builtin_bit_cast(fh16x8, l);
+  return r;
+}
+__device__ __forceinline__ X3FragH x3h_a(const float* ab) {
+  f32x4 b0 = {ab[0], ab[4 * LT], ab[8 * LT], ab[12 * LT]};
+  const float* a1 = ab + 16 * LT;
+  f32x4 b1 = {a1[0], a1[4 * LT], a1[8 * LT], a1[12 * LT]};
+  return x3h_pack(b0, b1);
+}
+__device__ __forceinline__ f32x4 x3h_mma(const X3FragH& a, const X3FragH& w, f32x4 acc) {
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.lo, w.hi, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.hi, w.lo, acc, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a.hi, w.hi, acc, 0, 0, 0);
+  return acc;
+}
+
 // this lane's fragments of one 16-column tile of a pre-split backward image: nb2 32-k blocks of gate g
 template <int MAXB2>
 __device__ __forceinline__ void x3_load(X3Frag (&w)[MAXB2], const uint4* __restrict__ img, long per, int g, int nB, int J, int col,
@@ -1016,6 +1055,38 @@ __device__ __forceinline__ void fast_cell_p2_x3(const FlowK& f, const float* Zt,
       const X3Frag a = x3_a(hl + b * 32 * LT);
 #pragma unroll
       for (int g = 0; g < NG; ++g) ah[g] = x3_mma(a, wh[g][b], ah[g]);
+    }
+  fast_cell_p2_gates<NG>(f, Ht, Hn, az, ah, gc, bh, cprev, j2, kq, b0, rows, h_out, c_out, g_out, cnew);
+}
+
+// fp16 x 3 form (x3h_*): the sampler's reverse cells
+template <int NG>
+__device__ __forceinline__ void fast_cell_p2_x3h(const FlowK& f, const float* Zt, const float* Ht, float* Hn,
+                                                 const X3FragH (&wz)[NG][FB_Z / 2], const X3FragH (&wh)[NG][FB_H / 2],
+                                                 const float (&gc)[4][NG], const float (&bh)[NG], const float (&cprev)[4], int nbZ2,
+                                                 int nbH2, int j2, int kq, int l15, int b0, int rows, float* h_out, float* c_out,
+                                                 float* g_out, float* cnew) {
+  f32x4 az[NG], ah[NG];
+#pragma unroll
+  for (int g = 0; g < NG; ++g) {
+    az[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    ah[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+  const float* zl = Zt + kq * LT + l15;
+  const float* hl = Ht + kq * LT + l15;
+#pragma unroll
+  for (int b = 0; b < FB_Z / 2; ++b)
+    if (b < nbZ2) {
+      const X3FragH a = x3h_a(zl + b * 32 * LT);
+#pragma unroll
+      for (int g = 0; g < NG; ++g) az[g] = x3h_mma(a, wz[g][b], az[g]);
+    }
+#pragma unroll
+  for (int b = 0; b < FB_H / 2; ++b)
+    if (b < nbH2) {
+      const X3FragH a = x3h_a(hl + b * 32 * LT);
+#pragma unroll
+      for (int g = 0; g < NG; ++g) ah[g] = x3h_mma(a, wh[g][b], ah[g]);
     }
   fast_cell_p2_gates<NG>(f, Ht, Hn, az, ah, gc, bh, cprev, j2, kq, b0, rows, h_out, c_out, g_out, cnew);
 }
@@ -1630,17 +1701,17 @@ __device__ __forceinline__ void rev_fast_cell(const FlowK& f, const CellIO& io, 
   load_frag<FB_C>(w1, f.pWinv + (long)k * C16 * C16, C16, tcol, kq, nbC, t1);
   __syncthreads();
   if (t2) {
-    if constexpr (X3) {   // bf16 x 3 recurrent products: the fragments split in registers (this launch's weights, used once)
-      X3Frag wzx[NG][FB_Z / 2], whx[NG][FB_H / 2];
+    if constexpr (X3) {   // three fp16 products (fp32-grade, x3h_*): the fragments split in registers (this launch's weights, used once)
+      X3FragH wzx[NG][FB_Z / 2], whx[NG][FB_H / 2];
 #pragma unroll
       for (int g = 0; g < NG; ++g) {
 #pragma unroll
-        for (int b = 0; b < FB_Z / 2; ++b) wzx[g][b] = x3_pack(wz[g][2 * b], wz[g][2 * b + 1]);
+        for (int b = 0; b < FB_Z / 2; ++b) wzx[g][b] = x3h_pack(wz[g][2 * b], wz[g][2 * b + 1]);
 #pragma unroll
-        for (int b = 0; b < FB_H / 2; ++b) whx[g][b] = x3_pack(wh[g][2 * b], wh[g][2 * b + 1]);
+        for (int b = 0; b < FB_H / 2; ++b) whx[g][b] = x3h_pack(wh[g][2 * b], wh[g][2 * b + 1]);
       }
-      fast_cell_p2_x3<NG>(f, Zt, Ht, Hn, wzx, whx, gc, bh, cprev, (nbZ + 1) >> 1, (nbH + 1) >> 1, tcol, kq, l15, b0, rows, io.h_out,
-                          io.c_out, nullptr, nullptr);
+      fast_cell_p2_x3h<NG>(f, Zt, Ht, Hn, wzx, whx, gc, bh, cprev, (nbZ + 1) >> 1, (nbH + 1) >> 1, tcol, kq, l15, b0, rows, io.h_out,
+                           io.c_out, nullptr, nullptr);
     } else {
       fast_cell_p2<NG>(f, Zt, Ht, Hn, wz, wh, gc, bh, cprev, nbZ, nbH, tcol, kq, l15, b0, rows, io.h_out, io.c_out, nullptr);
     }
@@ -3408,8 +3479,8 @@ extern "C" int lfi_flow_sample_seq(const lfi_flow_dims* d, const lfi_flow_params
   // LFI_SAMPLE_CHAIN=0 keeps one launch per flow step
   const char* ce = getenv("LFI_SAMPLE_CHAIN");
   const bool chain = fast && !(ce && ce[0] == '0');
-  // (gemm_precision bit 2 - six bf16 products in the per-frame GEMMs, fp32-grade - goes with exact f32 cells)
-  const bool x3 = (d->gemm_precision & 1) && !(d->gemm_precision & 4) && !f.lstm && (f.H16 % 32 == 0) && (f.Ch16 % 32 == 0) && flow_pipe_x3_enabled();
+  // (the reverse cells' recurrent products as three fp16 products - fp32-grade - in both bf16 modes of the per-frame GEMMs)
+  const bool x3 = (d->gemm_precision & 1) && !f.lstm && (f.H16 % 32 == 0) && (f.Ch16 % 32 == 0) && flow_pipe_x3_enabled();
   unsigned* chain_state = reinterpret_cast<unsigned*>((reinterpret_cast<uintptr_t>(xb + (long)B * C) + 15) & ~(uintptr_t)15);
   const size_t chain_words = (size_t)(((long)PIPE_HDR + (long)Ks * f.nbt + 3) & ~3L);
   // raw prev_p1_face windows start (t - hist1) * C floats into a row: 16-byte aligned only on every other frame at C = 50,

@@ -220,16 +220,15 @@ class GlowEngine:
         # fly, three bf16 MFMAs per step, fp32 accumulation: ~2^-16 relative, 16x the MFMA rate)
         self.precision = 0
         # arithmetic of the AUTOREGRESSIVE part of sample() (per generated frame: the window columns of cond_transform, gic and
-        # the Ks reverse cells' recurrent products): exact f32 by default. At full depth (K = 16 x 56 generated frames) plain fp32
-        # torch is itself 2.4e-5 from the fp64 oracle; with this part in bf16x3 the sampler lands at 5.6e-5, in f32 at 2.7e-5 (gate:
-        # 1.5 x the fp32 floor) whatever the static part uses - every frame's error feeds all later frames through the
-        # prev_p1_face window (profiles/round3_sample_precision.md: 95.7 -> 123 ms per 1024 x 300 call; the static part - window
-        # encoders, non-autoregressive cond_transform columns - stays in the engine's mode). LFI_SAMPLE_FRAME_PRECISION=bf16x3
-        # (or this attribute = 1) buys the 29 % back for callers that do not need the last 3e-5.
-        # In bf16x3 engine mode the per-frame GEMMs take SIX bf16 products of three-piece operands (lfi_gemm_desc.precision 5:
-        # fp32-grade, 6/16 of the f32-input MFMA's cost) next to exact-f32 reverse cells: same error as all-f32 (value 5);
-        # LFI_SAMPLE_FRAME_PRECISION=f32 keeps everything on the f32-input MFMA (0).
-        # (None = by engine mode: 5 in bf16x3 mode, 0 in f32 mode)
+        # the Ks reverse cells). At full depth (K = 16 x 56 generated frames) plain fp32 torch is itself 2.4e-5 from the fp64
+        # oracle, and every frame's error feeds all later frames through the prev_p1_face window: this part has to be
+        # fp32-grade whatever the static part (window encoders, non-autoregressive cond_transform columns) uses - with
+        # three bf16 products here the sampler lands at 4.7e-5 - 5.6e-5 (gate: 1.5 x the fp32 floor). In bf16x3 engine mode it
+        # is, at bf16 MFMA rates (value 5, the default; profiles/round3_sample_precision.md): the per-frame GEMMs as SIX bf16
+        # products of three-piece operands (lfi_gemm_desc.precision 5), the reverse cells' recurrent products as three FP16
+        # products of two-piece operands (11 + 11 mantissa bits; their operands - h, flow activations, weights - sit far inside
+        # fp16's range): 2.4e-5 at 99 ms per 1024 x 300 call, against 122 ms with everything on the f32-input MFMA (value 0,
+        # LFI_SAMPLE_FRAME_PRECISION=f32) and 94 ms with three-product GEMMs (value 1, =bf16x3: 4.7e-5).
         self.sample_frame_precision = {"bf16x3": 1, "f32": 0, "bf16x6": 5}.get(os.environ.get("LFI_SAMPLE_FRAME_PRECISION", ""))
         self._mask_calls = 0
         # GEMM class -> bf16x3 products to drop (bit 0: a_lo b_hi, bit 1: a_hi b_lo; 3 = plain bf16 operands, one product).

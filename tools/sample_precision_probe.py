@@ -44,10 +44,12 @@ def main():
           "gate = max(1e-5, 1.5 x that) = %.2e. Time: batch 1024 x 300 frames (276 generated), hipGraph replay, median of 5.\n" % (own, max(1e-5, 1.5 * own)))
     print("| static part | autoregressive part | max abs err vs fp64 oracle | ms per call (1024 x 300) |")
     print("|---|---|---|---|")
-    for static, frame in (("bf16x3", "bf16x3"), ("bf16x3", "f32"), ("bf16x3", "bf16x6 GEMMs + f32 cells"), ("f32", "bf16x3"), ("f32", "f32")):
+    modes = {"bf16x3 GEMMs + fp16x3 cells": 1, "f32": 0, "bf16x6 GEMMs + fp16x3 cells": 5}
+    for static, frame in (("bf16x3", "bf16x3 GEMMs + fp16x3 cells"), ("bf16x3", "f32"), ("bf16x3", "bf16x6 GEMMs + fp16x3 cells"),
+                          ("f32", "bf16x3 GEMMs + fp16x3 cells"), ("f32", "f32")):
         m.precision = static
         eng = m._ensure_engine(dev)
-        eng.sample_frame_precision = {"bf16x3": 1, "f32": 0}.get(frame, 5)
+        eng.sample_frame_precision = modes[frame]
         out = m.inference(seq_len, to_dev(data, dev), noise=noise.to(dev))
         err = float((out.cpu().double() - ref).abs().max())
         for _ in range(3):
