@@ -28,7 +28,12 @@ def main():
     def make(B):
         random.seed(1); np.random.seed(1); torch.manual_seed(1)
         h = copy.deepcopy(hp); h["batch_size"] = B
-        m = LetsFaceItGlow(Namespace(**h)).to(dev).train()
+        ns = Namespace(**h)
+        m = LetsFaceItGlow(ns).to(dev).train()
+        from lets_face_it_amd.trainer import Trainer
+        tr = Trainer(ns, device=dev)            # as bench.py: without these hooks the negative-example switch syncs the host every step
+        m.seq_glow.allreduce_hook = tr.allreduce_stats
+        m.nll_sync_hook = tr.sync_scalar
         return m
 
     def timeit(fn, n=20):
@@ -61,6 +66,33 @@ def main():
     print("one model, batch 256:                          %.3f ms per 256 x 56 frames" % t_full)
     print("two models, batch 128 each, back to back:      %.3f ms" % t_seq)
     print("two models, batch 128 each, on two streams:    %.3f ms" % t_conc)
+    sys.stdout.flush()
+    # the same with the chip PARTITIONED: each model's streams (main + the engine's second stream) may only use one half of the
+    # CUs (hipExtStreamCreateWithCUMask; alternate CUs, so both halves span every XCD), so that one model's latency-bound walks
+    # (128 workgroups at batch 128) and the other's throughput-bound kernels really run side by side
+    import ctypes
+    hip = ctypes.CDLL("libamdhip64.so")
+
+    def masked(word):
+        h = ctypes.c_void_p()
+        arr = (ctypes.c_uint32 * 8)(*([word] * 8))
+        rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(h), 8, arr)
+        if rc != 0:
+            raise RuntimeError("hipExtStreamCreateWithCUMask: %d" % rc)
+        return torch.cuda.ExternalStream(h.value, device=dev)
+
+    for name, wa, wb in (("alternate CUs", 0x55555555, 0xAAAAAAAA), ("low / high 16 of every 32", 0x0000FFFF, 0xFFFF0000)):
+        ma, mb = masked(wa), masked(wb)
+        a.seq_glow.engine._side_stream, b.seq_glow.engine._side_stream = masked(wa), masked(wb)
+
+        def conc_masked():
+            with torch.cuda.stream(ma):
+                a.fused_training_step(ba, 1e-5)
+            with torch.cuda.stream(mb):
+                b.fused_training_step(bb, 1e-5)
+
+        print("two models, batch 128 each, two CU-masked stream pairs (%s): %.3f ms" % (name, timeit(conc_masked)))
+        sys.stdout.flush()
 
 
 if __name__ == "__main__":
