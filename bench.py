@@ -419,13 +419,16 @@ def _dtype_label(precision, eng, frames):
 def _sample_frame_label(eng):
     fp = eng.sample_frame_precision
     if fp is None:
-        fp = 5 if eng.precision == 1 else 0
+        fp = 9 if eng.precision == 1 else 0
     return {0: "per-frame GEMMs and reverse cells on the exact f32-input MFMA",
             1: "per-frame GEMMs as three bf16 products (2^-16 relative); the reverse cells' recurrent products as three fp16 "
                "products (2^-22), their LinearZeros / W^-1 products on the f32-input MFMA",
             5: "fp32-grade throughout: per-frame GEMMs as six bf16 products of three-piece operands (dropped terms 2^-24 relative), "
                "the reverse cells' recurrent products as three fp16 products of two-piece operands (2^-22), their LinearZeros / "
-               "W^-1 products on the f32-input MFMA"}.get(int(fp), str(fp))
+               "W^-1 products on the f32-input MFMA",
+            9: "fp32-grade throughout: per-frame GEMMs and the reverse cells' recurrent products as three fp16 products of two-piece "
+               "operands (11 + 11 mantissa bits, 2^-22 relative; activations and weights sit inside fp16's range), the cells' "
+               "LinearZeros / W^-1 products on the f32-input MFMA"}.get(int(fp), str(fp))
 
 
 def bench_sample(args, model, spec, device, world, rank, hp):

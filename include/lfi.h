@@ -58,7 +58,9 @@ typedef struct {
                                  kernel) or 0x20 (force 128 x 128) instead of the library's own choice. Bit 2 (1 | 4 = 5): SIX bf16
                                  products of three-piece operands (x = p0 + p1 + p2, 24 mantissa bits; what is dropped is 2^-24 relative:
                                  fp32-grade results at 6/16 of the f32-input MFMA's cost; 128 x 128 tiles; the sampler's per-frame
-                                 products). Bits 8 / 9 (0x100 / 0x200) DROP the
+                                 products). Bit 3 (1 | 8 = 9): three products of FP16 pieces (11 + 11 mantissa bits, 2^-22 relative: fp32-grade at the
+                                 three-product cost) - for operands inside fp16's range only (a value beyond 65504 turns into NaN):
+                                 activations and weights, never gradients; 128 x 128 tiles. Bits 8 / 9 (0x100 / 0x200) DROP the
                                  a_lo * b_hi / a_hi * b_lo product of the bf16x3 kernels (a measurement switch: what each GEMM
                                  class loses with one or two bf16 passes, tools/precision_sweep.py -> profiles/precision_sweep.md;
                                  never set by the engine's default configuration) */

@@ -201,6 +201,23 @@ __device__ __forceinline__ void split4(const f32x4 v, bf16x4* hi, bf16x4* lo) {
   }
 }
 
+// fp16 pieces (XT == 4): hi = fp16(x), lo = fp16(x - hi): 11 + 11 mantissa bits, three products are 2^-22 relative - fp32-grade at
+// the three-product cost - for operands inside fp16's range (activations and weights of the sampler's per-frame products; a
+// value beyond 65504 becomes inf - inf = NaN; gradients, which underflow, never take this path). The LDS images are typed
+// __bf16: the same 2-byte slots carry the fp16 bit patterns.
+typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void split4h(const f32x4 v, bf16x4* hi, bf16x4* lo) {
+  h16x4 h, l;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    h[j] = (_Float16)v[j];
+    l[j] = (_Float16)(v[j] - (float)h[j]);
+  }
+  *hi = __builtin_bit_cast(bf16x4, h);
+  *lo = __builtin_bit_cast(bf16x4, l);
+}
+
 // x = p0 + p1 + p2 with three bf16 pieces (8 + 8 + 8 mantissa bits: all 24 of an fp32 but the last rounding): the six-product
 // form of the kernel below (XT == 3) sums p2 b0 + p0 b2 + p1 b1 + p1 b0 + p0 b1 + p0 b0 - what is dropped is 2^-24 relative, the
 // fp32 rounding itself - at 6/16 of the f32-input MFMA's cost
@@ -253,6 +270,7 @@ struct XStager {
 #pragma unroll
     for (int i = 0; i < 4; ++i) r[i] = (in[i] && kk[i] < krem) ? *reinterpret_cast<const f32x4*>(p + off[i]) : z;
   }
+  template <bool H16 = false>
   __device__ __forceinline__ void store(__bf16* hi_img, __bf16* lo_img, int krem, f32x4 (&r)[4]) const {
     if (KC) {
 #pragma unroll
@@ -260,7 +278,8 @@ struct XStager {
 #pragma unroll
         for (int j = 1; j < 4; ++j) r[i][j] = (kk[i] + j < krem) ? r[i][j] : 0.0f;
         bf16x4 h, l;
-        split4(r[i], &h, &l);
+        if (H16) split4h(r[i], &h, &l);
+        else split4(r[i], &h, &l);
         *reinterpret_cast<bf16x4*>(hi_img + lds[i]) = h;
         *reinterpret_cast<bf16x4*>(lo_img + lds[i]) = l;
       }
@@ -270,7 +289,8 @@ struct XStager {
       for (int i = 0; i < 4; ++i) {
         const f32x4 col = {r[0][i], r[1][i], r[2][i], r[3][i]};
         bf16x4 h, l;
-        split4(col, &h, &l);
+        if (H16) split4h(col, &h, &l);
+        else split4(col, &h, &l);
         *reinterpret_cast<bf16x4*>(hi_img + (mn_l + i) * XROW + kg4) = h;
         *reinterpret_cast<bf16x4*>(lo_img + (mn_l + i) * XROW + kg4) = l;
       }
@@ -341,9 +361,15 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(GemmArgs g) {
       sa.store3(base, base + XIMG, base + 2 * XIMG, krem, ra);
       sb.store3(base + 3 * XIMG, base + 4 * XIMG, base + 5 * XIMG, krem, rb);
     } else {
-      sa.store(base, base + XIMG, krem, ra);
-      sb.store(base + 2 * XIMG, base + 3 * XIMG, krem, rb);
+      sa.template store<XT == 4>(base, base + XIMG, krem, ra);
+      sb.template store<XT == 4>(base + 2 * XIMG, base + 3 * XIMG, krem, rb);
     }
+  };
+  auto mfma3 = [](const bf16x8& x, const bf16x8& y, const f32x16& c) {   // bf16 pieces, or (XT == 4) fp16 pieces in the same slots
+    if constexpr (XT == 4)
+      return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(h16x8, x), __builtin_bit_cast(h16x8, y), c, 0, 0, 0);
+    else
+      return __builtin_amdgcn_mfma_f32_32x32x16_bf16(x, y, c, 0, 0, 0);
   };
 
   const int wm = wave >> 1, wn = wave & 1;
@@ -410,18 +436,18 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(GemmArgs g) {
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-          for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+          for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = mfma3(al[mt], bh[nt], acc[mt][nt]);
       }
       if (!LFI_GSKIP(2)) {
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-          for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt], bl[nt], acc[mt][nt], 0, 0, 0);
+          for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = mfma3(ah[mt], bl[nt], acc[mt][nt]);
       }
 #pragma unroll
       for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[mt], bh[nt], acc[mt][nt], 0, 0, 0);
+        for (int nt = 0; nt < 2; ++nt) acc[mt][nt] = mfma3(ah[mt], bh[nt], acc[mt][nt]);
     }
     if (NBUF == 1) __syncthreads();   // every wave has read tile kt before it is overwritten
     if (kt + 1 < nkt) store_tiles(kt + 1, NBUF == 2 ? (buf ^ 1) : 0);
@@ -904,7 +930,7 @@ extern "C" long lfi_gemm_colpart_rows(const lfi_gemm_desc* d) {
   if (!(c_ok && g_ok && !(d->act == 2 && d->accumulate != 0))) return 0;
   GemmPlan plan = gemm_plan(d->M, d->N, d->K, d->batch, 1, true);
   if (d->precision & 0x30) plan.shape = (d->precision & 0x10) ? 3 : 0;
-  if (d->precision & 4) plan.shape = 0;
+  if (d->precision & 12) plan.shape = 0;
   return plan.shape == 3 ? (long)lfi_cdiv(d->M, 256) * (256 / LFI_EPI_ROWS) : (long)lfi_cdiv(d->M, 128);
 }
 
@@ -934,7 +960,8 @@ extern "C" int lfi_gemm_f32(const lfi_gemm_desc* d, void* stream) {
   GemmPlan plan = gemm_plan(d->M, d->N, d->K, d->batch, (d->splitk == 0 && !d->work) ? 1 : d->splitk, use_x3 || d->a_bf16);
   if (use_x3 && (d->precision & 0x30)) plan.shape = (d->precision & 0x10) ? 3 : 0;  // tests pin the tile shape (lfi.h)
   const bool x6 = use_x3 && (d->precision & 4) && !d->a_bf16;   // six products: fp32-grade, 128 x 128 kernel only
-  if (x6) plan.shape = 0;
+  const bool x3h = use_x3 && !x6 && (d->precision & 8) && !d->a_bf16;   // three products of fp16 pieces, likewise
+  if (x6 || x3h) plan.shape = 0;
   if (d->a_bf16) plan.shape = 3;
   int splitk = plan.splitk < 1 ? 1 : plan.splitk;
   if (splitk > d->K / BKT) splitk = d->K / BKT < 1 ? 1 : d->K / BKT;
@@ -1004,6 +1031,7 @@ extern "C" int lfi_gemm_f32(const lfi_gemm_desc* d, void* stream) {
                           : (size_t)2 * 4 * XIMG * sizeof(__bf16);
     {
       const int rcl = x6 ? launch_x3_128<3>(a, d->a_kcontig, d->b_kcontig, grid, lds, st)
+                      : x3h ? launch_x3_128<4>(a, d->a_kcontig, d->b_kcontig, grid, lds, st)
                       : a.skip ? launch_x3_128<2>(a, d->a_kcontig, d->b_kcontig, grid, lds, st)
                              : (a.colpart ? launch_x3_128<1>(a, d->a_kcontig, d->b_kcontig, grid, lds, st)
                                           : launch_x3_128<0>(a, d->a_kcontig, d->b_kcontig, grid, lds, st));

@@ -229,7 +229,7 @@ class GlowEngine:
         # products of two-piece operands (11 + 11 mantissa bits; their operands - h, flow activations, weights - sit far inside
         # fp16's range): 2.4e-5 at 99 ms per 1024 x 300 call, against 122 ms with everything on the f32-input MFMA (value 0,
         # LFI_SAMPLE_FRAME_PRECISION=f32) and 94 ms with three-product GEMMs (value 1, =bf16x3: 4.7e-5).
-        self.sample_frame_precision = {"bf16x3": 1, "f32": 0, "bf16x6": 5}.get(os.environ.get("LFI_SAMPLE_FRAME_PRECISION", ""))
+        self.sample_frame_precision = {"bf16x3": 1, "f32": 0, "bf16x6": 5, "fp16x3": 9}.get(os.environ.get("LFI_SAMPLE_FRAME_PRECISION", ""))
         self._mask_calls = 0
         # GEMM class -> bf16x3 products to drop (bit 0: a_lo b_hi, bit 1: a_hi b_lo; 3 = plain bf16 operands, one product).
         # Measurement switch only: profiles/precision_sweep.md (tools/precision_sweep.py, final widths, against the fp64
@@ -1170,7 +1170,7 @@ class GlowEngine:
             pre[:F * KD].view(F, KD).copy_(self.fview("bct").reshape(1, KD).expand(F, KD))
         dims = self._flow_dims(B, nframes)
         fp = self.sample_frame_precision
-        dims.gemm_precision = int(fp) if fp is not None else (5 if self.precision == 1 else 0)
+        dims.gemm_precision = int(fp) if fp is not None else (9 if self.precision == 1 else 0)
         h = self._buf("sample_h", s.Ks * B * s.H, zero=True)
         cs = self._buf("sample_c", s.Ks * B * s.H, zero=True) if s.rnn_type == "lstm" else None
         work = self._buf("scratch.sample", self.L.lfi_flow_sample_work_floats(C.byref(dims)))

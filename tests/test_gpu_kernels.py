@@ -177,7 +177,7 @@ def test_gemm_six_bf16_products_are_fp32_grade(eng, gpu_device, akc, bkc, shape)
     Bd = (Bm[:, :K].t() if bkc else Bm[:, :N]).double()
     ref = Ad @ Bd + bias.double()
     errs = {}
-    for mode in (0, 1, 5):
+    for mode in (0, 1, 5, 9):
         Cm = torch.zeros(M, N, device=gpu_device)
         eng.precision = mode
         try:
@@ -187,10 +187,12 @@ def test_gemm_six_bf16_products_are_fp32_grade(eng, gpu_device, akc, bkc, shape)
         torch.cuda.synchronize()
         assert torch.isfinite(Cm).all()
         errs[mode] = rel_err(Cm, ref)
-    report("GEMM %s (A %s, B %s): rel L2 err vs fp64: exact f32 %.2e, three bf16 products %.2e, six %.2e"
-           % (shape, "k-contig" if akc else "mn-contig", "k-contig" if bkc else "mn-contig", errs[0], errs[1], errs[5]))
+    report("GEMM %s (A %s, B %s): rel L2 err vs fp64: exact f32 %.2e, three bf16 products %.2e, six %.2e, three fp16 products %.2e"
+           % (shape, "k-contig" if akc else "mn-contig", "k-contig" if bkc else "mn-contig", errs[0], errs[1], errs[5], errs[9]))
     assert errs[5] < max(1.5 * errs[0], 2e-7), errs
     assert errs[5] < 0.5 * errs[1], errs
+    # precision 9: fp16 pieces (11 + 11 bits, 2^-22 relative per product; N(0, 1) operands sit inside fp16's range)
+    assert errs[9] < max(1.5 * errs[0], 3e-7), errs
 
 
 @pytest.mark.parametrize("akc,bkc", [(1, 1), (1, 0), (0, 1), (0, 0)])

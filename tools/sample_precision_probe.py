@@ -44,8 +44,9 @@ def main():
           "gate = max(1e-5, 1.5 x that) = %.2e. Time: batch 1024 x 300 frames (276 generated), hipGraph replay, median of 5.\n" % (own, max(1e-5, 1.5 * own)))
     print("| static part | autoregressive part | max abs err vs fp64 oracle | ms per call (1024 x 300) |")
     print("|---|---|---|---|")
-    modes = {"bf16x3 GEMMs + fp16x3 cells": 1, "f32": 0, "bf16x6 GEMMs + fp16x3 cells": 5}
+    modes = {"bf16x3 GEMMs + fp16x3 cells": 1, "f32": 0, "bf16x6 GEMMs + fp16x3 cells": 5, "fp16x3 GEMMs + fp16x3 cells": 9}
     for static, frame in (("bf16x3", "bf16x3 GEMMs + fp16x3 cells"), ("bf16x3", "f32"), ("bf16x3", "bf16x6 GEMMs + fp16x3 cells"),
+                          ("bf16x3", "fp16x3 GEMMs + fp16x3 cells"),
                           ("f32", "bf16x3 GEMMs + fp16x3 cells"), ("f32", "f32")):
         m.precision = static
         eng = m._ensure_engine(dev)
