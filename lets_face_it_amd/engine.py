@@ -224,11 +224,12 @@ class GlowEngine:
         # oracle, and every frame's error feeds all later frames through the prev_p1_face window: this part has to be
         # fp32-grade whatever the static part (window encoders, non-autoregressive cond_transform columns) uses - with
         # three bf16 products here the sampler lands at 4.7e-5 - 5.6e-5 (gate: 1.5 x the fp32 floor). In bf16x3 engine mode it
-        # is, at bf16 MFMA rates (value 5, the default; profiles/round3_sample_precision.md): the per-frame GEMMs as SIX bf16
-        # products of three-piece operands (lfi_gemm_desc.precision 5), the reverse cells' recurrent products as three FP16
-        # products of two-piece operands (11 + 11 mantissa bits; their operands - h, flow activations, weights - sit far inside
-        # fp16's range): 2.4e-5 at 99 ms per 1024 x 300 call, against 122 ms with everything on the f32-input MFMA (value 0,
-        # LFI_SAMPLE_FRAME_PRECISION=f32) and 94 ms with three-product GEMMs (value 1, =bf16x3: 4.7e-5).
+        # is, at three-product cost (value 9, the default; profiles/round3_sample_precision.md): the per-frame GEMMs
+        # (lfi_gemm_desc.precision 9) and the reverse cells' recurrent products as three FP16 products of two-piece operands
+        # (11 + 11 mantissa bits, 2^-22 relative; their operands - h, standardised faces, flow activations, features, weights -
+        # sit far inside fp16's range): 2.2e-5 at 94 ms per 1024 x 300 call, against 122 ms with everything
+        # on the f32-input MFMA (value 0, LFI_SAMPLE_FRAME_PRECISION=f32), 99 ms with six bf16 products in the GEMMs (value 5,
+        # =bf16x6: no range caveat) and 93 ms with three bf16 products (value 1, =bf16x3: 4.7e-5). None = by engine mode (9 / 0).
         self.sample_frame_precision = {"bf16x3": 1, "f32": 0, "bf16x6": 5, "fp16x3": 9}.get(os.environ.get("LFI_SAMPLE_FRAME_PRECISION", ""))
         self._mask_calls = 0
         # GEMM class -> bf16x3 products to drop (bit 0: a_lo b_hi, bit 1: a_hi b_lo; 3 = plain bf16 operands, one product).
