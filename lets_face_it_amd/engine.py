@@ -1171,7 +1171,17 @@ class GlowEngine:
             pre[:F * KD].view(F, KD).copy_(self.fview("bct").reshape(1, KD).expand(F, KD))
         dims = self._flow_dims(B, nframes)
         fp = self.sample_frame_precision
-        dims.gemm_precision = int(fp) if fp is not None else (9 if self.precision == 1 else 0)
+        if fp is None:
+            fp = 0
+            if self.precision == 1:
+                # fp16 pieces want operands inside fp16's range. Weights are what training left; the data
+                # are the caller's: standardised corpora stay under ~10, and anything beyond 1e3 (features then reach 1e3 -
+                # 1e4, still finite, but the margin is gone) takes the six-product bf16 form, which has no range caveat. One
+                # reduction per input tensor and one host sync per sampling call.
+                amax = max(float(v.abs().max()) for k, v in data.items() if torch.is_tensor(v) and v.is_floating_point())
+                amax = max(amax, float(noise.abs().max()))
+                fp = 9 if amax <= 1e3 else 5
+        dims.gemm_precision = int(fp)
         h = self._buf("sample_h", s.Ks * B * s.H, zero=True)
         cs = self._buf("sample_c", s.Ks * B * s.H, zero=True) if s.rnn_type == "lstm" else None
         work = self._buf("scratch.sample", self.L.lfi_flow_sample_work_floats(C.byref(dims)))

@@ -119,6 +119,52 @@ def test_k16_sampling_against_oracle(gpu_device):
         assert err <= gate, (precision, err, gate)
 
 
+def test_sampler_leaves_fp16_pieces_for_out_of_range_inputs(gpu_device):
+    """The sampler's default per-frame arithmetic splits operands into fp16 pieces (fp32-grade inside fp16's range). Inputs
+    beyond 1e3 must send it to the six-product bf16 form instead (no range caveat): same frames as the all-f32-MFMA mode to
+    fp32 accuracy, finite, and the switch is visible in the flow dims the engine hands to the library."""
+    hp = final_model_hparams(50, 27, K=4)
+    m, _ = perturbed_model(hp, gpu_device)
+    m.eval()
+    m.precision = "bf16x3"
+    B, seq_len = 8, 24 + 6
+    g = torch.Generator().manual_seed(11)
+    data = {"p1_face": torch.randn(B, 24, 50, generator=g)}
+    for name, d in (("p2_face", 50), ("p1_speech", 27), ("p2_speech", 27)):
+        data[name] = torch.randn(B, seq_len, d, generator=g)
+    data["p2_speech"][0, 3, 5] = 4.0e3          # one unstandardised value: beyond the guard's 1e3
+    noise = (torch.randn(seq_len - 24, B, 50, generator=g) * 0.8).to(gpu_device)
+    dd = to_dev(data, gpu_device)
+    eng = m._ensure_engine(gpu_device)
+    seen = []
+    real = eng.L.lfi_flow_sample_seq
+
+    def spy(dims, *a):
+        seen.append(int(dims._obj.gemm_precision))
+        return real(dims, *a)
+
+    eng.L.lfi_flow_sample_seq = spy
+    try:
+        out = m.inference(seq_len, dd, noise=noise)
+    finally:
+        eng.L.lfi_flow_sample_seq = real
+    assert seen and seen[0] == 5, seen            # six bf16 products, not fp16 pieces
+    eng.sample_frame_precision = 0
+    ref = m.inference(seq_len, dd, noise=noise)
+    eng.sample_frame_precision = None
+    assert torch.isfinite(out).all()
+    scale = float(ref.abs().max())
+    assert float((out - ref).abs().max()) <= 2e-5 * max(scale, 1.0)
+    data["p2_speech"][0, 3, 5] = 4.0              # inside the range: fp16 pieces
+    seen.clear()
+    eng.L.lfi_flow_sample_seq = spy
+    try:
+        m.inference(seq_len, to_dev(data, gpu_device), noise=noise)
+    finally:
+        eng.L.lfi_flow_sample_seq = real
+    assert seen and seen[0] == 9, seen
+
+
 def test_strong_scaling_anchor_batch_matches_its_sub_batches(gpu_device):
     """bench.py's strong_scaling_anchor steps ONE GPU at the global batch of BASELINE configs[2] (2048 = 8 x 256). That batch
     must be the same function as its eight per-GPU shards: per-frame NLL bit-identical to the shards' (samples are independent),
