@@ -246,8 +246,7 @@ class GlowEngine:
         # and a 200-step loss curve is indistinguishable from the three-product one (parameter distance 8.5e-6 against 1.4e-3 for
         # another dropout seed). At a few hundred frames single small tensors exceed the gate (1.3e-3 .. 1.9e-3 per class), hence
         # the threshold. hparams `engine_backward_products` / LFI_BWD_PRODUCTS override.
-        bp = os.environ.get("LFI_BWD_PRODUCTS", "auto")
-        self.backward_products = bp if bp == "auto" else int(bp)
+        self.backward_products = self.check_backward_products(os.environ.get("LFI_BWD_PRODUCTS", "auto"))
         self._bwd_skip = 0   # skip bits of the backward classes for the backward pass in progress (set by backward())
         self.tile_pin = {k.strip(): int(v) for k, v in (it.split("=") for it in os.environ.get("LFI_TILE_PIN", "").split(",") if it)}
         self.pass_skip = {}
@@ -265,8 +264,22 @@ class GlowEngine:
             return self.pass_skip[cls] & 3
         return self._bwd_skip if cls in BWD_CLASSES else 0
 
+    @staticmethod
+    def check_backward_products(value):
+        """2, 3 or "auto" (LFI_BWD_PRODUCTS / hparams `engine_backward_products`); anything else - e.g. 1, which no kernel
+        implements and which used to run silently as 3 - raises."""
+        if isinstance(value, str) and value.strip().lower() == "auto":
+            return "auto"
+        try:
+            n = int(value)
+        except (TypeError, ValueError):
+            n = None
+        if n not in (2, 3) or (not isinstance(value, str) and n != value):
+            raise ValueError("backward products must be 2, 3 or 'auto', got %r" % (value,))
+        return n
+
     def backward_product_count(self, frames):
-        bp = self.backward_products
+        bp = self.check_backward_products(self.backward_products)
         if not (self.precision & 1):
             return 3
         return (2 if frames >= 8192 else 3) if bp == "auto" else int(bp)

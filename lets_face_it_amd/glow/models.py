@@ -428,7 +428,7 @@ class SeqGlow(nn.Module):
         eng.precision = 1 if self.precision == "bf16x3" else 0
         bp = getattr(self.hparams, "engine_backward_products", None)
         if bp is not None:
-            eng.backward_products = bp if bp == "auto" else int(bp)
+            eng.backward_products = eng.check_backward_products(bp)
         return eng
 
     def _still_bound(self):

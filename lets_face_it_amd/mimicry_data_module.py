@@ -150,6 +150,7 @@ class WindowLoader:
         self.dataset, self.batch_size, self.shuffle = dataset, int(batch_size), shuffle
         self.rank, self.world_size, self.generator = int(rank), int(world_size), generator
         self.seed, self.epoch = int(seed), 0
+        self.skip_batches = 0     # the next iteration starts at this batch of the epoch's order (Trainer: mid-epoch resume)
         if not 0 <= self.rank < self.world_size:
             raise ValueError("rank %d outside world of %d" % (self.rank, self.world_size))
 
@@ -180,7 +181,8 @@ class WindowLoader:
             if total > n:
                 order = torch.cat([order] * ((total + n - 1) // n))[:total]
             order = order[self.rank:total:self.world_size]
-        for b in range(0, order.numel(), self.batch_size):
+        skip, self.skip_batches = int(self.skip_batches), 0
+        for b in range(skip * self.batch_size, order.numel(), self.batch_size):
             yield self.dataset.batch(order[b:b + self.batch_size])
 
 

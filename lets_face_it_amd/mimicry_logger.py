@@ -16,8 +16,12 @@ from .glow import models, modules
 
 
 class MimicryLogger:
-    def __init__(self, render_hook=None):
+    def __init__(self, render_hook=None, seed=None):
         self.render_hook = render_hook  # callable(name, sequence, sequence2, pl_module) or None
+        # which sample gets rendered is drawn from a generator of the logger's OWN: under data parallelism the callbacks run on
+        # rank 0 only, while Python's global `random` decides the negative-example branch of every training step and has to stay
+        # in lockstep on all ranks (lets_face_it_glow.py:40-45; Trainer.fit)
+        self._rng = random.Random(seed)
 
     # ------------------------------------------------------------------ mimicry_logger.py:134-152
     def log_scales(self, pl_module):
@@ -56,7 +60,7 @@ class MimicryLogger:
                 pl_module.log("jerk/generated_mean", generated_mean_jerk)
                 pl_module.log("jerk/generated_mean_ratio", generated_mean_jerk / gt_mean_jerk)
                 if hp.Validation["render"] and self.render_hook is not None:
-                    idx = random.randint(0, cond_data["p1_face"].shape[0] - 1)
+                    idx = self._rng.randint(0, cond_data["p1_face"].shape[0] - 1)
                     self.render_hook("video", new_batch.get("p2_face", predicted_seq)[idx][-predicted_seq.shape[1]:],
                                      predicted_seq[idx], pl_module)
             if hp.Validation["check_invertion"]:
@@ -98,6 +102,7 @@ class MimicryLogger:
         for i in range(0, len(batches), per):
             group = batches[i:i + per]
             stacked = {k: torch.cat([b[k] for b in group], dim=0).contiguous() for k in group[0]}
+            sg._fwd_counter += 1     # the engine's stash and `_last` are replaced: a pending autograd graph must notice
             _, nll = eng.forward(stacked, None, with_stash=False)          # (N, len(group) * B)
             out += [nll[:, j * B:(j + 1) * B].mean().reshape(1) for j in range(len(group))]
         return out
@@ -107,7 +112,7 @@ class MimicryLogger:
         reconstr_seq, backward_loss = pl_module.seq_glow.invert(z_seq, data)
         error_percentage = (backward_loss + loss) / loss
         if pl_module.hparams.Validation["render"] and self.render_hook is not None:
-            i = random.randint(0, data["p1_face"].shape[0] - 1)
+            i = self._rng.randint(0, data["p1_face"].shape[0] - 1)
             seq = torch.stack(reconstr_seq, dim=1).type_as(data["p1_face"])[i]
             self.render_hook("test_reconstr", data["p1_face"][i, -len(z_seq):, :].detach(), seq, pl_module)
         return torch.abs(error_percentage)

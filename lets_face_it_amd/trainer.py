@@ -5,6 +5,7 @@ One process per GPU; with WORLD_SIZE > 1 the flat gradient buffer is all-reduced
 and ActNorm's data-dependent init statistics and the mismatched-NLL switch are all-reduced so every rank holds
 identical parameters and takes identical branches.
 """
+import itertools
 import os
 import random
 import time
@@ -36,6 +37,7 @@ class Trainer:
         self.max_steps = getattr(hparams, "max_steps", None)
         self.epoch = 0
         self.batches_into_epoch = 0   # batches of the current epoch already trained on (a max_steps checkpoint taken mid-epoch)
+        self._epoch_rng = None        # torch's CPU generator state at the start of the current epoch (see fit)
 
     # ------------------------------------------------------------------ distributed plumbing
     def setup_distributed(self):
@@ -105,10 +107,33 @@ class Trainer:
             if hasattr(loader, "set_epoch"):
                 loader.set_epoch(epoch)     # DistributedSampler.set_epoch: one shared permutation per epoch on every rank
             skip, self.batches_into_epoch = self.batches_into_epoch, 0
-            for bi, batch in enumerate(loader):
-                if bi < skip:     # resumed mid-epoch: these batches were trained on before the checkpoint (same shuffle: the
-                    self.batches_into_epoch = bi + 1   # RNG state the epoch's permutation was drawn from is part of it)
-                    continue
+            # The single-process loader draws the epoch's permutation from torch's GLOBAL generator when iteration starts
+            # (DataLoader(shuffle=True)). A run resumed mid-epoch has that generator at its checkpoint-time state - after the
+            # permutation and the steps' own draws (derange_batch) - so the permutation is re-drawn from the state the
+            # interrupted epoch started with (kept in the checkpoint), the batches already trained on are skipped, and the
+            # checkpoint-time state is put back before the first new step.
+            resume_rng = None
+            if skip and self._epoch_rng is not None:
+                resume_rng = torch.get_rng_state()
+                torch.set_rng_state(self._epoch_rng)
+            else:
+                if skip:    # a checkpoint from before the epoch-start state was kept: the epoch's remaining length is right,
+                    import warnings                                                       # its batch order is a new draw
+                    warnings.warn("checkpoint holds no epoch-start RNG state: the resumed epoch is reshuffled")
+                self._epoch_rng = torch.get_rng_state()
+            if hasattr(loader, "skip_batches"):
+                loader.skip_batches, first_bi = skip, skip      # WindowLoader starts at batch `skip` without gathering the others
+            else:
+                first_bi = 0
+            it = iter(loader)
+            head = next(it, None)                               # (draws the permutation)
+            while head is not None and first_bi < skip:         # a loader without skip_batches: consume
+                first_bi += 1
+                head = next(it, None)
+            if resume_rng is not None:
+                torch.set_rng_state(resume_rng)
+            self.batches_into_epoch = skip if head is not None else 0
+            for bi, batch in enumerate(itertools.chain([head] if head is not None else [], it), start=skip):
                 batch = {k: v.to(self.device, non_blocking=True).float().contiguous() for k, v in batch.items()}
                 loss = model.fused_training_step(batch, lr, self.world_size, allreduce)
                 x = batch["p1_face"]
@@ -174,7 +199,9 @@ class Trainer:
                         "optimizer_state": opt, "actnorm_inited": bool(model.seq_glow.glow.actnorm_inited()),
                         # the negative-example branch draws from Python's `random`, derange_batch from torch's CPU generator,
                         # the loader's shuffle too: a resumed run continues those streams instead of replaying them
-                        "rng": {"python": random.getstate(), "numpy": np.random.get_state(), "torch": torch.get_rng_state()},
+                        "rng": {"python": random.getstate(), "numpy": np.random.get_state(), "torch": torch.get_rng_state(),
+                                # what the current epoch's shuffle was drawn from (fit re-draws it on a mid-epoch resume)
+                                "torch_epoch_start": self._epoch_rng},
                         "batches_into_epoch": int(self.batches_into_epoch)}, tmp)
             os.replace(tmp, path)
 
@@ -219,6 +246,7 @@ class Trainer:
             random.setstate(rng["python"])
             np.random.set_state(rng["numpy"])
             torch.set_rng_state(rng["torch"])
+            self._epoch_rng = rng.get("torch_epoch_start")
         self.batches_into_epoch = int(ckpt.get("batches_into_epoch", 0))
         self.epoch = int(ckpt.get("epoch", 0))
         self.global_step = int(ckpt.get("global_step", 0))

@@ -1,0 +1,131 @@
+"""CPU: the training loop's host logic with a recording stand-in for the model (no kernels run) - mid-epoch resume keeps the
+epoch's batch order (trainer.py), the validation callbacks leave Python's global RNG alone (ADVICE r3,
+mimicry_logger.py), backward-product settings are validated."""
+import random
+from argparse import Namespace
+
+import pytest
+import torch
+
+from lets_face_it_amd.mimicry_data_module import WindowLoader
+from lets_face_it_amd.trainer import Trainer
+
+
+class _Windows:
+    """40 'windows': a batch is the float tensor of its window numbers (what the recording model logs)."""
+
+    def __len__(self):
+        return 40
+
+    def batch(self, index):
+        idx = torch.as_tensor(index, dtype=torch.int64)
+        return {"p1_face": idx.float().reshape(-1, 1, 1).repeat(1, 30, 1)}
+
+
+class _Data:
+    def __init__(self, shuffle=True):
+        self.shuffle = shuffle
+
+    def train_dataloader(self):
+        return WindowLoader(_Windows(), 8, shuffle=self.shuffle)
+
+
+class _Recorder(torch.nn.Module):
+    """Stands in for LetsFaceItGlow: records the window numbers of every step and draws from torch's global generator the way
+    derange_batch does on negative steps (so the stream the loader shuffles from moves between steps)."""
+
+    def __init__(self):
+        super().__init__()
+        self.w = torch.nn.Parameter(torch.zeros(3))
+        glow = Namespace(actnorm_inited=lambda: True, set_actnorm_init=lambda flag: None)
+        self.seq_glow = Namespace(spec=Namespace(start=24), engine=None, glow=glow, allreduce_hook=None,
+                                  _ensure_engine=lambda device: Namespace(load_optimizer_state=lambda st: None))
+        self.seen, self.draws = [], []
+
+    def fused_training_step(self, batch, lr, world, allreduce):
+        self.seen.append(batch["p1_face"][:, 0, 0].long().tolist())
+        self.draws.append(float(torch.rand(1)))
+        with torch.no_grad():
+            self.w += 1
+        return torch.zeros(())
+
+
+def _hparams(max_steps=None, max_epochs=2):
+    return Namespace(lr=1e-3, Optim={"Schedule": {"name": None}}, max_epochs=max_epochs, max_steps=max_steps,
+                     checkpoint_callback=True)
+
+
+@pytest.mark.parametrize("stop_at", [2, 5, 7])
+def test_mid_epoch_resume_continues_the_same_batch_order(tmp_path, stop_at):
+    """A run stopped by max_steps inside an epoch and resumed from its checkpoint sees exactly the batches (and the RNG
+    draws) an uninterrupted run sees: the epoch's permutation is re-drawn from the epoch-start generator state kept in the
+    checkpoint, not from the checkpoint-time state."""
+    torch.manual_seed(7)
+    ref = _Recorder()
+    Trainer(_hparams(), device="cpu", log_every=10 ** 9, checkpoint_dir="").fit(ref, _Data())
+    assert len(ref.seen) == 10 and sorted(sum(ref.seen[:5], [])) == list(range(40))
+
+    torch.manual_seed(7)
+    a = _Recorder()
+    Trainer(_hparams(max_steps=stop_at), device="cpu", log_every=10 ** 9, checkpoint_dir=str(tmp_path)).fit(a, _Data())
+    assert a.seen == ref.seen[:stop_at]
+
+    torch.manual_seed(999)      # a fresh process: whatever the generator holds is replaced by the checkpoint's
+    b = _Recorder()
+    tr = Trainer(_hparams(), device="cpu", log_every=10 ** 9, checkpoint_dir="")
+    tr.resume(b, str(tmp_path / "last.ckpt"))
+    assert tr.global_step == stop_at and tr.batches_into_epoch == (stop_at if stop_at <= 5 else stop_at - 5)
+    tr.fit(b, _Data())
+    assert a.seen + b.seen == ref.seen
+    assert a.draws + b.draws == ref.draws
+    assert float(b.w.detach()[0]) == 10.0    # weights came back with the checkpoint and were stepped 10 - stop_at more times
+
+
+def test_window_loader_skip_batches_starts_inside_the_order():
+    torch.manual_seed(3)
+    full = [b["p1_face"][:, 0, 0].long().tolist() for b in WindowLoader(_Windows(), 8)]
+    torch.manual_seed(3)
+    ld = WindowLoader(_Windows(), 8)
+    ld.skip_batches = 2
+    assert [b["p1_face"][:, 0, 0].long().tolist() for b in ld] == full[2:]
+    assert ld.skip_batches == 0      # one-shot
+
+
+def test_logger_render_draws_do_not_move_the_global_python_rng(monkeypatch):
+    """Under data parallelism the callbacks run on rank 0 only; the negative-example branch of every rank reads Python's global
+    `random`, so the logger must not draw from it."""
+    from lets_face_it_amd import mimicry_logger as ml
+    monkeypatch.setattr(ml, "calc_jerk", lambda x: x.abs().mean())
+    rendered = []
+    B, T, Cc = 6, 40, 4
+    batch = {"p1_face": torch.randn(B, T, Cc), "p2_face": torch.randn(B, T, Cc)}
+
+    class SG:
+        def __call__(self, b):
+            return [torch.zeros(B, Cc)] * 5, torch.ones(1), None
+
+        def inference(self, seq_len, data):
+            return torch.zeros(B, 10, Cc)
+
+        def invert(self, z_seq, data):
+            return [torch.zeros(B, Cc)] * 5, -torch.ones(1)
+
+    hp = Namespace(Validation={"inference": True, "seq_len": 34, "render": True, "check_invertion": True,
+                               "scale_logging": False, "wrong_context_test": False},
+                   Conditioning={m: {"history": 24} for m in ("p1_face", "p2_face", "p1_speech", "p2_speech")})
+    pl = Namespace(hparams=hp, seq_glow=SG(), log=lambda *a, **k: None)
+    random.seed(11)
+    before = random.getstate()
+    logger = ml.MimicryLogger(render_hook=lambda name, a, b, m: rendered.append(name), seed=5)
+    logger.on_validation_batch_end(None, pl, None, batch, 0)
+    assert rendered == ["video", "test_reconstr"]
+    assert random.getstate() == before
+
+
+def test_backward_products_setting_is_validated():
+    from lets_face_it_amd.engine import GlowEngine
+    assert GlowEngine.check_backward_products("auto") == "auto"
+    assert GlowEngine.check_backward_products("2") == 2 and GlowEngine.check_backward_products(3) == 3
+    for bad in (1, "1", 4, "two", None, 2.5):
+        with pytest.raises(ValueError):
+            GlowEngine.check_backward_products(bad)
