@@ -150,6 +150,74 @@ def cpu_baseline_sample(hp, C, S, B, nframes, budget_s):
                       "C=%d S=%d, batch %d, first %d generated frames, median of %d runs, %.1f s per run" % (C, S, B, nframes, len(times), med)}
 
 
+def gpu_state_under_load(fn, device, max_s=4.0):
+    """Shader clock / socket power of this GPU while `fn(i)` keeps it busy (outside every timed region): rocm-smi runs in a
+    thread while the main thread keeps enqueueing steps, so the reading is of the loaded chip, not of the idle one. A slow box
+    (power-capped, hot) can then be told from a regression in the record itself. None when rocm-smi cannot be run."""
+    import shutil
+    import subprocess
+    import threading
+    exe = shutil.which("rocm-smi") or "/opt/rocm/bin/rocm-smi"
+    if not os.path.exists(exe):
+        return None
+    box = {}
+
+    def read():
+        try:
+            r = subprocess.run([exe, "-d", str(device.index or 0), "--showclocks", "--showpower", "--showtemp", "--json"],
+                               capture_output=True, text=True, timeout=20)
+            box["raw"] = json.loads(r.stdout)
+        except Exception as e:      # noqa: BLE001 - diagnostics only
+            box["error"] = "%s: %s" % (type(e).__name__, e)
+
+    th = threading.Thread(target=read)
+    t0 = time.time()
+    i = 0
+    for _ in range(8):      # the queue holds work before the reader starts
+        fn(i)
+        i += 1
+    th.start()
+    while th.is_alive() and time.time() - t0 < max_s:
+        fn(i)
+        i += 1
+        if i % 8 == 0:
+            torch.cuda.synchronize()
+    th.join()
+    torch.cuda.synchronize()
+    if "raw" not in box:
+        return {"error": box.get("error", "no output")}
+    out = {"steps_issued_meanwhile": i}
+    for card, vals in box["raw"].items():
+        if not isinstance(vals, dict):
+            continue
+        for k, v in vals.items():
+            kl = k.lower()
+            if any(t in kl for t in ("sclk", "mclk", "fclk", "power", "temperature (sensor junction)", "temperature (sensor hotspot)")):
+                out["%s %s" % (card, k.strip())] = v
+    return out
+
+
+def _dp_summary(prof, eng, world):
+    """Mean milliseconds of the HIP-event intervals fused_training_step recorded around its two gradient buckets."""
+    if not prof:
+        return None
+    torch.cuda.synchronize()
+    keys = [k for k in prof[0] if k != "mode"]
+    res = {"mode": prof[0]["mode"], "steps": len(prof), "world_size": dist.get_world_size() if dist.is_initialized() else world,
+           "backend": dist.get_backend() if dist.is_initialized() else None,
+           "flow_bucket_bytes": 4 * (eng.n_params - eng.flow_offset), "encoder_bucket_bytes": 4 * eng.flow_offset}
+    for k in keys:
+        vals = [a.elapsed_time(b) for a, b in (p[k] for p in prof) if a is not None and b is not None]
+        res[k + "_ms"] = sum(vals) / len(vals) if vals else None
+    if res["mode"] == "overlap" and res.get("flow_bucket_exposed_ms") is not None:
+        res["flow_bucket_finished_under_bptt"] = bool(res["flow_bucket_exposed_ms"] < 0.05)
+        res["note"] = ("flow bucket all-reduced asynchronously from the moment its gradients are enqueued; bptt_window = main-stream "
+                       "time from that launch to the end of the window encoders' BPTT; flow_bucket_exposed = how long the main stream "
+                       "still waited for it after the encoder bucket (0 = fully hidden). LFI_DP_SYNC=1 runs both buckets "
+                       "synchronously after backward and reports their own durations")
+    return res
+
+
 def _timed(fn, steps, world, device):
     """EXACTLY `steps` calls bracketed by barrier + synchronize on both sides; max over ranks (seconds)."""
     torch.cuda.synchronize()
@@ -306,7 +374,15 @@ def bench_train(args, model, trainer, spec, device, world, rank, hp):
         timing_all.update(timing)   # the roofline kernels' figures stay those of the timed region
         timing = timing_all
     eng.enable_timing(False)
+    dp_line = None
+    if world > 1:
+        # a short region of its own (event records are marker packets): which bucket held the main stream for how long
+        model.dp_profile = []
+        _timed(step, 5, world, device)
+        dp_line = _dp_summary(model.dp_profile, eng, world)
+        model.dp_profile = None
     host_issue = _host_issue_ms(step, reps=5)   # (without any per-kernel events)
+    gpu_state = gpu_state_under_load(step, device) if (rank == 0 and not args.quick and world == 1) else None
     graph_line = None
     if world == 1 and args.graph_steps > 0:
         # the same step as ONE replayed hipGraph (opt-in: LetsFaceItGlow.step_graph; bit-identical parameters): two more eager calls
@@ -326,13 +402,14 @@ def bench_train(args, model, trainer, spec, device, world, rank, hp):
     F = B * N
     if deep:
         metric = "FLAME frames/s, full training step (fwd+bwd+clip+Adam), deep flow K=32 x L=3 (96 flow steps), batch %d per GPU" % B
-        workload = ("deep-flow training step: final_model.yaml widths with Glow K=32, L=3 (96 flow steps), synthetic 50-d FLAME + "
-                    "27-d speech, T=%d (%d timesteps), batch %d per GPU (BASELINE.json configs[4]%s)"
-                    % (T, N, B, "" if world == 1 else ", data-parallel"))
+        workload = ("deep-flow training step: final_model.yaml widths with Glow K=32, L=3 (96 flow steps), synthetic %d-d FLAME + "
+                    "%d-d speech, T=%d (%d timesteps), batch %d per GPU (BASELINE.json configs[4]%s)"
+                    % (C, S, T, N, B, "" if world == 1 else ", data-parallel"))
     else:
         metric = "FLAME frames/s, full training step (fwd+bwd+clip+Adam), final_model.yaml batch 256 per GPU"
-        workload = ("final_model.yaml training step, synthetic 50-d FLAME + 27-d speech, T=%d, batch %d per GPU "
-                    "(BASELINE.json configs[1]%s)" % (T, B, "" if world == 1 else ", data-parallel"))
+        workload = ("final_model.yaml training step, synthetic %d-d FLAME + %d-d speech, T=%d, batch %d per GPU (%s%s)"
+                    % (C, S, T, B, "BASELINE.json configs[1]" if (C, S) == (50, 27) else
+                       "the corpus' native dims, hparams/final_model.yaml as shipped", "" if world == 1 else ", data-parallel"))
     out = {
         "metric": metric,
         "value": frames / elapsed, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -349,7 +426,10 @@ def bench_train(args, model, trainer, spec, device, world, rank, hp):
         "roofline": _roofline(spec, F, timing, args.precision),
         "roofline_hbm": _roofline_hbm(spec, B, T, timing, args.precision),
         "kernel_timing": {t: {"launches": n, "ms": round(m_, 4)} for t, (n, m_) in timing.items()},
+        "gpu_state_under_load": gpu_state,
     }
+    if dp_line is not None:
+        out["data_parallel"] = dp_line
     if world == 1 and args.precision == "bf16x3" and eng.backward_product_count(F) == 2 and args.three_products_steps > 0:
         # the same step with three products in the backward GEMMs too (round 2's arithmetic), timed in the same process
         keep = eng.backward_products
@@ -526,7 +606,17 @@ def main():
                     help="N = 1, workload train: also time one GPU at this batch (the global batch of configs[2]) and report it "
                          "as strong_scaling_anchor; 0 disables it")
     ap.add_argument("--hparams", default=os.path.join(ROOT, "lets_face_it_amd", "hparams", "final_model_synthetic.yaml"))
+    ap.add_argument("--quick", action="store_true",
+                    help="the timed region and its roofline only: no baselines, no hipGraph / three-product / anchor legs, no "
+                         "further workloads (A/B runs)")
+    ap.add_argument("--no-more-workloads", action="store_true",
+                    help="N = 1, workload train: do not append the `sampling` (configs[3]), `deep_flow` (configs[4]) and "
+                         "`native_dims` (C=56 / S=30) sub-records")
     args = ap.parse_args()
+    if args.quick:
+        args.cpu_baseline_seconds = args.torch_gpu_baseline_seconds = 0.0
+        args.three_products_steps = args.graph_steps = args.strong_anchor_batch = 0
+        args.no_more_workloads = True
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -552,7 +642,50 @@ def main():
     from lets_face_it_amd.glow.utils import load_hparams_file
     from lets_face_it_amd.trainer import Trainer
 
-    hp = load_hparams_file(args.hparams)
+    def build(a, hparams_file=None):
+        """Random-init model of workload a.workload at a's batch / length (seeded as train.py does: seed_everything(1234))."""
+        hp = load_hparams_file(hparams_file or a.hparams)
+        if a.workload == "deep":
+            hp["Glow"]["K"], hp["Glow"]["L"] = 32, 3
+        hp["batch_size"] = a.batch
+        hp["engine_precision"] = a.precision
+        hp["Train"]["seq_len"] = a.seq_len
+        random.seed(1234)
+        np.random.seed(1234)
+        torch.manual_seed(1234)
+        ns = Namespace(**hp)
+        model = LetsFaceItGlow(ns)
+        model.to(device)
+        model.train()
+        trainer = Trainer(ns, device=device)
+        model.seq_glow.allreduce_hook = trainer.allreduce_stats
+        model.nll_sync_hook = trainer.sync_scalar
+        trainer.broadcast_parameters(model)
+        return hp, model, trainer
+
+    def release(model):
+        """Give a leg's workspaces (up to ~80 GB) back to the allocator before the next leg builds its own."""
+        import gc
+        eng = model.seq_glow.engine
+        if eng is not None:
+            eng._ws.clear()
+            eng._last = None
+            eng._sample_graphs = {}
+        model.__dict__.pop("_step_graphs", None)
+        gc.collect()
+        torch.cuda.empty_cache()
+
+    def run(a, hparams_file=None):
+        hp, model, trainer = build(a, hparams_file)
+        spec = model.seq_glow.spec
+        try:
+            if a.workload == "sample":
+                return bench_sample(a, model, spec, device, world, rank, hp)
+            return bench_train(a, model, trainer, spec, device, world, rank, hp)
+        finally:
+            release(model)
+            del model, trainer
+
     if args.workload == "deep":
         if args.batch == 256:
             args.batch = 128
@@ -560,27 +693,39 @@ def main():
             args.seq_len = 512
         if args.steps == 20:
             args.steps = 5
-        hp["Glow"]["K"], hp["Glow"]["L"] = 32, 3
-    hp["batch_size"] = args.batch
-    hp["engine_precision"] = args.precision
-    hp["Train"]["seq_len"] = args.seq_len
-    random.seed(1234)
-    np.random.seed(1234)
-    torch.manual_seed(1234)
-    ns = Namespace(**hp)
-    model = LetsFaceItGlow(ns)
-    model.to(device)
-    model.train()
-    trainer = Trainer(ns, device=device)
-    model.seq_glow.allreduce_hook = trainer.allreduce_stats
-    model.nll_sync_hook = trainer.sync_scalar
-    trainer.broadcast_parameters(model)
+    out = run(args)
+    if rank == 0 and world == 1 and args.workload == "train" and not args.no_more_workloads:
+        # The driver runs `bench.py --gpus 1` only: the other single-GPU workloads of BASELINE.json (configs[3] sampling, configs[4]
+        # deep flow) and the training step at the corpus' native dims (final_model.yaml as shipped: C = 56, S = 30) ride on the same
+        # line as sub-records, each timed by the same _timed() bracket in this process after the headline's workspaces were freed.
+        import copy
 
-    spec = model.seq_glow.spec
-    if args.workload == "sample":
-        out = bench_sample(args, model, spec, device, world, rank, hp)
-    else:
-        out = bench_train(args, model, trainer, spec, device, world, rank, hp)
+        def sub(workload, **kw):
+            a = copy.copy(args)
+            a.workload = workload
+            a.cpu_baseline_seconds = a.torch_gpu_baseline_seconds = 0.0
+            a.three_products_steps = a.graph_steps = a.strong_anchor_batch = 0
+            a.quick = True
+            hparams_file = kw.pop("hparams_file", None)
+            for k, v in kw.items():
+                setattr(a, k, v)
+            try:
+                r = run(a, hparams_file)
+            except Exception as e:      # noqa: BLE001 - a sub-record must not take the headline down with it
+                return {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+            roof = r.get("roofline") or {}
+            return {"metric": r["metric"], "value": r["value"], "unit": r["unit"], "ms_per_step": r["ms_per_step"],
+                    "steps": r["steps"], "warmup": r["warmup"], "workload": r["config"]["workload"], "dtype": r["dtype"],
+                    "arithmetic": r["config"].get("autoregressive_part") or r["config"].get("gemm_products"),
+                    "roofline_kernel": roof.get("kernel"), "roofline_frac": roof.get("frac"),
+                    "roofline_frac_of_mfma_issue": roof.get("frac_of_mfma_issue") or
+                    (roof.get("frac") * roof.get("mfma_flops_multiplier", 1.0) if roof.get("frac") is not None else None),
+                    "kernel_timing": r.get("kernel_timing"), "final_loss": r.get("final_loss"), "finite": r.get("finite")}
+
+        out["sampling"] = sub("sample", batch=1024, seq_len=300, steps=5, warmup=2)
+        out["deep_flow"] = sub("deep", batch=128, seq_len=512, steps=3, warmup=3)
+        out["native_dims"] = sub("train", batch=256, seq_len=80, steps=10, warmup=3,
+                                 hparams_file=os.path.join(ROOT, "lets_face_it_amd", "hparams", "final_model.yaml"))
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

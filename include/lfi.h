@@ -162,6 +162,10 @@ typedef struct {
                            "3*hid" below reads 4*hid, the gate stash row is 5*hid (i, f, g, o, c) and is required, dgi = dgh */
   int bwd_two_products; /* lfi_encode_windows_bwd, bf16x3 fused GRU path: 1 = two bf16 products per k-step in the d gates x W_hh
                            recurrence (d gates rounded to bf16), as lfi_gemm_desc.precision bit 8 does for a GEMM; 0 = three */
+  int stash_f16;        /* 1: `gates` is an fp16 array, [hist][F][hid][4] halves (r, z, n, W_hn h + b_hn of a hidden unit side by
+                           side; half the bytes of the fp32 form) - written by lfi_encode_windows_fwd, read by _bwd; only where
+                           lfi_encode_windows_stash_f16_ok(d) (the row-layout fused GRU kernels), both calls with the same value.
+                           The state stash hseq stays fp32: it is a GEMM operand of dW_hh (glow/models.py:63, nn.GRU's BPTT) */
 } lfi_enc_desc;
 
 long lfi_encode_windows_work_floats(const lfi_enc_desc* d);
@@ -192,6 +196,8 @@ int lfi_encode_windows_compact_dgi(const lfi_enc_desc* d);
 /* 1 when lfi_encode_windows_bwd (d->bwd_two_products set, fused GRU path, d->ldcond = lddcond) writes dgi / dgh as bf16 arrays of
  * the same shapes: the dW_hh product then takes dgh with lfi_gemm_desc.a_bf16 and lfi_encode_windows_scatter reads bf16. */
 int lfi_encode_windows_grad_stash_bf16(const lfi_enc_desc* d);
+/* 1 when the shape runs on the row-layout fused GRU kernels in both directions, i.e. lfi_enc_desc.stash_f16 may be set. */
+int lfi_encode_windows_stash_f16_ok(const lfi_enc_desc* d);
 int lfi_encode_windows_scatter(const lfi_enc_desc* d, const float* dgi, const float* dgh, const float* mask, float* dXp,
                                void* stream);
 /* "enc: none" modality (glow/models.py:76-77), the flattened p1_face history (glow/models.py:601-603) and the input of an
@@ -311,6 +317,17 @@ int lfi_actnorm_init_apply(const double* sums, double count, int C, float scale,
 int lfi_flow_step(const lfi_flow_dims* d, const lfi_flow_params* p, const float* prep, int k, int rows,
                   const float* x_in, long ldx, const float* h_prev, const float* c_prev, const float* gic_k,
                   float* x_out, long ldxo, float* h_out, float* c_out, float* ldc_acc, int reverse, void* stream);
+/* SeqGlow.invert (glow/models.py:617-645), the teacher-forced reverse pass of a whole sequence in ONE persistent launch (the
+ * reverse twin of lfi_flow_seq_fwd's walk; replaces N * Ks lfi_flow_step(reverse = 1) calls): z (N x B x C latents) ->
+ * x_out (N x B x C), logdet (N x B) = the sum over the flow steps of the coupling log-dets, negated as FlowStep.reverse_flow
+ * returns them (the constant ActNorm / invconv term is the caller's: lfi_flow_prep's constant). gic: [Ks][N*B][G] as for
+ * lfi_flow_seq_fwd. h / cstate: [Ks][B][H] scratch for the recurrent state (zero state at the first timestep, as
+ * init_rnn_hidden, glow/models.py:619). Only where lfi_flow_seq_rev_ok(d) (C <= 64, hidden_channels <= 128); prep must hold
+ * the inverse weights (lfi_flow_prep with_inverse = 1). */
+int lfi_flow_seq_rev_ok(const lfi_flow_dims* d);
+long lfi_flow_seq_rev_work_floats(const lfi_flow_dims* d);
+int lfi_flow_seq_rev(const lfi_flow_dims* d, const lfi_flow_params* p, const float* prep, const float* z, const float* gic,
+                     float* x_out, float* logdet, float* h, float* cstate, float* work, void* stream);
 
 /* Stand-alone module calls (what code/glow_pytorch/test_modules.py:9-29 exercises outside any flow).
  * lfi_actnorm_forward: ActNorm2d.forward (glow/modules.py:45-80) on a (rows x C) batch: out = (x + bias) exp(logs), or with

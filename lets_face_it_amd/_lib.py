@@ -53,7 +53,7 @@ class PGemmDesc(C.Structure):
 class EncDesc(C.Structure):
     _fields_ = [("B", C.c_int), ("T", C.c_int), ("N", C.c_int), ("start", C.c_int),
                 ("hist", C.c_int), ("hid", C.c_int), ("ldcond", C.c_int), ("col", C.c_int), ("precision", C.c_int),
-                ("dup", C.c_int), ("lstm", C.c_int), ("bwd_two_products", C.c_int)]
+                ("dup", C.c_int), ("lstm", C.c_int), ("bwd_two_products", C.c_int), ("stash_f16", C.c_int)]
 
 
 class FlowDims(C.Structure):
@@ -111,6 +111,7 @@ def lib():
         "lfi_flow_bwd_emits_planes": (i, [P(FlowDims)]),
         "lfi_flow_seq_bwd_planes": (i, [P(FlowDims), P(FlowParams), vp, vp, f, vp, vp, i, vp]),
         "lfi_encode_windows_grad_stash_bf16": (i, [P(EncDesc)]),
+        "lfi_encode_windows_stash_f16_ok": (i, [P(EncDesc)]),
         "lfi_gemm_planes_work_floats": (l, [P(PGemmDesc)]),
         "lfi_gemm_planes_colpart_rows": (l, [P(PGemmDesc)]),
         "lfi_colsum_work_floats": (l, [i, i, i]),
@@ -144,6 +145,9 @@ def lib():
         "lfi_actnorm_init_stats": (i, [vp, i, i, vp, vp]),
         "lfi_actnorm_init_apply": (i, [vp, d, i, f, vp, vp, vp]),
         "lfi_flow_step": (i, [P(FlowDims), P(FlowParams), vp, i, i, vp, l, vp, vp, vp, vp, l, vp, vp, vp, i, vp]),
+        "lfi_flow_seq_rev_ok": (i, [P(FlowDims)]),
+        "lfi_flow_seq_rev_work_floats": (l, [P(FlowDims)]),
+        "lfi_flow_seq_rev": (i, [P(FlowDims), P(FlowParams), vp, vp, vp, vp, vp, vp, vp, vp, vp]),
         "lfi_flow_sample_work_floats": (l, [P(FlowDims)]),
         "lfi_flow_sample_p1_work_floats": (l, [P(FlowDims), P(P1Enc), i]),
         "lfi_flow_sample_seq": (i, [P(FlowDims), P(FlowParams), vp, vp, l, i, vp, vp, vp, i, i, i, vp, vp, P(P1Enc), vp, vp,
@@ -169,13 +173,14 @@ def lib():
 EXPORTS = [
     "lfi_last_error", "lfi_version", "lfi_gemm_work_floats", "lfi_gemm_f32", "lfi_gemm_colpart_rows", "lfi_planes_elems", "lfi_planes_from_f32",
     "lfi_gemm_planes", "lfi_gemm_planes_work_floats", "lfi_gemm_planes_colpart_rows",
-    "lfi_flow_bwd_emits_planes", "lfi_flow_seq_bwd_planes", "lfi_encode_windows_grad_stash_bf16", "lfi_colsum_work_floats",
+    "lfi_flow_bwd_emits_planes", "lfi_flow_seq_bwd_planes", "lfi_encode_windows_grad_stash_bf16", "lfi_encode_windows_stash_f16_ok", "lfi_colsum_work_floats",
     "lfi_colsum_f32", "lfi_cols_fold", "lfi_encode_windows_work_floats", "lfi_encode_windows_fwd", "lfi_encode_windows_bwd",
     "lfi_encode_windows_bias_rows", "lfi_encode_windows_bias_grads",
     "lfi_encode_windows_scatter", "lfi_encode_windows_compact_dgi", "lfi_gather_windows", "lfi_pad_rows", "lfi_dropout_masks", "lfi_leaky_grad", "lfi_fill_frame_nb", "lfi_flow_prep_floats", "lfi_flow_prep",
     "lfi_flow_stash_floats", "lfi_flow_bstash_floats", "lfi_flow_stash_ptr", "lfi_flow_bstash_ptr",
     "lfi_flow_seq_fwd", "lfi_flow_seq_bwd", "lfi_flow_param_grads_work_floats", "lfi_flow_param_grads",
-    "lfi_actnorm_init_stats", "lfi_actnorm_init_apply", "lfi_flow_step", "lfi_flow_sample_work_floats",
+    "lfi_actnorm_init_stats", "lfi_actnorm_init_apply", "lfi_flow_step", "lfi_flow_seq_rev_ok", "lfi_flow_seq_rev_work_floats",
+    "lfi_flow_seq_rev", "lfi_flow_sample_work_floats",
     "lfi_flow_sample_p1_work_floats", "lfi_flow_sample_seq", "lfi_grad_sumsq", "lfi_adam_clip_step",
     "lfi_set_step_params", "lfi_dropout_masks_dev", "lfi_adam_clip_step_dev", "lfi_selftest_mfma", "lfi_debug_set_stamps",
     "lfi_gather_sequences", "lfi_jerk_mean", "lfi_actnorm_forward", "lfi_invconv_work_floats", "lfi_invconv_weights",

@@ -632,9 +632,29 @@ __device__ __forceinline__ void enc_st2h(f32x4 v, enc_rsrc r, unsigned voff, uns
   split2(v[0], v[1], &h.x, &l.x); split2(v[2], v[3], &h.y, &l.y);
   __builtin_amdgcn_raw_buffer_store_b64((enc_u32x2){h.x, h.y}, r, voff, soff, LFI_ENC_ST_AUX);
 }
+// fp16 gate stash (lfi_enc_desc.stash_f16): the four values BPTT needs of a hidden unit - r, z, n, W_hn h + b_hn - as four fp16
+// side by side (8 bytes per unit instead of 16: r, z, n lie in (-1, 1) and the last one within a few units of 0, so fp16's 11
+// bits round them by <= 2^-12 absolute, unbiased - finer than the bf16 rounding the two-product backward products apply to the
+// gate DERIVATIVES computed from them). A lane's four consecutive units are 32 contiguous bytes: two 16-byte accesses either way.
+typedef _Float16 enc_h16x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint2 enc_pack_gates(float r, float z, float n, float g) {
+  const enc_h16x4 h = __builtin_convertvector((f32x4){r, z, n, g}, enc_h16x4);   // round to nearest even
+  return __builtin_bit_cast(uint2, h);
+}
+__device__ __forceinline__ f32x4 enc_unpack_gates(unsigned lo, unsigned hi) {
+  const enc_h16x4 h = __builtin_bit_cast(enc_h16x4, (uint2){lo, hi});
+  return __builtin_convertvector(h, f32x4);
+}
 constexpr int ENC_TP = 68;   // floats per row of the transpose tile: 272 B (16-byte aligned rows, 4-bank skew per row)
 
-template <bool STASH, bool MASK>
+// Ingredient-removal builds (timing only, results are garbage; tools/enc_probe.py): -DLFI_ENC_EXP_FIXED_W = every k-tile reads the
+// weight fragments of k-tile 0 (the L2 -> CU weight stream becomes an L1 hit), -DLFI_ENC_EXP_NO_XP = no projected-input loads
+#ifdef LFI_ENC_EXP_FIXED_W
+#define ENC_WKT(kt) 0
+#else
+#define ENC_WKT(kt) (kt)
+#endif
+template <bool STASH, bool MASK, bool S16>
 __global__ __launch_bounds__(ENC_NT, 2) void enc_gru_fwd_wide_kernel(EncArgs a, EncFused q) {
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, half = lane >> 5;
@@ -701,7 +721,7 @@ __global__ __launch_bounds__(ENC_NT, 2) void enc_gru_fwd_wide_kernel(EncArgs a, 
         for (int g = 0; g < 3; ++g)
 #pragma unroll
           for (int t = 0; t < 2; ++t) {
-            const uint4* __restrict__ wf = q.wfrag + ((long)((kt * 3 + g) * nct + cg * 2 + t) * 2) * 64;  // uniform
+            const uint4* __restrict__ wf = q.wfrag + ((long)((ENC_WKT(kt) * 3 + g) * nct + cg * 2 + t) * 2) * 64;  // uniform
             f[t][g][0].u = wf[(unsigned)lane];
             f[t][g][1].u = (wf + 64)[(unsigned)lane];
           }
@@ -741,7 +761,9 @@ __global__ __launch_bounds__(ENC_NT, 2) void enc_gru_fwd_wide_kernel(EncArgs a, 
     const unsigned sx = (unsigned)s * (unsigned)(G3 * 4), j4 = (unsigned)jv * 4u;
     const unsigned oob = jv < hid ? 0u : 0x80000000u;
     const enc_rsrc bhs = enc_buf(STASH ? a.hseq + (long)s * a.F * hid : nullptr, STASH ? (long)a.F * hid * 4 : 0);
-    const enc_rsrc bgs = enc_buf(STASH ? a.gates + (long)s * a.F * 4 * hid : nullptr, STASH ? (long)a.F * hid * 16 : 0);
+    const enc_rsrc bgs = S16 ? enc_buf(STASH ? reinterpret_cast<const _Float16*>(a.gates) + (long)s * a.F * 4 * hid : nullptr,
+                                       STASH ? (long)a.F * hid * 8 : 0)
+                             : enc_buf(STASH ? a.gates + (long)s * a.F * 4 * hid : nullptr, STASH ? (long)a.F * hid * 16 : 0);
     float* Trow = T + rsv * ENC_TP + cv;                 // + 4 i * ENC_TP per row
     float* Tacc = T + (4 * half) * ENC_TP + l31;         // accumulator (t, r) at + ((r & 3) + 8 (r >> 2)) * ENC_TP + 32 t
     f32x4 hp[8], xin[8];
@@ -754,7 +776,11 @@ __global__ __launch_bounds__(ENC_NT, 2) void enc_gru_fwd_wide_kernel(EncArgs a, 
       wo[i] = roww[rl];
       mk[i] = MASK ? mk_tab[rl * a.hist + s] : 1.0f;
       hp[i] = *reinterpret_cast<const f32x4*>(Trow + 4 * i * ENC_TP);   // h_{s-1}, parked here by the previous step
+#ifdef LFI_ENC_EXP_NO_XP
+      xin[i] = f32x4{0.1f, 0.2f, 0.3f, 0.4f};
+#else
       xin[i] = enc_ld4(bx, xo[i], sx);
+#endif
     }
     auto transpose = [&](int g, f32x4 (&out)[8]) {   // gate g of this wave's tile: accumulator layout -> row layout
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // earlier reads of the tile are done
@@ -775,16 +801,20 @@ __global__ __launch_bounds__(ENC_NT, 2) void enc_gru_fwd_wide_kernel(EncArgs a, 
     for (int i = 0; i < 8; ++i) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) rr[i][e] = sigmoidf_(mk[i] * xin[i][e] + bir[e] + (gh[i][e] + bhr[e]));
-      if (STASH) enc_st4(rr[i], bgs, 4u * wo[i] + j4 + oob, 0);
+      if (STASH && !S16) enc_st4(rr[i], bgs, 4u * wo[i] + j4 + oob, 0);
+#ifndef LFI_ENC_EXP_NO_XP
       xin[i] = enc_ld4(bx, xo[i], sx + h4);
+#endif
     }
     transpose(1, gh);
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) uu[i][e] = sigmoidf_(mk[i] * xin[i][e] + biu[e] + (gh[i][e] + bhu[e]));
-      if (STASH) enc_st4(uu[i], bgs, 4u * wo[i] + j4 + oob, h4);
+      if (STASH && !S16) enc_st4(uu[i], bgs, 4u * wo[i] + j4 + oob, h4);
+#ifndef LFI_ENC_EXP_NO_XP
       xin[i] = enc_ld4(bx, xo[i], sx + 2 * h4);
+#endif
     }
     transpose(2, gh);
     __syncthreads();   // every wave has finished the MFMA phase: the state images may be overwritten
@@ -798,7 +828,15 @@ __global__ __launch_bounds__(ENC_NT, 2) void enc_gru_fwd_wide_kernel(EncArgs a, 
         nn[e] = tanhf_(mk[i] * xin[i][e] + bin[e] + rr[i][e] * ghn[e]);
         hn[e] = (1.0f - uu[i][e]) * nn[e] + uu[i][e] * hp[i][e];
       }
-      if (STASH) {
+      if (STASH && S16) {   // [window][unit][r, z, n, W_hn h] fp16: this lane's four units = 32 contiguous bytes
+        const uint2 g0 = enc_pack_gates(rr[i][0], uu[i][0], nn[0], ghn[0]), g1 = enc_pack_gates(rr[i][1], uu[i][1], nn[1], ghn[1]);
+        const uint2 g2 = enc_pack_gates(rr[i][2], uu[i][2], nn[2], ghn[2]), g3 = enc_pack_gates(rr[i][3], uu[i][3], nn[3], ghn[3]);
+        const unsigned go = 2u * (wo[i] + j4) + oob;
+        __builtin_amdgcn_raw_buffer_store_b128((enc_u32x4){g0.x, g0.y, g1.x, g1.y}, bgs, go, 0, LFI_ENC_ST_AUX);
+        __builtin_amdgcn_raw_buffer_store_b128((enc_u32x4){g2.x, g2.y, g3.x, g3.y}, bgs, go, 16, LFI_ENC_ST_AUX);
+        enc_st4(hn, bhs, wo[i] + j4 + oob, 0);
+        __builtin_amdgcn_sched_barrier(0);   // one row's packing temporaries at a time (register pressure)
+      } else if (STASH) {
         enc_st4(nn, bgs, 4u * wo[i] + j4 + oob, 2 * h4);
         enc_st4(ghn, bgs, 4u * wo[i] + j4 + oob, 3 * h4);
         enc_st4(hn, bhs, wo[i] + j4 + oob, 0);
@@ -1080,7 +1118,7 @@ __global__ __launch_bounds__(ENC_NT, 2) void enc_gru_bwd_fused_kernel(EncArgs a,
 // A2 (lfi_enc_desc.bwd_two_products): two bf16 products per k-step instead of three - the A operand, d(gate pre-activations),
 // enters rounded to bf16 (its lo image is neither written nor read, the a_lo * w_hi MFMA not issued), as the backward GEMM
 // classes do from 8192 frames up (profiles/precision_sweep_b256.md: this recurrence is one of them, class enc_bptt).
-template <bool A2>
+template <bool A2, bool S16>
 __global__ __launch_bounds__(ENC_NT, 2) void enc_gru_bwd_wide_kernel(EncArgs a, EncFused q) {
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, half = lane >> 5;
@@ -1159,7 +1197,8 @@ __global__ __launch_bounds__(ENC_NT, 2) void enc_gru_bwd_wide_kernel(EncArgs a, 
     }
     const int sp = s > 0 ? s - 1 : 0;
     const float hp_on = s > 0 ? 1.0f : 0.0f;
-    const enc_rsrc bgs = enc_buf(a.gates + (long)s * a.F * 4 * hid, (long)a.F * hid * 16);
+    const enc_rsrc bgs = S16 ? enc_buf(reinterpret_cast<const _Float16*>(a.gates) + (long)s * a.F * 4 * hid, (long)a.F * hid * 8)
+                             : enc_buf(a.gates + (long)s * a.F * 4 * hid, (long)a.F * hid * 16);
     const enc_rsrc bhp = enc_buf(a.hseq + (long)sp * a.F * hid, (long)a.F * hid * 4);
     // A2: the gradient stash leaves as bf16 (what its consumers - the dW_hh product's rounded A operand, the window scatter in
     // front of dW_ih's - use of it): half the bytes out here and half the bytes into both of them
@@ -1176,8 +1215,17 @@ __global__ __launch_bounds__(ENC_NT, 2) void enc_gru_bwd_wide_kernel(EncArgs a, 
       for (int u = 0; u < 4; ++u) {
         const int rl = rg * 32 + 4 * (4 * ih + u) + rsv;
         wo[u] = roww[rl];
-        const unsigned go = 4u * wo[u] + j4 + oob;
-        gr[u] = enc_ld4s(bgs, go, 0); gu[u] = enc_ld4s(bgs, go, h4); gn[u] = enc_ld4s(bgs, go, 2 * h4); gg[u] = enc_ld4s(bgs, go, 3 * h4);
+        if (S16) {   // fp16 stash, [window][unit][r, z, n, W_hn h]: two 16-byte loads hold this lane's four units
+          const unsigned go = 2u * (wo[u] + j4) + oob;
+          const enc_u32x4 p0 = __builtin_amdgcn_raw_buffer_load_b128(bgs, go, 0, 2), p1 = __builtin_amdgcn_raw_buffer_load_b128(bgs, go, 16, 2);
+          const f32x4 u0 = enc_unpack_gates(p0[0], p0[1]), u1 = enc_unpack_gates(p0[2], p0[3]);
+          const f32x4 u2 = enc_unpack_gates(p1[0], p1[1]), u3 = enc_unpack_gates(p1[2], p1[3]);
+          gr[u] = f32x4{u0[0], u1[0], u2[0], u3[0]}; gu[u] = f32x4{u0[1], u1[1], u2[1], u3[1]};
+          gn[u] = f32x4{u0[2], u1[2], u2[2], u3[2]}; gg[u] = f32x4{u0[3], u1[3], u2[3], u3[3]};
+        } else {
+          const unsigned go = 4u * wo[u] + j4 + oob;
+          gr[u] = enc_ld4s(bgs, go, 0); gu[u] = enc_ld4s(bgs, go, h4); gn[u] = enc_ld4s(bgs, go, 2 * h4); gg[u] = enc_ld4s(bgs, go, 3 * h4);
+        }
         hp[u] = enc_ld4s(bhp, wo[u] + j4 + oob, 0);
       }
 #pragma unroll
@@ -1238,7 +1286,7 @@ __global__ __launch_bounds__(ENC_NT, 2) void enc_gru_bwd_wide_kernel(EncArgs a, 
         else al = ah;
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-          const uint4* __restrict__ wf = q.wfrag + ((long)((g * nkt + kt) * nct + cg * 2 + t) * 2) * 64;  // uniform
+          const uint4* __restrict__ wf = q.wfrag + ((long)((g * nkt + ENC_WKT(kt)) * nct + cg * 2 + t) * 2) * 64;  // uniform
           f[t][0].u = wf[(unsigned)lane];
           f[t][1].u = (wf + 64)[(unsigned)lane];
         }
@@ -1384,6 +1432,8 @@ extern "C" int lfi_encode_windows_fwd(const lfi_enc_desc* d, const float* Xp, co
   a.stamps = g_lfi_stamps;
   hipStream_t st = (hipStream_t)stream;
   const int hid = d->hid, F = a.F;
+  LFI_REQUIRE(!d->stash_f16 || lfi_encode_windows_stash_f16_ok(d), "lfi_encode_windows_fwd: lfi_enc_desc.stash_f16 is set for a shape "
+              "whose gate stash is fp32 (ask lfi_encode_windows_stash_f16_ok)");
   if (d->lstm) {   // "enc: lstm": one GEMM + one gate kernel per history step (in no shipped hparams file: not fused)
     LFI_REQUIRE(gates && hseq, "lfi_encode_windows_fwd: the LSTM encoder keeps its cell state in the gate stash (5 * hid per row)");
     const int blocks = ew_blocks((long)F * hid);
@@ -1430,15 +1480,17 @@ extern "C" int lfi_encode_windows_fwd(const lfi_enc_desc* d, const float* Xp, co
                           (!gates || (al16(gates) && al16(hseq)));
       if (wide && vec_ok && ldsw <= 80 * 1024) {
         rc = LFI_OK;
-        switch ((gates ? 2 : 0) | (mask ? 1 : 0)) {
-#define LFI_ENC_FWDW(ST, MK)                                                                                  \
-  rc = enc_set_lds(enc_gru_fwd_wide_kernel<ST, MK>, ldsw);                                                    \
-  if (!rc) hipLaunchKernelGGL((enc_gru_fwd_wide_kernel<ST, MK>), grid, dim3(ENC_NT), ldsw, st, a, q);        \
+        switch ((gates && d->stash_f16 ? 4 : 0) | (gates ? 2 : 0) | (mask ? 1 : 0)) {
+#define LFI_ENC_FWDW(ST, MK, H)                                                                                  \
+  rc = enc_set_lds(enc_gru_fwd_wide_kernel<ST, MK, H>, ldsw);                                                    \
+  if (!rc) hipLaunchKernelGGL((enc_gru_fwd_wide_kernel<ST, MK, H>), grid, dim3(ENC_NT), ldsw, st, a, q);        \
   break
-          case 3: LFI_ENC_FWDW(true, true);
-          case 2: LFI_ENC_FWDW(true, false);
-          case 1: LFI_ENC_FWDW(false, true);
-          default: LFI_ENC_FWDW(false, false);
+          case 7: LFI_ENC_FWDW(true, true, true);
+          case 6: LFI_ENC_FWDW(true, false, true);
+          case 3: LFI_ENC_FWDW(true, true, false);
+          case 2: LFI_ENC_FWDW(true, false, false);
+          case 1: LFI_ENC_FWDW(false, true, false);
+          default: LFI_ENC_FWDW(false, false, false);
 #undef LFI_ENC_FWDW
         }
         if (rc) return rc;
@@ -1446,6 +1498,8 @@ extern "C" int lfi_encode_windows_fwd(const lfi_enc_desc* d, const float* Xp, co
         return LFI_OK;
       }
     }
+    LFI_REQUIRE(!(gates && d->stash_f16), "lfi_encode_windows_fwd: an fp16 gate stash (lfi_enc_desc.stash_f16) needs the row-layout "
+                "kernel (lfi_encode_windows_stash_f16_ok) and 16-byte aligned buffers");
     const int variant = (gates ? 4 : 0) | (mask ? 2 : 0) | (x3 ? 1 : 0);
     rc = LFI_OK;
     switch (variant) {
@@ -1517,6 +1571,22 @@ extern "C" int lfi_encode_windows_grad_stash_bf16(const lfi_enc_desc* d) {
   return (d && d->bwd_two_products && enc_wide_bwd_shape_ok(d, d->ldcond, &q)) ? 1 : 0;
 }
 
+// May the gate stash between lfi_encode_windows_fwd and _bwd be fp16 ([hist][F][hid][4] halves instead of [hist][F][4][hid] floats)?
+// Only the two row-layout fused GRU kernels read / write that form.
+static bool enc_wide_fwd_shape_ok(const lfi_enc_desc* d, EncFused* q, bool mask) {
+  if (!d || d->lstm || d->precision != 1 || !enc_fused_shape(d->hid, q)) return false;
+  const char* e = getenv("LFI_ENC_WIDE");
+  if (e && e[0] == '0') return false;
+  const size_t ldsw = (size_t)2 * q->R * (q->Kp + 8) * sizeof(__bf16) + (size_t)ENC_NW * 32 * ENC_TP * sizeof(float) +
+                      (size_t)6 * q->Jp * sizeof(float) + (size_t)2 * q->R * sizeof(unsigned) +
+                      (mask ? (size_t)q->R * d->hist * sizeof(float) : 0);
+  return d->hid % 4 == 0 && d->ldcond % 4 == 0 && d->col % 4 == 0 && ldsw <= 80 * 1024;
+}
+extern "C" int lfi_encode_windows_stash_f16_ok(const lfi_enc_desc* d) {
+  EncFused q = {};
+  return (enc_wide_fwd_shape_ok(d, &q, true) && enc_wide_bwd_shape_ok(d, d->ldcond, &q)) ? 1 : 0;
+}
+
 extern "C" int lfi_encode_windows_bwd(const lfi_enc_desc* d, const float* dcond, int lddcond, const float* whh,
                                       const float* gates, const float* hseq, float* dgi, float* dgh, float* bias_part,
                                       float* work, void* stream) {
@@ -1528,6 +1598,8 @@ extern "C" int lfi_encode_windows_bwd(const lfi_enc_desc* d, const float* dcond,
   a.bias_part = bias_part;
   hipStream_t st = (hipStream_t)stream;
   const int hid = d->hid, F = a.F;
+  LFI_REQUIRE(!d->stash_f16 || lfi_encode_windows_stash_f16_ok(d), "lfi_encode_windows_bwd: lfi_enc_desc.stash_f16 is set for a shape "
+              "whose gate stash is fp32 (ask lfi_encode_windows_stash_f16_ok)");
   if (d->lstm) {
     const int blocks = ew_blocks((long)F * hid);
     float* dhb[2] = {work, work + (long)F * hid};
@@ -1575,14 +1647,22 @@ extern "C" int lfi_encode_windows_bwd(const lfi_enc_desc* d, const float* dcond,
                          al16(dgi) && al16(dgh) && (!bias_part || al16(bias_part)) && ldsw <= 80 * 1024;
     LFI_REQUIRE(!want16 || wide_ok, "lfi_encode_windows_bwd: lfi_encode_windows_grad_stash_bf16 promised a bf16 gradient stash but the "
                 "buffers are not 16-byte aligned");
+    LFI_REQUIRE(!d->stash_f16 || wide_ok, "lfi_encode_windows_bwd: an fp16 gate stash (lfi_enc_desc.stash_f16) needs the row-layout "
+                "kernel (lfi_encode_windows_stash_f16_ok) and 16-byte aligned buffers");
     if (wide_ok) {
-      if (want16) {
-        if ((rc = enc_set_lds(enc_gru_bwd_wide_kernel<true>, ldsw))) return rc;
-        hipLaunchKernelGGL(enc_gru_bwd_wide_kernel<true>, dim3(lfi_cdiv(F, q.R)), dim3(ENC_NT), ldsw, st, a, q);
-      } else {
-        if ((rc = enc_set_lds(enc_gru_bwd_wide_kernel<false>, ldsw))) return rc;
-        hipLaunchKernelGGL(enc_gru_bwd_wide_kernel<false>, dim3(lfi_cdiv(F, q.R)), dim3(ENC_NT), ldsw, st, a, q);
+      rc = LFI_OK;
+      switch ((want16 ? 2 : 0) | (d->stash_f16 ? 1 : 0)) {
+#define LFI_ENC_BWDW(A2, H)                                                                                             \
+  rc = enc_set_lds(enc_gru_bwd_wide_kernel<A2, H>, ldsw);                                                               \
+  if (!rc) hipLaunchKernelGGL((enc_gru_bwd_wide_kernel<A2, H>), dim3(lfi_cdiv(F, q.R)), dim3(ENC_NT), ldsw, st, a, q);  \
+  break
+        case 3: LFI_ENC_BWDW(true, true);
+        case 2: LFI_ENC_BWDW(true, false);
+        case 1: LFI_ENC_BWDW(false, true);
+        default: LFI_ENC_BWDW(false, false);
+#undef LFI_ENC_BWDW
       }
+      if (rc) return rc;
     } else if (x3) {
       if ((rc = enc_set_lds(enc_gru_bwd_fused_kernel<true>, ldsx))) return rc;
       hipLaunchKernelGGL(enc_gru_bwd_fused_kernel<true>, dim3(lfi_cdiv(F, q.R)), dim3(ENC_NT), ldsx, st, a, q);

@@ -75,6 +75,8 @@ struct CellIO {
   long ldxo;              // leading dimension of x_out
   long ld_c, ld_o;        // leading dimensions of a_out / y_out and of o_out
   int l_accumulate;       // l_out += instead of =
+  int state_l2;           // reverse cell: read h_prev / c_prev with L1-bypassing (sc1) loads - the persistent reverse walk re-reads
+                          // the state its own workgroup stored one timestep earlier, with no kernel boundary in between
 };
 
 extern __shared__ __attribute__((aligned(16))) float flow_smem[];
@@ -1631,9 +1633,12 @@ __global__ __launch_bounds__(NT) void flow_pipe_fwd_kernel(FlowK f) {
 // wait_flag / pub_flag: hand-off words of the per-frame reverse chain (flow_rev_chain_kernel), or null for a stand-alone launch:
 // the input tile is then read with sc1 loads after the producer's progress word is seen, and the output tile is stored sc1,
 // drained and published (the hand-off of the persistent walks).
+// need / pub_value: the progress value waited for / published (1 for the one-frame chain; timestep + 1 in the persistent reverse
+// walk). false = the wait was abandoned (abort word set): nothing was computed.
 template <int NG, bool X3 = false>
-__device__ __forceinline__ void rev_fast_cell(const FlowK& f, const CellIO& io, int b0, const unsigned* wait_flag,
-                                              unsigned* abort_w, unsigned* pub_flag, int* s_ok) {
+__device__ __forceinline__ bool rev_fast_cell(const FlowK& f, const CellIO& io, int b0, const unsigned* wait_flag,
+                                              unsigned* abort_w, unsigned* pub_flag, int* s_ok, unsigned need = 1u,
+                                              unsigned pub_value = 1u) {
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l15 = lane & 15, kq = lane >> 4;
   const int ri = tid >> 5, cl = tid & 31;
@@ -1676,10 +1681,10 @@ __device__ __forceinline__ void rev_fast_cell(const FlowK& f, const CellIO& io, 
       const int row = min(b0 + kq * 4 + r, rows - 1);
 #pragma unroll
       for (int g = 0; g < NG; ++g) gc[r][g] = io.gic[(long)row * G + g * H + jc];
-      cprev[r] = (NG == 4 && io.c_prev) ? io.c_prev[(long)row * H + jc] : 0.0f;
+      cprev[r] = (NG == 4 && io.c_prev) ? ld_tile(io.c_prev + (long)row * H + jc, io.state_l2 == 0) : 0.0f;
     }
   }
-  if (wait_flag && !pipe_acquire(wait_flag, 1u, abort_w, tid, s_ok, false)) return;
+  if (wait_flag && !pipe_acquire(wait_flag, need, abort_w, tid, s_ok, false)) return false;
   // ---- R0: stage [z1 | z2'] and h_prev
   {
     const int row = b0 + ri;
@@ -1691,7 +1696,7 @@ __device__ __forceinline__ void rev_fast_cell(const FlowK& f, const CellIO& io, 
       if (c < Ch || c >= C) Yt[c * LT + ri] = v;   // z1 rows and the zero k padding; z2 rows come from R3
     }
     for (int j = cl; j < H16; j += 32) {
-      Ht[j * LT + ri] = (io.h_prev && rok && j < H) ? io.h_prev[(long)row * H + j] : 0.0f;
+      Ht[j * LT + ri] = (io.h_prev && rok && j < H) ? ld_tile(io.h_prev + (long)row * H + j, io.state_l2 == 0) : 0.0f;
       if (j >= H) Hn[j * LT + ri] = 0.0f;
     }
     for (int c = Ch + cl; c < Ch16; c += 32) Zt[c * LT + ri] = 0.0f;
@@ -1761,7 +1766,8 @@ __device__ __forceinline__ void rev_fast_cell(const FlowK& f, const CellIO& io, 
       }
     }
   }
-  if (pub_flag) pipe_publish(pub_flag, 1u, tid, true);
+  if (pub_flag) pipe_publish(pub_flag, pub_value, tid, true);
+  return true;
 }
 
 template <int NG>
@@ -1813,6 +1819,56 @@ __global__ __launch_bounds__(NT) void flow_rev_chain_kernel(FlowK f, RevChain rc
   }
 }
 
+// SeqGlow.invert (glow/models.py:617-645): the teacher-forced reverse pass over ALL timesteps in ONE launch - the reverse twin of the
+// persistent forward walk. Workgroup (k, tile), ids by ticket with k descending, walks n = 0 .. N-1: it waits for step k + 1's tile
+// of timestep n (the latent z_n for k = Ks - 1), runs the reverse cell with its recurrent state carried in h / cstate (its own
+// rows, updated in place) and hands its tile to step k - 1 (step 0 writes x_n). Every (n, k) tile has its own slot in `tiles`, so a
+// fast producer never overwrites what its consumer has not read and more workgroups than CUs just run as successive groups. The
+// coupling log-det of every (k, n, row) goes to its own word of `ldk` (workgroups on different CUs must not read-modify-write one
+// accumulator between kernel boundaries); the host call sums them over k.
+struct RevWalk {
+  const float* z;       // [N][B][C]
+  float* tiles;         // [Ks][N * B][C]
+  float* out;           // [N][B][C]
+  const float* gic;     // [Ks][N * B][G]
+  float *h, *cstate;    // [Ks][B][H]
+  float* ldk;           // [Ks][N * B]
+  unsigned* pipe;       // ticket, abort, 2 reserved, then one progress word per (k, tile): timesteps published
+};
+template <int NG>
+__global__ __launch_bounds__(NT) void flow_rev_walk_kernel(FlowK f, RevWalk rw) {
+  __shared__ int s_id, s_ok;
+  if (threadIdx.x == 0) s_id = (int)atomicAdd(rw.pipe, 1u);
+  __syncthreads();
+  const int nbt = f.nbt;
+  const int kk = s_id / nbt, bt = s_id - kk * nbt;
+  if (kk >= f.Ks) return;
+  const int k = f.Ks - 1 - kk;
+  unsigned* prog = rw.pipe + PIPE_HDR;
+  const long F = f.F, B = f.B;
+  bool ok = true;
+  for (int n = 0; n < f.N && ok; ++n) {
+    CellIO io = {};
+    io.k = k; io.rows = f.B; io.ldx = f.C; io.ldxo = f.C;
+    io.x_in = (k == f.Ks - 1) ? rw.z + (long)n * B * f.C : rw.tiles + ((long)(k + 1) * F + (long)n * B) * f.C;
+    io.x_out = (k == 0) ? rw.out + (long)n * B * f.C : rw.tiles + ((long)k * F + (long)n * B) * f.C;
+    io.h_prev = n > 0 ? rw.h + (long)k * B * f.H : nullptr;
+    io.h_out = rw.h + (long)k * B * f.H;
+    if (NG == 4) { io.c_prev = n > 0 ? rw.cstate + (long)k * B * f.H : nullptr; io.c_out = rw.cstate + (long)k * B * f.H; }
+    io.gic = rw.gic + ((long)k * F + (long)n * B) * f.G;
+    io.l_out = rw.ldk + (long)k * F + (long)n * B; io.l_accumulate = 0;
+    io.state_l2 = 1;
+    ok = rev_fast_cell<NG, false>(f, io, bt * MB, k + 1 < f.Ks ? prog + (k + 1) * nbt + bt : nullptr, rw.pipe + 1,
+                                  k > 0 ? prog + k * nbt + bt : nullptr, &s_ok, (unsigned)n + 1u, (unsigned)n + 1u);
+    __syncthreads();   // the cell's last reads of the LDS operands are done before the next timestep stages its own
+  }
+  if (k == 0 && ld_agent(rw.pipe + 1) != 0u) {   // an abandoned walk must not pass for a reconstruction
+    const int row = bt * MB + (int)(threadIdx.x >> 5);
+    if (row < f.B)
+      for (int n = 0; n < f.N; ++n)
+        for (int c = threadIdx.x & 31; c < f.C; c += 32) rw.out[((long)n * B + row) * f.C + c] = __builtin_nanf("");
+  }
+}
 
 struct CarveFB {
   int Dl, Gi, Dy, Cy, Pl, total;
@@ -3421,6 +3477,53 @@ extern "C" int lfi_flow_step(const lfi_flow_dims* d, const lfi_flow_params* p, c
   else hipLaunchKernelGGL(flow_step_kernel<false>, dim3(lfi_cdiv(rows, MB)), dim3(NT), lds, (hipStream_t)stream, f, io);
   LFI_LAUNCH_CHECK("lfi_flow_step");
   return LFI_OK;
+}
+
+// SeqGlow.invert (glow/models.py:617-645) as ONE persistent launch (flow_rev_walk_kernel) + the sum of the per-step log-dets.
+extern "C" int lfi_flow_seq_rev_ok(const lfi_flow_dims* d) {
+  if (!d) return 0;
+  const int Cout = d->affine ? 2 * (d->C - d->C / 2) : d->C - d->C / 2;
+  const char* e = getenv("LFI_INVERT_WALK");
+  return (flow_fast_ok(d->C, d->H, Cout) && !flow_force_generic() && !(e && e[0] == '0')) ? 1 : 0;
+}
+
+extern "C" long lfi_flow_seq_rev_work_floats(const lfi_flow_dims* d) {
+  if (!d) return 0;
+  const long F = (long)d->N * d->B, tiles = (d->B + MB - 1) / MB;
+  return (long)d->Ks * F * d->C + (long)d->Ks * F + lfi_colsum_work_floats(d->Ks, (int)F, 1) +
+         (((long)PIPE_HDR + d->Ks * tiles + 3) & ~3L) + 16;
+}
+
+extern "C" int lfi_flow_seq_rev(const lfi_flow_dims* d, const lfi_flow_params* p, const float* prep, const float* z,
+                                const float* gic, float* x_out, float* logdet, float* h, float* cstate, float* work,
+                                void* stream) {
+  FlowK f = {};
+  int rc = fill_flow(d, p, prep, &f, "lfi_flow_seq_rev");
+  if (rc) return rc;
+  LFI_REQUIRE(prep && z && gic && x_out && logdet && h && work, "lfi_flow_seq_rev: null pointer");
+  LFI_REQUIRE(!d->lstm || cstate, "lfi_flow_seq_rev: the LSTM cell needs cstate");
+  LFI_REQUIRE(lfi_flow_seq_rev_ok(d), "lfi_flow_seq_rev: C <= 64, hidden_channels <= 128 only (lfi_flow_seq_rev_ok); wider flows "
+              "walk cell by cell with lfi_flow_step");
+  LFI_REQUIRE((long)f.N * f.B < (1L << 31), "lfi_flow_seq_rev: too many frames");
+  hipStream_t st = (hipStream_t)stream;
+  const long F = f.F;
+  RevWalk rw = {};
+  rw.z = z; rw.gic = gic; rw.out = x_out; rw.h = h; rw.cstate = cstate;
+  rw.tiles = work;
+  rw.ldk = rw.tiles + (long)f.Ks * F * f.C;
+  float* cws = rw.ldk + (long)f.Ks * F;
+  rw.pipe = reinterpret_cast<unsigned*>((reinterpret_cast<uintptr_t>(cws + lfi_colsum_work_floats(f.Ks, (int)F, 1)) + 15) & ~(uintptr_t)15);
+  const size_t words = (size_t)(((long)PIPE_HDR + (long)f.Ks * f.nbt + 3) & ~3L);
+  hipError_t me = hipMemsetAsync(rw.pipe, 0, words * sizeof(unsigned), st);
+  LFI_REQUIRE(me == hipSuccess, "lfi_flow_seq_rev: hipMemsetAsync: %s", hipGetErrorString(me));
+  const size_t lds = (size_t)carve_fast_fwd(f.C, f.C16, f.H16, f.Ch16, f.Cout).total * sizeof(float);
+  rc = f.lstm ? set_flow_lds(flow_rev_walk_kernel<4>, lds, "lfi_flow_seq_rev") : set_flow_lds(flow_rev_walk_kernel<3>, lds, "lfi_flow_seq_rev");
+  if (rc) return rc;
+  if (f.lstm) hipLaunchKernelGGL(flow_rev_walk_kernel<4>, dim3(f.Ks * f.nbt), dim3(NT), lds, st, f, rw);
+  else hipLaunchKernelGGL(flow_rev_walk_kernel<3>, dim3(f.Ks * f.nbt), dim3(NT), lds, st, f, rw);
+  LFI_LAUNCH_CHECK("lfi_flow_seq_rev");
+  // logdet[n][b] = sum over the flow steps of the coupling log-dets (the constant ActNorm / invconv part is the caller's)
+  return lfi_colsum_f32(rw.ldk, F, 0, f.Ks, (int)F, 1, logdet, 0, 1.0f, 0, cws, stream);
 }
 
 // SeqGlow.inference (glow/models.py:567-596): everything that does not depend on generated frames was hoisted by the

@@ -232,6 +232,7 @@ class GlowEngine:
         # =bf16x6: no range caveat) and 93 ms with three bf16 products (value 1, =bf16x3: 4.7e-5). None = by engine mode (9 / 0).
         self.sample_frame_precision = {"bf16x3": 1, "f32": 0, "bf16x6": 5, "fp16x3": 9}.get(os.environ.get("LFI_SAMPLE_FRAME_PRECISION", ""))
         self._mask_calls = 0
+        self._enc_stash_f16 = {}   # modality -> did the last stashing forward write its gate stash as fp16 (build_features)
         # GEMM class -> bf16x3 products to drop (bit 0: a_lo b_hi, bit 1: a_hi b_lo; 3 = plain bf16 operands, one product).
         # Measurement switch only: profiles/precision_sweep.md (tools/precision_sweep.py, final widths, against the fp64
         # oracle) shows NO class that keeps the test bounds with fewer than three products - the forward classes cost
@@ -277,6 +278,14 @@ class GlowEngine:
         if n not in (2, 3) or (not isinstance(value, str) and n != value):
             raise ValueError("backward products must be 2, 3 or 'auto', got %r" % (value,))
         return n
+
+    def _want_stash_f16(self, frames):
+        """The window encoders' gate stash as fp16? LFI_ENC_STASH_F16=0 / 1 forces; by default wherever the backward GEMM classes
+        take two products (backward_product_count)."""
+        env = os.environ.get("LFI_ENC_STASH_F16")
+        if env in ("0", "1"):
+            return env == "1" and bool(self.precision & 1)
+        return self.backward_product_count(frames) == 2
 
     def backward_product_count(self, frames):
         bp = self.check_backward_products(self.backward_products)
@@ -666,9 +675,14 @@ class GlowEngine:
             xa, wa, ldi = self._aligned_input(e, x, B * Tx, G)
             self.gemm(B * Tx, G, e.in_dim, xa, ldi, 1, wa, ldi, 1, xp, G, cls="enc_xproj")
             # gate stash: r, z, n, W_hn h + b_hn (GRU; only kept for a backward pass) / i, f, g, o, c (LSTM: it is the cell state)
-            gates = self._buf("enc_gates." + e.name, e.hist * F * (5 if lstm else 4) * hid) if (with_stash or lstm) else None
-            hseq = self._buf("enc_hseq." + e.name, e.hist * F * hid)
             d = EncDesc(B, Tx, N, start - 1 + incl, e.hist, hid, s.ldf, e.fcol, self.precision, 0, 1 if lstm else 0)
+            # fp16 gate stash (r, z, n, W_hn h + b_hn as four halves per hidden unit): where the backward pass runs its two-product
+            # arithmetic anyway (gate DERIVATIVES rounded to bf16) and the row-layout kernels take the shape
+            s16 = bool(with_stash and not lstm and self._want_stash_f16(F) and self.L.lfi_encode_windows_stash_f16_ok(C.byref(d)))
+            d.stash_f16 = 1 if s16 else 0
+            self._enc_stash_f16[e.name] = s16
+            gates = self._buf("enc_gates." + e.name, e.hist * F * (5 if lstm else (2 if s16 else 4)) * hid) if (with_stash or lstm) else None
+            hseq = self._buf("enc_hseq." + e.name, e.hist * F * hid)
             work = self._buf("scratch.enc", self.L.lfi_encode_windows_work_floats(C.byref(d)))
             ev = self._tic("enc_fwd." + e.name)
             check(self.L.lfi_encode_windows_fwd(
@@ -762,6 +776,7 @@ class GlowEngine:
         ctx = _Ctx()
         ctx.batch, ctx.masks, ctx.B, ctx.T, ctx.N, ctx.F = batch, masks, B, T, N, F
         ctx.cond, ctx.cbuf, ctx.gic, ctx.stash, ctx.dims, ctx.with_stash, ctx.chain = cond, cbuf, gic, stash, dims, with_stash, chain
+        ctx.enc_stash_f16 = dict(self._enc_stash_f16)
         self._last = ctx
         return z, nll
 
@@ -967,7 +982,8 @@ class GlowEngine:
                     1 if e.enc == "lstm" else 0,
                     # two-product BPTT recurrence + bf16 gradient stash: only together with a two-product (A rounded) dW_hh
                     # product, the stash's other reader
-                    1 if ((self._skip_bits("enc_bptt") & 1) and (self._skip_bits("enc_dwhh") & 3) == 1) else 0)
+                    1 if ((self._skip_bits("enc_bptt") & 1) and (self._skip_bits("enc_dwhh") & 3) == 1) else 0,
+                    1 if ctx.enc_stash_f16.get(e.name) else 0)
         gates = self._ws["enc_gates." + e.name]
         hseq = self._ws["enc_hseq." + e.name]
         compact = bool(self.L.lfi_encode_windows_compact_dgi(C.byref(d)))   # fused GRU backward: dgi = its n block only
@@ -1250,20 +1266,38 @@ class GlowEngine:
         N = z_seq.shape[0]
         F = N * B
         Tn = s.start + N
-        self.run_prep(with_inverse=True)
-        cond = self._buf("cond", F * s.ldf)
-        self.build_features(batch, x, B, Tn, masks, cond, with_stash=False)
-        _, gic = self._project(cond, F)
+        # The inverse pass is ill-conditioned where the forward pass is not: an error of 2^-16 in the coupling nets' conditioning
+        # input (three bf16 products) comes back amplified by the chain of inverse couplings and inverse 1x1 convolutions - at 96 flow
+        # steps 1e-2 of x against 2.5e-3 for plain fp32 (tests/test_gpu_deep_parity.py) - so `invert`, a validation call
+        # (Validation.check_invertion, mimicry_logger.py:241-251), runs its window encoders and conditioning products in the exact
+        # f32 arithmetic whatever the engine mode.
+        keep_precision, self.precision = self.precision, 0
+        try:
+            self.run_prep(with_inverse=True)
+            cond = self._buf("cond", F * s.ldf)
+            self.build_features(batch, x, B, Tn, masks, cond, with_stash=False)
+            _, gic = self._project(cond, F)
+        finally:
+            self.precision = keep_precision
         dims = self._flow_dims(B, N)
         p = self._flow_params()
         st = _stream()
         out = torch.empty(N, B, s.C, dtype=torch.float32, device=self.device)
-        ld = torch.zeros(N, B, dtype=torch.float32, device=self.device)
         h = self._buf("sample_h", s.Ks * B * s.H, zero=True)
         cs = self._buf("sample_c", s.Ks * B * s.H, zero=True)
+        z_seq = z_seq.contiguous()
+        ldconst = self.prep[self._ldconst_offset()]
+        if self.L.lfi_flow_seq_rev_ok(C.byref(dims)):
+            # ONE persistent launch for the whole (timestep, flow step) grid: the reverse twin of the forward walk
+            ld = torch.empty(N, B, dtype=torch.float32, device=self.device)
+            work = self._buf("scratch.invert", self.L.lfi_flow_seq_rev_work_floats(C.byref(dims)))
+            check(self.L.lfi_flow_seq_rev(C.byref(dims), C.byref(p), self.prep.data_ptr(), z_seq.data_ptr(), gic.data_ptr(),
+                                          out.data_ptr(), ld.data_ptr(), h.data_ptr(), cs.data_ptr(), work.data_ptr(), st),
+                  "lfi_flow_seq_rev")
+            return out, ld - ldconst
+        ld = torch.zeros(N, B, dtype=torch.float32, device=self.device)
         xa = self._buf("init_xa", B * s.C)
         xb = self._buf("init_xb", B * s.C)
-        z_seq = z_seq.contiguous()
         for n in range(N):
             src, ldx = z_seq.data_ptr() + 4 * n * B * s.C, s.C
             for k in range(s.Ks - 1, -1, -1):
@@ -1275,7 +1309,6 @@ class GlowEngine:
                                            gic.data_ptr() + 4 * (k * F + n * B) * s.G, dst, s.C, hk, ck,
                                            ld.data_ptr() + 4 * n * B, 1, st), "lfi_flow_step")
                 src = dst
-        ldconst = self.prep[self._ldconst_offset()]
         return out, ld - ldconst
 
     def _wc_offset(self):

@@ -17,6 +17,12 @@ from .models import SeqGlow
 from .utils import derange_batch, get_mismatched_modalities, get_scheduler, test_params
 
 
+def _recorded_event():
+    ev = torch.cuda.Event(enable_timing=True)
+    ev.record()
+    return ev
+
+
 class LetsFaceItGlow(nn.Module):
     def __init__(self, hparams, dataset_root=None, test=None):
         super().__init__()
@@ -220,15 +226,45 @@ class LetsFaceItGlow(nn.Module):
             loss = loss * -0.1
         if allreduce is not None and world_size > 1:
             # two buckets: the flow block (>95 % of the floats) is all-reduced asynchronously as soon as its gradients are
-            # enqueued and travels over xGMI under the window encoders' BPTT; the encoder block follows on the main stream
+            # enqueued and travels over xGMI under the window encoders' BPTT; the encoder block follows on the main stream.
+            # LFI_DP_SYNC=1: both buckets synchronously after the whole backward pass (what the overlap buys = the difference).
+            # dp_profile (a list, bench.py): per step the HIP events that say how long each bucket held the main stream.
+            import os
             off = eng.flow_offset
-            pending = []
-            eng.backward(sign / nll.numel(), after_flow=lambda: pending.append(allreduce(eng.grads[off:], async_op=True)))
-            if off > 0:
-                allreduce(eng.grads[:off])
-            for work in pending:
-                if work is not None:
-                    work.wait()
+            prof = self.__dict__.get("dp_profile")
+            mark = (lambda: _recorded_event()) if prof is not None else (lambda: None)
+            if os.environ.get("LFI_DP_SYNC") == "1":
+                eng.backward(sign / nll.numel())
+                e0 = mark()
+                allreduce(eng.grads[off:])
+                e1 = mark()
+                if off > 0:
+                    allreduce(eng.grads[:off])
+                e2 = mark()
+                if prof is not None:
+                    prof.append({"mode": "sync", "flow_bucket": (e0, e1), "encoder_bucket": (e1, e2)})
+            else:
+                pending, ev = [], {}
+
+                def launch_flow_bucket():
+                    ev["flow_launched"] = mark()
+                    pending.append(allreduce(eng.grads[off:], async_op=True))
+
+                eng.backward(sign / nll.numel(), after_flow=launch_flow_bucket)
+                e1 = mark()        # the window encoders' BPTT is enqueued behind this point's predecessors
+                if off > 0:
+                    allreduce(eng.grads[:off])
+                e2 = mark()
+                for work in pending:
+                    if work is not None:
+                        work.wait()
+                e3 = mark()
+                if prof is not None:
+                    # bptt_window: main-stream time between the flow bucket's launch and the end of the encoder BPTT (what the
+                    # asynchronous bucket can hide under); flow_bucket_exposed: how long the main stream then still waited for it
+                    # (~0 = it finished before the BPTT and the encoder bucket did)
+                    prof.append({"mode": "overlap", "bptt_window": (ev.get("flow_launched"), e1), "encoder_bucket": (e1, e2),
+                                 "flow_bucket_exposed": (e2, e3)})
         else:
             eng.backward(sign / nll.numel())
         opt = self.hparams.Optim

@@ -1,0 +1,129 @@
+"""Oracle parity at the DEPTH of BASELINE configs[4] (missing #3 / weak #1b): K = 32 x L = 3 = 96 flow steps at
+final widths - the depth at which the persistent walk runs 96 x tiles workgroups as successive groups - for the per-frame NLL,
+every parameter gradient, autoregressive sampling and `invert`, against the fp64 CPU oracle (reference loops:
+glow/models.py:413-434 FlowNet, :534-561 forward, :567-596 inference, :617-645 invert), in both GEMM modes.
+
+The oracle walks 96 flow steps x 8 timesteps in seconds at these batch sizes; configs[4]'s own size (T = 512, B = 128) stays
+with the size-independent properties of tests/test_gpu_parity.py::test_config4_deep_flow_properties.
+"""
+import pytest
+import torch
+
+from helpers import max_rel, rel_err, report
+from oracle import seqglow_oracle as oracle
+from test_gpu_parity import final_model_hparams, perturbed_model, to_dev
+
+pytestmark = pytest.mark.gpu
+
+
+def deep_hparams():
+    hp = final_model_hparams(50, 27, K=32)
+    hp["Glow"]["L"] = 3
+    return hp
+
+
+def _masks(hp, N, B, seed):
+    g = torch.Generator().manual_seed(seed)
+    masks = {}
+    for name in ("p2_face", "p1_speech", "p2_speech"):
+        cfg = hp["Conditioning"][name]
+        keep = 1.0 - cfg["dropout"]
+        masks[name] = (torch.rand(N, B, cfg["history"], generator=g) < keep).float() / keep
+    return masks
+
+
+@pytest.mark.parametrize("precision", ["f32", "bf16x3"])
+@pytest.mark.parametrize("B", [6, 64])
+def test_deep_flow_against_oracle(gpu_device, B, precision):
+    """96 flow steps, T = 24 + 8, injected dropout masks: per-frame NLL (1e-4 relative) and EVERY parameter gradient (2e-3
+    relative L2) against the fp64 oracle. B = 6 is one ragged 16-sample tile per flow step (96 workgroups); B = 64 is four
+    tiles per step = 384 (k, tile) workgroups, more than the chip has CUs: the walk then runs them as successive groups, and it
+    is the ORACLE that pins that path here, not the walk compared with itself."""
+    hp = deep_hparams()
+    m, sd = perturbed_model(hp, gpu_device)
+    assert m.spec.Ks == 96
+    m.precision = precision
+    m.train()
+    T = 32
+    N = T - 24
+    batch = oracle.synthetic_batch(B, T, 50, 27, seed=40 + B)
+    masks = _masks(hp, N, B, 8)
+    m.injected_masks = masks
+    z_seq, loss, losses = m(to_dev(batch, gpu_device))
+    loss.sum().backward()
+    sdg = {k: v.double().requires_grad_(v.dtype.is_floating_point and not k.endswith((".p", ".sign_s")))
+           for k, v in sd.items()}
+    z64, oloss, onll = oracle.seqglow_forward(hp, sdg, {k: v.double() for k, v in batch.items()},
+                                              {k: v.double() for k, v in masks.items()})
+    oloss.sum().backward()
+    err = max_rel(torch.stack(losses), onll.detach(), floor=1.0)
+    zerr = rel_err(torch.stack(z_seq).detach(), z64.detach())
+    total = float(torch.sqrt(sum((v.grad ** 2).sum() for v in sdg.values() if v.grad is not None)))
+    worst = ("", 0.0)
+    for name, p in m.named_parameters():
+        ref = sdg[name].grad
+        diff = p.grad.double().cpu() - ref
+        rel = float(diff.norm() / max(float(ref.norm()), 1e-3 * total))
+        if rel > 1e-3 and precision == "bf16x3" and "cond_transform.0.weight" in name:
+            # LeakyReLU's kink (test_full_model_k16_gradients_against_oracle): with a few hundred frames behind each weight row,
+            # ONE (frame, unit) pre-activation within the 2^-16 product noise of 0 changes that unit's row by 1e-2; allow one
+            diff = diff.clone()
+            diff[int(diff.norm(dim=1).argmax())] = 0
+            rel = float(diff.norm() / max(float(ref.norm()), 1e-3 * total))
+        if rel > worst[1]:
+            worst = (name, rel)
+    report("DEEP flow K=32 x L=3 (96 steps) %s, B=%d, T=32 vs fp64 oracle: per-frame NLL max rel err %.3e, z rel err %.3e, worst "
+           "gradient rel L2 %.3e (%s)" % (precision, B, err, zerr, worst[1], worst[0]))
+    assert err < 1e-4 and zerr < 1e-4
+    assert worst[1] < 2e-3, worst
+
+
+@pytest.mark.parametrize("precision", ["f32", "bf16x3"])
+def test_deep_flow_sampling_and_invert_against_oracle(gpu_device, precision):
+    """96 reverse flow steps per generated frame: `inference` over 8 frames with injected prior noise and `invert` of the
+    teacher-forced latents, against the fp64 oracle. Sampling gate as at K = 16 (test_k16_sampling_against_oracle): north_star's
+    1e-5 absolute or 1.5 x what plain fp32 torch does on the same inputs, whichever is larger - both are reported."""
+    hp = deep_hparams()
+    m, sd = perturbed_model(hp, gpu_device)
+    m.precision = precision
+    m.eval()
+    B, seq_len = 6, 24 + 8
+    g = torch.Generator().manual_seed(13)
+    data = {"p1_face": torch.randn(B, 24, 50, generator=g)}
+    for name, d in (("p2_face", 50), ("p1_speech", 27), ("p2_speech", 27)):
+        data[name] = torch.randn(B, seq_len, d, generator=g)
+    noise = torch.randn(seq_len - 24, B, 50, generator=g) * 0.8
+    sd64 = {k: v.double() for k, v in sd.items()}
+    ref = oracle.seqglow_inference(hp, sd64, seq_len, {k: v.double() for k, v in data.items()}, noise.double())
+    ref32 = oracle.seqglow_inference(hp, sd, seq_len, data, noise)
+    # 96 inverse couplings (z2 / scale - shift with scale = sigmoid(.) < 1) of a random-init flow blow the frames up frame over frame
+    # (|x| reaches 1e9 and more by the eighth): the error is measured per generated frame relative to that frame's largest magnitude
+    # (never below 1: for |x| <= 1 it is north_star's absolute 1e-5)
+    scale = ref.abs().amax(dim=(0, 2)).clamp(min=1.0)                               # (frames,)
+    own = float(((ref32.double() - ref).abs().amax(dim=(0, 2)) / scale).max())
+    gate = max(1e-5, 1.5 * own)
+    out = m.inference(seq_len, to_dev(data, gpu_device), noise=noise.to(gpu_device))
+    out2 = m.inference(seq_len, to_dev(data, gpu_device), noise=noise.to(gpu_device))   # hipGraph replay
+    per_frame = (out.cpu().double() - ref).abs().amax(dim=(0, 2)) / scale
+    err = float(per_frame.max())
+    report("DEEP flow (96 steps) sampling %s, batch 6 x 8 generated frames (|x| up to %.1e): max error relative to the frame's largest "
+           "value vs fp64 oracle %.2e (first frame %.2e); plain fp32 torch on the CPU: %.2e; gate %.2e"
+           % (precision, float(ref.abs().max()), err, float(per_frame[0]), own, gate))
+    assert torch.equal(out, out2)
+    assert torch.isfinite(out).all()
+    assert err <= gate, (precision, err, gate)
+
+    # invert: teacher-forced reverse pass of the oracle's own latents on a fresh batch
+    batch = oracle.synthetic_batch(B, seq_len, 50, 27, seed=71)
+    b64 = {k: v.double() for k, v in batch.items()}
+    z64, floss, _ = oracle.seqglow_forward(hp, sd64, b64)
+    rec64, bl64 = oracle.seqglow_invert(hp, sd64, z64, b64)
+    rec32, _ = oracle.seqglow_invert(hp, sd, z64.float(), batch)
+    own_inv = float((rec32.double() - rec64).abs().max())
+    rec, bl = m.invert(list(z64.float().to(gpu_device).unbind(0)), to_dev(batch, gpu_device))
+    ierr = float((torch.stack(rec).cpu().double() - rec64).abs().max())
+    lerr = rel_err(bl, bl64)
+    report("DEEP flow (96 steps) invert %s, batch 6 x 8 frames: reconstruction max abs err vs fp64 oracle %.2e (plain fp32 torch: "
+           "%.2e), backward loss rel err %.2e" % (precision, ierr, own_inv, lerr))
+    assert ierr <= max(1e-4, 3.0 * own_inv), (ierr, own_inv)
+    assert lerr < 1e-4

@@ -30,29 +30,34 @@ def _masks(hp, N, B, seed):
     return masks
 
 
-def test_headline_config_gradients_against_oracle(gpu_device):
+def test_headline_config_gradients_against_oracle(gpu_device, monkeypatch):
     """BASELINE configs[1] itself: B=256, T=80, K=16, injected dropout masks, bf16x3. Per-frame NLL (gate 1e-4 relative,
     north_star) and every parameter gradient (relative L2 against the fp64 oracle, gate 2e-3 as everywhere else; no
     LeakyReLU-kink allowance is needed with 14 336 frames behind each weight row) - in the engine's default arithmetic at this
     size (engine_backward_products "auto": two bf16 products in the backward GEMM classes from 8192 frames up) and with three
-    products everywhere."""
+    products everywhere. The default arithmetic also keeps the window encoders' gate stash as fp16 (round 4): the same leg with
+    that stash in fp32 (LFI_ENC_STASH_F16=0) is reported beside it, so the stash's share of the error is visible."""
     hp = final_model_hparams(50, 27, K=16)
     B, T = 256, 80
     N = T - 24
     batch = oracle.synthetic_batch(B, T, 50, 27, seed=1234)
     masks = _masks(hp, N, B, 6)
     got = {}
-    for products in ("auto", 3):
+    for products in ("auto", "auto, fp32 gate stash", 3):
+        monkeypatch.delenv("LFI_ENC_STASH_F16", raising=False)
+        if products == "auto, fp32 gate stash":
+            monkeypatch.setenv("LFI_ENC_STASH_F16", "0")
         m, sd = perturbed_model(hp, gpu_device)
         m.precision = "bf16x3"
         m.train()
         m.injected_masks = masks
         eng = m._ensure_engine(gpu_device)
-        eng.backward_products = products
+        eng.backward_products = 3 if products == 3 else "auto"
         _, loss, losses = m(to_dev(batch, gpu_device))
         loss.sum().backward()
         torch.cuda.synchronize()
-        assert eng.backward_product_count(B * N) == (2 if products == "auto" else 3) and bool(eng._last.chain)
+        assert eng.backward_product_count(B * N) == (3 if products == 3 else 2) and bool(eng._last.chain)
+        assert all(eng._last.enc_stash_f16[n] == (products == "auto") for n in ("p2_face", "p1_speech", "p2_speech"))
         got[products] = (torch.stack(losses).double().cpu(), {n: p.grad.detach().double().cpu() for n, p in m.named_parameters()})
         del m, eng
         torch.cuda.empty_cache()
@@ -68,6 +73,7 @@ def test_headline_config_gradients_against_oracle(gpu_device):
     spent = time.time() - t0
     torch.set_num_threads(threads)
     total = float(torch.sqrt(sum((v.grad ** 2).sum() for v in sdg.values() if v.grad is not None)))
+    monkeypatch.delenv("LFI_ENC_STASH_F16", raising=False)
     for products, (nll, grads) in got.items():
         err = max_rel(nll, onll.detach(), floor=1.0)
         worst, raw, num = ("", 0.0), ("", 0.0), 0.0

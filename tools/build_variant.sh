@@ -1,0 +1,17 @@
+#!/bin/bash
+# Build a library variant for same-box A/Bs:  tools/build_variant.sh <name> <file.hip> [-Dmacro ...]
+# -> build/var/liblfi_<name>.so = the tree's objects with <file.hip> recompiled under the extra flags (picked with LFI_LIB_PATH).
+set -eu
+NAME=$1; SRC=$2; shift 2
+ROOT=$(cd "$(dirname "$0")/.." && pwd)
+make -C $ROOT/lets_face_it_amd/csrc -j4 > /dev/null
+mkdir -p $ROOT/build/var
+FLAGS="-O3 --offload-arch=gfx950 -fPIC -std=c++17 -I$ROOT/include -Wall -Wno-unused-function"
+[ "$SRC" = "lfi_encoder.hip" ] && FLAGS="$FLAGS -fno-slp-vectorize"
+hipcc $FLAGS "$@" -c $ROOT/lets_face_it_amd/csrc/$SRC -o $ROOT/build/var/${NAME}_${SRC%.hip}.o
+OBJS=""
+for f in lfi_core lfi_gemm lfi_pgemm lfi_encoder lfi_flow lfi_data; do
+  if [ "$f.hip" = "$SRC" ]; then OBJS="$OBJS $ROOT/build/var/${NAME}_$f.o"; else OBJS="$OBJS $ROOT/build/csrc/$f.o"; fi
+done
+hipcc --offload-arch=gfx950 -shared -fPIC -o $ROOT/build/var/liblfi_$NAME.so $OBJS
+echo "built build/var/liblfi_$NAME.so"
