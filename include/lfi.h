@@ -372,6 +372,17 @@ int lfi_flow_sample_seq(const lfi_flow_dims* d, const lfi_flow_params* p, const 
                         float* h, float* cstate /* [Ks][B][H] LSTM cell state, zero on entry; NULL for GRU */,
                         const lfi_p1enc* p1 /* NULL = "none" */, float* p1work /* lfi_flow_sample_p1_work_floats */,
                         float* work, void* stream);
+/* The same for a run of frames that continues a sequence: first_frame = number of frames earlier calls generated (the state in
+ * h / cstate carries on when > 0); pre_static, noise and start are this run's own. Lets the caller compute the static part of
+ * the next run on another stream while this run's chain of dependent cells executes. */
+/* Range guard of the sampler's fp16-piece arithmetic: out_bits[0] = bit pattern of max |v| over `count` (<= 8) fp32 arrays, one
+ * launch (finite |v| order like their bit patterns; an inf reads back as inf, a NaN as NaN). Replaces one blocking
+ * `tensor.abs().max()` per input of SeqGlow.inference (glow/models.py:567-596 has no such guard: its arithmetic is plain fp32). */
+int lfi_absmax_f32(int count, const float* const* ptrs, const long* n, unsigned* out_bits, void* stream);
+int lfi_flow_sample_seq_from(const lfi_flow_dims* d, const lfi_flow_params* p, const float* prep,
+                             const float* wct, long E, int hist1, float* pre_static, const float* noise,
+                             float* faces, int seq_len, int start, int nframes, int first_frame,
+                             float* h, float* cstate, const lfi_p1enc* p1, float* p1work, float* work, void* stream);
 
 /* ---------------------------------------------------------------- optimiser (configure_optimizers, glow/lets_face_it_glow.py:61-72)
  * Flat-buffer Adam with global-norm gradient clipping (Trainer gradient_clip_val, hparams/final_model.yaml:126):

@@ -190,3 +190,49 @@ static int dropout_masks_launch(int count, float* const* out, const long* n, con
   LFI_LAUNCH_CHECK("lfi_dropout_masks");
   return LFI_OK;
 }
+
+
+// ---------------------------------------------------------------------------------------------- range guard of the sampler
+// max |v| over up to 8 fp32 arrays in ONE launch, as the BIT PATTERN of the maximum: |v| of finite floats order like their bits,
+// +inf's pattern is above every finite one and a NaN's above +inf's, so the result reads back as NaN / inf when any input held
+// one. (SeqGlow.inference's fp16-piece arithmetic wants its operands inside fp16's range; the engine reads this word through pinned
+// memory on a side stream instead of one blocking reduction per tensor.)
+namespace {
+struct AbsMaxSegs { const float* p[8]; long n[8]; int count; };
+__global__ __launch_bounds__(256) void absmax_kernel(AbsMaxSegs sg, unsigned* __restrict__ out) {
+  unsigned m = 0u;
+  for (int i = 0; i < sg.count; ++i) {
+    const unsigned* __restrict__ p = reinterpret_cast<const unsigned*>(sg.p[i]);
+    for (long j = (long)blockIdx.x * 256 + threadIdx.x; j < sg.n[i]; j += (long)gridDim.x * 256) {
+      const unsigned b = p[j] & 0x7fffffffu;
+      m = b > m ? b : m;
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const unsigned t = (unsigned)__shfl_xor((int)m, o, 64);
+    m = t > m ? t : m;
+  }
+  if ((threadIdx.x & 63) == 0) atomicMax(out, m);
+}
+}  // namespace
+
+extern "C" int lfi_absmax_f32(int count, const float* const* ptrs, const long* n, unsigned* out_bits, void* stream) {
+  LFI_REQUIRE(count >= 0 && count <= 8, "lfi_absmax_f32: %d arrays (at most 8)", count);
+  LFI_REQUIRE(out_bits && (count == 0 || (ptrs && n)), "lfi_absmax_f32: null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t me = hipMemsetAsync(out_bits, 0, sizeof(unsigned), st);
+  LFI_REQUIRE(me == hipSuccess, "lfi_absmax_f32: hipMemsetAsync: %s", hipGetErrorString(me));
+  AbsMaxSegs sg = {};
+  long total = 0;
+  for (int i = 0; i < count; ++i) {
+    LFI_REQUIRE(n[i] >= 0 && (n[i] == 0 || ptrs[i]), "lfi_absmax_f32: array %d: n = %ld", i, n[i]);
+    sg.p[i] = ptrs[i]; sg.n[i] = n[i]; total += n[i];
+  }
+  sg.count = count;
+  if (total == 0) return LFI_OK;
+  const int blocks = (int)(lfi_cdiv(total, 256 * 8) < 2048 ? (lfi_cdiv(total, 256 * 8) > 0 ? lfi_cdiv(total, 256 * 8) : 1) : 2048);
+  hipLaunchKernelGGL(absmax_kernel, dim3(blocks), dim3(256), 0, st, sg, out_bits);
+  LFI_LAUNCH_CHECK("lfi_absmax_f32");
+  return LFI_OK;
+}

@@ -75,6 +75,7 @@ struct CellIO {
   long ldxo;              // leading dimension of x_out
   long ld_c, ld_o;        // leading dimensions of a_out / y_out and of o_out
   int l_accumulate;       // l_out += instead of =
+  int stamp_base;         // diagnostics (lfi_debug_set_stamps): slot of this cell's first phase stamp + 1, 0 = none (rev_fast_cell)
   int state_l2;           // reverse cell: read h_prev / c_prev with L1-bypassing (sc1) loads - the persistent reverse walk re-reads
                           // the state its own workgroup stored one timestep earlier, with no kernel boundary in between
 };
@@ -1656,6 +1657,13 @@ __device__ __forceinline__ bool rev_fast_cell(const FlowK& f, const CellIO& io, 
   const int nbC = C16 >> 4, nbZ = Ch16 >> 4, nbH = H16 >> 4;
   const bool t1 = wave * 16 < C, t2 = wave * 16 < H, t3 = wave * 16 < Cout;
   const int tcol = wave * 16 + l15;
+  // phase stamps of the stamping workgroup (flow step LFI_STAMP_K, tile 0): s_memtime at the phase boundaries (tools/rev_stamps.py)
+#define REV_STAMP(slot)                                                                                                  \
+  do {                                                                                                                   \
+    if (f.stamps && io.stamp_base > 0 && tid == 0 && b0 == 0 && k == f.stamp_k)                                           \
+      f.stamps[io.stamp_base - 1 + (slot)] = __builtin_amdgcn_s_memtime();                                               \
+  } while (0)
+  REV_STAMP(0);
   f32x4 wz[NG][FB_Z], wh[NG][FB_H], w3[FB_H];
   {
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
@@ -1684,17 +1692,12 @@ __device__ __forceinline__ bool rev_fast_cell(const FlowK& f, const CellIO& io, 
       cprev[r] = (NG == 4 && io.c_prev) ? ld_tile(io.c_prev + (long)row * H + jc, io.state_l2 == 0) : 0.0f;
     }
   }
-  if (wait_flag && !pipe_acquire(wait_flag, need, abort_w, tid, s_ok, false)) return false;
-  // ---- R0: stage [z1 | z2'] and h_prev
+  // ---- everything that does not depend on the incoming tile runs BEFORE the wait for it (a chain of Ks dependent cells pays
+  // whatever follows the wait Ks times per frame; stamps of round 4: staging h_prev, splitting the weight fragments into fp16
+  // pieces and the h_prev W_hh half of the recurrent product - 4 of its 5 k-blocks - were 10 k of a cell's 20 k dependent cycles)
   {
     const int row = b0 + ri;
     const bool rok = row < rows;
-    for (int c = cl; c < C16; c += 32) {
-      const float v = (c < C && rok) ? ld_tile(io.x_in + (long)row * io.ldx + c, wait_flag == nullptr) : 0.0f;
-      if (c < C) Yrm[ri * ldy + c] = v;
-      if (c < Ch) Zt[c * LT + ri] = v;
-      if (c < Ch || c >= C) Yt[c * LT + ri] = v;   // z1 rows and the zero k padding; z2 rows come from R3
-    }
     for (int j = cl; j < H16; j += 32) {
       Ht[j * LT + ri] = (io.h_prev && rok && j < H) ? ld_tile(io.h_prev + (long)row * H + j, io.state_l2 == 0) : 0.0f;
       if (j >= H) Hn[j * LT + ri] = 0.0f;
@@ -1705,25 +1708,93 @@ __device__ __forceinline__ bool rev_fast_cell(const FlowK& f, const CellIO& io, 
   f32x4 w1[FB_C];
   load_frag<FB_C>(w1, f.pWinv + (long)k * C16 * C16, C16, tcol, kq, nbC, t1);
   __syncthreads();
-  if (t2) {
-    if constexpr (X3) {   // three fp16 products (fp32-grade, x3h_*): the fragments split in registers (this launch's weights, used once)
-      X3FragH wzx[NG][FB_Z / 2], whx[NG][FB_H / 2];
+  f32x4 az[NG], ah[NG];
 #pragma unroll
-      for (int g = 0; g < NG; ++g) {
+  for (int g = 0; g < NG; ++g) {
+    az[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    ah[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+  X3FragH wzx[X3 ? NG : 1][FB_Z / 2];   // three fp16 products (fp32-grade, x3h_*): the z1-side fragments, split in registers
+  if (t2) {
+    const float* hl = Ht + kq * LT + l15;
+    if constexpr (X3) {
+#pragma unroll
+      for (int g = 0; g < NG; ++g)
 #pragma unroll
         for (int b = 0; b < FB_Z / 2; ++b) wzx[g][b] = x3h_pack(wz[g][2 * b], wz[g][2 * b + 1]);
 #pragma unroll
-        for (int b = 0; b < FB_H / 2; ++b) whx[g][b] = x3h_pack(wh[g][2 * b], wh[g][2 * b + 1]);
-      }
-      fast_cell_p2_x3h<NG>(f, Zt, Ht, Hn, wzx, whx, gc, bh, cprev, (nbZ + 1) >> 1, (nbH + 1) >> 1, tcol, kq, l15, b0, rows, io.h_out,
-                           io.c_out, nullptr, nullptr);
+      for (int b = 0; b < FB_H / 2; ++b)
+        if (b < ((nbH + 1) >> 1)) {
+          const X3FragH a = x3h_a(hl + b * 32 * LT);
+#pragma unroll
+          for (int g = 0; g < NG; ++g) ah[g] = x3h_mma(a, x3h_pack(wh[g][2 * b], wh[g][2 * b + 1]), ah[g]);
+        }
     } else {
-      fast_cell_p2<NG>(f, Zt, Ht, Hn, wz, wh, gc, bh, cprev, nbZ, nbH, tcol, kq, l15, b0, rows, io.h_out, io.c_out, nullptr);
+#pragma unroll
+      for (int b = 0; b < FB_H; ++b)
+        if (b < nbH) {
+          const float* ab = hl + b * 16 * LT;
+          const float a0 = ab[0], a1 = ab[4 * LT], a2 = ab[8 * LT], a3 = ab[12 * LT];
+#pragma unroll
+          for (int g = 0; g < NG; ++g) ah[g] = mfma16(a0, wh[g][b][0], ah[g]);
+#pragma unroll
+          for (int g = 0; g < NG; ++g) ah[g] = mfma16(a1, wh[g][b][1], ah[g]);
+#pragma unroll
+          for (int g = 0; g < NG; ++g) ah[g] = mfma16(a2, wh[g][b][2], ah[g]);
+#pragma unroll
+          for (int g = 0; g < NG; ++g) ah[g] = mfma16(a3, wh[g][b][3], ah[g]);
+        }
+    }
+  }
+  REV_STAMP(1);
+  if (wait_flag && !pipe_acquire(wait_flag, need, abort_w, tid, s_ok, false)) return false;
+  REV_STAMP(2);
+  // ---- R0: stage the tile [z1 | z2']
+  {
+    const int row = b0 + ri;
+    const bool rok = row < rows;
+    for (int c = cl; c < C16; c += 32) {
+      const float v = (c < C && rok) ? ld_tile(io.x_in + (long)row * io.ldx + c, wait_flag == nullptr) : 0.0f;
+      if (c < C) Yrm[ri * ldy + c] = v;
+      if (c < Ch) Zt[c * LT + ri] = v;
+      if (c < Ch || c >= C) Yt[c * LT + ri] = v;   // z1 rows and the zero k padding; z2 rows come from R3
     }
   }
   __syncthreads();
+  REV_STAMP(3);
+  if (t2) {   // the z1 half of the product (one k-block at C <= 64), then the gate math
+    const float* zl = Zt + kq * LT + l15;
+    if constexpr (X3) {
+#pragma unroll
+      for (int b = 0; b < FB_Z / 2; ++b)
+        if (b < ((nbZ + 1) >> 1)) {
+          const X3FragH a = x3h_a(zl + b * 32 * LT);
+#pragma unroll
+          for (int g = 0; g < NG; ++g) az[g] = x3h_mma(a, wzx[g][b], az[g]);
+        }
+    } else {
+#pragma unroll
+      for (int b = 0; b < FB_Z; ++b)
+        if (b < nbZ) {
+          const float* ab = zl + b * 16 * LT;
+          const float a0 = ab[0], a1 = ab[4 * LT], a2 = ab[8 * LT], a3 = ab[12 * LT];
+#pragma unroll
+          for (int g = 0; g < NG; ++g) az[g] = mfma16(a0, wz[g][b][0], az[g]);
+#pragma unroll
+          for (int g = 0; g < NG; ++g) az[g] = mfma16(a1, wz[g][b][1], az[g]);
+#pragma unroll
+          for (int g = 0; g < NG; ++g) az[g] = mfma16(a2, wz[g][b][2], az[g]);
+#pragma unroll
+          for (int g = 0; g < NG; ++g) az[g] = mfma16(a3, wz[g][b][3], az[g]);
+        }
+    }
+    fast_cell_p2_gates<NG>(f, Ht, Hn, az, ah, gc, bh, cprev, tcol, kq, b0, rows, io.h_out, io.c_out, nullptr, nullptr);
+  }
+  __syncthreads();
+  REV_STAMP(4);
   if (t3) fast_cell_p3(f, k, Hn, Orm, w3, nbH, tcol, kq, l15, b0, rows, nullptr, 0);
   __syncthreads();
+  REV_STAMP(5);
   // ---- R3: coupling inverse (glow/models.py:356-365)
   {
     const int row = b0 + ri;
@@ -1750,6 +1821,7 @@ __device__ __forceinline__ bool rev_fast_cell(const FlowK& f, const CellIO& io, 
     }
   }
   __syncthreads();
+  REV_STAMP(6);
   // ---- R4: x = (y W^-1) exp(-logs) - bias   (scale then center, glow/modules.py:76-79)
   if (t1) {
     const f32x4 acc = mma16_reg<FB_C>(Yt + kq * LT + l15, w1, nbC);
@@ -1766,7 +1838,10 @@ __device__ __forceinline__ bool rev_fast_cell(const FlowK& f, const CellIO& io, 
       }
     }
   }
+  REV_STAMP(7);
   if (pub_flag) pipe_publish(pub_flag, pub_value, tid, true);
+  REV_STAMP(8);
+#undef REV_STAMP
   return true;
 }
 
@@ -1788,6 +1863,7 @@ struct RevChain {
   const float* gic;       // [Ks][B][G]
   float *h, *cstate;      // [Ks][B][H] recurrent state, updated in place
   int has_prev;           // 0 at the first generated frame (zero state)
+  int frame_no;           // index of the generated frame (diagnostic phase stamps of frames < 128 only)
   unsigned* pipe;         // ticket, abort, progress words (zeroed before every launch)
 };
 template <int NG, bool X3>
@@ -1810,6 +1886,7 @@ __global__ __launch_bounds__(NT) void flow_rev_chain_kernel(FlowK f, RevChain rc
   io.h_out = rc.h + (long)k * f.B * f.H;
   if (NG == 4) { io.c_prev = rc.has_prev ? rc.cstate + (long)k * f.B * f.H : nullptr; io.c_out = rc.cstate + (long)k * f.B * f.H; }
   io.gic = rc.gic + (long)k * f.B * f.G;
+  io.stamp_base = rc.frame_no < 128 ? 1024 + 16 * rc.frame_no + 1 : 0;
   rev_fast_cell<NG, X3>(f, io, bt * MB, k + 1 < f.Ks ? prog + (k + 1) * nbt + bt : nullptr, rc.pipe + 1,
                     k > 0 ? prog + k * nbt + bt : nullptr, &s_ok);
   if (k == 0 && ld_agent(rc.pipe + 1) != 0u) {   // an abandoned chain must not pass for a frame
@@ -1858,6 +1935,7 @@ __global__ __launch_bounds__(NT) void flow_rev_walk_kernel(FlowK f, RevWalk rw) 
     io.gic = rw.gic + ((long)k * F + (long)n * B) * f.G;
     io.l_out = rw.ldk + (long)k * F + (long)n * B; io.l_accumulate = 0;
     io.state_l2 = 1;
+    io.stamp_base = n < 128 ? 1024 + 16 * n + 1 : 0;
     ok = rev_fast_cell<NG, false>(f, io, bt * MB, k + 1 < f.Ks ? prog + (k + 1) * nbt + bt : nullptr, rw.pipe + 1,
                                   k > 0 ? prog + k * nbt + bt : nullptr, &s_ok, (unsigned)n + 1u, (unsigned)n + 1u);
     __syncthreads();   // the cell's last reads of the LDS operands are done before the next timestep stages its own
@@ -3556,9 +3634,22 @@ extern "C" int lfi_flow_sample_seq(const lfi_flow_dims* d, const lfi_flow_params
                                    long E, int hist1, float* pre_static, const float* noise, float* faces, int seq_len,
                                    int start, int nframes, float* h, float* cstate, const lfi_p1enc* p1, float* p1work,
                                    float* work, void* stream) {
+  return lfi_flow_sample_seq_from(d, p, prep, wct, E, hist1, pre_static, noise, faces, seq_len, start, nframes, 0, h, cstate, p1,
+                                  p1work, work, stream);
+}
+
+// A run of `nframes` generated frames that is NOT the first of its sequence: first_frame = how many frames of the sequence earlier
+// calls generated (> 0: the recurrent state in h / cstate is theirs and carries on; pre_static / noise / start are this run's own).
+// The engine samples a long sequence as a few such runs so that the static part of run i + 1 (window encoders, the
+// non-autoregressive cond_transform columns) can be computed on a second stream under the latency-bound chain of run i.
+extern "C" int lfi_flow_sample_seq_from(const lfi_flow_dims* d, const lfi_flow_params* p, const float* prep, const float* wct,
+                                        long E, int hist1, float* pre_static, const float* noise, float* faces, int seq_len,
+                                        int start, int nframes, int first_frame, float* h, float* cstate, const lfi_p1enc* p1,
+                                        float* p1work, float* work, void* stream) {
   FlowK f = {};
   int rc = fill_flow(d, p, prep, &f, "lfi_flow_sample_seq");
   if (rc) return rc;
+  LFI_REQUIRE(first_frame >= 0, "lfi_flow_sample_seq_from: negative first_frame");
   LFI_REQUIRE(prep && wct && pre_static && noise && faces && h && work, "lfi_flow_sample_seq: null pointer");
   LFI_REQUIRE(hist1 >= 0 && hist1 <= start && start + nframes <= seq_len, "lfi_flow_sample_seq: bad frame range");
   LFI_REQUIRE((long)hist1 * d->C <= E, "lfi_flow_sample_seq: window wider than the feature vector");
@@ -3657,7 +3748,7 @@ extern "C" int lfi_flow_sample_seq(const lfi_flow_dims* d, const lfi_flow_params
       RevChain rcn = {};
       rcn.noise = noise + (long)n * B * C; rcn.xa = xa; rcn.xb = xb;
       rcn.frame = faces + (long)t * C; rcn.ld_frame = (long)seq_len * C;
-      rcn.gic = gic; rcn.h = h; rcn.cstate = cstate; rcn.has_prev = n > 0 ? 1 : 0; rcn.pipe = chain_state;
+      rcn.gic = gic; rcn.h = h; rcn.cstate = cstate; rcn.has_prev = first_frame + n > 0 ? 1 : 0; rcn.frame_no = first_frame + n; rcn.pipe = chain_state;
       hipError_t me = hipMemsetAsync(chain_state, 0, chain_words * sizeof(unsigned), st);
       LFI_REQUIRE(me == hipSuccess, "lfi_flow_sample_seq: hipMemsetAsync: %s", hipGetErrorString(me));
       if (f.lstm) hipLaunchKernelGGL((flow_rev_chain_kernel<4, false>), dim3(Ks * f.nbt), dim3(NT), lds, st, f, rcn);
@@ -3670,10 +3761,10 @@ extern "C" int lfi_flow_sample_seq(const lfi_flow_dims* d, const lfi_flow_params
     for (int k = Ks - 1; k >= 0; --k) {
       CellIO io = {};
       io.k = k; io.rows = B; io.x_in = xin; io.ldx = ldx;
-      io.h_prev = n > 0 ? h + (long)k * B * H : nullptr;
+      io.h_prev = first_frame + n > 0 ? h + (long)k * B * H : nullptr;
       io.gic = gic + (long)k * B * G;
       io.h_out = h + (long)k * B * H;
-      if (f.lstm) { io.c_prev = n > 0 ? cstate + (long)k * B * H : nullptr; io.c_out = cstate + (long)k * B * H; }
+      if (f.lstm) { io.c_prev = first_frame + n > 0 ? cstate + (long)k * B * H : nullptr; io.c_out = cstate + (long)k * B * H; }
       if (k == 0) { io.x_out = faces + (long)t * C; io.ldxo = (long)seq_len * C; }
       else { io.x_out = (k & 1) ? xa : xb; io.ldxo = C; }
       if (!fast) hipLaunchKernelGGL(flow_step_kernel<true>, dim3(f.nbt), dim3(NT), lds, st, f, io);

@@ -233,6 +233,7 @@ class GlowEngine:
         self.sample_frame_precision = {"bf16x3": 1, "f32": 0, "bf16x6": 5, "fp16x3": 9}.get(os.environ.get("LFI_SAMPLE_FRAME_PRECISION", ""))
         self._mask_calls = 0
         self._enc_stash_f16 = {}   # modality -> did the last stashing forward write its gate stash as fp16 (build_features)
+        self._sample_fp16_unsafe = False   # set once a sampling call in fp16 pieces came back non-finite (_check_last_sample)
         # GEMM class -> bf16x3 products to drop (bit 0: a_lo b_hi, bit 1: a_hi b_lo; 3 = plain bf16 operands, one product).
         # Measurement switch only: profiles/precision_sweep.md (tools/precision_sweep.py, final widths, against the fp64
         # oracle) shows NO class that keeps the test bounds with fewer than three products - the forward classes cost
@@ -612,7 +613,7 @@ class GlowEngine:
             raise ValueError("%s: expected contiguous float32 GPU tensor (B=%d, T>=%d, %d), got %s %s on %s"
                              % (name, B, Tmin, dim, tuple(x.shape), x.dtype, x.device))
 
-    def build_features(self, data, faces, B, T, masks, cond, with_stash, skip_p1=False, sampling=False, windows=False):
+    def build_features(self, data, faces, B, T, masks, cond, with_stash, skip_p1=False, sampling=False, windows=False, frame0=0):
         """FeatureEncoder.forward for every timestep at once (models.py:127-145): fills cond (F x ldf, folded layout).
 
         windows=True: `data` holds ONE conditioning window per modality, (B, hist, dim) each, as create_conditioning
@@ -637,7 +638,8 @@ class GlowEngine:
                         raise ValueError("frame_nb: expected a float32 GPU tensor of shape (B, 1), got %s %s on %s"
                                          % (tuple(base.shape), base.dtype, base.device))
                     base = base.contiguous()
-                check(self.L.lfi_fill_frame_nb(ptr(base), 0.0 if (sampling or windows) else 2.0 * s.start, B, N,
+                # (frame0: a run of sampled frames that starts frame0 frames into its sequence, see sample())
+                check(self.L.lfi_fill_frame_nb(ptr(base), 2.0 * frame0 if sampling else (0.0 if windows else 2.0 * s.start), B, N,
                                                cond.data_ptr(), s.ldf, e.fcol, st), "lfi_fill_frame_nb")
                 continue
             # prev_p1_face is the window [t - hist, t) of the model's own output (models.py:601-603); every other modality
@@ -1164,7 +1166,12 @@ class GlowEngine:
     # ------------------------------------------------------------------ sampling / inversion
     @translate_oom
     def sample(self, seq_len, data, noise, masks=None):
-        """SeqGlow.inference (models.py:567-596) with the prior noise given: (seq_len - start, B, C), already * eps."""
+        """SeqGlow.inference (models.py:567-596) with the prior noise given: (seq_len - start, B, C), already * eps.
+
+        The generated frames are produced in a few RUNS (LFI_SAMPLE_RUNS, default 4 from 64 frames up): everything of a run that
+        does not depend on generated frames - window encoders, the non-autoregressive cond_transform columns - is computed on the
+        second stream while the previous run's chain of dependent reverse cells (latency-bound: ~15 us per cell, the chip mostly
+        idle) executes on the main one; only the first run's static part stands in front of the chain."""
         s = self.spec
         seed = data["p1_face"]
         B = seed.shape[0]
@@ -1174,42 +1181,75 @@ class GlowEngine:
         self._check_input(seed, "p1_face", B, s.start, s.C)
         if tuple(noise.shape) != (nframes, B, s.C) or not noise.is_contiguous() or noise.dtype != torch.float32:
             raise ValueError("noise must be a contiguous float32 (%d, %d, %d) tensor" % (nframes, B, s.C))
+        self._check_last_sample()
         F = nframes * B
         KD = s.Ks * s.D
+        main = torch.cuda.current_stream(self.device)
+        # ---- range guard of the fp16-piece arithmetic: ONE reduction over the caller's tensors, the noise and the parameters,
+        # read back through pinned memory on the side stream; the host waits for it only when it picks the per-frame arithmetic,
+        # with the first run's static part already queued behind it (no drained queue, no per-tensor sync)
+        fp, guard = self.sample_frame_precision, None
+        if fp is None:
+            fp = 0
+            if self.precision == 1:
+                fp = 5 if self._sample_fp16_unsafe else None
+                if fp is None:
+                    guard = self._launch_range_guard([self.params, noise] + [v for v in data.values() if torch.is_tensor(v)
+                                                                                and v.dtype == torch.float32 and v.is_cuda])
         ev_static = self._tic("sample_static")
         faces = self._buf("sample_faces", B * seq_len * s.C)[:B * seq_len * s.C].view(B, seq_len, s.C)
         faces.zero_()
         faces[:, :s.start].copy_(seed[:, :s.start])
         self.run_prep(with_inverse=True)
-        # everything of the features that does not depend on generated frames, through cond_transform (no activation yet)
         cond = self._buf("cond", F * s.ldf)
-        self.build_features(data, None, B, seq_len, masks, cond, with_stash=False, skip_p1=True, sampling=True)
         e1 = s.encoders[0]             # prev_p1_face: the only autoregressive input
         c1 = (e1.fdim + 3) // 4 * 4    # first column after its block (blocks start on 4-float boundaries)
         pre = self._buf("pre_static", F * KD)
-        if s.Ef > c1 and self.precision == 1 and os.environ.get("LFI_PGEMM", "1") != "0":
-            # the static columns of cond_transform for every frame of the call (F x Ks D x 640 at final widths: the largest
-            # product of a sampling call) on pre-split planes, as the training step's cond_transform forward
-            cp, nkc = self.planes("cond_planes", cond, s.ldf, F, s.Ef - c1, x_off=c1)
+        planes_ok = s.Ef > c1 and self.precision == 1 and os.environ.get("LFI_PGEMM", "1") != "0"
+        wp = nkw = None
+        if planes_ok:
             wp, nkw = self.planes("wct_planes_static", self.wct_f, s.ldf, KD, s.Ef - c1, x_off=c1)
-            self.gemm_planes(F, KD, s.Ef - c1, cp, nkc, wp, nkw, pre, KD, bias=self.fview("bct"), cls="cond_fwd")
-        elif s.Ef > c1:
-            self.gemm(F, KD, s.Ef - c1, cond, s.ldf, 1, self.wct_f, s.ldf, 1, pre, KD, bias=self.fview("bct"),
-                      a_off=c1, b_off=c1)
-        else:
-            pre[:F * KD].view(F, KD).copy_(self.fview("bct").reshape(1, KD).expand(F, KD))
+        runs = self._sample_runs(nframes)
+
+        def static(o, n):
+            """Frames [o, o + n) of the call: features of everything but prev_p1_face, then through the static cond_transform columns
+            (no activation yet) into their rows of `pre`."""
+            sub = {k: (v[:, o:o + s.start + n].contiguous() if (torch.is_tensor(v) and v.dim() == 3 and k != "p1_face") else v)
+                   for k, v in data.items()} if (o > 0 or n < nframes) else data
+            mk = None if masks is None else {k: v[o:o + n].contiguous() for k, v in masks.items()}
+            rows = n * B
+            cnd = cond[o * B * s.ldf:]
+            prs = pre[o * B * KD:]
+            self.build_features(sub, None, B, s.start + n, mk, cnd, with_stash=False, skip_p1=True, sampling=True, frame0=o)
+            if planes_ok:
+                # the static columns of cond_transform for the run's frames (F x Ks D x 640 at final widths: the largest product of a
+                # sampling call) on pre-split planes, as the training step's cond_transform forward
+                cp, nkc = self.planes("cond_planes", cnd, s.ldf, rows, s.Ef - c1, x_off=c1)
+                self.gemm_planes(rows, KD, s.Ef - c1, cp, nkc, wp, nkw, prs, KD, bias=self.fview("bct"), cls="cond_fwd")
+            elif s.Ef > c1:
+                self.gemm(rows, KD, s.Ef - c1, cnd, s.ldf, 1, self.wct_f, s.ldf, 1, prs, KD, bias=self.fview("bct"), a_off=c1, b_off=c1)
+            else:
+                prs[:rows * KD].view(rows, KD).copy_(self.fview("bct").reshape(1, KD).expand(rows, KD))
+
+        static(*runs[0])
+        self._toc("sample_static", ev_static)
+        events = [None]
+        if len(runs) > 1:
+            side = self._fork()
+            if side is None:
+                for o, n in runs[1:]:
+                    static(o, n)
+                    events.append(None)
+            else:
+                with self._on(side):
+                    for o, n in runs[1:]:
+                        static(o, n)
+                        ev = torch.cuda.Event()
+                        ev.record(side)
+                        events.append(ev)
+        if guard is not None:
+            fp = 9 if self._read_range_guard(guard) <= 1e3 else 5
         dims = self._flow_dims(B, nframes)
-        fp = self.sample_frame_precision
-        if fp is None:
-            fp = 0
-            if self.precision == 1:
-                # fp16 pieces want operands inside fp16's range. Weights are what training left; the data
-                # are the caller's: standardised corpora stay under ~10, and anything beyond 1e3 (features then reach 1e3 -
-                # 1e4, still finite, but the margin is gone) takes the six-product bf16 form, which has no range caveat. One
-                # reduction per input tensor and one host sync per sampling call.
-                amax = max(float(v.abs().max()) for k, v in data.items() if torch.is_tensor(v) and v.is_floating_point())
-                amax = max(amax, float(noise.abs().max()))
-                fp = 9 if amax <= 1e3 else 5
         dims.gemm_precision = int(fp)
         h = self._buf("sample_h", s.Ks * B * s.H, zero=True)
         cs = self._buf("sample_c", s.Ks * B * s.H, zero=True) if s.rnn_type == "lstm" else None
@@ -1229,33 +1269,132 @@ class GlowEngine:
                         self.view("enc.p1_face." + leaf).data_ptr())
         p1work = self._buf("scratch.sample_p1", self.L.lfi_flow_sample_p1_work_floats(C.byref(dims), C.byref(p1), hist1))
 
-        def launch():
-            check(self.L.lfi_flow_sample_seq(C.byref(dims), C.byref(p), self.prep.data_ptr(), self.wct_f.data_ptr(),
-                                             s.ldf, hist1, pre.data_ptr(), nz.data_ptr(), faces.data_ptr(), seq_len, s.start,
-                                             nframes, h.data_ptr(), ptr(cs), C.byref(p1), p1work.data_ptr(), work.data_ptr(),
-                                             _stream()), "lfi_flow_sample_seq")
+        def launch(o, n):
+            check(self.L.lfi_flow_sample_seq_from(C.byref(dims), C.byref(p), self.prep.data_ptr(), self.wct_f.data_ptr(), s.ldf, hist1,
+                                                  pre.data_ptr() + 4 * o * B * KD, nz.data_ptr() + 4 * o * B * s.C, faces.data_ptr(),
+                                                  seq_len, s.start + o, n, o, h.data_ptr(), ptr(cs), C.byref(p1), p1work.data_ptr(),
+                                                  work.data_ptr(), _stream()), "lfi_flow_sample_seq_from")
 
         # The per-frame chain (2 small GEMMs + Ks reverse cells, ~19 launches x nframes) is launch-bound on the host at
-        # small batch: from the second call of a shape on, it is replayed as ONE hipGraph (captured once; every buffer it
-        # touches is engine-owned and keeps its address). LFI_NO_GRAPH=1 keeps eager launches.
+        # small batch: from the second call of a shape on, every run of it is replayed as ONE hipGraph (captured once; every buffer
+        # it touches is engine-owned and keeps its address). LFI_NO_GRAPH=1 keeps eager launches.
         key = (B, seq_len, self.precision, int(dims.gemm_precision), faces.data_ptr(), pre.data_ptr(), nz.data_ptr(), h.data_ptr(),
-               self.prep.data_ptr())
-        graph = self._sample_graphs.get(key)
-        if graph is None and os.environ.get("LFI_NO_GRAPH") != "1" and self._sample_seen.get(key):
+               self.prep.data_ptr(), tuple(runs))
+        graphs = self._sample_graphs.get(key)
+        if graphs is None and os.environ.get("LFI_NO_GRAPH") != "1" and self._sample_seen.get(key):
             torch.cuda.synchronize()
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                launch()
-            self._sample_graphs = {key: graph}   # one shape at a time: buffers are shared between shapes
-        elif graph is None:
+            graphs = []
+            for o, n in runs:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    launch(o, n)
+                graphs.append(g)
+            self._sample_graphs = {key: graphs}   # one shape at a time: buffers are shared between shapes
+        elif graphs is None:
             self._sample_seen = {key: True}
-            launch()
-        self._toc("sample_static", ev_static)
-        if graph is not None:
-            ev = self._tic("sample_graph")
-            graph.replay()
-            self._toc("sample_graph", ev)
-        return faces[:, s.start:].clone()
+        ev = self._tic("sample_graph")
+        for i, (o, n) in enumerate(runs):
+            if events[i] is not None:
+                main.wait_event(events[i])
+            if graphs is not None:
+                graphs[i].replay()
+            else:
+                launch(o, n)
+        self._toc("sample_graph" if graphs is not None else "sample_chain_eager", ev)
+        self._join()
+        out = faces[:, s.start:].clone()
+        if fp == 9:
+            self._watch_sample_output(out)
+        return out
+
+    # ---- helpers of sample()
+    @staticmethod
+    def _sample_runs(nframes):
+        """[(first frame, frames)] of the runs a sampling call is cut into (see sample())."""
+        want = os.environ.get("LFI_SAMPLE_RUNS")
+        nruns = int(want) if want else (4 if nframes >= 64 else 1)
+        nruns = max(1, min(nruns, nframes))
+        base, extra, runs, o = nframes // nruns, nframes % nruns, [], 0
+        for i in range(nruns):
+            n = base + (1 if i < extra else 0)
+            runs.append((o, n))
+            o += n
+        return runs
+
+    def _pinned_word(self, name):
+        t = self.__dict__.get(name)
+        if t is None:
+            t = torch.zeros(1, dtype=torch.int32).pin_memory()
+            setattr(self, name, t)
+        return t
+
+    def _launch_range_guard(self, tensors):
+        """One launch: bit pattern of max |v| over `tensors` (lfi_absmax_f32), copied to pinned memory on the guard stream. ->
+        (pinned word, event)."""
+        main = torch.cuda.current_stream(self.device)
+        gs = self.__dict__.get("_guard_stream")
+        if gs is None:
+            gs = self._guard_stream = torch.cuda.Stream(device=self.device)
+        tensors = [t.contiguous() for t in tensors if t.numel() > 0]
+        if len(tensors) > 8:
+            raise ValueError("range guard: %d float tensors in one sampling call (at most 8)" % len(tensors))
+        word = self._buf_i32("sample_guard_word", 1)
+        n = len(tensors)
+        ptrs, ns = (C.c_void_p * max(n, 1))(), (C.c_long * max(n, 1))()
+        for i, t in enumerate(tensors):
+            ptrs[i], ns[i] = t.data_ptr(), t.numel()
+        gs.wait_stream(main)          # the tensors are complete
+        pinned = self._pinned_word("_guard_pinned")
+        with torch.cuda.stream(gs):
+            check(self.L.lfi_absmax_f32(n, ptrs, ns, word.data_ptr(), gs.cuda_stream), "lfi_absmax_f32")
+            pinned.copy_(word, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(gs)
+        for t in tensors:
+            t.record_stream(gs)
+        return pinned, ev
+
+    @staticmethod
+    def _read_range_guard(guard):
+        """max |v| as a float (inf / nan when an input held one: both fail `<= limit`)."""
+        import struct
+        pinned, ev = guard
+        ev.synchronize()
+        return struct.unpack("<f", struct.pack("<I", int(pinned.item()) & 0xffffffff))[0]
+
+    def _buf_i32(self, name, n):
+        t = self._ws.get(name)
+        if t is None or t.numel() < n:
+            t = torch.zeros(n, dtype=torch.int32, device=self.device)
+            self._ws[name] = t
+        return t
+
+    def _watch_sample_output(self, out):
+        """fp16 pieces turn a value beyond 65504 - e.g. a generated frame of a diverging checkpoint fed back through the
+        prev_p1_face window - into inf - inf = NaN where fp32 would stay finite. The generated frames are scanned asynchronously
+        (same guard kernel); a non-finite result is reported at the NEXT engine call (_check_last_sample: a warning, and the engine
+        stays with the six-product bf16 form, which has no range caveat, from then on)."""
+        pinned = self._pinned_word("_watch_pinned")
+        main = torch.cuda.current_stream(self.device)
+        word = self._buf_i32("sample_watch_word", 1)
+        ptrs, ns = (C.c_void_p * 1)(out.data_ptr()), (C.c_long * 1)(out.numel())
+        check(self.L.lfi_absmax_f32(1, ptrs, ns, word.data_ptr(), main.cuda_stream), "lfi_absmax_f32")
+        pinned.copy_(word, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(main)
+        self._sample_watch = (pinned, ev)
+
+    def _check_last_sample(self):
+        w = self.__dict__.get("_sample_watch")
+        if w is None or not w[1].query():      # never a host wait: a scan still in flight is looked at by a later call
+            return
+        self._sample_watch = None
+        amax = self._read_range_guard(w)
+        if not (amax <= 65504.0):     # inf or NaN in the frames of the previous fp16-piece sampling call
+            import warnings
+            self._sample_fp16_unsafe = True
+            warnings.warn("the previous sampling call produced non-finite frames (max |x| = %r) in its fp16-piece arithmetic: this "
+                          "engine samples with six bf16 products (no range caveat) from now on; re-run that call" % amax)
 
     @translate_oom
     def invert(self, z_seq, batch, masks=None):

@@ -99,19 +99,22 @@ def test_deep_flow_sampling_and_invert_against_oracle(gpu_device, precision):
     # 96 inverse couplings (z2 / scale - shift with scale = sigmoid(.) < 1) of a random-init flow blow the frames up frame over frame
     # (|x| reaches 1e9 and more by the eighth): the error is measured per generated frame relative to that frame's largest magnitude
     # (never below 1: for |x| <= 1 it is north_star's absolute 1e-5)
+    # and that growth is chaotic: by the eighth frame plain fp32 torch has lost every digit against fp64 (relative error ~1). Each
+    # frame is therefore gated against what fp32 itself keeps of it: max(1e-5, 3 x the fp32 error of THAT frame); the first frames,
+    # where fp32 still means something, are the test
     scale = ref.abs().amax(dim=(0, 2)).clamp(min=1.0)                               # (frames,)
-    own = float(((ref32.double() - ref).abs().amax(dim=(0, 2)) / scale).max())
-    gate = max(1e-5, 1.5 * own)
+    own = (ref32.double() - ref).abs().amax(dim=(0, 2)) / scale
     out = m.inference(seq_len, to_dev(data, gpu_device), noise=noise.to(gpu_device))
     out2 = m.inference(seq_len, to_dev(data, gpu_device), noise=noise.to(gpu_device))   # hipGraph replay
     per_frame = (out.cpu().double() - ref).abs().amax(dim=(0, 2)) / scale
-    err = float(per_frame.max())
-    report("DEEP flow (96 steps) sampling %s, batch 6 x 8 generated frames (|x| up to %.1e): max error relative to the frame's largest "
-           "value vs fp64 oracle %.2e (first frame %.2e); plain fp32 torch on the CPU: %.2e; gate %.2e"
-           % (precision, float(ref.abs().max()), err, float(per_frame[0]), own, gate))
+    report("DEEP flow (96 steps) sampling %s, batch 6 x 8 generated frames (|x| up to %.1e): per-frame max error relative to the "
+           "frame's largest value vs fp64 oracle %s; plain fp32 torch on the CPU %s"
+           % (precision, float(ref.abs().max()), " ".join("%.1e" % v for v in per_frame.tolist()),
+              " ".join("%.1e" % v for v in own.tolist())))
     assert torch.equal(out, out2)
     assert torch.isfinite(out).all()
-    assert err <= gate, (precision, err, gate)
+    for fi in range(per_frame.numel()):
+        assert float(per_frame[fi]) <= max(1e-5, 3.0 * float(own[fi])), (precision, fi, float(per_frame[fi]), float(own[fi]))
 
     # invert: teacher-forced reverse pass of the oracle's own latents on a fresh batch
     batch = oracle.synthetic_batch(B, seq_len, 50, 27, seed=71)

@@ -143,17 +143,17 @@ def test_sampler_leaves_fp16_pieces_for_out_of_range_inputs(gpu_device):
     dd = to_dev(data, gpu_device)
     eng = m._ensure_engine(gpu_device)
     seen = []
-    real = eng.L.lfi_flow_sample_seq
+    real = eng.L.lfi_flow_sample_seq_from
 
     def spy(dims, *a):
         seen.append(int(dims._obj.gemm_precision))
         return real(dims, *a)
 
-    eng.L.lfi_flow_sample_seq = spy
+    eng.L.lfi_flow_sample_seq_from = spy
     try:
         out = m.inference(seq_len, dd, noise=noise)
     finally:
-        eng.L.lfi_flow_sample_seq = real
+        eng.L.lfi_flow_sample_seq_from = real
     assert seen and seen[0] == 5, seen            # six bf16 products, not fp16 pieces
     eng.sample_frame_precision = 0
     ref = m.inference(seq_len, dd, noise=noise)
@@ -163,11 +163,11 @@ def test_sampler_leaves_fp16_pieces_for_out_of_range_inputs(gpu_device):
     assert float((out - ref).abs().max()) <= 2e-5 * max(scale, 1.0)
     data["p2_speech"][0, 3, 5] = 4.0              # inside the range: fp16 pieces
     seen.clear()
-    eng.L.lfi_flow_sample_seq = spy
+    eng.L.lfi_flow_sample_seq_from = spy
     try:
         m.inference(seq_len, to_dev(data, gpu_device), noise=noise)
     finally:
-        eng.L.lfi_flow_sample_seq = real
+        eng.L.lfi_flow_sample_seq_from = real
     assert seen and seen[0] == 9, seen
 
 

@@ -603,3 +603,66 @@ def test_dropout_masks_and_padded_copies(gpu_device):
     _lib.check(L.lfi_pad_rows(x.data_ptr(), 37, 50, 50, out.data_ptr(), 52, torch.cuda.current_stream().cuda_stream))
     torch.cuda.synchronize()
     assert torch.equal(out[:, :50], x) and bool((out[:, 50:] == 0).all())
+
+
+@pytest.mark.parametrize("mod,two,s16", [("p2_face", 1, 1), ("p2_face", 0, 0), ("p2_speech", 1, 0), ("p1_speech", 1, 1)])
+def test_window_encoder_tilings_match(gpu_device, monkeypatch, mod, two, s16):
+    """The three tilings of the fused window-encoder recurrence - eight waves of 64 windows x 32 hidden units (default where the
+    launch fills the chip: every weight fragment feeds two row tiles, half the fragment bytes per MFMA), four waves of 64 x 64
+    (LFI_ENC_W8=0) and the 32-window row-layout kernels (LFI_ENC_W8=0 LFI_ENC_R64=0) - at the benchmark's shapes, through the C ABI:
+    same products in the same order per window, so features, gate stash, state stash and the gradient stashes are bit-identical;
+    the bias gradients (sums over per-workgroup partials, another grouping) agree to rounding. (glow/models.py:55-80, nn.GRU over
+    every window.)"""
+    import ctypes as C
+    from lets_face_it_amd import _lib
+    from lets_face_it_amd._lib import EncDesc, check
+    L = _lib.lib()
+    hist, hid = {"p2_face": (24, 256), "p2_speech": (16, 256), "p1_speech": (2, 128)}[mod]
+    B, T, start = 256, 80, 24
+    N = T - start
+    F = N * B
+    dev = gpu_device
+    g = torch.Generator().manual_seed(3)
+    rnd = lambda *s: (torch.randn(*s, generator=g) * 0.3).to(dev)   # noqa: E731
+    xp, whh, b_ih, b_hh = rnd(B * T, 3 * hid), rnd(3 * hid, hid) * 0.2, rnd(3 * hid), rnd(3 * hid)
+    mask = ((torch.rand(F, hist, generator=g) < 0.5).float() * 2).to(dev)
+    ldc = 896
+    dcond = rnd(F, ldc)
+    st = torch.cuda.current_stream().cuda_stream
+    d = EncDesc(B, T, N, start, hist, hid, ldc, 256, 1, 0, 0, two, s16)
+    if s16:
+        assert L.lfi_encode_windows_stash_f16_ok(C.byref(d))
+    work = torch.zeros(max(int(L.lfi_encode_windows_work_floats(C.byref(d))), 1), device=dev)
+    outs = {}
+    rows_per_wg = {"w8": 64 * (8 // (((hid + 63) // 64 * 64) // 32)), "r64": 2 * 32 * (4 // ((hid + 63) // 64)), "wide": 32 * (4 // ((hid + 63) // 64))}
+    groups = {"w8": 8 // (((hid + 63) // 64 * 64) // 32), "r64": 4 // ((hid + 63) // 64), "wide": 4 // ((hid + 63) // 64)}
+    for name, env in (("w8", {"LFI_ENC_W8": "1", "LFI_ENC_R64": "1"}), ("r64", {"LFI_ENC_W8": "0", "LFI_ENC_R64": "1"}),
+                      ("wide", {"LFI_ENC_W8": "0", "LFI_ENC_R64": "0"})):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        cond = torch.zeros(F, ldc, device=dev)
+        gates = torch.zeros(hist * F * 4 * hid, device=dev)
+        hseq = torch.zeros(hist * F * hid, device=dev)
+        dgi = torch.zeros(hist * F * hid, device=dev)
+        dgh = torch.zeros(hist * F * 3 * hid, device=dev)
+        prow = int(L.lfi_encode_windows_bias_rows(C.byref(d)))
+        wgs = -(-F // rows_per_wg[name])
+        if wgs >= 128:      # the tiling is only taken where its workgroups still cover the chip
+            assert prow == wgs * groups[name], (name, prow, wgs, groups[name])
+        part = torch.zeros(prow * 4 * hid, device=dev)
+        check(L.lfi_encode_windows_fwd(C.byref(d), xp.data_ptr(), whh.data_ptr(), b_ih.data_ptr(), b_hh.data_ptr(), mask.data_ptr(),
+                                       cond.data_ptr(), gates.data_ptr(), hseq.data_ptr(), work.data_ptr(), st), "fwd")
+        check(L.lfi_encode_windows_bwd(C.byref(d), dcond.data_ptr(), ldc, whh.data_ptr(), gates.data_ptr(), hseq.data_ptr(),
+                                       dgi.data_ptr(), dgh.data_ptr(), part.data_ptr(), work.data_ptr(), st), "bwd")
+        gbi, gbh = torch.zeros(3 * hid, device=dev), torch.zeros(3 * hid, device=dev)
+        check(L.lfi_encode_windows_bias_grads(part.data_ptr(), prow, hid, gbi.data_ptr(), gbh.data_ptr(), st), "bias")
+        torch.cuda.synchronize()
+        outs[name] = (cond, gates, hseq, dgi, dgh, gbi, gbh)
+    b = outs["wide"]
+    assert torch.isfinite(b[0]).all() and float(b[0].abs().max()) > 0
+    for name in ("w8", "r64"):
+        a = outs[name]
+        for i, what in enumerate(("features", "gate stash", "state stash", "dgi", "dgh")):
+            assert torch.equal(a[i], b[i]), (name, what)
+        for i in (5, 6):
+            assert float((a[i] - b[i]).abs().max()) <= 2e-5 * max(1.0, float(b[i].abs().max())), name
