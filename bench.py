@@ -307,7 +307,7 @@ def _roofline(spec, F, timing, precision):
             "ms_per_launch": ms, "launches_timed": n_launch}
 
 
-def _roofline_hbm(spec, B, T, timing, precision):
+def _roofline_hbm(spec, B, T, timing, precision, stash_f16=None):
     """Second roofline, for the largest HBM-bound kernel: the fused GRU window encoder of p2_face, forward
     (enc_gru_fwd_wide_kernel). Algorithmic bytes per launch = what must cross HBM once: the BPTT stash it writes (r, z, n,
     W_hn h + b_hn and h: 5 * hid floats per window and history step), the projected inputs it reads (B*T x 3*hid, shared by the
@@ -317,21 +317,28 @@ def _roofline_hbm(spec, B, T, timing, precision):
     if e is None or not n_launch:
         return None
     F = B * (T - spec.start)
-    alg = 4.0 * (e.hist * F * 5 * e.hid + B * T * 3 * e.hid + F * e.hid)
+    f16 = bool(stash_f16 and stash_f16.get("p2_face"))
+    # per window-step and hidden unit: h (4 B, fp32: a GEMM operand of dW_hh) + r, z, n, W_hn h as four fp16 (8 B) or four fp32 (16 B)
+    alg = e.hist * F * e.hid * (4.0 + (8.0 if f16 else 16.0)) + 4.0 * (B * T * 3 * e.hid + F * e.hid)
     traffic = None
     try:
         tj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_%s.json" % precision)))
         for name, v in tj["kernels"].items():
-            if ("enc_gru_fwd_wide_kernel" in name or "enc_gru_fwd_fused_kernel" in name) and name.endswith("grid=%d" % (((F + 31) // 32) * 256)):
+            if "enc_gru_fwd_" in name and any(name.endswith("grid=%d" % g) for g in (((F + 31) // 32) * 256, ((F + 63) // 64) * 256,
+                                                                                     ((F + 63) // 64) * 512)):
                 traffic = max(traffic or 0.0, v["hbm_bytes"])   # p2_face (24 steps) is the larger of the two 256-wide launches
     except (OSError, ValueError, KeyError):
         pass
     ach = alg / (ms * 1e-3) / 1e9
-    return {"bound": "hbm", "kernel": "enc_gru_fwd_wide_kernel, p2_face windows (hist %d, hid %d)" % (e.hist, e.hid),
+    return {"bound": "hbm", "kernel": "fused GRU window-encoder recurrence (enc_gru_fwd_*_kernel), p2_face windows (hist %d, hid %d), "
+                                      "gate stash %s" % (e.hist, e.hid, "fp16" if f16 else "fp32"),
             "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0, "traffic": traffic,
             "traffic_note": "PMC bytes per launch of this kernel name and grid: the mean over the p2_face (24 steps) and p2_speech "
                             "(16 steps) launches, which share them",
             "timing_note": "HIP events in the 5-step all-tags region that follows the timed region (bench_train)",
+            "bound_note": "the launch is paced by its matrix phase, not by these bytes: without any stash it takes 0.62 of 0.66 ms "
+                          "(tools/enc_probe.py, DESIGN.md section 9); the byte rate is reported because this is the step's largest "
+                          "HBM stream",
             "algorithmic_bytes_per_launch": alg, "ms_per_launch": ms, "launches_timed": n_launch}
 
 
@@ -424,7 +431,7 @@ def bench_train(args, model, trainer, spec, device, world, rank, hp):
                    "gemm_products": _products_label(args.precision, eng, F)},
         "final_loss": float(loss),
         "roofline": _roofline(spec, F, timing, args.precision),
-        "roofline_hbm": _roofline_hbm(spec, B, T, timing, args.precision),
+        "roofline_hbm": _roofline_hbm(spec, B, T, timing, args.precision, getattr(eng, "_enc_stash_f16", None)),
         "kernel_timing": {t: {"launches": n, "ms": round(m_, 4)} for t, (n, m_) in timing.items()},
         "gpu_state_under_load": gpu_state,
     }

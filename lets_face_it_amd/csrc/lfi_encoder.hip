@@ -39,7 +39,8 @@ struct EncArgs {
 #ifdef LFI_ENC_STAMPS
 #define ENC_STAMP(slot)                                                                                          \
   do {                                                                                                           \
-    if (a.stamps && tid == 0 && blockIdx.x == 0 && s == 5) a.stamps[128 + (slot)] = __builtin_amdgcn_s_memtime(); \
+    if (a.stamps && tid == 0 && blockIdx.x == 0 && s >= 4 && s < 12)                                              \
+      a.stamps[128 + 8 * (s - 4) + (slot)] = __builtin_amdgcn_s_memtime();                                        \
   } while (0)
 #else
 #define ENC_STAMP(slot) do { } while (0)
@@ -710,6 +711,7 @@ __global__ __launch_bounds__(ENC_NT, 2) void enc_gru_fwd_wide_kernel(EncArgs a, 
   __syncthreads();
 
   for (int s = 0; s < a.hist; ++s) {
+    ENC_STAMP(0);
     f32x16 acc[2][3];
 #pragma unroll
     for (int t = 0; t < 2; ++t)
@@ -735,6 +737,9 @@ __global__ __launch_bounds__(ENC_NT, 2) void enc_gru_fwd_wide_kernel(EncArgs a, 
 #pragma unroll
           for (int t = 0; t < 2; ++t) {
             const uint4* __restrict__ wf = q.wfrag + ((long)((ENC_WKT(kt) * 3 + g) * nct + cg * 2 + t) * 2) * 64;  // uniform
+#ifdef LFI_ENC_EXP_NO_WLOADS
+            if (kt > 1) continue;
+#endif
             f[t][g][0].u = wf[(unsigned)lane];
             f[t][g][1].u = (wf + 64)[(unsigned)lane];
           }
@@ -768,6 +773,7 @@ __global__ __launch_bounds__(ENC_NT, 2) void enc_gru_fwd_wide_kernel(EncArgs a, 
         mma(ah0, al0, f0);
       }
     }
+    ENC_STAMP(1);
     // ---- gate epilogue in the row layout
     int rsv = rsub, cv = c4, jv = j0;
     asm volatile("" : "+v"(rsv), "+v"(cv), "+v"(jv));   // keep the per-row address arithmetic inside the step loop (registers)
@@ -830,7 +836,9 @@ __global__ __launch_bounds__(ENC_NT, 2) void enc_gru_fwd_wide_kernel(EncArgs a, 
 #endif
     }
     transpose(2, gh);
+    ENC_STAMP(2);
     __syncthreads();   // every wave has finished the MFMA phase: the state images may be overwritten
+    ENC_STAMP(3);
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int rl = rg * 32 + 4 * i + rsv;
@@ -877,18 +885,24 @@ __global__ __launch_bounds__(ENC_NT, 2) void enc_gru_fwd_wide_kernel(EncArgs a, 
         }
       }
     }
+    ENC_STAMP(4);
     __syncthreads();   // the new state images are complete
+    ENC_STAMP(5);
   }
 }
 
 // ---- the forward recurrence with TWO 32-row tiles per wave (64 windows per row group) and one workgroup per CU.
-// What paces enc_gru_fwd_wide_kernel is neither the stash (launch time without any stash: 0.62 of 0.66 ms on the p2_face shape,
-// tools/enc_probe.py) nor the matrix pipe (18 % busy) but the L2 -> CU weight stream: every workgroup re-reads all of W_hh (786 KB of
-// bf16 hi / lo fragments at hid 256) every step for its 32 windows - 8.1 GB per launch, 13 TB/s, which is ~70 % of what the
-// chip's L2s deliver to 256 CUs at all (MI355X_MICROARCH.md, gather table: 16.8 - 18.8 TB/s). Here a wave keeps the accumulators of
-// 64 windows (2 row tiles x 2 column tiles x 3 gates = 192 registers of the 512 a lone wave per SIMD may use), so every weight
-// fragment it loads feeds six MFMAs instead of three and the stream per window halves. The gate epilogue is the row-layout one of
-// the wide kernel, run once per row tile.
+// What paces enc_gru_fwd_wide_kernel, from ingredient-removal builds (tools/enc_probe.py + tools/build_variant.sh, p2_face shape, ms per
+// launch): 0.66 as shipped; 0.62 without any stash; 0.65 with every k-tile reading the SAME weight fragments (L1 hits instead of the
+// L2 stream); 0.64 with no weight loads in the k loop at all; 0.65 with sigmoid / tanh replaced by a multiply; 0.17 without the
+// h W_hh^T loop. The k loop costs ~0.46 ms wherever its operands come from: 389 G MFMA-pass-FLOP at ~0.9 PFLOP/s, the rate every
+// three-product bf16 stream of this code base settles at on this chip (the planes GEMM: 1.0), and two workgroups per CU meet in the
+// matrix phase and in the gate epilogue alike (staggering the second one by 6 k .. 30 k cycles, by any pairing rule, changed nothing).
+// This tiling keeps the MFMA work and halves everything around it in the k loop: a wave holds the accumulators of 64 windows (2 row
+// tiles x 2 column tiles x 3 gates = 192 of the 512 registers a lone wave per SIMD may use), so a weight fragment and its address
+// arithmetic feed six MFMAs instead of three. Measured: forward 0.66 -> 0.61 ms, whole step -0.06 .. -0.08 ms on three boxes. (An
+// eight-wave variant - 64 windows x 32 hidden units per wave, two waves per SIMD - measured 0.58 - 0.67 ms by stash variant and
+// +0.05 ms on the whole step: removed.) The gate epilogue is the row-layout one of the wide kernel, run once per row tile.
 template <bool STASH, bool MASK, bool S16>
 __global__ __launch_bounds__(ENC_NT, 1) void enc_gru_fwd_r64_kernel(EncArgs a, EncFused q) {
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1592,241 +1606,10 @@ __global__ __launch_bounds__(ENC_NT, 2) void enc_gru_bwd_wide_kernel(EncArgs a, 
   }
 }
 
-// ---- EIGHT waves, each 64 windows x 32 hidden units x 3 gates (one 512-thread workgroup per CU, two waves per SIMD).
-// Ingredient-removal builds of enc_gru_fwd_wide_kernel (tools/enc_probe.py, p2_face shape): 0.65 ms per launch without any stash, 0.65
-// with every k-tile reading the SAME weight fragments (L1 hits instead of the L2 stream), 0.17 without the h W_hh^T loop - the k loop
-// costs 0.49 ms wherever its operands come from. What it moves is 12 KB of fragments per wave and k-tile for 18 MFMAs: 35 MB per
-// CU and launch through a vector-memory path that delivers ~33 B per clock and CU (MI355X_MICROARCH.md, gather table: 66 - 73 GB/s per CU
-// from L2) = 0.48 ms. The matrix pipe would need 0.19. Same accumulator budget as the wide kernel (6 tiles), other shape: a wave owns
-// TWO row tiles x ONE column tile x 3 gates, so a fragment feeds six MFMAs instead of three and the bytes per MFMA halve, with two
-// waves per SIMD still overlapping one wave's gate epilogue with the other's MFMAs (the 4-wave 64-window variant above has one).
-constexpr int ENC8_NT = 512;
-constexpr int ENC8_NW = 8;
-constexpr int ENC8_TP = 36;   // floats per row of a wave's 64 x 32 transpose tile (144 B: 16-byte aligned rows)
-template <bool STASH, bool MASK, bool S16>
-__global__ __launch_bounds__(ENC8_NT, 1) void enc_gru_fwd_w8_kernel(EncArgs a, EncFused q) {
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int l31 = lane & 31, half = lane >> 5;
-  const int ncg8 = q.Jp >> 5;                     // 32-wide column groups
-  const int cg = wave % ncg8, rg = wave / ncg8;
-  const int hid = a.hid, G3 = 3 * hid, Jp = q.Jp;
-  const int R8 = 64 * (ENC8_NW / ncg8);           // windows per workgroup
-  const int wbase = blockIdx.x * R8;
-  const int pos0 = a.start - a.hist + 1;
-  const int ldx = q.Kp + 8;
-  // LDS: bf16 hi / lo images of h_{s-1} (row-major [R8][Kp + 8]) | one 64 x 32 transpose tile per wave | biases [6][Jp] | row tables
-  __bf16* Xhi = reinterpret_cast<__bf16*>(enc_smem);
-  __bf16* Xlo = Xhi + R8 * ldx;
-  float* T = reinterpret_cast<float*>(Xlo + R8 * ldx) + wave * (64 * ENC8_TP);
-  float* bias = reinterpret_cast<float*>(Xlo + R8 * ldx) + ENC8_NW * (64 * ENC8_TP);   // [0..2][Jp] = b_ih, [3..5][Jp] = b_hh
-  unsigned* rowx = reinterpret_cast<unsigned*>(bias + 6 * Jp);
-  unsigned* roww = rowx + R8;
-  float* mk_tab = reinterpret_cast<float*>(roww + R8);                                 // [R8][hist] (MASK only)
-  for (int i = tid; i < R8 * ldx; i += ENC8_NT) { Xhi[i] = (__bf16)0.0f; Xlo[i] = (__bf16)0.0f; }
-  for (int i = tid; i < 6 * Jp; i += ENC8_NT) {
-    const int g = i / Jp, j = i - g * Jp;
-    bias[i] = j < hid ? (g < 3 ? a.b_ih[g * hid + j] : a.b_hh[(g - 3) * hid + j]) : 0.0f;
-  }
-  for (int i = tid; i < R8; i += ENC8_NT) {
-    const int w = min(wbase + i, a.F - 1);   // rows past F recompute and re-store the last window
-    const int n = w / a.B, b = w - n * a.B;
-    rowx[i] = (unsigned)(b * a.T + pos0 + n) * (unsigned)(G3 * 4);
-    roww[i] = (unsigned)w * (unsigned)(hid * 4);
-  }
-  if (MASK)
-    for (int i = tid; i < R8 * a.hist; i += ENC8_NT) {
-      const int rl = i / a.hist, s = i - rl * a.hist;
-      mk_tab[i] = a.mask[(long)min(wbase + rl, a.F - 1) * a.hist + s];
-    }
-  // row layout of the wave's 64 x 32 tile: lane owns columns c4 .. c4 + 3 of rows 8 i + rsub, i = 0 .. 7
-  const int rsub = lane >> 3, c4 = (lane & 7) * 4;
-  const int j0 = cg * 32 + c4;
-  const bool jok = j0 < hid;
-  {
-    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int i = 0; i < 8; ++i) *reinterpret_cast<f32x4*>(T + (8 * i + rsub) * ENC8_TP + c4) = z;   // h_{-1} = 0
-  }
-  const enc_rsrc bx = enc_buf(a.Xp, (long)a.B * a.T * G3 * 4);
-  const unsigned h4 = (unsigned)hid * 4u;
-  __syncthreads();
-
-  for (int s = 0; s < a.hist; ++s) {
-    f32x16 acc[2][3];   // [row tile][gate]
-#pragma unroll
-    for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-      for (int g = 0; g < 3; ++g)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[rt][g][r] = 0.0f;
-#ifdef LFI_ENC_EXP_NO_KLOOP
-    if (false) {
-#else
-    if (s > 0) {
-#endif
-      const int nkt = q.Kp >> 4, nct = Jp >> 5;
-      const __bf16* xh = Xhi + (rg * 64 + l31) * ldx + 8 * half;
-      const __bf16* xl = Xlo + (rg * 64 + l31) * ldx + 8 * half;
-      ebf16x8 ah0[2], al0[2], ah1[2], al1[2];
-      EncFrag f0[3][2], f1[3][2];  // [g][plane]
-      auto load = [&](int kt, ebf16x8 (&ah)[2], ebf16x8 (&al)[2], EncFrag (&f)[3][2]) {
-#pragma unroll
-        for (int rt = 0; rt < 2; ++rt) {
-          ah[rt] = *reinterpret_cast<const ebf16x8*>(xh + rt * 32 * ldx + kt * 16);
-          al[rt] = *reinterpret_cast<const ebf16x8*>(xl + rt * 32 * ldx + kt * 16);
-        }
-#pragma unroll
-        for (int g = 0; g < 3; ++g) {
-          const uint4* __restrict__ wf = q.wfrag + ((long)((ENC_WKT(kt) * 3 + g) * nct + cg) * 2) * 64;  // uniform
-          f[g][0].u = wf[(unsigned)lane];
-          f[g][1].u = (wf + 64)[(unsigned)lane];
-        }
-      };
-      auto mma = [&](const ebf16x8 (&ah)[2], const ebf16x8 (&al)[2], const EncFrag (&f)[3][2]) {
-#pragma unroll
-        for (int g = 0; g < 3; ++g)
-#pragma unroll
-          for (int rt = 0; rt < 2; ++rt) {
-            acc[rt][g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[rt], f[g][0].v, acc[rt][g], 0, 0, 0);
-            acc[rt][g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[rt], f[g][1].v, acc[rt][g], 0, 0, 0);
-            acc[rt][g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[rt], f[g][0].v, acc[rt][g], 0, 0, 0);
-          }
-      };
-      load(0, ah0, al0, f0);   // every load in the steady-state loop is unconditional (see enc_gru_fwd_fused_kernel)
-      int kt = 0;
-      for (; kt + 2 < nkt; kt += 2) {
-        load(kt + 1, ah1, al1, f1);
-        __builtin_amdgcn_sched_barrier(0);
-        mma(ah0, al0, f0);
-        load(kt + 2, ah0, al0, f0);
-        __builtin_amdgcn_sched_barrier(0);
-        mma(ah1, al1, f1);
-      }
-      if (kt + 1 < nkt) {
-        load(kt + 1, ah1, al1, f1);
-        __builtin_amdgcn_sched_barrier(0);
-        mma(ah0, al0, f0);
-        mma(ah1, al1, f1);
-      } else {
-        mma(ah0, al0, f0);
-      }
-    }
-    // ---- gate epilogue in the row layout
-    int rsv = rsub, cv = c4, jv = j0;
-    asm volatile("" : "+v"(rsv), "+v"(cv), "+v"(jv));   // keep the per-row address arithmetic inside the step loop (registers)
-    const unsigned sx = (unsigned)s * (unsigned)(G3 * 4), j4 = (unsigned)jv * 4u;
-    const unsigned oob = jv < hid ? 0u : 0x80000000u;
-    const enc_rsrc bhs = enc_buf(STASH ? a.hseq + (long)s * a.F * hid : nullptr, STASH ? (long)a.F * hid * 4 : 0);
-    const enc_rsrc bgs = S16 ? enc_buf(STASH ? reinterpret_cast<const _Float16*>(a.gates) + (long)s * a.F * 4 * hid : nullptr,
-                                       STASH ? (long)a.F * hid * 8 : 0)
-                             : enc_buf(STASH ? a.gates + (long)s * a.F * 4 * hid : nullptr, STASH ? (long)a.F * hid * 16 : 0);
-    float* Trow = T + rsv * ENC8_TP + cv;                 // + 8 i * ENC8_TP per row
-    float* Tacc = T + (4 * half) * ENC8_TP + l31;         // accumulator (rt, r) at + ((r & 3) + 8 (r >> 2) + 32 rt) * ENC8_TP
-    f32x4 hp[8], xin[8];
-    unsigned xo[8], wo[8];
-    float mk[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int rl = rg * 64 + 8 * i + rsv;
-      xo[i] = rowx[rl] + j4 + oob;   // columns past hid: an offset outside every buffer (loads return 0, stores are dropped)
-      wo[i] = roww[rl];
-      mk[i] = MASK ? mk_tab[rl * a.hist + s] : 1.0f;
-      hp[i] = *reinterpret_cast<const f32x4*>(Trow + 8 * i * ENC8_TP);   // h_{s-1}, parked here by the previous step
-#ifdef LFI_ENC_EXP_NO_XP
-      xin[i] = f32x4{0.1f, 0.2f, 0.3f, 0.4f};
-#else
-      xin[i] = enc_ld4(bx, xo[i], sx);
-#endif
-    }
-    auto transpose = [&](int g, f32x4 (&out)[8]) {   // gate g of this wave's tile: accumulator layout -> row layout
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // earlier reads of the tile are done
-#pragma unroll
-      for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) Tacc[((r & 3) + 8 * (r >> 2) + 32 * rt) * ENC8_TP] = acc[rt][g][r];
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-      for (int i = 0; i < 8; ++i) out[i] = *reinterpret_cast<const f32x4*>(Trow + 8 * i * ENC8_TP);
-    };
-    const f32x4 bir = *reinterpret_cast<const f32x4*>(bias + 0 * Jp + jv), bhr = *reinterpret_cast<const f32x4*>(bias + 3 * Jp + jv);
-    const f32x4 biu = *reinterpret_cast<const f32x4*>(bias + 1 * Jp + jv), bhu = *reinterpret_cast<const f32x4*>(bias + 4 * Jp + jv);
-    const f32x4 bin = *reinterpret_cast<const f32x4*>(bias + 2 * Jp + jv), bhn = *reinterpret_cast<const f32x4*>(bias + 5 * Jp + jv);
-    f32x4 rr[8], uu[8], gh[8];
-    transpose(0, gh);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) rr[i][e] = ENC_SIG(mk[i] * xin[i][e] + bir[e] + (gh[i][e] + bhr[e]));
-      if (STASH && !S16) enc_st4(rr[i], bgs, 4u * wo[i] + j4 + oob, 0);
-#ifndef LFI_ENC_EXP_NO_XP
-      xin[i] = enc_ld4(bx, xo[i], sx + h4);
-#endif
-    }
-    transpose(1, gh);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) uu[i][e] = ENC_SIG(mk[i] * xin[i][e] + biu[e] + (gh[i][e] + bhu[e]));
-      if (STASH && !S16) enc_st4(uu[i], bgs, 4u * wo[i] + j4 + oob, h4);
-#ifndef LFI_ENC_EXP_NO_XP
-      xin[i] = enc_ld4(bx, xo[i], sx + 2 * h4);
-#endif
-    }
-    transpose(2, gh);
-    __syncthreads();   // every wave has finished the MFMA phase: the state images may be overwritten
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int rl = rg * 64 + 8 * i + rsv;
-      f32x4 ghn, nn, hn;
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        ghn[e] = gh[i][e] + bhn[e];
-        nn[e] = ENC_TANH(mk[i] * xin[i][e] + bin[e] + rr[i][e] * ghn[e]);
-        hn[e] = (1.0f - uu[i][e]) * nn[e] + uu[i][e] * hp[i][e];
-      }
-      if (STASH && S16) {   // [window][unit][r, z, n, W_hn h] fp16: this lane's four units = 32 contiguous bytes
-        const uint2 g0 = enc_pack_gates(rr[i][0], uu[i][0], nn[0], ghn[0]), g1 = enc_pack_gates(rr[i][1], uu[i][1], nn[1], ghn[1]);
-        const uint2 g2 = enc_pack_gates(rr[i][2], uu[i][2], nn[2], ghn[2]), g3 = enc_pack_gates(rr[i][3], uu[i][3], nn[3], ghn[3]);
-        const unsigned go = 2u * (wo[i] + j4) + oob;
-        __builtin_amdgcn_raw_buffer_store_b128((enc_u32x4){g0.x, g0.y, g1.x, g1.y}, bgs, go, 0, LFI_ENC_ST_AUX);
-        __builtin_amdgcn_raw_buffer_store_b128((enc_u32x4){g2.x, g2.y, g3.x, g3.y}, bgs, go, 16, LFI_ENC_ST_AUX);
-        enc_st4(hn, bhs, wo[i] + j4 + oob, 0);
-      } else if (STASH) {
-        enc_st4(nn, bgs, 4u * wo[i] + j4 + oob, 2 * h4);
-        enc_st4(ghn, bgs, 4u * wo[i] + j4 + oob, 3 * h4);
-        enc_st4(hn, bhs, wo[i] + j4 + oob, 0);
-      }
-      if (jok) {
-        uint2 h, l;
-        split2(hn[0], hn[1], &h.x, &l.x);
-        split2(hn[2], hn[3], &h.y, &l.y);
-        *reinterpret_cast<uint2*>(Xhi + rl * ldx + jv) = h;
-        *reinterpret_cast<uint2*>(Xlo + rl * ldx + jv) = l;
-      }
-      hp[i] = hn;
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // the tile's last row-wise reads are done
-#pragma unroll
-    for (int i = 0; i < 8; ++i) *reinterpret_cast<f32x4*>(Trow + 8 * i * ENC8_TP) = hp[i];   // park h_s for the next step
-    if (s == a.hist - 1 && jok) {   // cat(seq[:, -1], h_n[0]): the final state, once or twice (glow/models.py:63-64)
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int w = wbase + rg * 64 + 8 * i + rsv;
-        if (w < a.F) {
-          float* c = a.cond + (long)w * a.ldcond + a.col + jv;
-          *reinterpret_cast<f32x4*>(c) = hp[i];
-          if (a.dup) *reinterpret_cast<f32x4*>(c + hid) = hp[i];
-        }
-      }
-    }
-    __syncthreads();   // the new state images are complete
-  }
-}
-
 // ---- BPTT with two 32-row tiles per wave (64 windows per row group), one workgroup per CU: the counterpart of
-// enc_gru_fwd_r64_kernel. The backward recurrence streams the same 786 KB of W_hh fragments per step and workgroup as the forward one
-// and is bound by the same L2 -> CU stream; with 64 windows behind every fragment the stream per window halves. Same phases and
-// barriers as enc_gru_bwd_wide_kernel, every row-layout phase run once per row tile.
+// enc_gru_fwd_r64_kernel (same reasoning: the d gates x W_hh products keep their MFMA work, every weight fragment feeds both row
+// tiles). Same phases and barriers as enc_gru_bwd_wide_kernel, every row-layout phase run once per row tile. Measured (p2_face
+// shape, two products, fp16 gate stash): 0.57 -> 0.52 ms per launch.
 template <bool A2, bool S16>
 __global__ __launch_bounds__(ENC_NT, 1) void enc_gru_bwd_r64_kernel(EncArgs a, EncFused q) {
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -2082,242 +1865,6 @@ __global__ __launch_bounds__(ENC_NT, 1) void enc_gru_bwd_r64_kernel(EncArgs a, E
   }
 }
 
-// ---- BPTT, eight waves of 64 windows x 32 hidden units (the counterpart of enc_gru_fwd_w8_kernel): a W_hh fragment feeds both row
-// tiles of its wave, so the backward recurrence - which streams the same 786 KB of fragments per step through the same ~33 B per
-// clock and CU - moves half the bytes per MFMA. Phases and barriers as in enc_gru_bwd_wide_kernel.
-template <bool A2, bool S16>
-__global__ __launch_bounds__(ENC8_NT, 1) void enc_gru_bwd_w8_kernel(EncArgs a, EncFused q) {
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int l31 = lane & 31, half = lane >> 5;
-  const int ncg8 = q.Jp >> 5;
-  const int cg = wave % ncg8, rg = wave / ncg8;
-  const int hid = a.hid, G3 = 3 * hid, Jp = q.Jp;
-  const int R8 = 64 * (ENC8_NW / ncg8);
-  const int wbase = blockIdx.x * R8;
-  const int ldx = q.Kp + 8;
-  const int img = R8 * ldx;                                     // bf16 elements of one image
-  __bf16* Xhi = reinterpret_cast<__bf16*>(enc_smem);
-  __bf16* Xlo = Xhi + img;
-  float* Treg = reinterpret_cast<float*>(Xlo + img);           // transpose tiles | second image pair (Yhi, Ylo)
-  const int tfloats = max(ENC8_NW * 64 * ENC8_TP, img);        // (2 * img bf16 = img floats)
-  float* T = Treg + wave * (64 * ENC8_TP);
-  __bf16* Yhi = reinterpret_cast<__bf16*>(Treg);
-  __bf16* Ylo = Yhi + img;
-  unsigned* roww = reinterpret_cast<unsigned*>(Treg + tfloats);
-  float* rlive = reinterpret_cast<float*>(roww + R8);
-  for (int i = tid; i < img; i += ENC8_NT) { Xhi[i] = (__bf16)0.0f; Xlo[i] = (__bf16)0.0f; }
-  for (int i = tid; i < tfloats; i += ENC8_NT) Treg[i] = 0.0f;   // (also the k padding of the second image pair)
-  for (int i = tid; i < R8; i += ENC8_NT) {
-    roww[i] = (unsigned)min(wbase + i, a.F - 1) * (unsigned)(hid * 4);
-    rlive[i] = wbase + i < a.F ? 1.0f : 0.0f;
-  }
-  const int rsub = lane >> 3, c4 = (lane & 7) * 4;
-  const int j0 = cg * 32 + c4;
-  const bool jok = j0 < hid;
-  const unsigned h4 = (unsigned)hid * 4u;
-  const enc_rsrc bdc = enc_buf(a.dcond, ((long)a.F * a.lddcond) * 4);
-  f32x4 dhu[8];          // d h_s * z_s: the part of d h_{s-1} that does not go through W_hh (row layout)
-  f32x4 bsum[4];         // column sums of d r, d z, d n, d n * r over this lane's rows and all steps
-#pragma unroll
-  for (int i = 0; i < 8; ++i) dhu[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-  for (int qq = 0; qq < 4; ++qq) bsum[qq] = f32x4{0.f, 0.f, 0.f, 0.f};
-  f32x16 acc[2];         // [row tile]
-#pragma unroll
-  for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[rt][r] = 0.0f;
-  __syncthreads();
-
-  for (int s = a.hist - 1; s >= 0; --s) {
-    int rsv = rsub, cv = c4, jv = j0;
-    asm volatile("" : "+v"(rsv), "+v"(cv), "+v"(jv));
-    const unsigned j4 = (unsigned)jv * 4u, oob = jv < hid ? 0u : 0x80000000u;
-    float* Trow = T + rsv * ENC8_TP + cv;
-    float* Tacc = T + (4 * half) * ENC8_TP + l31;
-    // ---- d h_s in the row layout
-    f32x4 dh[8];
-    if (s == a.hist - 1) {
-      const unsigned cb = (unsigned)a.col * 4u + j4 + oob;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const unsigned wrow = (roww[rg * 64 + 8 * i + rsv] / h4) * (unsigned)(a.lddcond * 4);
-        dh[i] = enc_ld4(bdc, wrow + cb, 0);
-        if (a.dup) dh[i] += enc_ld4(bdc, wrow + cb, h4);
-      }
-    } else {
-#pragma unroll
-      for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) Tacc[((r & 3) + 8 * (r >> 2) + 32 * rt) * ENC8_TP] = acc[rt][r];
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-#pragma unroll
-      for (int i = 0; i < 8; ++i) dh[i] = *reinterpret_cast<const f32x4*>(Trow + 8 * i * ENC8_TP) + dhu[i];
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    }
-    __syncthreads();   // B0: every wave is done with its transpose tile (the second image pair overlays those) and with the
-                       // previous step's n-gate product (which read the first image pair)
-    if (q.Kp > hid) {   // the transposes left accumulator bits in the second pair's k padding: NaN patterns x 0 would poison the product
-      const int pad = q.Kp - hid;
-      for (int i = tid; i < R8 * pad; i += ENC8_NT) {
-        const int rl = i / pad, c = hid + (i - rl * pad);
-        Yhi[rl * ldx + c] = (__bf16)0.0f; Ylo[rl * ldx + c] = (__bf16)0.0f;
-      }
-    }
-    const int sp = s > 0 ? s - 1 : 0;
-    const float hp_on = s > 0 ? 1.0f : 0.0f;
-    const enc_rsrc bgs = S16 ? enc_buf(reinterpret_cast<const _Float16*>(a.gates) + (long)s * a.F * 4 * hid, (long)a.F * hid * 8)
-                             : enc_buf(a.gates + (long)s * a.F * 4 * hid, (long)a.F * hid * 16);
-    const enc_rsrc bhp = enc_buf(a.hseq + (long)sp * a.F * hid, (long)a.F * hid * 4);
-    const enc_rsrc bgi = A2 ? enc_buf(reinterpret_cast<const __bf16*>(a.dgi) + (long)s * a.F * hid, (long)a.F * hid * 2)
-                            : enc_buf(a.dgi + (long)s * a.F * hid, (long)a.F * hid * 4);
-    const enc_rsrc bgh = A2 ? enc_buf(reinterpret_cast<const __bf16*>(a.dgh) + (long)s * a.F * G3, (long)a.F * G3 * 2)
-                            : enc_buf(a.dgh + (long)s * a.F * G3, (long)a.F * G3 * 4);
-    f32x4 danr[8];
-#pragma unroll
-    for (int ih = 0; ih < 2; ++ih) {
-      f32x4 gr[4], gu[4], gn[4], gg[4], hp[4];
-      unsigned wo[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int rl = rg * 64 + 8 * (4 * ih + u) + rsv;
-        wo[u] = roww[rl];
-        if (S16) {   // fp16 stash, [window][unit][r, z, n, W_hn h]: two 16-byte loads hold this lane's four units
-          const unsigned go = 2u * (wo[u] + j4) + oob;
-          const enc_u32x4 p0 = __builtin_amdgcn_raw_buffer_load_b128(bgs, go, 0, 2), p1 = __builtin_amdgcn_raw_buffer_load_b128(bgs, go, 16, 2);
-          const f32x4 u0 = enc_unpack_gates(p0[0], p0[1]), u1 = enc_unpack_gates(p0[2], p0[3]);
-          const f32x4 u2 = enc_unpack_gates(p1[0], p1[1]), u3 = enc_unpack_gates(p1[2], p1[3]);
-          gr[u] = f32x4{u0[0], u1[0], u2[0], u3[0]}; gu[u] = f32x4{u0[1], u1[1], u2[1], u3[1]};
-          gn[u] = f32x4{u0[2], u1[2], u2[2], u3[2]}; gg[u] = f32x4{u0[3], u1[3], u2[3], u3[3]};
-        } else {
-          const unsigned go = 4u * wo[u] + j4 + oob;
-          gr[u] = enc_ld4s(bgs, go, 0); gu[u] = enc_ld4s(bgs, go, h4); gn[u] = enc_ld4s(bgs, go, 2 * h4); gg[u] = enc_ld4s(bgs, go, 3 * h4);
-        }
-        hp[u] = enc_ld4s(bhp, wo[u] + j4 + oob, 0);
-      }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int i = 4 * ih + u;
-        const int rl = rg * 64 + 8 * i + rsv;
-        const float live = rlive[rl];
-        f32x4 dan, dau, dar, dnr;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float rr = gr[u][e], uu = gu[u][e], nn = gn[u][e], ghn = gg[u][e];
-          const float dhn = dh[i][e];
-          const float du = dhn * (hp[u][e] * hp_on - nn);
-          const float dn = dhn * (1.0f - uu);
-          dan[e] = dn * (1.0f - nn * nn);
-          dau[e] = du * uu * (1.0f - uu);
-          dar[e] = dan[e] * ghn * rr * (1.0f - rr);
-          dnr[e] = dan[e] * rr;
-          dhu[i][e] = dhn * uu;
-        }
-        if (A2) {
-          const unsigned j2 = j4 >> 1, h2 = h4 >> 1;
-          enc_st2h(dan, bgi, (wo[u] >> 1) + j2 + oob, 0);
-          const unsigned o = 3u * (wo[u] >> 1) + j2 + oob;
-          enc_st2h(dar, bgh, o, 0); enc_st2h(dau, bgh, o, h2); enc_st2h(dnr, bgh, o, 2 * h2);
-        } else {
-          enc_st4(dan, bgi, wo[u] + j4 + oob, 0);
-          const unsigned o = 3u * wo[u] + j4 + oob;
-          enc_st4(dar, bgh, o, 0); enc_st4(dau, bgh, o, h4); enc_st4(dnr, bgh, o, 2 * h4);
-        }
-        bsum[0] += live * dar; bsum[1] += live * dau; bsum[2] += live * dan; bsum[3] += live * dnr;
-        danr[i] = dnr;
-        if (s > 0 && jok) {   // gate images for the products: d r -> first pair, d z -> second pair
-          uint2 h, l;
-          split2(dar[0], dar[1], &h.x, &l.x); split2(dar[2], dar[3], &h.y, &l.y);
-          *reinterpret_cast<uint2*>(Xhi + rl * ldx + jv) = h;
-          if (!A2) *reinterpret_cast<uint2*>(Xlo + rl * ldx + jv) = l;
-          split2(dau[0], dau[1], &h.x, &l.x); split2(dau[2], dau[3], &h.y, &l.y);
-          *reinterpret_cast<uint2*>(Yhi + rl * ldx + jv) = h;
-          if (!A2) *reinterpret_cast<uint2*>(Ylo + rl * ldx + jv) = l;
-        }
-      }
-    }
-    if (s == 0) break;
-#pragma unroll
-    for (int rt = 0; rt < 2; ++rt)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[rt][r] = 0.0f;
-    auto product = [&](int g, const __bf16* Ih, const __bf16* Il) {   // acc += image_g (64 rows x hid) W_hh[g] (hid x this wave's 32 columns)
-      const int nkt = q.Kp >> 4, nct = Jp >> 5;
-      const __bf16* xh = Ih + (rg * 64 + l31) * ldx + 8 * half;
-      const __bf16* xl = Il + (rg * 64 + l31) * ldx + 8 * half;
-      ebf16x8 ah0[2], al0[2], ah1[2], al1[2];
-      EncFrag f0[2], f1[2];  // [plane]
-      auto load = [&](int kt, ebf16x8 (&ah)[2], ebf16x8 (&al)[2], EncFrag (&f)[2]) {
-#pragma unroll
-        for (int rt = 0; rt < 2; ++rt) {
-          ah[rt] = *reinterpret_cast<const ebf16x8*>(xh + rt * 32 * ldx + kt * 16);
-          if (!A2) al[rt] = *reinterpret_cast<const ebf16x8*>(xl + rt * 32 * ldx + kt * 16);
-          else al[rt] = ah[rt];
-        }
-        const uint4* __restrict__ wf = q.wfrag + ((long)((g * nkt + ENC_WKT(kt)) * nct + cg) * 2) * 64;  // uniform
-        f[0].u = wf[(unsigned)lane];
-        f[1].u = (wf + 64)[(unsigned)lane];
-      };
-      auto mma = [&](const ebf16x8 (&ah)[2], const ebf16x8 (&al)[2], const EncFrag (&f)[2]) {
-#pragma unroll
-        for (int rt = 0; rt < 2; ++rt) {
-          if (!A2) acc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[rt], f[0].v, acc[rt], 0, 0, 0);
-          acc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[rt], f[1].v, acc[rt], 0, 0, 0);
-          acc[rt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[rt], f[0].v, acc[rt], 0, 0, 0);
-        }
-      };
-      load(0, ah0, al0, f0);
-      int kt = 0;
-      for (; kt + 2 < nkt; kt += 2) {   // unconditional loads (see the forward kernel)
-        load(kt + 1, ah1, al1, f1);
-        __builtin_amdgcn_sched_barrier(0);
-        mma(ah0, al0, f0);
-        load(kt + 2, ah0, al0, f0);
-        __builtin_amdgcn_sched_barrier(0);
-        mma(ah1, al1, f1);
-      }
-      if (kt + 1 < nkt) {
-        load(kt + 1, ah1, al1, f1);
-        __builtin_amdgcn_sched_barrier(0);
-        mma(ah0, al0, f0);
-        mma(ah1, al1, f1);
-      } else {
-        mma(ah0, al0, f0);
-      }
-    };
-    __syncthreads();   // B1: both image pairs complete
-    product(0, Xhi, Xlo);
-    product(1, Yhi, Ylo);
-    __syncthreads();   // B2: every wave has read the first pair
-    if (jok) {
-#pragma unroll
-      for (int i = 0; i < 8; ++i) {
-        const int rl = rg * 64 + 8 * i + rsv;
-        uint2 h, l;
-        split2(danr[i][0], danr[i][1], &h.x, &l.x); split2(danr[i][2], danr[i][3], &h.y, &l.y);
-        *reinterpret_cast<uint2*>(Xhi + rl * ldx + jv) = h;
-        if (!A2) *reinterpret_cast<uint2*>(Xlo + rl * ldx + jv) = l;
-      }
-    }
-    __syncthreads();   // B3
-    product(2, Xhi, Xlo);
-  }
-  if (a.bias_part && jok) {
-    float* bp = a.bias_part + ((long)blockIdx.x * (ENC8_NW / ncg8) + rg) * 4 * hid;
-#pragma unroll
-    for (int qq = 0; qq < 4; ++qq) {
-      f32x4 v = bsum[qq];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        v[e] += __shfl_xor(v[e], 8, 64);
-        v[e] += __shfl_xor(v[e], 16, 64);
-        v[e] += __shfl_xor(v[e], 32, 64);
-      }
-      if (rsub == 0) *reinterpret_cast<f32x4*>(bp + qq * hid + j0) = v;
-    }
-  }
-}
-
 template <typename Kf>
 int enc_set_lds(Kf kernel, size_t bytes) {
   if (bytes <= 48 * 1024) return LFI_OK;
@@ -2386,10 +1933,6 @@ static bool enc_r64_enabled() {   // (read at every call: tests switch it inside
   const char* e = getenv("LFI_ENC_R64");
   return !(e && e[0] == '0');
 }
-static bool enc_w8_enabled() {
-  const char* e = getenv("LFI_ENC_W8");
-  return !(e && e[0] == '0');
-}
 static size_t enc_bwd_r64_lds(const EncFused& q) {
   const int R2 = 2 * q.R;
   const long imgf = (long)R2 * (q.Kp + 8);
@@ -2399,18 +1942,6 @@ static size_t enc_bwd_r64_lds(const EncFused& q) {
 static bool enc_wide_bwd_shape_ok(const lfi_enc_desc* d, int lddcond, EncFused* q);
 // does lfi_encode_windows_bwd run the two-row-tile kernel (enc_gru_bwd_r64_kernel) for this shape? (shape-only: the pointer
 // alignment the row-layout kernels need is REQUIREd there)
-static size_t enc_bwd_w8_lds(const EncFused& q) {
-  const int R8 = 64 * (ENC8_NW / (q.Jp >> 5));
-  const long imgf = (long)R8 * (q.Kp + 8);
-  return (size_t)2 * R8 * (q.Kp + 8) * sizeof(__bf16) +
-         (size_t)(ENC8_NW * 64 * ENC8_TP > imgf ? ENC8_NW * 64 * ENC8_TP : imgf) * sizeof(float) + (size_t)2 * R8 * sizeof(unsigned);
-}
-// does lfi_encode_windows_bwd run the eight-wave kernel (enc_gru_bwd_w8_kernel) for this shape?
-static bool enc_bwd_uses_w8(const lfi_enc_desc* d, EncFused* q) {
-  if (!enc_w8_enabled() || !enc_wide_bwd_shape_ok(d, d->ldcond, q)) return false;
-  const int ncg8 = q->Jp >> 5;
-  return ncg8 <= ENC8_NW && enc_bwd_w8_lds(*q) <= 160 * 1024 && lfi_cdiv((long)d->N * d->B, 64 * (ENC8_NW / ncg8)) >= 128;
-}
 static bool enc_bwd_uses_r64(const lfi_enc_desc* d, EncFused* q) {
   if (!enc_r64_enabled() || !enc_wide_bwd_shape_ok(d, d->ldcond, q)) return false;
   return enc_bwd_r64_lds(*q) <= 160 * 1024 && lfi_cdiv((long)d->N * d->B, 2 * q->R) >= 128;
@@ -2482,33 +2013,6 @@ extern "C" int lfi_encode_windows_fwd(const lfi_enc_desc* d, const float* Xp, co
                           (!gates || (al16(gates) && al16(hseq)));
       // two row tiles per wave, one workgroup per CU (enc_gru_fwd_r64_kernel): half the L2 -> CU weight stream per window; taken
       // when its workgroups still cover the chip (LFI_ENC_R64=0 keeps the 32-window kernel)
-      {   // eight waves x (64 windows x 32 hidden units): half the fragment bytes per MFMA at the wide kernel's occupancy
-        const int ncg8 = q.Jp >> 5;
-        const int R8 = 64 * (ENC8_NW / ncg8);
-        const size_t lds8 = (size_t)2 * R8 * (q.Kp + 8) * sizeof(__bf16) + (size_t)ENC8_NW * 64 * ENC8_TP * sizeof(float) +
-                            (size_t)6 * q.Jp * sizeof(float) + (size_t)2 * R8 * sizeof(unsigned) +
-                            (mask ? (size_t)R8 * d->hist * sizeof(float) : 0);
-        if (wide && enc_w8_enabled() && vec_ok && ncg8 <= ENC8_NW && lds8 <= 160 * 1024 && lfi_cdiv(F, R8) >= 128) {
-          const dim3 grid8(lfi_cdiv(F, R8));
-          rc = LFI_OK;
-          switch ((gates && d->stash_f16 ? 4 : 0) | (gates ? 2 : 0) | (mask ? 1 : 0)) {
-#define LFI_ENC_FWD8(ST, MK, H)                                                                                  \
-  rc = enc_set_lds(enc_gru_fwd_w8_kernel<ST, MK, H>, lds8);                                                      \
-  if (!rc) hipLaunchKernelGGL((enc_gru_fwd_w8_kernel<ST, MK, H>), grid8, dim3(ENC8_NT), lds8, st, a, q);        \
-  break
-            case 7: LFI_ENC_FWD8(true, true, true);
-            case 6: LFI_ENC_FWD8(true, false, true);
-            case 3: LFI_ENC_FWD8(true, true, false);
-            case 2: LFI_ENC_FWD8(true, false, false);
-            case 1: LFI_ENC_FWD8(false, true, false);
-            default: LFI_ENC_FWD8(false, false, false);
-#undef LFI_ENC_FWD8
-          }
-          if (rc) return rc;
-          LFI_LAUNCH_CHECK("lfi_encode_windows_fwd (fused, eight waves of 64 x 32)");
-          return LFI_OK;
-        }
-      }
       const bool r64 = enc_r64_enabled();
       const int R2 = 2 * q.R;
       const size_t lds64 = (size_t)2 * R2 * (q.Kp + 8) * sizeof(__bf16) + (size_t)ENC_NW * 2 * 32 * ENC_TP * sizeof(float) +
@@ -2597,10 +2101,6 @@ extern "C" int lfi_encode_windows_fwd(const lfi_enc_desc* d, const float* Xp, co
 extern "C" long lfi_encode_windows_bias_rows(const lfi_enc_desc* d) {
   EncFused q = {};
   if (!d || d->lstm || !enc_fused_shape(d->hid, &q)) return 0;
-  if (enc_bwd_uses_w8(d, &q)) {
-    const int ncg8 = q.Jp >> 5;
-    return (long)lfi_cdiv((long)d->N * d->B, 64 * (ENC8_NW / ncg8)) * (ENC8_NW / ncg8);
-  }
   const int rows_per_wg = enc_bwd_uses_r64(d, &q) ? 2 * q.R : q.R;
   return (long)lfi_cdiv((long)d->N * d->B, rows_per_wg) * (ENC_NW / q.ncg);
 }
@@ -2711,23 +2211,7 @@ extern "C" int lfi_encode_windows_bwd(const lfi_enc_desc* d, const float* dcond,
     LFI_REQUIRE(!d->stash_f16 || wide_ok, "lfi_encode_windows_bwd: an fp16 gate stash (lfi_enc_desc.stash_f16) needs the row-layout "
                 "kernel (lfi_encode_windows_stash_f16_ok) and 16-byte aligned buffers");
     EncFused q64 = {};
-    if (wide_ok && lddcond == d->ldcond && enc_bwd_uses_w8(d, &q64)) {   // eight waves of 64 windows x 32 hidden units
-      const size_t lds8 = enc_bwd_w8_lds(q);
-      const dim3 grid8(lfi_cdiv(F, 64 * (ENC8_NW / (q.Jp >> 5))));
-      rc = LFI_OK;
-      switch ((want16 ? 2 : 0) | (d->stash_f16 ? 1 : 0)) {
-#define LFI_ENC_BWD8(A2, H)                                                                                  \
-  rc = enc_set_lds(enc_gru_bwd_w8_kernel<A2, H>, lds8);                                                      \
-  if (!rc) hipLaunchKernelGGL((enc_gru_bwd_w8_kernel<A2, H>), grid8, dim3(ENC8_NT), lds8, st, a, q);        \
-  break
-        case 3: LFI_ENC_BWD8(true, true);
-        case 2: LFI_ENC_BWD8(true, false);
-        case 1: LFI_ENC_BWD8(false, true);
-        default: LFI_ENC_BWD8(false, false);
-#undef LFI_ENC_BWD8
-      }
-      if (rc) return rc;
-    } else if (wide_ok && lddcond == d->ldcond && enc_bwd_uses_r64(d, &q64)) {   // two row tiles per wave, one workgroup per CU
+    if (wide_ok && lddcond == d->ldcond && enc_bwd_uses_r64(d, &q64)) {   // two row tiles per wave, one workgroup per CU
       const size_t lds64 = enc_bwd_r64_lds(q);
       const dim3 grid64(lfi_cdiv(F, 2 * q.R));
       rc = LFI_OK;

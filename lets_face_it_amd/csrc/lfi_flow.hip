@@ -916,16 +916,18 @@ __device__ __forceinline__ void fast_cell_p2_gates(const FlowK& f, const float* 
         const float rr = sigmoidf_(az[0][r] + ah[0][r] + gc[r][0] + bh[0]);
         const float uu = sigmoidf_(az[1][r] + ah[1][r] + gc[r][1] + bh[1]);
         const float ghn = ah[2][r] + bh[2];
-        const float nn = tanhf_(az[2][r] + gc[r][2] + rr * ghn);
+        // (explicit fused forms: left to -ffp-contract, "(1 - z) n + z h" fuses either product, and which one depended on the
+        // kernel this function was inlined into - the persistent walk and the diagonal walk then differed by an ulp)
+        const float nn = tanhf_(__builtin_fmaf(rr, ghn, az[2][r] + gc[r][2]));
         const float hp = Ht[j2 * LT + i];
-        hnew = (1.0f - uu) * nn + uu * hp;
+        hnew = __builtin_fmaf(uu, hp, (1.0f - uu) * nn);
         gs0 = rr; gs1 = uu; gs2 = nn; gs3 = ghn;
       } else {        // torch.nn.LSTMCell, gate order i, f, g, o; zero (h, c) at the first modelled frame
         const float ii = sigmoidf_(az[0][r] + ah[0][r] + gc[r][0] + bh[0]);
         const float ff = sigmoidf_(az[1][r] + ah[1][r] + gc[r][1] + bh[1]);
         const float gg = tanhf_(az[2][r] + ah[2][r] + gc[r][2] + bh[2]);
         const float oo = sigmoidf_(az[NG - 1][r] + ah[NG - 1][r] + gc[r][NG - 1] + bh[NG - 1]);
-        const float c2 = ff * cprev[r] + ii * gg;
+        const float c2 = __builtin_fmaf(ff, cprev[r], ii * gg);
         hnew = oo * tanhf_(c2);
         if (row < rows) c_out[(long)row * H + j2] = c2;
         if (cnew) cnew[r] = c2;
@@ -934,7 +936,7 @@ __device__ __forceinline__ void fast_cell_p2_gates(const FlowK& f, const float* 
       Hn[j2 * LT + i] = hnew;
       if (img_hi) x3_put(img_hi, img_lo, i * img_ld + img_col + x3_pos(j2), hnew);   // bf16 hi / lo image for the next cell's product
       if (row < rows) {
-        h_out[(long)row * H + j2] = hnew;
+        if (h_out) h_out[(long)row * H + j2] = hnew;   // (null: the caller stores the tile's rows itself, 16 bytes at a time)
         if (g_out) {
           // the four stashed gate values of (row, hidden unit) lie together: ONE 16-byte store here and one 16-byte load in the
           // backward cell instead of four dword accesses each (the walks are bound by vector-memory instruction issue:
@@ -1505,10 +1507,7 @@ __global__ __launch_bounds__(NT) void flow_pipe_fwd_kernel(FlowK f) {
         const int c = cl + 32 * u;
         if (c < C16) {
           float a = 0.0f;
-          if (c < C && rok) {
-            a = ((k == 0 ? xin[c] : (have_next ? xnext[u] : ld_tile(xin + c, fenced))) + anb[u]) * ans[u];
-            f.sA[(kf + row) * LC + c] = a;
-          }
+          if (c < C && rok) a = ((k == 0 ? xin[c] : (have_next ? xnext[u] : ld_tile(xin + c, fenced))) + anb[u]) * ans[u];
           At[c * LT + ri] = a;
         }
       }
@@ -1524,14 +1523,12 @@ __global__ __launch_bounds__(NT) void flow_pipe_fwd_kernel(FlowK f) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int i = kq * 4 + r;
-          const int rw = b0 + i;
           const float v = acc[r];
           Yrm[i * ldy + c] = v;
           if (c < Ch) {
             Zt[c * LT + i] = v;
             if (X3) x3_put(ich, ich + MB * ldxi, i * ldxi + x3_pos(c), v);
           }
-          if (rw < B) f.sY[(kf + rw) * LC + c] = v;
         }
       }
     }
@@ -1543,10 +1540,10 @@ __global__ __launch_bounds__(NT) void flow_pipe_fwd_kernel(FlowK f) {
       float cnew[4] = {0.f, 0.f, 0.f, 0.f};
       if constexpr (X3)
         fast_cell_p2_x3_img<NG>(f, ich, ich + MB * ldxi, ldxi, Ch16, Ht, Hn, wzx, whx, gc, bh, cprev, (nbZ + 1) >> 1, (nbH + 1) >> 1,
-                                tcol, kq, l15, b0, B, f.sH + kf * H, NG == 4 ? f.sC + kf * H : nullptr, f.sG + kf * 4 * H, cnew,
+                                tcol, kq, l15, b0, B, nullptr, NG == 4 ? f.sC + kf * H : nullptr, f.sG + kf * 4 * H, cnew,
                                 inh, inh + MB * ldxi);
       else
-        fast_cell_p2<NG>(f, Zt, Ht, Hn, wz, wh, gc, bh, cprev, nbZ, nbH, tcol, kq, l15, b0, B, f.sH + kf * H,
+        fast_cell_p2<NG>(f, Zt, Ht, Hn, wz, wh, gc, bh, cprev, nbZ, nbH, tcol, kq, l15, b0, B, nullptr,
                          NG == 4 ? f.sC + kf * H : nullptr, f.sG + kf * 4 * H, cnew);
 #pragma unroll
       for (int r = 0; r < 4; ++r) cprev[r] = cnew[r];
@@ -1573,10 +1570,8 @@ __global__ __launch_bounds__(NT) void flow_pipe_fwd_kernel(FlowK f) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int i = kq * 4 + r;
-          const int rw = b0 + i;
           const float o = (acc[r] + flb) * fls;
           Orm[i * ldo + tcol] = o;
-          if (rw < B) f.sO[(kf + rw) * LO + tcol] = o;
         }
       }
     }
@@ -1587,6 +1582,37 @@ __global__ __launch_bounds__(NT) void flow_pipe_fwd_kernel(FlowK f) {
     const bool peek = k > 0 && !fenced && n + 1 < f.N;
     unsigned pk = 0u;
     if (peek && tid == 0) pk = ld_agent(prog + ((k - 1) * nbt + bt) * PIPE_STRIDE);
+    // the cell's stash rows a, y, h', o leave from their LDS tiles here, 16 bytes per thread and array (thread (row ri, columns
+    // 4 cl .. 4 cl + 3)): one store instruction each instead of the 2 / 4 / 4 / 4 dword stores per lane that P0 .. P3 issued from the
+    // MFMA accumulator layout (the walk is bound by vector-memory instruction issue; round 3: 20 % faster without its stash stores)
+    if (rok) {
+      const int c0 = 4 * cl;
+      if (c0 < C) {   // (LC, LO are multiples of 4 floats: the last vector's tail lies in the row padding)
+        f32x4 va, vy;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          va[e] = c0 + e < C ? At[(c0 + e) * LT + ri] : 0.0f;
+          vy[e] = c0 + e < C ? Yrm[ri * ldy + c0 + e] : 0.0f;
+        }
+        *reinterpret_cast<f32x4*>(f.sA + (kf + row) * LC + c0) = va;
+        *reinterpret_cast<f32x4*>(f.sY + (kf + row) * LC + c0) = vy;
+      }
+      if (c0 < Cout) {
+        f32x4 vo;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) vo[e] = c0 + e < Cout ? Orm[ri * ldo + c0 + e] : 0.0f;
+        *reinterpret_cast<f32x4*>(f.sO + (kf + row) * LO + c0) = vo;
+      }
+      for (int h0 = c0; h0 < H; h0 += 128) {   // (H <= 128 on this path: one trip)
+        f32x4 vh;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) vh[e] = h0 + e < H ? Hn[(h0 + e) * LT + ri] : 0.0f;
+        if (h0 + 3 < H && (H & 3) == 0) *reinterpret_cast<f32x4*>(f.sH + (kf + row) * H + h0) = vh;
+        else
+          for (int e = 0; e < 4; ++e)
+            if (h0 + e < H) f.sH[(kf + row) * H + h0 + e] = vh[e];
+      }
+    }
     {
       float lg = 0.0f;
       if (cl < C2) {
@@ -2502,6 +2528,9 @@ __global__ __launch_bounds__(NT) void flow_pipe_bwd_kernel(FlowK f) {
           float* go = f.bDgi + (kf + row) * G + j;
           float* ho = f.bDgh + (kf + row) * G + j;
 #pragma unroll
+          // (GRU: d r, d z on the hidden side equal the input side's. Storing only the n block of dgh and taking the other two
+          // rows of the W_hh gradient from dgi was measured in round 4: 8 of 24 dword stores per lane and cell less, but the
+          // gradient then needs two products over the frames instead of one - whole step 7.73 / 7.69 ms against 7.67 / 7.64: removed)
           for (int g = 0; g < NG; ++g) { go[g * H] = gi_[g]; ho[g * H] = gh_[g]; bsi[g] += gi_[g]; bsh[g] += gh_[g]; }
         }
 #pragma unroll

@@ -30,30 +30,33 @@ def _masks(hp, N, B, seed):
     return masks or None
 
 
-@pytest.mark.parametrize("mode", ["bf16x3, two-product backward", "exact f32"])
 @pytest.mark.parametrize("name", ["tiny", "mid"])
-def test_five_step_trajectory_against_oracle(gpu_device, monkeypatch, name, mode):
+def test_five_step_trajectory_against_oracle(gpu_device, monkeypatch, name):
     from lets_face_it_amd.glow import lets_face_it_glow as lfg
     import copy
     fx = Fixture(name)
     hp = fx.hp
     hp["Train"]["use_negative_nll_loss"] = True
     B, T, C, S, N = fx.B, fx.T, fx.C, fx.S, fx.N
-    ns = Namespace(**copy.deepcopy(hp))
-    ns.gradient_clip_val = CLIP
-    two = mode != "exact f32"
-    ns.engine_precision = "bf16x3" if two else "f32"
-    ns.engine_backward_products = 2 if two else 3     # 2: what "auto" picks at the benchmark's 14 336 frames
-    lm = lfg.LetsFaceItGlow(ns)
-    lm.seq_glow.load_state_dict(fx.state_dict(torch.float32))
-    lm.to(gpu_device)
-    lm.seq_glow.glow.set_actnorm_init(True)
-    lm.train()
     perm = torch.roll(torch.arange(B), 1)    # a derangement
     real_derange = lfg.derange_batch
     monkeypatch.setattr(lfg, "derange_batch", lambda b, mods, **kw: real_derange(b, mods, permutation=perm.clone()))
-    forced = iter([i == NEG_STEP for i in range(STEPS)])
-    lm._negative_branch = lambda: next(forced)
+
+    def engine_model(two):
+        ns = Namespace(**copy.deepcopy(hp))
+        ns.gradient_clip_val = CLIP
+        ns.engine_precision = "bf16x3" if two else "f32"
+        ns.engine_backward_products = 2 if two else 3     # 2: what "auto" picks at the benchmark's 14 336 frames
+        lm = lfg.LetsFaceItGlow(ns)
+        lm.seq_glow.load_state_dict(fx.state_dict(torch.float32))
+        lm.to(gpu_device)
+        lm.seq_glow.glow.set_actnorm_init(True)
+        lm.train()
+        forced = iter([i == NEG_STEP for i in range(STEPS)])
+        lm._negative_branch = lambda: next(forced)
+        return lm
+
+    lm = engine_model(True)
 
     batches = [oracle.synthetic_batch(B, T, C, S, seed=900 + i) for i in range(STEPS)]
     masks = [_masks(hp, N, B, 50 + i) for i in range(STEPS)]
@@ -86,7 +89,14 @@ def test_five_step_trajectory_against_oracle(gpu_device, monkeypatch, name, mode
             oracle.adam_clip_step([sd[k] for k in names], grads, [mom[k] for k in names], [var[k] for k in names], i + 1, LR,
                                   beta1, beta2, eps, CLIP)
 
-    # ---- the engine's
+    # ---- the engine's, in the benchmark's arithmetic and in the exact f32 mode
+    for mode, two in (("bf16x3, two-product backward", True), ("exact f32", False)):
+        if not two:
+            lm = engine_model(False)
+        _check_trajectory(lm, name, mode, two, batches, masks, names, p0, sd, ref_losses, ref_mm, B, N, gpu_device)
+
+
+def _check_trajectory(lm, name, mode, two, batches, masks, names, p0, sd, ref_losses, ref_mm, B, N, gpu_device):
     losses = []
     for i in range(STEPS):
         lm.seq_glow.injected_masks = None if masks[i] is None else {k: v.clone() for k, v in masks[i].items()}

@@ -129,3 +129,20 @@ def test_backward_products_setting_is_validated():
     for bad in (1, "1", 4, "two", None, 2.5):
         with pytest.raises(ValueError):
             GlowEngine.check_backward_products(bad)
+
+
+def test_sampler_run_split_covers_every_frame_once(monkeypatch):
+    """GlowEngine.sample cuts the generated frames into runs (static part of run i + 1 on the second stream under run i's chain):
+    the runs tile [0, nframes) in order, differ by at most one frame, and short sequences stay one run."""
+    from lets_face_it_amd.engine import GlowEngine
+    monkeypatch.delenv("LFI_SAMPLE_RUNS", raising=False)
+    for n in (1, 5, 63, 64, 276, 277, 1000):
+        runs = GlowEngine._sample_runs(n)
+        assert runs[0][0] == 0 and sum(c for _, c in runs) == n
+        assert all(runs[i][0] + runs[i][1] == runs[i + 1][0] for i in range(len(runs) - 1))
+        assert max(c for _, c in runs) - min(c for _, c in runs) <= 1
+        assert len(runs) == (4 if n >= 64 else 1)
+    monkeypatch.setenv("LFI_SAMPLE_RUNS", "3")
+    assert [c for _, c in GlowEngine._sample_runs(10)] == [4, 3, 3]
+    monkeypatch.setenv("LFI_SAMPLE_RUNS", "9")
+    assert len(GlowEngine._sample_runs(4)) == 4      # never more runs than frames
