@@ -613,7 +613,8 @@ class GlowEngine:
             raise ValueError("%s: expected contiguous float32 GPU tensor (B=%d, T>=%d, %d), got %s %s on %s"
                              % (name, B, Tmin, dim, tuple(x.shape), x.dtype, x.device))
 
-    def build_features(self, data, faces, B, T, masks, cond, with_stash, skip_p1=False, sampling=False, windows=False, frame0=0):
+    def build_features(self, data, faces, B, T, masks, cond, with_stash, skip_p1=False, sampling=False, windows=False, frame0=0,
+                       side=None):
         """FeatureEncoder.forward for every timestep at once (models.py:127-145): fills cond (F x ldf, folded layout).
 
         windows=True: `data` holds ONE conditioning window per modality, (B, hist, dim) each, as create_conditioning
@@ -621,77 +622,89 @@ class GlowEngine:
         s = self.spec
         N = 1 if windows else T - s.start
         F = N * B
-        st = _stream()
+        # side: a forked second stream (forward()): the SMALLEST recurrent encoder's whole chain (pads, x W_ih^T, the recurrence: ~60 us
+        # of small launches at final_model.yaml's p1_speech) runs there, next to the large ones; the caller joins
+        small = None
+        if side is not None and os.environ.get("LFI_ENC_FWD_SMALL_ON_SIDE", "1") != "0":
+            rec = sorted((e for e in s.encoders if e.enc in ("rnn", "lstm") and not (e.name == "p1_face" and skip_p1)),
+                         key=lambda e: e.hist * e.hid * e.hid)
+            small = rec[0] if len(rec) >= 3 else None
         for e in s.encoders:
-            p1 = e.name == "p1_face"
-            if p1 and skip_p1:
-                continue
-            if e.enc == "frame_nb":
-                # forward / invert count from batch["frame_nb"] + 2 * start (models.py:539-542,623-625); inference from
-                # ones (:572-575); +2 per timestep either way
-                base = None
-                if not sampling:
-                    base = data.get("frame_nb")
-                    if base is None:
-                        raise KeyError("Conditioning.use_frame_nb is set but the batch has no 'frame_nb' entry")
-                    if not (base.is_cuda and base.dtype == torch.float32 and base.numel() == B):
-                        raise ValueError("frame_nb: expected a float32 GPU tensor of shape (B, 1), got %s %s on %s"
-                                         % (tuple(base.shape), base.dtype, base.device))
-                    base = base.contiguous()
-                # (frame0: a run of sampled frames that starts frame0 frames into its sequence, see sample())
-                check(self.L.lfi_fill_frame_nb(ptr(base), 2.0 * frame0 if sampling else (0.0 if windows else 2.0 * s.start), B, N,
-                                               cond.data_ptr(), s.ldf, e.fcol, st), "lfi_fill_frame_nb")
-                continue
-            # prev_p1_face is the window [t - hist, t) of the model's own output (models.py:601-603); every other modality
-            # (t - hist, t] of its input stream (:607-610): same kernels, window end shifted by one frame
-            x = faces if p1 else data.get(e.name)
-            if x is None:
-                raise KeyError("batch is missing modality %r" % e.name)
-            self._check_input(x, e.name, B, e.hist if windows else T, e.in_dim)
-            Tx = x.shape[1]
-            incl = 0 if p1 else 1
-            start = (e.hist - incl) if windows else s.start   # a lone window ends at its own last row
-            if windows and Tx != e.hist:
-                raise ValueError("%s: a conditioning window has %d frames, got %d" % (e.name, e.hist, Tx))
-            mk = None if masks is None else masks.get(e.name)
-            if mk is not None and not (tuple(mk.shape) == (N, B, e.hist) and mk.is_contiguous()
-                                       and mk.dtype == torch.float32 and mk.is_cuda):
-                raise ValueError("mask for %s must be a contiguous float32 GPU tensor (N, B, hist)" % e.name)
-            if e.enc == "none":
-                check(self.L.lfi_gather_windows(x.data_ptr(), B, Tx, e.in_dim, N, start, e.hist, incl, ptr(mk),
-                                                cond.data_ptr(), s.ldf, e.fcol, st), "lfi_gather_windows")
-                continue
-            hid = e.hid
-            if e.enc == "mlp":  # Linear(hist * in -> hid) + LeakyReLU on the flattened (masked) window (models.py:70-71)
-                win = self._buf("enc_win." + e.name, F * e.win, zero=False)
-                check(self.L.lfi_gather_windows(x.data_ptr(), B, Tx, e.in_dim, N, start, e.hist, incl, ptr(mk),
-                                                win.data_ptr(), e.win, 0, st), "lfi_gather_windows")
-                self.gemm(F, hid, e.in_dim * e.hist, win, e.win, 1, self.view("enc.%s.mlp_weight" % e.name),
-                          e.in_dim * e.hist, 1, cond, s.ldf, bias=self.view("enc.%s.mlp_bias" % e.name), act=1, slope=0.01,
-                          c_off=e.fcol)
-                continue
-            # input projection hoisted over the B*Tx distinct frames (no bias: it is added after the dropout mask)
-            lstm = e.enc == "lstm"
-            G = e.ng * hid
-            xp = self._buf("xp." + e.name, B * Tx * G)
-            xa, wa, ldi = self._aligned_input(e, x, B * Tx, G)
-            self.gemm(B * Tx, G, e.in_dim, xa, ldi, 1, wa, ldi, 1, xp, G, cls="enc_xproj")
-            # gate stash: r, z, n, W_hn h + b_hn (GRU; only kept for a backward pass) / i, f, g, o, c (LSTM: it is the cell state)
-            d = EncDesc(B, Tx, N, start - 1 + incl, e.hist, hid, s.ldf, e.fcol, self.precision, 0, 1 if lstm else 0)
-            # fp16 gate stash (r, z, n, W_hn h + b_hn as four halves per hidden unit): where the backward pass runs its two-product
-            # arithmetic anyway (gate DERIVATIVES rounded to bf16) and the row-layout kernels take the shape
-            s16 = bool(with_stash and not lstm and self._want_stash_f16(F) and self.L.lfi_encode_windows_stash_f16_ok(C.byref(d)))
-            d.stash_f16 = 1 if s16 else 0
-            self._enc_stash_f16[e.name] = s16
-            gates = self._buf("enc_gates." + e.name, e.hist * F * (5 if lstm else (2 if s16 else 4)) * hid) if (with_stash or lstm) else None
-            hseq = self._buf("enc_hseq." + e.name, e.hist * F * hid)
-            work = self._buf("scratch.enc", self.L.lfi_encode_windows_work_floats(C.byref(d)))
-            ev = self._tic("enc_fwd." + e.name)
-            check(self.L.lfi_encode_windows_fwd(
-                C.byref(d), xp.data_ptr(), self.view("enc.%s.weight_hh" % e.name).data_ptr(),
-                self.view("enc.%s.bias_ih" % e.name).data_ptr(), self.view("enc.%s.bias_hh" % e.name).data_ptr(),
-                ptr(mk), cond.data_ptr(), ptr(gates), hseq.data_ptr(), work.data_ptr(), st), "lfi_encode_windows_fwd")
-            self._toc("enc_fwd." + e.name, ev)   # (includes the small weight-fragment kernel in front of the recurrence)
+            with (self._on(side) if e is small else contextlib.nullcontext()):
+                self._build_feature(e, data, faces, B, T, N, F, masks, cond, with_stash, skip_p1, sampling, windows, frame0)
+
+    def _build_feature(self, e, data, faces, B, T, N, F, masks, cond, with_stash, skip_p1, sampling, windows, frame0):
+        s = self.spec
+        st = _stream()
+        p1 = e.name == "p1_face"
+        if p1 and skip_p1:
+            return
+        if e.enc == "frame_nb":
+            # forward / invert count from batch["frame_nb"] + 2 * start (models.py:539-542,623-625); inference from
+            # ones (:572-575); +2 per timestep either way
+            base = None
+            if not sampling:
+                base = data.get("frame_nb")
+                if base is None:
+                    raise KeyError("Conditioning.use_frame_nb is set but the batch has no 'frame_nb' entry")
+                if not (base.is_cuda and base.dtype == torch.float32 and base.numel() == B):
+                    raise ValueError("frame_nb: expected a float32 GPU tensor of shape (B, 1), got %s %s on %s"
+                                     % (tuple(base.shape), base.dtype, base.device))
+                base = base.contiguous()
+            # (frame0: a run of sampled frames that starts frame0 frames into its sequence, see sample())
+            check(self.L.lfi_fill_frame_nb(ptr(base), 2.0 * frame0 if sampling else (0.0 if windows else 2.0 * s.start), B, N,
+                                           cond.data_ptr(), s.ldf, e.fcol, st), "lfi_fill_frame_nb")
+            return
+        # prev_p1_face is the window [t - hist, t) of the model's own output (models.py:601-603); every other modality
+        # (t - hist, t] of its input stream (:607-610): same kernels, window end shifted by one frame
+        x = faces if p1 else data.get(e.name)
+        if x is None:
+            raise KeyError("batch is missing modality %r" % e.name)
+        self._check_input(x, e.name, B, e.hist if windows else T, e.in_dim)
+        Tx = x.shape[1]
+        incl = 0 if p1 else 1
+        start = (e.hist - incl) if windows else s.start   # a lone window ends at its own last row
+        if windows and Tx != e.hist:
+            raise ValueError("%s: a conditioning window has %d frames, got %d" % (e.name, e.hist, Tx))
+        mk = None if masks is None else masks.get(e.name)
+        if mk is not None and not (tuple(mk.shape) == (N, B, e.hist) and mk.is_contiguous()
+                                   and mk.dtype == torch.float32 and mk.is_cuda):
+            raise ValueError("mask for %s must be a contiguous float32 GPU tensor (N, B, hist)" % e.name)
+        if e.enc == "none":
+            check(self.L.lfi_gather_windows(x.data_ptr(), B, Tx, e.in_dim, N, start, e.hist, incl, ptr(mk),
+                                            cond.data_ptr(), s.ldf, e.fcol, st), "lfi_gather_windows")
+            return
+        hid = e.hid
+        if e.enc == "mlp":  # Linear(hist * in -> hid) + LeakyReLU on the flattened (masked) window (models.py:70-71)
+            win = self._buf("enc_win." + e.name, F * e.win, zero=False)
+            check(self.L.lfi_gather_windows(x.data_ptr(), B, Tx, e.in_dim, N, start, e.hist, incl, ptr(mk),
+                                            win.data_ptr(), e.win, 0, st), "lfi_gather_windows")
+            self.gemm(F, hid, e.in_dim * e.hist, win, e.win, 1, self.view("enc.%s.mlp_weight" % e.name),
+                      e.in_dim * e.hist, 1, cond, s.ldf, bias=self.view("enc.%s.mlp_bias" % e.name), act=1, slope=0.01,
+                      c_off=e.fcol)
+            return
+        # input projection hoisted over the B*Tx distinct frames (no bias: it is added after the dropout mask)
+        lstm = e.enc == "lstm"
+        G = e.ng * hid
+        xp = self._buf("xp." + e.name, B * Tx * G)
+        xa, wa, ldi = self._aligned_input(e, x, B * Tx, G)
+        self.gemm(B * Tx, G, e.in_dim, xa, ldi, 1, wa, ldi, 1, xp, G, cls="enc_xproj")
+        # gate stash: r, z, n, W_hn h + b_hn (GRU; only kept for a backward pass) / i, f, g, o, c (LSTM: it is the cell state)
+        d = EncDesc(B, Tx, N, start - 1 + incl, e.hist, hid, s.ldf, e.fcol, self.precision, 0, 1 if lstm else 0)
+        # fp16 gate stash (r, z, n, W_hn h + b_hn as four halves per hidden unit): where the backward pass runs its two-product
+        # arithmetic anyway (gate DERIVATIVES rounded to bf16) and the row-layout kernels take the shape
+        s16 = bool(with_stash and not lstm and self._want_stash_f16(F) and self.L.lfi_encode_windows_stash_f16_ok(C.byref(d)))
+        d.stash_f16 = 1 if s16 else 0
+        self._enc_stash_f16[e.name] = s16
+        gates = self._buf("enc_gates." + e.name, e.hist * F * (5 if lstm else (2 if s16 else 4)) * hid) if (with_stash or lstm) else None
+        hseq = self._buf("enc_hseq." + e.name, e.hist * F * hid)
+        work = self._buf("scratch.enc_fwd." + e.name, self.L.lfi_encode_windows_work_floats(C.byref(d)))
+        ev = self._tic("enc_fwd." + e.name)
+        check(self.L.lfi_encode_windows_fwd(
+            C.byref(d), xp.data_ptr(), self.view("enc.%s.weight_hh" % e.name).data_ptr(),
+            self.view("enc.%s.bias_ih" % e.name).data_ptr(), self.view("enc.%s.bias_hh" % e.name).data_ptr(),
+            ptr(mk), cond.data_ptr(), ptr(gates), hseq.data_ptr(), work.data_ptr(), st), "lfi_encode_windows_fwd")
+        self._toc("enc_fwd." + e.name, ev)   # (includes the small weight-fragment kernel in front of the recurrence)
 
     def _aligned_input(self, e, x, rows, G):
         """Input stream and W_ih of a recurrent window encoder with 16-byte aligned rows. BASELINE's 50-d faces / 27-d speech
@@ -761,7 +774,7 @@ class GlowEngine:
         with self._on(side):
             self.run_prep()
         cond = self._buf("cond", F * s.ldf)
-        self.build_features(batch, x, B, T, masks, cond, with_stash)
+        self.build_features(batch, x, B, T, masks, cond, with_stash, side=side)
         self._join()
         dims = self._flow_dims(B, N)
         chain = self._chain_ok(dims, with_stash)
@@ -871,12 +884,7 @@ class GlowEngine:
             # 112 x 5 tiles = 1.09 rounds of the 512 resident workgroups: split K so the tail round is full too
             self.gemm(F, W, KD, dpre, KD, 1, self.wct_f, s.ldf, 0, dcond, ldd, b_off=col0, tag="gemm_cond_dgrad",
                       splitk=0, cls="cond_dgrad")
-            for e in self._bptt_order(rnn):
-                if e.enc == "mlp":
-                    self._mlp_backward(e, ctx, dcond, ldd, e.fcol - col0)
-                else:
-                    self._encoder_backward(e, ctx, dcond, ldd, e.fcol - col0)
-            self._join()
+            self._encoders_backward(rnn, ctx, dcond, ldd, col0)
 
     def _backward_chain(self, ctx, gscale, after_flow, bst):
         """backward() with every big GEMM operand on planes (see _chain_fwd_ok): the walk leaves dgi as operand planes,
@@ -945,12 +953,31 @@ class GlowEngine:
             wp, nkw = self._wct_planes
             self.gemm_planes(F, W, KD, dpre_p, nkKD, wp, nkw, dcond, ldd, b_fmt=1, b_off=(col0 // 16) * 1024,
                              splitk=self._planes_splitk(F, W, KD), tag="gemm_cond_dgrad", cls="cond_dgrad")
-            for e in self._bptt_order(rnn):
-                if e.enc == "mlp":
-                    self._mlp_backward(e, ctx, dcond, ldd, e.fcol - col0)
-                else:
-                    self._encoder_backward(e, ctx, dcond, ldd, e.fcol - col0)
-            self._join()
+            self._encoders_backward(rnn, ctx, dcond, ldd, col0)
+
+    def _encoders_backward(self, rnn, ctx, dcond, ldd, col0):
+        """BPTT of every trainable window encoder. Largest recurrence first on the main stream (each one's window scatter + dW_ih on
+        the second stream under its dW_hh product and the next encoder's recurrence); the SMALLEST recurrent encoder's whole chain
+        (p1_speech at final_model.yaml: 2 steps x 128 units, ~0.2 ms of small launches that used to trail the step) goes to the second
+        stream first, under the largest encoder's recurrence. LFI_ENC_BWD_SMALL_ON_SIDE=0 keeps everything in line."""
+        order = self._bptt_order(rnn)
+        recurrent = [e for e in order if e.enc != "mlp"]
+        small = None
+        if (len(recurrent) >= 3 and os.environ.get("LFI_ENC_BWD_SMALL_ON_SIDE", "1") != "0"
+                and os.environ.get("LFI_ENC_BWD_OVERLAP", "1") != "0"):
+            side = self._fork()
+            if side is not None:
+                small = recurrent[-1]
+                with self._on(side):
+                    self._encoder_backward(small, ctx, dcond, ldd, small.fcol - col0, inline=True)
+        for e in order:
+            if e is small:
+                continue
+            if e.enc == "mlp":
+                self._mlp_backward(e, ctx, dcond, ldd, e.fcol - col0)
+            else:
+                self._encoder_backward(e, ctx, dcond, ldd, e.fcol - col0)
+        self._join()
 
     @staticmethod
     def _bptt_order(encoders):
@@ -974,7 +1001,9 @@ class GlowEngine:
                   splitk=max(1, min(32, F // 1024)), a_off=col)
         self.colsum(dcond, lddcond, 0, F, e.hid, 1, self.view(gname + "mlp_bias", self.grads), 0, x_off=col)
 
-    def _encoder_backward(self, e, ctx, dcond, lddcond, col):
+    def _encoder_backward(self, e, ctx, dcond, lddcond, col, inline=False):
+        """BPTT of one window encoder + its weight / bias gradients. inline=True: every launch on the CURRENT stream, with split-K
+        workspaces of their own (the caller runs this encoder's whole chain on the second stream next to another encoder's)."""
         s = self.spec
         B, N, F = ctx.B, ctx.N, ctx.F
         x = ctx.batch[e.name]
@@ -991,7 +1020,7 @@ class GlowEngine:
         compact = bool(self.L.lfi_encode_windows_compact_dgi(C.byref(d)))   # fused GRU backward: dgi = its n block only
         dgi = self._buf("enc_dgi." + e.name, e.hist * F * (hid if compact else G3))
         dgh = self._buf("enc_dgh." + e.name, e.hist * F * G3)
-        work = self._buf("scratch.enc", self.L.lfi_encode_windows_work_floats(C.byref(d)))
+        work = self._buf("scratch.enc_bwd." + e.name, self.L.lfi_encode_windows_work_floats(C.byref(d)))
         whh = self.view("enc.%s.weight_hh" % e.name)
         prow = self.L.lfi_encode_windows_bias_rows(C.byref(d))
         part = self._buf("enc_bias_part." + e.name, prow * 4 * hid) if prow else None
@@ -1007,12 +1036,13 @@ class GlowEngine:
             xa, ldi = x, e.in_dim
         # the input side (window scatter: one HBM pass over dgi / dgh, then the thin dW_ih product) on the second stream, next
         # to the MFMA-bound dW_hh product of the hidden side - and to the next modality's backward recurrence
-        side = self._fork() if os.environ.get("LFI_ENC_BWD_OVERLAP", "1") != "0" else None
+        side = self._fork() if (os.environ.get("LFI_ENC_BWD_OVERLAP", "1") != "0" and not inline) else None
         with self._on(side):
             check(self.L.lfi_encode_windows_scatter(C.byref(d), dgi.data_ptr(), dgh.data_ptr(), ptr(mk), dxp.data_ptr(),
                                                     _stream()), "lfi_encode_windows_scatter")
             self.gemm(G3, e.in_dim, rows, dxp, G3, 0, xa, ldi, 0, self.view(gname + "weight_ih", self.grads), e.in_dim,
-                      splitk=self._long_k_splitk(G3, e.in_dim, rows, kmin=512), ws="scratch.gemm_splitk.side", cls="enc_dwih")
+                      splitk=self._long_k_splitk(G3, e.in_dim, rows, kmin=512),
+                      ws="scratch.gemm_splitk.side3" if inline else "scratch.gemm_splitk.side", cls="enc_dwih")
         gbi, gbh = self.view(gname + "bias_ih", self.grads), self.view(gname + "bias_hh", self.grads)
         if part is not None:  # per-workgroup partial sums of (d r, d z, d n, d n * r) left by the fused backward kernel
             check(self.L.lfi_encode_windows_bias_grads(part.data_ptr(), prow, hid, gbi.data_ptr(), gbh.data_ptr(), st),
@@ -1024,7 +1054,8 @@ class GlowEngine:
             # (a bf16 gradient stash: dgh holds bf16 values in the same [hist][F][3 hid] order - the two-product kernel's A operand)
             g16 = bool(self.L.lfi_encode_windows_grad_stash_bf16(C.byref(d)))
             self.gemm(G3, hid, kk, dgh, G3, 0, hseq, hid, 0, self.view(gname + "weight_hh", self.grads), hid,
-                      splitk=self._long_k_splitk(G3, hid, kk), a_off=F * G3, cls="enc_dwhh", a_bf16=g16)
+                      splitk=self._long_k_splitk(G3, hid, kk), a_off=F * G3, cls="enc_dwhh", a_bf16=g16,
+                      ws="scratch.gemm_splitk.side2" if inline else "scratch.gemm_splitk")
         else:
             self.view(gname + "weight_hh", self.grads).zero_()
         if part is None:

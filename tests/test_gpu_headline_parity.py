@@ -107,9 +107,12 @@ def test_k16_sampling_against_oracle(gpu_device):
     for name, d in (("p2_face", 50), ("p1_speech", 27), ("p2_speech", 27)):
         data[name] = torch.randn(B, seq_len, d, generator=g)
     noise = torch.randn(seq_len - 24, B, 50, generator=g) * 0.8
+    threads = torch.get_num_threads()
+    torch.set_num_threads(min(8, threads))   # (batch-8 ops: a modest thread team is several times faster than all of the box's cores)
     ref = oracle.seqglow_inference(hp, {k: v.double() for k, v in sd.items()}, seq_len,
                                    {k: v.double() for k, v in data.items()}, noise.double())
     ref32 = oracle.seqglow_inference(hp, sd, seq_len, data, noise)    # the same op sequence in plain fp32 (CPU)
+    torch.set_num_threads(threads)
     own = float((ref32.double() - ref).abs().max())
     gate = max(1e-5, 1.5 * own)
     for precision in ("f32", "bf16x3"):
