@@ -24,7 +24,13 @@ namespace {
 constexpr int MB = 16;        // samples per workgroup
 constexpr int NT = 512;       // threads per workgroup (8 waves: one 16-wide hidden tile each at H = 128)
 constexpr int NW = NT / 64;
-constexpr int LT = MB + 1;    // k-major LDS leading dimension
+constexpr int LT = MB + 1;    // k-major LDS leading dimension. (ds_read_b32 / ds_write_b32 bank = dword address mod 32, 32 lanes per LDS cycle:
+                              // with a pitch of 17 a column-of-k store (one row, 32 consecutive k) is conflict-free and the MFMA A-operand read
+                              // of two consecutive k rows x 16 lanes puts ONE lane of the second row on the first row's bank 0 - the extra cycle
+                              // SQ_LDS_BANK_CONFLICT counts on nearly every such read (36 - 40 % of the walks' LDS cycles). Round 4 tried a
+                              // pitch of 16 with 2 floats after every fourth row (reads conflict-free, stores 2 - 4-way): the counter stayed at
+                              // 36 - 40 % - it is not these reads that it counts - and the backward cell's Q3 went from 2.5 k to 5.4 k cycles:
+                              // reverted, profiles/round4_walk_ab.md.)
 constexpr float LOG2PI_F = 1.8378770664093453f;
 constexpr float LN2_F = 0.6931471805599453f;
 
@@ -672,16 +678,6 @@ __global__ __launch_bounds__(NT) void flow_diag_bwd_kernel(FlowK f, int d, int k
 }
 
 // ------------------------------------------------------------------------------------------- register-resident cells
-// k-major fp32 operand images of the register-resident cells. Element (k, i) - i one of the 16 rows of the tile - lives at
-// LFR(k) + i = 16 k + 2 (k >> 2) + i: rows of 16 floats, two floats of padding after every fourth. The MFMA A-operand read of a
-// 16x16x4 f32 step takes rows k0 .. k0 + 3 (k0 a multiple of 4), one per 16-lane group: with a 16-float pitch inside the group of four
-// the 64 lanes cover the 64 banks exactly once (the 17-float pitch of rounds 1 - 3 put the fourth group's last three lanes on the
-// first group's banks: SQ_LDS_BANK_CONFLICT 37 % of the walks' LDS cycles), and the 2-float step between groups of four keeps the
-// elementwise phases' column-of-k stores (one row i, 32 consecutive k per half-wave) on distinct banks. LFR is additive over
-// multiples of 4, so block strides are constants: 16 k -> LF16, 4 / 8 / 12 k -> LF4 / LF8 / LF12. (Carve sizes stay K * LT >= LFR(K).)
-__host__ __device__ constexpr int LFR(int k) { return k * 16 + ((k >> 2) << 1); }
-constexpr int LF4 = 66, LF8 = 132, LF12 = 198, LF16 = 264, LF32 = 528;
-
 // Same cells for the common sizes (C <= 64, H <= 128): the generic kernels above stream every weight chunk from L2 inside
 // the dependent MFMA chains (4 phases x ~10 chunk round trips per cell: ~54 % of a wave's life is s_waitcnt, rocprof
 // PMC). Weights do not depend on the data, so here each wave issues the loads of ITS slice of a phase's weights one phase
@@ -735,7 +731,7 @@ __host__ __device__ inline CarveF carve_fast_fwd(int C, int C16, int H16, int Ch
   return c;
 }
 
-// sum over nb blocks of 16 k: A(16 x 16 nb) from LDS (k-major: a_lane = a_lds + kq * 16 + l15, element k at + k * LT) times
+// sum over nb blocks of 16 k: A(16 x 16 nb) from LDS (k-major: a_lane = a_lds + kq * LT + l15, element k at + k * LT) times
 // the register-resident B slice w[b] (components e: k = 16 b + 4 e + kq). Two interleaved chains (40-cycle dependent latency
 // against a 32-cycle issue).
 template <int MAXB>
@@ -744,8 +740,8 @@ __device__ __forceinline__ f32x4 mma16_reg(const float* a_lane, const f32x4 (&w)
 #pragma unroll
   for (int b = 0; b < MAXB; ++b)
     if (b < nb) {
-      const float* ab = a_lane + b * LF16;
-      const float a0 = ab[0], a1 = ab[LF4], a2 = ab[LF8], a3 = ab[LF12];
+      const float* ab = a_lane + b * 16 * LT;
+      const float a0 = ab[0], a1 = ab[4 * LT], a2 = ab[8 * LT], a3 = ab[12 * LT];
       e = mfma16(a0, w[b][0], e);
       o = mfma16(a1, w[b][1], o);
       e = mfma16(a2, w[b][2], e);
@@ -797,9 +793,9 @@ __device__ __forceinline__ X3Frag x3_pack(const f32x4& b0, const f32x4& b1) {
 }
 // A fragment of 32 k from a k-major LDS operand: the eight reads of two f32 blocks
 __device__ __forceinline__ X3Frag x3_a(const float* ab) {
-  f32x4 b0 = {ab[0], ab[LF4], ab[LF8], ab[LF12]};
-  const float* a1 = ab + LF16;
-  f32x4 b1 = {a1[0], a1[LF4], a1[LF8], a1[LF12]};
+  f32x4 b0 = {ab[0], ab[4 * LT], ab[8 * LT], ab[12 * LT]};
+  const float* a1 = ab + 16 * LT;
+  f32x4 b1 = {a1[0], a1[4 * LT], a1[8 * LT], a1[12 * LT]};
   return x3_pack(b0, b1);
 }
 __device__ __forceinline__ f32x4 x3_mma(const X3Frag& a, const X3Frag& w, f32x4 acc) {
@@ -836,9 +832,9 @@ __device__ __forceinline__ X3FragH x3h_pack(const f32x4& b0, const f32x4& b1) {
   return r;
 }
 __device__ __forceinline__ X3FragH x3h_a(const float* ab) {
-  f32x4 b0 = {ab[0], ab[LF4], ab[LF8], ab[LF12]};
-  const float* a1 = ab + LF16;
-  f32x4 b1 = {a1[0], a1[LF4], a1[LF8], a1[LF12]};
+  f32x4 b0 = {ab[0], ab[4 * LT], ab[8 * LT], ab[12 * LT]};
+  const float* a1 = ab + 16 * LT;
+  f32x4 b1 = {a1[0], a1[4 * LT], a1[8 * LT], a1[12 * LT]};
   return x3h_pack(b0, b1);
 }
 __device__ __forceinline__ f32x4 x3h_mma(const X3FragH& a, const X3FragH& w, f32x4 acc) {
@@ -869,7 +865,7 @@ __device__ __forceinline__ f32x4 x3_mma_gates(const float* a_lane, int blk, cons
 #pragma unroll
     for (int b = 0; b < MAXB2; ++b)
       if (b < nb2) {
-        const X3Frag a = x3_a(a_lane + g * blk + b * LF32);
+        const X3Frag a = x3_a(a_lane + g * blk + b * 32 * LT);
         if ((g * MAXB2 + b) & 1) o = x3_mma(a, w[g][b], o);
         else e = x3_mma(a, w[g][b], e);
       }
@@ -929,7 +925,7 @@ __device__ __forceinline__ void fast_cell_p2_gates(const FlowK& f, const float* 
         // (explicit fused forms: left to -ffp-contract, "(1 - z) n + z h" fuses either product, and which one depended on the
         // kernel this function was inlined into - the persistent walk and the diagonal walk then differed by an ulp)
         const float nn = tanhf_(__builtin_fmaf(rr, ghn, az[2][r] + gc[r][2]));
-        const float hp = Ht[LFR(j2) + i];
+        const float hp = Ht[j2 * LT + i];
         hnew = __builtin_fmaf(uu, hp, (1.0f - uu) * nn);
         gs0 = rr; gs1 = uu; gs2 = nn; gs3 = ghn;
       } else {        // torch.nn.LSTMCell, gate order i, f, g, o; zero (h, c) at the first modelled frame
@@ -943,7 +939,7 @@ __device__ __forceinline__ void fast_cell_p2_gates(const FlowK& f, const float* 
         if (cnew) cnew[r] = c2;
         gs0 = ii; gs1 = ff; gs2 = gg; gs3 = oo;
       }
-      Hn[LFR(j2) + i] = hnew;
+      Hn[j2 * LT + i] = hnew;
       if (img_hi) x3_put(img_hi, img_lo, i * img_ld + img_col + x3_pos(j2), hnew);   // bf16 hi / lo image for the next cell's product
       if (row < rows) {
         if (h_out) h_out[(long)row * H + j2] = hnew;   // (null: the caller stores the tile's rows itself, 16 bytes at a time)
@@ -970,13 +966,13 @@ __device__ __forceinline__ void fast_cell_p2(const FlowK& f, const float* Zt, co
     az[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
     ah[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
   }
-  const float* zl = Zt + kq * 16 + l15;
-  const float* hl = Ht + kq * 16 + l15;
+  const float* zl = Zt + kq * LT + l15;
+  const float* hl = Ht + kq * LT + l15;
 #pragma unroll
   for (int b = 0; b < FB_Z; ++b)
     if (b < nbZ) {
-      const float* ab = zl + b * LF16;
-      const float a0 = ab[0], a1 = ab[LF4], a2 = ab[LF8], a3 = ab[LF12];
+      const float* ab = zl + b * 16 * LT;
+      const float a0 = ab[0], a1 = ab[4 * LT], a2 = ab[8 * LT], a3 = ab[12 * LT];
 #pragma unroll
       for (int g = 0; g < NG; ++g) az[g] = mfma16(a0, wz[g][b][0], az[g]);
 #pragma unroll
@@ -989,8 +985,8 @@ __device__ __forceinline__ void fast_cell_p2(const FlowK& f, const float* Zt, co
 #pragma unroll
   for (int b = 0; b < FB_H; ++b)
     if (b < nbH) {
-      const float* ab = hl + b * LF16;
-      const float a0 = ab[0], a1 = ab[LF4], a2 = ab[LF8], a3 = ab[LF12];
+      const float* ab = hl + b * 16 * LT;
+      const float a0 = ab[0], a1 = ab[4 * LT], a2 = ab[8 * LT], a3 = ab[12 * LT];
 #pragma unroll
       for (int g = 0; g < NG; ++g) ah[g] = mfma16(a0, wh[g][b][0], ah[g]);
 #pragma unroll
@@ -1055,19 +1051,19 @@ __device__ __forceinline__ void fast_cell_p2_x3(const FlowK& f, const float* Zt,
     az[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
     ah[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
   }
-  const float* zl = Zt + kq * 16 + l15;
-  const float* hl = Ht + kq * 16 + l15;
+  const float* zl = Zt + kq * LT + l15;
+  const float* hl = Ht + kq * LT + l15;
 #pragma unroll
   for (int b = 0; b < FB_Z / 2; ++b)
     if (b < nbZ2) {
-      const X3Frag a = x3_a(zl + b * LF32);
+      const X3Frag a = x3_a(zl + b * 32 * LT);
 #pragma unroll
       for (int g = 0; g < NG; ++g) az[g] = x3_mma(a, wz[g][b], az[g]);
     }
 #pragma unroll
   for (int b = 0; b < FB_H / 2; ++b)
     if (b < nbH2) {
-      const X3Frag a = x3_a(hl + b * LF32);
+      const X3Frag a = x3_a(hl + b * 32 * LT);
 #pragma unroll
       for (int g = 0; g < NG; ++g) ah[g] = x3_mma(a, wh[g][b], ah[g]);
     }
@@ -1087,19 +1083,19 @@ __device__ __forceinline__ void fast_cell_p2_x3h(const FlowK& f, const float* Zt
     az[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
     ah[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
   }
-  const float* zl = Zt + kq * 16 + l15;
-  const float* hl = Ht + kq * 16 + l15;
+  const float* zl = Zt + kq * LT + l15;
+  const float* hl = Ht + kq * LT + l15;
 #pragma unroll
   for (int b = 0; b < FB_Z / 2; ++b)
     if (b < nbZ2) {
-      const X3FragH a = x3h_a(zl + b * LF32);
+      const X3FragH a = x3h_a(zl + b * 32 * LT);
 #pragma unroll
       for (int g = 0; g < NG; ++g) az[g] = x3h_mma(a, wz[g][b], az[g]);
     }
 #pragma unroll
   for (int b = 0; b < FB_H / 2; ++b)
     if (b < nbH2) {
-      const X3FragH a = x3h_a(hl + b * LF32);
+      const X3FragH a = x3h_a(hl + b * 32 * LT);
 #pragma unroll
       for (int g = 0; g < NG; ++g) ah[g] = x3h_mma(a, wh[g][b], ah[g]);
     }
@@ -1110,7 +1106,7 @@ __device__ __forceinline__ void fast_cell_p2_x3h(const FlowK& f, const float* Zt
 __device__ __forceinline__ void fast_cell_p3(const FlowK& f, int k, const float* Hn, float* Orm, const f32x4 (&w3)[FB_H], int nbH,
                                              int col, int kq, int l15, int b0, int rows, float* o_out, long ld_out) {
   const int Cout = f.Cout, ldo = Cout + 1;
-  const f32x4 acc = mma16_reg<FB_H>(Hn + kq * 16 + l15, w3, nbH);
+  const f32x4 acc = mma16_reg<FB_H>(Hn + kq * LT + l15, w3, nbH);
   if (col < Cout) {
     const float bb = f.p.b_fl[(long)k * Cout + col], sc = expf(3.0f * f.p.l_fl[(long)k * Cout + col]);
 #pragma unroll
@@ -1192,21 +1188,21 @@ __global__ __launch_bounds__(NT) void flow_diag_fwd_fast_kernel(FlowK f, int d, 
         a = (xin[c] + anb[c]) * expf(anl[c]);
         f.sA[(kf + row) * LC + c] = a;
       }
-      At[LFR(c) + ri] = a;
+      At[c * LT + ri] = a;
     }
     const float* hp = n > 0 ? f.sH + (kf - B + row) * H : nullptr;
     for (int j = cl; j < H16; j += 32) {
-      Ht[LFR(j) + ri] = (hp && rok && j < H) ? hp[j] : 0.0f;
-      if (j >= H) Hn[LFR(j) + ri] = 0.0f;
+      Ht[j * LT + ri] = (hp && rok && j < H) ? hp[j] : 0.0f;
+      if (j >= H) Hn[j * LT + ri] = 0.0f;
     }
-    for (int c = Ch + cl; c < Ch16; c += 32) Zt[LFR(c) + ri] = 0.0f;
+    for (int c = Ch + cl; c < Ch16; c += 32) Zt[c * LT + ri] = 0.0f;
   }
   __syncthreads();
   LFI_STAMP(2);
 
   // ---- P1: y = a W   (InvertibleConv1x1.forward, glow/modules.py:186)
   if (t1) {
-    const f32x4 acc = mma16_reg<FB_C>(At + kq * 16 + l15, w1, nbC);
+    const f32x4 acc = mma16_reg<FB_C>(At + kq * LT + l15, w1, nbC);
     const int c = tcol;
     if (c < C) {
 #pragma unroll
@@ -1215,7 +1211,7 @@ __global__ __launch_bounds__(NT) void flow_diag_fwd_fast_kernel(FlowK f, int d, 
         const int row = b0 + i;
         const float v = acc[r];
         Yrm[i * ldy + c] = v;
-        if (c < Ch) Zt[LFR(c) + i] = v;
+        if (c < Ch) Zt[c * LT + i] = v;
         if (row < B) f.sY[(kf + row) * LC + c] = v;
       }
     }
@@ -1341,9 +1337,9 @@ __device__ __forceinline__ void pipe_publish(unsigned* flag, unsigned value, int
 __device__ __forceinline__ f32x4 mma16_lds(const float* a_lane, const f32x4* wl, int nb) {
   f32x4 e = {0.f, 0.f, 0.f, 0.f}, o = {0.f, 0.f, 0.f, 0.f};
   for (int b = 0; b < nb; ++b) {
-    const float* ab = a_lane + b * LF16;
+    const float* ab = a_lane + b * 16 * LT;
     const f32x4 w = wl[b * 64];
-    const float a0 = ab[0], a1 = ab[LF4], a2 = ab[LF8], a3 = ab[LF12];
+    const float a0 = ab[0], a1 = ab[4 * LT], a2 = ab[8 * LT], a3 = ab[12 * LT];
     e = mfma16(a0, w[0], e);
     o = mfma16(a1, w[1], o);
     e = mfma16(a2, w[2], e);
@@ -1467,10 +1463,10 @@ __global__ __launch_bounds__(NT) void flow_pipe_fwd_kernel(FlowK f) {
   }
   // zero state and the k padding of the LDS operands (never written again)
   for (int j = cl_0; j < H16; j += 32) {
-    Ht[LFR(j) + ri_0] = 0.0f;
-    Hn[LFR(j) + ri_0] = 0.0f;
+    Ht[j * LT + ri_0] = 0.0f;
+    Hn[j * LT + ri_0] = 0.0f;
   }
-  for (int c = Ch + cl_0; c < Ch16; c += 32) Zt[LFR(c) + ri_0] = 0.0f;
+  for (int c = Ch + cl_0; c < Ch16; c += 32) Zt[c * LT + ri_0] = 0.0f;
   __syncthreads();
 
   const int row = b0 + ri_0;          // elementwise phases: this thread's sample
@@ -1518,7 +1514,7 @@ __global__ __launch_bounds__(NT) void flow_pipe_fwd_kernel(FlowK f) {
         if (c < C16) {
           float a = 0.0f;
           if (c < C && rok) a = ((k == 0 ? xin[c] : (have_next ? xnext[u] : ld_tile(xin + c, fenced))) + anb[u]) * ans[u];
-          At[LFR(c) + ri] = a;
+          At[c * LT + ri] = a;
         }
       }
     }
@@ -1527,7 +1523,7 @@ __global__ __launch_bounds__(NT) void flow_pipe_fwd_kernel(FlowK f) {
 
     // ---- P1: y = a W   (InvertibleConv1x1.forward, glow/modules.py:186)
     if (t1) {
-      const f32x4 acc = mma16_lds(At + kq * 16 + l15, w1s, nbC);
+      const f32x4 acc = mma16_lds(At + kq * LT + l15, w1s, nbC);
       const int c = tcol;
       if (c < C) {
 #pragma unroll
@@ -1536,7 +1532,7 @@ __global__ __launch_bounds__(NT) void flow_pipe_fwd_kernel(FlowK f) {
           const float v = acc[r];
           Yrm[i * ldy + c] = v;
           if (c < Ch) {
-            Zt[LFR(c) + i] = v;
+            Zt[c * LT + i] = v;
             if (X3) x3_put(ich, ich + MB * ldxi, i * ldxi + x3_pos(c), v);
           }
         }
@@ -1575,7 +1571,7 @@ __global__ __launch_bounds__(NT) void flow_pipe_fwd_kernel(FlowK f) {
       // (exact f32 MFMA in every mode: o sets the coupling's scale and shift directly, and the inverse pass - sampling, invert -
       // computes it in exact f32; with three bf16 products here decode(encode(x)) at 96 flow steps went from 7e-4 to 3e-3 of x
       // for 20 us of a 500 us walk)
-      const f32x4 acc = mma16_lds(Hn + kq * 16 + l15, w3s, nbH);
+      const f32x4 acc = mma16_lds(Hn + kq * LT + l15, w3s, nbH);
       if (tcol < Cout) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -1601,7 +1597,7 @@ __global__ __launch_bounds__(NT) void flow_pipe_fwd_kernel(FlowK f) {
         f32x4 va, vy;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          va[e] = c0 + e < C ? At[LFR((c0 + e)) + ri] : 0.0f;
+          va[e] = c0 + e < C ? At[(c0 + e) * LT + ri] : 0.0f;
           vy[e] = c0 + e < C ? Yrm[ri * ldy + c0 + e] : 0.0f;
         }
         *reinterpret_cast<f32x4*>(f.sA + (kf + row) * LC + c0) = va;
@@ -1616,7 +1612,7 @@ __global__ __launch_bounds__(NT) void flow_pipe_fwd_kernel(FlowK f) {
       for (int h0 = c0; h0 < H; h0 += 128) {   // (H <= 128 on this path: one trip)
         f32x4 vh;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) vh[e] = h0 + e < H ? Hn[LFR((h0 + e)) + ri] : 0.0f;
+        for (int e = 0; e < 4; ++e) vh[e] = h0 + e < H ? Hn[(h0 + e) * LT + ri] : 0.0f;
         if (h0 + 3 < H && (H & 3) == 0) *reinterpret_cast<f32x4*>(f.sH + (kf + row) * H + h0) = vh;
         else
           for (int e = 0; e < 4; ++e)
@@ -1735,10 +1731,10 @@ __device__ __forceinline__ bool rev_fast_cell(const FlowK& f, const CellIO& io, 
     const int row = b0 + ri;
     const bool rok = row < rows;
     for (int j = cl; j < H16; j += 32) {
-      Ht[LFR(j) + ri] = (io.h_prev && rok && j < H) ? ld_tile(io.h_prev + (long)row * H + j, io.state_l2 == 0) : 0.0f;
-      if (j >= H) Hn[LFR(j) + ri] = 0.0f;
+      Ht[j * LT + ri] = (io.h_prev && rok && j < H) ? ld_tile(io.h_prev + (long)row * H + j, io.state_l2 == 0) : 0.0f;
+      if (j >= H) Hn[j * LT + ri] = 0.0f;
     }
-    for (int c = Ch + cl; c < Ch16; c += 32) Zt[LFR(c) + ri] = 0.0f;
+    for (int c = Ch + cl; c < Ch16; c += 32) Zt[c * LT + ri] = 0.0f;
   }
   // W^-1 slice of this wave's 16 output channels: in flight under the coupling net
   f32x4 w1[FB_C];
@@ -1752,7 +1748,7 @@ __device__ __forceinline__ bool rev_fast_cell(const FlowK& f, const CellIO& io, 
   }
   X3FragH wzx[X3 ? NG : 1][FB_Z / 2];   // three fp16 products (fp32-grade, x3h_*): the z1-side fragments, split in registers
   if (t2) {
-    const float* hl = Ht + kq * 16 + l15;
+    const float* hl = Ht + kq * LT + l15;
     if constexpr (X3) {
 #pragma unroll
       for (int g = 0; g < NG; ++g)
@@ -1761,7 +1757,7 @@ __device__ __forceinline__ bool rev_fast_cell(const FlowK& f, const CellIO& io, 
 #pragma unroll
       for (int b = 0; b < FB_H / 2; ++b)
         if (b < ((nbH + 1) >> 1)) {
-          const X3FragH a = x3h_a(hl + b * LF32);
+          const X3FragH a = x3h_a(hl + b * 32 * LT);
 #pragma unroll
           for (int g = 0; g < NG; ++g) ah[g] = x3h_mma(a, x3h_pack(wh[g][2 * b], wh[g][2 * b + 1]), ah[g]);
         }
@@ -1769,8 +1765,8 @@ __device__ __forceinline__ bool rev_fast_cell(const FlowK& f, const CellIO& io, 
 #pragma unroll
       for (int b = 0; b < FB_H; ++b)
         if (b < nbH) {
-          const float* ab = hl + b * LF16;
-          const float a0 = ab[0], a1 = ab[LF4], a2 = ab[LF8], a3 = ab[LF12];
+          const float* ab = hl + b * 16 * LT;
+          const float a0 = ab[0], a1 = ab[4 * LT], a2 = ab[8 * LT], a3 = ab[12 * LT];
 #pragma unroll
           for (int g = 0; g < NG; ++g) ah[g] = mfma16(a0, wh[g][b][0], ah[g]);
 #pragma unroll
@@ -1792,19 +1788,19 @@ __device__ __forceinline__ bool rev_fast_cell(const FlowK& f, const CellIO& io, 
     for (int c = cl; c < C16; c += 32) {
       const float v = (c < C && rok) ? ld_tile(io.x_in + (long)row * io.ldx + c, wait_flag == nullptr) : 0.0f;
       if (c < C) Yrm[ri * ldy + c] = v;
-      if (c < Ch) Zt[LFR(c) + ri] = v;
-      if (c < Ch || c >= C) Yt[LFR(c) + ri] = v;   // z1 rows and the zero k padding; z2 rows come from R3
+      if (c < Ch) Zt[c * LT + ri] = v;
+      if (c < Ch || c >= C) Yt[c * LT + ri] = v;   // z1 rows and the zero k padding; z2 rows come from R3
     }
   }
   __syncthreads();
   REV_STAMP(3);
   if (t2) {   // the z1 half of the product (one k-block at C <= 64), then the gate math
-    const float* zl = Zt + kq * 16 + l15;
+    const float* zl = Zt + kq * LT + l15;
     if constexpr (X3) {
 #pragma unroll
       for (int b = 0; b < FB_Z / 2; ++b)
         if (b < ((nbZ + 1) >> 1)) {
-          const X3FragH a = x3h_a(zl + b * LF32);
+          const X3FragH a = x3h_a(zl + b * 32 * LT);
 #pragma unroll
           for (int g = 0; g < NG; ++g) az[g] = x3h_mma(a, wzx[g][b], az[g]);
         }
@@ -1812,8 +1808,8 @@ __device__ __forceinline__ bool rev_fast_cell(const FlowK& f, const CellIO& io, 
 #pragma unroll
       for (int b = 0; b < FB_Z; ++b)
         if (b < nbZ) {
-          const float* ab = zl + b * LF16;
-          const float a0 = ab[0], a1 = ab[LF4], a2 = ab[LF8], a3 = ab[LF12];
+          const float* ab = zl + b * 16 * LT;
+          const float a0 = ab[0], a1 = ab[4 * LT], a2 = ab[8 * LT], a3 = ab[12 * LT];
 #pragma unroll
           for (int g = 0; g < NG; ++g) az[g] = mfma16(a0, wz[g][b][0], az[g]);
 #pragma unroll
@@ -1848,7 +1844,7 @@ __device__ __forceinline__ bool rev_fast_cell(const FlowK& f, const CellIO& io, 
       } else {
         z2 = z2n - Orm[ri * ldo + cl];
       }
-      Yt[LFR((Ch + cl)) + ri] = z2;
+      Yt[(Ch + cl) * LT + ri] = z2;
     }
 #pragma unroll
     for (int o = 16; o > 0; o >>= 1) lg += __shfl_xor(lg, o, 64);
@@ -1860,7 +1856,7 @@ __device__ __forceinline__ bool rev_fast_cell(const FlowK& f, const CellIO& io, 
   REV_STAMP(6);
   // ---- R4: x = (y W^-1) exp(-logs) - bias   (scale then center, glow/modules.py:76-79)
   if (t1) {
-    const f32x4 acc = mma16_reg<FB_C>(Yt + kq * 16 + l15, w1, nbC);
+    const f32x4 acc = mma16_reg<FB_C>(Yt + kq * LT + l15, w1, nbC);
     const int c = tcol;
     if (c < C) {
       const float es = expf(-f.p.an_logs[(long)k * C + c]), bb = f.p.an_bias[(long)k * C + c];
@@ -2008,8 +2004,8 @@ __device__ __forceinline__ f32x4 mma16_reg_gates(const float* a_lane, int blk, c
 #pragma unroll
     for (int b = 0; b < MAXB; ++b)
       if (b < nb) {
-        const float* ab = a_lane + g * blk + b * LF16;
-        const float a0 = ab[0], a1 = ab[LF4], a2 = ab[LF8], a3 = ab[LF12];
+        const float* ab = a_lane + g * blk + b * 16 * LT;
+        const float a0 = ab[0], a1 = ab[4 * LT], a2 = ab[8 * LT], a3 = ab[12 * LT];
         e = mfma16(a0, w[g][b][0], e);
         o = mfma16(a1, w[g][b][1], o);
         e = mfma16(a2, w[g][b][2], e);
@@ -2115,20 +2111,20 @@ __global__ __launch_bounds__(NT) void flow_diag_bwd_fast_kernel(FlowK f, int d, 
         }
         f.bDy[(kf + row) * LC + Ch + cl] = dz2;
       }
-      Dy[LFR((Ch + cl)) + ri] = dz2;
+      Dy[(Ch + cl) * LT + ri] = dz2;
       if (f.affine) {
-        Dl[LFR((2 * cl)) + ri] = dl0; Dl[LFR((2 * cl + 1)) + ri] = dl1;
+        Dl[(2 * cl) * LT + ri] = dl0; Dl[(2 * cl + 1) * LT + ri] = dl1;
         Pl[ri * ldp + 2 * cl] = p0; Pl[ri * ldp + 2 * cl + 1] = p1;
       } else {
-        Dl[LFR(cl) + ri] = dl0;
+        Dl[cl * LT + ri] = dl0;
         Pl[ri * ldp + cl] = p0;
       }
     }
-    for (int c = Cout + cl; c < Co16; c += 32) Dl[LFR(c) + ri] = 0.0f;
-    for (int c = C + cl; c < C16; c += 32) Dy[LFR(c) + ri] = 0.0f;
+    for (int c = Cout + cl; c < Co16; c += 32) Dl[c * LT + ri] = 0.0f;
+    for (int c = C + cl; c < C16; c += 32) Dy[c * LT + ri] = 0.0f;
     for (int j = H + cl; j < H16; j += 32) {
 #pragma unroll
-      for (int g = 0; g < NG; ++g) { Gi[LFR((g * H16 + j)) + ri] = 0.0f; Gh[LFR((g * H16 + j)) + ri] = 0.0f; }
+      for (int g = 0; g < NG; ++g) { Gi[(g * H16 + j) * LT + ri] = 0.0f; Gh[(g * H16 + j) * LT + ri] = 0.0f; }
     }
   }
   __syncthreads();
@@ -2140,7 +2136,7 @@ __global__ __launch_bounds__(NT) void flow_diag_bwd_fast_kernel(FlowK f, int d, 
 
   // ---- Q1: d h' = dlin Wfl + dh carried from timestep n + 1; recurrent cell backward
   if (th) {
-    const f32x4 acc = mma16_reg<FB_O>(Dl + kq * 16 + l15, wq1, nbO);
+    const f32x4 acc = mma16_reg<FB_O>(Dl + kq * LT + l15, wq1, nbO);
     const int j = tcol;
     if (j < H) {
 #pragma unroll
@@ -2182,8 +2178,8 @@ __global__ __launch_bounds__(NT) void flow_diag_bwd_fast_kernel(FlowK f, int d, 
           for (int g = 0; g < NG; ++g) { go[g * H] = gi_[g]; ho[g * H] = gh_[g]; }
         }
 #pragma unroll
-        for (int g = 0; g < NG; ++g) { Gi[LFR((g * H16 + j)) + i] = gi_[g]; Gh[LFR((g * H16 + j)) + i] = gh_[g]; }
-        Cy[LFR(j) + i] = cy;
+        for (int g = 0; g < NG; ++g) { Gi[(g * H16 + j) * LT + i] = gi_[g]; Gh[(g * H16 + j) * LT + i] = gh_[g]; }
+        Cy[j * LT + i] = cy;
       }
     }
   }
@@ -2196,20 +2192,20 @@ __global__ __launch_bounds__(NT) void flow_diag_bwd_fast_kernel(FlowK f, int d, 
   //          d h_prev = dgh W_hh + carry (to timestep n - 1; not needed inside this cell)
   auto dh_prev_tile = [&](const f32x4 (&w)[NG][FB_H]) {
     if (n > 0 && th) {
-      const f32x4 acc = mma16_reg_gates<NG, FB_H>(Gh + kq * 16 + l15, LFR(H16), w, nbH);
+      const f32x4 acc = mma16_reg_gates<NG, FB_H>(Gh + kq * LT + l15, H16 * LT, w, nbH);
       const int j = tcol;
       if (j < H) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int i = kq * 4 + r;
           const int row = b0 + i;
-          if (row < B) f.bDh[(kf + row) * H + j] = acc[r] + Cy[LFR(j) + i];
+          if (row < B) f.bDh[(kf + row) * H + j] = acc[r] + Cy[j * LT + i];
         }
       }
     }
   };
   if (tz) {
-    const f32x4 acc = mma16_reg_gates<NG, FB_H>(Gi + kq * 16 + l15, LFR(H16), wq2, nbH);
+    const f32x4 acc = mma16_reg_gates<NG, FB_H>(Gi + kq * LT + l15, H16 * LT, wq2, nbH);
     const int c = tcol;
     if (c < Ch) {
 #pragma unroll
@@ -2221,7 +2217,7 @@ __global__ __launch_bounds__(NT) void flow_diag_bwd_fast_kernel(FlowK f, int d, 
           v = acc[r] + sdxo[r];
           f.bDy[(kf + row) * LC + c] = v;
         }
-        Dy[LFR(c) + i] = v;
+        Dy[c * LT + i] = v;
       }
     }
     // now fetch this wave's W_hh slice for its d h_prev tile (runs after Q3)
@@ -2234,7 +2230,7 @@ __global__ __launch_bounds__(NT) void flow_diag_bwd_fast_kernel(FlowK f, int d, 
 
   // ---- Q3: d a = dy W^T ; actnorm backward ; d x_in to flow step k - 1
   if (tc) {
-    const f32x4 acc = mma16_reg<FB_C>(Dy + kq * 16 + l15, wq3, nbC);
+    const f32x4 acc = mma16_reg<FB_C>(Dy + kq * LT + l15, wq3, nbC);
     const int c = tcol;
     float sl = 0.0f, sb = 0.0f;
     if (c < C) {
@@ -2449,27 +2445,27 @@ __global__ __launch_bounds__(NT) void flow_pipe_bwd_kernel(FlowK f) {
         }
         f.bDy[(kf + row) * LC + Ch + cl] = dz2;
       }
-      Dy[LFR((Ch + cl)) + ri] = dz2;
+      Dy[(Ch + cl) * LT + ri] = dz2;
       if (f.affine) {
         if constexpr (X3) {
           x3_put(DlH, DlL, ri * ldxd + x3_pos(2 * cl), dl0);
           x3_put(DlH, DlL, ri * ldxd + x3_pos(2 * cl + 1), dl1);
         } else {
-          Dl[LFR((2 * cl)) + ri] = dl0; Dl[LFR((2 * cl + 1)) + ri] = dl1;
+          Dl[(2 * cl) * LT + ri] = dl0; Dl[(2 * cl + 1) * LT + ri] = dl1;
         }
         Pl[ri * ldp + 2 * cl] = p0; Pl[ri * ldp + 2 * cl + 1] = p1;
       } else {
         if constexpr (X3) x3_put(DlH, DlL, ri * ldxd + x3_pos(cl), dl0);
-        else Dl[LFR(cl) + ri] = dl0;
+        else Dl[cl * LT + ri] = dl0;
         Pl[ri * ldp + cl] = p0;
       }
     }
-    if (!X3) for (int c = Cout + cl; c < Co16; c += 32) Dl[LFR(c) + ri] = 0.0f;
-    for (int c = C + cl; c < C16; c += 32) Dy[LFR(c) + ri] = 0.0f;
+    if (!X3) for (int c = Cout + cl; c < Co16; c += 32) Dl[c * LT + ri] = 0.0f;
+    for (int c = C + cl; c < C16; c += 32) Dy[c * LT + ri] = 0.0f;
     for (int j = H + cl; j < H16; j += 32) {
 #pragma unroll
       for (int g = 0; g < NG; ++g)
-        if (!X3) { Gi[LFR((g * H16 + j)) + ri] = 0.0f; Gh[LFR((g * H16 + j)) + ri] = 0.0f; }
+        if (!X3) { Gi[(g * H16 + j) * LT + ri] = 0.0f; Gh[(g * H16 + j) * LT + ri] = 0.0f; }
     }
   }
   __syncthreads();
@@ -2498,7 +2494,7 @@ __global__ __launch_bounds__(NT) void flow_pipe_bwd_kernel(FlowK f) {
         }
       acc = e + o;
     } else {
-      acc = mma16_reg<FB_O>(Dl + kq * 16 + l15, wq1, nbO);
+      acc = mma16_reg<FB_O>(Dl + kq * LT + l15, wq1, nbO);
     }
     const int j = tcol;
     if (j < H) {
@@ -2550,10 +2546,10 @@ __global__ __launch_bounds__(NT) void flow_pipe_bwd_kernel(FlowK f) {
             x3_put(GiH, GiL, at, gi_[g]);
             x3_put(GhH, GhL, at, gh_[g]);
           } else {
-            Gi[LFR((g * H16 + j)) + i] = gi_[g]; Gh[LFR((g * H16 + j)) + i] = gh_[g];
+            Gi[(g * H16 + j) * LT + i] = gi_[g]; Gh[(g * H16 + j) * LT + i] = gh_[g];
           }
         }
-        Cy[LFR(j) + i] = cy;
+        Cy[j * LT + i] = cy;
       }
     }
   }
@@ -2566,7 +2562,7 @@ __global__ __launch_bounds__(NT) void flow_pipe_bwd_kernel(FlowK f) {
     if (n > 0 && th) {
       f32x4 acc;
       if constexpr (X3) acc = x3_mma_gates_img<NG, FB_H / 2>(GhH + l15 * ldx + 8 * kq, GhL + l15 * ldx + 8 * kq, H16, wq2x, nbH2);
-      else acc = mma16_reg_gates<NG, FB_H>(Gh + kq * 16 + l15, LFR(H16), wq2, nbH);
+      else acc = mma16_reg_gates<NG, FB_H>(Gh + kq * LT + l15, H16 * LT, wq2, nbH);
       const int j = tcol;
       if (j < H) {
 #pragma unroll
@@ -2574,7 +2570,7 @@ __global__ __launch_bounds__(NT) void flow_pipe_bwd_kernel(FlowK f) {
           const int i = kq * 4 + r;
           const int row = b0 + i;
           (void)row;
-          dhc[r] = acc[r] + Cy[LFR(j) + i];
+          dhc[r] = acc[r] + Cy[j * LT + i];
         }
       }
     }
@@ -2582,7 +2578,7 @@ __global__ __launch_bounds__(NT) void flow_pipe_bwd_kernel(FlowK f) {
   if (tz) {
     f32x4 acc;
     if constexpr (X3) acc = x3_mma_gates_img<NG, FB_H / 2>(GiH + l15 * ldx + 8 * kq, GiL + l15 * ldx + 8 * kq, H16, wq2x, nbH2);
-    else acc = mma16_reg_gates<NG, FB_H>(Gi + kq * 16 + l15, LFR(H16), wq2, nbH);
+    else acc = mma16_reg_gates<NG, FB_H>(Gi + kq * LT + l15, H16 * LT, wq2, nbH);
     const int c = tcol;
     if (c < Ch) {
 #pragma unroll
@@ -2594,7 +2590,7 @@ __global__ __launch_bounds__(NT) void flow_pipe_bwd_kernel(FlowK f) {
           v = acc[r] + sdxo[r];
           f.bDy[(kf + row) * LC + c] = v;
         }
-        Dy[LFR(c) + i] = v;
+        Dy[c * LT + i] = v;
       }
     }
     // now fetch this wave's W_hh slice for its d h_prev tile (runs after Q3)
@@ -2638,7 +2634,7 @@ __global__ __launch_bounds__(NT) void flow_pipe_bwd_kernel(FlowK f) {
     }
   }
   if (tc) {
-    const f32x4 acc = mma16_reg<FB_C>(Dy + kq * 16 + l15, wq3, nbC);
+    const f32x4 acc = mma16_reg<FB_C>(Dy + kq * LT + l15, wq3, nbC);
     const int c = tcol;
     float sl = 0.0f, sb = 0.0f;
     if (c < C) {
