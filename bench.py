@@ -150,23 +150,57 @@ def cpu_baseline_sample(hp, C, S, B, nframes, budget_s):
                       "C=%d S=%d, batch %d, first %d generated frames, median of %d runs, %.1f s per run" % (C, S, B, nframes, len(times), med)}
 
 
-def gpu_state_under_load(fn, device, max_s=4.0):
-    """Shader clock / socket power of this GPU while `fn(i)` keeps it busy (outside every timed region): rocm-smi runs in a
-    thread while the main thread keeps enqueueing steps, so the reading is of the loaded chip, not of the idle one. A slow box
-    (power-capped, hot) can then be told from a regression in the record itself. None when rocm-smi cannot be run."""
-    import shutil
+_SMI_HELPER = r"""
+import json, shutil, subprocess, sys
+exe = shutil.which("rocm-smi") or "/opt/rocm/bin/rocm-smi"
+for line in sys.stdin:
+    dev = line.strip()
+    if not dev:
+        break
+    try:
+        r = subprocess.run([exe, "-d", dev, "--showclocks", "--showpower", "--showtemp", "--json"], capture_output=True, text=True, timeout=20)
+        print(json.dumps({"raw": json.loads(r.stdout)}), flush=True)
+    except Exception as e:
+        print(json.dumps({"error": "%s: %s" % (type(e).__name__, e)}), flush=True)
+"""
+
+
+def start_smi_helper():
+    """A child process that runs rocm-smi on request. Started BEFORE this process touches the GPU: on this pool a process that has
+    initialised HIP must not fork + exec another program (the box refuses it; under rocprofv3 --pmc it did), and rocm-smi is a
+    Python script. The helper never initialises the GPU itself. None when it cannot be started."""
     import subprocess
+    try:
+        return subprocess.Popen([sys.executable, "-c", _SMI_HELPER], stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True)
+    except Exception:      # noqa: BLE001 - diagnostics only
+        return None
+
+
+def stop_smi_helper(helper):
+    if helper is None:
+        return
+    try:
+        helper.stdin.write("\n")
+        helper.stdin.flush()
+        helper.wait(timeout=5)
+    except Exception:      # noqa: BLE001
+        helper.kill()
+
+
+def gpu_state_under_load(fn, device, helper, max_s=6.0):
+    """Shader clock / socket power of this GPU while `fn(i)` keeps it busy (outside every timed region): the helper runs rocm-smi
+    while this process keeps enqueueing steps, so the reading is of the loaded chip, not of the idle one. A slow box (power-capped,
+    hot) can then be told from a regression in the record itself. None when there is no helper."""
     import threading
-    exe = shutil.which("rocm-smi") or "/opt/rocm/bin/rocm-smi"
-    if not os.path.exists(exe):
+    if helper is None or helper.poll() is not None:
         return None
     box = {}
 
     def read():
         try:
-            r = subprocess.run([exe, "-d", str(device.index or 0), "--showclocks", "--showpower", "--showtemp", "--json"],
-                               capture_output=True, text=True, timeout=20)
-            box["raw"] = json.loads(r.stdout)
+            helper.stdin.write("%d\n" % (device.index or 0))
+            helper.stdin.flush()
+            box.update(json.loads(helper.stdout.readline()))
         except Exception as e:      # noqa: BLE001 - diagnostics only
             box["error"] = "%s: %s" % (type(e).__name__, e)
 
@@ -182,7 +216,7 @@ def gpu_state_under_load(fn, device, max_s=4.0):
         i += 1
         if i % 8 == 0:
             torch.cuda.synchronize()
-    th.join()
+    th.join(timeout=25)
     torch.cuda.synchronize()
     if "raw" not in box:
         return {"error": box.get("error", "no output")}
@@ -389,7 +423,7 @@ def bench_train(args, model, trainer, spec, device, world, rank, hp):
         dp_line = _dp_summary(model.dp_profile, eng, world)
         model.dp_profile = None
     host_issue = _host_issue_ms(step, reps=5)   # (without any per-kernel events)
-    gpu_state = gpu_state_under_load(step, device) if (rank == 0 and not args.quick and world == 1) else None
+    gpu_state = gpu_state_under_load(step, device, getattr(args, "smi_helper", None)) if (rank == 0 and not args.quick and world == 1) else None
     graph_line = None
     if world == 1 and args.graph_steps > 0:
         # the same step as ONE replayed hipGraph (opt-in: LetsFaceItGlow.step_graph; bit-identical parameters): two more eager calls
@@ -613,6 +647,9 @@ def main():
                     help="N = 1, workload train: also time one GPU at this batch (the global batch of configs[2]) and report it "
                          "as strong_scaling_anchor; 0 disables it")
     ap.add_argument("--hparams", default=os.path.join(ROOT, "lets_face_it_amd", "hparams", "final_model_synthetic.yaml"))
+    ap.add_argument("--no-gpu-state", action="store_true",
+                    help="do not start the rocm-smi helper process (runs under rocprofv3 --pmc, where the profiler has initialised the "
+                         "GPU before this program starts and the box refuses every fork + exec)")
     ap.add_argument("--quick", action="store_true",
                     help="the timed region and its roofline only: no baselines, no hipGraph / three-product / anchor legs, no "
                          "further workloads (A/B runs)")
@@ -635,6 +672,8 @@ def main():
     # LFI_DIST_BACKEND=gloo rehearses the N > 1 path on a box with fewer GPUs than ranks (ranks share cards, tensors travel
     # through the host): same code path, barriers and timing; the default is RCCL with one GPU per rank
     backend = os.environ.get("LFI_DIST_BACKEND", "nccl")
+    # (before anything initialises the GPU: see start_smi_helper)
+    args.smi_helper = start_smi_helper() if (world == 1 and rank == 0 and not args.quick and not args.no_gpu_state) else None
     ndev = torch.cuda.device_count()
     device = torch.device("cuda", local_rank % ndev if (backend != "nccl" and ndev > 0) else local_rank)
     torch.cuda.set_device(device)
@@ -733,6 +772,7 @@ def main():
         out["deep_flow"] = sub("deep", batch=128, seq_len=512, steps=3, warmup=3)
         out["native_dims"] = sub("train", batch=256, seq_len=80, steps=10, warmup=3,
                                  hparams_file=os.path.join(ROOT, "lets_face_it_amd", "hparams", "final_model.yaml"))
+    stop_smi_helper(getattr(args, "smi_helper", None))
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

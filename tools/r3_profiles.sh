@@ -4,7 +4,7 @@ set -u
 TAG=${1:-r3}
 O=gpurun_out/$TAG; mkdir -p $O
 export TMPDIR=/tmp
-NOBASE="--cpu-baseline-seconds 0 --torch-gpu-baseline-seconds 0 --strong-anchor-batch 0 --graph-steps 0 --three-products-steps 0"
+NOBASE="--no-gpu-state --no-more-workloads --cpu-baseline-seconds 0 --torch-gpu-baseline-seconds 0 --strong-anchor-batch 0 --graph-steps 0 --three-products-steps 0"
 # 1. kernel statistics + one steady step's timeline, two streams (as the step runs) and one stream (every duration its own)
 timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $O/prof2 -o run -- python3 bench.py $NOBASE --steps 12 > $O/prof2.log 2>&1; echo "prof2 rc=$?"
 python3 tools/rocpd_stats.py $O/prof2/run_results.db 45 > $O/kernel_stats.md 2>&1
