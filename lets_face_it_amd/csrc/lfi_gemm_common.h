@@ -195,8 +195,10 @@ __device__ __forceinline__ void gemm_sign_tile_from_planes(const GemmArgs& g, fl
   }
 }
 
-template <int BN, int NTH = 256, int MT = 2, bool COLP = false, bool PL = false>
-__device__ __forceinline__ void gemm_epilogue_wide(const GemmArgs& g, const f32x16 (&acc)[MT][2], float* lds, int rows_per_pass,
+// L16: the accumulators are the 4 x 4 tiles of v_mfma_f32_16x16x32_bf16 (f32x4 acc[4][4]; tile (mi, ni) register r = row
+// 16 mi + 4 (lane >> 4) + r, column 16 ni + (lane & 15) of the wave's 64 x 64 patch) instead of 2 x 2 tiles of the 32 x 32 shape.
+template <int BN, int NTH = 256, int MT = 2, bool COLP = false, bool PL = false, bool L16 = false, typename ACC>
+__device__ __forceinline__ void gemm_epilogue_wide(const GemmArgs& g, const ACC& acc, float* lds, int rows_per_pass,
                                                    int m0, int n0, int wm, int wn, int l31, int half, int batch, int split, int bm,
                                                    bool has_acc = true) {
   constexpr int WLD = BN + 4;       // LDS row pitch (floats)
@@ -231,6 +233,33 @@ __device__ __forceinline__ void gemm_epilogue_wide(const GemmArgs& g, const f32x
       }
       __syncthreads();
     }
+    if constexpr (L16) {
+      static_assert(!L16 || MT == 2, "16 x 16 accumulator tiles: 64-row patches");
+      const int lane = threadIdx.x & 63, c15 = lane & 15, r4 = (lane >> 4) * 4;
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi)
+        if (has_acc && wm * 64 + mi * 16 >= p0 && wm * 64 + mi * 16 < p0 + rows_per_pass)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+          const int cl = wn * 64 + ni * 16 + c15;
+          const int col = n0 + cl;
+          const float bv = (!partial && bias && col < g.N) ? bias[col] : 0.0f;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int rl = wm * 64 - p0 + mi * 16 + r4 + r;
+            float v = acc[mi][ni][r];
+            if (!partial) {
+              v += bv;
+              const float o = (need_c || need_g) ? lds[rl * WLD + cl] : 0.0f;
+              if (g.accumulate == 2) v += o;
+              if (g.act == 1) v = v > 0.0f ? v : v * g.slope;
+              else if (g.act == 2) v = o > 0.0f ? v : v * g.slope;
+              if (g.accumulate == 1) v += o;
+            }
+            lds[rl * WLD + cl] = v;
+          }
+        }
+    } else
     if (has_acc) {   // a wave's patch is MT x 32 rows from wm * MT * 32: the row tiles that lie in this pass take part
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)

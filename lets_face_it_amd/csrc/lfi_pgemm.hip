@@ -35,6 +35,7 @@
 // format, and the act == 2 operand (cond_transform's LeakyReLU mask) can be read from the hi plane of its row planes.
 // History (rounds 1-2: 256 x 256 one-per-CU and four-wave 128 x 64-patch variants, ingredient-removal builds, stamps): DESIGN.md.
 #include "lfi_gemm_common.h"
+#include <type_traits>
 
 namespace {
 
@@ -57,7 +58,21 @@ __device__ __forceinline__ bf16x8 pg_frag(const char* blk, int uoff, int toff) {
   return r;
 }
 
+#ifdef LFI_PG_EXP_16
+// timing-only experiment (garbage results): the same operand registers through two v_mfma_f32_16x16x32_bf16 (same FLOP, same
+// issue cycles) - does the chip hold a higher clock on that shape (MI355X_MICROARCH.md, DVFS give-back item 7)?
+__device__ __forceinline__ f32x16 pg_mfma16(bf16x8 a, bf16x8 b, f32x16 c) {
+  f32x4 q0 = {c[0], c[1], c[2], c[3]}, q1 = {c[4], c[5], c[6], c[7]};
+  q0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, q0, 0, 0, 0);
+  q1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, q1, 0, 0, 0);
+  c[0] = q0[0]; c[1] = q0[1]; c[2] = q0[2]; c[3] = q0[3];
+  c[4] = q1[0]; c[5] = q1[1]; c[6] = q1[2]; c[7] = q1[3];
+  return c;
+}
+#define PG_MFMA(a, b, c) pg_mfma16(a, b, c)
+#else
 #define PG_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
+#endif
 
 // WMT x WNT waves of 64 x 64 patches (WMT * WNT = 8): 2 x 4 = the 128 x 256 tile, 4 x 2 = a 256 x 128 tile for products whose N
 // fills 128-wide tiles better than 256-wide ones (gic: N = 3 H = 384; the cond_transform weight gradient: N = 896). Same slot
@@ -202,6 +217,149 @@ __global__ __launch_bounds__(512, 4) void gemm_planes_kernel(GemmArgs g) {
   else gemm_epilogue_n<64 * WNT>(g, acc, m0, n0, wm, wn, l31, half, batch, split);
 }
 
+// The row-use / row-use products (cond_transform forward, gic) on v_mfma_f32_16x16x32_bf16. Same FLOP per cycle as the 32 x 32 x 16
+// shape, but the chip holds a higher clock on it under load (MI355X_MICROARCH.md, DVFS give-back item 7; timing-only build of the
+// kernel above with its MFMAs swapped: cond_transform forward 0.574 -> 0.530 ms, gic 0.295 -> 0.271 on one box). The shape wants
+// 32 k-values per instruction, a block holds 16: k-tiles are taken in PAIRS, and a ring slot holds, for one pair, ONE plane of
+// either operand: sub-slot 2 p = [A: lo blocks of k-tiles 2 p, 2 p + 1 of its 2 WMT mn tiles][B: hi blocks], sub-slot 2 p + 1 =
+// [A: hi][B: lo] (24 blocks either way: ring, DMA pieces, counted waits and the one barrier per 16 k are those of the kernel above).
+// Lane l of a fragment read (one ds_read_b128) takes row l & 15 of its 16-row tile and k-group g = l >> 4 = chunk g >> 1 of the
+// block of k-tile g & 1: the four 16-lane groups of the read then cover all 64 banks (the same k assignment on both operands, so
+// the sum is unchanged). Every fragment is read once per pair, as before, and at most three of the four fragment sets (A hi, A lo,
+// B hi, B lo: 16 VGPRs each beside the 64 accumulators) are alive at a time:
+//   phase 2 p     (A lo, B hi in registers):  acc += a_lo b_hi (16 MFMAs, 32 deep);  A hi read at once, B lo row by row into the
+//                                             registers a_lo leaves
+//   phase 2 p + 1:                            acc += a_hi b_hi, then a_hi b_lo;      the next pair's B hi read after the first product
+//                                             (into b_hi's registers), its A lo row by row into those a_hi leaves
+// Needs three products and an even number of k-tiles per split (the host falls back to the kernel above otherwise). Sums differ from
+// the 32 x 32 kernel's in the order of their fp32 additions only.
+#define PG_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
+template <bool COLP, int WMT, int WNT>
+__global__ __launch_bounds__(512, 4) void gemm_planes16_kernel(GemmArgs g) {
+  constexpr int NA = 4 * WMT;   // A blocks per sub-slot (2 WMT mn tiles x 2 k-tiles); B: 4 WNT
+  static_assert(WMT * WNT == 8 && NA + 4 * WNT == 24, "eight waves, 24 blocks per slot");
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int tm, tn, batch, split;
+  gemm_tile_of_block(g, &tm, &tn, &batch, &split);
+  const int m0 = tm * 64 * WMT, n0 = tn * 64 * WNT;
+  const int ktc = g.kchunk >> 4;
+  const int kt0 = split * ktc;
+  const int npair = max(min(g.nkt - kt0, ktc), 0) >> 1;
+  char* lds = reinterpret_cast<char*>(xsmem);
+  // LDS-DMA through buffer descriptors (one per operand panel, built from workgroup-uniform values): a piece's source is
+  // descriptor + SGPR offset + ONE per-lane VGPR (16 lane) - no 64-bit per-lane pointers in the loop
+  const char* baseA = reinterpret_cast<const char*>(g.Ap + batch * g.pstrideA) + (long)(tm * 2 * WMT) * g.nktA * 2048 + (long)kt0 * 2048;
+  const char* baseB = reinterpret_cast<const char*>(g.Bp + batch * g.pstrideB) + (long)(tn * 2 * WNT) * g.nktB * 2048 + (long)kt0 * 2048;
+  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(baseA), 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(baseB), 0, 0x7fffffff, 0x00020000);
+  const int lane16 = lane * 16;
+  // this wave's three blocks of a sub-slot; sof: the block's lo (A) / hi (B) plane in pair 0, i.e. its place in sub-slot 0;
+  // flip: what the odd sub-slots add (A: back to hi, B: on to lo)
+  int sof[3], doff[3], flip[3];
+  bool pieceB[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int j = wave * 3 + i;                       // block 0 .. 23 of the sub-slot
+    const int isB = j >= NA, jj = isB ? j - NA : j;   // (mn tile, k-tile of the pair) = (jj >> 1, jj & 1)
+    const int mt = jj >> 1;
+    sof[i] = (isB ? mt * g.nktB * 2048 : mt * g.nktA * 2048 + 1024) + (jj & 1) * 2048;
+    flip[i] = isB ? 1024 : -1024;
+    pieceB[i] = isB != 0;
+    doff[i] = j * 1024;
+  }
+  auto dma = [&](int ph, int slot) {   // sub-slot ph of the ring (past the end: the last pair's again, never used)
+    const int ko = max(min(ph >> 1, npair - 1), 0) * 4096;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(pieceB[i] ? rsB : rsA, (plds_void*)(lds + slot * QSLOT + doff[i]), 16, lane16,
+                                           sof[i] + ko + ((ph & 1) ? flip[i] : 0), 0, 0);
+  };
+  const int wm = wave / WNT, wn = wave % WNT;
+  const int g4 = lane >> 4;
+  const int fo = (g4 & 1) * 1024 + lfi_u_plane_offset(lane & 15, g4 >> 1);   // 16-row tile 1 of a block: + 512
+  // (the ring position is a compile-time constant below: every fragment read is one of two VGPR addresses + an immediate)
+  const char* ldsA = lds + (wm * 4) * 1024 + fo;
+  const char* ldsB = lds + NA * 1024 + (wn * 4) * 1024 + fo;
+  auto fragA = [&](int slot, int i) { return *reinterpret_cast<const bf16x8*>(ldsA + slot * QSLOT + (i >> 1) * 2048 + (i & 1) * 512); };
+  auto fragB = [&](int slot, int i) { return *reinterpret_cast<const bf16x8*>(ldsB + slot * QSLOT + (i >> 1) * 2048 + (i & 1) * 512); };
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  if (npair > 0) {
+    bf16x8 al[4], bh[4];
+    dma(0, 0); dma(1, 1); dma(2, 2);
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { al[i] = fragA(0, i); bh[i] = fragB(0, i); }
+    asm volatile("s_waitcnt vmcnt(3)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    // one pair; SX = ring slot of its sub-slot 2 p (2 p + 1: the next slot; the next pair's first: the one after)
+    auto pair = [&](auto SX, int p) {
+      constexpr int sx = decltype(SX)::value, sy = (sx + 1) % 3, sn = (sx + 2) % 3;
+      bf16x8 ah[4], bl[4], nal[4], nbh[4];
+      // ---- phase 2 p: a_lo b_hi
+      dma(2 * p + 3, sx);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = PG_MFMA16(al[i], bh[j], acc[i][j]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (i == 0) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) ah[q] = fragA(sy, q);
+        }
+        bl[i] = fragB(sy, i);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      asm volatile("s_waitcnt vmcnt(3)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      // ---- phase 2 p + 1: a_hi b_hi, a_hi b_lo
+      dma(2 * p + 4, sy);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = PG_MFMA16(ah[i], bh[j], acc[i][j]);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = PG_MFMA16(ah[i], bl[j], acc[i][j]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (i == 0) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) nbh[q] = fragB(sn, q);
+        }
+        nal[i] = fragA(sn, i);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      asm volatile("s_waitcnt vmcnt(3)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { al[i] = nal[i]; bh[i] = nbh[i]; }
+    };
+    for (int p = 0; p < npair; p += 3) {
+      pair(std::integral_constant<int, 0>{}, p);
+      if (p + 1 >= npair) break;
+      pair(std::integral_constant<int, 2>{}, p + 1);
+      if (p + 2 >= npair) break;
+      pair(std::integral_constant<int, 1>{}, p + 2);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __syncthreads();
+  gemm_epilogue_wide<64 * WNT, 512, 2, COLP, true, true>(g, acc, reinterpret_cast<float*>(xsmem), WNT == 4 ? 64 : 128, m0, n0, wm, wn,
+                                                         lane & 31, lane >> 5, batch, split, 64 * WMT);
+}
+
 // fp32 (rows x cols, row pitch ldx) -> bf16 hi / lo planes, zero padded to rows_pad x 16 nkt: block ((rt * nkt + kt) * 2 + plane),
 // thread l of a block converts row rt * 32 + (l & 31), columns kt * 16 + 8 (l >> 5) .. + 7 into the chunk at lfi_u_plane_offset.
 // One thread per (block pair, lane): 8 floats in (two 16-byte loads when the row allows), 16 + 16 bytes out.
@@ -231,6 +389,14 @@ __global__ __launch_bounds__(256) void planes_from_f32_kernel(const float* __res
   }
 }
 
+// the 16 x 16 x 32 kernel: both operands by rows, three products, whole pairs of k-tiles in every split, the through-LDS epilogue (LFI_PGEMM_16=0:
+// the 32 x 32 x 16 kernel everywhere)
+bool planes16_ok(const GemmArgs& a) {
+  const char* e = getenv("LFI_PGEMM_16");   // (read per call: the tests compare the two kernels)
+  if (e && e[0] == '0') return false;
+  return a.vecC && a.skip == 0 && (a.nkt & 1) == 0 && ((a.kchunk >> 4) & 1) == 0;
+}
+
 template <bool COLP, int WMT, int WNT>
 int launch_planes(const GemmArgs& a, int at, int bt, dim3 grid, size_t lds, hipStream_t st) {
   static bool attr = false;
@@ -245,7 +411,17 @@ int launch_planes(const GemmArgs& a, int at, int bt, dim3 grid, size_t lds, hipS
     }
     attr = true;
   }
-  if (!at && !bt) hipLaunchKernelGGL((gemm_planes_kernel<false, false, COLP, WMT, WNT>), grid, dim3(512), lds, st, a);
+  if (!at && !bt && planes16_ok(a)) {
+    static bool attr16 = false;
+    if (!attr16) {
+      if (hipFuncSetAttribute((const void*)gemm_planes16_kernel<COLP, WMT, WNT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+        lfi_set_error("lfi_gemm_planes: cannot reserve %zu bytes of LDS", lds);
+        return LFI_ERR_LAUNCH;
+      }
+      attr16 = true;
+    }
+    hipLaunchKernelGGL((gemm_planes16_kernel<COLP, WMT, WNT>), grid, dim3(512), lds, st, a);
+  } else if (!at && !bt) hipLaunchKernelGGL((gemm_planes_kernel<false, false, COLP, WMT, WNT>), grid, dim3(512), lds, st, a);
   else if (!at) hipLaunchKernelGGL((gemm_planes_kernel<false, true, COLP, WMT, WNT>), grid, dim3(512), lds, st, a);
   else if (!bt) hipLaunchKernelGGL((gemm_planes_kernel<true, false, COLP, WMT, WNT>), grid, dim3(512), lds, st, a);
   else hipLaunchKernelGGL((gemm_planes_kernel<true, true, COLP, WMT, WNT>), grid, dim3(512), lds, st, a);

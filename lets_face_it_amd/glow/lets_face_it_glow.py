@@ -107,9 +107,11 @@ class LetsFaceItGlow(nn.Module):
     # batch copy into the graph's input buffers, lfi_set_step_params, the replay). What differs between steps lives in device
     # memory: the dropout key and Adam's bias-corrected step size (include/lfi.h, lfi_set_step_params); the ordinary and the
     # negative-example step (loss x -0.1, lets_face_it_glow.py:40-50) are two graphs. Parameters after replayed steps are
-    # bit-identical to eager steps' (tests/test_gpu_headline_parity.py). Measured on MI355X / ROCm 7.0 (profiles/round3_*): host
-    # issue 1.5 -> 0.8-1.0 ms per step (hipGraphLaunch of ~100 nodes on two streams is not free), GPU step time level with the
-    # eager step's (7.71 vs 7.74 ms: the eager queue is already kept full by the host running ahead).
+    # bit-identical to eager steps' (tests/test_gpu_headline_parity.py). Measured on MI355X / ROCm 7.0: host issue 1.5 -> 0.7-1.0 ms
+    # per step (hipGraphLaunch of ~100 nodes on two streams is not free). GPU step time: within +-0.1 ms of the eager step's on the
+    # builder's boxes (round 4: 7.22 against 7.27 ms), but 0.7 ms (9 %) SLOWER than eager on the driver's box of round 3 (8.40
+    # against 7.71) - the eager queue is already kept full by the host running ahead, so replay has little to win and, box by
+    # box, something to lose.
     # OFF by default; bench.py reports both. Always eager: data-parallel steps (the collectives stay
     # outside any graph), injected masks, ActNorm's data-dependent init, per-kernel timing (HIP events cannot bracket a kernel
     # inside a replay).

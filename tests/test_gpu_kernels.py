@@ -245,10 +245,13 @@ def test_gemm_bf16x3_256_tile(eng, gpu_device, akc, bkc, shape, splitk, pin):
 
 @pytest.mark.parametrize("shape", [(700, 520, 330), (256, 256, 16), (513, 257, 75), (300, 260, 128), (1024, 768, 896), (40, 33, 7)])
 @pytest.mark.parametrize("epi", ["bias_leaky", "plain", "accumulate"])
-def test_gemm_on_presplit_planes(eng, gpu_device, shape, epi):
+def test_gemm_on_presplit_planes(eng, gpu_device, shape, epi, monkeypatch):
     """lfi_planes_from_f32 + lfi_gemm_planes (operands split to bf16 hi / lo ONCE, in MFMA fragment order, streamed to LDS by
     LDS-DMA through a three-slot ring) against the fp64 product and, bit for bit, against lfi_gemm_f32's 256 x 256 bf16x3
-    kernel (same split, same products, same accumulation order): ragged M / N / K, fewer k-tiles than ring slots, many tiles."""
+    kernel (same split, same products, same accumulation order): ragged M / N / K, fewer k-tiles than ring slots, many tiles.
+    With an even number of k-tiles both operands by rows take the v_mfma_f32_16x16x32_bf16 kernel (k-tiles in pairs): the same
+    products summed in another order - against fp64 and the 32 x 32 kernel to fp32 rounding, bit for bit with itself, and the
+    32 x 32 kernel (LFI_PGEMM_16=0) bit for bit against lfi_gemm_f32 as before."""
     M, N, K = shape
     g = torch.Generator().manual_seed(M + 3 * N + 7 * K)
     r4 = lambda v: (v + 3) // 4 * 4  # noqa: E731
@@ -282,6 +285,17 @@ def test_gemm_on_presplit_planes(eng, gpu_device, shape, epi):
         ref = ref + C0[:, :N].double()
     assert torch.equal(C1[:, N:], C0[:, N:]), "wrote outside the N columns"
     assert rel_err(C1[:, :N], ref) < 3e-5
+    if ((K + 15) // 16) % 2 == 0:
+        C3 = C0.clone()
+        eng.gemm_planes(M, N, K, Ap, nka, Bp, nkb, C3, ldc, bias=bias, act=act, accumulate=acc)
+        monkeypatch.setenv("LFI_PGEMM_16", "0")
+        C4 = C0.clone()
+        eng.gemm_planes(M, N, K, Ap, nka, Bp, nkb, C4, ldc, bias=bias, act=act, accumulate=acc)
+        torch.cuda.synchronize()
+        assert torch.equal(C1, C3)
+        assert not torch.equal(C1, C4), "the 16 x 16 x 32 kernel did not run"
+        assert rel_err(C1[:, :N], C4[:, :N]) < 2e-6
+        C1 = C4
     assert torch.equal(C1, C2)
 
 
