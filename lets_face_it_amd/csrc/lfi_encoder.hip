@@ -13,8 +13,28 @@
 // Backward mirrors it: per step one gate-derivative kernel and one GEMM dgh_s (F x 3hid) @ W_hh accumulated onto the
 // carried gradient.
 #include "lfi_common.h"
+#include <type_traits>
 
+// (LFI_ENC_EXP_M16: timing-only experiment, garbage results - the recurrences' MFMAs as two v_mfma_f32_16x16x32_bf16 on the same
+// registers, to see whether the chip holds a higher clock on that shape here as it does in the planes GEMMs)
+#ifdef LFI_ENC_EXP_M16
+#define ENC_MFMA(a, b, c, x, y, z) enc_mfma16_probe(a, b, c)
+#else
+#define ENC_MFMA(a, b, c, x, y, z) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, x, y, z)
+#endif
 namespace {
+#ifdef LFI_ENC_EXP_M16
+template <typename AV, typename BV>
+__device__ __forceinline__ f32x16 enc_mfma16_probe(AV a, BV b, f32x16 c) {
+  f32x4 q0 = {c[0], c[1], c[2], c[3]}, q1 = {c[4], c[5], c[6], c[7]};
+  q0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, q0, 0, 0, 0);
+  q1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, q1, 0, 0, 0);
+  c[0] = q0[0]; c[1] = q0[1]; c[2] = q0[2]; c[3] = q0[3];
+  c[4] = q1[0]; c[5] = q1[1]; c[6] = q1[2]; c[7] = q1[3];
+  return c;
+}
+#endif
+
 
 struct EncArgs {
   int B, T, N, start, hist, hid, ldcond, col, dup;
@@ -346,6 +366,28 @@ __global__ __launch_bounds__(256) void enc_frag_weights_kernel(const float* __re
   }
 }
 
+// Fragment order of v_mfma_f32_16x16x32_bf16 for the forward recurrence (enc_gru_fwd_r64_kernel<.., M16 = true>; Kp a multiple of 256):
+// element ((((m*3 + g)*nct + ct)*2 + plane)*64 + lane)*8 + e holds column j = ct*16 + (lane&15) of W_hh^T[k][g*hid + j] at
+// k = 8 enc_chunk16(m, lane>>4, Kp/8) + e: lane group q of MFMA m takes the 16-byte k-chunk 2m + (q>>1) of the first (q even) or
+// second (q odd) half of the row - the chunks of the groups that share a ds_read_b128 cycle lie 256 bytes apart in the state
+// images, whose rows (Kp + 8 bf16) advance by one 16-byte slot: all 64 banks, no conflict.
+__host__ __device__ inline int enc_chunk16(int m, int q, int nchunk) { return 2 * m + (q >> 1) + (nchunk >> 1) * (q & 1); }
+__global__ __launch_bounds__(256) void enc_frag_weights16_kernel(const float* __restrict__ whh, int hid, int Kp, int Jp, __bf16* __restrict__ dst) {
+  const int nct = Jp >> 4, nchunk = Kp >> 3;
+  const long n = 3L * Kp * Jp * 2;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < n; idx += (long)gridDim.x * 256) {
+    const int e = (int)(idx & 7), l = (int)((idx >> 3) & 63), plane = (int)((idx >> 9) & 1);
+    long q = idx >> 10;
+    const int ct = (int)(q % nct); q /= nct;
+    const int g = (int)(q % 3), m = (int)(q / 3);
+    const int k = 8 * enc_chunk16(m, l >> 4, nchunk) + e, j = ct * 16 + (l & 15);
+    float v = 0.0f;
+    if (k < hid && j < hid) v = whh[((long)g * hid + j) * hid + k];
+    const __bf16 hi = (__bf16)v;
+    dst[idx] = plane ? (__bf16)(v - (float)hi) : hi;
+  }
+}
+
 // fwd = 1: dst[(k*3 + g)*Jp + j] = whh[(g*hid + j)*hid + k] ; fwd = 0: dst[(g*Kp + k)*Jp + j] = whh[(g*hid + k)*hid + j]
 __global__ __launch_bounds__(256) void enc_pad_weights_kernel(const float* __restrict__ whh, int hid, int Kp, int Jp, int fwd,
                                                               float* __restrict__ dst) {
@@ -468,9 +510,9 @@ __global__ __launch_bounds__(ENC_NT, 2) void enc_gru_fwd_fused_kernel(EncArgs a,
         for (int g = 0; g < 3; ++g)
 #pragma unroll
           for (int t = 0; t < 2; ++t) {
-            acc[t][g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, f[t][g][0].v, acc[t][g], 0, 0, 0);
-            acc[t][g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, f[t][g][1].v, acc[t][g], 0, 0, 0);
-            acc[t][g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, f[t][g][0].v, acc[t][g], 0, 0, 0);
+            acc[t][g] = ENC_MFMA(al, f[t][g][0].v, acc[t][g], 0, 0, 0);
+            acc[t][g] = ENC_MFMA(ah, f[t][g][1].v, acc[t][g], 0, 0, 0);
+            acc[t][g] = ENC_MFMA(ah, f[t][g][0].v, acc[t][g], 0, 0, 0);
           }
       };
       // every load in the steady-state loop is unconditional: with a conditional load the compiler cannot count the loads
@@ -749,9 +791,9 @@ __global__ __launch_bounds__(ENC_NT, 2) void enc_gru_fwd_wide_kernel(EncArgs a, 
         for (int g = 0; g < 3; ++g)
 #pragma unroll
           for (int t = 0; t < 2; ++t) {
-            acc[t][g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, f[t][g][0].v, acc[t][g], 0, 0, 0);
-            acc[t][g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, f[t][g][1].v, acc[t][g], 0, 0, 0);
-            acc[t][g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, f[t][g][0].v, acc[t][g], 0, 0, 0);
+            acc[t][g] = ENC_MFMA(al, f[t][g][0].v, acc[t][g], 0, 0, 0);
+            acc[t][g] = ENC_MFMA(ah, f[t][g][1].v, acc[t][g], 0, 0, 0);
+            acc[t][g] = ENC_MFMA(ah, f[t][g][0].v, acc[t][g], 0, 0, 0);
           }
       };
       load(0, ah0, al0, f0);   // every load in the steady-state loop is unconditional (see enc_gru_fwd_fused_kernel)
@@ -903,7 +945,13 @@ __global__ __launch_bounds__(ENC_NT, 2) void enc_gru_fwd_wide_kernel(EncArgs a, 
 // arithmetic feed six MFMAs instead of three. Measured: forward 0.66 -> 0.61 ms, whole step -0.06 .. -0.08 ms on three boxes. (An
 // eight-wave variant - 64 windows x 32 hidden units per wave, two waves per SIMD - measured 0.58 - 0.67 ms by stash variant and
 // +0.05 ms on the whole step: removed.) The gate epilogue is the row-layout one of the wide kernel, run once per row tile.
-template <bool STASH, bool MASK, bool S16>
+// M16 (round 4, Kp a multiple of 256): the same products on v_mfma_f32_16x16x32_bf16 - same FLOP per cycle, but the chip holds a
+// higher clock on that shape in three-product streams (timing-only build with the MFMAs swapped: forward 0.614 -> 0.554 ms on the
+// p2_face shape; the two-product BPTT kernels gain nothing and keep the 32 x 32 shape). A wave's 64 x 64 x 3 gates are 4 x 4 x 3
+// accumulator tiles; per 32-deep MFMA step m the state fragments (4 row tiles x hi / lo, one ds_read_b128 each) are read once and
+// serve the three gates, the weight fragments of gate g (4 column tiles x hi / lo, 1 KB each from L2) are reloaded for step m + 1
+// as soon as step m's MFMAs on them have issued: three stages of 48 MFMAs in flight between a load and its use.
+template <bool STASH, bool MASK, bool S16, bool M16 = false>
 __global__ __launch_bounds__(ENC_NT, 1) void enc_gru_fwd_r64_kernel(EncArgs a, EncFused q) {
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, half = lane >> 5;
@@ -953,16 +1001,86 @@ __global__ __launch_bounds__(ENC_NT, 1) void enc_gru_fwd_r64_kernel(EncArgs a, E
   __syncthreads();
 
   for (int s = 0; s < a.hist; ++s) {
-    f32x16 acc[2][2][3];   // [row tile][column tile][gate]
+    constexpr int A32 = M16 ? 1 : 2, A16 = M16 ? 4 : 1;
+    f32x16 acc[A32][A32][3];   // [row tile][column tile][gate]
+    f32x4 acc16[A16][A16][3];  // M16: [16-row tile][16-column tile][gate]
 #pragma unroll
-    for (int rt = 0; rt < 2; ++rt)
+    for (int rt = 0; rt < A32; ++rt)
 #pragma unroll
-      for (int t = 0; t < 2; ++t)
+      for (int t = 0; t < A32; ++t)
 #pragma unroll
         for (int g = 0; g < 3; ++g)
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[rt][t][g][r] = 0.0f;
-    if (s > 0) {
+#pragma unroll
+    for (int mi = 0; mi < A16; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < A16; ++ni)
+#pragma unroll
+        for (int g = 0; g < 3; ++g) acc16[mi][ni][g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if constexpr (M16) if (s > 0) {
+      const int nct = Jp >> 4, nchunk = q.Kp >> 3;
+      const int gq = lane >> 4;
+      const __bf16* xh = Xhi + (rg * 64 + (lane & 15)) * ldx + 8 * ((gq >> 1) + (nchunk >> 1) * (gq & 1));
+      const __bf16* xl = xh + R2 * ldx;
+      ebf16x8 ahA[4], alA[4], ahB[4], alB[4];
+      EncFrag fb[3][4][2];   // [gate][column tile][plane]
+      auto loadA = [&](int m, ebf16x8 (&ah)[4], ebf16x8 (&al)[4]) {
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+          ah[mi] = *reinterpret_cast<const ebf16x8*>(xh + mi * 16 * ldx + m * 16);
+          al[mi] = *reinterpret_cast<const ebf16x8*>(xl + mi * 16 * ldx + m * 16);
+        }
+      };
+      // (buffer loads: descriptor + per-lane 16 lane + a scalar fragment offset - 192 per-lane 64-bit addresses would not fit)
+      const enc_rsrc bw = enc_buf(q.wfrag, 12L * q.Kp * Jp);
+      const unsigned lane16 = (unsigned)lane * 16u;
+      auto wload = [&](int m, int g, int ni, int plane) {
+        const unsigned so = (unsigned)((((m * 3 + g) * nct + cg * 4 + ni) * 2 + plane) * 1024);
+        return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(bw, lane16, so, 0));
+      };
+      // one stage: gate G of MFMA step m; its weight fragments are reloaded for step mn column tile by column tile
+      auto stage = [&](auto G, const ebf16x8 (&ah)[4], const ebf16x8 (&al)[4], int mn) {
+        constexpr int g = decltype(G)::value;
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+#pragma unroll
+          for (int mi = 0; mi < 4; ++mi) acc16[mi][ni][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[mi], fb[g][ni][0].v, acc16[mi][ni][g], 0, 0, 0);
+#pragma unroll
+          for (int mi = 0; mi < 4; ++mi) acc16[mi][ni][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mi], fb[g][ni][1].v, acc16[mi][ni][g], 0, 0, 0);
+#pragma unroll
+          for (int mi = 0; mi < 4; ++mi) acc16[mi][ni][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[mi], fb[g][ni][0].v, acc16[mi][ni][g], 0, 0, 0);
+          __builtin_amdgcn_sched_barrier(0);
+          fb[g][ni][0].u = wload(mn, g, ni, 0);
+          fb[g][ni][1].u = wload(mn, g, ni, 1);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      };
+      using G0 = std::integral_constant<int, 0>; using G1 = std::integral_constant<int, 1>; using G2 = std::integral_constant<int, 2>;
+#pragma unroll
+      for (int g = 0; g < 3; ++g)
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) {
+          fb[g][ni][0].u = wload(0, g, ni, 0);
+          fb[g][ni][1].u = wload(0, g, ni, 1);
+        }
+      loadA(0, ahA, alA);
+#pragma unroll
+      for (int m = 0; m < 8; m += 2) {   // (Kp = 256: eight 32-deep steps, straight-line; loads past the end re-read the last step)
+        const int m1 = m + 1, m2 = min(m + 2, 7);
+        stage(G0{}, ahA, alA, m1);
+        loadA(m1, ahB, alB);
+        __builtin_amdgcn_sched_barrier(0);
+        stage(G1{}, ahA, alA, m1);
+        stage(G2{}, ahA, alA, m1);
+        stage(G0{}, ahB, alB, m2);
+        loadA(m2, ahA, alA);
+        __builtin_amdgcn_sched_barrier(0);
+        stage(G1{}, ahB, alB, m2);
+        stage(G2{}, ahB, alB, m2);
+      }
+    }
+    if constexpr (!M16) if (s > 0) {
       const int nkt = q.Kp >> 4, nct = Jp >> 5;
       const __bf16* xh = Xhi + (rg * 64 + l31) * ldx + 8 * half;
       const __bf16* xl = Xlo + (rg * 64 + l31) * ldx + 8 * half;
@@ -990,9 +1108,9 @@ __global__ __launch_bounds__(ENC_NT, 1) void enc_gru_fwd_r64_kernel(EncArgs a, E
           for (int t = 0; t < 2; ++t)
 #pragma unroll
             for (int rt = 0; rt < 2; ++rt) {
-              acc[rt][t][g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[rt], f[t][g][0].v, acc[rt][t][g], 0, 0, 0);
-              acc[rt][t][g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[rt], f[t][g][1].v, acc[rt][t][g], 0, 0, 0);
-              acc[rt][t][g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[rt], f[t][g][0].v, acc[rt][t][g], 0, 0, 0);
+              acc[rt][t][g] = ENC_MFMA(al[rt], f[t][g][0].v, acc[rt][t][g], 0, 0, 0);
+              acc[rt][t][g] = ENC_MFMA(ah[rt], f[t][g][1].v, acc[rt][t][g], 0, 0, 0);
+              acc[rt][t][g] = ENC_MFMA(ah[rt], f[t][g][0].v, acc[rt][t][g], 0, 0, 0);
             }
       };
       load(0, ah0, al0, f0);   // every load in the steady-state loop is unconditional (see enc_gru_fwd_fused_kernel)
@@ -1029,6 +1147,7 @@ __global__ __launch_bounds__(ENC_NT, 1) void enc_gru_fwd_r64_kernel(EncArgs a, E
       float* T = Tw + rt * (32 * ENC_TP);
       float* Trow = T + rsv * ENC_TP + cv;                 // + 4 i * ENC_TP per row
       float* Tacc = T + (4 * half) * ENC_TP + l31;         // accumulator (t, r) at + ((r & 3) + 8 (r >> 2)) * ENC_TP + 32 t
+      float* Tacc16 = T + (4 * (lane >> 4)) * ENC_TP + (lane & 15);   // M16: tile (mi, ni) register r at + (16 mi + r) * ENC_TP + 16 ni
       const int rbase = rg * 64 + rt * 32;
       f32x4 hp[8], xin[8];
       unsigned xo[8], wo[8];
@@ -1044,10 +1163,19 @@ __global__ __launch_bounds__(ENC_NT, 1) void enc_gru_fwd_r64_kernel(EncArgs a, E
       }
       auto transpose = [&](int g, f32x4 (&out)[8]) {   // gate g of this tile: accumulator layout -> row layout
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // earlier reads of the tile are done
+        if constexpr (M16) {
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+          for (int mi = 0; mi < 2; ++mi)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) Tacc[((r & 3) + 8 * (r >> 2)) * ENC_TP + 32 * t] = acc[rt][t][g][r];
+            for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) Tacc16[(16 * mi + r) * ENC_TP + 16 * ni] = acc16[2 * rt + mi][ni][g][r];
+        } else {
+#pragma unroll
+          for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) Tacc[((r & 3) + 8 * (r >> 2)) * ENC_TP + 32 * t] = acc[rt][t][g][r];
+        }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
         for (int i = 0; i < 8; ++i) out[i] = *reinterpret_cast<const f32x4*>(Trow + 4 * i * ENC_TP);
@@ -1287,9 +1415,9 @@ __global__ __launch_bounds__(ENC_NT, 2) void enc_gru_bwd_fused_kernel(EncArgs a,
         auto mma = [&](const ebf16x8& ah, const ebf16x8& al, const EncFrag (&f)[2][2]) {
 #pragma unroll
           for (int t = 0; t < 2; ++t) {
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, f[t][0].v, acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, f[t][1].v, acc[t], 0, 0, 0);
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, f[t][0].v, acc[t], 0, 0, 0);
+            acc[t] = ENC_MFMA(al, f[t][0].v, acc[t], 0, 0, 0);
+            acc[t] = ENC_MFMA(ah, f[t][1].v, acc[t], 0, 0, 0);
+            acc[t] = ENC_MFMA(ah, f[t][0].v, acc[t], 0, 0, 0);
           }
         };
         load(0, ah0, al0, f0);
@@ -1550,9 +1678,9 @@ __global__ __launch_bounds__(ENC_NT, 2) void enc_gru_bwd_wide_kernel(EncArgs a, 
       auto mma = [&](const ebf16x8& ah, const ebf16x8& al, const EncFrag (&f)[2][2]) {
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
-          if (!A2) acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, f[t][0].v, acc[t], 0, 0, 0);
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, f[t][1].v, acc[t], 0, 0, 0);
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, f[t][0].v, acc[t], 0, 0, 0);
+          if (!A2) acc[t] = ENC_MFMA(al, f[t][0].v, acc[t], 0, 0, 0);
+          acc[t] = ENC_MFMA(ah, f[t][1].v, acc[t], 0, 0, 0);
+          acc[t] = ENC_MFMA(ah, f[t][0].v, acc[t], 0, 0, 0);
         }
       };
       load(0, ah0, al0, f0);
@@ -1807,9 +1935,9 @@ __global__ __launch_bounds__(ENC_NT, 1) void enc_gru_bwd_r64_kernel(EncArgs a, E
         for (int t = 0; t < 2; ++t)
 #pragma unroll
           for (int rt = 0; rt < 2; ++rt) {
-            if (!A2) acc[rt][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[rt], f[t][0].v, acc[rt][t], 0, 0, 0);
-            acc[rt][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[rt], f[t][1].v, acc[rt][t], 0, 0, 0);
-            acc[rt][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[rt], f[t][0].v, acc[rt][t], 0, 0, 0);
+            if (!A2) acc[rt][t] = ENC_MFMA(al[rt], f[t][0].v, acc[rt][t], 0, 0, 0);
+            acc[rt][t] = ENC_MFMA(ah[rt], f[t][1].v, acc[rt][t], 0, 0, 0);
+            acc[rt][t] = ENC_MFMA(ah[rt], f[t][0].v, acc[rt][t], 0, 0, 0);
           }
       };
       load(0, ah0, al0, f0);
@@ -1929,6 +2057,18 @@ int ew_blocks(long total) { return (int)(lfi_cdiv(total, 256) < 4096 ? lfi_cdiv(
 
 }  // namespace
 
+static bool enc_wide_enabled() {
+  static int wide = -1;
+  if (wide < 0) {
+    const char* e = getenv("LFI_ENC_WIDE");
+    wide = (e && e[0] == '0') ? 0 : 1;
+  }
+  return wide != 0;
+}
+static bool enc_m16_enabled() {   // the forward 64-window kernel on v_mfma_f32_16x16x32_bf16 (read at every call: tests compare)
+  const char* e = getenv("LFI_ENC_M16");
+  return !(e && e[0] == '0');
+}
 static bool enc_r64_enabled() {   // (read at every call: tests switch it inside one process)
   const char* e = getenv("LFI_ENC_R64");
   return !(e && e[0] == '0');
@@ -1989,8 +2129,20 @@ extern "C" int lfi_encode_windows_fwd(const lfi_enc_desc* d, const float* Xp, co
     LFI_REQUIRE(!gates || hseq, "lfi_encode_windows_fwd: the gate stash needs the state stash too");
     // (without a gate stash nothing is kept for a backward pass: hseq is not written either)
     const bool x3 = d->precision == 1;
-    if (x3) hipLaunchKernelGGL(enc_frag_weights_kernel, dim3(lfi_cdiv(6L * q.Kp * q.Jp, 256)), dim3(256), 0, st, whh, hid, q.Kp,
-                               q.Jp, 1, reinterpret_cast<__bf16*>(work));
+    // (decided before the weights are converted: the 64-window kernel on the 16 x 16 x 32 shape wants its own fragment order)
+    auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    const bool vec_ok = x3 && hid % 4 == 0 && d->ldcond % 4 == 0 && d->col % 4 == 0 && al16(Xp) && al16(cond) &&
+                        (!gates || (al16(gates) && al16(hseq)));
+    const int R2 = 2 * q.R;
+    const size_t lds64 = (size_t)2 * R2 * (q.Kp + 8) * sizeof(__bf16) + (size_t)ENC_NW * 2 * 32 * ENC_TP * sizeof(float) +
+                         (size_t)6 * q.Jp * sizeof(float) + (size_t)2 * R2 * sizeof(unsigned) +
+                         (mask ? (size_t)R2 * d->hist * sizeof(float) : 0);
+    const bool take64 = enc_wide_enabled() && enc_r64_enabled() && vec_ok && lds64 <= 160 * 1024 && lfi_cdiv(F, R2) >= 128;
+    const bool m16 = take64 && q.Kp == 256 && q.ncg * 64 == q.Jp && enc_m16_enabled();
+    if (x3 && m16) hipLaunchKernelGGL(enc_frag_weights16_kernel, dim3(lfi_cdiv(6L * q.Kp * q.Jp, 256)), dim3(256), 0, st, whh, hid, q.Kp,
+                                      q.Jp, reinterpret_cast<__bf16*>(work));
+    else if (x3) hipLaunchKernelGGL(enc_frag_weights_kernel, dim3(lfi_cdiv(6L * q.Kp * q.Jp, 256)), dim3(256), 0, st, whh, hid, q.Kp,
+                                    q.Jp, 1, reinterpret_cast<__bf16*>(work));
     else hipLaunchKernelGGL(enc_pad_weights_kernel, dim3(lfi_cdiv(3L * q.Kp * q.Jp, 256)), dim3(256), 0, st, whh, hid, q.Kp, q.Jp,
                             1, work);
     q.wpad = work;
@@ -2000,29 +2152,22 @@ extern "C" int lfi_encode_windows_fwd(const lfi_enc_desc* d, const float* Xp, co
     const dim3 grid(lfi_cdiv(F, q.R));
     {
       // row-layout epilogue variant (16-byte accesses): needs 4-float granular rows everywhere it vectorises
-      static int wide = -1;
-      if (wide < 0) {
-        const char* e = getenv("LFI_ENC_WIDE");
-        wide = (e && e[0] == '0') ? 0 : 1;
-      }
-      auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+      const bool wide = enc_wide_enabled();
       const size_t ldsw = (size_t)2 * q.R * (q.Kp + 8) * sizeof(__bf16) + (size_t)ENC_NW * 32 * ENC_TP * sizeof(float) +
                           (size_t)6 * q.Jp * sizeof(float) + (size_t)2 * q.R * sizeof(unsigned) +
                           (mask ? (size_t)q.R * d->hist * sizeof(float) : 0);
-      const bool vec_ok = x3 && hid % 4 == 0 && d->ldcond % 4 == 0 && d->col % 4 == 0 && al16(Xp) && al16(cond) &&
-                          (!gates || (al16(gates) && al16(hseq)));
       // two row tiles per wave, one workgroup per CU (enc_gru_fwd_r64_kernel): half the L2 -> CU weight stream per window; taken
       // when its workgroups still cover the chip (LFI_ENC_R64=0 keeps the 32-window kernel)
-      const bool r64 = enc_r64_enabled();
-      const int R2 = 2 * q.R;
-      const size_t lds64 = (size_t)2 * R2 * (q.Kp + 8) * sizeof(__bf16) + (size_t)ENC_NW * 2 * 32 * ENC_TP * sizeof(float) +
-                           (size_t)6 * q.Jp * sizeof(float) + (size_t)2 * R2 * sizeof(unsigned) +
-                           (mask ? (size_t)R2 * d->hist * sizeof(float) : 0);
-      if (wide && r64 && vec_ok && lds64 <= 160 * 1024 && lfi_cdiv(F, R2) >= 128) {
+      if (take64) {
         const dim3 grid64(lfi_cdiv(F, R2));
         rc = LFI_OK;
         switch ((gates && d->stash_f16 ? 4 : 0) | (gates ? 2 : 0) | (mask ? 1 : 0)) {
 #define LFI_ENC_FWD64(ST, MK, H)                                                                                   \
+  if (m16) {                                                                                                       \
+    rc = enc_set_lds(enc_gru_fwd_r64_kernel<ST, MK, H, true>, lds64);                                              \
+    if (!rc) hipLaunchKernelGGL((enc_gru_fwd_r64_kernel<ST, MK, H, true>), grid64, dim3(ENC_NT), lds64, st, a, q); \
+    break;                                                                                                         \
+  }                                                                                                                \
   rc = enc_set_lds(enc_gru_fwd_r64_kernel<ST, MK, H>, lds64);                                                      \
   if (!rc) hipLaunchKernelGGL((enc_gru_fwd_r64_kernel<ST, MK, H>), grid64, dim3(ENC_NT), lds64, st, a, q);        \
   break

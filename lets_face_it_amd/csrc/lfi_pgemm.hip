@@ -360,6 +360,165 @@ __global__ __launch_bounds__(512, 4) void gemm_planes16_kernel(GemmArgs g) {
                                                          lane & 31, lane >> 5, batch, split, 64 * WMT);
 }
 
+// The backward products - TWO products per k (A rounded to bf16: a_hi b_hi + a_hi b_lo), B in transposed use, A by rows (dpre, the
+// feature gradient) or transposed (the weight gradients) - on v_mfma_f32_16x16x32_bf16, with the pair / sub-slot structure of the
+// kernel above. In the 32 x 32 kernel such a product keeps a k-tile's whole overhead (barrier, eight fragment reads, three DMA
+// pieces of which A's lo blocks are dummies) for 8 MFMAs instead of 12; here a pair of k-tiles costs two phases of 16 MFMAs:
+//   sub-slot 2 p     = [A: hi blocks of the pair][B: hi blocks]     (24 blocks, three DMA pieces per wave)
+//   sub-slot 2 p + 1 = [ -                      ][B: lo blocks]     (4 WNT blocks: NY = WNT / 2 pieces per wave)
+//   phase 2 p     (A hi, B hi in registers):  acc += a_hi b_hi;  B lo read row by row under it
+//   phase 2 p + 1:                            acc += a_hi b_lo;  the next pair's B hi read at once (b_hi's registers), its A hi row by
+//                                             row into those a_hi leaves
+// Transposed use of a pair: the pair IS one 32-row block of the buffer (k = its rows), an mn tile of 32 = its column tiles 2 mt,
+// 2 mt + 1 = two 16-mn fragments. The LDS-DMA copies a block with rows 16-19 <-> 20-23 and 24-27 <-> 28-31 trading places (per-lane
+// source address); lane 16 g + 4 q + p of ds_read_b64_tr_b16 addresses k row 16 (g & 1) + 8 (g >> 1) + q (then + 4), columns 4 p .. + 3:
+// the same k assignment as the row-use read (k-tile g & 1, chunk g >> 1), and the two 16-lane groups of a 32-lane half land in
+// opposite halves of the 256-byte bank row.
+template <bool AT, bool COLP, int WMT, int WNT>
+__global__ __launch_bounds__(512, 4) void gemm_planes16t_kernel(GemmArgs g) {
+  constexpr int NA = 4 * WMT, NY = WNT / 2;   // A blocks per sub-slot; DMA pieces per wave of the lo sub-slot (its 4 WNT B blocks)
+  static_assert(WMT * WNT == 8 && NA + 4 * WNT == 24, "eight waves, 24 blocks per slot");
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int tm, tn, batch, split;
+  gemm_tile_of_block(g, &tm, &tn, &batch, &split);
+  const int m0 = tm * 64 * WMT, n0 = tn * 64 * WNT;
+  const int ktc = g.kchunk >> 4;
+  const int kt0 = split * ktc;
+  const int npair = max(min(g.nkt - kt0, ktc), 0) >> 1;
+  char* lds = reinterpret_cast<char*>(xsmem);
+  const long rowA = (long)g.nktA * 2048, rowB = (long)g.nktB * 2048;   // bytes per row tile of either plane buffer
+  // panel bases at this split's first pair. Row use: + 4096 per pair (k-tiles are column tiles); transposed: + a row tile per pair
+  // (64-bit: folded into the descriptor's base, pair by pair)
+  const char* baseA = reinterpret_cast<const char*>(g.Ap + batch * g.pstrideA) +
+                      (AT ? (long)(tm * 2 * WMT) * 4096 + (long)(kt0 >> 1) * rowA : (long)(tm * 2 * WMT) * rowA + (long)kt0 * 2048);
+  const char* baseB = reinterpret_cast<const char*>(g.Bp + batch * g.pstrideB) + (long)(tn * 2 * WNT) * 4096 + (long)(kt0 >> 1) * rowB;
+  // per-lane source offset inside a block: as it lies (row use), or with the row swap of the header (transposed use)
+  const int prow = lane >> 1, srow = prow ^ ((prow & 16) ? 4 : 0);
+  const int laneR = lane * 16, laneT = srow * 32 + (lane & 1) * 16;
+  // this wave's pieces: piece i = block 8 i + wave, so that which operand a piece belongs to is a compile-time fact. Sub-slot 2 p:
+  // [A (NA)][B hi (4 WNT)]; sub-slot 2 p + 1: B lo, NY pieces, in B's place
+  int sofX[3], doffX[3], sofY[2], doffY[2];   // (NY <= 2 used; a template-dependent bound here breaks the host pass of this hipcc)
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int j = 8 * i + wave;
+    const bool isB = 8 * i >= NA;
+    const int jj = isB ? j - NA : j;   // (mn tile, half) = (jj >> 1, jj & 1): half = k-tile of the pair (row use) / column tile (transposed)
+    const int mt = jj >> 1, h = jj & 1;
+    sofX[i] = (isB || AT) ? mt * 4096 + h * 2048 : mt * (int)rowA + h * 2048;
+    doffX[i] = j * 1024;
+  }
+#pragma unroll
+  for (int i = 0; i < NY; ++i) {
+    const int jj = 8 * i + wave;                      // block 0 .. 4 WNT - 1 of B
+    sofY[i] = (jj >> 1) * 4096 + (jj & 1) * 2048 + 1024;
+    doffY[i] = (NA + jj) * 1024;
+  }
+  // (descriptors are built at the call: base + the pair's offset, all wave-uniform)
+#define PG_RSRC(ptr) __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(ptr), 0, 0x7fffffff, 0x00020000)
+  auto dmaX = [&](int pair, int slot) {   // (past the end: the last pair again, never used)
+    const int pp = max(min(pair, npair - 1), 0);
+    const char* pa = baseA + (AT ? pp * rowA : (long)pp * 4096);
+    const char* pb = baseB + pp * rowB;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const bool isB = 8 * i >= NA;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(PG_RSRC(isB ? pb : pa), (plds_void*)(lds + slot * QSLOT + doffX[i]), 16, (isB || AT) ? laneT : laneR,
+                                               sofX[i], 0, 0);
+    }
+  };
+  auto dmaY = [&](int pair, int slot) {
+    const int pp = max(min(pair, npair - 1), 0);
+    const char* pb = baseB + pp * rowB;
+#pragma unroll
+    for (int i = 0; i < NY; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(PG_RSRC(pb), (plds_void*)(lds + slot * QSLOT + doffY[i]), 16, laneT, sofY[i], 0, 0);
+  };
+#undef PG_RSRC
+  const int wm = wave / WNT, wn = wave % WNT;
+  const int g4 = lane >> 4, tq = (lane >> 2) & 3, tp = lane & 3;
+  // row use: one ds_read_b128 (16-row tile 1 of a block pair: + 512). Transposed use: two ds_read_b64_tr_b16 on ONE block (16 mn
+  // columns x the pair's 32 k rows), the second at toff ^ 128 (k rows + 4)
+  const int fo = (g4 & 1) * 1024 + lfi_u_plane_offset(lane & 15, g4 >> 1);
+  const int kr = 16 * (g4 & 1) + 8 * (g4 >> 1) + tq;
+  const int toff = (kr ^ ((kr & 16) ? 4 : 0)) * 32 + (((tp >> 1) ^ ((kr >> 3) & 1)) << 4) + (tp & 1) * 8;
+  const char* ldsA = lds + (wm * 4) * 1024;
+  const char* ldsB = lds + NA * 1024 + (wn * 4) * 1024;
+  auto fragA = [&](int slot, int i) -> bf16x8 {
+    if constexpr (AT) return pg_frag<true>(ldsA + slot * QSLOT + i * 1024, 0, toff);
+    else return *reinterpret_cast<const bf16x8*>(ldsA + slot * QSLOT + (i >> 1) * 2048 + (i & 1) * 512 + fo);
+  };
+  auto fragB = [&](int slot, int i) -> bf16x8 { return pg_frag<true>(ldsB + slot * QSLOT + i * 1024, 0, toff); };
+
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  if (npair > 0) {
+    bf16x8 ah[4], bh[4];
+    dmaX(0, 0); dmaY(0, 1); dmaX(1, 2);
+    if (NY == 2) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { ah[i] = fragA(0, i); bh[i] = fragB(0, i); }
+    asm volatile("s_waitcnt vmcnt(3)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+
+    // one pair; SX = ring slot of its sub-slot 2 p (2 p + 1: the next slot; the next pair's first: the one after)
+    auto pair = [&](auto SX, int p) {
+      constexpr int sx = decltype(SX)::value, sy = (sx + 1) % 3, sn = (sx + 2) % 3;
+      bf16x8 bl[4], nah[4], nbh[4];
+      // ---- phase 2 p: a_hi b_hi
+      dmaY(p + 1, sx);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = PG_MFMA16(ah[i], bh[j], acc[i][j]);
+        __builtin_amdgcn_sched_barrier(0);
+        bl[i] = fragB(sy, i);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (NY == 2) asm volatile("s_waitcnt vmcnt(2)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(1)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      // ---- phase 2 p + 1: a_hi b_lo
+      dmaX(p + 2, sy);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = PG_MFMA16(ah[i], bl[j], acc[i][j]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (i == 0) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) nbh[q] = fragB(sn, q);
+        }
+        nah[i] = fragA(sn, i);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      asm volatile("s_waitcnt vmcnt(3)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+#pragma unroll
+      for (int i = 0; i < 4; ++i) { ah[i] = nah[i]; bh[i] = nbh[i]; }
+    };
+    for (int p = 0; p < npair; p += 3) {
+      pair(std::integral_constant<int, 0>{}, p);
+      if (p + 1 >= npair) break;
+      pair(std::integral_constant<int, 2>{}, p + 1);
+      if (p + 2 >= npair) break;
+      pair(std::integral_constant<int, 1>{}, p + 2);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  }
+  __syncthreads();
+  gemm_epilogue_wide<64 * WNT, 512, 2, COLP, true, true>(g, acc, reinterpret_cast<float*>(xsmem), WNT == 4 ? 64 : 128, m0, n0, wm, wn,
+                                                         lane & 31, lane >> 5, batch, split, 64 * WMT);
+}
+
 // fp32 (rows x cols, row pitch ldx) -> bf16 hi / lo planes, zero padded to rows_pad x 16 nkt: block ((rt * nkt + kt) * 2 + plane),
 // thread l of a block converts row rt * 32 + (l & 31), columns kt * 16 + 8 (l >> 5) .. + 7 into the chunk at lfi_u_plane_offset.
 // One thread per (block pair, lane): 8 floats in (two 16-byte loads when the row allows), 16 + 16 bytes out.
@@ -397,6 +556,13 @@ bool planes16_ok(const GemmArgs& a) {
   return a.vecC && a.skip == 0 && (a.nkt & 1) == 0 && ((a.kchunk >> 4) & 1) == 0;
 }
 
+// the two-product 16 x 16 x 32 kernel: B transposed, A either way, skip bit 0 alone (LFI_PGEMM_16T=0: the 32 x 32 x 16 kernel)
+bool planes16t_ok(const GemmArgs& a) {
+  const char* e = getenv("LFI_PGEMM_16T");
+  if (e && e[0] == '0') return false;
+  return a.vecC && a.skip == 1 && (a.nkt & 1) == 0 && ((a.kchunk >> 4) & 1) == 0;
+}
+
 template <bool COLP, int WMT, int WNT>
 int launch_planes(const GemmArgs& a, int at, int bt, dim3 grid, size_t lds, hipStream_t st) {
   static bool attr = false;
@@ -411,7 +577,20 @@ int launch_planes(const GemmArgs& a, int at, int bt, dim3 grid, size_t lds, hipS
     }
     attr = true;
   }
-  if (!at && !bt && planes16_ok(a)) {
+  if (bt && planes16t_ok(a)) {
+    static bool attr16t = false;
+    if (!attr16t) {
+      hipError_t e1 = hipFuncSetAttribute((const void*)gemm_planes16t_kernel<false, COLP, WMT, WNT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      hipError_t e2 = hipFuncSetAttribute((const void*)gemm_planes16t_kernel<true, COLP, WMT, WNT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e1 != hipSuccess || e2 != hipSuccess) {
+        lfi_set_error("lfi_gemm_planes: cannot reserve %zu bytes of LDS", lds);
+        return LFI_ERR_LAUNCH;
+      }
+      attr16t = true;
+    }
+    if (at) hipLaunchKernelGGL((gemm_planes16t_kernel<true, COLP, WMT, WNT>), grid, dim3(512), lds, st, a);
+    else hipLaunchKernelGGL((gemm_planes16t_kernel<false, COLP, WMT, WNT>), grid, dim3(512), lds, st, a);
+  } else if (!at && !bt && planes16_ok(a)) {
     static bool attr16 = false;
     if (!attr16) {
       if (hipFuncSetAttribute((const void*)gemm_planes16_kernel<COLP, WMT, WNT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
@@ -508,7 +687,12 @@ extern "C" int lfi_gemm_planes(const lfi_pgemm_desc* d, void* stream) {
   a.strideC = d->strideC; a.strideBias = d->strideBias; a.strideG = d->strideG;
   a.accumulate = d->accumulate; a.act = d->act; a.slope = d->slope;
   a.splitk = splitk;
-  a.kchunk = splitk > 1 ? lfi_cdiv(nkt, splitk) * 16 : nkt * 16;
+  {
+    // K split in whole PAIRS of k-tiles where K allows it (the 16 x 16 x 32 kernels take k-tiles two at a time)
+    int ktc = splitk > 1 ? lfi_cdiv(nkt, splitk) : nkt;
+    if (splitk > 1 && (nkt & 1) == 0 && (ktc & 1) && (long)(splitk - 1) * (ktc + 1) < nkt) ++ktc;
+    a.kchunk = ktc * 16;
+  }
   a.work = d->work;
   a.Ap = reinterpret_cast<const __bf16*>(d->Ap); a.Bp = reinterpret_cast<const __bf16*>(d->Bp);
   a.nkt = nkt; a.nktA = (int)d->a_nkt; a.nktB = (int)d->b_nkt; a.pstrideA = d->a_stride; a.pstrideB = d->b_stride;

@@ -368,35 +368,90 @@ def test_gemm_planes_kmajor_operands_and_split_k(eng, gpu_device, shape, fmt, sp
         assert torch.equal(C1, C2)
 
 
-@pytest.mark.parametrize("fmt", ["RR", "TT"])
-def test_gemm_planes_two_products_never_touch_a_lo(eng, gpu_device, fmt):
+@pytest.mark.parametrize("fmt", ["RR", "TT", "RT"])
+@pytest.mark.parametrize("k16", ["1", "0"])
+def test_gemm_planes_two_products_never_touch_a_lo(eng, gpu_device, monkeypatch, fmt, k16):
     """Skip bit 0 (two products per k-step, A rounded to bf16): A's lo planes are neither fetched nor read - poisoned with NaN
-    they leave the result unchanged - and the result equals lfi_gemm_f32's two-product kernel bit for bit. That is what lets the
-    producers of A (the backward walk's dgi, the dpre product) write hi planes only (lfi_pgemm_desc.out_hi_only)."""
+    they leave the result unchanged - and the result equals lfi_gemm_f32's two-product kernel bit for bit (the 32 x 32 x 16 kernel;
+    with B in transposed use the default is the 16 x 16 x 32 kernel, k-tiles in pairs: the same products in another summation order,
+    equal to fp32 rounding). That is what lets the producers of A (the backward walk's dgi, the dpre product) write hi planes only
+    (lfi_pgemm_desc.out_hi_only)."""
+    monkeypatch.setenv("LFI_PGEMM_16T", k16)
     M, N, K = 384, 512, 2048
     g = torch.Generator().manual_seed(1)
-    at = fmt[0] == "T"
+    at, bt = fmt[0] == "T", fmt[1] == "T"
     A = torch.randn((K, M) if at else (M, K), generator=g).to(gpu_device)
-    Bm = torch.randn((K, N) if at else (N, K), generator=g).to(gpu_device)
+    Bm = torch.randn((K, N) if bt else (N, K), generator=g).to(gpu_device)
     Ap, nka = eng.planes("test.pa", A, M, K, M) if at else eng.planes("test.pa", A, K, M, K)
-    Bp, nkb = eng.planes("test.pb", Bm, N, K, N) if at else eng.planes("test.pb", Bm, K, N, K)
+    Bp, nkb = eng.planes("test.pb", Bm, N, K, N) if bt else eng.planes("test.pb", Bm, K, N, K)
     eng.pass_skip = {"t": 1}
     try:
         C1 = torch.zeros(M, N, device=gpu_device)
-        eng.gemm_planes(M, N, K, Ap, nka, Bp, nkb, C1, N, a_fmt=int(at), b_fmt=int(at), cls="t")
+        eng.gemm_planes(M, N, K, Ap, nka, Bp, nkb, C1, N, a_fmt=int(at), b_fmt=int(bt), cls="t")
         Ap.view(-1, 2, 512)[:, 1] = float("nan")          # every lo block of A
         C2 = torch.zeros(M, N, device=gpu_device)
-        eng.gemm_planes(M, N, K, Ap, nka, Bp, nkb, C2, N, a_fmt=int(at), b_fmt=int(at), cls="t")
+        eng.gemm_planes(M, N, K, Ap, nka, Bp, nkb, C2, N, a_fmt=int(at), b_fmt=int(bt), cls="t")
         C3 = torch.zeros(M, N, device=gpu_device)
         eng.precision = 0x11
-        eng.gemm(M, N, K, A, M if at else K, 0 if at else 1, Bm, N if at else K, 0 if at else 1, C3, N, cls="t")
+        eng.gemm(M, N, K, A, M if at else K, 0 if at else 1, Bm, N if bt else K, 0 if bt else 1, C3, N, cls="t")
     finally:
         eng.precision = 0
         eng.pass_skip = {}
     torch.cuda.synchronize()
-    assert torch.isfinite(C2).all() and torch.equal(C1, C2) and torch.equal(C1, C3)
-    ref = (A.t() if at else A).double() @ (Bm if at else Bm.t()).double()
+    assert torch.isfinite(C2).all() and torch.equal(C1, C2)
+    if bt and k16 == "1":
+        assert not torch.equal(C1, C3), "the 16 x 16 x 32 kernel did not run"
+        assert rel_err(C1, C3) < 2e-6
+    else:
+        assert torch.equal(C1, C3)
+    ref = (A.t() if at else A).double() @ (Bm if bt else Bm.t()).double()
     assert 1e-5 < rel_err(C1, ref) < 3e-3       # a rounded operand: 2^-9 per element, averaged over K
+
+
+@pytest.mark.parametrize("shape", [(700, 520, 352), (384, 512, 14336), (513, 257, 96), (130, 40, 32), (1024, 896, 2048)])
+@pytest.mark.parametrize("fmt", ["RT", "TT"])
+@pytest.mark.parametrize("splitk,tile", [(1, 1), (3, 1), (1, 2), (2, 2)])
+def test_gemm_planes_two_products_on_16x16x32(eng, gpu_device, monkeypatch, shape, fmt, splitk, tile):
+    """The backward products' kernel (two products, B in transposed use, A by rows or transposed, v_mfma_f32_16x16x32_bf16 on pairs
+    of k-tiles, one plane per ring slot): ragged M / N, K down to one pair, split K (whole pairs per split or the 32 x 32 kernel),
+    both tile shapes - against the 32 x 32 x 16 kernel (LFI_PGEMM_16T=0) to fp32 rounding, against the fp64 product of the ROUNDED A,
+    bit for bit with itself, bias + LeakyReLU epilogue, nothing written outside the N columns."""
+    M, N, K = shape
+    g = torch.Generator().manual_seed(M + 3 * N + 7 * K)
+    r4 = lambda v: (v + 3) // 4 * 4  # noqa: E731
+    at = fmt[0] == "T"
+    lda, ldb = (r4(M) + 4 if at else r4(K) + 4), r4(N)
+    A = torch.zeros((K, lda) if at else (M, lda))
+    Bm = torch.zeros((K, ldb))
+    if at:
+        A[:, :M] = torch.randn(K, M, generator=g)
+    else:
+        A[:, :K] = torch.randn(M, K, generator=g)
+    Bm[:, :N] = torch.randn(K, N, generator=g)
+    A, Bm = A.to(gpu_device), Bm.to(gpu_device)
+    ldc = r4(N) + 4
+    bias = torch.randn(N, generator=g).to(gpu_device)
+    Ap, nka = eng.planes("test.pa", A, lda, K, M) if at else eng.planes("test.pa", A, lda, M, K)
+    Bp, nkb = eng.planes("test.pb", Bm, ldb, K, N)
+    outs = []
+    eng.pass_skip = {"t": 1}
+    try:
+        for k16 in ("1", "1", "0"):
+            monkeypatch.setenv("LFI_PGEMM_16T", k16)
+            Cm = torch.full((M, ldc), 7.0, device=gpu_device)
+            eng.gemm_planes(M, N, K, Ap, nka, Bp, nkb, Cm, ldc, bias=bias, act=1, a_fmt=int(at), b_fmt=1, splitk=splitk, tile=tile,
+                            cls="t")
+            outs.append(Cm)
+    finally:
+        eng.pass_skip = {}
+    torch.cuda.synchronize()
+    C1, C1b, C0 = outs
+    Ad = (A[:, :M].t() if at else A[:, :K]).bfloat16().double()          # the A operand as the kernel sees it
+    ref = torch.nn.functional.leaky_relu(Ad @ Bm[:, :N].double() + bias.double(), 0.01)
+    assert bool((C1[:, N:] == 7.0).all()), "wrote outside the N columns"
+    assert torch.equal(C1, C1b)
+    assert rel_err(C1[:, :N], ref) < 3e-5
+    assert rel_err(C1[:, :N], C0[:, :N]) < 2e-6
 
 
 @pytest.mark.parametrize("M,N,K,batch", [(700, 512, 96, 1), (14336 // 8, 128, 384, 4), (333, 96, 64, 2)])
@@ -650,7 +705,9 @@ def test_window_encoder_tilings_match(gpu_device, monkeypatch, mod, two, s16):
     outs = {}
     rows_per_wg = {"r64": 2 * 32 * (4 // ((hid + 63) // 64)), "wide": 32 * (4 // ((hid + 63) // 64))}
     groups = {"r64": 4 // ((hid + 63) // 64), "wide": 4 // ((hid + 63) // 64)}
-    for name, env in (("r64", {"LFI_ENC_R64": "1"}), ("wide", {"LFI_ENC_R64": "0"})):
+    rows_per_wg["r64m16"], groups["r64m16"] = rows_per_wg["r64"], groups["r64"]
+    for name, env in (("r64", {"LFI_ENC_R64": "1", "LFI_ENC_M16": "0"}), ("r64m16", {"LFI_ENC_R64": "1", "LFI_ENC_M16": "1"}),
+                      ("wide", {"LFI_ENC_R64": "0"})):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
         cond = torch.zeros(F, ldc, device=dev)
@@ -679,3 +736,20 @@ def test_window_encoder_tilings_match(gpu_device, monkeypatch, mod, two, s16):
             assert torch.equal(a[i], b[i]), (name, what)
         for i in (5, 6):
             assert float((a[i] - b[i]).abs().max()) <= 2e-5 * max(1.0, float(b[i].abs().max())), name
+    # the forward 64-window kernel on v_mfma_f32_16x16x32_bf16 (hid a multiple of 256): the same three products per k, summed in
+    # another order - fp32 rounding on the state, one fp16 / bf16 rounding step on what is stashed in those types
+    a = outs["r64m16"]
+    if hid % 256 == 0 and -(-F // rows_per_wg["r64"]) >= 128:
+        assert not torch.equal(a[0], b[0]), "the 16 x 16 x 32 kernel did not run"
+    n_g, n_dgi, n_dgh = hist * F * 4 * hid, hist * F * hid, hist * F * 3 * hid
+    views = [(a[0], b[0], 5e-6), (a[2], b[2], 5e-6)]
+    views.append((a[1].view(torch.float16)[:n_g].float(), b[1].view(torch.float16)[:n_g].float(), 2e-3) if s16 else (a[1], b[1], 5e-6))
+    if two:
+        views += [(a[3].view(torch.bfloat16)[:n_dgi].float(), b[3].view(torch.bfloat16)[:n_dgi].float(), 1e-2),
+                  (a[4].view(torch.bfloat16)[:n_dgh].float(), b[4].view(torch.bfloat16)[:n_dgh].float(), 1e-2)]
+    else:
+        views += [(a[3], b[3], 1e-4), (a[4], b[4], 1e-4)]
+    for x, y, tol in views:
+        assert float((x - y).abs().max()) <= tol * max(1.0, float(y.abs().max())), tol
+    for i in (5, 6):
+        assert float((a[i] - b[i]).abs().max()) <= 1e-3 * max(1.0, float(b[i].abs().max()))

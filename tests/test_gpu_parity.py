@@ -471,8 +471,10 @@ def test_full_size_properties(gpu_device):
         _, loss_p, losses_p = m({k: v[perm].contiguous() for k, v in batch.items()})
         assert torch.equal(torch.stack(losses_p), nll[:, perm.cpu()])
         # (3) a sub-batch reproduces its rows (no cross-sample coupling, tiles of 16 vs ragged 40)
+        # (2 240 windows take the 32-window encoder kernels on the 32 x 32 x 16 MFMA, 14 336 the 64-window ones on 16 x 16 x 32: the same
+        # products summed in another order, so this comparison is to fp32 rounding; cross-sample coupling would show as O(1))
         _, _, losses_s = m({k: v[:40].contiguous() for k, v in batch.items()})
-        assert torch.equal(torch.stack(losses_s), nll[:, :40])
+        assert max_rel(torch.stack(losses_s), nll[:, :40], floor=1.0) < 1e-5
 
 
 def test_config4_deep_flow_properties(gpu_device):
@@ -493,14 +495,16 @@ def test_config4_deep_flow_properties(gpu_device):
         assert nll.shape == (T - 24, B) and torch.isfinite(nll).all()
         short = {k: v[:, :24 + 40].contiguous() for k, v in batch.items()}   # invert walks (n, k) cell by cell: keep it short
         z_short, loss_s, _ = m(short)
-        assert torch.equal(torch.stack(z_short), torch.stack(z_seq[:40]))    # causal: a prefix reproduces its timesteps
+        # causal: a prefix reproduces its timesteps - to fp32 rounding: its 5 120 windows take the 32-window encoder kernels
+        # (32 x 32 x 16 MFMA), the full sequence's 62 464 the 64-window ones (16 x 16 x 32: the same products, another summation order)
+        assert rel_err(torch.stack(z_short), torch.stack(z_seq[:40])) < 1e-5
         rec, bl = m.invert(z_short, short)
         # 96 chained fp32 inverses (W^-1 is the fp64 inverse cast to fp32, modules.py:175-177): 7e-4 measured; K=16: 2e-4
         assert rel_err(torch.stack(rec), short["p1_face"][:, 24:].transpose(0, 1)) < 3e-3
         logp = (-0.5 * (torch.stack(z_short) ** 2 + oracle.LOG2PI)).sum(-1)
         assert rel_err(bl + loss_s, -2.0 * logp.mean().reshape(1) / oracle.LN2) < 1e-4
         _, _, losses_s = m({k: v[:24].contiguous() for k, v in batch.items()})
-        assert torch.equal(torch.stack(losses_s), nll[:, :24])
+        assert max_rel(torch.stack(losses_s), nll[:, :24], floor=1.0) < 1e-5     # (same kernels as the full batch here: 11 712 windows)
 
     def grads(b):
         m.zero_grad(set_to_none=True)
@@ -539,8 +543,13 @@ def test_config3_sampling_full_size(gpu_device):
     out3 = m.inference(T, data, noise=noise)   # replayed
     assert out1.shape == (B, T - 24, 50) and torch.isfinite(out1).all()
     assert torch.equal(out1, out2) and torch.equal(out1, out3)
+    # a sub-batch reproduces its rows: to what 276 autoregressive frames make of an fp32 rounding difference in the window encoders
+    # (the sampler encodes its windows in four frame runs: 48 x 69 = 3 312 windows a run take the 32-window kernels on the 32 x 32 x 16
+    # MFMA, the full batch's 70 656 the 64-window ones on 16 x 16 x 32 - the same products, another summation order)
     sub = m.inference(T, {k: v[:48].contiguous() for k, v in data.items()}, noise=noise[:, :48].contiguous())
-    assert torch.equal(sub, out1[:48])
+    sub_err = float((sub - out1[:48]).abs().max() / out1[:48].abs().max().clamp(min=1.0))
+    report("config[3] sub-batch of 48 against its rows of the batch of 1024: max abs difference %.3e of the largest value" % sub_err)
+    assert sub_err < 1e-3
     full = dict(data)
     full["p1_face"] = torch.cat([data["p1_face"][:, :24], out1], dim=1).contiguous()
     with torch.no_grad():
