@@ -303,8 +303,11 @@ def _roofline(spec, F, timing, precision):
     if precision == "bf16x3" and os.environ.get("LFI_PGEMM", "1") != "0":
         # the product runs on pre-split operand planes (lfi_gemm_planes, lfi_pgemm.hip): 128 x 256 tiles, 512 threads, two
         # workgroups per CU; both operands as row planes, no column-sum epilogue
+        # (v_mfma_f32_16x16x32_bf16 on pairs of k-tiles when K has an even number of them - final_model.yaml: 56 - else the
+        # 32 x 32 x 16 kernel; LFI_PGEMM_16=0 pins the latter)
         peak, mult = BF16_MFMA_PEAK_TFLOPS, 3.0
-        kern = "gemm_planes_kernel<false, false, false, 2, 4>"
+        pairs = ((spec.ldf + 15) // 16) % 2 == 0 and os.environ.get("LFI_PGEMM_16", "1") != "0"
+        kern = "gemm_planes16_kernel<false, 2, 4>" if pairs else "gemm_planes_kernel<false, false, false, 2, 4>"
         tile, threads = 128, 512
         tile_n = 256
     elif precision == "bf16x3":

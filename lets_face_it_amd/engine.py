@@ -121,7 +121,9 @@ class ModelSpec:
             self.unfold += [fcol + (j % e.fdim) for j in range(e.dim)]
             fcol += e.fdim
         self.Ef = fcol
-        self.ldf = (fcol + 15) // 16 * 16  # row stride of the folded feature matrix / weights (16-float aligned)
+        # row stride of the folded feature matrix / weights: whole PAIRS of 16-column k-tiles (the planes products on
+        # v_mfma_f32_16x16x32_bf16 take k-tiles two at a time; the padding columns are zeros)
+        self.ldf = (fcol + 31) // 32 * 32
 
     @classmethod
     def flow_only(cls, C, H, D, Ks, E, affine, rnn_type, lu, scale_eps, actnorm_scale):
@@ -139,7 +141,7 @@ class ModelSpec:
         s.I = s.Ch + s.D
         s.fold_a, s.fold_b, s.unfold = list(range(s.E)), [-1] * s.E, list(range(s.E))
         s.Ef = s.E
-        s.ldf = (s.E + 15) // 16 * 16
+        s.ldf = (s.E + 31) // 32 * 32
         return s
 
     def flow_shapes(self):
