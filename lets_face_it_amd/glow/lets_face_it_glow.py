@@ -109,7 +109,7 @@ class LetsFaceItGlow(nn.Module):
     # negative-example step (loss x -0.1, lets_face_it_glow.py:40-50) are two graphs. Parameters after replayed steps are
     # bit-identical to eager steps' (tests/test_gpu_headline_parity.py). Measured on MI355X / ROCm 7.0: host issue 1.5 -> 0.7-1.0 ms
     # per step (hipGraphLaunch of ~100 nodes on two streams is not free). GPU step time: within +-0.1 ms of the eager step's on the
-    # builder's boxes (round 4: 7.22 against 7.27 ms), but 0.7 ms (9 %) SLOWER than eager on the driver's box of round 3 (8.40
+    # builder's boxes (round 4: 6.89 against 6.95 ms), but 0.7 ms (9 %) SLOWER than eager on the driver's box of round 3 (8.40
     # against 7.71) - the eager queue is already kept full by the host running ahead, so replay has little to win and, box by
     # box, something to lose.
     # OFF by default; bench.py reports both. Always eager: data-parallel steps (the collectives stay
