@@ -31,6 +31,15 @@ extern unsigned long long* g_lfi_stamps;  // diagnostics only (lfi_debug_set_sta
 
 static inline int lfi_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+// ---- internal (not part of the C ABI): the sampler's fused per-frame conditioning (lfi_sample.hip), called by lfi_flow.hip
+extern "C" __attribute__((visibility("hidden"))) int lfi_internal_sample_cond_ok(int D, int G, int K1);
+extern "C" __attribute__((visibility("hidden"))) long lfi_internal_sample_cond_bytes(int B, int Ks, int G, int K1);
+extern "C" __attribute__((visibility("hidden"))) int lfi_internal_sample_cond_prepare(const float* wct, long ldw, int col0, int K1, const float* wc,
+                                                                                      int Ks, int G, void* frags, void* stream);
+extern "C" __attribute__((visibility("hidden"))) int lfi_internal_sample_cond(const float* faces, long ld_faces, long off, int K1, int B, int Ks, int G,
+                                                                              const float* pre, const float* b_ih, void* frags, float* gic,
+                                                                              float slope, void* stream);
+
 // ---- device side -----------------------------------------------------------
 // Operand planes (lfi_planes_from_f32, lfi_pgemm.hip): byte offset inside a 1-KB block (32 rows x 16 columns, bf16, row-major
 // 32-byte rows) of the 16-byte chunk ch (columns 8 ch .. + 7) of row r. The two chunks of a row trade places in rows 8-15 and

@@ -3662,7 +3662,8 @@ extern "C" long lfi_flow_sample_work_floats(const lfi_flow_dims* d) {
   const long tiles = (d->B + MB - 1) / MB;
   return (long)d->B * d->Ks * d->D + (long)d->Ks * d->B * G + 2L * d->B * d->C + 16
          + (((long)PIPE_HDR + d->Ks * tiles + 3) & ~3L) + 4    // + the hand-off words of the per-frame reverse chain
-         + (long)d->B * 64 * ((d->C + 3) & ~3) + 4;            // + the aligned copy of the raw prev_p1_face window (hist1 <= 64)
+         + (long)d->B * 64 * ((d->C + 3) & ~3) + 4             // + the aligned copy of the raw prev_p1_face window (hist1 <= 64)
+         + lfi_internal_sample_cond_bytes(d->B, d->Ks, G, 512) / 4 + 64;   // + the fused conditioning's fragments (window <= 512 floats)
 }
 
 extern "C" int lfi_flow_sample_seq(const lfi_flow_dims* d, const lfi_flow_params* p, const float* prep, const float* wct,
@@ -3717,6 +3718,15 @@ extern "C" int lfi_flow_sample_seq_from(const lfi_flow_dims* d, const lfi_flow_p
   float* wstage = reinterpret_cast<float*>(chain_state + chain_words);
   const int ldw = (hist1 * C + 3) & ~3;
   const bool stage_win = p1kind == 0 && hist1 <= 64;
+  // raw window + fp16 pieces (precision 9) + final widths: cond_transform's window part and the coupling cell's input projection
+  // as ONE launch per frame, c never written (lfi_sample.hip); the weights' fragments are made here, once per call
+  const int K1 = hist1 * C;
+  const bool fused = stage_win && (d->gemm_precision & 0xff) == 9 && lfi_internal_sample_cond_ok(D, G, K1) &&
+                     (reinterpret_cast<uintptr_t>(pre_static) & 15) == 0;
+  void* cfrags = reinterpret_cast<void*>((reinterpret_cast<uintptr_t>(wstage + (long)B * 64 * ((C + 3) & ~3)) + 255) & ~(uintptr_t)255);
+  if (fused && nframes > 0) {
+    if ((rc = lfi_internal_sample_cond_prepare(wct, E, p1col, K1, f.wc, Ks, G, cfrags, stream))) return rc;
+  }
   if (chain) {
     rc = f.lstm ? set_flow_lds(flow_rev_chain_kernel<4, false>, lds, "lfi_flow_sample_seq")
                 : (x3 ? set_flow_lds(flow_rev_chain_kernel<3, true>, lds, "lfi_flow_sample_seq")
@@ -3765,19 +3775,24 @@ extern "C" int lfi_flow_sample_seq_from(const lfi_flow_dims* d, const lfi_flow_p
       }
       q.K = hid; q.A = ebuf; q.lda = hid4;
     }
-    if (stage_win) {
-      if ((rc = lfi_gather_windows(faces, B, seq_len, C, 1, t, hist1, 0, nullptr, wstage, ldw, 0, stream))) return rc;
-      q.A = wstage; q.lda = ldw;
+    if (fused) {
+      if ((rc = lfi_internal_sample_cond(faces, (long)seq_len * C, (long)(t - hist1) * C, K1, B, Ks, G, cfr, p->b_ih, cfrags, gic, 0.01f, stream)))
+        return rc;
+    } else {
+      if (stage_win) {
+        if ((rc = lfi_gather_windows(faces, B, seq_len, C, 1, t, hist1, 0, nullptr, wstage, ldw, 0, stream))) return rc;
+        q.A = wstage; q.lda = ldw;
+      }
+      if ((rc = lfi_gemm_f32(&q, stream))) return rc;
+      // gic[k] = c[:, kD:(k+1)D] @ W_ih[k][:, Ch:]^T + b_ih[k]
+      lfi_gemm_desc r = {};
+      r.batch = Ks; r.M = B; r.N = G; r.K = D;
+      r.A = cfr; r.lda = (long)Ks * D; r.a_kcontig = 1; r.strideA = D;
+      r.B = f.wc; r.ldb = D; r.b_kcontig = 1; r.strideB = (long)G * D;
+      r.C = gic; r.ldc = G; r.strideC = (long)B * G;
+      r.bias = p->b_ih; r.strideBias = G; r.precision = d->gemm_precision;
+      if ((rc = lfi_gemm_f32(&r, stream))) return rc;
     }
-    if ((rc = lfi_gemm_f32(&q, stream))) return rc;
-    // gic[k] = c[:, kD:(k+1)D] @ W_ih[k][:, Ch:]^T + b_ih[k]
-    lfi_gemm_desc r = {};
-    r.batch = Ks; r.M = B; r.N = G; r.K = D;
-    r.A = cfr; r.lda = (long)Ks * D; r.a_kcontig = 1; r.strideA = D;
-    r.B = f.wc; r.ldb = D; r.b_kcontig = 1; r.strideB = (long)G * D;
-    r.C = gic; r.ldc = G; r.strideC = (long)B * G;
-    r.bias = p->b_ih; r.strideBias = G; r.precision = d->gemm_precision;
-    if ((rc = lfi_gemm_f32(&r, stream))) return rc;
     // reverse flow: z -> x through steps Ks-1 .. 0
     if (chain) {   // one launch for the whole chain of this frame
       RevChain rcn = {};

@@ -1,0 +1,327 @@
+// The per-frame conditioning of the autoregressive sampler as ONE launch (glow/models.py:567-596 inference -> :598-615
+// create_conditioning -> FlowStep's cond_transform + the coupling cell's input projection, per generated frame):
+//   c    = LeakyReLU(pre_static[frame] + window @ Wct[:, window columns]^T)         (B x Ks D; window = the last hist1 generated frames)
+//   gic  = c[:, k D:(k+1) D] @ W_ih[k][:, Ch:]^T + b_ih[k]                           (Ks x B x G)
+// Round 3 ran these as two GEMMs per frame (42 us each at batch 1024, two and three times their MFMA time: 33 MB of c written and read
+// back per frame, two launches' ramps). Here workgroup (64-row tile, flow step k) computes its 64 x D slice of c, keeps it in LDS as
+// fp16 hi / lo pieces and multiplies it by W_ih[k] at once; c never reaches memory. Arithmetic as the per-frame GEMMs it replaces
+// (lfi_gemm_desc.precision 9): three v_mfma_f32_16x16x32_f16 products of two-piece fp16 operands, x = hi + lo with hi = fp16(x),
+// lo = fp16(x - hi) - 2^-22 relative, fp32 accumulation; the caller keeps the range guard of that path.
+// Both products are computed TRANSPOSED (weights as the MFMA's A operand, samples as its B operand): a lane then holds four
+// consecutive output columns of one sample - 8-byte LDS writes of the c pieces, 16-byte loads of pre_static and stores of gic.
+// All weight operands are converted once per call into MFMA fragment order (1 KB per fragment, one coalesced 16-byte load per lane):
+// they are the same for every frame; the window's fragments are rebuilt per frame by a small kernel that replaces the aligned
+// gather the GEMM path needed.
+#include "lfi_common.h"
+#include <type_traits>
+
+namespace {
+
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+union HFrag { uint4 u; h16x8 v; };
+
+constexpr int SC_ROWS = 64;                 // samples per workgroup
+constexpr int SC_D = 512;                   // cond_transform width per flow step (8 waves x 64 columns)
+constexpr int SC_PITCH = SC_D * 2 + 16;     // bytes per row of a c plane in LDS: 65 16-byte slots = 1 (mod 16)
+constexpr int SC_PLANE = SC_ROWS * SC_PITCH;
+constexpr int SC_NT = 512;
+
+// 16-byte k-chunk of lane group q in MFMA step m of a row of nchunk chunks: the chunks of the groups that share a ds_read_b128
+// cycle lie half a row apart (a multiple of 256 bytes at D = 512), rows advance by one 16-byte slot: all 64 banks (lfi_encoder.hip,
+// enc_chunk16: the same rule)
+__host__ __device__ inline int sc_chunk(int m, int q, int nchunk) { return 2 * m + (q >> 1) + (nchunk >> 1) * (q & 1); }
+
+__device__ __forceinline__ void sc_split(float x, _Float16* hi, _Float16* lo) {
+  const _Float16 h = (_Float16)x;
+  *hi = h;
+  *lo = (_Float16)(x - (float)h);
+}
+
+// ---- weights -> fragments, once per call
+// wf1: cond_transform's window columns as the A operand of phase 1. Fragment (k, wave, m, ci, plane): lane l, element e holds
+//      Wct[k D + 64 wave + 16 ci + (l & 15)][col0 + 32 m + 8 (l >> 4) + e]  (0 beyond K1)
+// wf2: W_ih[k][:, Ch:] (G x D) as the A operand of phase 2. Fragment (k, wave, m, ni, plane): lane l, element e holds
+//      wc[k][NGT 16 wave + 16 ni + (l & 15)][8 sc_chunk(m, l >> 4, 64) + e]
+__global__ __launch_bounds__(256) void sc_wfrag1_kernel(const float* __restrict__ wct, long ldw, int col0, int K1, int Ks, int NM1,
+                                                        _Float16* __restrict__ dst) {
+  const long n = (long)Ks * 8 * NM1 * 4 * 2 * 512;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < n; idx += (long)gridDim.x * 256) {
+    const int e = (int)(idx & 7), l = (int)((idx >> 3) & 63), plane = (int)((idx >> 9) & 1);
+    long q = idx >> 10;
+    const int ci = (int)(q & 3); q >>= 2;
+    const int m = (int)(q % NM1); q /= NM1;
+    const int w = (int)(q & 7), k = (int)(q >> 3);
+    const int kk = 32 * m + 8 * (l >> 4) + e;
+    const float v = kk < K1 ? wct[((long)k * SC_D + 64 * w + 16 * ci + (l & 15)) * ldw + col0 + kk] : 0.0f;
+    _Float16 hi, lo;
+    sc_split(v, &hi, &lo);
+    dst[idx] = plane ? lo : hi;
+  }
+}
+__global__ __launch_bounds__(256) void sc_wfrag2_kernel(const float* __restrict__ wc, int G, int Ks, int NGT, _Float16* __restrict__ dst) {
+  const long n = (long)Ks * 8 * 16 * NGT * 2 * 512;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < n; idx += (long)gridDim.x * 256) {
+    const int e = (int)(idx & 7), l = (int)((idx >> 3) & 63), plane = (int)((idx >> 9) & 1);
+    long q = idx >> 10;
+    const int ni = (int)(q % NGT); q /= NGT;
+    const int m = (int)(q & 15); q >>= 4;
+    const int w = (int)(q & 7), k = (int)(q >> 3);
+    const int col = NGT * 16 * w + 16 * ni + (l & 15);
+    const int kc = 8 * sc_chunk(m, l >> 4, SC_D / 8) + e;
+    const float v = wc[((long)k * G + col) * SC_D + kc];
+    _Float16 hi, lo;
+    sc_split(v, &hi, &lo);
+    dst[idx] = plane ? lo : hi;
+  }
+}
+// ---- the frame's window -> fragments (B operand of phase 1). Fragment (16-row tile rt, m, plane): lane l, element e holds
+//      window[16 rt + (l & 15)][32 m + 8 (l >> 4) + e] = faces[row][off + kk]  (0 beyond K1 / B)
+__global__ __launch_bounds__(256) void sc_xfrag_kernel(const float* __restrict__ faces, long ld_faces, long off, int K1, int B, int NM1,
+                                                       int ntile, _Float16* __restrict__ dst) {
+  const long n = (long)ntile * NM1 * 2 * 512;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < n; idx += (long)gridDim.x * 256) {
+    const int e = (int)(idx & 7), l = (int)((idx >> 3) & 63), plane = (int)((idx >> 9) & 1);
+    long q = idx >> 10;
+    const int m = (int)(q % NM1);
+    const int rt = (int)(q / NM1);
+    const int row = 16 * rt + (l & 15), kk = 32 * m + 8 * (l >> 4) + e;
+    const float v = (row < B && kk < K1) ? faces[(long)row * ld_faces + off + kk] : 0.0f;
+    _Float16 hi, lo;
+    sc_split(v, &hi, &lo);
+    dst[idx] = plane ? lo : hi;
+  }
+}
+
+#define SC_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0)
+
+struct ScArgs {
+  const uint4* wf1;      // [Ks][8][NM1][4][2] fragments
+  const uint4* wf2;      // [Ks][8][16][NGT][2]
+  const uint4* xf;       // [ntile][NM1][2]
+  const float* pre;      // B x Ks D: the frame's rows of pre_static (bias included)
+  const float* b_ih;     // Ks x G
+  float* gic;            // Ks x B x G
+  int B, Ks, G, NM1;
+  float slope;
+};
+
+// grid (Ks, row tiles of 64); 512 threads = 8 waves: wave w owns c columns [64 w, 64 w + 64) in phase 1 and gic columns
+// [16 NGT w, 16 NGT (w + 1)) in phase 2; one workgroup per CU (133 KB of LDS).
+template <int NGT>
+__global__ __launch_bounds__(SC_NT, 1) void sc_cond_kernel(ScArgs a) {
+  extern __shared__ __attribute__((aligned(16))) char sc_smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // workgroups are dealt round-robin over the 8 XCDs: flow step on grid.x, so that the row tiles of one step - which read the same
+  // 1.3 MB of weight fragments - share ONE 4 MB L2 (two steps per XCD at Ks = 16) instead of every L2 seeing all 20 MB
+  const int k = blockIdx.x, rt = blockIdx.y;
+  const int l15 = lane & 15, g4 = lane >> 4;
+  const int NM1 = a.NM1;
+  const long KD = (long)a.Ks * SC_D;
+  const unsigned lane16 = (unsigned)lane * 16u;
+  const __amdgpu_buffer_rsrc_t bw1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(a.wf1 + (long)(k * 8 + wave) * NM1 * 4 * 2 * 64), 0,
+                                                                      NM1 * 4 * 2 * 1024, 0x00020000);
+  const __amdgpu_buffer_rsrc_t bx = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(a.xf + (long)(rt * 4) * NM1 * 2 * 64), 0,
+                                                                     4 * NM1 * 2 * 1024, 0x00020000);
+  const __amdgpu_buffer_rsrc_t bw2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(a.wf2 + (long)(k * 8 + wave) * 16 * NGT * 2 * 64), 0,
+                                                                      16 * NGT * 2 * 1024, 0x00020000);
+  auto ld = [&](__amdgpu_buffer_rsrc_t r, int frag) {
+    return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(r, lane16, (unsigned)frag * 1024u, 0));
+  };
+
+  // ---- phase 1: acc1[ci][ri] = (Wct rows 16 ci ..) x (window rows 16 ri ..)^T, 32 k per step
+  f32x4 acc1[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc1[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  {
+    HFrag wa[4][2], xa[4][2], wb[4][2], xb[4][2];   // [tile][plane], two buffers
+    auto load1 = [&](int m, HFrag (&w)[4][2], HFrag (&x)[4][2]) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) {
+          w[t][pl].u = ld(bw1, (m * 4 + t) * 2 + pl);
+          x[t][pl].u = ld(bx, (t * NM1 + m) * 2 + pl);
+        }
+    };
+    auto mma1 = [&](const HFrag (&w)[4][2], const HFrag (&x)[4][2]) {
+#pragma unroll
+      for (int ci = 0; ci < 4; ++ci) {
+#pragma unroll
+        for (int ri = 0; ri < 4; ++ri) acc1[ci][ri] = SC_MFMA(w[ci][1].v, x[ri][0].v, acc1[ci][ri]);
+#pragma unroll
+        for (int ri = 0; ri < 4; ++ri) acc1[ci][ri] = SC_MFMA(w[ci][0].v, x[ri][1].v, acc1[ci][ri]);
+#pragma unroll
+        for (int ri = 0; ri < 4; ++ri) acc1[ci][ri] = SC_MFMA(w[ci][0].v, x[ri][0].v, acc1[ci][ri]);
+      }
+    };
+    load1(0, wa, xa);
+    int m = 0;
+    for (; m + 2 < NM1; m += 2) {
+      load1(m + 1, wb, xb);
+      __builtin_amdgcn_sched_barrier(0);
+      mma1(wa, xa);
+      load1(m + 2, wa, xa);
+      __builtin_amdgcn_sched_barrier(0);
+      mma1(wb, xb);
+    }
+    if (m + 1 < NM1) {
+      load1(m + 1, wb, xb);
+      __builtin_amdgcn_sched_barrier(0);
+      mma1(wa, xa);
+      mma1(wb, xb);
+    } else {
+      mma1(wa, xa);
+    }
+  }
+  // the first W_ih fragments travel while the c pieces are made
+  HFrag w2a[NGT][2], w2b[NGT][2];
+  auto load2 = [&](int m, HFrag (&w)[NGT][2]) {
+#pragma unroll
+    for (int t = 0; t < NGT; ++t)
+#pragma unroll
+      for (int pl = 0; pl < 2; ++pl) w[t][pl].u = ld(bw2, (m * NGT + t) * 2 + pl);
+  };
+  load2(0, w2a);
+  // ---- c = LeakyReLU(acc1 + pre_static) -> fp16 hi / lo pieces in LDS, row-major [64][D] per plane
+  // accumulator (ci, ri) register r = c column 64 wave + 16 ci + 4 g4 + r of sample 16 ri + l15
+#pragma unroll
+  for (int ri = 0; ri < 4; ++ri) {
+    const int rl = 16 * ri + l15;
+    const long row = (long)rt * SC_ROWS + rl;
+    f32x4 ps[4];
+#pragma unroll
+    for (int ci = 0; ci < 4; ++ci) {
+      ps[ci] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (row < a.B) ps[ci] = *reinterpret_cast<const f32x4*>(a.pre + row * KD + (long)k * SC_D + 64 * wave + 16 * ci + 4 * g4);
+    }
+#pragma unroll
+    for (int ci = 0; ci < 4; ++ci) {
+      h16x4 hi, lo;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float v = acc1[ci][ri][r] + ps[ci][r];
+        v = v > 0.0f ? v : v * a.slope;
+        _Float16 h, l;
+        sc_split(v, &h, &l);
+        hi[r] = h; lo[r] = l;
+      }
+      char* dst = sc_smem + rl * SC_PITCH + (64 * wave + 16 * ci + 4 * g4) * 2;
+      *reinterpret_cast<h16x4*>(dst) = hi;
+      *reinterpret_cast<h16x4*>(dst + SC_PLANE) = lo;
+    }
+  }
+  __syncthreads();
+  // ---- phase 2: acc2[ni][ri] = (W_ih rows 16 ni ..) x (c rows 16 ri ..)^T over D = 512: 16 steps
+  f32x4 acc2[NGT][4];
+#pragma unroll
+  for (int i = 0; i < NGT; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc2[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  {
+    const char* cbase = sc_smem + l15 * SC_PITCH + 16 * ((g4 >> 1) + (SC_D / 16) * (g4 & 1));   // + 32 m per step, + 16 rows per ri
+    h16x8 cah[4], cal[4], cbh[4], cbl[4];
+    auto loadc = [&](int m, h16x8 (&ch)[4], h16x8 (&cl)[4]) {
+#pragma unroll
+      for (int ri = 0; ri < 4; ++ri) {
+        ch[ri] = *reinterpret_cast<const h16x8*>(cbase + ri * 16 * SC_PITCH + 32 * m);
+        cl[ri] = *reinterpret_cast<const h16x8*>(cbase + ri * 16 * SC_PITCH + 32 * m + SC_PLANE);
+      }
+    };
+    auto mma2 = [&](const HFrag (&w)[NGT][2], const h16x8 (&ch)[4], const h16x8 (&cl)[4]) {
+#pragma unroll
+      for (int ni = 0; ni < NGT; ++ni) {
+#pragma unroll
+        for (int ri = 0; ri < 4; ++ri) acc2[ni][ri] = SC_MFMA(w[ni][1].v, ch[ri], acc2[ni][ri]);
+#pragma unroll
+        for (int ri = 0; ri < 4; ++ri) acc2[ni][ri] = SC_MFMA(w[ni][0].v, cl[ri], acc2[ni][ri]);
+#pragma unroll
+        for (int ri = 0; ri < 4; ++ri) acc2[ni][ri] = SC_MFMA(w[ni][0].v, ch[ri], acc2[ni][ri]);
+      }
+    };
+    loadc(0, cah, cal);
+#pragma unroll
+    for (int m = 0; m < 16; m += 2) {
+      load2(m + 1, w2b);
+      loadc(m + 1, cbh, cbl);
+      __builtin_amdgcn_sched_barrier(0);
+      mma2(w2a, cah, cal);
+      if (m + 2 < 16) {
+        load2(m + 2, w2a);
+        loadc(m + 2, cah, cal);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      mma2(w2b, cbh, cbl);
+    }
+  }
+  // ---- gic[k][row][16 NGT wave + 16 ni + 4 g4 + r] = acc2 + b_ih
+#pragma unroll
+  for (int ni = 0; ni < NGT; ++ni) {
+    const int col = NGT * 16 * wave + 16 * ni + 4 * g4;
+    const f32x4 bv = *reinterpret_cast<const f32x4*>(a.b_ih + (long)k * a.G + col);
+#pragma unroll
+    for (int ri = 0; ri < 4; ++ri) {
+      const long row = (long)rt * SC_ROWS + 16 * ri + l15;
+      if (row < a.B) *reinterpret_cast<f32x4*>(a.gic + ((long)k * a.B + row) * a.G + col) = acc2[ni][ri] + bv;
+    }
+  }
+}
+
+}  // namespace
+
+// shapes the fused conditioning takes (the caller falls back to its two GEMMs otherwise)
+extern "C" __attribute__((visibility("hidden"))) int lfi_internal_sample_cond_ok(int D, int G, int K1) {
+  const char* e = getenv("LFI_SAMPLE_FUSED");
+  if (e && e[0] == '0') return 0;
+  return (D == SC_D && (G == 384 || G == 512) && K1 >= 1 && K1 <= 512) ? 1 : 0;
+}
+// bytes of fragment storage: [weights of phase 1][weights of phase 2][the frame's window]
+extern "C" __attribute__((visibility("hidden"))) long lfi_internal_sample_cond_bytes(int B, int Ks, int G, int K1) {
+  const long NM1 = (K1 + 31) / 32, NGT = G / 128, ntile = ((long)B + 63) / 64 * 4;
+  return ((long)Ks * 8 * NM1 * 4 * 2 + (long)Ks * 8 * 16 * NGT * 2 + ntile * NM1 * 2) * 1024 + 256;
+}
+extern "C" __attribute__((visibility("hidden"))) int lfi_internal_sample_cond_prepare(const float* wct, long ldw, int col0, int K1, const float* wc,
+                                                                                      int Ks, int G, void* frags, void* stream) {
+  const int NM1 = (K1 + 31) / 32, NGT = G / 128;
+  _Float16* f1 = reinterpret_cast<_Float16*>(frags);
+  _Float16* f2 = f1 + (long)Ks * 8 * NM1 * 4 * 2 * 512;
+  const long n1 = (long)Ks * 8 * NM1 * 4 * 2 * 512, n2 = (long)Ks * 8 * 16 * NGT * 2 * 512;
+  hipLaunchKernelGGL(sc_wfrag1_kernel, dim3((unsigned)min((n1 + 255) / 256, 65535L * 4)), dim3(256), 0, (hipStream_t)stream, wct, ldw, col0, K1,
+                     Ks, NM1, f1);
+  hipLaunchKernelGGL(sc_wfrag2_kernel, dim3((unsigned)min((n2 + 255) / 256, 65535L * 4)), dim3(256), 0, (hipStream_t)stream, wc, G, Ks, NGT, f2);
+  LFI_LAUNCH_CHECK("sampler conditioning: weight fragments");
+  return LFI_OK;
+}
+extern "C" __attribute__((visibility("hidden"))) int lfi_internal_sample_cond(const float* faces, long ld_faces, long off, int K1, int B, int Ks, int G,
+                                                                              const float* pre, const float* b_ih, void* frags, float* gic,
+                                                                              float slope, void* stream) {
+  const int NM1 = (K1 + 31) / 32, NGT = G / 128;
+  const int ntile = (B + 63) / 64 * 4;
+  _Float16* f1 = reinterpret_cast<_Float16*>(frags);
+  _Float16* f2 = f1 + (long)Ks * 8 * NM1 * 4 * 2 * 512;
+  _Float16* fx = f2 + (long)Ks * 8 * 16 * NGT * 2 * 512;
+  const long nx = (long)ntile * NM1 * 2 * 512;
+  hipLaunchKernelGGL(sc_xfrag_kernel, dim3((unsigned)((nx + 255) / 256)), dim3(256), 0, (hipStream_t)stream, faces, ld_faces, off, K1, B, NM1, ntile,
+                     fx);
+  ScArgs a = {};
+  a.wf1 = reinterpret_cast<const uint4*>(f1); a.wf2 = reinterpret_cast<const uint4*>(f2); a.xf = reinterpret_cast<const uint4*>(fx);
+  a.pre = pre; a.b_ih = b_ih; a.gic = gic; a.B = B; a.Ks = Ks; a.G = G; a.NM1 = NM1; a.slope = slope;
+  const size_t lds = (size_t)2 * SC_PLANE;
+  static bool attr = false;
+  if (!attr) {
+    hipError_t e1 = hipFuncSetAttribute((const void*)sc_cond_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e2 = hipFuncSetAttribute((const void*)sc_cond_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e1 != hipSuccess || e2 != hipSuccess) {
+      lfi_set_error("sampler conditioning: cannot reserve %zu bytes of LDS", lds);
+      return LFI_ERR_LAUNCH;
+    }
+    attr = true;
+  }
+  const dim3 grid(Ks, (B + 63) / 64);
+  if (NGT == 3) hipLaunchKernelGGL(sc_cond_kernel<3>, grid, dim3(SC_NT), lds, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL(sc_cond_kernel<4>, grid, dim3(SC_NT), lds, (hipStream_t)stream, a);
+  LFI_LAUNCH_CHECK("sampler conditioning");
+  return LFI_OK;
+}

@@ -128,6 +128,36 @@ def test_k16_sampling_against_oracle(gpu_device):
         assert err <= gate, (precision, err, gate)
 
 
+def test_sampler_fused_conditioning_matches_two_gemms(gpu_device, monkeypatch):
+    """The sampler's per-frame conditioning as one launch (lfi_sample.hip: c = LeakyReLU(pre_static + window Wct^T) kept in LDS as
+    fp16 pieces and multiplied by W_ih[k] at once; glow/models.py:598-615 + the coupling cell's input projection) against the two
+    GEMMs it replaces (LFI_SAMPLE_FUSED=0), both in three fp16 products: a ragged batch (64 + 6 rows: two row tiles, one partial),
+    6 generated frames at final widths - equal to fp32 rounding carried through the frames, and not bit-equal (it did run)."""
+    hp = final_model_hparams(50, 27, K=16)
+    m, _ = perturbed_model(hp, gpu_device)
+    m.eval()
+    m.precision = "bf16x3"
+    B, seq_len = 70, 24 + 6
+    g = torch.Generator().manual_seed(21)
+    data = {"p1_face": torch.randn(B, 24, 50, generator=g)}
+    for name, d in (("p2_face", 50), ("p1_speech", 27), ("p2_speech", 27)):
+        data[name] = torch.randn(B, seq_len, d, generator=g)
+    noise = (torch.randn(seq_len - 24, B, 50, generator=g) * 0.8).to(gpu_device)
+    dd = to_dev(data, gpu_device)
+    outs = {}
+    for fused in ("1", "0"):
+        monkeypatch.setenv("LFI_SAMPLE_FUSED", fused)
+        monkeypatch.setenv("LFI_NO_GRAPH", "1")
+        outs[fused] = m.inference(seq_len, dd, noise=noise).clone()
+    a, b = outs["1"], outs["0"]
+    assert torch.isfinite(a).all()
+    err = float((a - b).abs().max() / b.abs().max().clamp(min=1.0))
+    report("sampler: fused per-frame conditioning vs its two GEMMs, batch 70 x 6 frames at K = 16: max abs difference %.2e of the "
+           "largest value" % err)
+    assert not torch.equal(a, b), "the fused conditioning did not run"
+    assert err < 2e-5
+
+
 def test_sampler_leaves_fp16_pieces_for_out_of_range_inputs(gpu_device):
     """The sampler's default per-frame arithmetic splits operands into fp16 pieces (fp32-grade inside fp16's range). Inputs
     beyond 1e3 must send it to the six-product bf16 form instead (no range caveat): same frames as the all-f32-MFMA mode to
