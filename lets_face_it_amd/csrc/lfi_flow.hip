@@ -3007,12 +3007,22 @@ __global__ __launch_bounds__(256) void flow_invconv_bwd_kernel(FlowK f, const fl
   const float* P = f.p.inv_p + kc;
   const float* sg = f.p.inv_sign + (long)k * C;
   const float* ls = f.p.inv_logs + (long)k * C;
+  // (P and dW through LDS first: read from global inside the inner product - 100 dependent L2 round trips per thread - this
+  // 16-workgroup kernel took 88 us alone and 260 us next to the HBM streams it shares its stream slot with)
+  float* Pm = Q + C * C;
+  float* Dm = Pm + C * C;
   for (int idx = tid; idx < C * C; idx += 256) {
     const int i = idx / C, j = idx - i * C;
     Lm[idx] = i > j ? l[idx] : (i == j ? 1.0f : 0.0f);
     Um[idx] = i < j ? u[idx] : (i == j ? sg[i] * expf(ls[i]) : 0.0f);
+    Pm[idx] = P[idx];
+    Dm[idx] = dW[kc + idx];
+  }
+  __syncthreads();
+  for (int idx = tid; idx < C * C; idx += 256) {
+    const int i = idx / C, j = idx - i * C;
     float s = 0.0f;
-    for (int q = 0; q < C; ++q) s += P[q * C + i] * dW[kc + (long)q * C + j];
+    for (int q = 0; q < C; ++q) s += Pm[q * C + i] * Dm[q * C + j];
     Q[idx] = s;
   }
   __syncthreads();
@@ -3490,7 +3500,8 @@ extern "C" int lfi_flow_param_grads(const lfi_flow_dims* d, const lfi_flow_param
   }
   // The other products are thin (K = F frames, a few output tiles per step), HBM-bound at 3 - 4 TB/s. (Moving them to
   // bias_stream as well, next to the caller's MFMA-bound products, was measured no better than leaving them here: same-box
-  // A/B 0.18 ms per step gained with them there, 0.21 ms without.)
+  // A/B 0.18 ms per step gained with them there, 0.21 ms without; round 4, any one or two of them: 6.86 - 6.91 ms per step
+  // whichever way.)
   // w_fl[k] (Cout x H) = dlin[k]^T h[k]
   q.M = Cout; q.N = H; q.splitk = fill_split(Cout, H, F); q.A = f.bDlin; q.lda = f.ldo; q.strideA = (long)F * f.ldo; q.B = f.sH; q.ldb = H; q.strideB = (long)F * H;
   q.C = g->w_fl; q.ldc = H; q.strideC = (long)Cout * H;
@@ -3519,7 +3530,7 @@ extern "C" int lfi_flow_param_grads(const lfi_flow_dims* d, const lfi_flow_param
   // constant log-det terms: nll has -(C sum(logs))/ln2 per frame -> d/dlogs = -C/ln2 * gscale * F
   const float cconst = -(float)((double)gscale * (double)F * (double)C / 0.6931471805599453);
   {
-    const size_t lds = (size_t)3 * C * C * sizeof(float);
+    const size_t lds = (size_t)5 * C * C * sizeof(float);
     rc = set_flow_lds(flow_invconv_bwd_kernel, lds, "lfi_flow_param_grads");
     if (rc) return rc;
     hipLaunchKernelGGL(flow_invconv_bwd_kernel, dim3(Ks), dim3(256), lds, (hipStream_t)bs, f, dW, *g, cconst, accumulate);
