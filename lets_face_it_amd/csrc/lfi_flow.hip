@@ -1103,12 +1103,12 @@ __device__ __forceinline__ void fast_cell_p2_x3h(const FlowK& f, const float* Zt
 }
 
 // P3: o = (h' Wfl^T + b) exp(3 logs) on this wave's 16 outputs   (LinearZeros, glow/modules.py:93-95); o_out may be null
+// (bb, sc: LinearZeros bias and exp(3 logs) of this lane's output column, loaded by the caller OUTSIDE its dependent phases)
 __device__ __forceinline__ void fast_cell_p3(const FlowK& f, int k, const float* Hn, float* Orm, const f32x4 (&w3)[FB_H], int nbH,
-                                             int col, int kq, int l15, int b0, int rows, float* o_out, long ld_out) {
+                                             int col, int kq, int l15, int b0, int rows, float* o_out, long ld_out, float bb, float sc) {
   const int Cout = f.Cout, ldo = Cout + 1;
   const f32x4 acc = mma16_reg<FB_H>(Hn + kq * LT + l15, w3, nbH);
   if (col < Cout) {
-    const float bb = f.p.b_fl[(long)k * Cout + col], sc = expf(3.0f * f.p.l_fl[(long)k * Cout + col]);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int i = kq * 4 + r;
@@ -1229,7 +1229,11 @@ __global__ __launch_bounds__(NT) void flow_diag_fwd_fast_kernel(FlowK f, int d, 
   LFI_STAMP(4);
 
   // ---- P3: o = (h' Wfl^T + b) exp(3 logs)   (LinearZeros, glow/modules.py:93-95)
-  if (t3) fast_cell_p3(f, k, Hn, Orm, w3, nbH, tcol, kq, l15, b0, B, f.sO + kf * LO, LO);
+  if (t3) {
+    const int cj = tcol < Cout ? tcol : 0;
+    fast_cell_p3(f, k, Hn, Orm, w3, nbH, tcol, kq, l15, b0, B, f.sO + kf * LO, LO, f.p.b_fl[(long)k * Cout + cj],
+                 expf(3.0f * f.p.l_fl[(long)k * Cout + cj]));
+  }
   __syncthreads();
   LFI_STAMP(5);
 
@@ -1739,6 +1743,12 @@ __device__ __forceinline__ bool rev_fast_cell(const FlowK& f, const CellIO& io, 
   // W^-1 slice of this wave's 16 output channels: in flight under the coupling net
   f32x4 w1[FB_C];
   load_frag<FB_C>(w1, f.pWinv + (long)k * C16 * C16, C16, tcol, kq, nbC, t1);
+  // per-column constants of the phases after the wait (LinearZeros bias / scale, ActNorm^-1 scale / bias): loaded here, not between
+  // the barriers of the dependent phases (two L2 round trips per cell each)
+  const float flb = tcol < Cout ? f.p.b_fl[(long)k * Cout + tcol] : 0.0f;
+  const float fls = tcol < Cout ? expf(3.0f * f.p.l_fl[(long)k * Cout + tcol]) : 0.0f;
+  const float an_es = tcol < C ? expf(-f.p.an_logs[(long)k * C + tcol]) : 0.0f;
+  const float an_bb = tcol < C ? f.p.an_bias[(long)k * C + tcol] : 0.0f;
   __syncthreads();
   f32x4 az[NG], ah[NG];
 #pragma unroll
@@ -1824,7 +1834,7 @@ __device__ __forceinline__ bool rev_fast_cell(const FlowK& f, const CellIO& io, 
   }
   __syncthreads();
   REV_STAMP(4);
-  if (t3) fast_cell_p3(f, k, Hn, Orm, w3, nbH, tcol, kq, l15, b0, rows, nullptr, 0);
+  if (t3) fast_cell_p3(f, k, Hn, Orm, w3, nbH, tcol, kq, l15, b0, rows, nullptr, 0, flb, fls);
   __syncthreads();
   REV_STAMP(5);
   // ---- R3: coupling inverse (glow/models.py:356-365)
@@ -1859,7 +1869,7 @@ __device__ __forceinline__ bool rev_fast_cell(const FlowK& f, const CellIO& io, 
     const f32x4 acc = mma16_reg<FB_C>(Yt + kq * LT + l15, w1, nbC);
     const int c = tcol;
     if (c < C) {
-      const float es = expf(-f.p.an_logs[(long)k * C + c]), bb = f.p.an_bias[(long)k * C + c];
+      const float es = an_es, bb = an_bb;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int row = b0 + kq * 4 + r;
