@@ -1749,6 +1749,18 @@ __device__ __forceinline__ bool rev_fast_cell(const FlowK& f, const CellIO& io, 
   const float fls = tcol < Cout ? expf(3.0f * f.p.l_fl[(long)k * Cout + tcol]) : 0.0f;
   const float an_es = tcol < C ? expf(-f.p.an_logs[(long)k * C + tcol]) : 0.0f;
   const float an_bb = tcol < C ? f.p.an_bias[(long)k * C + tcol] : 0.0f;
+  // X3: LinearZeros and W^-1 as three fp16 products too (K = H and K = C: 32 and 16 dependent f32-input MFMAs of 32 cycles
+  // otherwise, per cell, after the wait); their weight fragments are split here, before it. Whole pairs of 16-k blocks only.
+  // (X3 is only instantiated for shapes with whole pairs everywhere: the launcher checks H16, Ch16 and C16)
+  X3FragH w3x[X3 ? FB_H / 2 : 1], w1x[X3 ? FB_C / 2 : 1];
+  if constexpr (X3) {
+#pragma unroll
+    for (int b = 0; b < FB_H / 2; ++b)
+      if (b < (nbH >> 1)) w3x[b] = x3h_pack(w3[2 * b], w3[2 * b + 1]);
+#pragma unroll
+    for (int b = 0; b < FB_C / 2; ++b)
+      if (b < (nbC >> 1)) w1x[b] = x3h_pack(w1[2 * b], w1[2 * b + 1]);
+  }
   __syncthreads();
   f32x4 az[NG], ah[NG];
 #pragma unroll
@@ -1834,7 +1846,21 @@ __device__ __forceinline__ bool rev_fast_cell(const FlowK& f, const CellIO& io, 
   }
   __syncthreads();
   REV_STAMP(4);
-  if (t3) fast_cell_p3(f, k, Hn, Orm, w3, nbH, tcol, kq, l15, b0, rows, nullptr, 0, flb, fls);
+  if (t3) {
+    if constexpr (X3) {
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      const float* hl = Hn + kq * LT + l15;
+#pragma unroll
+      for (int b = 0; b < FB_H / 2; ++b)
+        if (b < (nbH >> 1)) acc = x3h_mma(x3h_a(hl + b * 32 * LT), w3x[b], acc);
+      if (tcol < Cout) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) Orm[(kq * 4 + r) * ldo + tcol] = (acc[r] + flb) * fls;
+      }
+    } else {
+      fast_cell_p3(f, k, Hn, Orm, w3, nbH, tcol, kq, l15, b0, rows, nullptr, 0, flb, fls);
+    }
+  }
   __syncthreads();
   REV_STAMP(5);
   // ---- R3: coupling inverse (glow/models.py:356-365)
@@ -1866,7 +1892,15 @@ __device__ __forceinline__ bool rev_fast_cell(const FlowK& f, const CellIO& io, 
   REV_STAMP(6);
   // ---- R4: x = (y W^-1) exp(-logs) - bias   (scale then center, glow/modules.py:76-79)
   if (t1) {
-    const f32x4 acc = mma16_reg<FB_C>(Yt + kq * LT + l15, w1, nbC);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if constexpr (X3) {
+      const float* yl = Yt + kq * LT + l15;
+#pragma unroll
+      for (int b = 0; b < FB_C / 2; ++b)
+        if (b < (nbC >> 1)) acc = x3h_mma(x3h_a(yl + b * 32 * LT), w1x[b], acc);
+    } else {
+      acc = mma16_reg<FB_C>(Yt + kq * LT + l15, w1, nbC);
+    }
     const int c = tcol;
     if (c < C) {
       const float es = an_es, bb = an_bb;
@@ -3731,7 +3765,7 @@ extern "C" int lfi_flow_sample_seq_from(const lfi_flow_dims* d, const lfi_flow_p
   const char* ce = getenv("LFI_SAMPLE_CHAIN");
   const bool chain = fast && !(ce && ce[0] == '0');
   // (the reverse cells' recurrent products as three fp16 products - fp32-grade - in both bf16 modes of the per-frame GEMMs)
-  const bool x3 = (d->gemm_precision & 1) && !f.lstm && (f.H16 % 32 == 0) && (f.Ch16 % 32 == 0) && flow_pipe_x3_enabled();
+  const bool x3 = (d->gemm_precision & 1) && !f.lstm && (f.H16 % 32 == 0) && (f.Ch16 % 32 == 0) && (f.C16 % 32 == 0) && flow_pipe_x3_enabled();
   unsigned* chain_state = reinterpret_cast<unsigned*>((reinterpret_cast<uintptr_t>(xb + (long)B * C) + 15) & ~(uintptr_t)15);
   const size_t chain_words = (size_t)(((long)PIPE_HDR + (long)Ks * f.nbt + 3) & ~3L);
   // raw prev_p1_face windows start (t - hist1) * C floats into a row: 16-byte aligned only on every other frame at C = 50,
