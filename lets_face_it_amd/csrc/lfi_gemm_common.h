@@ -326,6 +326,62 @@ __device__ __forceinline__ void gemm_epilogue_wide(const GemmArgs& g, const ACC&
   }
 }
 
+// Epilogue WITHOUT the LDS round trip, for the 16 x 16 x 32 kernels when they compute the product transposed (weights / B fragments
+// as the MFMA's A operand): accumulator (i, j) register r is then C[64 wm + 16 i + (lane & 15)][64 wn + 16 j + 4 (lane >> 4) + r] - four
+// CONSECUTIVE columns of one row per lane. MODE 3: operand planes
+// only, 8 bytes per lane and plane (half a 16-byte chunk of the block format; a wave-instruction writes a contiguous 512-byte half
+// block). Bias and LeakyReLU (act 1) in registers; NOT the act-2 mask, accumulate, per-pass column sums or planes + rows together
+// (those keep the LDS form). All addressing is a buffer descriptor + a scalar offset + one per-lane VGPR, stores are predicated.
+// fp32 ROW outputs were tried the same way (16-byte stores of a lane's four columns, 16 rows per wave-instruction: 64-byte runs)
+// and dropped: gic 0.284 -> 0.357 ms, the split-K partials -1 .. -2 %; planes: cond_transform forward 0.505 -> 0.459 ms.
+// (the through-LDS epilogue of a 128 x 256 tile measured about half as long as the tile's whole main loop at K = 896)
+typedef unsigned gu32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned gu32x2 __attribute__((ext_vector_type(2)));
+template <int MODE>
+__device__ __forceinline__ void gemm_epilogue_direct16(const GemmArgs& g, const f32x4 (&acc)[4][4], int m0, int n0, int wm, int wn, int lane,
+                                                       int batch, int split) {
+  const int l15 = lane & 15, g4 = lane >> 4;
+  const int r0 = m0 + wm * 64, c0 = n0 + wn * 64;             // this wave's patch (wave-uniform)
+  const float* bias = g.bias ? g.bias + batch * g.strideBias : nullptr;
+  f32x4 bv[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int col = c0 + 16 * j + 4 * g4;
+    bv[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (bias && col < g.N) bv[j] = *reinterpret_cast<const f32x4*>(bias + col);
+  }
+  static_assert(MODE == 3, "plane outputs only");
+  {
+    const long gcol0 = g.colCr + (long)batch * g.strideC + c0;      // multiple of 16 (colCr, strideC, c0 are)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = r0 + 16 * i + l15;
+      const bool blk = (r0 + 16 * (i & ~1)) < g.M;                    // the 32-row block exists (rows past M inside it: zeros)
+      const long rt = (r0 + 16 * i) >> 5;
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(g.Cr) + (rt * g.nktCr + (gcol0 >> 4)) * 2048, 0,
+                                                                         0x7fffffff, 0x00020000);
+      const unsigned voff = (unsigned)(lfi_u_plane_offset(16 * (i & 1) + l15, g4 >> 1) + (g4 & 1) * 8);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int col = c0 + 16 * j + 4 * g4;
+        f32x4 v = acc[i][j] + bv[j];
+        if (g.act == 1) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.0f ? v[r] : v[r] * g.slope;
+        }
+        if (row >= g.M || col >= g.N) v = (f32x4){0.f, 0.f, 0.f, 0.f};   // inside an existing block: zeros (k of a later product)
+        uint2 h, l;
+        split2(v[0], v[1], &h.x, &l.x);
+        split2(v[2], v[3], &h.y, &l.y);
+        if (blk && c0 + 16 * j < g.N) {
+          __builtin_amdgcn_raw_buffer_store_b64((gu32x2){h.x, h.y}, rs, voff, 2048 * j, 2);
+          if (!g.hiOnly) __builtin_amdgcn_raw_buffer_store_b64((gu32x2){l.x, l.y}, rs, voff, 2048 * j + 1024, 2);
+        }
+      }
+    }
+  }
+}
+
 // XCD-aware, grouped work order shared by both GEMM kernels: workgroups b, b+8, ... share an XCD (round-robin dispatch over
 // the linearised grid). Each XCD gets a contiguous run of (split, batch, tile) work items (bijective for any grid size),
 // so that all tiles of one K-split / one batch entry - which re-read the same operand panels - meet in ONE 4 MB L2 instead

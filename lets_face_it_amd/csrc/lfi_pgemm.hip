@@ -234,7 +234,10 @@ __global__ __launch_bounds__(512, 4) void gemm_planes_kernel(GemmArgs g) {
 // Needs three products and an even number of k-tiles per split (the host falls back to the kernel above otherwise). Sums differ from
 // the 32 x 32 kernel's in the order of their fp32 additions only.
 #define PG_MFMA16(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0)
-template <bool COLP, int WMT, int WNT>
+// TRP != 0: the product is computed transposed (B fragments as the MFMA's A operand: the same products, the same sums) so that a lane
+// holds four consecutive columns of a row and the epilogue needs no LDS (gemm_epilogue_direct16<3>: plane outputs); the launcher takes it whenever the epilogue is one it covers.
+#define PG_MFMA16X(a, b, c) (TRP ? PG_MFMA16(b, a, c) : PG_MFMA16(a, b, c))
+template <bool COLP, int WMT, int WNT, int TRP = 0>
 __global__ __launch_bounds__(512, 4) void gemm_planes16_kernel(GemmArgs g) {
   constexpr int NA = 4 * WMT;   // A blocks per sub-slot (2 WMT mn tiles x 2 k-tiles); B: 4 WNT
   static_assert(WMT * WNT == 8 && NA + 4 * WNT == 24, "eight waves, 24 blocks per slot");
@@ -310,7 +313,7 @@ __global__ __launch_bounds__(512, 4) void gemm_planes16_kernel(GemmArgs g) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = PG_MFMA16(al[i], bh[j], acc[i][j]);
+        for (int j = 0; j < 4; ++j) acc[i][j] = PG_MFMA16X(al[i], bh[j], acc[i][j]);
         __builtin_amdgcn_sched_barrier(0);
         if (i == 0) {
 #pragma unroll
@@ -327,12 +330,12 @@ __global__ __launch_bounds__(512, 4) void gemm_planes16_kernel(GemmArgs g) {
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = PG_MFMA16(ah[i], bh[j], acc[i][j]);
+        for (int j = 0; j < 4; ++j) acc[i][j] = PG_MFMA16X(ah[i], bh[j], acc[i][j]);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = PG_MFMA16(ah[i], bl[j], acc[i][j]);
+        for (int j = 0; j < 4; ++j) acc[i][j] = PG_MFMA16X(ah[i], bl[j], acc[i][j]);
         __builtin_amdgcn_sched_barrier(0);
         if (i == 0) {
 #pragma unroll
@@ -355,9 +358,16 @@ __global__ __launch_bounds__(512, 4) void gemm_planes16_kernel(GemmArgs g) {
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
-  __syncthreads();
-  gemm_epilogue_wide<64 * WNT, 512, 2, COLP, true, true>(g, acc, reinterpret_cast<float*>(xsmem), WNT == 4 ? 64 : 128, m0, n0, wm, wn,
-                                                         lane & 31, lane >> 5, batch, split, 64 * WMT);
+  if constexpr (TRP != 0) {
+    // (laundered: otherwise the epilogue's address arithmetic is hoisted above the main loop and lives through it in registers)
+    int lanez = lane, m0z = m0, n0z = n0;
+    asm volatile("" : "+v"(lanez), "+s"(m0z), "+s"(n0z));
+    gemm_epilogue_direct16<TRP>(g, acc, m0z, n0z, wm, wn, lanez, batch, split);
+  } else {
+    __syncthreads();
+    gemm_epilogue_wide<64 * WNT, 512, 2, COLP, true, true>(g, acc, reinterpret_cast<float*>(xsmem), WNT == 4 ? 64 : 128, m0, n0, wm, wn,
+                                                           lane & 31, lane >> 5, batch, split, 64 * WMT);
+  }
 }
 
 // The backward products - TWO products per k (A rounded to bf16: a_hi b_hi + a_hi b_lo), B in transposed use, A by rows (dpre, the
@@ -563,6 +573,17 @@ bool planes16t_ok(const GemmArgs& a) {
   return a.vecC && a.skip == 1 && (a.nkt & 1) == 0 && ((a.kchunk >> 4) & 1) == 0;
 }
 
+// the LDS-free epilogue of the 16 x 16 x 32 kernels (gemm_epilogue_direct16): bias / LeakyReLU / plane outputs only; not the act-2
+// mask, accumulate, column sums, fp32 rows or split-K partials (LFI_PGEMM_DIRECT=0: always through LDS)
+// -> 0: not covered; 3: planes only
+int planes16_direct_mode(const GemmArgs& a) {
+  const char* e = getenv("LFI_PGEMM_DIRECT");
+  if (e && e[0] == '0') return 0;
+  if (!(a.vecC && a.act != 2 && a.accumulate == 0 && !a.colpart && (a.N & 3) == 0) || a.splitk > 1) return 0;
+  if (a.Cr && !a.storeC) return ((a.strideC & 31) == 0 && (a.colCr & 15) == 0) ? 3 : 0;
+  return 0;
+}
+
 template <bool COLP, int WMT, int WNT>
 int launch_planes(const GemmArgs& a, int at, int bt, dim3 grid, size_t lds, hipStream_t st) {
   static bool attr = false;
@@ -590,6 +611,16 @@ int launch_planes(const GemmArgs& a, int at, int bt, dim3 grid, size_t lds, hipS
     }
     if (at) hipLaunchKernelGGL((gemm_planes16t_kernel<true, COLP, WMT, WNT>), grid, dim3(512), lds, st, a);
     else hipLaunchKernelGGL((gemm_planes16t_kernel<false, COLP, WMT, WNT>), grid, dim3(512), lds, st, a);
+  } else if (!at && !bt && planes16_ok(a) && !COLP && planes16_direct_mode(a)) {
+    static bool attrd16 = false;
+    if (!attrd16) {
+      if (hipFuncSetAttribute((const void*)gemm_planes16_kernel<false, WMT, WNT, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+        lfi_set_error("lfi_gemm_planes: cannot reserve %zu bytes of LDS", lds);
+        return LFI_ERR_LAUNCH;
+      }
+      attrd16 = true;
+    }
+    hipLaunchKernelGGL((gemm_planes16_kernel<false, WMT, WNT, 3>), grid, dim3(512), lds, st, a);
   } else if (!at && !bt && planes16_ok(a)) {
     static bool attr16 = false;
     if (!attr16) {

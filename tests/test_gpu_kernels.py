@@ -509,6 +509,43 @@ def test_gemm_planes_emits_its_result_as_planes(eng, gpu_device, M, N, K, batch)
             assert rel_err(o1, rc @ X.double()) < 3e-5 and rel_err(o2, rc.t() @ Y.double()) < 3e-5
 
 
+@pytest.mark.parametrize("M,N,K", [(700, 512, 96), (513, 544, 64), (1792, 8192, 896), (40, 48, 32)])
+@pytest.mark.parametrize("hi_only", [False, True])
+def test_gemm_planes_direct_plane_epilogue(eng, gpu_device, monkeypatch, M, N, K, hi_only):
+    """The cond_transform forward product's epilogue (planes out, bias + LeakyReLU, no fp32 rows) without the LDS round trip:
+    the 16 x 16 x 32 kernel computes the product transposed so that a lane holds four consecutive columns of a row and writes
+    8 bytes per plane itself (gemm_epilogue_direct16). Same products, same sums: the emitted planes equal the through-LDS
+    epilogue's (LFI_PGEMM_DIRECT=0) bit for bit - ragged M, N not a multiple of the tile, zero rows / columns inside the last
+    blocks, hi planes only - and what lfi_planes_from_f32 makes of the fp32 result."""
+    g = torch.Generator().manual_seed(M + N + K)
+    A = torch.randn(M, K, generator=g).to(gpu_device)
+    W = torch.randn(N, K, generator=g).to(gpu_device)
+    bias = torch.randn(N, generator=g).to(gpu_device)
+    Ap, nka = eng.planes("test.pa", A, K, M, K)
+    Wp, nkw = eng.planes("test.pw", W, K, N, K)
+    ref = torch.empty(M, N, device=gpu_device)
+    eng.gemm_planes(M, N, K, Ap, nka, Wp, nkw, ref, N, bias=bias, act=1)
+    want, nkr = eng.planes("test.wr", ref, N, M, N)
+    want = want.clone()
+    n_el = eng.L.lfi_planes_elems(M, N)
+    outs = []
+    for direct in ("1", "0"):
+        monkeypatch.setenv("LFI_PGEMM_DIRECT", direct)
+        Cr = torch.full((want.numel(),), float("nan"), dtype=torch.bfloat16, device=gpu_device)
+        eng.gemm_planes(M, N, K, Ap, nka, Wp, nkw, None, N, bias=bias, act=1, store=False, Cr=Cr, cr_nkt=nkr, hi_only=hi_only)
+        torch.cuda.synchronize()
+        outs.append(Cr)
+    a, b = outs
+    nblk = (M + 31) // 32 * nkr                       # blocks of the row tiles that exist
+    av = a[:nblk * 1024].view(-1, 2, 512).view(torch.int16)
+    bv = b[:nblk * 1024].view(-1, 2, 512).view(torch.int16)
+    wv = want[:nblk * 1024].view(-1, 2, 512).view(torch.int16)
+    npl = 1 if hi_only else 2
+    assert torch.equal(av[:, :npl], bv[:, :npl])
+    assert torch.equal(av[:, :npl], wv[:, :npl])
+    assert n_el >= nblk * 1024
+
+
 @pytest.mark.parametrize("M,N,K,splitk", [(768, 256, 9000, 4), (384, 128, 2049, 1), (768, 52, 4100, 3)])
 def test_gemm_with_a_bf16_operand(eng, gpu_device, M, N, K, splitk):
     """lfi_gemm_desc.a_bf16 (the window encoders' bf16 gradient stash as the A operand of dW_hh = dgh^T hseq, glow/models.py:60-64
