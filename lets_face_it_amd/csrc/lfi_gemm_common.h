@@ -350,7 +350,13 @@ __device__ __forceinline__ void gemm_epilogue_direct16(const GemmArgs& g, const 
     bv[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     if (bias && col < g.N) bv[j] = *reinterpret_cast<const f32x4*>(bias + col);
   }
-  static_assert(MODE == 3, "plane outputs only");
+  static_assert(MODE == 3 || MODE == 4, "plane outputs only");
+  // MODE 4 (the in-place dpre product): + the act-2 mask read from the hi plane of Gr at the element's own place (8 bytes per lane:
+  // only the signs are used), + per-wave column sums of the stored values (the wave's 64 rows are one "pass" of the 128-row tile:
+  // partial row 2 (m0 / 128) + wm of colpart, the layout the through-LDS epilogue fills; sums over rows in another order)
+  f32x4 csum[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) csum[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
   {
     const long gcol0 = g.colCr + (long)batch * g.strideC + c0;      // multiple of 16 (colCr, strideC, c0 are)
 #pragma unroll
@@ -361,15 +367,29 @@ __device__ __forceinline__ void gemm_epilogue_direct16(const GemmArgs& g, const 
       const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(g.Cr) + (rt * g.nktCr + (gcol0 >> 4)) * 2048, 0,
                                                                          0x7fffffff, 0x00020000);
       const unsigned voff = (unsigned)(lfi_u_plane_offset(16 * (i & 1) + l15, g4 >> 1) + (g4 & 1) * 8);
+      __amdgpu_buffer_rsrc_t rg = rs;
+      if constexpr (MODE == 4) {
+        const long ggcol0 = g.colGr + (long)batch * g.strideC + c0;
+        rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(reinterpret_cast<const char*>(g.Gr)) + (rt * g.nktGr + (ggcol0 >> 4)) * 2048, 0,
+                                               0x7fffffff, 0x00020000);
+      }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int col = c0 + 16 * j + 4 * g4;
         f32x4 v = acc[i][j] + bv[j];
-        if (g.act == 1) {
+        if constexpr (MODE == 4) {
+          gu32x2 m2 = {0u, 0u};
+          if (blk && c0 + 16 * j < g.N) m2 = __builtin_amdgcn_raw_buffer_load_b64(rg, voff, 2048 * j, 0);
+          const float o0 = __builtin_bit_cast(float, m2[0] << 16), o1 = __builtin_bit_cast(float, m2[0] & 0xffff0000u);
+          const float o2 = __builtin_bit_cast(float, m2[1] << 16), o3 = __builtin_bit_cast(float, m2[1] & 0xffff0000u);
+          v[0] = o0 > 0.0f ? v[0] : v[0] * g.slope; v[1] = o1 > 0.0f ? v[1] : v[1] * g.slope;
+          v[2] = o2 > 0.0f ? v[2] : v[2] * g.slope; v[3] = o3 > 0.0f ? v[3] : v[3] * g.slope;
+        } else if (g.act == 1) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.0f ? v[r] : v[r] * g.slope;
         }
         if (row >= g.M || col >= g.N) v = (f32x4){0.f, 0.f, 0.f, 0.f};   // inside an existing block: zeros (k of a later product)
+        if constexpr (MODE == 4) csum[j] += v;
         uint2 h, l;
         split2(v[0], v[1], &h.x, &l.x);
         split2(v[2], v[3], &h.y, &l.y);
@@ -377,6 +397,22 @@ __device__ __forceinline__ void gemm_epilogue_direct16(const GemmArgs& g, const 
           __builtin_amdgcn_raw_buffer_store_b64((gu32x2){h.x, h.y}, rs, voff, 2048 * j, 2);
           if (!g.hiOnly) __builtin_amdgcn_raw_buffer_store_b64((gu32x2){l.x, l.y}, rs, voff, 2048 * j + 1024, 2);
         }
+      }
+    }
+  }
+  if constexpr (MODE == 4) {
+    if (g.colpart) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        f32x4 v = csum[j];
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] += __shfl_xor(v[r], o, 64);
+        }
+        const int col = c0 + 16 * j + 4 * g4;
+        if (l15 == 0 && col < g.N)
+          *reinterpret_cast<f32x4*>(g.colpart + ((long)(m0 >> 7) * 2 + wm) * g.ldpart + (long)batch * g.strideC + col) = v;
       }
     }
   }

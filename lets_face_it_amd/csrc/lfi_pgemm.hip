@@ -384,7 +384,7 @@ __global__ __launch_bounds__(512, 4) void gemm_planes16_kernel(GemmArgs g) {
 // source address); lane 16 g + 4 q + p of ds_read_b64_tr_b16 addresses k row 16 (g & 1) + 8 (g >> 1) + q (then + 4), columns 4 p .. + 3:
 // the same k assignment as the row-use read (k-tile g & 1, chunk g >> 1), and the two 16-lane groups of a 32-lane half land in
 // opposite halves of the 256-byte bank row.
-template <bool AT, bool COLP, int WMT, int WNT>
+template <bool AT, bool COLP, int WMT, int WNT, int TRP = 0>
 __global__ __launch_bounds__(512, 4) void gemm_planes16t_kernel(GemmArgs g) {
   constexpr int NA = 4 * WMT, NY = WNT / 2;   // A blocks per sub-slot; DMA pieces per wave of the lo sub-slot (its 4 WNT B blocks)
   static_assert(WMT * WNT == 8 && NA + 4 * WNT == 24, "eight waves, 24 blocks per slot");
@@ -487,7 +487,7 @@ __global__ __launch_bounds__(512, 4) void gemm_planes16t_kernel(GemmArgs g) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = PG_MFMA16(ah[i], bh[j], acc[i][j]);
+        for (int j = 0; j < 4; ++j) acc[i][j] = PG_MFMA16X(ah[i], bh[j], acc[i][j]);
         __builtin_amdgcn_sched_barrier(0);
         bl[i] = fragB(sy, i);
         __builtin_amdgcn_sched_barrier(0);
@@ -501,7 +501,7 @@ __global__ __launch_bounds__(512, 4) void gemm_planes16t_kernel(GemmArgs g) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = PG_MFMA16(ah[i], bl[j], acc[i][j]);
+        for (int j = 0; j < 4; ++j) acc[i][j] = PG_MFMA16X(ah[i], bl[j], acc[i][j]);
         __builtin_amdgcn_sched_barrier(0);
         if (i == 0) {
 #pragma unroll
@@ -524,9 +524,15 @@ __global__ __launch_bounds__(512, 4) void gemm_planes16t_kernel(GemmArgs g) {
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   }
-  __syncthreads();
-  gemm_epilogue_wide<64 * WNT, 512, 2, COLP, true, true>(g, acc, reinterpret_cast<float*>(xsmem), WNT == 4 ? 64 : 128, m0, n0, wm, wn,
-                                                         lane & 31, lane >> 5, batch, split, 64 * WMT);
+  if constexpr (TRP != 0) {
+    int lanez = lane, m0z = m0, n0z = n0;
+    asm volatile("" : "+v"(lanez), "+s"(m0z), "+s"(n0z));
+    gemm_epilogue_direct16<TRP>(g, acc, m0z, n0z, wm, wn, lanez, batch, split);
+  } else {
+    __syncthreads();
+    gemm_epilogue_wide<64 * WNT, 512, 2, COLP, true, true>(g, acc, reinterpret_cast<float*>(xsmem), WNT == 4 ? 64 : 128, m0, n0, wm, wn,
+                                                           lane & 31, lane >> 5, batch, split, 64 * WMT);
+  }
 }
 
 // fp32 (rows x cols, row pitch ldx) -> bf16 hi / lo planes, zero padded to rows_pad x 16 nkt: block ((rt * nkt + kt) * 2 + plane),
@@ -584,6 +590,14 @@ int planes16_direct_mode(const GemmArgs& a) {
   return 0;
 }
 
+// MODE 4 of the direct epilogue: plane outputs only, act 2 with the mask in planes, column sums, 128 x 256 tiles
+bool planes16_direct_mask_ok(const GemmArgs& a) {
+  const char* e = getenv("LFI_PGEMM_DIRECT");
+  if (e && e[0] == '0') return false;
+  return a.vecC && a.act == 2 && a.Gr && !a.G && a.accumulate == 0 && a.colpart && a.splitk == 1 && a.Cr && !a.storeC && !a.bias &&
+         (a.N & 3) == 0 && (a.strideC & 31) == 0 && (a.colCr & 15) == 0 && (a.colGr & 15) == 0 && (a.ldpart & 3) == 0;
+}
+
 template <bool COLP, int WMT, int WNT>
 int launch_planes(const GemmArgs& a, int at, int bt, dim3 grid, size_t lds, hipStream_t st) {
   static bool attr = false;
@@ -609,7 +623,17 @@ int launch_planes(const GemmArgs& a, int at, int bt, dim3 grid, size_t lds, hipS
       }
       attr16t = true;
     }
-    if (at) hipLaunchKernelGGL((gemm_planes16t_kernel<true, COLP, WMT, WNT>), grid, dim3(512), lds, st, a);
+    if (COLP && WMT == 2 && !at && planes16_direct_mask_ok(a)) {   // the in-place dpre product: planes + mask from planes + column sums
+      static bool attr4 = false;
+      if (!attr4) {
+        if (hipFuncSetAttribute((const void*)gemm_planes16t_kernel<false, true, 2, 4, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+          lfi_set_error("lfi_gemm_planes: cannot reserve %zu bytes of LDS", lds);
+          return LFI_ERR_LAUNCH;
+        }
+        attr4 = true;
+      }
+      hipLaunchKernelGGL((gemm_planes16t_kernel<false, true, 2, 4, 4>), grid, dim3(512), lds, st, a);
+    } else if (at) hipLaunchKernelGGL((gemm_planes16t_kernel<true, COLP, WMT, WNT>), grid, dim3(512), lds, st, a);
     else hipLaunchKernelGGL((gemm_planes16t_kernel<false, COLP, WMT, WNT>), grid, dim3(512), lds, st, a);
   } else if (!at && !bt && planes16_ok(a) && !COLP && planes16_direct_mode(a)) {
     static bool attrd16 = false;

@@ -546,6 +546,45 @@ def test_gemm_planes_direct_plane_epilogue(eng, gpu_device, monkeypatch, M, N, K
     assert n_el >= nblk * 1024
 
 
+@pytest.mark.parametrize("M,N,K,batch", [(700, 512, 384, 1), (1792, 512, 384, 4), (333, 64, 96, 2)])
+def test_gemm_planes_direct_epilogue_of_the_dpre_product(eng, gpu_device, monkeypatch, M, N, K, batch):
+    """The in-place dpre product's epilogue without the LDS round trip (gemm_epilogue_direct16<4>; glow/models.py:187-190 backward):
+    two products, A by rows, B transposed, LeakyReLU-gradient mask read from the hi plane of the planes it overwrites, hi planes
+    out, per-wave column sums (the cond_transform bias gradient). Against the through-LDS epilogue (LFI_PGEMM_DIRECT=0): planes
+    bit for bit (same products, same sums), column sums to fp32 rounding (another order over the rows)."""
+    g = torch.Generator().manual_seed(M + N + K + batch)
+    Ncols = batch * N
+    A = torch.randn(M, batch * K, generator=g).to(gpu_device)          # dgi: batch entry b = columns [b K, (b + 1) K)
+    W = torch.randn(batch * K, N, generator=g).to(gpu_device)          # W_c[b]: K x N, its ROWS are the contraction index
+    Gm = torch.randn(M, Ncols, generator=g).to(gpu_device)             # c: its sign gates the result; overwritten by it
+    Ap, nka = eng.planes("test.pa", A, batch * K, M, batch * K)
+    Wp, nkw = eng.planes("test.pw", W, N, batch * K, N)
+    outs = []
+    eng.pass_skip = {"t": 1}
+    try:
+        for direct in ("1", "0"):
+            monkeypatch.setenv("LFI_PGEMM_DIRECT", direct)
+            Gp, nkg = eng.planes("test.pg", Gm, Ncols, M, Ncols)           # fresh planes of c every time: the product runs in place
+            sums = torch.zeros(Ncols, device=gpu_device)
+            done = eng.gemm_planes(M, N, K, Ap, nka, Wp, nkw, None, Ncols, act=2, slope=0.01, batch=batch, b_fmt=1,
+                                   a_stride=(K // 16) * 1024, b_stride=(K // 32) * nkw * 1024, sC=N, store=False,
+                                   Gr=Gp, gr_nkt=nkg, Cr=Gp, cr_nkt=nkg, hi_only=True, colsum_into=sums, cls="t")
+            torch.cuda.synchronize()
+            assert done
+            outs.append((Gp.clone(), sums))
+    finally:
+        eng.pass_skip = {}
+    (pa, sa), (pb, sb) = outs
+    nblk = (M + 31) // 32 * nkg
+    assert torch.equal(pa[:nblk * 1024].view(-1, 2, 512)[:, 0].view(torch.int16), pb[:nblk * 1024].view(-1, 2, 512)[:, 0].view(torch.int16))
+    ref = torch.zeros(M, Ncols, dtype=torch.float64)
+    for b in range(batch):
+        ref[:, b * N:(b + 1) * N] = A[:, b * K:(b + 1) * K].bfloat16().double().cpu() @ W[b * K:(b + 1) * K].double().cpu()
+    ref = torch.where(Gm.cpu().bfloat16().double() > 0, ref, 0.01 * ref)
+    assert rel_err(sa, ref.sum(0)) < 2e-4 and rel_err(sb, ref.sum(0)) < 2e-4
+    assert float((sa - sb).abs().max()) <= 1e-5 * max(1.0, float(sb.abs().max()))
+
+
 @pytest.mark.parametrize("M,N,K,splitk", [(768, 256, 9000, 4), (384, 128, 2049, 1), (768, 52, 4100, 3)])
 def test_gemm_with_a_bf16_operand(eng, gpu_device, M, N, K, splitk):
     """lfi_gemm_desc.a_bf16 (the window encoders' bf16 gradient stash as the A operand of dW_hh = dgh^T hseq, glow/models.py:60-64
