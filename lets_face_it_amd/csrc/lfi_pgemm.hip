@@ -34,6 +34,12 @@
 // Epilogue (gemm_epilogue_wide<.., PL = true>): besides / instead of fp32 rows the result tile can leave as planes of either
 // format, and the act == 2 operand (cond_transform's LeakyReLU mask) can be read from the hi plane of its row planes.
 // History (rounds 1-2: 256 x 256 one-per-CU and four-wave 128 x 64-patch variants, ingredient-removal builds, stamps): DESIGN.md.
+// Round 4: the kernel below (v_mfma_f32_32x32x16_bf16, one k-tile per phase) is the GENERAL member of the family. The step's six
+// products run on two siblings further down that take k-tiles in pairs on v_mfma_f32_16x16x32_bf16 - gemm_planes16_kernel (both
+// operands by rows, three products: cond_transform forward, gic) and gemm_planes16t_kernel (two products, B transposed: dW_c, dpre,
+// the cond_transform weight gradient, the feature gradient) - whenever K has whole pairs of k-tiles in every split; the two whose
+// result leaves as planes only write them straight from the accumulators (gemm_epilogue_direct16). LFI_PGEMM_16 / _16T / _DIRECT = 0
+// bring this kernel and the through-LDS epilogue back.
 #include "lfi_gemm_common.h"
 #include <type_traits>
 
