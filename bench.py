@@ -307,7 +307,8 @@ def _roofline(spec, F, timing, precision):
         # 32 x 32 x 16 kernel; LFI_PGEMM_16=0 pins the latter)
         peak, mult = BF16_MFMA_PEAK_TFLOPS, 3.0
         pairs = ((spec.ldf + 15) // 16) % 2 == 0 and os.environ.get("LFI_PGEMM_16", "1") != "0"
-        kern = "gemm_planes16_kernel<false, 2, 4>" if pairs else "gemm_planes_kernel<false, false, false, 2, 4>"
+        # (name prefix as rocprofv3 prints it; the 16 x 16 x 32 kernel carries one more template argument: its epilogue form)
+        kern = "gemm_planes16_kernel<false, 2, 4" if pairs else "gemm_planes_kernel<false, false, false, 2, 4>"
         tile, threads = 128, 512
         tile_n = 256
     elif precision == "bf16x3":
@@ -331,7 +332,7 @@ def _roofline(spec, F, timing, precision):
                 traffic, traffic_src = v["hbm_bytes"], "profiles/pmc_traffic_%s.json (%s)" % (precision, tj["source"])
     except (OSError, ValueError, KeyError):
         pass
-    return {"bound": "mfma", "kernel": kern + " cond_transform forward (F x Ks*D x Ef)",
+    return {"bound": "mfma", "kernel": kern + ("" if kern.endswith(">") else ", ...>") + " cond_transform forward (F x Ks*D x Ef)",
             "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic,
             "traffic_unit": "bytes per launch (HBM read + write)", "traffic_source": traffic_src,
             "algorithmic_bytes_per_launch": 4.0 * (F * spec.ldf + KD * spec.ldf + F * KD),
