@@ -35,9 +35,10 @@
 // format, and the act == 2 operand (cond_transform's LeakyReLU mask) can be read from the hi plane of its row planes.
 // History (rounds 1-2: 256 x 256 one-per-CU and four-wave 128 x 64-patch variants, ingredient-removal builds, stamps): DESIGN.md.
 // Round 4: the kernel below (v_mfma_f32_32x32x16_bf16, one k-tile per phase) is the GENERAL member of the family. The step's six
-// products run on two siblings further down that take k-tiles in pairs on v_mfma_f32_16x16x32_bf16 - gemm_planes16_kernel (both
-// operands by rows, three products: cond_transform forward, gic) and gemm_planes16t_kernel (two products, B transposed: dW_c, dpre,
-// the cond_transform weight gradient, the feature gradient) - whenever K has whole pairs of k-tiles in every split; the two whose
+// products run on two siblings further down that take k-tiles in pairs on v_mfma_f32_16x16x32_bf16 - gemm_planes16_kernel (three
+// products, either operand by rows or transposed: cond_transform forward, gic; the backward products when they take three) and
+// gemm_planes16t_kernel (two products, B transposed: dW_c, dpre, the cond_transform weight gradient, the feature gradient) -
+// whenever K has whole pairs of k-tiles in every split; the two whose
 // result leaves as planes only write them straight from the accumulators (gemm_epilogue_direct16). LFI_PGEMM_16 / _16T / _DIRECT = 0
 // bring this kernel and the through-LDS epilogue back.
 #include "lfi_gemm_common.h"
@@ -243,7 +244,10 @@ __global__ __launch_bounds__(512, 4) void gemm_planes_kernel(GemmArgs g) {
 // TRP != 0: the product is computed transposed (B fragments as the MFMA's A operand: the same products, the same sums) so that a lane
 // holds four consecutive columns of a row and the epilogue needs no LDS (gemm_epilogue_direct16<3>: plane outputs); the launcher takes it whenever the epilogue is one it covers.
 #define PG_MFMA16X(a, b, c) (TRP ? PG_MFMA16(b, a, c) : PG_MFMA16(a, b, c))
-template <bool COLP, int WMT, int WNT, int TRP = 0>
+// AT / BT: that operand in transposed use (a pair of k-tiles is then ONE 32-row block of its buffer; DMA row swap and
+// ds_read_b64_tr_b16 as in gemm_planes16t_kernel below) - the three-product form of the weight-gradient and feature-gradient
+// products (engine_backward_products = 3: small batches, three_products_everywhere).
+template <bool AT, bool BT, bool COLP, int WMT, int WNT, int TRP = 0>
 __global__ __launch_bounds__(512, 4) void gemm_planes16_kernel(GemmArgs g) {
   constexpr int NA = 4 * WMT;   // A blocks per sub-slot (2 WMT mn tiles x 2 k-tiles); B: 4 WNT
   static_assert(WMT * WNT == 8 && NA + 4 * WNT == 24, "eight waves, 24 blocks per slot");
@@ -256,42 +260,58 @@ __global__ __launch_bounds__(512, 4) void gemm_planes16_kernel(GemmArgs g) {
   const int kt0 = split * ktc;
   const int npair = max(min(g.nkt - kt0, ktc), 0) >> 1;
   char* lds = reinterpret_cast<char*>(xsmem);
-  // LDS-DMA through buffer descriptors (one per operand panel, built from workgroup-uniform values): a piece's source is
-  // descriptor + SGPR offset + ONE per-lane VGPR (16 lane) - no 64-bit per-lane pointers in the loop
-  const char* baseA = reinterpret_cast<const char*>(g.Ap + batch * g.pstrideA) + (long)(tm * 2 * WMT) * g.nktA * 2048 + (long)kt0 * 2048;
-  const char* baseB = reinterpret_cast<const char*>(g.Bp + batch * g.pstrideB) + (long)(tn * 2 * WNT) * g.nktB * 2048 + (long)kt0 * 2048;
-  const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(baseA), 0, 0x7fffffff, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(baseB), 0, 0x7fffffff, 0x00020000);
-  const int lane16 = lane * 16;
-  // this wave's three blocks of a sub-slot; sof: the block's lo (A) / hi (B) plane in pair 0, i.e. its place in sub-slot 0;
-  // flip: what the odd sub-slots add (A: back to hi, B: on to lo)
-  int sof[3], doff[3], flip[3];
-  bool pieceB[3];
+  const long rowA = (long)g.nktA * 2048, rowB = (long)g.nktB * 2048;   // bytes per row tile of either plane buffer
+  // LDS-DMA through buffer descriptors built from workgroup-uniform values (panel base + the pair's offset: + 4096 per pair in
+  // row use - k-tiles are column tiles -, + a row tile per pair in transposed use) + an SGPR offset + ONE per-lane VGPR
+  const char* baseA = reinterpret_cast<const char*>(g.Ap + batch * g.pstrideA) +
+                      (AT ? (long)(tm * 2 * WMT) * 4096 + (long)(kt0 >> 1) * rowA : (long)(tm * 2 * WMT) * rowA + (long)kt0 * 2048);
+  const char* baseB = reinterpret_cast<const char*>(g.Bp + batch * g.pstrideB) +
+                      (BT ? (long)(tn * 2 * WNT) * 4096 + (long)(kt0 >> 1) * rowB : (long)(tn * 2 * WNT) * rowB + (long)kt0 * 2048);
+  // per-lane source offset inside a block: as it lies (row use), or with rows 16-19 <-> 20-23, 24-27 <-> 28-31 swapped (transposed)
+  const int prow = lane >> 1, srow = prow ^ ((prow & 16) ? 4 : 0);
+  const int laneR = lane * 16, laneT = srow * 32 + (lane & 1) * 16;
+  // this wave's three blocks of a sub-slot: piece i = block 8 i + wave (which operand a piece belongs to is a compile-time fact);
+  // sof: the block's lo (A) / hi (B) plane, i.e. its place in sub-slot 0; the odd sub-slots flip A back to hi and B on to lo
+  int sof[3], doff[3];
 #pragma unroll
   for (int i = 0; i < 3; ++i) {
-    const int j = wave * 3 + i;                       // block 0 .. 23 of the sub-slot
-    const int isB = j >= NA, jj = isB ? j - NA : j;   // (mn tile, k-tile of the pair) = (jj >> 1, jj & 1)
-    const int mt = jj >> 1;
-    sof[i] = (isB ? mt * g.nktB * 2048 : mt * g.nktA * 2048 + 1024) + (jj & 1) * 2048;
-    flip[i] = isB ? 1024 : -1024;
-    pieceB[i] = isB != 0;
+    const int j = 8 * i + wave;
+    const bool isB = 8 * i >= NA;
+    const int jj = isB ? j - NA : j;   // (mn tile, half) = (jj >> 1, jj & 1): half = k-tile of the pair (row use) / column tile (transposed)
+    const int mt = jj >> 1, h = jj & 1;
+    const bool tr = isB ? BT : AT;
+    sof[i] = (tr ? mt * 4096 : mt * (int)(isB ? rowB : rowA)) + h * 2048 + (isB ? 0 : 1024);
     doff[i] = j * 1024;
   }
+#define PG_RSRC(ptr) __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(ptr), 0, 0x7fffffff, 0x00020000)
   auto dma = [&](int ph, int slot) {   // sub-slot ph of the ring (past the end: the last pair's again, never used)
-    const int ko = max(min(ph >> 1, npair - 1), 0) * 4096;
+    const int pp = max(min(ph >> 1, npair - 1), 0);
+    const char* pa = baseA + (AT ? pp * rowA : (long)pp * 4096);
+    const char* pb = baseB + (BT ? pp * rowB : (long)pp * 4096);
 #pragma unroll
-    for (int i = 0; i < 3; ++i)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(pieceB[i] ? rsB : rsA, (plds_void*)(lds + slot * QSLOT + doff[i]), 16, lane16,
-                                           sof[i] + ko + ((ph & 1) ? flip[i] : 0), 0, 0);
+    for (int i = 0; i < 3; ++i) {
+      const bool isB = 8 * i >= NA;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(PG_RSRC(isB ? pb : pa), (plds_void*)(lds + slot * QSLOT + doff[i]), 16,
+                                               (isB ? BT : AT) ? laneT : laneR, sof[i] + ((ph & 1) ? (isB ? 1024 : -1024) : 0), 0, 0);
+    }
   };
+#undef PG_RSRC
   const int wm = wave / WNT, wn = wave % WNT;
-  const int g4 = lane >> 4;
-  const int fo = (g4 & 1) * 1024 + lfi_u_plane_offset(lane & 15, g4 >> 1);   // 16-row tile 1 of a block: + 512
-  // (the ring position is a compile-time constant below: every fragment read is one of two VGPR addresses + an immediate)
-  const char* ldsA = lds + (wm * 4) * 1024 + fo;
-  const char* ldsB = lds + NA * 1024 + (wn * 4) * 1024 + fo;
-  auto fragA = [&](int slot, int i) { return *reinterpret_cast<const bf16x8*>(ldsA + slot * QSLOT + (i >> 1) * 2048 + (i & 1) * 512); };
-  auto fragB = [&](int slot, int i) { return *reinterpret_cast<const bf16x8*>(ldsB + slot * QSLOT + (i >> 1) * 2048 + (i & 1) * 512); };
+  const int g4 = lane >> 4, tq = (lane >> 2) & 3, tp = lane & 3;
+  const int fo = (g4 & 1) * 1024 + lfi_u_plane_offset(lane & 15, g4 >> 1);   // row use: 16-row tile 1 of a block pair: + 512
+  const int kr = 16 * (g4 & 1) + 8 * (g4 >> 1) + tq;                           // transposed use: k row of this lane's first read
+  const int toff = (kr ^ ((kr & 16) ? 4 : 0)) * 32 + (((tp >> 1) ^ ((kr >> 3) & 1)) << 4) + (tp & 1) * 8;
+  // (the ring position is a compile-time constant below: every fragment read is a VGPR address + an immediate)
+  const char* ldsA = lds + (wm * 4) * 1024;
+  const char* ldsB = lds + NA * 1024 + (wn * 4) * 1024;
+  auto fragA = [&](int slot, int i) -> bf16x8 {
+    if constexpr (AT) return pg_frag<true>(ldsA + slot * QSLOT + i * 1024, 0, toff);
+    else return *reinterpret_cast<const bf16x8*>(ldsA + slot * QSLOT + (i >> 1) * 2048 + (i & 1) * 512 + fo);
+  };
+  auto fragB = [&](int slot, int i) -> bf16x8 {
+    if constexpr (BT) return pg_frag<true>(ldsB + slot * QSLOT + i * 1024, 0, toff);
+    else return *reinterpret_cast<const bf16x8*>(ldsB + slot * QSLOT + (i >> 1) * 2048 + (i & 1) * 512 + fo);
+  };
 
   f32x4 acc[4][4];
 #pragma unroll
@@ -570,7 +590,7 @@ __global__ __launch_bounds__(256) void planes_from_f32_kernel(const float* __res
   }
 }
 
-// the 16 x 16 x 32 kernel: both operands by rows, three products, whole pairs of k-tiles in every split, the through-LDS epilogue (LFI_PGEMM_16=0:
+// the three-product 16 x 16 x 32 kernel: whole pairs of k-tiles in every split, the through-LDS or the direct plane epilogue (LFI_PGEMM_16=0:
 // the 32 x 32 x 16 kernel everywhere)
 bool planes16_ok(const GemmArgs& a) {
   const char* e = getenv("LFI_PGEMM_16");   // (read per call: the tests compare the two kernels)
@@ -644,23 +664,30 @@ int launch_planes(const GemmArgs& a, int at, int bt, dim3 grid, size_t lds, hipS
   } else if (!at && !bt && planes16_ok(a) && !COLP && planes16_direct_mode(a)) {
     static bool attrd16 = false;
     if (!attrd16) {
-      if (hipFuncSetAttribute((const void*)gemm_planes16_kernel<false, WMT, WNT, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+      if (hipFuncSetAttribute((const void*)gemm_planes16_kernel<false, false, false, WMT, WNT, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
         lfi_set_error("lfi_gemm_planes: cannot reserve %zu bytes of LDS", lds);
         return LFI_ERR_LAUNCH;
       }
       attrd16 = true;
     }
-    hipLaunchKernelGGL((gemm_planes16_kernel<false, WMT, WNT, 3>), grid, dim3(512), lds, st, a);
-  } else if (!at && !bt && planes16_ok(a)) {
+    hipLaunchKernelGGL((gemm_planes16_kernel<false, false, false, WMT, WNT, 3>), grid, dim3(512), lds, st, a);
+  } else if (planes16_ok(a)) {   // three products, any use of either operand
     static bool attr16 = false;
     if (!attr16) {
-      if (hipFuncSetAttribute((const void*)gemm_planes16_kernel<COLP, WMT, WNT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+      bool ok = hipFuncSetAttribute((const void*)gemm_planes16_kernel<false, false, COLP, WMT, WNT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
+      ok = ok && hipFuncSetAttribute((const void*)gemm_planes16_kernel<false, true, COLP, WMT, WNT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
+      ok = ok && hipFuncSetAttribute((const void*)gemm_planes16_kernel<true, false, COLP, WMT, WNT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
+      ok = ok && hipFuncSetAttribute((const void*)gemm_planes16_kernel<true, true, COLP, WMT, WNT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess;
+      if (!ok) {
         lfi_set_error("lfi_gemm_planes: cannot reserve %zu bytes of LDS", lds);
         return LFI_ERR_LAUNCH;
       }
       attr16 = true;
     }
-    hipLaunchKernelGGL((gemm_planes16_kernel<COLP, WMT, WNT>), grid, dim3(512), lds, st, a);
+    if (!at && !bt) hipLaunchKernelGGL((gemm_planes16_kernel<false, false, COLP, WMT, WNT>), grid, dim3(512), lds, st, a);
+    else if (!at) hipLaunchKernelGGL((gemm_planes16_kernel<false, true, COLP, WMT, WNT>), grid, dim3(512), lds, st, a);
+    else if (!bt) hipLaunchKernelGGL((gemm_planes16_kernel<true, false, COLP, WMT, WNT>), grid, dim3(512), lds, st, a);
+    else hipLaunchKernelGGL((gemm_planes16_kernel<true, true, COLP, WMT, WNT>), grid, dim3(512), lds, st, a);
   } else if (!at && !bt) hipLaunchKernelGGL((gemm_planes_kernel<false, false, COLP, WMT, WNT>), grid, dim3(512), lds, st, a);
   else if (!at) hipLaunchKernelGGL((gemm_planes_kernel<false, true, COLP, WMT, WNT>), grid, dim3(512), lds, st, a);
   else if (!bt) hipLaunchKernelGGL((gemm_planes_kernel<true, false, COLP, WMT, WNT>), grid, dim3(512), lds, st, a);

@@ -322,11 +322,13 @@ def test_gemm_on_presplit_planes_batched_k_ranges(eng, gpu_device):
 @pytest.mark.parametrize("shape", [(700, 520, 330), (384, 512, 14336), (513, 257, 75), (130, 40, 16), (1024, 896, 2048)])
 @pytest.mark.parametrize("fmt", ["RT", "TR", "TT"])
 @pytest.mark.parametrize("splitk,tile", [(1, 1), (3, 1), (1, 2), (2, 2)])
-def test_gemm_planes_kmajor_operands_and_split_k(eng, gpu_device, shape, fmt, splitk, tile):
+def test_gemm_planes_kmajor_operands_and_split_k(eng, gpu_device, monkeypatch, shape, fmt, splitk, tile):
     """Planes in TRANSPOSED use (a_fmt / b_fmt = 1: the matrix' ROWS are the contraction index - every weight-gradient product sums
     over frames) in either operand slot, read with ds_read_b64_tr_b16, with and without a K split:
     against the fp64 product and, bit for bit, against lfi_gemm_f32's bf16x3 kernel on the same fp32 operands (same split, same
-    products, same order - with a K split only when both split the same way, so that case is checked against fp64 alone)."""
+    products, same order - with a K split only when both split the same way, so that case is checked against fp64 alone).
+    Both kernels: the 32 x 32 x 16 one (LFI_PGEMM_16=0: the bitwise comparison) and, where K has whole pairs of k-tiles, the
+    16 x 16 x 32 one (default; equal to the other to fp32 rounding)."""
     M, N, K = shape
     g = torch.Generator().manual_seed(M + 3 * N + 7 * K)
     r4 = lambda v: (v + 3) // 4 * 4  # noqa: E731
@@ -351,6 +353,9 @@ def test_gemm_planes_kmajor_operands_and_split_k(eng, gpu_device, shape, fmt, sp
     Ap, nka = eng.planes("test.pa", A, lda, K, M) if at else eng.planes("test.pa", A, lda, M, K)
     Bp, nkb = eng.planes("test.pb", Bm, ldb, K, N) if bt else eng.planes("test.pb", Bm, ldb, N, K)
     # tile 1: 128 x 256 tiles, 2: 256 x 128 (what the library picks for N = 384 or 896)
+    C16 = torch.full((M, ldc), 7.0, device=gpu_device)
+    eng.gemm_planes(M, N, K, Ap, nka, Bp, nkb, C16, ldc, bias=bias, act=1, a_fmt=int(at), b_fmt=int(bt), splitk=splitk, tile=tile)
+    monkeypatch.setenv("LFI_PGEMM_16", "0")
     eng.gemm_planes(M, N, K, Ap, nka, Bp, nkb, C1, ldc, bias=bias, act=1, a_fmt=int(at), b_fmt=int(bt), splitk=splitk, tile=tile)
     C2 = torch.full((M, ldc), 7.0, device=gpu_device)
     eng.precision = 0x11
@@ -362,8 +367,9 @@ def test_gemm_planes_kmajor_operands_and_split_k(eng, gpu_device, shape, fmt, sp
     Ad = (A[:, :M].t() if at else A[:, :K]).double()
     Bd = (Bm[:, :N] if bt else Bm[:, :K].t()).double()
     ref = torch.nn.functional.leaky_relu(Ad @ Bd + bias.double(), 0.01)
-    assert bool((C1[:, N:] == 7.0).all()), "wrote outside the N columns"
-    assert rel_err(C1[:, :N], ref) < 3e-5
+    assert bool((C1[:, N:] == 7.0).all()) and bool((C16[:, N:] == 7.0).all()), "wrote outside the N columns"
+    assert rel_err(C1[:, :N], ref) < 3e-5 and rel_err(C16[:, :N], ref) < 3e-5
+    assert rel_err(C16[:, :N], C1[:, :N]) < 2e-6
     if splitk == 1:
         assert torch.equal(C1, C2)
 
