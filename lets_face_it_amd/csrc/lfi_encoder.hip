@@ -260,6 +260,50 @@ __global__ __launch_bounds__(256) void enc_scatter_kernel(EncArgs a, float* __re
     }
 }
 
+// The same sums for the bf16 compact stash with hid % 8 == 0: 8 values per thread through ONE 16-byte load, and as many frame rows
+// per workgroup as 256 threads hold (3 hid / 8 threads per row). Same products, same order over s: bit-identical to the kernel above.
+typedef unsigned su32x4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void enc_scatter16_kernel(EncArgs a, float* __restrict__ dXp, int rows, int cpr, int rpw) {
+  const int rl = threadIdx.x / cpr, c = threadIdx.x - rl * cpr;
+  const int row = blockIdx.x * rpw + rl;
+  if (rl >= rpw || row >= rows) return;
+  const int b = row / a.T, p = row - b * a.T;
+  const int pos0 = a.start - a.hist + 1;
+  const int c8 = 8 * c;
+  const bool hh = c8 < 2 * a.hid;
+  const __bf16* base = hh ? reinterpret_cast<const __bf16*>(a.dgh) + c8 : reinterpret_cast<const __bf16*>(a.dgi) + (c8 - 2 * a.hid);
+  const long ldr = hh ? a.G : a.hid;
+  constexpr int UB = 8;   // loads in flight per thread (4 / 8 / 12 and non-temporal loads measured alike: tools/scatter_probe.py)
+  float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int s0 = 0; s0 < a.hist; s0 += UB) {
+    su32x4 v[UB];
+    float wgt[UB];
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+      const int s = s0 + u;
+      const int n = p - pos0 - s;
+      const bool ok = s < a.hist && n >= 0 && n < a.N;
+      const long w = ok ? (long)n * a.B + b : 0;
+      const int sc = ok ? s : 0;
+      wgt[u] = ok ? (a.mask ? a.mask[w * a.hist + sc] : 1.0f) : 0.0f;
+      const su32x4* src = reinterpret_cast<const su32x4*>(base + ((long)sc * a.F + w) * ldr);
+      v[u] = *src;
+    }
+#pragma unroll
+    for (int u = 0; u < UB; ++u) {
+      const unsigned q[4] = {v[u][0], v[u][1], v[u][2], v[u][3]};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        acc[2 * e] += wgt[u] * __builtin_bit_cast(float, q[e] << 16);
+        acc[2 * e + 1] += wgt[u] * __builtin_bit_cast(float, q[e] & 0xffff0000u);
+      }
+    }
+  }
+  float* dst = dXp + (long)row * a.G + c8;
+  *reinterpret_cast<f32x4*>(dst) = f32x4{acc[0], acc[1], acc[2], acc[3]};
+  *reinterpret_cast<f32x4*>(dst + 4) = f32x4{acc[4], acc[5], acc[6], acc[7]};
+}
+
 __global__ __launch_bounds__(256) void gather_windows_kernel(const float* __restrict__ X, int B, int T, int dim, int N, int start,
                                                              int hist, int incl, const float* __restrict__ mask,
                                                              float* __restrict__ cond, int ldcond, int col) {
@@ -2430,7 +2474,15 @@ extern "C" int lfi_encode_windows_scatter(const lfi_enc_desc* d, const float* dg
   LFI_REQUIRE(!a.compact || dgh, "lfi_encode_windows_scatter: the compact dgi of the fused backward needs dgh too");
   a.dgi = (float*)dgi; a.dgh = (float*)dgh; a.mask = mask;
   a.g16 = lfi_encode_windows_grad_stash_bf16(d);
-  hipLaunchKernelGGL(enc_scatter_kernel, dim3(d->B * d->T), dim3(256), 0, (hipStream_t)stream, a, dXp);
+  // bf16 compact stash (the training step's): 16-byte loads, several frame rows per workgroup (LFI_ENC_SCATTER16=0: the kernel above)
+  const char* ev = getenv("LFI_ENC_SCATTER16");
+  const int cpr = 3 * d->hid / 8;
+  auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  if (!(ev && ev[0] == '0') && a.g16 && a.compact && d->hid % 8 == 0 && cpr <= 256 && al16(dgi) && al16(dgh) && al16(dXp)) {
+    const int rows = d->B * d->T, rpw = 256 / cpr;
+    hipLaunchKernelGGL(enc_scatter16_kernel, dim3(lfi_cdiv(rows, rpw)), dim3(256), 0, (hipStream_t)stream, a, dXp, rows, cpr, rpw);
+  } else
+    hipLaunchKernelGGL(enc_scatter_kernel, dim3(d->B * d->T), dim3(256), 0, (hipStream_t)stream, a, dXp);
   LFI_LAUNCH_CHECK("lfi_encode_windows_scatter");
   return LFI_OK;
 }

@@ -757,6 +757,50 @@ def test_dropout_masks_and_padded_copies(gpu_device):
     assert torch.equal(out[:, :50], x) and bool((out[:, 50:] == 0).all())
 
 
+@pytest.mark.parametrize("shape", [(256, 80, 24, 24, 256), (16, 30, 7, 5, 128), (5, 19, 3, 2, 64), (3, 12, 11, 12, 256)])
+@pytest.mark.parametrize("masked", [True, False])
+def test_window_scatter_kernels_match(gpu_device, monkeypatch, shape, masked):
+    """lfi_encode_windows_scatter on the bf16 compact gradient stash (the training step's): the sum over the windows a frame
+    belongs to - dXp[b T + p] = sum_s mask[w][s] (dgh[s][w][:2 hid], dgi[s][w]) with w = (p - pos0 - s) B + b - against that
+    definition in fp64, and the 16-byte-load kernel (several frame rows per workgroup, default) bit for bit against the 8-byte one
+    (LFI_ENC_SCATTER16=0): same products, same order over s. Ragged row counts, frames no window reaches (zero rows), more
+    history steps than windows. (The input side of nn.GRU's weight gradient, glow/models.py:55-80.)"""
+    import ctypes as C
+    from lets_face_it_amd import _lib
+    from lets_face_it_amd._lib import EncDesc, check
+    L = _lib.lib()
+    B, T, start, hist, hid = shape
+    N = T - start
+    F = N * B
+    dev = gpu_device
+    g = torch.Generator().manual_seed(B + T + hist)
+    d = EncDesc(B, T, N, start, hist, hid, 896, 256, 1, 0, 0, 1, 1)
+    assert L.lfi_encode_windows_grad_stash_bf16(C.byref(d)) and L.lfi_encode_windows_compact_dgi(C.byref(d))
+    dgh = torch.randn(hist, N, B, 3 * hid, generator=g).to(torch.bfloat16).to(dev)
+    dgi = torch.randn(hist, N, B, hid, generator=g).to(torch.bfloat16).to(dev)
+    mask = ((torch.rand(N, B, hist, generator=g) < 0.6).float() * 1.7).to(dev) if masked else None
+    st = torch.cuda.current_stream().cuda_stream
+    outs = []
+    for sw in ("1", "0"):
+        monkeypatch.setenv("LFI_ENC_SCATTER16", sw)
+        dxp = torch.full((B * T + 1, 3 * hid), 7.0, device=dev)
+        check(L.lfi_encode_windows_scatter(C.byref(d), dgi.data_ptr(), dgh.data_ptr(), mask.data_ptr() if masked else None,
+                                           dxp.data_ptr(), st), "scatter")
+        torch.cuda.synchronize()
+        assert bool((dxp[B * T] == 7.0).all()), "wrote past the last frame row"
+        outs.append(dxp[:B * T])
+    assert torch.equal(outs[0], outs[1])
+    D = torch.cat([dgh[..., :2 * hid], dgi], dim=-1).double()       # (hist, N, B, 3 hid)
+    ref = torch.zeros(B, T, 3 * hid, dtype=torch.float64, device=dev)
+    pos0 = start - hist + 1
+    for s_ in range(hist):
+        term = D[s_] * (mask[..., s_].double().unsqueeze(-1) if masked else 1.0)
+        ref[:, pos0 + s_:pos0 + s_ + N] += term.permute(1, 0, 2)
+    err = rel_err(outs[0].view(B, T, 3 * hid), ref)
+    report("window scatter %s masked=%s: %.2e vs fp64, two kernels bit-identical" % (shape, masked, err))
+    assert err < 2e-6, err
+
+
 @pytest.mark.parametrize("mod,two,s16", [("p2_face", 1, 1), ("p2_face", 0, 0), ("p2_speech", 1, 0), ("p1_speech", 1, 1)])
 def test_window_encoder_tilings_match(gpu_device, monkeypatch, mod, two, s16):
     """The two tilings of the fused window-encoder recurrence - four waves of 64 windows x 64 hidden units, one workgroup per CU
