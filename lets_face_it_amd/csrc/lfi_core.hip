@@ -169,7 +169,18 @@ constexpr int SUMSQ_BLOCKS = 1024;
 __global__ __launch_bounds__(256) void sumsq_stage1(const float* __restrict__ g, long n, double* __restrict__ part) {
   __shared__ double red[4];
   double s = 0.0;
-  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+  const long stride = (long)gridDim.x * 256;
+  long i = (long)blockIdx.x * 256 + threadIdx.x;
+  // eight loads in flight per thread, added in the order the one-at-a-time loop adds them (17 M gradients took 33 us at the end
+  // of the step, one outstanding 4-byte load per wave)
+  for (; i + 7 * stride < n; i += 8 * stride) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = g[i + u * stride];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += (double)v[u] * (double)v[u];
+  }
+  for (; i < n; i += stride) {
     const double v = (double)g[i];
     s += v * v;
   }

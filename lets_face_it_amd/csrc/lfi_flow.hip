@@ -413,17 +413,37 @@ __global__ __launch_bounds__(NT) void flow_step_kernel(FlowK f, CellIO io) {
 }
 
 // nll[f] = -(logdet + sum_c -0.5 (z^2 + log 2pi)) / ln 2   (SeqGlow.loss, glow/models.py:563-565)
+// 64 frames per workgroup: their z rows (C floats at stride ldc) come in through LDS with coalesced loads (and leave to the
+// caller's z the same way); thread i then sums frame i's row in column order - one thread per frame reading its row straight from
+// memory took 30 us of the step's critical path between the two walks for 3.7 MB. C > NLL_CMAX: that form (STAGED = false).
+constexpr int NLL_FR = 64, NLL_CMAX = 128;
+template <bool STAGED>
 __global__ __launch_bounds__(256) void flow_nll_kernel(FlowK f, float* __restrict__ z, float* __restrict__ nll) {
-  const long fr = (long)blockIdx.x * 256 + threadIdx.x;
-  if (fr >= f.F) return;
+  extern __shared__ float nll_rows[];   // [NLL_FR][C + 1]
+  const int nfr = STAGED ? NLL_FR : 256;
+  const long fr0 = (long)blockIdx.x * nfr;
+  const float* zbase = f.sX + (long)(f.Ks - 1) * f.F * f.ldc;
+  if (STAGED) {
+    const long left = f.F - fr0;
+    const int tot = (int)(left < NLL_FR ? left : NLL_FR) * f.C;
+    for (int e = threadIdx.x; e < tot; e += 256) {
+      const int r = e / f.C, c = e - r * f.C;
+      const float v = zbase[(fr0 + r) * f.ldc + c];
+      nll_rows[r * (f.C + 1) + c] = v;
+      if (z) z[fr0 * f.C + e] = v;
+    }
+    __syncthreads();
+  }
+  const long fr = fr0 + threadIdx.x;
+  if (threadIdx.x >= nfr || fr >= f.F) return;
   float ld = f.ldconst[0];
   for (int k = 0; k < f.Ks; ++k) ld += f.sL[(long)k * f.F + fr];
-  const float* zz = f.sX + ((long)(f.Ks - 1) * f.F + fr) * f.ldc;
+  const float* zz = STAGED ? nll_rows + threadIdx.x * (f.C + 1) : zbase + fr * f.ldc;
   float lp = 0.0f;
   for (int c = 0; c < f.C; ++c) {
     const float v = zz[c];
     lp += -0.5f * (v * v + LOG2PI_F);
-    if (z) z[fr * f.C + c] = v;
+    if (!STAGED && z) z[fr * f.C + c] = v;
   }
   // a persistent walk that gave up (bounded spin timed out, abort word set) must not pass for a result: poison it
   const bool aborted = f.pipe && f.pipe[1] != 0u;
@@ -3411,7 +3431,10 @@ extern "C" int lfi_flow_seq_fwd(const lfi_flow_dims* d, const lfi_flow_params* p
     else hipLaunchKernelGGL(flow_diag_fwd_fast_kernel<3>, grid, dim3(NT), lds, st, f, dg, klo);
   }
   LFI_LAUNCH_CHECK("lfi_flow_seq_fwd");
-  hipLaunchKernelGGL(flow_nll_kernel, dim3(lfi_cdiv(f.F, 256)), dim3(256), 0, st, f, z, nll);
+  if (f.C <= NLL_CMAX)
+    hipLaunchKernelGGL(flow_nll_kernel<true>, dim3(lfi_cdiv(f.F, NLL_FR)), dim3(256), (size_t)NLL_FR * (f.C + 1) * sizeof(float), st, f, z, nll);
+  else
+    hipLaunchKernelGGL(flow_nll_kernel<false>, dim3(lfi_cdiv(f.F, 256)), dim3(256), 0, st, f, z, nll);
   LFI_LAUNCH_CHECK("lfi_flow_seq_fwd nll");
   return LFI_OK;
 }
