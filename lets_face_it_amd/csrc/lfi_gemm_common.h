@@ -459,7 +459,15 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(GemmArgs g) {
     const int row = (int)(i / g.N), col = (int)(i % g.N);
     const float* w = g.work + (long)batch * g.splitk * mn + i;
     float v = 0.0f;
-    for (int s = 0; s < g.splitk; ++s) v += w[(long)s * mn];
+    int s = 0;
+    for (; s + 8 <= g.splitk; s += 8) {   // eight partials in flight, added in split order (the long-K products leave up to 85)
+      float t[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) t[u] = w[(long)(s + u) * mn];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v += t[u];
+    }
+    for (; s < g.splitk; ++s) v += w[(long)s * mn];
     if (bias) v += bias[col];
     if (g.accumulate == 2) v += C[(long)row * g.ldc + col];
     v = apply_act(v, g.act, g.slope, G, (long)row * g.ldg + col);
@@ -480,7 +488,15 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce4_kernel(GemmArgs g) {
     const int row = (int)(i / n4), col = (int)(i - (long)row * n4) * 4;
     const float* w = g.work + (long)batch * g.splitk * mn + 4 * i;
     f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    for (int s = 0; s < g.splitk; ++s) v += __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(w + (long)s * mn));
+    int s = 0;
+    for (; s + 8 <= g.splitk; s += 8) {   // (as above)
+      f32x4 t[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) t[u] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(w + (long)(s + u) * mn));
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v += t[u];
+    }
+    for (; s < g.splitk; ++s) v += __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(w + (long)s * mn));
     f32x4* cp = reinterpret_cast<f32x4*>(C + (long)row * g.ldc + col);
     f32x4 c0 = {0.f, 0.f, 0.f, 0.f};
     if (g.accumulate) c0 = *cp;
