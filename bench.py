@@ -308,7 +308,7 @@ def _roofline(spec, F, timing, precision):
         peak, mult = BF16_MFMA_PEAK_TFLOPS, 3.0
         pairs = ((spec.ldf + 15) // 16) % 2 == 0 and os.environ.get("LFI_PGEMM_16", "1") != "0"
         # (name prefix as rocprofv3 prints it; the 16 x 16 x 32 kernel carries one more template argument: its epilogue form)
-        kern = "gemm_planes16_kernel<false, 2, 4" if pairs else "gemm_planes_kernel<false, false, false, 2, 4>"
+        kern = "gemm_planes16_kernel<false, false, false, 2, 4" if pairs else "gemm_planes_kernel<false, false, false, 2, 4>"
         tile, threads = 128, 512
         tile_n = 256
     elif precision == "bf16x3":
