@@ -6,8 +6,10 @@ Adam) of final_model.yaml at BASELINE.json's synthetic dims (50-d FLAME + 27-d s
          bench.py --gpus N --steps K --warmup W
 
 Rank 0 prints ONE JSON line. `value` = frames processed by all ranks / max-over-ranks wall time of the K timed steps
-(inputs resident in HBM before the timed region). `roofline` is for the dominant kernel, the cond_transform GEMM
-(F x Ks*D x Ef, bf16 hi/lo operand planes, three bf16 MFMA products per k-step), timed with HIP events on its launch stream inside the timed region. `cpu_baseline`
+(inputs resident in HBM before the timed region). `roofline` is for the step's largest kernel by time, the persistent GRU
+window-encoder forward recurrence (two launches per step), timed with HIP events on its launch stream inside the timed region;
+`roofline_best_gemm` is the cond_transform forward product (F x Ks*D x Ef, bf16 hi/lo operand planes, three bf16 MFMA products per
+k-step: the fastest kernel of the step, ~5 % of its time); `roofline_whole_step` prices the whole step. `cpu_baseline`
 (N = 1 only) times the CPU oracle — a plain-PyTorch port of the reference's per-timestep loop — on the host cores on a
 bounded sample of the same workload; it is a reported baseline, not the thing measured above.
 """
@@ -170,10 +172,24 @@ def start_smi_helper():
     initialised HIP must not fork + exec another program (the box refuses it; under rocprofv3 --pmc it did), and rocm-smi is a
     Python script. The helper never initialises the GPU itself. None when it cannot be started."""
     import subprocess
+    if under_profiler():
+        return None
+    env = {k: v for k, v in os.environ.items() if not _is_profiler_var(k)}
     try:
-        return subprocess.Popen([sys.executable, "-c", _SMI_HELPER], stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True)
+        return subprocess.Popen([sys.executable, "-c", _SMI_HELPER], stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True, env=env)
     except Exception:      # noqa: BLE001 - diagnostics only
         return None
+
+
+def _is_profiler_var(name):
+    return name in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "HSA_TOOLS_LIB", "ROCP_TOOL_LIB") or name.startswith(("ROCPROFILER_", "ROCPROF_", "ROCTRACER_", "ROCP_"))
+
+
+def under_profiler():
+    """True when a tool library is (or may be) preloaded into this process - rocprofv3 sets LD_PRELOAD / ROCP_TOOL_LIBRARIES /
+    ROCPROFILER_* and its library can initialise the GPU before bench.py's first line runs (with --pmc it does): the helper would
+    then be a fork + exec from a GPU-initialised process, which the pool forbids, so it is not started at all."""
+    return any(_is_profiler_var(k) and os.environ.get(k) for k in os.environ)
 
 
 def stop_smi_helper(helper):
@@ -288,8 +304,8 @@ def _host_issue_ms(fn, reps=3):
     return 1e3 * sorted(ts)[len(ts) // 2]
 
 
-def _roofline(spec, F, timing, precision):
-    """Dominant kernel = the cond_transform forward GEMM (F x Ks*D x Ef). SURVEY.md par. 8d counts 2*E*D per flow step and
+def _roofline_gemm(spec, F, timing, precision):
+    """The step's best GEMM (NOT its largest kernel: ~5 % of kernel time) = the cond_transform forward product (F x Ks*D x Ef). SURVEY.md par. 8d counts 2*E*D per flow step and
     frame as written (E = 1530: every GRU output twice); the kernel runs on the folded layout (Ef = 890).
     `achieved` is the product's FLOPs (2 M N K on the folded K) over the HIP-event launch time. In bf16x3 mode every
     product costs three bf16 MFMAs, so the MFMA pipe does 3x that work: both fractions are reported."""
@@ -333,6 +349,7 @@ def _roofline(spec, F, timing, precision):
     except (OSError, ValueError, KeyError):
         pass
     return {"bound": "mfma", "kernel": kern + ("" if kern.endswith(">") else ", ...>") + " cond_transform forward (F x Ks*D x Ef)",
+            "role": "best GEMM of the step (about 5 % of its kernel time), not its dominant kernel",
             "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic,
             "traffic_unit": "bytes per launch (HBM read + write)", "traffic_source": traffic_src,
             "algorithmic_bytes_per_launch": 4.0 * (F * spec.ldf + KD * spec.ldf + F * KD),
@@ -345,39 +362,99 @@ def _roofline(spec, F, timing, precision):
             "ms_per_launch": ms, "launches_timed": n_launch}
 
 
-def _roofline_hbm(spec, B, T, timing, precision, stash_f16=None):
-    """Second roofline, for the largest HBM-bound kernel: the fused GRU window encoder of p2_face, forward
-    (enc_gru_fwd_wide_kernel). Algorithmic bytes per launch = what must cross HBM once: the BPTT stash it writes (r, z, n,
-    W_hn h + b_hn and h: 5 * hid floats per window and history step), the projected inputs it reads (B*T x 3*hid, shared by the
-    overlapping windows) and the feature block it writes (F x hid). Launch time: HIP events on the launch stream."""
-    e = next((x for x in spec.encoders if x.name == "p2_face" and x.enc == "rnn"), None)
-    n_launch, ms = timing.get("enc_fwd.p2_face", (0, float("nan")))
-    if e is None or not n_launch:
-        return None
-    F = B * (T - spec.start)
-    f16 = bool(stash_f16 and stash_f16.get("p2_face"))
-    # per window-step and hidden unit: h (4 B, fp32: a GEMM operand of dW_hh) + r, z, n, W_hn h as four fp16 (8 B) or four fp32 (16 B)
-    alg = e.hist * F * e.hid * (4.0 + (8.0 if f16 else 16.0)) + 4.0 * (B * T * 3 * e.hid + F * e.hid)
-    traffic = None
+def _pmc_traffic(precision):
     try:
-        tj = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_%s.json" % precision)))
+        return json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic_%s.json" % precision)))
+    except (OSError, ValueError):
+        return None
+
+
+def _fwd_flops_per_frame(spec):
+    """SURVEY.md par. 8d: as-written forward GEMM FLOPs per frame (2 m n k, elementwise excluded; every window re-encoded per
+    timestep, every GRU output twice in the feature vector) -> (encoders, flow steps)."""
+    enc = 0.0
+    for e in spec.encoders:
+        if e.enc in ("rnn", "lstm"):
+            enc += e.hist * 2.0 * (e.in_dim + e.hid) * e.ng * e.hid
+        elif e.enc == "mlp":
+            enc += 2.0 * e.in_dim * e.hist * e.hid
+    flow = spec.Ks * (2.0 * spec.E * spec.D + 2.0 * (spec.Ch + spec.D) * spec.G + 2.0 * spec.H * spec.G + 2.0 * spec.H * spec.Cout
+                      + 2.0 * spec.C * spec.C)
+    return enc, flow
+
+
+def _roofline_whole_step(spec, F, ms_per_step, precision):
+    """The whole training step against both nominal peaks: SURVEY.md 8d's algorithmic FLOPs (3 x forward, as written) over the
+    step time and the bf16 dense peak; PMC bytes per step (every kernel, L2 <-> fabric counters of the committed passes of this
+    command) over the step time and 8 TB/s."""
+    enc, flow = _fwd_flops_per_frame(spec)
+    flops = 3.0 * (enc + flow) * F
+    peak = BF16_MFMA_PEAK_TFLOPS if precision == "bf16x3" else F32_MFMA_PEAK_TFLOPS
+    ach = flops / (ms_per_step * 1e-3) / 1e12
+    out = {"flops_per_step_algorithmic": flops, "mflop_per_frame_forward_as_written": (enc + flow) / 1e6,
+           "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
+           "hbm_bytes_per_step": None, "hbm_achieved_GBps": None, "hbm_frac": None}
+    tj = _pmc_traffic(precision)
+    if tj:
+        per_step = tj.get("per_step_hbm_bytes")
+        if per_step is None:     # every kernel's bytes / the number of optimiser steps of the profiled run (one adam_clip_kernel each)
+            steps = sum(v["dispatches"] for k, v in tj["kernels"].items() if k.startswith("adam_clip_kernel"))
+            per_step = sum(v["hbm_bytes"] * v["dispatches"] for v in tj["kernels"].values()) / steps if steps else None
+        if per_step:
+            gbps = per_step / (ms_per_step * 1e-3) / 1e9
+            out.update(hbm_bytes_per_step=per_step, hbm_achieved_GBps=gbps, hbm_frac=gbps / 8000.0,
+                       hbm_source="profiles/pmc_traffic_%s.json (committed PMC passes of this command at F = 14 336; applies to that shape)" % precision)
+    return out
+
+
+def _roofline_encoder(spec, B, T, timing, precision, stash_f16=None):
+    """`roofline`: the step's LARGEST kernel by time (profiles/*kernel_stats*: ~12 % forward + ~10 % for its BPTT twin) - the
+    persistent window-encoder forward recurrence enc_gru_fwd_*_kernel, two launches per step that share the kernel name (p2_face:
+    hist 24, p2_speech: hist 16; hid 256). bound = mfma: `achieved` = the recurrence's as-written FLOPs 2 * hid * 3 hid per window
+    step (SURVEY.md 8d's `hist * 2 * (in + hid) * 3 hid` less the x-projection, which is hoisted into ONE GEMM over the B * T distinct
+    frames and is not this kernel's work) summed over the launches / their summed HIP-event time; ms_per_launch = the mean over the
+    launches, which is what rocprofv3 --stats prints for the kernel name. None when the model has no GRU window encoder of that kind."""
+    F = B * (T - spec.start)
+    legs = []
+    for e in spec.encoders:
+        n_launch, ms = timing.get("enc_fwd." + e.name, (0, float("nan")))
+        if e.enc == "rnn" and e.hid == 256 and n_launch:
+            legs.append((e, n_launch, ms))
+    if not legs:
+        return None
+    peak, mult = (BF16_MFMA_PEAK_TFLOPS, 3.0) if precision == "bf16x3" else (F32_MFMA_PEAK_TFLOPS, 1.0)
+    flops = sum(2.0 * e.hid * 3 * e.hid * e.hist * F for e, _, _ in legs)
+    flops_x = sum(2.0 * (e.in_dim + e.hid) * 3 * e.hid * e.hist * F for e, _, _ in legs)
+    ms_sum = sum(ms for _, _, ms in legs)
+    ach = flops / (ms_sum * 1e-3) / 1e12
+    alg_bytes = 0.0
+    for e, _, _ in legs:
+        f16 = bool(stash_f16 and stash_f16.get(e.name))
+        # per window step and hidden unit: h (4 B, fp32: a GEMM operand of dW_hh) + r, z, n, W_hn h as four fp16 (8 B) or fp32 (16 B);
+        # the projected inputs once (B T x 3 hid, shared by the overlapping windows) and the feature block (F x hid)
+        alg_bytes += e.hist * F * e.hid * (4.0 + (8.0 if f16 else 16.0)) + 4.0 * (B * T * 3 * e.hid + F * e.hid)
+    traffic = None
+    tj = _pmc_traffic(precision)
+    if tj:
         for name, v in tj["kernels"].items():
             if "enc_gru_fwd_" in name and any(name.endswith("grid=%d" % g) for g in (((F + 31) // 32) * 256, ((F + 63) // 64) * 256,
                                                                                      ((F + 63) // 64) * 512)):
-                traffic = max(traffic or 0.0, v["hbm_bytes"])   # p2_face (24 steps) is the larger of the two 256-wide launches
-    except (OSError, ValueError, KeyError):
-        pass
-    ach = alg / (ms * 1e-3) / 1e9
-    return {"bound": "hbm", "kernel": "fused GRU window-encoder recurrence (enc_gru_fwd_*_kernel), p2_face windows (hist %d, hid %d), "
-                                      "gate stash %s" % (e.hist, e.hid, "fp16" if f16 else "fp32"),
-            "achieved": ach, "peak": 8000.0, "unit": "GB/s", "frac": ach / 8000.0, "traffic": traffic,
-            "traffic_note": "PMC bytes per launch of this kernel name and grid: the mean over the p2_face (24 steps) and p2_speech "
-                            "(16 steps) launches, which share them",
-            "timing_note": "HIP events in the 5-step all-tags region that follows the timed region (bench_train)",
-            "bound_note": "the launch is paced by its matrix phase, not by these bytes: without any stash it takes 0.62 of 0.66 ms "
-                          "(tools/enc_probe.py, DESIGN.md section 9); the byte rate is reported because this is the step's largest "
-                          "HBM stream",
-            "algorithmic_bytes_per_launch": alg, "ms_per_launch": ms, "launches_timed": n_launch}
+                traffic = max(traffic or 0.0, v["hbm_bytes"])   # the 256-wide launches (the small encoder shares the grid size, not the bytes)
+    sec = ms_sum * 1e-3
+    return {"bound": "mfma", "kernel": "enc_gru_fwd_*_kernel: persistent GRU window-encoder forward recurrence, %s" % " + ".join(
+                "%s (hist %d, hid %d)" % (e.name, e.hist, e.hid) for e, _, _ in legs),
+            "role": "largest kernel of the step by time (with its BPTT twin about 22 % of kernel time and ~40 % of the critical path)",
+            "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak,
+            "traffic": traffic, "traffic_unit": "bytes per launch (HBM read + write), mean over the launches of this kernel name and grid",
+            "mfma_flops_multiplier": mult, "frac_of_mfma_issue": mult * ach / peak,
+            "flops_per_step_this_kernel": flops, "launches_per_step": len(legs),
+            "achieved_crediting_hoisted_x_projection": flops_x / sec / 1e12, "frac_crediting_hoisted_x_projection": flops_x / sec / 1e12 / peak,
+            "ms_per_launch": ms_sum / len(legs), "ms_by_launch": {e.name: round(ms, 4) for e, _, ms in legs},
+            "launches_timed": sum(n for _, n, _ in legs),
+            "timing_note": "HIP events on the launch stream inside the timed region, around lfi_encode_windows_fwd (the recurrence + a "
+                           "few-us weight-fragment kernel in front of it); the small third encoder runs beside them on the second stream",
+            "algorithmic_bytes_per_step_this_kernel": alg_bytes, "hbm_achieved_GBps": alg_bytes / sec / 1e9,
+            "hbm_frac": alg_bytes / sec / 1e9 / 8000.0}
 
 
 def _time_steps_at_batch(model, trainer, spec, B, T, device, warmup, steps):
@@ -408,7 +485,8 @@ def bench_train(args, model, trainer, spec, device, world, rank, hp):
     # timed in a short region of their own afterwards: every event record is a marker packet in the queue (~6 us of dispatch
     # gap), and with all nine tags on the timed step carried 18 of them - 0.1 ms that no training step pays (same-call A/B:
     # 7.86 ms with all tags, 7.77 with the roofline kernels' only; LFI_BENCH_ALL_TAGS=1: the old behaviour)
-    roof_tags = None if os.environ.get("LFI_BENCH_ALL_TAGS") == "1" else ("gemm_cond_fwd",)
+    roof_tags = None if os.environ.get("LFI_BENCH_ALL_TAGS") == "1" else (
+        ("gemm_cond_fwd",) + tuple("enc_fwd." + e.name for e in spec.encoders if e.enc == "rnn" and e.hid == 256))
     eng.enable_timing(True, only=roof_tags)
     elapsed, loss = _timed(step, args.steps, world, device)
     timing = eng.timing_summary()
@@ -427,7 +505,15 @@ def bench_train(args, model, trainer, spec, device, world, rank, hp):
         dp_line = _dp_summary(model.dp_profile, eng, world)
         model.dp_profile = None
     host_issue = _host_issue_ms(step, reps=5)   # (without any per-kernel events)
-    gpu_state = gpu_state_under_load(step, device, getattr(args, "smi_helper", None)) if (rank == 0 and not args.quick and world == 1) else None
+    gpu_state = None
+    if rank == 0 and not args.quick and world == 1 and getattr(args, "smi_helper", None) is not None:
+        # the load is the real step at lr = 0 (parameters do not move) with Adam's moments, step count and dropout counter put
+        # back afterwards: the legs below run on the state the timed region left
+        keep = eng.optimizer_state()
+        gpu_state = gpu_state_under_load(lambda i: model.fused_training_step(batches[i & 1], 0.0, world, allreduce), device,
+                                         args.smi_helper)
+        eng.load_optimizer_state(keep)
+        del keep
     graph_line = None
     if world == 1 and args.graph_steps > 0:
         # the same step as ONE replayed hipGraph (opt-in: LetsFaceItGlow.step_graph; bit-identical parameters): two more eager calls
@@ -455,11 +541,15 @@ def bench_train(args, model, trainer, spec, device, world, rank, hp):
         workload = ("final_model.yaml training step, synthetic %d-d FLAME + %d-d speech, T=%d, batch %d per GPU (%s%s)"
                     % (C, S, T, B, "BASELINE.json configs[1]" if (C, S) == (50, 27) else
                        "the corpus' native dims, hparams/final_model.yaml as shipped", "" if world == 1 else ", data-parallel"))
+    ms_step = 1e3 * elapsed / args.steps
+    roof_gemm = _roofline_gemm(spec, F, timing, args.precision)
+    roof = None if deep else _roofline_encoder(spec, B, T, timing, args.precision, getattr(eng, "_enc_stash_f16", None))
+    # the verbose records first, the short ones that summarise the run LAST: the driver stores the tail of this line
     out = {
         "metric": metric,
         "value": frames / elapsed, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": 1e3 * elapsed / args.steps, "host_issue_ms_per_step": host_issue,
-        "step_launch": "eager (~100 launches per step on two streams)", "hipgraph_replay": graph_line,
+        "ms_per_step": ms_step, "host_issue_ms_per_step": host_issue,
+        "step_launch": "eager (~100 launches per step on two streams)",
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": _dtype_label(args.precision, eng, F),
         "data": "synthetic",
@@ -468,11 +558,12 @@ def bench_train(args, model, trainer, spec, device, world, rank, hp):
                    "parallelism": "dp%d" % world, "params": eng.n_params, "gemm_precision": args.precision,
                    "gemm_products": _products_label(args.precision, eng, F)},
         "final_loss": float(loss),
-        "roofline": _roofline(spec, F, timing, args.precision),
-        "roofline_hbm": _roofline_hbm(spec, B, T, timing, args.precision, getattr(eng, "_enc_stash_f16", None)),
+        "roofline": roof if roof is not None else roof_gemm,
+        "roofline_best_gemm": roof_gemm if roof is not None else None,
         "kernel_timing": {t: {"launches": n, "ms": round(m_, 4)} for t, (n, m_) in timing.items()},
         "gpu_state_under_load": gpu_state,
     }
+    tail = {"roofline_whole_step": _roofline_whole_step(spec, F, ms_step, args.precision), "hipgraph_replay": graph_line}
     if dp_line is not None:
         out["data_parallel"] = dp_line
     if world == 1 and args.precision == "bf16x3" and eng.backward_product_count(F) == 2 and args.three_products_steps > 0:
@@ -484,7 +575,7 @@ def bench_train(args, model, trainer, spec, device, world, rank, hp):
         n3 = args.three_products_steps
         el3, _ = _timed(step, n3, 1, device)
         eng.backward_products = keep
-        out["three_products_everywhere"] = {"ms_per_step": 1e3 * el3 / n3, "value": world * B * N * n3 / el3, "unit": "frames/s",
+        tail["three_products_everywhere"] = {"ms_per_step": 1e3 * el3 / n3, "value": world * B * N * n3 / el3, "unit": "frames/s",
                                             "note": "engine_backward_products=3; same process, same batches, %d steps" % n3}
     if world == 1 and not deep and B == 256 and args.strong_anchor_batch > 0:
         # north_star asks for STRONG scaling at 8 GPUs (configs[2]: global batch 2048 = 8 x 256). The driver's N-GPU runs keep
@@ -492,7 +583,7 @@ def bench_train(args, model, trainer, spec, device, world, rank, hp):
         # so that strong-scaling speed-up at N = 8 is strong_scaling_anchor.ms_per_step / that run's ms_per_step
         gb = args.strong_anchor_batch
         ms = _time_steps_at_batch(model, trainer, spec, gb, T, device, 2, 5)
-        out["strong_scaling_anchor"] = {"batch": gb, "ms_per_step": ms, "frames_per_s": gb * N / (ms * 1e-3), "n_gpus": 1,
+        tail["strong_scaling_anchor"] = {"batch": gb, "ms_per_step": ms, "frames_per_s": gb * N / (ms * 1e-3), "n_gpus": 1,
                                         "note": "one GPU at the global batch of BASELINE.json configs[2] (8 x 256), mean of 5 steps "
                                                 "after 2 warm-ups; strong speed-up at N GPUs = this / the N-GPU run's ms_per_step "
                                                 "at batch %d per GPU" % (gb // 8)}
@@ -506,8 +597,8 @@ def bench_train(args, model, trainer, spec, device, world, rank, hp):
         # `vs_baseline` stays null (bench contract); the measured ratio is reported under its own name
         tg = torch_gpu_baseline(hp, C, S, T, B, device, args.torch_gpu_baseline_seconds)
         out["torch_gpu_baseline"] = tg
-        out["vs_torch_gpu_baseline"] = out["value"] / tg["value"]
-        out["vs_torch_gpu_baseline_spelled_out_cells"] = out["value"] / tg["spelled_out_cells"]["value"]
+        tail["vs_torch_gpu_baseline"] = out["value"] / tg["value"]
+        tail["vs_torch_gpu_baseline_spelled_out_cells"] = out["value"] / tg["spelled_out_cells"]["value"]
     if world == 1 and args.cpu_baseline_seconds > 0:
         if deep:
             # bounded sample of the same workload: the full batch, the first 8 of the 488 timesteps (every timestep costs the
@@ -517,6 +608,7 @@ def bench_train(args, model, trainer, spec, device, world, rank, hp):
                                                note=" (bounded sample: the full batch, the first 8 of %d timesteps)" % N)
         else:
             out["cpu_baseline"] = cpu_baseline(hp, C, S, T, B, args.cpu_baseline_seconds)
+    out.update(tail)
     return out
 
 
@@ -554,6 +646,28 @@ def _sample_frame_label(eng):
             9: "fp32-grade throughout: per-frame GEMMs and the reverse cells' recurrent products as three fp16 products of two-piece "
                "operands (11 + 11 mantissa bits, 2^-22 relative; activations and weights sit inside fp16's range), the cells' "
                "LinearZeros / W^-1 products on the f32-input MFMA"}.get(int(fp), str(fp))
+
+
+def _sampling_error_record(precision):
+    """err / fp32 floor of the K = 16 sampler against the fp64 oracle, as the GPU suite last measured it
+    (tests/test_gpu_headline_parity.py::test_k16_sampling_against_oracle writes the line into the parity report committed under
+    profiles/): bench.py does not run the oracle outside its cpu_baseline leg, so it quotes the committed measurement."""
+    import glob
+    import re
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "round*_parity_report.txt")), reverse=True):
+        try:
+            txt = open(path).read()
+        except OSError:
+            continue
+        m = None
+        for m in re.finditer(r"K=16 sampling, batch 8 x 56 generated frames \(%s\): max abs err vs fp64 oracle ([0-9.e+-]+) .*?plain fp32 "
+                             r"torch on the CPU: ([0-9.e+-]+); gate ([0-9.e+-]+)" % re.escape(precision), txt):
+            pass
+        if m:
+            err, floor = float(m.group(1)), float(m.group(2))
+            return {"max_abs_err_vs_fp64_oracle": err, "fp32_floor": floor, "err_over_fp32_floor": err / floor,
+                    "north_star_abs_tolerance": 1e-5, "source": os.path.relpath(path, ROOT) + " (K = 16, batch 8 x 56 generated frames)"}
+    return None
 
 
 def bench_sample(args, model, spec, device, world, rank, hp):
@@ -608,6 +722,7 @@ def bench_sample(args, model, spec, device, world, rank, hp):
                    "autoregressive_part": _sample_frame_label(eng)},
         "ms_per_generated_frame": 1e3 * elapsed / args.steps / nframes,
         "finite": bool(torch.isfinite(out_faces).all()),
+        "error_vs_fp32_floor": _sampling_error_record(args.precision),
         "roofline": {"bound": "mfma", "kernel": "hipGraph of the per-frame sequence x %d frames: 2 conditioning GEMMs + state "
                                                 "reset + flow_rev_chain_kernel (%d dependent reverse flow steps)" % (nframes, spec.Ks),
                      "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
@@ -621,6 +736,64 @@ def bench_sample(args, model, spec, device, world, rank, hp):
     if world == 1 and args.cpu_baseline_seconds > 0:
         res["cpu_baseline"] = cpu_baseline_sample(hp, C, S, B, 24, min(args.cpu_baseline_seconds, 30.0))
     return res
+
+
+def self_launch(n):
+    """`bench.py --gpus N` (N > 1) started as a plain process: run the N ranks as CHILD processes under torch.distributed.run (one
+    rank per GPU, rendezvous on 127.0.0.1, a free port) and hand back their exit code. The parent imports torch but never
+    initialises HIP (no device query, no tensor on a GPU), and it starts a child - it does not exec - so the pool's rule against
+    replacing a GPU-initialised process is not in play anywhere. stdout of the ranks: the ONE JSON line of rank 0 goes to this
+    process' stdout, anything else a rank or the launcher prints there is passed on to stderr."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    print("bench.py: starting %d ranks: %s" % (n, " ".join(cmd)), file=sys.stderr, flush=True)
+    proc = subprocess.Popen(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = 0
+    for line in proc.stdout:
+        txt = line.strip()
+        is_json = False
+        if txt.startswith("{") and txt.endswith("}"):
+            try:
+                is_json = "metric" in json.loads(txt)
+            except ValueError:
+                pass
+        if is_json:
+            lines += 1
+            print(txt, flush=True)
+        else:
+            print(line, end="", file=sys.stderr, flush=True)
+    rc = proc.wait()
+    if rc == 0 and lines != 1:
+        print("bench.py: the ranks exited 0 but printed %d JSON lines (expected 1)" % lines, file=sys.stderr)
+        return 1
+    return rc
+
+
+def launch_check(world, rank):
+    """--launch-check: the launch shape only (self_launch / torch.distributed.run, rendezvous, rank 0's one JSON line), on gloo
+    with CPU tensors - no GPU, no engine. The -m "not gpu" suite runs this; the real N > 1 bench needs N GPUs."""
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        t = torch.tensor([float(rank + 1)], dtype=torch.float64)
+        dist.all_reduce(t)
+        seen = float(t.item())
+        dist.barrier()
+        dist.destroy_process_group()
+    else:
+        seen = 1.0
+    if rank == 0:
+        print(json.dumps({"metric": "launch check (no measurement)", "value": None, "n_gpus": world, "launch_check": True,
+                          "rank_sum": seen, "expected_rank_sum": world * (world + 1) / 2.0}), flush=True)
+    return 0
 
 
 def main():
@@ -657,6 +830,8 @@ def main():
     ap.add_argument("--quick", action="store_true",
                     help="the timed region and its roofline only: no baselines, no hipGraph / three-product / anchor legs, no "
                          "further workloads (A/B runs)")
+    ap.add_argument("--launch-check", action="store_true",
+                    help="rendezvous of the ranks on gloo + rank 0's JSON line only (no GPU): checks the way --gpus N starts itself")
     ap.add_argument("--no-more-workloads", action="store_true",
                     help="N = 1, workload train: do not append the `sampling` (configs[3]), `deep_flow` (configs[4]) and "
                          "`native_dims` (C=56 / S=30) sub-records")
@@ -670,9 +845,16 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:   # checked before anything touches the GPU
+        if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+            # `python bench.py --gpus N` typed as for N = 1: this process - which has not touched the GPU and never will - starts
+            # the N ranks itself and relays rank 0's JSON line and the launcher's exit code
+            raise SystemExit(self_launch(args.gpus))
         raise SystemExit("--gpus %d but WORLD_SIZE is %d: launch N > 1 as `python -m torch.distributed.run --nnodes=1 "
-                         "--nproc-per-node %d --master-addr 127.0.0.1 --master-port P bench.py --gpus %d ...`"
+                         "--nproc-per-node %d --master-addr 127.0.0.1 --master-port P bench.py --gpus %d ...` (or without "
+                         "WORLD_SIZE in the environment: bench.py then starts the ranks itself)"
                          % (args.gpus, world, args.gpus, args.gpus))
+    if args.launch_check:
+        return launch_check(world, rank)
     # LFI_DIST_BACKEND=gloo rehearses the N > 1 path on a box with fewer GPUs than ranks (ranks share cards, tensors travel
     # through the host): same code path, barriers and timing; the default is RCCL with one GPU per rank
     backend = os.environ.get("LFI_DIST_BACKEND", "nccl")
@@ -764,12 +946,15 @@ def main():
             except Exception as e:      # noqa: BLE001 - a sub-record must not take the headline down with it
                 return {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
             roof = r.get("roofline") or {}
+            whole = r.get("roofline_whole_step") or {}
             return {"metric": r["metric"], "value": r["value"], "unit": r["unit"], "ms_per_step": r["ms_per_step"],
                     "steps": r["steps"], "warmup": r["warmup"], "workload": r["config"]["workload"], "dtype": r["dtype"],
                     "arithmetic": r["config"].get("autoregressive_part") or r["config"].get("gemm_products"),
                     "roofline_kernel": roof.get("kernel"), "roofline_frac": roof.get("frac"),
                     "roofline_frac_of_mfma_issue": roof.get("frac_of_mfma_issue") or
                     (roof.get("frac") * roof.get("mfma_flops_multiplier", 1.0) if roof.get("frac") is not None else None),
+                    "whole_step_frac_of_mfma_peak": whole.get("frac"),
+                    "sampling_error_vs_fp32_floor": r.get("error_vs_fp32_floor"),
                     "kernel_timing": r.get("kernel_timing"), "final_loss": r.get("final_loss"), "finite": r.get("finite")}
 
         out["sampling"] = sub("sample", batch=1024, seq_len=300, steps=5, warmup=2)

@@ -393,6 +393,17 @@ int lfi_adam_clip_step(float* p, const float* g, float* m, float* v, long n, con
                        float clip, float gmul, float lr, float beta1, float beta2, float eps, int step_count,
                        void* stream);
 
+/* The other two optimisers configure_optimizers can build (glow/lets_face_it_glow.py:61-72: `{"adam", "sgd", "rmsprop"}[name](params,
+ * lr=hparams.lr, **hparams.Optim["args"][name])`; hparam_tuning_configs/large_hparam_search.py:9-11 draws all three), on the same
+ * flat buffers with the same global-norm clip in front: torch.optim.SGD (momentum, dampening, weight_decay, nesterov; final_model.yaml:
+ * momentum 0.9; buf = the momentum buffer, may be NULL when momentum == 0; step_count 1-based: the first step sets buf = g) and
+ * torch.optim.RMSprop (alpha, eps, weight_decay, momentum, centered: sq = the square average, buf = the momentum buffer or NULL,
+ * gavg = the centered variant's gradient average or NULL; final_model.yaml: eps 1e-8, torch defaults otherwise). */
+int lfi_sgd_clip_step(float* p, const float* g, float* buf, long n, const double* sumsq, float clip, float gmul, float lr,
+                      float momentum, float dampening, float weight_decay, int nesterov, int step_count, void* stream);
+int lfi_rmsprop_clip_step(float* p, const float* g, float* sq, float* buf, float* gavg, long n, const double* sumsq, float clip,
+                          float gmul, float lr, float alpha, float eps, float weight_decay, float momentum, void* stream);
+
 /* The training step as a captured hipGraph (lets_face_it_amd/glow/lets_face_it_glow.py, fused_training_step): what changes from
  * one optimiser step to the next - the dropout-mask key, Adam's bias-corrected step size - lives in a 32-byte device block
  * (u64 seed, u64 mask offset, f32 step_size = lr / (1 - beta1^t), f32 1 / sqrt(1 - beta2^t)) that lfi_set_step_params fills with

@@ -221,7 +221,93 @@ __global__ __launch_bounds__(256) void adam_clip_kernel(float* __restrict__ p, c
     p[i] -= step_size * (mi / denom);
   }
 }
+// clip coefficient shared by every flat-buffer optimiser: torch.nn.utils.clip_grad_norm_ (coef = clip / (norm + 1e-6), applied when < 1)
+__device__ __forceinline__ float clip_coef(const double* __restrict__ sumsq, float clip, float gmul) {
+  float coef = gmul;
+  if (clip > 0.0f) {
+    const double total = sqrt(sumsq[0]) * (double)fabsf(gmul);
+    const double c = (double)clip / (total + 1e-6);
+    if (c < 1.0) coef *= (float)c;
+  }
+  return coef;
+}
+
+// torch.optim.SGD (single-tensor form): g += wd p; buf = g on the first step, else momentum buf + (1 - dampening) g;
+// nesterov: g += momentum buf, else g = buf; p -= lr g
+__global__ __launch_bounds__(256) void sgd_clip_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ buf, long n,
+                                                       const double* __restrict__ sumsq, float clip, float gmul, float lr,
+                                                       float momentum, float dampening, float weight_decay, int nesterov, int first) {
+  const float coef = clip_coef(sumsq, clip, gmul);
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const float pi = p[i];
+    float gi = g[i] * coef;
+    if (weight_decay != 0.0f) gi = gi + weight_decay * pi;
+    if (momentum != 0.0f) {
+      const float bi = first ? gi : momentum * buf[i] + (1.0f - dampening) * gi;
+      buf[i] = bi;
+      gi = nesterov ? gi + momentum * bi : bi;
+    }
+    p[i] = pi - lr * gi;
+  }
+}
+
+// torch.optim.RMSprop (single-tensor form): g += wd p; sq = alpha sq + (1 - alpha) g^2; centered: gavg = lerp(gavg, g, 1 - alpha),
+// avg = sqrt(sq - gavg^2) + eps, else avg = sqrt(sq) + eps; momentum: buf = momentum buf + g / avg, p -= lr buf; else p -= lr g / avg
+__global__ __launch_bounds__(256) void rmsprop_clip_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ sq,
+                                                           float* __restrict__ buf, float* __restrict__ gavg, long n,
+                                                           const double* __restrict__ sumsq, float clip, float gmul, float lr, float alpha,
+                                                           float eps, float weight_decay, float momentum) {
+  const float coef = clip_coef(sumsq, clip, gmul);
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const float pi = p[i];
+    float gi = g[i] * coef;
+    if (weight_decay != 0.0f) gi = gi + weight_decay * pi;
+    const float si = alpha * sq[i] + (1.0f - alpha) * gi * gi;
+    sq[i] = si;
+    float avg;
+    if (gavg) {
+      const float ga = gavg[i] + (1.0f - alpha) * (gi - gavg[i]);
+      gavg[i] = ga;
+      avg = sqrtf(si - ga * ga) + eps;
+    } else {
+      avg = sqrtf(si) + eps;
+    }
+    if (momentum > 0.0f) {
+      const float bi = momentum * buf[i] + gi / avg;
+      buf[i] = bi;
+      p[i] = pi - lr * bi;
+    } else {
+      p[i] = pi - lr * (gi / avg);
+    }
+  }
+}
 }  // namespace
+
+extern "C" int lfi_sgd_clip_step(float* p, const float* g, float* buf, long n, const double* sumsq, float clip, float gmul, float lr,
+                                 float momentum, float dampening, float weight_decay, int nesterov, int step_count, void* stream) {
+  LFI_REQUIRE(p && g && n >= 0 && step_count >= 1, "lfi_sgd_clip_step: bad arguments");
+  LFI_REQUIRE(momentum == 0.0f || buf, "lfi_sgd_clip_step: momentum needs its buffer");
+  LFI_REQUIRE(clip <= 0.0f || sumsq, "lfi_sgd_clip_step: clipping needs sumsq");
+  LFI_REQUIRE(!nesterov || (momentum > 0.0f && dampening == 0.0f), "lfi_sgd_clip_step: nesterov needs momentum > 0 and dampening 0");
+  int blocks = (int)min(2048L, (long)lfi_cdiv(n > 0 ? n : 1, 256));
+  hipLaunchKernelGGL(sgd_clip_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, g, buf, n, sumsq, clip, gmul, lr, momentum,
+                     dampening, weight_decay, nesterov ? 1 : 0, step_count == 1 ? 1 : 0);
+  LFI_LAUNCH_CHECK("lfi_sgd_clip_step");
+  return LFI_OK;
+}
+
+extern "C" int lfi_rmsprop_clip_step(float* p, const float* g, float* sq, float* buf, float* gavg, long n, const double* sumsq,
+                                     float clip, float gmul, float lr, float alpha, float eps, float weight_decay, float momentum,
+                                     void* stream) {
+  LFI_REQUIRE(p && g && sq && n >= 0, "lfi_rmsprop_clip_step: bad arguments");
+  LFI_REQUIRE(momentum <= 0.0f || buf, "lfi_rmsprop_clip_step: momentum needs its buffer");
+  LFI_REQUIRE(clip <= 0.0f || sumsq, "lfi_rmsprop_clip_step: clipping needs sumsq");
+  int blocks = (int)min(2048L, (long)lfi_cdiv(n > 0 ? n : 1, 256));
+  hipLaunchKernelGGL(rmsprop_clip_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, g, sq, buf, gavg, n, sumsq, clip, gmul, lr,
+                     alpha, eps, weight_decay, momentum);
+  LFI_LAUNCH_CHECK("lfi_rmsprop_clip_step");
+  return LFI_OK;
+}
 
 extern "C" int lfi_grad_sumsq(const float* g, long n, double* sumsq, double* work, void* stream) {
   LFI_REQUIRE(g && sumsq && work && n >= 0, "lfi_grad_sumsq: bad arguments");

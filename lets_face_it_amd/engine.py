@@ -1170,9 +1170,49 @@ class GlowEngine:
                                         float(clip or 0.0), gmul, lr, beta1, beta2, eps, self.step_count, st),
               "lfi_adam_clip_step")
 
+    @translate_oom
+    def optimizer_step_sgd(self, lr, momentum=0.0, dampening=0.0, weight_decay=0.0, nesterov=False, clip=0.0, gmul=1.0):
+        """clip_grad_norm_(clip) + torch.optim.SGD on the flat buffers (lets_face_it_glow.py:61-72 with Optim.name = "sgd";
+        final_model.yaml:98-99: momentum 0.9). The momentum buffer lives in `adam_m` (one optimiser per model)."""
+        if momentum and self.adam_m is None:
+            self.adam_m = torch.zeros_like(self.params)
+        st = _stream()
+        if clip and clip > 0:
+            check(self.L.lfi_grad_sumsq(self.grads.data_ptr(), self.n_params, self.sumsq.data_ptr(),
+                                        self.sumsq_work.data_ptr(), st), "lfi_grad_sumsq")
+        self.step_count += 1
+        check(self.L.lfi_sgd_clip_step(self.params.data_ptr(), self.grads.data_ptr(), ptr(self.adam_m if momentum else None),
+                                       self.n_params, self.sumsq.data_ptr(), float(clip or 0.0), gmul, lr, float(momentum),
+                                       float(dampening), float(weight_decay), 1 if nesterov else 0, self.step_count, st),
+              "lfi_sgd_clip_step")
+
+    @translate_oom
+    def optimizer_step_rmsprop(self, lr, alpha=0.99, eps=1e-8, weight_decay=0.0, momentum=0.0, centered=False, clip=0.0, gmul=1.0):
+        """clip_grad_norm_(clip) + torch.optim.RMSprop on the flat buffers (Optim.name = "rmsprop"; final_model.yaml:96-97: eps 1e-8).
+        Square average in `adam_v`, momentum buffer in `adam_m`, the centered variant's gradient average in `opt_aux`."""
+        if self.adam_v is None:
+            self.adam_v = torch.zeros_like(self.params)
+        if momentum and self.adam_m is None:
+            self.adam_m = torch.zeros_like(self.params)
+        if centered and self.__dict__.get("opt_aux") is None:
+            self.opt_aux = torch.zeros_like(self.params)
+        st = _stream()
+        if clip and clip > 0:
+            check(self.L.lfi_grad_sumsq(self.grads.data_ptr(), self.n_params, self.sumsq.data_ptr(),
+                                        self.sumsq_work.data_ptr(), st), "lfi_grad_sumsq")
+        self.step_count += 1
+        check(self.L.lfi_rmsprop_clip_step(self.params.data_ptr(), self.grads.data_ptr(), self.adam_v.data_ptr(),
+                                           ptr(self.adam_m if momentum else None), ptr(self.opt_aux if centered else None),
+                                           self.n_params, self.sumsq.data_ptr(), float(clip or 0.0), gmul, lr, float(alpha), float(eps),
+                                           float(weight_decay), float(momentum), st), "lfi_rmsprop_clip_step")
+
     def optimizer_state(self):
-        """Adam's moments and step count (checkpoints, engine re-binds). Moments are None before the first step."""
+        """The optimiser's state buffers and step count (checkpoints, engine re-binds). Adam: first / second moments; SGD: `adam_m` =
+        momentum buffer; RMSprop: `adam_v` = square average, `adam_m` = momentum buffer, `opt_aux` = centered gradient average.
+        Buffers are None before the first step."""
+        aux = self.__dict__.get("opt_aux")
         return {"step_count": int(self.step_count),
+                "opt_aux": None if aux is None else aux.detach().clone(),
                 # the dropout-mask stream is keyed on (seed, call counter): a resumed / re-bound run must not replay the masks
                 # of steps 1..k (ADVICE r2)
                 "mask_calls": int(self._mask_calls),
@@ -1182,7 +1222,7 @@ class GlowEngine:
     def load_optimizer_state(self, state):
         self.step_count = int(state.get("step_count", 0))
         self._mask_calls = int(state.get("mask_calls", self._mask_calls))
-        for name in ("adam_m", "adam_v"):
+        for name in ("adam_m", "adam_v", "opt_aux"):
             t = state.get(name)
             if t is None:
                 setattr(self, name, None)

@@ -269,16 +269,39 @@ class LetsFaceItGlow(nn.Module):
                                  "flow_bucket_exposed": (e2, e3)})
         else:
             eng.backward(sign / nll.numel())
-        opt = self.hparams.Optim
-        if opt["name"] != "adam":
-            raise NotImplementedError("fused_training_step implements Adam (final_model.yaml); use training_step with "
-                                      "a torch optimiser for %r" % opt["name"])
-        a = opt["args"]["adam"]
-        eng.optimizer_step(lr, float(a["betas"][0]), float(a["betas"][1]), float(a["eps"]),
-                           clip=float(getattr(self.hparams, "gradient_clip_val", 0) or 0), gmul=1.0 / world_size)
+        self._fused_optimizer_step(eng, lr, 1.0 / world_size)
         self.global_step += 1
         self.log("train_loss", loss)
         return loss.detach()
+
+    def _fused_optimizer_step(self, eng, lr, gmul):
+        """configure_optimizers' three choices (lets_face_it_glow.py:61-72: Adam / SGD / RMSprop built as `cls(params, lr=lr,
+        **Optim["args"][name])`, torch defaults for whatever the YAML leaves out) as one launch on the flat buffers, the Trainer's
+        gradient_clip_val in front. Unknown keyword arguments raise as torch's constructors would."""
+        opt = self.hparams.Optim
+        name = opt["name"]
+        a = dict((opt.get("args") or {}).get(name) or {})
+        clip = float(getattr(self.hparams, "gradient_clip_val", 0) or 0)
+        if name == "adam":
+            betas = a.pop("betas", (0.9, 0.999))
+            eps = float(a.pop("eps", 1e-8))
+            if a.pop("weight_decay", 0) or a.pop("amsgrad", False):
+                raise NotImplementedError("fused Adam: weight_decay / amsgrad are not implemented (no shipped hparams file sets them)")
+            if a:
+                raise TypeError("Adam got unexpected arguments %s" % sorted(a))
+            eng.optimizer_step(lr, float(betas[0]), float(betas[1]), eps, clip=clip, gmul=gmul)
+        elif name == "sgd":
+            kw = {k: a.pop(k) for k in ("momentum", "dampening", "weight_decay", "nesterov") if k in a}
+            if a:
+                raise TypeError("SGD got unexpected arguments %s" % sorted(a))
+            eng.optimizer_step_sgd(lr, clip=clip, gmul=gmul, **kw)
+        elif name == "rmsprop":
+            kw = {k: a.pop(k) for k in ("alpha", "eps", "weight_decay", "momentum", "centered") if k in a}
+            if a:
+                raise TypeError("RMSprop got unexpected arguments %s" % sorted(a))
+            eng.optimizer_step_rmsprop(lr, clip=clip, gmul=gmul, **kw)
+        else:
+            raise KeyError(name)
 
     def validation_step(self, batch, batch_idx):
         with torch.no_grad():

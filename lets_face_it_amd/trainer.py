@@ -73,16 +73,30 @@ class Trainer:
             dist.broadcast(eng.inv_p, src=0)
             dist.broadcast(eng.inv_sign, src=0)
 
-    # ------------------------------------------------------------------ schedule (get_scheduler "step", utils.py:72-73)
+    # ------------------------------------------------------------------ schedule (get_scheduler, utils.py:60-82; stepped once per epoch)
     def lr_at(self, epoch):
+        """Learning rate of `epoch` under the three schedules get_scheduler builds, in closed form:
+        "step"            StepLR(step_size, gamma):                lr0 * gamma^(epoch // step_size)
+        "lambda"          LambdaLR(lambda e: e // val):            lr0 * (epoch // val)            (zero for the first `val` epochs)
+        "multiplicative"  MultiplicativeLR(lambda e: e // val):    lr0 * prod_{i=1..epoch} (i // val)   (zero from epoch 1 on while
+                          val > 1 - that is what the reference's lambda1 yields, utils.py:60-61,74-77; reproduced, not repaired)
+        no name           the optimiser's own lr."""
         lr = float(self.hparams.lr)
         sched = self.hparams.Optim["Schedule"]
-        if sched["name"] == "step":
+        name = sched["name"]
+        if not name:
+            return lr
+        if name == "step":
             a = sched["args"]["step"]
-            lr *= float(a["gamma"]) ** (epoch // int(a["step_size"]))
-        elif sched["name"]:
-            raise NotImplementedError("schedule %r in the fused trainer" % sched["name"])
-        return lr
+            return lr * float(a["gamma"]) ** (epoch // int(a["step_size"]))
+        if name == "lambda":
+            return lr * (epoch // int(sched["args"]["lambda"]["val"]))
+        if name == "multiplicative":
+            val = int(sched["args"]["multiplicative"]["val"])
+            for i in range(1, epoch + 1):
+                lr *= i // val
+            return lr
+        raise NotImplementedError("Unimplemented Scheduler!")
 
     # ------------------------------------------------------------------ loop
     def fit(self, model, datamodule):

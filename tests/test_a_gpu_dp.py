@@ -79,3 +79,35 @@ def test_rccl_launch_path_with_one_rank():
     tail = "\n".join(r.stdout.splitlines()[-15:])
     assert r.returncode == 0, tail
     assert "(nccl)" in r.stdout and "parameters identical to the collective-free steps: True" in r.stdout, tail
+
+
+def test_bench_gpus_2_starts_itself_and_reports_data_parallel():
+    """`python bench.py --gpus 2 --quick ...` typed like the N = 1 line (no launcher, no WORLD_SIZE): bench.py starts its two
+    ranks itself (bench.self_launch; here gloo, both ranks on the box's one card) and its stdout is ONE JSON line with n_gpus 2
+    and the `data_parallel` record of the two gradient buckets. The record is also kept as
+    gpurun_out/bench_n2_gloo_selflaunch.json (the rehearsal the driver's 8-GPU run will repeat on RCCL)."""
+    import json
+    if torch.cuda.is_initialized():
+        pytest.skip("the GPU is already initialised in this process: run tests/test_a_gpu_dp.py on its own or first")
+    if not os.path.exists("/dev/kfd"):
+        pytest.skip("no GPU")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", LFI_DIST_BACKEND="gloo")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    cmd = ["timeout", "-k", "10", "420", sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--quick", "--steps", "3",
+           "--warmup", "2"]
+    r = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=480)
+    assert r.returncode == 0, r.stderr[-1500:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout[-1500:]
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["steps"] == 3 and rec["scaling"] == "weak"
+    assert rec["config"]["parallelism"] == "dp2" and rec["config"]["frames_per_step_per_gpu"] == 256 * 56
+    dp = rec["data_parallel"]
+    assert dp["world_size"] == 2 and dp["backend"] == "gloo" and dp["mode"] == "overlap"
+    assert dp["flow_bucket_bytes"] + dp["encoder_bucket_bytes"] == 4 * rec["config"]["params"]
+    assert rec["value"] > 0 and rec["final_loss"] == rec["final_loss"]
+    out = os.path.join(ROOT, "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, "bench_n2_gloo_selflaunch.json"), "w") as f:
+        f.write(lines[0] + "\n")

@@ -1,0 +1,84 @@
+"""GPU: every optimiser and schedule the reference's configure_optimizers / get_scheduler can build
+(glow/lets_face_it_glow.py:61-72, glow/utils.py:60-82; hparam_tuning_configs/large_hparam_search.py:9-16 draws adam / sgd / rmsprop)
+runs on the fused path: clip + update as ONE launch on the flat buffers, checked against torch.optim + clip_grad_norm_ fed the
+engine's own gradients, step by step."""
+import copy
+from argparse import Namespace
+
+import pytest
+import torch
+
+from helpers import Fixture, report
+
+pytestmark = pytest.mark.gpu
+
+CASES = [
+    ("sgd", {"momentum": 0.9}),                                    # final_model.yaml:98-99
+    ("sgd", {}),
+    ("sgd", {"momentum": 0.8, "dampening": 0.1, "weight_decay": 1e-3}),
+    ("sgd", {"momentum": 0.9, "nesterov": True}),
+    ("rmsprop", {"eps": 1e-8}),                                    # final_model.yaml:96-97
+    ("rmsprop", {"eps": 1e-6, "alpha": 0.9, "momentum": 0.5, "weight_decay": 1e-3}),
+    ("rmsprop", {"eps": 1e-8, "centered": True}),
+    ("adam", {"betas": [0.9, 0.9999], "eps": 1e-8}),
+]
+
+
+@pytest.mark.parametrize("fx_name", ["tiny", "mid"])
+@pytest.mark.parametrize("name,kwargs", CASES, ids=["%s-%d" % (c[0], i) for i, c in enumerate(CASES)])
+def test_fused_optimizer_matches_torch_optim(fx_name, name, kwargs, gpu_device):
+    from lets_face_it_amd.glow.lets_face_it_glow import LetsFaceItGlow
+    fx = Fixture(fx_name)
+    hp = Namespace(**copy.deepcopy(fx.hp))
+    hp.Train["use_negative_nll_loss"] = False
+    hp.gradient_clip_val = 5.0
+    hp.Optim["name"] = name
+    hp.Optim["args"][name] = dict(kwargs)
+    hp.engine_precision = "f32"
+    lm = LetsFaceItGlow(hp)
+    lm.seq_glow.load_state_dict(fx.state_dict(torch.float32))
+    lm.to(gpu_device)
+    lm.seq_glow.glow.set_actnorm_init(True)
+    lm.train()
+    lm.seq_glow.injected_masks = {k: v.to(gpu_device) for k, v in fx.masks(torch.float32).items()} if fx.masks() else None
+    batch = {k: v.to(gpu_device) for k, v in fx.batch(torch.float32).items()}
+    eng = lm.seq_glow._ensure_engine(gpu_device)
+    ref_p = torch.nn.Parameter(eng.params.detach().clone())
+    cls = {"adam": torch.optim.Adam, "sgd": torch.optim.SGD, "rmsprop": torch.optim.RMSprop}[name]
+    kw = dict(kwargs)
+    if "betas" in kw:
+        kw["betas"] = tuple(kw["betas"])
+    opt = cls([ref_p], lr=3e-3, foreach=False, **kw)
+    worst = 0.0
+    for step in range(4):
+        lm.fused_training_step(batch, 3e-3)
+        # the reference side: the SAME gradient (the engine's, as it lies in the flat buffer after the step), clipped and applied by torch
+        ref_p.grad = eng.grads.detach().clone()
+        torch.nn.utils.clip_grad_norm_([ref_p], 5.0)
+        opt.step()
+        d = (eng.params - ref_p.detach()).abs().max().item()
+        scale = max(1.0, ref_p.detach().abs().max().item())
+        worst = max(worst, d / scale)
+        # keep the two trajectories on the same parameters so that every step compares ONE update (rounding does not compound into
+        # the next step's gradient)
+        with torch.no_grad():
+            ref_p.copy_(eng.params)
+    report("fused %s %s on %s: worst parameter difference after one update, 4 steps: %.2e" % (name, kwargs, fx_name, worst))
+    assert worst < 2e-6
+
+
+def test_unknown_optimizer_arguments_raise(gpu_device):
+    from lets_face_it_amd.glow.lets_face_it_glow import LetsFaceItGlow
+    fx = Fixture("tiny")
+    hp = Namespace(**copy.deepcopy(fx.hp))
+    hp.Train["use_negative_nll_loss"] = False
+    hp.Optim["name"] = "sgd"
+    hp.Optim["args"]["sgd"] = {"momentum": 0.9, "bogus": 1}
+    lm = LetsFaceItGlow(hp)
+    lm.seq_glow.load_state_dict(fx.state_dict(torch.float32))
+    lm.to(gpu_device)
+    lm.seq_glow.glow.set_actnorm_init(True)
+    lm.train()
+    batch = {k: v.to(gpu_device) for k, v in fx.batch(torch.float32).items()}
+    with pytest.raises(TypeError, match="bogus"):
+        lm.fused_training_step(batch, 1e-3)

@@ -149,18 +149,45 @@ def test_oom_is_reported_in_the_wording_the_tuning_harness_matches():
         other()
 
 
-def test_bench_refuses_multi_gpu_without_a_launcher():
-    """`bench.py --gpus N` outside torch.distributed.run must exit non-zero before it touches the GPU (a HIP poison that makes
-    hipInit fail proves the order: the error text is bench.py's own, not a HIP failure)."""
+def _run_bench(argv, env_extra=None, drop=("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"), limit=300):
     import subprocess
     import sys
-    env = dict(os.environ, HIP_VISIBLE_DEVICES="-1", ROCR_VISIBLE_DEVICES="-1")
-    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+    env = dict(os.environ, HIP_VISIBLE_DEVICES="-1", ROCR_VISIBLE_DEVICES="-1")   # a HIP poison: nothing here may reach the GPU
+    for k in drop:
         env.pop(k, None)
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "1", "--warmup", "0"],
-                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv, env=env, stdout=subprocess.PIPE,
+                          stderr=subprocess.PIPE, text=True, timeout=limit)
+
+
+def test_bench_refuses_a_world_size_that_contradicts_gpus():
+    """Inside a launcher (WORLD_SIZE set) `--gpus N` must equal it; the refusal comes before anything touches the GPU (the HIP
+    poison proves the order: the error text is bench.py's own, not a HIP failure)."""
+    r = _run_bench(["--gpus", "4", "--steps", "1", "--warmup", "0"], {"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"}, drop=())
     assert r.returncode != 0
-    assert "torch.distributed.run" in r.stdout and "--nproc-per-node 4" in r.stdout, r.stdout[-500:]
+    assert "torch.distributed.run" in r.stderr and "--nproc-per-node 4" in r.stderr, r.stderr[-500:]
+
+
+def test_bench_gpus_n_starts_its_own_ranks():
+    """`python bench.py --gpus 2 ...` exactly as the driver types the N = 1 line (no WORLD_SIZE): the process starts the two ranks
+    under torch.distributed.run as children, they rendezvous on 127.0.0.1 (gloo, --launch-check: no GPU in this suite), and the
+    parent's stdout is rank 0's ONE JSON line with n_gpus = 2."""
+    import json
+    r = _run_bench(["--gpus", "2", "--launch-check"])
+    assert r.returncode == 0, r.stderr[-800:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["launch_check"] is True and rec["rank_sum"] == rec["expected_rank_sum"] == 3.0
+    assert "--nproc-per-node 2" in r.stderr and "--master-addr 127.0.0.1" in r.stderr
+
+
+def test_bench_gpus_n_relays_a_failing_rank():
+    """The real workload on a box without GPUs: every rank dies when it asks for its device; the parent prints no JSON line and
+    exits non-zero with the launcher's code."""
+    r = _run_bench(["--gpus", "2", "--quick", "--steps", "1", "--warmup", "0"], {"LFI_DIST_BACKEND": "gloo"}, limit=600)
+    assert r.returncode != 0
+    assert not [ln for ln in r.stdout.splitlines() if ln.strip().startswith("{")], r.stdout[-500:]
 
 
 def test_trainer_picks_rccl_on_cuda(monkeypatch):

@@ -146,3 +146,37 @@ def test_sampler_run_split_covers_every_frame_once(monkeypatch):
     assert [c for _, c in GlowEngine._sample_runs(10)] == [4, 3, 3]
     monkeypatch.setenv("LFI_SAMPLE_RUNS", "9")
     assert len(GlowEngine._sample_runs(4)) == 4      # never more runs than frames
+
+
+def test_lr_at_reproduces_every_reference_schedule():
+    """Trainer.lr_at in closed form == the torch schedulers get_scheduler builds (glow/utils.py:60-82), stepped once per epoch as
+    Lightning does: StepLR, LambdaLR(e // val), MultiplicativeLR(e // val), and no schedule."""
+    import copy
+    from argparse import Namespace
+    from torch.optim.lr_scheduler import LambdaLR, MultiplicativeLR, StepLR
+    from helpers import Fixture
+    from lets_face_it_amd.trainer import Trainer
+    base = Fixture("tiny").hp
+    for name, args in (("step", {"gamma": 0.73, "step_size": 3}), ("lambda", {"val": 4}), ("multiplicative", {"val": 1}),
+                       ("multiplicative", {"val": 3}), (None, None)):
+        hp = copy.deepcopy(base)
+        hp["lr"] = 2e-4
+        hp["Optim"]["Schedule"]["name"] = name
+        if name:
+            hp["Optim"]["Schedule"]["args"][name] = args
+        tr = Trainer(Namespace(**hp), device="cpu", checkpoint_dir="")
+        p = torch.nn.Parameter(torch.zeros(1))
+        opt = torch.optim.SGD([p], lr=2e-4)
+        sched = {"step": lambda: StepLR(opt, **args), "lambda": lambda: LambdaLR(opt, lr_lambda=[lambda e: e // args["val"]]),
+                 "multiplicative": lambda: MultiplicativeLR(opt, lr_lambda=[lambda e: e // args["val"]]), None: lambda: None}[name]()
+        for epoch in range(12):
+            want = opt.param_groups[0]["lr"]
+            assert abs(tr.lr_at(epoch) - want) <= 1e-12 * max(1.0, abs(want)) + 1e-18, (name, args, epoch, tr.lr_at(epoch), want)
+            opt.step()
+            if sched is not None:
+                sched.step()
+    hp = copy.deepcopy(base)
+    hp["Optim"]["Schedule"]["name"] = "cosine"
+    import pytest
+    with pytest.raises(NotImplementedError):
+        Trainer(Namespace(**hp), device="cpu", checkpoint_dir="").lr_at(0)

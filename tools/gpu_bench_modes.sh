@@ -15,8 +15,8 @@ for P in f32 bf16x3; do
   tail -1 $OUT/${TAG}_sample_$P.log | cut -c1-600
 done
 for P in f32 bf16x3; do
-  timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_prof_train_$P -o run -- python3 bench.py --steps 5 --warmup 2 --precision $P --cpu-baseline-seconds 0 > $OUT/${TAG}_prof_train_$P.log 2>&1
+  timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_prof_train_$P -o run -- python3 bench.py --no-gpu-state --steps 5 --warmup 2 --precision $P --cpu-baseline-seconds 0 > $OUT/${TAG}_prof_train_$P.log 2>&1
 done
-timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_prof_sample -o run -- python3 bench.py --workload sample --steps 1 --warmup 1 --precision f32 > $OUT/${TAG}_prof_sample.log 2>&1
+timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/${TAG}_prof_sample -o run -- python3 bench.py --no-gpu-state --workload sample --steps 1 --warmup 1 --precision f32 > $OUT/${TAG}_prof_sample.log 2>&1
 find $OUT -name "*kernel_trace.csv" -size +20M -delete
 ls -la $OUT | tail -20
