@@ -198,6 +198,11 @@ int lfi_encode_windows_compact_dgi(const lfi_enc_desc* d);
 int lfi_encode_windows_grad_stash_bf16(const lfi_enc_desc* d);
 /* 1 when the shape runs on the row-layout fused GRU kernels in both directions, i.e. lfi_enc_desc.stash_f16 may be set. */
 int lfi_encode_windows_stash_f16_ok(const lfi_enc_desc* d);
+/* Which forward kernel lfi_encode_windows_fwd takes for this descriptor with 16-byte aligned buffers (tests and the bench's kernel
+ * name; shape and environment switches only): 0 = one GEMM + gate kernel per history step, 1 = fused accumulator-layout kernel,
+ * 2 = 32-window row-layout kernel, 3 = 64-window kernel (32 x 32 x 16), 4 = 64-window kernel (16 x 16 x 32), 5 = 64-window
+ * kernel with the gate epilogue under the matrix phase (transposed product, hid = 256). (glow/models.py:55-80) */
+int lfi_encode_windows_fwd_variant(const lfi_enc_desc* d, int masked, int stashed);
 int lfi_encode_windows_scatter(const lfi_enc_desc* d, const float* dgi, const float* dgh, const float* mask, float* dXp,
                                void* stream);
 /* "enc: none" modality (glow/models.py:76-77), the flattened p1_face history (glow/models.py:601-603) and the input of an

@@ -112,6 +112,7 @@ def lib():
         "lfi_flow_seq_bwd_planes": (i, [P(FlowDims), P(FlowParams), vp, vp, f, vp, vp, i, vp]),
         "lfi_encode_windows_grad_stash_bf16": (i, [P(EncDesc)]),
         "lfi_encode_windows_stash_f16_ok": (i, [P(EncDesc)]),
+        "lfi_encode_windows_fwd_variant": (i, [P(EncDesc), i, i]),
         "lfi_gemm_planes_work_floats": (l, [P(PGemmDesc)]),
         "lfi_gemm_planes_colpart_rows": (l, [P(PGemmDesc)]),
         "lfi_colsum_work_floats": (l, [i, i, i]),
@@ -178,7 +179,7 @@ def lib():
 EXPORTS = [
     "lfi_last_error", "lfi_version", "lfi_gemm_work_floats", "lfi_gemm_f32", "lfi_gemm_colpart_rows", "lfi_planes_elems", "lfi_planes_from_f32",
     "lfi_gemm_planes", "lfi_gemm_planes_work_floats", "lfi_gemm_planes_colpart_rows",
-    "lfi_flow_bwd_emits_planes", "lfi_flow_seq_bwd_planes", "lfi_encode_windows_grad_stash_bf16", "lfi_encode_windows_stash_f16_ok", "lfi_colsum_work_floats",
+    "lfi_flow_bwd_emits_planes", "lfi_flow_seq_bwd_planes", "lfi_encode_windows_grad_stash_bf16", "lfi_encode_windows_stash_f16_ok", "lfi_encode_windows_fwd_variant", "lfi_colsum_work_floats",
     "lfi_colsum_f32", "lfi_cols_fold", "lfi_encode_windows_work_floats", "lfi_encode_windows_fwd", "lfi_encode_windows_bwd",
     "lfi_encode_windows_bias_rows", "lfi_encode_windows_bias_grads",
     "lfi_encode_windows_scatter", "lfi_encode_windows_compact_dgi", "lfi_gather_windows", "lfi_pad_rows", "lfi_dropout_masks", "lfi_leaky_grad", "lfi_fill_frame_nb", "lfi_flow_prep_floats", "lfi_flow_prep",

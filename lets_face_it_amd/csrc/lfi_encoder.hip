@@ -1296,6 +1296,268 @@ __global__ __launch_bounds__(ENC_NT, 1) void enc_gru_fwd_r64_kernel(EncArgs a, E
   }
 }
 
+// ---- the forward recurrence with the gate epilogue UNDER the matrix phase (round 5; hid = 256, fragment order of
+// enc_frag_weights16_kernel). enc_gru_fwd_r64_kernel runs a step as two serial parts on a lone wave per SIMD: 1152 MFMAs (18.4 k
+// cycles of matrix pipe), then ~20 k cycles of transposes through LDS, gate math and stores while the pipe idles (PMC: MFMA busy
+// 35 % of the wave's lifetime). Two changes let one wave fill the pipe's shadow with its own VALU work:
+//   1. the product is taken TRANSPOSED (weights as the MFMA's A operand, state as B: the same products in the same order, bit for
+//      bit): accumulator (mi, ni) register r is window 16 ni + (lane & 15), hidden unit 64 cg + 16 mi + 4 (lane >> 4) + r - four
+//      consecutive units of one window per lane, which is the epilogue's own 16-byte layout: no transpose tiles (69 KB of LDS, six
+//      write-wait-read round trips per step), and h_{s-1} stays in registers;
+//   2. the wave's 64 hidden units are taken as four 16-unit tiles one after the other, each with its whole k sweep (phase p: 8
+//      blocks of 36 MFMAs); tile p - 1's epilogue is independent of tile p's MFMAs and is issued between them (sched_group_barrier:
+//      one MFMA, then up to three VALU). Only the last tile's epilogue is exposed. The state images are double-buffered (step parity)
+//      because tile 0's new state is written while other waves still read the old one: one barrier per step.
+// Weight fragments: a ring of four blocks, loaded three blocks (~1.7 k cycles) ahead and straight through the step boundary and the
+// barrier; every fragment is fetched once per step and wave as before (L2 -> CU stream unchanged), the state fragments are re-read
+// from LDS for each of the four tiles. Projected inputs are loaded one phase ahead of their use, three loads per two blocks.
+// (timing-only experiment switches, garbage results: -DLFI_T16_NV=n VALU per MFMA in the interleave (0: the compiler's own order),
+// -DLFI_T16_NO_XP no projected-input loads, -DLFI_T16_NO_W no weight loads in the loop, -DLFI_T16_NO_MFMA no products,
+// -DLFI_T16_NO_EPI no gate math / stores under the products, -DLFI_T16_RING=n blocks of weight prefetch)
+#ifndef LFI_T16_NV
+#define LFI_T16_NV 3
+#endif
+#ifndef LFI_T16_RING
+#define LFI_T16_RING 12   // weight ring: slots of one (block, gate) = two fragments; a divisor of 96; RING - 1 of them in flight
+#endif
+template <bool STASH, bool MASK, bool S16>
+__global__ __launch_bounds__(ENC_NT, 1) void enc_gru_fwd_t16_kernel(EncArgs a, EncFused q) {
+  constexpr int hid = 256, G3 = 768, ldx = 264, R2 = 64, nct = 16, IMG = R2 * ldx;
+  constexpr unsigned h4 = hid * 4u;
+  const int tid = threadIdx.x, lane = tid & 63, cg = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wl = lane & 15, jq = lane >> 4;
+  const int wbase = blockIdx.x * R2;
+  const int pos0 = a.start - a.hist + 1;
+  // LDS: state images [step parity][hi, lo][R2][ldx] bf16 | biases [6][256] | per-row tables | masks [R2][hist]
+  __bf16* X = reinterpret_cast<__bf16*>(enc_smem);
+  float* bias = reinterpret_cast<float*>(X + 4 * IMG);
+  unsigned* rowx = reinterpret_cast<unsigned*>(bias + 6 * hid);
+  unsigned* roww = rowx + R2;
+  float* mk_tab = reinterpret_cast<float*>(roww + R2);
+  {
+    uint4* z = reinterpret_cast<uint4*>(X);
+    for (int i = tid; i < 4 * IMG / 8; i += ENC_NT) z[i] = uint4{0u, 0u, 0u, 0u};   // h_{-1} = 0
+  }
+  for (int i = tid; i < 6 * hid; i += ENC_NT) bias[i] = i < 3 * hid ? a.b_ih[i] : a.b_hh[i - 3 * hid];
+  for (int i = tid; i < R2; i += ENC_NT) {
+    const int w = min(wbase + i, a.F - 1);   // rows past F recompute and re-store the last window
+    const int n = w / a.B, b = w - n * a.B;
+    rowx[i] = (unsigned)(b * a.T + pos0 + n) * (unsigned)(G3 * 4);
+    roww[i] = (unsigned)w * h4;
+  }
+  if (MASK)
+    for (int i = tid; i < R2 * a.hist; i += ENC_NT) {
+      const int rl = i / a.hist, s = i - rl * a.hist;
+      mk_tab[i] = a.mask[(long)min(wbase + rl, a.F - 1) * a.hist + s];
+    }
+  const enc_rsrc bx = enc_buf(a.Xp, (long)a.B * a.T * G3 * 4);
+  const enc_rsrc bw = enc_buf(q.wfrag, 12L * hid * hid);
+  const unsigned lane16 = (unsigned)lane * 16u;
+  const unsigned jb4 = (unsigned)(cg * 64 + 4 * jq) * 4u;   // byte offset of this lane's units in tile 0 of its wave (+ 64 per tile)
+  // element offsets into an image: fragment reads (row wl of window tile ni, k chunk of lane group jq) and state writes
+  const int sfr = wl * ldx + 8 * ((jq >> 1) + 16 * (jq & 1));
+  const int swr = wl * ldx + cg * 64 + 4 * jq;
+  // (the wave's column group goes into the per-lane offset, the plane into the instruction's immediate: what is left for the scalar
+  // offset is a compile-time constant per load - 192 runtime scalars lived in VGPR lanes and cost a v_readlane each)
+  const unsigned lanecg = lane16 + (unsigned)cg * 8192u;
+  auto wload = [&](int m, int g, int mi, int plane) {
+    const unsigned so = (unsigned)((((m * 3 + g) * nct + mi) * 2) * 1024);
+    return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(bw, lanecg + (unsigned)plane * 1024u, so, 0));
+  };
+  constexpr int WR = LFI_T16_RING;
+  EncFrag wr[WR][2];             // weight ring [slot = (block, gate) mod WR][plane (hi, lo)]
+  ebf16x8 sh[2][4], sl[2][4];    // state fragments [buffer][window tile]
+  f32x4 acc[2][4][3];            // [phase parity][window tile][gate]
+  f32x4 hprev[4][4];             // h_{s-1} of this lane's units [unit tile][window tile]
+  f32x4 xin[4][3];               // projected inputs of the tile whose MFMAs run now [window tile][gate]
+  f32x4 rr, uu;                  // between the two halves of an epilogue chunk
+  unsigned xo[4], wo[4];
+  float mk[4];
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni) hprev[mi][ni] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j < WR - 1; ++j) {
+    wr[j][0].u = wload((j / 3) & 7, j % 3, (j / 3) >> 3, 0);
+    wr[j][1].u = wload((j / 3) & 7, j % 3, (j / 3) >> 3, 1);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int ni = 0; ni < 4; ++ni) {
+    xo[ni] = rowx[16 * ni + wl] + jb4;
+    wo[ni] = roww[16 * ni + wl];
+    mk[ni] = 1.0f;
+  }
+
+  for (int s = 0; s < a.hist; ++s) {
+    const __bf16* Xr = X + ((s & 1) ^ 1) * (2 * IMG) + sfr;   // h_{s-1}
+    __bf16* Xw = X + (s & 1) * (2 * IMG) + swr;               // h_s
+    const unsigned sx = (unsigned)s * (unsigned)(G3 * 4);
+    const enc_rsrc bhs = enc_buf(STASH ? a.hseq + (long)s * a.F * hid : nullptr, STASH ? (long)a.F * hid * 4 : 0);
+    const enc_rsrc bgs = S16 ? enc_buf(STASH ? reinterpret_cast<const _Float16*>(a.gates) + (long)s * a.F * 4 * hid : nullptr,
+                                       STASH ? (long)a.F * hid * 8 : 0)
+                             : enc_buf(STASH ? a.gates + (long)s * a.F * 4 * hid : nullptr, STASH ? (long)a.F * hid * 16 : 0);
+    if (MASK) {
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) mk[ni] = mk_tab[(16 * ni + wl) * a.hist + s];
+    }
+    auto sload = [&](int m, ebf16x8 (&h)[4], ebf16x8 (&l)[4]) {
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) {
+        h[ni] = *reinterpret_cast<const ebf16x8*>(Xr + ni * 16 * ldx + m * 16);
+        l[ni] = *reinterpret_cast<const ebf16x8*>(Xr + IMG + ni * 16 * ldx + m * 16);
+      }
+    };
+    sload(0, sh[0], sl[0]);
+    f32x4 bir, bhr, biu, bhu, bin, bhn;
+#pragma unroll
+    for (int p = 0; p < 5; ++p) {
+      if (p > 0) {   // biases of the tile whose epilogue runs in this phase
+        const float* bb = bias + cg * 64 + 16 * (p - 1) + 4 * jq;
+        bir = *reinterpret_cast<const f32x4*>(bb); bhr = *reinterpret_cast<const f32x4*>(bb + 3 * hid);
+        biu = *reinterpret_cast<const f32x4*>(bb + hid); bhu = *reinterpret_cast<const f32x4*>(bb + 4 * hid);
+        bin = *reinterpret_cast<const f32x4*>(bb + 2 * hid); bhn = *reinterpret_cast<const f32x4*>(bb + 5 * hid);
+      }
+#pragma unroll
+      for (int m = 0; m < 8; ++m) {
+        const int i = p * 8 + m, ni = m >> 1;
+        if (p < 4) {
+          if (i + 1 < 32) sload((i + 1) & 7, sh[(i + 1) & 1], sl[(i + 1) & 1]);
+          const ebf16x8 (&bh)[4] = sh[i & 1];
+          const ebf16x8 (&bl)[4] = sl[i & 1];
+#ifdef LFI_T16_NO_MFMA
+          if (m == 0)
+#pragma unroll
+            for (int g = 0; g < 3; ++g)
+#pragma unroll
+              for (int n4 = 0; n4 < 4; ++n4) acc[p & 1][n4][g] = f32x4{(float)bh[n4][0], (float)bl[n4][1], (float)wr[(i * 3 + g) % WR][0].v[0], (float)wr[(i * 3 + g) % WR][1].v[1]};
+#else
+#pragma unroll
+          for (int g = 0; g < 3; ++g) {
+#ifndef LFI_T16_NO_W
+            {
+              const int jn = (i * 3 + g + WR - 1) % 96, in = jn / 3;   // (past the last block: the next step's first ones)
+              wr[jn % WR][0].u = wload(in & 7, jn % 3, in >> 3, 0);
+              wr[jn % WR][1].u = wload(in & 7, jn % 3, in >> 3, 1);
+            }
+#endif
+            const ebf16x8 whi = wr[(i * 3 + g) % WR][0].v, wlo = wr[(i * 3 + g) % WR][1].v;
+#pragma unroll
+            for (int n4 = 0; n4 < 4; ++n4) {
+              const f32x4 c0 = m == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[p & 1][n4][g];
+              acc[p & 1][n4][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whi, bl[n4], c0, 0, 0, 0);
+            }
+#pragma unroll
+            for (int n4 = 0; n4 < 4; ++n4) acc[p & 1][n4][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wlo, bh[n4], acc[p & 1][n4][g], 0, 0, 0);
+#pragma unroll
+            for (int n4 = 0; n4 < 4; ++n4) acc[p & 1][n4][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(whi, bh[n4], acc[p & 1][n4][g], 0, 0, 0);
+          }
+#endif
+        }
+#ifdef LFI_T16_NO_EPI
+        if (p > 0 && m == 7) {
+          const int qt = p - 1;
+#pragma unroll
+          for (int n4 = 0; n4 < 4; ++n4) {
+            const f32x4 hn = acc[qt & 1][n4][0] + acc[qt & 1][n4][1] + acc[qt & 1][n4][2] + xin[n4][0] + xin[n4][1] + xin[n4][2];
+            uint2 h, l;
+            split2(hn[0], hn[1], &h.x, &l.x);
+            split2(hn[2], hn[3], &h.y, &l.y);
+            *reinterpret_cast<uint2*>(Xw + n4 * 16 * ldx + 16 * qt) = h;
+            *reinterpret_cast<uint2*>(Xw + IMG + n4 * 16 * ldx + 16 * qt) = l;
+            hprev[qt][n4] = hn;
+          }
+        }
+#else
+        if (p > 0) {   // epilogue chunk (unit tile p - 1, window tile ni): first half in the even block, second half in the odd one
+          const int qt = p - 1;
+          const f32x4 (&ac)[3] = acc[qt & 1][ni];
+          const unsigned t64 = (unsigned)qt * 64u;   // byte offset of the tile's units in fp32 rows
+          if ((m & 1) == 0) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              rr[e] = ENC_SIG(mk[ni] * xin[ni][0][e] + bir[e] + (ac[0][e] + bhr[e]));
+              uu[e] = ENC_SIG(mk[ni] * xin[ni][1][e] + biu[e] + (ac[1][e] + bhu[e]));
+            }
+            if (STASH && !S16) {
+              enc_st4(rr, bgs, 4u * wo[ni] + jb4, t64);
+              enc_st4(uu, bgs, 4u * wo[ni] + jb4, h4 + t64);
+            }
+          } else {
+            f32x4 ghn, nn, hn;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              ghn[e] = ac[2][e] + bhn[e];
+              nn[e] = ENC_TANH(mk[ni] * xin[ni][2][e] + bin[e] + rr[e] * ghn[e]);
+              hn[e] = (1.0f - uu[e]) * nn[e] + uu[e] * hprev[qt][ni][e];
+            }
+            if (STASH && S16) {   // [window][unit][r, z, n, W_hn h] fp16: this lane's four units = 32 contiguous bytes
+              const uint2 g0 = enc_pack_gates(rr[0], uu[0], nn[0], ghn[0]), g1 = enc_pack_gates(rr[1], uu[1], nn[1], ghn[1]);
+              const uint2 g2 = enc_pack_gates(rr[2], uu[2], nn[2], ghn[2]), g3 = enc_pack_gates(rr[3], uu[3], nn[3], ghn[3]);
+              const unsigned go = 2u * (wo[ni] + jb4);
+              __builtin_amdgcn_raw_buffer_store_b128((enc_u32x4){g0.x, g0.y, g1.x, g1.y}, bgs, go, 2 * t64, LFI_ENC_ST_AUX);
+              __builtin_amdgcn_raw_buffer_store_b128((enc_u32x4){g2.x, g2.y, g3.x, g3.y}, bgs, go, 2 * t64 + 16, LFI_ENC_ST_AUX);
+              enc_st4(hn, bhs, wo[ni] + jb4, t64);
+            } else if (STASH) {
+              enc_st4(nn, bgs, 4u * wo[ni] + jb4, 2 * h4 + t64);
+              enc_st4(ghn, bgs, 4u * wo[ni] + jb4, 3 * h4 + t64);
+              enc_st4(hn, bhs, wo[ni] + jb4, t64);
+            }
+            {
+              uint2 h, l;
+              split2(hn[0], hn[1], &h.x, &l.x);
+              split2(hn[2], hn[3], &h.y, &l.y);
+              *reinterpret_cast<uint2*>(Xw + ni * 16 * ldx + 16 * qt) = h;
+              *reinterpret_cast<uint2*>(Xw + IMG + ni * 16 * ldx + 16 * qt) = l;
+            }
+            hprev[qt][ni] = hn;
+          }
+        }
+#endif
+        if (p < 4) {   // projected inputs of tile p, for its epilogue one phase from now
+          const unsigned t64 = (unsigned)p * 64u;
+#ifdef LFI_T16_NO_XP
+          if (s == 0 && p == 0) xin[ni][0] = xin[ni][1] = xin[ni][2] = f32x4{0.1f, 0.2f, 0.3f, 0.4f} * (float)(t64 + lane);
+#else
+          if ((m & 1) == 0) {
+            xin[ni][0] = enc_ld4(bx, xo[ni], sx + t64);
+            xin[ni][1] = enc_ld4(bx, xo[ni], sx + h4 + t64);
+          } else {
+            xin[ni][2] = enc_ld4(bx, xo[ni], sx + 2 * h4 + t64);
+          }
+#endif
+        }
+#if LFI_T16_NV > 0
+        if (p > 0 && p < 4) {
+#pragma unroll
+          for (int k = 0; k < 36; ++k) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, LFI_T16_NV, 0);
+          }
+        }
+#endif
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    __syncthreads();   // h_s is complete in its image, and every wave has read h_{s-1} for the last time
+  }
+  // cat(seq[:, -1], h_n[0]): the final state, once or twice (glow/models.py:63-64) - outside the step loop, whose body stays one
+  // basic block (a branch would cut the scheduling regions the interleave lives in)
+#pragma unroll
+  for (int ni = 0; ni < 4; ++ni) {
+    const int w = wbase + 16 * ni + wl;
+    if (w < a.F) {
+      float* c = a.cond + (long)w * a.ldcond + a.col + cg * 64 + 4 * jq;
+#pragma unroll
+      for (int mi = 0; mi < 4; ++mi) {
+        *reinterpret_cast<f32x4*>(c + 16 * mi) = hprev[mi][ni];
+        if (a.dup) *reinterpret_cast<f32x4*>(c + hid + 16 * mi) = hprev[mi][ni];
+      }
+    }
+  }
+}
+
 // BPTT of the same block of windows in one workgroup: dh lives in the accumulator layout of the wave that owns
 // (rows, hidden) tile (rg, cg); per step the gate derivatives are taken in registers, written to dgi / dgh (the
 // deferred weight-gradient GEMMs read those) and fed gate by gate through LDS as the A operand of
@@ -2113,6 +2375,14 @@ static bool enc_m16_enabled() {   // the forward 64-window kernel on v_mfma_f32_
   const char* e = getenv("LFI_ENC_M16");
   return !(e && e[0] == '0');
 }
+// the forward kernel with the gate epilogue under the matrix phase (read at every call: tests compare): LFI_ENC_T16 = 0 never,
+// 1 (default) where no stash is written (inference, validation, the sampler's static part: 0.46 against 0.51 ms on the p2_face
+// shape), 2 with a stash too (training: measured SLOWER there, 0.545 against 0.532 ms alone and +0.15 ms on the whole step - the
+// stash stores share the wave's in-order vmcnt queue with the weight stream)
+static int enc_t16_mode() {
+  const char* e = getenv("LFI_ENC_T16");
+  return e && e[0] >= '0' && e[0] <= '2' ? e[0] - '0' : 1;
+}
 static bool enc_r64_enabled() {   // (read at every call: tests switch it inside one process)
   const char* e = getenv("LFI_ENC_R64");
   return !(e && e[0] == '0');
@@ -2129,6 +2399,39 @@ static bool enc_wide_bwd_shape_ok(const lfi_enc_desc* d, int lddcond, EncFused* 
 static bool enc_bwd_uses_r64(const lfi_enc_desc* d, EncFused* q) {
   if (!enc_r64_enabled() || !enc_wide_bwd_shape_ok(d, d->ldcond, q)) return false;
   return enc_bwd_r64_lds(*q) <= 160 * 1024 && lfi_cdiv((long)d->N * d->B, 2 * q->R) >= 128;
+}
+
+static size_t enc_fwd_r64_lds(const EncFused& q, int hist, bool masked) {
+  const int R2 = 2 * q.R;
+  return (size_t)2 * R2 * (q.Kp + 8) * sizeof(__bf16) + (size_t)ENC_NW * 2 * 32 * ENC_TP * sizeof(float) +
+         (size_t)6 * q.Jp * sizeof(float) + (size_t)2 * R2 * sizeof(unsigned) + (masked ? (size_t)R2 * hist * sizeof(float) : 0);
+}
+static size_t enc_fwd_t16_lds(int hist, bool masked) {
+  return (size_t)4 * 64 * 264 * sizeof(__bf16) + (size_t)6 * 256 * sizeof(float) + (size_t)2 * 64 * sizeof(unsigned) +
+         (masked ? (size_t)64 * hist * sizeof(float) : 0);
+}
+// which forward kernel a descriptor takes (lfi_encode_windows_fwd_variant's numbering); fills q for the fused ones
+static int enc_fwd_variant(const lfi_enc_desc* d, bool masked, bool stashed, bool aligned, EncFused* q) {
+  if (d->lstm || !enc_fused_shape(d->hid, q)) return 0;
+  const int hid = d->hid;
+  const long F = (long)d->N * d->B;
+  const bool vec_ok = d->precision == 1 && hid % 4 == 0 && d->ldcond % 4 == 0 && d->col % 4 == 0 && aligned;
+  const int R2 = 2 * q->R;
+  const bool take64 = enc_wide_enabled() && enc_r64_enabled() && vec_ok && enc_fwd_r64_lds(*q, d->hist, masked) <= 160 * 1024 &&
+                      lfi_cdiv(F, R2) >= 128;
+  const bool m16 = take64 && q->Kp == 256 && q->ncg * 64 == q->Jp && enc_m16_enabled();
+  if (m16 && hid == 256 && R2 == 64 && enc_fwd_t16_lds(d->hist, masked) <= 160 * 1024 && enc_t16_mode() >= (stashed ? 2 : 1)) return 5;
+  if (m16) return 4;
+  if (take64) return 3;
+  const size_t ldsw = (size_t)2 * q->R * (q->Kp + 8) * sizeof(__bf16) + (size_t)ENC_NW * 32 * ENC_TP * sizeof(float) +
+                      (size_t)6 * q->Jp * sizeof(float) + (size_t)2 * q->R * sizeof(unsigned) +
+                      (masked ? (size_t)q->R * d->hist * sizeof(float) : 0);
+  if (enc_wide_enabled() && vec_ok && ldsw <= 80 * 1024) return 2;
+  return 1;
+}
+extern "C" int lfi_encode_windows_fwd_variant(const lfi_enc_desc* d, int masked, int stashed) {
+  EncFused q = {};
+  return d ? enc_fwd_variant(d, masked != 0, stashed != 0, true, &q) : 0;
 }
 
 extern "C" long lfi_encode_windows_work_floats(const lfi_enc_desc* d) {
@@ -2173,16 +2476,13 @@ extern "C" int lfi_encode_windows_fwd(const lfi_enc_desc* d, const float* Xp, co
     LFI_REQUIRE(!gates || hseq, "lfi_encode_windows_fwd: the gate stash needs the state stash too");
     // (without a gate stash nothing is kept for a backward pass: hseq is not written either)
     const bool x3 = d->precision == 1;
-    // (decided before the weights are converted: the 64-window kernel on the 16 x 16 x 32 shape wants its own fragment order)
+    // (decided before the weights are converted: the 64-window kernels on the 16 x 16 x 32 shape want their own fragment order)
     auto al16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
-    const bool vec_ok = x3 && hid % 4 == 0 && d->ldcond % 4 == 0 && d->col % 4 == 0 && al16(Xp) && al16(cond) &&
-                        (!gates || (al16(gates) && al16(hseq)));
+    const bool aligned = al16(Xp) && al16(cond) && (!gates || (al16(gates) && al16(hseq)));
     const int R2 = 2 * q.R;
-    const size_t lds64 = (size_t)2 * R2 * (q.Kp + 8) * sizeof(__bf16) + (size_t)ENC_NW * 2 * 32 * ENC_TP * sizeof(float) +
-                         (size_t)6 * q.Jp * sizeof(float) + (size_t)2 * R2 * sizeof(unsigned) +
-                         (mask ? (size_t)R2 * d->hist * sizeof(float) : 0);
-    const bool take64 = enc_wide_enabled() && enc_r64_enabled() && vec_ok && lds64 <= 160 * 1024 && lfi_cdiv(F, R2) >= 128;
-    const bool m16 = take64 && q.Kp == 256 && q.ncg * 64 == q.Jp && enc_m16_enabled();
+    const int fv = enc_fwd_variant(d, mask != nullptr, gates != nullptr, aligned, &q);
+    const bool take64 = fv >= 3, m16 = fv >= 4, t16 = fv == 5;
+    const size_t lds64 = enc_fwd_r64_lds(q, d->hist, mask != nullptr), ldst = enc_fwd_t16_lds(d->hist, mask != nullptr);
     if (x3 && m16) hipLaunchKernelGGL(enc_frag_weights16_kernel, dim3(lfi_cdiv(6L * q.Kp * q.Jp, 256)), dim3(256), 0, st, whh, hid, q.Kp,
                                       q.Jp, reinterpret_cast<__bf16*>(work));
     else if (x3) hipLaunchKernelGGL(enc_frag_weights_kernel, dim3(lfi_cdiv(6L * q.Kp * q.Jp, 256)), dim3(256), 0, st, whh, hid, q.Kp,
@@ -2196,7 +2496,6 @@ extern "C" int lfi_encode_windows_fwd(const lfi_enc_desc* d, const float* Xp, co
     const dim3 grid(lfi_cdiv(F, q.R));
     {
       // row-layout epilogue variant (16-byte accesses): needs 4-float granular rows everywhere it vectorises
-      const bool wide = enc_wide_enabled();
       const size_t ldsw = (size_t)2 * q.R * (q.Kp + 8) * sizeof(__bf16) + (size_t)ENC_NW * 32 * ENC_TP * sizeof(float) +
                           (size_t)6 * q.Jp * sizeof(float) + (size_t)2 * q.R * sizeof(unsigned) +
                           (mask ? (size_t)q.R * d->hist * sizeof(float) : 0);
@@ -2207,6 +2506,11 @@ extern "C" int lfi_encode_windows_fwd(const lfi_enc_desc* d, const float* Xp, co
         rc = LFI_OK;
         switch ((gates && d->stash_f16 ? 4 : 0) | (gates ? 2 : 0) | (mask ? 1 : 0)) {
 #define LFI_ENC_FWD64(ST, MK, H)                                                                                   \
+  if (t16) {                                                                                                       \
+    rc = enc_set_lds(enc_gru_fwd_t16_kernel<ST, MK, H>, ldst);                                                     \
+    if (!rc) hipLaunchKernelGGL((enc_gru_fwd_t16_kernel<ST, MK, H>), grid64, dim3(ENC_NT), ldst, st, a, q);        \
+    break;                                                                                                         \
+  }                                                                                                                \
   if (m16) {                                                                                                       \
     rc = enc_set_lds(enc_gru_fwd_r64_kernel<ST, MK, H, true>, lds64);                                              \
     if (!rc) hipLaunchKernelGGL((enc_gru_fwd_r64_kernel<ST, MK, H, true>), grid64, dim3(ENC_NT), lds64, st, a, q); \
@@ -2227,7 +2531,7 @@ extern "C" int lfi_encode_windows_fwd(const lfi_enc_desc* d, const float* Xp, co
         LFI_LAUNCH_CHECK("lfi_encode_windows_fwd (fused, two row tiles per wave)");
         return LFI_OK;
       }
-      if (wide && vec_ok && ldsw <= 80 * 1024) {
+      if (fv == 2) {
         rc = LFI_OK;
         switch ((gates && d->stash_f16 ? 4 : 0) | (gates ? 2 : 0) | (mask ? 1 : 0)) {
 #define LFI_ENC_FWDW(ST, MK, H)                                                                                  \

@@ -833,10 +833,13 @@ def test_window_encoder_tilings_match(gpu_device, monkeypatch, mod, two, s16):
     rows_per_wg = {"r64": 2 * 32 * (4 // ((hid + 63) // 64)), "wide": 32 * (4 // ((hid + 63) // 64))}
     groups = {"r64": 4 // ((hid + 63) // 64), "wide": 4 // ((hid + 63) // 64)}
     rows_per_wg["r64m16"], groups["r64m16"] = rows_per_wg["r64"], groups["r64"]
-    for name, env in (("r64", {"LFI_ENC_R64": "1", "LFI_ENC_M16": "0"}), ("r64m16", {"LFI_ENC_R64": "1", "LFI_ENC_M16": "1"}),
-                      ("wide", {"LFI_ENC_R64": "0"})):
+    rows_per_wg["t16"], groups["t16"] = rows_per_wg["r64"], groups["r64"]
+    variant = {}
+    for name, env in (("r64", {"LFI_ENC_R64": "1", "LFI_ENC_M16": "0"}), ("r64m16", {"LFI_ENC_R64": "1", "LFI_ENC_M16": "1", "LFI_ENC_T16": "0"}),
+                      ("t16", {"LFI_ENC_R64": "1", "LFI_ENC_M16": "1", "LFI_ENC_T16": "2"}), ("wide", {"LFI_ENC_R64": "0"})):
         for k, v in env.items():
             monkeypatch.setenv(k, v)
+        variant[name] = int(L.lfi_encode_windows_fwd_variant(C.byref(d), 1, 1))
         cond = torch.zeros(F, ldc, device=dev)
         gates = torch.zeros(hist * F * 4 * hid, device=dev)
         hseq = torch.zeros(hist * F * hid, device=dev)
@@ -868,6 +871,29 @@ def test_window_encoder_tilings_match(gpu_device, monkeypatch, mod, two, s16):
     a = outs["r64m16"]
     if hid % 256 == 0 and -(-F // rows_per_wg["r64"]) >= 128:
         assert not torch.equal(a[0], b[0]), "the 16 x 16 x 32 kernel did not run"
+        assert variant["r64m16"] == 4 and variant["t16"] == 5 and variant["r64"] == 3 and variant["wide"] == 2, variant
+        # round 5: the same 16 x 16 x 32 products taken transposed (weights as the A operand) with the gate epilogue issued under the
+        # next unit tile's MFMAs: same products, same order, same gate expressions - everything the forward pass writes is
+        # bit-identical, and so is the BPTT that runs on those stashes
+        t = outs["t16"]
+        for i, what in enumerate(("features", "gate stash", "state stash", "dgi", "dgh")):
+            assert torch.equal(t[i], a[i]), ("t16 vs r64m16", what, float((t[i] - a[i]).abs().max()))
+        # the default: taken where nothing is stashed (inference / validation forward), not in training
+        monkeypatch.delenv("LFI_ENC_T16")
+        assert int(L.lfi_encode_windows_fwd_variant(C.byref(d), 1, 0)) == 5 and int(L.lfi_encode_windows_fwd_variant(C.byref(d), 1, 1)) == 4
+        plain = {}
+        for mode in ("0", "1"):
+            monkeypatch.setenv("LFI_ENC_T16", mode)
+            for masked in (True, False):
+                cond = torch.zeros(F, ldc, device=dev)
+                check(L.lfi_encode_windows_fwd(C.byref(d), xp.data_ptr(), whh.data_ptr(), b_ih.data_ptr(), b_hh.data_ptr(),
+                                               mask.data_ptr() if masked else None, cond.data_ptr(), None, None, work.data_ptr(), st), "fwd")
+                torch.cuda.synchronize()
+                plain[mode, masked] = cond
+        assert torch.equal(plain["1", True], a[0]) and torch.equal(plain["0", True], a[0])
+        assert torch.equal(plain["1", False], plain["0", False]) and not torch.equal(plain["1", False], a[0])
+    else:
+        assert variant["t16"] == variant["r64m16"], variant
     n_g, n_dgi, n_dgh = hist * F * 4 * hid, hist * F * hid, hist * F * 3 * hid
     views = [(a[0], b[0], 5e-6), (a[2], b[2], 5e-6)]
     views.append((a[1].view(torch.float16)[:n_g].float(), b[1].view(torch.float16)[:n_g].float(), 2e-3) if s16 else (a[1], b[1], 5e-6))

@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--mod", default="p2_face")
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--batch", type=int, default=256)
+    ap.add_argument("--fwd-only", action="store_true")
     a = ap.parse_args()
     hist, hid = {"p2_face": (24, 256), "p2_speech": (16, 256), "p1_speech": (2, 128)}[a.mod]
     B, T, start = a.batch, 80, 24
@@ -78,6 +79,8 @@ def main():
     print("  fwd, fp32 gate stash    %.4f" % timed(lambda: fwd(0)))
     if ok16:
         print("  fwd, fp16 gate stash    %.4f" % timed(lambda: fwd(1)))
+    if a.fwd_only:
+        return
     fwd(0)
     print("  bwd 3 products, fp32 stash / fp32 grads   %.4f" % timed(lambda: bwd(0, 0)))
     print("  bwd 2 products, fp32 stash / bf16 grads   %.4f" % timed(lambda: bwd(1, 0)))
