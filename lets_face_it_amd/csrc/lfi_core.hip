@@ -13,7 +13,7 @@ void lfi_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
-unsigned long long* g_lfi_stamps = nullptr;
+thread_local unsigned long long* g_lfi_stamps = nullptr;   // per calling thread: the header promises no process-global state
 
 extern "C" const char* lfi_last_error(void) { return g_err; }
 extern "C" int lfi_version(void) { return 100; }

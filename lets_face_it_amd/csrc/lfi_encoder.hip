@@ -1411,14 +1411,72 @@ __global__ __launch_bounds__(ENC_NT, 1) void enc_gru_fwd_t16_kernel(EncArgs a, E
     };
     sload(0, sh[0], sl[0]);
     f32x4 bir, bhr, biu, bhu, bin, bhn;
+    auto load_biases = [&](int qt) {   // biases of unit tile qt
+      const float* bb = bias + cg * 64 + 16 * qt + 4 * jq;
+      bir = *reinterpret_cast<const f32x4*>(bb); bhr = *reinterpret_cast<const f32x4*>(bb + 3 * hid);
+      biu = *reinterpret_cast<const f32x4*>(bb + hid); bhu = *reinterpret_cast<const f32x4*>(bb + 4 * hid);
+      bin = *reinterpret_cast<const f32x4*>(bb + 2 * hid); bhn = *reinterpret_cast<const f32x4*>(bb + 5 * hid);
+    };
+    // projected inputs of (unit tile t, window tile ni): gates r, z in the even block of a pair, n in the odd one
+    auto xload = [&](int t, int ni, int odd, f32x4 (&x)[3]) {
+      const unsigned t64 = (unsigned)t * 64u;
+#ifdef LFI_T16_NO_XP
+      if (s == 0 && t == 0) x[0] = x[1] = x[2] = f32x4{0.1f, 0.2f, 0.3f, 0.4f} * (float)(t64 + lane);
+#else
+      if (!odd) {
+        x[0] = enc_ld4(bx, xo[ni], sx + t64);
+        x[1] = enc_ld4(bx, xo[ni], sx + h4 + t64);
+      } else {
+        x[2] = enc_ld4(bx, xo[ni], sx + 2 * h4 + t64);
+      }
+#endif
+    };
+    // one half of the epilogue chunk (unit tile qt, window tile ni): r, z (even) | n, h, stash, state images (odd)
+    auto epi_half = [&](int qt, int ni, int odd, const f32x4 (&ac)[3], const f32x4 (&x)[3]) {
+      const unsigned t64 = (unsigned)qt * 64u;   // byte offset of the tile's units in fp32 rows
+      if (!odd) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          rr[e] = ENC_SIG(mk[ni] * x[0][e] + bir[e] + (ac[0][e] + bhr[e]));
+          uu[e] = ENC_SIG(mk[ni] * x[1][e] + biu[e] + (ac[1][e] + bhu[e]));
+        }
+        if (STASH && !S16) {
+          enc_st4(rr, bgs, 4u * wo[ni] + jb4, t64);
+          enc_st4(uu, bgs, 4u * wo[ni] + jb4, h4 + t64);
+        }
+      } else {
+        f32x4 ghn, nn, hn;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          ghn[e] = ac[2][e] + bhn[e];
+          nn[e] = ENC_TANH(mk[ni] * x[2][e] + bin[e] + rr[e] * ghn[e]);
+          hn[e] = (1.0f - uu[e]) * nn[e] + uu[e] * hprev[qt][ni][e];
+        }
+        if (STASH && S16) {   // [window][unit][r, z, n, W_hn h] fp16: this lane's four units = 32 contiguous bytes
+          const uint2 g0 = enc_pack_gates(rr[0], uu[0], nn[0], ghn[0]), g1 = enc_pack_gates(rr[1], uu[1], nn[1], ghn[1]);
+          const uint2 g2 = enc_pack_gates(rr[2], uu[2], nn[2], ghn[2]), g3 = enc_pack_gates(rr[3], uu[3], nn[3], ghn[3]);
+          const unsigned go = 2u * (wo[ni] + jb4);
+          __builtin_amdgcn_raw_buffer_store_b128((enc_u32x4){g0.x, g0.y, g1.x, g1.y}, bgs, go, 2 * t64, LFI_ENC_ST_AUX);
+          __builtin_amdgcn_raw_buffer_store_b128((enc_u32x4){g2.x, g2.y, g3.x, g3.y}, bgs, go, 2 * t64 + 16, LFI_ENC_ST_AUX);
+          enc_st4(hn, bhs, wo[ni] + jb4, t64);
+        } else if (STASH) {
+          enc_st4(nn, bgs, 4u * wo[ni] + jb4, 2 * h4 + t64);
+          enc_st4(ghn, bgs, 4u * wo[ni] + jb4, 3 * h4 + t64);
+          enc_st4(hn, bhs, wo[ni] + jb4, t64);
+        }
+        {
+          uint2 h, l;
+          split2(hn[0], hn[1], &h.x, &l.x);
+          split2(hn[2], hn[3], &h.y, &l.y);
+          *reinterpret_cast<uint2*>(Xw + ni * 16 * ldx + 16 * qt) = h;
+          *reinterpret_cast<uint2*>(Xw + IMG + ni * 16 * ldx + 16 * qt) = l;
+        }
+        hprev[qt][ni] = hn;
+      }
+    };
 #pragma unroll
     for (int p = 0; p < 5; ++p) {
-      if (p > 0) {   // biases of the tile whose epilogue runs in this phase
-        const float* bb = bias + cg * 64 + 16 * (p - 1) + 4 * jq;
-        bir = *reinterpret_cast<const f32x4*>(bb); bhr = *reinterpret_cast<const f32x4*>(bb + 3 * hid);
-        biu = *reinterpret_cast<const f32x4*>(bb + hid); bhu = *reinterpret_cast<const f32x4*>(bb + 4 * hid);
-        bin = *reinterpret_cast<const f32x4*>(bb + 2 * hid); bhn = *reinterpret_cast<const f32x4*>(bb + 5 * hid);
-      }
+      if (p > 0) load_biases(p - 1);
 #pragma unroll
       for (int m = 0; m < 8; ++m) {
         const int i = p * 8 + m, ni = m >> 1;
@@ -1470,64 +1528,10 @@ __global__ __launch_bounds__(ENC_NT, 1) void enc_gru_fwd_t16_kernel(EncArgs a, E
           }
         }
 #else
-        if (p > 0) {   // epilogue chunk (unit tile p - 1, window tile ni): first half in the even block, second half in the odd one
-          const int qt = p - 1;
-          const f32x4 (&ac)[3] = acc[qt & 1][ni];
-          const unsigned t64 = (unsigned)qt * 64u;   // byte offset of the tile's units in fp32 rows
-          if ((m & 1) == 0) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              rr[e] = ENC_SIG(mk[ni] * xin[ni][0][e] + bir[e] + (ac[0][e] + bhr[e]));
-              uu[e] = ENC_SIG(mk[ni] * xin[ni][1][e] + biu[e] + (ac[1][e] + bhu[e]));
-            }
-            if (STASH && !S16) {
-              enc_st4(rr, bgs, 4u * wo[ni] + jb4, t64);
-              enc_st4(uu, bgs, 4u * wo[ni] + jb4, h4 + t64);
-            }
-          } else {
-            f32x4 ghn, nn, hn;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              ghn[e] = ac[2][e] + bhn[e];
-              nn[e] = ENC_TANH(mk[ni] * xin[ni][2][e] + bin[e] + rr[e] * ghn[e]);
-              hn[e] = (1.0f - uu[e]) * nn[e] + uu[e] * hprev[qt][ni][e];
-            }
-            if (STASH && S16) {   // [window][unit][r, z, n, W_hn h] fp16: this lane's four units = 32 contiguous bytes
-              const uint2 g0 = enc_pack_gates(rr[0], uu[0], nn[0], ghn[0]), g1 = enc_pack_gates(rr[1], uu[1], nn[1], ghn[1]);
-              const uint2 g2 = enc_pack_gates(rr[2], uu[2], nn[2], ghn[2]), g3 = enc_pack_gates(rr[3], uu[3], nn[3], ghn[3]);
-              const unsigned go = 2u * (wo[ni] + jb4);
-              __builtin_amdgcn_raw_buffer_store_b128((enc_u32x4){g0.x, g0.y, g1.x, g1.y}, bgs, go, 2 * t64, LFI_ENC_ST_AUX);
-              __builtin_amdgcn_raw_buffer_store_b128((enc_u32x4){g2.x, g2.y, g3.x, g3.y}, bgs, go, 2 * t64 + 16, LFI_ENC_ST_AUX);
-              enc_st4(hn, bhs, wo[ni] + jb4, t64);
-            } else if (STASH) {
-              enc_st4(nn, bgs, 4u * wo[ni] + jb4, 2 * h4 + t64);
-              enc_st4(ghn, bgs, 4u * wo[ni] + jb4, 3 * h4 + t64);
-              enc_st4(hn, bhs, wo[ni] + jb4, t64);
-            }
-            {
-              uint2 h, l;
-              split2(hn[0], hn[1], &h.x, &l.x);
-              split2(hn[2], hn[3], &h.y, &l.y);
-              *reinterpret_cast<uint2*>(Xw + ni * 16 * ldx + 16 * qt) = h;
-              *reinterpret_cast<uint2*>(Xw + IMG + ni * 16 * ldx + 16 * qt) = l;
-            }
-            hprev[qt][ni] = hn;
-          }
-        }
+        // epilogue chunk (unit tile p - 1, window tile ni): first half in the even block, second half in the odd one
+        if (p > 0) epi_half(p - 1, ni, m & 1, acc[(p - 1) & 1][ni], xin[ni]);
 #endif
-        if (p < 4) {   // projected inputs of tile p, for its epilogue one phase from now
-          const unsigned t64 = (unsigned)p * 64u;
-#ifdef LFI_T16_NO_XP
-          if (s == 0 && p == 0) xin[ni][0] = xin[ni][1] = xin[ni][2] = f32x4{0.1f, 0.2f, 0.3f, 0.4f} * (float)(t64 + lane);
-#else
-          if ((m & 1) == 0) {
-            xin[ni][0] = enc_ld4(bx, xo[ni], sx + t64);
-            xin[ni][1] = enc_ld4(bx, xo[ni], sx + h4 + t64);
-          } else {
-            xin[ni][2] = enc_ld4(bx, xo[ni], sx + 2 * h4 + t64);
-          }
-#endif
-        }
+        if (p < 4) xload(p, ni, m & 1, xin[ni]);   // projected inputs of tile p, for its epilogue one phase from now
 #if LFI_T16_NV > 0
         if (p > 0 && p < 4) {
 #pragma unroll
@@ -1562,8 +1566,11 @@ __global__ __launch_bounds__(ENC_NT, 1) void enc_gru_fwd_t16_kernel(EncArgs a, E
 // (rows, hidden) tile (rg, cg); per step the gate derivatives are taken in registers, written to dgi / dgh (the
 // deferred weight-gradient GEMMs read those) and fed gate by gate through LDS as the A operand of
 // dh_{s-1} = dgh_s W_hh + dh_s * u   (K = 3 hid, B = W_hh rows streamed from L2).
+#ifndef LFI_ENC_FUSED_BWD_OCC
+#define LFI_ENC_FUSED_BWD_OCC 2   // (1: the whole register file for one workgroup - the round-5 SLP chase builds it to take the spills away)
+#endif
 template <bool X3>
-__global__ __launch_bounds__(ENC_NT, 2) void enc_gru_bwd_fused_kernel(EncArgs a, EncFused q) {
+__global__ __launch_bounds__(ENC_NT, LFI_ENC_FUSED_BWD_OCC) void enc_gru_bwd_fused_kernel(EncArgs a, EncFused q) {
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, half = lane >> 5;
   const int cg = wave % q.ncg, rg = wave / q.ncg;

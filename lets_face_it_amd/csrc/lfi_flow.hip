@@ -3051,7 +3051,7 @@ __global__ __launch_bounds__(256) void flow_prep_transpose_kernel(FlowK f, float
 
 // Gradients of the LU parameters from dW (glow/modules.py:167-173 differentiated), one workgroup per flow step.
 __global__ __launch_bounds__(256) void flow_invconv_bwd_kernel(FlowK f, const float* __restrict__ dW, lfi_flow_grads g,
-                                                               float cconst, int accumulate) {
+                                                               float cconst, int accumulate, int stage) {
   const int k = blockIdx.x, C = f.C, tid = threadIdx.x;
   const long kc = (long)k * C * C;
   float* Lm = flow_smem;
@@ -3073,14 +3073,19 @@ __global__ __launch_bounds__(256) void flow_invconv_bwd_kernel(FlowK f, const fl
   const float* ls = f.p.inv_logs + (long)k * C;
   // (P and dW through LDS first: read from global inside the inner product - 100 dependent L2 round trips per thread - this
   // 16-workgroup kernel took 88 us alone and 260 us next to the HBM streams it shares its stream slot with)
-  float* Pm = Q + C * C;
-  float* Dm = Pm + C * C;
+  // (stage = 0, C > 90: five C x C images do not fit 160 KB of LDS - P and dW are then read where they lie, as before round 4)
+  float* Pl = Q + C * C;
+  float* Dl = Pl + C * C;
+  const float* Pm = stage ? Pl : P;
+  const float* Dm = stage ? Dl : dW + kc;
   for (int idx = tid; idx < C * C; idx += 256) {
     const int i = idx / C, j = idx - i * C;
     Lm[idx] = i > j ? l[idx] : (i == j ? 1.0f : 0.0f);
     Um[idx] = i < j ? u[idx] : (i == j ? sg[i] * expf(ls[i]) : 0.0f);
-    Pm[idx] = P[idx];
-    Dm[idx] = dW[kc + idx];
+    if (stage) {
+      Pl[idx] = P[idx];
+      Dl[idx] = dW[kc + idx];
+    }
   }
   __syncthreads();
   for (int idx = tid; idx < C * C; idx += 256) {
@@ -3597,10 +3602,11 @@ extern "C" int lfi_flow_param_grads(const lfi_flow_dims* d, const lfi_flow_param
   // constant log-det terms: nll has -(C sum(logs))/ln2 per frame -> d/dlogs = -C/ln2 * gscale * F
   const float cconst = -(float)((double)gscale * (double)F * (double)C / 0.6931471805599453);
   {
-    const size_t lds = (size_t)5 * C * C * sizeof(float);
+    const int stage = (size_t)5 * C * C * sizeof(float) <= 160 * 1024 ? 1 : 0;
+    const size_t lds = (size_t)(stage ? 5 : 3) * C * C * sizeof(float);
     rc = set_flow_lds(flow_invconv_bwd_kernel, lds, "lfi_flow_param_grads");
     if (rc) return rc;
-    hipLaunchKernelGGL(flow_invconv_bwd_kernel, dim3(Ks), dim3(256), lds, (hipStream_t)bs, f, dW, *g, cconst, accumulate);
+    hipLaunchKernelGGL(flow_invconv_bwd_kernel, dim3(Ks), dim3(256), lds, (hipStream_t)bs, f, dW, *g, cconst, accumulate, stage);
     LFI_LAUNCH_CHECK("lfi_flow_param_grads invconv");
   }
   // biases and the per-tile partial sums: column sums over the backward stash only (HBM streams), independent of the

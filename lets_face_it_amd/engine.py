@@ -601,7 +601,9 @@ class GlowEngine:
         if self.precision == 1:
             # bf16 hi / lo planes of the folded weights for the cond_transform forward product: split once per parameter state
             # here instead of once per row tile (56 times) inside the GEMM
-            self._wct_planes = self.planes("wct_planes", self.wct_f, s.ldf, s.Ks * s.D, s.Ef)
+            # (over all ldf columns - the padding columns are zero - so that the k-tile count is even whatever the widths and the
+            # products take the v_mfma_f32_16x16x32_bf16 kernels, which consume k-tiles in pairs)
+            self._wct_planes = self.planes("wct_planes", self.wct_f, s.ldf, s.Ks * s.D, s.ldf)
             if self._chain_fwd_ok():
                 # W_c = W_ih[:, Ch:] of every flow step, (Ks G x D): row use in gic = c W_c^T (sums over D), transposed use in
                 # d pre-activation = dgi W_c (sums over the gate rows). (The folded cond_transform weights above serve the
@@ -730,11 +732,11 @@ class GlowEngine:
         s = self.spec
         KD = s.Ks * s.D
         if chain:
-            cp, nkc = self.planes("cond_planes", cond, s.ldf, F, s.Ef)
+            cp, nkc = self.planes("cond_planes", cond, s.ldf, F, s.ldf)   # (ldf columns: an even k-tile count; the padding is zero)
             wp, nkw = self._wct_planes
             nkKD = KD // 16
             c_r = self.plane_buf("c_r", self.L.lfi_planes_elems(F, KD) + 256 * KD * 2)
-            self.gemm_planes(F, KD, s.Ef, cp, nkc, wp, nkw, None, KD, bias=self.fview("bct"), act=1, slope=0.01, store=False,
+            self.gemm_planes(F, KD, s.ldf, cp, nkc, wp, nkw, None, KD, bias=self.fview("bct"), act=1, slope=0.01, store=False,
                              Cr=c_r, cr_nkt=nkKD, tag="gemm_cond_fwd", cls="cond_fwd")
             gic = self._buf("gic", s.Ks * F * s.G)
             wr, nkwr = self._wc_r
@@ -747,9 +749,9 @@ class GlowEngine:
         if self.precision == 1 and os.environ.get("LFI_PGEMM", "1") != "0":
             # operands pre-split into bf16 hi / lo planes in MFMA fragment order, streamed to LDS by LDS-DMA: same products
             # and accumulation order as the fp32-operand bf16x3 kernel (bit-identical results; LFI_PGEMM=0 keeps that one)
-            cp, nkc = self.planes("cond_planes", cond, s.ldf, F, s.Ef)
+            cp, nkc = self.planes("cond_planes", cond, s.ldf, F, s.ldf)
             wp, nkw = self._wct_planes
-            self.gemm_planes(F, KD, s.Ef, cp, nkc, wp, nkw, cbuf, KD, bias=self.fview("bct"), act=1, slope=0.01,
+            self.gemm_planes(F, KD, s.ldf, cp, nkc, wp, nkw, cbuf, KD, bias=self.fview("bct"), act=1, slope=0.01,
                              tag="gemm_cond_fwd", cls="cond_fwd")
         else:
             self.gemm(F, KD, s.Ef, cond, s.ldf, 1, self.wct_f, s.ldf, 1, cbuf, KD, bias=self.fview("bct"), act=1, slope=0.01,

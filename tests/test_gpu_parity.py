@@ -466,7 +466,7 @@ def test_wide_hidden_sizes_take_the_generic_paths(gpu_device):
         assert rel < 2e-3, (name, rel)
 
 
-def test_full_size_properties(gpu_device):
+def test_full_size_properties(gpu_device, monkeypatch):
     """BASELINE configs[1] size (B=256, T=80, K=16): size-independent properties instead of an oracle run."""
     hp = final_model_hparams(50, 27)
     m, _ = perturbed_model(hp, gpu_device)
@@ -491,9 +491,18 @@ def test_full_size_properties(gpu_device):
         # products summed in another order, so this comparison is to fp32 rounding; cross-sample coupling would show as O(1))
         _, _, losses_s = m({k: v[:40].contiguous() for k, v in batch.items()})
         assert max_rel(torch.stack(losses_s), nll[:, :40], floor=1.0) < 1e-5
+        # the same with the window encoders pinned to ONE kernel family at both sizes (the 32-window kernels): only then is every sum
+        # taken in the same order, and the comparison is bitwise - the detector of cross-sample leakage
+        monkeypatch.setenv("LFI_ENC_R64", "0")
+        monkeypatch.setenv("LFI_ENC_M16", "0")
+        _, _, losses_f = m(batch)
+        _, _, losses_s = m({k: v[:40].contiguous() for k, v in batch.items()})
+        assert torch.equal(torch.stack(losses_s), torch.stack(losses_f)[:, :40])
+        monkeypatch.delenv("LFI_ENC_R64")
+        monkeypatch.delenv("LFI_ENC_M16")
 
 
-def test_config4_deep_flow_properties(gpu_device):
+def test_config4_deep_flow_properties(gpu_device, monkeypatch):
     """BASELINE configs[4]: K=32 x L=3 (96 flow steps), seq_len 512, batch 128 - too large for the CPU oracle, so
     size-independent properties: finite NLL, decode(encode(x)) = x, forward/backward NLL identity, sub-batch invariance, and
     additivity of the gradient over a split of the batch (the loss is a batch mean: grad(B) = (grad(B1) + grad(B2)) / 2)."""
@@ -514,6 +523,14 @@ def test_config4_deep_flow_properties(gpu_device):
         # causal: a prefix reproduces its timesteps - to fp32 rounding: its 5 120 windows take the 32-window encoder kernels
         # (32 x 32 x 16 MFMA), the full sequence's 62 464 the 64-window ones (16 x 16 x 32: the same products, another summation order)
         assert rel_err(torch.stack(z_short), torch.stack(z_seq[:40])) < 1e-5
+        # bitwise with the window encoders pinned to one kernel family (no leakage from later timesteps into earlier ones)
+        monkeypatch.setenv("LFI_ENC_R64", "0")
+        monkeypatch.setenv("LFI_ENC_M16", "0")
+        z_full_p, _, _ = m(batch)
+        z_short_p, _, _ = m(short)
+        assert torch.equal(torch.stack(z_short_p), torch.stack(z_full_p[:40]))
+        monkeypatch.delenv("LFI_ENC_R64")
+        monkeypatch.delenv("LFI_ENC_M16")
         rec, bl = m.invert(z_short, short)
         # 96 chained fp32 inverses (W^-1 is the fp64 inverse cast to fp32, modules.py:175-177): 7e-4 measured; K=16: 2e-4
         assert rel_err(torch.stack(rec), short["p1_face"][:, 24:].transpose(0, 1)) < 3e-3
@@ -540,7 +557,7 @@ def test_config4_deep_flow_properties(gpu_device):
     assert worst < 1e-4
 
 
-def test_config3_sampling_full_size(gpu_device):
+def test_config3_sampling_full_size(gpu_device, monkeypatch):
     """BASELINE configs[3]: autoregressive sampling, batch 1024, seq_len 300. Properties: finite; the hipGraph replay (second
     call of a shape) is bit-identical to the eager first call; a sub-batch reproduces its rows; and the teacher-forced
     forward pass maps the generated frames back to the injected prior noise (encode(decode(z)) = z)."""
@@ -566,6 +583,14 @@ def test_config3_sampling_full_size(gpu_device):
     sub_err = float((sub - out1[:48]).abs().max() / out1[:48].abs().max().clamp(min=1.0))
     report("config[3] sub-batch of 48 against its rows of the batch of 1024: max abs difference %.3e of the largest value" % sub_err)
     assert sub_err < 1e-3
+    # bitwise with the window encoders pinned to one kernel family at both batch sizes (the leakage detector)
+    monkeypatch.setenv("LFI_ENC_R64", "0")
+    monkeypatch.setenv("LFI_ENC_M16", "0")
+    out_p = m.inference(T, data, noise=noise)
+    sub_p = m.inference(T, {k: v[:48].contiguous() for k, v in data.items()}, noise=noise[:, :48].contiguous())
+    assert torch.equal(sub_p, out_p[:48])
+    monkeypatch.delenv("LFI_ENC_R64")
+    monkeypatch.delenv("LFI_ENC_M16")
     full = dict(data)
     full["p1_face"] = torch.cat([data["p1_face"][:, :24], out1], dim=1).contiguous()
     with torch.no_grad():

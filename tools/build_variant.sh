@@ -7,7 +7,8 @@ ROOT=$(cd "$(dirname "$0")/.." && pwd)
 make -C $ROOT/lets_face_it_amd/csrc -j4 > /dev/null
 mkdir -p $ROOT/build/var
 FLAGS="-O3 --offload-arch=gfx950 -fPIC -std=c++17 -I$ROOT/include -Wall -Wno-unused-function"
-[ "$SRC" = "lfi_encoder.hip" ] && FLAGS="$FLAGS -fno-slp-vectorize"
+# (LFI_SLP=1: with the SLP vectoriser, which the Makefile switches off for this file - the determinism chase of round 5)
+[ "$SRC" = "lfi_encoder.hip" ] && [ -z "${LFI_SLP:-}" ] && FLAGS="$FLAGS -fno-slp-vectorize"
 hipcc $FLAGS "$@" -c $ROOT/lets_face_it_amd/csrc/$SRC -o $ROOT/build/var/${NAME}_${SRC%.hip}.o
 OBJS=""
 for f in lfi_core lfi_gemm lfi_pgemm lfi_encoder lfi_flow lfi_data lfi_sample; do
