@@ -3860,7 +3860,9 @@ extern "C" int lfi_flow_sample_seq_from(const lfi_flow_dims* d, const lfi_flow_p
       q.K = hid; q.A = ebuf; q.lda = hid4;
     }
     if (fused) {
-      if ((rc = lfi_internal_sample_cond(faces, (long)seq_len * C, (long)(t - hist1) * C, K1, B, Ks, G, cfr, p->b_ih, cfrags, gic, 0.01f, stream)))
+      // (its first workgroup also clears the reverse chain's ticket / progress words for the launch below: no memset node per frame)
+      if ((rc = lfi_internal_sample_cond(faces, (long)seq_len * C, (long)(t - hist1) * C, K1, B, Ks, G, cfr, p->b_ih, cfrags, gic, 0.01f,
+                                         (long)B * seq_len * C, chain ? chain_state : nullptr, (int)chain_words, stream)))
         return rc;
     } else {
       if (stage_win) {
@@ -3883,8 +3885,10 @@ extern "C" int lfi_flow_sample_seq_from(const lfi_flow_dims* d, const lfi_flow_p
       rcn.noise = noise + (long)n * B * C; rcn.xa = xa; rcn.xb = xb;
       rcn.frame = faces + (long)t * C; rcn.ld_frame = (long)seq_len * C;
       rcn.gic = gic; rcn.h = h; rcn.cstate = cstate; rcn.has_prev = first_frame + n > 0 ? 1 : 0; rcn.frame_no = first_frame + n; rcn.pipe = chain_state;
-      hipError_t me = hipMemsetAsync(chain_state, 0, chain_words * sizeof(unsigned), st);
-      LFI_REQUIRE(me == hipSuccess, "lfi_flow_sample_seq: hipMemsetAsync: %s", hipGetErrorString(me));
+      if (!fused) {   // (the fused conditioning kernel has cleared them)
+        hipError_t me = hipMemsetAsync(chain_state, 0, chain_words * sizeof(unsigned), st);
+        LFI_REQUIRE(me == hipSuccess, "lfi_flow_sample_seq: hipMemsetAsync: %s", hipGetErrorString(me));
+      }
       if (f.lstm) hipLaunchKernelGGL((flow_rev_chain_kernel<4, false>), dim3(Ks * f.nbt), dim3(NT), lds, st, f, rcn);
       else if (x3) hipLaunchKernelGGL((flow_rev_chain_kernel<3, true>), dim3(Ks * f.nbt), dim3(NT), lds, st, f, rcn);
       else hipLaunchKernelGGL((flow_rev_chain_kernel<3, false>), dim3(Ks * f.nbt), dim3(NT), lds, st, f, rcn);

@@ -98,7 +98,12 @@ __global__ __launch_bounds__(256) void sc_xfrag_kernel(const float* __restrict__
 struct ScArgs {
   const uint4* wf1;      // [Ks][8][NM1][4][2] fragments
   const uint4* wf2;      // [Ks][8][16][NGT][2]
-  const uint4* xf;       // [ntile][NM1][2]
+  const uint4* xf;       // [ntile][NM1][2] window fragments made by sc_xfrag_kernel, or null: the kernel splits the window itself
+  const float* faces;    // xf == null: the window rows, faces[row * ld_faces + off + kk] (kk < K1), row pitch and offset 8-byte aligned
+  long ld_faces, off, faces_bytes;
+  int K1;
+  unsigned* reset;       // words the LAST-dispatched... (any one) workgroup zeroes before it ends: the reverse chain's ticket /
+  int reset_words;       // progress words for the launch that follows in the stream (instead of a memset node per frame), or null
   const float* pre;      // B x Ks D: the frame's rows of pre_static (bias included)
   const float* b_ih;     // Ks x G
   float* gic;            // Ks x B x G
@@ -108,7 +113,9 @@ struct ScArgs {
 
 // grid (Ks, row tiles of 64); 512 threads = 8 waves: wave w owns c columns [64 w, 64 w + 64) in phase 1 and gic columns
 // [16 NGT w, 16 NGT (w + 1)) in phase 2; one workgroup per CU (133 KB of LDS).
-template <int NGT>
+// XF = false (round 5): the window's fp16 pieces are made in registers from the fp32 frames - 16 workgroups repeat the split of
+// a row tile, 256 values per lane, instead of a launch of its own per generated frame (12.6 us + its boundary)
+template <int NGT, bool XF>
 __global__ __launch_bounds__(SC_NT, 1) void sc_cond_kernel(ScArgs a) {
   extern __shared__ __attribute__((aligned(16))) char sc_smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -137,14 +144,45 @@ __global__ __launch_bounds__(SC_NT, 1) void sc_cond_kernel(ScArgs a) {
     for (int j = 0; j < 4; ++j) acc1[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
   {
     HFrag wa[4][2], xa[4][2], wb[4][2], xb[4][2];   // [tile][plane], two buffers
+    // (XF = false) fragment (16-row tile t, step m): lane l, element e = window[16 t + (l & 15)][32 m + 8 (l >> 4) + e]; the frames
+    // through a buffer descriptor (reads past the last row's end return 0), 8-byte loads (the window starts (t - hist1) C floats
+    // into a 16-byte aligned row: 8-byte aligned for even C)
+    const __amdgpu_buffer_rsrc_t bf = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.faces), 0,
+                                                                       (int)(a.faces_bytes > 0xfffffff0L ? 0xfffffff0L : a.faces_bytes), 0x00020000);
+    unsigned frow[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const long row = min((long)rt * SC_ROWS + 16 * t + l15, (long)a.B - 1);   // rows past B repeat the last one (never stored)
+      frow[t] = (unsigned)((row * a.ld_faces + a.off) * 4 + 32 * g4);
+    }
+    typedef unsigned sc_u32x2 __attribute__((ext_vector_type(2)));
     auto load1 = [&](int m, HFrag (&w)[4][2], HFrag (&x)[4][2]) {
 #pragma unroll
-      for (int t = 0; t < 4; ++t)
+      for (int t = 0; t < 4; ++t) {
 #pragma unroll
-        for (int pl = 0; pl < 2; ++pl) {
-          w[t][pl].u = ld(bw1, (m * 4 + t) * 2 + pl);
-          x[t][pl].u = ld(bx, (t * NM1 + m) * 2 + pl);
+        for (int pl = 0; pl < 2; ++pl) w[t][pl].u = ld(bw1, (m * 4 + t) * 2 + pl);
+        if (XF) {
+#pragma unroll
+          for (int pl = 0; pl < 2; ++pl) x[t][pl].u = ld(bx, (t * NM1 + m) * 2 + pl);
+        } else {
+          const int kk0 = 32 * m + 8 * g4;
+#pragma unroll
+          for (int c2 = 0; c2 < 4; ++c2) {
+            // (bit_cast, not an initialisation: the builtin's 8-byte result is not this vector type, and converting it splats ONE dword)
+            const sc_u32x2 v2 = __builtin_bit_cast(sc_u32x2, __builtin_amdgcn_raw_buffer_load_b64(bf, frow[t] + 8u * c2, (unsigned)m * 128u, 0));
+            // (through scalars: __builtin_bit_cast applied to a vector ELEMENT expression reads element 0 whatever the index - this
+            // hipcc loads from the vector's base address; seen in the IR, round 5)
+            const unsigned u0 = v2[0], u1 = v2[1];
+            const float v0 = kk0 + 2 * c2 < a.K1 ? __builtin_bit_cast(float, u0) : 0.0f;
+            const float v1 = kk0 + 2 * c2 + 1 < a.K1 ? __builtin_bit_cast(float, u1) : 0.0f;
+            _Float16 h0, l0, h1, l1;
+            sc_split(v0, &h0, &l0);
+            sc_split(v1, &h1, &l1);
+            x[t][0].v[2 * c2] = h0; x[t][0].v[2 * c2 + 1] = h1;
+            x[t][1].v[2 * c2] = l0; x[t][1].v[2 * c2 + 1] = l1;
+          }
         }
+      }
     };
     auto mma1 = [&](const HFrag (&w)[4][2], const HFrag (&x)[4][2]) {
 #pragma unroll
@@ -267,6 +305,10 @@ __global__ __launch_bounds__(SC_NT, 1) void sc_cond_kernel(ScArgs a) {
       if (row < a.B) *reinterpret_cast<f32x4*>(a.gic + ((long)k * a.B + row) * a.G + col) = acc2[ni][ri] + bv;
     }
   }
+  // the reverse chain that follows in the stream starts from zeroed ticket / abort / progress words: one workgroup of this launch
+  // clears them (the previous frame's chain has completed: stream order), instead of a memset node per frame
+  if (a.reset && blockIdx.x == 0 && blockIdx.y == 0)
+    for (int i = tid; i < a.reset_words; i += SC_NT) a.reset[i] = 0u;
 }
 
 }  // namespace
@@ -294,34 +336,52 @@ extern "C" __attribute__((visibility("hidden"))) int lfi_internal_sample_cond_pr
   LFI_LAUNCH_CHECK("sampler conditioning: weight fragments");
   return LFI_OK;
 }
+// faces_floats: floats from `faces` to the end of its buffer (the window loads are bounds-checked against it); reset / reset_words: the
+// reverse chain's state words to clear for the launch that follows (or null: the caller memsets them)
 extern "C" __attribute__((visibility("hidden"))) int lfi_internal_sample_cond(const float* faces, long ld_faces, long off, int K1, int B, int Ks, int G,
                                                                               const float* pre, const float* b_ih, void* frags, float* gic,
-                                                                              float slope, void* stream) {
+                                                                              float slope, long faces_floats, unsigned* reset, int reset_words,
+                                                                              void* stream) {
   const int NM1 = (K1 + 31) / 32, NGT = G / 128;
   const int ntile = (B + 63) / 64 * 4;
   _Float16* f1 = reinterpret_cast<_Float16*>(frags);
   _Float16* f2 = f1 + (long)Ks * 8 * NM1 * 4 * 2 * 512;
   _Float16* fx = f2 + (long)Ks * 8 * 16 * NGT * 2 * 512;
-  const long nx = (long)ntile * NM1 * 2 * 512;
-  hipLaunchKernelGGL(sc_xfrag_kernel, dim3((unsigned)((nx + 255) / 256)), dim3(256), 0, (hipStream_t)stream, faces, ld_faces, off, K1, B, NM1, ntile,
-                     fx);
+  // The window's fp16 pieces come from round 4's fragment kernel in front of this one (default). LFI_SAMPLE_XFRAG=0 splits them
+  // inside the conditioning kernel instead (needs 8-byte aligned window rows; bit-identical, tested): one launch less per frame,
+  // but 16 workgroups repeat each row tile's split with 8-byte loads - measured 60.0 against 57.0 - 57.4 ms per 1024 x 300 call
+  // (profiles/round5_sampler_ab.md): kept as the switch only.
+  const char* xe = getenv("LFI_SAMPLE_XFRAG");
+  const bool inreg = (xe && xe[0] == '0') && ld_faces % 2 == 0 && off % 2 == 0 && (reinterpret_cast<uintptr_t>(faces) & 7) == 0 &&
+                     faces_floats > 0;
+  if (!inreg) {
+    const long nx = (long)ntile * NM1 * 2 * 512;
+    hipLaunchKernelGGL(sc_xfrag_kernel, dim3((unsigned)((nx + 255) / 256)), dim3(256), 0, (hipStream_t)stream, faces, ld_faces, off, K1, B, NM1, ntile,
+                       fx);
+  }
   ScArgs a = {};
-  a.wf1 = reinterpret_cast<const uint4*>(f1); a.wf2 = reinterpret_cast<const uint4*>(f2); a.xf = reinterpret_cast<const uint4*>(fx);
+  a.wf1 = reinterpret_cast<const uint4*>(f1); a.wf2 = reinterpret_cast<const uint4*>(f2); a.xf = inreg ? nullptr : reinterpret_cast<const uint4*>(fx);
+  a.faces = faces; a.ld_faces = ld_faces; a.off = off; a.faces_bytes = faces_floats * 4; a.K1 = K1;
+  a.reset = reset; a.reset_words = reset_words;
   a.pre = pre; a.b_ih = b_ih; a.gic = gic; a.B = B; a.Ks = Ks; a.G = G; a.NM1 = NM1; a.slope = slope;
   const size_t lds = (size_t)2 * SC_PLANE;
   static bool attr = false;
   if (!attr) {
-    hipError_t e1 = hipFuncSetAttribute((const void*)sc_cond_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipError_t e2 = hipFuncSetAttribute((const void*)sc_cond_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e1 != hipSuccess || e2 != hipSuccess) {
+    hipError_t e1 = hipFuncSetAttribute((const void*)sc_cond_kernel<3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e2 = hipFuncSetAttribute((const void*)sc_cond_kernel<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e3 = hipFuncSetAttribute((const void*)sc_cond_kernel<3, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e4 = hipFuncSetAttribute((const void*)sc_cond_kernel<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess) {
       lfi_set_error("sampler conditioning: cannot reserve %zu bytes of LDS", lds);
       return LFI_ERR_LAUNCH;
     }
     attr = true;
   }
   const dim3 grid(Ks, (B + 63) / 64);
-  if (NGT == 3) hipLaunchKernelGGL(sc_cond_kernel<3>, grid, dim3(SC_NT), lds, (hipStream_t)stream, a);
-  else hipLaunchKernelGGL(sc_cond_kernel<4>, grid, dim3(SC_NT), lds, (hipStream_t)stream, a);
+  if (NGT == 3 && inreg) hipLaunchKernelGGL((sc_cond_kernel<3, false>), grid, dim3(SC_NT), lds, (hipStream_t)stream, a);
+  else if (NGT == 3) hipLaunchKernelGGL((sc_cond_kernel<3, true>), grid, dim3(SC_NT), lds, (hipStream_t)stream, a);
+  else if (inreg) hipLaunchKernelGGL((sc_cond_kernel<4, false>), grid, dim3(SC_NT), lds, (hipStream_t)stream, a);
+  else hipLaunchKernelGGL((sc_cond_kernel<4, true>), grid, dim3(SC_NT), lds, (hipStream_t)stream, a);
   LFI_LAUNCH_CHECK("sampler conditioning");
   return LFI_OK;
 }

@@ -156,6 +156,13 @@ def test_sampler_fused_conditioning_matches_two_gemms(gpu_device, monkeypatch):
            "largest value" % err)
     assert not torch.equal(a, b), "the fused conditioning did not run"
     assert err < 2e-5
+    # round 5: the conditioning kernel clears the reverse chain's state words itself (no memset node per frame), and can split the
+    # window's fp16 pieces itself too (LFI_SAMPLE_XFRAG=0; off by default: measured slower): the same pieces, the same products
+    monkeypatch.setenv("LFI_SAMPLE_FUSED", "1")
+    monkeypatch.setenv("LFI_SAMPLE_XFRAG", "0")
+    c = m.inference(seq_len, dd, noise=noise).clone()
+    per_frame = (a - c).abs().amax(dim=(0, 2))
+    assert torch.equal(a, c), ("in-kernel window split differs from the fragment kernel, per frame:", per_frame.tolist())
 
 
 def test_sampler_leaves_fp16_pieces_for_out_of_range_inputs(gpu_device):
