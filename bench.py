@@ -174,7 +174,7 @@ def start_smi_helper():
     import subprocess
     if under_profiler():
         return None
-    env = {k: v for k, v in os.environ.items() if not _is_profiler_var(k)}
+    env = {k: v for k, v in os.environ.items() if not (_is_profiler_var(k) and (k != "LD_PRELOAD" or _profiler_preload(v)))}
     try:
         return subprocess.Popen([sys.executable, "-c", _SMI_HELPER], stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True, env=env)
     except Exception:      # noqa: BLE001 - diagnostics only
@@ -185,11 +185,21 @@ def _is_profiler_var(name):
     return name in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "HSA_TOOLS_LIB", "ROCP_TOOL_LIB") or name.startswith(("ROCPROFILER_", "ROCPROF_", "ROCTRACER_", "ROCP_"))
 
 
+def _profiler_preload(value):
+    return any(t in value.lower() for t in ("rocprof", "roctracer", "roctx"))
+
+
 def under_profiler():
     """True when a tool library is (or may be) preloaded into this process - rocprofv3 sets LD_PRELOAD / ROCP_TOOL_LIBRARIES /
     ROCPROFILER_* and its library can initialise the GPU before bench.py's first line runs (with --pmc it does): the helper would
     then be a fork + exec from a GPU-initialised process, which the pool forbids, so it is not started at all."""
-    return any(_is_profiler_var(k) and os.environ.get(k) for k in os.environ)
+    for k, v in os.environ.items():
+        if not v or not _is_profiler_var(k):
+            continue
+        if k == "LD_PRELOAD" and not _profiler_preload(v):
+            continue      # (the GPU pool preloads a library of its own into every process: not a profiler)
+        return True
+    return False
 
 
 def stop_smi_helper(helper):

@@ -10,8 +10,8 @@
  *
  * Conventions
  *  - extern "C", plain pointers and sizes; every pointer is a DEVICE pointer to fp32 unless noted.
- *  - The caller owns every buffer; the library allocates nothing and keeps no global mutable state (per thread only: the last
- *    error message and the diagnostic stamp pointer of lfi_debug_set_stamps).
+ *  - The caller owns every buffer; the library allocates nothing and keeps no global mutable state in normal operation (per
+ *    thread: the last error message; process-wide and null unless a diagnostic tool sets it: lfi_debug_set_stamps's pointer).
  *  - `stream` is a hipStream_t passed as void* (torch's current stream); all work is enqueued on it, no host
  *    synchronisation, so every call is hipGraph-capturable.
  *  - Return value: 0 = ok, < 0 = error; the message is in lfi_last_error() (thread-local).
@@ -434,9 +434,10 @@ int lfi_jerk_mean(const float* x, int B, int T, int C, float* out, double* work 
 
 /* ---------------------------------------------------------------- diagnostics */
 /* Timing probe of the register-resident forward cells: a device buffer of >= 16 * Ks 64-bit slots stamped with s_memtime
- * (100 MHz) at the phase boundaries of the cells in workgroup column 0; NULL switches it off. The pointer is kept PER CALLING
- * THREAD (thread_local, as lfi_last_error's message is): it applies to the launches that thread makes until it clears it, and
- * no other thread or engine instance sees it - the one piece of state this library keeps, off in normal operation. */
+ * (100 MHz) at the phase boundaries of the cells in workgroup column 0; NULL switches it off. Process-global - the ONE piece of
+ * global mutable state in this library, null in normal operation (a per-thread pointer was tried in round 5: PyTorch runs the
+ * backward pass on its autograd thread, so the walks' backward stamps never saw it). Set it only around a single-engine
+ * diagnostic run (tools/pipe_stamps.py, tools/rev_stamps.py). */
 int lfi_debug_set_stamps(void* device_buffer);
 /* Checks the MFMA operand/accumulator lane maps the kernels rely on; out[0] = number of mismatches. */
 int lfi_selftest_mfma(int* out, void* stream);

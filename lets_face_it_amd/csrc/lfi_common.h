@@ -10,7 +10,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // ---- host side -------------------------------------------------------------
 void lfi_set_error(const char* fmt, ...);
-extern thread_local unsigned long long* g_lfi_stamps;  // diagnostics only (lfi_debug_set_stamps), null in normal operation
+extern unsigned long long* g_lfi_stamps;  // diagnostics only (lfi_debug_set_stamps), null in normal operation
 
 #define LFI_REQUIRE(cond, ...)                 \
   do {                                         \

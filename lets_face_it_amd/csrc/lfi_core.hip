@@ -13,7 +13,7 @@ void lfi_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 
-thread_local unsigned long long* g_lfi_stamps = nullptr;   // per calling thread: the header promises no process-global state
+unsigned long long* g_lfi_stamps = nullptr;   // diagnostics only, process-global by necessity (include/lfi.h says so): backward passes run on autograd's thread
 
 extern "C" const char* lfi_last_error(void) { return g_err; }
 extern "C" int lfi_version(void) { return 100; }

@@ -1306,7 +1306,7 @@ __global__ __launch_bounds__(ENC_NT, 1) void enc_gru_fwd_r64_kernel(EncArgs a, E
 //      write-wait-read round trips per step), and h_{s-1} stays in registers;
 //   2. the wave's 64 hidden units are taken as four 16-unit tiles one after the other, each with its whole k sweep (phase p: 8
 //      blocks of 36 MFMAs); tile p - 1's epilogue is independent of tile p's MFMAs and is issued between them (sched_group_barrier:
-//      one MFMA, then up to three VALU). Only the last tile's epilogue is exposed. The state images are double-buffered (step parity)
+//      one MFMA, then up to LFI_T16_NV VALU). Only the last tile's epilogue is exposed. The state images are double-buffered (step parity)
 //      because tile 0's new state is written while other waves still read the old one: one barrier per step.
 // Weight fragments: a ring of four blocks, loaded three blocks (~1.7 k cycles) ahead and straight through the step boundary and the
 // barrier; every fragment is fetched once per step and wave as before (L2 -> CU stream unchanged), the state fragments are re-read
@@ -1315,7 +1315,7 @@ __global__ __launch_bounds__(ENC_NT, 1) void enc_gru_fwd_r64_kernel(EncArgs a, E
 // -DLFI_T16_NO_XP no projected-input loads, -DLFI_T16_NO_W no weight loads in the loop, -DLFI_T16_NO_MFMA no products,
 // -DLFI_T16_NO_EPI no gate math / stores under the products, -DLFI_T16_RING=n blocks of weight prefetch)
 #ifndef LFI_T16_NV
-#define LFI_T16_NV 3
+#define LFI_T16_NV 2   // (an MFMA of this shape holds the vector issue for 8 of its 16 cycles: two 4-cycle fillers fit; measured level with 3: 0.44 - 0.46 ms)
 #endif
 #ifndef LFI_T16_RING
 #define LFI_T16_RING 12   // weight ring: slots of one (block, gate) = two fragments; a divisor of 96; RING - 1 of them in flight
