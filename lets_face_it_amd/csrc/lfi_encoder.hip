@@ -989,6 +989,8 @@ __global__ __launch_bounds__(ENC_NT, 2) void enc_gru_fwd_wide_kernel(EncArgs a, 
 // arithmetic feed six MFMAs instead of three. Measured: forward 0.66 -> 0.61 ms, whole step -0.06 .. -0.08 ms on three boxes. (An
 // eight-wave variant - 64 windows x 32 hidden units per wave, two waves per SIMD - measured 0.58 - 0.67 ms by stash variant and
 // +0.05 ms on the whole step: removed.) The gate epilogue is the row-layout one of the wide kernel, run once per row tile.
+// (Round 5: the second row tile's first projected inputs requested one gate early - 32 more live registers in a kernel that already
+// spills 10: 19 spilled, fp16-stash launch 0.544 -> 0.563 ms. Removed.)
 // M16 (round 4, Kp a multiple of 256): the same products on v_mfma_f32_16x16x32_bf16 - same FLOP per cycle, but the chip holds a
 // higher clock on that shape in three-product streams (timing-only build with the MFMAs swapped: forward 0.614 -> 0.554 ms on the
 // p2_face shape; the two-product BPTT kernels gain nothing and keep the 32 x 32 shape). A wave's 64 x 64 x 3 gates are 4 x 4 x 3
@@ -2068,6 +2070,10 @@ __global__ __launch_bounds__(ENC_NT, 1) void enc_gru_bwd_r64_kernel(EncArgs a, E
   float* Tw = Treg + wave * (2 * 32 * ENC_TP);
   __bf16* Yhi = reinterpret_cast<__bf16*>(Treg);
   __bf16* Ylo = Yhi + img;
+  // A2 (two products: the hi pieces of the gate derivatives only): the first pair's lo image is never written - its space holds the
+  // THIRD gate's image (d n * r), so the three products run back to back: no 64-register copy of d n * r across the first two, no
+  // image rewrite between them, three barriers per step instead of four (round 5; same values in the same order)
+  __bf16* Zhi = Xlo;
   unsigned* roww = reinterpret_cast<unsigned*>(Treg + tfloats);
   float* rlive = reinterpret_cast<float*>(roww + R2);
   for (int i = tid; i < img; i += ENC_NT) { Xhi[i] = (__bf16)0.0f; Xlo[i] = (__bf16)0.0f; }
@@ -2097,6 +2103,46 @@ __global__ __launch_bounds__(ENC_NT, 1) void enc_gru_bwd_r64_kernel(EncArgs a, E
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[rt][t][r] = 0.0f;
   __syncthreads();
+  // PIPE (two products + fp16 gate stash = the training default; round 5): the step's stash comes in four batches of 12 loads
+  // (row tile x half, 4 rows each). Round 4 issued a batch and waited for it, four exposed HBM latencies per step; here batch b + 1 is
+  // in flight while batch b is worked on. Same values, same order.
+#ifdef LFI_ENC_BWD_NOPIPE   // (same-box A/B builds: tools/build_variant.sh; LFI_ENC_BWD_NOZ keeps round 4's two image phases)
+  constexpr bool PIPE = false;
+#else
+  constexpr bool PIPE = A2 && S16;
+#endif
+#ifdef LFI_ENC_BWD_NOZ
+  constexpr bool Z3 = false;
+#else
+  constexpr bool Z3 = A2;
+#endif
+  // Two buffers (batch b -> buffer b & 1). Batch 0 of the NEXT step is issued right after this step's last product has issued its
+  // last weight load: it travels under the closing barrier, the transposes and B0. Measured (p2_face / p2_speech, ms per launch, same
+  // box): round 4's form 0.517 / 0.353; this 0.487 / 0.331. Issued EARLIER - during this step's last batch, in front of the products -
+  // it sits in the same in-order queue in front of their weight fragments and gives most of that back (0.516 / 0.358); with a third
+  // buffer, one batch earlier still: 20 spilled VGPRs. Neither kept.
+  enc_u32x4 rp0[2][4], rp1[2][4];   // [buffer][row of the batch]: the two 16-byte halves of a lane's four units' gates
+  f32x4 rhp[2][4];                  // h_{s-1}
+  unsigned rwo[2][4];
+  constexpr int BUF[4] = {0, 1, 0, 1};
+  auto issue = [&](int bi, int sq) {   // batch bi = 2 rt + ih of step sq -> buffer BUF[bi]
+    int rsv = rsub, jv = j0;
+    asm volatile("" : "+v"(rsv), "+v"(jv));
+    const unsigned j4 = (unsigned)jv * 4u, oob = jv < hid ? 0u : 0x80000000u;
+    const enc_rsrc gs = enc_buf(reinterpret_cast<const _Float16*>(a.gates) + (long)sq * a.F * 4 * hid, (long)a.F * hid * 8);
+    const enc_rsrc hs = enc_buf(a.hseq + (long)(sq > 0 ? sq - 1 : 0) * a.F * hid, (long)a.F * hid * 4);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int rl = rg * 64 + (bi >> 1) * 32 + 4 * (4 * (bi & 1) + u) + rsv;
+      const unsigned w = roww[rl];
+      const unsigned go = 2u * (w + j4) + oob;
+      rwo[BUF[bi]][u] = w;
+      rp0[BUF[bi]][u] = __builtin_amdgcn_raw_buffer_load_b128(gs, go, 0, 2);
+      rp1[BUF[bi]][u] = __builtin_amdgcn_raw_buffer_load_b128(gs, go, 16, 2);
+      rhp[BUF[bi]][u] = enc_ld4s(hs, w + j4 + oob, 0);
+    }
+  };
+  if (PIPE) issue(0, a.hist - 1);
 
   for (int s = a.hist - 1; s >= 0; --s) {
     // ---- d h_s in the row layout
@@ -2156,8 +2202,22 @@ __global__ __launch_bounds__(ENC_NT, 1) void enc_gru_bwd_r64_kernel(EncArgs a, E
       for (int ih = 0; ih < 2; ++ih) {
         f32x4 gr[4], gu[4], gn[4], gg[4], hp[4];
         unsigned wo[4];
+        if (PIPE) {
+          const int bi = 2 * rt + ih;
+          if (bi < 3) issue(bi + 1, s);
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+          for (int u = 0; u < 4; ++u) {
+            const enc_u32x4 p0 = rp0[BUF[bi]][u], p1 = rp1[BUF[bi]][u];
+            const f32x4 u0 = enc_unpack_gates(p0[0], p0[1]), u1 = enc_unpack_gates(p0[2], p0[3]);
+            const f32x4 u2 = enc_unpack_gates(p1[0], p1[1]), u3 = enc_unpack_gates(p1[2], p1[3]);
+            gr[u] = f32x4{u0[0], u1[0], u2[0], u3[0]}; gu[u] = f32x4{u0[1], u1[1], u2[1], u3[1]};
+            gn[u] = f32x4{u0[2], u1[2], u2[2], u3[2]}; gg[u] = f32x4{u0[3], u1[3], u2[3], u3[3]};
+            hp[u] = rhp[BUF[bi]][u];
+            wo[u] = rwo[BUF[bi]][u];
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 4 && !PIPE; ++u) {
           const int rl = rg * 64 + rt * 32 + 4 * (4 * ih + u) + rsv;
           wo[u] = roww[rl];
           if (S16) {   // fp16 stash, [window][unit][r, z, n, W_hn h]: two 16-byte loads hold this lane's four units
@@ -2202,8 +2262,8 @@ __global__ __launch_bounds__(ENC_NT, 1) void enc_gru_bwd_r64_kernel(EncArgs a, E
             enc_st4(dar, bgh, o, 0); enc_st4(dau, bgh, o, h4); enc_st4(dnr, bgh, o, 2 * h4);
           }
           bsum[0] += live * dar; bsum[1] += live * dau; bsum[2] += live * dan; bsum[3] += live * dnr;
-          danr[rt][i] = dnr;
-          if (s > 0 && jok) {   // gate images for the products: d r -> first pair, d z -> second pair
+          if (!Z3) danr[rt][i] = dnr;
+          if (s > 0 && jok) {   // gate images for the products: d r -> first pair, d z -> second pair (A2: d n * r -> the third image)
             uint2 h, l;
             split2(dar[0], dar[1], &h.x, &l.x); split2(dar[2], dar[3], &h.y, &l.y);
             *reinterpret_cast<uint2*>(Xhi + rl * ldx + jv) = h;
@@ -2211,6 +2271,10 @@ __global__ __launch_bounds__(ENC_NT, 1) void enc_gru_bwd_r64_kernel(EncArgs a, E
             split2(dau[0], dau[1], &h.x, &l.x); split2(dau[2], dau[3], &h.y, &l.y);
             *reinterpret_cast<uint2*>(Yhi + rl * ldx + jv) = h;
             if (!A2) *reinterpret_cast<uint2*>(Ylo + rl * ldx + jv) = l;
+            if (Z3) {
+              split2(dnr[0], dnr[1], &h.x, &l.x); split2(dnr[2], dnr[3], &h.y, &l.y);
+              *reinterpret_cast<uint2*>(Zhi + rl * ldx + jv) = h;
+            }
           }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -2275,6 +2339,12 @@ __global__ __launch_bounds__(ENC_NT, 1) void enc_gru_bwd_r64_kernel(EncArgs a, E
     __syncthreads();   // B1: both image pairs complete
     product(0, Xhi, Xlo);
     product(1, Yhi, Ylo);
+    if (Z3) {
+      product(2, Zhi, Zhi);
+      if (PIPE) issue(0, s - 1);   // (s >= 1 here: the step loop left at s == 0 above)
+      __syncthreads();   // B2: every wave has read the second image (the next step's transpose tiles overlay it)
+      continue;
+    }
     __syncthreads();   // B2: every wave has read the first pair
     if (jok) {
 #pragma unroll
@@ -2290,6 +2360,7 @@ __global__ __launch_bounds__(ENC_NT, 1) void enc_gru_bwd_r64_kernel(EncArgs a, E
     }
     __syncthreads();   // B3
     product(2, Xhi, Xlo);
+    if (PIPE) issue(0, s - 1);
   }
   if (a.bias_part && jok) {
     float* bp = a.bias_part + ((long)blockIdx.x * (ENC_NW / q.ncg) + rg) * 4 * hid;
