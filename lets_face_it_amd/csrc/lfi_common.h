@@ -39,7 +39,8 @@ extern "C" __attribute__((visibility("hidden"))) int lfi_internal_sample_cond_pr
 extern "C" __attribute__((visibility("hidden"))) int lfi_internal_sample_cond(const float* faces, long ld_faces, long off, int K1, int B, int Ks, int G,
                                                                               const float* pre, const float* b_ih, void* frags, float* gic,
                                                                               float slope, long faces_floats, unsigned* reset, int reset_words,
-                                                                              void* stream);
+                                                                              int have_xfrag, void* stream);
+extern "C" __attribute__((visibility("hidden"))) void* lfi_internal_sample_cond_xfrag_ptr(void* frags, int Ks, int G, int K1);
 
 // ---- device side -----------------------------------------------------------
 // Operand planes (lfi_planes_from_f32, lfi_pgemm.hip): byte offset inside a 1-KB block (32 rows x 16 columns, bf16, row-major

@@ -1961,6 +1961,13 @@ struct RevChain {
   int has_prev;           // 0 at the first generated frame (zero state)
   int frame_no;           // index of the generated frame (diagnostic phase stamps of frames < 128 only)
   unsigned* pipe;         // ticket, abort, progress words (zeroed before every launch)
+  // round 5: step 0's workgroups also leave the NEXT frame's window as the fp16 fragments the fused conditioning kernel reads
+  // (lfi_sample.hip, sc_xfrag_kernel's format: tile bt, step m, plane: lane l, element e = window[16 bt + (l & 15)][32 m + 8 (l >> 4) + e])
+  // - one launch per generated frame less; null: the conditioning call makes them itself
+  _Float16* xf;
+  const float* faces;     // row 0 of the frames buffer (row pitch ld_frame)
+  long xf_off;            // first window column of the next frame in a row: (t + 1 - hist1) * C
+  int K1, NM1;
 };
 template <int NG, bool X3>
 __global__ __launch_bounds__(NT) void flow_rev_chain_kernel(FlowK f, RevChain rc) {
@@ -1989,6 +1996,28 @@ __global__ __launch_bounds__(NT) void flow_rev_chain_kernel(FlowK f, RevChain rc
     const int row = bt * MB + (int)(threadIdx.x >> 5);
     if (row < f.B)
       for (int c = threadIdx.x & 31; c < f.C; c += 32) rc.frame[(long)row * rc.ld_frame + c] = __builtin_nanf("");
+  }
+  if (k == 0 && rc.xf) {
+    // the frame's rows of this tile are on their way to memory: drain, meet, then read the window back past the L1 (agent scope)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    typedef _Float16 xh8 __attribute__((ext_vector_type(8)));
+    for (int it = threadIdx.x; it < rc.NM1 * 64; it += NT) {
+      const int l = it & 63, m = it >> 6;
+      const int row = bt * MB + (l & 15), kk0 = 32 * m + 8 * (l >> 4);
+      xh8 hi, lo;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        float v = 0.0f;
+        if (row < f.B && kk0 + e < rc.K1) v = ld_tile(rc.faces + (long)row * rc.ld_frame + rc.xf_off + kk0 + e, false);
+        const _Float16 h = (_Float16)v;
+        hi[e] = h;
+        lo[e] = (_Float16)(v - (float)h);
+      }
+      _Float16* dst = rc.xf + ((long)(bt * rc.NM1 + m) * 2) * 512 + l * 8;
+      *reinterpret_cast<xh8*>(dst) = hi;
+      *reinterpret_cast<xh8*>(dst + 512) = lo;
+    }
   }
 }
 
@@ -3811,6 +3840,9 @@ extern "C" int lfi_flow_sample_seq_from(const lfi_flow_dims* d, const lfi_flow_p
   if (fused && nframes > 0) {
     if ((rc = lfi_internal_sample_cond_prepare(wct, E, p1col, K1, f.wc, Ks, G, cfrags, stream))) return rc;
   }
+  // LFI_SAMPLE_XF_CHAIN=0 keeps the window-fragment kernel in front of every frame's conditioning
+  const char* xce = getenv("LFI_SAMPLE_XF_CHAIN");
+  const bool xf_chain = fused && chain && !(xce && xce[0] == '0');
   if (chain) {
     rc = f.lstm ? set_flow_lds(flow_rev_chain_kernel<4, false>, lds, "lfi_flow_sample_seq")
                 : (x3 ? set_flow_lds(flow_rev_chain_kernel<3, true>, lds, "lfi_flow_sample_seq")
@@ -3861,8 +3893,10 @@ extern "C" int lfi_flow_sample_seq_from(const lfi_flow_dims* d, const lfi_flow_p
     }
     if (fused) {
       // (its first workgroup also clears the reverse chain's ticket / progress words for the launch below: no memset node per frame)
+      // (from the run's second frame on the window's fragments are already there: the previous frame's chain left them)
       if ((rc = lfi_internal_sample_cond(faces, (long)seq_len * C, (long)(t - hist1) * C, K1, B, Ks, G, cfr, p->b_ih, cfrags, gic, 0.01f,
-                                         (long)B * seq_len * C, chain ? chain_state : nullptr, (int)chain_words, stream)))
+                                         (long)B * seq_len * C, chain ? chain_state : nullptr, (int)chain_words,
+                                         (xf_chain && n > 0) ? 1 : 0, stream)))
         return rc;
     } else {
       if (stage_win) {
@@ -3885,6 +3919,10 @@ extern "C" int lfi_flow_sample_seq_from(const lfi_flow_dims* d, const lfi_flow_p
       rcn.noise = noise + (long)n * B * C; rcn.xa = xa; rcn.xb = xb;
       rcn.frame = faces + (long)t * C; rcn.ld_frame = (long)seq_len * C;
       rcn.gic = gic; rcn.h = h; rcn.cstate = cstate; rcn.has_prev = first_frame + n > 0 ? 1 : 0; rcn.frame_no = first_frame + n; rcn.pipe = chain_state;
+      if (xf_chain && n + 1 < nframes) {
+        rcn.xf = reinterpret_cast<_Float16*>(lfi_internal_sample_cond_xfrag_ptr(cfrags, Ks, G, K1));
+        rcn.faces = faces; rcn.xf_off = (long)(t + 1 - hist1) * C; rcn.K1 = K1; rcn.NM1 = (K1 + 31) / 32;
+      }
       if (!fused) {   // (the fused conditioning kernel has cleared them)
         hipError_t me = hipMemsetAsync(chain_state, 0, chain_words * sizeof(unsigned), st);
         LFI_REQUIRE(me == hipSuccess, "lfi_flow_sample_seq: hipMemsetAsync: %s", hipGetErrorString(me));

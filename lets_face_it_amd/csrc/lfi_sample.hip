@@ -324,6 +324,11 @@ extern "C" __attribute__((visibility("hidden"))) long lfi_internal_sample_cond_b
   const long NM1 = (K1 + 31) / 32, NGT = G / 128, ntile = ((long)B + 63) / 64 * 4;
   return ((long)Ks * 8 * NM1 * 4 * 2 + (long)Ks * 8 * 16 * NGT * 2 + ntile * NM1 * 2) * 1024 + 256;
 }
+// where the window's fragments live inside `frags` (written by sc_xfrag_kernel or by the reverse chain's step-0 workgroups)
+extern "C" __attribute__((visibility("hidden"))) void* lfi_internal_sample_cond_xfrag_ptr(void* frags, int Ks, int G, int K1) {
+  const long NM1 = (K1 + 31) / 32, NGT = G / 128;
+  return reinterpret_cast<_Float16*>(frags) + (long)Ks * 8 * NM1 * 4 * 2 * 512 + (long)Ks * 8 * 16 * NGT * 2 * 512;
+}
 extern "C" __attribute__((visibility("hidden"))) int lfi_internal_sample_cond_prepare(const float* wct, long ldw, int col0, int K1, const float* wc,
                                                                                       int Ks, int G, void* frags, void* stream) {
   const int NM1 = (K1 + 31) / 32, NGT = G / 128;
@@ -341,7 +346,7 @@ extern "C" __attribute__((visibility("hidden"))) int lfi_internal_sample_cond_pr
 extern "C" __attribute__((visibility("hidden"))) int lfi_internal_sample_cond(const float* faces, long ld_faces, long off, int K1, int B, int Ks, int G,
                                                                               const float* pre, const float* b_ih, void* frags, float* gic,
                                                                               float slope, long faces_floats, unsigned* reset, int reset_words,
-                                                                              void* stream) {
+                                                                              int have_xfrag, void* stream) {
   const int NM1 = (K1 + 31) / 32, NGT = G / 128;
   const int ntile = (B + 63) / 64 * 4;
   _Float16* f1 = reinterpret_cast<_Float16*>(frags);
@@ -354,7 +359,7 @@ extern "C" __attribute__((visibility("hidden"))) int lfi_internal_sample_cond(co
   const char* xe = getenv("LFI_SAMPLE_XFRAG");
   const bool inreg = (xe && xe[0] == '0') && ld_faces % 2 == 0 && off % 2 == 0 && (reinterpret_cast<uintptr_t>(faces) & 7) == 0 &&
                      faces_floats > 0;
-  if (!inreg) {
+  if (!inreg && !have_xfrag) {   // (have_xfrag: the previous frame's reverse chain left this frame's window fragments - lfi_flow.hip, RevChain.xf)
     const long nx = (long)ntile * NM1 * 2 * 512;
     hipLaunchKernelGGL(sc_xfrag_kernel, dim3((unsigned)((nx + 255) / 256)), dim3(256), 0, (hipStream_t)stream, faces, ld_faces, off, K1, B, NM1, ntile,
                        fx);

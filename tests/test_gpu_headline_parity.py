@@ -163,6 +163,12 @@ def test_sampler_fused_conditioning_matches_two_gemms(gpu_device, monkeypatch):
     c = m.inference(seq_len, dd, noise=noise).clone()
     per_frame = (a - c).abs().amax(dim=(0, 2))
     assert torch.equal(a, c), ("in-kernel window split differs from the fragment kernel, per frame:", per_frame.tolist())
+    # ... and by default the reverse chain's step-0 workgroups leave the next frame's fragments (no fragment launch from a run's second
+    # frame on); LFI_SAMPLE_XF_CHAIN=0 keeps the fragment kernel in front of every frame: the same fragments
+    monkeypatch.delenv("LFI_SAMPLE_XFRAG")
+    monkeypatch.setenv("LFI_SAMPLE_XF_CHAIN", "0")
+    e = m.inference(seq_len, dd, noise=noise).clone()
+    assert torch.equal(a, e), ("fragments left by the chain differ from the fragment kernel's, per frame:", (a - e).abs().amax(dim=(0, 2)).tolist())
 
 
 def test_sampler_leaves_fp16_pieces_for_out_of_range_inputs(gpu_device):

@@ -7,9 +7,9 @@ export TMPDIR=/tmp
 timeout -k 10 600 python -m pytest tests -x -q -m gpu -k "sampl or inference or generate" > $O/pytest_sampling.log 2>&1; rc=$?
 echo "sampling tests rc=$rc"; tail -4 $O/pytest_sampling.log
 [ $rc -ne 0 ] && exit $rc
-for x in 1 0 1 0; do   # (1 = the default: fragment kernel in front; 0 = split inside the conditioning kernel)
-  LFI_SAMPLE_XFRAG=$x timeout -k 10 300 python bench.py --workload sample > $O/bench_sample_xfrag_$x.json 2> $O/bench_sample_xfrag_$x.err || exit 1
+for x in 1 0 1 0; do   # (1 = the default: the reverse chain leaves the next frame's window fragments; 0 = a fragment launch per frame)
+  LFI_SAMPLE_XF_CHAIN=$x timeout -k 10 300 python bench.py --workload sample > $O/bench_sample_xfchain_$x.json 2> $O/bench_sample_xfchain_$x.err || exit 1
   python -c "
 import json
-d=json.loads(open('$O/bench_sample_xfrag_$x.json').read().strip().splitlines()[-1]); print('XFRAG=$x', round(d['ms_per_step'],2), 'ms', {k: v for k, v in d['kernel_timing'].items()})"
+d=json.loads(open('$O/bench_sample_xfchain_$x.json').read().strip().splitlines()[-1]); print('XF_CHAIN=$x', round(d['ms_per_step'],2), 'ms', d['kernel_timing'].get('sample_graph'))"
 done
