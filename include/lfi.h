@@ -239,7 +239,11 @@ typedef struct {
   int lstm;                  /* 0 GRUCell, 1 LSTMCell coupling net (glow/models.py:176-185); the LSTM starts from zero
                                 (h, c) at the first modelled frame (the reference's own call, models.py:209-213, crashes) */
   float scale_eps;           /* Glow.scale_eps */
-  int gemm_precision;        /* lfi_gemm_desc.precision of the GEMMs issued by lfi_flow_param_grads / lfi_flow_sample_seq */
+  int gemm_precision;        /* lfi_gemm_desc.precision of the GEMMs issued by lfi_flow_param_grads / lfi_flow_sample_seq (bits 0..15).
+                                Bit 16 (round 5; the same value in lfi_flow_seq_bwd_planes and lfi_flow_param_grads, planes mode and
+                                two-product thin products only - skip bit 0x100 set): the backward stash's dgi | dgh ROWS are bf16
+                                arrays of the same shapes instead of fp32 - their only readers round that operand to bf16 anyway
+                                (glow/models.py:204-214 backward: the GRUCell's weight gradients) */
 } lfi_flow_dims;
 /* derived: Ch = C/2, C2 = C - Ch, Cout = affine ? 2*C2 : C2, G = lstm ? 4H : 3H, I = Ch + D */
 

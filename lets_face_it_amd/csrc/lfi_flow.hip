@@ -51,6 +51,9 @@ struct FlowK {
   // one uint4 per entry and plane; the lo plane follows the hi plane of an image
   const uint4 *xbwh, *xbwz;
   int dgi_hi_only;         // the dgi planes' hi halves only (their consumers take them as a rounded A operand: two products)
+  int g16;                 // backward walk (planes mode): the dgi | dgh ROWS of the backward stash are bf16 arrays of the same shapes -
+                           // their readers, the thin weight-gradient products, round that operand to bf16 anyway (two products):
+                           // lfi_flow_dims.gemm_precision bit 16, honoured by lfi_flow_seq_bwd_planes and lfi_flow_param_grads alike
   __bf16* bDgiR;           // backward walk (bf16x3): dgi also as operand planes of the (Ks F x G) matrix (lfi_flow_seq_bwd_planes)
   int C16, Ch16, H16, Co16, NG;
   // forward stash
@@ -2630,7 +2633,15 @@ __global__ __launch_bounds__(NT) void flow_pipe_bwd_kernel(FlowK f) {
           // (GRU: d r, d z on the hidden side equal the input side's. Storing only the n block of dgh and taking the other two
           // rows of the W_hh gradient from dgi was measured in round 4: 8 of 24 dword stores per lane and cell less, but the
           // gradient then needs two products over the frames instead of one - whole step 7.73 / 7.69 ms against 7.67 / 7.64: removed)
-          for (int g = 0; g < NG; ++g) { go[g * H] = gi_[g]; ho[g * H] = gh_[g]; bsi[g] += gi_[g]; bsh[g] += gh_[g]; }
+          for (int g = 0; g < NG; ++g) {
+            if (X3 && f.g16) {   // (rounded as the products' operand split rounds its hi part: to nearest even)
+              reinterpret_cast<__bf16*>(f.bDgi)[(kf + row) * G + j + g * H] = (__bf16)gi_[g];
+              reinterpret_cast<__bf16*>(f.bDgh)[(kf + row) * G + j + g * H] = (__bf16)gh_[g];
+            } else {
+              go[g * H] = gi_[g]; ho[g * H] = gh_[g];
+            }
+            bsi[g] += gi_[g]; bsh[g] += gh_[g];
+          }
         }
 #pragma unroll
         for (int g = 0; g < NG; ++g) {
@@ -3501,6 +3512,7 @@ extern "C" int lfi_flow_seq_bwd_planes(const lfi_flow_dims* d, const lfi_flow_pa
   bind_bstash(&f, bstash);
   f.bDgiR = reinterpret_cast<__bf16*>(dgi_rows);
   f.dgi_hi_only = hi_only ? 1 : 0;
+  f.g16 = (dgi_rows && ((d->gemm_precision >> 16) & 1)) ? 1 : 0;
   f.gscale = gscale;
   hipStream_t st = (hipStream_t)stream;
   const bool fast = flow_fast_ok(f.C, f.H, f.Cout) && !flow_force_generic();
@@ -3575,8 +3587,13 @@ extern "C" int lfi_flow_param_grads(const lfi_flow_dims* d, const lfi_flow_param
   float* gws2 = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(cws + cws_floats) + 63) & ~(uintptr_t)63);  // dW split-K partials
   void* bs = bias_stream ? bias_stream : stream;
 
+  // gemm_precision bit 16 (with the walk's planes mode): dgi | dgh rows are bf16 (FlowK.g16) - the two products that read them take
+  // them as an operand that arrives rounded (lfi_gemm_desc.a_bf16: two-product mode, i.e. skip bit 0 set by the caller)
+  const bool g16 = ((d->gemm_precision >> 16) & 1) != 0;
+  LFI_REQUIRE(!g16 || (flow_bwd_planes_ok(d) && !c && (d->gemm_precision & 0x100) && !(d->gemm_precision & 0x200)),
+              "lfi_flow_param_grads: bf16 gradient rows (gemm_precision bit 16) need the walk's planes mode and two-product thin products");
   lfi_gemm_desc q = {};
-  q.batch = Ks; q.accumulate = accumulate; q.splitk = splitk; q.work = gws; q.precision = d->gemm_precision;
+  q.batch = Ks; q.accumulate = accumulate; q.splitk = splitk; q.work = gws; q.precision = d->gemm_precision & 0xffff;
   q.a_kcontig = 0; q.b_kcontig = 0; q.K = F;
   // K split (<= 16, what the workspace holds) of a K = F product with Ks x few 128 x 128 output tiles: the one that best
   // fills whole rounds of the 512 co-resident workgroups, less 3 % per extra partial for the reduce pass
@@ -3611,7 +3628,9 @@ extern "C" int lfi_flow_param_grads(const lfi_flow_dims* d, const lfi_flow_param
   if (f.N > 1) {
     q.K = F - B; q.M = G; q.N = H; q.splitk = fill_split(G, H, F - B); q.A = f.bDgh + (long)B * G; q.lda = G; q.strideA = (long)F * G; q.B = f.sH; q.ldb = H;
     q.strideB = (long)F * H; q.C = g->w_hh; q.ldc = H; q.strideC = (long)G * H;
+    if (g16) { q.a_bf16 = 1; q.A = reinterpret_cast<const float*>(reinterpret_cast<const __bf16*>(f.bDgh) + (long)B * G); }
     if ((rc = lfi_gemm_f32(&q, stream))) return rc;
+    q.a_bf16 = 0;
   } else if (!accumulate) {
     (void)hipMemsetAsync(g->w_hh, 0, sizeof(float) * (size_t)Ks * G * H, (hipStream_t)stream);
   }
@@ -3620,7 +3639,9 @@ extern "C" int lfi_flow_param_grads(const lfi_flow_dims* d, const lfi_flow_param
   if (Ch > 0) {
     q.M = G; q.N = Ch; q.splitk = fill_split(G, Ch, F); q.A = f.bDgi; q.lda = G; q.strideA = (long)F * G; q.B = f.sY; q.ldb = f.ldc; q.strideB = (long)F * f.ldc;
     q.C = g->w_ih; q.ldc = I; q.strideC = (long)G * I;
+    q.a_bf16 = g16 ? 1 : 0;
     if ((rc = lfi_gemm_f32(&q, stream))) return rc;
+    q.a_bf16 = 0;
   }
   // dW[k] (C x C) = a[k]^T dy[k]  -> LU parameter gradients, then a 16-workgroup kernel: on bias_stream (with a split-K
   // workspace of their own) they run next to the products above instead of holding the chip for 0.14 ms

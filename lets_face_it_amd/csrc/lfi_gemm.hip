@@ -270,6 +270,17 @@ struct XStager {
 #pragma unroll
     for (int i = 0; i < 4; ++i) r[i] = (in[i] && kk[i] < krem) ? *reinterpret_cast<const f32x4*>(p + off[i]) : z;
   }
+  // the same patch of an operand that ARRIVES rounded to bf16 (lfi_gemm_desc.a_bf16; !KC only): 8-byte loads, widened exactly - the
+  // split below then yields hi = the value, lo = 0
+  __device__ __forceinline__ void load16(const __bf16* __restrict__ p, int krem, f32x4 (&r)[4]) const {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      uint2 b = {0u, 0u};
+      if (in[i] && kk[i] < krem) b = *reinterpret_cast<const uint2*>(p + off[i]);
+      r[i] = f32x4{__builtin_bit_cast(float, b.x << 16), __builtin_bit_cast(float, b.x & 0xffff0000u),
+                   __builtin_bit_cast(float, b.y << 16), __builtin_bit_cast(float, b.y & 0xffff0000u)};
+    }
+  }
   template <bool H16 = false>
   __device__ __forceinline__ void store(__bf16* hi_img, __bf16* lo_img, int krem, f32x4 (&r)[4]) const {
     if (KC) {
@@ -322,7 +333,9 @@ struct XStager {
   }
 };
 
-template <bool AKC, bool BKC, int XT = 0>
+// ABF (round 5): A arrives rounded to bf16 (lfi_gemm_desc.a_bf16; mn-contiguous, two-product mode): half the A bytes of the thin
+// HBM-bound weight-gradient products, the same two products on the same values as the fp32 form with skip bit 0
+template <bool AKC, bool BKC, int XT = 0, bool ABF = false>
 __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(GemmArgs g) {
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -343,11 +356,13 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16x3_kernel(GemmArgs g) {
   const float* __restrict__ tA = AKC ? A + (long)m0 * g.lda + kbeg : A + (long)kbeg * g.lda + m0;
   const float* __restrict__ tB = BKC ? B + (long)n0 * g.ldb + kbeg : B + (long)kbeg * g.ldb + n0;
   const long stepA = AKC ? XBK : (long)XBK * g.lda, stepB = BKC ? XBK : (long)XBK * g.ldb;
+  const __bf16* __restrict__ tA16 = reinterpret_cast<const __bf16*>(g.A) + batch * g.strideA + (long)kbeg * g.lda + m0;   // (ABF)
 
   f32x4 ra[4], rb[4];
   auto load_tiles = [&](int kt) {
     const int krem = kend - (kbeg + kt * XBK);
-    sa.load(tA + kt * stepA, krem, ra);
+    if constexpr (ABF) sa.load16(tA16 + kt * stepA, krem, ra);
+    else sa.load(tA + kt * stepA, krem, ra);
     sb.load(tB + kt * stepB, krem, rb);
   };
   constexpr int NIMG = XT == 3 ? 6 : 4;   // images per buffer: A hi, A lo, B hi, B lo - or three pieces of each (six products)
@@ -962,7 +977,10 @@ extern "C" int lfi_gemm_f32(const lfi_gemm_desc* d, void* stream) {
   const bool x6 = use_x3 && (d->precision & 4) && !d->a_bf16;   // six products: fp32-grade, 128 x 128 kernel only
   const bool x3h = use_x3 && !x6 && (d->precision & 8) && !d->a_bf16;   // three products of fp16 pieces, likewise
   if (x6 || x3h) plan.shape = 0;
-  if (d->a_bf16) plan.shape = 3;
+  // (a_bf16: the 256 x 256 kernel - the window encoders' long-K dW_hh - unless the plan wants 128 x 128 tiles for a BATCHED product:
+  // the flow's thin weight-gradient products, round 5)
+  const bool a16_128 = d->a_bf16 && d->batch > 1 && plan.shape == 0;
+  if (d->a_bf16 && !a16_128) plan.shape = 3;
   int splitk = plan.splitk < 1 ? 1 : plan.splitk;
   if (splitk > d->K / BKT) splitk = d->K / BKT < 1 ? 1 : d->K / BKT;
   LFI_REQUIRE(splitk == 1 || d->work, "lfi_gemm_f32: splitk needs a workspace");
@@ -1006,7 +1024,18 @@ extern "C" int lfi_gemm_f32(const lfi_gemm_desc* d, void* stream) {
   // floats past K (k-contiguous; zeroed before it reaches LDS) or past M/N (mn-contiguous; those LDS columns only feed
   // output rows/columns that are never stored) — see vec_ok above.)
   dim3 grid(a.tiles_m * a.tiles_n, d->batch, splitk);
-  if (d->a_bf16) {
+  if (a16_128) {
+    const size_t lds = (size_t)2 * 4 * XIMG * sizeof(__bf16);
+    static bool attrb = false;
+    if (!attrb) {
+      if (hipFuncSetAttribute((const void*)gemm_bf16x3_kernel<false, false, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) {
+        lfi_set_error("lfi_gemm_f32: cannot reserve %zu bytes of LDS for the bf16-A 128 x 128 kernel", lds);
+        return LFI_ERR_LAUNCH;
+      }
+      attrb = true;
+    }
+    hipLaunchKernelGGL((gemm_bf16x3_kernel<false, false, 2, true>), grid, dim3(256), lds, st, a);
+  } else if (d->a_bf16) {
     const size_t lds_loop = (size_t)2 * 4 * YIMG * sizeof(__bf16), lds_epi = (size_t)LFI_EPI_ROWS * 260 * sizeof(float);
     const size_t lds = lds_loop > lds_epi ? lds_loop : lds_epi;
     static bool attra = false;

@@ -907,7 +907,15 @@ class GlowEngine:
         # fetched: the walk / the dpre epilogue then write the hi planes only (half the plane traffic)
         dgi_hi = all(self._skip_bits(c) & 1 for c in ("dpre", "flow_pgrads"))
         dpre_hi = all(self._skip_bits(c) & 1 for c in ("cond_wgrad", "cond_dgrad"))
-        check(self.L.lfi_flow_seq_bwd_planes(C.byref(dims), C.byref(p), self.prep.data_ptr(), ctx.stash.data_ptr(), gscale,
+        # two-product thin weight-gradient products round dgi | dgh to bf16 on arrival: the walk then leaves those ROWS as bf16 (half the
+        # bytes written by the walk and read by the products; gemm_precision bit 16, same bit in both calls; LFI_FLOW_G16=0: fp32 rows)
+        pg_skip = self._skip_bits("flow_pgrads")
+        g16 = bool((pg_skip & 1) and not (pg_skip & 2) and (self.precision & 1) and os.environ.get("LFI_FLOW_G16", "1") != "0")
+        bdims = dims
+        if g16:
+            bdims = self._flow_dims(B, N)
+            bdims.gemm_precision = dims.gemm_precision | (1 << 16)
+        check(self.L.lfi_flow_seq_bwd_planes(C.byref(bdims), C.byref(p), self.prep.data_ptr(), ctx.stash.data_ptr(), gscale,
                                              bst.data_ptr(), dgi_p.data_ptr(), 1 if dgi_hi else 0, st), "lfi_flow_seq_bwd_planes")
         work = self._buf("scratch.pg", self.L.lfi_flow_param_grads_work_floats(C.byref(dims)))
         g = self._flow_grads()
@@ -921,7 +929,7 @@ class GlowEngine:
         pg_dims = dims
         if self._skip_bits("flow_pgrads") and (self.precision & 1):
             pg_dims = self._flow_dims(B, N)
-            pg_dims.gemm_precision = self.precision | (self._skip_bits("flow_pgrads") << 8)
+            pg_dims.gemm_precision = self.precision | (self._skip_bits("flow_pgrads") << 8) | ((1 << 16) if g16 else 0)
         check(self.L.lfi_flow_param_grads(C.byref(pg_dims), C.byref(p), self.prep.data_ptr(), ctx.stash.data_ptr(),
                                           bst.data_ptr(), None, KD, gscale, C.byref(g), 0, work.data_ptr(),
                                           st, side.cuda_stream if side is not None else None), "lfi_flow_param_grads")

@@ -688,8 +688,14 @@ def test_two_bucket_allreduce_protocol(gpu_device):
     from lets_face_it_amd.glow.lets_face_it_glow import LetsFaceItGlow
     fxm = Fixture("mid")
 
+    import random
+
     def make():
         torch.manual_seed(0)
+        # the negative-example branch is on in this fixture and is drawn from PYTHON's generator (lets_face_it_glow.py:40, 10 % of the
+        # steps): unseeded, one of the two models took it in 18 % of the runs and the bitwise comparison below failed (round 5:
+        # tools/step_determinism_probe.py showed every gradient x -0.1 in those runs - the branch, not the engine)
+        random.seed(0)
         m = LetsFaceItGlow(Namespace(**fxm.hp))
         m.seq_glow.load_state_dict(fxm.state_dict(torch.float32))
         m.to(gpu_device).train()
