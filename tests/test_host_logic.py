@@ -255,3 +255,30 @@ def test_window_loader_gives_every_rank_the_same_steps(n, batch, world):
     # single process: DataLoader(drop_last=False) semantics, ragged last batch kept
     one = [b["idx"] for b in WindowLoader(ds, batch, shuffle=False)]
     assert torch.equal(torch.cat(one), torch.arange(n)) and len(one) == -(-n // batch)
+
+
+def test_window_encoder_forward_variant_selection(monkeypatch):
+    """lfi_encode_windows_fwd_variant (host logic only: no GPU): which forward kernel a descriptor takes by shape and switches -
+    the round-5 kernel with the epilogue under the matrix phase only for hid = 256 launches that fill the chip and, by default, only
+    where no stash is written (glow/models.py:55-80)."""
+    import ctypes as C
+    from lets_face_it_amd import _lib
+    from lets_face_it_amd._lib import EncDesc
+    L = _lib.lib()
+    for k in ("LFI_ENC_T16", "LFI_ENC_R64", "LFI_ENC_M16", "LFI_ENC_WIDE"):
+        monkeypatch.delenv(k, raising=False)
+    big = EncDesc(256, 80, 56, 24, 24, 256, 896, 256, 1, 0, 0, 1, 1)       # p2_face at the headline shape
+    small = EncDesc(256, 80, 56, 24, 2, 128, 896, 768, 1, 0, 0, 1, 1)      # p1_speech: hid 128
+    ragged = EncDesc(40, 80, 56, 24, 24, 256, 896, 256, 1, 0, 0, 1, 1)     # 2 240 windows: too few 64-window workgroups for the chip
+    assert L.lfi_encode_windows_fwd_variant(C.byref(big), 1, 0) == 5 and L.lfi_encode_windows_fwd_variant(C.byref(big), 1, 1) == 4
+    assert L.lfi_encode_windows_fwd_variant(C.byref(small), 1, 1) in (2, 3) and L.lfi_encode_windows_fwd_variant(C.byref(ragged), 1, 0) == 2
+    monkeypatch.setenv("LFI_ENC_T16", "2")
+    assert L.lfi_encode_windows_fwd_variant(C.byref(big), 1, 1) == 5
+    monkeypatch.setenv("LFI_ENC_T16", "0")
+    assert L.lfi_encode_windows_fwd_variant(C.byref(big), 0, 0) == 4
+    monkeypatch.setenv("LFI_ENC_M16", "0")
+    assert L.lfi_encode_windows_fwd_variant(C.byref(big), 0, 0) == 3
+    monkeypatch.setenv("LFI_ENC_R64", "0")
+    assert L.lfi_encode_windows_fwd_variant(C.byref(big), 0, 0) == 2
+    f32 = EncDesc(256, 80, 56, 24, 24, 256, 896, 256, 0, 0, 0, 0, 0)       # exact-product mode: the accumulator-layout fused kernel
+    assert L.lfi_encode_windows_fwd_variant(C.byref(f32), 0, 0) == 1
