@@ -593,9 +593,14 @@ class GlowEngine:
         if self.prep is None or self.prep.numel() < need:
             self.prep = torch.zeros(need, dtype=torch.float32, device=self.device)
         p = self._flow_params()
-        check(self.L.lfi_flow_prep(C.byref(d), C.byref(p), self.prep.data_ptr(), 1 if with_inverse else 0, _stream()),
-              "lfi_flow_prep")
         s = self.spec
+        # the two STREAMING kernels of this block (80 + 60 MB) first: on the second stream they then run in the step's first ~90 us,
+        # beside the small launches in front of the window encoders, instead of under the largest encoder's recurrence, which they
+        # slowed (round 5: cols_fold started 128 us into the step behind the latency-bound invconv kernels and took 300 us there)
+        prep_first = os.environ.get("LFI_PREP_FOLD_FIRST", "1") == "0"
+        if prep_first:
+            check(self.L.lfi_flow_prep(C.byref(d), C.byref(p), self.prep.data_ptr(), 1 if with_inverse else 0, _stream()),
+                  "lfi_flow_prep")
         check(self.L.lfi_cols_fold(self.fview("wct").data_ptr(), s.E, s.Ks * s.D, self.fold_a.data_ptr(),
                                    self.fold_b.data_ptr(), s.Ef, self.wct_f.data_ptr(), s.ldf, _stream()), "lfi_cols_fold")
         if self.precision == 1:
@@ -604,6 +609,10 @@ class GlowEngine:
             # (over all ldf columns - the padding columns are zero - so that the k-tile count is even whatever the widths and the
             # products take the v_mfma_f32_16x16x32_bf16 kernels, which consume k-tiles in pairs)
             self._wct_planes = self.planes("wct_planes", self.wct_f, s.ldf, s.Ks * s.D, s.ldf)
+        if not prep_first:
+            check(self.L.lfi_flow_prep(C.byref(d), C.byref(p), self.prep.data_ptr(), 1 if with_inverse else 0, _stream()),
+                  "lfi_flow_prep")
+        if self.precision == 1:
             if self._chain_fwd_ok():
                 # W_c = W_ih[:, Ch:] of every flow step, (Ks G x D): row use in gic = c W_c^T (sums over D), transposed use in
                 # d pre-activation = dgi W_c (sums over the gate rows). (The folded cond_transform weights above serve the
