@@ -801,8 +801,9 @@ def test_window_scatter_kernels_match(gpu_device, monkeypatch, shape, masked):
     assert err < 2e-6, err
 
 
-@pytest.mark.parametrize("mod,two,s16", [("p2_face", 1, 1), ("p2_face", 0, 0), ("p2_speech", 1, 0), ("p1_speech", 1, 1)])
-def test_window_encoder_tilings_match(gpu_device, monkeypatch, mod, two, s16):
+@pytest.mark.parametrize("mod,two,s16,B", [("p2_face", 1, 1, 256), ("p2_face", 0, 0, 256), ("p2_speech", 1, 0, 256), ("p1_speech", 1, 1, 256),
+                                          ("p2_face", 1, 1, 250)])   # (250: 14 000 windows - the last 64-window workgroup is ragged)
+def test_window_encoder_tilings_match(gpu_device, monkeypatch, mod, two, s16, B):
     """The two tilings of the fused window-encoder recurrence - four waves of 64 windows x 64 hidden units, one workgroup per CU
     (default where the launch fills the chip: every weight fragment feeds two row tiles) and the 32-window row-layout kernels
     (LFI_ENC_R64=0) - at the benchmark's shapes, through the C ABI:
@@ -814,7 +815,7 @@ def test_window_encoder_tilings_match(gpu_device, monkeypatch, mod, two, s16):
     from lets_face_it_amd._lib import EncDesc, check
     L = _lib.lib()
     hist, hid = {"p2_face": (24, 256), "p2_speech": (16, 256), "p1_speech": (2, 128)}[mod]
-    B, T, start = 256, 80, 24
+    T, start = 80, 24
     N = T - start
     F = N * B
     dev = gpu_device
