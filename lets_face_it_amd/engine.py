@@ -1261,9 +1261,10 @@ class GlowEngine:
         """SeqGlow.inference (models.py:567-596) with the prior noise given: (seq_len - start, B, C), already * eps.
 
         The generated frames are produced in a few RUNS (LFI_SAMPLE_RUNS, default 4 from 64 frames up): everything of a run that
-        does not depend on generated frames - window encoders, the non-autoregressive cond_transform columns - is computed on the
-        second stream while the previous run's chain of dependent reverse cells (latency-bound: ~15 us per cell, the chip mostly
-        idle) executes on the main one; only the first run's static part stands in front of the chain."""
+        does not depend on generated frames - window encoders, the non-autoregressive cond_transform columns - is queued on the
+        second stream behind the previous run's chain of dependent reverse cells, so that only the first run's static part stands in
+        front of the first frame. It does not shorten the call: a chain launch holds every CU, and the call takes static + chain
+        whatever the number of runs (profiles/round5_sampler_one_run_kernel_stats.md)."""
         s = self.spec
         seed = data["p1_face"]
         B = seed.shape[0]

@@ -22,9 +22,11 @@ def main():
     ap.add_argument("--reps", type=int, default=20)
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--fwd-only", action="store_true")
+    ap.add_argument("--no-mask", action="store_true", help="no feature-dropout mask (validation / sampling)")
+    ap.add_argument("--frames", type=int, default=80, help="T: frames per sequence (windows = (T - 24) * batch)")
     a = ap.parse_args()
     hist, hid = {"p2_face": (24, 256), "p2_speech": (16, 256), "p1_speech": (2, 128)}[a.mod]
-    B, T, start = a.batch, 80, 24
+    B, T, start = a.batch, a.frames, 24
     N = T - start
     F = N * B
     dev = torch.device("cuda:0")
@@ -52,7 +54,7 @@ def main():
 
     def fwd(s16, stash=True):
         d = desc(1, s16)
-        check(L.lfi_encode_windows_fwd(C.byref(d), xp.data_ptr(), whh.data_ptr(), b_ih.data_ptr(), b_hh.data_ptr(), mask.data_ptr(),
+        check(L.lfi_encode_windows_fwd(C.byref(d), xp.data_ptr(), whh.data_ptr(), b_ih.data_ptr(), b_hh.data_ptr(), None if a.no_mask else mask.data_ptr(),
                                        cond.data_ptr(), gates.data_ptr() if stash else None, hseq.data_ptr(), work.data_ptr(), st), "fwd")
 
     def bwd(two, s16):
