@@ -18,6 +18,39 @@ unsigned long long* g_lfi_stamps = nullptr;   // diagnostics only, process-globa
 extern "C" const char* lfi_last_error(void) { return g_err; }
 extern "C" int lfi_version(void) { return 100; }
 
+// ------------------------------------------------------------------ a stream confined to part of every XCD
+// hipExtStreamCreateWithCUMask on this card (tools/probes/cu_mask_map_probe.hip): bits 8g .. 8g+7 of the mask are CU slot g of the
+// eight XCDs (a group with any bit set enables all eight), so `cus_per_xcd` leading groups give a stream that owns that many CUs of
+// every XCD - its kernels leave the other CUs (and their share of each L2) to whatever runs beside them.
+extern "C" int lfi_stream_create_partial(int cus_per_xcd, void** stream) {
+  LFI_REQUIRE(stream != nullptr, "lfi_stream_create_partial: null output pointer");
+  int dev = 0, cus = 0;
+  LFI_REQUIRE(hipGetDevice(&dev) == hipSuccess &&
+                  hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess,
+              "lfi_stream_create_partial: no device");
+  LFI_REQUIRE(cus % 8 == 0 && cus <= 2048 && cus_per_xcd >= 1 && cus_per_xcd <= cus / 8,
+              "lfi_stream_create_partial: %d CUs per XCD asked of a device with %d CUs in 8 XCDs", cus_per_xcd, cus);
+  uint32_t mask[64] = {0};
+  for (int b = 0; b < 8 * cus_per_xcd; ++b) mask[b >> 5] |= 1u << (b & 31);
+  hipStream_t st = nullptr;
+  const hipError_t e = hipExtStreamCreateWithCUMask(&st, (uint32_t)((cus + 31) / 32), mask);
+  if (e != hipSuccess) {
+    lfi_set_error("hipExtStreamCreateWithCUMask: %s", hipGetErrorString(e));
+    return LFI_ERR_LAUNCH;
+  }
+  *stream = (void*)st;
+  return LFI_OK;
+}
+extern "C" int lfi_stream_destroy(void* stream) {
+  if (!stream) return LFI_OK;
+  const hipError_t e = hipStreamDestroy((hipStream_t)stream);
+  if (e != hipSuccess) {
+    lfi_set_error("hipStreamDestroy: %s", hipGetErrorString(e));
+    return LFI_ERR_LAUNCH;
+  }
+  return LFI_OK;
+}
+
 // ------------------------------------------------------------------ MFMA lane-map self-test
 // A(i,k) = 1 + i + 100 k ; B(k,j) = (k == kk) * (1 + 1000 j) summed over k gives D(i,j) = sum_k A(i,k) B(k,j):
 // with small integers every product is exact, and an asymmetric B exposes a transposed accumulator map.

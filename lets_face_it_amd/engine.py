@@ -13,10 +13,12 @@ module only sequences the C-ABI calls of include/lfi.h:
 What the reference does instead: SeqGlow.forward's Python loop over timesteps and flow steps
 (/root/reference/code/glow_pytorch/glow/models.py:534-561), ~5.4k ATen calls per timestep.
 """
+import atexit
 import ctypes as C
 import math
 import contextlib
 import os
+import weakref
 
 import torch
 
@@ -211,6 +213,8 @@ class GlowEngine:
         self.unfold = torch.tensor(spec.unfold, **i32)
         self.wct_f = torch.zeros(spec.Ks * spec.D, spec.ldf, **f32)  # folded cond_transform weights, rebuilt by run_prep
         self._side_stream = None
+        self._partial_streams = {}
+        self._sample_stream = None
         self._ws = {}
         self._sample_graphs = {}
         self._sample_seen = {}
@@ -408,6 +412,27 @@ class GlowEngine:
             self._side_stream = torch.cuda.Stream(device=self.device)
         self._side_stream.wait_stream(torch.cuda.current_stream(self.device))
         return self._side_stream
+
+    def close(self):
+        """Destroys the partial-chip streams this engine created (after their work has finished)."""
+        streams, self._partial_streams = self._partial_streams, {}
+        for st in streams.values():
+            st.synchronize()
+            self.L.lfi_stream_destroy(C.c_void_p(st.cuda_stream))
+
+    def _fork_partial(self, cus_per_xcd):
+        """A second stream that owns `cus_per_xcd` CUs of every XCD (lfi_stream_create_partial), ordered after the current stream
+        like _fork()'s; the caller joins it through events (sample())."""
+        st = self._partial_streams.get(cus_per_xcd)
+        if st is None:
+            ptr = C.c_void_p()
+            check(self.L.lfi_stream_create_partial(int(cus_per_xcd), C.byref(ptr)), "lfi_stream_create_partial")
+            st = self._partial_streams[cus_per_xcd] = torch.cuda.ExternalStream(ptr.value, device=self.device)
+            if len(self._partial_streams) == 1:
+                ref = weakref.ref(self)
+                atexit.register(lambda: ref() is not None and ref().close())
+        st.wait_stream(torch.cuda.current_stream(self.device))
+        return st
 
     @staticmethod
     def _on(side):
@@ -1258,6 +1283,23 @@ class GlowEngine:
     # ------------------------------------------------------------------ sampling / inversion
     @translate_oom
     def sample(self, seq_len, data, noise, masks=None):
+        """SeqGlow.inference (models.py:567-596); see _sample. With the static part on a partial-chip stream (LFI_SAMPLE_STATIC_CUS)
+        the whole call runs on a private non-blocking stream between two joins with the caller's: hipExtStreamCreateWithCUMask makes a
+        BLOCKING stream, which takes turns with the legacy default stream - and that is the stream most callers are on."""
+        if self._sample_static_cus(seq_len - self.spec.start) <= 0:
+            return self._sample(seq_len, data, noise, masks)
+        caller = torch.cuda.current_stream(self.device)
+        if self._sample_stream is None:
+            self._sample_stream = torch.cuda.Stream(device=self.device)
+        own = self._sample_stream
+        own.wait_stream(caller)
+        with torch.cuda.stream(own):
+            out = self._sample(seq_len, data, noise, masks)
+        caller.wait_stream(own)
+        out.record_stream(caller)
+        return out
+
+    def _sample(self, seq_len, data, noise, masks=None):
         """SeqGlow.inference (models.py:567-596) with the prior noise given: (seq_len - start, B, C), already * eps.
 
         The generated frames are produced in a few RUNS (LFI_SAMPLE_RUNS, default 4 from 64 frames up): everything of a run that
@@ -1328,7 +1370,8 @@ class GlowEngine:
         self._toc("sample_static", ev_static)
         events = [None]
         if len(runs) > 1:
-            side = self._fork()
+            part = self._sample_static_cus(nframes)
+            side = self._fork_partial(part) if part > 0 else self._fork()
             if side is None:
                 for o, n in runs[1:]:
                     static(o, n)
@@ -1401,10 +1444,31 @@ class GlowEngine:
         return out
 
     # ---- helpers of sample()
+    def _sample_static_cus(self, nframes):
+        """CUs of every XCD that the static part of runs 2.. gets beside the chain (0: an ordinary second stream, where the two
+        only take turns). LFI_SAMPLE_STATIC_CUS overrides; by default HALF of each XCD on the 256-CU card, where the chain's 256
+        one-per-CU workgroups then go in exactly two rounds (14 or 18 of 32 measured 7 / 2 ms worse per call)."""
+        if os.environ.get("LFI_NO_OVERLAP") == "1" or nframes <= 0 or len(self._sample_runs(nframes)) < 2:
+            return 0
+        want = os.environ.get("LFI_SAMPLE_STATIC_CUS")
+        if want is not None:
+            return max(int(want), 0)
+        return 16 if torch.cuda.get_device_properties(self.device).multi_processor_count == 256 else 0
+
     @staticmethod
     def _sample_runs(nframes):
         """[(first frame, frames)] of the runs a sampling call is cut into (see sample())."""
         want = os.environ.get("LFI_SAMPLE_RUNS")
+        if want and "," in want:  # an explicit list of run lengths; a last run takes what is left
+            runs, o = [], 0
+            for n in (int(v) for v in want.split(",")):
+                n = min(n, nframes - o)
+                if n > 0:
+                    runs.append((o, n))
+                    o += n
+            if o < nframes:
+                runs.append((o, nframes - o))
+            return runs
         nruns = int(want) if want else (4 if nframes >= 64 else 1)
         nruns = max(1, min(nruns, nframes))
         base, extra, runs, o = nframes // nruns, nframes % nruns, [], 0

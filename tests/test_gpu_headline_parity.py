@@ -171,6 +171,50 @@ def test_sampler_fused_conditioning_matches_two_gemms(gpu_device, monkeypatch):
     assert torch.equal(a, e), ("fragments left by the chain differ from the fragment kernel's, per frame:", (a - e).abs().amax(dim=(0, 2)).tolist())
 
 
+def test_sampler_static_part_beside_the_chain(gpu_device, monkeypatch):
+    """The sampler cuts a call into runs of frames and computes run i + 1's static part (window encoders, static cond_transform
+    columns) while run i's chain executes - on a stream that owns some CUs of every XCD (lfi_stream_create_partial), the call itself
+    on a private non-blocking stream between two joins with the caller's. Three short runs forced on a ragged batch at final
+    widths: the same bits as one run in line, as an ordinary second stream, and as another share of the chip; eager and replayed;
+    called from the default stream and from a side stream."""
+    hp = final_model_hparams(50, 27, K=16)
+    m, _ = perturbed_model(hp, gpu_device)
+    m.eval()
+    m.precision = "bf16x3"
+    B, seq_len = 70, 24 + 11
+    g = torch.Generator().manual_seed(23)
+    data = {"p1_face": torch.randn(B, 24, 50, generator=g)}
+    for name, d in (("p2_face", 50), ("p1_speech", 27), ("p2_speech", 27)):
+        data[name] = torch.randn(B, seq_len, d, generator=g)
+    noise = (torch.randn(seq_len - 24, B, 50, generator=g) * 0.8).to(gpu_device)
+    dd = to_dev(data, gpu_device)
+    monkeypatch.setenv("LFI_SAMPLE_RUNS", "1")
+    ref = m.inference(seq_len, dd, noise=noise).clone()
+    assert torch.isfinite(ref).all()
+    eng = m._ensure_engine(gpu_device)
+    for runs, cus in (("3", None), ("3", "0"), ("4,3", "8"), ("3", "16")):
+        monkeypatch.setenv("LFI_SAMPLE_RUNS", runs)
+        if cus is None:
+            monkeypatch.delenv("LFI_SAMPLE_STATIC_CUS", raising=False)
+        else:
+            monkeypatch.setenv("LFI_SAMPLE_STATIC_CUS", cus)
+        assert eng._sample_static_cus(seq_len - 24) == (16 if cus is None else int(cus))
+        for _ in range(3):   # eager, captured, replayed
+            assert torch.equal(m.inference(seq_len, dd, noise=noise), ref), (runs, cus)
+    side = torch.cuda.Stream(device=gpu_device)
+    side.wait_stream(torch.cuda.current_stream(gpu_device))
+    with torch.cuda.stream(side):
+        out = m.inference(seq_len, dd, noise=noise)
+    torch.cuda.current_stream(gpu_device).wait_stream(side)
+    assert torch.equal(out, ref)
+    monkeypatch.setenv("LFI_NO_OVERLAP", "1")
+    assert eng._sample_static_cus(seq_len - 24) == 0
+    assert torch.equal(m.inference(seq_len, dd, noise=noise), ref)
+    assert set(eng._partial_streams) == {8, 16}
+    eng.close()
+    assert not eng._partial_streams
+
+
 def test_sampler_leaves_fp16_pieces_for_out_of_range_inputs(gpu_device):
     """The sampler's default per-frame arithmetic splits operands into fp16 pieces (fp32-grade inside fp16's range). Inputs
     beyond 1e3 must send it to the six-product bf16 form instead (no range caveat): same frames as the all-f32-MFMA mode to

@@ -700,6 +700,52 @@ def test_colsum(eng, gpu_device):
     assert rel_err(out, ref) < 2e-6
 
 
+def test_partial_chip_stream(eng, gpu_device):
+    """lfi_stream_create_partial: a stream that owns n CUs of every XCD. Argument errors; a product launched on it gives the bits it
+    gives on the current stream; and it is confined - 896 one-CU-wide workgroups of the window encoder take longer on 4 CUs per
+    XCD than on all 32 (the probe that decoded the mask's bit order: tools/probes/cu_mask_map_probe.hip)."""
+    from lets_face_it_amd import _lib
+    from lets_face_it_amd._lib import EncDesc, check
+    L = _lib.lib()
+    st = C.c_void_p()
+    for bad in (0, -1, 33):
+        assert L.lfi_stream_create_partial(bad, C.byref(st)) == -1 and b"CUs per XCD" in L.lfi_last_error()
+    assert L.lfi_stream_create_partial(4, None) == -1
+    check(L.lfi_stream_create_partial(4, C.byref(st)), "lfi_stream_create_partial")
+    assert st.value
+    ext = torch.cuda.ExternalStream(st.value, device=gpu_device)
+    g = torch.Generator().manual_seed(5)
+    rnd = lambda *s: (torch.randn(*s, generator=g) * 0.3).to(gpu_device)   # noqa: E731
+    hist, hid, B, T, start = 24, 256, 1024, 80, 24
+    N = T - start
+    F = N * B
+    xp, whh, b_ih, b_hh = rnd(B * T, 3 * hid), rnd(3 * hid, hid) * 0.2, rnd(3 * hid), rnd(3 * hid)
+    hseq = torch.zeros(hist * F * hid, device=gpu_device)
+    d = EncDesc(B, T, N, start, hist, hid, 512, 0, 1, 0, 0, 1, 0)
+    work = torch.zeros(max(int(L.lfi_encode_windows_work_floats(C.byref(d))), 1), device=gpu_device)
+    outs, ms = [], []
+    torch.cuda.synchronize()
+    for stream in (torch.cuda.current_stream(gpu_device), ext):
+        cond = torch.zeros(F, 512, device=gpu_device)
+        torch.cuda.synchronize()
+        with torch.cuda.stream(stream):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            for i in range(3):
+                if i == 1:
+                    e0.record(stream)
+                check(L.lfi_encode_windows_fwd(C.byref(d), xp.data_ptr(), whh.data_ptr(), b_ih.data_ptr(), b_hh.data_ptr(), None,
+                                               cond.data_ptr(), None, hseq.data_ptr(), work.data_ptr(), stream.cuda_stream), "fwd")
+            e1.record(stream)
+        stream.synchronize()
+        outs.append(cond)
+        ms.append(e0.elapsed_time(e1) / 2)
+    assert torch.equal(outs[0], outs[1])
+    report("window encoder forward, 896 workgroups: %.2f ms on the whole chip, %.2f ms on a stream with 4 CUs of every XCD" % tuple(ms))
+    assert ms[1] > 3.0 * ms[0], ms
+    check(L.lfi_stream_destroy(st), "lfi_stream_destroy")
+    check(L.lfi_stream_destroy(None), "lfi_stream_destroy(NULL)")
+
+
 def test_adam_clip_step_matches_oracle(gpu_device):
     from argparse import Namespace
     from helpers import Fixture

@@ -591,6 +591,14 @@ def test_config3_sampling_full_size(gpu_device, monkeypatch):
     assert torch.equal(sub_p, out_p[:48])
     monkeypatch.delenv("LFI_ENC_R64")
     monkeypatch.delenv("LFI_ENC_M16")
+    # round 5: the static part of runs 2.. executes on a stream that owns half of every XCD BESIDE the chain (the default on this card);
+    # on an ordinary second stream (LFI_SAMPLE_STATIC_CUS=0) or with another share of the chip the same kernels give the same bits
+    eng = m._ensure_engine(gpu_device)
+    assert eng._sample_static_cus(T - 24) == 16 and len(eng._partial_streams) == 1
+    for cus in ("0", "8"):
+        monkeypatch.setenv("LFI_SAMPLE_STATIC_CUS", cus)
+        assert torch.equal(m.inference(T, data, noise=noise), out1), "static part on %s CUs per XCD" % cus
+    monkeypatch.delenv("LFI_SAMPLE_STATIC_CUS")
     full = dict(data)
     full["p1_face"] = torch.cat([data["p1_face"][:, :24], out1], dim=1).contiguous()
     with torch.no_grad():

@@ -282,3 +282,21 @@ def test_window_encoder_forward_variant_selection(monkeypatch):
     assert L.lfi_encode_windows_fwd_variant(C.byref(big), 0, 0) == 2
     f32 = EncDesc(256, 80, 56, 24, 24, 256, 896, 256, 0, 0, 0, 0, 0)       # exact-product mode: the accumulator-layout fused kernel
     assert L.lfi_encode_windows_fwd_variant(C.byref(f32), 0, 0) == 1
+
+
+def test_sampling_run_lengths(monkeypatch):
+    """engine._sample_runs: how a sampling call's generated frames are cut into runs (the static part of run i + 1 is computed
+    beside run i's chain): four equal runs from 64 frames up, LFI_SAMPLE_RUNS = a count or an explicit list of lengths."""
+    from lets_face_it_amd.engine import GlowEngine
+    monkeypatch.delenv("LFI_SAMPLE_RUNS", raising=False)
+    assert GlowEngine._sample_runs(276) == [(0, 69), (69, 69), (138, 69), (207, 69)]
+    assert GlowEngine._sample_runs(63) == [(0, 63)]
+    assert GlowEngine._sample_runs(66) == [(0, 17), (17, 17), (34, 16), (50, 16)]
+    monkeypatch.setenv("LFI_SAMPLE_RUNS", "3")
+    assert GlowEngine._sample_runs(10) == [(0, 4), (4, 3), (7, 3)]
+    assert GlowEngine._sample_runs(2) == [(0, 1), (1, 1)]
+    monkeypatch.setenv("LFI_SAMPLE_RUNS", "80,70,66")
+    assert GlowEngine._sample_runs(276) == [(0, 80), (80, 70), (150, 66), (216, 60)]
+    assert GlowEngine._sample_runs(100) == [(0, 80), (80, 20)]
+    for runs in (GlowEngine._sample_runs(276), GlowEngine._sample_runs(100)):
+        assert sum(n for _, n in runs) in (276, 100) and all(runs[i][0] + runs[i][1] == runs[i + 1][0] for i in range(len(runs) - 1))
