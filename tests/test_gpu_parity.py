@@ -7,6 +7,7 @@ same noise (`infer/out_ref_fp32`): its distance from fp64 (8e-7 ... 2.4e-6 on th
 Measured errors go through helpers.report(): with LFI_PARITY_REPORT=<file> they are appended to that file
 (profiles/parity_report_r02.txt is the final GPU run's).
 """
+import os
 from argparse import Namespace
 
 import pytest
@@ -576,6 +577,15 @@ def test_config3_sampling_full_size(gpu_device, monkeypatch):
     out3 = m.inference(T, data, noise=noise)   # replayed
     assert out1.shape == (B, T - 24, 50) and torch.isfinite(out1).all()
     assert torch.equal(out1, out2) and torch.equal(out1, out3)
+    # round 5: the static part of runs 2.. executes on a stream that owns half of every XCD BESIDE the chain (the default on this card);
+    # on an ordinary second stream (LFI_SAMPLE_STATIC_CUS=0) or with another share of the chip the same kernels give the same bits
+    eng = m._ensure_engine(gpu_device)
+    if "LFI_SAMPLE_STATIC_CUS" not in os.environ:
+        assert eng._sample_static_cus(T - 24) == 16 and len(eng._partial_streams) == 1
+    for cus in ("0", "8"):
+        monkeypatch.setenv("LFI_SAMPLE_STATIC_CUS", cus)
+        assert torch.equal(m.inference(T, data, noise=noise), out1), "static part on %s CUs per XCD" % cus
+    monkeypatch.undo()
     # a sub-batch reproduces its rows: to what 276 autoregressive frames make of an fp32 rounding difference in the window encoders
     # (the sampler encodes its windows in four frame runs: 48 x 69 = 3 312 windows a run take the 32-window kernels on the 32 x 32 x 16
     # MFMA, the full batch's 70 656 the 64-window ones on 16 x 16 x 32 - the same products, another summation order)
@@ -591,14 +601,6 @@ def test_config3_sampling_full_size(gpu_device, monkeypatch):
     assert torch.equal(sub_p, out_p[:48])
     monkeypatch.delenv("LFI_ENC_R64")
     monkeypatch.delenv("LFI_ENC_M16")
-    # round 5: the static part of runs 2.. executes on a stream that owns half of every XCD BESIDE the chain (the default on this card);
-    # on an ordinary second stream (LFI_SAMPLE_STATIC_CUS=0) or with another share of the chip the same kernels give the same bits
-    eng = m._ensure_engine(gpu_device)
-    assert eng._sample_static_cus(T - 24) == 16 and len(eng._partial_streams) == 1
-    for cus in ("0", "8"):
-        monkeypatch.setenv("LFI_SAMPLE_STATIC_CUS", cus)
-        assert torch.equal(m.inference(T, data, noise=noise), out1), "static part on %s CUs per XCD" % cus
-    monkeypatch.delenv("LFI_SAMPLE_STATIC_CUS")
     full = dict(data)
     full["p1_face"] = torch.cat([data["p1_face"][:, :24], out1], dim=1).contiguous()
     with torch.no_grad():
