@@ -18,6 +18,7 @@ import ctypes as C
 import math
 import contextlib
 import os
+import warnings
 import weakref
 
 import torch
@@ -215,6 +216,7 @@ class GlowEngine:
         self._side_stream = None
         self._partial_streams = {}
         self._sample_stream = None
+        self._partial_refused = False
         self._ws = {}
         self._sample_graphs = {}
         self._sample_seen = {}
@@ -426,7 +428,13 @@ class GlowEngine:
         st = self._partial_streams.get(cus_per_xcd)
         if st is None:
             ptr = C.c_void_p()
-            check(self.L.lfi_stream_create_partial(int(cus_per_xcd), C.byref(ptr)), "lfi_stream_create_partial")
+            if self.L.lfi_stream_create_partial(int(cus_per_xcd), C.byref(ptr)) != 0:
+                # a driver that refuses CU masks: the ordinary second stream does the same work, in turns with the chain
+                if not self._partial_refused:
+                    warnings.warn("lets_face_it_amd: no partial-chip stream (%s); the sampler's static part runs on an ordinary "
+                                  "second stream" % self.L.lfi_last_error().decode(), RuntimeWarning)
+                self._partial_refused = True
+                return self._fork()
             st = self._partial_streams[cus_per_xcd] = torch.cuda.ExternalStream(ptr.value, device=self.device)
             if len(self._partial_streams) == 1:
                 ref = weakref.ref(self)
@@ -1448,7 +1456,7 @@ class GlowEngine:
         """CUs of every XCD that the static part of runs 2.. gets beside the chain (0: an ordinary second stream, where the two
         only take turns). LFI_SAMPLE_STATIC_CUS overrides; by default HALF of each XCD on the 256-CU card, where the chain's 256
         one-per-CU workgroups then go in exactly two rounds (14 or 18 of 32 measured 7 / 2 ms worse per call)."""
-        if os.environ.get("LFI_NO_OVERLAP") == "1" or nframes <= 0 or len(self._sample_runs(nframes)) < 2:
+        if os.environ.get("LFI_NO_OVERLAP") == "1" or nframes <= 0 or len(self._sample_runs(nframes)) < 2 or self._partial_refused:
             return 0
         want = os.environ.get("LFI_SAMPLE_STATIC_CUS")
         if want is not None:

@@ -213,6 +213,15 @@ def test_sampler_static_part_beside_the_chain(gpu_device, monkeypatch):
     assert set(eng._partial_streams) == {8, 16}
     eng.close()
     assert not eng._partial_streams
+    # a driver that refuses the CU mask: a warning, the ordinary second stream from then on, the same frames
+    monkeypatch.delenv("LFI_NO_OVERLAP")
+    monkeypatch.setenv("LFI_SAMPLE_STATIC_CUS", "16")
+    monkeypatch.setattr(eng.L, "lfi_stream_create_partial", lambda *a: -1)
+    with pytest.warns(RuntimeWarning, match="partial-chip stream"):
+        out = m.inference(seq_len, dd, noise=noise)
+    assert torch.equal(out, ref) and eng._partial_refused and eng._sample_static_cus(seq_len - 24) == 0 and not eng._partial_streams
+    assert torch.equal(m.inference(seq_len, dd, noise=noise), ref)
+    eng._partial_refused = False
 
 
 def test_sampler_leaves_fp16_pieces_for_out_of_range_inputs(gpu_device):
