@@ -50,6 +50,10 @@ struct FlowK {
   // backward recurrent weights pre-split into bf16 hi / lo 32-k fragments (bf16 x 3 walk): [Ks][NG][H16/32][J][4 lane groups],
   // one uint4 per entry and plane; the lo plane follows the hi plane of an image
   const uint4 *xbwh, *xbwz;
+  // reverse (sampling) cell weights pre-split into fp16 hi / lo 32-k fragments (flow_prep_x3h_kernel): images of pwz, pwh, pwfl and
+  // pWinv, entry (32-k block b, lane group kq, column) = x3h_pack of the two f32x4 entries the cell used to load and split itself;
+  // one uint4 per entry and plane, the lo plane follows the hi plane of a flow step's image. Null unless lfi_flow_prep made them.
+  const uint4 *hwz, *hwh, *hwfl, *hWinv;
   int dgi_hi_only;         // the dgi planes' hi halves only (their consumers take them as a rounded A operand: two products)
   int g16;                 // backward walk (planes mode): the dgi | dgh ROWS of the backward stash are bf16 arrays of the same shapes -
                            // their readers, the thin weight-gradient products, round that operand to bf16 anyway (two products):
@@ -1695,7 +1699,8 @@ __global__ __launch_bounds__(NT) void flow_pipe_fwd_kernel(FlowK f) {
 // drained and published (the hand-off of the persistent walks).
 // need / pub_value: the progress value waited for / published (1 for the one-frame chain; timestep + 1 in the persistent reverse
 // walk). false = the wait was abandoned (abort word set): nothing was computed.
-template <int NG, bool X3 = false>
+// XW (with X3): the weights come as the fp16 fragment images lfi_flow_prep left (FlowK.hwz ..): no f32 fragments, no split here.
+template <int NG, bool X3 = false, bool XW = false>
 __device__ __forceinline__ bool rev_fast_cell(const FlowK& f, const CellIO& io, int b0, const unsigned* wait_flag,
                                               unsigned* abort_w, unsigned* pub_flag, int* s_ok, unsigned need = 1u,
                                               unsigned pub_value = 1u) {
@@ -1723,8 +1728,44 @@ __device__ __forceinline__ bool rev_fast_cell(const FlowK& f, const CellIO& io, 
       f.stamps[io.stamp_base - 1 + (slot)] = __builtin_amdgcn_s_memtime();                                               \
   } while (0)
   REV_STAMP(0);
-  f32x4 wz[NG][FB_Z], wh[NG][FB_H], w3[FB_H];
-  {
+  static_assert(!XW || X3, "pre-split weight images are the X3 cell's");
+  f32x4 wz[XW ? 1 : NG][XW ? 1 : FB_Z], wh[XW ? 1 : NG][XW ? 1 : FB_H], w3[XW ? 1 : FB_H];
+  X3FragH wzx[X3 ? NG : 1][FB_Z / 2];            // three fp16 products (fp32-grade, x3h_*): the z1-side fragments
+  X3FragH whx[XW ? NG : 1][XW ? FB_H / 2 : 1];   // XW: the h-side fragments too (otherwise split where they are used)
+  X3FragH w3x[X3 ? FB_H / 2 : 1], w1x[X3 ? FB_C / 2 : 1];
+  // this lane's entries of a pre-split image of flow step k: nb2 32-k blocks of the 16-column tile at `col` (row pitch J entries)
+  auto load_x3h = [&](X3FragH* w, int maxb2, const uint4* img, int K16, int J, int col, int nb2, bool on) {
+    const long per = (long)(K16 >> 5) * 4 * J;
+    const uint4* p = img + (long)k * 2 * per + (long)kq * J + col;
+#pragma unroll
+    for (int b = 0; b < maxb2; ++b)
+      if (on && b < nb2) {
+        w[b].hi = __builtin_bit_cast(fh16x8, p[(long)b * 4 * J]);
+        w[b].lo = __builtin_bit_cast(fh16x8, p[(long)b * 4 * J + per]);
+      } else {
+        w[b].hi = (fh16x8)(_Float16)0.0f;
+        w[b].lo = (fh16x8)(_Float16)0.0f;
+      }
+  };
+  float hv[XW ? FB_H / 2 : 1];   // XW: this thread's elements of h_prev (row ri, columns cl + 32 q), staged to LDS further down
+  if constexpr (XW) {
+    // Vector-memory results come back in issue order: what the work in front of the wait needs first is issued first - h_prev
+    // (its LDS image gates the barrier), then the h-side fragments of the product that runs before the wait; the fragments of the
+    // phases behind the wait follow and arrive under that product.
+    const int row = b0 + ri;
+#pragma unroll
+    for (int q = 0; q < FB_H / 2; ++q) {
+      const int j = cl + 32 * q;
+      hv[q] = (io.h_prev && row < rows && j < H) ? ld_tile(io.h_prev + (long)row * H + j, io.state_l2 == 0) : 0.0f;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int g = 0; g < NG; ++g) load_x3h(whx[g], FB_H / 2, f.hwh, H16, NG * H16, g * H16 + tcol, nbH >> 1, t2);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int g = 0; g < NG; ++g) load_x3h(wzx[g], FB_Z / 2, f.hwz, Ch16, NG * H16, g * H16 + tcol, nbZ >> 1, t2);
+    load_x3h(w3x, FB_H / 2, f.hwfl, H16, Co16, tcol, nbH >> 1, t3);
+  } else {
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
@@ -1735,8 +1776,8 @@ __device__ __forceinline__ bool rev_fast_cell(const FlowK& f, const CellIO& io, 
       load_frag<FB_Z>(wz[g], f.pwz + (long)k * Ch16 * NG * H16, NG * H16, g * H16 + tcol, kq, nbZ, t2);
       load_frag<FB_H>(wh[g], f.pwh + (long)k * H16 * NG * H16, NG * H16, g * H16 + tcol, kq, nbH, t2);
     }
+    load_frag<FB_H>(w3, f.pwfl + (long)k * H16 * Co16, Co16, tcol, kq, nbH, t3);
   }
-  load_frag<FB_H>(w3, f.pwfl + (long)k * H16 * Co16, Co16, tcol, kq, nbH, t3);
   float gc[4][NG], bh[NG], cprev[4];
   {
     const float* bhh = f.p.b_hh + (long)k * G;
@@ -1754,7 +1795,17 @@ __device__ __forceinline__ bool rev_fast_cell(const FlowK& f, const CellIO& io, 
   // ---- everything that does not depend on the incoming tile runs BEFORE the wait for it (a chain of Ks dependent cells pays
   // whatever follows the wait Ks times per frame; stamps of round 4: staging h_prev, splitting the weight fragments into fp16
   // pieces and the h_prev W_hh half of the recurrent product - 4 of its 5 k-blocks - were 10 k of a cell's 20 k dependent cycles)
-  {
+  if constexpr (XW) {
+#pragma unroll
+    for (int q = 0; q < FB_H / 2; ++q) {
+      const int j = cl + 32 * q;
+      if (j < H16) {
+        Ht[j * LT + ri] = hv[q];
+        if (j >= H) Hn[j * LT + ri] = 0.0f;
+      }
+    }
+    for (int c = Ch + cl; c < Ch16; c += 32) Zt[c * LT + ri] = 0.0f;
+  } else {
     const int row = b0 + ri;
     const bool rok = row < rows;
     for (int j = cl; j < H16; j += 32) {
@@ -1764,8 +1815,9 @@ __device__ __forceinline__ bool rev_fast_cell(const FlowK& f, const CellIO& io, 
     for (int c = Ch + cl; c < Ch16; c += 32) Zt[c * LT + ri] = 0.0f;
   }
   // W^-1 slice of this wave's 16 output channels: in flight under the coupling net
-  f32x4 w1[FB_C];
-  load_frag<FB_C>(w1, f.pWinv + (long)k * C16 * C16, C16, tcol, kq, nbC, t1);
+  f32x4 w1[XW ? 1 : FB_C];
+  if constexpr (XW) load_x3h(w1x, FB_C / 2, f.hWinv, C16, C16, tcol, nbC >> 1, t1);
+  else load_frag<FB_C>(w1, f.pWinv + (long)k * C16 * C16, C16, tcol, kq, nbC, t1);
   // per-column constants of the phases after the wait (LinearZeros bias / scale, ActNorm^-1 scale / bias): loaded here, not between
   // the barriers of the dependent phases (two L2 round trips per cell each)
   const float flb = tcol < Cout ? f.p.b_fl[(long)k * Cout + tcol] : 0.0f;
@@ -1775,8 +1827,7 @@ __device__ __forceinline__ bool rev_fast_cell(const FlowK& f, const CellIO& io, 
   // X3: LinearZeros and W^-1 as three fp16 products too (K = H and K = C: 32 and 16 dependent f32-input MFMAs of 32 cycles
   // otherwise, per cell, after the wait); their weight fragments are split here, before it. Whole pairs of 16-k blocks only.
   // (X3 is only instantiated for shapes with whole pairs everywhere: the launcher checks H16, Ch16 and C16)
-  X3FragH w3x[X3 ? FB_H / 2 : 1], w1x[X3 ? FB_C / 2 : 1];
-  if constexpr (X3) {
+  if constexpr (X3 && !XW) {
 #pragma unroll
     for (int b = 0; b < FB_H / 2; ++b)
       if (b < (nbH >> 1)) w3x[b] = x3h_pack(w3[2 * b], w3[2 * b + 1]);
@@ -1791,10 +1842,17 @@ __device__ __forceinline__ bool rev_fast_cell(const FlowK& f, const CellIO& io, 
     az[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
     ah[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
   }
-  X3FragH wzx[X3 ? NG : 1][FB_Z / 2];   // three fp16 products (fp32-grade, x3h_*): the z1-side fragments, split in registers
   if (t2) {
     const float* hl = Ht + kq * LT + l15;
-    if constexpr (X3) {
+    if constexpr (XW) {
+#pragma unroll
+      for (int b = 0; b < FB_H / 2; ++b)
+        if (b < ((nbH + 1) >> 1)) {
+          const X3FragH a = x3h_a(hl + b * 32 * LT);
+#pragma unroll
+          for (int g = 0; g < NG; ++g) ah[g] = x3h_mma(a, whx[g][b], ah[g]);
+        }
+    } else if constexpr (X3) {
 #pragma unroll
       for (int g = 0; g < NG; ++g)
 #pragma unroll
@@ -1822,6 +1880,19 @@ __device__ __forceinline__ bool rev_fast_cell(const FlowK& f, const CellIO& io, 
           for (int g = 0; g < NG; ++g) ah[g] = mfma16(a3, wh[g][b][3], ah[g]);
         }
     }
+  }
+  if constexpr (XW) {
+    // the fragments of the phases AFTER the wait are plain loads now: pin them in front of it (the compiler sinks a load towards its
+    // use - behind the wait, where a chain of Ks cells pays its L2 round trip Ks times per frame)
+    auto pin = [](X3FragH& w) { asm volatile("" : "+v"(w.hi), "+v"(w.lo)); };
+#pragma unroll
+    for (int g = 0; g < NG; ++g)
+#pragma unroll
+      for (int b = 0; b < FB_Z / 2; ++b) pin(wzx[g][b]);
+#pragma unroll
+    for (int b = 0; b < FB_H / 2; ++b) pin(w3x[b]);
+#pragma unroll
+    for (int b = 0; b < FB_C / 2; ++b) pin(w1x[b]);
   }
   REV_STAMP(1);
   if (wait_flag && !pipe_acquire(wait_flag, need, abort_w, tid, s_ok, false)) return false;
@@ -1972,7 +2043,7 @@ struct RevChain {
   long xf_off;            // first window column of the next frame in a row: (t + 1 - hist1) * C
   int K1, NM1;
 };
-template <int NG, bool X3>
+template <int NG, bool X3, bool XW = false>
 __global__ __launch_bounds__(NT) void flow_rev_chain_kernel(FlowK f, RevChain rc) {
   __shared__ int s_id, s_ok;
   if (threadIdx.x == 0) s_id = (int)atomicAdd(rc.pipe, 1u);
@@ -1993,7 +2064,7 @@ __global__ __launch_bounds__(NT) void flow_rev_chain_kernel(FlowK f, RevChain rc
   if (NG == 4) { io.c_prev = rc.has_prev ? rc.cstate + (long)k * f.B * f.H : nullptr; io.c_out = rc.cstate + (long)k * f.B * f.H; }
   io.gic = rc.gic + (long)k * f.B * f.G;
   io.stamp_base = rc.frame_no < 128 ? 1024 + 16 * rc.frame_no + 1 : 0;
-  rev_fast_cell<NG, X3>(f, io, bt * MB, k + 1 < f.Ks ? prog + (k + 1) * nbt + bt : nullptr, rc.pipe + 1,
+  rev_fast_cell<NG, X3, XW>(f, io, bt * MB, k + 1 < f.Ks ? prog + (k + 1) * nbt + bt : nullptr, rc.pipe + 1,
                     k > 0 ? prog + k * nbt + bt : nullptr, &s_ok);
   if (k == 0 && ld_agent(rc.pipe + 1) != 0u) {   // an abandoned chain must not pass for a frame
     const int row = bt * MB + (int)(threadIdx.x >> 5);
@@ -2897,6 +2968,30 @@ __global__ __launch_bounds__(256) void flow_prep_x3_kernel(FlowK f, uint4* xbwh,
   }
 }
 
+// fp16 hi / lo fragment images of the reverse cell's weights (three fp16 products, x3h_*): image `which` 0: pwz (K = Ch16,
+// J = NG H16), 1: pwh (H16, NG H16), 2: pwfl (H16, Co16), 3: pWinv (C16, C16) of flow step blockIdx.y. Entry (b, kq, col) is
+// x3h_pack of the padded f32 image's entries (2b, kq, col) and (2b + 1, kq, col) - exactly what rev_fast_cell made of them in
+// registers in every workgroup of every generated frame (672 conversions per lane in front of a cell's first product).
+__global__ __launch_bounds__(256) void flow_prep_x3h_kernel(FlowK f, uint4* hwz, uint4* hwh, uint4* hwfl, uint4* hWinv) {
+  const int k = blockIdx.y, which = blockIdx.z;
+  const int K16 = which == 0 ? f.Ch16 : (which == 3 ? f.C16 : f.H16);
+  const int J = which < 2 ? f.NG * f.H16 : (which == 2 ? f.Co16 : f.C16);
+  const float* src = which == 0 ? f.pwz : (which == 1 ? f.pwh : (which == 2 ? f.pwfl : f.pWinv));
+  uint4* dst = which == 0 ? hwz : (which == 1 ? hwh : (which == 2 ? hwfl : hWinv));
+  const long per = (long)(K16 >> 5) * 4 * J;            // uint4 entries per flow step and plane
+  const f32x4* img = reinterpret_cast<const f32x4*>(src + (long)k * K16 * J);
+  uint4* hi = dst + (long)k * 2 * per;
+  uint4* lo = hi + per;
+  for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < per; idx += (long)gridDim.x * 256) {
+    const int col = (int)(idx % J);
+    const long r = idx / J;
+    const int kq = (int)(r & 3), b = (int)(r >> 2);
+    const X3FragH w = x3h_pack(img[((long)(2 * b) * 4 + kq) * J + col], img[((long)(2 * b + 1) * 4 + kq) * J + col]);
+    hi[idx] = __builtin_bit_cast(uint4, w.hi);
+    lo[idx] = __builtin_bit_cast(uint4, w.lo);
+  }
+}
+
 // ActNorm2d.forward as a stand-alone module call (glow/modules.py:45-80): out = (x + bias) exp(logs), or its inverse
 // x exp(-logs) - bias; dlogdet[0] = +-C * sum(logs) (the x C factor of modules.py:62)
 __global__ __launch_bounds__(256) void actnorm_module_kernel(const float* __restrict__ x, long rows, int C, const float* __restrict__ bias,
@@ -3201,7 +3296,8 @@ long prep_padded_floats(const lfi_flow_dims* d) {
   auto r16 = [](int x) { return (long)((x + 15) & ~15); };
   const long C16 = r16(d->C), Ch16 = Ch ? r16(Ch) : 16, H16 = r16(d->H), Co16 = r16(Cout);
   return d->Ks * (3 * C16 * C16 + Ch16 * NG * H16 + H16 * NG * H16 + 2 * H16 * Co16 + NG * H16 * H16 + NG * H16 * Ch16)
-         + d->Ks * (NG * H16 * H16 + NG * H16 * Ch16) + 8;   // + the bf16 hi/lo fragment images of bwh / bwz (same byte counts)
+         + d->Ks * (NG * H16 * H16 + NG * H16 * Ch16) + 8    // + the bf16 hi/lo fragment images of bwh / bwz (same byte counts)
+         + d->Ks * (Ch16 * NG * H16 + H16 * NG * H16 + H16 * Co16 + C16 * C16) + 8;   // + the fp16 hi/lo images of pwz / pwh / pwfl / pWinv
 }
 
 int fill_flow(const lfi_flow_dims* d, const lfi_flow_params* p, const float* prep, FlowK* f, const char* who) {
@@ -3247,6 +3343,11 @@ int fill_flow(const lfi_flow_dims* d, const lfi_flow_params* p, const float* pre
     q = reinterpret_cast<const float*>((reinterpret_cast<uintptr_t>(q) + 15) & ~(uintptr_t)15);
     f->xbwh = reinterpret_cast<const uint4*>(q); q += Ks * f->NG * f->H16 * f->H16;
     f->xbwz = reinterpret_cast<const uint4*>(q); q += Ks * f->NG * f->H16 * f->Ch16;
+    q = reinterpret_cast<const float*>((reinterpret_cast<uintptr_t>(q) + 15) & ~(uintptr_t)15);
+    f->hwz = reinterpret_cast<const uint4*>(q); q += Ks * f->Ch16 * f->NG * f->H16;
+    f->hwh = reinterpret_cast<const uint4*>(q); q += Ks * f->H16 * f->NG * f->H16;
+    f->hwfl = reinterpret_cast<const uint4*>(q); q += Ks * f->H16 * f->Co16;
+    f->hWinv = reinterpret_cast<const uint4*>(q); q += Ks * f->C16 * f->C16;
   }
   return LFI_OK;
 }
@@ -3313,6 +3414,13 @@ bool flow_pipe_enabled() {
 // LFI_PIPE_X3=0: keep the exact f32 MFMA for the recurrent products of the persistent walk in bf16x3 mode too
 bool flow_pipe_x3_enabled() {
   const char* e = getenv("LFI_PIPE_X3");
+  return !(e && e[0] == '0');
+}
+// shapes for which lfi_flow_prep leaves the reverse cell's fp16 fragment images (whole 32-k blocks everywhere: the X3 reverse cell's condition)
+bool flow_x3h_images_ok(const FlowK& f) { return !f.lstm && f.H16 % 32 == 0 && f.Ch16 % 32 == 0 && f.C16 % 32 == 0; }
+// LFI_SAMPLE_WFRAG16=0: the sampler's reverse cells load the f32 images and split them in registers, as before round 5
+bool flow_sample_wfrag16_enabled() {
+  const char* e = getenv("LFI_SAMPLE_WFRAG16");
   return !(e && e[0] == '0');
 }
 // LFI_PIPE_FORCE_ABORT=1 (tests): start the walk with the abort word already set, as if a spin had timed out
@@ -3391,6 +3499,11 @@ extern "C" int lfi_flow_prep(const lfi_flow_dims* d, const lfi_flow_params* p, f
       hipLaunchKernelGGL(flow_prep_x3_kernel, dim3(16, d->Ks, 2), dim3(256), 0, st, f, const_cast<uint4*>(f.xbwh),
                          const_cast<uint4*>(f.xbwz));
       LFI_LAUNCH_CHECK("lfi_flow_prep x3");
+    }
+    if ((with_inverse || p->inv_w) && flow_x3h_images_ok(f)) {   // (whatever the precision of this call: the sampler picks its own)
+      hipLaunchKernelGGL(flow_prep_x3h_kernel, dim3(8, d->Ks, 4), dim3(256), 0, st, f, const_cast<uint4*>(f.hwz),
+                         const_cast<uint4*>(f.hwh), const_cast<uint4*>(f.hwfl), const_cast<uint4*>(f.hWinv));
+      LFI_LAUNCH_CHECK("lfi_flow_prep x3h");
     }
   }
   return LFI_OK;
@@ -3864,10 +3977,13 @@ extern "C" int lfi_flow_sample_seq_from(const lfi_flow_dims* d, const lfi_flow_p
   // LFI_SAMPLE_XF_CHAIN=0 keeps the window-fragment kernel in front of every frame's conditioning
   const char* xce = getenv("LFI_SAMPLE_XF_CHAIN");
   const bool xf_chain = fused && chain && !(xce && xce[0] == '0');
+  // the reverse cells' weights as the fp16 fragment images lfi_flow_prep left (no split in every workgroup of every frame)
+  const bool xw = x3 && chain && flow_x3h_images_ok(f) && flow_sample_wfrag16_enabled();
   if (chain) {
     rc = f.lstm ? set_flow_lds(flow_rev_chain_kernel<4, false>, lds, "lfi_flow_sample_seq")
-                : (x3 ? set_flow_lds(flow_rev_chain_kernel<3, true>, lds, "lfi_flow_sample_seq")
-                      : set_flow_lds(flow_rev_chain_kernel<3, false>, lds, "lfi_flow_sample_seq"));
+                : (xw ? set_flow_lds(flow_rev_chain_kernel<3, true, true>, lds, "lfi_flow_sample_seq")
+                      : (x3 ? set_flow_lds(flow_rev_chain_kernel<3, true>, lds, "lfi_flow_sample_seq")
+                            : set_flow_lds(flow_rev_chain_kernel<3, false>, lds, "lfi_flow_sample_seq")));
     if (rc) return rc;
   }
   for (int n = 0; n < nframes; ++n) {
@@ -3949,6 +4065,7 @@ extern "C" int lfi_flow_sample_seq_from(const lfi_flow_dims* d, const lfi_flow_p
         LFI_REQUIRE(me == hipSuccess, "lfi_flow_sample_seq: hipMemsetAsync: %s", hipGetErrorString(me));
       }
       if (f.lstm) hipLaunchKernelGGL((flow_rev_chain_kernel<4, false>), dim3(Ks * f.nbt), dim3(NT), lds, st, f, rcn);
+      else if (xw) hipLaunchKernelGGL((flow_rev_chain_kernel<3, true, true>), dim3(Ks * f.nbt), dim3(NT), lds, st, f, rcn);
       else if (x3) hipLaunchKernelGGL((flow_rev_chain_kernel<3, true>), dim3(Ks * f.nbt), dim3(NT), lds, st, f, rcn);
       else hipLaunchKernelGGL((flow_rev_chain_kernel<3, false>), dim3(Ks * f.nbt), dim3(NT), lds, st, f, rcn);
       continue;

@@ -169,6 +169,12 @@ def test_sampler_fused_conditioning_matches_two_gemms(gpu_device, monkeypatch):
     monkeypatch.setenv("LFI_SAMPLE_XF_CHAIN", "0")
     e = m.inference(seq_len, dd, noise=noise).clone()
     assert torch.equal(a, e), ("fragments left by the chain differ from the fragment kernel's, per frame:", (a - e).abs().amax(dim=(0, 2)).tolist())
+    # ... and the reverse cells take their weights as the fp16 hi / lo fragment images lfi_flow_prep leaves (flow_prep_x3h_kernel)
+    # instead of splitting the f32 images in registers in every workgroup of every frame (LFI_SAMPLE_WFRAG16=0): the same pieces
+    monkeypatch.delenv("LFI_SAMPLE_XF_CHAIN")
+    monkeypatch.setenv("LFI_SAMPLE_WFRAG16", "0")
+    w = m.inference(seq_len, dd, noise=noise).clone()
+    assert torch.equal(a, w), ("pre-split weight fragments differ from the in-register split, per frame:", (a - w).abs().amax(dim=(0, 2)).tolist())
 
 
 def test_sampler_static_part_beside_the_chain(gpu_device, monkeypatch):

@@ -35,6 +35,6 @@ if has tests; then
   export LFI_PARITY_REPORT=$O/parity.txt
   timeout -k 10 1000 python -m pytest tests -x -q -m gpu --durations=10 > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -4 $O/pytest_gpu.log
   unset LFI_PARITY_REPORT
-  LFI_PGEMM_16=0 LFI_PGEMM_16T=0 LFI_PGEMM_DIRECT=0 LFI_ENC_M16=0 LFI_ENC_T16=0 LFI_ENC_SCATTER16=0 LFI_SAMPLE_FUSED=0 LFI_FLOW_G16=0 LFI_SAMPLE_XF_CHAIN=0 LFI_SAMPLE_STATIC_CUS=0 \
+  LFI_PGEMM_16=0 LFI_PGEMM_16T=0 LFI_PGEMM_DIRECT=0 LFI_ENC_M16=0 LFI_ENC_T16=0 LFI_ENC_SCATTER16=0 LFI_SAMPLE_FUSED=0 LFI_FLOW_G16=0 LFI_SAMPLE_XF_CHAIN=0 LFI_SAMPLE_STATIC_CUS=0 LFI_SAMPLE_WFRAG16=0 \
     timeout -k 10 1000 python -m pytest tests -x -q -m gpu > $O/pytest_gpu_switches_off.log 2>&1; echo "pytest (switches off) rc=$?"; tail -3 $O/pytest_gpu_switches_off.log
 fi
