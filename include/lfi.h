@@ -260,7 +260,10 @@ typedef struct {
  * InvertibleConv1x1.get_weight does (glow/modules.py:147-178). Layout of `prep` (floats), step-major blocks:
  *   W [Ks][C][C], Wt [Ks][C][C], Winv [Ks][C][C] (reverse weight, fp64 inverse cast to fp32),
  *   wz_t [Ks][Ch][G], whh_t [Ks][H][G], wfl_t [Ks][H][Cout], wc [Ks][G][D] (= W_ih[:, Ch:], 16-byte aligned copy),
- *   logdet_const [1] = C * sum(an_logs + inv_logs) */
+ *   logdet_const [1] = C * sum(an_logs + inv_logs)
+ * followed by private images of the same weights in the layouts the cell kernels load (zero-padded f32 fragments; bf16 hi / lo
+ * fragments of the backward recurrent weights; with_inverse: fp16 hi / lo fragments of the reverse cell's weights, which the
+ * sampler's cells load instead of splitting f32 fragments in every workgroup of every generated frame). */
 long lfi_flow_prep_floats(const lfi_flow_dims* d);
 int lfi_flow_prep(const lfi_flow_dims* d, const lfi_flow_params* p, float* prep, int with_inverse, void* stream);
 
