@@ -94,6 +94,18 @@ __global__ __launch_bounds__(256) void sc_xfrag_kernel(const float* __restrict__
 }
 
 #define SC_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0)
+// timing-only removal builds (tools/build_variant.sh; results are garbage): -DSC_NO_W1 / -DSC_NO_W2 re-read the first step's weight
+// fragments in every step of phase 1 / 2 (same instructions, L1 hits instead of the L2 stream)
+#ifdef SC_NO_W1
+#define SC_TIMING_W1(m) 0
+#else
+#define SC_TIMING_W1(m) (m)
+#endif
+#ifdef SC_NO_W2
+#define SC_TIMING_W2(m) 0
+#else
+#define SC_TIMING_W2(m) (m)
+#endif
 
 struct ScArgs {
   const uint4* wf1;      // [Ks][8][NM1][4][2] fragments
@@ -160,7 +172,7 @@ __global__ __launch_bounds__(SC_NT, 1) void sc_cond_kernel(ScArgs a) {
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
 #pragma unroll
-        for (int pl = 0; pl < 2; ++pl) w[t][pl].u = ld(bw1, (m * 4 + t) * 2 + pl);
+        for (int pl = 0; pl < 2; ++pl) w[t][pl].u = ld(bw1, (SC_TIMING_W1(m) * 4 + t) * 2 + pl);
         if (XF) {
 #pragma unroll
           for (int pl = 0; pl < 2; ++pl) x[t][pl].u = ld(bx, (t * NM1 + m) * 2 + pl);
@@ -220,27 +232,31 @@ __global__ __launch_bounds__(SC_NT, 1) void sc_cond_kernel(ScArgs a) {
 #pragma unroll
     for (int t = 0; t < NGT; ++t)
 #pragma unroll
-      for (int pl = 0; pl < 2; ++pl) w[t][pl].u = ld(bw2, (m * NGT + t) * 2 + pl);
+      for (int pl = 0; pl < 2; ++pl) w[t][pl].u = ld(bw2, (SC_TIMING_W2(m) * NGT + t) * 2 + pl);
   };
   load2(0, w2a);
   // ---- c = LeakyReLU(acc1 + pre_static) -> fp16 hi / lo pieces in LDS, row-major [64][D] per plane
   // accumulator (ci, ri) register r = c column 64 wave + 16 ci + 4 g4 + r of sample 16 ri + l15
+  // The frame's rows of pre_static come out of HBM (33 MB per frame, read once): all 16 loads of a lane are issued here in one
+  // batch, from a clamped row so that none sits under a branch - one round trip between the phases where there were four (a
+  // wait for four loads in front of each row tile's pieces), with nothing for the matrix pipe to do meanwhile.
+  f32x4 ps[4][4];
+#pragma unroll
+  for (int ri = 0; ri < 4; ++ri) {
+    const long row = min((long)rt * SC_ROWS + 16 * ri + l15, (long)a.B - 1);   // (rows past B: values never stored)
+#pragma unroll
+    for (int ci = 0; ci < 4; ++ci)
+      ps[ri][ci] = *reinterpret_cast<const f32x4*>(a.pre + row * KD + (long)k * SC_D + 64 * wave + 16 * ci + 4 * g4);
+  }
 #pragma unroll
   for (int ri = 0; ri < 4; ++ri) {
     const int rl = 16 * ri + l15;
-    const long row = (long)rt * SC_ROWS + rl;
-    f32x4 ps[4];
-#pragma unroll
-    for (int ci = 0; ci < 4; ++ci) {
-      ps[ci] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      if (row < a.B) ps[ci] = *reinterpret_cast<const f32x4*>(a.pre + row * KD + (long)k * SC_D + 64 * wave + 16 * ci + 4 * g4);
-    }
 #pragma unroll
     for (int ci = 0; ci < 4; ++ci) {
       h16x4 hi, lo;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        float v = acc1[ci][ri][r] + ps[ci][r];
+        float v = acc1[ci][ri][r] + ps[ri][ci][r];
         v = v > 0.0f ? v : v * a.slope;
         _Float16 h, l;
         sc_split(v, &h, &l);
@@ -295,14 +311,24 @@ __global__ __launch_bounds__(SC_NT, 1) void sc_cond_kernel(ScArgs a) {
     }
   }
   // ---- gic[k][row][16 NGT wave + 16 ni + 4 g4 + r] = acc2 + b_ih
+  // (the biases first, all of them: a load between two groups of stores makes the second group wait for the first to drain)
+  f32x4 bv[NGT];
+#pragma unroll
+  for (int ni = 0; ni < NGT; ++ni) bv[ni] = *reinterpret_cast<const f32x4*>(a.b_ih + (long)k * a.G + NGT * 16 * wave + 16 * ni + 4 * g4);
+#pragma unroll
+  for (int ni = 0; ni < NGT; ++ni)
+#pragma unroll
+    for (int ri = 0; ri < 4; ++ri) {
+      acc2[ni][ri] += bv[ni];
+      asm volatile("" : "+v"(acc2[ni][ri]));   // here, not inside the row predicate of a store (where the compiler sinks it, and with
+    }                                          // it a wait that also drains the stores in front: they count in vmcnt too)
 #pragma unroll
   for (int ni = 0; ni < NGT; ++ni) {
     const int col = NGT * 16 * wave + 16 * ni + 4 * g4;
-    const f32x4 bv = *reinterpret_cast<const f32x4*>(a.b_ih + (long)k * a.G + col);
 #pragma unroll
     for (int ri = 0; ri < 4; ++ri) {
       const long row = (long)rt * SC_ROWS + 16 * ri + l15;
-      if (row < a.B) *reinterpret_cast<f32x4*>(a.gic + ((long)k * a.B + row) * a.G + col) = acc2[ni][ri] + bv;
+      if (row < a.B) *reinterpret_cast<f32x4*>(a.gic + ((long)k * a.B + row) * a.G + col) = acc2[ni][ri];
     }
   }
   // the reverse chain that follows in the stream starts from zeroed ticket / abort / progress words: one workgroup of this launch
