@@ -587,7 +587,7 @@ def test_config3_sampling_full_size(gpu_device, monkeypatch):
         assert torch.equal(m.inference(T, data, noise=noise), out1), "static part on %s CUs per XCD" % cus
     monkeypatch.undo()
     # a sub-batch reproduces its rows: to what 276 autoregressive frames make of an fp32 rounding difference in the window encoders
-    # (the sampler encodes its windows in four frame runs: 48 x 69 = 3 312 windows a run take the 32-window kernels on the 32 x 32 x 16
+    # (the sampler encodes its windows in frame runs of 46 - 69 frames: 48 x 69 = 3 312 windows a run take the 32-window kernels on the 32 x 32 x 16
     # MFMA, the full batch's 70 656 the 64-window ones on 16 x 16 x 32 - the same products, another summation order)
     sub = m.inference(T, {k: v[:48].contiguous() for k, v in data.items()}, noise=noise[:, :48].contiguous())
     sub_err = float((sub - out1[:48]).abs().max() / out1[:48].abs().max().clamp(min=1.0))

@@ -292,6 +292,10 @@ def test_sampling_run_lengths(monkeypatch):
     assert GlowEngine._sample_runs(276) == [(0, 69), (69, 69), (138, 69), (207, 69)]
     assert GlowEngine._sample_runs(63) == [(0, 63)]
     assert GlowEngine._sample_runs(66) == [(0, 17), (17, 17), (34, 16), (50, 16)]
+    # with the static part on its own share of the chip: six runs from 96 frames up
+    assert GlowEngine._sample_runs(276, beside=True) == [(0, 46), (46, 46), (92, 46), (138, 46), (184, 46), (230, 46)]
+    assert GlowEngine._sample_runs(95, beside=True) == GlowEngine._sample_runs(95) and len(GlowEngine._sample_runs(95)) == 4
+    assert GlowEngine._sample_runs(63, beside=True) == [(0, 63)]
     monkeypatch.setenv("LFI_SAMPLE_RUNS", "3")
     assert GlowEngine._sample_runs(10) == [(0, 4), (4, 3), (7, 3)]
     assert GlowEngine._sample_runs(2) == [(0, 1), (1, 1)]
