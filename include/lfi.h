@@ -406,11 +406,19 @@ int lfi_flow_sample_seq_from(const lfi_flow_dims* d, const lfi_flow_params* p, c
 /* ---------------------------------------------------------------- optimiser (configure_optimizers, glow/lets_face_it_glow.py:61-72)
  * Flat-buffer Adam with global-norm gradient clipping (Trainer gradient_clip_val, hparams/final_model.yaml:126):
  * norm: sumsq[0] = sum g^2 (fp64, deterministic). step: coef = min(1, clip/(sqrt(sumsq)+1e-6)) (clip <= 0: 1),
- * g *= coef * gmul; Adam (no weight decay / amsgrad). step_count is 1-based. */
+ * g *= coef * gmul; Adam (weight decay / amsgrad: lfi_adam_clip_step_ex below). step_count is 1-based. */
 int lfi_grad_sumsq(const float* g, long n, double* sumsq, double* work /* 1024 doubles */, void* stream);
 int lfi_adam_clip_step(float* p, const float* g, float* m, float* v, long n, const double* sumsq,
                        float clip, float gmul, float lr, float beta1, float beta2, float eps, int step_count,
                        void* stream);
+
+/* torch.optim.Adam's remaining constructor arguments, which the reference forwards verbatim from the YAML
+ * (glow/lets_face_it_glow.py:61-70: `Adam(params, lr=lr, **Optim["args"]["adam"])`): weight_decay (L2 term `wd * p` added to the
+ * clipped gradient before the moments) and amsgrad (vmax = running maximum of the second moment, used in the denominator; NULL =
+ * off). hyper: NULL, or the device block of a captured step (as lfi_adam_clip_step_dev; lr / step_count are then not read). */
+int lfi_adam_clip_step_ex(float* p, const float* g, float* m, float* v, float* vmax, long n, const double* sumsq, float clip,
+                          float gmul, float lr, float beta1, float beta2, float eps, float weight_decay, int step_count,
+                          const float* hyper, void* stream);
 
 /* The other two optimisers configure_optimizers can build (glow/lets_face_it_glow.py:61-72: `{"adam", "sgd", "rmsprop"}[name](params,
  * lr=hparams.lr, **hparams.Optim["args"][name])`; hparam_tuning_configs/large_hparam_search.py:9-11 draws all three), on the same

@@ -160,6 +160,7 @@ def lib():
         "lfi_stream_destroy": (i, [vp]),
         "lfi_grad_sumsq": (i, [vp, l, vp, vp, vp]),
         "lfi_adam_clip_step": (i, [vp, vp, vp, vp, l, vp, f, f, f, f, f, f, i, vp]),
+        "lfi_adam_clip_step_ex": (i, [vp, vp, vp, vp, vp, l, vp, f, f, f, f, f, f, f, i, vp, vp]),
         "lfi_sgd_clip_step": (i, [vp, vp, vp, l, vp, f, f, f, f, f, f, i, i, vp]),
         "lfi_rmsprop_clip_step": (i, [vp, vp, vp, vp, vp, l, vp, f, f, f, f, f, f, f, vp]),
         "lfi_actnorm_forward": (i, [vp, i, i, vp, vp, i, vp, vp, vp]),
@@ -189,7 +190,7 @@ EXPORTS = [
     "lfi_flow_seq_fwd", "lfi_flow_seq_bwd", "lfi_flow_param_grads_work_floats", "lfi_flow_param_grads",
     "lfi_actnorm_init_stats", "lfi_actnorm_init_apply", "lfi_flow_step", "lfi_flow_seq_rev_ok", "lfi_flow_seq_rev_work_floats",
     "lfi_flow_seq_rev", "lfi_flow_sample_work_floats",
-    "lfi_flow_sample_p1_work_floats", "lfi_flow_sample_seq", "lfi_flow_sample_seq_from", "lfi_absmax_f32", "lfi_stream_create_partial", "lfi_stream_destroy", "lfi_grad_sumsq", "lfi_adam_clip_step",
+    "lfi_flow_sample_p1_work_floats", "lfi_flow_sample_seq", "lfi_flow_sample_seq_from", "lfi_absmax_f32", "lfi_stream_create_partial", "lfi_stream_destroy", "lfi_grad_sumsq", "lfi_adam_clip_step", "lfi_adam_clip_step_ex",
     "lfi_sgd_clip_step", "lfi_rmsprop_clip_step", "lfi_set_step_params", "lfi_dropout_masks_dev", "lfi_adam_clip_step_dev", "lfi_selftest_mfma", "lfi_debug_set_stamps",
     "lfi_gather_sequences", "lfi_jerk_mean", "lfi_actnorm_forward", "lfi_invconv_work_floats", "lfi_invconv_weights",
 ]

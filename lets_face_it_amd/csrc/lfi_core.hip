@@ -254,6 +254,39 @@ __global__ __launch_bounds__(256) void adam_clip_kernel(float* __restrict__ p, c
     p[i] -= step_size * (mi / denom);
   }
 }
+// torch.optim.Adam's two optional terms (single-tensor form, torch/optim/adam.py): weight_decay folds `wd * p` into the clipped
+// gradient BEFORE the moments; amsgrad keeps the running maximum of the second moment and divides by its root instead. Template
+// switches: the plain kernel above stays the instruction stream every earlier parity figure was measured on.
+template <bool WD, bool AMS>
+__global__ __launch_bounds__(256) void adam_ex_clip_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                           float* __restrict__ v, float* __restrict__ vmax, long n,
+                                                           const double* __restrict__ sumsq, float clip, float gmul, float step_size,
+                                                           float beta1, float beta2, float eps, float inv_sqrt_bc2, float weight_decay,
+                                                           const float* __restrict__ hyper) {
+  if (hyper) { step_size = hyper[0]; inv_sqrt_bc2 = hyper[1]; }
+  float coef = gmul;
+  if (clip > 0.0f) {
+    const double total = sqrt(sumsq[0]) * (double)fabsf(gmul);
+    const double c = (double)clip / (total + 1e-6);
+    if (c < 1.0) coef *= (float)c;
+  }
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const float pi = p[i];
+    float gi = g[i] * coef;
+    if (WD) gi = gi + weight_decay * pi;
+    const float mi = beta1 * m[i] + (1.0f - beta1) * gi;
+    const float vi = beta2 * v[i] + (1.0f - beta2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    float vd = vi;
+    if (AMS) {
+      vd = fmaxf(vmax[i], vi);
+      vmax[i] = vd;
+    }
+    const float denom = sqrtf(vd) * inv_sqrt_bc2 + eps;
+    p[i] = pi - step_size * (mi / denom);
+  }
+}
 // clip coefficient shared by every flat-buffer optimiser: torch.nn.utils.clip_grad_norm_ (coef = clip / (norm + 1e-6), applied when < 1)
 __device__ __forceinline__ float clip_coef(const double* __restrict__ sumsq, float clip, float gmul) {
   float coef = gmul;
@@ -365,6 +398,32 @@ extern "C" int lfi_adam_clip_step(float* p, const float* g, float* m, float* v, 
   hipLaunchKernelGGL(adam_clip_kernel, dim3(blocks), dim3(256), 0, st, p, g, m, v, n, sumsq, clip, gmul, step_size, beta1,
                      beta2, eps, inv_sqrt_bc2, (const float*)nullptr);
   LFI_LAUNCH_CHECK("lfi_adam_clip_step");
+  return LFI_OK;
+}
+
+extern "C" int lfi_adam_clip_step_ex(float* p, const float* g, float* m, float* v, float* vmax, long n, const double* sumsq, float clip,
+                                     float gmul, float lr, float beta1, float beta2, float eps, float weight_decay, int step_count,
+                                     const float* hyper, void* stream) {
+  LFI_REQUIRE(p && g && m && v && n >= 0 && (hyper || step_count >= 1), "lfi_adam_clip_step_ex: bad arguments");
+  LFI_REQUIRE(clip <= 0.0f || sumsq, "lfi_adam_clip_step_ex: clipping needs sumsq");
+  LFI_REQUIRE(weight_decay >= 0.0f, "lfi_adam_clip_step_ex: weight_decay < 0 (torch.optim.Adam raises too)");
+  float step_size = 0.0f, inv_sqrt_bc2 = 0.0f;
+  if (!hyper) {
+    const double bc1 = 1.0 - pow((double)beta1, step_count), bc2 = 1.0 - pow((double)beta2, step_count);
+    step_size = (float)((double)lr / bc1);
+    inv_sqrt_bc2 = (float)(1.0 / sqrt(bc2));
+  }
+  const int blocks = (int)min(2048L, (long)lfi_cdiv(n > 0 ? n : 1, 256));
+  const bool wd = weight_decay != 0.0f, ams = vmax != nullptr;
+#define LFI_ADAM_EX(W, A)                                                                                                          \
+  hipLaunchKernelGGL((adam_ex_clip_kernel<W, A>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, p, g, m, v, vmax, n, sumsq, clip, \
+                     gmul, step_size, beta1, beta2, eps, inv_sqrt_bc2, weight_decay, hyper)
+  if (wd && ams) LFI_ADAM_EX(true, true);
+  else if (wd) LFI_ADAM_EX(true, false);
+  else if (ams) LFI_ADAM_EX(false, true);
+  else LFI_ADAM_EX(false, false);
+#undef LFI_ADAM_EX
+  LFI_LAUNCH_CHECK("lfi_adam_clip_step_ex");
   return LFI_OK;
 }
 

@@ -3678,7 +3678,17 @@ extern "C" long lfi_flow_param_grads_work_floats(const lfi_flow_dims* d) {
   long gemm_ws = (long)f.Ks * splitk * ((long)f.G * f.I > (long)f.C * f.C ? (long)f.G * f.I : (long)f.C * f.C);
   long cs = lfi_colsum_work_floats(f.F > f.N * f.nbt ? f.F : f.N * f.nbt, f.G > 2 * f.C ? f.G : 2 * f.C, f.Ks);
   // + a second split-K workspace for the products that run on bias_stream
-  return (long)f.Ks * f.C * f.C + gemm_ws + cs + 16 + gemm_ws + 16;
+  // + the per-workgroup partials of the one-pass form of the thin products (lfi_wgrad.hip)
+  long fused = 0;
+  if (lfi_internal_flow_wgrad_ok(f.B, f.N, f.C, f.Ch, f.Cout, f.H, f.G, f.ldc, f.ldo))
+    fused = lfi_internal_flow_wgrad_work_floats(f.B, f.N, f.Ks) + 16;
+  return (long)f.Ks * f.C * f.C + gemm_ws + cs + 16 + gemm_ws + 16 + fused;
+}
+
+// LFI_FLOW_WGRAD_FUSED=0: the thin weight-gradient products as four batched split-K launches + a column-sum pass (rounds 2 - 5)
+bool flow_wgrad_fused_enabled() {
+  const char* e = getenv("LFI_FLOW_WGRAD_FUSED");
+  return !(e && e[0] == '0');
 }
 
 extern "C" int lfi_flow_param_grads(const lfi_flow_dims* d, const lfi_flow_params* p, const float* prep, const float* stash,
@@ -3729,6 +3739,26 @@ extern "C" int lfi_flow_param_grads(const lfi_flow_dims* d, const lfi_flow_param
     q.C = g->w_ih + Ch; q.ldc = I; q.strideC = (long)G * I;
     if ((rc = lfi_gemm_f32(&q, stream))) return rc;
   }
+  // Round 6: ONE pass over the backward stash for all of the thin products below, b_fl's column sums included (lfi_wgrad.hip) -
+  // when the walk left dgi | dgh as bf16 rows (two-product mode) and the shapes are the register-resident cell's. On bias_stream,
+  // beside the caller's MFMA-bound dgi^T c and dpre products (LFI_FLOW_WGRAD_STREAM=main: in line).
+  const bool fused = g16 && !f.lstm && flow_wgrad_fused_enabled() &&
+                     lfi_internal_flow_wgrad_ok(B, f.N, C, Ch, Cout, H, G, f.ldc, f.ldo) != 0;
+  if (fused) {
+    float* part = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(gws2 + gws_floats) + 63) & ~(uintptr_t)63);
+    const char* ws = getenv("LFI_FLOW_WGRAD_STREAM");
+    void* fs = (ws && ws[0] == 'm') ? stream : bs;
+    if ((rc = lfi_internal_flow_wgrad(B, f.N, Ks, C, Ch, Cout, I, f.ldc, f.ldo, f.bDgh, f.bDgi, f.sH, f.bDlin, f.sY, f.sA, f.bDy, part,
+                                      g->w_hh, g->w_ih, g->w_fl, g->b_fl, dW, accumulate, fs)))
+      return rc;
+    if (fs != bs) {   // the LU-gradient kernel below reads dW on bias_stream
+      hipEvent_t ev;
+      if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { lfi_set_error("lfi_flow_param_grads: hipEventCreate failed"); return LFI_ERR_LAUNCH; }
+      (void)hipEventRecord(ev, (hipStream_t)fs);
+      (void)hipStreamWaitEvent((hipStream_t)bs, ev, 0);
+      (void)hipEventDestroy(ev);
+    }
+  } else {
   // The other products are thin (K = F frames, a few output tiles per step), HBM-bound at 3 - 4 TB/s. (Moving them to
   // bias_stream as well, next to the caller's MFMA-bound products, was measured no better than leaving them here: same-box
   // A/B 0.18 ms per step gained with them there, 0.21 ms without; round 4, any one or two of them: 6.86 - 6.91 ms per step
@@ -3762,6 +3792,7 @@ extern "C" int lfi_flow_param_grads(const lfi_flow_dims* d, const lfi_flow_param
   q.M = C; q.N = C; q.splitk = fill_split(C, C, F); q.A = f.sA; q.lda = f.ldc; q.strideA = (long)F * f.ldc; q.B = f.bDy; q.ldb = f.ldc; q.strideB = (long)F * f.ldc;
   q.C = dW; q.ldc = C; q.strideC = (long)C * C;
   if ((rc = lfi_gemm_f32(&q, bs))) return rc;
+  }
   // constant log-det terms: nll has -(C sum(logs))/ln2 per frame -> d/dlogs = -C/ln2 * gscale * F
   const float cconst = -(float)((double)gscale * (double)F * (double)C / 0.6931471805599453);
   {
@@ -3774,7 +3805,7 @@ extern "C" int lfi_flow_param_grads(const lfi_flow_dims* d, const lfi_flow_param
   }
   // biases and the per-tile partial sums: column sums over the backward stash only (HBM streams), independent of the
   // products above - on bias_stream when the caller has forked one after the backward walk
-  if ((rc = lfi_colsum_f32(f.bDlin, f.ldo, (long)F * f.ldo, F, Cout, Ks, g->b_fl, Cout, 1.0f, accumulate, cws, bs))) return rc;
+  if (!fused && (rc = lfi_colsum_f32(f.bDlin, f.ldo, (long)F * f.ldo, F, Cout, Ks, g->b_fl, Cout, 1.0f, accumulate, cws, bs))) return rc;
   if (flow_fast_ok(f.C, f.H, f.Cout) && !flow_force_generic() && flow_pipe_enabled()) {
     // the persistent backward walk left per-workgroup sums of dgi | dgh: [Ks][nbt][2][G]
     if ((rc = lfi_colsum_f32(f.bPbias, 2 * G, (long)f.nbt * 2 * G, f.nbt, G, Ks, g->b_ih, G, 1.0f, accumulate, cws, bs))) return rc;

@@ -1201,16 +1201,28 @@ class GlowEngine:
         return float(np.float32(lr64 / bc1)), float(np.float32(1.0 / math.sqrt(bc2)))
 
     @translate_oom
-    def optimizer_step(self, lr, beta1, beta2, eps, clip=0.0, gmul=1.0, hyper_dev=None):
+    def optimizer_step(self, lr, beta1, beta2, eps, clip=0.0, gmul=1.0, hyper_dev=None, weight_decay=0.0, amsgrad=False):
         """clip_grad_norm_(clip) + Adam on the flat buffers (lets_face_it_glow.py:61-72; final_model.yaml:126).
-        hyper_dev: device pointer to (step_size, 1 / sqrt(1 - beta2^t)) - a captured step; the caller keeps step_count."""
+        hyper_dev: device pointer to (step_size, 1 / sqrt(1 - beta2^t)) - a captured step; the caller keeps step_count.
+        weight_decay / amsgrad: torch.optim.Adam's (the reference forwards Optim["args"]["adam"] verbatim); the running maximum of
+        the second moment lives in `opt_aux`."""
         if self.adam_m is None:
             self.adam_m = torch.zeros_like(self.params)
             self.adam_v = torch.zeros_like(self.params)
+        if amsgrad and self.__dict__.get("opt_aux") is None:
+            self.opt_aux = torch.zeros_like(self.params)
         st = _stream()
         if clip and clip > 0:
             check(self.L.lfi_grad_sumsq(self.grads.data_ptr(), self.n_params, self.sumsq.data_ptr(),
                                         self.sumsq_work.data_ptr(), st), "lfi_grad_sumsq")
+        if weight_decay or amsgrad:
+            if hyper_dev is None:
+                self.step_count += 1
+            check(self.L.lfi_adam_clip_step_ex(self.params.data_ptr(), self.grads.data_ptr(), self.adam_m.data_ptr(),
+                                               self.adam_v.data_ptr(), ptr(self.opt_aux if amsgrad else None), self.n_params,
+                                               self.sumsq.data_ptr(), float(clip or 0.0), gmul, lr, beta1, beta2, eps,
+                                               float(weight_decay), self.step_count, hyper_dev, st), "lfi_adam_clip_step_ex")
+            return
         if hyper_dev is not None:
             check(self.L.lfi_adam_clip_step_dev(self.params.data_ptr(), self.grads.data_ptr(), self.adam_m.data_ptr(),
                                                 self.adam_v.data_ptr(), self.n_params, self.sumsq.data_ptr(),

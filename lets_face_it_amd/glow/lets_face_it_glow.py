@@ -146,7 +146,8 @@ class LetsFaceItGlow(nn.Module):
             st["mean"] = nll.mean().reshape(1)
             eng.backward(sign / nll.numel())
             eng.optimizer_step(0.0, float(a["betas"][0]), float(a["betas"][1]), float(a["eps"]), clip=clip, gmul=1.0,
-                               hyper_dev=st["params"].data_ptr() + 16)
+                               hyper_dev=st["params"].data_ptr() + 16, weight_decay=float(a.get("weight_decay", 0) or 0),
+                               amsgrad=bool(a.get("amsgrad", False)))
         st["dropout"] = masks is not None
         return st
 
@@ -285,11 +286,13 @@ class LetsFaceItGlow(nn.Module):
         if name == "adam":
             betas = a.pop("betas", (0.9, 0.999))
             eps = float(a.pop("eps", 1e-8))
-            if a.pop("weight_decay", 0) or a.pop("amsgrad", False):
-                raise NotImplementedError("fused Adam: weight_decay / amsgrad are not implemented (no shipped hparams file sets them)")
+            wd = float(a.pop("weight_decay", 0) or 0)
+            ams = bool(a.pop("amsgrad", False))
+            if wd < 0:
+                raise ValueError("Invalid weight_decay value: %s" % wd)      # torch.optim.Adam's own check
             if a:
                 raise TypeError("Adam got unexpected arguments %s" % sorted(a))
-            eng.optimizer_step(lr, float(betas[0]), float(betas[1]), eps, clip=clip, gmul=gmul)
+            eng.optimizer_step(lr, float(betas[0]), float(betas[1]), eps, clip=clip, gmul=gmul, weight_decay=wd, amsgrad=ams)
         elif name == "sgd":
             kw = {k: a.pop(k) for k in ("momentum", "dampening", "weight_decay", "nesterov") if k in a}
             if a:

@@ -21,6 +21,10 @@ CASES = [
     ("rmsprop", {"eps": 1e-6, "alpha": 0.9, "momentum": 0.5, "weight_decay": 1e-3}),
     ("rmsprop", {"eps": 1e-8, "centered": True}),
     ("adam", {"betas": [0.9, 0.9999], "eps": 1e-8}),
+    # torch.optim.Adam's remaining arguments, which the reference forwards verbatim from the YAML (lets_face_it_glow.py:61-70)
+    ("adam", {"betas": [0.9, 0.999], "eps": 1e-8, "weight_decay": 1e-2}),
+    ("adam", {"betas": [0.9, 0.99], "eps": 1e-8, "amsgrad": True}),
+    ("adam", {"betas": [0.8, 0.99], "eps": 1e-6, "weight_decay": 1e-3, "amsgrad": True}),
 ]
 
 

@@ -882,3 +882,43 @@ def test_checkpoint_resume_keeps_the_optimiser_state(gpu_device, tmp_path):
     c.double().float()
     c.seq_glow._ensure_engine(gpu_device)
     assert c.seq_glow.engine.step_count == 4 and torch.equal(a.seq_glow.engine.adam_m, c.seq_glow.engine.adam_m)
+
+
+@pytest.mark.parametrize("B,T,K", [(48, 24 + 7, 3), (16, 24 + 1, 2), (32, 24 + 40, 2)])
+def test_one_pass_thin_weight_gradients_match_the_four_products(gpu_device, monkeypatch, B, T, K):
+    """Round 6: the flow's thin weight-gradient products (w_hh, w_ih[:, :Ch], w_fl, b_fl and the invconv's dW: autograd of
+    glow/models.py:204-214, glow/modules.py:93-95,147-177) in ONE pass over the backward stash (lfi_wgrad.hip) against the four
+    batched split-K products + column-sum pass they replace (LFI_FLOW_WGRAD_FUSED=0), final widths, two-product backward (the
+    mode the one-pass form exists for: dgi | dgh arrive as bf16 rows). Same operands, same roundings, another summation order:
+    every flow gradient agrees to fp32 rounding; every other gradient bit for bit (they do not pass through the changed code).
+    Cases: several batch tiles and timestep ranges (3 x 3 x 2 workgroups), a single timestep (w_hh = 0), a longer walk."""
+    hp = final_model_hparams(50, 27, K=K)
+    N = T - 24
+    batch = oracle.synthetic_batch(B, T, 50, 27, seed=77)
+    got = {}
+    for fused in ("0", "1"):
+        monkeypatch.setenv("LFI_FLOW_WGRAD_FUSED", fused)
+        m, _ = perturbed_model(hp, gpu_device)
+        m.precision = "bf16x3"
+        m.eval()
+        eng = m._ensure_engine(gpu_device)
+        eng.backward_products = 2
+        _, loss, _ = m(to_dev(batch, gpu_device))
+        loss.sum().backward()
+        torch.cuda.synchronize()
+        assert bool(eng._last.chain) and eng.backward_product_count(B * N) == 2
+        got[fused] = {n: p.grad.detach().clone() for n, p in m.named_parameters()}
+        del m, eng
+    touched = ("f.rnn.weight_hh", "f.rnn.weight_ih", "f.final_linear.weight", "f.final_linear.bias", "invconv.")
+    worst = ("", 0.0)
+    for name, ref in got["0"].items():
+        g = got["1"][name]
+        if any(t in name for t in touched):
+            e = rel_err(g, ref)
+            if e > worst[1]:
+                worst = (name, e)
+            assert e < 2e-5, (name, e)
+        else:
+            assert torch.equal(g, ref), name
+    report("one-pass thin weight gradients vs the four split-K products (B=%d, N=%d, K=%d): worst tensor rel L2 %.2e (%s)"
+           % (B, N, K, worst[1], worst[0]))
