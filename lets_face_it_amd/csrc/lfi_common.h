@@ -46,13 +46,13 @@ extern "C" __attribute__((visibility("hidden"))) void* lfi_internal_sample_cond_
 // lfi_flow_param_grads (lfi_flow.hip)
 extern "C" __attribute__((visibility("hidden"))) int lfi_internal_flow_wgrad_ok(int B, int N, int C, int Ch, int Cout, int H, int G, int ldc,
                                                                                  int ldo);
-extern "C" __attribute__((visibility("hidden"))) long lfi_internal_flow_wgrad_work_floats(int B, int N, int Ks);
-extern "C" __attribute__((visibility("hidden"))) int lfi_internal_flow_wgrad(int B, int N, int Ks, int C, int Ch, int Cout, int I, int ldc,
-                                                                              int ldo, const void* dgh, const void* dgi, const float* h,
-                                                                              const float* dlin, const float* sY, const float* sA,
-                                                                              const float* dy, float* part, float* w_hh, float* w_ih,
-                                                                              float* w_fl, float* b_fl, float* dW, int accumulate,
-                                                                              void* stream);
+extern "C" __attribute__((visibility("hidden"))) long lfi_internal_flow_wgrad_work_floats(int B, int N, int Ks, int role);
+extern "C" __attribute__((visibility("hidden"))) int lfi_internal_flow_wgrad(int role, int B, int N, int Ks, int C, int Ch, int Cout, int I,
+                                                                              int ldc, int ldo, const void* dgh, const void* dgi,
+                                                                              const float* h, const float* dlin, const float* sY,
+                                                                              const float* sA, const float* dy, float* part, float* w_hh,
+                                                                              float* w_ih, float* w_fl, float* b_fl, float* dW,
+                                                                              int accumulate, void* stream);
 
 // ---- device side -----------------------------------------------------------
 // Operand planes (lfi_planes_from_f32, lfi_pgemm.hip): byte offset inside a 1-KB block (32 rows x 16 columns, bf16, row-major

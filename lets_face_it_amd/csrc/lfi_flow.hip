@@ -3681,7 +3681,7 @@ extern "C" long lfi_flow_param_grads_work_floats(const lfi_flow_dims* d) {
   // + the per-workgroup partials of the one-pass form of the thin products (lfi_wgrad.hip)
   long fused = 0;
   if (lfi_internal_flow_wgrad_ok(f.B, f.N, f.C, f.Ch, f.Cout, f.H, f.G, f.ldc, f.ldo))
-    fused = lfi_internal_flow_wgrad_work_floats(f.B, f.N, f.Ks) + 16;
+    fused = lfi_internal_flow_wgrad_work_floats(f.B, f.N, f.Ks, 0) + lfi_internal_flow_wgrad_work_floats(f.B, f.N, f.Ks, 1) + 32;
   return (long)f.Ks * f.C * f.C + gemm_ws + cs + 16 + gemm_ws + 16 + fused;
 }
 
@@ -3740,24 +3740,30 @@ extern "C" int lfi_flow_param_grads(const lfi_flow_dims* d, const lfi_flow_param
     if ((rc = lfi_gemm_f32(&q, stream))) return rc;
   }
   // Round 6: ONE pass over the backward stash for all of the thin products below, b_fl's column sums included (lfi_wgrad.hip) -
-  // when the walk left dgi | dgh as bf16 rows (two-product mode) and the shapes are the register-resident cell's. On bias_stream,
-  // beside the caller's MFMA-bound dgi^T c and dpre products (LFI_FLOW_WGRAD_STREAM=main: in line).
+  // when the walk left dgi | dgh as bf16 rows (two-product mode) and the shapes are the register-resident cell's. Two roles:
+  // w_hh | w_fl | b_fl in line on `stream` (its workgroups hold a CU each: beside the caller's MFMA-bound dgi^T c product on the
+  // other stream both ran at half speed, profiles/round6_thin_products_ab.md), w_ih[:, :Ch] | dW (two workgroups per CU) on
+  // bias_stream, where dW's reader, the LU-gradient kernel, follows (LFI_FLOW_WGRAD_IH=main: in line as well).
   const bool fused = g16 && !f.lstm && flow_wgrad_fused_enabled() &&
                      lfi_internal_flow_wgrad_ok(B, f.N, C, Ch, Cout, H, G, f.ldc, f.ldo) != 0;
   if (fused) {
-    float* part = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(gws2 + gws_floats) + 63) & ~(uintptr_t)63);
-    const char* ws = getenv("LFI_FLOW_WGRAD_STREAM");
-    void* fs = (ws && ws[0] == 'm') ? stream : bs;
-    if ((rc = lfi_internal_flow_wgrad(B, f.N, Ks, C, Ch, Cout, I, f.ldc, f.ldo, f.bDgh, f.bDgi, f.sH, f.bDlin, f.sY, f.sA, f.bDy, part,
-                                      g->w_hh, g->w_ih, g->w_fl, g->b_fl, dW, accumulate, fs)))
+    float* part0 = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(gws2 + gws_floats) + 63) & ~(uintptr_t)63);
+    float* part1 = reinterpret_cast<float*>((reinterpret_cast<uintptr_t>(part0 + lfi_internal_flow_wgrad_work_floats(B, f.N, Ks, 0)) + 63) & ~(uintptr_t)63);
+    const char* ws = getenv("LFI_FLOW_WGRAD_IH");
+    void* s1 = (ws && ws[0] == 'm') ? stream : bs;   // default: side (same-box A/B 6.44 against 6.48 ms per step in line)
+    if ((rc = lfi_internal_flow_wgrad(1, B, f.N, Ks, C, Ch, Cout, I, f.ldc, f.ldo, f.bDgh, f.bDgi, f.sH, f.bDlin, f.sY, f.sA, f.bDy, part1,
+                                      g->w_hh, g->w_ih, g->w_fl, g->b_fl, dW, accumulate, s1)))
       return rc;
-    if (fs != bs) {   // the LU-gradient kernel below reads dW on bias_stream
+    if (s1 != bs) {   // the LU-gradient kernel below reads dW on bias_stream
       hipEvent_t ev;
       if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) { lfi_set_error("lfi_flow_param_grads: hipEventCreate failed"); return LFI_ERR_LAUNCH; }
-      (void)hipEventRecord(ev, (hipStream_t)fs);
+      (void)hipEventRecord(ev, (hipStream_t)s1);
       (void)hipStreamWaitEvent((hipStream_t)bs, ev, 0);
       (void)hipEventDestroy(ev);
     }
+    if ((rc = lfi_internal_flow_wgrad(0, B, f.N, Ks, C, Ch, Cout, I, f.ldc, f.ldo, f.bDgh, f.bDgi, f.sH, f.bDlin, f.sY, f.sA, f.bDy, part0,
+                                      g->w_hh, g->w_ih, g->w_fl, g->b_fl, dW, accumulate, stream)))
+      return rc;
   } else {
   // The other products are thin (K = F frames, a few output tiles per step), HBM-bound at 3 - 4 TB/s. (Moving them to
   // bias_stream as well, next to the caller's MFMA-bound products, was measured no better than leaving them here: same-box

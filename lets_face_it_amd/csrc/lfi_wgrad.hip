@@ -54,15 +54,16 @@ constexpr int LDS0_BF16 = 2 * STAGE0 + 3 * HSLOT;      // 63 488 bytes
 constexpr int S1_GI = 0, S1_SA = WR * PG, S1_DYH = S1_SA + WR * PS, S1_DYL = S1_DYH + WR * PS, S1_ZH = S1_DYL + WR * PS,
               S1_ZL = S1_ZH + WR * PS, STAGE1 = S1_ZL + WR * PS;
 constexpr int LDS1_BF16 = 2 * STAGE1;                  // 57 344 bytes
-// partial layout of one (flow step, batch tile, timestep range), floats: role 0 writes w_hh | w_fl | b_fl, role 1 w_ih | dW
-constexpr int P_HH = 0, P_IZ = WG_ * WH, P_FL = P_IZ + WG_ * 32, P_DW = P_FL + 64 * WH, P_BF = P_DW + 64 * 64, PART = P_BF + 64;
+// partial layouts of one (flow step, batch tile, timestep range), floats. Role 0: w_hh | w_fl | b_fl; role 1: w_ih[:, :Ch] | dW
+constexpr int P0_HH = 0, P0_FL = WG_ * WH, P0_BF = P0_FL + 64 * WH, PART0 = P0_BF + 64;
+constexpr int P1_IZ = 0, P1_DW = WG_ * 32, PART1 = P1_DW + 64 * 64;
 
 struct WgradArgs {
   int B, N, Ks, F, C, Ch, Cout, I, ldc, ldo;
-  int nbt, ns, nchunk;           // batch tiles, timestep ranges per (k, tile), timesteps per range
+  int nbt, ns, nchunk;           // batch tiles, timestep ranges per (k, tile), timesteps per range - of the role launched
   const __bf16 *dgh, *dgi;       // [Ks][F][G] bf16
   const float *h, *dlin, *sY, *sA, *dy;
-  float* part;                   // [Ks][nbt * ns][PART]
+  float* part;                   // [Ks][nbt * ns][PART0 | PART1]
   // reduce
   float *w_hh, *w_ih, *w_fl, *b_fl, *dW;
   int accumulate;
@@ -124,26 +125,38 @@ struct StageRegs {
 };
 
 // The walk of one workgroup over its timesteps: loads two timesteps ahead in registers, LDS stages double-buffered, one barrier
-// per timestep. LOAD(n, regs), STORE(n, buf, regs), MMA(n, buf).
+// per timestep. LOAD(n, regs), STORE(n, buf, regs), MMA(n, buf). The steady loop has no branch between a load and the store that
+// consumes it two phases later (every load is unconditional - slots a thread does not own read an address it does own - so the
+// s_waitcnt before a store counts the younger stage's loads instead of draining them: vmcnt(0) there would halve the bytes in flight).
 #define LFI_WGRAD_WALK(LOAD, STORE, MMA)                     \
   {                                                          \
     StageRegs R0, R1;                                        \
     LOAD(n0, R0);                                            \
-    if (n0 + 1 < n1) LOAD(n0 + 1, R1);                       \
+    LOAD(min(n0 + 1, n1 - 1), R1);                           \
     STORE(n0, 0, R0);                                        \
     __syncthreads();                                         \
-    for (int n = n0; n < n1; n += 2) {                       \
-      if (n + 2 < n1) LOAD(n + 2, R0);                       \
+    int n = n0;                                              \
+    for (; n + 3 < n1; n += 2) {                             \
+      LOAD(n + 2, R0);                                       \
       __builtin_amdgcn_sched_barrier(0);                     \
       MMA(n, 0);                                             \
       __builtin_amdgcn_sched_barrier(0);                     \
+      STORE(n + 1, 1, R1);                                   \
+      __syncthreads();                                       \
+      LOAD(n + 3, R1);                                       \
+      __builtin_amdgcn_sched_barrier(0);                     \
+      MMA(n + 1, 1);                                         \
+      __builtin_amdgcn_sched_barrier(0);                     \
+      STORE(n + 2, 0, R0);                                   \
+      __syncthreads();                                       \
+    }                                                        \
+    for (; n < n1; n += 2) {                                 \
+      if (n + 2 < n1) LOAD(n + 2, R0);                       \
+      MMA(n, 0);                                             \
       if (n + 1 < n1) STORE(n + 1, 1, R1);                   \
       __syncthreads();                                       \
       if (n + 1 < n1) {                                      \
-        if (n + 3 < n1) LOAD(n + 3, R1);                     \
-        __builtin_amdgcn_sched_barrier(0);                   \
         MMA(n + 1, 1);                                       \
-        __builtin_amdgcn_sched_barrier(0);                   \
         if (n + 2 < n1) STORE(n + 2, 0, R0);                 \
         __syncthreads();                                     \
       }                                                      \
@@ -158,7 +171,7 @@ __global__ __launch_bounds__(WNT, 1) void flow_wgrad_hh_kernel(WgradArgs g) {
   const int n0 = sp * g.nchunk, n1 = min(g.N, n0 + g.nchunk);
   const long kF = (long)k * g.F;
   const int b0 = bt * WR;
-  float* __restrict__ P = g.part + ((long)k * (g.nbt * g.ns) + blockIdx.x) * PART;
+  float* __restrict__ P = g.part + ((long)k * (g.nbt * g.ns) + blockIdx.x) * PART0;
   if (n0 >= n1) return;   // (an empty range: wgrad_splits never makes one)
 
   // per-thread load slots, fixed for the whole walk: one pointer per slot at timestep 0 of this batch tile
@@ -166,14 +179,14 @@ __global__ __launch_bounds__(WNT, 1) void flow_wgrad_hh_kernel(WgradArgs g) {
   const int r1 = (tid + WNT) / 48, c1 = (tid + WNT) - r1 * 48;    // dgh chunk tid + 512 (threads 0-255)
   const bool g1ok = tid < WR * 48 - WNT;
   const __bf16* gp0 = g.dgh + (kF + b0 + r0) * WG_ + c0 * 8;
-  const __bf16* gp1 = g.dgh + (kF + b0 + (g1ok ? r1 : 0)) * WG_ + c1 * 8;
+  const __bf16* gp1 = g1ok ? g.dgh + (kF + b0 + r1) * WG_ + c1 * 8 : gp0;
   const int gl0 = S0_GH + r0 * PG + c0 * 8, gl1 = S0_GH + r1 * PG + c1 * 8;
   const int hrow = tid >> 5, hch = tid & 31;                      // h: 16 rows x 32 chunks of four floats
   const float* hp = g.h + (kF + b0 + hrow) * WH + hch * 4;
   const int hl = hrow * PH + hch * 4;
   const int srow = (tid >> 4) & 15, sch = tid & 15;               // dlin: 16 rows x 16 chunk slots, threads 0-255
   const bool sok = tid < 256 && sch < (g.ldo >> 2);
-  const float* sp0 = g.dlin + (kF + b0 + srow) * g.ldo + sch * 4;
+  const float* sp0 = g.dlin + (kF + b0 + srow) * g.ldo + (sch < (g.ldo >> 2) ? sch * 4 : 0);   // (a slot past the row re-reads its first chunk)
   const int sl = srow * PS + sch * 4;
   const long stepG = (long)g.B * WG_, stepH = (long)g.B * WH, stepS = (long)g.B * g.ldo;
   f32x4 bsum = {0.f, 0.f, 0.f, 0.f};     // column sums of dlin
@@ -181,12 +194,10 @@ __global__ __launch_bounds__(WNT, 1) void flow_wgrad_hh_kernel(WgradArgs g) {
   auto hslot = [&](int n) { return wsmem + 2 * STAGE0 + (n % 3) * HSLOT; };
 #define LOAD0(n_, R)                                                                      \
   {                                                                                       \
-    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};                                                \
-    const u32x4 zu = {0u, 0u, 0u, 0u};                                                    \
     R.g0 = *reinterpret_cast<const u32x4*>(gp0 + (n_) * stepG);                           \
-    R.g1 = g1ok ? *reinterpret_cast<const u32x4*>(gp1 + (n_) * stepG) : zu;               \
+    R.g1 = *reinterpret_cast<const u32x4*>(gp1 + (n_) * stepG);                           \
     R.a = *reinterpret_cast<const f32x4*>(hp + (n_) * stepH);                             \
-    R.b = sok ? *reinterpret_cast<const f32x4*>(sp0 + (n_) * stepS) : z4;                 \
+    R.b = *reinterpret_cast<const f32x4*>(sp0 + (n_) * stepS);                            \
   }
 #define STORE0(n_, buf, R)                                                                \
   {                                                                                       \
@@ -196,8 +207,10 @@ __global__ __launch_bounds__(WNT, 1) void flow_wgrad_hh_kernel(WgradArgs g) {
     __bf16* hs = hslot(n_);                                                               \
     put_split(hs, hs + WR * PH, hl, R.a);                                                 \
     if (tid < 256) {                                                                      \
-      bsum += R.b;                                                                        \
-      put_round(st + S0_DL, sl, R.b);                                                     \
+      const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};                                              \
+      const f32x4 dv = sok ? R.b : z4;                                                    \
+      bsum += dv;                                                                         \
+      put_round(st + S0_DL, sl, dv);                                                      \
     }                                                                                     \
   }
   // accumulators: 6 tiles of w_hh (rows 96 wm + 32 mt, columns 64 wn + 32 nt), 1 of w_fl (row tile wave >> 2, column tile wave & 3)
@@ -246,8 +259,8 @@ __global__ __launch_bounds__(WNT, 1) void flow_wgrad_hh_kernel(WgradArgs g) {
 #pragma unroll
   for (int mt = 0; mt < 3; ++mt)
 #pragma unroll
-    for (int nt = 0; nt < 2; ++nt) put_tile(ahh[mt][nt], P + P_HH, WH, 96 * wm + 32 * mt, 64 * wn + 32 * nt, lane);
-  put_tile(afl, P + P_FL, WH, 32 * (wave >> 2), 32 * (wave & 3), lane);
+    for (int nt = 0; nt < 2; ++nt) put_tile(ahh[mt][nt], P + P0_HH, WH, 96 * wm + 32 * mt, 64 * wn + 32 * nt, lane);
+  put_tile(afl, P + P0_FL, WH, 32 * (wave >> 2), 32 * (wave & 3), lane);
   // column sums of dlin: 16 row slots per column chunk, summed in row order
   float* red = reinterpret_cast<float*>(wsmem);
   __syncthreads();
@@ -257,7 +270,7 @@ __global__ __launch_bounds__(WNT, 1) void flow_wgrad_hh_kernel(WgradArgs g) {
     float s = 0.0f;
 #pragma unroll
     for (int r = 0; r < WR; ++r) s += red[r * 64 + tid];
-    P[P_BF + tid] = s;
+    P[P0_BF + tid] = s;
   }
 }
 
@@ -269,33 +282,31 @@ __global__ __launch_bounds__(WNT) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   const int n0 = sp * g.nchunk, n1 = min(g.N, n0 + g.nchunk);
   const long kF = (long)k * g.F;
   const int b0 = bt * WR;
-  float* __restrict__ P = g.part + ((long)k * (g.nbt * g.ns) + blockIdx.x) * PART;
+  float* __restrict__ P = g.part + ((long)k * (g.nbt * g.ns) + blockIdx.x) * PART1;
   if (n0 >= n1) return;
 
   const int r0 = tid / 48, c0 = tid - r0 * 48;
   const int r1 = (tid + WNT) / 48, c1 = (tid + WNT) - r1 * 48;
   const bool g1ok = tid < WR * 48 - WNT;
   const __bf16* gp0 = g.dgi + (kF + b0 + r0) * WG_ + c0 * 8;
-  const __bf16* gp1 = g.dgi + (kF + b0 + (g1ok ? r1 : 0)) * WG_ + c1 * 8;
+  const __bf16* gp1 = g1ok ? g.dgi + (kF + b0 + r1) * WG_ + c1 * 8 : gp0;
   const int gl0 = S1_GI + r0 * PG + c0 * 8, gl1 = S1_GI + r1 * PG + c1 * 8;
   // fp32 arrays, 16 rows x 16 chunk slots each: slot a = a (threads 0-255) | dy (256-511); slot b = z1 (threads 0-255, its first
   // 32 columns at most)
   const int srow = (tid >> 4) & 15, sch = tid & 15, ncc = g.ldc >> 2;
   const bool hi_half = tid >= 256;
   const bool aok = sch < ncc, bok = !hi_half && sch < min(ncc, 8);
-  const float* ap = (hi_half ? g.dy : g.sA) + (kF + b0 + srow) * g.ldc + sch * 4;
-  const float* bp = g.sY + (kF + b0 + srow) * g.ldc + sch * 4;
+  const float* ap = (hi_half ? g.dy : g.sA) + (kF + b0 + srow) * g.ldc + (aok ? sch * 4 : 0);   // (a slot past the row: its first chunk)
+  const float* bp = bok ? g.sY + (kF + b0 + srow) * g.ldc + sch * 4 : ap;
   const int sl = srow * PS + sch * 4;
   const long stepG = (long)g.B * WG_, stepS = (long)g.B * g.ldc;
 
 #define LOAD1(n_, R)                                                                      \
   {                                                                                       \
-    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};                                                \
-    const u32x4 zu = {0u, 0u, 0u, 0u};                                                    \
     R.g0 = *reinterpret_cast<const u32x4*>(gp0 + (n_) * stepG);                           \
-    R.g1 = g1ok ? *reinterpret_cast<const u32x4*>(gp1 + (n_) * stepG) : zu;               \
-    R.a = aok ? *reinterpret_cast<const f32x4*>(ap + (n_) * stepS) : z4;                  \
-    R.b = bok ? *reinterpret_cast<const f32x4*>(bp + (n_) * stepS) : z4;                  \
+    R.g1 = *reinterpret_cast<const u32x4*>(gp1 + (n_) * stepG);                           \
+    R.a = *reinterpret_cast<const f32x4*>(ap + (n_) * stepS);                             \
+    R.b = *reinterpret_cast<const f32x4*>(bp + (n_) * stepS);                             \
   }
 #define STORE1(n_, buf, R)                                                                \
   {                                                                                       \
@@ -331,47 +342,66 @@ __global__ __launch_bounds__(WNT) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
 #undef LOAD1
 #undef STORE1
 #undef MMA1
-  put_tile(ax0, P + P_IZ, 32, 32 * wave, 0, lane);
-  if (lowave) put_tile(ax1, P + P_IZ, 32, 32 * (8 + wave), 0, lane);
-  else put_tile(ax1, P + P_DW, 64, 32 * dwm, 32 * dwn, lane);
+  put_tile(ax0, P + P1_IZ, 32, 32 * wave, 0, lane);
+  if (lowave) put_tile(ax1, P + P1_IZ, 32, 32 * (8 + wave), 0, lane);
+  else put_tile(ax1, P + P1_DW, 64, 32 * dwm, 32 * dwn, lane);
 }
 
-// out[k][j] = sum over the splits (in split order) of part[k][split][j], scattered to the gradient buffers
+// out[k][j .. j + 3] = sum over the splits (in split order) of part[k][split][j .. j + 3], scattered to the gradient buffers
+template <int ROLE>
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(WgradArgs g) {
+  constexpr int PART = ROLE == 0 ? PART0 : PART1;
   const int k = blockIdx.y;
-  const int j = blockIdx.x * 256 + threadIdx.x;
+  const int j = (blockIdx.x * 256 + threadIdx.x) * 4;
   if (j >= PART) return;
   const int S = g.nbt * g.ns;
   const float* __restrict__ p = g.part + (long)k * S * PART + j;
-  float s = 0.0f;
-  for (int i = 0; i < S; ++i) s += p[(long)i * PART];
-  float* dst = nullptr;
-  bool acc = g.accumulate != 0;
-  if (j < P_IZ) {
-    dst = g.w_hh + (long)k * WG_ * WH + j;
-  } else if (j < P_FL) {
-    const int row = (j - P_IZ) >> 5, col = (j - P_IZ) & 31;
-    if (col < g.Ch) dst = g.w_ih + ((long)k * WG_ + row) * g.I + col;
-  } else if (j < P_DW) {
-    const int row = (j - P_FL) >> 7, col = (j - P_FL) & 127;
-    if (row < g.Cout) dst = g.w_fl + ((long)k * g.Cout + row) * WH + col;
-  } else if (j < P_BF) {
-    const int row = (j - P_DW) >> 6, col = (j - P_DW) & 63;
-    if (row < g.C && col < g.C) dst = g.dW + ((long)k * g.C + row) * g.C + col;
-    acc = false;
-  } else {
-    const int col = j - P_BF;
-    if (col < g.Cout) dst = g.b_fl + (long)k * g.Cout + col;
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  int i = 0;
+  for (; i + 4 <= S; i += 4) {   // four loads in flight, summed in split order
+    const f32x4 a = *reinterpret_cast<const f32x4*>(p + (long)i * PART), b = *reinterpret_cast<const f32x4*>(p + (long)(i + 1) * PART);
+    const f32x4 c = *reinterpret_cast<const f32x4*>(p + (long)(i + 2) * PART), d = *reinterpret_cast<const f32x4*>(p + (long)(i + 3) * PART);
+    s += a; s += b; s += c; s += d;
   }
-  if (dst) *dst = acc ? *dst + s : s;
+  for (; i < S; ++i) s += *reinterpret_cast<const f32x4*>(p + (long)i * PART);
+  const bool accf = g.accumulate != 0;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int je = j + e;
+    float* dst = nullptr;
+    bool acc = accf;
+    if (ROLE == 0) {
+      if (je < P0_FL) {
+        dst = g.w_hh + (long)k * WG_ * WH + je;
+      } else if (je < P0_BF) {
+        const int row = (je - P0_FL) >> 7, col = (je - P0_FL) & 127;
+        if (row < g.Cout) dst = g.w_fl + ((long)k * g.Cout + row) * WH + col;
+      } else {
+        const int col = je - P0_BF;
+        if (col < g.Cout) dst = g.b_fl + (long)k * g.Cout + col;
+      }
+    } else {
+      if (je < P1_DW) {
+        const int row = je >> 5, col = je & 31;
+        if (col < g.Ch) dst = g.w_ih + ((long)k * WG_ + row) * g.I + col;
+      } else {
+        const int row = (je - P1_DW) >> 6, col = (je - P1_DW) & 63;
+        if (row < g.C && col < g.C) dst = g.dW + ((long)k * g.C + row) * g.C + col;
+        acc = false;
+      }
+    }
+    if (dst) *dst = acc ? *dst + s[e] : s[e];
+  }
 }
 
-// timestep ranges per (flow step, batch tile): enough workgroups for one round of 256 CUs, ranges of at least 4 timesteps
-int wgrad_splits(int Ks, int nbt, int N) {
+// timestep ranges per (flow step, batch tile): enough workgroups for `want` of them, ranges of at least 4 timesteps
+int wgrad_splits(int Ks, int nbt, int N, int want) {
   int ns = 1;
-  while ((long)Ks * nbt * ns < 256 && N / (ns * 2) >= 4) ns *= 2;
+  while ((long)Ks * nbt * ns < want && N / (ns * 2) >= 4) ns *= 2;
   return ns;
 }
+// role 0 holds a CU per workgroup (210 VGPRs x 8 waves): one round of 256; role 1 fits twice per CU
+constexpr int WANT0 = 256, WANT1 = 512;
 }  // namespace
 
 extern "C" __attribute__((visibility("hidden"))) int lfi_internal_flow_wgrad_ok(int B, int N, int C, int Ch, int Cout, int H, int G,
@@ -380,21 +410,24 @@ extern "C" __attribute__((visibility("hidden"))) int lfi_internal_flow_wgrad_ok(
           ldc % 4 == 0 && ldo % 4 == 0 && ldc <= 64 && ldo <= 64) ? 1 : 0;
 }
 
-extern "C" __attribute__((visibility("hidden"))) long lfi_internal_flow_wgrad_work_floats(int B, int N, int Ks) {
+// floats of the partials of role 0 (w_hh | w_fl | b_fl) and role 1 (w_ih[:, :Ch] | dW); the caller places role 1's after role 0's
+extern "C" __attribute__((visibility("hidden"))) long lfi_internal_flow_wgrad_work_floats(int B, int N, int Ks, int role) {
   const int nbt = B / WR;
-  return (long)Ks * nbt * wgrad_splits(Ks, nbt, N) * PART;
+  return role == 0 ? (long)Ks * nbt * wgrad_splits(Ks, nbt, N, WANT0) * PART0 : (long)Ks * nbt * wgrad_splits(Ks, nbt, N, WANT1) * PART1;
 }
 
-extern "C" __attribute__((visibility("hidden"))) int lfi_internal_flow_wgrad(int B, int N, int Ks, int C, int Ch, int Cout, int I, int ldc,
-                                                                              int ldo, const void* dgh, const void* dgi, const float* h,
-                                                                              const float* dlin, const float* sY, const float* sA,
-                                                                              const float* dy, float* part, float* w_hh, float* w_ih,
-                                                                              float* w_fl, float* b_fl, float* dW, int accumulate,
-                                                                              void* stream) {
+// role 0: w_hh, w_fl, b_fl from dgh, h, dlin; role 1: w_ih[:, :Ch], dW from dgi, z1 (= sY's first Ch columns), a, dy. Each role is
+// two launches on `stream` (walk + reduce); the roles share nothing but read-only inputs and may run on different streams.
+extern "C" __attribute__((visibility("hidden"))) int lfi_internal_flow_wgrad(int role, int B, int N, int Ks, int C, int Ch, int Cout, int I,
+                                                                              int ldc, int ldo, const void* dgh, const void* dgi,
+                                                                              const float* h, const float* dlin, const float* sY,
+                                                                              const float* sA, const float* dy, float* part, float* w_hh,
+                                                                              float* w_ih, float* w_fl, float* b_fl, float* dW,
+                                                                              int accumulate, void* stream) {
   WgradArgs g = {};
   g.B = B; g.N = N; g.Ks = Ks; g.F = B * N; g.C = C; g.Ch = Ch; g.Cout = Cout; g.I = I; g.ldc = ldc; g.ldo = ldo;
   g.nbt = B / WR;
-  g.ns = wgrad_splits(Ks, g.nbt, N);
+  g.ns = wgrad_splits(Ks, g.nbt, N, role == 0 ? WANT0 : WANT1);
   g.nchunk = (N + g.ns - 1) / g.ns;
   g.dgh = reinterpret_cast<const __bf16*>(dgh); g.dgi = reinterpret_cast<const __bf16*>(dgi);
   g.h = h; g.dlin = dlin; g.sY = sY; g.sA = sA; g.dy = dy; g.part = part;
@@ -411,11 +444,15 @@ extern "C" __attribute__((visibility("hidden"))) int lfi_internal_flow_wgrad(int
     }
     attr_set = true;
   }
-  hipLaunchKernelGGL(flow_wgrad_ih_kernel, dim3(g.nbt * g.ns, Ks), dim3(WNT), lds1, (hipStream_t)stream, g);
-  LFI_LAUNCH_CHECK("lfi_flow_param_grads one-pass thin products (w_ih | dW)");
-  hipLaunchKernelGGL(flow_wgrad_hh_kernel, dim3(g.nbt * g.ns, Ks), dim3(WNT), lds0, (hipStream_t)stream, g);
-  LFI_LAUNCH_CHECK("lfi_flow_param_grads one-pass thin products (w_hh | w_fl)");
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(lfi_cdiv(PART, 256), Ks), dim3(256), 0, (hipStream_t)stream, g);
-  LFI_LAUNCH_CHECK("lfi_flow_param_grads fused thin products reduce");
+  if (role == 0) {
+    hipLaunchKernelGGL(flow_wgrad_hh_kernel, dim3(g.nbt * g.ns, Ks), dim3(WNT), lds0, (hipStream_t)stream, g);
+    LFI_LAUNCH_CHECK("lfi_flow_param_grads one-pass thin products (w_hh | w_fl)");
+    hipLaunchKernelGGL(wgrad_reduce_kernel<0>, dim3(lfi_cdiv(PART0 / 4, 256), Ks), dim3(256), 0, (hipStream_t)stream, g);
+  } else {
+    hipLaunchKernelGGL(flow_wgrad_ih_kernel, dim3(g.nbt * g.ns, Ks), dim3(WNT), lds1, (hipStream_t)stream, g);
+    LFI_LAUNCH_CHECK("lfi_flow_param_grads one-pass thin products (w_ih | dW)");
+    hipLaunchKernelGGL(wgrad_reduce_kernel<1>, dim3(lfi_cdiv(PART1 / 4, 256), Ks), dim3(256), 0, (hipStream_t)stream, g);
+  }
+  LFI_LAUNCH_CHECK("lfi_flow_param_grads one-pass thin products reduce");
   return LFI_OK;
 }

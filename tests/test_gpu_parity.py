@@ -884,14 +884,14 @@ def test_checkpoint_resume_keeps_the_optimiser_state(gpu_device, tmp_path):
     assert c.seq_glow.engine.step_count == 4 and torch.equal(a.seq_glow.engine.adam_m, c.seq_glow.engine.adam_m)
 
 
-@pytest.mark.parametrize("B,T,K", [(48, 24 + 7, 3), (16, 24 + 1, 2), (32, 24 + 40, 2)])
+@pytest.mark.parametrize("B,T,K", [(64, 24 + 8, 3), (32, 24 + 1, 2), (32, 24 + 40, 2)])
 def test_one_pass_thin_weight_gradients_match_the_four_products(gpu_device, monkeypatch, B, T, K):
     """Round 6: the flow's thin weight-gradient products (w_hh, w_ih[:, :Ch], w_fl, b_fl and the invconv's dW: autograd of
     glow/models.py:204-214, glow/modules.py:93-95,147-177) in ONE pass over the backward stash (lfi_wgrad.hip) against the four
     batched split-K products + column-sum pass they replace (LFI_FLOW_WGRAD_FUSED=0), final widths, two-product backward (the
     mode the one-pass form exists for: dgi | dgh arrive as bf16 rows). Same operands, same roundings, another summation order:
     every flow gradient agrees to fp32 rounding; every other gradient bit for bit (they do not pass through the changed code).
-    Cases: several batch tiles and timestep ranges (3 x 3 x 2 workgroups), a single timestep (w_hh = 0), a longer walk."""
+    Cases (the planes chain needs F % 32 == 0): several batch tiles and timestep ranges (the w_hh role: 3 flow steps x 4 tiles x 2 ranges), a single timestep (w_hh = 0), a longer walk."""
     hp = final_model_hparams(50, 27, K=K)
     N = T - 24
     batch = oracle.synthetic_batch(B, T, 50, 27, seed=77)
