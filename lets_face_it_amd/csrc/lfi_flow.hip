@@ -2873,10 +2873,18 @@ __global__ __launch_bounds__(64) void flow_pipe_poison_kernel(FlowK f) {
   for (int k = threadIdx.x; k < f.Ks; k += 64) {
     for (long fr = 0; fr < f.F; fr += (f.F > 1 ? f.F - 1 : 1)) {   // first and last frame (the W_hh gradient skips timestep 0)
       f.bDlin[((long)k * f.F + fr) * f.ldo] = nan;
-      f.bDgi[((long)k * f.F + fr) * f.G] = nan;
-      f.bDgh[((long)k * f.F + fr) * f.G] = nan;
+      if (f.g16) {   // the dgi | dgh rows are bf16 arrays of the same shapes (an fp32 store here landed on two bf16
+                     // elements of another flow step's frame, or past the bf16 region)
+        reinterpret_cast<__bf16*>(f.bDgi)[((long)k * f.F + fr) * f.G] = (__bf16)nan;
+        reinterpret_cast<__bf16*>(f.bDgh)[((long)k * f.F + fr) * f.G] = (__bf16)nan;
+      } else {
+        f.bDgi[((long)k * f.F + fr) * f.G] = nan;
+        f.bDgh[((long)k * f.F + fr) * f.G] = nan;
+      }
       f.bDy[((long)k * f.F + fr) * f.ldc] = nan;
     }
+    // dgi as operand planes (the dgi^T c and dpre products read these, not the rows): element (row k F, column 0) of the hi plane
+    if (f.bDgiR && f.F % 32 == 0) f.bDgiR[(((long)k * f.F / 32) * (f.G / 16) * 2) * 512] = (__bf16)nan;
   }
 }
 

@@ -1200,12 +1200,22 @@ class GlowEngine:
         bc1, bc2 = 1.0 - b1 ** int(step_count), 1.0 - b2 ** int(step_count)
         return float(np.float32(lr64 / bc1)), float(np.float32(1.0 / math.sqrt(bc2)))
 
+    def _claim_optimizer(self, name):
+        """The state buffers mean different things per optimiser (optimizer_state): a state loaded from a checkpoint of one
+        optimiser must not be stepped by another (Adam's moments were silently reused as a momentum buffer)."""
+        have = self.__dict__.get("_opt_name")
+        if have is not None and have != name:
+            raise ValueError("the engine holds optimiser state of %r (checkpoint or earlier steps); stepping it with %r would "
+                             "reinterpret its buffers - start from fresh state (load_optimizer_state({})) or keep Optim.name" % (have, name))
+        self._opt_name = name
+
     @translate_oom
     def optimizer_step(self, lr, beta1, beta2, eps, clip=0.0, gmul=1.0, hyper_dev=None, weight_decay=0.0, amsgrad=False):
         """clip_grad_norm_(clip) + Adam on the flat buffers (lets_face_it_glow.py:61-72; final_model.yaml:126).
         hyper_dev: device pointer to (step_size, 1 / sqrt(1 - beta2^t)) - a captured step; the caller keeps step_count.
         weight_decay / amsgrad: torch.optim.Adam's (the reference forwards Optim["args"]["adam"] verbatim); the running maximum of
         the second moment lives in `opt_aux`."""
+        self._claim_optimizer("adam")
         if self.adam_m is None:
             self.adam_m = torch.zeros_like(self.params)
             self.adam_v = torch.zeros_like(self.params)
@@ -1238,6 +1248,10 @@ class GlowEngine:
     def optimizer_step_sgd(self, lr, momentum=0.0, dampening=0.0, weight_decay=0.0, nesterov=False, clip=0.0, gmul=1.0):
         """clip_grad_norm_(clip) + torch.optim.SGD on the flat buffers (lets_face_it_glow.py:61-72 with Optim.name = "sgd";
         final_model.yaml:98-99: momentum 0.9). The momentum buffer lives in `adam_m` (one optimiser per model)."""
+        self._claim_optimizer("sgd")
+        # torch.optim.SGD's "first step" (buf = g) is "no momentum buffer yet", not "step 1": a reference checkpoint carries a
+        # buffer and no step count (ADVICE r5: the imported buffer was overwritten with g on the first resumed step)
+        first = momentum and (self.adam_m is None or not self.__dict__.get("_momentum_inited", False))
         if momentum and self.adam_m is None:
             self.adam_m = torch.zeros_like(self.params)
         st = _stream()
@@ -1247,13 +1261,16 @@ class GlowEngine:
         self.step_count += 1
         check(self.L.lfi_sgd_clip_step(self.params.data_ptr(), self.grads.data_ptr(), ptr(self.adam_m if momentum else None),
                                        self.n_params, self.sumsq.data_ptr(), float(clip or 0.0), gmul, lr, float(momentum),
-                                       float(dampening), float(weight_decay), 1 if nesterov else 0, self.step_count, st),
+                                       float(dampening), float(weight_decay), 1 if nesterov else 0, 1 if first else 2, st),
               "lfi_sgd_clip_step")
+        if momentum:
+            self._momentum_inited = True
 
     @translate_oom
     def optimizer_step_rmsprop(self, lr, alpha=0.99, eps=1e-8, weight_decay=0.0, momentum=0.0, centered=False, clip=0.0, gmul=1.0):
         """clip_grad_norm_(clip) + torch.optim.RMSprop on the flat buffers (Optim.name = "rmsprop"; final_model.yaml:96-97: eps 1e-8).
         Square average in `adam_v`, momentum buffer in `adam_m`, the centered variant's gradient average in `opt_aux`."""
+        self._claim_optimizer("rmsprop")
         if self.adam_v is None:
             self.adam_v = torch.zeros_like(self.params)
         if momentum and self.adam_m is None:
@@ -1271,11 +1288,14 @@ class GlowEngine:
                                            float(weight_decay), float(momentum), st), "lfi_rmsprop_clip_step")
 
     def optimizer_state(self):
-        """The optimiser's state buffers and step count (checkpoints, engine re-binds). Adam: first / second moments; SGD: `adam_m` =
-        momentum buffer; RMSprop: `adam_v` = square average, `adam_m` = momentum buffer, `opt_aux` = centered gradient average.
-        Buffers are None before the first step."""
+        """The optimiser's state buffers and step count (checkpoints, engine re-binds). Adam: first / second moments, `opt_aux` =
+        amsgrad's running maximum; SGD: `adam_m` = momentum buffer; RMSprop: `adam_v` = square average, `adam_m` = momentum buffer,
+        `opt_aux` = centered gradient average. `optimizer` names whose state this is (None before the first step) - another
+        optimiser refuses to step it. Buffers are None before the first step."""
         aux = self.__dict__.get("opt_aux")
         return {"step_count": int(self.step_count),
+                "optimizer": self.__dict__.get("_opt_name"),
+                "momentum_inited": bool(self.__dict__.get("_momentum_inited", False)),
                 "opt_aux": None if aux is None else aux.detach().clone(),
                 # the dropout-mask stream is keyed on (seed, call counter): a resumed / re-bound run must not replay the masks
                 # of steps 1..k (ADVICE r2)
@@ -1286,6 +1306,9 @@ class GlowEngine:
     def load_optimizer_state(self, state):
         self.step_count = int(state.get("step_count", 0))
         self._mask_calls = int(state.get("mask_calls", self._mask_calls))
+        self._opt_name = state.get("optimizer")     # None (older checkpoints, fresh state): the first step claims it
+        # (checkpoints from before round 6 carry no flag: a momentum buffer that exists has been written)
+        self._momentum_inited = bool(state.get("momentum_inited", state.get("adam_m") is not None))
         for name in ("adam_m", "adam_v", "opt_aux"):
             t = state.get(name)
             if t is None:

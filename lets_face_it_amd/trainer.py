@@ -220,10 +220,15 @@ class Trainer:
             os.replace(tmp, path)
 
     @staticmethod
-    def _flat_adam_state(model, eng, opt_state):
-        """torch.optim.Adam state_dict ({'state': {i: {'step', 'exp_avg', 'exp_avg_sq'}}, ...}; i = index in model.parameters())
-        -> the engine's flat-buffer state. Parameters are views of the flat buffer, so a moment's place is its parameter's."""
-        m, v = torch.zeros_like(eng.params), torch.zeros_like(eng.params)
+    def _flat_optimizer_state(model, eng, opt_state, name="adam"):
+        """A torch.optim state_dict ({'state': {i: {...}}, ...}; i = index in model.parameters()) of the optimiser `name`
+        (configure_optimizers, lets_face_it_glow.py:61-72) -> the engine's flat-buffer state. Parameters are views of the flat buffer, so
+        a state tensor's place is its parameter's. Adam: exp_avg / exp_avg_sq / max_exp_avg_sq (amsgrad) / step; SGD: momentum_buffer
+        (torch keeps no step count for it); RMSprop: square_avg / momentum_buffer / grad_avg (centered) / step."""
+        keys = {"adam": {"exp_avg": "adam_m", "exp_avg_sq": "adam_v", "max_exp_avg_sq": "opt_aux"},
+                "sgd": {"momentum_buffer": "adam_m"},
+                "rmsprop": {"square_avg": "adam_v", "momentum_buffer": "adam_m", "grad_avg": "opt_aux"}}[name]
+        flat = {}
         step, base = 0, eng.params.data_ptr()
         for i, p in enumerate(model.parameters()):
             st = opt_state["state"].get(i)
@@ -232,10 +237,25 @@ class Trainer:
             off = (p.data_ptr() - base) // 4
             if not (0 <= off and off + p.numel() <= eng.n_params):
                 raise ValueError("parameter %d does not live in the engine's flat buffer" % i)
-            m[off:off + p.numel()].copy_(st["exp_avg"].reshape(-1))
-            v[off:off + p.numel()].copy_(st["exp_avg_sq"].reshape(-1))
-            step = max(step, int(st["step"]))
-        return {"step_count": step, "adam_m": m, "adam_v": v}
+            unknown = [k for k in st if k not in keys and k != "step"]
+            if unknown:
+                raise KeyError("optimizer state of parameter %d holds %s: not a torch %s state (Optim.name = %r)"
+                               % (i, unknown, name, name))
+            for k, dst in keys.items():
+                t = st.get(k)
+                if t is None:
+                    continue
+                if dst not in flat:
+                    flat[dst] = torch.zeros_like(eng.params)
+                flat[dst][off:off + p.numel()].copy_(t.reshape(-1))
+            if "step" in st:
+                step = max(step, int(st["step"]))
+        return {"step_count": step, "optimizer": name, "momentum_inited": "adam_m" in flat and name == "sgd",
+                "adam_m": flat.get("adam_m"), "adam_v": flat.get("adam_v"), "opt_aux": flat.get("opt_aux")}
+
+    @classmethod
+    def _flat_adam_state(cls, model, eng, opt_state):
+        return cls._flat_optimizer_state(model, eng, opt_state, "adam")
 
     def resume(self, model, path):
         """Continue a run from a checkpoint of save_checkpoint: weights, ActNorm's inited flag, Adam state, epoch and step."""
@@ -246,11 +266,17 @@ class Trainer:
             model.seq_glow.glow.set_actnorm_init(True)
         eng = model.seq_glow._ensure_engine(self.device)
         if ckpt.get("optimizer_state") is not None:
+            saved = ckpt["optimizer_state"].get("optimizer")
+            if saved is not None and saved != model.hparams.Optim["name"]:
+                raise ValueError("checkpoint %s holds %s state, hparams.Optim.name is %r: the state buffers would be reinterpreted "
+                                 "(Adam's moments as a momentum buffer / square average)" % (path, saved, model.hparams.Optim["name"]))
             eng.load_optimizer_state(ckpt["optimizer_state"])
         elif ckpt.get("optimizer_states"):
             # a Lightning / reference checkpoint: torch.optim.Adam's per-parameter state, in model.parameters() order
             # (configure_optimizers, lets_face_it_glow.py:61-72) -> the flat moments
-            eng.load_optimizer_state(self._flat_adam_state(model, eng, ckpt["optimizer_states"][0]))
+            # (whichever of Adam / SGD / RMSprop hparams.Optim names: their state keys differ)
+            eng.load_optimizer_state(self._flat_optimizer_state(model, eng, ckpt["optimizer_states"][0],
+                                                                model.hparams.Optim["name"]))
         else:
             import warnings
             warnings.warn("checkpoint %s holds no optimiser state: Adam's moments restart from zero (with betas[1] = 0.9999 "

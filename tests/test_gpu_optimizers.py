@@ -86,3 +86,57 @@ def test_unknown_optimizer_arguments_raise(gpu_device):
     batch = {k: v.to(gpu_device) for k, v in fx.batch(torch.float32).items()}
     with pytest.raises(TypeError, match="bogus"):
         lm.fused_training_step(batch, 1e-3)
+
+
+def _tiny_module(gpu_device, name, kwargs):
+    from lets_face_it_amd.glow.lets_face_it_glow import LetsFaceItGlow
+    fx = Fixture("tiny")
+    hp = Namespace(**copy.deepcopy(fx.hp))
+    hp.Train["use_negative_nll_loss"] = False
+    hp.gradient_clip_val = 5.0
+    hp.Optim["name"] = name
+    hp.Optim["args"][name] = dict(kwargs)
+    hp.engine_precision = "f32"
+    lm = LetsFaceItGlow(hp)
+    lm.seq_glow.load_state_dict(fx.state_dict(torch.float32))
+    lm.to(gpu_device)
+    lm.seq_glow.glow.set_actnorm_init(True)
+    lm.train()
+    lm.seq_glow.injected_masks = {k: v.to(gpu_device) for k, v in fx.masks(torch.float32).items()} if fx.masks() else None
+    return lm, {k: v.to(gpu_device) for k, v in fx.batch(torch.float32).items()}
+
+
+def test_resumed_sgd_keeps_its_imported_momentum_buffer(gpu_device):
+    """torch.optim.SGD's "first step" (buf = g) means "this parameter has no momentum buffer yet"; the fused step keyed
+    it on its own step count, so a state imported from a reference checkpoint (a buffer, no step count) was overwritten with g on the
+    first resumed step. One resumed step against torch.optim.SGD holding the same buffer."""
+    lm, batch = _tiny_module(gpu_device, "sgd", {"momentum": 0.9})
+    eng = lm.seq_glow._ensure_engine(gpu_device)
+    buf = torch.randn_like(eng.params) * 0.1
+    eng.load_optimizer_state({"step_count": 0, "optimizer": "sgd", "momentum_inited": True, "adam_m": buf.clone(), "adam_v": None,
+                              "opt_aux": None})
+    ref_p = torch.nn.Parameter(eng.params.detach().clone())
+    opt = torch.optim.SGD([ref_p], lr=3e-3, momentum=0.9, foreach=False)
+    opt.state[ref_p]["momentum_buffer"] = buf.clone()
+    lm.fused_training_step(batch, 3e-3)
+    ref_p.grad = eng.grads.detach().clone()
+    torch.nn.utils.clip_grad_norm_([ref_p], 5.0)
+    opt.step()
+    d = (eng.params - ref_p.detach()).abs().max().item()
+    assert d < 2e-6, d
+    assert (eng.adam_m - opt.state[ref_p]["momentum_buffer"]).abs().max().item() < 2e-6
+
+
+def test_optimizer_state_of_another_optimizer_is_refused(gpu_device):
+    """native checkpoints carried no optimiser tag, so resuming with another Optim.name silently reused Adam's moments as
+    a momentum buffer / square average. The state names its optimiser; another one refuses to step it."""
+    lm, batch = _tiny_module(gpu_device, "adam", {"betas": [0.9, 0.999], "eps": 1e-8})
+    lm.fused_training_step(batch, 1e-3)
+    eng = lm.seq_glow._ensure_engine(gpu_device)
+    state = eng.optimizer_state()
+    assert state["optimizer"] == "adam"
+    lm2, batch2 = _tiny_module(gpu_device, "sgd", {"momentum": 0.9})
+    eng2 = lm2.seq_glow._ensure_engine(gpu_device)
+    eng2.load_optimizer_state(state)
+    with pytest.raises(ValueError, match="adam"):
+        lm2.fused_training_step(batch2, 1e-3)

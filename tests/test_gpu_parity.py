@@ -691,6 +691,37 @@ def test_abandoned_walk_is_loud(gpu_device, monkeypatch):
     assert max_rel(torch.stack(losses), fxm.get("train/nll"), floor=1.0) < 1e-4
 
 
+def test_abandoned_walk_is_loud_with_bf16_gradient_rows(gpu_device, monkeypatch):
+    """with the backward walk's dgi | dgh rows stored as bf16 (two-product mode on the planes chain, the benchmark's
+    arithmetic) the poison kernel's fp32 NaN stores landed on other rows or outside the bf16 region, so w_hh of even flow steps and
+    half of the w_ih targets stayed finite after an abandoned walk. Every flow step's w_ih (both column blocks), w_hh, w_fl and the
+    LU parameters must come out NaN - through the one-pass thin products and through the four split-K products alike."""
+    hp = final_model_hparams(50, 27, K=3)
+    B, T = 32, 24 + 8
+    batch = oracle.synthetic_batch(B, T, 50, 27, seed=5)
+    for fused in ("1", "0"):
+        monkeypatch.setenv("LFI_FLOW_WGRAD_FUSED", fused)
+        m, _ = perturbed_model(hp, gpu_device)
+        m.precision = "bf16x3"
+        m.eval()
+        eng = m._ensure_engine(gpu_device)
+        eng.backward_products = 2
+        _, loss, _ = m(to_dev(batch, gpu_device))      # a clean forward: only the backward walk is abandoned
+        monkeypatch.setenv("LFI_PIPE_FORCE_ABORT", "1")
+        eng.backward(1.0)
+        torch.cuda.synchronize()
+        monkeypatch.delenv("LFI_PIPE_FORCE_ABORT")
+        assert bool(eng._last.chain)
+        Ks, s = eng.spec.Ks, eng.spec
+        for name in ("w_hh", "w_fl", "inv_l"):
+            g = eng.fview(name, eng.grads).reshape(Ks, -1)
+            assert torch.isnan(g).any(dim=1).all(), (fused, name)
+        w_ih = eng.fview("w_ih", eng.grads).reshape(Ks, s.G, s.I)
+        assert torch.isnan(w_ih[:, :, :s.Ch]).reshape(Ks, -1).any(dim=1).all(), fused
+        assert torch.isnan(w_ih[:, :, s.Ch:]).reshape(Ks, -1).any(dim=1).all(), fused
+        del m, eng
+
+
 def test_two_bucket_allreduce_protocol(gpu_device):
     """fused_training_step under data parallelism hands the gradient to the all-reduce callable in two buckets (flow block
     asynchronously before the encoder BPTT, encoder block after): every float exactly once, and with a stand-in that behaves

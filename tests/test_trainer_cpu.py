@@ -180,3 +180,58 @@ def test_lr_at_reproduces_every_reference_schedule():
     import pytest
     with pytest.raises(NotImplementedError):
         Trainer(Namespace(**hp), device="cpu", checkpoint_dir="").lr_at(0)
+
+
+@pytest.mark.parametrize("name,kwargs", [("adam", {}), ("adam", {"amsgrad": True}), ("sgd", {"momentum": 0.9}), ("sgd", {}),
+                                         ("rmsprop", {}), ("rmsprop", {"momentum": 0.5, "centered": True})])
+def test_reference_optimizer_state_maps_onto_the_flat_buffers(name, kwargs):
+    """a Lightning / reference checkpoint's `optimizer_states[0]` is whatever configure_optimizers built
+    (glow/lets_face_it_glow.py:61-72: Adam, SGD or RMSprop) - their per-parameter state keys differ (exp_avg / exp_avg_sq /
+    max_exp_avg_sq, momentum_buffer, square_avg / momentum_buffer / grad_avg) and SGD keeps no step count. Each lands in the flat
+    buffer the fused step of the SAME optimiser reads it from, tagged with the optimiser's name."""
+    torch.manual_seed(0)
+    shapes = [(3, 4), (5,), (2, 2, 2)]
+    n = sum(int(torch.tensor(s).prod()) for s in shapes)
+    flat = torch.randn(n)
+    params, off = [], 0
+    for s in shapes:
+        k = int(torch.tensor(s).prod())
+        params.append(torch.nn.Parameter(flat[off:off + k].view(s)))
+        off += k
+    assert all(p.data_ptr() == flat.data_ptr() + 4 * o for p, o in zip(params, (0, 12, 17)))
+    model = Namespace(parameters=lambda: iter(params))
+    eng = Namespace(params=flat, n_params=n)
+    cls = {"adam": torch.optim.Adam, "sgd": torch.optim.SGD, "rmsprop": torch.optim.RMSprop}[name]
+    opt = cls(params, lr=1e-2, **kwargs)
+    for _ in range(3):
+        for p in params:
+            p.grad = torch.randn_like(p)
+        opt.step()
+    st = Trainer._flat_optimizer_state(model, eng, opt.state_dict(), name)
+    assert st["optimizer"] == name
+
+    def cat(key):
+        return torch.cat([opt.state[p][key].reshape(-1) for p in params])
+
+    if name == "adam":
+        assert torch.equal(st["adam_m"], cat("exp_avg")) and torch.equal(st["adam_v"], cat("exp_avg_sq")) and st["step_count"] == 3
+        assert (st["opt_aux"] is None) == (not kwargs.get("amsgrad"))
+        if kwargs.get("amsgrad"):
+            assert torch.equal(st["opt_aux"], cat("max_exp_avg_sq"))
+    elif name == "sgd":
+        if kwargs.get("momentum"):
+            assert torch.equal(st["adam_m"], cat("momentum_buffer")) and st["momentum_inited"]
+        else:
+            assert st["adam_m"] is None and not st["momentum_inited"]
+        assert st["adam_v"] is None and st["opt_aux"] is None
+    else:
+        assert torch.equal(st["adam_v"], cat("square_avg")) and st["step_count"] == 3
+        if kwargs.get("momentum"):
+            assert torch.equal(st["adam_m"], cat("momentum_buffer")) and torch.equal(st["opt_aux"], cat("grad_avg"))
+        else:
+            assert st["adam_m"] is None and st["opt_aux"] is None
+    # the wrong optimiser's reader refuses the state instead of guessing
+    other = "sgd" if name != "sgd" else "adam"
+    if opt.state_dict()["state"] and any(len(v) for v in opt.state_dict()["state"].values()):
+        with pytest.raises(KeyError):
+            Trainer._flat_optimizer_state(model, eng, opt.state_dict(), other)
