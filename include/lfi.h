@@ -395,7 +395,9 @@ int lfi_absmax_f32(int count, const float* const* ptrs, const long* n, unsigned*
 /* A HIP stream that owns `cus_per_xcd` CUs of every XCD (1 .. 32 on MI355X) and leaves the rest of the chip to the streams beside
  * it: the sampler's static part (window encoders, static cond_transform columns of the NEXT run of frames) runs on one while the
  * per-frame chain keeps the other CUs - on an ordinary second stream the two only take turns. Not a reference
- * interface: SeqGlow.inference (glow/models.py:567-596) is one PyTorch stream. Destroy with lfi_stream_destroy. */
+ * interface: SeqGlow.inference (glow/models.py:567-596) is one PyTorch stream. Destroy with lfi_stream_destroy. The CU-mask bit
+ * layout is known (probed) for the 256-CU / 8-XCD part only: any other device gets LFI_ERR_ARG and the caller stays on an ordinary
+ * second stream. */
 int lfi_stream_create_partial(int cus_per_xcd, void** stream);
 int lfi_stream_destroy(void* stream);
 int lfi_flow_sample_seq_from(const lfi_flow_dims* d, const lfi_flow_params* p, const float* prep,

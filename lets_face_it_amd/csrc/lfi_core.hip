@@ -28,8 +28,11 @@ extern "C" int lfi_stream_create_partial(int cus_per_xcd, void** stream) {
   LFI_REQUIRE(hipGetDevice(&dev) == hipSuccess &&
                   hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess,
               "lfi_stream_create_partial: no device");
-  LFI_REQUIRE(cus % 8 == 0 && cus <= 2048 && cus_per_xcd >= 1 && cus_per_xcd <= cus / 8,
-              "lfi_stream_create_partial: %d CUs per XCD asked of a device with %d CUs in 8 XCDs", cus_per_xcd, cus);
+  // The mask layout below (bit 8 c + x = CU c of XCD x) was probed on the 256-CU / 8-XCD MI355X only (tools/cu_mask_probe.py):
+  // any other part gets an error, and the caller falls back to an ordinary second stream, instead of a partition nobody measured
+  LFI_REQUIRE(cus == 256 && cus_per_xcd >= 1 && cus_per_xcd <= cus / 8,
+              "lfi_stream_create_partial: %d CUs per XCD asked of a device with %d CUs (the CU-mask layout is known for 256 CUs in 8 "
+              "XCDs only)", cus_per_xcd, cus);
   uint32_t mask[64] = {0};
   for (int b = 0; b < 8 * cus_per_xcd; ++b) mask[b >> 5] |= 1u << (b & 31);
   hipStream_t st = nullptr;

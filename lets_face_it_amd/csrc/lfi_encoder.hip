@@ -1568,11 +1568,12 @@ __global__ __launch_bounds__(ENC_NT, 1) void enc_gru_fwd_t16_kernel(EncArgs a, E
 // (rows, hidden) tile (rg, cg); per step the gate derivatives are taken in registers, written to dgi / dgh (the
 // deferred weight-gradient GEMMs read those) and fed gate by gate through LDS as the A operand of
 // dh_{s-1} = dgh_s W_hh + dh_s * u   (K = 3 hid, B = W_hh rows streamed from L2).
-#ifndef LFI_ENC_FUSED_BWD_OCC
-#define LFI_ENC_FUSED_BWD_OCC 2   // (1: the whole register file for one workgroup - the round-5 SLP chase builds it to take the spills away)
-#endif
-template <bool X3>
-__global__ __launch_bounds__(ENC_NT, LFI_ENC_FUSED_BWD_OCC) void enc_gru_bwd_fused_kernel(EncArgs a, EncFused q) {
+// Round 6: this kernel is the exact-f32 form only. Its bf16x3 twin (the same layout with three bf16 products per k-step) was the
+// fallback behind LFI_ENC_WIDE_BWD=0 and for shapes the row-layout kernels do not take; built with the SLP vectoriser it returned
+// different bits on 19 of 19 repeat launches (spill reloads inside its counted-vmcnt product loops, profiles/round5_slp_chase.md;
+// the instruction at fault was never found). A kernel that is nondeterministic under a legal compiler flag does not ship: it is
+// gone, and those cases run this kernel instead (bit-exact fp32 FMA chains on v_mfma_f32_32x32x2_f32 - slower, never wrong).
+__global__ __launch_bounds__(ENC_NT, 2) void enc_gru_bwd_fused_kernel(EncArgs a, EncFused q) {
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, half = lane >> 5;
   const int cg = wave % q.ncg, rg = wave / q.ncg;
@@ -1581,16 +1582,9 @@ __global__ __launch_bounds__(ENC_NT, LFI_ENC_FUSED_BWD_OCC) void enc_gru_bwd_fus
   const bool jok0 = jb < hid, jok1 = jb + 32 < hid;
   const int wbase = blockIdx.x * q.R;
   float* Dls = enc_smem;  // one gate's derivatives: element (row, k) at Dls[k * ldk + row], rows k >= hid stay zero
-  const int ldx = q.Kp + 8;
-  __bf16* Xhi = reinterpret_cast<__bf16*>(enc_smem);  // X3: bf16 hi / lo images instead, row-major [R][Kp + 8]
-  __bf16* Xlo = Xhi + q.R * ldx;
-  if (X3) {
-    for (int i = tid; i < q.R * ldx; i += ENC_NT) { Xhi[i] = (__bf16)0.0f; Xlo[i] = (__bf16)0.0f; }
-  } else {
-    for (int i = tid; i < q.Kp * ldk; i += ENC_NT) Dls[i] = 0.0f;
-  }
+  for (int i = tid; i < q.Kp * ldk; i += ENC_NT) Dls[i] = 0.0f;
   // roww[row] = w * hid * 4 (rows past F clamped), live[row] = 1 for real windows (bias sums skip the clamped duplicates)
-  unsigned* roww = X3 ? reinterpret_cast<unsigned*>(Xlo + q.R * ldx) : reinterpret_cast<unsigned*>(enc_smem + q.Kp * ldk);
+  unsigned* roww = reinterpret_cast<unsigned*>(enc_smem + q.Kp * ldk);
   float* rlive = reinterpret_cast<float*>(roww + q.R);
   for (int i = tid; i < q.R; i += ENC_NT) {
     roww[i] = (unsigned)min(wbase + i, a.F - 1) * (unsigned)(hid * 4);
@@ -1671,13 +1665,7 @@ __global__ __launch_bounds__(ENC_NT, LFI_ENC_FUSED_BWD_OCC) void enc_gru_bwd_fus
             dg[0][t][r] = dau; dg[1][t][r] = danr;
             if (s > 0) {
               const int rl = enc_rowl(rg, r, halfv);
-              if (X3) {
-                const __bf16 hi = (__bf16)dar;
-                Xhi[rl * ldx + j] = hi;
-                Xlo[rl * ldx + j] = (__bf16)(dar - (float)hi);
-              } else {
-                Dls[j * ldk + rl] = dar;
-              }
+              Dls[j * ldk + rl] = dar;
             }
             acc[t][r] = dhn * uu;
             bsum[0][t] += live[e] * dar; bsum[1][t] += live[e] * dau; bsum[2][t] += live[e] * dan; bsum[3][t] += live[e] * danr;
@@ -1696,64 +1684,11 @@ __global__ __launch_bounds__(ENC_NT, LFI_ENC_FUSED_BWD_OCC) void enc_gru_bwd_fus
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int rl = enc_rowl(rg, r, halfv);
-        if (X3) {
-#pragma unroll
-          for (int t = 0; t < 2; ++t)
-            if (t ? jok1 : jok0) {
-              const float v = dg[g - 1][t][r];
-              const __bf16 hi = (__bf16)v;
-              Xhi[rl * ldx + jv + 32 * t] = hi;
-              Xlo[rl * ldx + jv + 32 * t] = (__bf16)(v - (float)hi);
-            }
-        } else {
-          if (jok0) Dls[jv * ldk + rl] = dg[g - 1][0][r];
-          if (jok1) Dls[(jv + 32) * ldk + rl] = dg[g - 1][1][r];
-        }
+        if (jok0) Dls[jv * ldk + rl] = dg[g - 1][0][r];
+        if (jok1) Dls[(jv + 32) * ldk + rl] = dg[g - 1][1][r];
       }
       __syncthreads();
-      if (X3) {
-        const int nkt = q.Kp >> 4, nct = Jp >> 5;
-        const __bf16* xh = Xhi + (rg * 32 + l31) * ldx + 8 * half;
-        const __bf16* xl = Xlo + (rg * 32 + l31) * ldx + 8 * half;
-        ebf16x8 ah0, al0, ah1, al1;
-        EncFrag f0[2][2], f1[2][2];  // [t][plane]
-        auto load = [&](int kt, ebf16x8& ah, ebf16x8& al, EncFrag (&f)[2][2]) {
-          ah = *reinterpret_cast<const ebf16x8*>(xh + kt * 16);
-          al = *reinterpret_cast<const ebf16x8*>(xl + kt * 16);
-#pragma unroll
-          for (int t = 0; t < 2; ++t) {
-            const uint4* __restrict__ wf = q.wfrag + ((long)((g * nkt + kt) * nct + cg * 2 + t) * 2) * 64;  // uniform
-            f[t][0].u = wf[(unsigned)lane];
-            f[t][1].u = (wf + 64)[(unsigned)lane];
-          }
-        };
-        auto mma = [&](const ebf16x8& ah, const ebf16x8& al, const EncFrag (&f)[2][2]) {
-#pragma unroll
-          for (int t = 0; t < 2; ++t) {
-            acc[t] = ENC_MFMA(al, f[t][0].v, acc[t], 0, 0, 0);
-            acc[t] = ENC_MFMA(ah, f[t][1].v, acc[t], 0, 0, 0);
-            acc[t] = ENC_MFMA(ah, f[t][0].v, acc[t], 0, 0, 0);
-          }
-        };
-        load(0, ah0, al0, f0);
-        int kt = 0;
-        for (; kt + 2 < nkt; kt += 2) {   // unconditional loads (see the forward kernel)
-          load(kt + 1, ah1, al1, f1);
-          __builtin_amdgcn_sched_barrier(0);
-          mma(ah0, al0, f0);
-          load(kt + 2, ah0, al0, f0);
-          __builtin_amdgcn_sched_barrier(0);
-          mma(ah1, al1, f1);
-        }
-        if (kt + 1 < nkt) {
-          load(kt + 1, ah1, al1, f1);
-          __builtin_amdgcn_sched_barrier(0);
-          mma(ah0, al0, f0);
-          mma(ah1, al1, f1);
-        } else {
-          mma(ah0, al0, f0);
-        }
-      } else {
+      {
         float a0[ENC_KC], a1[ENC_KC], b0[ENC_KC][2], b1[ENC_KC][2];
         const float* __restrict__ wg = q.wpad + (long)g * q.Kp * Jp;
         auto load = [&](int kp0, float (&av)[ENC_KC], float (&bv)[ENC_KC][2]) {
@@ -2756,15 +2691,8 @@ extern "C" int lfi_encode_windows_bwd(const lfi_enc_desc* d, const float* dcond,
   }
   EncFused q = {};
   if (enc_fused_shape(hid, &q)) {
-    const bool x3 = d->precision == 1;
-    if (x3) hipLaunchKernelGGL(enc_frag_weights_kernel, dim3(lfi_cdiv(6L * q.Kp * q.Jp, 256)), dim3(256), 0, st, whh, hid, q.Kp,
-                               q.Jp, 0, reinterpret_cast<__bf16*>(work));
-    else hipLaunchKernelGGL(enc_pad_weights_kernel, dim3(lfi_cdiv(3L * q.Kp * q.Jp, 256)), dim3(256), 0, st, whh, hid, q.Kp, q.Jp,
-                            0, work);
-    q.wpad = work;
-    q.wfrag = reinterpret_cast<const uint4*>(work);
     const size_t tab = (size_t)2 * q.R * sizeof(unsigned);   // per-row offset / liveness tables
-    const size_t ldsf = (size_t)q.Kp * (q.R + 1) * sizeof(float) + tab, ldsx = (size_t)2 * q.R * (q.Kp + 8) * sizeof(__bf16) + tab;
+    const size_t ldsf = (size_t)q.Kp * (q.R + 1) * sizeof(float) + tab;
     static int widebw = -1;
     if (widebw < 0) {
       const char* e = getenv("LFI_ENC_WIDE_BWD");
@@ -2775,8 +2703,17 @@ extern "C" int lfi_encode_windows_bwd(const lfi_enc_desc* d, const float* dcond,
     const size_t ldsw = (size_t)2 * q.R * (q.Kp + 8) * sizeof(__bf16) +
                         (size_t)(ENC_NW * 32 * ENC_TP > imgf ? ENC_NW * 32 * ENC_TP : imgf) * sizeof(float) + tab;
     const bool want16 = d->bwd_two_products && lddcond == d->ldcond && lfi_encode_windows_grad_stash_bf16(d);
-    const bool wide_ok = x3 && widebw && hid % 4 == 0 && lddcond % 4 == 0 && d->col % 4 == 0 && al16(dcond) && al16(gates) && al16(hseq) &&
-                         al16(dgi) && al16(dgh) && (!bias_part || al16(bias_part)) && ldsw <= 80 * 1024;
+    const bool wide_ok = d->precision == 1 && widebw && hid % 4 == 0 && lddcond % 4 == 0 && d->col % 4 == 0 && al16(dcond) && al16(gates) &&
+                         al16(hseq) && al16(dgi) && al16(dgh) && (!bias_part || al16(bias_part)) && ldsw <= 80 * 1024;
+    // bf16x3 recurrence: the row-layout kernels only. What they do not take (LFI_ENC_WIDE_BWD=0, hid not a multiple of 4, unaligned
+    // buffers) runs the exact-f32 accumulator-layout kernel, whatever the engine's GEMM mode (see enc_gru_bwd_fused_kernel)
+    const bool x3 = wide_ok;
+    if (x3) hipLaunchKernelGGL(enc_frag_weights_kernel, dim3(lfi_cdiv(6L * q.Kp * q.Jp, 256)), dim3(256), 0, st, whh, hid, q.Kp,
+                               q.Jp, 0, reinterpret_cast<__bf16*>(work));
+    else hipLaunchKernelGGL(enc_pad_weights_kernel, dim3(lfi_cdiv(3L * q.Kp * q.Jp, 256)), dim3(256), 0, st, whh, hid, q.Kp, q.Jp,
+                            0, work);
+    q.wpad = work;
+    q.wfrag = reinterpret_cast<const uint4*>(work);
     LFI_REQUIRE(!want16 || wide_ok, "lfi_encode_windows_bwd: lfi_encode_windows_grad_stash_bf16 promised a bf16 gradient stash but the "
                 "buffers are not 16-byte aligned");
     LFI_REQUIRE(!d->stash_f16 || wide_ok, "lfi_encode_windows_bwd: an fp16 gate stash (lfi_enc_desc.stash_f16) needs the row-layout "
@@ -2812,11 +2749,8 @@ extern "C" int lfi_encode_windows_bwd(const lfi_enc_desc* d, const float* dcond,
 #undef LFI_ENC_BWDW
       }
       if (rc) return rc;
-    } else if (x3) {
-      if ((rc = enc_set_lds(enc_gru_bwd_fused_kernel<true>, ldsx))) return rc;
-      hipLaunchKernelGGL(enc_gru_bwd_fused_kernel<true>, dim3(lfi_cdiv(F, q.R)), dim3(ENC_NT), ldsx, st, a, q);
     } else {
-      hipLaunchKernelGGL(enc_gru_bwd_fused_kernel<false>, dim3(lfi_cdiv(F, q.R)), dim3(ENC_NT), ldsf, st, a, q);
+      hipLaunchKernelGGL(enc_gru_bwd_fused_kernel, dim3(lfi_cdiv(F, q.R)), dim3(ENC_NT), ldsf, st, a, q);
     }
     LFI_LAUNCH_CHECK("lfi_encode_windows_bwd (fused)");
     return LFI_OK;

@@ -403,6 +403,9 @@ class SeqGlow(nn.Module):
         if self.spec.rnn_type not in ("gru", "lstm"):
             raise NotImplementedError("Glow.rnn_type=%r: the coupling cell is 'gru' or 'lstm' (models.py:176-185)"
                                       % self.spec.rnn_type)
+        prev = getattr(self, "engine", None)
+        if prev is not None:
+            prev.close()       # (a re-bind leaked the previous engine's CU-masked streams)
         eng = _engine.GlowEngine(self.spec, device)
 
         _bind_flat(eng, self._named_flat(), self.glow.flow.layers, device)

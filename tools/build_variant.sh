@@ -11,7 +11,7 @@ FLAGS="-O3 --offload-arch=gfx950 -fPIC -std=c++17 -I$ROOT/include -Wall -Wno-unu
 [ "$SRC" = "lfi_encoder.hip" ] && [ -z "${LFI_SLP:-}" ] && FLAGS="$FLAGS -fno-slp-vectorize"
 hipcc $FLAGS "$@" -c $ROOT/lets_face_it_amd/csrc/$SRC -o $ROOT/build/var/${NAME}_${SRC%.hip}.o
 OBJS=""
-for f in lfi_core lfi_gemm lfi_pgemm lfi_encoder lfi_flow lfi_data lfi_sample; do
+for f in lfi_core lfi_gemm lfi_pgemm lfi_encoder lfi_flow lfi_data lfi_sample lfi_wgrad; do
   if [ "$f.hip" = "$SRC" ]; then OBJS="$OBJS $ROOT/build/var/${NAME}_$f.o"; else OBJS="$OBJS $ROOT/build/csrc/$f.o"; fi
 done
 hipcc --offload-arch=gfx950 -shared -fPIC -o $ROOT/build/var/liblfi_$NAME.so $OBJS

@@ -1,9 +1,11 @@
 #!/usr/bin/env python3
-"""Minimal repro of the SLP note in csrc/Makefile, through the C ABI: the accumulator-layout fused BPTT kernel
-(enc_gru_bwd_fused_kernel<true>; LFI_ENC_WIDE_BWD=0 selects it) launched N times on the same inputs, outputs compared bit for bit.
+"""Repeat-launch determinism of the window encoders' fallback BPTT kernel, through the C ABI: what LFI_ENC_WIDE_BWD=0 selects, launched N
+times on the same inputs, outputs compared bit for bit.
    LFI_ENC_WIDE=0 LFI_ENC_WIDE_BWD=0 [LFI_LIB_PATH=build/var/liblfi_slp.so] python tools/enc_bwd_repro.py [--mod p1_speech] [--reps 20]
-Tree build (lfi_encoder.hip without the SLP vectoriser, no scratch): every launch identical. LFI_SLP=1 tools/build_variant.sh slp
-lfi_encoder.hip (16 spilled VGPRs in this kernel): launches differ. The same with -DLFI_ENC_FUSED_BWD_OCC=1 (no spills): identical."""
+Until round 5 that was enc_gru_bwd_fused_kernel<true> (bf16x3), which differed launch to launch in an SLP-vectorised build
+(profiles/round5_enc_bwd_repro.txt: 19 of 19). Round 6 deleted it: the switch now selects the exact-f32 accumulator-layout kernel, and
+this tool is the check that the fallback is bit-identical in the tree's build and in the SLP build (LFI_SLP=1 tools/build_variant.sh
+slp lfi_encoder.hip) alike - profiles/round6_enc_bwd_repro.txt."""
 import argparse
 import ctypes as C
 import os
