@@ -74,12 +74,26 @@ __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
 // Gate non-linearities on the hardware transcendental units (v_exp_f32 = 2^x, v_rcp_f32; ~1 ulp each): the libm expf /
 // tanhf calls cost 15-50 VALU instructions apiece and the gate epilogues run hundreds of them per lane. Absolute error
 // ~1e-7 on values in (-1, 1) (tanh near 0 loses relative, not absolute, accuracy), saturating correctly at +-inf.
+// -DLFI_EXACT_GATES=1 (measurement builds, tools/build_variant.sh): libm expf / tanhf and a true division;
+// =2: the hardware exp2 with ONE Newton step on the reciprocal (rcp error ~1 ulp -> ~0.5 ulp).
+#if defined(LFI_EXACT_GATES) && LFI_EXACT_GATES == 1
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + expf(-x)); }
+__device__ __forceinline__ float tanhf_(float x) { return tanhf(x); }
+#elif defined(LFI_EXACT_GATES) && LFI_EXACT_GATES == 2
+__device__ __forceinline__ float rcp_newton_(float d) {
+  const float r = __builtin_amdgcn_rcpf(d);
+  return __builtin_fmaf(r, __builtin_fmaf(-d, r, 1.0f), r);
+}
+__device__ __forceinline__ float sigmoidf_(float x) { return rcp_newton_(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x)); }
+__device__ __forceinline__ float tanhf_(float x) { return 1.0f - 2.0f * rcp_newton_(1.0f + __builtin_amdgcn_exp2f(2.8853900817779268f * x)); }
+#else
 __device__ __forceinline__ float sigmoidf_(float x) {
   return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
 }
 __device__ __forceinline__ float tanhf_(float x) {
   return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.8853900817779268f * x));
 }
+#endif
 
 // NACC 16 x 16 output tiles that share the A operand: acc[c] += A(16 x K) * B_c(K x 16), c < NACC.
 //   A is in LDS, k-major: element (i, k) at a_lds[k * lda + i]                       (i = 0..15)

@@ -114,6 +114,7 @@ def test_k16_sampling_against_oracle(gpu_device):
     ref32 = oracle.seqglow_inference(hp, sd, seq_len, data, noise)    # the same op sequence in plain fp32 (CPU)
     torch.set_num_threads(threads)
     own = float((ref32.double() - ref).abs().max())
+    own_rms = float((ref32.double() - ref).pow(2).mean().sqrt())
     gate = max(1e-5, 1.5 * own)
     for precision in ("f32", "bf16x3"):
         m.precision = precision
@@ -121,9 +122,12 @@ def test_k16_sampling_against_oracle(gpu_device):
         out2 = m.inference(seq_len, to_dev(data, gpu_device), noise=noise.to(gpu_device))   # hipGraph replay
         err = float((out.cpu().double() - ref).abs().max())
         per_frame = (out.cpu().double() - ref).abs().amax(dim=(0, 2))
+        # (the maximum over 22 400 values of an error that compounds through 56 autoregressive frames is a noisy statistic: any two
+        # fp32 roundings of the same computation differ by +-15 % in it; the RMS over all values is the stable one - round 6)
+        rms = float((out.cpu().double() - ref).pow(2).mean().sqrt())
         report("K=16 sampling, batch 8 x 56 generated frames (%s): max abs err vs fp64 oracle %.2e (first frame %.2e, last frame "
-               "%.2e); plain fp32 torch on the CPU: %.2e; gate %.2e" % (precision, err, float(per_frame[0]), float(per_frame[-1]),
-                                                                        own, gate))
+               "%.2e); plain fp32 torch on the CPU: %.2e; gate %.2e; rms err %.3e, plain fp32 torch rms %.3e"
+               % (precision, err, float(per_frame[0]), float(per_frame[-1]), own, gate, rms, own_rms))
         assert torch.equal(out, out2)
         assert err <= gate, (precision, err, gate)
 
