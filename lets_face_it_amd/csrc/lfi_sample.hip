@@ -21,10 +21,8 @@ typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
 union HFrag { uint4 u; h16x8 v; };
 
-constexpr int SC_ROWS = 64;                 // samples per workgroup
 constexpr int SC_D = 512;                   // cond_transform width per flow step (8 waves x 64 columns)
 constexpr int SC_PITCH = SC_D * 2 + 16;     // bytes per row of a c plane in LDS: 65 16-byte slots = 1 (mod 16)
-constexpr int SC_PLANE = SC_ROWS * SC_PITCH;
 constexpr int SC_NT = 512;
 
 // 16-byte k-chunk of lane group q in MFMA step m of a row of nchunk chunks: the chunks of the groups that share a ds_read_b128
@@ -123,12 +121,16 @@ struct ScArgs {
   float slope;
 };
 
-// grid (Ks, row tiles of 64); 512 threads = 8 waves: wave w owns c columns [64 w, 64 w + 64) in phase 1 and gic columns
-// [16 NGT w, 16 NGT (w + 1)) in phase 2; one workgroup per CU (133 KB of LDS).
+// grid (Ks, row tiles of 16 RT); 512 threads = 8 waves: wave w owns c columns [64 w, 64 w + 64) in phase 1 and gic columns
+// [16 NGT w, 16 NGT (w + 1)) in phase 2. RT = 4 (64 samples, the default): one workgroup per CU (133 KB of LDS, ~230 VGPRs). RT = 2
+// (32 samples, round 6, LFI_SAMPLE_COND_ROWS=32): 67 KB and <= 128 VGPRs, TWO workgroups per CU - measured slower (see the launch
+// site). Same arithmetic per output element either way: bit-identical (tested).
 // XF = false (round 5): the window's fp16 pieces are made in registers from the fp32 frames - 16 workgroups repeat the split of
 // a row tile, 256 values per lane, instead of a launch of its own per generated frame (12.6 us + its boundary)
-template <int NGT, bool XF>
-__global__ __launch_bounds__(SC_NT, 1) void sc_cond_kernel(ScArgs a) {
+template <int NGT, bool XF, int RT>
+__global__ __launch_bounds__(SC_NT) __attribute__((amdgpu_waves_per_eu(RT == 2 ? 4 : 2, RT == 2 ? 4 : 2))) void sc_cond_kernel(ScArgs a) {
+  constexpr int SC_ROWS = 16 * RT;
+  constexpr int SC_PLANE = SC_ROWS * SC_PITCH;
   extern __shared__ __attribute__((aligned(16))) char sc_smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   // workgroups are dealt round-robin over the 8 XCDs: flow step on grid.x, so that the row tiles of one step - which read the same
@@ -140,8 +142,8 @@ __global__ __launch_bounds__(SC_NT, 1) void sc_cond_kernel(ScArgs a) {
   const unsigned lane16 = (unsigned)lane * 16u;
   const __amdgpu_buffer_rsrc_t bw1 = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(a.wf1 + (long)(k * 8 + wave) * NM1 * 4 * 2 * 64), 0,
                                                                       NM1 * 4 * 2 * 1024, 0x00020000);
-  const __amdgpu_buffer_rsrc_t bx = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(a.xf + (long)(rt * 4) * NM1 * 2 * 64), 0,
-                                                                     4 * NM1 * 2 * 1024, 0x00020000);
+  const __amdgpu_buffer_rsrc_t bx = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(a.xf + (long)(rt * RT) * NM1 * 2 * 64), 0,
+                                                                     RT * NM1 * 2 * 1024, 0x00020000);
   const __amdgpu_buffer_rsrc_t bw2 = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint4*>(a.wf2 + (long)(k * 8 + wave) * 16 * NGT * 2 * 64), 0,
                                                                       16 * NGT * 2 * 1024, 0x00020000);
   auto ld = [&](__amdgpu_buffer_rsrc_t r, int frag) {
@@ -149,30 +151,32 @@ __global__ __launch_bounds__(SC_NT, 1) void sc_cond_kernel(ScArgs a) {
   };
 
   // ---- phase 1: acc1[ci][ri] = (Wct rows 16 ci ..) x (window rows 16 ri ..)^T, 32 k per step
-  f32x4 acc1[4][4];
+  f32x4 acc1[4][RT];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc1[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < RT; ++j) acc1[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
   {
-    HFrag wa[4][2], xa[4][2], wb[4][2], xb[4][2];   // [tile][plane], two buffers
+    HFrag wa[4][2], xa[RT][2], wb[4][2], xb[RT][2];   // [tile][plane], two buffers
     // (XF = false) fragment (16-row tile t, step m): lane l, element e = window[16 t + (l & 15)][32 m + 8 (l >> 4) + e]; the frames
     // through a buffer descriptor (reads past the last row's end return 0), 8-byte loads (the window starts (t - hist1) C floats
     // into a 16-byte aligned row: 8-byte aligned for even C)
     const __amdgpu_buffer_rsrc_t bf = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.faces), 0,
                                                                        (int)(a.faces_bytes > 0xfffffff0L ? 0xfffffff0L : a.faces_bytes), 0x00020000);
-    unsigned frow[4];
+    unsigned frow[RT];
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
+    for (int t = 0; t < RT; ++t) {
       const long row = min((long)rt * SC_ROWS + 16 * t + l15, (long)a.B - 1);   // rows past B repeat the last one (never stored)
       frow[t] = (unsigned)((row * a.ld_faces + a.off) * 4 + 32 * g4);
     }
     typedef unsigned sc_u32x2 __attribute__((ext_vector_type(2)));
-    auto load1 = [&](int m, HFrag (&w)[4][2], HFrag (&x)[4][2]) {
+    auto load1 = [&](int m, HFrag (&w)[4][2], HFrag (&x)[RT][2]) {
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
+      for (int t = 0; t < 4; ++t)
 #pragma unroll
         for (int pl = 0; pl < 2; ++pl) w[t][pl].u = ld(bw1, (SC_TIMING_W1(m) * 4 + t) * 2 + pl);
+#pragma unroll
+      for (int t = 0; t < RT; ++t) {
         if (XF) {
 #pragma unroll
           for (int pl = 0; pl < 2; ++pl) x[t][pl].u = ld(bx, (t * NM1 + m) * 2 + pl);
@@ -196,17 +200,70 @@ __global__ __launch_bounds__(SC_NT, 1) void sc_cond_kernel(ScArgs a) {
         }
       }
     };
-    auto mma1 = [&](const HFrag (&w)[4][2], const HFrag (&x)[4][2]) {
+    auto mma1 = [&](const HFrag (&w)[4][2], const HFrag (&x)[RT][2]) {
 #pragma unroll
       for (int ci = 0; ci < 4; ++ci) {
 #pragma unroll
-        for (int ri = 0; ri < 4; ++ri) acc1[ci][ri] = SC_MFMA(w[ci][1].v, x[ri][0].v, acc1[ci][ri]);
+        for (int ri = 0; ri < RT; ++ri) acc1[ci][ri] = SC_MFMA(w[ci][1].v, x[ri][0].v, acc1[ci][ri]);
 #pragma unroll
-        for (int ri = 0; ri < 4; ++ri) acc1[ci][ri] = SC_MFMA(w[ci][0].v, x[ri][1].v, acc1[ci][ri]);
+        for (int ri = 0; ri < RT; ++ri) acc1[ci][ri] = SC_MFMA(w[ci][0].v, x[ri][1].v, acc1[ci][ri]);
 #pragma unroll
-        for (int ri = 0; ri < 4; ++ri) acc1[ci][ri] = SC_MFMA(w[ci][0].v, x[ri][0].v, acc1[ci][ri]);
+        for (int ri = 0; ri < RT; ++ri) acc1[ci][ri] = SC_MFMA(w[ci][0].v, x[ri][0].v, acc1[ci][ri]);
       }
     };
+    if constexpr (RT == 2) {
+      // two workgroups per CU = 128 VGPRs: the weight fragments of a step travel in two halves (c column tiles 0-1, then 2-3), one
+      // half in flight under the other's products; the window's fragments once per step. Per accumulator the same three products
+      // per step in the same order as below.
+      (void)load1; (void)mma1; (void)wb;
+      HFrag (&wh0)[2][2] = reinterpret_cast<HFrag (&)[2][2]>(wa[0]);   // wa[0..1] and wa[2..3] serve as the two half buffers
+      HFrag (&wh1)[2][2] = reinterpret_cast<HFrag (&)[2][2]>(wa[2]);
+      auto loadw = [&](int m, int hf, HFrag (&w)[2][2]) {
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int pl = 0; pl < 2; ++pl) w[t][pl].u = ld(bw1, (SC_TIMING_W1(m) * 4 + 2 * hf + t) * 2 + pl);
+      };
+      auto loadx = [&](int m, HFrag (&x)[RT][2]) {
+#pragma unroll
+        for (int t = 0; t < RT; ++t)
+#pragma unroll
+          for (int pl = 0; pl < 2; ++pl) x[t][pl].u = ld(bx, (t * NM1 + m) * 2 + pl);
+      };
+      auto mmah = [&](int hf, const HFrag (&w)[2][2], const HFrag (&x)[RT][2]) {
+#pragma unroll
+        for (int c2 = 0; c2 < 2; ++c2) {
+          const int ci = 2 * hf + c2;
+#pragma unroll
+          for (int ri = 0; ri < RT; ++ri) acc1[ci][ri] = SC_MFMA(w[c2][1].v, x[ri][0].v, acc1[ci][ri]);
+#pragma unroll
+          for (int ri = 0; ri < RT; ++ri) acc1[ci][ri] = SC_MFMA(w[c2][0].v, x[ri][1].v, acc1[ci][ri]);
+#pragma unroll
+          for (int ri = 0; ri < RT; ++ri) acc1[ci][ri] = SC_MFMA(w[c2][0].v, x[ri][0].v, acc1[ci][ri]);
+        }
+      };
+      static_assert(XF || RT != 2, "the 32-sample tile takes the window's fragments from sc_xfrag_kernel / the reverse chain");
+      loadx(0, xa);
+      loadw(0, 0, wh0);
+      for (int m = 0; m < NM1; m += 2) {
+        loadw(m, 1, wh1);
+        if (m + 1 < NM1) loadx(m + 1, xb);
+        __builtin_amdgcn_sched_barrier(0);
+        mmah(0, wh0, xa);
+        if (m + 1 < NM1) loadw(m + 1, 0, wh0);
+        __builtin_amdgcn_sched_barrier(0);
+        mmah(1, wh1, xa);
+        if (m + 1 < NM1) {
+          loadw(m + 1, 1, wh1);
+          if (m + 2 < NM1) loadx(m + 2, xa);
+          __builtin_amdgcn_sched_barrier(0);
+          mmah(0, wh0, xb);
+          if (m + 2 < NM1) loadw(m + 2, 0, wh0);
+          __builtin_amdgcn_sched_barrier(0);
+          mmah(1, wh1, xb);
+        }
+      }
+    } else {
     load1(0, wa, xa);
     int m = 0;
     for (; m + 2 < NM1; m += 2) {
@@ -225,6 +282,7 @@ __global__ __launch_bounds__(SC_NT, 1) void sc_cond_kernel(ScArgs a) {
     } else {
       mma1(wa, xa);
     }
+    }
   }
   // the first W_ih fragments travel while the c pieces are made
   HFrag w2a[NGT][2], w2b[NGT][2];
@@ -240,16 +298,16 @@ __global__ __launch_bounds__(SC_NT, 1) void sc_cond_kernel(ScArgs a) {
   // The frame's rows of pre_static come out of HBM (33 MB per frame, read once): all 16 loads of a lane are issued here in one
   // batch, from a clamped row so that none sits under a branch - one round trip between the phases where there were four (a
   // wait for four loads in front of each row tile's pieces), with nothing for the matrix pipe to do meanwhile.
-  f32x4 ps[4][4];
+  f32x4 ps[RT][4];
 #pragma unroll
-  for (int ri = 0; ri < 4; ++ri) {
+  for (int ri = 0; ri < RT; ++ri) {
     const long row = min((long)rt * SC_ROWS + 16 * ri + l15, (long)a.B - 1);   // (rows past B: values never stored)
 #pragma unroll
     for (int ci = 0; ci < 4; ++ci)
       ps[ri][ci] = *reinterpret_cast<const f32x4*>(a.pre + row * KD + (long)k * SC_D + 64 * wave + 16 * ci + 4 * g4);
   }
 #pragma unroll
-  for (int ri = 0; ri < 4; ++ri) {
+  for (int ri = 0; ri < RT; ++ri) {
     const int rl = 16 * ri + l15;
 #pragma unroll
     for (int ci = 0; ci < 4; ++ci) {
@@ -269,30 +327,30 @@ __global__ __launch_bounds__(SC_NT, 1) void sc_cond_kernel(ScArgs a) {
   }
   __syncthreads();
   // ---- phase 2: acc2[ni][ri] = (W_ih rows 16 ni ..) x (c rows 16 ri ..)^T over D = 512: 16 steps
-  f32x4 acc2[NGT][4];
+  f32x4 acc2[NGT][RT];
 #pragma unroll
   for (int i = 0; i < NGT; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc2[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < RT; ++j) acc2[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
   {
     const char* cbase = sc_smem + l15 * SC_PITCH + 16 * ((g4 >> 1) + (SC_D / 16) * (g4 & 1));   // + 32 m per step, + 16 rows per ri
-    h16x8 cah[4], cal[4], cbh[4], cbl[4];
-    auto loadc = [&](int m, h16x8 (&ch)[4], h16x8 (&cl)[4]) {
+    h16x8 cah[RT], cal[RT], cbh[RT], cbl[RT];
+    auto loadc = [&](int m, h16x8 (&ch)[RT], h16x8 (&cl)[RT]) {
 #pragma unroll
-      for (int ri = 0; ri < 4; ++ri) {
+      for (int ri = 0; ri < RT; ++ri) {
         ch[ri] = *reinterpret_cast<const h16x8*>(cbase + ri * 16 * SC_PITCH + 32 * m);
         cl[ri] = *reinterpret_cast<const h16x8*>(cbase + ri * 16 * SC_PITCH + 32 * m + SC_PLANE);
       }
     };
-    auto mma2 = [&](const HFrag (&w)[NGT][2], const h16x8 (&ch)[4], const h16x8 (&cl)[4]) {
+    auto mma2 = [&](const HFrag (&w)[NGT][2], const h16x8 (&ch)[RT], const h16x8 (&cl)[RT]) {
 #pragma unroll
       for (int ni = 0; ni < NGT; ++ni) {
 #pragma unroll
-        for (int ri = 0; ri < 4; ++ri) acc2[ni][ri] = SC_MFMA(w[ni][1].v, ch[ri], acc2[ni][ri]);
+        for (int ri = 0; ri < RT; ++ri) acc2[ni][ri] = SC_MFMA(w[ni][1].v, ch[ri], acc2[ni][ri]);
 #pragma unroll
-        for (int ri = 0; ri < 4; ++ri) acc2[ni][ri] = SC_MFMA(w[ni][0].v, cl[ri], acc2[ni][ri]);
+        for (int ri = 0; ri < RT; ++ri) acc2[ni][ri] = SC_MFMA(w[ni][0].v, cl[ri], acc2[ni][ri]);
 #pragma unroll
-        for (int ri = 0; ri < 4; ++ri) acc2[ni][ri] = SC_MFMA(w[ni][0].v, ch[ri], acc2[ni][ri]);
+        for (int ri = 0; ri < RT; ++ri) acc2[ni][ri] = SC_MFMA(w[ni][0].v, ch[ri], acc2[ni][ri]);
       }
     };
     loadc(0, cah, cal);
@@ -318,7 +376,7 @@ __global__ __launch_bounds__(SC_NT, 1) void sc_cond_kernel(ScArgs a) {
 #pragma unroll
   for (int ni = 0; ni < NGT; ++ni)
 #pragma unroll
-    for (int ri = 0; ri < 4; ++ri) {
+    for (int ri = 0; ri < RT; ++ri) {
       acc2[ni][ri] += bv[ni];
       asm volatile("" : "+v"(acc2[ni][ri]));   // here, not inside the row predicate of a store (where the compiler sinks it, and with
     }                                          // it a wait that also drains the stores in front: they count in vmcnt too)
@@ -326,7 +384,7 @@ __global__ __launch_bounds__(SC_NT, 1) void sc_cond_kernel(ScArgs a) {
   for (int ni = 0; ni < NGT; ++ni) {
     const int col = NGT * 16 * wave + 16 * ni + 4 * g4;
 #pragma unroll
-    for (int ri = 0; ri < 4; ++ri) {
+    for (int ri = 0; ri < RT; ++ri) {
       const long row = (long)rt * SC_ROWS + 16 * ri + l15;
       if (row < a.B) *reinterpret_cast<f32x4*>(a.gic + ((long)k * a.B + row) * a.G + col) = acc2[ni][ri];
     }
@@ -395,24 +453,42 @@ extern "C" __attribute__((visibility("hidden"))) int lfi_internal_sample_cond(co
   a.faces = faces; a.ld_faces = ld_faces; a.off = off; a.faces_bytes = faces_floats * 4; a.K1 = K1;
   a.reset = reset; a.reset_words = reset_words;
   a.pre = pre; a.b_ih = b_ih; a.gic = gic; a.B = B; a.Ks = Ks; a.G = G; a.NM1 = NM1; a.slope = slope;
-  const size_t lds = (size_t)2 * SC_PLANE;
+  // samples per workgroup: 64 (one workgroup per CU). LFI_SAMPLE_COND_ROWS=32: the two-per-CU tile VERDICT r5 asked for (67 KB of LDS,
+  // 126 VGPRs, no spills) - built, bit-identical, and SLOWER: 44.3 against 40.6 ms of per-frame graphs per 1024 x 300 call, 48.96 against
+  // 45.13 ms per call, same box, alternating (profiles/round6_sampler_ab.md): every workgroup streams its flow step's 1.3 MB of weight
+  // fragments whatever its height, so half the rows per workgroup is twice the L2 -> CU traffic per frame (0.67 GB), and the second
+  // resident workgroup does not buy that back. Kept as the switch only.
+  // (the in-register window split, LFI_SAMPLE_XFRAG=0, and the LSTM cell's four gate blocks - 82 spilled VGPRs at the 128-register
+  // cap - keep the 64-sample tile)
+  const char* re = getenv("LFI_SAMPLE_COND_ROWS");
+  const int RT = ((re && re[0] == '3') && !inreg && NGT == 3) ? 2 : 4;
+  const size_t lds = (size_t)2 * 16 * RT * SC_PITCH;
   static bool attr = false;
   if (!attr) {
-    hipError_t e1 = hipFuncSetAttribute((const void*)sc_cond_kernel<3, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipError_t e2 = hipFuncSetAttribute((const void*)sc_cond_kernel<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipError_t e3 = hipFuncSetAttribute((const void*)sc_cond_kernel<3, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipError_t e4 = hipFuncSetAttribute((const void*)sc_cond_kernel<4, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess) {
-      lfi_set_error("sampler conditioning: cannot reserve %zu bytes of LDS", lds);
+    const size_t l4 = (size_t)2 * 64 * SC_PITCH, l2 = (size_t)2 * 32 * SC_PITCH;
+    bool ok = true;
+#define SC_ATTR(N)                                                                                                                             \
+  ok = ok && hipFuncSetAttribute((const void*)sc_cond_kernel<N, true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l4) == hipSuccess &&  \
+       hipFuncSetAttribute((const void*)sc_cond_kernel<N, false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l4) == hipSuccess
+    SC_ATTR(3); SC_ATTR(4);
+    ok = ok && hipFuncSetAttribute((const void*)sc_cond_kernel<3, true, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2) == hipSuccess;
+#undef SC_ATTR
+    if (!ok) {
+      lfi_set_error("sampler conditioning: cannot reserve %zu bytes of LDS", l4);
       return LFI_ERR_LAUNCH;
     }
     attr = true;
   }
-  const dim3 grid(Ks, (B + 63) / 64);
-  if (NGT == 3 && inreg) hipLaunchKernelGGL((sc_cond_kernel<3, false>), grid, dim3(SC_NT), lds, (hipStream_t)stream, a);
-  else if (NGT == 3) hipLaunchKernelGGL((sc_cond_kernel<3, true>), grid, dim3(SC_NT), lds, (hipStream_t)stream, a);
-  else if (inreg) hipLaunchKernelGGL((sc_cond_kernel<4, false>), grid, dim3(SC_NT), lds, (hipStream_t)stream, a);
-  else hipLaunchKernelGGL((sc_cond_kernel<4, true>), grid, dim3(SC_NT), lds, (hipStream_t)stream, a);
+  const dim3 grid(Ks, (B + 16 * RT - 1) / (16 * RT));
+#define SC_LAUNCH(N)                                                                                                \
+  do {                                                                                                              \
+    if (inreg) hipLaunchKernelGGL((sc_cond_kernel<N, false, 4>), grid, dim3(SC_NT), lds, (hipStream_t)stream, a);   \
+    else hipLaunchKernelGGL((sc_cond_kernel<N, true, 4>), grid, dim3(SC_NT), lds, (hipStream_t)stream, a);          \
+  } while (0)
+  if (RT == 2) hipLaunchKernelGGL((sc_cond_kernel<3, true, 2>), grid, dim3(SC_NT), lds, (hipStream_t)stream, a);
+  else if (NGT == 3) SC_LAUNCH(3);
+  else SC_LAUNCH(4);
+#undef SC_LAUNCH
   LFI_LAUNCH_CHECK("sampler conditioning");
   return LFI_OK;
 }

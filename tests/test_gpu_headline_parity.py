@@ -179,6 +179,12 @@ def test_sampler_fused_conditioning_matches_two_gemms(gpu_device, monkeypatch):
     monkeypatch.setenv("LFI_SAMPLE_WFRAG16", "0")
     w = m.inference(seq_len, dd, noise=noise).clone()
     assert torch.equal(a, w), ("pre-split weight fragments differ from the in-register split, per frame:", (a - w).abs().amax(dim=(0, 2)).tolist())
+    # round 6: LFI_SAMPLE_COND_ROWS=32 gives the conditioning kernel's workgroups 32 samples instead of 64 (two workgroups per CU;
+    # measured slower, kept as a switch): the same products per output element in the same order
+    monkeypatch.delenv("LFI_SAMPLE_WFRAG16")
+    monkeypatch.setenv("LFI_SAMPLE_COND_ROWS", "32")
+    r32 = m.inference(seq_len, dd, noise=noise).clone()
+    assert torch.equal(a, r32), ("32-sample conditioning tiles differ from 64-sample ones, per frame:", (a - r32).abs().amax(dim=(0, 2)).tolist())
 
 
 def test_sampler_static_part_beside_the_chain(gpu_device, monkeypatch):
