@@ -112,9 +112,9 @@ class LetsFaceItGlow(nn.Module):
     # builder's boxes (round 4: 6.89 against 6.95 ms), but 0.7 ms (9 %) SLOWER than eager on the driver's box of round 3 (8.40
     # against 7.71) - the eager queue is already kept full by the host running ahead, so replay has little to win and, box by
     # box, something to lose.
-    # OFF by default; bench.py reports both. Always eager: data-parallel steps (the collectives stay
-    # outside any graph), injected masks, ActNorm's data-dependent init, per-kernel timing (HIP events cannot bracket a kernel
-    # inside a replay).
+    # OFF by default; bench.py reports both. Data-parallel steps replay TWO graphs with the collectives between them
+    # (_capture_dp_step). Always eager: injected masks, ActNorm's data-dependent init, per-kernel timing (HIP events cannot bracket a
+    # kernel inside a replay), LFI_DP_SYNC=1 and the bench's per-bucket event profile.
     def _graph_key(self, batch, negative, eng):
         return (bool(negative), eng.precision, str(eng.backward_products), tuple(sorted(eng.pass_skip.items())),
                 tuple((k, tuple(v.shape)) for k, v in sorted(batch.items())))
@@ -124,9 +124,100 @@ class LetsFaceItGlow(nn.Module):
         on = self.__dict__.get("step_graph")
         if on is None:
             on = os.environ.get("LFI_STEP_GRAPH", "0") == "1"
-        return (bool(on) and (allreduce is None or world_size == 1)
+        import os as _os
+        dp = allreduce is not None and world_size > 1
+        return (bool(on) and (not dp or (_os.environ.get("LFI_DP_SYNC") != "1" and self.__dict__.get("dp_profile") is None))
                 and sg.injected_masks is None and sg.training and sg.glow.actnorm_inited() and eng.timers is None
                 and self.hparams.Optim["name"] == "adam")
+
+    # Data parallelism (round 6): the collectives stay outside any graph, so the step is TWO graphs split where
+    # the eager step launches the flow bucket's all-reduce (engine.backward's after_flow point: every flow gradient enqueued, the
+    # window encoders' BPTT not yet): A = dropout masks + forward + the flow's backward, B = the encoders' backward; between them the
+    # asynchronous all-reduce of the flow bucket, after B the encoder bucket's, then clip + Adam as three eager launches (their
+    # gradient multiplier 1 / world is a kernel argument). Per step the host issues two replays, two collectives and ~6 launches
+    # instead of ~100. Same kernels on the same buffers in the same order: parameters bit-identical to the eager data-parallel step
+    # (tools/dp_gloo_check.py --graph; tests/test_a_gpu_dp.py).
+    def _capture_dp_step(self, key, batch, negative, eng):
+        sg = self.seq_glow
+        dev = batch["p1_face"].device
+        st = {"in": {k: torch.empty_like(v) for k, v in batch.items()},
+              "params": torch.zeros(4, dtype=torch.int64, device=dev), "graph": torch.cuda.CUDAGraph(), "graph_b": torch.cuda.CUDAGraph(),
+              "dp": True}
+        x = batch["p1_face"]
+        B, N = x.shape[0], x.shape[1] - sg.spec.start
+        sign = -0.1 if negative else 1.0
+        ga, gb = st["graph"], st["graph_b"]
+        pool = torch.cuda.graph_pool_handle()
+        cap = torch.cuda.Stream(device=dev)
+        torch.cuda.synchronize(dev)
+        cap.wait_stream(torch.cuda.current_stream(dev))
+        state = {"open": None}
+
+        def split():
+            ga.capture_end()
+            state["open"] = None
+            gb.capture_begin(pool=pool)
+            state["open"] = gb
+
+        try:
+            with torch.cuda.stream(cap):
+                ga.capture_begin(pool=pool)
+                state["open"] = ga
+                masks = eng.draw_masks(B, N, 0, key_dev=st["params"]) if eng.has_dropout() else None
+                _, nll = eng.forward(st["in"], masks, with_stash=True)
+                st["mean"] = nll.mean().reshape(1)
+                st["numel"] = nll.numel()
+                eng.backward(sign / nll.numel(), after_flow=split)
+                if state["open"] is not gb:
+                    raise RuntimeError("engine.backward did not reach its after_flow point")
+                gb.capture_end()
+                state["open"] = None
+        except Exception:
+            if state["open"] is not None:      # leave capture mode before the error travels on
+                try:
+                    state["open"].capture_end()
+                except Exception:      # noqa: BLE001
+                    pass
+            raise
+        finally:
+            torch.cuda.current_stream(dev).wait_stream(cap)
+        st["dropout"] = masks is not None
+        return st
+
+    def _replay_dp_step(self, st, batch, lr, negative, eng, world_size, allreduce):
+        from .. import _lib
+        sg = self.seq_glow
+        for k, v in st["in"].items():
+            v.copy_(batch[k], non_blocking=True)
+        a = self.hparams.Optim["args"]["adam"]
+        step_size, inv_sqrt_bc2 = eng.adam_step_floats(lr, float(a["betas"][0]), float(a["betas"][1]), eng.step_count + 1)
+        seed = (torch.initial_seed() + sg.mask_seed_offset) & (2 ** 64 - 1)
+        _lib.check(eng.L.lfi_set_step_params(st["params"].data_ptr(), seed, eng._mask_calls + 1, step_size, inv_sqrt_bc2,
+                                             torch.cuda.current_stream().cuda_stream), "lfi_set_step_params")
+        off = eng.flow_offset
+        st["graph"].replay()                                     # masks, forward, the flow's backward
+        pending = allreduce(eng.grads[off:], async_op=True)      # travels under graph B
+        st["graph_b"].replay()                                   # the window encoders' backward
+        if off > 0:
+            allreduce(eng.grads[:off])
+        if pending is not None:
+            pending.wait()
+        clip = float(getattr(self.hparams, "gradient_clip_val", 0) or 0)
+        eng.optimizer_step(0.0, float(a["betas"][0]), float(a["betas"][1]), float(a["eps"]), clip=clip, gmul=1.0 / world_size,
+                           hyper_dev=st["params"].data_ptr() + 16, weight_decay=float(a.get("weight_decay", 0) or 0),
+                           amsgrad=bool(a.get("amsgrad", False)))
+        eng.step_count += 1
+        if st["dropout"]:
+            eng._mask_calls += 1
+        sg._fwd_counter += 1
+        mean = st["mean"].clone()
+        if negative:
+            self.log("Loss/missmatched_nll", -mean)
+            self._store_mismatched(-mean)
+            mean = mean * -0.1
+        self.global_step += 1
+        self.log("train_loss", mean)
+        return mean.detach()
 
     def _capture_step(self, key, batch, negative, eng):
         from .. import _lib
@@ -195,16 +286,20 @@ class LetsFaceItGlow(nn.Module):
                 graphs.clear()
                 graphs["engine"] = eng
             key = self._graph_key(batch, negative, eng)
+            dp = allreduce is not None and world_size > 1
+            capture = self._capture_dp_step if dp else self._capture_step
+            if dp:
+                key = ("dp",) + key
             st = graphs.get(key)
             if st is None and graphs.get(("seen",) + key, 0) >= 2 and not graphs.get("broken"):
                 try:
-                    st = graphs[key] = self._capture_step(key, batch, negative, eng)
+                    st = graphs[key] = capture(key, batch, negative, eng)
                     # the other branch's graph now too (same shapes, same kernels; capturing executes nothing): a negative step
                     # turns up once in ten steps, and its capture should not land in the middle of somebody's timed region
                     if self.hparams.Train["use_negative_nll_loss"] and self.missmatched_modalities:
-                        other = self._graph_key(batch, not negative, eng)
+                        other = (("dp",) if dp else ()) + self._graph_key(batch, not negative, eng)
                         if other not in graphs:
-                            graphs[other] = self._capture_step(other, batch, not negative, eng)
+                            graphs[other] = capture(other, batch, not negative, eng)
                 except Exception as e:   # a runtime that cannot capture this step keeps launching it eagerly
                     import warnings
                     warnings.warn("hipGraph capture of the training step failed (%s: %s); staying with eager launches"
@@ -212,6 +307,8 @@ class LetsFaceItGlow(nn.Module):
                     graphs["broken"] = True
                     torch.cuda.synchronize(x.device)
             if st is not None:
+                if st.get("dp"):
+                    return self._replay_dp_step(st, batch, lr, negative, eng, world_size, allreduce)
                 return self._replay_step(st, batch, lr, negative, eng)
             graphs[("seen",) + key] = graphs.get(("seen",) + key, 0) + 1
         masks = sg._draw_masks(B, N, x.device)

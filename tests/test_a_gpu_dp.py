@@ -68,6 +68,23 @@ def test_two_rank_data_parallel_at_final_widths():
     assert m.group(1) == "True" and float(m.group(2)) < 2e-4
 
 
+@pytest.mark.parametrize("final", [False, True])
+def test_two_rank_data_parallel_step_as_two_graphs(final):
+    """Round 6: under data parallelism the step replays TWO hipGraphs split at the flow bucket's launch point
+    (masks + forward + flow backward | window encoders' backward) with the collectives between / behind them and clip + Adam as three
+    launches, instead of ~100 eager launches. Two ranks over gloo, the engine's own dropout masks, 8 optimiser steps: parameters and
+    Adam moments bit-identical to the eager data-parallel steps on every rank, the ranks identical, and at least three steps really
+    ran on the captured graphs. final=True: final_model.yaml widths at batch 256 per rank (the bucket sizes of the 8-GPU node)."""
+    r = _launch(["--graph"] + (["--final"] if final else []), limit=420)
+    tail = "\n".join(r.stdout.splitlines()[-15:])
+    assert r.returncode == 0, tail
+    m = re.search(r"bit-identical to the eager data-parallel step on every rank: (\w+); steps on captured graphs \(min over ranks\): (\d+); "
+                  r"ranks identical: (\w+)", r.stdout)
+    assert m, tail
+    print(m.group(0))
+    assert m.group(1) == "True" and int(m.group(2)) >= 3 and m.group(3) == "True"
+
+
 def test_rccl_launch_path_with_one_rank():
     """RCCL itself, as far as one card allows: ONE rank on torch.distributed backend "nccl" runs fused_training_step with the
     trainer's real all-reduce hooks at final widths (the asynchronous flow bucket travels on RCCL's stream under the encoders'

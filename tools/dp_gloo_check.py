@@ -13,6 +13,7 @@ import torch.distributed as dist  # noqa: E402
 
 
 
+GRAPH = "--graph" in sys.argv   # the data-parallel step as two replayed hipGraphs with the collectives between them vs eager launches
 NCCL1 = "--nccl1" in sys.argv   # ONE rank on backend "nccl" (= RCCL): the collectives' launch path on this ROCm, no transport
 FINAL = "--final" in sys.argv or NCCL1   # final_model.yaml widths at BASELINE's synthetic dims, batch 256 per rank, T = 80
 
@@ -96,6 +97,31 @@ def run(rank, world, dev, tr):
     return m.seq_glow.engine.params.detach().cpu()
 
 
+def run_graph_leg(rank, world, dev, graph, steps=8):
+    """`steps` data-parallel optimiser steps with the engine's own dropout masks (a captured step cannot take injected ones) and the
+    negative-example branch off; graph=True: LetsFaceItGlow.step_graph (from the third step of the shape on the step is two replayed
+    hipGraphs with the two gradient buckets' all-reduces between and behind them). -> (parameters, Adam moments, replayed steps)"""
+    from argparse import Namespace
+    from lets_face_it_amd.trainer import Trainer
+    fx, hp, m = _make("mid", dev)
+    m.step_graph = graph
+    tr = Trainer(Namespace(**hp), device=dev)
+    m.seq_glow.allreduce_hook = tr.allreduce_stats
+    m.nll_sync_hook = tr.sync_scalar
+    tr.broadcast_parameters(m)
+    B = 256 if FINAL else 16
+    torch.manual_seed(11)          # the dropout masks' key is (torch.initial_seed() + offset, call counter): the same in both legs
+    replayed = 0
+    for step, full in enumerate(_batches(fx, steps, world * B)):
+        shard = {k: v[rank * B:(rank + 1) * B].to(dev).contiguous() for k, v in full.items()}
+        m.fused_training_step(shard, 1e-3, world, tr.allreduce_grads)
+        g = m.__dict__.get("_step_graphs") or {}
+        replayed += 1 if any(isinstance(v, dict) and v.get("dp") for v in g.values()) else 0
+    torch.cuda.synchronize()
+    eng = m.seq_glow.engine
+    return eng.params.detach().clone(), eng.adam_m.detach().clone(), eng.adam_v.detach().clone(), replayed
+
+
 def main():
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     dev = torch.device("cuda", 0)
@@ -103,6 +129,21 @@ def main():
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     dist.init_process_group("nccl" if NCCL1 else "gloo", rank=rank, world_size=world)
     print("rank %d of %d up (%s)" % (rank, world, dist.get_backend()), flush=True)
+    if GRAPH:
+        pe, me, ve, _ = run_graph_leg(rank, world, dev, False)
+        pg, mg, vg, replayed = run_graph_leg(rank, world, dev, True)
+        same = torch.equal(pe, pg) and torch.equal(me, mg) and torch.equal(ve, vg)
+        flags = torch.tensor([1.0 if same else 0.0, float(replayed)], dtype=torch.float64)
+        dist.all_reduce(flags, op=dist.ReduceOp.MIN)
+        gathered = [torch.zeros_like(pg.cpu()) for _ in range(world)]
+        dist.all_gather(gathered, pg.cpu())
+        ranks_same = all(torch.equal(gathered[0], g) for g in gathered)
+        if rank == 0:
+            print("graph data-parallel step: parameters and Adam moments bit-identical to the eager data-parallel step on every rank: %s; "
+                  "steps on captured graphs (min over ranks): %d; ranks identical: %s" % (bool(flags[0] > 0), int(flags[1]), ranks_same), flush=True)
+        dist.barrier()
+        dist.destroy_process_group()
+        sys.exit(0 if (flags[0] > 0 and flags[1] >= 3 and ranks_same) else 1)
     if NCCL1:
         # world size 1 on RCCL: fused_training_step with the trainer's real hooks (two-bucket asynchronous all-reduce on the
         # flat gradient, ActNorm statistics, parameter broadcast) against the same steps without any collective
