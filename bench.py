@@ -516,6 +516,18 @@ def bench_train(args, model, trainer, spec, device, world, rank, hp):
         _timed(step, 5, world, device)
         dp_line = _dp_summary(model.dp_profile, eng, world)
         model.dp_profile = None
+        if args.graph_steps > 0 and os.environ.get("LFI_BENCH_DP_GRAPH") == "1":
+            # opt-in (never rehearsed on a real multi-GPU transport: the driver's scaling run stays on the eager step): the same
+            # data-parallel step as two replayed hipGraphs with the collectives between them (LetsFaceItGlow._capture_dp_step)
+            model.step_graph = True
+            for i in range(4):
+                step(i)
+            el_g, _ = _timed(step, args.graph_steps, world, device)
+            dp_line["hipgraph_replay"] = {
+                "captured": any(isinstance(v, dict) and v.get("dp") for v in getattr(model, "_step_graphs", {}).values()),
+                "ms_per_step": 1e3 * el_g / args.graph_steps, "host_issue_ms_per_step": _host_issue_ms(step), "steps": args.graph_steps,
+                "note": "two graphs per step split at the flow bucket's launch point, both all-reduces and clip + Adam eager"}
+            model.step_graph = False
     host_issue = _host_issue_ms(step, reps=5)   # (without any per-kernel events)
     gpu_state = None
     if rank == 0 and not args.quick and world == 1 and getattr(args, "smi_helper", None) is not None:
