@@ -16,6 +16,8 @@ import os
 import sys
 import types
 
+sys.dont_write_bytecode = True   # importing /root/reference must not leave __pycache__ behind there (it is read-only by contract)
+
 import numpy as np
 import torch
 import yaml
