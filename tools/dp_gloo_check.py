@@ -112,7 +112,7 @@ def run_graph_leg(rank, world, dev, graph, steps=8):
     B = 256 if FINAL else 16
     torch.manual_seed(11)          # the dropout masks' key is (torch.initial_seed() + offset, call counter): the same in both legs
     replayed = 0
-    for step, full in enumerate(_batches(fx, steps, world * B)):
+    for step, full in enumerate(_batches(fx, steps, world * B)):      # (on the default stream, as the trainer and bench.py run)
         shard = {k: v[rank * B:(rank + 1) * B].to(dev).contiguous() for k, v in full.items()}
         m.fused_training_step(shard, 1e-3, world, tr.allreduce_grads)
         g = m.__dict__.get("_step_graphs") or {}
@@ -133,6 +133,12 @@ def main():
         pe, me, ve, _ = run_graph_leg(rank, world, dev, False)
         pg, mg, vg, replayed = run_graph_leg(rank, world, dev, True)
         same = torch.equal(pe, pg) and torch.equal(me, mg) and torch.equal(ve, vg)
+        print("rank %d checksums: eager leg %.12e, graph leg %.12e" % (rank, float(pe.double().sum()), float(pg.double().sum())), flush=True)
+        if not same or replayed < 3:
+            print("rank %d: eager vs graph legs differ: params %d of %d elements (max abs %.3e), adam_m %d, adam_v %d; finite %s / %s; "
+                  "steps on graphs %d" % (rank, int((pe != pg).sum()), pe.numel(), float((pe - pg).abs().max()), int((me != mg).sum()),
+                                          int((ve != vg).sum()), bool(torch.isfinite(pe).all()), bool(torch.isfinite(pg).all()), replayed),
+                  flush=True)
         flags = torch.tensor([1.0 if same else 0.0, float(replayed)], dtype=torch.float64)
         dist.all_reduce(flags, op=dist.ReduceOp.MIN)
         gathered = [torch.zeros_like(pg.cpu()) for _ in range(world)]
