@@ -924,6 +924,16 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world == 1 and args.gpus == 1:
+        # A process that has trained before it samples (this one: the `sampling` sub-record runs behind the training legs) binds more
+        # HIP streams to hardware queues than a process that only samples, and the sampler's ~550 dependent launches per run of frames
+        # then cost 15 us more per generated frame: 50.8 ms per 1024 x 300 call against 45.3 in a fresh process on the same box -
+        # reproduced by ONE earlier fork / join of a second stream with the default stream, and gone with three hardware queues per
+        # process instead of HIP's default four (two runs each, one box: 45.2 / 46.1 against 51.5 / 50.8 ms; the training step, its
+        # graph replay, the batch-2048 anchor and the deep flow within run-to-run noise either way:
+        # profiles/round6_sampler_stream_pick.md, tools/sample_after_train_probe.py). Read by the HIP runtime when it initialises,
+        # i.e. after this line; only for the single-process run (data-parallel ranks keep the default: RCCL's streams want queues).
+        os.environ.setdefault("GPU_MAX_HW_QUEUES", "3")
     if world != args.gpus:   # checked before anything touches the GPU
         if "WORLD_SIZE" not in os.environ and args.gpus > 1:
             # `python bench.py --gpus N` typed as for N = 1: this process - which has not touched the GPU and never will - starts
