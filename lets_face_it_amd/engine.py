@@ -682,8 +682,12 @@ class GlowEngine:
             rec = sorted((e for e in s.encoders if e.enc in ("rnn", "lstm") and not (e.name == "p1_face" and skip_p1)),
                          key=lambda e: e.hist * e.hid * e.hid)
             small = rec[0] if len(rec) >= 3 else None
+        # (round 6) pure window gathers (enc: none - at final_model.yaml the prev_p1_face history, 23 us) touch nothing the recurrent
+        # encoders read: on the second stream too, instead of in front of the first recurrence (6.364 against 6.392 ms per step, same box;
+        # LFI_ENC_GATHER_ON_SIDE=0: in line)
+        gather_side = side is not None and os.environ.get("LFI_ENC_GATHER_ON_SIDE", "1") != "0"
         for e in s.encoders:
-            with (self._on(side) if e is small else contextlib.nullcontext()):
+            with (self._on(side) if (e is small or (gather_side and e.enc == "none")) else contextlib.nullcontext()):
                 self._build_feature(e, data, faces, B, T, N, F, masks, cond, with_stash, skip_p1, sampling, windows, frame0)
 
     def _build_feature(self, e, data, faces, B, T, N, F, masks, cond, with_stash, skip_p1, sampling, windows, frame0):
@@ -999,6 +1003,7 @@ class GlowEngine:
         dwf = self._buf("dwct_f", KD * s.ldf)
         self.gemm_planes(KD, s.ldf, F, dpre_p, nkKD, cp, nkc, dwf, s.ldf, a_fmt=1, b_fmt=1,
                          splitk=self._planes_splitk(KD, s.ldf, F), tag="gemm_cond_wgrad", cls="cond_wgrad")
+        # (the unfold on the second stream beside the feature gradient was measured in round 6: 6.397 against 6.392 ms, nothing)
         check(self.L.lfi_cols_fold(dwf.data_ptr(), s.ldf, KD, self.unfold.data_ptr(), None, s.E,
                                    self.fview("wct", self.grads).data_ptr(), s.E, st), "lfi_cols_fold")
         if after_flow is not None:
