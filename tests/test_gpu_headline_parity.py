@@ -317,8 +317,11 @@ def test_strong_scaling_anchor_batch_matches_its_sub_batches(gpu_device):
     assert err < 2e-5
 
 
-def test_graphed_training_step_is_bit_identical_to_eager(gpu_device, monkeypatch):
-    """with step_graph on (LFI_STEP_GRAPH=1), from its third call a single-GPU fused_training_step is ONE replayed hipGraph (dropout masks,
+@pytest.mark.parametrize("products", ["auto", 2])
+def test_graphed_training_step_is_bit_identical_to_eager(gpu_device, monkeypatch, products):
+    """(products = 2, round 6: the two-product backward at this small size - bf16 gradient rows from the walk, hence the one-pass thin
+    weight gradients of csrc/lfi_wgrad.hip on both streams - inside the captured step.)
+    VERDICT r2 item 6: with step_graph on (LFI_STEP_GRAPH=1), from its third call a single-GPU fused_training_step is ONE replayed hipGraph (dropout masks,
     forward, backward, clip, Adam; the dropout key and Adam's step size read from a device block set before every replay; the
     negative-example step a second graph). Twelve steps at the benchmark's shape with the negative branch forced on steps 4 and
     9: parameters, Adam moments, the loss of every step and the mismatched-NLL buffer are bit-identical to eager launches."""
@@ -331,6 +334,7 @@ def test_graphed_training_step_is_bit_identical_to_eager(gpu_device, monkeypatch
     hp = load_hparams_file(os.path.join(root, "lets_face_it_amd", "hparams", "final_model_synthetic.yaml"))
     hp["batch_size"] = 64
     hp["gradient_clip_val"] = 20
+    hp["engine_backward_products"] = products
     batches = [to_dev(oracle.synthetic_batch(64, 48, 50, 27, seed=100 + i), gpu_device) for i in range(3)]
     runs = {}
     for mode in ("0", "1"):
@@ -343,6 +347,7 @@ def test_graphed_training_step_is_bit_identical_to_eager(gpu_device, monkeypatch
         m._negative_branch = lambda: next(forced)
         losses = [m.fused_training_step(batches[i % 3], 1e-4 * (1 + i % 2)).clone() for i in range(12)]
         eng = m.seq_glow.engine
+        assert eng.backward_product_count(64 * 24) == (2 if products == 2 else 3)
         graphs = [v for v in getattr(m, "_step_graphs", {}).values() if isinstance(v, dict)]
         assert len(graphs) == (2 if mode == "1" else 0), "expected the ordinary and the negative-example graph"
         runs[mode] = (torch.stack(losses).cpu(), eng.params.clone(), eng.adam_m.clone(), eng.adam_v.clone(), eng.step_count,
