@@ -370,9 +370,25 @@ class GlowEngine:
             # always born zeroed: padding columns of the folded feature matrix are never written and must stay zero
             t = torch.zeros(max(int(floats), 1), dtype=torch.float32, device=self.device)
             self._ws[name] = t
+            self._order_birth()
         elif zero:
             t.zero_()
         return t
+
+    def _order_birth(self):
+        """A buffer's zero fill runs on the stream that is current when the buffer is born; work that was FORKED earlier onto the second
+        stream is not ordered behind it. Round 6 found what that does (tools/dp_gloo_check.py, DP_CHECK_EAGER_TWICE): in the first
+        forward pass of a new engine the feature matrix `cond` is born on the main stream after the fork, the smallest window encoder
+        (and, since this round, the prev_p1_face gather) writes its columns of it on the second stream - and when the fill happened to
+        run late (two ranks sharing one card: reliably; a card of one's own: never observed) it wiped them: ActNorm's data-dependent
+        init, which is exactly that first pass, then saw zero features, and the run continued from other parameters - identical on both
+        ranks, different from run to run. So: whoever is forked waits for the birth."""
+        if os.environ.get("LFI_NO_BIRTH_ORDER") == "1":      # test hook: the behaviour before the fix (tests/test_gpu_parity.py)
+            return
+        cur = torch.cuda.current_stream(self.device)
+        for st in [self._side_stream] + list((self.__dict__.get("_partial_streams") or {}).values()):
+            if st is not None and st != cur:
+                st.wait_stream(cur)
 
     def draw_masks(self, B, N, seed, key_dev=None):
         """{modality: (N, B, hist)} dropout multipliers of the window encoders in ONE launch (lfi_dropout_masks); the call
@@ -1584,6 +1600,7 @@ class GlowEngine:
         if t is None or t.numel() < n:
             t = torch.zeros(n, dtype=torch.int32, device=self.device)
             self._ws[name] = t
+            self._order_birth()
         return t
 
     def _watch_sample_output(self, out):

@@ -6,7 +6,6 @@ HIP backward kernels (drop-in for an external optimiser loop); `fused_training_s
 Trainer uses: forward + backward + gradient all-reduce + clip + Adam with no autograd graph and no per-parameter
 kernels.
 """
-import contextlib
 import random
 
 import numpy as np
@@ -116,27 +115,6 @@ class LetsFaceItGlow(nn.Module):
     # OFF by default; bench.py reports both. Data-parallel steps replay TWO graphs with the collectives between them
     # (_capture_dp_step). Always eager: injected masks, ActNorm's data-dependent init, per-kernel timing (HIP events cannot bracket a
     # kernel inside a replay), LFI_DP_SYNC=1 and the bench's per-bucket event profile.
-    @contextlib.contextmanager
-    def _off_default_stream(self, dev):
-        """Replays never run on the legacy default stream. Found in round 6 (tools/r6_dp_flake.sh, tools/graph_flake_probe.py): with the
-        two-graph data-parallel step replayed on the default stream, a collective that picks the gradient up on ANOTHER stream through an
-        event recorded behind the replay (gloo's copy streams; RCCL's stream does the same) read stale gradients in ~25 % of the runs -
-        the same legs on a stream of their own: 0 of 14. A hipGraphLaunch into the NULL stream is evidently not something a later event on
-        that stream can be relied on to cover. So: when the caller is on the default stream, the replay (and everything between and
-        behind it: collectives, clip + Adam) runs on a stream of this module's, joined to the caller's on both sides with events around
-        ordinary kernels. Yields the caller's stream (None when no switch was needed)."""
-        cur = torch.cuda.current_stream(dev)
-        if cur != torch.cuda.default_stream(dev):
-            yield None
-            return
-        own = self.__dict__.get("_graph_stream")
-        if own is None or own.device != torch.device(dev):
-            own = self._graph_stream = torch.cuda.Stream(device=dev)
-        own.wait_stream(cur)
-        with torch.cuda.stream(own):
-            yield cur
-        cur.wait_stream(own)
-
     def _graph_key(self, batch, negative, eng):
         return (bool(negative), eng.precision, str(eng.backward_products), tuple(sorted(eng.pass_skip.items())),
                 tuple((k, tuple(v.shape)) for k, v in sorted(batch.items())))
@@ -329,14 +307,9 @@ class LetsFaceItGlow(nn.Module):
                     graphs["broken"] = True
                     torch.cuda.synchronize(x.device)
             if st is not None:
-                with self._off_default_stream(x.device) as back:
-                    if st.get("dp"):
-                        out = self._replay_dp_step(st, batch, lr, negative, eng, world_size, allreduce)
-                    else:
-                        out = self._replay_step(st, batch, lr, negative, eng)
-                    if back is not None:
-                        out.record_stream(back)
-                return out
+                if st.get("dp"):
+                    return self._replay_dp_step(st, batch, lr, negative, eng, world_size, allreduce)
+                return self._replay_step(st, batch, lr, negative, eng)
             graphs[("seen",) + key] = graphs.get(("seen",) + key, 0) + 1
         masks = sg._draw_masks(B, N, x.device)
         init = sg._allreduce() if (sg.training and not sg.glow.actnorm_inited()) else None

@@ -953,3 +953,42 @@ def test_one_pass_thin_weight_gradients_match_the_four_products(gpu_device, monk
             assert torch.equal(g, ref), name
     report("one-pass thin weight gradients vs the four split-K products (B=%d, N=%d, K=%d): worst tensor rel L2 %.2e (%s)"
            % (B, N, K, worst[1], worst[0]))
+
+
+def test_first_forward_of_a_new_engine_waits_for_its_buffers_births(gpu_device, monkeypatch):
+    """Round 6: an engine's workspaces are born zeroed on first use, on the stream that is current then; work forked onto the second
+    stream BEFORE that (the smallest window encoder, the prev_p1_face gather) was not ordered behind the fill, and when the fill ran late
+    it wiped the feature columns they had written - in the FIRST forward pass of a new engine only, which is the pass ActNorm's
+    data-dependent init runs in (seen as run-to-run different parameters on two ranks sharing a card; tools/dp_gloo_check.py). Here the
+    late fill is forced: the main stream is kept busy for a few milliseconds right after every fork. The first forward pass of a fresh
+    engine must give the NLL of an undisturbed one bit for bit - and, with the ordering switched off (LFI_NO_BIRTH_ORDER=1: the old
+    behaviour), it must NOT, or this test proves nothing."""
+    fxm = Fixture("mid")
+    batch = to_dev(fxm.batch(), gpu_device)
+    big = torch.randn(6144, 6144, device=gpu_device)
+
+    def first_forward(delay, ordered):
+        if ordered:
+            monkeypatch.delenv("LFI_NO_BIRTH_ORDER", raising=False)
+        else:
+            monkeypatch.setenv("LFI_NO_BIRTH_ORDER", "1")
+        m = build(fxm, gpu_device, train=False)
+        eng = m._ensure_engine(gpu_device)
+        if delay:
+            fork = eng._fork
+
+            def slow_fork():
+                side = fork()
+                for _ in range(4):
+                    torch.mm(big, big)      # the main stream falls behind the second one
+                return side
+            eng._fork = slow_fork
+        with torch.no_grad():
+            _, _, losses = m(batch)
+        torch.cuda.synchronize()
+        return torch.stack(losses)
+
+    ref = first_forward(False, True)
+    assert max_rel(ref, fxm.get("eval/nll"), floor=1.0) < 1e-4
+    assert torch.equal(first_forward(True, True), ref), "the first forward pass of a new engine depends on stream timing"
+    assert not torch.equal(first_forward(True, False), ref), "the forced late fill did not reproduce the race: the test checks nothing"

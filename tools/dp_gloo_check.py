@@ -117,6 +117,18 @@ def run_graph_leg(rank, world, dev, graph, steps=8):
         m.fused_training_step(shard, 1e-3, world, tr.allreduce_grads)
         g = m.__dict__.get("_step_graphs") or {}
         replayed += 1 if any(isinstance(v, dict) and v.get("dp") for v in g.values()) else 0
+        if os.environ.get("DP_CHECK_TRACE") == "1":      # (synchronises every step: diagnosis only)
+            torch.cuda.synchronize()
+            e = m.seq_glow.engine
+            off = e.flow_offset
+            if step == 0:
+                mk = e._ws.get("dropout_masks")
+                print("trace rank %d step 0: an_bias %.10e an_logs %.10e masks %s loss %s" % (
+                    rank, float(e.fview("an_bias").double().sum()), float(e.fview("an_logs").double().sum()),
+                    "none" if mk is None else "%.6e" % float(mk.double().sum()), float(m.logged.get("train_loss", torch.zeros(1)).sum())), flush=True)
+            print("trace rank %d graph %d step %d: grads enc %.10e flow %.10e | params enc %.10e flow %.10e | step_count %d mask_calls %d"
+                  % (rank, int(graph), step, float(e.grads[:off].double().sum()), float(e.grads[off:].double().sum()),
+                     float(e.params[:off].double().sum()), float(e.params[off:].double().sum()), e.step_count, e._mask_calls), flush=True)
     torch.cuda.synchronize()
     eng = m.seq_glow.engine
     return eng.params.detach().clone(), eng.adam_m.detach().clone(), eng.adam_v.detach().clone(), replayed
@@ -129,6 +141,14 @@ def main():
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     dist.init_process_group("nccl" if NCCL1 else "gloo", rank=rank, world_size=world)
     print("rank %d of %d up (%s)" % (rank, world, dist.get_backend()), flush=True)
+    if GRAPH and os.environ.get("DP_CHECK_EAGER_TWICE") == "1":      # diagnosis: is a SECOND eager model in the process the same as the first?
+        pa = run_graph_leg(rank, world, dev, False, steps=2)[0]
+        pb = run_graph_leg(rank, world, dev, False, steps=2)[0]
+        pc = run_graph_leg(rank, world, dev, False, steps=2)[0]
+        print("rank %d eager legs: %.12e %.12e %.12e" % (rank, float(pa.double().sum()), float(pb.double().sum()), float(pc.double().sum())), flush=True)
+        dist.barrier()
+        dist.destroy_process_group()
+        sys.exit(0)
     if GRAPH:
         pe, me, ve, _ = run_graph_leg(rank, world, dev, False)
         pg, mg, vg, replayed = run_graph_leg(rank, world, dev, True)
