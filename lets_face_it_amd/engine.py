@@ -385,6 +385,8 @@ class GlowEngine:
         ranks, different from run to run. So: whoever is forked waits for the birth."""
         if os.environ.get("LFI_NO_BIRTH_ORDER") == "1":      # test hook: the behaviour before the fix (tests/test_gpu_parity.py)
             return
+        if torch.cuda.is_current_stream_capturing():         # (inside a capture the fill is a node of the graph; a stream outside the
+            return                                           # capture must not be made to wait on it)
         cur = torch.cuda.current_stream(self.device)
         for st in [self._side_stream] + list((self.__dict__.get("_partial_streams") or {}).values()):
             if st is not None and st != cur:

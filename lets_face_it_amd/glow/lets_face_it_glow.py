@@ -6,6 +6,7 @@ HIP backward kernels (drop-in for an external optimiser loop); `fused_training_s
 Trainer uses: forward + backward + gradient all-reduce + clip + Adam with no autograd graph and no per-parameter
 kernels.
 """
+import contextlib
 import random
 
 import numpy as np
@@ -115,6 +116,26 @@ class LetsFaceItGlow(nn.Module):
     # OFF by default; bench.py reports both. Data-parallel steps replay TWO graphs with the collectives between them
     # (_capture_dp_step). Always eager: injected masks, ActNorm's data-dependent init, per-kernel timing (HIP events cannot bracket a
     # kernel inside a replay), LFI_DP_SYNC=1 and the bench's per-bucket event profile.
+    @contextlib.contextmanager
+    def _off_default_stream(self, dev):
+        """Replays never run on the legacy default stream: with GPU_MAX_HW_QUEUES=3 (what a process that trains AND samples wants,
+        profiles/round6_sampler_stream_pick.md; bench.py sets it) hipGraphLaunch of the two-stream step graph into the NULL stream
+        segfaults inside the HIP runtime on ROCm 7.2 (reproduced three times in a row; the same graph on any other stream, or with four
+        queues, runs). When the caller is on the default stream the replay - and, under data parallelism, the collectives and clip + Adam
+        between and behind the two replays - runs on a stream of this module's, joined to the caller's on both sides.
+        Yields the caller's stream (None when no switch was needed)."""
+        cur = torch.cuda.current_stream(dev)
+        if cur != torch.cuda.default_stream(dev):
+            yield None
+            return
+        own = self.__dict__.get("_graph_stream")
+        if own is None or own.device != torch.device(dev):
+            own = self._graph_stream = torch.cuda.Stream(device=dev)
+        own.wait_stream(cur)
+        with torch.cuda.stream(own):
+            yield cur
+        cur.wait_stream(own)
+
     def _graph_key(self, batch, negative, eng):
         return (bool(negative), eng.precision, str(eng.backward_products), tuple(sorted(eng.pass_skip.items())),
                 tuple((k, tuple(v.shape)) for k, v in sorted(batch.items())))
@@ -307,9 +328,14 @@ class LetsFaceItGlow(nn.Module):
                     graphs["broken"] = True
                     torch.cuda.synchronize(x.device)
             if st is not None:
-                if st.get("dp"):
-                    return self._replay_dp_step(st, batch, lr, negative, eng, world_size, allreduce)
-                return self._replay_step(st, batch, lr, negative, eng)
+                with self._off_default_stream(x.device) as back:
+                    if st.get("dp"):
+                        out = self._replay_dp_step(st, batch, lr, negative, eng, world_size, allreduce)
+                    else:
+                        out = self._replay_step(st, batch, lr, negative, eng)
+                    if back is not None:
+                        out.record_stream(back)
+                return out
             graphs[("seen",) + key] = graphs.get(("seen",) + key, 0) + 1
         masks = sg._draw_masks(B, N, x.device)
         init = sg._allreduce() if (sg.training and not sg.glow.actnorm_inited()) else None
