@@ -959,15 +959,18 @@ def test_first_forward_of_a_new_engine_waits_for_its_buffers_births(gpu_device, 
     """Round 6: an engine's workspaces are born zeroed on first use, on the stream that is current then; work forked onto the second
     stream BEFORE that (the smallest window encoder, the prev_p1_face gather) was not ordered behind the fill, and when the fill ran late
     it wiped the feature columns they had written - in the FIRST forward pass of a new engine only, which is the pass ActNorm's
-    data-dependent init runs in (seen as run-to-run different parameters on two ranks sharing a card; tools/dp_gloo_check.py). Here the
-    late fill is forced: the main stream is kept busy for a few milliseconds right after every fork. The first forward pass of a fresh
-    engine must give the NLL of an undisturbed one bit for bit - and, with the ordering switched off (LFI_NO_BIRTH_ORDER=1: the old
-    behaviour), it must NOT, or this test proves nothing."""
+    data-dependent init runs in (seen as run-to-run different parameters on two ranks sharing a card; tools/dp_gloo_check.py,
+    profiles/round6_first_forward_race.md). Two checks. Structural: every buffer born while the second stream is forked makes that
+    stream wait for the creating stream (no timing involved). Behavioural: with the main stream kept busy for milliseconds right after
+    every fork - the fill is then late whenever the two streams run concurrently - the first forward pass of a fresh engine gives the
+    NLL of an undisturbed one bit for bit. Whether the old behaviour (LFI_NO_BIRTH_ORDER=1) reproduces the wipe under that load depends on
+    the two streams sitting on different hardware queues (alone in a process it does; late in a long test process it did not): reported,
+    not asserted."""
     fxm = Fixture("mid")
     batch = to_dev(fxm.batch(), gpu_device)
     big = torch.randn(6144, 6144, device=gpu_device)
 
-    def first_forward(delay, ordered):
+    def first_forward(delay, ordered, log=None):
         if ordered:
             monkeypatch.delenv("LFI_NO_BIRTH_ORDER", raising=False)
         else:
@@ -983,12 +986,34 @@ def test_first_forward_of_a_new_engine_waits_for_its_buffers_births(gpu_device, 
                     torch.mm(big, big)      # the main stream falls behind the second one
                 return side
             eng._fork = slow_fork
+        if log is not None:
+            buf, birth = eng._buf, eng._order_birth
+
+            def logged_buf(name, floats, zero=False):
+                new = name not in eng._ws
+                t = buf(name, floats, zero)
+                if new:
+                    log.append(("born", name, eng._side_stream is not None))
+                return t
+
+            def logged_birth():
+                log.append(("ordered",))
+                return birth()
+            eng._buf, eng._order_birth = logged_buf, logged_birth
         with torch.no_grad():
             _, _, losses = m(batch)
         torch.cuda.synchronize()
         return torch.stack(losses)
 
-    ref = first_forward(False, True)
+    log = []
+    ref = first_forward(False, True, log)
     assert max_rel(ref, fxm.get("eval/nll"), floor=1.0) < 1e-4
+    births = [i for i, e in enumerate(log) if e[0] == "born"]
+    assert any(log[i][1] == "cond" and log[i][2] for i in births), "the feature matrix was not born after the fork: the scenario is gone"
+    # every birth is preceded (inside _buf) by its ordering call
+    assert all(i > 0 and log[i - 1] == ("ordered",) for i in births), log[:12]
     assert torch.equal(first_forward(True, True), ref), "the first forward pass of a new engine depends on stream timing"
-    assert not torch.equal(first_forward(True, False), ref), "the forced late fill did not reproduce the race: the test checks nothing"
+    old = first_forward(True, False)
+    report("first forward pass of a new engine with the buffers' zero fill forced late: ordered births bit-identical to an undisturbed pass; "
+           "the old behaviour (no ordering) under the same load: %s" % ("reproduces the wipe (NLL differs)" if not torch.equal(old, ref)
+                                                                          else "did not lose the race in this process"))
