@@ -1573,7 +1573,11 @@ __global__ __launch_bounds__(ENC_NT, 1) void enc_gru_fwd_t16_kernel(EncArgs a, E
 // different bits on 19 of 19 repeat launches (spill reloads inside its counted-vmcnt product loops, profiles/round5_slp_chase.md;
 // the instruction at fault was never found). A kernel that is nondeterministic under a legal compiler flag does not ship: it is
 // gone, and those cases run this kernel instead (bit-exact fp32 FMA chains on v_mfma_f32_32x32x2_f32 - slower, never wrong).
-__global__ __launch_bounds__(ENC_NT, 2) void enc_gru_bwd_fused_kernel(EncArgs a, EncFused q) {
+// One workgroup per CU's worth of registers (launch bound 1, not 2): at two it fits without the SLP vectoriser (230 VGPRs) but spills
+// 26 with it - and the spilling SLP build of THIS form turned out to differ between whole passes as well (p2_face, batch 256:
+// profiles/round6_determinism.txt, first run), as its bf16x3 twin had: spill code inside these product loops is what goes wrong, in
+// whichever arithmetic. With the whole register file it never spills, in either build.
+__global__ __launch_bounds__(ENC_NT, 1) void enc_gru_bwd_fused_kernel(EncArgs a, EncFused q) {
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, half = lane >> 5;
   const int cg = wave % q.ncg, rg = wave / q.ncg;
