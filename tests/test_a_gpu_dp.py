@@ -52,6 +52,18 @@ def test_two_rank_data_parallel_matches_single_process():
     assert m.group(1) == "True" and float(m.group(2)) < 2e-5
 
 
+def test_four_rank_data_parallel_matches_single_process():
+    """World size 4 (four gloo ranks on one card: the bucket offsets, the 1 / world gradient multiplier and the ActNorm-statistics
+    all-reduce at a world size that is not 2) against ONE process on the concatenated batch of the four shards."""
+    r = _launch([], nproc=4)
+    tail = "\n".join(r.stdout.splitlines()[-15:])
+    assert r.returncode == 0, tail
+    m = re.search(r"ranks identical: (\w+); vs one process on the concatenated batch: max rel diff ([0-9.e+-]+)", r.stdout)
+    assert m, tail
+    print(m.group(0))
+    assert m.group(1) == "True" and float(m.group(2)) < 2e-5
+
+
 def test_two_rank_data_parallel_at_final_widths():
     """The same check at final_model.yaml widths (17.3 M parameters: a 69 MB flat gradient in two buckets, 16 flow steps of
     ActNorm statistics), batch 256 per rank, T = 80: the bucket offsets, the asynchronous handle and the statistics

@@ -66,7 +66,8 @@ def _batches(fx, steps, B):
              (("p1_face", fx.C), ("p2_face", fx.C), ("p1_speech", fx.S), ("p2_speech", fx.S))} for _ in range(steps)]
 
 
-def run(rank, world, dev, tr):
+def run(rank, world, dev, tr, ranks=2):
+    """world > 1: this rank's shard of every batch; world == 1: ONE process on the concatenated batch of `ranks` ranks."""
     from argparse import Namespace
     fx, hp, m = _make("mid", dev)
     if tr is None and world > 1:
@@ -76,7 +77,7 @@ def run(rank, world, dev, tr):
         m.nll_sync_hook = tr.sync_scalar
         tr.broadcast_parameters(m)
     B = 256 if FINAL else 16
-    for step, full in enumerate(_batches(fx, 3 if FINAL else 4, max(world, 1) * B if world > 1 else 2 * B)):
+    for step, full in enumerate(_batches(fx, 3 if FINAL else 4, world * B if world > 1 else ranks * B)):
         nb = full["p1_face"].shape[0]
         lo, hi = (rank * B, (rank + 1) * B) if world > 1 else (0, nb)
         shard = {k: v[lo:hi].to(dev).contiguous() for k, v in full.items()}
@@ -200,7 +201,7 @@ def main():
     dist.all_gather(gathered, p)
     if rank == 0:
         same = all(torch.equal(gathered[0], g) for g in gathered)
-        ref = run(0, 1, dev, None)
+        ref = run(0, 1, dev, None, ranks=world)
         err = float((p - ref).abs().max() / ref.abs().max())
         print("ranks identical: %s; vs one process on the concatenated batch: max rel diff %.2e" % (same, err), flush=True)
     dist.barrier()
