@@ -1359,9 +1359,12 @@ class GlowEngine:
         """SeqGlow.inference (models.py:567-596); see _sample. With the static part on a partial-chip stream (LFI_SAMPLE_STATIC_CUS)
         the whole call runs on a private non-blocking stream between two joins with the caller's: hipExtStreamCreateWithCUMask makes a
         BLOCKING stream, which takes turns with the legacy default stream - and that is the stream most callers are on."""
-        if self._sample_static_cus(seq_len - self.spec.start) <= 0:
-            return self._sample(seq_len, data, noise, masks)
         caller = torch.cuda.current_stream(self.device)
+        # (also without a partial-chip stream when the caller is on the legacy default stream: the per-run graphs are not replayed
+        # there - with fewer than four hardware queues per process, GPU_MAX_HW_QUEUES=3, hipGraphLaunch into the NULL stream was seen to
+        # segfault inside the HIP runtime on the training step's graph, DESIGN.md 11.5)
+        if self._sample_static_cus(seq_len - self.spec.start) <= 0 and caller != torch.cuda.default_stream(self.device):
+            return self._sample(seq_len, data, noise, masks)
         if self._sample_stream is None:
             self._sample_stream = torch.cuda.Stream(device=self.device)
         own = self._sample_stream
